@@ -1,0 +1,53 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+
+    def load(name):
+        return np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"), allow_pickle=False)
+    return load
+
+
+def _reference_state_dict():
+    """Reference-format state dict with closed-form weights (tests/closed_form.py), built
+    from the committed key/shape table of the reference's `STYLER().state_dict()`
+    (tests/golden/state_dict_shapes.json); the three formula-defined buffers come from
+    their defining formulas (Models.py:11-30, modules.py:278-281)."""
+    import json
+    import math
+    import numpy as np
+    import torch
+    from closed_form import closed_form_tensor
+    from oracle import styler_oracle as O
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_shapes.json")) as f:
+        table = json.load(f)
+    sd = {}
+    for k, (shape, dtype) in table.items():
+        if "position_enc" in k:
+            sd[k] = O.sinusoid_table(1001, 256)[None]
+        elif k.endswith("pitch_bins"):
+            sd[k] = torch.exp(torch.linspace(np.log(71.0), np.log(797.9), 255))
+        elif k.endswith("energy_bins"):
+            sd[k] = torch.linspace(0.1, 525.43, 255)
+        else:
+            sd[k] = closed_form_tensor(k, torch.zeros(shape, dtype=getattr(torch, dtype)))
+    return sd
+
+
+@pytest.fixture(scope="session")
+def ref_state_dict():
+    return _reference_state_dict()

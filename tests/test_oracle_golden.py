@@ -1,0 +1,199 @@
+"""CPU: pin the oracle (oracle/styler_oracle.py) against fixtures generated from the
+reference itself (tests/golden/make_golden.py).  Tolerance 1e-5 abs unless stated;
+integer outputs bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import styler_oracle as O
+
+T = torch.from_numpy
+
+
+def close(a, b, tol=1e-5):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) if a.size else 0.0
+    assert err <= tol, f"max abs err {err:.3e} > {tol}"
+
+
+def test_fft_block(golden, ref_state_dict):
+    g, P = golden("fft_block"), ref_state_dict
+    x, lens = T(g["x"]), T(g["lens"])
+    pad = O.length_mask(lens, x.shape[1])
+    pre = "decoder.layer_stack.0"
+    close(O.attention(P, pre + ".slf_attn", x, pad), g["attn_out"])
+    close(O.pos_ffn(P, pre + ".pos_ffn", x), g["ffn_out"])
+    close(O.fft_block(P, pre, x, pad), g["y"])
+
+
+def test_encoder_decoder(golden, ref_state_dict):
+    g, P = golden("enc_dec"), ref_state_dict
+    pad = O.length_mask(T(g["lens"]), g["x"].shape[1])
+    close(O.text_encoder(P, "style_modeling.style_encoder.text_encoder", T(g["text"]), pad), g["enc"])
+    close(O.decoder(P, "decoder", T(g["x"]), pad), g["dec"], 2e-5)
+
+
+def test_decoder_long_position_table(golden, ref_state_dict):
+    from closed_form import hash_uniform
+    g, P = golden("decoder_long"), ref_state_dict
+    L = int(g["lens"][0])
+    x = torch.from_numpy(0.1 * hash_uniform(99, L * 256).reshape(1, L, 256)).float()
+    pad = O.length_mask(T(g["lens"]), L)
+    close(O.sinusoid_table(L, 256)[-4:], g["pe_tail"], 0)
+    close(O.decoder(P, "decoder", x, pad)[:, ::50], g["y"], 2e-5)
+    with pytest.raises(RuntimeError):
+        O.decoder(P, "decoder", x, pad, training=True)     # Models.py:124-125 broadcast failure
+
+
+def test_position_table_matches_stored(golden):
+    close(O.sinusoid_table(1001, 256)[[0, 1, 2, 499, 1000]], golden("decoder_long")["pe_stored_rows"], 0)
+
+
+def test_style_predictor(golden, ref_state_dict):
+    g = golden("style_predictor")
+    pad = O.length_mask(T(g["lens"]), g["x"].shape[1])
+    close(O.style_predictor(ref_state_dict, "style_modeling.pitch_predictor", T(g["x"]), pad), g["y"])
+
+
+def test_length_regulator(golden):
+    g = golden("length_regulator")
+    x = T(g["x"])
+    for d, ml, ko, kl in ((g["d_int"], None, "o1", "l1"), (g["d_int"], 14, "o2", "l2"),
+                          (g["d_int"], 9, "o3", "l3"), (g["d_flt"], None, "o4", "l4")):
+        out, mel_len = O.length_regulate(x, T(d), ml)
+        close(out, g[ko], 0)
+        assert mel_len.dtype == torch.int64 and np.array_equal(mel_len.numpy(), g[kl])
+
+
+def test_duration_round(golden):
+    g = golden("duration_round")
+    for c in (1.0, 0.7, 1.3):
+        close(O.rounded_duration(T(g["log_d"]), c), g[f"c{c}"], 0)
+
+
+def test_mel_calibrator(golden):
+    g = golden("mel_calibrator")
+    close(O.mel_calibrate(T(g["x"]), T(g["mel_len"]), T(g["src_len"])), g["y"], 1e-6)
+
+
+def test_quantize(golden):
+    g = golden("quantize")
+    idx = O.quantize_index(T(g["x"]))
+    assert np.array_equal(idx.numpy(), g["idx"]) and np.array_equal(idx.numpy(), g["onehot_argmax"])
+    with pytest.raises(AssertionError):
+        O.quantize_index(torch.tensor([[1.5]]))
+
+
+def test_bucketize_and_bins(golden, ref_state_dict):
+    g, P = golden("bucketize"), ref_state_dict
+    close(P["style_modeling.pitch_bins"], g["pitch_bins"], 0)
+    close(P["style_modeling.energy_bins"], g["energy_bins"], 0)
+    v = T(g["v"])
+    assert np.array_equal(torch.bucketize(v, P["style_modeling.pitch_bins"]).numpy(), g["p_idx"])
+    assert np.array_equal(torch.bucketize(v, P["style_modeling.energy_bins"]).numpy(), g["e_idx"])
+
+
+def test_audio_encoder(golden, ref_state_dict):
+    g, P = golden("audio_encoder"), ref_state_dict
+    cat = O.encoder_input_cat(T(g["mel"]), T(g["f0_norm"]), T(g["energy_input"]), T(g["mel_aug"]))
+    d, p, e, r = O.audio_encoder(P, "style_modeling.style_encoder.audio_encoder", cat,
+                                 T(g["mel_len"]), T(g["src_len"]))
+    for a, k in ((d, "d"), (p, "p"), (e, "e"), (r, "r")):
+        close(a, g[k], 2e-5)
+
+
+def test_bilstm(golden, ref_state_dict):
+    g = golden("bilstm")
+    close(O.bilstm2(ref_state_dict, "style_modeling.style_encoder.audio_encoder.lstm_2", T(g["x"])), g["y"])
+
+
+def test_aug_classifier(golden, ref_state_dict):
+    g = golden("aug_classifier")
+    close(O.aug_classifier(ref_state_dict, "style_modeling.augmentation_classifier_d", T(g["x"])), g["y"])
+
+
+def test_postnet(golden, ref_state_dict):
+    g = golden("postnet_eval")
+    close(O.postnet(ref_state_dict, "postnet", T(g["x"])), g["y"], 2e-5)
+    g = golden("postnet_train")
+    close(O.postnet(ref_state_dict, "postnet", T(g["x"]), training="bn_only"), g["y"], 5e-5)
+
+
+def _batch(g):
+    return {k[3:]: T(g[k]) for k in g.files if k.startswith("in_")}
+
+
+def test_full_teacher_forced(golden, ref_state_dict):
+    g = golden("full_teacher")
+    b = _batch(g)
+    S, Tm = b["text"].shape[1], b["mel_target"].shape[1]
+    out = O.styler_forward(ref_state_dict, b["text"], b["mel_target"], b["mel_aug"], b["f0_norm"],
+                           b["energy_input"], b["src_len"], b["mel_len"], b["D"], b["f0"],
+                           b["energy"], S, Tm, speaker_embed=b["speaker_embed"])
+    (mel, mel_n), (post, post_n), log_d, p_pred, e_pred, src_pad, mel_pad, mel_len, aug = out
+    for a, k in ((mel, "mel"), (mel_n, "mel_n"), (post, "post"), (post_n, "post_n"),
+                 (log_d, "log_d"), (p_pred, "p_pred"), (e_pred, "e_pred"), (aug[0], "aug_d"),
+                 (aug[1], "aug_p"), (aug[2], "aug_e")):
+        close(a, g[k], 5e-5)
+    assert np.array_equal(src_pad.numpy(), g["src_mask"]) and np.array_equal(mel_pad.numpy(), g["mel_mask"])
+    assert np.array_equal(mel_len.numpy(), g["mel_len"])
+
+
+def test_full_free_running(golden, ref_state_dict):
+    g, b = golden("full_free"), _batch(golden("full_teacher"))
+    S = b["text"].shape[1]
+    out = O.styler_forward(ref_state_dict, b["text"], b["mel_target"], b["mel_target"], b["f0_norm"],
+                           b["energy_input"], b["src_len"], b["mel_len"], None, None, None, S, None,
+                           speaker_embed=b["speaker_embed"], d_control=1.2, p_control=0.9,
+                           e_control=1.1)
+    (mel, mel_n), (post, post_n), log_d, p_pred, e_pred, _, mel_pad, mel_len, _ = out
+    assert np.array_equal(mel_len.numpy(), g["mel_len"])
+    assert np.array_equal(mel_pad.numpy(), g["mel_mask"])
+    close(O.rounded_duration(log_d, 1.2), g["dur"], 0)
+    for a, k in ((mel, "mel"), (mel_n, "mel_n"), (post, "post"), (post_n, "post_n"),
+                 (log_d, "log_d"), (p_pred, "p_pred"), (e_pred, "e_pred")):
+        close(a, g[k], 5e-5)
+
+
+def test_train_step_losses_and_grads(golden, ref_state_dict):
+    from golden.make_golden import grad_sample
+    g, b = golden("train_step"), _batch(golden("full_teacher"))
+    P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "position_enc" not in k
+             and "_bins" not in k and "running_" not in k else v) for k, v in ref_state_dict.items()}
+    losses = O.train_losses(P, b, training="bn_only")
+    close(torch.stack(losses), g["losses"], 2e-4)
+    losses[0].backward()
+    gn = torch.sqrt(sum((p.grad ** 2).sum() for p in P.values() if p.grad is not None))
+    assert abs(float(gn) - float(g["grad_norm"])) <= 1e-3 * float(g["grad_norm"])
+    no_grad = sorted(k for k, p in P.items() if p.requires_grad and p.grad is None)
+    assert no_grad == sorted(str(k) for k in g["no_grad_keys"])
+    for k in g.files:
+        if k.startswith("g:"):
+            got = grad_sample(P[k[2:]].grad)
+            scale = max(1.0, float(g["n:" + k[2:]]))
+            close(got / scale, g[k] / scale, 2e-4)
+
+
+def test_noam_lr(golden):
+    g = golden("noam_lr")
+    for n, lr in zip(g["steps"], g["lr"]):
+        assert abs(O.noam_lr(int(n)) - float(lr)) <= 1e-12 * max(1.0, abs(lr)) + 1e-15
+
+
+def test_stft_mel(golden):
+    g = golden("stft")
+    wav = T(g["wav"])
+    close(O.stft_basis()[[0, 1, 7, 512, 513, 514, 700, 1025]], g["basis_rows"], 1e-6)
+    close(O.stft_magnitude(wav), g["mag"], 2e-4)
+    mel, energy = O.mel_spectrogram(wav)
+    close(mel, g["mel"], 2e-4)
+    close(energy, g["energy"], 1e-3)
+    fb = O.mel_filterbank().numpy()
+    # self-checks of the (unpinned) librosa-0.7.2 Slaney filterbank restatement
+    assert fb.shape == (80, 513) and (fb >= 0).all()
+    peaks = fb.argmax(1)
+    assert (np.diff(peaks) > 0).all() and fb[:, 372:].sum() == 0     # fmax 8000 Hz -> bin 371.5
+    with pytest.raises(AssertionError):
+        O.mel_spectrogram(torch.full((1, 2048), 1.5))
