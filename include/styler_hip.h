@@ -1,0 +1,210 @@
+/* styler_hip.h -- C ABI of libstyler_hip.so: the MI355X (gfx950) kernels behind the
+ * STYLER forward/backward hot path.
+ *
+ * The reference (keonlee9420/STYLER) is pure Python on stock PyTorch ops; it has no FFI.
+ * Each entry point below replaces the PyTorch op sequence at the cited reference
+ * file:line (paths relative to the reference root).  The host side
+ * (the styler_amd Python package) binds these with ctypes and mirrors the reference's nn.Module API.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers unless named host_*.  No torch types cross this ABI.
+ *  - Activations are fp32, channels-last [B, L, C], row stride `ld*` in ELEMENTS (so an
+ *    op can read or write a channel slice of a wider buffer: no torch.cat / split copies).
+ *  - Lengths are int64 [B] as in the reference (src_len / mel_len); masks are derived in
+ *    the kernels (position t of item b is padding iff t >= len[b]).
+ *  - `stream` is a hipStream_t (passed as void*); every call only enqueues work.
+ *  - Return value: 0 on success, a negative STYLER_E* code on argument errors, or a
+ *    positive hipError_t from the launch.
+ */
+#ifndef STYLER_HIP_H
+#define STYLER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STYLER_EINVAL (-1)
+#define STYLER_EALIGN (-2)
+
+/* activation codes for fused epilogues */
+#define STYLER_ACT_NONE 0
+#define STYLER_ACT_RELU 1
+#define STYLER_ACT_TANH 2
+
+/* arithmetic of the MFMA GEMM core */
+#define STYLER_PREC_F32  0  /* v_mfma_f32_32x32x2_f32: exact fp32 (parity mode)            */
+#define STYLER_PREC_BF16 1  /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate    */
+
+int styler_abi_version(void);
+
+/* ---- GEMM / Conv1d-as-implicit-GEMM -------------------------------------------------
+ * y[b,t,n] = act( scale[n] * (sum_{j<kw} sum_{c<cin} x[b, t+j-kw/2, c] * w[n, j*cin+c])
+ *                 + shift[n] ) (+ res[b,t,n])          x = 0 outside 0 <= t+j-kw/2 < L
+ * Replaces nn.Linear (kw=1: SubLayers.py:41-43,58; styler.py:31; modules.py:211-216,
+ * 250-271) and nn.Conv1d with 'same' padding (SubLayers.py:72-76; modules.py:103-161,
+ * 444-453; Layers.py:78-118).  `w` is [n, kw*cin] row-major, i.e. nn.Linear layout, or
+ * nn.Conv1d weight [n, cin, kw] permuted to [n, kw, cin].  With prec = BF16, `w` points
+ * to bf16 (uint16) data of the same layout.  scale may be NULL (=1); shift is the bias
+ * (or the folded BatchNorm shift, Layers.py:91); res may be NULL.  cin % 4 == 0,
+ * ldx % 4 == 0 and 16-byte aligned x / w are required.
+ * If len != NULL, output rows with t >= len[b] are written as 0 (masked_fill). */
+int styler_conv_gemm(const float* x, int64_t ldx, const void* w, const float* scale,
+                     const float* shift, const float* res, int64_t ldres, float* y,
+                     int64_t ldy, int B, int L, int cin, int n, int kw, int act, int prec,
+                     const int64_t* len, void* stream);
+
+/* fp32 -> bf16 (round-to-nearest-even) weight shadow for STYLER_PREC_BF16 */
+int styler_cast_bf16(const float* src, uint16_t* dst, int64_t count, void* stream);
+
+/* Conv1d weight repack [n, cin, kw] <-> [n, kw, cin] (state-dict layout <-> kernel layout) */
+int styler_repack_conv_weight(const float* src, float* dst, int n, int cin, int kw,
+                              int to_kernel_layout, void* stream);
+
+/* ---- attention ----------------------------------------------------------------------
+ * Multi-head self-attention over the fused QKV projection (ScaledDotProductAttention,
+ * transformer/Modules.py:14-25 inside MultiHeadAttention, SubLayers.py:44-56): 4 heads,
+ * d_k = 64, scores / sqrt(64), keys t >= len[b] masked with -inf, softmax, PV.  Online
+ * softmax in LDS/registers: the [4B, L, L] score tensor is never materialised.
+ * qkv: [B, L, 768] = q | k | v (each 4 heads x 64, head-major within the 256 block);
+ * out: [B, L, 256] (b x lq x (n*dv), SubLayers.py:54-56).  lse (optional, [B,4,L]) gets
+ * the log-sum-exp per query row for the backward pass. */
+int styler_attention_fwd(const float* qkv, float* out, float* lse, int B, int L,
+                         const int64_t* len, void* stream);
+
+/* ---- normalisation / epilogues ------------------------------------------------------
+ * y = LayerNorm_256(x + res) * gamma + beta, then rows t >= len[b] set to 0
+ * (SubLayers.py:58-59,86-87 + Layers.py:29,32).  res, len may be NULL.  C must be 256.
+ * If dot_w != NULL the kernel instead writes the scalar out[b,t] = <y, dot_w> + dot_b[0]
+ * (masked) -- the StylePredictor's LayerNorm -> Linear(256,1) -> masked_fill tail,
+ * modules.py:449-465 -- and y may be NULL. */
+int styler_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldres,
+                         const float* gamma, const float* beta, float* y, int64_t ldy,
+                         const float* dot_w, const float* dot_b, float* dot_out, int B, int L,
+                         int C, const int64_t* len, void* stream);
+
+/* y = relu(GroupNorm(x)) with groups of 16 channels and statistics over 16 ch x the whole
+ * padded L (modules.py:103-113,171-175; eps 1e-5).  In place allowed (y == x). */
+int styler_groupnorm_relu(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                          float* y, int64_t ldy, int B, int L, int C, void* stream);
+
+/* BatchNorm1d folding for eval mode (Layers.py:91,105,118): scale = g * rsqrt(var + eps),
+ * shift = (conv_bias - mean) * scale + b.  All [C]. */
+int styler_bn_fold(const float* gamma, const float* beta, const float* running_mean,
+                   const float* running_var, const float* conv_bias, float* scale,
+                   float* shift, int C, void* stream);
+
+/* Train-mode BatchNorm1d over (B*L) rows incl. padded frames: computes batch mean / biased
+ * var per channel of x (= conv output incl. bias), writes y = act((x-mean)*rstd*g + b),
+ * saves mean / rstd [C] for backward and updates running stats with momentum 0.1
+ * (unbiased var), as torch.nn.BatchNorm1d does.  workspace: 2*C doubles, zeroed here. */
+int styler_batchnorm_train(const float* x, const float* gamma, const float* beta, float* y,
+                           float* save_mean, float* save_rstd, float* running_mean,
+                           float* running_var, double* workspace, int64_t rows, int C,
+                           int act, void* stream);
+
+/* ---- embeddings / positions ---------------------------------------------------------
+ * out[b,t,:] = emb[text[b,t],:] + pe[t,:]            (Models.py:73-74; emb [152,256])
+ * x may be NULL-free variant: out[b,t,:] = x[b,t,:] + pe[t,:]   (Models.py:124-125) */
+int styler_embed_pos(const int64_t* text, const float* emb, const float* pe, float* out,
+                     int B, int L, int C, void* stream);
+int styler_add_pos(const float* x, int64_t ldx, const float* pe, float* out, int B, int L,
+                   int C, void* stream);
+/* Sinusoid table rows [0, L) x 256, angles in float64 then cast (Models.py:11-30); used
+ * when L > 1000 in eval mode (Models.py:69-71,120-122). */
+int styler_sinusoid_table(float* pe, int L, int C, void* stream);
+
+/* ---- style encoders -----------------------------------------------------------------
+ * quantize_1D_torch (utils.py:417-429) fused with the first Conv1d(257 -> C, k=5) of the
+ * f0 / energy streams (modules.py:120-146): idx = 0 if v <= 0 else rint(v*255)+1; the
+ * one-hot [B,L,257] is never built: y[b,t,:] = bias + sum_j wt[j, idx[b,t+j-2], :].
+ * wt is the conv weight permuted to [5, 257, C].  err_flag (int32[1]) is set to 1 if any
+ * v > 1 (the reference's assert, utils.py:423).  idx_out (optional) int32 [B,L]. */
+int styler_onehot_conv5(const float* v, const float* wt, const float* bias, float* y,
+                        int64_t ldy, int32_t* idx_out, int32_t* err_flag, int B, int L, int C,
+                        void* stream);
+
+/* mel_calibrator (utils.py:351-384): per item resample frames mel_len[b] -> src_len[b]
+ * by near-equal segment means or repeats; rows s >= src_len[b] are zero.
+ * x [B, T, C] -> y [B, S, C]. */
+int styler_mel_calibrate(const float* x, int64_t ldx, float* y, int64_t ldy,
+                         const int64_t* mel_len, const int64_t* src_len, int B, int T, int S,
+                         int C, void* stream);
+
+/* One direction-pair of one nn.LSTM layer (modules.py:117,179-182; gate order i,f,g,o; zero
+ * initial state; run over the whole padded S).  gx [B, S, 2*4H] holds the input
+ * projections x W_ih^T + b_ih + b_hh for (forward | reverse) (computed by
+ * styler_conv_gemm); w_hh [2, 4H, H].  out [B, S, 2H] = forward | reverse hidden states.
+ * H must be 64 or 80.  cell_out (optional, [B,S,2H]) / gates_out (optional [B,S,2*4H],
+ * post-activation) are saved for backward. */
+int styler_lstm_bidir(const float* gx, const float* w_hh, float* out, float* cell_out,
+                      float* gates_out, int B, int S, int H, void* stream);
+
+/* AugmentationClassifier tail (modules.py:29-45): h [B,S,256] (= d_fc1 output) ->
+ * LayerNorm -> ReLU -> Linear(256,2) -> LogSoftmax -> mean over all S rows (pads
+ * included) -> out [B,2]. */
+int styler_aug_classifier_tail(const float* h, const float* ln_g, const float* ln_b,
+                               const float* w2, const float* b2, float* out, int B, int S,
+                               void* stream);
+
+/* ---- LengthRegulator ----------------------------------------------------------------
+ * modules.py:396-423 + utils.pad (utils.py:332-348).  Step 1 (scan): durations [B,S]
+ * (int64 if dur_is_float == 0, else fp32 truncated like int()) -> inclusive prefix sums
+ * csum [B,S] int32 and mel_len [B] int64 (= un-cropped sum).  If log_d != NULL the
+ * free-running rounding is fused: d = max(rint(exp(log_d) - 1) * d_control, 0)
+ * (modules.py:357-358) and also written to dur_out (fp32, optional).
+ * Step 2 (expand): out[b,t,:] = x[b, i, :] with csum[b,i-1] <= t < csum[b,i], zero for
+ * t >= min(mel_len[b], T); frame_idx [B,T] int32 (optional) gets i or -1. */
+int styler_duration_scan(const void* dur, int dur_is_float, const float* log_d, float d_control,
+                         float* dur_out, int32_t* csum, int64_t* mel_len, int B, int S,
+                         void* stream);
+int styler_length_regulate(const float* x, int64_t ldx, const int32_t* csum, float* out,
+                           int64_t ldo, int32_t* frame_idx, int B, int S, int T, int C,
+                           void* stream);
+
+/* bucketize + 2 embeddings + 4-way add (modules.py:365-385):
+ * out[b,t,:] = text[b,t,:] + pitch_emb[bucketize(p[b,t]*p_scale, pitch_bins)] +
+ *              speaker[b,t,:] + energy_emb[bucketize(e[b,t]*e_scale, energy_bins)]
+ * bins are 255 ascending fp32 bounds, bucketize(right=False).  noise (optional) is added
+ * into out2 = out + noise (the noisy-branch input, styler.py:55).  ids (optional) int32. */
+int styler_bucket_embed_add(const float* text, int64_t ldt, const float* speaker, int64_t lds,
+                            const float* p, float p_scale, const float* e, float e_scale,
+                            const float* pitch_bins, const float* energy_bins,
+                            const float* pitch_emb, const float* energy_emb, float* out,
+                            const float* noise, int64_t ldn, float* out2, int32_t* p_ids,
+                            int32_t* e_ids, int B, int T, void* stream);
+
+/* elementwise helpers used to stitch channel slices: y = a (+ b) with row strides, and a
+ * per-item row broadcast y[b,t,:] = (a[b,t,:] if a) + v[b,:] (speaker repeat,
+ * modules.py:324-325,333). */
+int styler_add2(const float* a, int64_t lda, const float* b, int64_t ldb, float* y,
+                int64_t ldy, int64_t rows, int C, void* stream);
+int styler_add_rowvec(const float* a, int64_t lda, const float* v, int64_t ldv, float* y,
+                      int64_t ldy, int B, int L, int C, void* stream);
+
+/* get_mask_from_lengths (utils.py:223-232): mask[b,t] = (t >= len[b]), 1 byte per element
+ * (torch.bool storage), True = padding. */
+int styler_length_mask(const int64_t* len, uint8_t* mask, int B, int L, void* stream);
+
+/* ---- losses (loss.py:16-50) -----------------------------------------------------------
+ * acc[0] += sum over valid rows (t < len[b]) and C columns of (a-b)^2  (kind 0)
+ *           or |a-b| (kind 1); acc[1] += number of valid elements.  acc is double[2],
+ * caller zeroes it.  Mean-reduced loss = acc[0]/acc[1] (masked_select + MSELoss/L1Loss). */
+int styler_masked_err_sum(const float* a, int64_t lda, const float* b, int64_t ldb,
+                          double* acc, int kind, int B, int L, int C, const int64_t* len,
+                          void* stream);
+
+/* ---- STFT -> mel (audio/stft.py:51-79,141-160) ----------------------------------------
+ * wav [B, N] in [-1,1] -> frames with reflect padding 512, hop 256, windowed DFT as an
+ * MFMA GEMM against basis [1026,1024] (rows 0..512 Re, 513..1025 Im), magnitude,
+ * mel = log(clamp(mel_basis[80,513] @ mag, 1e-5)), energy = ||mag||_2.
+ * mag (optional) [B, F, 513]; mel [B, F, 80] (channels-last, the layout the model takes);
+ * energy [B, F]; F = 1 + N/256. */
+int styler_stft_mel(const float* wav, int64_t ldw, const float* basis, const float* mel_basis,
+                    float* mag, float* mel, float* energy, int B, int N, int prec, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STYLER_HIP_H */

@@ -1,0 +1,58 @@
+"""ctypes binding of libstyler_hip.so (the C ABI declared in include/styler_hip.h).
+
+The product path has NO CPU fallback: importing this module without the built library raises, and
+every op raises on a non-zero return code."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstyler_hip.so")
+
+P = ctypes.c_void_p
+I = ctypes.c_int
+I64 = ctypes.c_int64
+F = ctypes.c_float
+
+_SIGS = {
+    "styler_abi_version": [],
+    "styler_conv_gemm": [P, I64, P, P, P, P, I64, P, I64, I, I, I, I, I, I, I, P, P],
+    "styler_cast_bf16": [P, P, I64, P],
+    "styler_repack_conv_weight": [P, P, I, I, I, I, P],
+    "styler_attention_fwd": [P, P, P, I, I, P, P],
+    "styler_add_layernorm": [P, I64, P, I64, P, P, P, I64, P, P, P, I, I, I, P, P],
+    "styler_groupnorm_relu": [P, I64, P, P, P, I64, I, I, I, P],
+    "styler_bn_fold": [P, P, P, P, P, P, P, I, P],
+    "styler_batchnorm_train": [P, P, P, P, P, P, P, P, P, I64, I, I, P],
+    "styler_embed_pos": [P, P, P, P, I, I, I, P],
+    "styler_add_pos": [P, I64, P, P, I, I, I, P],
+    "styler_sinusoid_table": [P, I, I, P],
+    "styler_onehot_conv5": [P, P, P, P, I64, P, P, I, I, I, P],
+    "styler_mel_calibrate": [P, I64, P, I64, P, P, I, I, I, I, P],
+    "styler_lstm_bidir": [P, P, P, P, P, I, I, I, P],
+    "styler_aug_classifier_tail": [P, P, P, P, P, P, I, I, P],
+    "styler_duration_scan": [P, I, P, F, P, P, P, I, I, P],
+    "styler_length_regulate": [P, I64, P, P, I64, P, I, I, I, I, P],
+    "styler_bucket_embed_add": [P, I64, P, I64, P, F, P, F, P, P, P, P, P, P, I64, P, P, P, I, I, P],
+    "styler_add2": [P, I64, P, I64, P, I64, I64, I, P],
+    "styler_add_rowvec": [P, I64, P, I64, P, I64, I, I, I, P],
+    "styler_length_mask": [P, P, I, I, P],
+    "styler_masked_err_sum": [P, I64, P, I64, P, I, I, I, I, P, P],
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C styler_amd/csrc`).  styler_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    return lib
+
+
+lib = _load()
+ABI_VERSION = lib.styler_abi_version()
+EXPORTED = tuple(_SIGS)

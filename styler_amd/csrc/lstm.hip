@@ -1,0 +1,74 @@
+// Recurrent half of nn.LSTM(.., bidirectional=True) for one layer (modules.py:117,132,147,162,179-182).
+//
+// The input projections x W_ih^T + b_ih + b_hh for both directions are one MFMA GEMM (styler_conv_gemm,
+// N = 2*4H).  This kernel runs the sequential part: one block per (item, direction), 4H threads; thread j
+// keeps row j of W_hh in REGISTERS (H floats) for the whole sequence, h_{t-1} is broadcast from LDS
+// (ds_read_b128), gates cross threads through LDS, so a step costs H FMAs + two barriers and touches
+// HBM only for the 4H-float gx row and the H-float output row.  Latency-bound by construction
+// (S <= ~300 steps); all items/directions/LSTMs run concurrently on separate CUs.
+#include "common.h"
+
+template <int H>
+__global__ __launch_bounds__(4 * H) void lstm_bidir_kernel(const float* __restrict__ gx,
+                                                           const float* __restrict__ w_hh, float* __restrict__ out,
+                                                           float* __restrict__ cell_out,
+                                                           float* __restrict__ gates_out, int S) {
+  __shared__ __attribute__((aligned(16))) float hbuf[H];
+  __shared__ float gbuf[4 * H];
+  const int j = threadIdx.x;                 // gate row 0..4H-1 (i | f | g | o)
+  const int b = blockIdx.x, dir = blockIdx.y;
+  float w[H];
+  {
+    const float* wp = w_hh + ((int64_t)dir * 4 * H + j) * H;
+#pragma unroll
+    for (int k = 0; k < H; k += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(wp + k);
+      w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
+    }
+  }
+  if (j < H) hbuf[j] = 0.f;
+  float c = 0.f;
+  __syncthreads();
+  const int64_t gx_ld = 2 * 4 * H, out_ld = 2 * H;
+  const float* gxp = gx + (int64_t)b * S * gx_ld + dir * 4 * H + j;
+  int t = dir ? S - 1 : 0;
+  const int dt = dir ? -1 : 1;
+  float gnext = gxp[(int64_t)t * gx_ld];
+  for (int step = 0; step < S; ++step, t += dt) {
+    float a0 = gnext, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (step + 1 < S) gnext = gxp[(int64_t)(t + dt) * gx_ld];        // prefetch next step's row
+#pragma unroll
+    for (int k = 0; k < H; k += 4) {
+      const float4 hv = *reinterpret_cast<const float4*>(&hbuf[k]);
+      a0 = fmaf(w[k], hv.x, a0); a1 = fmaf(w[k + 1], hv.y, a1);
+      a2 = fmaf(w[k + 2], hv.z, a2); a3 = fmaf(w[k + 3], hv.w, a3);
+    }
+    const float pre = (a0 + a1) + (a2 + a3);
+    const bool is_g = (j >= 2 * H) && (j < 3 * H);
+    const float act = is_g ? tanhf(pre) : 1.0f / (1.0f + expf(-pre));
+    gbuf[j] = act;
+    if (gates_out) gates_out[((int64_t)b * S + t) * gx_ld + dir * 4 * H + j] = act;
+    __syncthreads();
+    if (j < H) {
+      c = gbuf[H + j] * c + gbuf[j] * gbuf[2 * H + j];
+      const float h = gbuf[3 * H + j] * tanhf(c);
+      hbuf[j] = h;
+      out[((int64_t)b * S + t) * out_ld + dir * H + j] = h;
+      if (cell_out) cell_out[((int64_t)b * S + t) * out_ld + dir * H + j] = c;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int styler_lstm_bidir(const float* gx, const float* w_hh, float* out, float* cell_out, float* gates_out,
+                                 int B, int S, int H, void* stream) {
+  if (!gx || !w_hh || !out || B <= 0 || S <= 0) return STYLER_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (H == 64)
+    hipLaunchKernelGGL(lstm_bidir_kernel<64>, dim3(B, 2), dim3(256), 0, st, gx, w_hh, out, cell_out, gates_out, S);
+  else if (H == 80)
+    hipLaunchKernelGGL(lstm_bidir_kernel<80>, dim3(B, 2), dim3(320), 0, st, gx, w_hh, out, cell_out, gates_out, S);
+  else
+    return STYLER_EINVAL;
+  return launch_status();
+}

@@ -1,0 +1,343 @@
+// Memory-bound stitching kernels of the STYLER path: embeddings + position tables, one-hot-aware first
+// conv of the f0/energy streams, mel calibrator, augmentation-classifier tail, bucketise+embed+add,
+// strided adds, masked error sums.  All are single-pass, float4-vectorised, channels-last.
+#include "common.h"
+
+// ---- embedding + position ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_pos_kernel(const int64_t* __restrict__ text,
+                                                        const float* __restrict__ emb,
+                                                        const float* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ pe, float* __restrict__ out,
+                                                        int64_t rows, int L, int C) {
+  const int nq = C / 4;
+  const int64_t total = rows * nq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / nq; const int q = (int)(i - row * nq);
+    const int t = (int)(row % L);
+    const float* src = text ? emb + text[row] * C : x + row * ldx;
+    const float4 a = *reinterpret_cast<const float4*>(src + q * 4);
+    const float4 p = *reinterpret_cast<const float4*>(pe + (int64_t)t * C + q * 4);
+    *reinterpret_cast<float4*>(out + row * C + q * 4) = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+  }
+}
+
+static inline unsigned grid_for(int64_t work, int per_block = 256, int cap = 4096) {
+  int64_t b = (work + per_block - 1) / per_block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+extern "C" int styler_embed_pos(const int64_t* text, const float* emb, const float* pe, float* out, int B, int L,
+                                int C, void* stream) {
+  if (!text || !emb || !pe || !out || B <= 0 || L <= 0 || (C & 3)) return STYLER_EINVAL;
+  const int64_t rows = (int64_t)B * L;
+  hipLaunchKernelGGL(embed_pos_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, text, emb,
+                     (const float*)nullptr, (int64_t)0, pe, out, rows, L, C);
+  return launch_status();
+}
+
+extern "C" int styler_add_pos(const float* x, int64_t ldx, const float* pe, float* out, int B, int L, int C,
+                              void* stream) {
+  if (!x || !pe || !out || B <= 0 || L <= 0 || (C & 3) || (ldx & 3)) return STYLER_EINVAL;
+  const int64_t rows = (int64_t)B * L;
+  hipLaunchKernelGGL(embed_pos_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                     (const int64_t*)nullptr, (const float*)nullptr, x, ldx, pe, out, rows, L, C);
+  return launch_status();
+}
+
+__global__ void sinusoid_kernel(float* pe, int L, int C) {
+  const int64_t total = (int64_t)L * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int pos = (int)(i / C), j = (int)(i % C);
+    const double angle = (double)pos / pow(10000.0, 2.0 * (double)(j / 2) / (double)C);
+    pe[i] = (float)((j & 1) ? cos(angle) : sin(angle));
+  }
+}
+
+extern "C" int styler_sinusoid_table(float* pe, int L, int C, void* stream) {
+  if (!pe || L <= 0 || C <= 0) return STYLER_EINVAL;
+  hipLaunchKernelGGL(sinusoid_kernel, dim3(grid_for((int64_t)L * C)), dim3(256), 0, (hipStream_t)stream, pe, L, C);
+  return launch_status();
+}
+
+// ---- quantise + one-hot-aware Conv1d(257 -> C, k = 5) -------------------------------------
+__device__ __forceinline__ int quant_index(float v, int* bad) {
+  if (v <= 0.f) return 0;
+  if (v > 1.f) { *bad = 1; v = 1.f; }
+  return (int)rintf(v * 255.f) + 1;        // rintf = round-half-to-even, as torch.round
+}
+
+// one wave per frame; lanes stride the output channels (coalesced 256-B rows of wt)
+__global__ __launch_bounds__(256) void onehot_conv5_kernel(const float* __restrict__ v, const float* __restrict__ wt,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           int64_t ldy, int32_t* __restrict__ idx_out,
+                                                           int32_t* __restrict__ err_flag, int64_t rows, int L,
+                                                           int C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int t = (int)(row % L);
+  int bad = 0;
+  int idx[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int tt = t + j - 2;
+    idx[j] = (tt >= 0 && tt < L) ? quant_index(v[row + j - 2], &bad) : -1;
+  }
+  if (bad && lane == 0 && err_flag) atomicOr(err_flag, 1);
+  if (idx_out && lane == 0) idx_out[row] = idx[2];
+  for (int c = lane; c < C; c += 64) {
+    float acc = bias[c];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      if (idx[j] >= 0) acc += wt[((int64_t)j * 257 + idx[j]) * C + c];
+    y[row * ldy + c] = acc;
+  }
+}
+
+extern "C" int styler_onehot_conv5(const float* v, const float* wt, const float* bias, float* y, int64_t ldy,
+                                   int32_t* idx_out, int32_t* err_flag, int B, int L, int C, void* stream) {
+  if (!v || !wt || !bias || !y || B <= 0 || L <= 0 || C <= 0) return STYLER_EINVAL;
+  const int64_t rows = (int64_t)B * L;
+  hipLaunchKernelGGL(onehot_conv5_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, v, wt,
+                     bias, y, ldy, idx_out, err_flag, rows, L, C);
+  return launch_status();
+}
+
+// ---- mel calibrator ------------------------------------------------------------------------
+// grid (S, B); output row s of item b:
+//   ml > sl : mean of frames [start, start+n), n = ml/sl + (s < ml%sl), start = s*(ml/sl) + min(s, ml%sl)
+//   ml < sl : frame f with f*(q) + min(f, r) <= s, q = sl/ml, r = sl%ml
+//   ml == sl: copy;   s >= sl: zeros
+__global__ __launch_bounds__(256) void mel_calibrate_kernel(const float* __restrict__ x, int64_t ldx,
+                                                            float* __restrict__ y, int64_t ldy,
+                                                            const int64_t* __restrict__ mel_len,
+                                                            const int64_t* __restrict__ src_len, int T, int S,
+                                                            int C) {
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int ml = (int)mel_len[b], sl = (int)src_len[b];
+  float* yp = y + ((int64_t)b * S + s) * ldy;
+  const float* xb = x + (int64_t)b * T * ldx;
+  int start = 0, n = 0;
+  if (s < sl && ml > 0) {
+    if (ml >= sl) {
+      const int q = ml / sl, r = ml % sl;
+      n = q + (s < r ? 1 : 0);
+      start = s * q + (s < r ? s : r);
+    } else {
+      const int q = sl / ml, r = sl % ml;
+      const int f = (s < r * (q + 1)) ? s / (q + 1) : r + (s - r * (q + 1)) / q;
+      start = f; n = 1;
+    }
+  }
+  for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int f = 0; f < n; ++f) {
+      const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)(start + f) * ldx + c);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (n > 1) { const float d = (float)n; acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d; }
+    *reinterpret_cast<float4*>(yp + c) = acc;
+  }
+}
+
+extern "C" int styler_mel_calibrate(const float* x, int64_t ldx, float* y, int64_t ldy, const int64_t* mel_len,
+                                    const int64_t* src_len, int B, int T, int S, int C, void* stream) {
+  if (!x || !y || !mel_len || !src_len || B <= 0 || T <= 0 || S <= 0 || C <= 0 || (C & 3)) return STYLER_EINVAL;
+  if ((ldx & 3) || (ldy & 3)) return STYLER_EALIGN;
+  hipLaunchKernelGGL(mel_calibrate_kernel, dim3(S, B), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, mel_len,
+                     src_len, T, S, C);
+  return launch_status();
+}
+
+// ---- augmentation classifier tail ------------------------------------------------------------
+// block per item; wave per row (strided); LN(256) -> ReLU -> Linear(256,2) -> log_softmax; mean over S
+__global__ __launch_bounds__(256) void aug_tail_kernel(const float* __restrict__ h, const float* __restrict__ g,
+                                                       const float* __restrict__ bt, const float* __restrict__ w2,
+                                                       const float* __restrict__ b2, float* __restrict__ out,
+                                                       float* __restrict__ rows_out, int S) {
+  __shared__ float part[4][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x;
+  const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4);
+  const float4 bb = *reinterpret_cast<const float4*>(bt + lane * 4);
+  const float4 w0 = *reinterpret_cast<const float4*>(w2 + lane * 4);
+  const float4 w1 = *reinterpret_cast<const float4*>(w2 + 256 + lane * 4);
+  float a0 = 0.f, a1 = 0.f;
+  for (int s = wave; s < S; s += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(h + ((int64_t)b * S + s) * 256 + lane * 4);
+    const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
+    const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+    const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.f / 256.f);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float ox = fmaxf(dx * rstd * gg.x + bb.x, 0.f), oy = fmaxf(dy * rstd * gg.y + bb.y, 0.f);
+    const float oz = fmaxf(dz * rstd * gg.z + bb.z, 0.f), ow = fmaxf(dw * rstd * gg.w + bb.w, 0.f);
+    const float z0 = wave_sum(ox * w0.x + oy * w0.y + oz * w0.z + ow * w0.w) + b2[0];
+    const float z1 = wave_sum(ox * w1.x + oy * w1.y + oz * w1.z + ow * w1.w) + b2[1];
+    const float m = fmaxf(z0, z1);
+    const float lse = m + logf(expf(z0 - m) + expf(z1 - m));
+    a0 += z0 - lse; a1 += z1 - lse;
+    if (rows_out && lane == 0) {
+      rows_out[((int64_t)b * S + s) * 2 + 0] = z0 - lse;
+      rows_out[((int64_t)b * S + s) * 2 + 1] = z1 - lse;
+    }
+  }
+  if (lane == 0) { part[wave][0] = a0; part[wave][1] = a1; }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    out[b * 2 + threadIdx.x] =
+        (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) / (float)S;
+}
+
+extern "C" int styler_aug_classifier_tail(const float* h, const float* ln_g, const float* ln_b, const float* w2,
+                                          const float* b2, float* out, int B, int S, void* stream) {
+  if (!h || !ln_g || !ln_b || !w2 || !b2 || !out || B <= 0 || S <= 0) return STYLER_EINVAL;
+  hipLaunchKernelGGL(aug_tail_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, h, ln_g, ln_b, w2, b2, out,
+                     (float*)nullptr, S);
+  return launch_status();
+}
+
+// ---- bucketise + embeddings + 4-way add --------------------------------------------------------
+// wave per frame.  bucketize(v, bins, right=False) = #{bins < v}: 255 bins, lane holds 4 (256th = +inf),
+// count via ballots.
+__device__ __forceinline__ int bucketize255(float v, const float* __restrict__ bins, int lane) {
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = k * 64 + lane;
+    const float bv = (i < 255) ? bins[i] : INFINITY;
+    cnt += __popcll(__ballot(bv < v));
+  }
+  return cnt;
+}
+
+__global__ __launch_bounds__(256) void bucket_embed_add_kernel(
+    const float* __restrict__ text, int64_t ldt, const float* __restrict__ speaker, int64_t lds,
+    const float* __restrict__ p, float p_scale, const float* __restrict__ e, float e_scale,
+    const float* __restrict__ pitch_bins, const float* __restrict__ energy_bins,
+    const float* __restrict__ pitch_emb, const float* __restrict__ energy_emb, float* __restrict__ out,
+    const float* __restrict__ noise, int64_t ldn, float* __restrict__ out2, int32_t* __restrict__ p_ids,
+    int32_t* __restrict__ e_ids, int64_t rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int pi = bucketize255(p[row] * p_scale, pitch_bins, lane);
+  const int ei = bucketize255(e[row] * e_scale, energy_bins, lane);
+  if (lane == 0) { if (p_ids) p_ids[row] = pi; if (e_ids) e_ids[row] = ei; }
+  const float4 a = *reinterpret_cast<const float4*>(text + row * ldt + lane * 4);
+  const float4 s = *reinterpret_cast<const float4*>(speaker + row * lds + lane * 4);
+  const float4 pe = *reinterpret_cast<const float4*>(pitch_emb + (int64_t)pi * 256 + lane * 4);
+  const float4 ee = *reinterpret_cast<const float4*>(energy_emb + (int64_t)ei * 256 + lane * 4);
+  // reference order: text + pitch_embedding + speaker + energy_embedding (modules.py:385)
+  float4 o = make_float4(((a.x + pe.x) + s.x) + ee.x, ((a.y + pe.y) + s.y) + ee.y, ((a.z + pe.z) + s.z) + ee.z,
+                         ((a.w + pe.w) + s.w) + ee.w);
+  *reinterpret_cast<float4*>(out + row * 256 + lane * 4) = o;
+  if (out2) {
+    const float4 nz = *reinterpret_cast<const float4*>(noise + row * ldn + lane * 4);
+    *reinterpret_cast<float4*>(out2 + row * 256 + lane * 4) = make_float4(o.x + nz.x, o.y + nz.y, o.z + nz.z, o.w + nz.w);
+  }
+}
+
+extern "C" int styler_bucket_embed_add(const float* text, int64_t ldt, const float* speaker, int64_t lds,
+                                       const float* p, float p_scale, const float* e, float e_scale,
+                                       const float* pitch_bins, const float* energy_bins, const float* pitch_emb,
+                                       const float* energy_emb, float* out, const float* noise, int64_t ldn,
+                                       float* out2, int32_t* p_ids, int32_t* e_ids, int B, int T, void* stream) {
+  if (!text || !speaker || !p || !e || !pitch_bins || !energy_bins || !pitch_emb || !energy_emb || !out || B <= 0 ||
+      T <= 0)
+    return STYLER_EINVAL;
+  if (out2 && !noise) return STYLER_EINVAL;
+  if ((ldt & 3) || (lds & 3) || (out2 && (ldn & 3))) return STYLER_EALIGN;
+  const int64_t rows = (int64_t)B * T;
+  hipLaunchKernelGGL(bucket_embed_add_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     text, ldt, speaker, lds, p, p_scale, e, e_scale, pitch_bins, energy_bins, pitch_emb, energy_emb,
+                     out, noise, ldn, out2, p_ids, e_ids, rows);
+  return launch_status();
+}
+
+// ---- strided adds ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void add2_kernel(const float* __restrict__ a, int64_t lda,
+                                                   const float* __restrict__ b, int64_t ldb, int64_t b_row_div,
+                                                   float* __restrict__ y, int64_t ldy, int64_t rows, int C) {
+  const int nq = C / 4;
+  const int64_t total = rows * nq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / nq; const int q = (int)(i - row * nq);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a) v = *reinterpret_cast<const float4*>(a + row * lda + q * 4);
+    if (b) {
+      const float4 w = *reinterpret_cast<const float4*>(b + (row / b_row_div) * ldb + q * 4);
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    *reinterpret_cast<float4*>(y + row * ldy + q * 4) = v;
+  }
+}
+
+extern "C" int styler_add2(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy,
+                           int64_t rows, int C, void* stream) {
+  if (!a || !y || rows <= 0 || C <= 0 || (C & 3)) return STYLER_EINVAL;
+  if ((lda & 3) || (ldy & 3) || (b && (ldb & 3))) return STYLER_EALIGN;
+  hipLaunchKernelGGL(add2_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb,
+                     (int64_t)1, y, ldy, rows, C);
+  return launch_status();
+}
+
+extern "C" int styler_add_rowvec(const float* a, int64_t lda, const float* v, int64_t ldv, float* y, int64_t ldy,
+                                 int B, int L, int C, void* stream) {
+  if (!v || !y || B <= 0 || L <= 0 || C <= 0 || (C & 3)) return STYLER_EINVAL;
+  if ((a && (lda & 3)) || (ldy & 3) || (ldv & 3)) return STYLER_EALIGN;
+  const int64_t rows = (int64_t)B * L;
+  hipLaunchKernelGGL(add2_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, a, lda, v, ldv,
+                     (int64_t)L, y, ldy, rows, C);
+  return launch_status();
+}
+
+// ---- masked error sums ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void masked_err_kernel(const float* __restrict__ a, int64_t lda,
+                                                         const float* __restrict__ b, int64_t ldb,
+                                                         double* __restrict__ acc, int kind, int64_t rows, int L,
+                                                         int C, const int64_t* __restrict__ len) {
+  __shared__ double red[4][2];
+  double s = 0.0, n = 0.0;
+  const int64_t total = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / C; const int c = (int)(i - row * C);
+    const int64_t bb = row / L;
+    if (len && (row - bb * L) >= len[bb]) continue;
+    const float d = a[row * lda + c] - b[row * ldb + c];
+    s += kind == 0 ? (double)d * d : (double)fabsf(d);
+    n += 1.0;
+  }
+  s = wave_sum_d(s); n = wave_sum_d(n);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave][0] = s; red[wave][1] = n; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&acc[0], red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+    atomicAdd(&acc[1], red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+  }
+}
+
+extern "C" int styler_masked_err_sum(const float* a, int64_t lda, const float* b, int64_t ldb, double* acc, int kind,
+                                     int B, int L, int C, const int64_t* len, void* stream) {
+  if (!a || !b || !acc || B <= 0 || L <= 0 || C <= 0 || (kind != 0 && kind != 1)) return STYLER_EINVAL;
+  const int64_t rows = (int64_t)B * L;
+  hipLaunchKernelGGL(masked_err_kernel, dim3(grid_for(rows * C, 256, 1024)), dim3(256), 0, (hipStream_t)stream, a, lda,
+                     b, ldb, acc, kind, rows, L, C, len);
+  return launch_status();
+}
+
+// ---- length mask (utils.py:223-232): mask[b,t] = t >= len[b] (True = padding), torch.bool storage ----
+__global__ void length_mask_kernel(const int64_t* __restrict__ len, uint8_t* __restrict__ mask, int64_t total, int L) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / L;
+    mask[i] = (uint8_t)((i - b * L) >= len[b]);
+  }
+}
+
+extern "C" int styler_length_mask(const int64_t* len, uint8_t* mask, int B, int L, void* stream) {
+  if (!len || !mask || B <= 0 || L <= 0) return STYLER_EINVAL;
+  hipLaunchKernelGGL(length_mask_kernel, dim3(grid_for((int64_t)B * L)), dim3(256), 0, (hipStream_t)stream, len, mask,
+                     (int64_t)B * L, L);
+  return launch_status();
+}

@@ -1,0 +1,216 @@
+// Normalisation kernels: fused residual + LayerNorm(256) + pad mask (+ optional Linear(256,1) tail),
+// GroupNorm(16 ch / group, stats over the padded time axis) + ReLU, BatchNorm1d eval fold and train.
+// All HBM-bound: one read + one write of the activation (GroupNorm re-reads once from L2).
+#include "common.h"
+
+// one wave per row; lane holds 4 consecutive channels (64 x 4 = 256)
+__global__ __launch_bounds__(256) void add_layernorm_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ res, int64_t ldres,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, int64_t ldy,
+    const float* __restrict__ dot_w, const float* __restrict__ dot_b, float* __restrict__ dot_out, int64_t rows,
+    int L, const int64_t* __restrict__ len) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  bool masked = false;
+  if (len) {
+    const int64_t b = row / L;
+    masked = (row - b * L) >= len[b];
+  }
+  if (masked) {
+    if (y) *reinterpret_cast<float4*>(y + row * ldy + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dot_out && lane == 0) dot_out[row] = 0.f;
+    return;
+  }
+  float4 v = *reinterpret_cast<const float4*>(x + row * ldx + lane * 4);
+  if (res) {
+    const float4 r = *reinterpret_cast<const float4*>(res + row * ldres + lane * 4);
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  }
+  const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
+  const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+  const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.f / 256.f);
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
+  const float4 bt = *reinterpret_cast<const float4*>(beta + lane * 4);
+  float4 o = make_float4(dx * rstd * g.x + bt.x, dy * rstd * g.y + bt.y, dz * rstd * g.z + bt.z,
+                         dw * rstd * g.w + bt.w);
+  if (y) *reinterpret_cast<float4*>(y + row * ldy + lane * 4) = o;
+  if (dot_out) {
+    const float4 w = *reinterpret_cast<const float4*>(dot_w + lane * 4);
+    const float d = wave_sum(o.x * w.x + o.y * w.y + o.z * w.z + o.w * w.w);
+    if (lane == 0) dot_out[row] = d + dot_b[0];
+  }
+}
+
+extern "C" int styler_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldres,
+                                    const float* gamma, const float* beta, float* y, int64_t ldy,
+                                    const float* dot_w, const float* dot_b, float* dot_out, int B, int L, int C,
+                                    const int64_t* len, void* stream) {
+  if (!x || !gamma || !beta || (!y && !dot_out) || B <= 0 || L <= 0) return STYLER_EINVAL;
+  if (C != 256) return STYLER_EINVAL;
+  if (dot_out && (!dot_w || !dot_b)) return STYLER_EINVAL;
+  if ((ldx & 3) || (res && (ldres & 3)) || (y && (ldy & 3))) return STYLER_EALIGN;
+  const int64_t rows = (int64_t)B * L;
+  hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
+                     ldx, res, ldres, gamma, beta, y, ldy, dot_w, dot_b, dot_out, rows, L, len);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// GroupNorm + ReLU.  Block = (item b, 64-channel chunk = 4 groups).  256 threads as 16 row-lanes x
+// 16 channel-quads: thread (rl, cq) streams rows rl, rl+16, ... reading float4 = 4 channels of group
+// cq/4.  Pass 1 accumulates sum / sumsq in fp64 (exact enough to match a two-pass fp32 reference);
+// pass 2 re-reads the (L2-resident) chunk, normalises, applies ReLU.
+__global__ __launch_bounds__(256) void groupnorm_relu_kernel(const float* __restrict__ x, int64_t ldx,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ y,
+                                                             int64_t ldy, int L, int C) {
+  __shared__ double red[2][16][16];
+  __shared__ float stat[2][4];
+  const int b = blockIdx.y, c0 = blockIdx.x * 64;
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const float* xp = x + (int64_t)b * L * ldx + c0 + cq * 4;
+  double s = 0.0, ss = 0.0;
+  for (int t = rl; t < L; t += 16) {
+    const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
+    s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+    ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  red[0][rl][cq] = s; red[1][rl][cq] = ss;
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double ts = 0.0, tss = 0.0;
+    for (int r = 0; r < 16; ++r)
+      for (int q = 0; q < 4; ++q) { ts += red[0][r][threadIdx.x * 4 + q]; tss += red[1][r][threadIdx.x * 4 + q]; }
+    const double n = 16.0 * L;
+    const double mean = ts / n;
+    double var = tss / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stat[0][threadIdx.x] = (float)mean;
+    stat[1][threadIdx.x] = (float)(1.0 / sqrt(var + 1e-5));
+  }
+  __syncthreads();
+  const float mean = stat[0][cq >> 2], rstd = stat[1][cq >> 2];
+  const float4 g = *reinterpret_cast<const float4*>(gamma + c0 + cq * 4);
+  const float4 bt = *reinterpret_cast<const float4*>(beta + c0 + cq * 4);
+  float* yp = y + (int64_t)b * L * ldy + c0 + cq * 4;
+  for (int t = rl; t < L; t += 16) {
+    const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
+    float4 o;
+    o.x = fmaxf((v.x - mean) * rstd * g.x + bt.x, 0.f);
+    o.y = fmaxf((v.y - mean) * rstd * g.y + bt.y, 0.f);
+    o.z = fmaxf((v.z - mean) * rstd * g.z + bt.z, 0.f);
+    o.w = fmaxf((v.w - mean) * rstd * g.w + bt.w, 0.f);
+    *reinterpret_cast<float4*>(yp + (int64_t)t * ldy) = o;
+  }
+}
+
+extern "C" int styler_groupnorm_relu(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
+                                     int64_t ldy, int B, int L, int C, void* stream) {
+  if (!x || !y || !gamma || !beta || B <= 0 || L <= 0 || C <= 0 || (C & 63)) return STYLER_EINVAL;
+  if ((ldx & 3) || (ldy & 3)) return STYLER_EALIGN;
+  hipLaunchKernelGGL(groupnorm_relu_kernel, dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
+                     y, ldy, L, C);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ void bn_fold_kernel(const float* g, const float* b, const float* rm, const float* rv, const float* cb,
+                               float* scale, float* shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = g[c] / sqrtf(rv[c] + 1e-5f);
+  scale[c] = sc;
+  shift[c] = ((cb ? cb[c] : 0.f) - rm[c]) * sc + b[c];
+}
+
+extern "C" int styler_bn_fold(const float* gamma, const float* beta, const float* running_mean,
+                              const float* running_var, const float* conv_bias, float* scale, float* shift, int C,
+                              void* stream) {
+  if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0) return STYLER_EINVAL;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, conv_bias, scale, shift, C);
+  return launch_status();
+}
+
+// Train-mode BatchNorm: pass 1 column sums (fp64 atomics per block), pass 2 finalize + normalise.
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ ws,
+                                                       int64_t rows, int C, int rows_per_block) {
+  // thread -> channel quad cq = tid % (C/4)... generic: loop channels by float4 columns
+  const int nq = C / 4;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block; if (r1 > rows) r1 = rows;
+  for (int q = threadIdx.x; q < nq; q += blockDim.x) {
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    for (int64_t r = r0; r < r1; ++r) {
+      const float4 v = *reinterpret_cast<const float4*>(x + r * C + q * 4);
+      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+      ss[0] += (double)v.x * v.x; ss[1] += (double)v.y * v.y; ss[2] += (double)v.z * v.z; ss[3] += (double)v.w * v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      atomicAdd(&ws[q * 4 + k], s[k]);
+      atomicAdd(&ws[C + q * 4 + k], ss[k]);
+    }
+  }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ ws, float* save_mean, float* save_rstd,
+                                   float* running_mean, float* running_var, int64_t rows, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double n = (double)rows;
+  const double mean = ws[c] / n;
+  double var = ws[C + c] / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  save_mean[c] = (float)mean;
+  save_rstd[c] = (float)(1.0 / sqrt(var + 1e-5));
+  if (running_mean) {
+    const double unbiased = rows > 1 ? var * n / (n - 1.0) : var;
+    running_mean[c] = 0.9f * running_mean[c] + 0.1f * (float)mean;
+    running_var[c] = 0.9f * running_var[c] + 0.1f * (float)unbiased;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, float* __restrict__ y,
+                                                       int64_t total4, int C, int act) {
+  const int nq = C / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i % nq);
+    const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + q * 4);
+    const float4 b = *reinterpret_cast<const float4*>(beta + q * 4);
+    const float4 m = *reinterpret_cast<const float4*>(mean + q * 4);
+    const float4 r = *reinterpret_cast<const float4*>(rstd + q * 4);
+    float4 o;
+    o.x = apply_act((v.x - m.x) * r.x * g.x + b.x, act);
+    o.y = apply_act((v.y - m.y) * r.y * g.y + b.y, act);
+    o.z = apply_act((v.z - m.z) * r.z * g.z + b.z, act);
+    o.w = apply_act((v.w - m.w) * r.w * g.w + b.w, act);
+    *reinterpret_cast<float4*>(y + i * 4) = o;
+  }
+}
+
+extern "C" int styler_batchnorm_train(const float* x, const float* gamma, const float* beta, float* y,
+                                      float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                                      double* workspace, int64_t rows, int C, int act, void* stream) {
+  if (!x || !gamma || !beta || !y || !save_mean || !save_rstd || !workspace || rows <= 0 || C <= 0 || (C & 3))
+    return STYLER_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
+  if (e != hipSuccess) return (int)e;
+  const int rpb = 64;
+  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(128), 0, st, x, workspace, rows,
+                     C, rpb);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, save_mean, save_rstd,
+                     running_mean, running_var, rows, C);
+  const int64_t total4 = rows * C / 4;
+  int64_t blocks = (total4 + 255) / 256; if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta, save_mean, save_rstd,
+                     y, total4, C, act);
+  return launch_status();
+}

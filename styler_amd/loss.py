@@ -1,0 +1,45 @@
+"""`loss.STYLERLoss` / `DomainAdversarialTrainingLoss` drop-ins (reference loss.py:7-68).
+
+masked_select + MSELoss / L1Loss become one masked-reduction kernel per term (no compacted copies):
+sum over valid positions / count, accumulated in fp64.  Masks arrive as the reference passes them
+(True = valid, i.e. the caller's `~src_mask`, `~mel_mask`); the kernels take lengths, so `src_len` /
+`mel_len` (already part of the reference signature) are what is actually consumed."""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _masked_mean(a, b, kind, lens):
+    acc = torch.zeros(2, dtype=torch.float64, device=a.device)
+    ops.masked_err_sum(a.contiguous(), b.contiguous(), acc, kind, lens)
+    return (acc[0] / acc[1]).float()
+
+
+def _nll3(posteriors, label):
+    """3 x NLLLoss(mean) on [B, 2] log-probabilities (loss.py:46-48)."""
+    idx = label.view(-1, 1)
+    return sum(-(p.gather(1, idx)).mean() for p in posteriors)
+
+
+class STYLERLoss(nn.Module):
+    """loss.py:7-50."""
+
+    def cal_mel_loss(self, mel, mel_postnet, mel_target, mel_mask, mel_len=None):
+        lens = mel_len if mel_len is not None else mel_mask.sum(dim=1).to(torch.int64)
+        return _masked_mean(mel, mel_target, 0, lens), _masked_mean(mel_postnet, mel_target, 0, lens)
+
+    def forward(self, log_d_predicted, log_d_target, p_predicted, p_target, e_predicted, e_target, mel, mel_postnet,
+                mel_target, src_mask, mel_mask, src_len, mel_len, aug_posteriors, aug_label):
+        mel_loss, mel_postnet_loss = self.cal_mel_loss(mel, mel_postnet, mel_target, mel_mask, mel_len)
+        d_loss = _masked_mean(log_d_predicted, log_d_target, 1, src_len)
+        p_loss = _masked_mean(p_predicted, p_target, 1, mel_len)
+        e_loss = _masked_mean(e_predicted, e_target, 1, mel_len)
+        return mel_loss, mel_postnet_loss, d_loss, p_loss, e_loss, _nll3(aug_posteriors, aug_label)
+
+
+class DomainAdversarialTrainingLoss(nn.Module):
+    """loss.py:53-68."""
+
+    def forward(self, augmentation_posterior, aug_label):
+        return _nll3(augmentation_posterior, aug_label)

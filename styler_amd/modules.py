@@ -1,0 +1,370 @@
+"""Host-side mirror of the reference's `modules.py`: StyleModeling and its blocks, with the reference's
+module tree / parameter names, built from libstyler_hip.so kernels only.
+
+Layout notes (all channels-last fp32):
+  * the reference's `enc_cat [B, 674, T]` (mel | one-hot f0 | one-hot energy | mel_aug) is never
+    built: `encoder_input_cat` returns an `EncoderInput` record and the one-hot streams enter through
+    the 5-tap weight-gather kernel (styler_onehot_conv5);
+  * the four conv stacks write their last GroupNorm+ReLU straight into one [B, T, 1152] buffer
+    (channel slices), which the mel calibrator resamples to [B, S, 1152];
+  * the five style encodings are written straight into channel slices of one [B, S, 1280] buffer that
+    the LengthRegulator expands to [B, T, 1280]; predictors read its slices in place.
+"""
+from collections import OrderedDict, namedtuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hparams as hp
+from . import ops
+from .runtime import rt
+from .transformer import ConvNorm, Encoder, _HipModule
+
+EncoderInput = namedtuple("EncoderInput", "mel p_norm e_input mel_aug")
+
+
+class GradientReversalLayer(nn.Module):
+    """modules.py:48-81: identity forward, gradient * (-alpha) backward (applied in the backward ops)."""
+
+    def __init__(self, alpha=1):
+        super().__init__()
+        self._alpha = torch.tensor(alpha, requires_grad=False)
+
+    def forward(self, x):
+        return x
+
+
+class AugmentationClassifier(_HipModule):
+    """modules.py:23-45."""
+
+    def __init__(self, input_dim=hp.encoder_hidden):
+        super().__init__()
+        self.grl = GradientReversalLayer()
+        self.hidden = hp.encoder_hidden
+        self.classifier = nn.Sequential(OrderedDict([
+            ("d_fc1", nn.Linear(input_dim, self.hidden)),
+            ("d_bn1", nn.LayerNorm(self.hidden)),
+            ("d_relu1", nn.ReLU()),
+            ("d_fc2", nn.Linear(self.hidden, 2)),
+            ("d_softmax", nn.LogSoftmax(dim=-1)),
+        ]))
+
+    def forward(self, x):
+        c = self.classifier
+        h = self._gemm("fc1", x, c.d_fc1)
+        return ops.aug_classifier_tail(h, c.d_bn1.weight, c.d_bn1.bias, c.d_fc2.weight, c.d_fc2.bias)
+
+
+class AudioEncoder(_HipModule):
+    """modules.py:84-201."""
+
+    def __init__(self):
+        super().__init__()
+        self.widths = [hp.va_enc_dim_d, hp.va_enc_dim_p, hp.va_enc_dim_e, hp.va_enc_dim_r]
+        self.necks = [hp.va_neck_hidden_d, hp.va_neck_hidden_p, hp.va_neck_hidden_e, hp.va_neck_hidden_r]
+        in_dims = [hp.n_mel_channels, hp.va_dim_f0, hp.va_dim_energy, hp.n_mel_channels]
+        for s in range(4):
+            convs = []
+            for i in range(3):
+                convs.append(nn.Sequential(
+                    ConvNorm(in_dims[s] if i == 0 else self.widths[s], self.widths[s], kernel_size=5, stride=1,
+                             padding=2, dilation=1, w_init_gain="relu"),
+                    nn.GroupNorm(self.widths[s] // hp.va_chs_grp, self.widths[s])))
+            setattr(self, f"convolutions_{s + 1}", nn.ModuleList(convs))
+            setattr(self, f"lstm_{s + 1}",
+                    nn.LSTM(self.widths[s], self.necks[s], 2, batch_first=True, bidirectional=True))
+
+    def _lstm(self, s, x):
+        """2-layer BiLSTM: per layer one MFMA GEMM for both directions' input projections, then the
+        persistent recurrent kernel."""
+        lstm = getattr(self, f"lstm_{s + 1}")
+        H = self.necks[s]
+        d = self._derived
+        for layer in range(2):
+            names = [f"weight_ih_l{layer}", f"weight_ih_l{layer}_reverse", f"weight_hh_l{layer}",
+                     f"weight_hh_l{layer}_reverse", f"bias_ih_l{layer}", f"bias_hh_l{layer}",
+                     f"bias_ih_l{layer}_reverse", f"bias_hh_l{layer}_reverse"]
+            wi, wir, wh, whr, bi, bh, bir, bhr = [getattr(lstm, n) for n in names]
+            key = f"lstm{s}_{layer}"
+            w_ih = d.get(key + "wi", [wi, wir], lambda a, b: torch.cat([a.detach(), b.detach()]))
+            bias = d.get(key + "b", [bi, bh, bir, bhr],
+                         lambda a, b, c, e: torch.cat([a.detach() + b.detach(), c.detach() + e.detach()]))
+            w_hh = d.get(key + "wh", [wh, whr], lambda a, b: torch.stack([a.detach(), b.detach()]).contiguous())
+            prec = ops.PREC_F32
+            w = w_ih
+            if rt.prec == ops.PREC_BF16 and x.shape[-1] % 8 == 0:
+                w = d.get(key + "wi16", [wi, wir], lambda a, b: ops.cast_bf16(torch.cat([a.detach(), b.detach()])))
+                prec = ops.PREC_BF16
+            gx = ops.conv_gemm(x, w, bias, n=8 * H, prec=prec)
+            x = ops.lstm_bidir(gx, w_hh, H)
+        return x
+
+    def forward(self, cat, len_org, seq_len, mask=None, max_seq_len=None):
+        """cat: EncoderInput (from StyleEncoder.encoder_input_cat); len_org = mel_len, seq_len = src_len.
+        Returns (duration, f0, energy, noise) encodings [B, S, 2*neck].  S = max(seq_len) as in
+        utils.mel_calibrator's re-padding; pass `max_seq_len` to avoid the host sync that needs."""
+        if not isinstance(cat, EncoderInput):
+            raise TypeError("audio_encoder expects the EncoderInput returned by encoder_input_cat "
+                            "(the dense one-hot [B, 674, T] tensor is never materialised)")
+        mel, p_norm, e_input, mel_aug = cat
+        B, T, _ = mel.shape
+        dev = mel.device
+        W = self.widths
+        offs = [0, W[0], W[0] + W[1], W[0] + W[1] + W[2]]
+        catbuf = torch.empty(B, T, sum(W), device=dev, dtype=torch.float32)
+        err = torch.zeros(1, device=dev, dtype=torch.int32) if rt.strict_inputs else None
+        for s in range(4):
+            convs = getattr(self, f"convolutions_{s + 1}")
+            x = None
+            for i in range(3):
+                conv, gn = convs[i][0].conv, convs[i][1]
+                if i == 0 and s in (1, 2):
+                    wt = self._derived.get(f"oh{s}", [conv.weight],
+                                           lambda w: w.detach().permute(2, 1, 0).contiguous())
+                    y = torch.empty(B, T, W[s], device=dev, dtype=torch.float32)
+                    ops.onehot_conv5(p_norm if s == 1 else e_input, wt, conv.bias, y, err_flag=err)
+                else:
+                    src = (mel if s == 0 else mel_aug) if i == 0 else x
+                    y = self._gemm(f"c{s}_{i}", src, conv, kw=5)
+                out = catbuf[..., offs[s]:offs[s] + W[s]] if i == 2 else y
+                x = ops.groupnorm_relu(y, gn.weight, gn.bias, out=out)
+        if err is not None and int(err.item()) != 0:
+            raise AssertionError("quantize_1D_torch: input outside [0, 1] (utils.py:423)")
+        S = int(max_seq_len) if max_seq_len is not None else int(seq_len.max().item())
+        cal = ops.mel_calibrate(catbuf, len_org, seq_len, S)
+        outs = []
+        for s in range(4):
+            outs.append(self._lstm(s, cal[..., offs[s]:offs[s] + W[s]]))
+        return tuple(outs)
+
+
+class StyleEncoder(_HipModule):
+    """modules.py:204-235."""
+
+    def __init__(self):
+        super().__init__()
+        self.text_encoder = Encoder()
+        self.audio_encoder = AudioEncoder()
+        self.text_linear_down = nn.Sequential(nn.Linear(hp.encoder_hidden, hp.va_neck_hidden_t), nn.ReLU())
+        self.speaker_linear_p = nn.Sequential(nn.Linear(hp.speaker_embed_dim, hp.va_neck_hidden_p * 2), nn.ReLU())
+        self.speaker_linear = nn.Sequential(nn.Linear(hp.speaker_embed_dim, hp.encoder_hidden), nn.ReLU())
+
+    def encoder_input_cat(self, mel_target, p_norm, e_input, mel_aug):
+        return EncoderInput(mel_target.contiguous(), p_norm.contiguous(), e_input.contiguous(),
+                            mel_aug.contiguous())
+
+    def forward(self, text, speaker_embed, mel_target, p_norm, e_input, mel_aug, mel_len, src_len, src_mask,
+                text_out=None):
+        text_encoding = self.text_encoder(text, src_len, out=text_out)
+        text_encoding_neck = self._gemm("tld", text_encoding, self.text_linear_down[0], act=ops.ACT_RELU)
+        spk_in = speaker_embed.unsqueeze(1)
+        speaker_encoding_p = self._gemm("slp", spk_in, self.speaker_linear_p[0], act=ops.ACT_RELU).squeeze(1)
+        speaker_encoding = self._gemm("sl", spk_in, self.speaker_linear[0], act=ops.ACT_RELU).squeeze(1)
+        enc_cat = self.encoder_input_cat(mel_target, p_norm, e_input, mel_aug)
+        d, p, e, n = self.audio_encoder(enc_cat, mel_len, src_len, mask=None, max_seq_len=text.shape[1])
+        return text_encoding, text_encoding_neck, speaker_encoding_p, speaker_encoding, d, p, e, n
+
+
+class LengthRegulator(nn.Module):
+    """modules.py:390-423."""
+
+    def forward(self, x, duration, max_len):
+        B, S, _ = x.shape
+        csum, mel_len, _ = ops.duration_scan(B, S, x.device, dur=duration.contiguous())
+        T = int(max_len) if max_len is not None else int(mel_len.max().item())
+        return ops.length_regulate(x, csum, T), mel_len
+
+
+class Conv(nn.Module):
+    """modules.py:468-507 (parameter holder: `.conv`)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, padding=0, dilation=1, bias=True,
+                 w_init="linear"):
+        super().__init__()
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                              dilation=dilation, bias=bias)
+
+
+class StylePredictor(_HipModule):
+    """modules.py:426-465: [Conv1d(k=3) -> ReLU -> LayerNorm -> dropout] x 2 -> Linear(256,1) -> mask.
+    ReLU rides in the GEMM epilogue; the second LayerNorm, the Linear(256,1) and the mask are one kernel."""
+
+    def __init__(self):
+        super().__init__()
+        k = hp.style_predictor_kernel_size
+        f = hp.style_predictor_filter_size
+        self.conv_layer = nn.Sequential(OrderedDict([
+            ("conv1d_1", Conv(hp.encoder_hidden, f, kernel_size=k, padding=(k - 1) // 2)),
+            ("relu_1", nn.ReLU()),
+            ("layer_norm_1", nn.LayerNorm(f)),
+            ("dropout_1", nn.Dropout(hp.style_predictor_dropout)),
+            ("conv1d_2", Conv(f, f, kernel_size=k, padding=1)),
+            ("relu_2", nn.ReLU()),
+            ("layer_norm_2", nn.LayerNorm(f)),
+            ("dropout_2", nn.Dropout(hp.style_predictor_dropout)),
+        ]))
+        self.linear_layer = nn.Linear(f, 1)
+
+    def forward(self, encoder_output, lens):
+        c = self.conv_layer
+        k = hp.style_predictor_kernel_size
+        h = self._gemm("c1", encoder_output, c.conv1d_1.conv, kw=k, act=ops.ACT_RELU)
+        h = ops.add_layernorm(h, c.layer_norm_1.weight, c.layer_norm_1.bias)
+        h = self._gemm("c2", h, c.conv1d_2.conv, kw=k, act=ops.ACT_RELU)
+        return ops.add_layernorm(h, c.layer_norm_2.weight, c.layer_norm_2.bias, lens=lens,
+                                 dot_w=self.linear_layer.weight, dot_b=self.linear_layer.bias)
+
+
+def _mlp(in_dim):
+    return nn.Sequential(nn.Linear(in_dim, hp.encoder_hidden), nn.ReLU(),
+                         nn.Linear(hp.encoder_hidden, hp.encoder_hidden), nn.ReLU())
+
+
+class StyleModeling(_HipModule):
+    """modules.py:238-387."""
+
+    def __init__(self):
+        super().__init__()
+        self.style_encoder = StyleEncoder()
+        self.augmentation_classifier_d = AugmentationClassifier(input_dim=hp.va_neck_hidden_d * 2)
+        self.augmentation_classifier_p = AugmentationClassifier(input_dim=hp.va_neck_hidden_p * 2)
+        self.augmentation_classifier_e = AugmentationClassifier(input_dim=hp.va_neck_hidden_e * 2)
+        self.duration_linear = _mlp(hp.va_neck_hidden_d * 2)
+        self.pitch_norm_linear = _mlp(hp.va_neck_hidden_p * 2)
+        self.pitch_linear = _mlp(hp.va_neck_hidden_p * 2)
+        self.energy_linear = _mlp(hp.va_neck_hidden_e * 2)
+        self.residual_linear = _mlp(hp.va_neck_hidden_r * 2)
+        self.text_linear_up = nn.Sequential(nn.Linear(hp.va_neck_hidden_t, hp.encoder_hidden), nn.ReLU())
+        self.duration_predictor = StylePredictor()
+        self.length_regulator = LengthRegulator()
+        self.pitch_predictor = StylePredictor()
+        self.energy_predictor = StylePredictor()
+        self.pitch_bins = nn.Parameter(torch.exp(torch.linspace(
+            np.log(hp.f0_min), np.log(hp.f0_max), hp.n_bins - 1)), requires_grad=False)
+        self.energy_bins = nn.Parameter(torch.linspace(hp.energy_min, hp.energy_max, hp.n_bins - 1),
+                                        requires_grad=False)
+        self.pitch_embedding = nn.Embedding(hp.n_bins, hp.encoder_hidden)
+        self.energy_embedding = nn.Embedding(hp.n_bins, hp.encoder_hidden)
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _mlp2(self, key, seq, x, res=None, out=None):
+        h = self._gemm(key + "0", x, seq[0], act=ops.ACT_RELU)
+        return self._gemm(key + "2", h, seq[2], act=ops.ACT_RELU, res=res, out=out)
+
+    def _expand_and_predict(self, encodings, src_len, duration_target, log_d, max_len, mel_len_in, mel_mask,
+                            pitch_target, energy_target, d_control, p_control, e_control, pitch_plus_speaker=True,
+                            want_noise_sum=True, ids=None):
+        """LengthRegulator + energy/pitch predictors + bucketise/embed/add (modules.py:352-385)."""
+        B, S, _ = encodings.shape
+        H = hp.encoder_hidden
+        if duration_target is not None:
+            csum, mel_len, _ = ops.duration_scan(B, S, encodings.device, dur=duration_target.contiguous())
+            T = int(max_len) if max_len is not None else int(mel_len.max().item())
+            lens = mel_len_in
+            out_len, out_mask = mel_len_in, mel_mask
+        else:
+            csum, mel_len, _ = ops.duration_scan(B, S, encodings.device, log_d=log_d, d_control=d_control)
+            T = int(max_len) if max_len is not None else int(mel_len.max().item())
+            lens = mel_len
+            out_len, out_mask = mel_len, ops.length_mask(mel_len, T)
+        lr = ops.length_regulate(encodings, csum, T)                       # [B, T, 1280]
+        t_e, p_e, s_e, e_e, n_e = (lr[..., i * H:(i + 1) * H] for i in range(5))
+
+        energy_prediction = self.energy_predictor(e_e, lens)
+        p_in = ops.add2(p_e, s_e) if pitch_plus_speaker else p_e
+        pitch_prediction = self.pitch_predictor(p_in, lens)
+        if energy_target is not None:
+            e_src, e_scale = energy_target.contiguous(), 1.0
+        else:
+            e_src, e_scale = energy_prediction, e_control
+        if pitch_target is not None:
+            p_src, p_scale = pitch_target.contiguous(), 1.0
+        else:
+            p_src, p_scale = pitch_prediction, p_control
+        out, out_noisy = ops.bucket_embed_add(
+            t_e, s_e, p_src, p_scale, e_src, e_scale, self.pitch_bins, self.energy_bins,
+            self.pitch_embedding.weight, self.energy_embedding.weight, noise=n_e if want_noise_sum else None,
+            p_ids=ids[0] if ids else None, e_ids=ids[1] if ids else None)
+        if energy_target is None and e_control != 1.0:
+            energy_prediction = energy_prediction * e_control
+        if pitch_target is None and p_control != 1.0:
+            pitch_prediction = pitch_prediction * p_control
+        return out, out_noisy, n_e, pitch_prediction, energy_prediction, out_len, out_mask, lr
+
+    # -- reference entry points ----------------------------------------------------------------
+    def forward(self, text, speaker_embed, mel_target, mel_aug, p_norm, e_input, src_len, mel_len, src_mask,
+                mel_mask=None, duration_target=None, pitch_target=None, energy_target=None, max_len=None,
+                d_control=1.0, p_control=1.0, e_control=1.0):
+        B, S = text.shape
+        H = hp.encoder_hidden
+        encodings = torch.empty(B, S, 5 * H, device=text.device, dtype=torch.float32)
+        sl = [encodings[..., i * H:(i + 1) * H] for i in range(5)]
+
+        (text_encoding, text_encoding_neck, speaker_encoding_p, speaker_encoding, duration_encoding,
+         pitch_encoding, energy_encoding, noise_encoding) = self.style_encoder(
+            text, speaker_embed, mel_target, p_norm, e_input, mel_aug, mel_len, src_len, src_mask, text_out=sl[0])
+        max_seq_len = S
+
+        aug_posterior_d = self.augmentation_classifier_d(duration_encoding)
+        aug_posterior_p = self.augmentation_classifier_p(pitch_encoding)
+        aug_posterior_e = self.augmentation_classifier_e(energy_encoding)
+
+        # for the inspection (modules.py:327-333)
+        self.max_seq_len = max_seq_len
+        self.pitch_encoding = pitch_encoding
+        self.speaker_encoding = speaker_encoding.unsqueeze(1).expand(-1, S, -1)
+        self.speaker_encoding_p = speaker_encoding_p.unsqueeze(1).expand(-1, S, -1)
+        pitch_in = ops.add_rowvec(pitch_encoding, speaker_encoding_p, S)
+
+        text_neck_up = self._gemm("tlu", text_encoding_neck, self.text_linear_up[0], act=ops.ACT_RELU)
+        duration_up = self._mlp2("dl", self.duration_linear, duration_encoding)
+        dp_in = ops.add2(text_neck_up, duration_up)
+        self._mlp2("pl", self.pitch_linear, pitch_in, res=text_neck_up, out=sl[1])
+        ops.add_rowvec(None, speaker_encoding, S, out=sl[2])
+        energy_up = self._mlp2("el", self.energy_linear, energy_encoding)
+        ops.add2(text_neck_up, energy_up, out=sl[3])
+        self._mlp2("rl", self.residual_linear, noise_encoding, out=sl[4])
+
+        # for the inspection (modules.py:341-348)
+        self.text_encoding_neck = text_neck_up
+        self.duration_encoding = duration_up
+        self.energy_encoding = energy_up
+        self.noise_encoding = sl[4]
+        self.text_encoding = sl[0]
+        self.src_mask = src_mask
+        self.max_len = max_len
+
+        log_duration_prediction = self.duration_predictor(dp_in, src_len)
+        out, out_noisy, n_e, pitch_prediction, energy_prediction, out_len, out_mask, _ = self._expand_and_predict(
+            encodings, src_len, duration_target, log_duration_prediction, max_len, mel_len, mel_mask, pitch_target,
+            energy_target, d_control, p_control, e_control)
+        self._out_noisy = out_noisy
+        return (out, n_e, log_duration_prediction, pitch_prediction, energy_prediction, out_len, out_mask,
+                (aug_posterior_d, aug_posterior_p, aug_posterior_e))
+
+    def predict_inference(self, text_encoding, pitch_encoding, energy_encoding, duration_encoding,
+                          speaker_encoding, noise_encoding, src_mask, max_len, speaker_normalized=True,
+                          d_control=1.0, p_control=1.0, e_control=1.0):
+        """modules.py:285-309 (the synthesize.py inspection path)."""
+        B, S, H = text_encoding.shape
+        encodings = torch.empty(B, S, 5 * H, device=text_encoding.device, dtype=torch.float32)
+        for i, part in enumerate((text_encoding, pitch_encoding, speaker_encoding, energy_encoding,
+                                  noise_encoding)):
+            ops.add2(part.contiguous() if part.stride(-1) != 1 or part.stride(0) != S * part.stride(1)
+                     else part, None, out=encodings[..., i * H:(i + 1) * H])
+        src_len = (~src_mask).sum(dim=1).to(torch.int64)
+        log_d = self.duration_predictor(duration_encoding.contiguous(), src_len)
+        csum, mel_len, _ = ops.duration_scan(B, S, encodings.device, log_d=log_d, d_control=d_control)
+        T = int(max_len) if max_len is not None else int(mel_len.max().item())
+        ids = (torch.empty(B, T, device=encodings.device, dtype=torch.int32),
+               torch.empty(B, T, device=encodings.device, dtype=torch.int32))
+        out, _, n_e, pitch_prediction, energy_prediction, _, mel_mask, lr = self._expand_and_predict(
+            encodings, src_len, None, log_d, T, None, None, None, None, d_control, p_control, e_control,
+            pitch_plus_speaker=not speaker_normalized, want_noise_sum=False, ids=ids)
+        t_e, _, s_e, _, _ = (lr[..., i * H:(i + 1) * H] for i in range(5))
+        # inspection-only entry: the two embedding tables are returned un-summed, as the reference does
+        pitch_embedding = torch.nn.functional.embedding(ids[0].long(), self.pitch_embedding.weight)
+        energy_embedding = torch.nn.functional.embedding(ids[1].long(), self.energy_embedding.weight)
+        return (t_e, pitch_embedding, s_e, energy_embedding, n_e, log_d, pitch_prediction, energy_prediction,
+                mel_mask)

@@ -1,0 +1,275 @@
+"""Tensor-level wrappers over the C ABI (include/styler_hip.h).
+
+PyTorch supplies device memory (caching allocator), the current HIP stream and nothing else: every
+function here hands raw device pointers + sizes to libstyler_hip.so.  Activations are fp32
+channels-last [B, L, C]; a channel slice `x[..., a:b]` of a wider buffer is a legal argument (the row
+stride travels as `ld`), which is how torch.cat / torch.split copies of the reference disappear."""
+import torch
+
+from ._lib import lib
+
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+PREC_F32, PREC_BF16 = 0, 1
+
+
+class StylerHipError(RuntimeError):
+    pass
+
+
+def _chk(rc, name):
+    if rc != 0:
+        raise StylerHipError(f"{name} failed with code {rc}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ld(t):
+    """Row stride (elements) of a [B, L, C] or [rows, C] fp32 view whose channels are contiguous."""
+    assert t.stride(-1) == 1 or t.shape[-1] == 1, "channel dim must be contiguous"
+    ld = t.stride(-2)
+    if t.dim() == 3 and t.shape[0] > 1:
+        assert t.stride(0) == t.shape[1] * ld, "batch stride must equal L * row stride"
+    return ld
+
+
+def _f32(t):
+    assert t.dtype == torch.float32 and t.is_cuda, (t.dtype, t.device)
+    return t
+
+
+def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, scale=None, res=None,
+              out=None, lens=None):
+    """y = act(scale * conv1d_same(x, w) + bias) (+ res); x [B, L, cin] -> y [B, L, n].
+    `w` is the kernel-layout weight [n, kw*cin] (fp32, or bf16 when prec == PREC_BF16)."""
+    _f32(x)
+    B, L, cin = x.shape
+    n = w.shape[0] if n is None else n
+    if prec == PREC_BF16 and (w.dtype != torch.bfloat16 or cin % 8):
+        raise StylerHipError("bf16 GEMM needs a bf16 weight shadow and cin % 8 == 0")
+    if out is None:
+        out = torch.empty(B, L, n, device=x.device, dtype=torch.float32)
+    _chk(lib.styler_conv_gemm(x.data_ptr(), _ld(x), w.data_ptr(), _ptr(scale), _ptr(bias), _ptr(res),
+                              _ld(res) if res is not None else 0, out.data_ptr(), _ld(out), B, L, cin, n,
+                              kw, act, prec, _ptr(lens), _stream()), "styler_conv_gemm")
+    return out
+
+
+def cast_bf16(src):
+    dst = torch.empty(src.shape, device=src.device, dtype=torch.bfloat16)
+    _chk(lib.styler_cast_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "styler_cast_bf16")
+    return dst
+
+
+def repack_conv_weight(w, to_kernel_layout=True):
+    """[n, cin, kw] -> [n, kw*cin] (kernel layout) or back."""
+    if to_kernel_layout:
+        n, cin, kw = w.shape
+        dst = torch.empty(n, kw * cin, device=w.device, dtype=torch.float32)
+    else:
+        raise NotImplementedError
+    _chk(lib.styler_repack_conv_weight(w.data_ptr(), dst.data_ptr(), n, cin, kw, 1, _stream()),
+         "styler_repack_conv_weight")
+    return dst
+
+
+def attention_fwd(qkv, lens, lse=None):
+    B, L, _ = qkv.shape
+    assert qkv.is_contiguous() and qkv.shape[2] == 768
+    out = torch.empty(B, L, 256, device=qkv.device, dtype=torch.float32)
+    _chk(lib.styler_attention_fwd(qkv.data_ptr(), out.data_ptr(), _ptr(lse), B, L, _ptr(lens), _stream()),
+         "styler_attention_fwd")
+    return out
+
+
+def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, dot_b=None):
+    """LayerNorm(x + res) with pad-mask; with dot_w returns the [B, L] scalar head instead."""
+    B, L, C = x.shape
+    dot_out = None
+    if dot_w is not None:
+        dot_out = torch.empty(B, L, device=x.device, dtype=torch.float32)
+    elif out is None:
+        out = torch.empty(B, L, C, device=x.device, dtype=torch.float32)
+    _chk(lib.styler_add_layernorm(x.data_ptr(), _ld(x), _ptr(res), _ld(res) if res is not None else 0,
+                                  gamma.data_ptr(), beta.data_ptr(), _ptr(out),
+                                  _ld(out) if out is not None else 0, _ptr(dot_w), _ptr(dot_b),
+                                  _ptr(dot_out), B, L, C, _ptr(lens), _stream()), "styler_add_layernorm")
+    return dot_out if dot_w is not None else out
+
+
+def groupnorm_relu(x, gamma, beta, out=None):
+    B, L, C = x.shape
+    if out is None:
+        out = x
+    _chk(lib.styler_groupnorm_relu(x.data_ptr(), _ld(x), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                   _ld(out), B, L, C, _stream()), "styler_groupnorm_relu")
+    return out
+
+
+def bn_fold(gamma, beta, running_mean, running_var, conv_bias):
+    C = gamma.numel()
+    scale = torch.empty(C, device=gamma.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    _chk(lib.styler_bn_fold(gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
+                            _ptr(conv_bias), scale.data_ptr(), shift.data_ptr(), C, _stream()), "styler_bn_fold")
+    return scale, shift
+
+
+def batchnorm_train(x, gamma, beta, running_mean, running_var, act):
+    """x [B, L, C] contiguous (conv output incl. bias). Returns y, save_mean, save_rstd."""
+    assert x.is_contiguous()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    ws = torch.empty(2 * C, device=x.device, dtype=torch.float64)
+    _chk(lib.styler_batchnorm_train(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                    mean.data_ptr(), rstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
+                                    ws.data_ptr(), rows, C, act, _stream()), "styler_batchnorm_train")
+    return y, mean, rstd
+
+
+def embed_pos(text, emb, pe):
+    B, L = text.shape
+    out = torch.empty(B, L, emb.shape[1], device=emb.device, dtype=torch.float32)
+    assert text.dtype == torch.int64 and text.is_contiguous() and pe.shape[0] >= L
+    _chk(lib.styler_embed_pos(text.data_ptr(), emb.data_ptr(), pe.data_ptr(), out.data_ptr(), B, L,
+                              emb.shape[1], _stream()), "styler_embed_pos")
+    return out
+
+
+def add_pos(x, pe):
+    B, L, C = x.shape
+    assert pe.shape[0] >= L
+    out = torch.empty(B, L, C, device=x.device, dtype=torch.float32)
+    _chk(lib.styler_add_pos(x.data_ptr(), _ld(x), pe.data_ptr(), out.data_ptr(), B, L, C, _stream()),
+         "styler_add_pos")
+    return out
+
+
+def sinusoid_table(L, C, device):
+    pe = torch.empty(L, C, device=device, dtype=torch.float32)
+    _chk(lib.styler_sinusoid_table(pe.data_ptr(), L, C, _stream()), "styler_sinusoid_table")
+    return pe
+
+
+def onehot_conv5(v, wt, bias, out, err_flag=None, idx_out=None):
+    B, L = v.shape
+    C = bias.numel()
+    assert v.is_contiguous()
+    _chk(lib.styler_onehot_conv5(v.data_ptr(), wt.data_ptr(), bias.data_ptr(), out.data_ptr(), _ld(out),
+                                 _ptr(idx_out), _ptr(err_flag), B, L, C, _stream()), "styler_onehot_conv5")
+    return out
+
+
+def mel_calibrate(x, mel_len, src_len, S):
+    B, T, C = x.shape
+    y = torch.empty(B, S, C, device=x.device, dtype=torch.float32)
+    _chk(lib.styler_mel_calibrate(x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), mel_len.data_ptr(),
+                                  src_len.data_ptr(), B, T, S, C, _stream()), "styler_mel_calibrate")
+    return y
+
+
+def lstm_bidir(gx, w_hh, H, cell_out=None, gates_out=None):
+    B, S, _ = gx.shape
+    assert gx.is_contiguous() and gx.shape[2] == 8 * H and w_hh.is_contiguous()
+    out = torch.empty(B, S, 2 * H, device=gx.device, dtype=torch.float32)
+    _chk(lib.styler_lstm_bidir(gx.data_ptr(), w_hh.data_ptr(), out.data_ptr(), _ptr(cell_out), _ptr(gates_out),
+                               B, S, H, _stream()), "styler_lstm_bidir")
+    return out
+
+
+def aug_classifier_tail(h, ln_g, ln_b, w2, b2):
+    B, S, _ = h.shape
+    assert h.is_contiguous()
+    out = torch.empty(B, 2, device=h.device, dtype=torch.float32)
+    _chk(lib.styler_aug_classifier_tail(h.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), w2.data_ptr(),
+                                        b2.data_ptr(), out.data_ptr(), B, S, _stream()),
+         "styler_aug_classifier_tail")
+    return out
+
+
+def duration_scan(B, S, device, dur=None, log_d=None, d_control=1.0, want_dur=False):
+    """-> (csum int32 [B,S], mel_len int64 [B], dur_out fp32 [B,S] | None)"""
+    csum = torch.empty(B, S, device=device, dtype=torch.int32)
+    mel_len = torch.empty(B, device=device, dtype=torch.int64)
+    dur_out = torch.empty(B, S, device=device, dtype=torch.float32) if (want_dur and log_d is not None) else None
+    is_float = 0
+    if dur is not None:
+        assert dur.is_contiguous() and dur.dtype in (torch.int64, torch.float32)
+        is_float = int(dur.dtype == torch.float32)
+    if log_d is not None:
+        assert log_d.is_contiguous()
+    _chk(lib.styler_duration_scan(_ptr(dur), is_float, _ptr(log_d), float(d_control), _ptr(dur_out),
+                                  csum.data_ptr(), mel_len.data_ptr(), B, S, _stream()), "styler_duration_scan")
+    return csum, mel_len, dur_out
+
+
+def length_regulate(x, csum, T, frame_idx=None):
+    B, S, C = x.shape
+    out = torch.empty(B, T, C, device=x.device, dtype=torch.float32)
+    _chk(lib.styler_length_regulate(x.data_ptr(), _ld(x), csum.data_ptr(), out.data_ptr(), _ld(out),
+                                    _ptr(frame_idx), B, S, T, C, _stream()), "styler_length_regulate")
+    return out
+
+
+def bucket_embed_add(text, speaker, p, p_scale, e, e_scale, pitch_bins, energy_bins, pitch_emb, energy_emb,
+                     noise=None, p_ids=None, e_ids=None):
+    B, T, _ = text.shape
+    out = torch.empty(B, T, 256, device=text.device, dtype=torch.float32)
+    out2 = torch.empty_like(out) if noise is not None else None
+    assert p.is_contiguous() and e.is_contiguous()
+    _chk(lib.styler_bucket_embed_add(text.data_ptr(), _ld(text), speaker.data_ptr(), _ld(speaker), p.data_ptr(),
+                                     float(p_scale), e.data_ptr(), float(e_scale), pitch_bins.data_ptr(),
+                                     energy_bins.data_ptr(), pitch_emb.data_ptr(), energy_emb.data_ptr(),
+                                     out.data_ptr(), _ptr(noise), _ld(noise) if noise is not None else 0,
+                                     _ptr(out2), _ptr(p_ids), _ptr(e_ids), B, T, _stream()),
+         "styler_bucket_embed_add")
+    return out, out2
+
+
+def add2(a, b, out=None):
+    """out = a + b over [.., C] views (channel slices allowed)."""
+    C = a.shape[-1]
+    rows = a.numel() // C
+    if out is None:
+        out = torch.empty(a.shape, device=a.device, dtype=torch.float32)
+    _chk(lib.styler_add2(a.data_ptr(), _ld(a), _ptr(b), _ld(b) if b is not None else 0, out.data_ptr(), _ld(out),
+                         rows, C, _stream()), "styler_add2")
+    return out
+
+
+def add_rowvec(a, v, L, out=None):
+    """out[b,t,:] = (a[b,t,:] if a is not None else 0) + v[b,:]"""
+    B, C = v.shape
+    if out is None:
+        out = torch.empty(B, L, C, device=v.device, dtype=torch.float32)
+    _chk(lib.styler_add_rowvec(_ptr(a), _ld(a) if a is not None else 0, v.data_ptr(), v.stride(0), out.data_ptr(),
+                               _ld(out), B, L, C, _stream()), "styler_add_rowvec")
+    return out
+
+
+def length_mask(lens, L):
+    B = lens.shape[0]
+    mask = torch.empty(B, L, device=lens.device, dtype=torch.bool)
+    _chk(lib.styler_length_mask(lens.data_ptr(), mask.data_ptr(), B, L, _stream()), "styler_length_mask")
+    return mask
+
+
+def masked_err_sum(a, b, acc, kind, lens):
+    """acc (double[2], zeroed by caller) += (sum err over valid, count).  a, b: [B, L] or [B, L, C]."""
+    if a.dim() == 2:
+        B, L = a.shape
+        C, lda, ldb = 1, 1, 1
+    else:
+        B, L, C = a.shape
+        lda, ldb = _ld(a), _ld(b)
+    _chk(lib.styler_masked_err_sum(a.data_ptr(), lda, b.data_ptr(), ldb, acc.data_ptr(), kind, B, L, C,
+                                   _ptr(lens), _stream()), "styler_masked_err_sum")
+    return acc

@@ -1,0 +1,49 @@
+"""Process-wide runtime switches of the HIP path."""
+from . import ops
+
+
+class _Runtime:
+    def __init__(self):
+        self.prec = ops.PREC_F32        # PREC_F32: exact-fp32 MFMA (parity mode); PREC_BF16: throughput mode
+        self.strict_inputs = True       # raise like the reference's assert on p_norm / e_input outside [0, 1]
+
+    def set_precision(self, name):
+        self.prec = {"fp32": ops.PREC_F32, "bf16": ops.PREC_BF16}[name]
+
+
+rt = _Runtime()
+
+
+class Derived:
+    """Cache of tensors derived from parameters (kernel-layout conv weights, fused QKV, bf16 shadows,
+    folded BatchNorm).  An entry is rebuilt when any source's storage or in-place version changes
+    (optimizer steps and load_state_dict bump `_version`)."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, key, srcs, fn):
+        ver = tuple((s.data_ptr(), s._version) for s in srcs)
+        ent = self._store.get(key)
+        if ent is None or ent[0] != ver:
+            import torch
+            with torch.no_grad():
+                val = fn(*srcs)
+            self._store[key] = (ver, val)
+            return val
+        return ent[1]
+
+    def clear(self):
+        self._store.clear()
+
+
+def gemm_weight(cache, key, weight, cin):
+    """Kernel-layout weight for the current precision: ([n, kw*cin] tensor, prec)."""
+    import torch
+    w32 = cache.get(key + ":k", [weight],
+                    lambda w: w.detach() if w.dim() == 2 else ops.repack_conv_weight(w.detach()))
+    if rt.prec == ops.PREC_BF16 and cin % 8 == 0:
+        wb = cache.get(key + ":bf16", [weight], lambda w: ops.cast_bf16(
+            w.detach() if w.dim() == 2 else ops.repack_conv_weight(w.detach())))
+        return wb, ops.PREC_BF16
+    return w32, ops.PREC_F32

@@ -1,0 +1,208 @@
+"""Host-side mirror of the reference's `transformer/` package (Models.py, Layers.py, SubLayers.py):
+same module tree and parameter names/shapes (so `state_dict()` is the reference's), forward passes
+built only from libstyler_hip.so kernels."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hparams as hp
+from . import ops
+from .runtime import Derived, gemm_weight, rt
+
+
+def get_sinusoid_encoding_table(n_position, d_hid, padding_idx=None):
+    """transformer/Models.py:11-30 (float64 numpy, then cast) -- host-side, construction time only."""
+    pos = np.arange(n_position, dtype=np.float64)[:, None]
+    j = np.arange(d_hid)[None, :]
+    tab = pos / np.power(10000.0, 2.0 * (j // 2) / d_hid)
+    tab[:, 0::2] = np.sin(tab[:, 0::2])
+    tab[:, 1::2] = np.cos(tab[:, 1::2])
+    if padding_idx is not None:
+        tab[padding_idx] = 0.0
+    return torch.FloatTensor(tab)
+
+
+class _HipModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        object.__setattr__(self, "_derived", Derived())
+
+    def _gemm(self, key, x, lin, *, kw=1, act=ops.ACT_NONE, res=None, out=None, lens=None, scale=None,
+              shift=None):
+        """conv_gemm with the weight of an nn.Linear / nn.Conv1d parameter holder."""
+        w, prec = gemm_weight(self._derived, key, lin.weight, x.shape[-1])
+        bias = lin.bias if shift is None else shift
+        return ops.conv_gemm(x, w, bias, kw=kw, n=lin.weight.shape[0], act=act, prec=prec, scale=scale, res=res,
+                             out=out, lens=lens)
+
+
+class MultiHeadAttention(_HipModule):
+    """SubLayers.py:9-61.  Fused QKV projection (one N=768 GEMM), LDS-tiled online-softmax attention,
+    output projection with the residual folded into its epilogue, LayerNorm + pad mask in one pass."""
+
+    def __init__(self, n_head, d_model, d_k, d_v, dropout=0.1):
+        super().__init__()
+        assert (n_head, d_model, d_k, d_v) == (4, 256, 64, 64), "kernels are specialised for 4 x 64"
+        self.n_head, self.d_k, self.d_v = n_head, d_k, d_v
+        self.w_qs = nn.Linear(d_model, n_head * d_k)
+        self.w_ks = nn.Linear(d_model, n_head * d_k)
+        self.w_vs = nn.Linear(d_model, n_head * d_v)
+        self.layer_norm = nn.LayerNorm(d_model)
+        self.fc = nn.Linear(n_head * d_v, d_model)
+        self.dropout = nn.Dropout(dropout)
+
+    def _qkv(self):
+        d = self._derived
+        srcs_w = [self.w_qs.weight, self.w_ks.weight, self.w_vs.weight]
+        srcs_b = [self.w_qs.bias, self.w_ks.bias, self.w_vs.bias]
+        b = d.get("qkv_b", srcs_b, lambda *t: torch.cat([u.detach() for u in t]))
+        if rt.prec == ops.PREC_BF16:
+            w = d.get("qkv_w16", srcs_w, lambda *t: ops.cast_bf16(torch.cat([u.detach() for u in t])))
+            return w, b, ops.PREC_BF16
+        w = d.get("qkv_w", srcs_w, lambda *t: torch.cat([u.detach() for u in t]))
+        return w, b, ops.PREC_F32
+
+    def forward(self, x, lens, out=None):
+        """x [B, L, 256]; lens int64 [B]; returns LayerNorm(fc(attn) + x) with padded rows zeroed
+        (the masked_fill of Layers.py:29 is fused here)."""
+        w, b, prec = self._qkv()
+        qkv = ops.conv_gemm(x, w, b, n=768, prec=prec)
+        ctx = ops.attention_fwd(qkv, lens)
+        o = self._gemm("fc", ctx, self.fc, res=x)
+        return ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out)
+
+
+class PositionwiseFeedForward(_HipModule):
+    """SubLayers.py:64-89: Conv1d(256->1024, k=9) + ReLU and Conv1d(1024->256, k=1) as implicit GEMMs."""
+
+    def __init__(self, d_in, d_hid, dropout=0.1):
+        super().__init__()
+        k = hp.fft_conv1d_kernel_size
+        self.w_1 = nn.Conv1d(d_in, d_hid, kernel_size=k[0], padding=(k[0] - 1) // 2)
+        self.w_2 = nn.Conv1d(d_hid, d_in, kernel_size=k[1], padding=(k[1] - 1) // 2)
+        self.layer_norm = nn.LayerNorm(d_in)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x, lens, out=None):
+        h = self._gemm("w_1", x, self.w_1, kw=hp.fft_conv1d_kernel_size[0], act=ops.ACT_RELU)
+        o = self._gemm("w_2", h, self.w_2, kw=hp.fft_conv1d_kernel_size[1], res=x)
+        return ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out)
+
+
+class FFTBlock(nn.Module):
+    """Layers.py:10-34."""
+
+    def __init__(self, d_model, d_inner, n_head, d_k, d_v, dropout=0.1):
+        super().__init__()
+        self.slf_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout)
+        self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, dropout=dropout)
+
+    def forward(self, x, lens, out=None):
+        return self.pos_ffn(self.slf_attn(x, lens), lens, out=out)
+
+
+class _PositionMixin:
+    def _pe(self, L, device):
+        """Models.py:69-74 / 120-125: stored table for L <= 1001; eval mode regenerates longer ones
+        (on device, float64 angles); train mode cannot exceed the stored table."""
+        if L <= self.position_enc.shape[1] and not ((not self.training) and L > hp.max_seq_len):
+            return self.position_enc[0]
+        if self.training:
+            raise RuntimeError(f"sequence length {L} exceeds the position table "
+                               f"({self.position_enc.shape[1]}) in train mode (Models.py:124-125)")
+        cache = self.__dict__.setdefault("_pe_cache", {})
+        if cache.get("L") != L or cache["pe"].device != device:
+            cache["L"], cache["pe"] = L, ops.sinusoid_table(L, hp.encoder_hidden, device)
+        return cache["pe"]
+
+
+class Encoder(nn.Module, _PositionMixin):
+    """Models.py:33-84."""
+
+    def __init__(self, n_src_vocab=hp.n_src_vocab, len_max_seq=hp.max_seq_len, d_word_vec=hp.encoder_hidden,
+                 n_layers=hp.encoder_layer, n_head=hp.encoder_head, d_k=hp.encoder_hidden // hp.encoder_head,
+                 d_v=hp.encoder_hidden // hp.encoder_head, d_model=hp.encoder_hidden,
+                 d_inner=hp.fft_conv1d_filter_size, dropout=hp.encoder_dropout):
+        super().__init__()
+        self.src_word_emb = nn.Embedding(n_src_vocab, d_word_vec, padding_idx=0)
+        self.position_enc = nn.Parameter(
+            get_sinusoid_encoding_table(len_max_seq + 1, d_word_vec).unsqueeze(0), requires_grad=False)
+        self.layer_stack = nn.ModuleList(
+            [FFTBlock(d_model, d_inner, n_head, d_k, d_v, dropout=dropout) for _ in range(n_layers)])
+
+    def forward(self, src_seq, lens, out=None):
+        x = ops.embed_pos(src_seq, self.src_word_emb.weight, self._pe(src_seq.shape[1], src_seq.device))
+        for i, layer in enumerate(self.layer_stack):
+            x = layer(x, lens, out=out if i == len(self.layer_stack) - 1 else None)
+        return x
+
+
+class Decoder(nn.Module, _PositionMixin):
+    """Models.py:87-135."""
+
+    def __init__(self, len_max_seq=hp.max_seq_len, d_word_vec=hp.encoder_hidden, n_layers=hp.decoder_layer,
+                 n_head=hp.decoder_head, d_k=hp.decoder_hidden // hp.decoder_head,
+                 d_v=hp.decoder_hidden // hp.decoder_head, d_model=hp.decoder_hidden,
+                 d_inner=hp.fft_conv1d_filter_size, dropout=hp.decoder_dropout):
+        super().__init__()
+        self.position_enc = nn.Parameter(
+            get_sinusoid_encoding_table(len_max_seq + 1, d_word_vec).unsqueeze(0), requires_grad=False)
+        self.layer_stack = nn.ModuleList(
+            [FFTBlock(d_model, d_inner, n_head, d_k, d_v, dropout=dropout) for _ in range(n_layers)])
+
+    def forward(self, enc_seq, lens):
+        x = ops.add_pos(enc_seq, self._pe(enc_seq.shape[1], enc_seq.device))
+        for layer in self.layer_stack:
+            x = layer(x, lens)
+        return x
+
+
+class ConvNorm(nn.Module):
+    """Layers.py:37-64 (parameter holder: `.conv`)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, padding=None, dilation=1, bias=True,
+                 w_init_gain="linear"):
+        super().__init__()
+        if padding is None:
+            assert kernel_size % 2 == 1
+            padding = int(dilation * (kernel_size - 1) / 2)
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                              dilation=dilation, bias=bias)
+
+
+class PostNet(_HipModule):
+    """Layers.py:67-130: five Conv1d(k=5) + BatchNorm1d (+tanh).  Eval: BatchNorm folded into the GEMM
+    epilogue (scale/shift), the final residual `+ mel` (styler.py:34) folded into the last one."""
+
+    def __init__(self, n_mel_channels=80, postnet_embedding_dim=512, postnet_kernel_size=5,
+                 postnet_n_convolutions=5):
+        super().__init__()
+        self.convolutions = nn.ModuleList()
+        dims = [n_mel_channels] + [postnet_embedding_dim] * (postnet_n_convolutions - 1) + [n_mel_channels]
+        for i in range(postnet_n_convolutions):
+            self.convolutions.append(nn.Sequential(
+                ConvNorm(dims[i], dims[i + 1], kernel_size=postnet_kernel_size, stride=1,
+                         padding=int((postnet_kernel_size - 1) / 2), dilation=1),
+                nn.BatchNorm1d(dims[i + 1])))
+        self.kernel_size = postnet_kernel_size
+
+    def forward(self, x, add_residual=None):
+        """x [B, T, 80] channels-last -> [B, T, 80]; `add_residual` (the mel) is added to the output."""
+        n = len(self.convolutions)
+        for i, seq in enumerate(self.convolutions):
+            conv, bn = seq[0].conv, seq[1]
+            last = i == n - 1
+            act = ops.ACT_NONE if last else ops.ACT_TANH
+            if self.training:
+                y = self._gemm(f"c{i}", x, conv, kw=self.kernel_size)
+                y, _, _ = ops.batchnorm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, act)
+                with torch.no_grad():
+                    bn.num_batches_tracked += 1
+                x = ops.add2(y, add_residual) if (last and add_residual is not None) else y
+            else:
+                scale, shift = self._derived.get(
+                    f"bn{i}", [bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.bias],
+                    lambda g, b, rm, rv, cb: ops.bn_fold(g, b, rm, rv, cb))
+                x = self._gemm(f"c{i}", x, conv, kw=self.kernel_size, act=act, scale=scale, shift=shift,
+                               res=add_residual if last else None)
+        return x

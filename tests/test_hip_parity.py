@@ -1,0 +1,460 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the oracle and vs the reference-generated
+golden fixtures.  fp32 (exact-fp32 MFMA) tolerance: 1e-3 abs on mel (north_star), tighter per op;
+indices / lengths / masks bit-exact.  Run with `pytest -m gpu` on the MI355X box."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import styler_oracle
+    return styler_oracle
+
+
+@pytest.fixture(scope="module")
+def model(dev, ref_state_dict):
+    from styler_amd import STYLER
+    m = STYLER()
+    m.load_state_dict(ref_state_dict)
+    return m.to(dev).eval()
+
+
+def maxerr(a, b):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu() if isinstance(b, torch.Tensor) else torch.from_numpy(np.asarray(b)).float()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max()) if a.numel() else 0.0
+
+
+def check(a, b, tol, what=""):
+    e = maxerr(a, b)
+    assert e <= tol, f"{what}: max abs err {e:.3e} > {tol}"
+
+
+# ----------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize("B,L,cin,n,kw", [
+    (2, 37, 256, 256, 1), (3, 50, 256, 1024, 9), (2, 41, 1024, 256, 1), (2, 33, 80, 512, 5),
+    (2, 29, 512, 80, 5), (5, 1, 512, 128, 1), (2, 19, 4, 256, 1), (2, 23, 256, 4, 1),
+    (2, 64, 256, 768, 1), (4, 300, 256, 256, 3), (2, 130, 320, 320, 5), (3, 17, 160, 256, 1),
+])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_conv_gemm(dev, B, L, cin, n, kw, prec):
+    from styler_amd import ops
+    if prec == "bf16" and cin % 8:
+        pytest.skip("bf16 path needs cin % 8 == 0")
+    g = torch.Generator().manual_seed(B * 1000 + L + cin + n + kw)
+    x = torch.randn(B, L, cin, generator=g)
+    w = torch.randn(n, cin, kw, generator=g) / np.sqrt(cin * kw)
+    b = torch.randn(n, generator=g)
+    ref = F.conv1d(x.transpose(1, 2).double(), w.double(), b.double(), padding=kw // 2).transpose(1, 2)
+    wk = w.permute(0, 2, 1).reshape(n, kw * cin).contiguous().to(dev)
+    if prec == "bf16":
+        y = ops.conv_gemm(x.to(dev), ops.cast_bf16(wk), b.to(dev), kw=kw, prec=ops.PREC_BF16)
+        check(y, ref.float(), 6e-2, "bf16 gemm")
+    else:
+        y = ops.conv_gemm(x.to(dev), wk, b.to(dev), kw=kw)
+        check(y, ref.float(), 2e-5, "fp32 gemm")
+
+
+def test_conv_gemm_epilogue_and_slices(dev):
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, L, cin, n = 3, 45, 256, 256
+    wide = torch.randn(B, L, 1280, generator=g)
+    x = wide[..., 512:768]
+    w = torch.randn(n, cin, 3, generator=g) / 27.0
+    b, sc = torch.randn(n, generator=g), torch.rand(n, generator=g) + 0.5
+    res = torch.randn(B, L, n, generator=g)
+    lens = torch.tensor([45, 20, 1])
+    ref = torch.tanh(F.conv1d(x.transpose(1, 2), w, None, padding=1).transpose(1, 2) * sc + b) + res
+    ref = ref * (torch.arange(L)[None, :, None] < lens[:, None, None])
+    outwide = torch.full((B, L, 1024), -7.0, device=dev)
+    wk = w.permute(0, 2, 1).reshape(n, -1).contiguous().to(dev)
+    dwide = wide.to(dev)
+    ops.conv_gemm(dwide[..., 512:768], wk, b.to(dev), kw=3, act=ops.ACT_TANH, scale=sc.to(dev), res=res.to(dev),
+                  out=outwide[..., 256:512], lens=lens.to(dev))
+    check(outwide[..., 256:512], ref, 2e-5, "epilogue")
+    assert float(outwide[..., :256].min()) == -7.0 and float(outwide[..., 512:].max()) == -7.0
+
+
+@pytest.mark.parametrize("B,L,lens", [(2, 24, [24, 17]), (3, 200, [200, 130, 1]), (1, 333, [333]), (2, 64, [64, 33])])
+def test_attention(dev, B, L, lens):
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(L)
+    qkv = torch.randn(B, L, 768, generator=g)
+    ln = torch.tensor(lens)
+    q, k, v = [t.view(B, L, 4, 64).permute(0, 2, 1, 3).double() for t in qkv.split(256, dim=-1)]
+    s = (q @ k.transpose(-1, -2)) / 8.0
+    s = s.masked_fill((torch.arange(L)[None, :] >= ln[:, None])[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B, L, 256)
+    lse = torch.empty(B, 4, L, device=dev)
+    out = ops.attention_fwd(qkv.to(dev), ln.to(dev), lse=lse)
+    check(out, ref.float(), 2e-5, "attention")
+    check(lse, torch.logsumexp(s, -1).float(), 2e-5, "lse")
+
+
+def test_add_layernorm(dev):
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, L = 3, 50
+    x, r = torch.randn(B, L, 256, generator=g) * 3, torch.randn(B, L, 256, generator=g)
+    ga, be = torch.randn(256, generator=g), torch.randn(256, generator=g)
+    lens = torch.tensor([50, 7, 31])
+    valid = (torch.arange(L)[None, :] < lens[:, None])
+    ref = F.layer_norm(x + r, (256,), ga, be) * valid[..., None]
+    y = ops.add_layernorm(x.to(dev), ga.to(dev), be.to(dev), res=r.to(dev), lens=lens.to(dev))
+    check(y, ref, 1e-5, "layernorm")
+    w, b0 = torch.randn(1, 256, generator=g), torch.randn(1, generator=g)
+    ref2 = (F.linear(F.layer_norm(x, (256,), ga, be), w, b0).squeeze(-1)) * valid
+    d = ops.add_layernorm(x.to(dev), ga.to(dev), be.to(dev), lens=lens.to(dev), dot_w=w.to(dev), dot_b=b0.to(dev))
+    check(d, ref2, 5e-5, "layernorm-dot")
+
+
+@pytest.mark.parametrize("C", [256, 320])
+def test_groupnorm_relu(dev, C):
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(3, 77, C, generator=g) * 2 + 0.5
+    ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.relu(F.group_norm(x.transpose(1, 2), C // 16, ga, be)).transpose(1, 2)
+    wide = torch.zeros(3, 77, 1152, device=dev)
+    ops.groupnorm_relu(x.to(dev), ga.to(dev), be.to(dev), out=wide[..., 256:256 + C])
+    check(wide[..., 256:256 + C], ref, 1e-5, "groupnorm")
+
+
+def test_batchnorm_train(dev):
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(3, 41, 512, generator=g) * 1.5 + 0.3
+    bn = torch.nn.BatchNorm1d(512)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(512, generator=g)); bn.bias.copy_(torch.randn(512, generator=g))
+    ref = torch.tanh(bn(x.transpose(1, 2))).transpose(1, 2)
+    rm, rv = torch.zeros(512, device=dev), torch.ones(512, device=dev)
+    y, mean, rstd = ops.batchnorm_train(x.to(dev), bn.weight.data.to(dev), bn.bias.data.to(dev), rm, rv, ops.ACT_TANH)
+    check(y, ref, 2e-5, "bn train")
+    check(rm, bn.running_mean, 1e-6, "running mean")
+    check(rv, bn.running_var, 1e-6, "running var")
+
+
+def test_embed_and_positions(dev, O):
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(2)
+    text = torch.randint(0, 152, (3, 40), generator=g)
+    emb = torch.randn(152, 256, generator=g)
+    pe = O.sinusoid_table(1001, 256)
+    check(ops.embed_pos(text.to(dev), emb.to(dev), pe.to(dev)), emb[text] + pe[:40], 0, "embed_pos")
+    x = torch.randn(2, 33, 256, generator=g)
+    check(ops.add_pos(x.to(dev), pe.to(dev)), x + pe[:33], 0, "add_pos")
+    check(ops.sinusoid_table(2100, 256, dev), O.sinusoid_table(2100, 256), 1e-6, "sinusoid table")
+
+
+def test_onehot_conv5(dev, O, golden):
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, L, C = 3, 50, 320
+    v = torch.rand(B, L, generator=g) * (torch.rand(B, L, generator=g) > 0.3)
+    v[0, :5] = torch.tensor([0.0, 1.0, -0.5, 1 / 510.0, 3 / 510.0])
+    w = torch.randn(C, 257, 5, generator=g) / 10
+    b = torch.randn(C, generator=g)
+    idx = O.quantize_index(v)
+    ref = F.conv1d(F.one_hot(idx, 257).float().transpose(1, 2), w, b, padding=2).transpose(1, 2)
+    y = torch.empty(B, L, C, device=dev)
+    idx_out = torch.empty(B, L, dtype=torch.int32, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.onehot_conv5(v.to(dev), w.permute(2, 1, 0).contiguous().to(dev), b.to(dev), y, err_flag=err, idx_out=idx_out)
+    assert torch.equal(idx_out.cpu().long(), idx)
+    assert int(err.item()) == 0
+    check(y, ref, 1e-5, "onehot conv")
+    q = golden("quantize")
+    qi = torch.empty(1, q["x"].shape[1], dtype=torch.int32, device=dev)
+    ops.onehot_conv5(T(q["x"]).to(dev), w.permute(2, 1, 0).contiguous().to(dev), b.to(dev),
+                     torch.empty(1, q["x"].shape[1], C, device=dev), idx_out=qi)
+    assert np.array_equal(qi.cpu().numpy().astype(np.int64), q["idx"])
+    ops.onehot_conv5(torch.full((1, 8), 1.5, device=dev), w.permute(2, 1, 0).contiguous().to(dev), b.to(dev),
+                     torch.empty(1, 8, C, device=dev), err_flag=err)
+    assert int(err.item()) == 1
+
+
+def test_mel_calibrate(dev, O, golden):
+    from styler_amd import ops
+    g = golden("mel_calibrator")
+    y = ops.mel_calibrate(T(g["x"]).to(dev), T(g["mel_len"]).to(dev), T(g["src_len"]).to(dev), int(g["src_len"].max()))
+    check(y, g["y"], 1e-6, "mel_calibrator golden")
+    gen = torch.Generator().manual_seed(6)
+    B, Tm, C = 6, 120, 1152
+    ml = torch.tensor([120, 7, 60, 33, 1, 119])
+    sl = torch.tensor([13, 40, 60, 32, 5, 120 // 3])
+    x = torch.randn(B, Tm, C, generator=gen) * (torch.arange(Tm)[None, :, None] < ml[:, None, None])
+    y = ops.mel_calibrate(x.to(dev), ml.to(dev), sl.to(dev), 60)
+    ref = torch.zeros(B, 60, C)
+    r = O.mel_calibrate(x, ml, sl)
+    ref[:, :r.shape[1]] = r
+    check(y, ref, 1e-5, "mel_calibrator random")
+
+
+def test_lstm(dev, O, golden, ref_state_dict, model):
+    g = golden("bilstm")
+    y = model.style_modeling.style_encoder.audio_encoder._lstm(1, T(g["x"]).to(dev))
+    check(y, g["y"], 2e-5, "bilstm golden")
+    x = torch.randn(5, 61, 256, generator=torch.Generator().manual_seed(1))
+    ref = O.bilstm2(ref_state_dict, "style_modeling.style_encoder.audio_encoder.lstm_1", x)
+    check(model.style_modeling.style_encoder.audio_encoder._lstm(0, x.to(dev)), ref, 5e-5, "bilstm H=80")
+
+
+def test_length_regulator(dev, O, golden):
+    from styler_amd.modules import LengthRegulator
+    g = golden("length_regulator")
+    lr = LengthRegulator()
+    x = T(g["x"])
+    xpad = torch.zeros(2, 6, 8)
+    xpad[:] = x
+    for d, ml, ko, kl in ((g["d_int"], None, "o1", "l1"), (g["d_int"], 14, "o2", "l2"),
+                          (g["d_int"], 9, "o3", "l3"), (g["d_flt"], None, "o4", "l4")):
+        out, mel_len = lr(xpad.to(dev), T(d).to(dev), ml)
+        check(out, g[ko], 0, "LR golden")
+        assert mel_len.dtype == torch.int64 and np.array_equal(mel_len.cpu().numpy(), g[kl])
+
+
+def test_length_regulator_large_index_exact(dev, O):
+    """BASELINE config-4 shape: B=128, S=300, T=2000; indices and mel_len bit-exact vs the oracle,
+    plus the size-independent property sum_t [idx==i] == d[i]."""
+    from styler_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    B, S, C = 128, 300, 1280
+    d = torch.randint(5, 9, (B, S), generator=gen)
+    for b in range(B):
+        d[b, -1] += 2000 - int(d[b].sum())
+    d[3, 10:20] = 0
+    d[3, -1] += 2000 - int(d[3].sum())
+    x = torch.randn(B, S, C, generator=gen).to(dev)
+    csum, mel_len, _ = ops.duration_scan(B, S, dev, dur=d.to(dev))
+    fidx = torch.empty(B, 2000, dtype=torch.int32, device=dev)
+    out = ops.length_regulate(x, csum, 2000, frame_idx=fidx)
+    ridx, rlen = O.frame_to_phoneme(d, 2000)
+    assert torch.equal(mel_len.cpu(), rlen) and torch.equal(fidx.cpu().long(), ridx)
+    counts = torch.zeros(B, S, dtype=torch.int64).scatter_add_(1, ridx.clamp_min(0), (ridx >= 0).long())
+    assert torch.equal(counts, d)
+    ref = torch.gather(x.cpu(), 1, ridx.clamp_min(0)[..., None].expand(-1, -1, C))
+    check(out, ref, 0, "LR big")
+
+
+def test_duration_rounding(dev, golden):
+    from styler_amd import ops
+    g = golden("duration_round")
+    ld = T(g["log_d"]).to(dev).contiguous()
+    for c in (1.0, 0.7, 1.3):
+        csum, mel_len, dur = ops.duration_scan(1, ld.shape[1], dev, log_d=ld, d_control=c, want_dur=True)
+        check(dur, g[f"c{c}"], 0, "rounded durations")
+        assert torch.equal(csum.cpu().long(), torch.cumsum(T(g[f"c{c}"]).double().trunc().long(), 1))
+
+
+def test_bucket_embed_add(dev, golden):
+    from styler_amd import ops
+    g = golden("bucketize")
+    gen = torch.Generator().manual_seed(12)
+    pb, eb = T(g["pitch_bins"]), T(g["energy_bins"])
+    v = T(g["v"])
+    n = v.numel()
+    text, spk, noise = (torch.randn(1, n, 256, generator=gen) for _ in range(3))
+    pe, ee = torch.randn(256, 256, generator=gen), torch.randn(256, 256, generator=gen)
+    pid = torch.empty(1, n, dtype=torch.int32, device=dev)
+    eid = torch.empty(1, n, dtype=torch.int32, device=dev)
+    out, out2 = ops.bucket_embed_add(text.to(dev), spk.to(dev), v[None].to(dev).contiguous(), 1.0,
+                                     v[None].to(dev).contiguous(), 1.0, pb.to(dev), eb.to(dev), pe.to(dev),
+                                     ee.to(dev), noise=noise.to(dev), p_ids=pid, e_ids=eid)
+    assert np.array_equal(pid.cpu().numpy()[0], g["p_idx"]) and np.array_equal(eid.cpu().numpy()[0], g["e_idx"])
+    ref = text + pe[T(g["p_idx"])][None] + spk + ee[T(g["e_idx"])][None]
+    check(out, ref, 1e-6, "bucket embed add")
+    check(out2, ref + noise, 1e-6, "noisy sum")
+    big = (torch.rand(4, 500, generator=gen) * 900).contiguous()
+    ops.bucket_embed_add(torch.zeros(4, 500, 256, device=dev), torch.zeros(4, 500, 256, device=dev), big.to(dev), 0.9,
+                         big.to(dev), 1.1, pb.to(dev), eb.to(dev), pe.to(dev), ee.to(dev),
+                         p_ids=(p2 := torch.empty(4, 500, dtype=torch.int32, device=dev)),
+                         e_ids=(e2 := torch.empty(4, 500, dtype=torch.int32, device=dev)))
+    assert torch.equal(p2.cpu().long(), torch.bucketize(big * 0.9, pb))
+    assert torch.equal(e2.cpu().long(), torch.bucketize(big * 1.1, eb))
+
+
+def test_masks_and_losses(dev, O):
+    from styler_amd import ops
+    from styler_amd.loss import STYLERLoss
+    lens = torch.tensor([5, 0, 9, 3])
+    assert torch.equal(ops.length_mask(lens.to(dev), 9).cpu(), O.length_mask(lens, 9))
+    gen = torch.Generator().manual_seed(13)
+    a, b = torch.randn(4, 9, 80, generator=gen), torch.randn(4, 9, 80, generator=gen)
+    valid = ~O.length_mask(lens, 9)
+    acc = torch.zeros(2, dtype=torch.float64, device=dev)
+    ops.masked_err_sum(a.to(dev), b.to(dev), acc, 0, lens.to(dev))
+    ref = O._masked_mean((a - b) ** 2, valid)
+    assert abs(float(acc[0] / acc[1]) - float(ref)) < 1e-6
+
+
+# ----------------------------------------------------------------------------- modules vs golden
+def test_fft_block_golden(dev, model, golden):
+    g = golden("fft_block")
+    x, lens = T(g["x"]).to(dev), T(g["lens"]).to(dev)
+    blk = model.decoder.layer_stack[0]
+    # attn_out / ffn_out fixtures are un-masked; compare valid rows only (the kernels fuse masked_fill)
+    valid = (torch.arange(x.shape[1])[None, :] < T(g["lens"])[:, None])[..., None]
+    check(blk.slf_attn(x, lens).cpu() * valid, T(g["attn_out"]) * valid, 5e-5, "slf_attn")
+    check(blk.pos_ffn(x, lens).cpu() * valid, T(g["ffn_out"]) * valid, 5e-5, "pos_ffn")
+    check(blk(x, lens), g["y"], 1e-4, "fft block")
+
+
+def test_encoder_decoder_golden(dev, model, golden):
+    g = golden("enc_dec")
+    lens = T(g["lens"]).to(dev)
+    check(model.style_modeling.style_encoder.text_encoder(T(g["text"]).to(dev), lens), g["enc"], 1e-4, "encoder")
+    check(model.decoder(T(g["x"]).to(dev), lens), g["dec"], 2e-4, "decoder")
+
+
+def test_decoder_long_golden(dev, model, golden):
+    from closed_form import hash_uniform
+    g = golden("decoder_long")
+    L = int(g["lens"][0])
+    x = torch.from_numpy(0.1 * hash_uniform(99, L * 256).reshape(1, L, 256)).float().to(dev)
+    check(model.decoder(x, T(g["lens"]).to(dev))[:, ::50], g["y"], 2e-4, "decoder L>1000")
+    model.train()
+    try:
+        with pytest.raises(RuntimeError):
+            model.decoder(x, T(g["lens"]).to(dev))
+    finally:
+        model.eval()
+
+
+def test_style_predictor_golden(dev, model, golden):
+    g = golden("style_predictor")
+    check(model.style_modeling.pitch_predictor(T(g["x"]).to(dev), T(g["lens"]).to(dev)), g["y"], 1e-4, "predictor")
+
+
+def test_audio_encoder_golden(dev, model, golden):
+    g = golden("audio_encoder")
+    se = model.style_modeling.style_encoder
+    cat = se.encoder_input_cat(T(g["mel"]).to(dev), T(g["f0_norm"]).to(dev), T(g["energy_input"]).to(dev),
+                               T(g["mel_aug"]).to(dev))
+    outs = se.audio_encoder(cat, T(g["mel_len"]).to(dev), T(g["src_len"]).to(dev), mask=None)
+    for o, k in zip(outs, "dper"):
+        check(o, g[k], 1e-4, "audio encoder " + k)
+
+
+def test_aug_classifier_golden(dev, model, golden):
+    g = golden("aug_classifier")
+    check(model.style_modeling.augmentation_classifier_d(T(g["x"]).to(dev)), g["y"], 2e-5, "aug classifier")
+
+
+def test_postnet_golden(dev, model, golden, ref_state_dict):
+    g = golden("postnet_eval")
+    check(model.postnet(T(g["x"]).to(dev)), g["y"], 1e-4, "postnet eval")
+    g = golden("postnet_train")
+    model.postnet.train()
+    try:
+        y = model.postnet(T(g["x"]).to(dev))
+        check(y, g["y"], 2e-4, "postnet train-mode BN")
+        check(model.postnet.convolutions[0][1].running_mean, g["running_mean0"], 1e-5, "running mean")
+        check(model.postnet.convolutions[0][1].running_var, g["running_var0"], 1e-5, "running var")
+    finally:
+        model.load_state_dict(ref_state_dict)
+        model.eval()
+
+
+# ----------------------------------------------------------------------------- full model
+def _to(b, dev):
+    return {k: v.to(dev) for k, v in b.items()}
+
+
+def _golden_batch(g):
+    return {k[3:]: T(g[k]) for k in g.files if k.startswith("in_")}
+
+
+def _forward(model, b, teacher=True, **kw):
+    S, Tm = b["text"].shape[1], b["mel_target"].shape[1]
+    if teacher:
+        return model(b["text"], b["mel_target"], b["mel_aug"], b["f0_norm"], b["energy_input"], b["src_len"],
+                     b["mel_len"], b["D"], b["f0"], b["energy"], S, Tm, speaker_embed=b["speaker_embed"], **kw)
+    return model(b["text"], b["mel_target"], b["mel_target"], b["f0_norm"], b["energy_input"], b["src_len"],
+                 b["mel_len"], None, None, None, S, None, speaker_embed=b["speaker_embed"], **kw)
+
+
+def test_full_teacher_forced_golden(dev, model, golden):
+    g = golden("full_teacher")
+    out = _forward(model, _to(_golden_batch(g), dev))
+    (mel, mel_n), (post, post_n), log_d, p_pred, e_pred, src_mask, mel_mask, mel_len, aug = out
+    for a, k in ((mel, "mel"), (mel_n, "mel_n"), (post, "post"), (post_n, "post_n"), (log_d, "log_d"),
+                 (p_pred, "p_pred"), (e_pred, "e_pred"), (aug[0], "aug_d"), (aug[1], "aug_p"), (aug[2], "aug_e")):
+        check(a, g[k], 1e-3, k)
+    assert np.array_equal(src_mask.cpu().numpy(), g["src_mask"]) and np.array_equal(mel_mask.cpu().numpy(), g["mel_mask"])
+    assert mel_len.dtype == torch.int64 and np.array_equal(mel_len.cpu().numpy(), g["mel_len"])
+    sm = model.style_modeling
+    check(sm.noise_encoding, g["cached_noise"], 1e-4, "cached noise_encoding")
+    check(sm.pitch_encoding, g["cached_pitch"], 1e-4, "cached pitch_encoding")
+    check(sm.text_encoding_neck, g["cached_text_neck"], 1e-4, "cached text neck")
+    check(sm.duration_encoding, g["cached_duration"], 1e-4, "cached duration encoding")
+
+
+def test_full_free_running_golden(dev, model, golden):
+    g = golden("full_free")
+    b = _to(_golden_batch(golden("full_teacher")), dev)
+    out = _forward(model, b, teacher=False, d_control=1.2, p_control=0.9, e_control=1.1)
+    (mel, mel_n), (post, post_n), log_d, p_pred, e_pred, _, mel_mask, mel_len, _ = out
+    assert np.array_equal(mel_len.cpu().numpy(), g["mel_len"]), "free-running mel_len must be bit-exact"
+    assert np.array_equal(mel_mask.cpu().numpy(), g["mel_mask"])
+    for a, k in ((mel, "mel"), (mel_n, "mel_n"), (post, "post"), (post_n, "post_n"), (log_d, "log_d"),
+                 (p_pred, "p_pred"), (e_pred, "e_pred")):
+        check(a, g[k], 1e-3, k)
+
+
+@pytest.mark.parametrize("B,s_lo,s_hi", [(4, 20, 60), (16, 20, 60)])
+def test_full_vs_oracle_vctk_shape(dev, model, O, ref_state_dict, B, s_lo, s_hi):
+    """VCTK-shape batch vs the oracle, fp32 parity mode, 1e-3 abs on mel."""
+    from closed_form import make_batch
+    b = make_batch(B, s_lo, s_hi, 2, 13, seed=100 + B)
+    S, Tm = b["text"].shape[1], b["mel_target"].shape[1]
+    with torch.no_grad():
+        ref = O.styler_forward(ref_state_dict, b["text"], b["mel_target"], b["mel_aug"], b["f0_norm"],
+                               b["energy_input"], b["src_len"], b["mel_len"], b["D"], b["f0"], b["energy"], S, Tm,
+                               speaker_embed=b["speaker_embed"])
+    out = _forward(model, _to(b, dev))
+    names = ["mel", "mel_n", "post", "post_n", "log_d", "p_pred", "e_pred"]
+    got = [out[0][0], out[0][1], out[1][0], out[1][1], out[2], out[3], out[4]]
+    exp = [ref[0][0], ref[0][1], ref[1][0], ref[1][1], ref[2], ref[3], ref[4]]
+    for n, a, e in zip(names, got, exp):
+        check(a, e, 1e-3, n)
+    for a, e in zip(out[8], ref[8]):
+        check(a, e, 1e-4, "aug posterior")
+
+
+def test_clean_only_and_bf16_mode(dev, model, O, ref_state_dict):
+    from closed_form import make_batch
+    from styler_amd import rt
+    b = make_batch(4, 20, 60, 2, 13, seed=77)
+    S, Tm = b["text"].shape[1], b["mel_target"].shape[1]
+    with torch.no_grad():
+        ref = O.styler_forward(ref_state_dict, b["text"], b["mel_target"], b["mel_aug"], b["f0_norm"],
+                               b["energy_input"], b["src_len"], b["mel_len"], b["D"], b["f0"], b["energy"], S, Tm,
+                               speaker_embed=b["speaker_embed"], noisy_branch=False)
+    model.clean_only = True
+    rt.set_precision("bf16")
+    try:
+        out = _forward(model, _to(b, dev))
+    finally:
+        rt.set_precision("fp32")
+        model.clean_only = False
+    assert out[0][1] is out[0][0]
+    # bf16 operands (fp32 accumulate, fp32 activations): throughput mode, looser tolerance stated here
+    check(out[0][0], ref[0][0], 0.15, "bf16 mel")
+    check(out[1][0], ref[1][0], 0.15, "bf16 postnet mel")
+    rel = float((out[1][0].cpu() - ref[1][0]).norm() / ref[1][0].norm())
+    assert rel < 2e-2, f"bf16 relative L2 error {rel}"
