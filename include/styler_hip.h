@@ -55,6 +55,10 @@ int styler_conv_gemm(const float* x, int64_t ldx, const void* w, const float* sc
                      int64_t ldy, int B, int L, int cin, int n, int kw, int act, int prec,
                      const int64_t* len, void* stream);
 
+/* Which tile engine styler_conv_gemm dispatches for a shape: bit0 = 128x128 block tile (else
+ * 64x64), bit1 = bf16 MFMA (else fp32 MFMA).  Used by bench.py to attribute launches. */
+int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, int prec);
+
 /* fp32 -> bf16 (round-to-nearest-even) weight shadow for STYLER_PREC_BF16 */
 int styler_cast_bf16(const float* src, uint16_t* dst, int64_t count, void* stream);
 

@@ -16,6 +16,7 @@ F = ctypes.c_float
 _SIGS = {
     "styler_abi_version": [],
     "styler_conv_gemm": [P, I64, P, P, P, P, I64, P, I64, I, I, I, I, I, I, I, P, P],
+    "styler_conv_gemm_variant": [I, I, I, I, I, I],
     "styler_cast_bf16": [P, P, I64, P],
     "styler_repack_conv_weight": [P, P, I, I, I, I, P],
     "styler_attention_fwd": [P, P, P, I, I, P, P],

@@ -205,6 +205,16 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
   return launch_status();
 }
 
+// Tile choice: the 128x128 tile needs >= ~1 block per CU to pay; otherwise 64x64 (4x the blocks).
+// Returns bit0 = 128x128 tile (else 64x64), bit1 = bf16 MFMA (else fp32 MFMA).
+extern "C" int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, int prec) {
+  (void)cin; (void)kw;
+  const int64_t M = (int64_t)B * L;
+  const int64_t big_blocks = ((M + 127) / 128) * ((n + 127) / 128);
+  const int big = (big_blocks >= 192 && n >= 96) ? 1 : 0;
+  return big | (prec == STYLER_PREC_BF16 ? 2 : 0);
+}
+
 extern "C" int styler_conv_gemm(const float* x, int64_t ldx, const void* w, const float* scale,
                                 const float* shift, const float* res, int64_t ldres, float* y,
                                 int64_t ldy, int B, int L, int cin, int n, int kw, int act, int prec,
@@ -215,9 +225,7 @@ extern "C" int styler_conv_gemm(const float* x, int64_t ldx, const void* w, cons
   GemmArgs a{x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, act, len};
   hipStream_t st = (hipStream_t)stream;
   const int64_t M = (int64_t)B * L;
-  // Tile choice: the 128x128 tile needs >= ~1 block per CU to pay; otherwise 64x64 (4x the blocks).
-  const int64_t big_blocks = ((M + 127) / 128) * ((n + 127) / 128);
-  const bool big = big_blocks >= 192 && n >= 96;
+  const bool big = styler_conv_gemm_variant(B, L, cin, n, kw, prec) & 1;
   if (prec == STYLER_PREC_BF16) return big ? launch_gemm<2, 2, true>(a, st) : launch_gemm<1, 1, true>(a, st);
   return big ? launch_gemm<2, 2, false>(a, st) : launch_gemm<1, 1, false>(a, st);
 }

@@ -43,6 +43,26 @@ def _f32(t):
     return t
 
 
+class GemmProfiler:
+    """Optional HIP-event bracket around every styler_conv_gemm launch (bench.py's live roofline
+    measurement).  Events are recorded on the launch stream; elapsed times are read after a sync."""
+
+    def __init__(self):
+        self.records = []          # (variant, flops, start_event, end_event)
+
+    def summary(self):
+        out = {}
+        for var, flops, e0, e1 in self.records:
+            d = out.setdefault(var, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+gemm_profiler = None
+
+
 def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, scale=None, res=None,
               out=None, lens=None):
     """y = act(scale * conv1d_same(x, w) + bias) (+ res); x [B, L, cin] -> y [B, L, n].
@@ -54,9 +74,17 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
         raise StylerHipError("bf16 GEMM needs a bf16 weight shadow and cin % 8 == 0")
     if out is None:
         out = torch.empty(B, L, n, device=x.device, dtype=torch.float32)
+    prof = gemm_profiler
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _chk(lib.styler_conv_gemm(x.data_ptr(), _ld(x), w.data_ptr(), _ptr(scale), _ptr(bias), _ptr(res),
                               _ld(res) if res is not None else 0, out.data_ptr(), _ld(out), B, L, cin, n,
                               kw, act, prec, _ptr(lens), _stream()), "styler_conv_gemm")
+    if prof is not None:
+        e1.record()
+        prof.records.append((lib.styler_conv_gemm_variant(B, L, cin, n, kw, prec), 2.0 * B * L * n * kw * cin,
+                             e0, e1))
     return out
 
 
