@@ -2,20 +2,29 @@
 //
 //   y[m, n] = act(scale[n] * sum_{j<kw, c<cin} x[row(m) + j - kw/2, c] * w[n, j*cin + c] + shift[n]) (+ res)
 //
-// m = b*L + t indexes the padded rectangle [B, L]; rows shifted outside [0, L) of their own
-// item read as zero ('same' zero padding), so no im2col buffer is ever built.  The K loop
-// walks (tap j, channel chunk); A tiles are gathered straight from the channels-last
-// activation with a per-row validity predicate.
+// m = b*L + t indexes the padded rectangle [B, L]; rows shifted outside [0, L) of their own item
+// contribute zero ('same' zero padding).  No im2col buffer exists, not even in LDS: for each channel
+// chunk the block stages ONE haloed activation tile [(BM + kw - 1) rows x BK channels] and walks the kw
+// taps over it by shifting the LDS row index, so an activation element is fetched from L2 once per
+// chunk instead of kw times (and converted to bf16 once).  Only the weight tile [BN x BK] streams per
+// (chunk, tap) step; it is double-buffered in LDS with its global loads issued one step ahead, so a
+// step costs one barrier.
 //
-// Tile engine: 256 threads = 4 waves as 2x2, each wave owns TM x TN MFMA tiles of 32x32,
-// so the block tile is (64*TM) x (64*TN).  Two arithmetic modes share the skeleton:
+// Tile engine: 256 threads = 4 waves as 2x2, each wave owns TM x TN MFMA tiles of 32x32, block tile
+// (64*TM) x (64*TN).  Two arithmetic modes share the skeleton:
 //   * F32 : v_mfma_f32_32x32x2_f32, BK = 32 floats, exact fp32 (== an fmaf chain).
-//   * BF16: v_mfma_f32_32x32x16_bf16, BK = 64; activations are converted fp32->bf16 (RNE)
+//   * BF16: v_mfma_f32_32x32x16_bf16, BK = 64; activations are converted fp32->bf16 (v_cvt_pk_bf16_f32)
 //           while being staged into LDS, weights come from a bf16 shadow copy.
-// K is permuted inside a chunk so that each lane's fragment is CONTIGUOUS in LDS (the k <-> lane
-// map only has to agree between A and B): lane (i = l&31, h = l>>5) reads 16 floats (F32) or
-// 8 bf16 per MFMA step with ds_read_b128.  LDS rows are padded to 36 dwords: for
-// ds_read_b128 that makes 16 consecutive rows hit 16 distinct 16-byte slots (conflict-free).
+// K is permuted inside a chunk so that each lane's fragment is CONTIGUOUS in LDS (the k <-> lane map
+// only has to agree between A and B): lane (i = l&31, h = l>>5) reads 16 floats (F32) or 8 bf16 per
+// MFMA step with ds_read_b128.  LDS rows are padded to 36 dwords: 16 consecutive rows then hit 16
+// distinct 16-byte slots of the 64-bank row (conflict-free ds_read_b128), for any tap shift.
+//
+// Block -> tile map is XCD-aware: workgroup b runs on XCD b % 8 (observed dispatch rule, speed only), so
+// each XCD is handed a CONTIGUOUS range of tiles with the n index fastest: the n-tiles that share an
+// activation tile run on the same L2.
+#include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 struct GemmArgs {
@@ -26,91 +35,150 @@ struct GemmArgs {
   float* y; int64_t ldy;
   int B, L, cin, n, kw, act;
   const int64_t* len;
+  int mt, nt;                                      // tile counts
 };
 
-template <int TM, int TN, bool BF16>
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+template <int TM, int TN, bool BF16, bool KW1>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int BK = BF16 ? 64 : 32;
-  constexpr int LDS_LD = 36;                       // dwords per LDS row (32 data + 4 pad)
-  constexpr int A_V = BK / 4;                      // float4 per A row (global)
+  constexpr int LD = 36;                           // dwords per LDS row (32 data + 4 pad)
+  constexpr int A_ROWS = BM + (KW1 ? 0 : 8);       // halo for kw <= 9
+  constexpr int A_V = BK / 4;                      // float4 per A row (global, fp32)
   constexpr int A_RPP = 256 / A_V;                 // rows per pass
-  constexpr int A_P = BM / A_RPP;                  // passes
-  constexpr int B_V = BF16 ? 8 : 8;                // 16-byte vectors per B row
+  constexpr int A_P = (A_ROWS + A_RPP - 1) / A_RPP;
+  constexpr int B_V = 8;                           // 16-byte vectors per B row
   constexpr int B_RPP = 256 / B_V;
   constexpr int B_P = BN / B_RPP;
+  constexpr int B_ES = BF16 ? 2 : 4;               // bytes per weight element
+  constexpr int CLD = 32 * TN + 4;                 // epilogue staging row stride (floats)
+  constexpr int SMEM_MAIN = 2 * A_ROWS * LD + 2 * BN * LD + LD;   // + one row of zeros
+  constexpr int SMEM_EPI = 4 * 32 * TM * CLD;
+  constexpr int SMEM = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
 
-  __shared__ __attribute__((aligned(16))) uint32_t sA[BM * LDS_LD];
-  __shared__ __attribute__((aligned(16))) uint32_t sB[BN * LDS_LD];
+  __shared__ __attribute__((aligned(16))) uint32_t smem[SMEM];
+  uint32_t* const sA = smem;                       // 2 x [A_ROWS][LD]
+  uint32_t* const sB = smem + 2 * A_ROWS * LD;     // 2 x [BN][LD]
+  uint32_t* const sZ = sB + 2 * BN * LD;           // [LD] zeros
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
 
-  const int64_t M = (int64_t)a.B * a.L;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
-  const int pad = a.kw / 2;
-  const int ktot = a.kw * a.cin;
-  const int cpt = (a.cin + BK - 1) / BK;           // chunks per tap
-  const int nq = a.kw * cpt;
-
-  // ---- per-thread load coordinates ----
-  const int a_col = (tid % A_V) * 4;
-  int a_t[A_P]; int64_t a_m[A_P];
-#pragma unroll
-  for (int p = 0; p < A_P; ++p) {
-    int64_t m = m0 + tid / A_V + p * A_RPP;
-    a_m[p] = m;
-    a_t[p] = (m < M) ? (int)(m % a.L) : -1000000;  // invalid rows never pass the range test
+  // ---- XCD-aware tile assignment (bijective for any tile count) ----
+  int tile;
+  {
+    const int total = a.mt * a.nt;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, k = bid >> 3;
+    const int q = total >> 3, r = total & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
-  const int b_col = (tid % B_V) * (BF16 ? 8 : 4);  // element offset inside the chunk
-  int b_n[B_P];
+  const int64_t M = (int64_t)a.B * a.L;
+  const int64_t m0 = (int64_t)(tile / a.nt) * BM;
+  const int n0 = (tile % a.nt) * BN;
+  const int kw = KW1 ? 1 : a.kw;
+  const int pad = kw / 2;
+  const int ktot = kw * a.cin;
+  const int ncc = (a.cin + BK - 1) / BK;           // channel chunks
+  const int nsteps = ncc * kw;
+
+  // ---- per-lane load coordinates: every global address is (wave-uniform base) + (32-bit lane offset) ----
+  const int a_col = (tid % A_V) * 4;
+  const int a_r0 = tid / A_V;
+  const uint32_t a_voff = (uint32_t)((a_r0 * a.ldx + a_col) * 4);           // bytes from the tile's first halo row
+  uint32_t a_ok = 0;                                                         // bit p: halo row exists
+  {
+    const int a_rows = BM + kw - 1;
 #pragma unroll
-  for (int p = 0; p < B_P; ++p) b_n[p] = n0 + tid / B_V + p * B_RPP;
+    for (int p = 0; p < A_P; ++p) {
+      const int r = a_r0 + p * A_RPP;
+      const int64_t m = m0 - pad + r;
+      if (r < a_rows && m >= 0 && m < M) a_ok |= 1u << p;
+    }
+  }
+  const char* const a_base = reinterpret_cast<const char*>(a.x) + (m0 - pad) * a.ldx * 4;   // uniform
+  const int64_t a_pstride = (int64_t)A_RPP * a.ldx * 4;                                     // uniform
+
+  const int b_col = (tid % B_V) * (BF16 ? 8 : 4);  // element offset inside the chunk
+  const int b_r0 = tid / B_V;
+  const uint32_t b_voff = (uint32_t)(((int64_t)(n0 + b_r0) * ktot + b_col) * B_ES);
+  uint32_t b_ok = 0;
+#pragma unroll
+  for (int p = 0; p < B_P; ++p)
+    if (n0 + b_r0 + p * B_RPP < a.n) b_ok |= 1u << p;
+  const int64_t b_pstride = (int64_t)B_RPP * ktot * B_ES;                                   // uniform
+
+  // LDS byte offsets (per lane), everything else in the fragment addresses is uniform or immediate
+  const uint32_t fa_off = ((wm * TM * 32 + li) * LD + lh * (BF16 ? 4 : 16));
+  const uint32_t fb_off = ((wn * TN * 32 + li) * LD + lh * (BF16 ? 4 : 16));
+  const uint32_t sa_off = a_r0 * LD + (BF16 ? a_col / 2 : a_col);
+  const uint32_t sb_off = b_r0 * LD + (tid % B_V) * 4;
+
+  // per-lane tap validity for the wave's output rows: bit j set <=> row t + j - pad lies in [0, L)
+  uint32_t tapmask[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int64_t m = m0 + (wm * TM + i) * 32 + li;
+    uint32_t bits = 0;
+    if (!KW1 && m < M) {
+      const int t = (int)(m % a.L);
+      for (int j = 0; j < kw; ++j) {
+        const int tt = t + j - pad;
+        if (tt >= 0 && tt < a.L) bits |= 1u << j;
+      }
+    }
+    tapmask[i] = bits;
+  }
 
   float4 ra[A_P];
   uint4 rb[B_P];
 
-  auto load_global = [&](int q) {
-    const int j = q / cpt, c0 = (q - j * cpt) * BK;
-    const int sh = j - pad;
+  auto load_a = [&](int cc) {
+    const int c0 = cc * BK;
+    const bool chunk_ok = c0 + a_col < a.cin;
+    const char* base = a_base + (int64_t)c0 * 4;
 #pragma unroll
     for (int p = 0; p < A_P; ++p) {
-      const int tt = a_t[p] + sh;
-      const bool ok = (tt >= 0) && (tt < a.L) && (c0 + a_col < a.cin);
-      ra[p] = ok ? *reinterpret_cast<const float4*>(a.x + (a_m[p] + sh) * a.ldx + c0 + a_col)
-                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = chunk_ok && ((a_ok >> p) & 1u);
+      ra[p] = ok ? *reinterpret_cast<const float4*>(base + p * a_pstride + a_voff) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  };
+  auto store_a = [&](int buf) {
+    uint32_t* dst = sA + buf * A_ROWS * LD + sa_off;
 #pragma unroll
-    for (int p = 0; p < B_P; ++p) {
-      const bool ok = (b_n[p] < a.n) && (c0 + b_col < a.cin);
-      if (BF16) {
-        const uint16_t* wp = reinterpret_cast<const uint16_t*>(a.w) + (int64_t)b_n[p] * ktot + j * a.cin + c0 + b_col;
-        rb[p] = ok ? *reinterpret_cast<const uint4*>(wp) : make_uint4(0, 0, 0, 0);
-      } else {
-        const float* wp = reinterpret_cast<const float*>(a.w) + (int64_t)b_n[p] * ktot + j * a.cin + c0 + b_col;
-        rb[p] = ok ? *reinterpret_cast<const uint4*>(wp) : make_uint4(0, 0, 0, 0);
+    for (int p = 0; p < A_P; ++p) {
+      if (a_r0 + p * A_RPP < A_ROWS) {
+        if (BF16) {
+          *reinterpret_cast<uint2*>(&dst[p * A_RPP * LD]) =
+              make_uint2(cvt_pk_bf16(ra[p].x, ra[p].y), cvt_pk_bf16(ra[p].z, ra[p].w));
+        } else {
+          *reinterpret_cast<float4*>(&dst[p * A_RPP * LD]) = ra[p];
+        }
       }
     }
   };
-  auto store_lds = [&]() {
-#pragma unroll
-    for (int p = 0; p < A_P; ++p) {
-      const int r = tid / A_V + p * A_RPP;
-      if (BF16) {
-        uint2 v = make_uint2(pack_bf16x2(ra[p].x, ra[p].y), pack_bf16x2(ra[p].z, ra[p].w));
-        *reinterpret_cast<uint2*>(&sA[r * LDS_LD + a_col / 2]) = v;
-      } else {
-        *reinterpret_cast<float4*>(&sA[r * LDS_LD + a_col]) = ra[p];
-      }
-    }
+  auto load_b = [&](int cc, int j) {
+    const int c0 = cc * BK;
+    const bool chunk_ok = c0 + b_col < a.cin;
+    const char* base = reinterpret_cast<const char*>(a.w) + ((int64_t)j * a.cin + c0) * B_ES;
 #pragma unroll
     for (int p = 0; p < B_P; ++p) {
-      const int r = tid / B_V + p * B_RPP;
-      *reinterpret_cast<uint4*>(&sB[r * LDS_LD + (tid % B_V) * 4]) = rb[p];
+      const bool ok = chunk_ok && ((b_ok >> p) & 1u);
+      rb[p] = ok ? *reinterpret_cast<const uint4*>(base + p * b_pstride + b_voff) : make_uint4(0, 0, 0, 0);
     }
+  };
+  auto store_b = [&](int buf) {
+    uint32_t* dst = sB + buf * BN * LD + sb_off;
+#pragma unroll
+    for (int p = 0; p < B_P; ++p) *reinterpret_cast<uint4*>(&dst[p * B_RPP * LD]) = rb[p];
   };
 
   f32x16 acc[TM][TN];
@@ -121,87 +189,127 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_global(0);
-  store_lds();
+  if (tid < LD) sZ[tid] = 0u;
+  const uint32_t* const zrow = sZ + lh * (BF16 ? 4 : 16);
+  load_a(0);
+  load_b(0, 0);
+  store_a(0);
+  store_b(0);
   __syncthreads();
 
-  for (int q = 0; q < nq; ++q) {
-    if (q + 1 < nq) load_global(q + 1);
+  int cc = 0, j = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    // next step's coordinates; its global loads are issued now and land in LDS after this step's MFMAs
+    int ccn = cc, jn = j + 1;
+    if (jn == kw) { jn = 0; ccn = cc + 1; }
+    const bool more = step + 1 < nsteps;
+    if (more) {
+      load_b(ccn, jn);
+      if (jn == 0) load_a(ccn);
+    }
 
+    const uint32_t* cA = sA + (cc & 1) * A_ROWS * LD + j * LD + fa_off;
+    const uint32_t* cB = sB + (step & 1) * BN * LD + fb_off;
+    // 'same' zero padding across item boundaries: a lane whose row t + j - pad falls outside [0, L)
+    // reads its A fragment from a row of zeros instead (one address select per tile, no data selects)
+    const uint32_t* pa[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      pa[i] = cA + i * 32 * LD;
+      if (!KW1) pa[i] = ((tapmask[i] >> j) & 1u) ? pa[i] : zrow;
+    }
     if (BF16) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         bf16x8 fa[TM], fb[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-          fa[i] = *reinterpret_cast<const bf16x8*>(&sA[((wm * TM + i) * 32 + li) * LDS_LD + s * 8 + lh * 4]);
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&pa[i][s * 8]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          fb[j] = *reinterpret_cast<const bf16x8*>(&sB[((wn * TN + j) * 32 + li) * LDS_LD + s * 8 + lh * 4]);
+        for (int jj = 0; jj < TN; ++jj) fb[jj] = *reinterpret_cast<const bf16x8*>(&cB[jj * 32 * LD + s * 8]);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          for (int jj = 0; jj < TN; ++jj)
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
       }
     } else {
       f32x4 fa[TM][4], fb[TN][4];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
-          fa[i][v] = *reinterpret_cast<const f32x4*>(&sA[((wm * TM + i) * 32 + li) * LDS_LD + lh * 16 + v * 4]);
+        for (int v = 0; v < 4; ++v) fa[i][v] = *reinterpret_cast<const f32x4*>(&pa[i][v * 4]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int jj = 0; jj < TN; ++jj)
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
-          fb[j][v] = *reinterpret_cast<const f32x4*>(&sB[((wn * TN + j) * 32 + li) * LDS_LD + lh * 16 + v * 4]);
+        for (int v = 0; v < 4; ++v) fb[jj][v] = *reinterpret_cast<const f32x4*>(&cB[jj * 32 * LD + v * 4]);
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk >> 2][kk & 3], fb[j][kk >> 2][kk & 3],
-                                                             acc[i][j], 0, 0, 0);
+          for (int jj = 0; jj < TN; ++jj)
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk >> 2][kk & 3], fb[jj][kk >> 2][kk & 3],
+                                                              acc[i][jj], 0, 0, 0);
+    }
+
+    if (more) {
+      store_b((step + 1) & 1);
+      if (jn == 0) store_a(ccn & 1);
     }
     __syncthreads();
-    if (q + 1 < nq) {
-      store_lds();
-      __syncthreads();
-    }
+    cc = ccn; j = jn;
   }
 
-  // ---- epilogue: C layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  // ---- epilogue: accumulators -> per-wave LDS tile -> coalesced float4 rows ----
+  // C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* cst = reinterpret_cast<float*>(smem) + wave * (32 * TM * CLD);
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + (wn * TN + j) * 32 + li;
-    if (col >= a.n) continue;
-    const float sc = a.scale ? a.scale[col] : 1.f;
-    const float sf = a.shift ? a.shift[col] : 0.f;
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int jj = 0; jj < TN; ++jj)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row >= M) continue;
-        float v = apply_act(acc[i][j][r] * sc + sf, a.act);
-        if (a.res) v += a.res[row * a.ldres + col];
-        if (a.len) {
-          const int64_t b = row / a.L;
-          if ((row - b * a.L) >= a.len[b]) v = 0.f;
-        }
-        a.y[row * a.ldy + col] = v;
+      for (int r = 0; r < 16; ++r)
+        cst[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CLD + jj * 32 + li] = acc[i][jj][r];
+  __syncthreads();
+
+  constexpr int LPR = 8 * TN;                      // lanes per output row (float4 each)
+  constexpr int RPP = 64 / LPR;                    // rows per pass
+  const int c4 = (lane % LPR) * 4;
+  const int col = n0 + wn * 32 * TN + c4;
+  if (col < a.n) {
+    const float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sf = a.shift ? *reinterpret_cast<const float4*>(a.shift + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int p = 0; p < 32 * TM / RPP; ++p) {
+      const int rl = p * RPP + lane / LPR;
+      const int64_t row = m0 + wm * 32 * TM + rl;
+      if (row >= M) break;
+      float4 v = *reinterpret_cast<const float4*>(&cst[rl * CLD + c4]);
+      v.x = apply_act(v.x * sc.x + sf.x, a.act); v.y = apply_act(v.y * sc.y + sf.y, a.act);
+      v.z = apply_act(v.z * sc.z + sf.z, a.act); v.w = apply_act(v.w * sc.w + sf.w, a.act);
+      if (a.res) {
+        const float4 rr = *reinterpret_cast<const float4*>(a.res + row * a.ldres + col);
+        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
       }
+      if (a.len) {
+        const int64_t b = row / a.L;
+        if ((row - b * a.L) >= a.len[b]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      *reinterpret_cast<float4*>(a.y + row * a.ldy + col) = v;
     }
   }
 }
 
 template <int TM, int TN, bool BF16>
-static int launch_gemm(const GemmArgs& a, hipStream_t st) {
+static int launch_gemm(GemmArgs a, hipStream_t st) {
   const int64_t M = (int64_t)a.B * a.L;
-  dim3 grid((unsigned)((M + 64 * TM - 1) / (64 * TM)), (unsigned)((a.n + 64 * TN - 1) / (64 * TN)));
-  hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, BF16>), grid, dim3(256), 0, st, a);
+  a.mt = (int)((M + 64 * TM - 1) / (64 * TM));
+  a.nt = (a.n + 64 * TN - 1) / (64 * TN);
+  const dim3 grid((unsigned)(a.mt * a.nt));
+  if (a.kw == 1)
+    hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, BF16, true>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, BF16, false>), grid, dim3(256), 0, st, a);
   return launch_status();
 }
 
@@ -211,7 +319,10 @@ extern "C" int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, in
   (void)cin; (void)kw;
   const int64_t M = (int64_t)B * L;
   const int64_t big_blocks = ((M + 127) / 128) * ((n + 127) / 128);
-  const int big = (big_blocks >= 192 && n >= 96) ? 1 : 0;
+  int big = (big_blocks >= 192 && n >= 96) ? 1 : 0;
+  static const int force = [] { const char* e = getenv("STYLER_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  if (force == 1) big = 0;
+  if (force == 2) big = 1;
   return big | (prec == STYLER_PREC_BF16 ? 2 : 0);
 }
 
@@ -219,10 +330,12 @@ extern "C" int styler_conv_gemm(const float* x, int64_t ldx, const void* w, cons
                                 const float* shift, const float* res, int64_t ldres, float* y,
                                 int64_t ldy, int B, int L, int cin, int n, int kw, int act, int prec,
                                 const int64_t* len, void* stream) {
-  if (!x || !w || !y || B <= 0 || L <= 0 || cin <= 0 || n <= 0 || kw <= 0 || !(kw & 1)) return STYLER_EINVAL;
+  if (!x || !w || !y || B <= 0 || L <= 0 || cin <= 0 || n <= 0 || kw <= 0 || kw > 9 || !(kw & 1)) return STYLER_EINVAL;
   if ((cin & 3) || (ldx & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return STYLER_EALIGN;
+  if ((n & 3) || (ldy & 3) || ((uintptr_t)y & 15) || (res && ((ldres & 3) || ((uintptr_t)res & 15)))) return STYLER_EALIGN;
+  if (kw > 1 && kw < 3) return STYLER_EINVAL;
   if (prec == STYLER_PREC_BF16 && (cin & 7)) return STYLER_EALIGN;
-  GemmArgs a{x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, act, len};
+  GemmArgs a{x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, act, len, 0, 0};
   hipStream_t st = (hipStream_t)stream;
   const int64_t M = (int64_t)B * L;
   const bool big = styler_conv_gemm_variant(B, L, cin, n, kw, prec) & 1;

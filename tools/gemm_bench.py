@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Micro-benchmark of styler_conv_gemm on the shapes of the C2 forward (per-shape TFLOP/s)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from styler_amd import ops
+
+SHAPES = [  # name, B, L, cin, n, kw
+    ("ffn_w1_k9", 48, 441, 256, 1024, 9), ("ffn_w2_k1", 48, 441, 1024, 256, 1), ("qkv", 48, 441, 256, 768, 1),
+    ("attn_fc", 48, 441, 256, 256, 1), ("postnet_512_k5", 48, 441, 512, 512, 5), ("postnet_in", 48, 441, 80, 512, 5),
+    ("postnet_out", 48, 441, 512, 80, 5), ("pred_k3", 48, 441, 256, 256, 3), ("aenc_320_k5", 48, 441, 320, 320, 5),
+    ("enc_w1_k9", 48, 60, 256, 1024, 9), ("mel_linear", 48, 441, 256, 80, 1), ("big_w1", 128, 2000, 256, 1024, 9),
+]
+
+def main():
+    dev = torch.device("cuda")
+    precs = [a for a in sys.argv[1:] if a in ("bf16", "fp32")] or ["bf16", "fp32"]
+    only = [a for a in sys.argv[1:] if a not in ("bf16", "fp32")]
+    for name, B, L, cin, n, kw in SHAPES:
+        if only and name not in only:
+            continue
+        x = torch.randn(B, L, cin, device=dev)
+        w = torch.randn(n, kw * cin, device=dev) / (kw * cin) ** 0.5
+        b = torch.randn(n, device=dev)
+        for prec in precs:
+            wk = ops.cast_bf16(w) if prec == "bf16" else w
+            p = ops.PREC_BF16 if prec == "bf16" else ops.PREC_F32
+            y = torch.empty(B, L, n, device=dev)
+            for _ in range(3):
+                ops.conv_gemm(x, wk, b, kw=kw, prec=p, out=y)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            iters = 20
+            e0.record()
+            for _ in range(iters):
+                ops.conv_gemm(x, wk, b, kw=kw, prec=p, out=y)
+            e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / iters
+            fl = 2.0 * B * L * n * kw * cin
+            print(f"{name:16s} {prec:5s} M={B*L:6d} N={n:5d} K={kw*cin:5d}  {us:9.1f} us  {fl/us/1e6:8.1f} TFLOP/s", flush=True)
+
+if __name__ == "__main__":
+    main()
