@@ -32,6 +32,7 @@ extern "C" {
 #define STYLER_ACT_NONE 0
 #define STYLER_ACT_RELU 1
 #define STYLER_ACT_TANH 2
+#define STYLER_ACT_LOGCLAMP 3 /* log(max(v, 1e-5)): dynamic_range_compression, audio_processing.py:80-86 */
 
 /* arithmetic of the MFMA GEMM core */
 #define STYLER_PREC_F32  0  /* v_mfma_f32_32x32x2_f32: exact fp32 (parity mode)            */
@@ -200,13 +201,18 @@ int styler_masked_err_sum(const float* a, int64_t lda, const float* b, int64_t l
                           void* stream);
 
 /* ---- STFT -> mel (audio/stft.py:51-79,141-160) ----------------------------------------
- * wav [B, N] in [-1,1] -> frames with reflect padding 512, hop 256, windowed DFT as an
- * MFMA GEMM against basis [1026,1024] (rows 0..512 Re, 513..1025 Im), magnitude,
- * mel = log(clamp(mel_basis[80,513] @ mag, 1e-5)), energy = ||mag||_2.
- * mag (optional) [B, F, 513]; mel [B, F, 80] (channels-last, the layout the model takes);
- * energy [B, F]; F = 1 + N/256. */
-int styler_stft_mel(const float* wav, int64_t ldw, const float* basis, const float* mel_basis,
-                    float* mag, float* mel, float* energy, int B, int N, int prec, void* stream);
+ * wav [B, N] in [-1,1] -> reflect padding 512, hop 256, windowed DFT, magnitude,
+ * mel = log(clamp(mel_basis @ mag, 1e-5)), energy = ||mag||_2, F = 1 + N/256 frames.
+ * The framing conv (stft.py:65-69) is the MFMA implicit GEMM over the padded signal viewed
+ * as [B, F+3, 256] with 4 taps.  basis: [1028, 1024] (rows 0..512 Re, 513..1025 Im of the
+ * windowed DFT, last 2 rows zero), fp32 or bf16 per `prec`; mel_basis: [80, 516] fp32 (cols
+ * 513..515 zero).  Outputs channels-last: mel [B, F, 80], energy [B, F], mag (optional)
+ * [B, F, 516].  workspace: styler_stft_mel_workspace_bytes(B, N) bytes.
+ * err_flag (int32[1], optional) is set to 1 if any |wav| > 1 (the asserts at stft.py:151-152). */
+int64_t styler_stft_mel_workspace_bytes(int B, int N);
+int styler_stft_mel(const float* wav, int64_t ldw, const void* basis, const float* mel_basis,
+                    float* mag, float* mel, float* energy, void* workspace, int32_t* err_flag,
+                    int B, int N, int prec, void* stream);
 
 #ifdef __cplusplus
 }

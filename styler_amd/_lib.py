@@ -38,6 +38,8 @@ _SIGS = {
     "styler_add_rowvec": [P, I64, P, I64, P, I64, I, I, I, P],
     "styler_length_mask": [P, P, I, I, P],
     "styler_masked_err_sum": [P, I64, P, I64, P, I, I, I, I, P, P],
+    "styler_stft_mel_workspace_bytes": [I, I],
+    "styler_stft_mel": [P, I64, P, P, P, P, P, P, P, I, I, I, P],
 }
 
 
@@ -50,7 +52,7 @@ def _load():
     for name, argtypes in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_int64 if name.endswith("_bytes") else ctypes.c_int
     return lib
 
 

@@ -45,5 +45,6 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == STYLER_ACT_RELU) return fmaxf(v, 0.f);
   if (act == STYLER_ACT_TANH) return tanhf(v);
+  if (act == STYLER_ACT_LOGCLAMP) return logf(fmaxf(v, 1e-5f));
   return v;
 }

@@ -33,7 +33,7 @@ struct GemmArgs {
   const float* scale; const float* shift;
   const float* res; int64_t ldres;
   float* y; int64_t ldy;
-  int B, L, cin, n, kw, act;
+  int B, L, cin, n, kw, act, pad;
   const int64_t* len;
   int mt, nt;                                      // tile counts
 };
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
   const int64_t m0 = (int64_t)(tile / a.nt) * BM;
   const int n0 = (tile % a.nt) * BN;
   const int kw = KW1 ? 1 : a.kw;
-  const int pad = kw / 2;
+  const int pad = KW1 ? 0 : a.pad;
   const int ktot = kw * a.cin;
   const int ncc = (a.cin + BK - 1) / BK;           // channel chunks
   const int nsteps = ncc * kw;
@@ -326,21 +326,30 @@ extern "C" int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, in
   return big | (prec == STYLER_PREC_BF16 ? 2 : 0);
 }
 
+// Internal entry with an explicit left padding (pad = kw/2 is the 'same' conv of the model; pad = 0 with an
+// even kw is the framing conv of the STFT, stft.hip).
+int styler_conv_gemm_impl(const float* x, int64_t ldx, const void* w, const float* scale, const float* shift,
+                          const float* res, int64_t ldres, float* y, int64_t ldy, int B, int L, int cin, int n,
+                          int kw, int pad, int act, int prec, const int64_t* len, void* stream) {
+  if (!x || !w || !y || B <= 0 || L <= 0 || cin <= 0 || n <= 0 || kw <= 0 || kw > 9 || pad < 0 || pad >= kw)
+    return STYLER_EINVAL;
+  if ((cin & 3) || (ldx & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return STYLER_EALIGN;
+  if ((n & 3) || (ldy & 3) || ((uintptr_t)y & 15) || (res && ((ldres & 3) || ((uintptr_t)res & 15)))) return STYLER_EALIGN;
+  if (prec == STYLER_PREC_BF16 && (cin & 7)) return STYLER_EALIGN;
+  GemmArgs a{x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, act, pad, len, 0, 0};
+  hipStream_t st = (hipStream_t)stream;
+  const bool big = styler_conv_gemm_variant(B, L, cin, n, kw, prec) & 1;
+  if (prec == STYLER_PREC_BF16) return big ? launch_gemm<2, 2, true>(a, st) : launch_gemm<1, 1, true>(a, st);
+  return big ? launch_gemm<2, 2, false>(a, st) : launch_gemm<1, 1, false>(a, st);
+}
+
 extern "C" int styler_conv_gemm(const float* x, int64_t ldx, const void* w, const float* scale,
                                 const float* shift, const float* res, int64_t ldres, float* y,
                                 int64_t ldy, int B, int L, int cin, int n, int kw, int act, int prec,
                                 const int64_t* len, void* stream) {
-  if (!x || !w || !y || B <= 0 || L <= 0 || cin <= 0 || n <= 0 || kw <= 0 || kw > 9 || !(kw & 1)) return STYLER_EINVAL;
-  if ((cin & 3) || (ldx & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return STYLER_EALIGN;
-  if ((n & 3) || (ldy & 3) || ((uintptr_t)y & 15) || (res && ((ldres & 3) || ((uintptr_t)res & 15)))) return STYLER_EALIGN;
-  if (kw > 1 && kw < 3) return STYLER_EINVAL;
-  if (prec == STYLER_PREC_BF16 && (cin & 7)) return STYLER_EALIGN;
-  GemmArgs a{x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, act, len, 0, 0};
-  hipStream_t st = (hipStream_t)stream;
-  const int64_t M = (int64_t)B * L;
-  const bool big = styler_conv_gemm_variant(B, L, cin, n, kw, prec) & 1;
-  if (prec == STYLER_PREC_BF16) return big ? launch_gemm<2, 2, true>(a, st) : launch_gemm<1, 1, true>(a, st);
-  return big ? launch_gemm<2, 2, false>(a, st) : launch_gemm<1, 1, false>(a, st);
+  if (!(kw & 1)) return STYLER_EINVAL;
+  return styler_conv_gemm_impl(x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, kw / 2, act, prec, len,
+                               stream);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -302,6 +302,31 @@ def test_masks_and_losses(dev, O):
     assert abs(float(acc[0] / acc[1]) - float(ref)) < 1e-6
 
 
+def test_stft_mel_golden(dev, golden, O):
+    """audio/stft.py path vs the reference-generated fixture (magnitude, log-mel, energy)."""
+    from styler_amd.audio import TacotronSTFT
+    g = golden("stft")
+    st = TacotronSTFT().to(dev)
+    check(st.mel_basis, g["mel_basis"], 1e-7, "mel filterbank")
+    check(st.stft_fn.forward_basis[[0, 1, 7, 512, 513, 514, 700, 1025], 0], g["basis_rows"], 1e-6, "DFT basis")
+    wav = T(g["wav"]).to(dev)
+    mel, energy, mag = st.mel_spectrogram_cl(wav, want_mag=True)
+    check(mag.transpose(1, 2), g["mag"], 1e-3, "stft magnitude")       # |X| up to ~1e2, fp32 DFT with K = 1024
+    check(mel.transpose(1, 2), g["mel"], 1e-3, "log-mel")
+    check(energy, g["energy"], 2e-3, "energy")
+    m2, e2 = st.mel_spectrogram(wav)
+    assert m2.shape == (2, 80, g["mel"].shape[2]) and e2.shape == energy.shape
+    with pytest.raises(AssertionError):
+        st.mel_spectrogram(torch.full((1, 4096), 1.5, device=dev))
+    # BASELINE config-5 shape: B=256 wavs of 3-4 s, vs the oracle on a strided sample of items
+    gen = torch.Generator().manual_seed(55)
+    big = (torch.rand(256, 88200, generator=gen) - 0.5)
+    melb, enb = st.mel_spectrogram_cl(big.to(dev))
+    ref_mel, ref_en = O.mel_spectrogram(big[::64])
+    check(melb[::64].transpose(1, 2), ref_mel, 1e-3, "C5 log-mel")
+    check(enb[::64], ref_en, 2e-3, "C5 energy")
+
+
 # ----------------------------------------------------------------------------- modules vs golden
 def test_fft_block_golden(dev, model, golden):
     g = golden("fft_block")
