@@ -82,12 +82,13 @@ int styler_attention_fwd(const float* qkv, float* out, float* lse, int B, int L,
  * y = LayerNorm_256(x + res) * gamma + beta, then rows t >= len[b] set to 0
  * (SubLayers.py:58-59,86-87 + Layers.py:29,32).  res, len may be NULL.  C must be 256.
  * If dot_w != NULL the kernel instead writes the scalar out[b,t] = <y, dot_w> + dot_b[0]
- * (masked) -- the StylePredictor's LayerNorm -> Linear(256,1) -> masked_fill tail,
- * modules.py:449-465 -- and y may be NULL. */
+ * (masked) -- the StylePredictor's LayerNorm -> dropout -> Linear(256,1) -> masked_fill
+ * tail, modules.py:449-465 -- and y may be NULL; drop_p > 0 applies the train-mode dropout of
+ * that tail with the counter-based stream of styler_dropout (seed drop_seed). */
 int styler_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldres,
                          const float* gamma, const float* beta, float* y, int64_t ldy,
                          const float* dot_w, const float* dot_b, float* dot_out, int B, int L,
-                         int C, const int64_t* len, void* stream);
+                         int C, const int64_t* len, float drop_p, uint64_t drop_seed, void* stream);
 
 /* y = relu(GroupNorm(x)) with groups of 16 channels and statistics over 16 ch x the whole
  * padded L (modules.py:103-113,171-175; eps 1e-5).  In place allowed (y == x). */
@@ -213,6 +214,94 @@ int64_t styler_stft_mel_workspace_bytes(int B, int N);
 int styler_stft_mel(const float* wav, int64_t ldw, const void* basis, const float* mel_basis,
                     float* mag, float* mel, float* energy, void* workspace, int32_t* err_flag,
                     int B, int N, int prec, void* stream);
+
+/* ==== backward / training entry points ==================================================
+ * Parameter gradients are ACCUMULATED (atomicAdd) into fp32 buffers in the PARAMETER layout
+ * of the reference state dict; the caller zeroes them once per step. */
+
+/* dz = mask(dy) * act'(y): backward of the fused GEMM epilogue (ReLU / tanh use the saved
+ * post-activation y); rows t >= len[b] get zero (masked_fill backward). */
+int styler_act_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, float* dz,
+                   int64_t lddz, int B, int L, int C, int act, const int64_t* len, void* stream);
+
+/* Weight gradient of Linear / one Conv1d tap (autograd of SubLayers.py:41-43,72-76 etc.):
+ * dw[nn*stride_n + c*stride_c] += sum_{b,t} dz[b,t,nn] * x[b,t+shift,c] (x = 0 outside the
+ * item).  Exact-fp32 MFMA, split over rows with atomics.  Linear: shift 0, strides (cin, 1);
+ * conv tap j of a [n, cin, kw] weight: shift j - kw/2, dw + j, strides (cin*kw, kw). */
+int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw,
+                 int64_t stride_n, int64_t stride_c, int B, int L, int n, int cin, int shift,
+                 void* stream);
+
+/* out[c] += sum over rows of dz[row, c] (bias gradient); out2 (optional) gets the same sum
+ * (nn.LSTM's b_ih and b_hh). */
+int styler_colsum(const float* dz, int64_t lddz, float* out, float* out2, int64_t rows, int C,
+                  void* stream);
+
+/* Weight of the dX convolution: dst[c, j, nn] = src[nn, c, kw-1-j] (src in parameter layout
+ * [n, cin, kw]); dx = styler_conv_gemm(dz, dst, cin := n, n := cin, kw). */
+int styler_repack_weight_bwd(const float* src, float* dst, int n, int cin, int kw, void* stream);
+
+/* Attention backward (recomputes P from lse): dqkv [B,L,768]; delta_ws: B*4*L floats. */
+int styler_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
+                         float* dqkv, float* delta_ws, int B, int L, const int64_t* len,
+                         void* stream);
+
+/* LayerNorm(256) backward from the saved INPUT x (= pre-norm sum).  dx may be NULL.  With
+ * dot_w (predictor tail) the incoming gradient is dout [B,L] and ddot_w/ddot_b accumulate. */
+int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy,
+                         const float* gamma, const float* beta, float* dx, int64_t lddx,
+                         float* dgamma, float* dbeta, const float* dot_w, const float* dout,
+                         float* ddot_w, float* ddot_b, int B, int L, int C, const int64_t* len,
+                         float drop_p, uint64_t drop_seed, void* stream);
+
+int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy,
+                              const float* gamma, const float* beta, float* dx, int64_t lddx,
+                              float* dgamma, float* dbeta, int B, int L, int C, void* stream);
+
+/* BatchNorm1d(train)+act backward; x, y, dy, dx contiguous [rows, C]; workspace 2*C doubles. */
+int styler_batchnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
+                         const float* save_mean, const float* save_rstd, float* dx, float* dgamma,
+                         float* dbeta, double* workspace, int64_t rows, int C, int act, void* stream);
+
+int styler_embed_bwd(const int64_t* text, const float* dy, int64_t lddy, float* demb, int B, int L,
+                     int C, void* stream);
+/* dw in parameter layout [C, 257, 5]; db [C]. */
+int styler_onehot_conv5_bwd(const float* v, const float* dy, int64_t lddy, float* dw, float* db,
+                            int B, int L, int C, void* stream);
+int styler_mel_calibrate_bwd(const float* dy, int64_t lddy, float* dx, int64_t lddx,
+                             const int64_t* mel_len, const int64_t* src_len, int B, int T, int S,
+                             int C, void* stream);
+int styler_lstm_bidir_bwd(const float* dout, const float* gates, const float* cell,
+                          const float* w_hh, float* dgp, int B, int S, int H, void* stream);
+int styler_aug_classifier_tail_bwd(const float* h, const float* ln_g, const float* ln_b,
+                                   const float* w2, const float* b2, const float* dout, float* dh,
+                                   float* dln_g, float* dln_b, float* dw2, float* db2, int B, int S,
+                                   void* stream);
+int styler_length_regulate_bwd(const float* dy, int64_t lddy, const int32_t* csum, float* dx,
+                               int64_t lddx, int B, int S, int T, int C, void* stream);
+int styler_bucket_embed_bwd(const float* dy, const int32_t* p_ids, const int32_t* e_ids,
+                            float* dpitch_emb, float* denergy_emb, int B, int T, void* stream);
+/* out[b,:] (+)= sum_t x[b,t,:] */
+int styler_rowsum(const float* x, int64_t ldx, float* out, int64_t ldo, int B, int L, int C,
+                  int accumulate, void* stream);
+/* da = gscale[0] * d(err)/da / acc[1] on valid rows (acc from styler_masked_err_sum). */
+int styler_masked_err_bwd(const float* a, int64_t lda, const float* b, int64_t ldb,
+                          const double* acc, const float* gscale, float* da, int kind, int B, int L,
+                          int C, const int64_t* len, void* stream);
+/* NLLLoss(mean) on [B,2] log-probs (loss.py:46-48): loss[0] (optional) and/or dlogp. */
+int styler_nll(const float* logp, const int64_t* label, float* loss, const float* gscale,
+               float* dlogp, int B, void* stream);
+/* y = x * keep / (1-p); keep is a counter-based hash of (seed, element index): the same call on
+ * dy is the backward (no mask tensor). */
+int styler_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int C, float p,
+                   uint64_t seed, void* stream);
+/* out[0] += sum g^2 (fp64) -- the global gradient norm of clip_grad_norm_ (train.py:181-182). */
+int styler_sumsq(const float* g, int64_t n, double* out, void* stream);
+/* clip (coef = min(1, max_norm / (sqrt(sumsq) + 1e-6)), sumsq may be NULL) fused with Adam
+ * (hparams.py:99-101; bias-corrected, no weight decay) over flat buffers; `step` >= 1. */
+int styler_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq,
+                     float max_norm, float lr, float beta1, float beta2, float eps, int step,
+                     void* stream);
 
 #ifdef __cplusplus
 }

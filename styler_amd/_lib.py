@@ -20,7 +20,7 @@ _SIGS = {
     "styler_cast_bf16": [P, P, I64, P],
     "styler_repack_conv_weight": [P, P, I, I, I, I, P],
     "styler_attention_fwd": [P, P, P, I, I, P, P],
-    "styler_add_layernorm": [P, I64, P, I64, P, P, P, I64, P, P, P, I, I, I, P, P],
+    "styler_add_layernorm": [P, I64, P, I64, P, P, P, I64, P, P, P, I, I, I, P, F, ctypes.c_uint64, P],
     "styler_groupnorm_relu": [P, I64, P, P, P, I64, I, I, I, P],
     "styler_bn_fold": [P, P, P, P, P, P, P, I, P],
     "styler_batchnorm_train": [P, P, P, P, P, P, P, P, P, I64, I, I, P],
@@ -38,6 +38,27 @@ _SIGS = {
     "styler_add_rowvec": [P, I64, P, I64, P, I64, I, I, I, P],
     "styler_length_mask": [P, P, I, I, P],
     "styler_masked_err_sum": [P, I64, P, I64, P, I, I, I, I, P, P],
+    "styler_act_bwd": [P, I64, P, I64, P, I64, I, I, I, I, P, P],
+    "styler_wgrad": [P, I64, P, I64, P, I64, I64, I, I, I, I, I, P],
+    "styler_colsum": [P, I64, P, P, I64, I, P],
+    "styler_repack_weight_bwd": [P, P, I, I, I, P],
+    "styler_attention_bwd": [P, P, P, P, P, P, I, I, P, P],
+    "styler_layernorm_bwd": [P, I64, P, I64, P, P, P, I64, P, P, P, P, P, P, I, I, I, P, F, ctypes.c_uint64, P],
+    "styler_groupnorm_relu_bwd": [P, I64, P, I64, P, P, P, I64, P, P, I, I, I, P],
+    "styler_batchnorm_bwd": [P, P, P, P, P, P, P, P, P, P, I64, I, I, P],
+    "styler_embed_bwd": [P, P, I64, P, I, I, I, P],
+    "styler_onehot_conv5_bwd": [P, P, I64, P, P, I, I, I, P],
+    "styler_mel_calibrate_bwd": [P, I64, P, I64, P, P, I, I, I, I, P],
+    "styler_lstm_bidir_bwd": [P, P, P, P, P, I, I, I, P],
+    "styler_aug_classifier_tail_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, P],
+    "styler_length_regulate_bwd": [P, I64, P, P, I64, I, I, I, I, P],
+    "styler_bucket_embed_bwd": [P, P, P, P, P, I, I, P],
+    "styler_rowsum": [P, I64, P, I64, I, I, I, I, P],
+    "styler_masked_err_bwd": [P, I64, P, I64, P, P, P, I, I, I, I, P, P],
+    "styler_nll": [P, P, P, P, P, I, P],
+    "styler_dropout": [P, I64, P, I64, I64, I, F, ctypes.c_uint64, P],
+    "styler_sumsq": [P, I64, P, P],
+    "styler_adam_step": [P, P, P, P, I64, P, F, F, F, F, F, I, P],
     "styler_stft_mel_workspace_bytes": [I, I],
     "styler_stft_mel": [P, I64, P, P, P, P, P, P, P, I, I, I, P],
 }

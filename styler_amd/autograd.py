@@ -1,0 +1,433 @@
+"""Autograd bindings: every differentiable op of the path is a torch.autograd.Function whose forward and
+backward are libstyler_hip.so kernels.  torch.autograd only supplies the tape.
+
+Parameter gradients are accumulated by the kernels (atomicAdd) straight into `param.grad` -- a view of the
+flat fp32 gradient buffer owned by `training.TrainState` -- so the Functions return None for parameters
+(the fused wgrad-accumulation scheme); activations' gradients flow through the tape as usual."""
+import torch
+from torch.autograd import Function
+
+from . import ops
+from .runtime import gemm_weight, rt
+
+NONE, RELU, TANH = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_TANH
+
+
+def G(p):
+    """Gradient buffer of a parameter (allocated zeroed on first use when no TrainState owns it)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+_neg_ones = {}
+
+
+def _neg(n, device):
+    key = (n, str(device))
+    if key not in _neg_ones:
+        _neg_ones[key] = torch.full((n,), -1.0, device=device)
+    return _neg_ones[key]
+
+
+class ConvGemmFn(Function):
+    """y = act(conv_same(x, W) + b) (+ res when act is NONE).  W / b are nn.Parameters in reference layout."""
+
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, cache, key, kw, act, neg_dx):
+        w, prec = gemm_weight(cache, key, weight, x.shape[-1])
+        fuse_res = res is not None and act == NONE
+        y = ops.conv_gemm(x, w, bias, kw=kw, n=weight.shape[0], act=act, prec=prec, res=res if fuse_res else None)
+        ctx.save_for_backward(x, y if act != NONE else None)
+        ctx.weight, ctx.bias, ctx.cache, ctx.key = weight, bias, cache, key
+        ctx.kw, ctx.act, ctx.neg_dx, ctx.has_res = kw, act, neg_dx, res is not None
+        if res is not None and not fuse_res:
+            return ops.add2(y, res)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        weight, bias, kw = ctx.weight, ctx.bias, ctx.kw
+        n, cin = weight.shape[0], x.shape[-1]
+        dy = ops._rows_view(dy)
+        dz = ops.act_bwd(dy, y, ctx.act) if ctx.act != NONE else dy
+        if weight.requires_grad:
+            gw = G(weight)
+            if kw == 1:
+                ops.wgrad(dz, x, gw, cin, 1, n, cin)
+            else:
+                for j in range(kw):
+                    ops.wgrad(dz, x, gw, cin * kw, kw, n, cin, shift=j - kw // 2, dw_offset=j)
+        if bias is not None and bias.requires_grad:
+            ops.colsum(dz, G(bias))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = ctx.cache.get(ctx.key + ":T", [weight], lambda w: ops.repack_weight_bwd(w.detach()))
+            prec = ops.PREC_F32
+            if rt.prec == ops.PREC_BF16 and n % 8 == 0:
+                wt = ctx.cache.get(ctx.key + ":T16", [weight], lambda w: ops.cast_bf16(ops.repack_weight_bwd(w.detach())))
+                prec = ops.PREC_BF16
+            dx = ops.conv_gemm(dz, wt, None, kw=kw, n=cin, prec=prec,
+                               scale=_neg(cin, dz.device) if ctx.neg_dx else None)
+        return dx, (dy if ctx.has_res else None), None, None, None, None, None, None, None
+
+
+class QkvAttentionFn(Function):
+    """Fused QKV projection + attention (SubLayers.py:41-56)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, mha, lens):
+        w, b, prec = mha._qkv()
+        qkv = ops.conv_gemm(x, w, b, n=768, prec=prec)
+        B, L, _ = x.shape
+        lse = torch.empty(B, 4, L, device=x.device, dtype=torch.float32)
+        out = ops.attention_fwd(qkv, lens, lse=lse)
+        ctx.save_for_backward(x, qkv, out, lse, lens)
+        ctx.mha = mha
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, qkv, out, lse, lens = ctx.saved_tensors
+        mha = ctx.mha
+        dqkv = ops.attention_bwd(qkv, out, dout, lse, lens)
+        for i, lin in enumerate((mha.w_qs, mha.w_ks, mha.w_vs)):
+            sl = dqkv[..., i * 256:(i + 1) * 256]
+            ops.wgrad(sl, x, G(lin.weight), 256, 1, 256, 256)
+            ops.colsum(sl, G(lin.bias))
+        d = mha._derived
+        srcs = [mha.w_qs.weight, mha.w_ks.weight, mha.w_vs.weight]
+        if rt.prec == ops.PREC_BF16:
+            wt = d.get("qkv_wT16", srcs, lambda *t: ops.cast_bf16(torch.cat([u.detach() for u in t]).t().contiguous()))
+            prec = ops.PREC_BF16
+        else:
+            wt = d.get("qkv_wT", srcs, lambda *t: torch.cat([u.detach() for u in t]).t().contiguous())
+            prec = ops.PREC_F32
+        dx = ops.conv_gemm(dqkv, wt, None, n=256, prec=prec)
+        return dx, None, None, None
+
+
+class LayerNormFn(Function):
+    """LayerNorm(x + res) with pad mask (SubLayers.py:59,87 + Layers.py:29,32)."""
+
+    @staticmethod
+    def forward(ctx, x, res, anchor, ln, lens):
+        if res is not None:
+            s = ops.add2(x, res)
+        else:
+            s = x
+        y = ops.add_layernorm(s, ln.weight, ln.bias, lens=lens)
+        ctx.save_for_backward(s, lens)
+        ctx.ln, ctx.has_res = ln, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        s, lens = ctx.saved_tensors
+        ln = ctx.ln
+        dx = ops.layernorm_bwd(s, dy, ln.weight, ln.bias, G(ln.weight), G(ln.bias), lens=lens)
+        return dx, (dx if ctx.has_res else None), None, None, None
+
+
+class LayerNormDotFn(Function):
+    """StylePredictor tail: LayerNorm -> Linear(256,1) -> masked_fill (modules.py:449-465)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, ln, lin, lens, drop_p, seed):
+        out = ops.add_layernorm(x, ln.weight, ln.bias, lens=lens, dot_w=lin.weight, dot_b=lin.bias, drop_p=drop_p,
+                                drop_seed=seed)
+        ctx.save_for_backward(x, lens)
+        ctx.ln, ctx.lin, ctx.drop = ln, lin, (drop_p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, lens = ctx.saved_tensors
+        ln, lin = ctx.ln, ctx.lin
+        dx = ops.layernorm_bwd(x, None, ln.weight, ln.bias, G(ln.weight), G(ln.bias), lens=lens, dot_w=lin.weight,
+                               dout=dout, ddot_w=G(lin.weight), ddot_b=G(lin.bias), drop_p=ctx.drop[0],
+                               drop_seed=ctx.drop[1])
+        return dx, None, None, None, None, None, None
+
+
+class GroupNormReluFn(Function):
+    @staticmethod
+    def forward(ctx, x, anchor, gn):
+        y = ops.groupnorm_relu(x, gn.weight, gn.bias, out=torch.empty_like(x))
+        ctx.save_for_backward(x)
+        ctx.gn = gn
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        gn = ctx.gn
+        return ops.groupnorm_relu_bwd(x, dy, gn.weight, gn.bias, G(gn.weight), G(gn.bias)), None, None
+
+
+class BatchNormActFn(Function):
+    @staticmethod
+    def forward(ctx, x, anchor, bn, act):
+        y, mean, rstd = ops.batchnorm_train(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, act)
+        ctx.save_for_backward(x, y, mean, rstd)
+        ctx.bn, ctx.act = bn, act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, rstd = ctx.saved_tensors
+        bn = ctx.bn
+        return ops.batchnorm_bwd(x, y, dy, bn.weight, mean, rstd, G(bn.weight), G(bn.bias), ctx.act), None, None, None
+
+
+class EmbedPosFn(Function):
+    @staticmethod
+    def forward(ctx, text, anchor, emb, pe):
+        ctx.save_for_backward(text)
+        ctx.emb = emb
+        return ops.embed_pos(text, emb.weight, pe)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (text,) = ctx.saved_tensors
+        ops.embed_bwd(text, dy, G(ctx.emb.weight))
+        return None, None, None, None
+
+
+class OnehotConv5Fn(Function):
+    @staticmethod
+    def forward(ctx, v, anchor, conv, cache, key, err):
+        wt = cache.get(key, [conv.weight], lambda w: w.detach().permute(2, 1, 0).contiguous())
+        B, L = v.shape
+        y = torch.empty(B, L, conv.weight.shape[0], device=v.device, dtype=torch.float32)
+        ops.onehot_conv5(v, wt, conv.bias, y, err_flag=err)
+        ctx.save_for_backward(v)
+        ctx.conv = conv
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (v,) = ctx.saved_tensors
+        ops.onehot_conv5_bwd(v, dy, G(ctx.conv.weight), G(ctx.conv.bias))
+        return None, None, None, None, None, None
+
+
+class MelCalibrateFn(Function):
+    @staticmethod
+    def forward(ctx, x, mel_len, src_len, S):
+        ctx.save_for_backward(mel_len, src_len)
+        ctx.T = x.shape[1]
+        return ops.mel_calibrate(x, mel_len, src_len, S)
+
+    @staticmethod
+    def backward(ctx, dy):
+        mel_len, src_len = ctx.saved_tensors
+        return ops.mel_calibrate_bwd(dy, mel_len, src_len, ctx.T), None, None, None
+
+
+class LstmLayerFn(Function):
+    """One bidirectional nn.LSTM layer: input GEMM (both directions) + recurrent kernel."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, lstm, layer, H, enc, key):
+        w, bias, w_hh, prec = enc._lstm_weights(lstm, layer, key, x.shape[-1])
+        gx = ops.conv_gemm(x, w, bias, n=8 * H, prec=prec)
+        B, S, _ = gx.shape
+        gates = torch.empty(B, S, 8 * H, device=x.device, dtype=torch.float32)
+        cell = torch.empty(B, S, 2 * H, device=x.device, dtype=torch.float32)
+        out = ops.lstm_bidir(gx, w_hh, H, cell_out=cell, gates_out=gates)
+        ctx.save_for_backward(x, out, gates, cell, w_hh)
+        ctx.lstm, ctx.layer, ctx.H, ctx.enc, ctx.key = lstm, layer, H, enc, key
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, out, gates, cell, w_hh = ctx.saved_tensors
+        lstm, layer, H = ctx.lstm, ctx.layer, ctx.H
+        cin = x.shape[-1]
+        dgp = ops.lstm_bidir_bwd(dout, gates, cell, w_hh, H)
+        for d, sfx in enumerate(("", "_reverse")):
+            sl = dgp[..., d * 4 * H:(d + 1) * 4 * H]
+            ops.wgrad(sl, x, G(getattr(lstm, f"weight_ih_l{layer}{sfx}")), cin, 1, 4 * H, cin)
+            # h_{prev}: forward direction reads out[t-1], reverse direction out[t+1]
+            ops.wgrad(sl, out[..., d * H:(d + 1) * H], G(getattr(lstm, f"weight_hh_l{layer}{sfx}")), H, 1, 4 * H, H,
+                      shift=-1 if d == 0 else 1)
+            ops.colsum(sl, G(getattr(lstm, f"bias_ih_l{layer}{sfx}")), G(getattr(lstm, f"bias_hh_l{layer}{sfx}")))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            names = [f"weight_ih_l{layer}", f"weight_ih_l{layer}_reverse"]
+            srcs = [getattr(lstm, n) for n in names]
+            wt = ctx.enc._derived.get(ctx.key + "wiT", srcs,
+                                      lambda a, b: torch.cat([a.detach(), b.detach()]).t().contiguous())
+            dx = ops.conv_gemm(dgp, wt, None, n=cin)
+        return dx, None, None, None, None, None, None
+
+
+class AugTailFn(Function):
+    @staticmethod
+    def forward(ctx, h, anchor, c):
+        ctx.save_for_backward(h)
+        ctx.c = c
+        return ops.aug_classifier_tail(h, c.d_bn1.weight, c.d_bn1.bias, c.d_fc2.weight, c.d_fc2.bias)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (h,) = ctx.saved_tensors
+        c = ctx.c
+        dh = ops.aug_classifier_tail_bwd(h, c.d_bn1.weight, c.d_bn1.bias, c.d_fc2.weight, c.d_fc2.bias, dout,
+                                         G(c.d_bn1.weight), G(c.d_bn1.bias), G(c.d_fc2.weight), G(c.d_fc2.bias))
+        return dh, None, None
+
+
+class LengthRegulateFn(Function):
+    @staticmethod
+    def forward(ctx, x, csum, T):
+        ctx.save_for_backward(csum)
+        ctx.S = x.shape[1]
+        return ops.length_regulate(x, csum, T)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (csum,) = ctx.saved_tensors
+        return ops.length_regulate_bwd(dy, csum, ctx.S), None, None
+
+
+class BucketEmbedAddFn(Function):
+    """out = text + pitch_emb[..] + speaker + energy_emb[..]; out2 = out.detach() + noise (styler.py:55)."""
+
+    @staticmethod
+    def forward(ctx, text, speaker, noise, anchor, p_src, p_scale, e_src, e_scale, sm):
+        B, T, _ = text.shape
+        pid = torch.empty(B, T, device=text.device, dtype=torch.int32)
+        eid = torch.empty_like(pid)
+        out, out2 = ops.bucket_embed_add(text, speaker, p_src, p_scale, e_src, e_scale, sm.pitch_bins, sm.energy_bins,
+                                         sm.pitch_embedding.weight, sm.energy_embedding.weight, noise=noise, p_ids=pid,
+                                         e_ids=eid)
+        ctx.save_for_backward(pid, eid)
+        ctx.sm = sm
+        if out2 is None:
+            out2 = out.new_zeros(1)
+        return out, out2
+
+    @staticmethod
+    def backward(ctx, dout, dout2):
+        pid, eid = ctx.saved_tensors
+        sm = ctx.sm
+        dout = dout.contiguous()
+        ops.bucket_embed_bwd(dout, pid, eid, G(sm.pitch_embedding.weight), G(sm.energy_embedding.weight))
+        dnoise = dout2 if ctx.needs_input_grad[2] else None
+        return dout, dout, dnoise, None, None, None, None, None, None
+
+
+class AddPosFn(Function):
+    @staticmethod
+    def forward(ctx, x, pe):
+        return ops.add_pos(x, pe)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None
+
+
+class Add2Fn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add2(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class AddRowvecFn(Function):
+    """out[b,t,:] = a[b,t,:] + v[b,:]  (a may be None: pure broadcast)."""
+
+    @staticmethod
+    def forward(ctx, a, v, L):
+        ctx.has_a = a is not None
+        return ops.add_rowvec(a, v, L)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return (dy if ctx.has_a else None), ops.rowsum(dy), None
+
+
+class CatFn(Function):
+    """Channel concatenation into one [B, L, sum C] buffer (strided copies; backward = slice views)."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        B, L = parts[0].shape[:2]
+        widths = [p.shape[-1] for p in parts]
+        out = torch.empty(B, L, sum(widths), device=parts[0].device, dtype=torch.float32)
+        off = 0
+        for p, w in zip(parts, widths):
+            ops.add2(ops._rows_view(p), None, out=out[..., off:off + w])
+            off += w
+        ctx.widths = widths
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        outs, off = [], 0
+        for w in ctx.widths:
+            outs.append(dy[..., off:off + w])
+            off += w
+        return tuple(outs)
+
+
+class DropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return ops.dropout(x, p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout(dy, ctx.p, ctx.seed), None, None
+
+
+class MaskedErrFn(Function):
+    """mean over valid positions of (a-b)^2 (kind 0) or |a-b| (kind 1): masked_select + MSELoss/L1Loss."""
+
+    @staticmethod
+    def forward(ctx, a, b, kind, lens):
+        a, b = a.contiguous(), b.contiguous()
+        acc = torch.zeros(2, dtype=torch.float64, device=a.device)
+        ops.masked_err_sum(a, b, acc, kind, lens)
+        ctx.save_for_backward(a, b, acc, lens)
+        ctx.kind = kind
+        return (acc[0] / acc[1]).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, acc, lens = ctx.saved_tensors
+        return ops.masked_err_bwd(a, b, acc, g.reshape(1).float().contiguous(), ctx.kind, lens), None, None, None
+
+
+class NllFn(Function):
+    @staticmethod
+    def forward(ctx, logp, label):
+        logp = logp.contiguous()
+        ctx.save_for_backward(logp, label)
+        return ops.nll(logp, label)
+
+    @staticmethod
+    def backward(ctx, g):
+        logp, label = ctx.saved_tensors
+        return ops.nll(logp, label, gscale=g.reshape(1).float().contiguous(), want_grad=True), None
+
+
+def next_dropout_seed():
+    rt.dropout_calls += 1
+    return (rt.seed * 1000003 + rt.dropout_calls) & 0x7FFFFFFFFFFFFFFF
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0 or rt.disable_dropout:
+        return x
+    seed = next_dropout_seed()
+    if torch.is_grad_enabled() and x.requires_grad:
+        return DropoutFn.apply(x, p, seed)
+    return ops.dropout(x, p, seed)

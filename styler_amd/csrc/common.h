@@ -48,3 +48,12 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == STYLER_ACT_LOGCLAMP) return logf(fmaxf(v, 1e-5f));
   return v;
 }
+
+// counter-based dropout stream: keep element e of a tensor iff dropout_hash32(seed, e) >= p * 2^32
+__device__ __forceinline__ uint32_t dropout_hash32(uint64_t seed, uint64_t idx) {
+  uint64_t z = idx + seed * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}

@@ -72,3 +72,80 @@ extern "C" int styler_lstm_bidir(const float* gx, const float* w_hh, float* out,
     return STYLER_EINVAL;
   return launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Backward of the recurrent half (BPTT).  One block per (item, direction), 4H threads.
+// Saved by forward: gates (post-activation i|f|g|o) [B,S,2*4H], cell states c [B,S,2H], hidden states out [B,S,2H].
+// Produces dgp = dL/d(pre-activation gates) [B,S,2*4H]; every weight / input gradient is then a GEMM:
+//   dx = dgp W_ih (styler_conv_gemm), dW_ih = dgp^T x, dW_hh = dgp^T h_{prev} (styler_wgrad, shift -1 / +1),
+//   db_ih = db_hh = colsum(dgp).
+// Per step: threads u < H form the four gate gradients of unit u; then all 4H threads do the transposed
+// mat-vec dh_prev[k] = sum_j W_hh[j][k] dgp[j] with thread (q = tid / H, k = tid % H) holding the H
+// weights W_hh[q*H + j'][k] in registers and the 4 partial sums combined through LDS.
+template <int H>
+__global__ __launch_bounds__(4 * H) void lstm_bidir_bwd_kernel(const float* __restrict__ dout,
+                                                               const float* __restrict__ gates,
+                                                               const float* __restrict__ cell,
+                                                               const float* __restrict__ w_hh,
+                                                               float* __restrict__ dgp, int S) {
+  __shared__ __attribute__((aligned(16))) float sdg[4 * H];
+  __shared__ float part[4][H];
+  const int tid = threadIdx.x, q = tid / H, k = tid % H;
+  const int b = blockIdx.x, dir = blockIdx.y;
+  float w[H];
+  {
+    const float* wp = w_hh + ((int64_t)dir * 4 * H + q * H) * H + k;     // column k of gate block q
+#pragma unroll
+    for (int j = 0; j < H; ++j) w[j] = wp[(int64_t)j * H];
+  }
+  float dh_rec = 0.f, dc_next = 0.f;
+  const int64_t g_ld = 2 * 4 * H, o_ld = 2 * H;
+  // reverse of the forward processing order: forward dir processed t = 0..S-1, so walk S-1..0 (and vice versa)
+  int t = dir ? 0 : S - 1;
+  const int dt = dir ? 1 : -1;
+  for (int step = 0; step < S; ++step, t += dt) {
+    if (tid < H) {
+      const int u = tid;
+      const int64_t go = ((int64_t)b * S + t) * g_ld + dir * 4 * H;
+      const int64_t oo = ((int64_t)b * S + t) * o_ld + dir * H;
+      const float gi = gates[go + u], gf = gates[go + H + u], gg = gates[go + 2 * H + u], gout = gates[go + 3 * H + u];
+      const float c = cell[oo + u];
+      const int tp = t - (dir ? -1 : 1);                           // previous step in forward processing order
+      const float c_prev = (tp >= 0 && tp < S) ? cell[((int64_t)b * S + tp) * o_ld + dir * H + u] : 0.f;
+      const float dh = dout[oo + u] + dh_rec;
+      const float tc = tanhf(c);
+      const float d_o = dh * tc;
+      const float dc = dc_next + dh * gout * (1.f - tc * tc);
+      const float di = dc * gg, dg = dc * gi, df = dc * c_prev;
+      dc_next = dc * gf;
+      const float pi = di * gi * (1.f - gi), pf = df * gf * (1.f - gf), pg = dg * (1.f - gg * gg),
+                  po = d_o * gout * (1.f - gout);
+      sdg[u] = pi; sdg[H + u] = pf; sdg[2 * H + u] = pg; sdg[3 * H + u] = po;
+      dgp[go + u] = pi; dgp[go + H + u] = pf; dgp[go + 2 * H + u] = pg; dgp[go + 3 * H + u] = po;
+    }
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int j = 0; j < H; j += 4) {
+      const float4 d = *reinterpret_cast<const float4*>(&sdg[q * H + j]);
+      a0 = fmaf(w[j], d.x, a0); a1 = fmaf(w[j + 1], d.y, a1); a2 = fmaf(w[j + 2], d.z, a2); a3 = fmaf(w[j + 3], d.w, a3);
+    }
+    part[q][k] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (tid < H) dh_rec = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    __syncthreads();
+  }
+}
+
+extern "C" int styler_lstm_bidir_bwd(const float* dout, const float* gates, const float* cell, const float* w_hh,
+                                     float* dgp, int B, int S, int H, void* stream) {
+  if (!dout || !gates || !cell || !w_hh || !dgp || B <= 0 || S <= 0) return STYLER_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (H == 64)
+    hipLaunchKernelGGL(lstm_bidir_bwd_kernel<64>, dim3(B, 2), dim3(256), 0, st, dout, gates, cell, w_hh, dgp, S);
+  else if (H == 80)
+    hipLaunchKernelGGL(lstm_bidir_bwd_kernel<80>, dim3(B, 2), dim3(320), 0, st, dout, gates, cell, w_hh, dgp, S);
+  else
+    return STYLER_EINVAL;
+  return launch_status();
+}

@@ -1,0 +1,404 @@
+// Backward of the memory-bound stitching kernels (misc.hip, length_regulator.hip), the loss gradients,
+// dropout and the fused clip + Adam update.
+#include "common.h"
+
+static inline unsigned grid_for(int64_t work, int per_block = 256, int cap = 4096) {
+  int64_t b = (work + per_block - 1) / per_block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// ---- embedding backward: demb[text[b,t], :] += dy[b,t,:], padding_idx 0 receives nothing (Models.py:52-53) ----
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ text, const float* __restrict__ dy,
+                                                        int64_t lddy, float* __restrict__ demb, int64_t rows, int C) {
+  const int64_t total = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / C; const int c = (int)(i - row * C);
+    const int64_t id = text[row];
+    if (id != 0) atomicAdd(demb + id * C + c, dy[row * lddy + c]);
+  }
+}
+
+extern "C" int styler_embed_bwd(const int64_t* text, const float* dy, int64_t lddy, float* demb, int B, int L, int C,
+                                void* stream) {
+  if (!text || !dy || !demb || B <= 0 || L <= 0 || C <= 0) return STYLER_EINVAL;
+  const int64_t rows = (int64_t)B * L;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, text, dy, lddy, demb,
+                     rows, C);
+  return launch_status();
+}
+
+// ---- one-hot conv backward: dw[c, idx[b,t+j-2], j] += dy[b,t,c] (parameter layout [C, 257, 5]); db += colsum ----
+__device__ __forceinline__ int quant_index_b(float v) {
+  if (v <= 0.f) return 0;
+  if (v > 1.f) v = 1.f;
+  return (int)rintf(v * 255.f) + 1;
+}
+
+__global__ __launch_bounds__(256) void onehot_conv5_bwd_kernel(const float* __restrict__ v, const float* __restrict__ dy,
+                                                               int64_t lddy, float* __restrict__ dw,
+                                                               float* __restrict__ db, int64_t rows, int L, int C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int t = (int)(row % L);
+  int idx[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int tt = t + j - 2;
+    idx[j] = (tt >= 0 && tt < L) ? quant_index_b(v[row + j - 2]) : -1;
+  }
+  for (int c = lane; c < C; c += 64) {
+    const float g = dy[row * lddy + c];
+    atomicAdd(db + c, g);
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      if (idx[j] >= 0) atomicAdd(dw + ((int64_t)c * 257 + idx[j]) * 5 + j, g);
+  }
+}
+
+extern "C" int styler_onehot_conv5_bwd(const float* v, const float* dy, int64_t lddy, float* dw, float* db, int B, int L,
+                                       int C, void* stream) {
+  if (!v || !dy || !dw || !db || B <= 0 || L <= 0 || C <= 0) return STYLER_EINVAL;
+  const int64_t rows = (int64_t)B * L;
+  hipLaunchKernelGGL(onehot_conv5_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, v, dy,
+                     lddy, dw, db, rows, L, C);
+  return launch_status();
+}
+
+// ---- mel calibrator backward: grid (T, B) over INPUT frames -----------------------------------------------
+__global__ __launch_bounds__(256) void mel_calibrate_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                                float* __restrict__ dx, int64_t lddx,
+                                                                const int64_t* __restrict__ mel_len,
+                                                                const int64_t* __restrict__ src_len, int T, int S, int C) {
+  const int t = blockIdx.x, b = blockIdx.y;
+  const int ml = (int)mel_len[b], sl = (int)src_len[b];
+  float* dxp = dx + ((int64_t)b * T + t) * lddx;
+  const float* dyb = dy + (int64_t)b * S * lddy;
+  int s0 = 0, cnt = 0; float scale = 1.f;
+  if (t < ml && sl > 0) {
+    if (ml >= sl) {                                  // frame t belongs to one segment s; grad = dy[s] / n_s
+      const int q = ml / sl, r = ml % sl;
+      const int s = (t < r * (q + 1)) ? t / (q + 1) : r + (t - r * (q + 1)) / q;
+      const int n = q + (s < r ? 1 : 0);
+      s0 = s; cnt = 1; scale = n > 1 ? 1.f / (float)n : 1.f;
+      if (n > 1) scale = 1.f;                        // division is applied exactly as forward: g / n (below)
+      cnt = -n;                                      // negative = "divide by n"
+    } else {                                         // frame t was repeated q + (t < r) times
+      const int q = sl / ml, r = sl % ml;
+      cnt = q + (t < r ? 1 : 0);
+      s0 = t * q + (t < r ? t : r);
+    }
+  }
+  for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cnt < 0) {
+      acc = *reinterpret_cast<const float4*>(dyb + (int64_t)s0 * lddy + c);
+      if (cnt < -1) { const float d = (float)(-cnt); acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d; }
+    } else {
+      for (int k = 0; k < cnt; ++k) {
+        const float4 g = *reinterpret_cast<const float4*>(dyb + (int64_t)(s0 + k) * lddy + c);
+        acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+      }
+    }
+    *reinterpret_cast<float4*>(dxp + c) = acc;
+  }
+}
+
+extern "C" int styler_mel_calibrate_bwd(const float* dy, int64_t lddy, float* dx, int64_t lddx, const int64_t* mel_len,
+                                        const int64_t* src_len, int B, int T, int S, int C, void* stream) {
+  if (!dy || !dx || !mel_len || !src_len || B <= 0 || T <= 0 || S <= 0 || C <= 0 || (C & 3)) return STYLER_EINVAL;
+  if ((lddy & 3) || (lddx & 3)) return STYLER_EALIGN;
+  hipLaunchKernelGGL(mel_calibrate_bwd_kernel, dim3(T, B), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx, lddx, mel_len,
+                     src_len, T, S, C);
+  return launch_status();
+}
+
+// ---- augmentation classifier tail backward ----------------------------------------------------------------
+// forward: y = relu(LN(h)*g + b); z = W2 y + b2; out[b] = mean_s log_softmax(z).  Given dout [B,2].
+__global__ __launch_bounds__(256) void aug_tail_bwd_kernel(const float* __restrict__ h, const float* __restrict__ g,
+                                                           const float* __restrict__ bt, const float* __restrict__ w2,
+                                                           const float* __restrict__ b2, const float* __restrict__ dout,
+                                                           float* __restrict__ dh, float* __restrict__ dg,
+                                                           float* __restrict__ dbt, float* __restrict__ dw2,
+                                                           float* __restrict__ db2, int S) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x;
+  const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4);
+  const float4 bb = *reinterpret_cast<const float4*>(bt + lane * 4);
+  const float4 w0 = *reinterpret_cast<const float4*>(w2 + lane * 4);
+  const float4 w1 = *reinterpret_cast<const float4*>(w2 + 256 + lane * 4);
+  const float go0 = dout[b * 2] / (float)S, go1 = dout[b * 2 + 1] / (float)S;
+  float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag, aw0 = ag, aw1 = ag;
+  float ab0 = 0.f, ab1 = 0.f;
+  for (int s = wave; s < S; s += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(h + ((int64_t)b * S + s) * 256 + lane * 4);
+    const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
+    const float cx = v.x - mean, cy = v.y - mean, cz = v.z - mean, cw = v.w - mean;
+    const float var = wave_sum(cx * cx + cy * cy + cz * cz + cw * cw) * (1.f / 256.f);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float hx = cx * rstd, hy = cy * rstd, hz = cz * rstd, hw = cw * rstd;
+    const float px = hx * gg.x + bb.x, py = hy * gg.y + bb.y, pz = hz * gg.z + bb.z, pw = hw * gg.w + bb.w;
+    const float ox = fmaxf(px, 0.f), oy = fmaxf(py, 0.f), oz = fmaxf(pz, 0.f), ow = fmaxf(pw, 0.f);
+    const float z0 = wave_sum(ox * w0.x + oy * w0.y + oz * w0.z + ow * w0.w) + b2[0];
+    const float z1 = wave_sum(ox * w1.x + oy * w1.y + oz * w1.z + ow * w1.w) + b2[1];
+    const float m = fmaxf(z0, z1);
+    const float e0 = expf(z0 - m), e1 = expf(z1 - m), inv = 1.f / (e0 + e1);
+    const float p0 = e0 * inv, p1 = e1 * inv;
+    // d log_softmax: dz_k = go_k - p_k * (go_0 + go_1)
+    const float dz0 = go0 - p0 * (go0 + go1), dz1 = go1 - p1 * (go0 + go1);
+    ab0 += dz0; ab1 += dz1;
+    aw0.x += dz0 * ox; aw0.y += dz0 * oy; aw0.z += dz0 * oz; aw0.w += dz0 * ow;
+    aw1.x += dz1 * ox; aw1.y += dz1 * oy; aw1.z += dz1 * oz; aw1.w += dz1 * ow;
+    float dx_ = px > 0.f ? dz0 * w0.x + dz1 * w1.x : 0.f, dy_ = py > 0.f ? dz0 * w0.y + dz1 * w1.y : 0.f;
+    float dz_ = pz > 0.f ? dz0 * w0.z + dz1 * w1.z : 0.f, dw_ = pw > 0.f ? dz0 * w0.w + dz1 * w1.w : 0.f;
+    ag.x += dx_ * hx; ag.y += dy_ * hy; ag.z += dz_ * hz; ag.w += dw_ * hw;
+    ab.x += dx_; ab.y += dy_; ab.z += dz_; ab.w += dw_;
+    const float ex = dx_ * gg.x, ey = dy_ * gg.y, ez = dz_ * gg.z, ew = dw_ * gg.w;
+    const float m1 = wave_sum(ex + ey + ez + ew) * (1.f / 256.f);
+    const float m2 = wave_sum(ex * hx + ey * hy + ez * hz + ew * hw) * (1.f / 256.f);
+    *reinterpret_cast<float4*>(dh + ((int64_t)b * S + s) * 256 + lane * 4) =
+        make_float4(rstd * (ex - m1 - hx * m2), rstd * (ey - m1 - hy * m2), rstd * (ez - m1 - hz * m2),
+                    rstd * (ew - m1 - hw * m2));
+  }
+  const float* srcs[4] = {&ag.x, &ab.x, &aw0.x, &aw1.x};
+  float* dsts[4] = {dg, dbt, dw2, dw2 + 256};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(dsts[k] + lane * 4 + e, srcs[k][e]);
+  if (lane == 0) { atomicAdd(db2, ab0); atomicAdd(db2 + 1, ab1); }
+}
+
+extern "C" int styler_aug_classifier_tail_bwd(const float* h, const float* ln_g, const float* ln_b, const float* w2,
+                                              const float* b2, const float* dout, float* dh, float* dln_g,
+                                              float* dln_b, float* dw2, float* db2, int B, int S, void* stream) {
+  if (!h || !ln_g || !ln_b || !w2 || !b2 || !dout || !dh || !dln_g || !dln_b || !dw2 || !db2 || B <= 0 || S <= 0)
+    return STYLER_EINVAL;
+  hipLaunchKernelGGL(aug_tail_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, h, ln_g, ln_b, w2, b2, dout, dh,
+                     dln_g, dln_b, dw2, db2, S);
+  return launch_status();
+}
+
+// ---- LengthRegulator backward: dx[b,i,:] = sum of dy over the frames of phoneme i (contiguous segment) ----
+__global__ __launch_bounds__(256) void length_regulate_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                                  const int32_t* __restrict__ csum,
+                                                                  float* __restrict__ dx, int64_t lddx, int S, int T,
+                                                                  int C) {
+  const int i = blockIdx.x, b = blockIdx.y;
+  const int32_t* cs = csum + (int64_t)b * S;
+  int t0 = i ? cs[i - 1] : 0, t1 = cs[i];
+  if (t0 > T) t0 = T;
+  if (t1 > T) t1 = T;
+  float* dxp = dx + ((int64_t)b * S + i) * lddx;
+  const float* dyb = dy + (int64_t)b * T * lddy;
+  for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = t0; t < t1; ++t) {
+      const float4 g = *reinterpret_cast<const float4*>(dyb + (int64_t)t * lddy + c);
+      acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+    }
+    *reinterpret_cast<float4*>(dxp + c) = acc;
+  }
+}
+
+extern "C" int styler_length_regulate_bwd(const float* dy, int64_t lddy, const int32_t* csum, float* dx, int64_t lddx,
+                                          int B, int S, int T, int C, void* stream) {
+  if (!dy || !csum || !dx || B <= 0 || S <= 0 || T <= 0 || C <= 0 || (C & 3)) return STYLER_EINVAL;
+  if ((lddy & 3) || (lddx & 3)) return STYLER_EALIGN;
+  hipLaunchKernelGGL(length_regulate_bwd_kernel, dim3(S, B), dim3(256), 0, (hipStream_t)stream, dy, lddy, csum, dx, lddx,
+                     S, T, C);
+  return launch_status();
+}
+
+// ---- bucketise/embed/add backward: scatter dy rows into the two embedding tables --------------------------
+__global__ __launch_bounds__(256) void bucket_embed_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ pid,
+                                                               const int32_t* __restrict__ eid, float* __restrict__ dpe,
+                                                               float* __restrict__ dee, int64_t rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4 g = *reinterpret_cast<const float4*>(dy + row * 256 + lane * 4);
+  float* p = dpe + (int64_t)pid[row] * 256 + lane * 4;
+  float* e = dee + (int64_t)eid[row] * 256 + lane * 4;
+  atomicAdd(p, g.x); atomicAdd(p + 1, g.y); atomicAdd(p + 2, g.z); atomicAdd(p + 3, g.w);
+  atomicAdd(e, g.x); atomicAdd(e + 1, g.y); atomicAdd(e + 2, g.z); atomicAdd(e + 3, g.w);
+}
+
+extern "C" int styler_bucket_embed_bwd(const float* dy, const int32_t* p_ids, const int32_t* e_ids, float* dpitch_emb,
+                                       float* denergy_emb, int B, int T, void* stream) {
+  if (!dy || !p_ids || !e_ids || !dpitch_emb || !denergy_emb || B <= 0 || T <= 0) return STYLER_EINVAL;
+  const int64_t rows = (int64_t)B * T;
+  hipLaunchKernelGGL(bucket_embed_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dy,
+                     p_ids, e_ids, dpitch_emb, denergy_emb, rows);
+  return launch_status();
+}
+
+// ---- per-item row sum: out[b,:] (+)= sum_t x[b,t,:]  (gradient of the speaker row broadcast) ----------------
+__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ out,
+                                                     int64_t ldo, int L, int C, int accumulate) {
+  const int b = blockIdx.y;
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (c >= C) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* xp = x + (int64_t)b * L * ldx + c;
+  for (int t = 0; t < L; ++t) {
+    const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  float4* o = reinterpret_cast<float4*>(out + (int64_t)b * ldo + c);
+  if (accumulate) { const float4 p = *o; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+  *o = acc;
+}
+
+extern "C" int styler_rowsum(const float* x, int64_t ldx, float* out, int64_t ldo, int B, int L, int C, int accumulate,
+                             void* stream) {
+  if (!x || !out || B <= 0 || L <= 0 || C <= 0 || (C & 3) || (ldx & 3) || (ldo & 3)) return STYLER_EINVAL;
+  hipLaunchKernelGGL(rowsum_kernel, dim3((C / 4 + 63) / 64, B), dim3(64), 0, (hipStream_t)stream, x, ldx, out, ldo, L, C,
+                     accumulate);
+  return launch_status();
+}
+
+// ---- masked error gradient: da = gscale * d/da err(a-b) / count on valid rows, 0 elsewhere -------------------
+__global__ __launch_bounds__(256) void masked_err_bwd_kernel(const float* __restrict__ a, int64_t lda,
+                                                             const float* __restrict__ b, int64_t ldb,
+                                                             const double* __restrict__ acc,
+                                                             const float* __restrict__ gscale, float* __restrict__ da,
+                                                             int kind, int64_t rows, int L, int C,
+                                                             const int64_t* __restrict__ len) {
+  const float k = gscale[0] / (float)acc[1];
+  const int64_t total = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / C; const int c = (int)(i - row * C);
+    const int64_t bb = row / L;
+    float g = 0.f;
+    if (!len || (row - bb * L) < len[bb]) {
+      const float d = a[row * lda + c] - b[row * ldb + c];
+      g = kind == 0 ? 2.f * d * k : (d > 0.f ? k : (d < 0.f ? -k : 0.f));
+    }
+    da[i] = g;
+  }
+}
+
+extern "C" int styler_masked_err_bwd(const float* a, int64_t lda, const float* b, int64_t ldb, const double* acc,
+                                     const float* gscale, float* da, int kind, int B, int L, int C, const int64_t* len,
+                                     void* stream) {
+  if (!a || !b || !acc || !gscale || !da || B <= 0 || L <= 0 || C <= 0) return STYLER_EINVAL;
+  const int64_t rows = (int64_t)B * L;
+  hipLaunchKernelGGL(masked_err_bwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb,
+                     acc, gscale, da, kind, rows, L, C, len);
+  return launch_status();
+}
+
+// ---- NLL over [B,2] log-probabilities: loss = -mean_b logp[b, label[b]]; fwd (+ optional bwd into dlogp) -----
+__global__ void nll_kernel(const float* __restrict__ logp, const int64_t* __restrict__ label, float* __restrict__ loss,
+                           const float* __restrict__ gscale, float* __restrict__ dlogp, int B) {
+  __shared__ float red[64];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += 64) {
+    const int l = (int)label[b];
+    s -= logp[b * 2 + l];
+    if (dlogp) {
+      const float g = -gscale[0] / (float)B;
+      dlogp[b * 2 + l] = g; dlogp[b * 2 + 1 - l] = 0.f;
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0 && loss) {
+    float t = 0.f;
+    for (int i = 0; i < 64; ++i) t += red[i];
+    loss[0] = t / (float)B;
+  }
+}
+
+extern "C" int styler_nll(const float* logp, const int64_t* label, float* loss, const float* gscale, float* dlogp, int B,
+                          void* stream) {
+  if (!logp || !label || (!loss && !dlogp) || (dlogp && !gscale) || B <= 0) return STYLER_EINVAL;
+  hipLaunchKernelGGL(nll_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, logp, label, loss, gscale, dlogp, B);
+  return launch_status();
+}
+
+// ---- dropout: y = x * keep / (1 - p), keep from a counter-based hash of (seed, element index) -------------
+// The same (seed, index) stream regenerates the mask in backward: no mask tensor is stored.
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
+                                                      int64_t ldy, int64_t rows, int C, float p, uint64_t seed) {
+  const int nq = C / 4;
+  const int64_t total = rows * nq;
+  const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+  const float sc = 1.f / (1.f - p);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / nq; const int q = (int)(i - row * nq);
+    float4 v = *reinterpret_cast<const float4*>(x + row * ldx + q * 4);
+    const uint64_t e = (uint64_t)(row * C + q * 4);
+    v.x = dropout_hash32(seed, e) >= thr ? v.x * sc : 0.f;
+    v.y = dropout_hash32(seed, e + 1) >= thr ? v.y * sc : 0.f;
+    v.z = dropout_hash32(seed, e + 2) >= thr ? v.z * sc : 0.f;
+    v.w = dropout_hash32(seed, e + 3) >= thr ? v.w * sc : 0.f;
+    *reinterpret_cast<float4*>(y + row * ldy + q * 4) = v;
+  }
+}
+
+extern "C" int styler_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int C, float p,
+                              uint64_t seed, void* stream) {
+  if (!x || !y || rows <= 0 || C <= 0 || (C & 3) || (ldx & 3) || (ldy & 3) || p < 0.f || p >= 1.f) return STYLER_EINVAL;
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
+                     rows, C, p, seed);
+  return launch_status();
+}
+
+// ---- optimizer: global grad norm (fp64 sum of squares) + fused clip + Adam on FLAT fp32 buffers ------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+    if (i + 3 < n) {
+      const float4 v = *reinterpret_cast<const float4*>(g + i);
+      s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    } else {
+      for (int64_t k = i; k < n; ++k) s += (double)g[k] * g[k];
+    }
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+extern "C" int styler_sumsq(const float* g, int64_t n, double* out, void* stream) {
+  if (!g || !out || n <= 0 || ((uintptr_t)g & 15)) return STYLER_EINVAL;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1, 256, 1024)), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  return launch_status();
+}
+
+// clip_grad_norm_(max_norm) (train.py:181-182: coef = max_norm / (norm + 1e-6), applied only if < 1) fused with
+// torch.optim.Adam (betas, eps, no weight decay, bias correction with step count `step`).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   const double* __restrict__ sumsq, float max_norm, float lr, float b1,
+                                                   float b2, float eps, float bc1, float bc2_sqrt) {
+  float coef = 1.f;
+  if (sumsq) {
+    const float norm = (float)sqrt(sumsq[0]);
+    const float c = max_norm / (norm + 1e-6f);
+    coef = c < 1.f ? c : 1.f;
+  }
+  const float step_size = lr / bc1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= step_size * mi / (sqrtf(vi) / bc2_sqrt + eps);
+  }
+}
+
+extern "C" int styler_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq,
+                                float max_norm, float lr, float beta1, float beta2, float eps, int step, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step <= 0) return STYLER_EINVAL;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq,
+                     max_norm, lr, beta1, beta2, eps, bc1, bc2s);
+  return launch_status();
+}

@@ -8,7 +8,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ res, int64_t ldres,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, int64_t ldy,
     const float* __restrict__ dot_w, const float* __restrict__ dot_b, float* __restrict__ dot_out, int64_t rows,
-    int L, const int64_t* __restrict__ len) {
+    int L, const int64_t* __restrict__ len, float drop_p, uint64_t drop_seed) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -37,6 +37,15 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
                          dw * rstd * g.w + bt.w);
   if (y) *reinterpret_cast<float4*>(y + row * ldy + lane * 4) = o;
   if (dot_out) {
+    if (drop_p > 0.f) {                                  // dropout between LayerNorm and Linear(256,1) (train mode)
+      const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);
+      const float sc = 1.f / (1.f - drop_p);
+      const uint64_t e = (uint64_t)row * 256 + lane * 4;
+      o.x = dropout_hash32(drop_seed, e) >= thr ? o.x * sc : 0.f;
+      o.y = dropout_hash32(drop_seed, e + 1) >= thr ? o.y * sc : 0.f;
+      o.z = dropout_hash32(drop_seed, e + 2) >= thr ? o.z * sc : 0.f;
+      o.w = dropout_hash32(drop_seed, e + 3) >= thr ? o.w * sc : 0.f;
+    }
     const float4 w = *reinterpret_cast<const float4*>(dot_w + lane * 4);
     const float d = wave_sum(o.x * w.x + o.y * w.y + o.z * w.z + o.w * w.w);
     if (lane == 0) dot_out[row] = d + dot_b[0];
@@ -46,14 +55,14 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
 extern "C" int styler_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldres,
                                     const float* gamma, const float* beta, float* y, int64_t ldy,
                                     const float* dot_w, const float* dot_b, float* dot_out, int B, int L, int C,
-                                    const int64_t* len, void* stream) {
+                                    const int64_t* len, float drop_p, uint64_t drop_seed, void* stream) {
   if (!x || !gamma || !beta || (!y && !dot_out) || B <= 0 || L <= 0) return STYLER_EINVAL;
   if (C != 256) return STYLER_EINVAL;
   if (dot_out && (!dot_w || !dot_b)) return STYLER_EINVAL;
   if ((ldx & 3) || (res && (ldres & 3)) || (y && (ldy & 3))) return STYLER_EALIGN;
   const int64_t rows = (int64_t)B * L;
   hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
-                     ldx, res, ldres, gamma, beta, y, ldy, dot_w, dot_b, dot_out, rows, L, len);
+                     ldx, res, ldres, gamma, beta, y, ldy, dot_w, dot_b, dot_out, rows, L, len, drop_p, drop_seed);
   return launch_status();
 }
 

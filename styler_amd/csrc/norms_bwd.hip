@@ -1,0 +1,271 @@
+// Backward of the normalisation kernels (norms.hip).  Statistics are recomputed from the saved input
+// (cheaper than a second saved tensor); parameter gradients are reduced in registers per wave and added
+// with one atomic per (lane, channel) to the fp32 gradient buffer.
+#include "common.h"
+
+// LayerNorm(256) backward.  y = LN(x) * g + b (rows t >= len[b] are zero in forward => zero gradient).
+//   dx = rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)),  dxh = dy * g
+// dot variant (predictor tail, out = <y, w> + b0): dy = dout[row] * w, dw += dout * y, db0 += dout.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dx, int64_t lddx,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ dot_w,
+    const float* __restrict__ dout, float* __restrict__ ddot_w, float* __restrict__ ddot_b, int64_t rows, int L,
+    const int64_t* __restrict__ len, float drop_p, uint64_t drop_seed) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t wstride = (int64_t)gridDim.x * 4;
+  const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
+  float4 bt = make_float4(0.f, 0.f, 0.f, 0.f), dw4 = bt;
+  if (dot_w) { bt = *reinterpret_cast<const float4*>(beta + lane * 4); dw4 = *reinterpret_cast<const float4*>(dot_w + lane * 4); }
+  float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag, aw = ag;
+  float adb = 0.f;
+  for (int64_t row = w0; row < rows; row += wstride) {
+    bool masked = false;
+    if (len) { const int64_t b = row / L; masked = (row - b * L) >= len[b]; }
+    if (masked) {
+      if (dx) *reinterpret_cast<float4*>(dx + row * lddx + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
+    const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + lane * 4);
+    const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
+    const float cx = v.x - mean, cy = v.y - mean, cz = v.z - mean, cw = v.w - mean;
+    const float var = wave_sum(cx * cx + cy * cy + cz * cz + cw * cw) * (1.f / 256.f);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float hx = cx * rstd, hy = cy * rstd, hz = cz * rstd, hw = cw * rstd;
+    float4 d;
+    if (dot_w) {
+      const float go = dout[row];
+      float kx = 1.f, ky = 1.f, kz = 1.f, kw_ = 1.f;       // dropout keep * 1/(1-p) between LN and the dot
+      if (drop_p > 0.f) {
+        const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);
+        const float sc = 1.f / (1.f - drop_p);
+        const uint64_t e = (uint64_t)row * 256 + lane * 4;
+        kx = dropout_hash32(drop_seed, e) >= thr ? sc : 0.f; ky = dropout_hash32(drop_seed, e + 1) >= thr ? sc : 0.f;
+        kz = dropout_hash32(drop_seed, e + 2) >= thr ? sc : 0.f; kw_ = dropout_hash32(drop_seed, e + 3) >= thr ? sc : 0.f;
+      }
+      d = make_float4(go * dw4.x * kx, go * dw4.y * ky, go * dw4.z * kz, go * dw4.w * kw_);
+      aw.x += go * kx * (hx * g.x + bt.x); aw.y += go * ky * (hy * g.y + bt.y);
+      aw.z += go * kz * (hz * g.z + bt.z); aw.w += go * kw_ * (hw * g.w + bt.w);
+      adb += go;
+    } else {
+      d = *reinterpret_cast<const float4*>(dy + row * lddy + lane * 4);
+    }
+    ag.x += d.x * hx; ag.y += d.y * hy; ag.z += d.z * hz; ag.w += d.w * hw;
+    ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
+    const float ex = d.x * g.x, ey = d.y * g.y, ez = d.z * g.z, ew = d.w * g.w;
+    const float m1 = wave_sum(ex + ey + ez + ew) * (1.f / 256.f);
+    const float m2 = wave_sum(ex * hx + ey * hy + ez * hz + ew * hw) * (1.f / 256.f);
+    if (dx)
+      *reinterpret_cast<float4*>(dx + row * lddx + lane * 4) =
+          make_float4(rstd * (ex - m1 - hx * m2), rstd * (ey - m1 - hy * m2), rstd * (ez - m1 - hz * m2),
+                      rstd * (ew - m1 - hw * m2));
+  }
+  atomicAdd(dgamma + lane * 4 + 0, ag.x); atomicAdd(dgamma + lane * 4 + 1, ag.y);
+  atomicAdd(dgamma + lane * 4 + 2, ag.z); atomicAdd(dgamma + lane * 4 + 3, ag.w);
+  atomicAdd(dbeta + lane * 4 + 0, ab.x); atomicAdd(dbeta + lane * 4 + 1, ab.y);
+  atomicAdd(dbeta + lane * 4 + 2, ab.z); atomicAdd(dbeta + lane * 4 + 3, ab.w);
+  if (dot_w) {
+    atomicAdd(ddot_w + lane * 4 + 0, aw.x); atomicAdd(ddot_w + lane * 4 + 1, aw.y);
+    atomicAdd(ddot_w + lane * 4 + 2, aw.z); atomicAdd(ddot_w + lane * 4 + 3, aw.w);
+    if (lane == 0) atomicAdd(ddot_b, adb);
+  }
+}
+
+extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* gamma,
+                                    const float* beta, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                                    const float* dot_w, const float* dout, float* ddot_w, float* ddot_b, int B, int L,
+                                    int C, const int64_t* len, float drop_p, uint64_t drop_seed, void* stream) {
+  if (!x || !gamma || !dgamma || !dbeta || B <= 0 || L <= 0 || C != 256) return STYLER_EINVAL;
+  if (!dot_w && !dy) return STYLER_EINVAL;
+  if (dot_w && (!dout || !ddot_w || !ddot_b || !beta)) return STYLER_EINVAL;
+  if ((ldx & 3) || (dy && (lddy & 3)) || (dx && (lddx & 3))) return STYLER_EALIGN;
+  const int64_t rows = (int64_t)B * L;
+  int64_t blocks = (rows + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy,
+                     gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b, rows, L, len, drop_p, drop_seed);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm(16 ch/group over padded L) + ReLU backward.  Block = (item, 64-channel chunk), as forward.
+//   g = dy * (y > 0);  dxh = g * gamma;  dx = rstd * (dxh - mean_g(dxh) - xh * mean_g(dxh * xh))
+__global__ __launch_bounds__(256) void groupnorm_relu_bwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                 const float* __restrict__ dy, int64_t lddy,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* __restrict__ dx,
+                                                                 int64_t lddx, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, int L, int C) {
+  __shared__ double red[4][16][16];
+  __shared__ float stat[4][4];
+  __shared__ float pg[2][16][64];
+  const int b = blockIdx.y, c0 = blockIdx.x * 64;
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const float* xp = x + (int64_t)b * L * ldx + c0 + cq * 4;
+  const float* gp = dy + (int64_t)b * L * lddy + c0 + cq * 4;
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + c0 + cq * 4);
+  const float4 be = *reinterpret_cast<const float4*>(beta + c0 + cq * 4);
+  // pass 1: statistics of x
+  double s = 0.0, ss = 0.0;
+  for (int t = rl; t < L; t += 16) {
+    const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
+    s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+    ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  red[0][rl][cq] = s; red[1][rl][cq] = ss;
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double ts = 0.0, tss = 0.0;
+    for (int r = 0; r < 16; ++r)
+      for (int q = 0; q < 4; ++q) { ts += red[0][r][threadIdx.x * 4 + q]; tss += red[1][r][threadIdx.x * 4 + q]; }
+    const double n = 16.0 * L, mean = ts / n;
+    double var = tss / n - mean * mean; if (var < 0.0) var = 0.0;
+    stat[0][threadIdx.x] = (float)mean;
+    stat[1][threadIdx.x] = (float)(1.0 / sqrt(var + 1e-5));
+  }
+  __syncthreads();
+  const float mean = stat[0][cq >> 2], rstd = stat[1][cq >> 2];
+  // pass 2: sums of dxh and dxh*xh per group, dgamma/dbeta per channel
+  double s1 = 0.0, s2 = 0.0;
+  float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
+  for (int t = rl; t < L; t += 16) {
+    const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
+    float4 g = *reinterpret_cast<const float4*>(gp + (int64_t)t * lddy);
+    const float hx = (v.x - mean) * rstd, hy = (v.y - mean) * rstd, hz = (v.z - mean) * rstd, hw = (v.w - mean) * rstd;
+    g.x = (hx * ga.x + be.x) > 0.f ? g.x : 0.f; g.y = (hy * ga.y + be.y) > 0.f ? g.y : 0.f;
+    g.z = (hz * ga.z + be.z) > 0.f ? g.z : 0.f; g.w = (hw * ga.w + be.w) > 0.f ? g.w : 0.f;
+    ag.x += g.x * hx; ag.y += g.y * hy; ag.z += g.z * hz; ag.w += g.w * hw;
+    ab.x += g.x; ab.y += g.y; ab.z += g.z; ab.w += g.w;
+    const float ex = g.x * ga.x, ey = g.y * ga.y, ez = g.z * ga.z, ew = g.w * ga.w;
+    s1 += (double)ex + (double)ey + (double)ez + (double)ew;
+    s2 += (double)ex * hx + (double)ey * hy + (double)ez * hz + (double)ew * hw;
+  }
+  red[2][rl][cq] = s1; red[3][rl][cq] = s2;
+  pg[0][rl][cq * 4 + 0] = ag.x; pg[0][rl][cq * 4 + 1] = ag.y; pg[0][rl][cq * 4 + 2] = ag.z; pg[0][rl][cq * 4 + 3] = ag.w;
+  pg[1][rl][cq * 4 + 0] = ab.x; pg[1][rl][cq * 4 + 1] = ab.y; pg[1][rl][cq * 4 + 2] = ab.z; pg[1][rl][cq * 4 + 3] = ab.w;
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int r = 0; r < 16; ++r)
+      for (int q = 0; q < 4; ++q) { t1 += red[2][r][threadIdx.x * 4 + q]; t2 += red[3][r][threadIdx.x * 4 + q]; }
+    const double n = 16.0 * L;
+    stat[2][threadIdx.x] = (float)(t1 / n);
+    stat[3][threadIdx.x] = (float)(t2 / n);
+  }
+  if (threadIdx.x < 128) {
+    const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+    float t = 0.f;
+    for (int r = 0; r < 16; ++r) t += pg[which][r][c];
+    atomicAdd((which ? dbeta : dgamma) + c0 + c, t);
+  }
+  __syncthreads();
+  const float m1 = stat[2][cq >> 2], m2 = stat[3][cq >> 2];
+  float* dxp = dx + (int64_t)b * L * lddx + c0 + cq * 4;
+  for (int t = rl; t < L; t += 16) {
+    const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
+    float4 g = *reinterpret_cast<const float4*>(gp + (int64_t)t * lddy);
+    const float hx = (v.x - mean) * rstd, hy = (v.y - mean) * rstd, hz = (v.z - mean) * rstd, hw = (v.w - mean) * rstd;
+    g.x = (hx * ga.x + be.x) > 0.f ? g.x * ga.x : 0.f; g.y = (hy * ga.y + be.y) > 0.f ? g.y * ga.y : 0.f;
+    g.z = (hz * ga.z + be.z) > 0.f ? g.z * ga.z : 0.f; g.w = (hw * ga.w + be.w) > 0.f ? g.w * ga.w : 0.f;
+    *reinterpret_cast<float4*>(dxp + (int64_t)t * lddx) =
+        make_float4(rstd * (g.x - m1 - hx * m2), rstd * (g.y - m1 - hy * m2), rstd * (g.z - m1 - hz * m2),
+                    rstd * (g.w - m1 - hw * m2));
+  }
+}
+
+extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy,
+                                         const float* gamma, const float* beta, float* dx, int64_t lddx,
+                                         float* dgamma, float* dbeta, int B, int L, int C, void* stream) {
+  if (!x || !dy || !gamma || !beta || !dx || !dgamma || !dbeta || B <= 0 || L <= 0 || C <= 0 || (C & 63)) return STYLER_EINVAL;
+  if ((ldx & 3) || (lddy & 3) || (lddx & 3)) return STYLER_EALIGN;
+  hipLaunchKernelGGL(groupnorm_relu_bwd_kernel, dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy,
+                     gamma, beta, dx, lddx, dgamma, dbeta, L, C);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// BatchNorm1d (train) + act backward over rows = B*L (pads included), channels-last contiguous [rows, C].
+//   dz = dy * act'(y); dgamma = sum dz*xh; dbeta = sum dz; dx = g*rstd*(dz - dbeta/N - xh*dgamma/N)
+__global__ __launch_bounds__(128) void bn_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ dy, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, double* __restrict__ ws,
+                                                           int64_t rows, int C, int act, int rows_per_block) {
+  const int nq = C / 4;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block; if (r1 > rows) r1 = rows;
+  for (int q = threadIdx.x; q < nq; q += blockDim.x) {
+    const float4 m = *reinterpret_cast<const float4*>(mean + q * 4);
+    const float4 rs = *reinterpret_cast<const float4*>(rstd + q * 4);
+    double s[4] = {0, 0, 0, 0}, sh[4] = {0, 0, 0, 0};
+    for (int64_t r = r0; r < r1; ++r) {
+      const float4 v = *reinterpret_cast<const float4*>(x + r * C + q * 4);
+      float4 g = *reinterpret_cast<const float4*>(dy + r * C + q * 4);
+      if (act == STYLER_ACT_TANH) {
+        const float4 o = *reinterpret_cast<const float4*>(y + r * C + q * 4);
+        g.x *= 1.f - o.x * o.x; g.y *= 1.f - o.y * o.y; g.z *= 1.f - o.z * o.z; g.w *= 1.f - o.w * o.w;
+      }
+      s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
+      sh[0] += (double)g.x * ((v.x - m.x) * rs.x); sh[1] += (double)g.y * ((v.y - m.y) * rs.y);
+      sh[2] += (double)g.z * ((v.z - m.z) * rs.z); sh[3] += (double)g.w * ((v.w - m.w) * rs.w);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { atomicAdd(&ws[q * 4 + k], s[k]); atomicAdd(&ws[C + q * 4 + k], sh[k]); }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const double* __restrict__ ws, float* __restrict__ dx,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           int64_t rows, int C, int act) {
+  const int nq = C / 4;
+  const int64_t total4 = rows * nq;
+  const double inv_n = 1.0 / (double)rows;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i % nq);
+    const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    float4 g = *reinterpret_cast<const float4*>(dy + i * 4);
+    if (act == STYLER_ACT_TANH) {
+      const float4 o = *reinterpret_cast<const float4*>(y + i * 4);
+      g.x *= 1.f - o.x * o.x; g.y *= 1.f - o.y * o.y; g.z *= 1.f - o.z * o.z; g.w *= 1.f - o.w * o.w;
+    }
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + q * 4);
+    const float4 m = *reinterpret_cast<const float4*>(mean + q * 4);
+    const float4 rs = *reinterpret_cast<const float4*>(rstd + q * 4);
+    float out[4];
+    const float gv[4] = {g.x, g.y, g.z, g.w}, xv[4] = {v.x, v.y, v.z, v.w};
+    const float gav[4] = {ga.x, ga.y, ga.z, ga.w}, mv[4] = {m.x, m.y, m.z, m.w}, rv[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xh = (xv[k] - mv[k]) * rv[k];
+      const float sb = (float)(ws[q * 4 + k] * inv_n), sg = (float)(ws[C + q * 4 + k] * inv_n);
+      out[k] = gav[k] * rv[k] * (gv[k] - sb - xh * sg);
+    }
+    *reinterpret_cast<float4*>(dx + i * 4) = make_float4(out[0], out[1], out[2], out[3]);
+  }
+  // parameter gradients: first C threads of the grid
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < C) { atomicAdd(dbeta + gid, (float)ws[gid]); atomicAdd(dgamma + gid, (float)ws[C + gid]); }
+}
+
+extern "C" int styler_batchnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
+                                    const float* save_mean, const float* save_rstd, float* dx, float* dgamma,
+                                    float* dbeta, double* workspace, int64_t rows, int C, int act, void* stream) {
+  if (!x || !dy || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || C <= 0 ||
+      (C & 3) || (act == STYLER_ACT_TANH && !y))
+    return STYLER_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
+  if (e != hipSuccess) return (int)e;
+  const int rpb = 64;
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(128), 0, st, x, y, dy, save_mean,
+                     save_rstd, workspace, rows, C, act, rpb);
+  const int64_t total4 = rows * C / 4;
+  int64_t blocks = (total4 + 255) / 256; if (blocks > 4096) blocks = 4096;
+  if (blocks * 256 < C) blocks = (C + 255) / 256;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd,
+                     workspace, dx, dgamma, dbeta, rows, C, act);
+  return launch_status();
+}

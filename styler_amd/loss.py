@@ -7,10 +7,13 @@ sum over valid positions / count, accumulated in fp64.  Masks arrive as the refe
 import torch
 import torch.nn as nn
 
+from . import autograd as AG
 from . import ops
 
 
 def _masked_mean(a, b, kind, lens):
+    if torch.is_grad_enabled() and a.requires_grad:
+        return AG.MaskedErrFn.apply(a, b.detach(), kind, lens)
     acc = torch.zeros(2, dtype=torch.float64, device=a.device)
     ops.masked_err_sum(a.contiguous(), b.contiguous(), acc, kind, lens)
     return (acc[0] / acc[1]).float()
@@ -18,8 +21,10 @@ def _masked_mean(a, b, kind, lens):
 
 def _nll3(posteriors, label):
     """3 x NLLLoss(mean) on [B, 2] log-probabilities (loss.py:46-48)."""
-    idx = label.view(-1, 1)
-    return sum(-(p.gather(1, idx)).mean() for p in posteriors)
+    label = label.contiguous()
+    if torch.is_grad_enabled() and any(p.requires_grad for p in posteriors):
+        return sum(AG.NllFn.apply(p, label) for p in posteriors)
+    return sum(ops.nll(p.contiguous(), label) for p in posteriors)
 
 
 class STYLERLoss(nn.Module):

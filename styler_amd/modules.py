@@ -16,6 +16,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import autograd as AG
 from . import hparams as hp
 from . import ops
 from .runtime import rt
@@ -52,7 +53,9 @@ class AugmentationClassifier(_HipModule):
 
     def forward(self, x):
         c = self.classifier
-        h = self._gemm("fc1", x, c.d_fc1)
+        h = self._gemm("fc1", x, c.d_fc1, neg_dx=True)       # GRL: dX of the first Linear is negated (modules.py:61-66)
+        if (self.training and torch.is_grad_enabled()):
+            return AG.AugTailFn.apply(h, c.d_fc2.weight, c)
         return ops.aug_classifier_tail(h, c.d_bn1.weight, c.d_bn1.bias, c.d_fc2.weight, c.d_fc2.bias)
 
 
@@ -75,29 +78,35 @@ class AudioEncoder(_HipModule):
             setattr(self, f"lstm_{s + 1}",
                     nn.LSTM(self.widths[s], self.necks[s], 2, batch_first=True, bidirectional=True))
 
+    def _lstm_weights(self, lstm, layer, key, cin):
+        """Derived tensors of one BiLSTM layer: fused input weights [8H, in] (fp32 or bf16), summed biases
+        [8H] (b_ih + b_hh, forward | reverse), stacked recurrent weights [2, 4H, H]."""
+        d = self._derived
+        names = [f"weight_ih_l{layer}", f"weight_ih_l{layer}_reverse", f"weight_hh_l{layer}",
+                 f"weight_hh_l{layer}_reverse", f"bias_ih_l{layer}", f"bias_hh_l{layer}",
+                 f"bias_ih_l{layer}_reverse", f"bias_hh_l{layer}_reverse"]
+        wi, wir, wh, whr, bi, bh, bir, bhr = [getattr(lstm, n) for n in names]
+        bias = d.get(key + "b", [bi, bh, bir, bhr],
+                     lambda a, b, c, e: torch.cat([a.detach() + b.detach(), c.detach() + e.detach()]))
+        w_hh = d.get(key + "wh", [wh, whr], lambda a, b: torch.stack([a.detach(), b.detach()]).contiguous())
+        if rt.prec == ops.PREC_BF16 and cin % 8 == 0:
+            w = d.get(key + "wi16", [wi, wir], lambda a, b: ops.cast_bf16(torch.cat([a.detach(), b.detach()])))
+            return w, bias, w_hh, ops.PREC_BF16
+        w = d.get(key + "wi", [wi, wir], lambda a, b: torch.cat([a.detach(), b.detach()]))
+        return w, bias, w_hh, ops.PREC_F32
+
     def _lstm(self, s, x):
         """2-layer BiLSTM: per layer one MFMA GEMM for both directions' input projections, then the
         persistent recurrent kernel."""
         lstm = getattr(self, f"lstm_{s + 1}")
         H = self.necks[s]
-        d = self._derived
         for layer in range(2):
-            names = [f"weight_ih_l{layer}", f"weight_ih_l{layer}_reverse", f"weight_hh_l{layer}",
-                     f"weight_hh_l{layer}_reverse", f"bias_ih_l{layer}", f"bias_hh_l{layer}",
-                     f"bias_ih_l{layer}_reverse", f"bias_hh_l{layer}_reverse"]
-            wi, wir, wh, whr, bi, bh, bir, bhr = [getattr(lstm, n) for n in names]
             key = f"lstm{s}_{layer}"
-            w_ih = d.get(key + "wi", [wi, wir], lambda a, b: torch.cat([a.detach(), b.detach()]))
-            bias = d.get(key + "b", [bi, bh, bir, bhr],
-                         lambda a, b, c, e: torch.cat([a.detach() + b.detach(), c.detach() + e.detach()]))
-            w_hh = d.get(key + "wh", [wh, whr], lambda a, b: torch.stack([a.detach(), b.detach()]).contiguous())
-            prec = ops.PREC_F32
-            w = w_ih
-            if rt.prec == ops.PREC_BF16 and x.shape[-1] % 8 == 0:
-                w = d.get(key + "wi16", [wi, wir], lambda a, b: ops.cast_bf16(torch.cat([a.detach(), b.detach()])))
-                prec = ops.PREC_BF16
-            gx = ops.conv_gemm(x, w, bias, n=8 * H, prec=prec)
-            x = ops.lstm_bidir(gx, w_hh, H)
+            if (self.training and torch.is_grad_enabled()):
+                x = AG.LstmLayerFn.apply(x, getattr(lstm, f"weight_ih_l{layer}"), lstm, layer, H, self, key)
+            else:
+                w, bias, w_hh, prec = self._lstm_weights(lstm, layer, key, x.shape[-1])
+                x = ops.lstm_bidir(ops.conv_gemm(x, w, bias, n=8 * H, prec=prec), w_hh, H)
         return x
 
     def forward(self, cat, len_org, seq_len, mask=None, max_seq_len=None):
@@ -112,27 +121,39 @@ class AudioEncoder(_HipModule):
         dev = mel.device
         W = self.widths
         offs = [0, W[0], W[0] + W[1], W[0] + W[1] + W[2]]
-        catbuf = torch.empty(B, T, sum(W), device=dev, dtype=torch.float32)
+        grad = (self.training and torch.is_grad_enabled())
+        catbuf = None if grad else torch.empty(B, T, sum(W), device=dev, dtype=torch.float32)
         err = torch.zeros(1, device=dev, dtype=torch.int32) if rt.strict_inputs else None
+        finals = []
         for s in range(4):
             convs = getattr(self, f"convolutions_{s + 1}")
             x = None
             for i in range(3):
                 conv, gn = convs[i][0].conv, convs[i][1]
                 if i == 0 and s in (1, 2):
-                    wt = self._derived.get(f"oh{s}", [conv.weight],
-                                           lambda w: w.detach().permute(2, 1, 0).contiguous())
-                    y = torch.empty(B, T, W[s], device=dev, dtype=torch.float32)
-                    ops.onehot_conv5(p_norm if s == 1 else e_input, wt, conv.bias, y, err_flag=err)
+                    v = p_norm if s == 1 else e_input
+                    if grad:
+                        y = AG.OnehotConv5Fn.apply(v, conv.weight, conv, self._derived, f"oh{s}", err)
+                    else:
+                        wt = self._derived.get(f"oh{s}", [conv.weight],
+                                               lambda w: w.detach().permute(2, 1, 0).contiguous())
+                        y = torch.empty(B, T, W[s], device=dev, dtype=torch.float32)
+                        ops.onehot_conv5(v, wt, conv.bias, y, err_flag=err)
                 else:
                     src = (mel if s == 0 else mel_aug) if i == 0 else x
                     y = self._gemm(f"c{s}_{i}", src, conv, kw=5)
-                out = catbuf[..., offs[s]:offs[s] + W[s]] if i == 2 else y
-                x = ops.groupnorm_relu(y, gn.weight, gn.bias, out=out)
+                if grad:
+                    x = AG.GroupNormReluFn.apply(y, gn.weight, gn)
+                else:
+                    out = catbuf[..., offs[s]:offs[s] + W[s]] if i == 2 else y
+                    x = ops.groupnorm_relu(y, gn.weight, gn.bias, out=out)
+            finals.append(x)
+        if grad:
+            catbuf = AG.CatFn.apply(*finals)
         if err is not None and int(err.item()) != 0:
             raise AssertionError("quantize_1D_torch: input outside [0, 1] (utils.py:423)")
         S = int(max_seq_len) if max_seq_len is not None else int(seq_len.max().item())
-        cal = ops.mel_calibrate(catbuf, len_org, seq_len, S)
+        cal = AG.MelCalibrateFn.apply(catbuf, len_org, seq_len, S) if grad else ops.mel_calibrate(catbuf, len_org, seq_len, S)
         outs = []
         for s in range(4):
             outs.append(self._lstm(s, cal[..., offs[s]:offs[s] + W[s]]))
@@ -209,11 +230,18 @@ class StylePredictor(_HipModule):
     def forward(self, encoder_output, lens):
         c = self.conv_layer
         k = hp.style_predictor_kernel_size
+        p = hp.style_predictor_dropout
+        grad = (self.training and torch.is_grad_enabled())
+        drop = self.training and p > 0 and not rt.disable_dropout
         h = self._gemm("c1", encoder_output, c.conv1d_1.conv, kw=k, act=ops.ACT_RELU)
-        h = ops.add_layernorm(h, c.layer_norm_1.weight, c.layer_norm_1.bias)
+        h = self._ln(h, None, c.layer_norm_1, None)
+        h = AG.dropout(h, p, self.training)
         h = self._gemm("c2", h, c.conv1d_2.conv, kw=k, act=ops.ACT_RELU)
+        dp, seed = (p, AG.next_dropout_seed()) if drop else (0.0, 0)
+        if grad:
+            return AG.LayerNormDotFn.apply(h, self.linear_layer.weight, c.layer_norm_2, self.linear_layer, lens, dp, seed)
         return ops.add_layernorm(h, c.layer_norm_2.weight, c.layer_norm_2.bias, lens=lens,
-                                 dot_w=self.linear_layer.weight, dot_b=self.linear_layer.bias)
+                                 dot_w=self.linear_layer.weight, dot_b=self.linear_layer.bias, drop_p=dp, drop_seed=seed)
 
 
 def _mlp(in_dim):
@@ -268,11 +296,15 @@ class StyleModeling(_HipModule):
             T = int(max_len) if max_len is not None else int(mel_len.max().item())
             lens = mel_len
             out_len, out_mask = mel_len, ops.length_mask(mel_len, T)
-        lr = ops.length_regulate(encodings, csum, T)                       # [B, T, 1280]
-        t_e, p_e, s_e, e_e, n_e = (lr[..., i * H:(i + 1) * H] for i in range(5))
+        grad = (self.training and torch.is_grad_enabled()) and encodings.requires_grad
+        lr = AG.LengthRegulateFn.apply(encodings, csum, T) if grad else ops.length_regulate(encodings, csum, T)
+        t_e, p_e, s_e, e_e, n_e = (lr[..., i * H:(i + 1) * H] for i in range(5))           # [B, T, 1280] slices
 
         energy_prediction = self.energy_predictor(e_e, lens)
-        p_in = ops.add2(p_e, s_e) if pitch_plus_speaker else p_e
+        if pitch_plus_speaker:
+            p_in = AG.Add2Fn.apply(p_e, s_e) if grad else ops.add2(p_e, s_e)
+        else:
+            p_in = p_e
         pitch_prediction = self.pitch_predictor(p_in, lens)
         if energy_target is not None:
             e_src, e_scale = energy_target.contiguous(), 1.0
@@ -282,10 +314,15 @@ class StyleModeling(_HipModule):
             p_src, p_scale = pitch_target.contiguous(), 1.0
         else:
             p_src, p_scale = pitch_prediction, p_control
-        out, out_noisy = ops.bucket_embed_add(
-            t_e, s_e, p_src, p_scale, e_src, e_scale, self.pitch_bins, self.energy_bins,
-            self.pitch_embedding.weight, self.energy_embedding.weight, noise=n_e if want_noise_sum else None,
-            p_ids=ids[0] if ids else None, e_ids=ids[1] if ids else None)
+        if grad:
+            out, out_noisy = AG.BucketEmbedAddFn.apply(t_e, s_e, n_e if want_noise_sum else None,
+                                                       self.pitch_embedding.weight, p_src.detach(), p_scale,
+                                                       e_src.detach(), e_scale, self)
+        else:
+            out, out_noisy = ops.bucket_embed_add(
+                t_e, s_e, p_src, p_scale, e_src, e_scale, self.pitch_bins, self.energy_bins,
+                self.pitch_embedding.weight, self.energy_embedding.weight, noise=n_e if want_noise_sum else None,
+                p_ids=ids[0] if ids else None, e_ids=ids[1] if ids else None)
         if energy_target is None and e_control != 1.0:
             energy_prediction = energy_prediction * e_control
         if pitch_target is None and p_control != 1.0:
@@ -298,8 +335,11 @@ class StyleModeling(_HipModule):
                 d_control=1.0, p_control=1.0, e_control=1.0):
         B, S = text.shape
         H = hp.encoder_hidden
-        encodings = torch.empty(B, S, 5 * H, device=text.device, dtype=torch.float32)
-        sl = [encodings[..., i * H:(i + 1) * H] for i in range(5)]
+        grad = (self.training and torch.is_grad_enabled())
+        # eval: the five encodings are written straight into channel slices of one [B, S, 1280] buffer;
+        # under autograd they are separate tape tensors joined by CatFn (backward = slice views)
+        encodings = None if grad else torch.empty(B, S, 5 * H, device=text.device, dtype=torch.float32)
+        sl = [None] * 5 if grad else [encodings[..., i * H:(i + 1) * H] for i in range(5)]
 
         (text_encoding, text_encoding_neck, speaker_encoding_p, speaker_encoding, duration_encoding,
          pitch_encoding, energy_encoding, noise_encoding) = self.style_encoder(
@@ -315,16 +355,29 @@ class StyleModeling(_HipModule):
         self.pitch_encoding = pitch_encoding
         self.speaker_encoding = speaker_encoding.unsqueeze(1).expand(-1, S, -1)
         self.speaker_encoding_p = speaker_encoding_p.unsqueeze(1).expand(-1, S, -1)
-        pitch_in = ops.add_rowvec(pitch_encoding, speaker_encoding_p, S)
 
-        text_neck_up = self._gemm("tlu", text_encoding_neck, self.text_linear_up[0], act=ops.ACT_RELU)
-        duration_up = self._mlp2("dl", self.duration_linear, duration_encoding)
-        dp_in = ops.add2(text_neck_up, duration_up)
-        self._mlp2("pl", self.pitch_linear, pitch_in, res=text_neck_up, out=sl[1])
-        ops.add_rowvec(None, speaker_encoding, S, out=sl[2])
-        energy_up = self._mlp2("el", self.energy_linear, energy_encoding)
-        ops.add2(text_neck_up, energy_up, out=sl[3])
-        self._mlp2("rl", self.residual_linear, noise_encoding, out=sl[4])
+        if grad:
+            pitch_in = AG.AddRowvecFn.apply(pitch_encoding, speaker_encoding_p, S)
+            text_neck_up = self._gemm("tlu", text_encoding_neck, self.text_linear_up[0], act=ops.ACT_RELU)
+            duration_up = self._mlp2("dl", self.duration_linear, duration_encoding)
+            dp_in = AG.Add2Fn.apply(text_neck_up, duration_up)
+            sl[0] = text_encoding
+            sl[1] = self._mlp2("pl", self.pitch_linear, pitch_in, res=text_neck_up)
+            sl[2] = AG.AddRowvecFn.apply(None, speaker_encoding, S)
+            energy_up = self._mlp2("el", self.energy_linear, energy_encoding)
+            sl[3] = AG.Add2Fn.apply(text_neck_up, energy_up)
+            sl[4] = self._mlp2("rl", self.residual_linear, noise_encoding)
+            encodings = AG.CatFn.apply(*sl)
+        else:
+            pitch_in = ops.add_rowvec(pitch_encoding, speaker_encoding_p, S)
+            text_neck_up = self._gemm("tlu", text_encoding_neck, self.text_linear_up[0], act=ops.ACT_RELU)
+            duration_up = self._mlp2("dl", self.duration_linear, duration_encoding)
+            dp_in = ops.add2(text_neck_up, duration_up)
+            self._mlp2("pl", self.pitch_linear, pitch_in, res=text_neck_up, out=sl[1])
+            ops.add_rowvec(None, speaker_encoding, S, out=sl[2])
+            energy_up = self._mlp2("el", self.energy_linear, energy_encoding)
+            ops.add2(text_neck_up, energy_up, out=sl[3])
+            self._mlp2("rl", self.residual_linear, noise_encoding, out=sl[4])
 
         # for the inspection (modules.py:341-348)
         self.text_encoding_neck = text_neck_up

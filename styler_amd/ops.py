@@ -115,7 +115,7 @@ def attention_fwd(qkv, lens, lse=None):
     return out
 
 
-def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, dot_b=None):
+def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, dot_b=None, drop_p=0.0, drop_seed=0):
     """LayerNorm(x + res) with pad-mask; with dot_w returns the [B, L] scalar head instead."""
     B, L, C = x.shape
     dot_out = None
@@ -126,7 +126,8 @@ def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, 
     _chk(lib.styler_add_layernorm(x.data_ptr(), _ld(x), _ptr(res), _ld(res) if res is not None else 0,
                                   gamma.data_ptr(), beta.data_ptr(), _ptr(out),
                                   _ld(out) if out is not None else 0, _ptr(dot_w), _ptr(dot_b),
-                                  _ptr(dot_out), B, L, C, _ptr(lens), _stream()), "styler_add_layernorm")
+                                  _ptr(dot_out), B, L, C, _ptr(lens), float(drop_p), int(drop_seed), _stream()),
+         "styler_add_layernorm")
     return dot_out if dot_w is not None else out
 
 
@@ -301,3 +302,209 @@ def masked_err_sum(a, b, acc, kind, lens):
     _chk(lib.styler_masked_err_sum(a.data_ptr(), lda, b.data_ptr(), ldb, acc.data_ptr(), kind, B, L, C,
                                    _ptr(lens), _stream()), "styler_masked_err_sum")
     return acc
+
+
+# ======================================================================================
+# backward / training wrappers
+# ======================================================================================
+def _rows_view(t):
+    """Make a [.., C] gradient usable by the kernels: contiguous channels and uniform row stride."""
+    if t.stride(-1) != 1 and t.shape[-1] != 1:
+        return t.contiguous()
+    if t.dim() == 3 and t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.stride(1):
+        return t.contiguous()
+    if t.dim() == 3 and (t.stride(1) & 3 or t.data_ptr() & 15):
+        return t.contiguous()
+    return t
+
+
+def act_bwd(dy, y, act, lens=None):
+    dy = _rows_view(dy)
+    B, L, C = dy.shape
+    dz = torch.empty(B, L, C, device=dy.device, dtype=torch.float32)
+    _chk(lib.styler_act_bwd(dy.data_ptr(), _ld(dy), _ptr(y), _ld(y) if y is not None else 0, dz.data_ptr(), C, B, L, C,
+                            act, _ptr(lens), _stream()), "styler_act_bwd")
+    return dz
+
+
+def wgrad(dz, x, dw, stride_n, stride_c, n, cin, shift=0, dw_offset=0):
+    """dw (fp32 tensor, parameter layout) += dz^T x with an optional time shift of x."""
+    B, L = dz.shape[0], dz.shape[1]
+    _chk(lib.styler_wgrad(dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), dw.data_ptr() + 4 * dw_offset, stride_n,
+                          stride_c, B, L, n, cin, shift, _stream()), "styler_wgrad")
+
+
+def colsum(dz, out, out2=None):
+    C = dz.shape[-1]
+    rows = dz.numel() // C
+    _chk(lib.styler_colsum(dz.data_ptr(), _ld(dz), out.data_ptr(), _ptr(out2), rows, C, _stream()), "styler_colsum")
+
+
+def repack_weight_bwd(w):
+    """parameter layout [n, cin, kw] (or [n, cin]) -> dX-conv weight [cin, kw*n] (taps flipped)."""
+    if w.dim() == 2:
+        n, cin, kw = w.shape[0], w.shape[1], 1
+    else:
+        n, cin, kw = w.shape
+    dst = torch.empty(cin, kw * n, device=w.device, dtype=torch.float32)
+    _chk(lib.styler_repack_weight_bwd(w.data_ptr(), dst.data_ptr(), n, cin, kw, _stream()), "styler_repack_weight_bwd")
+    return dst
+
+
+def attention_bwd(qkv, out, dout, lse, lens):
+    B, L, _ = qkv.shape
+    dout = dout.contiguous()
+    dqkv = torch.empty_like(qkv)
+    ws = torch.empty(B * 4 * L, device=qkv.device, dtype=torch.float32)
+    _chk(lib.styler_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                  ws.data_ptr(), B, L, _ptr(lens), _stream()), "styler_attention_bwd")
+    return dqkv
+
+
+def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, dot_w=None, dout=None, ddot_w=None,
+                  ddot_b=None, drop_p=0.0, drop_seed=0):
+    B, L, C = x.shape
+    dx = torch.empty(B, L, C, device=x.device, dtype=torch.float32) if need_dx else None
+    if dy is not None:
+        dy = _rows_view(dy)
+    if dout is not None:
+        dout = dout.contiguous()
+    _chk(lib.styler_layernorm_bwd(x.data_ptr(), _ld(x), _ptr(dy), _ld(dy) if dy is not None else 0, gamma.data_ptr(),
+                                  _ptr(beta), _ptr(dx), C, dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dot_w),
+                                  _ptr(dout), _ptr(ddot_w), _ptr(ddot_b), B, L, C, _ptr(lens), float(drop_p),
+                                  int(drop_seed), _stream()), "styler_layernorm_bwd")
+    return dx
+
+
+def groupnorm_relu_bwd(x, dy, gamma, beta, dgamma, dbeta):
+    B, L, C = x.shape
+    dy = _rows_view(dy)
+    dx = torch.empty(B, L, C, device=x.device, dtype=torch.float32)
+    _chk(lib.styler_groupnorm_relu_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), gamma.data_ptr(), beta.data_ptr(),
+                                       dx.data_ptr(), C, dgamma.data_ptr(), dbeta.data_ptr(), B, L, C, _stream()),
+         "styler_groupnorm_relu_bwd")
+    return dx
+
+
+def batchnorm_bwd(x, y, dy, gamma, mean, rstd, dgamma, dbeta, act):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dy = dy.contiguous()
+    dx = torch.empty_like(x)
+    ws = torch.empty(2 * C, device=x.device, dtype=torch.float64)
+    _chk(lib.styler_batchnorm_bwd(x.data_ptr(), _ptr(y), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                  rstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
+                                  rows, C, act, _stream()), "styler_batchnorm_bwd")
+    return dx
+
+
+def embed_bwd(text, dy, demb):
+    dy = _rows_view(dy)
+    B, L = text.shape
+    _chk(lib.styler_embed_bwd(text.data_ptr(), dy.data_ptr(), _ld(dy), demb.data_ptr(), B, L, demb.shape[1], _stream()),
+         "styler_embed_bwd")
+
+
+def onehot_conv5_bwd(v, dy, dw, db):
+    dy = _rows_view(dy)
+    B, L = v.shape
+    _chk(lib.styler_onehot_conv5_bwd(v.data_ptr(), dy.data_ptr(), _ld(dy), dw.data_ptr(), db.data_ptr(), B, L,
+                                     db.numel(), _stream()), "styler_onehot_conv5_bwd")
+
+
+def mel_calibrate_bwd(dy, mel_len, src_len, T):
+    dy = _rows_view(dy)
+    B, S, C = dy.shape
+    dx = torch.empty(B, T, C, device=dy.device, dtype=torch.float32)
+    _chk(lib.styler_mel_calibrate_bwd(dy.data_ptr(), _ld(dy), dx.data_ptr(), C, mel_len.data_ptr(), src_len.data_ptr(),
+                                      B, T, S, C, _stream()), "styler_mel_calibrate_bwd")
+    return dx
+
+
+def lstm_bidir_bwd(dout, gates, cell, w_hh, H):
+    dout = dout.contiguous()
+    B, S, _ = dout.shape
+    dgp = torch.empty(B, S, 8 * H, device=dout.device, dtype=torch.float32)
+    _chk(lib.styler_lstm_bidir_bwd(dout.data_ptr(), gates.data_ptr(), cell.data_ptr(), w_hh.data_ptr(), dgp.data_ptr(),
+                                   B, S, H, _stream()), "styler_lstm_bidir_bwd")
+    return dgp
+
+
+def aug_classifier_tail_bwd(h, ln_g, ln_b, w2, b2, dout, dln_g, dln_b, dw2, db2):
+    B, S, _ = h.shape
+    dh = torch.empty_like(h)
+    dout = dout.contiguous()
+    _chk(lib.styler_aug_classifier_tail_bwd(h.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                            dout.data_ptr(), dh.data_ptr(), dln_g.data_ptr(), dln_b.data_ptr(),
+                                            dw2.data_ptr(), db2.data_ptr(), B, S, _stream()),
+         "styler_aug_classifier_tail_bwd")
+    return dh
+
+
+def length_regulate_bwd(dy, csum, S):
+    dy = _rows_view(dy)
+    B, T, C = dy.shape
+    dx = torch.empty(B, S, C, device=dy.device, dtype=torch.float32)
+    _chk(lib.styler_length_regulate_bwd(dy.data_ptr(), _ld(dy), csum.data_ptr(), dx.data_ptr(), C, B, S, T, C,
+                                        _stream()), "styler_length_regulate_bwd")
+    return dx
+
+
+def bucket_embed_bwd(dy, p_ids, e_ids, dpitch_emb, denergy_emb):
+    dy = dy.contiguous()
+    B, T, _ = dy.shape
+    _chk(lib.styler_bucket_embed_bwd(dy.data_ptr(), p_ids.data_ptr(), e_ids.data_ptr(), dpitch_emb.data_ptr(),
+                                     denergy_emb.data_ptr(), B, T, _stream()), "styler_bucket_embed_bwd")
+
+
+def rowsum(x, out=None, accumulate=False):
+    x = _rows_view(x)
+    B, L, C = x.shape
+    if out is None:
+        out = torch.empty(B, C, device=x.device, dtype=torch.float32)
+    _chk(lib.styler_rowsum(x.data_ptr(), _ld(x), out.data_ptr(), out.stride(0), B, L, C, int(accumulate), _stream()),
+         "styler_rowsum")
+    return out
+
+
+def masked_err_bwd(a, b, acc, gscale, kind, lens):
+    if a.dim() == 2:
+        B, L = a.shape
+        C, lda, ldb = 1, 1, 1
+    else:
+        B, L, C = a.shape
+        lda, ldb = _ld(a), _ld(b)
+    da = torch.empty(a.shape, device=a.device, dtype=torch.float32)
+    _chk(lib.styler_masked_err_bwd(a.data_ptr(), lda, b.data_ptr(), ldb, acc.data_ptr(), gscale.data_ptr(),
+                                   da.data_ptr(), kind, B, L, C, _ptr(lens), _stream()), "styler_masked_err_bwd")
+    return da
+
+
+def nll(logp, label, gscale=None, want_grad=False):
+    B = logp.shape[0]
+    loss = torch.empty(1, device=logp.device, dtype=torch.float32) if not want_grad else None
+    dlogp = torch.empty_like(logp) if want_grad else None
+    _chk(lib.styler_nll(logp.data_ptr(), label.data_ptr(), _ptr(loss), _ptr(gscale), _ptr(dlogp), B, _stream()),
+         "styler_nll")
+    return dlogp if want_grad else loss[0]
+
+
+def dropout(x, p, seed):
+    x = _rows_view(x)
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    _chk(lib.styler_dropout(x.data_ptr(), _ld(x), y.data_ptr(), C, rows, C, float(p), int(seed), _stream()),
+         "styler_dropout")
+    return y
+
+
+def sumsq(flat, out):
+    _chk(lib.styler_sumsq(flat.data_ptr(), flat.numel(), out.data_ptr(), _stream()), "styler_sumsq")
+    return out
+
+
+def adam_step(p, g, m, v, sumsq_buf, max_norm, lr, beta1, beta2, eps, step):
+    _chk(lib.styler_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), _ptr(sumsq_buf),
+                              float(max_norm), float(lr), float(beta1), float(beta2), float(eps), int(step), _stream()),
+         "styler_adam_step")

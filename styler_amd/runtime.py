@@ -6,6 +6,11 @@ class _Runtime:
     def __init__(self):
         self.prec = ops.PREC_F32        # PREC_F32: exact-fp32 MFMA (parity mode); PREC_BF16: throughput mode
         self.strict_inputs = True       # raise like the reference's assert on p_norm / e_input outside [0, 1]
+        self.weights_epoch = 0          # bumped by TrainState.step(): invalidates every derived weight layout
+        self.seed = 0                   # dropout stream seed (train.py:22 seeds torch with 0)
+        self.dropout_calls = 0          # per-call counter mixed into the seed
+        self.disable_dropout = False    # parity tests: train-mode BatchNorm / tape, dropout off (RNG streams
+                                        # of the reference cannot be reproduced)
 
     def set_precision(self, name):
         self.prec = {"fp32": ops.PREC_F32, "bf16": ops.PREC_BF16}[name]
@@ -23,7 +28,7 @@ class Derived:
         self._store = {}
 
     def get(self, key, srcs, fn):
-        ver = tuple((s.data_ptr(), s._version) for s in srcs)
+        ver = (rt.weights_epoch,) + tuple((s.data_ptr(), s._version) for s in srcs)
         ent = self._store.get(key)
         if ent is None or ent[0] != ver:
             import torch

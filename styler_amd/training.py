@@ -1,0 +1,100 @@
+"""Training step of the path (reference train.py:99-186): forward (clean + noisy decode), clean losses,
+noisy mel losses, DAT pass + DAT loss, backward (HIP kernels through the autograd tape), gradient all-reduce,
+clip_grad_norm_(1.0) + Adam with the Noam schedule -- the last two fused over FLAT fp32 buffers."""
+import torch
+
+from . import hparams as hp
+from . import ops
+from .dist import allreduce_mean_
+from .loss import DomainAdversarialTrainingLoss, STYLERLoss
+from .runtime import rt
+
+
+class TrainState:
+    """Flat fp32 parameter / gradient / Adam-moment buffers.  Every trainable nn.Parameter becomes a view of
+    `flat_p`, its `.grad` a view of `flat_g` (so the backward kernels' atomics, the RCCL all-reduce, the global
+    norm and the Adam update all run over one contiguous 117.9 MB buffer)."""
+
+    def __init__(self, model, restore_step=0):
+        params = [p for p in model.parameters() if p.requires_grad]
+        align = lambda k: (k + 3) & ~3                  # every view starts 16-byte aligned (float4 / MFMA staging loads)
+        n = sum(align(p.numel()) for p in params)
+        dev = params[0].device
+        self.flat_p = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.flat_m = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.flat_v = torch.zeros(n, device=dev, dtype=torch.float32)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                self.flat_p[off:off + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat_p[off:off + k].view(p.shape)
+                p.grad = self.flat_g[off:off + k].view(p.shape)
+                off += align(k)
+        self.params = params
+        self.n = n
+        self.n_current_steps = restore_step            # optimizer.py:10
+        self.sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def lr(self):
+        """optimizer.py:21-32: the counter is incremented BEFORE the rate is computed."""
+        self.n_current_steps += 1
+        s = self.n_current_steps
+        return hp.encoder_hidden ** -0.5 * min(s ** -0.5, hp.n_warm_up_step ** -1.5 * s)
+
+    def step(self):
+        """nn.utils.clip_grad_norm_(params, 1.0) + ScheduledOptim.step_and_update_lr() (train.py:181-185)."""
+        for w in allreduce_mean_(self.flat_g):
+            w.wait()
+        lr = self.lr()
+        self.sumsq.zero_()
+        ops.sumsq(self.flat_g, self.sumsq)
+        ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.sumsq, hp.grad_clip_thresh, lr,
+                      hp.betas[0], hp.betas[1], hp.eps, self.n_current_steps)
+        rt.weights_epoch += 1       # the flat update bypasses torch's version counters: invalidate derived layouts
+        return lr
+
+    def grad_norm(self):
+        self.sumsq.zero_()
+        ops.sumsq(self.flat_g, self.sumsq)
+        return float(self.sumsq.sqrt().item())
+
+
+def train_losses(model, batch, loss_fn=None, dat_fn=None):
+    """The ten scalars of one step (total first), train.py:135-160.  `batch` holds CUDA tensors."""
+    loss_fn = loss_fn or STYLERLoss()
+    dat_fn = dat_fn or DomainAdversarialTrainingLoss()
+    B = batch["text"].shape[0]
+    S, T = batch["text"].shape[1], batch["mel_target"].shape[1]
+    dev = batch["text"].device
+    out = model(batch["text"], batch["mel_target"], batch["mel_aug"], batch["f0_norm"], batch["energy_input"],
+                batch["src_len"], batch["mel_len"], batch["D"], batch["f0"], batch["energy"], S, T,
+                speaker_embed=batch["speaker_embed"])
+    (mel, mel_n), (post, post_n), log_d, p_pred, e_pred, src_mask, mel_mask, _, aug = out
+    zeros = torch.zeros(B, dtype=torch.long, device=dev)
+    ones = torch.ones(B, dtype=torch.long, device=dev)
+    mel_l, post_l, d_l, p_l, e_l, cls = loss_fn(log_d, batch["log_D"], p_pred, batch["f0"], e_pred, batch["energy"],
+                                                mel, post, batch["mel_target"], ~src_mask, ~mel_mask,
+                                                batch["src_len"], batch["mel_len"], aug, zeros)
+    mel_nl, post_nl = loss_fn.cal_mel_loss(mel_n, post_n, batch["mel_aug"], ~mel_mask, batch["mel_len"])
+    se = model.style_modeling.style_encoder
+    enc_cat = se.encoder_input_cat(batch["mel_aug"], batch["f0_norm_aug"], batch["energy_input_aug"], batch["mel_aug"])
+    d, p, e, _ = se.audio_encoder(enc_cat, batch["mel_len"], batch["src_len"], mask=None, max_seq_len=S)
+    sm = model.style_modeling
+    cls_dat = dat_fn((sm.augmentation_classifier_d(d), sm.augmentation_classifier_p(p),
+                      sm.augmentation_classifier_e(e)), ones)
+    total = mel_l + post_l + mel_nl + post_nl + d_l + p_l + e_l + hp.dat_weight * (cls + cls_dat)
+    return total, mel_l, post_l, mel_nl, post_nl, d_l, p_l, e_l, cls, cls_dat
+
+
+def train_step(model, state, batch, loss_fn=None, dat_fn=None):
+    """One optimisation step (train.py:135-186).  Returns the 10 loss scalars (device tensors) and the lr."""
+    state.zero_grad()
+    losses = train_losses(model, batch, loss_fn, dat_fn)
+    (losses[0] / hp.acc_steps).backward()
+    lr = state.step()
+    return losses, lr

@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from . import hparams as hp
+from . import autograd as AG
 from . import ops
 from .runtime import Derived, gemm_weight, rt
 
@@ -23,17 +24,30 @@ def get_sinusoid_encoding_table(n_position, d_hid, padding_idx=None):
 
 
 class _HipModule(nn.Module):
+    """Base of the HIP-backed modules.  The autograd tape (HIP backward kernels) is recorded only in train()
+    mode with grad enabled; eval() forwards are inference-only and use the fully fused kernels."""
+
     def __init__(self):
         super().__init__()
         object.__setattr__(self, "_derived", Derived())
 
     def _gemm(self, key, x, lin, *, kw=1, act=ops.ACT_NONE, res=None, out=None, lens=None, scale=None,
-              shift=None):
-        """conv_gemm with the weight of an nn.Linear / nn.Conv1d parameter holder."""
+              shift=None, neg_dx=False):
+        """conv_gemm with the weight of an nn.Linear / nn.Conv1d parameter holder.  Under autograd the call
+        goes through ConvGemmFn (HIP backward: dX conv, wgrad, bias column sums)."""
+        if (self.training and torch.is_grad_enabled()) and (lin.weight.requires_grad or x.requires_grad):
+            assert out is None and scale is None and shift is None and lens is None
+            return AG.ConvGemmFn.apply(x, res, lin.weight, lin.bias, self._derived, key, kw, act, neg_dx)
         w, prec = gemm_weight(self._derived, key, lin.weight, x.shape[-1])
         bias = lin.bias if shift is None else shift
         return ops.conv_gemm(x, w, bias, kw=kw, n=lin.weight.shape[0], act=act, prec=prec, scale=scale, res=res,
                              out=out, lens=lens)
+
+    def _ln(self, x, res, ln, lens, out=None):
+        """LayerNorm(x + res) + pad mask, tape-aware."""
+        if (self.training and torch.is_grad_enabled()) and (x.requires_grad or ln.weight.requires_grad):
+            return AG.LayerNormFn.apply(x, res, ln.weight, ln, lens)
+        return ops.add_layernorm(x, ln.weight, ln.bias, res=res, lens=lens, out=out)
 
 
 class MultiHeadAttention(_HipModule):
@@ -63,12 +77,19 @@ class MultiHeadAttention(_HipModule):
         return w, b, ops.PREC_F32
 
     def forward(self, x, lens, out=None):
-        """x [B, L, 256]; lens int64 [B]; returns LayerNorm(fc(attn) + x) with padded rows zeroed
-        (the masked_fill of Layers.py:29 is fused here)."""
-        w, b, prec = self._qkv()
-        qkv = ops.conv_gemm(x, w, b, n=768, prec=prec)
-        ctx = ops.attention_fwd(qkv, lens)
-        o = self._gemm("fc", ctx, self.fc, res=x)
+        """x [B, L, 256]; lens int64 [B]; returns LayerNorm(dropout(fc(attn)) + x) with padded rows zeroed
+        (the masked_fill of Layers.py:29 is fused into the LayerNorm kernel)."""
+        grad = (self.training and torch.is_grad_enabled())
+        drop = self.training and self.dropout.p > 0
+        if grad:
+            ctx = AG.QkvAttentionFn.apply(x, self.w_qs.weight, self, lens)
+        else:
+            w, b, prec = self._qkv()
+            ctx = ops.attention_fwd(ops.conv_gemm(x, w, b, n=768, prec=prec), lens)
+        if grad or drop:
+            o = AG.dropout(self._gemm("fc", ctx, self.fc), self.dropout.p, self.training)
+            return self._ln(o, x, self.layer_norm, lens, out)
+        o = self._gemm("fc", ctx, self.fc, res=x)            # eval: residual rides in the GEMM epilogue
         return ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out)
 
 
@@ -84,8 +105,12 @@ class PositionwiseFeedForward(_HipModule):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x, lens, out=None):
-        h = self._gemm("w_1", x, self.w_1, kw=hp.fft_conv1d_kernel_size[0], act=ops.ACT_RELU)
-        o = self._gemm("w_2", h, self.w_2, kw=hp.fft_conv1d_kernel_size[1], res=x)
+        k = hp.fft_conv1d_kernel_size
+        h = self._gemm("w_1", x, self.w_1, kw=k[0], act=ops.ACT_RELU)
+        if (self.training and torch.is_grad_enabled()) or (self.training and self.dropout.p > 0):
+            o = AG.dropout(self._gemm("w_2", h, self.w_2, kw=k[1]), self.dropout.p, self.training)
+            return self._ln(o, x, self.layer_norm, lens, out)
+        o = self._gemm("w_2", h, self.w_2, kw=k[1], res=x)
         return ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out)
 
 
@@ -131,7 +156,11 @@ class Encoder(nn.Module, _PositionMixin):
             [FFTBlock(d_model, d_inner, n_head, d_k, d_v, dropout=dropout) for _ in range(n_layers)])
 
     def forward(self, src_seq, lens, out=None):
-        x = ops.embed_pos(src_seq, self.src_word_emb.weight, self._pe(src_seq.shape[1], src_seq.device))
+        pe = self._pe(src_seq.shape[1], src_seq.device)
+        if (self.training and torch.is_grad_enabled()) and self.src_word_emb.weight.requires_grad:
+            x = AG.EmbedPosFn.apply(src_seq, self.src_word_emb.weight, self.src_word_emb, pe)
+        else:
+            x = ops.embed_pos(src_seq, self.src_word_emb.weight, pe)
         for i, layer in enumerate(self.layer_stack):
             x = layer(x, lens, out=out if i == len(self.layer_stack) - 1 else None)
         return x
@@ -151,7 +180,8 @@ class Decoder(nn.Module, _PositionMixin):
             [FFTBlock(d_model, d_inner, n_head, d_k, d_v, dropout=dropout) for _ in range(n_layers)])
 
     def forward(self, enc_seq, lens):
-        x = ops.add_pos(enc_seq, self._pe(enc_seq.shape[1], enc_seq.device))
+        pe = self._pe(enc_seq.shape[1], enc_seq.device)
+        x = AG.AddPosFn.apply(enc_seq, pe) if ((self.training and torch.is_grad_enabled()) and enc_seq.requires_grad) else ops.add_pos(enc_seq, pe)
         for layer in self.layer_stack:
             x = layer(x, lens)
         return x
@@ -195,10 +225,16 @@ class PostNet(_HipModule):
             act = ops.ACT_NONE if last else ops.ACT_TANH
             if self.training:
                 y = self._gemm(f"c{i}", x, conv, kw=self.kernel_size)
-                y, _, _ = ops.batchnorm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, act)
+                if (self.training and torch.is_grad_enabled()):
+                    y = AG.BatchNormActFn.apply(y, bn.weight, bn, act)
+                else:
+                    y, _, _ = ops.batchnorm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, act)
                 with torch.no_grad():
                     bn.num_batches_tracked += 1
-                x = ops.add2(y, add_residual) if (last and add_residual is not None) else y
+                y = AG.dropout(y, 0.5, True)                     # F.dropout(.., 0.5, self.training), Layers.py:126-128
+                if last and add_residual is not None:
+                    y = AG.Add2Fn.apply(y, add_residual) if (self.training and torch.is_grad_enabled()) else ops.add2(y, add_residual)
+                x = y
             else:
                 scale, shift = self._derived.get(
                     f"bn{i}", [bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.bias],
