@@ -38,7 +38,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=48)
     ap.add_argument("--prec", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--mode", default="fwd", choices=["fwd"])
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
+                    help="fwd: C2 eval forward; train: full reference step (dual decode + DAT pass + losses + backward "
+                         "+ grad all-reduce + clip + Adam), train.py:135-186")
     ap.add_argument("--dual", action="store_true", help="also run the noisy-branch decode (styler.py:55)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -68,8 +70,10 @@ def main():
     from closed_form import make_batch
 
     torch.manual_seed(0)                       # identical random-init weights on every rank
-    model = styler_amd.STYLER().to(dev).eval()
-    model.clean_only = not args.dual
+    train = args.mode == "train"
+    model = styler_amd.STYLER().to(dev)
+    model = model.train() if train else model.eval()
+    model.clean_only = (not args.dual) and not train
     rt.set_precision(args.prec)
     rt.strict_inputs = False                   # no host sync inside the forward
 
@@ -78,7 +82,14 @@ def main():
     S, T = batch["text"].shape[1], batch["mel_target"].shape[1]
     bd = {k: v.to(dev) for k, v in batch.items()}
 
+    if train:
+        from styler_amd.training import TrainState, train_step
+        state = TrainState(model)
+        args.no_graph = True                   # the tape-driven step launches eagerly (lr / step count are host scalars)
+
     def step():
+        if train:
+            return train_step(model, state, bd)
         return model(bd["text"], bd["mel_target"], bd["mel_aug"], bd["f0_norm"], bd["energy_input"],
                      bd["src_len"], bd["mel_len"], bd["D"], bd["f0"], bd["energy"], S, T,
                      speaker_embed=bd["speaker_embed"])
@@ -89,7 +100,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
+    with (torch.enable_grad() if train else torch.no_grad()):
         for _ in range(3):                      # builds derived weights (bf16 shadows etc.)
             out = step()
         torch.cuda.synchronize()
@@ -145,22 +156,25 @@ def main():
                     "gemm_ms_per_step_all_variants": round(sum(v["ms"] for v in gsum.values()) / max(1, args.prof_steps), 3)}
         cpu = None
         if not args.no_cpu:
-            cpu = cpu_baseline(model, batch, S, T, not args.dual)
+            cpu = cpu_baseline(model, batch, S, T, model.clean_only, train=train)
         print(json.dumps({
             "metric": "mel_frames_per_sec", "value": round(value, 1),
             "unit": "valid mel-frames/s (80-bin mel, whole job)", "per_gpu": round(value / world, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.prec,
             "data": "synthetic (seeded VCTK-shape batch, random-init weights)",
-            "config": {"workload": f"C2: STYLER.forward eval teacher-forced, {'dual' if args.dual else 'clean'}-branch, "
-                                   f"B={args.batch}/GPU, S={S}, T={T}, valid frames={frames}/GPU",
+            "config": {"workload": (f"C3 per-rank: full train step (dual decode + DAT pass + 10 losses + backward + "
+                                    f"grad all-reduce + clip + Adam), B={args.batch}/GPU, S={S}, T={T}, valid frames="
+                                    f"{frames}/GPU" if train else
+                                    f"C2: STYLER.forward eval teacher-forced, {'dual' if args.dual else 'clean'}-branch, "
+                                    f"B={args.batch}/GPU, S={S}, T={T}, valid frames={frames}/GPU"),
                        "launch": "eager" if graph is None else "hipGraph replay", "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu}))
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(model, batch, S, T, clean_only, sample_items=16, max_threads=16):
+def cpu_baseline(model, batch, S, T, clean_only, sample_items=16, max_threads=16, train=False):
     """Oracle forward (PyTorch-CPU eager fp32) on a bounded sample of the same workload: the first
     `sample_items` utterances of the batch, re-padded to their own max lengths, 1 warm-up + timed runs
     bounded to ~20 s.  Threads are capped (torch's intra-op pool degrades badly past ~16 threads on the
@@ -178,7 +192,16 @@ def cpu_baseline(model, batch, S, T, clean_only, sample_items=16, max_threads=16
         sb[k] = sb[k][:, :T2]
     frames = int(sb["mel_len"].sum())
 
+    if train:
+        sd = {k: (v.requires_grad_(True) if v.is_floating_point() and "position_enc" not in k and "_bins" not in k
+                  and "running_" not in k else v) for k, v in sd.items()}
+
     def run():
+        if train:                              # forward + DAT pass + losses + backward (no optimiser) on the CPU port
+            for v in sd.values():
+                v.grad = None
+            O.train_losses(sd, sb, training=True)[0].backward()
+            return
         with torch.no_grad():
             O.styler_forward(sd, sb["text"], sb["mel_target"], sb["mel_aug"], sb["f0_norm"], sb["energy_input"],
                              sb["src_len"], sb["mel_len"], sb["D"], sb["f0"], sb["energy"], S2, T2,
@@ -187,7 +210,7 @@ def cpu_baseline(model, batch, S, T, clean_only, sample_items=16, max_threads=16
     run()
     warm = time.perf_counter() - t0
     n, t0 = 0, time.perf_counter()
-    while n < 5 and (time.perf_counter() - t0) + warm < 20.0:
+    while n < 5 and (time.perf_counter() - t0) + warm < 20.0 and warm < 15.0:
         run()
         n += 1
     dt = (time.perf_counter() - t0) / n if n else warm

@@ -224,13 +224,16 @@ int styler_stft_mel(const float* wav, int64_t ldw, const void* basis, const floa
 int styler_act_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, float* dz,
                    int64_t lddz, int B, int L, int C, int act, const int64_t* len, void* stream);
 
-/* Weight gradient of Linear / one Conv1d tap (autograd of SubLayers.py:41-43,72-76 etc.):
- * dw[nn*stride_n + c*stride_c] += sum_{b,t} dz[b,t,nn] * x[b,t+shift,c] (x = 0 outside the
- * item).  Exact-fp32 MFMA, split over rows with atomics.  Linear: shift 0, strides (cin, 1);
- * conv tap j of a [n, cin, kw] weight: shift j - kw/2, dw + j, strides (cin*kw, kw). */
-int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw,
-                 int64_t stride_n, int64_t stride_c, int B, int L, int n, int cin, int shift,
-                 void* stream);
+/* Weight (+ bias) gradient of Linear / Conv1d, all kw taps in one launch (autograd of
+ * SubLayers.py:41-43,72-76 etc.):
+ *   dw[nn*stride_n + c*stride_c + j*stride_j] += sum_{b,t} dz[b,t,nn] * x[b, t+j-pad_left, c]
+ *   db[nn] += sum_{b,t} dz[b,t,nn]     (db may be NULL)
+ * x = 0 outside the item.  Exact-fp32 MFMA, split over rows, fp32 atomics.  kw in {1,3,5,9}.
+ * Linear: kw 1, pad 0, strides (cin, 1, 0); Conv1d [n, cin, kw]: pad kw/2, strides (cin*kw, kw, 1);
+ * LSTM W_hh: kw 1, pad_left = +1 / -1 selects h_{t-1} / h_{t+1}. */
+int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db,
+                 int64_t stride_n, int64_t stride_c, int64_t stride_j, int B, int L, int n, int cin,
+                 int kw, int pad_left, void* stream);
 
 /* out[c] += sum over rows of dz[row, c] (bias gradient); out2 (optional) gets the same sum
  * (nn.LSTM's b_ih and b_hh). */
@@ -265,9 +268,10 @@ int styler_batchnorm_bwd(const float* x, const float* y, const float* dy, const 
 
 int styler_embed_bwd(const int64_t* text, const float* dy, int64_t lddy, float* demb, int B, int L,
                      int C, void* stream);
-/* dw in parameter layout [C, 257, 5]; db [C]. */
-int styler_onehot_conv5_bwd(const float* v, const float* dy, int64_t lddy, float* dw, float* db,
-                            int B, int L, int C, void* stream);
+/* Backward of styler_onehot_conv5: materialise the one-hot rows [rows, 260] (257 zero-padded)
+ * so that the weight gradient becomes styler_wgrad(dy, onehot, dw [C,257,5], db, strides
+ * (257*5, 5, 1), n = C, cin = 257, kw = 5) on the MFMA engine. */
+int styler_onehot_expand(const float* v, float* onehot, int64_t rows, void* stream);
 int styler_mel_calibrate_bwd(const float* dy, int64_t lddy, float* dx, int64_t lddx,
                              const int64_t* mel_len, const int64_t* src_len, int B, int T, int S,
                              int C, void* stream);

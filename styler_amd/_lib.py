@@ -39,7 +39,7 @@ _SIGS = {
     "styler_length_mask": [P, P, I, I, P],
     "styler_masked_err_sum": [P, I64, P, I64, P, I, I, I, I, P, P],
     "styler_act_bwd": [P, I64, P, I64, P, I64, I, I, I, I, P, P],
-    "styler_wgrad": [P, I64, P, I64, P, I64, I64, I, I, I, I, I, P],
+    "styler_wgrad": [P, I64, P, I64, P, P, I64, I64, I64, I, I, I, I, I, I, P],
     "styler_colsum": [P, I64, P, P, I64, I, P],
     "styler_repack_weight_bwd": [P, P, I, I, I, P],
     "styler_attention_bwd": [P, P, P, P, P, P, I, I, P, P],
@@ -47,7 +47,7 @@ _SIGS = {
     "styler_groupnorm_relu_bwd": [P, I64, P, I64, P, P, P, I64, P, P, I, I, I, P],
     "styler_batchnorm_bwd": [P, P, P, P, P, P, P, P, P, P, I64, I, I, P],
     "styler_embed_bwd": [P, P, I64, P, I, I, I, P],
-    "styler_onehot_conv5_bwd": [P, P, I64, P, P, I, I, I, P],
+    "styler_onehot_expand": [P, P, I64, P],
     "styler_mel_calibrate_bwd": [P, I64, P, I64, P, P, I, I, I, I, P],
     "styler_lstm_bidir_bwd": [P, P, P, P, P, I, I, I, P],
     "styler_aug_classifier_tail_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, P],

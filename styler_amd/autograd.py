@@ -53,14 +53,8 @@ class ConvGemmFn(Function):
         dy = ops._rows_view(dy)
         dz = ops.act_bwd(dy, y, ctx.act) if ctx.act != NONE else dy
         if weight.requires_grad:
-            gw = G(weight)
-            if kw == 1:
-                ops.wgrad(dz, x, gw, cin, 1, n, cin)
-            else:
-                for j in range(kw):
-                    ops.wgrad(dz, x, gw, cin * kw, kw, n, cin, shift=j - kw // 2, dw_offset=j)
-        if bias is not None and bias.requires_grad:
-            ops.colsum(dz, G(bias))
+            ops.wgrad(dz, x, G(weight), n, cin, kw=kw,
+                      db=G(bias) if (bias is not None and bias.requires_grad) else None)
         dx = None
         if ctx.needs_input_grad[0]:
             wt = ctx.cache.get(ctx.key + ":T", [weight], lambda w: ops.repack_weight_bwd(w.detach()))
@@ -94,8 +88,7 @@ class QkvAttentionFn(Function):
         dqkv = ops.attention_bwd(qkv, out, dout, lse, lens)
         for i, lin in enumerate((mha.w_qs, mha.w_ks, mha.w_vs)):
             sl = dqkv[..., i * 256:(i + 1) * 256]
-            ops.wgrad(sl, x, G(lin.weight), 256, 1, 256, 256)
-            ops.colsum(sl, G(lin.bias))
+            ops.wgrad(sl, x, G(lin.weight), 256, 256, db=G(lin.bias))
         d = mha._derived
         srcs = [mha.w_qs.weight, mha.w_ks.weight, mha.w_vs.weight]
         if rt.prec == ops.PREC_BF16:
@@ -249,10 +242,10 @@ class LstmLayerFn(Function):
         dgp = ops.lstm_bidir_bwd(dout, gates, cell, w_hh, H)
         for d, sfx in enumerate(("", "_reverse")):
             sl = dgp[..., d * 4 * H:(d + 1) * 4 * H]
-            ops.wgrad(sl, x, G(getattr(lstm, f"weight_ih_l{layer}{sfx}")), cin, 1, 4 * H, cin)
+            ops.wgrad(sl, x, G(getattr(lstm, f"weight_ih_l{layer}{sfx}")), 4 * H, cin)
             # h_{prev}: forward direction reads out[t-1], reverse direction out[t+1]
-            ops.wgrad(sl, out[..., d * H:(d + 1) * H], G(getattr(lstm, f"weight_hh_l{layer}{sfx}")), H, 1, 4 * H, H,
-                      shift=-1 if d == 0 else 1)
+            ops.wgrad(sl, out[..., d * H:(d + 1) * H], G(getattr(lstm, f"weight_hh_l{layer}{sfx}")), 4 * H, H,
+                      pad_left=1 if d == 0 else -1)
             ops.colsum(sl, G(getattr(lstm, f"bias_ih_l{layer}{sfx}")), G(getattr(lstm, f"bias_hh_l{layer}{sfx}")))
         dx = None
         if ctx.needs_input_grad[0]:

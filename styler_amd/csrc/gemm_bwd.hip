@@ -1,8 +1,8 @@
 // Backward companions of the GEMM / implicit-GEMM conv engine.
 //
 //   act_bwd    : dz = mask(dy) * act'(y)                                  (HBM-bound, one pass)
-//   wgrad      : dw[n, c] += sum_{b,t} dz[b,t,n] * x[b, t+shift, c]       (MFMA "TN" GEMM, K = B*L, split-K + atomics)
-//   colsum     : db[n]    += sum_{b,t} dz[b,t,n]
+//   wgrad      : dw[n, c, j] += sum_{b,t} dz[b,t,n] * x[b, t+j-pad, c], db[n] += sum dz   (MFMA "TN" GEMM, K = B*L)
+//   colsum     : out[n]   += sum_{b,t} dz[b,t,n]
 //   repack_bwd : conv weight [n, cin, kw] -> [cin, kw*n] with taps flipped, the weight of the dX conv:
 //                dx = conv_same(dz, w_flipped^T), which runs on the forward engine (styler_conv_gemm).
 //
@@ -51,57 +51,88 @@ extern "C" int styler_act_bwd(const float* dy, int64_t lddy, const float* y, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// wgrad: block tile 128 (n) x 128 (c), 4 waves as 2x2 each 64x64 (2x2 MFMA tiles of 32x32), K chunk = 32 rows.
+// wgrad: all KW taps of a conv weight (or a Linear, KW = 1) in ONE launch.
+//   dw[nn*sn + c*sc + j*sj] += sum_{b,t} dz[b,t,nn] * x[b, t + j - pad_left, c]      (x = 0 outside the item)
+//   db[nn]                  += sum_{b,t} dz[b,t,nn]                                   (optional, fused)
+// Block tile 64 (n) x 64 (c), 4 waves as 2x2 (one 32x32 MFMA tile each) with KW accumulators per wave;
+// K chunk = 32 rows of the flattened [B*L] axis.  The dz chunk [32][64] and the haloed x chunk
+// [32 + KW - 1][64] are staged once per chunk; tap j reads x rows shifted by j.  Rows whose shifted
+// time index leaves the item are zeroed by a per-row tap mask (LDS).  Both operands are consumed from their
+// row-major images (A[i][k]: lane (i, h) reads row k = 2*kk + h), no transposition.  The row axis is split over
+// blockIdx.y; partial tiles are combined with fp32 atomics straight into the parameter-layout gradient.
 #define WG_BK 32
-#define WG_LD 132            // LDS row stride (floats): 128 + 4 keeps float4 stores aligned; reads are ds_read_b32
+#define WG_LD 68            // LDS row stride (floats)
 
+template <int KW>
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dz, int64_t lddz,
                                                     const float* __restrict__ x, int64_t ldx, float* __restrict__ dw,
-                                                    int64_t sn, int64_t sc, int B, int L, int n, int cin, int shift,
-                                                    int nt, int ct, int chunks_per_split) {
+                                                    float* __restrict__ db, int64_t sn, int64_t sc, int64_t sj, int B,
+                                                    int L, int n, int cin, int pad_left, int ct, int chunks_per_split) {
+  constexpr int XR = WG_BK + KW - 1;                 // x rows per chunk (with halo)
   __shared__ __attribute__((aligned(16))) float sA[2][WG_BK * WG_LD];
-  __shared__ __attribute__((aligned(16))) float sB[2][WG_BK * WG_LD];
+  __shared__ __attribute__((aligned(16))) float sB[2][XR * WG_LD];
+  __shared__ uint32_t sMask[2][WG_BK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
   const int tile = blockIdx.x;
-  const int n0 = (tile / ct) * 128, c0 = (tile % ct) * 128;
+  const int n0 = (tile / ct) * 64, c0 = (tile % ct) * 64;
   const int64_t M = (int64_t)B * L;
   const int64_t nchunks = (M + WG_BK - 1) / WG_BK;
   const int64_t ch0 = (int64_t)blockIdx.y * chunks_per_split;
   int64_t ch1 = ch0 + chunks_per_split; if (ch1 > nchunks) ch1 = nchunks;
   if (ch0 >= ch1) return;
 
-  // staging: 32 rows x 128 cols = 1024 float4 per operand -> 4 per thread; thread (r = tid/32 + 8p, q = tid%32)
-  const int sr = tid >> 5, sq = (tid & 31) * 4;
-  float4 ra[4], rb[4];
+  // staging: a row is 64 floats = 16 float4; 256 threads cover 16 rows per pass
+  const int sr = tid >> 4, sq = (tid & 15) * 4;
+  constexpr int XP = (XR + 15) / 16;
+  float4 ra[2], rb[XP];
+  uint32_t rmask = 0;
   auto load = [&](int64_t ch) {
     const int64_t mb = ch * WG_BK;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int64_t m = mb + sr + p * 8;
-      ra[p] = make_float4(0.f, 0.f, 0.f, 0.f); rb[p] = ra[p];
+    for (int p = 0; p < 2; ++p) {
+      const int64_t m = mb + sr + p * 16;
+      ra[p] = (m < M && n0 + sq < n) ? *reinterpret_cast<const float4*>(dz + m * lddz + n0 + sq)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      const int r = sr + p * 16;
+      const int64_t m = mb - pad_left + r;
+      rb[p] = (r < XR && m >= 0 && m < M && c0 + sq < ((cin + 3) & ~3)) ? *reinterpret_cast<const float4*>(x + m * ldx + c0 + sq)
+                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < WG_BK) {                               // tap validity of output row m = mb + tid
+      const int64_t m = mb + tid;
+      uint32_t bits = 0;
       if (m < M) {
-        if (n0 + sq < n) ra[p] = *reinterpret_cast<const float4*>(dz + m * lddz + n0 + sq);
-        const int t = (int)(m % L) + shift;
-        if (t >= 0 && t < L && c0 + sq < cin) rb[p] = *reinterpret_cast<const float4*>(x + (m + shift) * ldx + c0 + sq);
+        const int t = (int)(m % L);
+#pragma unroll
+        for (int j = 0; j < KW; ++j) {
+          const int tt = t + j - pad_left;
+          if (tt >= 0 && tt < L) bits |= 1u << j;
+        }
       }
+      rmask = bits;
     }
   };
   auto store = [&](int buf) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      *reinterpret_cast<float4*>(&sA[buf][(sr + p * 8) * WG_LD + sq]) = ra[p];
-      *reinterpret_cast<float4*>(&sB[buf][(sr + p * 8) * WG_LD + sq]) = rb[p];
-    }
+    for (int p = 0; p < 2; ++p) *reinterpret_cast<float4*>(&sA[buf][(sr + p * 16) * WG_LD + sq]) = ra[p];
+#pragma unroll
+    for (int p = 0; p < XP; ++p)
+      if (sr + p * 16 < XR) *reinterpret_cast<float4*>(&sB[buf][(sr + p * 16) * WG_LD + sq]) = rb[p];
+    if (tid < WG_BK) sMask[buf][tid] = rmask;
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[KW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < KW; ++j)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const bool use_mask = KW > 1 || pad_left != 0;     // a shifted Linear (LSTM W_hh) also crosses item boundaries
+  float bsum = 0.f;                                  // bias partial (threads < 64 of c-tile 0)
+  const bool do_bias = db && (tile % ct) == 0 && tid < 64;
 
   load(ch0);
   store(0);
@@ -110,50 +141,61 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dz
   for (int64_t ch = ch0; ch < ch1; ++ch) {
     const bool more = ch + 1 < ch1;
     if (more) load(ch + 1);
-    const float* pa = &sA[buf][lh * WG_LD + wm * 64 + li];
-    const float* pb = &sB[buf][lh * WG_LD + wn * 64 + li];
+    const float* pa = &sA[buf][lh * WG_LD + wm * 32 + li];
+    const float* pb = &sB[buf][lh * WG_LD + wn * 32 + li];
 #pragma unroll
     for (int kk = 0; kk < WG_BK / 2; ++kk) {
-      const float a0 = pa[kk * 2 * WG_LD], a1 = pa[kk * 2 * WG_LD + 32];
-      const float b0 = pb[kk * 2 * WG_LD], b1 = pb[kk * 2 * WG_LD + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      const float a = pa[kk * 2 * WG_LD];
+      const uint32_t mk = use_mask ? sMask[buf][kk * 2 + lh] : 0xffffffffu;
+#pragma unroll
+      for (int j = 0; j < KW; ++j) {
+        float bv = pb[(kk * 2 + j) * WG_LD];
+        bv = ((mk >> j) & 1u) ? bv : 0.f;
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[j], 0, 0, 0);
+      }
+    }
+    if (do_bias) {
+#pragma unroll 8
+      for (int k = 0; k < WG_BK; ++k) bsum += sA[buf][k * WG_LD + tid];
     }
     if (more) store(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
   // C layout: col (= c) = lane&31, row (= n) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int c = c0 + wn * 32 + li;
+  if (c < cin) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = c0 + wn * 64 + j * 32 + li;
-      if (c >= cin) continue;
+    for (int j = 0; j < KW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int nn = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (nn < n) atomicAdd(dw + nn * sn + c * sc, acc[i][j][r]);
+        const int nn = n0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (nn < n) atomicAdd(dw + nn * sn + c * sc + j * sj, acc[j][r]);
       }
-    }
+  }
+  if (do_bias && n0 + tid < n) atomicAdd(db + n0 + tid, bsum);
 }
 
-extern "C" int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, int64_t stride_n,
-                            int64_t stride_c, int B, int L, int n, int cin, int shift, void* stream) {
+extern "C" int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db,
+                            int64_t stride_n, int64_t stride_c, int64_t stride_j, int B, int L, int n, int cin, int kw,
+                            int pad_left, void* stream) {
   if (!dz || !x || !dw || B <= 0 || L <= 0 || n <= 0 || cin <= 0) return STYLER_EINVAL;
-  if ((lddz & 3) || (ldx & 3) || (n & 3) || (cin & 3) || ((uintptr_t)dz & 15) || ((uintptr_t)x & 15)) return STYLER_EALIGN;
-  const int nt = (n + 127) / 128, ct = (cin + 127) / 128;
+  if (kw != 1 && kw != 3 && kw != 5 && kw != 9) return STYLER_EINVAL;
+  if ((lddz & 3) || (ldx & 3) || (n & 3) || ldx < ((cin + 3) & ~3) || ((uintptr_t)dz & 15) || ((uintptr_t)x & 15)) return STYLER_EALIGN;
+  const int nt = (n + 63) / 64, ct = (cin + 63) / 64;
   const int64_t M = (int64_t)B * L;
   const int64_t nchunks = (M + WG_BK - 1) / WG_BK;
-  int64_t splits = (1024 + nt * ct - 1) / (nt * ct);
-  if (splits > nchunks / 4) splits = nchunks / 4;
+  int64_t splits = (512 + nt * ct - 1) / (nt * ct);
+  if (splits > nchunks / 8) splits = nchunks / 8;
   if (splits < 1) splits = 1;
   const int cps = (int)((nchunks + splits - 1) / splits);
   splits = (nchunks + cps - 1) / cps;
-  hipLaunchKernelGGL(wgrad_kernel, dim3(nt * ct, (unsigned)splits), dim3(256), 0, (hipStream_t)stream, dz, lddz, x, ldx,
-                     dw, stride_n, stride_c, B, L, n, cin, shift, nt, ct, cps);
+  const dim3 grid(nt * ct, (unsigned)splits);
+  hipStream_t st = (hipStream_t)stream;
+#define WG_LAUNCH(K) hipLaunchKernelGGL(wgrad_kernel<K>, grid, dim3(256), 0, st, dz, lddz, x, ldx, dw, db, stride_n, \
+                                        stride_c, stride_j, B, L, n, cin, pad_left, ct, cps)
+  if (kw == 1) WG_LAUNCH(1); else if (kw == 3) WG_LAUNCH(3); else if (kw == 5) WG_LAUNCH(5); else WG_LAUNCH(9);
+#undef WG_LAUNCH
   return launch_status();
 }
 

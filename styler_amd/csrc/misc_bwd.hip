@@ -36,34 +36,23 @@ __device__ __forceinline__ int quant_index_b(float v) {
   return (int)rintf(v * 255.f) + 1;
 }
 
-__global__ __launch_bounds__(256) void onehot_conv5_bwd_kernel(const float* __restrict__ v, const float* __restrict__ dy,
-                                                               int64_t lddy, float* __restrict__ dw,
-                                                               float* __restrict__ db, int64_t rows, int L, int C) {
+// The scatter form contends on index 0 (unvoiced + padded frames); instead the one-hot [rows, 260] (zero padded
+// from 257) is materialised once in backward and the gradient is a wgrad GEMM (styler_wgrad, kw = 5, strides of the
+// parameter layout [C, 257, 5]) -- 17.6 GFLOP on the MFMA engine instead of ~34 M contended atomics.
+__global__ __launch_bounds__(256) void onehot_expand_kernel(const float* __restrict__ v, float* __restrict__ oh,
+                                                            int64_t rows) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const int t = (int)(row % L);
-  int idx[5];
-#pragma unroll
-  for (int j = 0; j < 5; ++j) {
-    const int tt = t + j - 2;
-    idx[j] = (tt >= 0 && tt < L) ? quant_index_b(v[row + j - 2]) : -1;
-  }
-  for (int c = lane; c < C; c += 64) {
-    const float g = dy[row * lddy + c];
-    atomicAdd(db + c, g);
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-      if (idx[j] >= 0) atomicAdd(dw + ((int64_t)c * 257 + idx[j]) * 5 + j, g);
-  }
+  const int idx = quant_index_b(v[row]);
+  float* o = oh + row * 260;
+  for (int c = lane; c < 260; c += 64) o[c] = (c == idx) ? 1.f : 0.f;
 }
 
-extern "C" int styler_onehot_conv5_bwd(const float* v, const float* dy, int64_t lddy, float* dw, float* db, int B, int L,
-                                       int C, void* stream) {
-  if (!v || !dy || !dw || !db || B <= 0 || L <= 0 || C <= 0) return STYLER_EINVAL;
-  const int64_t rows = (int64_t)B * L;
-  hipLaunchKernelGGL(onehot_conv5_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, v, dy,
-                     lddy, dw, db, rows, L, C);
+extern "C" int styler_onehot_expand(const float* v, float* onehot, int64_t rows, void* stream) {
+  if (!v || !onehot || rows <= 0) return STYLER_EINVAL;
+  hipLaunchKernelGGL(onehot_expand_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, v, onehot,
+                     rows);
   return launch_status();
 }
 
@@ -219,6 +208,7 @@ __global__ __launch_bounds__(256) void bucket_embed_bwd_kernel(const float* __re
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float4 g = *reinterpret_cast<const float4*>(dy + row * 256 + lane * 4);
+  if (g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) return;      // padded frames carry exactly zero gradient
   float* p = dpe + (int64_t)pid[row] * 256 + lane * 4;
   float* e = dee + (int64_t)eid[row] * 256 + lane * 4;
   atomicAdd(p, g.x); atomicAdd(p + 1, g.y); atomicAdd(p + 2, g.z); atomicAdd(p + 3, g.w);

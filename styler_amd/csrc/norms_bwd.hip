@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
       d = make_float4(go * dw4.x * kx, go * dw4.y * ky, go * dw4.z * kz, go * dw4.w * kw_);
       aw.x += go * kx * (hx * g.x + bt.x); aw.y += go * ky * (hy * g.y + bt.y);
       aw.z += go * kz * (hz * g.z + bt.z); aw.w += go * kw_ * (hw * g.w + bt.w);
-      adb += go;
+      if (lane == 0) adb += go;
     } else {
       d = *reinterpret_cast<const float4*>(dy + row * lddy + lane * 4);
     }
@@ -61,14 +61,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
           make_float4(rstd * (ex - m1 - hx * m2), rstd * (ey - m1 - hy * m2), rstd * (ez - m1 - hz * m2),
                       rstd * (ew - m1 - hw * m2));
   }
-  atomicAdd(dgamma + lane * 4 + 0, ag.x); atomicAdd(dgamma + lane * 4 + 1, ag.y);
-  atomicAdd(dgamma + lane * 4 + 2, ag.z); atomicAdd(dgamma + lane * 4 + 3, ag.w);
-  atomicAdd(dbeta + lane * 4 + 0, ab.x); atomicAdd(dbeta + lane * 4 + 1, ab.y);
-  atomicAdd(dbeta + lane * 4 + 2, ab.z); atomicAdd(dbeta + lane * 4 + 3, ab.w);
+  // block-level reduction (4 waves) before the atomics: 256 + 256 (+ 256 + 1) atomics per block
+  __shared__ float red[3][4][256];
+  __shared__ float redb[4];
+  const int wv = threadIdx.x >> 6;
+  red[0][wv][lane * 4 + 0] = ag.x; red[0][wv][lane * 4 + 1] = ag.y; red[0][wv][lane * 4 + 2] = ag.z; red[0][wv][lane * 4 + 3] = ag.w;
+  red[1][wv][lane * 4 + 0] = ab.x; red[1][wv][lane * 4 + 1] = ab.y; red[1][wv][lane * 4 + 2] = ab.z; red[1][wv][lane * 4 + 3] = ab.w;
+  red[2][wv][lane * 4 + 0] = aw.x; red[2][wv][lane * 4 + 1] = aw.y; red[2][wv][lane * 4 + 2] = aw.z; red[2][wv][lane * 4 + 3] = aw.w;
+  const float wsum = wave_sum(adb);
+  if (lane == 0) redb[wv] = wsum;
+  __syncthreads();
+  const int c = threadIdx.x;
+  atomicAdd(dgamma + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
+  atomicAdd(dbeta + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
   if (dot_w) {
-    atomicAdd(ddot_w + lane * 4 + 0, aw.x); atomicAdd(ddot_w + lane * 4 + 1, aw.y);
-    atomicAdd(ddot_w + lane * 4 + 2, aw.z); atomicAdd(ddot_w + lane * 4 + 3, aw.w);
-    if (lane == 0) atomicAdd(ddot_b, adb);
+    atomicAdd(ddot_w + c, (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]));
+    if (c == 0) atomicAdd(ddot_b, (redb[0] + redb[1]) + (redb[2] + redb[3]));
   }
 }
 
@@ -82,7 +90,7 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
   if ((ldx & 3) || (dy && (lddy & 3)) || (dx && (lddx & 3))) return STYLER_EALIGN;
   const int64_t rows = (int64_t)B * L;
   int64_t blocks = (rows + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy,
                      gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b, rows, L, len, drop_p, drop_seed);
   return launch_status();

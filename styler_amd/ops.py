@@ -327,11 +327,15 @@ def act_bwd(dy, y, act, lens=None):
     return dz
 
 
-def wgrad(dz, x, dw, stride_n, stride_c, n, cin, shift=0, dw_offset=0):
-    """dw (fp32 tensor, parameter layout) += dz^T x with an optional time shift of x."""
+def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None):
+    """dw (fp32, parameter layout [n, cin] or [n, cin, kw]) += dz^T x over all taps; db += colsum(dz)."""
     B, L = dz.shape[0], dz.shape[1]
-    _chk(lib.styler_wgrad(dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), dw.data_ptr() + 4 * dw_offset, stride_n,
-                          stride_c, B, L, n, cin, shift, _stream()), "styler_wgrad")
+    if strides is None:
+        strides = (cin * kw, kw, 1) if kw > 1 else (cin, 1, 0)
+    if pad_left is None:
+        pad_left = kw // 2
+    _chk(lib.styler_wgrad(dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), dw.data_ptr(), _ptr(db), strides[0], strides[1],
+                          strides[2], B, L, n, cin, kw, pad_left, _stream()), "styler_wgrad")
 
 
 def colsum(dz, out, out2=None):
@@ -406,10 +410,13 @@ def embed_bwd(text, dy, demb):
 
 
 def onehot_conv5_bwd(v, dy, dw, db):
+    """dw [C, 257, 5] += onehot(v)^T-conv dy, db += colsum(dy): one-hot expansion + the wgrad GEMM."""
     dy = _rows_view(dy)
     B, L = v.shape
-    _chk(lib.styler_onehot_conv5_bwd(v.data_ptr(), dy.data_ptr(), _ld(dy), dw.data_ptr(), db.data_ptr(), B, L,
-                                     db.numel(), _stream()), "styler_onehot_conv5_bwd")
+    C = db.numel()
+    oh = torch.empty(B, L, 260, device=v.device, dtype=torch.float32)
+    _chk(lib.styler_onehot_expand(v.data_ptr(), oh.data_ptr(), B * L, _stream()), "styler_onehot_expand")
+    wgrad(dy, oh, dw, C, 257, kw=5, db=db, strides=(257 * 5, 5, 1))
 
 
 def mel_calibrate_bwd(dy, mel_len, src_len, T):
