@@ -1,18 +1,24 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the STYLER hot path on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W] [--mode fwd] [--prec bf16|fp32] [--no-graph]
+    python bench.py [--gpus N --steps K --warmup W] [--mode train|fwd] [--prec bf16|fp32] [--aux] [--no-graph]
 
-One "step" = one pass of the hot path (STYLER.forward, teacher-forced, eval) over one synthetic
-VCTK-shape batch resident in HBM (B=48, src_len~U{20..60},
-D~U{2..13}, 80-bin mel, clean branch only, bf16 MFMA operands / fp32 accumulate).  The metric is
-BASELINE.json's: valid mel-frames per second, reported as the WHOLE-JOB aggregate over N GPUs (each rank
-runs its own batch: data parallel, weak scaling, no data-path collective in the forward).
+Metric (BASELINE.json): valid mel-frames per second on a seeded synthetic VCTK-shape batch resident in HBM
+(B=48 per GPU, src_len~U{20..60}, D~U{2..13}, 80-bin mel), reported as the WHOLE-JOB
+aggregate over N GPUs (one process per GPU, each rank its own batch: weak scaling).
+
+One "step" is one pass of the hot path over one batch:
+  --mode train (default): the full reference optimisation step, train.py:135-186 -- forward with both decodes,
+        clean + noisy losses, the DAT pass, backward, gradient all-reduce (RCCL, N > 1), clip_grad_norm_(1.0),
+        Adam with the Noam schedule (BASELINE config 3 per-rank shape).  bf16 MFMA operands for forward / dX GEMMs,
+        exact-fp32 MFMA for the weight gradients, fp32 accumulate / activations / optimiser state.
+  --mode fwd: BASELINE config 2 -- eval forward, teacher-forced, clean branch only, replayed from a hipGraph.
+  --aux adds the other mode's figure under "aux" in the same JSON line.
 
 Rank 0 prints ONE JSON line.  It also carries
-  roofline     : the dominant kernel (conv_gemm_kernel<2,2,bf16>: 128x128 MFMA tile engine) -- algorithmic
-                 FLOPs of its launches / their HIP-event durations measured live in the timed steps;
-  cpu_baseline : the oracle (plain PyTorch-CPU restatement) timed on this host's cores on the same batch.
+  roofline     : the dominant kernel of the step -- algorithmic FLOPs of its launches / their HIP-event durations
+                 (events bracket each launch on the launch stream during extra eager steps);
+  cpu_baseline : the oracle (plain PyTorch-CPU restatement) timed on this host's cores on a bounded sample.
 """
 import argparse
 import json
@@ -34,58 +40,45 @@ VARIANT_NAMES = {0: "conv_gemm_kernel<1,1,f32>", 1: "conv_gemm_kernel<2,2,f32>",
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=48)
     ap.add_argument("--prec", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
+    ap.add_argument("--mode", default="train", choices=["fwd", "train"],
                     help="fwd: C2 eval forward; train: full reference step (dual decode + DAT pass + losses + backward "
                          "+ grad all-reduce + clip + Adam), train.py:135-186")
     ap.add_argument("--dual", action="store_true", help="also run the noisy-branch decode (styler.py:55)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--prof-steps", type=int, default=5, help="extra eager steps with HIP-event GEMM brackets")
+    ap.add_argument("--prof-steps", type=int, default=3, help="extra eager steps with HIP-event GEMM brackets")
+    ap.add_argument("--aux", action="store_true", help="also time the other mode and report it under 'aux'")
     return ap.parse_args()
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
+def run(args, mode, rank, world, dev, dist):
+    """Time `args.steps` steps of `mode` ("fwd" | "train") after `args.warmup` warm-up steps.  Returns the result
+    dict of rank 0 (None elsewhere)."""
     import styler_amd
     from styler_amd import ops, rt
+    from styler_amd.dist import aggregate_throughput
     from closed_form import make_batch
 
     torch.manual_seed(0)                       # identical random-init weights on every rank
-    train = args.mode == "train"
+    train = mode == "train"
     model = styler_amd.STYLER().to(dev)
     model = model.train() if train else model.eval()
     model.clean_only = (not args.dual) and not train
     rt.set_precision(args.prec)
-    rt.strict_inputs = False                   # no host sync inside the forward
+    rt.strict_inputs = False                   # no host sync inside the step
 
     batch = make_batch(args.batch, 20, 60, 2, 13, seed=1234 + rank)
     frames = int(batch["mel_len"].sum())
     S, T = batch["text"].shape[1], batch["mel_target"].shape[1]
     bd = {k: v.to(dev) for k, v in batch.items()}
-
+    use_graph = (not args.no_graph) and not train   # the tape-driven step launches eagerly (lr / step are host scalars)
     if train:
         from styler_amd.training import TrainState, train_step
         state = TrainState(model)
-        args.no_graph = True                   # the tape-driven step launches eagerly (lr / step count are host scalars)
 
     def step():
         if train:
@@ -102,10 +95,10 @@ def main():
 
     with (torch.enable_grad() if train else torch.no_grad()):
         for _ in range(3):                      # builds derived weights (bf16 shadows etc.)
-            out = step()
+            step()
         torch.cuda.synchronize()
         graph = None
-        if not args.no_graph:
+        if use_graph:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -113,19 +106,19 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                out = step()
-        run = graph.replay if graph is not None else step
+                step()
+        go = graph.replay if graph is not None else step
 
         for _ in range(args.warmup):
-            run()
+            go()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            run()
+            go()
         barrier()
         elapsed = time.perf_counter() - t0
 
-        # ---- live roofline measurement: HIP events around every GEMM launch, eager steps ----
+        # ---- live roofline measurement: HIP events around every MFMA-GEMM launch, extra eager steps ----
         prof = ops.GemmProfiler()
         ops.gemm_profiler = prof
         for _ in range(args.prof_steps):
@@ -134,42 +127,74 @@ def main():
         ops.gemm_profiler = None
         gsum = prof.summary()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    fr = torch.tensor([float(frames)], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(fr, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
-    total_frames = float(fr.item())
-
-    if rank == 0:
-        ms = elapsed / args.steps * 1e3
-        value = total_frames * args.steps / elapsed
+    elapsed, total_frames = aggregate_throughput(elapsed, frames, dev)
+    if rank != 0:
+        return None
+    ms = elapsed / args.steps * 1e3
+    value = total_frames * args.steps / elapsed
+    ps = max(1, args.prof_steps)
+    if train:       # dominant kernel of the step by time: the weight-gradient MFMA GEMM (exact-fp32 MFMA)
+        dom, dom_name, peak = "wgrad", "wgrad_kernel<KW> (all tap counts)", MFMA_PEAK_TFLOPS["fp32"]
+    else:
         dom = 3 if args.prec == "bf16" else 1
-        d = gsum.get(dom, {"launches": 0, "flops": 0.0, "ms": 1.0})
-        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["launches"] else 0.0
-        peak = MFMA_PEAK_TFLOPS[args.prec]
-        roofline = {"bound": "mfma", "kernel": VARIANT_NAMES[dom], "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-                    "launches_per_step": d["launches"] // max(1, args.prof_steps),
-                    "avg_launch_us": round(d["ms"] * 1e3 / max(1, d["launches"]), 2),
-                    "gemm_ms_per_step_all_variants": round(sum(v["ms"] for v in gsum.values()) / max(1, args.prof_steps), 3)}
-        cpu = None
-        if not args.no_cpu:
-            cpu = cpu_baseline(model, batch, S, T, model.clean_only, train=train)
-        print(json.dumps({
-            "metric": "mel_frames_per_sec", "value": round(value, 1),
-            "unit": "valid mel-frames/s (80-bin mel, whole job)", "per_gpu": round(value / world, 1),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+        dom_name, peak = VARIANT_NAMES[dom], MFMA_PEAK_TFLOPS[args.prec]
+    d = gsum.get(dom, {"launches": 0, "flops": 0.0, "ms": 1.0})
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["launches"] else 0.0
+    roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "launches_per_step": d["launches"] // ps, "avg_launch_us": round(d["ms"] * 1e3 / max(1, d["launches"]), 2),
+                "kernel_ms_per_step": round(d["ms"] / ps, 3),
+                "all_mfma_gemm_ms_per_step": round(sum(v["ms"] for v in gsum.values()) / ps, 3)}
+    workload = (f"C3 per-rank shape: full reference train step (dual decode + DAT pass + 10 losses + backward + grad "
+                f"all-reduce + clip + Adam, train.py:135-186), B={args.batch}/GPU, S={S}, T={T}, valid frames={frames}/GPU"
+                if train else
+                f"C2: STYLER.forward eval teacher-forced, {'dual' if args.dual else 'clean'}-branch, "
+                f"B={args.batch}/GPU, S={S}, T={T}, valid frames={frames}/GPU")
+    res = {"value": round(value, 1), "ms_per_step": round(ms, 4), "workload": workload,
+           "launch": "hipGraph replay" if graph is not None else "eager", "roofline": roofline}
+    if not args.no_cpu:
+        res["cpu_baseline"] = cpu_baseline(model, batch, S, T, model.clean_only, train=train)
+    return res
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    dist = None
+    if world > 1 or os.environ.get("STYLER_FORCE_PG"):
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    main_res = run(args, args.mode, rank, world, dev, dist)
+    aux = None
+    if args.aux:
+        other = "fwd" if args.mode == "train" else "train"
+        no_cpu, args.no_cpu = args.no_cpu, True
+        aux_steps, args.steps = args.steps, max(5, args.steps // 2)
+        aux = run(args, other, rank, world, dev, dist)
+        args.no_cpu, args.steps = no_cpu, aux_steps
+    if rank == 0:
+        line = {
+            "metric": "mel_frames_per_sec", "value": main_res["value"],
+            "unit": "valid mel-frames/s (80-bin mel, whole job)", "per_gpu": round(main_res["value"] / world, 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.prec,
             "data": "synthetic (seeded VCTK-shape batch, random-init weights)",
-            "config": {"workload": (f"C3 per-rank: full train step (dual decode + DAT pass + 10 losses + backward + "
-                                    f"grad all-reduce + clip + Adam), B={args.batch}/GPU, S={S}, T={T}, valid frames="
-                                    f"{frames}/GPU" if train else
-                                    f"C2: STYLER.forward eval teacher-forced, {'dual' if args.dual else 'clean'}-branch, "
-                                    f"B={args.batch}/GPU, S={S}, T={T}, valid frames={frames}/GPU"),
-                       "launch": "eager" if graph is None else "hipGraph replay", "parallelism": f"dp{world}"},
-            "roofline": roofline, "cpu_baseline": cpu}))
+            "config": {"workload": main_res["workload"], "launch": main_res["launch"], "parallelism": f"dp{world}"},
+            "roofline": main_res["roofline"], "cpu_baseline": main_res.get("cpu_baseline")}
+        if aux is not None:
+            line["aux"] = {("forward_c2" if args.mode == "train" else "train_c3"): {
+                "value": aux["value"], "ms_per_step": aux["ms_per_step"], "workload": aux["workload"],
+                "launch": aux["launch"], "roofline": aux["roofline"]}}
+        print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -334,8 +334,15 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None):
         strides = (cin * kw, kw, 1) if kw > 1 else (cin, 1, 0)
     if pad_left is None:
         pad_left = kw // 2
+    prof = gemm_profiler
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _chk(lib.styler_wgrad(dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), dw.data_ptr(), _ptr(db), strides[0], strides[1],
                           strides[2], B, L, n, cin, kw, pad_left, _stream()), "styler_wgrad")
+    if prof is not None:
+        e1.record()
+        prof.records.append(("wgrad", 2.0 * B * L * n * kw * cin, e0, e1))
 
 
 def colsum(dz, out, out2=None):
