@@ -133,8 +133,11 @@ def run(args, mode, rank, world, dev, dist):
     ms = elapsed / args.steps * 1e3
     value = total_frames * args.steps / elapsed
     ps = max(1, args.prof_steps)
-    if train:       # dominant kernel of the step by time: the weight-gradient MFMA GEMM (exact-fp32 MFMA)
-        dom, dom_name, peak = "wgrad", "wgrad_kernel<KW> (all tap counts)", MFMA_PEAK_TFLOPS["fp32"]
+    if train:       # dominant kernel of the step by time: the weight-gradient MFMA GEMM
+        if args.prec == "bf16":
+            dom, dom_name, peak = "wgrad_bf16", "wgrad_bf16_kernel<KW> (all tap counts)", MFMA_PEAK_TFLOPS["bf16"]
+        else:
+            dom, dom_name, peak = "wgrad", "wgrad_kernel<KW> (all tap counts)", MFMA_PEAK_TFLOPS["fp32"]
     else:
         dom = 3 if args.prec == "bf16" else 1
         dom_name, peak = VARIANT_NAMES[dom], MFMA_PEAK_TFLOPS[args.prec]

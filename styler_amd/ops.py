@@ -327,22 +327,27 @@ def act_bwd(dy, y, act, lens=None):
     return dz
 
 
-def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None):
+def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=None):
     """dw (fp32, parameter layout [n, cin] or [n, cin, kw]) += dz^T x over all taps; db += colsum(dz)."""
     B, L = dz.shape[0], dz.shape[1]
     if strides is None:
         strides = (cin * kw, kw, 1) if kw > 1 else (cin, 1, 0)
     if pad_left is None:
         pad_left = kw // 2
+    if prec is None:
+        from .runtime import rt
+        prec = rt.prec
     prof = gemm_profiler
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    ws = torch.empty(int(lib.styler_wgrad_workspace_bytes(B, L, n, cin, kw, pad_left, prec)) // 4, device=dz.device,
+                     dtype=torch.float32)
     _chk(lib.styler_wgrad(dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), dw.data_ptr(), _ptr(db), strides[0], strides[1],
-                          strides[2], B, L, n, cin, kw, pad_left, _stream()), "styler_wgrad")
+                          strides[2], B, L, n, cin, kw, pad_left, prec, ws.data_ptr(), _stream()), "styler_wgrad")
     if prof is not None:
         e1.record()
-        prof.records.append(("wgrad", 2.0 * B * L * n * kw * cin, e0, e1))
+        prof.records.append(("wgrad_bf16" if prec == PREC_BF16 else "wgrad", 2.0 * B * L * n * kw * cin, e0, e1))
 
 
 def colsum(dz, out, out2=None):

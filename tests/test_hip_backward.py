@@ -68,6 +68,35 @@ def test_conv_gemm_backward(dev, B, L, cin, n, kw, act):
     check(lin.bias.grad, conv.bias.grad, 2e-5, "db")
 
 
+@pytest.mark.parametrize("B,L,cin,n,kw,pad", [(3, 137, 256, 256, 1, 0), (2, 150, 256, 1024, 9, 4), (2, 141, 80, 512, 5, 2),
+                                               (4, 61, 256, 256, 3, 1), (5, 1, 512, 128, 1, 0), (3, 70, 64, 256, 1, 1),
+                                               (3, 70, 64, 256, 1, -1), (2, 66, 260, 320, 5, 2)])
+def test_wgrad_bf16(dev, B, L, cin, n, kw, pad):
+    """bf16-operand weight gradient (sliding-window gather kernel) vs fp64; also the shifted-Linear form used for
+    the LSTM recurrent weights (pad +1 / -1) and the one-hot conv form (cin = 257 padded to 260)."""
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(B * 7 + kw)
+    dz = torch.randn(B, L, n, generator=g, dtype=torch.float64)
+    x = torch.randn(B, L, cin, generator=g, dtype=torch.float64)
+    cin_eff = 257 if cin == 260 else cin
+    ref = torch.zeros(n, cin_eff, kw, dtype=torch.float64)
+    for j in range(kw):
+        sh = j - pad
+        xs = torch.zeros_like(x)
+        if sh >= 0:
+            xs[:, :L - sh] = x[:, sh:]
+        else:
+            xs[:, -sh:] = x[:, :L + sh]
+        ref[:, :, j] = torch.einsum("btn,btc->nc", dz, xs)[:, :cin_eff]
+    for prec, tol in ((ops.PREC_BF16, 2e-2), (ops.PREC_F32, 2e-5)):
+        dw = torch.zeros(n, cin_eff, kw, device=dev)
+        db = torch.zeros(n, device=dev)
+        ops.wgrad(dz.float().to(dev), x.float().to(dev), dw, n, cin_eff, kw=kw, db=db, pad_left=pad,
+                  strides=(cin_eff * kw, kw, 1), prec=prec)
+        check(dw, ref, tol, f"dw prec={prec}")
+        check(db, dz.sum((0, 1)), 1e-4, "db")
+
+
 @pytest.mark.parametrize("B,L,lens", [(2, 24, [24, 17]), (2, 150, [150, 77]), (1, 200, [131])])
 def test_attention_backward(dev, B, L, lens):
     from styler_amd import ops
