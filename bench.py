@@ -144,7 +144,7 @@ def run(args, mode, rank, world, dev, dist):
     d = gsum.get(dom, {"launches": 0, "flops": 0.0, "ms": 1.0})
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["launches"] else 0.0
     roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(train, args.prec),
                 "launches_per_step": d["launches"] // ps, "avg_launch_us": round(d["ms"] * 1e3 / max(1, d["launches"]), 2),
                 "kernel_ms_per_step": round(d["ms"] / ps, 3),
                 "all_mfma_gemm_ms_per_step": round(sum(v["ms"] for v in gsum.values()) / ps, 3)}
@@ -200,6 +200,25 @@ def main():
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pmc_traffic(train, prec):
+    """HBM-side bytes per launch of the dominant kernel, from the SEPARATE rocprofv3 --pmc passes of this same command
+    (tools/pmc_run.sh -> tools/pmc_traffic.py, committed as profiles/r01_pmc_traffic.jsonl; FETCH_SIZE doubled per the
+    gfx950 correction).  PMC collection cannot run inside the timed process, so the figure is read from that file;
+    null when it is absent or was taken for another precision."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.jsonl")
+    want = "train_wgrad_bf16" if train else "fwd_conv_gemm_2x2_bf16"
+    if prec != "bf16" or not os.path.exists(path):
+        return None
+    for line in open(path):
+        try:
+            rec = json.loads(line)
+        except ValueError:
+            continue
+        if rec.get("label") == want:
+            return rec["traffic_bytes_per_launch"]
+    return None
 
 
 def cpu_baseline(model, batch, S, T, clean_only, sample_items=16, max_threads=16, train=False):
