@@ -78,6 +78,14 @@ int styler_repack_conv_weight(const float* src, float* dst, int n, int cin, int 
 int styler_attention_fwd(const float* qkv, float* out, float* lse, int B, int L,
                          const int64_t* len, void* stream);
 
+/* Throughput-mode variants: bf16 MFMA operands (Q, K, V, P, dS, dO rounded to bf16 while staged),
+ * fp32 softmax / accumulation; same arguments as the exact-fp32 entry points. */
+int styler_attention_fwd_bf16(const float* qkv, float* out, float* lse, int B, int L,
+                              const int64_t* len, void* stream);
+int styler_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse,
+                              float* dqkv, float* delta_ws, int B, int L, const int64_t* len,
+                              void* stream);
+
 /* ---- normalisation / epilogues ------------------------------------------------------
  * y = LayerNorm_256(x + res) * gamma + beta, then rows t >= len[b] set to 0
  * (SubLayers.py:58-59,86-87 + Layers.py:29,32).  res, len may be NULL.  C must be 256.

@@ -106,12 +106,19 @@ def repack_conv_weight(w, to_kernel_layout=True):
     return dst
 
 
-def attention_fwd(qkv, lens, lse=None):
+def _prec(prec):
+    if prec is None:
+        from .runtime import rt
+        return rt.prec
+    return prec
+
+
+def attention_fwd(qkv, lens, lse=None, prec=None):
     B, L, _ = qkv.shape
     assert qkv.is_contiguous() and qkv.shape[2] == 768
     out = torch.empty(B, L, 256, device=qkv.device, dtype=torch.float32)
-    _chk(lib.styler_attention_fwd(qkv.data_ptr(), out.data_ptr(), _ptr(lse), B, L, _ptr(lens), _stream()),
-         "styler_attention_fwd")
+    fn = lib.styler_attention_fwd_bf16 if _prec(prec) == PREC_BF16 else lib.styler_attention_fwd
+    _chk(fn(qkv.data_ptr(), out.data_ptr(), _ptr(lse), B, L, _ptr(lens), _stream()), "styler_attention_fwd")
     return out
 
 
@@ -367,13 +374,14 @@ def repack_weight_bwd(w):
     return dst
 
 
-def attention_bwd(qkv, out, dout, lse, lens):
+def attention_bwd(qkv, out, dout, lse, lens, prec=None):
     B, L, _ = qkv.shape
     dout = dout.contiguous()
     dqkv = torch.empty_like(qkv)
     ws = torch.empty(B * 4 * L, device=qkv.device, dtype=torch.float32)
-    _chk(lib.styler_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
-                                  ws.data_ptr(), B, L, _ptr(lens), _stream()), "styler_attention_bwd")
+    fn = lib.styler_attention_bwd_bf16 if _prec(prec) == PREC_BF16 else lib.styler_attention_bwd
+    _chk(fn(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), ws.data_ptr(), B, L,
+            _ptr(lens), _stream()), "styler_attention_bwd")
     return dqkv
 
 

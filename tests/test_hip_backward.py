@@ -112,9 +112,12 @@ def test_attention_backward(dev, B, L, lens):
     out.backward(gy)
     qd = qkv.detach().float().to(dev)
     lse = torch.empty(B, 4, L, device=dev)
-    od = ops.attention_fwd(qd, ln.to(dev), lse=lse)
-    dq = ops.attention_bwd(qd, od, gy.float().to(dev), lse, ln.to(dev))
+    od = ops.attention_fwd(qd, ln.to(dev), lse=lse, prec=ops.PREC_F32)
+    dq = ops.attention_bwd(qd, od, gy.float().to(dev), lse, ln.to(dev), prec=ops.PREC_F32)
     check(dq, qkv.grad, 3e-5, "dqkv")
+    od16 = ops.attention_fwd(qd, ln.to(dev), lse=lse, prec=ops.PREC_BF16)
+    dq16 = ops.attention_bwd(qd, od16, gy.float().to(dev), lse, ln.to(dev), prec=ops.PREC_BF16)
+    check(dq16, qkv.grad, 3e-2, "dqkv bf16")
 
 
 def test_layernorm_backward(dev):

@@ -100,9 +100,12 @@ def test_attention(dev, B, L, lens):
     s = s.masked_fill((torch.arange(L)[None, :] >= ln[:, None])[:, None, None, :], float("-inf"))
     ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B, L, 256)
     lse = torch.empty(B, 4, L, device=dev)
-    out = ops.attention_fwd(qkv.to(dev), ln.to(dev), lse=lse)
+    out = ops.attention_fwd(qkv.to(dev), ln.to(dev), lse=lse, prec=ops.PREC_F32)
     check(out, ref.float(), 2e-5, "attention")
     check(lse, torch.logsumexp(s, -1).float(), 2e-5, "lse")
+    out16 = ops.attention_fwd(qkv.to(dev), ln.to(dev), lse=lse, prec=ops.PREC_BF16)     # bf16 operands, fp32 softmax
+    check(out16, ref.float(), 3e-2, "attention bf16")
+    check(lse, torch.logsumexp(s, -1).float(), 3e-2, "lse bf16")
 
 
 def test_add_layernorm(dev):
