@@ -65,16 +65,15 @@ __global__ __launch_bounds__(256) void mel_calibrate_bwd_kernel(const float* __r
   const int ml = (int)mel_len[b], sl = (int)src_len[b];
   float* dxp = dx + ((int64_t)b * T + t) * lddx;
   const float* dyb = dy + (int64_t)b * S * lddy;
-  int s0 = 0, cnt = 0; float scale = 1.f;
+  // div > 0: frame t lies in exactly one segment (compression / copy): grad = dy[s0] / div
+  // div == 0: frame t was repeated `cnt` times (expansion): grad = sum of those output rows
+  int s0 = 0, cnt = 0, div = 0;
   if (t < ml && sl > 0) {
-    if (ml >= sl) {                                  // frame t belongs to one segment s; grad = dy[s] / n_s
+    if (ml >= sl) {
       const int q = ml / sl, r = ml % sl;
-      const int s = (t < r * (q + 1)) ? t / (q + 1) : r + (t - r * (q + 1)) / q;
-      const int n = q + (s < r ? 1 : 0);
-      s0 = s; cnt = 1; scale = n > 1 ? 1.f / (float)n : 1.f;
-      if (n > 1) scale = 1.f;                        // division is applied exactly as forward: g / n (below)
-      cnt = -n;                                      // negative = "divide by n"
-    } else {                                         // frame t was repeated q + (t < r) times
+      s0 = (t < r * (q + 1)) ? t / (q + 1) : r + (t - r * (q + 1)) / q;
+      div = q + (s0 < r ? 1 : 0);
+    } else {
       const int q = sl / ml, r = sl % ml;
       cnt = q + (t < r ? 1 : 0);
       s0 = t * q + (t < r ? t : r);
@@ -82,9 +81,9 @@ __global__ __launch_bounds__(256) void mel_calibrate_bwd_kernel(const float* __r
   }
   for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cnt < 0) {
+    if (div > 0) {
       acc = *reinterpret_cast<const float4*>(dyb + (int64_t)s0 * lddy + c);
-      if (cnt < -1) { const float d = (float)(-cnt); acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d; }
+      if (div > 1) { const float d = (float)div; acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d; }
     } else {
       for (int k = 0; k < cnt; ++k) {
         const float4 g = *reinterpret_cast<const float4*>(dyb + (int64_t)(s0 + k) * lddy + c);
