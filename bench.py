@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--prof-steps", type=int, default=3, help="extra eager steps with HIP-event GEMM brackets")
     ap.add_argument("--aux", action="store_true", help="also time the other mode and report it under 'aux'")
+    ap.add_argument("--shape", default="vctk", choices=["vctk", "c4"],
+                    help="vctk: src_len~U{20..60}, D~U{2..13} (C1-C3); c4: long-form S=300, T=2000 (eval forward only)")
     return ap.parse_args()
 
 
@@ -71,7 +73,10 @@ def run(args, mode, rank, world, dev, dist):
     rt.set_precision(args.prec)
     rt.strict_inputs = False                   # no host sync inside the step
 
-    batch = make_batch(args.batch, 20, 60, 2, 13, seed=1234 + rank)
+    if args.shape == "c4":
+        batch = make_batch(args.batch, 300, 300, 5, 8, seed=1234 + rank, fix_src=300, fix_mel=2000)
+    else:
+        batch = make_batch(args.batch, 20, 60, 2, 13, seed=1234 + rank)
     frames = int(batch["mel_len"].sum())
     S, T = batch["text"].shape[1], batch["mel_target"].shape[1]
     bd = {k: v.to(dev) for k, v in batch.items()}

@@ -294,6 +294,8 @@ class StyleModeling(_HipModule):
         else:
             csum, mel_len, _ = ops.duration_scan(B, S, encodings.device, log_d=log_d, d_control=d_control)
             T = int(max_len) if max_len is not None else int(mel_len.max().item())
+            if T <= 0:
+                raise ValueError("free-running synthesis: every predicted duration is zero (empty mel)")
             lens = mel_len
             out_len, out_mask = mel_len, ops.length_mask(mel_len, T)
         grad = (self.training and torch.is_grad_enabled()) and encodings.requires_grad

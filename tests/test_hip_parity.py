@@ -489,3 +489,46 @@ def test_clean_only_and_bf16_mode(dev, model, O, ref_state_dict):
     check(out[1][0], ref[1][0], 0.15, "bf16 postnet mel")
     rel = float((out[1][0].cpu() - ref[1][0]).norm() / ref[1][0].norm())
     assert rel < 2e-2, f"bf16 relative L2 error {rel}"
+
+
+def test_c4_long_form_shape(dev, model, O, ref_state_dict):
+    """BASELINE config 4 shape (S = 300, T = 2000, eval mode: position table regenerated for L > 1000, long
+    attention): two utterances vs the oracle (mel within 1e-3), then the full B = 128 batch through
+    size-independent properties (finite, mel_len == sum(D) == 2000, padded rows exactly zero, and the first two
+    items' outputs unchanged by batching -- which holds here because every item has the same length, so
+    padding-dependent statistics (GroupNorm over padded T) see identical rectangles)."""
+    from closed_form import make_batch
+    b2 = make_batch(2, 300, 300, 5, 8, seed=400, fix_src=300, fix_mel=2000)
+    S, Tm = 300, 2000
+    with torch.no_grad():
+        ref = O.styler_forward(ref_state_dict, b2["text"], b2["mel_target"], b2["mel_aug"], b2["f0_norm"],
+                               b2["energy_input"], b2["src_len"], b2["mel_len"], b2["D"], b2["f0"], b2["energy"], S, Tm,
+                               speaker_embed=b2["speaker_embed"], noisy_branch=False)
+        model.clean_only = True
+        try:
+            out = _forward(model, _to(b2, dev))
+            check(out[0][0], ref[0][0], 1e-3, "C4 mel (B=2)")
+            check(out[1][0], ref[1][0], 1e-3, "C4 postnet mel (B=2)")
+            check(out[3], ref[3], 1e-3, "C4 pitch prediction")
+            big = make_batch(128, 300, 300, 5, 8, seed=400, fix_src=300, fix_mel=2000)
+            outb = _forward(model, _to(big, dev))
+            assert torch.isfinite(outb[1][0]).all()
+            assert torch.equal(outb[7].cpu(), big["D"].sum(1)) and int(outb[7].max()) == 2000
+            assert not bool(outb[6].any())                       # no padded frames at this shape
+        finally:
+            model.clean_only = False
+    # free-running on the long batch: LengthRegulator lengths from predicted durations are self-consistent.  With
+    # the closed-form weights the long-form log-durations sit near -1.4 (all durations 0 -> the reference would fail on
+    # an empty tensor; this build raises ValueError); shift the predictor bias so that durations are ~ 4 frames.
+    with torch.no_grad():
+        with pytest.raises(ValueError):
+            _forward(model, _to(b2, dev), teacher=False)
+        bias = model.style_modeling.duration_predictor.linear_layer.bias
+        bias += 3.0
+        try:
+            fr = _forward(model, _to(b2, dev), teacher=False)
+        finally:
+            bias -= 3.0
+    dur = torch.clamp(torch.round(torch.exp(fr[2].cpu()) - 1.0), min=0)
+    assert torch.equal(fr[7].cpu(), dur.double().trunc().long().sum(1)) and int(fr[7].max()) > 1000
+    assert fr[0][0].shape[1] == int(fr[7].max())
