@@ -44,7 +44,7 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   return r;
 }
 
-template <int TM, int TN, bool BF16, bool KW1>
+template <int TM, int TN, bool BF16, bool KW1, bool OCC3>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int BK = BF16 ? 64 : 32;
@@ -58,14 +58,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
   constexpr int B_P = BN / B_RPP;
   constexpr int B_ES = BF16 ? 2 : 4;               // bytes per weight element
   constexpr int CLD = 32 * TN + 4;                 // epilogue staging row stride (floats)
-  constexpr int SMEM_MAIN = 2 * A_ROWS * LD + 2 * BN * LD + LD;   // + one row of zeros
-  constexpr int SMEM_EPI = 4 * 32 * TM * CLD;
+  // OCC3 (occupancy-3 layout, 52.6 KB for the 128x128 bf16 tile => 3 blocks per CU): ONE activation buffer (re-staged
+  // behind an extra barrier at chunk boundaries), weight rows unpadded (32 dwords) with the 16-byte slot index
+  // XOR-swizzled by (row & 7), epilogue staged in two halves.
+  constexpr int NABUF = OCC3 ? 1 : 2;
+  constexpr int LDB = OCC3 ? 32 : LD;
+  constexpr int EPI_H = OCC3 ? 2 : 1;              // epilogue passes
+  constexpr int SMEM_MAIN = NABUF * A_ROWS * LD + 2 * BN * LDB + LD;   // + one row of zeros
+  constexpr int SMEM_EPI = 4 * 32 * TM * CLD / EPI_H;
   constexpr int SMEM = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
 
   __shared__ __attribute__((aligned(16))) uint32_t smem[SMEM];
-  uint32_t* const sA = smem;                       // 2 x [A_ROWS][LD]
-  uint32_t* const sB = smem + 2 * A_ROWS * LD;     // 2 x [BN][LD]
-  uint32_t* const sZ = sB + 2 * BN * LD;           // [LD] zeros
+  uint32_t* const sA = smem;                       // NABUF x [A_ROWS][LD]
+  uint32_t* const sB = smem + NABUF * A_ROWS * LD; // 2 x [BN][LDB]
+  uint32_t* const sZ = sB + 2 * BN * LDB;          // [LD] zeros
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -118,9 +124,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
 
   // LDS byte offsets (per lane), everything else in the fragment addresses is uniform or immediate
   const uint32_t fa_off = ((wm * TM * 32 + li) * LD + lh * (BF16 ? 4 : 16));
-  const uint32_t fb_off = ((wn * TN * 32 + li) * LD + lh * (BF16 ? 4 : 16));
+  const uint32_t fb_off = OCC3 ? (wn * TN * 32 + li) * LDB : ((wn * TN * 32 + li) * LD + lh * (BF16 ? 4 : 16));
+  uint32_t fb_sw[4];                               // OCC3: swizzled dword offset of MFMA step s inside the row
+#pragma unroll
+  for (int sx = 0; sx < 4; ++sx) fb_sw[sx] = (uint32_t)(((sx * 2 + lh) ^ (li & 7)) * 4);
   const uint32_t sa_off = a_r0 * LD + (BF16 ? a_col / 2 : a_col);
-  const uint32_t sb_off = b_r0 * LD + (tid % B_V) * 4;
+  const uint32_t sb_off = OCC3 ? b_r0 * LDB + (((tid % B_V) ^ (b_r0 & 7)) * 4) : b_r0 * LD + (tid % B_V) * 4;
 
   // per-lane tap validity for the wave's output rows: bit j set <=> row t + j - pad lies in [0, L)
   uint32_t tapmask[TM];
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     }
   };
   auto store_a = [&](int buf) {
-    uint32_t* dst = sA + buf * A_ROWS * LD + sa_off;
+    uint32_t* dst = sA + (OCC3 ? 0 : buf) * A_ROWS * LD + sa_off;
 #pragma unroll
     for (int p = 0; p < A_P; ++p) {
       if (a_r0 + p * A_RPP < A_ROWS) {
@@ -176,9 +185,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     }
   };
   auto store_b = [&](int buf) {
-    uint32_t* dst = sB + buf * BN * LD + sb_off;
+    uint32_t* dst = sB + buf * BN * LDB + sb_off;      // B_RPP = 32 rows per pass: (row & 7) is pass-invariant
 #pragma unroll
-    for (int p = 0; p < B_P; ++p) *reinterpret_cast<uint4*>(&dst[p * B_RPP * LD]) = rb[p];
+    for (int p = 0; p < B_P; ++p) *reinterpret_cast<uint4*>(&dst[p * B_RPP * LDB]) = rb[p];
   };
 
   f32x16 acc[TM][TN];
@@ -208,8 +217,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
       if (jn == 0) load_a(ccn);
     }
 
-    const uint32_t* cA = sA + (cc & 1) * A_ROWS * LD + j * LD + fa_off;
-    const uint32_t* cB = sB + (step & 1) * BN * LD + fb_off;
+    const uint32_t* cA = sA + (OCC3 ? 0 : (cc & 1)) * A_ROWS * LD + j * LD + fa_off;
+    const uint32_t* cB = sB + (step & 1) * BN * LDB + fb_off;
     // 'same' zero padding across item boundaries: a lane whose row t + j - pad falls outside [0, L)
     // reads its A fragment from a row of zeros instead (one address select per tile, no data selects)
     const uint32_t* pa[TM];
@@ -225,7 +234,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&pa[i][s * 8]);
 #pragma unroll
-        for (int jj = 0; jj < TN; ++jj) fb[jj] = *reinterpret_cast<const bf16x8*>(&cB[jj * 32 * LD + s * 8]);
+        for (int jj = 0; jj < TN; ++jj)
+          fb[jj] = OCC3 ? *reinterpret_cast<const bf16x8*>(&cB[jj * 32 * LDB + fb_sw[s]])
+                        : *reinterpret_cast<const bf16x8*>(&cB[jj * 32 * LD + s * 8]);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -254,7 +265,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
 
     if (more) {
       store_b((step + 1) & 1);
-      if (jn == 0) store_a(ccn & 1);
+      if (jn == 0) {
+        if (OCC3) __syncthreads();                     // every wave is done with the single activation buffer
+        store_a(ccn & 1);
+      }
     }
     __syncthreads();
     cc = ccn; j = jn;
@@ -262,40 +276,50 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
 
   // ---- epilogue: accumulators -> per-wave LDS tile -> coalesced float4 rows ----
   // C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  float* cst = reinterpret_cast<float*>(smem) + wave * (32 * TM * CLD);
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int jj = 0; jj < TN; ++jj)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        cst[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CLD + jj * 32 + li] = acc[i][jj][r];
-  __syncthreads();
-
   constexpr int LPR = 8 * TN;                      // lanes per output row (float4 each)
   constexpr int RPP = 64 / LPR;                    // rows per pass
+  constexpr int ROWS_H = 32 * TM / EPI_H;          // tile rows staged per epilogue pass
+  float* cst = reinterpret_cast<float*>(smem) + wave * (ROWS_H * CLD);
   const int c4 = (lane % LPR) * 4;
   const int col = n0 + wn * 32 * TN + c4;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
   if (col < a.n) {
-    const float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
-    const float4 sf = a.shift ? *reinterpret_cast<const float4*>(a.shift + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.scale) sc = *reinterpret_cast<const float4*>(a.scale + col);
+    if (a.shift) sf = *reinterpret_cast<const float4*>(a.shift + col);
+  }
+#pragma unroll
+  for (int hh = 0; hh < EPI_H; ++hh) {
+    if (hh) __syncthreads();
+    static_assert(EPI_H == 1 || TM == 2, "two-pass epilogue stages one 32-row MFMA tile row per pass");
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (EPI_H == 2 && i != hh) continue;
+#pragma unroll
+      for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          cst[((EPI_H == 2 ? 0 : i * 32) + (r & 3) + 8 * (r >> 2) + 4 * lh) * CLD + jj * 32 + li] = acc[i][jj][r];
+    }
+    __syncthreads();
+    if (col < a.n) {
 #pragma unroll 4
-    for (int p = 0; p < 32 * TM / RPP; ++p) {
-      const int rl = p * RPP + lane / LPR;
-      const int64_t row = m0 + wm * 32 * TM + rl;
-      if (row >= M) break;
-      float4 v = *reinterpret_cast<const float4*>(&cst[rl * CLD + c4]);
-      v.x = apply_act(v.x * sc.x + sf.x, a.act); v.y = apply_act(v.y * sc.y + sf.y, a.act);
-      v.z = apply_act(v.z * sc.z + sf.z, a.act); v.w = apply_act(v.w * sc.w + sf.w, a.act);
-      if (a.res) {
-        const float4 rr = *reinterpret_cast<const float4*>(a.res + row * a.ldres + col);
-        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      for (int p = 0; p < ROWS_H / RPP; ++p) {
+        const int rl = p * RPP + lane / LPR;
+        const int64_t row = m0 + wm * 32 * TM + hh * ROWS_H + rl;
+        if (row >= M) break;
+        float4 v = *reinterpret_cast<const float4*>(&cst[rl * CLD + c4]);
+        v.x = apply_act(v.x * sc.x + sf.x, a.act); v.y = apply_act(v.y * sc.y + sf.y, a.act);
+        v.z = apply_act(v.z * sc.z + sf.z, a.act); v.w = apply_act(v.w * sc.w + sf.w, a.act);
+        if (a.res) {
+          const float4 rr = *reinterpret_cast<const float4*>(a.res + row * a.ldres + col);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        if (a.len) {
+          const int64_t b = row / a.L;
+          if ((row - b * a.L) >= a.len[b]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        *reinterpret_cast<float4*>(a.y + row * a.ldy + col) = v;
       }
-      if (a.len) {
-        const int64_t b = row / a.L;
-        if ((row - b * a.L) >= a.len[b]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      *reinterpret_cast<float4*>(a.y + row * a.ldy + col) = v;
     }
   }
 }
@@ -306,10 +330,17 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   a.mt = (int)((M + 64 * TM - 1) / (64 * TM));
   a.nt = (a.n + 64 * TN - 1) / (64 * TN);
   const dim3 grid((unsigned)(a.mt * a.nt));
-  if (a.kw == 1)
-    hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, BF16, true>), grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, BF16, false>), grid, dim3(256), 0, st, a);
+  // occupancy-3 layout pays when a chunk spans >= 5 taps (one extra barrier per chunk): measured +12..15 % on the
+  // k = 9 / k = 5 convs, -5 % on k = 3.  STYLER_GEMM_OCC3=0/1 overrides for experiments.
+  static const int occ3_env = [] { const char* e = getenv("STYLER_GEMM_OCC3"); return e ? atoi(e) : -1; }();
+  const bool occ3 = occ3_env >= 0 ? occ3_env != 0 : a.kw >= 5;
+  if (a.kw == 1) {
+    hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, BF16, true, false>), grid, dim3(256), 0, st, a);
+  } else if (BF16 && TM == 2 && occ3) {
+    hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, BF16, false, BF16 && TM == 2>), grid, dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, BF16, false, false>), grid, dim3(256), 0, st, a);
+  }
   return launch_status();
 }
 
