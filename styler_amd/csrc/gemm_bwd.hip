@@ -418,7 +418,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
 
 extern "C" int styler_colsum(const float* dz, int64_t lddz, float* out, float* out2, int64_t rows, int C, void* stream) {
   if (!dz || !out || rows <= 0 || C <= 0 || (C & 3) || (lddz & 3)) return STYLER_EINVAL;
-  int rpb = 128;
+  // 32 rows per block: enough blocks to cover the chip for the S-domain shapes without flooding the atomics
+  int rpb = 32;
   if (rows / rpb > 2048) rpb = (int)((rows + 2047) / 2048);
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(C / 4 >= 256 ? 256 : 64), 0,
                      (hipStream_t)stream, dz, lddz, out, out2, rows, C, rpb);
