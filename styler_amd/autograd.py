@@ -307,6 +307,8 @@ class BucketEmbedAddFn(Function):
     def backward(ctx, dout, dout2):
         pid, eid = ctx.saved_tensors
         sm = ctx.sm
+        if rt.grad_ready_hook is not None:      # both decodes are back-propagated: decoder/PostNet grads are final
+            rt.grad_ready_hook()
         dout = dout.contiguous()
         ops.bucket_embed_bwd(dout, pid, eid, G(sm.pitch_embedding.weight), G(sm.energy_embedding.weight))
         dnoise = dout2 if ctx.needs_input_grad[2] else None

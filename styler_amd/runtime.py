@@ -6,6 +6,7 @@ class _Runtime:
     def __init__(self):
         self.prec = ops.PREC_F32        # PREC_F32: exact-fp32 MFMA (parity mode); PREC_BF16: throughput mode
         self.strict_inputs = True       # raise like the reference's assert on p_norm / e_input outside [0, 1]
+        self.grad_ready_hook = None     # set by training.train_step: called when the decoder-side gradients are final
         self.weights_epoch = 0          # bumped by TrainState.step(): invalidates every derived weight layout
         self.seed = 0                   # dropout stream seed (train.py:22 seeds torch with 0)
         self.dropout_calls = 0          # per-call counter mixed into the seed

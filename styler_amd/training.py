@@ -34,11 +34,33 @@ class TrainState:
                 off += align(k)
         self.params = params
         self.n = n
+        # flat offset where the decoder / mel_linear / PostNet parameters start (registration order of STYLER puts
+        # style_modeling first): their gradients are final as soon as backward reaches the decoder INPUT, so their
+        # all-reduce is launched from there and overlaps the rest of backward (style encoders, predictors, DAT pass)
+        self.tail_start = self._tail_offset(model, params, align)
+        self._tail_works = None
         self.n_current_steps = restore_step            # optimizer.py:10
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
 
+    @staticmethod
+    def _tail_offset(model, params, align):
+        ids = {id(p) for n_, p in model.named_parameters() if not n_.startswith("style_modeling.")}
+        off = 0
+        for p in params:
+            if id(p) in ids:
+                return off
+            off += align(p.numel())
+        return off
+
     def zero_grad(self):
         self.flat_g.zero_()
+        self._tail_works = None
+
+    def on_decoder_grads_ready(self):
+        """Called from BucketEmbedAddFn.backward (both decode branches fully back-propagated): start the all-reduce
+        of the decoder + mel_linear + PostNet gradient range (55 % of the bytes) while backward continues."""
+        if self._tail_works is None:
+            self._tail_works = allreduce_mean_(self.flat_g[self.tail_start:])
 
     def lr(self):
         """optimizer.py:21-32: the counter is incremented BEFORE the rate is computed."""
@@ -48,8 +70,13 @@ class TrainState:
 
     def step(self):
         """nn.utils.clip_grad_norm_(params, 1.0) + ScheduledOptim.step_and_update_lr() (train.py:181-185)."""
-        for w in allreduce_mean_(self.flat_g):
+        if self._tail_works is not None:                     # tail range already in flight: reduce only the head
+            works = self._tail_works + allreduce_mean_(self.flat_g[:self.tail_start])
+        else:
+            works = allreduce_mean_(self.flat_g)
+        for w in works:
             w.wait()
+        self._tail_works = None
         lr = self.lr()
         self.sumsq.zero_()
         ops.sumsq(self.flat_g, self.sumsq)
@@ -95,6 +122,10 @@ def train_step(model, state, batch, loss_fn=None, dat_fn=None):
     """One optimisation step (train.py:135-186).  Returns the 10 loss scalars (device tensors) and the lr."""
     state.zero_grad()
     losses = train_losses(model, batch, loss_fn, dat_fn)
-    (losses[0] / hp.acc_steps).backward()
+    rt.grad_ready_hook = state.on_decoder_grads_ready
+    try:
+        (losses[0] / hp.acc_steps).backward()
+    finally:
+        rt.grad_ready_hook = None
     lr = state.step()
     return losses, lr

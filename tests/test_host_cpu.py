@@ -89,6 +89,13 @@ g = torch.arange(10, dtype=torch.float32) * (rank + 1)
 for w in allreduce_mean_(g, bucket_bytes=16):
     w.wait()
 assert torch.allclose(g, torch.arange(10, dtype=torch.float32) * 1.5), g
+# two-phase (overlapped) reduction of a flat buffer: tail range first, head at step time -- same result as one pass
+flat = torch.arange(37, dtype=torch.float32) * (rank + 1)
+tail = allreduce_mean_(flat[20:], bucket_bytes=24)
+head = allreduce_mean_(flat[:20], bucket_bytes=24)
+for w in tail + head:
+    w.wait()
+assert torch.allclose(flat, torch.arange(37, dtype=torch.float32) * 1.5), flat
 dist.destroy_process_group()
 print("ok", rank)
 """
@@ -103,3 +110,20 @@ def test_two_rank_gloo_helpers(tmp_path):
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_collate_matches_reference(golden):
+    """styler_amd.data.collate_fn vs the reference Dataset.collate_fn (tests/golden/make_golden_collate.py)."""
+    import numpy as np
+    from golden.make_golden_collate import synthetic_items
+    from styler_amd.data import collate_fn
+    g = golden("collate")
+    out = collate_fn(synthetic_items())
+    assert len(out) == 4
+    for k, sub in enumerate(out):
+        for kk, vv in sub.items():
+            ref = g[f"b{k}:{kk}"]
+            if kk == "id":
+                assert list(vv) == [str(x) for x in ref]
+            else:
+                assert np.asarray(vv).shape == ref.shape and np.array_equal(np.asarray(vv, dtype=ref.dtype), ref), (k, kk)
