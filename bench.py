@@ -160,7 +160,7 @@ def run(args, mode, rank, world, dev, dist):
                 f"B={args.batch}/GPU, S={S}, T={T}, valid frames={frames}/GPU")
     res = {"value": round(value, 1), "ms_per_step": round(ms, 4), "workload": workload,
            "launch": "hipGraph replay" if graph is not None else "eager", "roofline": roofline}
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:              # reported at N = 1 only (rank 0's host cores)
         res["cpu_baseline"] = cpu_baseline(model, batch, S, T, model.clean_only, train=train)
     return res
 
