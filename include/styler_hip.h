@@ -243,7 +243,24 @@ int styler_act_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, f
  * LSTM W_hh: kw 1, pad_left = +1 / -1 selects h_{t-1} / h_{t+1}. */
 int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db,
                  int64_t stride_n, int64_t stride_c, int64_t stride_j, int B, int L, int n, int cin,
-                 int kw, int pad_left, int prec, void* workspace, void* stream);
+                 int kw, int pad_left, int prec, void* workspace, int defer_reduce, void* stream);
+/* Split count styler_wgrad uses for a shape (workspace = splits * n * kw * cin floats). */
+int styler_wgrad_splits(int B, int L, int n, int cin, int kw, int pad_left, int prec);
+
+/* Deferred reduction: with defer_reduce != 0 styler_wgrad leaves its partial tiles in `workspace`;
+ * one styler_wgrad_reduce_multi launch then folds the partials of MANY gradients into their
+ * parameter-layout buffers (dw[nn*stride_n + c*stride_c + j*stride_j] += sum_split ws[...]).
+ * `desc_dev` is a device array; descriptor i owns blocks [block_start, next.block_start), one
+ * block per 1024 outputs: block_start[0] = 0, total_blocks = sum ceil(n*kw*cin / 1024). */
+typedef struct StylerWgradDesc {
+  const void* ws;
+  void* dw;
+  int64_t stride_n, stride_c, stride_j;
+  int64_t block_start;
+  int32_t n, cin, kw, splits;
+} StylerWgradDesc;
+int styler_wgrad_reduce_multi(const StylerWgradDesc* desc_dev, int count, int64_t total_blocks,
+                              void* stream);
 /* bytes of `workspace` styler_wgrad needs for a shape (split-K partial tiles, reduced without atomics) */
 int64_t styler_wgrad_workspace_bytes(int B, int L, int n, int cin, int kw, int pad_left, int prec);
 

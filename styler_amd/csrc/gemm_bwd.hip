@@ -349,7 +349,7 @@ static void wgrad_plan(int B, int L, int n, int cin, int kw, int pad_left, int p
     *cpi = 0;
     nchunks = ((int64_t)B * L + WG_BK - 1) / WG_BK;
   }
-  int64_t sp = (768 + nt * ct - 1) / (nt * ct);
+  int64_t sp = (512 + nt * ct - 1) / (nt * ct);      // ~2 blocks per CU; every extra split costs a partial tile round trip
   if (sp > nchunks / 4) sp = nchunks / 4;
   if (sp < 1) sp = 1;
   *cps = (int)((nchunks + sp - 1) / sp);
@@ -365,7 +365,7 @@ extern "C" int64_t styler_wgrad_workspace_bytes(int B, int L, int n, int cin, in
 
 extern "C" int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db,
                             int64_t stride_n, int64_t stride_c, int64_t stride_j, int B, int L, int n, int cin, int kw,
-                            int pad_left, int prec, void* workspace, void* stream) {
+                            int pad_left, int prec, void* workspace, int defer_reduce, void* stream) {
   if (!dz || !x || !dw || !workspace || B <= 0 || L <= 0 || n <= 0 || cin <= 0) return STYLER_EINVAL;
   if (kw != 1 && kw != 3 && kw != 5 && kw != 9) return STYLER_EINVAL;
   if ((lddz & 3) || (ldx & 3) || (n & 3) || ldx < ((cin + 3) & ~3) || ((uintptr_t)dz & 15) || ((uintptr_t)x & 15)) return STYLER_EALIGN;
@@ -386,10 +386,47 @@ extern "C" int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64
     if (kw == 1) WG_LAUNCH(1); else if (kw == 3) WG_LAUNCH(3); else if (kw == 5) WG_LAUNCH(5); else WG_LAUNCH(9);
 #undef WG_LAUNCH
   }
+  if (defer_reduce) return launch_status();          // the caller batches all reductions: styler_wgrad_reduce_multi
   const int64_t per = (int64_t)n * kw * cin;
   int64_t rb = (per + 255) / 256; if (rb > 2048) rb = 2048;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, ws, dw, stride_n, stride_c, stride_j, n,
                      cin, kw, splits);
+  return launch_status();
+}
+
+extern "C" int styler_wgrad_splits(int B, int L, int n, int cin, int kw, int pad_left, int prec) {
+  if (B <= 0 || L <= 0 || n <= 0 || cin <= 0 || kw <= 0) return 0;
+  int Be, Le, cpi, cps, splits;
+  wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits);
+  return splits;
+}
+
+// One launch reducing the split-K partials of MANY weight gradients (a whole backward pass): descriptor i covers
+// blocks [block_start[i], block_start[i+1]); every block handles 1024 consecutive outputs of its descriptor.
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const StylerWgradDesc* __restrict__ desc, int count) {
+  int lo = 0, hi = count - 1;                        // last descriptor with block_start <= blockIdx.x
+  const int64_t bid = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].block_start <= bid) lo = mid; else hi = mid - 1; }
+  const StylerWgradDesc d = desc[lo];
+  const int64_t per = (int64_t)d.n * d.kw * d.cin;
+  const float* ws = reinterpret_cast<const float*>(d.ws);
+  float* dw = reinterpret_cast<float*>(d.dw);
+  const int64_t i0 = (bid - d.block_start) * 1024;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t i = i0 + k * 256 + threadIdx.x;
+    if (i >= per) return;
+    float s = 0.f;
+    for (int sp = 0; sp < d.splits; ++sp) s += ws[(int64_t)sp * per + i];
+    const int c = (int)(i % d.cin); const int j = (int)((i / d.cin) % d.kw); const int64_t nn = i / ((int64_t)d.cin * d.kw);
+    dw[nn * d.stride_n + c * d.stride_c + j * d.stride_j] += s;
+  }
+}
+
+extern "C" int styler_wgrad_reduce_multi(const StylerWgradDesc* desc_dev, int count, int64_t total_blocks, void* stream) {
+  if (!desc_dev || count <= 0 || total_blocks <= 0) return STYLER_EINVAL;
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, desc_dev,
+                     count);
   return launch_status();
 }
 

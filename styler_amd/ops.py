@@ -43,6 +43,63 @@ def _f32(t):
     return t
 
 
+class WgradArena:
+    """Workspace arena for one backward pass: every styler_wgrad call takes a slice and defers its split-K
+    reduction; `flush()` folds all partials into the gradients with ONE launch.  The first pass only measures
+    (calls reduce immediately); the arena is sized from it."""
+
+    _DESC = None
+
+    def __init__(self):
+        self.buf = None
+        self.used = 0
+        self.need = 0
+        self.descs = []
+        self._cache = {}                             # descriptor tuple -> (device table, total blocks)
+
+    def begin(self):
+        self.used = 0
+        self.descs = []
+
+    def take(self, nfloats, device):
+        nfloats = (nfloats + 3) & ~3
+        if self.buf is None or self.used + nfloats > self.buf.numel():
+            self.need += nfloats                     # measuring pass (or overflow): caller reduces immediately
+            return None
+        out = self.buf[self.used:self.used + nfloats]
+        self.used += nfloats
+        return out
+
+    def flush(self, device):
+        import ctypes
+        import numpy as np
+        if self.buf is None and self.need:
+            self.buf = torch.empty(self.need, device=device, dtype=torch.float32)
+        self.need = 0
+        if not self.descs:
+            return
+        key = tuple(self.descs)
+        if key not in self._cache:
+            dt = np.dtype([("ws", np.uint64), ("dw", np.uint64), ("sn", np.int64), ("sc", np.int64), ("sj", np.int64),
+                           ("block_start", np.int64), ("n", np.int32), ("cin", np.int32), ("kw", np.int32),
+                           ("splits", np.int32)])
+            arr = np.zeros(len(self.descs), dtype=dt)
+            start = 0
+            for i, (ws, dw, sn, sc, sj, n, cin, kw, splits) in enumerate(self.descs):
+                arr[i] = (ws, dw, sn, sc, sj, start, n, cin, kw, splits)
+                start += (n * cin * kw + 1023) // 1024
+            if len(self._cache) > 8:
+                self._cache.clear()
+            self._cache[key] = (torch.from_numpy(arr.view(np.uint8).copy()).to(device), start)
+        table, blocks = self._cache[key]
+        _chk(lib.styler_wgrad_reduce_multi(table.data_ptr(), len(self.descs), blocks, _stream()),
+             "styler_wgrad_reduce_multi")
+        self.descs = []
+
+
+wgrad_arena = None
+
+
 class GemmProfiler:
     """Optional HIP-event bracket around every styler_conv_gemm launch (bench.py's live roofline
     measurement).  Events are recorded on the launch stream; elapsed times are read after a sync."""
@@ -348,10 +405,19 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    ws = torch.empty(int(lib.styler_wgrad_workspace_bytes(B, L, n, cin, kw, pad_left, prec)) // 4, device=dz.device,
-                     dtype=torch.float32)
+    nfloats = int(lib.styler_wgrad_workspace_bytes(B, L, n, cin, kw, pad_left, prec)) // 4
+    arena = wgrad_arena
+    ws, defer = None, 0
+    if arena is not None:
+        ws = arena.take(nfloats, dz.device)
+        if ws is not None:
+            defer = 1
+            arena.descs.append((ws.data_ptr(), dw.data_ptr(), strides[0], strides[1], strides[2], n, cin, kw,
+                                int(lib.styler_wgrad_splits(B, L, n, cin, kw, pad_left, prec))))
+    if ws is None:
+        ws = torch.empty(nfloats, device=dz.device, dtype=torch.float32)
     _chk(lib.styler_wgrad(dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), dw.data_ptr(), _ptr(db), strides[0], strides[1],
-                          strides[2], B, L, n, cin, kw, pad_left, prec, ws.data_ptr(), _stream()), "styler_wgrad")
+                          strides[2], B, L, n, cin, kw, pad_left, prec, ws.data_ptr(), defer, _stream()), "styler_wgrad")
     if prof is not None:
         e1.record()
         prof.records.append(("wgrad_bf16" if prec == PREC_BF16 else "wgrad", 2.0 * B * L * n * kw * cin, e0, e1))

@@ -41,6 +41,7 @@ class TrainState:
         self._tail_works = None
         self.n_current_steps = restore_step            # optimizer.py:10
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
+        self.arena = ops.WgradArena()                  # split-K partials of every weight gradient of one backward
 
     @staticmethod
     def _tail_offset(model, params, align):
@@ -60,6 +61,7 @@ class TrainState:
         """Called from BucketEmbedAddFn.backward (both decode branches fully back-propagated): start the all-reduce
         of the decoder + mel_linear + PostNet gradient range (55 % of the bytes) while backward continues."""
         if self._tail_works is None:
+            self.arena.flush(self.flat_g.device)      # fold the decoder-side split-K partials before they are reduced
             self._tail_works = allreduce_mean_(self.flat_g[self.tail_start:])
 
     def lr(self):
@@ -123,9 +125,13 @@ def train_step(model, state, batch, loss_fn=None, dat_fn=None):
     state.zero_grad()
     losses = train_losses(model, batch, loss_fn, dat_fn)
     rt.grad_ready_hook = state.on_decoder_grads_ready
+    state.arena.begin()
+    ops.wgrad_arena = state.arena
     try:
         (losses[0] / hp.acc_steps).backward()
+        state.arena.flush(state.flat_g.device)         # one launch folds all split-K partials into flat_g
     finally:
         rt.grad_ready_hook = None
+        ops.wgrad_arena = None
     lr = state.step()
     return losses, lr

@@ -386,6 +386,37 @@ def test_train_step_vs_oracle_vctk_shape(dev, train_model, ref_state_dict):
     train_model.load_state_dict(ref_state_dict)
 
 
+def test_deferred_wgrad_reduce_matches_immediate(dev, train_model, ref_state_dict):
+    """The arena path of train_step (every split-K reduction deferred to one multi-tensor launch) must produce the same
+    flat gradient as the immediate per-call reduction."""
+    from closed_form import make_batch
+    from styler_amd import ops
+    from styler_amd.training import train_losses
+    b = {k: v.to(dev) for k, v in make_batch(3, 20, 40, 2, 9, seed=33).items()}
+    train_model.load_state_dict(ref_state_dict)
+    grads = []
+    arena = ops.WgradArena()
+    for mode in ("immediate", "measure", "arena"):
+        train_model.zero_grad(set_to_none=True)
+        losses = train_losses(train_model, b)
+        if mode != "immediate":
+            arena.begin()
+            ops.wgrad_arena = arena
+        try:
+            losses[0].backward()
+            if mode != "immediate":
+                arena.flush(dev)
+        finally:
+            ops.wgrad_arena = None
+        grads.append({k: p.grad.clone() for k, p in train_model.named_parameters() if p.grad is not None})
+    assert arena.buf is not None and arena.used > 0
+    for k in grads[0]:
+        for other in grads[1:]:
+            e = float((grads[0][k] - other[k]).abs().max()) / max(float(grads[0][k].abs().max()), 1e-4)
+            assert e <= 1e-4, f"{k}: {e:.3e}"
+    train_model.load_state_dict(ref_state_dict)
+
+
 def test_train_state_steps_and_bf16(dev, ref_state_dict):
     """Flat-buffer optimiser: two steps reduce nothing to NaN, parameters move, derived layouts refresh; bf16 mode
     gradients stay close to fp32 ones."""
