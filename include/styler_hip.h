@@ -63,9 +63,10 @@ int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, int prec);
 /* fp32 -> bf16 (round-to-nearest-even) weight shadow for STYLER_PREC_BF16 */
 int styler_cast_bf16(const float* src, uint16_t* dst, int64_t count, void* stream);
 
-/* Conv1d weight repack [n, cin, kw] <-> [n, kw, cin] (state-dict layout <-> kernel layout) */
-int styler_repack_conv_weight(const float* src, float* dst, int n, int cin, int kw,
-                              int to_kernel_layout, void* stream);
+/* Conv1d weight repack [n, cin, kw] <-> [n, kw, cin] (state-dict layout <-> kernel layout);
+ * out_bf16 != 0 writes the bf16 shadow directly (dst is uint16). */
+int styler_repack_conv_weight(const float* src, void* dst, int n, int cin, int kw,
+                              int to_kernel_layout, int out_bf16, void* stream);
 
 /* ---- attention ----------------------------------------------------------------------
  * Multi-head self-attention over the fused QKV projection (ScaledDotProductAttention,
@@ -271,7 +272,8 @@ int styler_colsum(const float* dz, int64_t lddz, float* out, float* out2, int64_
 
 /* Weight of the dX convolution: dst[c, j, nn] = src[nn, c, kw-1-j] (src in parameter layout
  * [n, cin, kw]); dx = styler_conv_gemm(dz, dst, cin := n, n := cin, kw). */
-int styler_repack_weight_bwd(const float* src, float* dst, int n, int cin, int kw, void* stream);
+int styler_repack_weight_bwd(const float* src, void* dst, int n, int cin, int kw, int out_bf16,
+                             void* stream);
 
 /* Attention backward (recomputes P from lse): dqkv [B,L,768]; delta_ws: B*4*L floats. */
 int styler_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,

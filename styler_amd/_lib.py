@@ -18,7 +18,7 @@ _SIGS = {
     "styler_conv_gemm": [P, I64, P, P, P, P, I64, P, I64, I, I, I, I, I, I, I, P, P],
     "styler_conv_gemm_variant": [I, I, I, I, I, I],
     "styler_cast_bf16": [P, P, I64, P],
-    "styler_repack_conv_weight": [P, P, I, I, I, I, P],
+    "styler_repack_conv_weight": [P, P, I, I, I, I, I, P],
     "styler_attention_fwd": [P, P, P, I, I, P, P],
     "styler_attention_fwd_bf16": [P, P, P, I, I, P, P],
     "styler_attention_bwd_bf16": [P, P, P, P, P, P, I, I, P, P],
@@ -46,7 +46,7 @@ _SIGS = {
     "styler_wgrad_reduce_multi": [P, I, I64, P],
     "styler_wgrad_workspace_bytes": [I, I, I, I, I, I, I],
     "styler_colsum": [P, I64, P, P, I64, I, P],
-    "styler_repack_weight_bwd": [P, P, I, I, I, P],
+    "styler_repack_weight_bwd": [P, P, I, I, I, I, P],
     "styler_attention_bwd": [P, P, P, P, P, P, I, I, P, P],
     "styler_layernorm_bwd": [P, I64, P, I64, P, P, P, I64, P, P, P, P, P, P, I, I, I, P, F, ctypes.c_uint64, P],
     "styler_groupnorm_relu_bwd": [P, I64, P, I64, P, P, P, I64, P, P, I, I, I, P],

@@ -57,11 +57,12 @@ class ConvGemmFn(Function):
                       db=G(bias) if (bias is not None and bias.requires_grad) else None)
         dx = None
         if ctx.needs_input_grad[0]:
-            wt = ctx.cache.get(ctx.key + ":T", [weight], lambda w: ops.repack_weight_bwd(w.detach()))
-            prec = ops.PREC_F32
             if rt.prec == ops.PREC_BF16 and n % 8 == 0:
-                wt = ctx.cache.get(ctx.key + ":T16", [weight], lambda w: ops.cast_bf16(ops.repack_weight_bwd(w.detach())))
+                wt = ctx.cache.get(ctx.key + ":T16", [weight], lambda w: ops.repack_weight_bwd(w.detach(), bf16=True))
                 prec = ops.PREC_BF16
+            else:
+                wt = ctx.cache.get(ctx.key + ":T", [weight], lambda w: ops.repack_weight_bwd(w.detach()))
+                prec = ops.PREC_F32
             dx = ops.conv_gemm(dz, wt, None, kw=kw, n=cin, prec=prec,
                                scale=_neg(cin, dz.device) if ctx.neg_dx else None)
         return dx, (dy if ctx.has_res else None), None, None, None, None, None, None, None

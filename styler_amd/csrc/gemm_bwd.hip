@@ -465,18 +465,25 @@ extern "C" int styler_colsum(const float* dz, int64_t lddz, float* out, float* o
 
 // ---------------------------------------------------------------------------------------------
 // dst[c, j', nn] = src[nn, c, kw-1-j']     (src = parameter layout [n, cin, kw]; kw = 1: plain transpose)
-__global__ void repack_bwd_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int cin, int kw) {
+template <typename OutT>
+__global__ void repack_bwd_kernel(const float* __restrict__ src, OutT* __restrict__ dst, int n, int cin, int kw) {
   const int64_t total = (int64_t)n * cin * kw;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int nn = (int)(i % n); const int j = (int)((i / n) % kw); const int64_t c = i / ((int64_t)n * kw);
-    dst[i] = src[((int64_t)nn * cin + c) * kw + (kw - 1 - j)];
+    const float v = src[((int64_t)nn * cin + c) * kw + (kw - 1 - j)];
+    if constexpr (sizeof(OutT) == 2) dst[i] = (OutT)f32_to_bf16_bits(v); else dst[i] = v;
   }
 }
 
-extern "C" int styler_repack_weight_bwd(const float* src, float* dst, int n, int cin, int kw, void* stream) {
+extern "C" int styler_repack_weight_bwd(const float* src, void* dst, int n, int cin, int kw, int out_bf16, void* stream) {
   if (!src || !dst || n <= 0 || cin <= 0 || kw <= 0) return STYLER_EINVAL;
   const int64_t total = (int64_t)n * cin * kw;
   int64_t blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(repack_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n, cin, kw);
+  if (out_bf16)
+    hipLaunchKernelGGL(repack_bwd_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src,
+                       reinterpret_cast<uint16_t*>(dst), n, cin, kw);
+  else
+    hipLaunchKernelGGL(repack_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src,
+                       reinterpret_cast<float*>(dst), n, cin, kw);
   return launch_status();
 }

@@ -408,29 +408,36 @@ extern "C" int styler_cast_bf16(const float* src, uint16_t* dst, int64_t count, 
   return launch_status();
 }
 
-__global__ void repack_conv_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int cin,
-                                   int kw, int to_kernel) {
+template <typename OutT>
+__global__ void repack_conv_kernel(const float* __restrict__ src, OutT* __restrict__ dst, int n, int cin, int kw,
+                                   int to_kernel) {
   const int64_t total = (int64_t)n * cin * kw;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     // i enumerates the DESTINATION
+    float v;
     if (to_kernel) {  // dst [n, kw, cin] <- src [n, cin, kw]
       const int c = i % cin; const int j = (i / cin) % kw; const int64_t o = i / ((int64_t)cin * kw);
-      dst[i] = src[(o * cin + c) * kw + j];
+      v = src[(o * cin + c) * kw + j];
     } else {          // dst [n, cin, kw] <- src [n, kw, cin]
       const int j = i % kw; const int c = (i / kw) % cin; const int64_t o = i / ((int64_t)cin * kw);
-      dst[i] = src[(o * kw + j) * cin + c];
+      v = src[(o * kw + j) * cin + c];
     }
+    if constexpr (sizeof(OutT) == 2) dst[i] = (OutT)f32_to_bf16_bits(v); else dst[i] = v;
   }
 }
 
-extern "C" int styler_repack_conv_weight(const float* src, float* dst, int n, int cin, int kw,
-                                         int to_kernel_layout, void* stream) {
+extern "C" int styler_repack_conv_weight(const float* src, void* dst, int n, int cin, int kw, int to_kernel_layout,
+                                         int out_bf16, void* stream) {
   if (!src || !dst || n <= 0 || cin <= 0 || kw <= 0) return STYLER_EINVAL;
   const int64_t total = (int64_t)n * cin * kw;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(repack_conv_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n,
-                     cin, kw, to_kernel_layout);
+  if (out_bf16)
+    hipLaunchKernelGGL(repack_conv_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src,
+                       reinterpret_cast<uint16_t*>(dst), n, cin, kw, to_kernel_layout);
+  else
+    hipLaunchKernelGGL(repack_conv_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src,
+                       reinterpret_cast<float*>(dst), n, cin, kw, to_kernel_layout);
   return launch_status();
 }
 

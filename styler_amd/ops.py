@@ -151,14 +151,12 @@ def cast_bf16(src):
     return dst
 
 
-def repack_conv_weight(w, to_kernel_layout=True):
-    """[n, cin, kw] -> [n, kw*cin] (kernel layout) or back."""
-    if to_kernel_layout:
-        n, cin, kw = w.shape
-        dst = torch.empty(n, kw * cin, device=w.device, dtype=torch.float32)
-    else:
-        raise NotImplementedError
-    _chk(lib.styler_repack_conv_weight(w.data_ptr(), dst.data_ptr(), n, cin, kw, 1, _stream()),
+def repack_conv_weight(w, to_kernel_layout=True, bf16=False):
+    """[n, cin, kw] -> [n, kw*cin] (kernel layout), fp32 or directly the bf16 shadow."""
+    assert to_kernel_layout
+    n, cin, kw = w.shape
+    dst = torch.empty(n, kw * cin, device=w.device, dtype=torch.bfloat16 if bf16 else torch.float32)
+    _chk(lib.styler_repack_conv_weight(w.data_ptr(), dst.data_ptr(), n, cin, kw, 1, int(bf16), _stream()),
          "styler_repack_conv_weight")
     return dst
 
@@ -429,14 +427,15 @@ def colsum(dz, out, out2=None):
     _chk(lib.styler_colsum(dz.data_ptr(), _ld(dz), out.data_ptr(), _ptr(out2), rows, C, _stream()), "styler_colsum")
 
 
-def repack_weight_bwd(w):
-    """parameter layout [n, cin, kw] (or [n, cin]) -> dX-conv weight [cin, kw*n] (taps flipped)."""
+def repack_weight_bwd(w, bf16=False):
+    """parameter layout [n, cin, kw] (or [n, cin]) -> dX-conv weight [cin, kw*n] (taps flipped), fp32 or bf16."""
     if w.dim() == 2:
         n, cin, kw = w.shape[0], w.shape[1], 1
     else:
         n, cin, kw = w.shape
-    dst = torch.empty(cin, kw * n, device=w.device, dtype=torch.float32)
-    _chk(lib.styler_repack_weight_bwd(w.data_ptr(), dst.data_ptr(), n, cin, kw, _stream()), "styler_repack_weight_bwd")
+    dst = torch.empty(cin, kw * n, device=w.device, dtype=torch.bfloat16 if bf16 else torch.float32)
+    _chk(lib.styler_repack_weight_bwd(w.data_ptr(), dst.data_ptr(), n, cin, kw, int(bf16), _stream()),
+         "styler_repack_weight_bwd")
     return dst
 
 

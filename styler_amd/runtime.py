@@ -46,10 +46,10 @@ class Derived:
 def gemm_weight(cache, key, weight, cin):
     """Kernel-layout weight for the current precision: ([n, kw*cin] tensor, prec)."""
     import torch
+    if rt.prec == ops.PREC_BF16 and cin % 8 == 0:
+        wb = cache.get(key + ":bf16", [weight], lambda w: ops.cast_bf16(w.detach()) if w.dim() == 2
+                       else ops.repack_conv_weight(w.detach(), bf16=True))
+        return wb, ops.PREC_BF16
     w32 = cache.get(key + ":k", [weight],
                     lambda w: w.detach() if w.dim() == 2 else ops.repack_conv_weight(w.detach()))
-    if rt.prec == ops.PREC_BF16 and cin % 8 == 0:
-        wb = cache.get(key + ":bf16", [weight], lambda w: ops.cast_bf16(
-            w.detach() if w.dim() == 2 else ops.repack_conv_weight(w.detach())))
-        return wb, ops.PREC_BF16
     return w32, ops.PREC_F32
