@@ -156,6 +156,19 @@ int styler_mel_calibrate(const float* x, int64_t ldx, float* y, int64_t ldy,
 int styler_lstm_bidir(const float* gx, const float* w_hh, float* out, float* cell_out,
                       float* gates_out, int B, int S, int H, void* stream);
 
+/* Up to 4 independent BiLSTM layers in ONE launch (same semantics as styler_lstm_bidir per
+ * descriptor; `descs` is a HOST array of `count` <= 4 entries, H in {64, 80}). */
+typedef struct StylerLstmDesc {
+  const float* gx;
+  const float* w_hh;
+  float* out;
+  float* cell_out;   /* optional */
+  float* gates_out;  /* optional */
+  int32_t H;
+  int32_t _pad;
+} StylerLstmDesc;
+int styler_lstm_bidir_multi(const StylerLstmDesc* descs, int count, int B, int S, void* stream);
+
 /* AugmentationClassifier tail (modules.py:29-45): h [B,S,256] (= d_fc1 output) ->
  * LayerNorm -> ReLU -> Linear(256,2) -> LogSoftmax -> mean over all S rows (pads
  * included) -> out [B,2]. */
@@ -308,6 +321,17 @@ int styler_mel_calibrate_bwd(const float* dy, int64_t lddy, float* dx, int64_t l
                              int C, void* stream);
 int styler_lstm_bidir_bwd(const float* dout, const float* gates, const float* cell,
                           const float* w_hh, float* dgp, int B, int S, int H, void* stream);
+/* Backward of up to 4 BiLSTM layers in one launch (HOST descriptor array). */
+typedef struct StylerLstmBwdDesc {
+  const float* dout;
+  const float* gates;
+  const float* cell;
+  const float* w_hh;
+  float* dgp;
+  int32_t H;
+  int32_t _pad;
+} StylerLstmBwdDesc;
+int styler_lstm_bidir_bwd_multi(const StylerLstmBwdDesc* descs, int count, int B, int S, void* stream);
 int styler_aug_classifier_tail_bwd(const float* h, const float* ln_g, const float* ln_b,
                                    const float* w2, const float* b2, const float* dout, float* dh,
                                    float* dln_g, float* dln_b, float* dw2, float* db2, int B, int S,

@@ -32,6 +32,8 @@ _SIGS = {
     "styler_onehot_conv5": [P, P, P, P, I64, P, P, I, I, I, P],
     "styler_mel_calibrate": [P, I64, P, I64, P, P, I, I, I, I, P],
     "styler_lstm_bidir": [P, P, P, P, P, I, I, I, P],
+    "styler_lstm_bidir_multi": [P, I, I, I, P],
+    "styler_lstm_bidir_bwd_multi": [P, I, I, I, P],
     "styler_aug_classifier_tail": [P, P, P, P, P, P, I, I, P],
     "styler_duration_scan": [P, I, P, F, P, P, P, I, I, P],
     "styler_length_regulate": [P, I64, P, P, I64, P, I, I, I, I, P],
@@ -67,6 +69,16 @@ _SIGS = {
     "styler_stft_mel_workspace_bytes": [I, I],
     "styler_stft_mel": [P, I64, P, P, P, P, P, P, P, I, I, I, P],
 }
+
+
+class LstmDesc(ctypes.Structure):
+    _fields_ = [("gx", P), ("w_hh", P), ("out", P), ("cell_out", P), ("gates_out", P), ("H", ctypes.c_int32),
+                ("_pad", ctypes.c_int32)]
+
+
+class LstmBwdDesc(ctypes.Structure):
+    _fields_ = [("dout", P), ("gates", P), ("cell", P), ("w_hh", P), ("dgp", P), ("H", ctypes.c_int32),
+                ("_pad", ctypes.c_int32)]
 
 
 def _load():

@@ -258,6 +258,51 @@ class LstmLayerFn(Function):
         return dx, None, None, None, None, None, None
 
 
+class LstmMultiLayerFn(Function):
+    """One bidirectional layer of ALL four AudioEncoder LSTMs: four input GEMMs, one recurrent launch; backward: one
+    BPTT launch, then the weight / input gradients as GEMMs."""
+
+    @staticmethod
+    def forward(ctx, enc, layer, anchor, *xs):
+        Hs = enc.necks
+        gxs, w_hhs = [], []
+        for s, x in enumerate(xs):
+            lstm = getattr(enc, f"lstm_{s + 1}")
+            w, bias, w_hh, prec = enc._lstm_weights(lstm, layer, f"lstm{s}_{layer}", x.shape[-1])
+            gxs.append(ops.conv_gemm(x, w, bias, n=8 * Hs[s], prec=prec))
+            w_hhs.append(w_hh)
+        outs, cells, gates = ops.lstm_bidir_multi(gxs, w_hhs, Hs, save=True)
+        ctx.save_for_backward(*xs, *outs, *cells, *gates, *w_hhs)
+        ctx.enc, ctx.layer = enc, layer
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        enc, layer = ctx.enc, ctx.layer
+        Hs = enc.necks
+        t = ctx.saved_tensors
+        xs, outs, cells, gates, w_hhs = t[0:4], t[4:8], t[8:12], t[12:16], t[16:20]
+        dgps = ops.lstm_bidir_bwd_multi(douts, gates, cells, w_hhs, Hs)
+        dxs = []
+        for s in range(4):
+            lstm = getattr(enc, f"lstm_{s + 1}")
+            H, x, dgp, cin = Hs[s], xs[s], dgps[s], xs[s].shape[-1]
+            for d, sfx in enumerate(("", "_reverse")):
+                sl = dgp[..., d * 4 * H:(d + 1) * 4 * H]
+                ops.wgrad(sl, x, G(getattr(lstm, f"weight_ih_l{layer}{sfx}")), 4 * H, cin)
+                ops.wgrad(sl, outs[s][..., d * H:(d + 1) * H], G(getattr(lstm, f"weight_hh_l{layer}{sfx}")), 4 * H, H,
+                          pad_left=1 if d == 0 else -1)
+                ops.colsum(sl, G(getattr(lstm, f"bias_ih_l{layer}{sfx}")), G(getattr(lstm, f"bias_hh_l{layer}{sfx}")))
+            dx = None
+            if ctx.needs_input_grad[3 + s]:
+                srcs = [getattr(lstm, f"weight_ih_l{layer}"), getattr(lstm, f"weight_ih_l{layer}_reverse")]
+                wt = enc._derived.get(f"lstm{s}_{layer}wiT", srcs,
+                                      lambda a, b: torch.cat([a.detach(), b.detach()]).t().contiguous())
+                dx = ops.conv_gemm(dgp, wt, None, n=cin)
+            dxs.append(dx)
+        return (None, None, None, *dxs)
+
+
 class AugTailFn(Function):
     @staticmethod
     def forward(ctx, h, anchor, c):

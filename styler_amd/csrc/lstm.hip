@@ -9,14 +9,16 @@
 #include "common.h"
 
 template <int H>
-__global__ __launch_bounds__(4 * H) void lstm_bidir_kernel(const float* __restrict__ gx,
-                                                           const float* __restrict__ w_hh, float* __restrict__ out,
-                                                           float* __restrict__ cell_out,
-                                                           float* __restrict__ gates_out, int S) {
-  __shared__ __attribute__((aligned(16))) float hbuf[H];
-  __shared__ float gbuf[4 * H];
+__device__ __forceinline__ void lstm_fwd_body(const float* __restrict__ gx, const float* __restrict__ w_hh,
+                                              float* __restrict__ out, float* __restrict__ cell_out,
+                                              float* __restrict__ gates_out, int S, float* hbuf, float* gbuf) {
   const int j = threadIdx.x;                 // gate row 0..4H-1 (i | f | g | o)
   const int b = blockIdx.x, dir = blockIdx.y;
+  if (j >= 4 * H) {                          // surplus threads of a shared launch only take part in the barriers
+    __syncthreads();
+    for (int step = 0; step < S; ++step) { __syncthreads(); __syncthreads(); }
+    return;
+  }
   float w[H];
   {
     const float* wp = w_hh + ((int64_t)dir * 4 * H + j) * H;
@@ -60,6 +62,42 @@ __global__ __launch_bounds__(4 * H) void lstm_bidir_kernel(const float* __restri
   }
 }
 
+template <int H>
+__global__ __launch_bounds__(4 * H) void lstm_bidir_kernel(const float* __restrict__ gx,
+                                                           const float* __restrict__ w_hh, float* __restrict__ out,
+                                                           float* __restrict__ cell_out,
+                                                           float* __restrict__ gates_out, int S) {
+  __shared__ __attribute__((aligned(16))) float hbuf[H];
+  __shared__ float gbuf[4 * H];
+  lstm_fwd_body<H>(gx, w_hh, out, cell_out, gates_out, S, hbuf, gbuf);
+}
+
+// Up to 4 independent BiLSTM layers (the duration / f0 / energy / residual streams, modules.py:179-182) in ONE launch:
+// grid (B, 2, count), 320 threads; H is 80 or 64 per descriptor.  The four recurrences are latency-bound and use
+// 96 blocks each, so running them side by side costs the time of the slowest instead of the sum.
+struct LstmMultiArgs { StylerLstmDesc d[4]; };
+
+__global__ __launch_bounds__(320) void lstm_bidir_multi_kernel(LstmMultiArgs a, int S) {
+  __shared__ __attribute__((aligned(16))) float hbuf[80];
+  __shared__ float gbuf[320];
+  const StylerLstmDesc d = a.d[blockIdx.z];
+  if (d.H == 80)
+    lstm_fwd_body<80>(d.gx, d.w_hh, d.out, d.cell_out, d.gates_out, S, hbuf, gbuf);
+  else
+    lstm_fwd_body<64>(d.gx, d.w_hh, d.out, d.cell_out, d.gates_out, S, hbuf, gbuf);
+}
+
+extern "C" int styler_lstm_bidir_multi(const StylerLstmDesc* descs, int count, int B, int S, void* stream) {
+  if (!descs || count <= 0 || count > 4 || B <= 0 || S <= 0) return STYLER_EINVAL;
+  LstmMultiArgs a;
+  for (int i = 0; i < count; ++i) {
+    a.d[i] = descs[i];
+    if (!descs[i].gx || !descs[i].w_hh || !descs[i].out || (descs[i].H != 64 && descs[i].H != 80)) return STYLER_EINVAL;
+  }
+  hipLaunchKernelGGL(lstm_bidir_multi_kernel, dim3(B, 2, count), dim3(320), 0, (hipStream_t)stream, a, S);
+  return launch_status();
+}
+
 extern "C" int styler_lstm_bidir(const float* gx, const float* w_hh, float* out, float* cell_out, float* gates_out,
                                  int B, int S, int H, void* stream) {
   if (!gx || !w_hh || !out || B <= 0 || S <= 0) return STYLER_EINVAL;
@@ -83,15 +121,15 @@ extern "C" int styler_lstm_bidir(const float* gx, const float* w_hh, float* out,
 // mat-vec dh_prev[k] = sum_j W_hh[j][k] dgp[j] with thread (q = tid / H, k = tid % H) holding the H
 // weights W_hh[q*H + j'][k] in registers and the 4 partial sums combined through LDS.
 template <int H>
-__global__ __launch_bounds__(4 * H) void lstm_bidir_bwd_kernel(const float* __restrict__ dout,
-                                                               const float* __restrict__ gates,
-                                                               const float* __restrict__ cell,
-                                                               const float* __restrict__ w_hh,
-                                                               float* __restrict__ dgp, int S) {
-  __shared__ __attribute__((aligned(16))) float sdg[4 * H];
-  __shared__ float part[4][H];
+__device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ dout, const float* __restrict__ gates,
+                                              const float* __restrict__ cell, const float* __restrict__ w_hh,
+                                              float* __restrict__ dgp, int S, float* sdg, float (*part)[80]) {
   const int tid = threadIdx.x, q = tid / H, k = tid % H;
   const int b = blockIdx.x, dir = blockIdx.y;
+  if (tid >= 4 * H) {                        // surplus threads of a shared launch only take part in the barriers
+    for (int step = 0; step < S; ++step) { __syncthreads(); __syncthreads(); __syncthreads(); }
+    return;
+  }
   float w[H];
   {
     const float* wp = w_hh + ((int64_t)dir * 4 * H + q * H) * H + k;     // column k of gate block q
@@ -135,6 +173,42 @@ __global__ __launch_bounds__(4 * H) void lstm_bidir_bwd_kernel(const float* __re
     if (tid < H) dh_rec = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
     __syncthreads();
   }
+}
+
+template <int H>
+__global__ __launch_bounds__(4 * H) void lstm_bidir_bwd_kernel(const float* __restrict__ dout,
+                                                               const float* __restrict__ gates,
+                                                               const float* __restrict__ cell,
+                                                               const float* __restrict__ w_hh,
+                                                               float* __restrict__ dgp, int S) {
+  __shared__ __attribute__((aligned(16))) float sdg[4 * 80];
+  __shared__ float part[4][80];
+  lstm_bwd_body<H>(dout, gates, cell, w_hh, dgp, S, sdg, part);
+}
+
+struct LstmBwdMultiArgs { StylerLstmBwdDesc d[4]; };
+
+__global__ __launch_bounds__(320) void lstm_bidir_bwd_multi_kernel(LstmBwdMultiArgs a, int S) {
+  __shared__ __attribute__((aligned(16))) float sdg[4 * 80];
+  __shared__ float part[4][80];
+  const StylerLstmBwdDesc d = a.d[blockIdx.z];
+  if (d.H == 80)
+    lstm_bwd_body<80>(d.dout, d.gates, d.cell, d.w_hh, d.dgp, S, sdg, part);
+  else
+    lstm_bwd_body<64>(d.dout, d.gates, d.cell, d.w_hh, d.dgp, S, sdg, part);
+}
+
+extern "C" int styler_lstm_bidir_bwd_multi(const StylerLstmBwdDesc* descs, int count, int B, int S, void* stream) {
+  if (!descs || count <= 0 || count > 4 || B <= 0 || S <= 0) return STYLER_EINVAL;
+  LstmBwdMultiArgs a;
+  for (int i = 0; i < count; ++i) {
+    a.d[i] = descs[i];
+    if (!descs[i].dout || !descs[i].gates || !descs[i].cell || !descs[i].w_hh || !descs[i].dgp ||
+        (descs[i].H != 64 && descs[i].H != 80))
+      return STYLER_EINVAL;
+  }
+  hipLaunchKernelGGL(lstm_bidir_bwd_multi_kernel, dim3(B, 2, count), dim3(320), 0, (hipStream_t)stream, a, S);
+  return launch_status();
 }
 
 extern "C" int styler_lstm_bidir_bwd(const float* dout, const float* gates, const float* cell, const float* w_hh,

@@ -154,10 +154,20 @@ class AudioEncoder(_HipModule):
             raise AssertionError("quantize_1D_torch: input outside [0, 1] (utils.py:423)")
         S = int(max_seq_len) if max_seq_len is not None else int(seq_len.max().item())
         cal = AG.MelCalibrateFn.apply(catbuf, len_org, seq_len, S) if grad else ops.mel_calibrate(catbuf, len_org, seq_len, S)
-        outs = []
-        for s in range(4):
-            outs.append(self._lstm(s, cal[..., offs[s]:offs[s] + W[s]]))
-        return tuple(outs)
+        # the four 2-layer BiLSTMs advance layer by layer together: 4 input GEMMs + ONE recurrent launch per layer
+        xs = [cal[..., offs[s]:offs[s] + W[s]] for s in range(4)]
+        for layer in range(2):
+            if grad:
+                xs = list(AG.LstmMultiLayerFn.apply(self, layer, self.lstm_1.weight_hh_l0, *xs))
+            else:
+                gxs, w_hhs = [], []
+                for s in range(4):
+                    w, bias, w_hh, prec = self._lstm_weights(getattr(self, f"lstm_{s + 1}"), layer, f"lstm{s}_{layer}",
+                                                             xs[s].shape[-1])
+                    gxs.append(ops.conv_gemm(xs[s], w, bias, n=8 * self.necks[s], prec=prec))
+                    w_hhs.append(w_hh)
+                xs = ops.lstm_bidir_multi(gxs, w_hhs, self.necks)
+        return tuple(xs)
 
 
 class StyleEncoder(_HipModule):

@@ -276,6 +276,38 @@ def lstm_bidir(gx, w_hh, H, cell_out=None, gates_out=None):
     return out
 
 
+def lstm_bidir_multi(gxs, w_hhs, Hs, save=False):
+    """Up to 4 independent BiLSTM layers in one launch.  Returns outs (and, with save=True, cells and gates)."""
+    from ._lib import LstmDesc
+    n = len(gxs)
+    B, S, _ = gxs[0].shape
+    dev = gxs[0].device
+    outs = [torch.empty(B, S, 2 * H, device=dev, dtype=torch.float32) for H in Hs]
+    cells = [torch.empty(B, S, 2 * H, device=dev, dtype=torch.float32) for H in Hs] if save else [None] * n
+    gates = [torch.empty(B, S, 8 * H, device=dev, dtype=torch.float32) for H in Hs] if save else [None] * n
+    descs = (LstmDesc * n)()
+    for i in range(n):
+        assert gxs[i].is_contiguous() and w_hhs[i].is_contiguous() and gxs[i].shape[2] == 8 * Hs[i]
+        descs[i] = LstmDesc(gxs[i].data_ptr(), w_hhs[i].data_ptr(), outs[i].data_ptr(), _ptr(cells[i]), _ptr(gates[i]),
+                            Hs[i], 0)
+    _chk(lib.styler_lstm_bidir_multi(descs, n, B, S, _stream()), "styler_lstm_bidir_multi")
+    return (outs, cells, gates) if save else outs
+
+
+def lstm_bidir_bwd_multi(douts, gates, cells, w_hhs, Hs):
+    from ._lib import LstmBwdDesc
+    n = len(douts)
+    douts = [d.contiguous() for d in douts]
+    B, S, _ = douts[0].shape
+    dgps = [torch.empty(B, S, 8 * H, device=douts[0].device, dtype=torch.float32) for H in Hs]
+    descs = (LstmBwdDesc * n)()
+    for i in range(n):
+        descs[i] = LstmBwdDesc(douts[i].data_ptr(), gates[i].data_ptr(), cells[i].data_ptr(), w_hhs[i].data_ptr(),
+                               dgps[i].data_ptr(), Hs[i], 0)
+    _chk(lib.styler_lstm_bidir_bwd_multi(descs, n, B, S, _stream()), "styler_lstm_bidir_bwd_multi")
+    return dgps
+
+
 def aug_classifier_tail(h, ln_g, ln_b, w2, b2):
     B, S, _ = h.shape
     assert h.is_contiguous()
