@@ -140,7 +140,7 @@ def run(args, mode, rank, world, dev, dist):
     ps = max(1, args.prof_steps)
     if train:       # dominant kernel of the step by time: the weight-gradient MFMA GEMM
         if args.prec == "bf16":
-            dom, dom_name, peak = "wgrad_bf16", "wgrad_bf16_kernel<KW> (all tap counts)", MFMA_PEAK_TFLOPS["bf16"]
+            dom, dom_name, peak = "wgrad_bf16", "wgrad_tr_kernel<KW,TA,TB> (all tap counts)", MFMA_PEAK_TFLOPS["bf16"]
         else:
             dom, dom_name, peak = "wgrad", "wgrad_kernel<KW> (all tap counts)", MFMA_PEAK_TFLOPS["fp32"]
     else:

@@ -10,6 +10,7 @@
 // their row-major [k = time][feature] LDS images (A[i][k]: lane (i, h) reads row k = 2*kk + h), so no
 // transposition of dz or x is ever materialised.  dw is addressed with explicit strides so the result
 // lands directly in the PARAMETER layout ([n, cin, kw] for conv taps, [n, cin] for Linear).
+#include <cstdlib>
 #include "common.h"
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16_b(float lo, float hi) {
@@ -324,6 +325,234 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 wgrad, transpose-read engine (the default).  Same contraction and chunking as wgrad_bf16_kernel, but
+//   * the block tile is (64*TA) n-features x (64*TB) c-features x KW taps, 4 waves as 2x2, each wave TA x TB MFMA
+//     tiles per tap: operand bytes fetched per MFMA fall by TA*TB/(TA+TB) x 2 (the 64x64 tile is L2-fetch-bound on
+//     the Linear shapes: 16 flop per fp32 operand byte);
+//   * fragments come from gfx950's LDS transpose read (ds_read_b64_tr_b16): the time-major image is kept as
+//     [k/4][f/16] sub-tiles of [4 rows][16 features] bf16 (128 B each); one read hands every lane 4 consecutive time
+//     rows of ITS feature, i.e. half an MFMA fragment -- 2 reads per A fragment, 2..4 per x window, instead of
+//     8..16 two-byte reads plus the packing VALU.
+//   Row r of sub-tile fs sits in 32-byte slot (r + fs) & 3: a staging pass (16 lanes = one time row, four
+//   sub-tiles) and a transpose read (32 lanes = 2 sub-tiles x 4 rows = one full 256-B bank row) are both
+//   conflict-free.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint2 lds_tr_read(const uint16_t* p) {
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(const_cast<uint16_t*>(p)));
+  return *reinterpret_cast<const uint2*>(&v);
+}
+
+template <int KW, int TA, int TB>
+__global__ __launch_bounds__(256) void wgrad_tr_kernel(const float* __restrict__ dz, int64_t lddz,
+                                                       const float* __restrict__ x, int64_t ldx,
+                                                       float* __restrict__ db, int B, int L, int n, int cin,
+                                                       int pad_left, int ct, int cpi, int chunks_per_split,
+                                                       int tiles, int splits, float* __restrict__ ws) {
+  constexpr int FA = 64 * TA, FB = 64 * TB;          // features per block tile
+  constexpr int XR = KW == 1 ? 64 : 72;              // x rows per chunk incl. halo (KW - 1 <= 8)
+  constexpr int NR = (8 + KW - 1 + 3) / 4;           // transpose reads per x window
+  constexpr int SA = FA / 16, SB = FB / 16;          // sub-tiles per 4-row block
+  constexpr int VA = FA / 4, VB = FB / 4;            // float4 per staged row
+  constexpr int RPA = 256 / VA, RPB = 256 / VB;      // rows per staging pass
+  constexpr int PA = 64 / RPA, PB = (XR + RPB - 1) / RPB;
+  constexpr int SMEM_MAIN = 2 * (64 * FA + XR * FB) * 2;
+  constexpr int SMEM_BIAS = RPA * FA * 4;
+  __shared__ __attribute__((aligned(256))) unsigned char smem_raw[SMEM_MAIN > SMEM_BIAS ? SMEM_MAIN : SMEM_BIAS];
+  uint16_t* const sA = reinterpret_cast<uint16_t*>(smem_raw);            // 2 x [16][SA][4][16]
+  uint16_t* const sB = sA + 2 * 64 * FA;                                 // 2 x [XR/4][SB][4][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  // Block -> (split, tile): workgroup b runs on XCD b % 8 (observed dispatch rule, speed only).  With >= 8 splits an
+  // XCD owns whole splits: all tiles of a split read the SAME time rows of dz and x, so each operand slice is fetched
+  // into that XCD's L2 once and re-read from there by the other tiles (tile-major order scattered them over all
+  // eight L2s: 40 % hit rate, 2.4x the algorithmic HBM bytes).
+  int tile, split;
+  if (splits >= 8) {
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    split = xcd + 8 * (k / tiles);
+    tile = k % tiles;
+    if (split >= splits) return;
+  } else {
+    tile = blockIdx.x % tiles;
+    split = blockIdx.x / tiles;
+  }
+  const int n0 = (tile / ct) * FA, c0 = (tile % ct) * FB;
+  const int64_t nchunks = (int64_t)B * cpi;
+  const int64_t ch0 = (int64_t)split * chunks_per_split;
+  int64_t ch1 = ch0 + chunks_per_split; if (ch1 > nchunks) ch1 = nchunks;
+  if (ch0 >= ch1) return;
+
+  // ---- staging coordinates ----
+  const int aq = (tid % VA) * 4, ar = tid / VA;      // feature / first row of this thread's float4s (dz)
+  const int bq = (tid % VB) * 4, br = tid / VB;      // (x)
+  const uint32_t sa_off = ((ar >> 2) * SA + (aq >> 4)) * 64 + (((ar & 3) + (aq >> 4)) & 3) * 16 + (aq & 15);
+  const uint32_t sb_off = ((br >> 2) * SB + (bq >> 4)) * 64 + (((br & 3) + (bq >> 4)) & 3) * 16 + (bq & 15);
+  // Operand fetch = raw buffer loads against per-chunk descriptors (base = the chunk's first row inside the item,
+  // num_records = the bytes from there to the item's end): time rows after the item (ragged last chunk, trailing
+  // halo) are out of range and read as zeros in hardware; halo rows BEFORE the item get a negative offset, which
+  // wraps far above num_records; feature columns past the edge carry the OOB marker.  No masks, no branches, one
+  // v_add per load.
+  constexpr uint32_t OOB = 0x80000000u;
+  constexpr int64_t REC_MAX = (int64_t)1 << 30;      // chunk-relative offsets are < 3 MB; markers and wraps are > 2^30
+  const int cinp = (cin + 3) & ~3;
+  const uint32_t va0 = n0 + aq < n ? (uint32_t)((ar * lddz + n0 + aq) * 4) : OOB;
+  const uint32_t vb0 = c0 + bq < cinp ? (uint32_t)((br * ldx + c0 + bq) * 4) : OOB;
+  const uint32_t a_pstep = (uint32_t)(RPA * lddz * 4), b_pstep = (uint32_t)(RPB * ldx * 4);
+  float4 ra0[PA], rb0[PB];
+  auto load = [&](float4 (&ra)[PA], float4 (&rb)[PB], int ch) {
+    const int b = ch / cpi;
+    const int t0 = (ch - b * cpi) * WB_BK;
+    const int64_t rowb = (int64_t)b * L;
+    const int tx = t0 - pad_left;                    // first x row of the chunk (halo included); may be < 0
+    const int txb = tx > 0 ? tx : 0;
+    int64_t a_rec = ((int64_t)(L - t0 - 1) * lddz + n) * 4;
+    int64_t b_rec = ((int64_t)(L - txb - 1) * ldx + cinp) * 4;
+    a_rec = a_rec > REC_MAX ? REC_MAX : a_rec;
+    b_rec = b_rec > REC_MAX ? REC_MAX : (b_rec < 0 ? 0 : b_rec);
+    const __amdgpu_buffer_rsrc_t ra_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz + (rowb + t0) * lddz), 0, (int)a_rec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (rowb + txb) * ldx), 0, (int)b_rec, 0x00020000);
+    const uint32_t b_off = (uint32_t)((tx - txb) * (int)ldx * 4);        // <= 0: rows before the item wrap out of range
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, va0 + p * a_pstep, 0, 0);
+      ra[p] = *reinterpret_cast<const float4*>(&v);
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      if (p * RPB >= XR) continue;
+      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rb_rsrc, vb0 + (b_off + p * b_pstep), 0, 0);
+      rb[p] = *reinterpret_cast<const float4*>(&v);
+    }
+  };
+  float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto store = [&](const float4 (&ra)[PA], const float4 (&rb)[PB], int buf) {
+    uint16_t* da = sA + buf * 64 * FA + sa_off;
+    uint16_t* dbp = sB + buf * XR * FB + sb_off;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      bs.x += ra[p].x; bs.y += ra[p].y; bs.z += ra[p].z; bs.w += ra[p].w;
+      *reinterpret_cast<uint2*>(da + p * (RPA / 4) * SA * 64) =
+          make_uint2(cvt_pk_bf16_b(ra[p].x, ra[p].y), cvt_pk_bf16_b(ra[p].z, ra[p].w));
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p)
+      if (br + p * RPB < XR)
+        *reinterpret_cast<uint2*>(dbp + p * (RPB / 4) * SB * 64) =
+            make_uint2(cvt_pk_bf16_b(rb[p].x, rb[p].y), cvt_pk_bf16_b(rb[p].z, rb[p].w));
+  };
+
+  // ---- fragment read coordinates: 16-lane group (ch = feature half, lh = k half), q = lane in the group ----
+  const int q = lane & 15, chf = (lane >> 4) & 1;
+  uint32_t fa_off[TA], fb_off[TB];
+#pragma unroll
+  for (int i = 0; i < TA; ++i) {
+    const int fs = 2 * (wm * TA + i) + chf;
+    fa_off[i] = (lh * 2 * SA + fs) * 64 + (((q >> 2) + fs) & 3) * 16 + (q & 3) * 4;
+  }
+#pragma unroll
+  for (int i = 0; i < TB; ++i) {
+    const int fs = 2 * (wn * TB + i) + chf;
+    fb_off[i] = (lh * 2 * SB + fs) * 64 + (((q >> 2) + fs) & 3) * 16 + (q & 3) * 4;
+  }
+
+  f32x16 acc[TA][TB][KW];
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int jt = 0; jt < TB; ++jt)
+#pragma unroll
+      for (int j = 0; j < KW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][jt][j][r] = 0.f;
+
+  auto compute = [&](int buf) {
+    const uint16_t* pa = sA + buf * 64 * FA;
+    const uint16_t* pb = sB + buf * XR * FB;
+#pragma unroll
+    for (int s = 0; s < WB_BK / 16; ++s) {
+      bf16x8 fa[TA];
+#pragma unroll
+      for (int i = 0; i < TA; ++i) {
+        const uint2 lo = lds_tr_read(pa + fa_off[i] + (s * 4 + 0) * SA * 64);
+        const uint2 hi = lds_tr_read(pa + fa_off[i] + (s * 4 + 1) * SA * 64);
+        const uint4 a4 = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        fa[i] = *reinterpret_cast<const bf16x8*>(&a4);
+      }
+#pragma unroll
+      for (int jt = 0; jt < TB; ++jt) {
+        uint32_t win[2 * NR + 1];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const uint2 v = lds_tr_read(pb + fb_off[jt] + (s * 4 + r) * SB * 64);
+          win[2 * r] = v.x; win[2 * r + 1] = v.y;
+        }
+        win[2 * NR] = 0u;
+#pragma unroll
+        for (int j = 0; j < KW; ++j) {
+          uint4 b4;
+          const int o = j / 2;
+          if ((j & 1) == 0) {
+            b4 = make_uint4(win[o], win[o + 1], win[o + 2], win[o + 3]);
+          } else {
+            b4 = make_uint4(__builtin_amdgcn_alignbit(win[o + 1], win[o], 16), __builtin_amdgcn_alignbit(win[o + 2], win[o + 1], 16),
+                            __builtin_amdgcn_alignbit(win[o + 3], win[o + 2], 16), __builtin_amdgcn_alignbit(win[o + 4], win[o + 3], 16));
+          }
+          const bf16x8 fb = *reinterpret_cast<const bf16x8*>(&b4);
+#pragma unroll
+          for (int i = 0; i < TA; ++i) acc[i][jt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb, acc[i][jt][j], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  const int ich0 = (int)ch0, ich1 = (int)ch1;
+  load(ra0, rb0, ich0);
+  store(ra0, rb0, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int ch = ich0; ch < ich1; ++ch) {
+    const bool more = ch + 1 < ich1;
+    if (more) load(ra0, rb0, ch + 1);
+    compute(buf);
+    if (more) store(ra0, rb0, buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // partial tile -> workspace [split][n][KW][cin]; C layout: col (= c) = lane&31, row (= n) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* wp = ws + (int64_t)split * n * KW * cin;
+#pragma unroll
+  for (int jt = 0; jt < TB; ++jt) {
+    const int c = c0 + (wn * TB + jt) * 32 + li;
+    if (c >= cin) continue;
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+      for (int j = 0; j < KW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int nn = n0 + (wm * TA + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (nn < n) wp[((int64_t)nn * KW + j) * cin + c] = acc[i][jt][j][r];
+        }
+  }
+  if (db && (tile % ct) == 0) {                      // bias gradient from the fp32 staging registers
+    float* sBias = reinterpret_cast<float*>(smem_raw);                   // [RPA][FA]; the loop's last barrier is behind us
+    *reinterpret_cast<float4*>(&sBias[ar * FA + aq]) = bs;
+    __syncthreads();
+    if (tid < FA && n0 + tid < n) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < RPA; ++r) t += sBias[r * FA + tid];
+      atomicAdd(db + n0 + tid, t);
+    }
+  }
+}
+
 // dw[nn*sn + c*sc + j*sj] += sum over splits of ws[split][nn][j][c]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int64_t sn,
                                                            int64_t sc, int64_t sj, int n, int cin, int kw, int splits) {
@@ -336,9 +565,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// Block tile of the bf16 transpose-read engine, in 64-feature units (TA over n, TB over cin); 0 = the two-byte-gather
+// kernel (STYLER_WGRAD_TR=0, kept for A/B measurements).  STYLER_WGRAD_TILE=11 forces the 64x64 tile.
+static void wgrad_tile(int n, int cin, int kw, int prec, int* TA, int* TB) {
+  *TA = 1; *TB = 1;
+  if (prec != STYLER_PREC_BF16) return;
+  static const int tr_env = [] { const char* e = getenv("STYLER_WGRAD_TR"); return e ? atoi(e) : 1; }();
+  static const int tile_env = [] { const char* e = getenv("STYLER_WGRAD_TILE"); return e ? atoi(e) : 0; }();
+  if (!tr_env) { *TA = 0; *TB = 0; return; }
+  if (tile_env == 11) return;
+  if (tile_env == 22) {                              // experiments: the largest tile the tap count allows
+    if (kw <= 5 && n > 64) *TA = 2;
+    if (kw == 1 && cin > 64) *TB = 2;
+    return;
+  }
+  // measured (C2 shapes): the 128x128 tile pays only for Linear gradients with >= 48 64x64 tiles; with fewer tiles, or
+  // with taps (whose operand reuse already is KW-fold), the extra split-K partials and the lower occupancy cost more
+  if (kw == 1 && ((n + 63) / 64) * ((cin + 63) / 64) >= 48) { *TA = 2; *TB = 2; }
+}
+
 static void wgrad_plan(int B, int L, int n, int cin, int kw, int pad_left, int prec, int* Be, int* Le, int* cpi, int* cps,
                        int* splits) {
-  const int nt = (n + 63) / 64, ct = (cin + 63) / 64;
+  int TA, TB;
+  wgrad_tile(n, cin, kw, prec, &TA, &TB);
+  const int fa = 64 * (TA ? TA : 1), fb = 64 * (TB ? TB : 1);
+  const int nt = (n + fa - 1) / fa, ct = (cin + fb - 1) / fb;
   *Be = B; *Le = L;
   int64_t nchunks;
   if (prec == STYLER_PREC_BF16) {
@@ -350,6 +601,7 @@ static void wgrad_plan(int B, int L, int n, int cin, int kw, int pad_left, int p
     nchunks = ((int64_t)B * L + WG_BK - 1) / WG_BK;
   }
   int64_t sp = (512 + nt * ct - 1) / (nt * ct);      // ~2 blocks per CU; every extra split costs a partial tile round trip
+  if (sp >= 8 && TA) sp = (sp + 4) / 8 * 8;          // whole splits per XCD (see wgrad_tr_kernel)
   if (sp > nchunks / 4) sp = nchunks / 4;
   if (sp < 1) sp = 1;
   *cps = (int)((nchunks + sp - 1) / sp);
@@ -369,13 +621,32 @@ extern "C" int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64
   if (!dz || !x || !dw || !workspace || B <= 0 || L <= 0 || n <= 0 || cin <= 0) return STYLER_EINVAL;
   if (kw != 1 && kw != 3 && kw != 5 && kw != 9) return STYLER_EINVAL;
   if ((lddz & 3) || (ldx & 3) || (n & 3) || ldx < ((cin + 3) & ~3) || ((uintptr_t)dz & 15) || ((uintptr_t)x & 15)) return STYLER_EALIGN;
-  const int nt = (n + 63) / 64, ct = (cin + 63) / 64;
+  int TA, TB;
+  wgrad_tile(n, cin, kw, prec, &TA, &TB);
+  const int fa = 64 * (TA ? TA : 1), fb = 64 * (TB ? TB : 1);
+  const int nt = (n + fa - 1) / fa, ct = (cin + fb - 1) / fb;
   hipStream_t st = (hipStream_t)stream;
   int Be, Le, cpi, cps, splits;
   wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits);
   float* ws = reinterpret_cast<float*>(workspace);
   const dim3 grid(nt * ct, (unsigned)splits);
-  if (prec == STYLER_PREC_BF16) {
+  if (prec == STYLER_PREC_BF16 && TA) {
+    const int tiles = nt * ct;
+    const dim3 grid1((unsigned)(tiles * (splits >= 8 ? (splits + 7) / 8 * 8 : splits)));
+#define WT_LAUNCH(K, A_, B_) hipLaunchKernelGGL((wgrad_tr_kernel<K, A_, B_>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, \
+                                                Be, Le, n, cin, pad_left, ct, cpi, cps, tiles, splits, ws)
+    if (kw == 1) {
+      if (TA == 2 && TB == 2) WT_LAUNCH(1, 2, 2); else if (TA == 2) WT_LAUNCH(1, 2, 1);
+      else if (TB == 2) WT_LAUNCH(1, 1, 2); else WT_LAUNCH(1, 1, 1);
+    } else if (kw == 3) {
+      if (TA == 2) WT_LAUNCH(3, 2, 1); else WT_LAUNCH(3, 1, 1);
+    } else if (kw == 5) {
+      if (TA == 2) WT_LAUNCH(5, 2, 1); else WT_LAUNCH(5, 1, 1);
+    } else {
+      WT_LAUNCH(9, 1, 1);
+    }
+#undef WT_LAUNCH
+  } else if (prec == STYLER_PREC_BF16) {
 #define WB_LAUNCH(K) hipLaunchKernelGGL(wgrad_bf16_kernel<K>, grid, dim3(256), 0, st, dz, lddz, x, ldx, dw, db, stride_n, \
                                         stride_c, stride_j, Be, Le, n, cin, pad_left, ct, cpi, cps, ws)
     if (kw == 1) WB_LAUNCH(1); else if (kw == 3) WB_LAUNCH(3); else if (kw == 5) WB_LAUNCH(5); else WB_LAUNCH(9);

@@ -70,7 +70,8 @@ def test_conv_gemm_backward(dev, B, L, cin, n, kw, act):
 
 @pytest.mark.parametrize("B,L,cin,n,kw,pad", [(3, 137, 256, 256, 1, 0), (2, 150, 256, 1024, 9, 4), (2, 141, 80, 512, 5, 2),
                                                (4, 61, 256, 256, 3, 1), (5, 1, 512, 128, 1, 0), (3, 70, 64, 256, 1, 1),
-                                               (3, 70, 64, 256, 1, -1), (2, 66, 260, 320, 5, 2)])
+                                               (3, 70, 64, 256, 1, -1), (2, 66, 260, 320, 5, 2), (3, 90, 256, 64, 1, 0),
+                                               (2, 80, 48, 64, 3, 1), (2, 100, 320, 64, 5, 2), (2, 130, 192, 320, 1, 0)])
 def test_wgrad_bf16(dev, B, L, cin, n, kw, pad):
     """bf16-operand weight gradient (sliding-window gather kernel) vs fp64; also the shifted-Linear form used for
     the LSTM recurrent weights (pad +1 / -1) and the one-hot conv form (cin = 257 padded to 260)."""

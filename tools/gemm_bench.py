@@ -12,7 +12,40 @@ SHAPES = [  # name, B, L, cin, n, kw
     ("enc_w1_k9", 48, 60, 256, 1024, 9), ("mel_linear", 48, 441, 256, 80, 1), ("big_w1", 128, 2000, 256, 1024, 9),
 ]
 
+WGRAD_SHAPES = [  # name, B, L, cin, n, kw  (dw[n, cin, kw] += dz^T x)
+    ("w_ffn_w1_k9", 48, 441, 256, 1024, 9), ("w_ffn_w2_k1", 48, 441, 1024, 256, 1), ("w_qkv", 48, 441, 256, 768, 1),
+    ("w_attn_fc", 48, 441, 256, 256, 1), ("w_postnet_k5", 48, 441, 512, 512, 5), ("w_pred_k3", 48, 441, 256, 256, 3),
+    ("w_aenc_320_k5", 48, 441, 320, 320, 5), ("w_lstm_ih", 48, 60, 320, 640, 1), ("w_enc_qkv", 48, 60, 256, 768, 1),
+    ("w_mel_linear", 48, 441, 256, 80, 1),
+]
+
+
+def wgrad_main():
+    dev = torch.device("cuda")
+    for name, B, L, cin, n, kw in WGRAD_SHAPES:
+        dz = torch.randn(B, L, n, device=dev)
+        x = torch.randn(B, L, cin, device=dev)
+        dw = torch.zeros(n, cin, kw, device=dev) if kw > 1 else torch.zeros(n, cin, device=dev)
+        db = torch.zeros(n, device=dev)
+        for prec in ("bf16",):
+            p = ops.PREC_BF16
+            for _ in range(3):
+                ops.wgrad(dz, x, dw, n, cin, kw=kw, db=db, prec=p)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            iters = 20
+            e0.record()
+            for _ in range(iters):
+                ops.wgrad(dz, x, dw, n, cin, kw=kw, db=db, prec=p)
+            e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / iters
+            fl = 2.0 * B * L * n * kw * cin
+            sp = ops.lib.styler_wgrad_splits(B, L, n, cin, kw, kw // 2, p)
+            print(f"{name:16s} {prec:5s} K={B*L:6d} n={n:5d} cin={cin:5d} kw={kw} splits={sp:4d} {us:9.1f} us  {fl/us/1e6:8.1f} TFLOP/s (incl. reduce)", flush=True)
+
+
 def main():
+    if "wgrad" in sys.argv[1:]:
+        return wgrad_main()
     dev = torch.device("cuda")
     precs = [a for a in sys.argv[1:] if a in ("bf16", "fp32")] or ["bf16", "fp32"]
     only = [a for a in sys.argv[1:] if a not in ("bf16", "fp32")]
