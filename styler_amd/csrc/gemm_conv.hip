@@ -27,6 +27,8 @@
 #include <type_traits>
 #include "common.h"
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
 struct GemmArgs {
   const float* x; int64_t ldx;
   const void* w;
@@ -96,31 +98,24 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
   const int ncc = (a.cin + BK - 1) / BK;           // channel chunks
   const int nsteps = ncc * kw;
 
-  // ---- per-lane load coordinates: every global address is (wave-uniform base) + (32-bit lane offset) ----
+  // ---- operand fetch = raw buffer loads: (uniform descriptor) + (32-bit lane offset) ----
+  // The descriptor of a load starts at the tile's first row inside the tensor and ends with the tensor (num_records):
+  // rows past the end read as zeros in hardware; halo rows before row 0 get a negative offset, which wraps far above
+  // num_records; channels past cin (partial last chunk) swap in the OOB marker.  No masks, no branches, no zero-fill
+  // moves: one v_add per load.
+  constexpr uint32_t OOB = 0x80000000u;
+  constexpr int64_t REC_MAX = (int64_t)1 << 30;      // tile-relative offsets are < 5 MB; markers and wraps are > 2^30
   const int a_col = (tid % A_V) * 4;
   const int a_r0 = tid / A_V;
-  const uint32_t a_voff = (uint32_t)((a_r0 * a.ldx + a_col) * 4);           // bytes from the tile's first halo row
-  uint32_t a_ok = 0;                                                         // bit p: halo row exists
-  {
-    const int a_rows = BM + kw - 1;
-#pragma unroll
-    for (int p = 0; p < A_P; ++p) {
-      const int r = a_r0 + p * A_RPP;
-      const int64_t m = m0 - pad + r;
-      if (r < a_rows && m >= 0 && m < M) a_ok |= 1u << p;
-    }
-  }
-  const char* const a_base = reinterpret_cast<const char*>(a.x) + (m0 - pad) * a.ldx * 4;   // uniform
-  const int64_t a_pstride = (int64_t)A_RPP * a.ldx * 4;                                     // uniform
+  const int64_t mrow0 = m0 - pad;                    // first halo row of the tile (< 0 for the first tile)
+  const int64_t mbase = mrow0 > 0 ? mrow0 : 0;
+  const uint32_t va0 = (uint32_t)(((a_r0 + (int)(mrow0 - mbase)) * (int)a.ldx + a_col) * 4);
+  const uint32_t a_pstep = (uint32_t)(A_RPP * (int)a.ldx * 4);
 
   const int b_col = (tid % B_V) * (BF16 ? 8 : 4);  // element offset inside the chunk
   const int b_r0 = tid / B_V;
-  const uint32_t b_voff = (uint32_t)(((int64_t)(n0 + b_r0) * ktot + b_col) * B_ES);
-  uint32_t b_ok = 0;
-#pragma unroll
-  for (int p = 0; p < B_P; ++p)
-    if (n0 + b_r0 + p * B_RPP < a.n) b_ok |= 1u << p;
-  const int64_t b_pstride = (int64_t)B_RPP * ktot * B_ES;                                   // uniform
+  const uint32_t vb0 = (uint32_t)((b_r0 * ktot + b_col) * B_ES);
+  const uint32_t b_pstep = (uint32_t)(B_RPP * ktot * B_ES);
 
   // LDS byte offsets (per lane), everything else in the fragment addresses is uniform or immediate
   const uint32_t fa_off = ((wm * TM * 32 + li) * LD + lh * (BF16 ? 4 : 16));
@@ -152,12 +147,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
 
   auto load_a = [&](int cc) {
     const int c0 = cc * BK;
-    const bool chunk_ok = c0 + a_col < a.cin;
-    const char* base = a_base + (int64_t)c0 * 4;
+    int64_t rec = ((M - mbase - 1) * a.ldx + (a.cin - c0)) * 4;
+    rec = rec > REC_MAX ? REC_MAX : rec;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + mbase * a.ldx + c0), 0, (int)rec, 0x00020000);
+    const uint32_t v = c0 + a_col < a.cin ? va0 : OOB;
 #pragma unroll
     for (int p = 0; p < A_P; ++p) {
-      const bool ok = chunk_ok && ((a_ok >> p) & 1u);
-      ra[p] = ok ? *reinterpret_cast<const float4*>(base + p * a_pstride + a_voff) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const i32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v + p * a_pstep, 0, 0);
+      ra[p] = *reinterpret_cast<const float4*>(&t);
     }
   };
   auto store_a = [&](int buf) {
@@ -176,12 +174,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
   };
   auto load_b = [&](int cc, int j) {
     const int c0 = cc * BK;
-    const bool chunk_ok = c0 + b_col < a.cin;
-    const char* base = reinterpret_cast<const char*>(a.w) + ((int64_t)j * a.cin + c0) * B_ES;
+    int64_t rec = ((int64_t)(a.n - n0 - 1) * ktot + (a.cin - c0)) * B_ES;
+    rec = rec > REC_MAX ? REC_MAX : rec;
+    const char* base = reinterpret_cast<const char*>(a.w) + ((int64_t)n0 * ktot + (int64_t)j * a.cin + c0) * B_ES;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)rec, 0x00020000);
+    const uint32_t v = c0 + b_col < a.cin ? vb0 : OOB;
 #pragma unroll
     for (int p = 0; p < B_P; ++p) {
-      const bool ok = chunk_ok && ((b_ok >> p) & 1u);
-      rb[p] = ok ? *reinterpret_cast<const uint4*>(base + p * b_pstride + b_voff) : make_uint4(0, 0, 0, 0);
+      const i32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v + p * b_pstep, 0, 0);
+      rb[p] = *reinterpret_cast<const uint4*>(&t);
     }
   };
   auto store_b = [&](int buf) {
