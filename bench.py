@@ -80,9 +80,9 @@ def run(args, mode, rank, world, dev, dist):
     frames = int(batch["mel_len"].sum())
     S, T = batch["text"].shape[1], batch["mel_target"].shape[1]
     bd = {k: v.to(dev) for k, v in batch.items()}
-    use_graph = (not args.no_graph) and not train   # the tape-driven step launches eagerly (lr / step are host scalars)
+    use_graph = (not args.no_graph) and not train
     if train:
-        from styler_amd.training import TrainState, train_step
+        from styler_amd.training import GraphedTrainStep, TrainState, train_step
         state = TrainState(model)
 
     def step():
@@ -113,6 +113,9 @@ def run(args, mode, rank, world, dev, dist):
             with torch.cuda.graph(graph):
                 step()
         go = graph.replay if graph is not None else step
+        if train and not args.no_graph:         # forward + losses + backward replayed from one hipGraph; the
+            graph = GraphedTrainStep(model, state, bd)   # all-reduce, lr and clip + Adam launch stay eager
+            go = graph
 
         for _ in range(args.warmup):
             go()
@@ -122,6 +125,13 @@ def run(args, mode, rank, world, dev, dist):
             go()
         barrier()
         elapsed = time.perf_counter() - t0
+        host_ms = None
+        if graph is None:                       # eager launch: how long the host needs to ENQUEUE one step (diagnostic)
+            torch.cuda.synchronize()
+            h0 = time.perf_counter()
+            step()
+            host_ms = (time.perf_counter() - h0) * 1e3
+            torch.cuda.synchronize()
 
         # ---- live roofline measurement: HIP events around every MFMA-GEMM launch, extra eager steps ----
         prof = ops.GemmProfiler()
@@ -160,6 +170,8 @@ def run(args, mode, rank, world, dev, dist):
                 f"B={args.batch}/GPU, S={S}, T={T}, valid frames={frames}/GPU")
     res = {"value": round(value, 1), "ms_per_step": round(ms, 4), "workload": workload,
            "launch": "hipGraph replay" if graph is not None else "eager", "roofline": roofline}
+    if host_ms is not None:
+        res["host_enqueue_ms_per_step"] = round(host_ms, 2)
     if not args.no_cpu and world == 1:              # reported at N = 1 only (rank 0's host cores)
         res["cpu_baseline"] = cpu_baseline(model, batch, S, T, model.clean_only, train=train)
     return res
@@ -196,7 +208,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.prec,
             "data": "synthetic (seeded VCTK-shape batch, random-init weights)",
-            "config": {"workload": main_res["workload"], "launch": main_res["launch"], "parallelism": f"dp{world}"},
+            "config": {"workload": main_res["workload"], "launch": main_res["launch"], "parallelism": f"dp{world}",
+                       "host_enqueue_ms_per_step": main_res.get("host_enqueue_ms_per_step")},
             "roofline": main_res["roofline"], "cpu_baseline": main_res.get("cpu_baseline")}
         if aux is not None:
             line["aux"] = {("forward_c2" if args.mode == "train" else "train_c3"): {

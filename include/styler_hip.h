@@ -100,9 +100,12 @@ int styler_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t 
                          int C, const int64_t* len, float drop_p, uint64_t drop_seed, void* stream);
 
 /* y = relu(GroupNorm(x)) with groups of 16 channels and statistics over 16 ch x the whole
- * padded L (modules.py:103-113,171-175; eps 1e-5).  In place allowed (y == x). */
+ * padded L (modules.py:103-113,171-175; eps 1e-5).  In place allowed (y == x).
+ * workspace: 2*B*C/16 doubles (scratch); stats (optional): [B][C/16][2] floats = mean, rstd of every
+ * group, the input styler_groupnorm_relu_bwd needs. */
 int styler_groupnorm_relu(const float* x, int64_t ldx, const float* gamma, const float* beta,
-                          float* y, int64_t ldy, int B, int L, int C, void* stream);
+                          float* y, int64_t ldy, float* stats, double* workspace, int B, int L, int C,
+                          void* stream);
 
 /* BatchNorm1d folding for eval mode (Layers.py:91,105,118): scale = g * rsqrt(var + eps),
  * shift = (conv_bias - mean) * scale + b.  All [C]. */
@@ -113,7 +116,8 @@ int styler_bn_fold(const float* gamma, const float* beta, const float* running_m
 /* Train-mode BatchNorm1d over (B*L) rows incl. padded frames: computes batch mean / biased
  * var per channel of x (= conv output incl. bias), writes y = act((x-mean)*rstd*g + b),
  * saves mean / rstd [C] for backward and updates running stats with momentum 0.1
- * (unbiased var), as torch.nn.BatchNorm1d does.  workspace: 2*C doubles, zeroed here. */
+ * (unbiased var), as torch.nn.BatchNorm1d does.  workspace: 16 * 2*C doubles (16 replicas of the
+ * column accumulator, spreading the fp64 atomics), zeroed here. */
 int styler_batchnorm_train(const float* x, const float* gamma, const float* beta, float* y,
                            float* save_mean, float* save_rstd, float* running_mean,
                            float* running_var, double* workspace, int64_t rows, int C,
@@ -301,11 +305,13 @@ int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t l
                          float* ddot_w, float* ddot_b, int B, int L, int C, const int64_t* len,
                          float drop_p, uint64_t drop_seed, void* stream);
 
+/* stats = the forward's [B][C/16][2] (mean, rstd); workspace 2*B*C/16 doubles (scratch). */
 int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy,
-                              const float* gamma, const float* beta, float* dx, int64_t lddx,
-                              float* dgamma, float* dbeta, int B, int L, int C, void* stream);
+                              const float* gamma, const float* beta, const float* stats, float* dx,
+                              int64_t lddx, float* dgamma, float* dbeta, double* workspace, int B, int L,
+                              int C, void* stream);
 
-/* BatchNorm1d(train)+act backward; x, y, dy, dx contiguous [rows, C]; workspace 2*C doubles. */
+/* BatchNorm1d(train)+act backward; x, y, dy, dx contiguous [rows, C]; workspace 16 * 2*C doubles. */
 int styler_batchnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
                          const float* save_mean, const float* save_rstd, float* dx, float* dgamma,
                          float* dbeta, double* workspace, int64_t rows, int C, int act, void* stream);
@@ -350,6 +356,13 @@ int styler_masked_err_bwd(const float* a, int64_t lda, const float* b, int64_t l
 /* NLLLoss(mean) on [B,2] log-probs (loss.py:46-48): loss[0] (optional) and/or dlogp. */
 int styler_nll(const float* logp, const int64_t* label, float* loss, const float* gscale,
                float* dlogp, int B, void* stream);
+/* Registers the device address of a uint64 step counter (or NULL to unregister).  Every dropout-drawing entry
+ * point (styler_dropout, styler_add_layernorm / styler_layernorm_bwd with drop_p > 0) then uses
+ * seed + counter * odd-constant as its stream key, read on the device at execution time: a training step
+ * captured in a hipGraph draws fresh masks on every replay although its host seeds are baked in.  The caller
+ * increments the counter once per step, before the forward. */
+int styler_set_dropout_counter(const uint64_t* counter_dev);
+
 /* y = x * keep / (1-p); keep is a counter-based hash of (seed, element index): the same call on
  * dy is the backward (no mask tensor). */
 int styler_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int C, float p,

@@ -23,7 +23,7 @@ _SIGS = {
     "styler_attention_fwd_bf16": [P, P, P, I, I, P, P],
     "styler_attention_bwd_bf16": [P, P, P, P, P, P, I, I, P, P],
     "styler_add_layernorm": [P, I64, P, I64, P, P, P, I64, P, P, P, I, I, I, P, F, ctypes.c_uint64, P],
-    "styler_groupnorm_relu": [P, I64, P, P, P, I64, I, I, I, P],
+    "styler_groupnorm_relu": [P, I64, P, P, P, I64, P, P, I, I, I, P],
     "styler_bn_fold": [P, P, P, P, P, P, P, I, P],
     "styler_batchnorm_train": [P, P, P, P, P, P, P, P, P, I64, I, I, P],
     "styler_embed_pos": [P, P, P, P, I, I, I, P],
@@ -33,6 +33,7 @@ _SIGS = {
     "styler_mel_calibrate": [P, I64, P, I64, P, P, I, I, I, I, P],
     "styler_lstm_bidir": [P, P, P, P, P, I, I, I, P],
     "styler_lstm_bidir_multi": [P, I, I, I, P],
+    "styler_set_dropout_counter": [P],
     "styler_lstm_bidir_bwd_multi": [P, I, I, I, P],
     "styler_aug_classifier_tail": [P, P, P, P, P, P, I, I, P],
     "styler_duration_scan": [P, I, P, F, P, P, P, I, I, P],
@@ -51,7 +52,7 @@ _SIGS = {
     "styler_repack_weight_bwd": [P, P, I, I, I, I, P],
     "styler_attention_bwd": [P, P, P, P, P, P, I, I, P, P],
     "styler_layernorm_bwd": [P, I64, P, I64, P, P, P, I64, P, P, P, P, P, P, I, I, I, P, F, ctypes.c_uint64, P],
-    "styler_groupnorm_relu_bwd": [P, I64, P, I64, P, P, P, I64, P, P, I, I, I, P],
+    "styler_groupnorm_relu_bwd": [P, I64, P, I64, P, P, P, P, I64, P, P, P, I, I, I, P],
     "styler_batchnorm_bwd": [P, P, P, P, P, P, P, P, P, P, I64, I, I, P],
     "styler_embed_bwd": [P, P, I64, P, I, I, I, P],
     "styler_onehot_expand": [P, P, I64, P],

@@ -148,16 +148,17 @@ class LayerNormDotFn(Function):
 class GroupNormReluFn(Function):
     @staticmethod
     def forward(ctx, x, anchor, gn):
-        y = ops.groupnorm_relu(x, gn.weight, gn.bias, out=torch.empty_like(x))
-        ctx.save_for_backward(x)
+        stats = torch.empty(x.shape[0], x.shape[2] // 16, 2, device=x.device, dtype=torch.float32)
+        y = ops.groupnorm_relu(x, gn.weight, gn.bias, out=torch.empty_like(x), stats=stats)
+        ctx.save_for_backward(x, stats)
         ctx.gn = gn
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
+        x, stats = ctx.saved_tensors
         gn = ctx.gn
-        return ops.groupnorm_relu_bwd(x, dy, gn.weight, gn.bias, G(gn.weight), G(gn.bias)), None, None
+        return ops.groupnorm_relu_bwd(x, dy, gn.weight, gn.bias, stats, G(gn.weight), G(gn.bias)), None, None
 
 
 class BatchNormActFn(Function):

@@ -49,6 +49,14 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
+// Device address of a step counter that is mixed into every dropout seed (styler_set_dropout_counter), or null.
+// Seeds are host values baked into a captured hipGraph; the counter (incremented on the device once per step) is
+// what makes every replay draw fresh masks.  Forward and backward of one step read the same value.
+extern const uint64_t* g_styler_drop_epoch;
+__device__ __forceinline__ uint64_t mix_drop_epoch(uint64_t seed, const uint64_t* epoch) {
+  return epoch ? seed + *epoch * 0xD6E8FEB86659FD93ull : seed;
+}
+
 // counter-based dropout stream: keep element e of a tensor iff dropout_hash32(seed, e) >= p * 2^32
 __device__ __forceinline__ uint32_t dropout_hash32(uint64_t seed, uint64_t idx) {
   uint64_t z = idx + seed * 0x9E3779B97F4A7C15ull;

@@ -311,7 +311,9 @@ extern "C" int styler_nll(const float* logp, const int64_t* label, float* loss, 
 // ---- dropout: y = x * keep / (1 - p), keep from a counter-based hash of (seed, element index) -------------
 // The same (seed, index) stream regenerates the mask in backward: no mask tensor is stored.
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
-                                                      int64_t ldy, int64_t rows, int C, float p, uint64_t seed) {
+                                                      int64_t ldy, int64_t rows, int C, float p, uint64_t seed_host,
+                                                      const uint64_t* __restrict__ epoch) {
+  const uint64_t seed = mix_drop_epoch(seed_host, epoch);
   const int nq = C / 4;
   const int64_t total = rows * nq;
   const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
@@ -332,8 +334,15 @@ extern "C" int styler_dropout(const float* x, int64_t ldx, float* y, int64_t ldy
                               uint64_t seed, void* stream) {
   if (!x || !y || rows <= 0 || C <= 0 || (C & 3) || (ldx & 3) || (ldy & 3) || p < 0.f || p >= 1.f) return STYLER_EINVAL;
   hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
-                     rows, C, p, seed);
+                     rows, C, p, seed, g_styler_drop_epoch);
   return launch_status();
+}
+
+const uint64_t* g_styler_drop_epoch = nullptr;
+
+extern "C" int styler_set_dropout_counter(const uint64_t* counter_dev) {
+  g_styler_drop_epoch = counter_dev;
+  return 0;
 }
 
 // ---- optimizer: global grad norm (fp64 sum of squares) + fused clip + Adam on FLAT fp32 buffers ------------

@@ -8,7 +8,8 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ res, int64_t ldres,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, int64_t ldy,
     const float* __restrict__ dot_w, const float* __restrict__ dot_b, float* __restrict__ dot_out, int64_t rows,
-    int L, const int64_t* __restrict__ len, float drop_p, uint64_t drop_seed) {
+    int L, const int64_t* __restrict__ len, float drop_p, uint64_t drop_seed_host, const uint64_t* __restrict__ epoch) {
+  const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -62,49 +63,71 @@ extern "C" int styler_add_layernorm(const float* x, int64_t ldx, const float* re
   if ((ldx & 3) || (res && (ldres & 3)) || (y && (ldy & 3))) return STYLER_EALIGN;
   const int64_t rows = (int64_t)B * L;
   hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
-                     ldx, res, ldres, gamma, beta, y, ldy, dot_w, dot_b, dot_out, rows, L, len, drop_p, drop_seed);
+                     ldx, res, ldres, gamma, beta, y, ldy, dot_w, dot_b, dot_out, rows, L, len, drop_p, drop_seed,
+                     g_styler_drop_epoch);
   return launch_status();
 }
 
 // ---------------------------------------------------------------------------------------
-// GroupNorm + ReLU.  Block = (item b, 64-channel chunk = 4 groups).  256 threads as 16 row-lanes x
-// 16 channel-quads: thread (rl, cq) streams rows rl, rl+16, ... reading float4 = 4 channels of group
-// cq/4.  Pass 1 accumulates sum / sumsq in fp64 (exact enough to match a two-pass fp32 reference);
-// pass 2 re-reads the (L2-resident) chunk, normalises, applies ReLU.
-__global__ __launch_bounds__(256) void groupnorm_relu_kernel(const float* __restrict__ x, int64_t ldx,
-                                                             const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, float* __restrict__ y,
-                                                             int64_t ldy, int L, int C) {
+// GroupNorm + ReLU, two launches so that the whole chip streams: (item b, 64-channel chunk = 4 groups) alone is
+// only B*C/64 blocks (240 at the model's shapes, 12 % of the wave slots: 22 us against an 8 us stream).  The time
+// axis is therefore cut into segments -- grid (C/64, B, nseg):
+//   gn_stats : per-segment sum / sumsq of each group in fp64 -> fp64 atomics into ws[B][C/16][2];
+//   gn_apply : mean / rstd from ws, normalise, ReLU (the second read of x comes from L2 / MALL).
+// 256 threads = 16 row-lanes x 16 channel-quads: thread (rl, cq) streams rows rl, rl+16, ... of its segment reading
+// float4 = 4 channels of group cq/4.
+int gn_segments_host(int B, int L, int C) {
+  int nseg = (1024 + (C / 64) * B - 1) / ((C / 64) * B);
+  const int cap = (L + 31) / 32;
+  if (nseg > cap) nseg = cap;
+  return nseg < 1 ? 1 : nseg;
+}
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int64_t ldx, double* __restrict__ ws,
+                                                       int L, int C, int seg_rows) {
   __shared__ double red[2][16][16];
-  __shared__ float stat[2][4];
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int t0 = blockIdx.z * seg_rows;
+  const int t1 = min(L, t0 + seg_rows);
   const float* xp = x + (int64_t)b * L * ldx + c0 + cq * 4;
   double s = 0.0, ss = 0.0;
-  for (int t = rl; t < L; t += 16) {
+  for (int t = t0 + rl; t < t1; t += 16) {
     const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
     s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
     ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
   }
   red[0][rl][cq] = s; red[1][rl][cq] = ss;
   __syncthreads();
-  if (threadIdx.x < 4) {
-    double ts = 0.0, tss = 0.0;
+  if (threadIdx.x < 8) {
+    const int g = threadIdx.x & 3, which = threadIdx.x >> 2;
+    double t = 0.0;
     for (int r = 0; r < 16; ++r)
-      for (int q = 0; q < 4; ++q) { ts += red[0][r][threadIdx.x * 4 + q]; tss += red[1][r][threadIdx.x * 4 + q]; }
-    const double n = 16.0 * L;
-    const double mean = ts / n;
-    double var = tss / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stat[0][threadIdx.x] = (float)mean;
-    stat[1][threadIdx.x] = (float)(1.0 / sqrt(var + 1e-5));
+      for (int q = 0; q < 4; ++q) t += red[which][r][g * 4 + q];
+    atomicAdd(&ws[((int64_t)b * (C / 16) + c0 / 16 + g) * 2 + which], t);
   }
-  __syncthreads();
-  const float mean = stat[0][cq >> 2], rstd = stat[1][cq >> 2];
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int64_t ldx,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const double* __restrict__ ws, float* __restrict__ y, int64_t ldy,
+                                                       float* __restrict__ stats, int L, int C, int seg_rows) {
+  const int b = blockIdx.y, c0 = blockIdx.x * 64;
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int t0 = blockIdx.z * seg_rows;
+  const int t1 = min(L, t0 + seg_rows);
+  const int64_t gi = ((int64_t)b * (C / 16) + c0 / 16 + (cq >> 2)) * 2;
+  const double n = 16.0 * L;
+  const double dmean = ws[gi] / n;
+  double var = ws[gi + 1] / n - dmean * dmean;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)dmean, rstd = (float)(1.0 / sqrt(var + 1e-5));
+  if (stats && blockIdx.z == 0 && rl == 0 && (cq & 3) == 0) { stats[gi] = mean; stats[gi + 1] = rstd; }
   const float4 g = *reinterpret_cast<const float4*>(gamma + c0 + cq * 4);
   const float4 bt = *reinterpret_cast<const float4*>(beta + c0 + cq * 4);
+  const float* xp = x + (int64_t)b * L * ldx + c0 + cq * 4;
   float* yp = y + (int64_t)b * L * ldy + c0 + cq * 4;
-  for (int t = rl; t < L; t += 16) {
+  for (int t = t0 + rl; t < t1; t += 16) {
     const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
     float4 o;
     o.x = fmaxf((v.x - mean) * rstd * g.x + bt.x, 0.f);
@@ -116,11 +139,18 @@ __global__ __launch_bounds__(256) void groupnorm_relu_kernel(const float* __rest
 }
 
 extern "C" int styler_groupnorm_relu(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
-                                     int64_t ldy, int B, int L, int C, void* stream) {
-  if (!x || !y || !gamma || !beta || B <= 0 || L <= 0 || C <= 0 || (C & 63)) return STYLER_EINVAL;
+                                     int64_t ldy, float* stats, double* workspace, int B, int L, int C, void* stream) {
+  if (!x || !y || !gamma || !beta || !workspace || B <= 0 || L <= 0 || C <= 0 || (C & 63)) return STYLER_EINVAL;
   if ((ldx & 3) || (ldy & 3)) return STYLER_EALIGN;
-  hipLaunchKernelGGL(groupnorm_relu_kernel, dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
-                     y, ldy, L, C);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * B * (C / 16), st);
+  if (e != hipSuccess) return (int)e;
+  const int nseg = gn_segments_host(B, L, C);
+  const int seg_rows = ((L + nseg - 1) / nseg + 15) & ~15;
+  const dim3 grid(C / 64, B, (L + seg_rows - 1) / seg_rows);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, st, x, ldx, workspace, L, C, seg_rows);
+  hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, st, x, ldx, gamma, beta, workspace, y, ldy, stats, L, C,
+                     seg_rows);
   return launch_status();
 }
 
@@ -143,26 +173,85 @@ extern "C" int styler_bn_fold(const float* gamma, const float* beta, const float
   return launch_status();
 }
 
-// Train-mode BatchNorm: pass 1 column sums (fp64 atomics per block), pass 2 finalize + normalise.
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ ws,
-                                                       int64_t rows, int C, int rows_per_block) {
-  // thread -> channel quad cq = tid % (C/4)... generic: loop channels by float4 columns
+// Train-mode BatchNorm: pass 1 column sums, pass 2 finalize + normalise.
+// Column sums: block = 32 rows x all channels, 256 threads as (row-lane, float4 column); per-thread fp64 partials are
+// folded across the row-lanes in LDS and leave as fp64 atomics into one of STYLER_BN_COPIES replicas of the 2C-double
+// accumulator (replica = block % COPIES: 16x fewer collisions per address); bn_fold_copies_kernel sums the replicas.
+#define STYLER_BN_COPIES 16
+#define BN_RPB 32
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                          const float* __restrict__ dy, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, double* __restrict__ ws,
+                                                          int64_t rows, int C, int act) {
+  __shared__ double red[256][8];
   const int nq = C / 4;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  int64_t r1 = r0 + rows_per_block; if (r1 > rows) r1 = rows;
-  for (int q = threadIdx.x; q < nq; q += blockDim.x) {
-    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
-    for (int64_t r = r0; r < r1; ++r) {
-      const float4 v = *reinterpret_cast<const float4*>(x + r * C + q * 4);
-      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-      ss[0] += (double)v.x * v.x; ss[1] += (double)v.y * v.y; ss[2] += (double)v.z * v.z; ss[3] += (double)v.w * v.w;
+  const int nqt = nq < 256 ? nq : 256;               // threads across a row
+  const int lanes = 256 / nqt;                       // row-lanes
+  const int rl = threadIdx.x / nqt, ql = threadIdx.x - rl * nqt;
+  const bool live = rl < lanes;
+  const int64_t r0 = (int64_t)blockIdx.x * BN_RPB;
+  int64_t r1 = r0 + BN_RPB; if (r1 > rows) r1 = rows;
+  double* wsc = ws + (int64_t)(blockIdx.x % STYLER_BN_COPIES) * 2 * C;
+  for (int q0 = 0; q0 < nq; q0 += nqt) {
+    const int q = q0 + ql;
+    double s[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
+    if (live && q < nq) {
+      float4 m = make_float4(0.f, 0.f, 0.f, 0.f), rs = m;
+      if (BWD) { m = *reinterpret_cast<const float4*>(mean + q * 4); rs = *reinterpret_cast<const float4*>(rstd + q * 4); }
+      for (int64_t r = r0 + rl; r < r1; r += lanes) {
+        const float4 v = *reinterpret_cast<const float4*>(x + r * C + q * 4);
+        if (BWD) {
+          float4 g = *reinterpret_cast<const float4*>(dy + r * C + q * 4);
+          if (act == STYLER_ACT_TANH) {
+            const float4 o = *reinterpret_cast<const float4*>(y + r * C + q * 4);
+            g.x *= 1.f - o.x * o.x; g.y *= 1.f - o.y * o.y; g.z *= 1.f - o.z * o.z; g.w *= 1.f - o.w * o.w;
+          }
+          s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
+          t[0] += (double)g.x * ((v.x - m.x) * rs.x); t[1] += (double)g.y * ((v.y - m.y) * rs.y);
+          t[2] += (double)g.z * ((v.z - m.z) * rs.z); t[3] += (double)g.w * ((v.w - m.w) * rs.w);
+        } else {
+          s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+          t[0] += (double)v.x * v.x; t[1] += (double)v.y * v.y; t[2] += (double)v.z * v.z; t[3] += (double)v.w * v.w;
+        }
+      }
     }
+    if (lanes > 1) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      atomicAdd(&ws[q * 4 + k], s[k]);
-      atomicAdd(&ws[C + q * 4 + k], ss[k]);
+      for (int k = 0; k < 4; ++k) { red[threadIdx.x][k] = s[k]; red[threadIdx.x][4 + k] = t[k]; }
+      __syncthreads();
+      if (rl == 0)
+        for (int l = 1; l < lanes; ++l)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { s[k] += red[l * nqt + ql][k]; t[k] += red[l * nqt + ql][4 + k]; }
+      __syncthreads();
+    }
+    if (rl == 0 && q < nq) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { atomicAdd(&wsc[q * 4 + k], s[k]); atomicAdd(&wsc[C + q * 4 + k], t[k]); }
     }
   }
+}
+
+__global__ void bn_fold_copies_kernel(double* __restrict__ ws, int C2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C2) return;
+  double t = 0.0;
+#pragma unroll
+  for (int k = 0; k < STYLER_BN_COPIES; ++k) t += ws[(int64_t)k * C2 + i];
+  ws[i] = t;
+}
+
+int styler_bn_colstats(bool bwd, const float* x, const float* y, const float* dy, const float* mean, const float* rstd,
+                       double* ws, int64_t rows, int C, int act, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * STYLER_BN_COPIES, st);
+  if (e != hipSuccess) return (int)e;
+  const dim3 grid((unsigned)((rows + BN_RPB - 1) / BN_RPB));
+  if (bwd) hipLaunchKernelGGL(bn_colstats_kernel<true>, grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, rows, C, act);
+  else hipLaunchKernelGGL(bn_colstats_kernel<false>, grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, rows, C, act);
+  hipLaunchKernelGGL(bn_fold_copies_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, ws, 2 * C);
+  return 0;
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ ws, float* save_mean, float* save_rstd,
@@ -210,11 +299,8 @@ extern "C" int styler_batchnorm_train(const float* x, const float* gamma, const 
   if (!x || !gamma || !beta || !y || !save_mean || !save_rstd || !workspace || rows <= 0 || C <= 0 || (C & 3))
     return STYLER_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
-  if (e != hipSuccess) return (int)e;
-  const int rpb = 64;
-  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(128), 0, st, x, workspace, rows,
-                     C, rpb);
+  const int rc = styler_bn_colstats(false, x, nullptr, nullptr, nullptr, nullptr, workspace, rows, C, act, st);
+  if (rc) return rc;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, save_mean, save_rstd,
                      running_mean, running_var, rows, C);
   const int64_t total4 = rows * C / 4;

@@ -1,6 +1,7 @@
 // Backward of the normalisation kernels (norms.hip).  Statistics are recomputed from the saved input
 // (cheaper than a second saved tensor); parameter gradients are reduced in registers per wave and added
 // with one atomic per (lane, channel) to the fp32 gradient buffer.
+#include <cstdlib>
 #include "common.h"
 
 // LayerNorm(256) backward.  y = LN(x) * g + b (rows t >= len[b] are zero in forward => zero gradient).
@@ -11,7 +12,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dx, int64_t lddx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ dot_w,
     const float* __restrict__ dout, float* __restrict__ ddot_w, float* __restrict__ ddot_b, int64_t rows, int L,
-    const int64_t* __restrict__ len, float drop_p, uint64_t drop_seed) {
+    const int64_t* __restrict__ len, float drop_p, uint64_t drop_seed_host, const uint64_t* __restrict__ epoch) {
+  const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   const int lane = threadIdx.x & 63;
   const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t wstride = (int64_t)gridDim.x * 4;
@@ -90,54 +92,44 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
   if ((ldx & 3) || (dy && (lddy & 3)) || (dx && (lddx & 3))) return STYLER_EALIGN;
   const int64_t rows = (int64_t)B * L;
   int64_t blocks = (rows + 3) / 4;
-  if (blocks > 512) blocks = 512;
+  static const int cap = [] { const char* e = getenv("STYLER_LNBWD_BLOCKS"); return e ? atoi(e) : 512; }();
+  if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy,
-                     gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b, rows, L, len, drop_p, drop_seed);
+                     gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b, rows, L, len, drop_p, drop_seed,
+                     g_styler_drop_epoch);
   return launch_status();
 }
 
 // ---------------------------------------------------------------------------------------------------
-// GroupNorm(16 ch/group over padded L) + ReLU backward.  Block = (item, 64-channel chunk), as forward.
+// GroupNorm(16 ch/group over padded L) + ReLU backward, segmented over time like the forward (norms.hip):
 //   g = dy * (y > 0);  dxh = g * gamma;  dx = rstd * (dxh - mean_g(dxh) - xh * mean_g(dxh * xh))
-__global__ __launch_bounds__(256) void groupnorm_relu_bwd_kernel(const float* __restrict__ x, int64_t ldx,
-                                                                 const float* __restrict__ dy, int64_t lddy,
-                                                                 const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta, float* __restrict__ dx,
-                                                                 int64_t lddx, float* __restrict__ dgamma,
-                                                                 float* __restrict__ dbeta, int L, int C) {
-  __shared__ double red[4][16][16];
-  __shared__ float stat[4][4];
+//   gn_bwd_stats : per-segment sums of dxh and dxh*xh per group (fp64 atomics -> ws[B][C/16][2]) and the dgamma / dbeta
+//                  partials per channel (fp32 atomics); mean / rstd come from the forward's `stats`;
+//   gn_bwd_apply : dx.
+int gn_segments_host(int B, int L, int C);
+
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restrict__ x, int64_t ldx,
+                                                           const float* __restrict__ dy, int64_t lddy,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ stats, double* __restrict__ ws,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int L,
+                                                           int C, int seg_rows) {
+  __shared__ double red[2][16][16];
   __shared__ float pg[2][16][64];
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int t0 = blockIdx.z * seg_rows;
+  const int t1 = min(L, t0 + seg_rows);
+  const int64_t gi = ((int64_t)b * (C / 16) + c0 / 16 + (cq >> 2)) * 2;
+  const float mean = stats[gi], rstd = stats[gi + 1];
   const float* xp = x + (int64_t)b * L * ldx + c0 + cq * 4;
   const float* gp = dy + (int64_t)b * L * lddy + c0 + cq * 4;
   const float4 ga = *reinterpret_cast<const float4*>(gamma + c0 + cq * 4);
   const float4 be = *reinterpret_cast<const float4*>(beta + c0 + cq * 4);
-  // pass 1: statistics of x
-  double s = 0.0, ss = 0.0;
-  for (int t = rl; t < L; t += 16) {
-    const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
-    s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-    ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
-  }
-  red[0][rl][cq] = s; red[1][rl][cq] = ss;
-  __syncthreads();
-  if (threadIdx.x < 4) {
-    double ts = 0.0, tss = 0.0;
-    for (int r = 0; r < 16; ++r)
-      for (int q = 0; q < 4; ++q) { ts += red[0][r][threadIdx.x * 4 + q]; tss += red[1][r][threadIdx.x * 4 + q]; }
-    const double n = 16.0 * L, mean = ts / n;
-    double var = tss / n - mean * mean; if (var < 0.0) var = 0.0;
-    stat[0][threadIdx.x] = (float)mean;
-    stat[1][threadIdx.x] = (float)(1.0 / sqrt(var + 1e-5));
-  }
-  __syncthreads();
-  const float mean = stat[0][cq >> 2], rstd = stat[1][cq >> 2];
-  // pass 2: sums of dxh and dxh*xh per group, dgamma/dbeta per channel
   double s1 = 0.0, s2 = 0.0;
   float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
-  for (int t = rl; t < L; t += 16) {
+  for (int t = t0 + rl; t < t1; t += 16) {
     const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
     float4 g = *reinterpret_cast<const float4*>(gp + (int64_t)t * lddy);
     const float hx = (v.x - mean) * rstd, hy = (v.y - mean) * rstd, hz = (v.z - mean) * rstd, hw = (v.w - mean) * rstd;
@@ -149,28 +141,45 @@ __global__ __launch_bounds__(256) void groupnorm_relu_bwd_kernel(const float* __
     s1 += (double)ex + (double)ey + (double)ez + (double)ew;
     s2 += (double)ex * hx + (double)ey * hy + (double)ez * hz + (double)ew * hw;
   }
-  red[2][rl][cq] = s1; red[3][rl][cq] = s2;
+  red[0][rl][cq] = s1; red[1][rl][cq] = s2;
   pg[0][rl][cq * 4 + 0] = ag.x; pg[0][rl][cq * 4 + 1] = ag.y; pg[0][rl][cq * 4 + 2] = ag.z; pg[0][rl][cq * 4 + 3] = ag.w;
   pg[1][rl][cq * 4 + 0] = ab.x; pg[1][rl][cq * 4 + 1] = ab.y; pg[1][rl][cq * 4 + 2] = ab.z; pg[1][rl][cq * 4 + 3] = ab.w;
   __syncthreads();
-  if (threadIdx.x < 4) {
-    double t1 = 0.0, t2 = 0.0;
+  if (threadIdx.x < 8) {
+    const int g = threadIdx.x & 3, which = threadIdx.x >> 2;
+    double t = 0.0;
     for (int r = 0; r < 16; ++r)
-      for (int q = 0; q < 4; ++q) { t1 += red[2][r][threadIdx.x * 4 + q]; t2 += red[3][r][threadIdx.x * 4 + q]; }
-    const double n = 16.0 * L;
-    stat[2][threadIdx.x] = (float)(t1 / n);
-    stat[3][threadIdx.x] = (float)(t2 / n);
-  }
-  if (threadIdx.x < 128) {
-    const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+      for (int q = 0; q < 4; ++q) t += red[which][r][g * 4 + q];
+    atomicAdd(&ws[((int64_t)b * (C / 16) + c0 / 16 + g) * 2 + which], t);
+  } else if (threadIdx.x >= 64 && threadIdx.x < 192) {
+    const int which = (threadIdx.x - 64) >> 6, c = threadIdx.x & 63;
     float t = 0.f;
     for (int r = 0; r < 16; ++r) t += pg[which][r][c];
     atomicAdd((which ? dbeta : dgamma) + c0 + c, t);
   }
-  __syncthreads();
-  const float m1 = stat[2][cq >> 2], m2 = stat[3][cq >> 2];
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, int64_t ldx,
+                                                           const float* __restrict__ dy, int64_t lddy,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ stats,
+                                                           const double* __restrict__ ws, float* __restrict__ dx,
+                                                           int64_t lddx, int L, int C, int seg_rows) {
+  const int b = blockIdx.y, c0 = blockIdx.x * 64;
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int t0 = blockIdx.z * seg_rows;
+  const int t1 = min(L, t0 + seg_rows);
+  const int64_t gi = ((int64_t)b * (C / 16) + c0 / 16 + (cq >> 2)) * 2;
+  const float mean = stats[gi], rstd = stats[gi + 1];
+  const double n = 16.0 * L;
+  const float m1 = (float)(ws[gi] / n), m2 = (float)(ws[gi + 1] / n);
+  const float* xp = x + (int64_t)b * L * ldx + c0 + cq * 4;
+  const float* gp = dy + (int64_t)b * L * lddy + c0 + cq * 4;
   float* dxp = dx + (int64_t)b * L * lddx + c0 + cq * 4;
-  for (int t = rl; t < L; t += 16) {
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + c0 + cq * 4);
+  const float4 be = *reinterpret_cast<const float4*>(beta + c0 + cq * 4);
+  for (int t = t0 + rl; t < t1; t += 16) {
     const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
     float4 g = *reinterpret_cast<const float4*>(gp + (int64_t)t * lddy);
     const float hx = (v.x - mean) * rstd, hy = (v.y - mean) * rstd, hz = (v.z - mean) * rstd, hw = (v.w - mean) * rstd;
@@ -183,44 +192,31 @@ __global__ __launch_bounds__(256) void groupnorm_relu_bwd_kernel(const float* __
 }
 
 extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy,
-                                         const float* gamma, const float* beta, float* dx, int64_t lddx,
-                                         float* dgamma, float* dbeta, int B, int L, int C, void* stream) {
-  if (!x || !dy || !gamma || !beta || !dx || !dgamma || !dbeta || B <= 0 || L <= 0 || C <= 0 || (C & 63)) return STYLER_EINVAL;
+                                         const float* gamma, const float* beta, const float* stats, float* dx,
+                                         int64_t lddx, float* dgamma, float* dbeta, double* workspace, int B, int L, int C,
+                                         void* stream) {
+  if (!x || !dy || !gamma || !beta || !stats || !dx || !dgamma || !dbeta || !workspace || B <= 0 || L <= 0 || C <= 0 ||
+      (C & 63))
+    return STYLER_EINVAL;
   if ((ldx & 3) || (lddy & 3) || (lddx & 3)) return STYLER_EALIGN;
-  hipLaunchKernelGGL(groupnorm_relu_bwd_kernel, dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy,
-                     gamma, beta, dx, lddx, dgamma, dbeta, L, C);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * B * (C / 16), st);
+  if (e != hipSuccess) return (int)e;
+  const int nseg = gn_segments_host(B, L, C);
+  const int seg_rows = ((L + nseg - 1) / nseg + 15) & ~15;
+  const dim3 grid(C / 64, B, (L + seg_rows - 1) / seg_rows);
+  hipLaunchKernelGGL(gn_bwd_stats_kernel, grid, dim3(256), 0, st, x, ldx, dy, lddy, gamma, beta, stats, workspace, dgamma,
+                     dbeta, L, C, seg_rows);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, dim3(256), 0, st, x, ldx, dy, lddy, gamma, beta, stats, workspace, dx,
+                     lddx, L, C, seg_rows);
   return launch_status();
 }
 
 // ---------------------------------------------------------------------------------------------------
 // BatchNorm1d (train) + act backward over rows = B*L (pads included), channels-last contiguous [rows, C].
 //   dz = dy * act'(y); dgamma = sum dz*xh; dbeta = sum dz; dx = g*rstd*(dz - dbeta/N - xh*dgamma/N)
-__global__ __launch_bounds__(128) void bn_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                           const float* __restrict__ dy, const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, double* __restrict__ ws,
-                                                           int64_t rows, int C, int act, int rows_per_block) {
-  const int nq = C / 4;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  int64_t r1 = r0 + rows_per_block; if (r1 > rows) r1 = rows;
-  for (int q = threadIdx.x; q < nq; q += blockDim.x) {
-    const float4 m = *reinterpret_cast<const float4*>(mean + q * 4);
-    const float4 rs = *reinterpret_cast<const float4*>(rstd + q * 4);
-    double s[4] = {0, 0, 0, 0}, sh[4] = {0, 0, 0, 0};
-    for (int64_t r = r0; r < r1; ++r) {
-      const float4 v = *reinterpret_cast<const float4*>(x + r * C + q * 4);
-      float4 g = *reinterpret_cast<const float4*>(dy + r * C + q * 4);
-      if (act == STYLER_ACT_TANH) {
-        const float4 o = *reinterpret_cast<const float4*>(y + r * C + q * 4);
-        g.x *= 1.f - o.x * o.x; g.y *= 1.f - o.y * o.y; g.z *= 1.f - o.z * o.z; g.w *= 1.f - o.w * o.w;
-      }
-      s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
-      sh[0] += (double)g.x * ((v.x - m.x) * rs.x); sh[1] += (double)g.y * ((v.y - m.y) * rs.y);
-      sh[2] += (double)g.z * ((v.z - m.z) * rs.z); sh[3] += (double)g.w * ((v.w - m.w) * rs.w);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { atomicAdd(&ws[q * 4 + k], s[k]); atomicAdd(&ws[C + q * 4 + k], sh[k]); }
-  }
-}
+int styler_bn_colstats(bool bwd, const float* x, const float* y, const float* dy, const float* mean, const float* rstd,
+                       double* ws, int64_t rows, int C, int act, hipStream_t st);   // norms.hip
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy, const float* __restrict__ gamma,
@@ -265,11 +261,8 @@ extern "C" int styler_batchnorm_bwd(const float* x, const float* y, const float*
       (C & 3) || (act == STYLER_ACT_TANH && !y))
     return STYLER_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, st);
-  if (e != hipSuccess) return (int)e;
-  const int rpb = 64;
-  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(128), 0, st, x, y, dy, save_mean,
-                     save_rstd, workspace, rows, C, act, rpb);
+  const int rc = styler_bn_colstats(true, x, y, dy, save_mean, save_rstd, workspace, rows, C, act, st);
+  if (rc) return rc;
   const int64_t total4 = rows * C / 4;
   int64_t blocks = (total4 + 255) / 256; if (blocks > 4096) blocks = 4096;
   if (blocks * 256 < C) blocks = (C + 255) / 256;

@@ -145,6 +145,12 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
     return out
 
 
+def set_dropout_counter(counter):
+    """Register (or, with None, unregister) the int64 device step counter mixed into every dropout seed."""
+    assert counter is None or (counter.dtype == torch.int64 and counter.is_cuda)
+    _chk(lib.styler_set_dropout_counter(_ptr(counter)), "styler_set_dropout_counter")
+
+
 def cast_bf16(src):
     dst = torch.empty(src.shape, device=src.device, dtype=torch.bfloat16)
     _chk(lib.styler_cast_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "styler_cast_bf16")
@@ -193,12 +199,14 @@ def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, 
     return dot_out if dot_w is not None else out
 
 
-def groupnorm_relu(x, gamma, beta, out=None):
+def groupnorm_relu(x, gamma, beta, out=None, stats=None):
+    """`stats` (optional, [B, C/16, 2] fp32) receives mean / rstd of every group for the backward."""
     B, L, C = x.shape
     if out is None:
         out = x
+    ws = torch.empty(B * (C // 16) * 2, device=x.device, dtype=torch.float64)
     _chk(lib.styler_groupnorm_relu(x.data_ptr(), _ld(x), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
-                                   _ld(out), B, L, C, _stream()), "styler_groupnorm_relu")
+                                   _ld(out), _ptr(stats), ws.data_ptr(), B, L, C, _stream()), "styler_groupnorm_relu")
     return out
 
 
@@ -211,6 +219,9 @@ def bn_fold(gamma, beta, running_mean, running_var, conv_bias):
     return scale, shift
 
 
+BN_WS_COPIES = 16        # STYLER_BN_COPIES (norms.hip): replicas of the 2C-double column accumulator
+
+
 def batchnorm_train(x, gamma, beta, running_mean, running_var, act):
     """x [B, L, C] contiguous (conv output incl. bias). Returns y, save_mean, save_rstd."""
     assert x.is_contiguous()
@@ -219,7 +230,7 @@ def batchnorm_train(x, gamma, beta, running_mean, running_var, act):
     y = torch.empty_like(x)
     mean = torch.empty(C, device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
-    ws = torch.empty(2 * C, device=x.device, dtype=torch.float64)
+    ws = torch.empty(2 * C * BN_WS_COPIES, device=x.device, dtype=torch.float64)
     _chk(lib.styler_batchnorm_train(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
                                     mean.data_ptr(), rstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
                                     ws.data_ptr(), rows, C, act, _stream()), "styler_batchnorm_train")
@@ -497,12 +508,14 @@ def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, do
     return dx
 
 
-def groupnorm_relu_bwd(x, dy, gamma, beta, dgamma, dbeta):
+def groupnorm_relu_bwd(x, dy, gamma, beta, stats, dgamma, dbeta):
     B, L, C = x.shape
     dy = _rows_view(dy)
     dx = torch.empty(B, L, C, device=x.device, dtype=torch.float32)
+    ws = torch.empty(B * (C // 16) * 2, device=x.device, dtype=torch.float64)
     _chk(lib.styler_groupnorm_relu_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), gamma.data_ptr(), beta.data_ptr(),
-                                       dx.data_ptr(), C, dgamma.data_ptr(), dbeta.data_ptr(), B, L, C, _stream()),
+                                       stats.data_ptr(), dx.data_ptr(), C, dgamma.data_ptr(), dbeta.data_ptr(),
+                                       ws.data_ptr(), B, L, C, _stream()),
          "styler_groupnorm_relu_bwd")
     return dx
 
@@ -512,7 +525,7 @@ def batchnorm_bwd(x, y, dy, gamma, mean, rstd, dgamma, dbeta, act):
     rows = x.numel() // C
     dy = dy.contiguous()
     dx = torch.empty_like(x)
-    ws = torch.empty(2 * C, device=x.device, dtype=torch.float64)
+    ws = torch.empty(2 * C * BN_WS_COPIES, device=x.device, dtype=torch.float64)
     _chk(lib.styler_batchnorm_bwd(x.data_ptr(), _ptr(y), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                   rstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
                                   rows, C, act, _stream()), "styler_batchnorm_bwd")

@@ -42,6 +42,11 @@ class TrainState:
         self.n_current_steps = restore_step            # optimizer.py:10
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
         self.arena = ops.WgradArena()                  # split-K partials of every weight gradient of one backward
+        self.overlap_allreduce = True                  # start the decoder-side all-reduce from inside backward
+        # device step counter mixed into every dropout seed: host seeds are baked into a captured hipGraph, the
+        # counter is what changes between replays (styler_set_dropout_counter)
+        self.drop_epoch = torch.zeros(1, device=dev, dtype=torch.int64)
+        ops.set_dropout_counter(self.drop_epoch)
 
     @staticmethod
     def _tail_offset(model, params, align):
@@ -120,11 +125,13 @@ def train_losses(model, batch, loss_fn=None, dat_fn=None):
     return total, mel_l, post_l, mel_nl, post_nl, d_l, p_l, e_l, cls, cls_dat
 
 
-def train_step(model, state, batch, loss_fn=None, dat_fn=None):
-    """One optimisation step (train.py:135-186).  Returns the 10 loss scalars (device tensors) and the lr."""
+def forward_backward(model, state, batch, loss_fn=None, dat_fn=None):
+    """Everything of one step that runs on the device without host decisions: zero the flat gradient, forward, the
+    ten losses, backward into the flat gradient (train.py:135-179).  Capturable in a hipGraph."""
     state.zero_grad()
+    state.drop_epoch.add_(1)
     losses = train_losses(model, batch, loss_fn, dat_fn)
-    rt.grad_ready_hook = state.on_decoder_grads_ready
+    rt.grad_ready_hook = state.on_decoder_grads_ready if state.overlap_allreduce else None
     state.arena.begin()
     ops.wgrad_arena = state.arena
     try:
@@ -133,5 +140,59 @@ def train_step(model, state, batch, loss_fn=None, dat_fn=None):
     finally:
         rt.grad_ready_hook = None
         ops.wgrad_arena = None
+    return losses
+
+
+def train_step(model, state, batch, loss_fn=None, dat_fn=None):
+    """One optimisation step (train.py:135-186).  Returns the 10 loss scalars (device tensors) and the lr."""
+    losses = forward_backward(model, state, batch, loss_fn, dat_fn)
     lr = state.step()
     return losses, lr
+
+
+class GraphedTrainStep:
+    """The training step with forward + losses + backward replayed from ONE hipGraph (about 1300 kernel launches per
+    step; launched eagerly the host needs as long to enqueue them as the GPU needs to run them).  Outside the graph
+    stay the steps that take host decisions: the RCCL all-reduce of the flat gradient, the Noam learning rate and
+    the fused clip + Adam launch (`TrainState.step`).
+
+    The graph is captured for the shapes of `batch`; `__call__(batch)` copies a new batch of the same shapes into the
+    static input tensors (callers bucket their batches by padded shape and keep one instance per bucket).  The
+    all-reduce is not started from inside backward in this mode (a captured step has no host hook), and the
+    reference's host-side range assertion on p_norm / e_input (utils.py:423) is not evaluated inside the graph."""
+
+    def __init__(self, model, state, batch, warmup=3, loss_fn=None, dat_fn=None):
+        self.model, self.state = model, state
+        self.static = {k: v.clone() for k, v in batch.items()}
+        state.overlap_allreduce = False
+        strict, rt.strict_inputs = rt.strict_inputs, False    # the [0, 1] input assertion is a host sync (utils.py:423)
+        try:
+            self._capture(model, state, warmup, loss_fn, dat_fn)
+        finally:
+            rt.strict_inputs = strict
+
+    def _capture(self, model, state, warmup, loss_fn, dat_fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.enable_grad():
+            for _ in range(warmup):                     # sizes the wgrad arena, builds its descriptor table
+                forward_backward(model, state, self.static, loss_fn, dat_fn)
+                state.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.enable_grad():
+            self.losses = forward_backward(model, state, self.static, loss_fn, dat_fn)
+        # the capture itself did not execute: its step counter increment and BatchNorm momentum updates are part of
+        # the graph, nothing to undo
+
+    def __call__(self, batch=None):
+        if batch is not None:
+            for k, v in batch.items():
+                if self.static[k].shape != v.shape:
+                    raise ValueError(f"GraphedTrainStep was captured for {k} of shape {tuple(self.static[k].shape)}, "
+                                     f"got {tuple(v.shape)}")
+                self.static[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        lr = self.state.step()
+        return self.losses, lr

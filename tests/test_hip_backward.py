@@ -442,3 +442,47 @@ def test_train_state_steps_and_bf16(dev, ref_state_dict):
         assert all(torch.isfinite(x).all() for x in l3)
     finally:
         rt.set_precision("fp32")
+
+
+def test_graphed_train_step_matches_eager(dev, ref_state_dict):
+    """forward + losses + backward replayed from one hipGraph (GraphedTrainStep) must walk the same trajectory as the
+    eager step: same losses and same parameters after the same number of optimiser steps (dropout off: the two modes
+    draw different masks).  With dropout on, two replays must draw DIFFERENT masks (device step counter)."""
+    from closed_form import make_batch
+    from styler_amd import STYLER, rt
+    from styler_amd.training import GraphedTrainStep, TrainState, train_step
+    b = {k: v.to(dev) for k, v in make_batch(4, 20, 40, 2, 9, seed=35).items()}
+    rt.disable_dropout = True
+    try:
+        finals = []
+        for mode in ("eager", "graph"):
+            m = STYLER()
+            m.load_state_dict(ref_state_dict)
+            m = m.to(dev).train()
+            st = TrainState(m)
+            if mode == "eager":
+                for _ in range(5):
+                    losses, lr = train_step(m, st, b)
+            else:
+                g = GraphedTrainStep(m, st, b, warmup=3)     # 3 optimiser steps happen during warm-up
+                for _ in range(2):
+                    losses, lr = g(b)
+            finals.append((torch.stack([x.detach().float().reshape(()) for x in losses]).cpu(), st.flat_p.clone(), lr,
+                           st.n_current_steps))
+        (l_e, p_e, lr_e, n_e), (l_g, p_g, lr_g, n_g) = finals
+        assert n_e == n_g == 5 and lr_e == lr_g
+        assert float((l_e - l_g).abs().max()) <= 2e-4 * max(1.0, float(l_e.abs().max())), (l_e, l_g)
+        assert float((p_e - p_g).abs().max()) <= 1e-4
+    finally:
+        rt.disable_dropout = False
+    m = STYLER()
+    m.load_state_dict(ref_state_dict)
+    m = m.to(dev).train()
+    st = TrainState(m)
+    g = GraphedTrainStep(m, st, b, warmup=2)
+    p0, m0, v0, n0 = st.flat_p.clone(), st.flat_m.clone(), st.flat_v.clone(), st.n_current_steps
+    la = torch.stack([x.detach().float().reshape(()) for x in g(b)[0]]).cpu()
+    st.flat_p.copy_(p0); st.flat_m.copy_(m0); st.flat_v.copy_(v0); st.n_current_steps = n0      # same weights again
+    lb = torch.stack([x.detach().float().reshape(()) for x in g(b)[0]]).cpu()
+    assert torch.isfinite(la).all() and torch.isfinite(lb).all()
+    assert float((la - lb).abs().max()) > 0, "two replays drew the same dropout masks"
