@@ -253,14 +253,15 @@ int styler_act_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, f
 /* Weight (+ bias) gradient of Linear / Conv1d, all kw taps in one launch (autograd of
  * SubLayers.py:41-43,72-76 etc.):
  *   dw[nn*stride_n + c*stride_c + j*stride_j] += sum_{b,t} dz[b,t,nn] * x[b, t+j-pad_left, c]
- *   db[nn] += sum_{b,t} dz[b,t,nn]     (db may be NULL)
+ *   db[nn] += sum_{b,t} dz[b,t,nn]     (db may be NULL; db2, optional, receives the same sums --
+ *                                       nn.LSTM's bias_ih / bias_hh pair)
  * x = 0 outside the item.  prec F32: exact-fp32 MFMA; BF16: operands rounded to bf16 while
  * staged, fp32 accumulate.  Split over rows; partial tiles go to `workspace` and a reduce
  * kernel adds them into dw.  kw in {1,3,5,9}.
  * Linear: kw 1, pad 0, strides (cin, 1, 0); Conv1d [n, cin, kw]: pad kw/2, strides (cin*kw, kw, 1);
  * LSTM W_hh: kw 1, pad_left = +1 / -1 selects h_{t-1} / h_{t+1}. */
 int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db,
-                 int64_t stride_n, int64_t stride_c, int64_t stride_j, int B, int L, int n, int cin,
+                 float* db2, int64_t stride_n, int64_t stride_c, int64_t stride_j, int B, int L, int n, int cin,
                  int kw, int pad_left, int prec, void* workspace, int defer_reduce, void* stream);
 /* Split count styler_wgrad uses for a shape (workspace = splits * n * kw * cin floats). */
 int styler_wgrad_splits(int B, int L, int n, int cin, int kw, int pad_left, int prec);

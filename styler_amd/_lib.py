@@ -44,7 +44,7 @@ _SIGS = {
     "styler_length_mask": [P, P, I, I, P],
     "styler_masked_err_sum": [P, I64, P, I64, P, I, I, I, I, P, P],
     "styler_act_bwd": [P, I64, P, I64, P, I64, I, I, I, I, P, P],
-    "styler_wgrad": [P, I64, P, I64, P, P, I64, I64, I64, I, I, I, I, I, I, I, P, I, P],
+    "styler_wgrad": [P, I64, P, I64, P, P, P, I64, I64, I64, I, I, I, I, I, I, I, P, I, P],
     "styler_wgrad_splits": [I, I, I, I, I, I, I],
     "styler_wgrad_reduce_multi": [P, I, I64, P],
     "styler_wgrad_workspace_bytes": [I, I, I, I, I, I, I],

@@ -244,11 +244,12 @@ class LstmLayerFn(Function):
         dgp = ops.lstm_bidir_bwd(dout, gates, cell, w_hh, H)
         for d, sfx in enumerate(("", "_reverse")):
             sl = dgp[..., d * 4 * H:(d + 1) * 4 * H]
-            ops.wgrad(sl, x, G(getattr(lstm, f"weight_ih_l{layer}{sfx}")), 4 * H, cin)
+            # both biases receive colsum(dgates): fused into the input-weight gradient launch
+            ops.wgrad(sl, x, G(getattr(lstm, f"weight_ih_l{layer}{sfx}")), 4 * H, cin,
+                      db=G(getattr(lstm, f"bias_ih_l{layer}{sfx}")), db2=G(getattr(lstm, f"bias_hh_l{layer}{sfx}")))
             # h_{prev}: forward direction reads out[t-1], reverse direction out[t+1]
             ops.wgrad(sl, out[..., d * H:(d + 1) * H], G(getattr(lstm, f"weight_hh_l{layer}{sfx}")), 4 * H, H,
                       pad_left=1 if d == 0 else -1)
-            ops.colsum(sl, G(getattr(lstm, f"bias_ih_l{layer}{sfx}")), G(getattr(lstm, f"bias_hh_l{layer}{sfx}")))
         dx = None
         if ctx.needs_input_grad[0]:
             names = [f"weight_ih_l{layer}", f"weight_ih_l{layer}_reverse"]
@@ -290,10 +291,10 @@ class LstmMultiLayerFn(Function):
             H, x, dgp, cin = Hs[s], xs[s], dgps[s], xs[s].shape[-1]
             for d, sfx in enumerate(("", "_reverse")):
                 sl = dgp[..., d * 4 * H:(d + 1) * 4 * H]
-                ops.wgrad(sl, x, G(getattr(lstm, f"weight_ih_l{layer}{sfx}")), 4 * H, cin)
+                ops.wgrad(sl, x, G(getattr(lstm, f"weight_ih_l{layer}{sfx}")), 4 * H, cin,
+                          db=G(getattr(lstm, f"bias_ih_l{layer}{sfx}")), db2=G(getattr(lstm, f"bias_hh_l{layer}{sfx}")))
                 ops.wgrad(sl, outs[s][..., d * H:(d + 1) * H], G(getattr(lstm, f"weight_hh_l{layer}{sfx}")), 4 * H, H,
                           pad_left=1 if d == 0 else -1)
-                ops.colsum(sl, G(getattr(lstm, f"bias_ih_l{layer}{sfx}")), G(getattr(lstm, f"bias_hh_l{layer}{sfx}")))
             dx = None
             if ctx.needs_input_grad[3 + s]:
                 srcs = [getattr(lstm, f"weight_ih_l{layer}"), getattr(lstm, f"weight_ih_l{layer}_reverse")]

@@ -73,7 +73,8 @@ extern "C" int styler_act_bwd(const float* dy, int64_t lddy, const float* y, int
 template <int KW>
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dz, int64_t lddz,
                                                     const float* __restrict__ x, int64_t ldx, float* __restrict__ dw,
-                                                    float* __restrict__ db, int64_t sn, int64_t sc, int64_t sj, int B,
+                                                    float* __restrict__ db, float* __restrict__ db2, int64_t sn,
+                                                    int64_t sc, int64_t sj, int B,
                                                     int L, int n, int cin, int pad_left, int ct, int chunks_per_split,
                                                     float* __restrict__ ws) {
   constexpr int XR = WG_BK + KW - 1;                 // x rows per chunk (with halo)
@@ -184,152 +185,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dz
         if (nn < n) wp[((int64_t)nn * KW + j) * cin + c] = acc[j][r];
       }
   }
-  if (do_bias && n0 + tid < n) atomicAdd(db + n0 + tid, bsum);
+  if (do_bias && n0 + tid < n) {
+    atomicAdd(db + n0 + tid, bsum);
+    if (db2) atomicAdd(db2 + n0 + tid, bsum);
+  }
 }
 
-// ---------------------------------------------------------------------------------------------
-// bf16 wgrad (throughput mode): same contraction on v_mfma_f32_32x32x16_bf16.
-// MFMA wants 8 CONSECUTIVE k (= time rows) per lane, but both operands live time-major in HBM.  The LDS images stay
-// row-major [time][feature] in bf16 (coalesced staging: float4 -> 2 x v_cvt_pk_bf16_f32 -> ds_write_b64) and the lane
-// gathers its column with 2-byte reads: for a k-step of 16 rows a lane reads ONE window of 8 + KW - 1 rows of its x
-// column and slides it over the KW taps in registers (even taps: register-aligned; odd taps: v_alignbit), so the
-// gather cost is paid once per k-step, not once per tap.  K chunks never straddle utterances (chunks are enumerated
-// per item; halo rows outside the item are zero at staging), so no per-tap masks exist.
 #define WB_BK 64
 
-template <int KW>
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const float* __restrict__ dz, int64_t lddz,
-                                                         const float* __restrict__ x, int64_t ldx,
-                                                         float* __restrict__ dw, float* __restrict__ db, int64_t sn,
-                                                         int64_t sc, int64_t sj, int B, int L, int n, int cin,
-                                                         int pad_left, int ct, int cpi, int chunks_per_split,
-                                                         float* __restrict__ ws) {
-  constexpr int XR = WB_BK + 8;                      // x rows per chunk incl. halo (KW - 1 <= 8)
-  constexpr int WIN = 8 + KW - 1;                    // rows a lane gathers per k-step (<= 16)
-  constexpr int WD = (WIN + 1) / 2;                  // dwords holding the window
-  __shared__ __attribute__((aligned(16))) uint16_t sA[2][WB_BK * 64];
-  __shared__ __attribute__((aligned(16))) uint16_t sB[2][XR * 64];
-  __shared__ float sBias[16][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
-  const int tile = blockIdx.x;
-  const int n0 = (tile / ct) * 64, c0 = (tile % ct) * 64;
-  const int64_t nchunks = (int64_t)B * cpi;
-  const int64_t ch0 = (int64_t)blockIdx.y * chunks_per_split;
-  int64_t ch1 = ch0 + chunks_per_split; if (ch1 > nchunks) ch1 = nchunks;
-  if (ch0 >= ch1) return;
-
-  const int sr = tid >> 4, sq = (tid & 15) * 4;      // staging: 16 rows per pass, 16 float4 per row
-  constexpr int XP = (XR + 15) / 16;
-  float4 ra[4], rb[XP];
-  auto load = [&](int64_t ch) {
-    const int b = (int)(ch / cpi);
-    const int t0 = (int)(ch - (int64_t)b * cpi) * WB_BK;
-    const int64_t rowb = (int64_t)b * L;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int t = t0 + sr + p * 16;
-      ra[p] = (t < L && n0 + sq < n) ? *reinterpret_cast<const float4*>(dz + (rowb + t) * lddz + n0 + sq)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int p = 0; p < XP; ++p) {
-      const int r = sr + p * 16;
-      const int t = t0 - pad_left + r;
-      rb[p] = (r < XR && t >= 0 && t < L && c0 + sq < ((cin + 3) & ~3))
-                  ? *reinterpret_cast<const float4*>(x + (rowb + t) * ldx + c0 + sq) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto store = [&](int buf) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      bs.x += ra[p].x; bs.y += ra[p].y; bs.z += ra[p].z; bs.w += ra[p].w;
-      *reinterpret_cast<uint2*>(&sA[buf][(sr + p * 16) * 64 + sq]) =
-          make_uint2(cvt_pk_bf16_b(ra[p].x, ra[p].y), cvt_pk_bf16_b(ra[p].z, ra[p].w));
-    }
-#pragma unroll
-    for (int p = 0; p < XP; ++p)
-      if (sr + p * 16 < XR)
-        *reinterpret_cast<uint2*>(&sB[buf][(sr + p * 16) * 64 + sq]) =
-            make_uint2(cvt_pk_bf16_b(rb[p].x, rb[p].y), cvt_pk_bf16_b(rb[p].z, rb[p].w));
-  };
-
-  f32x16 acc[KW];
-#pragma unroll
-  for (int j = 0; j < KW; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-  load(ch0);
-  store(0);
-  __syncthreads();
-  int buf = 0;
-  for (int64_t ch = ch0; ch < ch1; ++ch) {
-    const bool more = ch + 1 < ch1;
-    if (more) load(ch + 1);
-    const uint16_t* pa = &sA[buf][(lh * 8) * 64 + wm * 32 + li];
-    const uint16_t* pb = &sB[buf][(lh * 8) * 64 + wn * 32 + li];
-#pragma unroll
-    for (int s = 0; s < WB_BK / 16; ++s) {
-      uint32_t af[4], win[WD + 1];
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        af[e] = (uint32_t)pa[(s * 16 + 2 * e) * 64] | ((uint32_t)pa[(s * 16 + 2 * e + 1) * 64] << 16);
-#pragma unroll
-      for (int e = 0; e < WD; ++e) {
-        const uint32_t lo = pb[(s * 16 + 2 * e) * 64];
-        const uint32_t hi = (2 * e + 1 < WIN) ? (uint32_t)pb[(s * 16 + 2 * e + 1) * 64] : 0u;
-        win[e] = lo | (hi << 16);
-      }
-      win[WD] = 0u;
-      const uint4 a4 = make_uint4(af[0], af[1], af[2], af[3]);
-      const bf16x8 fa = *reinterpret_cast<const bf16x8*>(&a4);
-#pragma unroll
-      for (int j = 0; j < KW; ++j) {
-        uint4 b4;
-        if ((j & 1) == 0) {
-          b4 = make_uint4(win[j / 2], win[j / 2 + 1], win[j / 2 + 2], win[j / 2 + 3]);
-        } else {
-          const int o = j / 2;
-          b4 = make_uint4(__builtin_amdgcn_alignbit(win[o + 1], win[o], 16), __builtin_amdgcn_alignbit(win[o + 2], win[o + 1], 16),
-                          __builtin_amdgcn_alignbit(win[o + 3], win[o + 2], 16), __builtin_amdgcn_alignbit(win[o + 4], win[o + 3], 16));
-        }
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, *reinterpret_cast<const bf16x8*>(&b4), acc[j], 0, 0, 0);
-      }
-    }
-    if (more) store(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
-  }
-  const int c = c0 + wn * 32 + li;
-  if (c < cin) {
-    float* wp = ws + (int64_t)blockIdx.y * n * KW * cin;
-#pragma unroll
-    for (int j = 0; j < KW; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int nn = n0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (nn < n) wp[((int64_t)nn * KW + j) * cin + c] = acc[j][r];
-      }
-  }
-  if (db && (tile % ct) == 0) {                      // bias gradient from the fp32 staging registers
-    sBias[sr][sq] = bs.x; sBias[sr][sq + 1] = bs.y; sBias[sr][sq + 2] = bs.z; sBias[sr][sq + 3] = bs.w;
-    __syncthreads();
-    if (tid < 64 && n0 + tid < n) {
-      float t = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) t += sBias[r][tid];
-      atomicAdd(db + n0 + tid, t);
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
-// bf16 wgrad, transpose-read engine (the default).  Same contraction and chunking as wgrad_bf16_kernel, but
+// bf16 wgrad (throughput mode): the same contraction on v_mfma_f32_32x32x16_bf16, transpose-read engine.
+// MFMA wants 8 CONSECUTIVE k (= time rows) per lane, but both operands live time-major in HBM.  K chunks (64 rows)
+// never straddle utterances (chunks are enumerated per item; halo rows outside the item read as zeros), so no per-tap
+// masks exist; a lane slides ONE window of 8 + KW - 1 rows of its x column over the KW taps in registers (even taps:
+// register-aligned; odd taps: v_alignbit).
 //   * the block tile is (64*TA) n-features x (64*TB) c-features x KW taps, 4 waves as 2x2, each wave TA x TB MFMA
-//     tiles per tap: operand bytes fetched per MFMA fall by TA*TB/(TA+TB) x 2 (the 64x64 tile is L2-fetch-bound on
-//     the Linear shapes: 16 flop per fp32 operand byte);
+//     tiles per tap (a 128x128 tile halves the operand bytes per MFMA of the Linear shapes);
 //   * fragments come from gfx950's LDS transpose read (ds_read_b64_tr_b16): the time-major image is kept as
 //     [k/4][f/16] sub-tiles of [4 rows][16 features] bf16 (128 B each); one read hands every lane 4 consecutive time
 //     rows of ITS feature, i.e. half an MFMA fragment -- 2 reads per A fragment, 2..4 per x window, instead of
@@ -349,9 +220,10 @@ __device__ __forceinline__ uint2 lds_tr_read(const uint16_t* p) {
 template <int KW, int TA, int TB>
 __global__ __launch_bounds__(256) void wgrad_tr_kernel(const float* __restrict__ dz, int64_t lddz,
                                                        const float* __restrict__ x, int64_t ldx,
-                                                       float* __restrict__ db, int B, int L, int n, int cin,
-                                                       int pad_left, int ct, int cpi, int chunks_per_split,
-                                                       int tiles, int splits, float* __restrict__ ws) {
+                                                       float* __restrict__ db, float* __restrict__ db2, int B, int L,
+                                                       int n, int cin, int pad_left, int ct, int cpi,
+                                                       int chunks_per_split, int tiles, int splits,
+                                                       float* __restrict__ ws) {
   constexpr int FA = 64 * TA, FB = 64 * TB;          // features per block tile
   constexpr int XR = KW == 1 ? 64 : 72;              // x rows per chunk incl. halo (KW - 1 <= 8)
   constexpr int NR = (8 + KW - 1 + 3) / 4;           // transpose reads per x window
@@ -549,6 +421,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const float* __restrict__
 #pragma unroll
       for (int r = 0; r < RPA; ++r) t += sBias[r * FA + tid];
       atomicAdd(db + n0 + tid, t);
+      if (db2) atomicAdd(db2 + n0 + tid, t);
     }
   }
 }
@@ -565,14 +438,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-// Block tile of the bf16 transpose-read engine, in 64-feature units (TA over n, TB over cin); 0 = the two-byte-gather
-// kernel (STYLER_WGRAD_TR=0, kept for A/B measurements).  STYLER_WGRAD_TILE=11 forces the 64x64 tile.
+// Block tile of the bf16 engine, in 64-feature units (TA over n, TB over cin).  STYLER_WGRAD_TILE=11 / 22 force the
+// smallest / largest tile (experiments).
 static void wgrad_tile(int n, int cin, int kw, int prec, int* TA, int* TB) {
   *TA = 1; *TB = 1;
   if (prec != STYLER_PREC_BF16) return;
-  static const int tr_env = [] { const char* e = getenv("STYLER_WGRAD_TR"); return e ? atoi(e) : 1; }();
   static const int tile_env = [] { const char* e = getenv("STYLER_WGRAD_TILE"); return e ? atoi(e) : 0; }();
-  if (!tr_env) { *TA = 0; *TB = 0; return; }
   if (tile_env == 11) return;
   if (tile_env == 22) {                              // experiments: the largest tile the tap count allows
     if (kw <= 5 && n > 64) *TA = 2;
@@ -588,7 +459,7 @@ static void wgrad_plan(int B, int L, int n, int cin, int kw, int pad_left, int p
                        int* splits) {
   int TA, TB;
   wgrad_tile(n, cin, kw, prec, &TA, &TB);
-  const int fa = 64 * (TA ? TA : 1), fb = 64 * (TB ? TB : 1);
+  const int fa = 64 * TA, fb = 64 * TB;
   const int nt = (n + fa - 1) / fa, ct = (cin + fb - 1) / fb;
   *Be = B; *Le = L;
   int64_t nchunks;
@@ -601,7 +472,7 @@ static void wgrad_plan(int B, int L, int n, int cin, int kw, int pad_left, int p
     nchunks = ((int64_t)B * L + WG_BK - 1) / WG_BK;
   }
   int64_t sp = (512 + nt * ct - 1) / (nt * ct);      // ~2 blocks per CU; every extra split costs a partial tile round trip
-  if (sp >= 8 && TA) sp = (sp + 4) / 8 * 8;          // whole splits per XCD (see wgrad_tr_kernel)
+  if (sp >= 8 && prec == STYLER_PREC_BF16) sp = (sp + 4) / 8 * 8;          // whole splits per XCD (see wgrad_tr_kernel)
   if (sp > nchunks / 4) sp = nchunks / 4;
   if (sp < 1) sp = 1;
   *cps = (int)((nchunks + sp - 1) / sp);
@@ -616,25 +487,25 @@ extern "C" int64_t styler_wgrad_workspace_bytes(int B, int L, int n, int cin, in
 }
 
 extern "C" int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db,
-                            int64_t stride_n, int64_t stride_c, int64_t stride_j, int B, int L, int n, int cin, int kw,
+                            float* db2, int64_t stride_n, int64_t stride_c, int64_t stride_j, int B, int L, int n, int cin, int kw,
                             int pad_left, int prec, void* workspace, int defer_reduce, void* stream) {
-  if (!dz || !x || !dw || !workspace || B <= 0 || L <= 0 || n <= 0 || cin <= 0) return STYLER_EINVAL;
+  if (!dz || !x || !dw || !workspace || B <= 0 || L <= 0 || n <= 0 || cin <= 0 || (db2 && !db)) return STYLER_EINVAL;
   if (kw != 1 && kw != 3 && kw != 5 && kw != 9) return STYLER_EINVAL;
   if ((lddz & 3) || (ldx & 3) || (n & 3) || ldx < ((cin + 3) & ~3) || ((uintptr_t)dz & 15) || ((uintptr_t)x & 15)) return STYLER_EALIGN;
   int TA, TB;
   wgrad_tile(n, cin, kw, prec, &TA, &TB);
-  const int fa = 64 * (TA ? TA : 1), fb = 64 * (TB ? TB : 1);
+  const int fa = 64 * TA, fb = 64 * TB;
   const int nt = (n + fa - 1) / fa, ct = (cin + fb - 1) / fb;
   hipStream_t st = (hipStream_t)stream;
   int Be, Le, cpi, cps, splits;
   wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits);
   float* ws = reinterpret_cast<float*>(workspace);
   const dim3 grid(nt * ct, (unsigned)splits);
-  if (prec == STYLER_PREC_BF16 && TA) {
+  if (prec == STYLER_PREC_BF16) {
     const int tiles = nt * ct;
     const dim3 grid1((unsigned)(tiles * (splits >= 8 ? (splits + 7) / 8 * 8 : splits)));
 #define WT_LAUNCH(K, A_, B_) hipLaunchKernelGGL((wgrad_tr_kernel<K, A_, B_>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, \
-                                                Be, Le, n, cin, pad_left, ct, cpi, cps, tiles, splits, ws)
+                                                db2, Be, Le, n, cin, pad_left, ct, cpi, cps, tiles, splits, ws)
     if (kw == 1) {
       if (TA == 2 && TB == 2) WT_LAUNCH(1, 2, 2); else if (TA == 2) WT_LAUNCH(1, 2, 1);
       else if (TB == 2) WT_LAUNCH(1, 1, 2); else WT_LAUNCH(1, 1, 1);
@@ -646,13 +517,8 @@ extern "C" int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64
       WT_LAUNCH(9, 1, 1);
     }
 #undef WT_LAUNCH
-  } else if (prec == STYLER_PREC_BF16) {
-#define WB_LAUNCH(K) hipLaunchKernelGGL(wgrad_bf16_kernel<K>, grid, dim3(256), 0, st, dz, lddz, x, ldx, dw, db, stride_n, \
-                                        stride_c, stride_j, Be, Le, n, cin, pad_left, ct, cpi, cps, ws)
-    if (kw == 1) WB_LAUNCH(1); else if (kw == 3) WB_LAUNCH(3); else if (kw == 5) WB_LAUNCH(5); else WB_LAUNCH(9);
-#undef WB_LAUNCH
   } else {
-#define WG_LAUNCH(K) hipLaunchKernelGGL(wgrad_kernel<K>, grid, dim3(256), 0, st, dz, lddz, x, ldx, dw, db, stride_n, \
+#define WG_LAUNCH(K) hipLaunchKernelGGL(wgrad_kernel<K>, grid, dim3(256), 0, st, dz, lddz, x, ldx, dw, db, db2, stride_n, \
                                         stride_c, stride_j, B, L, n, cin, pad_left, ct, cps, ws)
     if (kw == 1) WG_LAUNCH(1); else if (kw == 3) WG_LAUNCH(3); else if (kw == 5) WG_LAUNCH(5); else WG_LAUNCH(9);
 #undef WG_LAUNCH

@@ -432,8 +432,8 @@ def act_bwd(dy, y, act, lens=None):
     return dz
 
 
-def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=None):
-    """dw (fp32, parameter layout [n, cin] or [n, cin, kw]) += dz^T x over all taps; db += colsum(dz)."""
+def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=None, db2=None):
+    """dw (fp32, parameter layout [n, cin] or [n, cin, kw]) += dz^T x over all taps; db (and db2) += colsum(dz)."""
     B, L = dz.shape[0], dz.shape[1]
     if strides is None:
         strides = (cin * kw, kw, 1) if kw > 1 else (cin, 1, 0)
@@ -457,7 +457,7 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
                                 int(lib.styler_wgrad_splits(B, L, n, cin, kw, pad_left, prec))))
     if ws is None:
         ws = torch.empty(nfloats, device=dz.device, dtype=torch.float32)
-    _chk(lib.styler_wgrad(dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), dw.data_ptr(), _ptr(db), strides[0], strides[1],
+    _chk(lib.styler_wgrad(dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), dw.data_ptr(), _ptr(db), _ptr(db2), strides[0], strides[1],
                           strides[2], B, L, n, cin, kw, pad_left, prec, ws.data_ptr(), defer, _stream()), "styler_wgrad")
     if prof is not None:
         e1.record()
