@@ -80,7 +80,9 @@ int styler_attention_fwd(const float* qkv, float* out, float* lse, int B, int L,
                          const int64_t* len, void* stream);
 
 /* Throughput-mode variants: bf16 MFMA operands (Q, K, V, P, dS, dO rounded to bf16 while staged),
- * fp32 softmax / accumulation; same arguments as the exact-fp32 entry points. */
+ * fp32 softmax / accumulation; same arguments as the exact-fp32 entry points.  Query rows t >= len[b]
+ * are don't-care in the reference's use (zeroed after the following LayerNorm, Layers.py:29): the
+ * forward may leave zeros in `out` / `lse` there, and the backward treats their dout as zero. */
 int styler_attention_fwd_bf16(const float* qkv, float* out, float* lse, int B, int L,
                               const int64_t* len, void* stream);
 int styler_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse,

@@ -15,9 +15,7 @@
 #define ALD 36            // dwords per LDS row (64 bf16 + 16 B pad)
 
 __device__ __forceinline__ uint32_t cvtpk(float lo, float hi) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+  return cvt_pk_bf16_rne(lo, hi);
 }
 
 // 8 consecutive floats at p (scaled) -> bf16x8
@@ -101,10 +99,24 @@ __global__ __launch_bounds__(256) void attention_fwd_bf16_kernel(const float* __
   int klen = len ? (int)len[b] : L;
   if (klen > L) klen = L;
   const int q = q0 + li, qc = q < L ? q : L - 1;
+  // Query rows at or past the item's length are don't-care (every caller zeroes them after the following
+  // LayerNorm, Layers.py:29): blocks made only of such rows write zeros and leave.
+  if (blockIdx.x * 128 >= klen) {
+    if (q < L) {
+      float* op = out + (rowbase + q) * 256 + head * AD + lh * 32;
+#pragma unroll
+      for (int d = 0; d < 32; d += 4) *reinterpret_cast<float4*>(op + d) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lse && lh == 0) lse[((int64_t)b * 4 + head) * L + q] = 0.f;
+    }
+    return;
+  }
 
+  // scores are kept in the log2 domain: q is pre-scaled by log2(e) / sqrt(d_k), so that p = exp2(s - m) is one
+  // v_exp_f32 (no range fix-ups: p underflowing to zero is exactly what softmax wants)
   bf16x8 qf[4];
 #pragma unroll
-  for (int st = 0; st < 4; ++st) qf[st] = load8_bf16(qkv + (rowbase + qc) * 768 + head * AD + st * 16 + lh * 8, 0.125f);
+  for (int st = 0; st < 4; ++st)
+    qf[st] = load8_bf16(qkv + (rowbase + qc) * 768 + head * AD + st * 16 + lh * 8, 0.125f * 1.44269504088896f);
 
   f32x16 o0, o1;
 #pragma unroll
@@ -131,19 +143,22 @@ __global__ __launch_bounds__(256) void attention_fwd_bf16_kernel(const float* __
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[(kb * 32 + li) * ALD + st * 8 + lh * 4]);
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s, 0, 0, 0);
       }
+      if (k0 + kb * 32 + 32 > klen) {                  // only the block holding the length boundary masks keys
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (key >= klen) s[r] = -INFINITY;
+        }
+      }
       float mb = -1e30f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (key >= klen) s[r] = -INFINITY;
-        mb = fmaxf(mb, s[r]);
-      }
+      for (int r = 0; r < 16; ++r) mb = fmaxf(mb, s[r]);
       mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
       const float m_new = fmaxf(m_run, mb);
-      const float alpha = expf(m_run - m_new);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       float rs = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - m_new); rs += s[r]; }
+      for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); rs += s[r]; }
       rs += __shfl_xor(rs, 32, 64);
       l_run = l_run * alpha + rs;
       m_run = m_new;
@@ -159,7 +174,7 @@ __global__ __launch_bounds__(256) void attention_fwd_bf16_kernel(const float* __
   }
   if (q < L) {
     store_accT(out + (rowbase + q) * 256 + head * AD, o0, o1, lh, 1.f / l_run);
-    if (lse && lh == 0) lse[((int64_t)b * 4 + head) * L + q] = m_run + logf(l_run);
+    if (lse && lh == 0) lse[((int64_t)b * 4 + head) * L + q] = (m_run + log2f(l_run)) * 0.693147180559945f;   // natural log
   }
 }
 
@@ -181,12 +196,24 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_bf16_kernel(const float*
   if (klen > L) klen = L;
   const int q = q0 + li, qc = q < L ? q : L - 1;
 
+  // query rows at or past the item's length carry no gradient (they are zeroed after the LayerNorm that follows):
+  // blocks made only of such rows write dQ = 0, delta = 0 and leave
+  if (blockIdx.x * 128 >= klen) {
+    if (q < L) {
+      float* op = dqkv + (rowbase + q) * 768 + head * AD + lh * 32;
+#pragma unroll
+      for (int d = 0; d < 32; d += 4) *reinterpret_cast<float4*>(op + d) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lh == 0) delta[((int64_t)b * 4 + head) * L + q] = 0.f;
+    }
+    return;
+  }
+  constexpr float LOG2E = 1.44269504088896f;
   bf16x8 qf[4], dof[4];
   float dl = 0.f;
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
     const int off = head * AD + st * 16 + lh * 8;
-    qf[st] = load8_bf16(qkv + (rowbase + qc) * 768 + off, 0.125f);
+    qf[st] = load8_bf16(qkv + (rowbase + qc) * 768 + off, 0.125f * LOG2E);     // log2-domain scores, see forward
     const float* dp = dout + (rowbase + qc) * 256 + off;
     const float* op = o + (rowbase + qc) * 256 + off;
     dof[st] = load8_bf16(dp, 1.0f);
@@ -194,7 +221,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_bf16_kernel(const float*
     for (int e = 0; e < 8; ++e) dl += dp[e] * op[e];
   }
   dl += __shfl_xor(dl, 32, 64);
-  const float my_lse = lse[((int64_t)b * 4 + head) * L + qc];
+  const float my_lse = lse[((int64_t)b * 4 + head) * L + qc] * LOG2E;
   if (q < L && lh == 0) delta[((int64_t)b * 4 + head) * L + q] = dl;
 
   f32x16 dq0, dq1;
@@ -224,10 +251,13 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_bf16_kernel(const float*
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[st], dp, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float p = key < klen ? expf(s[r] - my_lse) : 0.f;
-        s[r] = p * (dp[r] - dl);
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] - my_lse) * (dp[r] - dl);
+      if (k0 + kb * 32 + 32 > klen) {                  // only the block holding the length boundary masks keys
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (key >= klen) s[r] = 0.f;
+        }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -261,10 +291,11 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_bf16_kernel(const float
   const int key = key0 + li, keyc = key < L ? key : L - 1;
   const bool key_ok = key < klen;
 
+  constexpr float LOG2E = 1.44269504088896f;
   bf16x8 kf[4], vf[4];
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
-    kf[st] = load8_bf16(qkv + (rowbase + keyc) * 768 + 256 + head * AD + st * 16 + lh * 8, 1.0f);
+    kf[st] = load8_bf16(qkv + (rowbase + keyc) * 768 + 256 + head * AD + st * 16 + lh * 8, 0.125f * LOG2E);
     vf[st] = load8_bf16(qkv + (rowbase + keyc) * 768 + 512 + head * AD + st * 16 + lh * 8, 1.0f);
   }
   f32x16 dk0, dk1, dv0, dv1;
@@ -273,8 +304,11 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_bf16_kernel(const float
 
   const float* qbase = qkv + rowbase * 768 + head * AD;
   const float* dobase = dout + rowbase * 256 + head * AD;
+  // A lane owns one key column, so an invalid key only pollutes its own dK / dV, which are written as zeros below.
+  // Query rows at or past klen have dO = 0 and delta = 0 (no gradient reaches them): they add nothing to any dK / dV,
+  // so the query loop stops at klen; rows of the last tile past L are staged as zeros (lse = delta = 0 there).
   const bool block_live = blockIdx.x * 128 < klen;
-  const int ntiles = block_live ? (L + 63) / 64 : 0;
+  const int ntiles = block_live ? (klen + 63) / 64 : 0;
   for (int qt = 0; qt < ntiles; ++qt) {
     const int qb = qt * 64;
     __syncthreads();
@@ -284,13 +318,14 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_bf16_kernel(const float
     else stage_transposed(sDOT, dobase, 256, qb, L, tid - 128);
     if (tid < 64) {
       const int qq = qb + tid;
-      sLse[tid] = qq < L ? lse[((int64_t)b * 4 + head) * L + qq] : 0.f;
-      sDl[tid] = qq < L ? delta[((int64_t)b * 4 + head) * L + qq] : 0.f;
+      // rows at or past klen: lse = +huge makes p exactly 0 (whatever dO / the forward's lse hold there)
+      sLse[tid] = qq < klen ? lse[((int64_t)b * 4 + head) * L + qq] * LOG2E : 1e30f;
+      sDl[tid] = qq < klen ? delta[((int64_t)b * 4 + head) * L + qq] : 0.f;
     }
     __syncthreads();
 #pragma unroll
     for (int qk = 0; qk < 2; ++qk) {
-      if (qb + qk * 32 >= L) break;
+      if (qb + qk * 32 >= klen) break;
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -304,8 +339,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_bf16_kernel(const float
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ql = qk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const bool ok = key_ok && (qb + ql < L);
-        const float p = ok ? expf(s[r] * 0.125f - sLse[ql]) : 0.f;
+        const float p = __builtin_amdgcn_exp2f(s[r] - sLse[ql]);
         s[r] = p;
         dp[r] = p * (dp[r] - sDl[ql]);
       }
@@ -320,8 +354,19 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_bf16_kernel(const float
     }
   }
   if (key < L) {
-    store_accT(dqkv + (rowbase + key) * 768 + 256 + head * AD, dk0, dk1, lh, 0.125f);
-    store_accT(dqkv + (rowbase + key) * 768 + 512 + head * AD, dv0, dv1, lh, 1.0f);
+    // dK = dS^T (Q / sqrt(d_k)): the staged Q tiles are unscaled, so the 1/8 is applied here; invalid keys get zeros
+    // (their accumulators may hold anything, inf included: written as literal zeros, never multiplied by 0)
+    if (key_ok) {
+      store_accT(dqkv + (rowbase + key) * 768 + 256 + head * AD, dk0, dk1, lh, 0.125f);
+      store_accT(dqkv + (rowbase + key) * 768 + 512 + head * AD, dv0, dv1, lh, 1.0f);
+    } else {
+#pragma unroll
+      for (int part = 1; part <= 2; ++part) {
+        float* op = dqkv + (rowbase + key) * 768 + part * 256 + head * AD + lh * 32;
+#pragma unroll
+        for (int d = 0; d < 32; d += 4) *reinterpret_cast<float4*>(op + d) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
   }
 }
 

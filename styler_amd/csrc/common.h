@@ -38,6 +38,17 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return u >> 16;
 }
+// Two floats -> packed bf16 pair (round-to-nearest-even), one v_cvt_pk_bf16_f32.  Written as a vector conversion, NOT
+// inline asm: the compiler must see the instruction to place the wait state the hardware needs between a
+// transcendental (v_exp_f32) and a consumer of its result -- an asm block right behind exp2 read garbage.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16_rne(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+  return *reinterpret_cast<const uint32_t*>(&b);
+}
+
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
 }

@@ -41,9 +41,7 @@ struct GemmArgs {
 };
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+  return cvt_pk_bf16_rne(lo, hi);
 }
 
 template <int TM, int TN, bool BF16, bool KW1, bool OCC3>

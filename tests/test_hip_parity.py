@@ -104,8 +104,11 @@ def test_attention(dev, B, L, lens):
     check(out, ref.float(), 2e-5, "attention")
     check(lse, torch.logsumexp(s, -1).float(), 2e-5, "lse")
     out16 = ops.attention_fwd(qkv.to(dev), ln.to(dev), lse=lse, prec=ops.PREC_BF16)     # bf16 operands, fp32 softmax
-    check(out16, ref.float(), 3e-2, "attention bf16")
-    check(lse, torch.logsumexp(s, -1).float(), 3e-2, "lse bf16")
+    # the throughput kernel leaves query rows past the item's length as don't-care (whole 128-row blocks of them are
+    # written as zeros): every caller zeroes those rows after the following LayerNorm (Layers.py:29)
+    vq = (torch.arange(L)[None, :] < ln[:, None])
+    check(out16 * vq[..., None].to(dev), ref.float() * vq[..., None], 3e-2, "attention bf16")
+    check(lse * vq[:, None, :].to(dev), torch.logsumexp(s, -1).float() * vq[:, None, :], 3e-2, "lse bf16")
 
 
 def test_add_layernorm(dev):
