@@ -140,7 +140,7 @@ def run(args, mode, rank, world, dev, dist):
             step()
         torch.cuda.synchronize()
         ops.gemm_profiler = None
-        gsum = prof.summary()
+        gsum = prof.summary(packed_fraction=frames / float(args.batch * T))
 
     elapsed, total_frames = aggregate_throughput(elapsed, frames, dev)
     if rank != 0:

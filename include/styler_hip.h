@@ -56,6 +56,32 @@ int styler_conv_gemm(const float* x, int64_t ldx, const void* w, const float* sc
                      int64_t ldy, int B, int L, int cin, int n, int kw, int act, int prec,
                      const int64_t* len, void* stream);
 
+/* ---- packed rows (the decoder runs on the valid frames only) --------------------------
+ * Every FFT block of the decoder (transformer/Models.py:111-135) zeroes its padded rows
+ * (Layers.py:29,32), masks padded keys and convolves over zeros there; on the padded rectangle
+ * [B, T] that is arithmetic on zeros for every padded frame.  The packed layout stores the valid
+ * rows of all items back to back (capacity B*T rows; the valid count stays on the device).
+ * styler_pack_plan derives the index tables from the int64 lengths (clamped to [0, T]):
+ *   cu [B+1] int32: first packed row of each item;  rowinfo [B*T] x (int32 t, int32 len-1-t),
+ *   (0,-1) behind the data;  chunktab [B*T/64 + B] x int32[4] = (first row, t0, len, b) of the
+ *   64-row K chunks of the weight-gradient GEMM;  counts [2] int64 = (valid rows, chunks).
+ * counts doubles as the `len` of the single packed "item" for the row-wise entry points
+ * (styler_add_layernorm, styler_layernorm_bwd, styler_act_bwd, styler_conv_gemm with B = 1). */
+int styler_pack_plan(const int64_t* len, int B, int T, int32_t* cu, int32_t* rowinfo,
+                     int32_t* chunktab, int64_t* counts, void* stream);
+/* packed[cu[b]+t] = padded[b,t] (+ add[t,:], e.g. the positional table of Models.py:120-125), t < len[b] */
+int styler_pack_rows(const float* padded, int64_t ldp, float* packed, int64_t ldk, const float* add,
+                     const int32_t* cu, int B, int T, int C, void* stream);
+/* padded[b,t] = t < len[b] ? packed[cu[b]+t] : 0   (also the backward of styler_pack_rows) */
+int styler_unpack_rows(const float* packed, int64_t ldk, float* padded, int64_t ldp,
+                       const int32_t* cu, int B, int T, int C, void* stream);
+/* styler_conv_gemm on packed rows: taps never cross an item (rowinfo), tiles behind the data are
+ * skipped, rows >= nrows[0] are written as 0. */
+int styler_conv_gemm_packed(const float* x, int64_t ldx, const void* w, const float* scale,
+                            const float* shift, const float* res, int64_t ldres, float* y,
+                            int64_t ldy, int rows, int cin, int n, int kw, int act, int prec,
+                            const int64_t* nrows, const int32_t* rowinfo, void* stream);
+
 /* Which tile engine styler_conv_gemm dispatches for a shape: bit0 = 128x128 block tile (else
  * 64x64), bit1 = bf16 MFMA (else fp32 MFMA).  Used by bench.py to attribute launches. */
 int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, int prec);
@@ -75,19 +101,21 @@ int styler_repack_conv_weight(const float* src, void* dst, int n, int cin, int k
  * softmax in LDS/registers: the [4B, L, L] score tensor is never materialised.
  * qkv: [B, L, 768] = q | k | v (each 4 heads x 64, head-major within the 256 block);
  * out: [B, L, 256] (b x lq x (n*dv), SubLayers.py:54-56).  lse (optional, [B,4,L]) gets
- * the log-sum-exp per query row for the backward pass. */
+ * the log-sum-exp per query row for the backward pass.
+ * cu (optional, int32 [B+1], requires len): packed rows -- item b occupies rows cu[b] .. cu[b]+len[b]-1
+ * of qkv / out (styler_pack_plan); L is then only the grid / lse stride (the longest item allowed). */
 int styler_attention_fwd(const float* qkv, float* out, float* lse, int B, int L,
-                         const int64_t* len, void* stream);
+                         const int64_t* len, const int32_t* cu, void* stream);
 
 /* Throughput-mode variants: bf16 MFMA operands (Q, K, V, P, dS, dO rounded to bf16 while staged),
  * fp32 softmax / accumulation; same arguments as the exact-fp32 entry points.  Query rows t >= len[b]
  * are don't-care in the reference's use (zeroed after the following LayerNorm, Layers.py:29): the
  * forward may leave zeros in `out` / `lse` there, and the backward treats their dout as zero. */
 int styler_attention_fwd_bf16(const float* qkv, float* out, float* lse, int B, int L,
-                              const int64_t* len, void* stream);
+                              const int64_t* len, const int32_t* cu, void* stream);
 int styler_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse,
                               float* dqkv, float* delta_ws, int B, int L, const int64_t* len,
-                              void* stream);
+                              const int32_t* cu, void* stream);
 
 /* ---- normalisation / epilogues ------------------------------------------------------
  * y = LayerNorm_256(x + res) * gamma + beta, then rows t >= len[b] set to 0
@@ -265,6 +293,12 @@ int styler_act_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, f
 int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db,
                  float* db2, int64_t stride_n, int64_t stride_c, int64_t stride_j, int B, int L, int n, int cin,
                  int kw, int pad_left, int prec, void* workspace, int defer_reduce, void* stream);
+/* styler_wgrad on packed rows (`rows` = capacity, counts[0] valid).  Workspace / split count: those of
+ * styler_wgrad_workspace_bytes / styler_wgrad_splits for (B = 1, L = rows, pad_left = kw/2). */
+int styler_wgrad_packed(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db,
+                        int64_t stride_n, int64_t stride_c, int64_t stride_j, int rows, int n, int cin,
+                        int kw, int prec, void* workspace, int defer_reduce, const int32_t* rowinfo,
+                        const int32_t* chunktab, const int64_t* counts, void* stream);
 /* Split count styler_wgrad uses for a shape (workspace = splits * n * kw * cin floats). */
 int styler_wgrad_splits(int B, int L, int n, int cin, int kw, int pad_left, int prec);
 
@@ -298,7 +332,7 @@ int styler_repack_weight_bwd(const float* src, void* dst, int n, int cin, int kw
 /* Attention backward (recomputes P from lse): dqkv [B,L,768]; delta_ws: B*4*L floats. */
 int styler_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                          float* dqkv, float* delta_ws, int B, int L, const int64_t* len,
-                         void* stream);
+                         const int32_t* cu, void* stream);
 
 /* LayerNorm(256) backward from the saved INPUT x (= pre-norm sum).  dx may be NULL.  With
  * dot_w (predictor tail) the incoming gradient is dout [B,L] and ddot_w/ddot_b accumulate. */

@@ -19,9 +19,9 @@ _SIGS = {
     "styler_conv_gemm_variant": [I, I, I, I, I, I],
     "styler_cast_bf16": [P, P, I64, P],
     "styler_repack_conv_weight": [P, P, I, I, I, I, I, P],
-    "styler_attention_fwd": [P, P, P, I, I, P, P],
-    "styler_attention_fwd_bf16": [P, P, P, I, I, P, P],
-    "styler_attention_bwd_bf16": [P, P, P, P, P, P, I, I, P, P],
+    "styler_attention_fwd": [P, P, P, I, I, P, P, P],
+    "styler_attention_fwd_bf16": [P, P, P, I, I, P, P, P],
+    "styler_attention_bwd_bf16": [P, P, P, P, P, P, I, I, P, P, P],
     "styler_add_layernorm": [P, I64, P, I64, P, P, P, I64, P, P, P, I, I, I, P, F, ctypes.c_uint64, P],
     "styler_groupnorm_relu": [P, I64, P, P, P, I64, P, P, I, I, I, P],
     "styler_bn_fold": [P, P, P, P, P, P, P, I, P],
@@ -34,6 +34,11 @@ _SIGS = {
     "styler_lstm_bidir": [P, P, P, P, P, I, I, I, P],
     "styler_lstm_bidir_multi": [P, I, I, I, P],
     "styler_set_dropout_counter": [P],
+    "styler_pack_plan": [P, I, I, P, P, P, P, P],
+    "styler_pack_rows": [P, I64, P, I64, P, P, I, I, I, P],
+    "styler_unpack_rows": [P, I64, P, I64, P, I, I, I, P],
+    "styler_conv_gemm_packed": [P, I64, P, P, P, P, I64, P, I64, I, I, I, I, I, I, P, P, P],
+    "styler_wgrad_packed": [P, I64, P, I64, P, P, I64, I64, I64, I, I, I, I, I, P, I, P, P, P, P],
     "styler_lstm_bidir_bwd_multi": [P, I, I, I, P],
     "styler_aug_classifier_tail": [P, P, P, P, P, P, I, I, P],
     "styler_duration_scan": [P, I, P, F, P, P, P, I, I, P],
@@ -50,7 +55,7 @@ _SIGS = {
     "styler_wgrad_workspace_bytes": [I, I, I, I, I, I, I],
     "styler_colsum": [P, I64, P, P, I64, I, P],
     "styler_repack_weight_bwd": [P, P, I, I, I, I, P],
-    "styler_attention_bwd": [P, P, P, P, P, P, I, I, P, P],
+    "styler_attention_bwd": [P, P, P, P, P, P, I, I, P, P, P],
     "styler_layernorm_bwd": [P, I64, P, I64, P, P, P, I64, P, P, P, P, P, P, I, I, I, P, F, ctypes.c_uint64, P],
     "styler_groupnorm_relu_bwd": [P, I64, P, I64, P, P, P, P, I64, P, P, P, I, I, I, P],
     "styler_batchnorm_bwd": [P, P, P, P, P, P, P, P, P, P, I64, I, I, P],

@@ -34,12 +34,13 @@ class ConvGemmFn(Function):
     """y = act(conv_same(x, W) + b) (+ res when act is NONE).  W / b are nn.Parameters in reference layout."""
 
     @staticmethod
-    def forward(ctx, x, res, weight, bias, cache, key, kw, act, neg_dx):
+    def forward(ctx, x, res, weight, bias, cache, key, kw, act, neg_dx, plan=None):
         w, prec = gemm_weight(cache, key, weight, x.shape[-1])
         fuse_res = res is not None and act == NONE
-        y = ops.conv_gemm(x, w, bias, kw=kw, n=weight.shape[0], act=act, prec=prec, res=res if fuse_res else None)
+        y = ops.conv_gemm(x, w, bias, kw=kw, n=weight.shape[0], act=act, prec=prec, res=res if fuse_res else None,
+                          plan=plan)
         ctx.save_for_backward(x, y if act != NONE else None)
-        ctx.weight, ctx.bias, ctx.cache, ctx.key = weight, bias, cache, key
+        ctx.weight, ctx.bias, ctx.cache, ctx.key, ctx.plan = weight, bias, cache, key, plan
         ctx.kw, ctx.act, ctx.neg_dx, ctx.has_res = kw, act, neg_dx, res is not None
         if res is not None and not fuse_res:
             return ops.add2(y, res)
@@ -51,10 +52,11 @@ class ConvGemmFn(Function):
         weight, bias, kw = ctx.weight, ctx.bias, ctx.kw
         n, cin = weight.shape[0], x.shape[-1]
         dy = ops._rows_view(dy)
-        dz = ops.act_bwd(dy, y, ctx.act) if ctx.act != NONE else dy
+        plan = ctx.plan
+        dz = ops.act_bwd(dy, y, ctx.act, lens=plan.nrows if plan is not None else None) if ctx.act != NONE else dy
         if weight.requires_grad:
             ops.wgrad(dz, x, G(weight), n, cin, kw=kw,
-                      db=G(bias) if (bias is not None and bias.requires_grad) else None)
+                      db=G(bias) if (bias is not None and bias.requires_grad) else None, plan=plan)
         dx = None
         if ctx.needs_input_grad[0]:
             if rt.prec == ops.PREC_BF16 and n % 8 == 0:
@@ -64,32 +66,32 @@ class ConvGemmFn(Function):
                 wt = ctx.cache.get(ctx.key + ":T", [weight], lambda w: ops.repack_weight_bwd(w.detach()))
                 prec = ops.PREC_F32
             dx = ops.conv_gemm(dz, wt, None, kw=kw, n=cin, prec=prec,
-                               scale=_neg(cin, dz.device) if ctx.neg_dx else None)
-        return dx, (dy if ctx.has_res else None), None, None, None, None, None, None, None
+                               scale=_neg(cin, dz.device) if ctx.neg_dx else None, plan=plan)
+        return dx, (dy if ctx.has_res else None), None, None, None, None, None, None, None, None
 
 
 class QkvAttentionFn(Function):
     """Fused QKV projection + attention (SubLayers.py:41-56)."""
 
     @staticmethod
-    def forward(ctx, x, anchor, mha, lens):
+    def forward(ctx, x, anchor, mha, lens, plan=None):
         w, b, prec = mha._qkv()
-        qkv = ops.conv_gemm(x, w, b, n=768, prec=prec)
-        B, L, _ = x.shape
+        qkv = ops.conv_gemm(x, w, b, n=768, prec=prec, plan=plan)
+        B, L = (plan.B, plan.T) if plan is not None else x.shape[:2]
         lse = torch.empty(B, 4, L, device=x.device, dtype=torch.float32)
-        out = ops.attention_fwd(qkv, lens, lse=lse)
+        out = ops.attention_fwd(qkv, lens, lse=lse, plan=plan)
         ctx.save_for_backward(x, qkv, out, lse, lens)
-        ctx.mha = mha
+        ctx.mha, ctx.plan = mha, plan
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, qkv, out, lse, lens = ctx.saved_tensors
-        mha = ctx.mha
-        dqkv = ops.attention_bwd(qkv, out, dout, lse, lens)
+        mha, plan = ctx.mha, ctx.plan
+        dqkv = ops.attention_bwd(qkv, out, dout, lse, lens, plan=plan)
         for i, lin in enumerate((mha.w_qs, mha.w_ks, mha.w_vs)):
             sl = dqkv[..., i * 256:(i + 1) * 256]
-            ops.wgrad(sl, x, G(lin.weight), 256, 256, db=G(lin.bias))
+            ops.wgrad(sl, x, G(lin.weight), 256, 256, db=G(lin.bias), plan=plan)
         d = mha._derived
         srcs = [mha.w_qs.weight, mha.w_ks.weight, mha.w_vs.weight]
         if rt.prec == ops.PREC_BF16:
@@ -98,8 +100,8 @@ class QkvAttentionFn(Function):
         else:
             wt = d.get("qkv_wT", srcs, lambda *t: torch.cat([u.detach() for u in t]).t().contiguous())
             prec = ops.PREC_F32
-        dx = ops.conv_gemm(dqkv, wt, None, n=256, prec=prec)
-        return dx, None, None, None
+        dx = ops.conv_gemm(dqkv, wt, None, n=256, prec=prec, plan=plan)
+        return dx, None, None, None, None
 
 
 class LayerNormFn(Function):
@@ -371,6 +373,32 @@ class AddPosFn(Function):
     @staticmethod
     def backward(ctx, dy):
         return dy, None
+
+
+class PackRowsFn(Function):
+    """padded [B, T, C] (+ positional table) -> packed [1, B*T, C] (ops.PackPlan); backward = unpack."""
+
+    @staticmethod
+    def forward(ctx, x, pe, plan):
+        ctx.plan = plan
+        return ops.pack_rows(x, plan, add=pe)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.unpack_rows(dy, ctx.plan), None, None
+
+
+class UnpackRowsFn(Function):
+    """packed -> padded with zero rows at t >= len[b]; backward = pack."""
+
+    @staticmethod
+    def forward(ctx, xp, plan):
+        ctx.plan = plan
+        return ops.unpack_rows(xp, plan)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.pack_rows(ops._rows_view(dy), ctx.plan), None
 
 
 class Add2Fn(Function):

@@ -20,7 +20,7 @@
 
 __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                             float* __restrict__ lse, int B, int L,
-                                                            const int64_t* __restrict__ len) {
+                                                            const int64_t* __restrict__ len, const int* __restrict__ cu) {
   __shared__ __attribute__((aligned(16))) float sK[ATT_KT * ATT_KLD];
   __shared__ __attribute__((aligned(16))) float sV[ATT_KT * ATT_D];
 
@@ -28,15 +28,17 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
   const int li = lane & 31, lh = lane >> 5;
   const int head = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * 128 + wave * 32;
-  const int64_t rowbase = (int64_t)b * L;
+  const int64_t rowbase = cu ? (int64_t)cu[b] : (int64_t)b * L;     // packed rows (pack.hip): items back to back
   int klen = len ? (int)len[b] : L;
   if (klen > L) klen = L;
+  const int Lr = cu ? klen : L;                                      // rows this item owns in memory
+  if (Lr <= 0) return;
 
   // Q fragment: lane (q = li, h) holds Q[q][h*32 .. h*32+31], pre-scaled by 1/sqrt(64) (exact)
   float qf[32];
   {
     const int q = q0 + li;
-    const float* qp = qkv + (rowbase + (q < L ? q : L - 1)) * 768 + head * ATT_D + lh * 32;
+    const float* qp = qkv + (rowbase + (q < Lr ? q : Lr - 1)) * 768 + head * ATT_D + lh * 32;
 #pragma unroll
     for (int v = 0; v < 8; ++v) {
       float4 t = *reinterpret_cast<const float4*>(qp + v * 4);
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
       const int kr = idx >> 4, c4 = (idx & 15) * 4;
       const int key = k0 + kr;
       float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-      if (key < L) {
+      if (key < Lr) {
         const float* base = qkv + (rowbase + key) * 768 + head * ATT_D + c4;
         kv = *reinterpret_cast<const float4*>(base + 256);
         vv = *reinterpret_cast<const float4*>(base + 512);
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
   }
 
   const int q = q0 + li;
-  if (q < L) {
+  if (q < Lr) {
     const float inv = 1.f / l_run;
     float* op = out + (rowbase + q) * 256 + head * ATT_D;
 #pragma unroll
@@ -133,10 +135,10 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
 }
 
 extern "C" int styler_attention_fwd(const float* qkv, float* out, float* lse, int B, int L, const int64_t* len,
-                                    void* stream) {
+                                    const int32_t* cu, void* stream) {
   if (!qkv || !out || B <= 0 || L <= 0) return STYLER_EINVAL;
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return STYLER_EALIGN;
   dim3 grid((L + 127) / 128, 4, B);
-  hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, lse, B, L, len);
+  hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, lse, B, L, len, cu);
   return launch_status();
 }

@@ -89,20 +89,23 @@ __device__ __forceinline__ void store_accT(float* op, const f32x16& a0, const f3
 // ------------------------------------------------------------------------------------------------- forward
 __global__ __launch_bounds__(256) void attention_fwd_bf16_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                  float* __restrict__ lse, int B, int L,
-                                                                 const int64_t* __restrict__ len) {
+                                                                 const int64_t* __restrict__ len,
+                                                                 const int* __restrict__ cu) {
   __shared__ __attribute__((aligned(16))) uint32_t sK[64 * ALD];
   __shared__ __attribute__((aligned(16))) uint32_t sVT[64 * ALD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int head = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * 128 + wave * 32;
-  const int64_t rowbase = (int64_t)b * L;
+  const int64_t rowbase = cu ? (int64_t)cu[b] : (int64_t)b * L;     // packed rows (pack.hip): items back to back
   int klen = len ? (int)len[b] : L;
   if (klen > L) klen = L;
-  const int q = q0 + li, qc = q < L ? q : L - 1;
+  const int Lr = cu ? klen : L;                                      // rows this item owns in memory
+  if (Lr <= 0) return;
+  const int q = q0 + li, qc = q < Lr ? q : Lr - 1;
   // Query rows at or past the item's length are don't-care (every caller zeroes them after the following
   // LayerNorm, Layers.py:29): blocks made only of such rows write zeros and leave.
   if (blockIdx.x * 128 >= klen) {
-    if (q < L) {
+    if (q < Lr) {
       float* op = out + (rowbase + q) * 256 + head * AD + lh * 32;
 #pragma unroll
       for (int d = 0; d < 32; d += 4) *reinterpret_cast<float4*>(op + d) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -129,8 +132,8 @@ __global__ __launch_bounds__(256) void attention_fwd_bf16_kernel(const float* __
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * 64;
     __syncthreads();
-    stage_rows(sK, kbase, 768, k0, L, tid);
-    if (tid < 128) stage_transposed(sVT, vbase, 768, k0, L, tid);
+    stage_rows(sK, kbase, 768, k0, Lr, tid);
+    if (tid < 128) stage_transposed(sVT, vbase, 768, k0, Lr, tid);
     __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void attention_fwd_bf16_kernel(const float* __
       }
     }
   }
-  if (q < L) {
+  if (q < Lr) {
     store_accT(out + (rowbase + q) * 256 + head * AD, o0, o1, lh, 1.f / l_run);
     if (lse && lh == 0) lse[((int64_t)b * 4 + head) * L + q] = (m_run + log2f(l_run)) * 0.693147180559945f;   // natural log
   }
@@ -184,22 +187,25 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_bf16_kernel(const float*
                                                                     const float* __restrict__ dout,
                                                                     const float* __restrict__ lse,
                                                                     float* __restrict__ dqkv, float* __restrict__ delta,
-                                                                    int B, int L, const int64_t* __restrict__ len) {
+                                                                    int B, int L, const int64_t* __restrict__ len,
+                                                                    const int* __restrict__ cu) {
   __shared__ __attribute__((aligned(16))) uint32_t sK[64 * ALD];
   __shared__ __attribute__((aligned(16))) uint32_t sV[64 * ALD];
   __shared__ __attribute__((aligned(16))) uint32_t sKT[64 * ALD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int head = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * 128 + wave * 32;
-  const int64_t rowbase = (int64_t)b * L;
+  const int64_t rowbase = cu ? (int64_t)cu[b] : (int64_t)b * L;
   int klen = len ? (int)len[b] : L;
   if (klen > L) klen = L;
-  const int q = q0 + li, qc = q < L ? q : L - 1;
+  const int Lr = cu ? klen : L;
+  if (Lr <= 0) return;
+  const int q = q0 + li, qc = q < Lr ? q : Lr - 1;
 
   // query rows at or past the item's length carry no gradient (they are zeroed after the LayerNorm that follows):
   // blocks made only of such rows write dQ = 0, delta = 0 and leave
   if (blockIdx.x * 128 >= klen) {
-    if (q < L) {
+    if (q < Lr) {
       float* op = dqkv + (rowbase + q) * 768 + head * AD + lh * 32;
 #pragma unroll
       for (int d = 0; d < 32; d += 4) *reinterpret_cast<float4*>(op + d) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_bf16_kernel(const float*
   }
   dl += __shfl_xor(dl, 32, 64);
   const float my_lse = lse[((int64_t)b * 4 + head) * L + qc] * LOG2E;
-  if (q < L && lh == 0) delta[((int64_t)b * 4 + head) * L + q] = dl;
+  if (q < Lr && lh == 0) delta[((int64_t)b * 4 + head) * L + q] = dl;
 
   f32x16 dq0, dq1;
 #pragma unroll
@@ -233,9 +239,9 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_bf16_kernel(const float*
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * 64;
     __syncthreads();
-    stage_rows(sK, kbase, 768, k0, L, tid);
-    stage_rows(sV, vbase, 768, k0, L, tid);
-    if (tid < 128) stage_transposed(sKT, kbase, 768, k0, L, tid);
+    stage_rows(sK, kbase, 768, k0, Lr, tid);
+    stage_rows(sV, vbase, 768, k0, Lr, tid);
+    if (tid < 128) stage_transposed(sKT, kbase, 768, k0, Lr, tid);
     __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_bf16_kernel(const float*
       }
     }
   }
-  if (q < L) store_accT(dqkv + (rowbase + q) * 768 + head * AD, dq0, dq1, lh, 0.125f);
+  if (q < Lr) store_accT(dqkv + (rowbase + q) * 768 + head * AD, dq0, dq1, lh, 0.125f);
 }
 
 // ------------------------------------------------------------------------------------------------- dK, dV
@@ -276,7 +282,8 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_bf16_kernel(const float
                                                                      const float* __restrict__ lse,
                                                                      const float* __restrict__ delta,
                                                                      float* __restrict__ dqkv, int B, int L,
-                                                                     const int64_t* __restrict__ len) {
+                                                                     const int64_t* __restrict__ len,
+                                                                     const int* __restrict__ cu) {
   __shared__ __attribute__((aligned(16))) uint32_t sQ[64 * ALD];
   __shared__ __attribute__((aligned(16))) uint32_t sDO[64 * ALD];
   __shared__ __attribute__((aligned(16))) uint32_t sQT[64 * ALD];
@@ -285,10 +292,12 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_bf16_kernel(const float
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int head = blockIdx.y, b = blockIdx.z;
   const int key0 = blockIdx.x * 128 + wave * 32;
-  const int64_t rowbase = (int64_t)b * L;
+  const int64_t rowbase = cu ? (int64_t)cu[b] : (int64_t)b * L;
   int klen = len ? (int)len[b] : L;
   if (klen > L) klen = L;
-  const int key = key0 + li, keyc = key < L ? key : L - 1;
+  const int Lr = cu ? klen : L;
+  if (Lr <= 0) return;
+  const int key = key0 + li, keyc = key < Lr ? key : Lr - 1;
   const bool key_ok = key < klen;
 
   constexpr float LOG2E = 1.44269504088896f;
@@ -312,10 +321,10 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_bf16_kernel(const float
   for (int qt = 0; qt < ntiles; ++qt) {
     const int qb = qt * 64;
     __syncthreads();
-    stage_rows(sQ, qbase, 768, qb, L, tid);
-    stage_rows(sDO, dobase, 256, qb, L, tid);
-    if (tid < 128) stage_transposed(sQT, qbase, 768, qb, L, tid);
-    else stage_transposed(sDOT, dobase, 256, qb, L, tid - 128);
+    stage_rows(sQ, qbase, 768, qb, Lr, tid);
+    stage_rows(sDO, dobase, 256, qb, Lr, tid);
+    if (tid < 128) stage_transposed(sQT, qbase, 768, qb, Lr, tid);
+    else stage_transposed(sDOT, dobase, 256, qb, Lr, tid - 128);
     if (tid < 64) {
       const int qq = qb + tid;
       // rows at or past klen: lse = +huge makes p exactly 0 (whatever dO / the forward's lse hold there)
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_bf16_kernel(const float
       }
     }
   }
-  if (key < L) {
+  if (key < Lr) {
     // dK = dS^T (Q / sqrt(d_k)): the staged Q tiles are unscaled, so the 1/8 is applied here; invalid keys get zeros
     // (their accumulators may hold anything, inf included: written as literal zeros, never multiplied by 0)
     if (key_ok) {
@@ -371,21 +380,22 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_bf16_kernel(const float
 }
 
 extern "C" int styler_attention_fwd_bf16(const float* qkv, float* out, float* lse, int B, int L, const int64_t* len,
-                                         void* stream) {
-  if (!qkv || !out || B <= 0 || L <= 0) return STYLER_EINVAL;
+                                         const int32_t* cu, void* stream) {
+  if (!qkv || !out || B <= 0 || L <= 0 || (cu && !len)) return STYLER_EINVAL;
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return STYLER_EALIGN;
   hipLaunchKernelGGL(attention_fwd_bf16_kernel, dim3((L + 127) / 128, 4, B), dim3(256), 0, (hipStream_t)stream, qkv, out,
-                     lse, B, L, len);
+                     lse, B, L, len, cu);
   return launch_status();
 }
 
 extern "C" int styler_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse,
-                                         float* dqkv, float* delta_ws, int B, int L, const int64_t* len, void* stream) {
+                                         float* dqkv, float* delta_ws, int B, int L, const int64_t* len,
+                                         const int32_t* cu, void* stream) {
   if (!qkv || !out || !dout || !lse || !dqkv || !delta_ws || B <= 0 || L <= 0) return STYLER_EINVAL;
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 15)) return STYLER_EALIGN;
   dim3 grid((L + 127) / 128, 4, B);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(attention_bwd_dq_bf16_kernel, grid, dim3(256), 0, st, qkv, out, dout, lse, dqkv, delta_ws, B, L, len);
-  hipLaunchKernelGGL(attention_bwd_dkv_bf16_kernel, grid, dim3(256), 0, st, qkv, dout, lse, delta_ws, dqkv, B, L, len);
+  hipLaunchKernelGGL(attention_bwd_dq_bf16_kernel, grid, dim3(256), 0, st, qkv, out, dout, lse, dqkv, delta_ws, B, L, len, cu);
+  hipLaunchKernelGGL(attention_bwd_dkv_bf16_kernel, grid, dim3(256), 0, st, qkv, dout, lse, delta_ws, dqkv, B, L, len, cu);
   return launch_status();
 }

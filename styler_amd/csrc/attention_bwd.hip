@@ -36,16 +36,18 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
                                                                const float* __restrict__ dout,
                                                                const float* __restrict__ lse,
                                                                float* __restrict__ dqkv, float* __restrict__ delta,
-                                                               int B, int L, const int64_t* __restrict__ len) {
+                                                               int B, int L, const int64_t* __restrict__ len, const int* __restrict__ cu) {
   __shared__ __attribute__((aligned(16))) float sK[64 * ATT_LD];
   __shared__ __attribute__((aligned(16))) float sV[64 * ATT_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int head = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * 128 + wave * 32;
-  const int64_t rowbase = (int64_t)b * L;
+  const int64_t rowbase = cu ? (int64_t)cu[b] : (int64_t)b * L;     // packed rows (pack.hip): items back to back
   int klen = len ? (int)len[b] : L;
   if (klen > L) klen = L;
-  const int q = q0 + li, qc = q < L ? q : L - 1;
+  const int Lr = cu ? klen : L;                                      // rows this item owns in memory
+  if (Lr <= 0) return;
+  const int q = q0 + li, qc = q < Lr ? q : Lr - 1;
 
   float qf[32], dof[32];
   load_frag32(qkv + (rowbase + qc) * 768 + head * ATT_D + lh * 32, qf, 0.125f);
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
     dl += __shfl_xor(dl, 32, 64);
   }
   const float my_lse = lse[((int64_t)b * 4 + head) * L + qc];
-  if (q < L && lh == 0) delta[((int64_t)b * 4 + head) * L + q] = dl;
+  if (q < Lr && lh == 0) delta[((int64_t)b * 4 + head) * L + q] = dl;
 
   f32x16 dq0, dq1;
 #pragma unroll
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
       const int kr = idx >> 4, c4 = (idx & 15) * 4;
       const int key = k0 + kr;
       float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-      if (key < L) {
+      if (key < Lr) {
         const float* base = qkv + (rowbase + key) * 768 + head * ATT_D + c4;
         kv = *reinterpret_cast<const float4*>(base + 256);
         vv = *reinterpret_cast<const float4*>(base + 512);
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
       }
     }
   }
-  if (q < L) store_acc_T(dqkv + (rowbase + q) * 768 + head * ATT_D, dq0, dq1, lh, 0.125f);
+  if (q < Lr) store_acc_T(dqkv + (rowbase + q) * 768 + head * ATT_D, dq0, dq1, lh, 0.125f);
 }
 
 // ------------------------------------------------------------------------------------------------- dK, dV
@@ -127,17 +129,19 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
                                                                 const float* __restrict__ lse,
                                                                 const float* __restrict__ delta,
                                                                 float* __restrict__ dqkv, int B, int L,
-                                                                const int64_t* __restrict__ len) {
+                                                                const int64_t* __restrict__ len, const int* __restrict__ cu) {
   __shared__ __attribute__((aligned(16))) float sQ[64 * ATT_LD];
   __shared__ __attribute__((aligned(16))) float sDO[64 * ATT_LD];
   __shared__ float sLse[64], sDl[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int head = blockIdx.y, b = blockIdx.z;
   const int key0 = blockIdx.x * 128 + wave * 32;
-  const int64_t rowbase = (int64_t)b * L;
+  const int64_t rowbase = cu ? (int64_t)cu[b] : (int64_t)b * L;     // packed rows (pack.hip): items back to back
   int klen = len ? (int)len[b] : L;
   if (klen > L) klen = L;
-  const int key = key0 + li, keyc = key < L ? key : L - 1;
+  const int Lr = cu ? klen : L;                                      // rows this item owns in memory
+  if (Lr <= 0) return;
+  const int key = key0 + li, keyc = key < Lr ? key : Lr - 1;
   const bool key_ok = key < klen;
 
   float kf[32], vf[32];
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
 
   // whole block skips when all its keys are padding (their dK = dV = 0 is still written below)
   const bool block_live = blockIdx.x * 128 < klen;
-  const int ntiles = block_live ? (L + 63) / 64 : 0;
+  const int ntiles = block_live ? (Lr + 63) / 64 : 0;
   for (int qt = 0; qt < ntiles; ++qt) {
     const int qb = qt * 64;
     __syncthreads();
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
       const int qr = idx >> 4, c4 = (idx & 15) * 4;
       const int qq = qb + qr;
       float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), dv = qv;
-      if (qq < L) {
+      if (qq < Lr) {
         qv = *reinterpret_cast<const float4*>(qkv + (rowbase + qq) * 768 + head * ATT_D + c4);
         dv = *reinterpret_cast<const float4*>(dout + (rowbase + qq) * 256 + head * ATT_D + c4);
       }
@@ -169,13 +173,13 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
     }
     if (tid < 64) {
       const int qq = qb + tid;
-      sLse[tid] = qq < L ? lse[((int64_t)b * 4 + head) * L + qq] : 0.f;
-      sDl[tid] = qq < L ? delta[((int64_t)b * 4 + head) * L + qq] : 0.f;
+      sLse[tid] = qq < Lr ? lse[((int64_t)b * 4 + head) * L + qq] : 0.f;
+      sDl[tid] = qq < Lr ? delta[((int64_t)b * 4 + head) * L + qq] : 0.f;
     }
     __syncthreads();
 #pragma unroll
     for (int qk = 0; qk < 2; ++qk) {
-      if (qb + qk * 32 >= L) break;
+      if (qb + qk * 32 >= Lr) break;
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ql = qk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const bool ok = key_ok && (qb + ql < L);
+        const bool ok = key_ok && (qb + ql < Lr);
         const float p = ok ? expf(s[r] * 0.125f - sLse[ql]) : 0.f;
         s[r] = p;
         ds[r] = p * (dp[r] - sDl[ql]);
@@ -210,19 +214,20 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
       }
     }
   }
-  if (key < L) {
+  if (key < Lr) {
     store_acc_T(dqkv + (rowbase + key) * 768 + 256 + head * ATT_D, dk0, dk1, lh, 0.125f);
     store_acc_T(dqkv + (rowbase + key) * 768 + 512 + head * ATT_D, dv0, dv1, lh, 1.0f);
   }
 }
 
 extern "C" int styler_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
-                                    float* dqkv, float* delta_ws, int B, int L, const int64_t* len, void* stream) {
+                                    float* dqkv, float* delta_ws, int B, int L, const int64_t* len,
+                                    const int32_t* cu, void* stream) {
   if (!qkv || !out || !dout || !lse || !dqkv || !delta_ws || B <= 0 || L <= 0) return STYLER_EINVAL;
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 15)) return STYLER_EALIGN;
   dim3 grid((L + 127) / 128, 4, B);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(attention_bwd_dq_kernel, grid, dim3(256), 0, st, qkv, out, dout, lse, dqkv, delta_ws, B, L, len);
-  hipLaunchKernelGGL(attention_bwd_dkv_kernel, grid, dim3(256), 0, st, qkv, dout, lse, delta_ws, dqkv, B, L, len);
+  hipLaunchKernelGGL(attention_bwd_dq_kernel, grid, dim3(256), 0, st, qkv, out, dout, lse, dqkv, delta_ws, B, L, len, cu);
+  hipLaunchKernelGGL(attention_bwd_dkv_kernel, grid, dim3(256), 0, st, qkv, dout, lse, delta_ws, dqkv, B, L, len, cu);
   return launch_status();
 }

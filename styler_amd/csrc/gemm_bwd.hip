@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dz
                                                     float* __restrict__ db, float* __restrict__ db2, int64_t sn,
                                                     int64_t sc, int64_t sj, int B,
                                                     int L, int n, int cin, int pad_left, int ct, int chunks_per_split,
-                                                    float* __restrict__ ws) {
+                                                    float* __restrict__ ws, const int2* __restrict__ rowinfo,
+                                                    const int64_t* __restrict__ counts) {
   constexpr int XR = WG_BK + KW - 1;                 // x rows per chunk (with halo)
   __shared__ __attribute__((aligned(16))) float sA[2][WG_BK * WG_LD];
   __shared__ __attribute__((aligned(16))) float sB[2][XR * WG_LD];
@@ -83,11 +84,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dz
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
   const int tile = blockIdx.x;
   const int n0 = (tile / ct) * 64, c0 = (tile % ct) * 64;
-  const int64_t M = (int64_t)B * L;
+  // packed rows (pack.hip): the row count lives on the device (counts[0]); chunks are spread evenly over the launch's
+  // splits (an empty split still writes its zero partial tile); tap validity comes from rowinfo = (t, len - 1 - t)
+  const int64_t M = counts ? counts[0] : (int64_t)B * L;
   const int64_t nchunks = (M + WG_BK - 1) / WG_BK;
+  if (counts) chunks_per_split = (int)((nchunks + gridDim.y - 1) / gridDim.y);
   const int64_t ch0 = (int64_t)blockIdx.y * chunks_per_split;
   int64_t ch1 = ch0 + chunks_per_split; if (ch1 > nchunks) ch1 = nchunks;
-  if (ch0 >= ch1) return;
+  if (ch0 >= ch1 && !counts) return;
 
   // staging: a row is 64 floats = 16 float4; 256 threads cover 16 rows per pass
   const int sr = tid >> 4, sq = (tid & 15) * 4;
@@ -113,11 +117,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dz
       const int64_t m = mb + tid;
       uint32_t bits = 0;
       if (m < M) {
-        const int t = (int)(m % L);
+        int t, rem;
+        if (rowinfo) { const int2 ri = rowinfo[m]; t = ri.x; rem = ri.y; }
+        else { t = (int)(m % L); rem = L - 1 - t; }
 #pragma unroll
         for (int j = 0; j < KW; ++j) {
-          const int tt = t + j - pad_left;
-          if (tt >= 0 && tt < L) bits |= 1u << j;
+          const int o = j - pad_left;
+          if (o >= -t && o <= rem) bits |= 1u << j;
         }
       }
       rmask = bits;
@@ -141,8 +147,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dz
   float bsum = 0.f;                                  // bias partial (threads < 64 of c-tile 0)
   const bool do_bias = db && (tile % ct) == 0 && tid < 64;
 
-  load(ch0);
-  store(0);
+  if (ch0 < ch1) {
+    load(ch0);
+    store(0);
+  }
   __syncthreads();
   int buf = 0;
   for (int64_t ch = ch0; ch < ch1; ++ch) {
@@ -221,7 +229,8 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const float* __restrict__
                                                        float* __restrict__ db, float* __restrict__ db2, int B, int L,
                                                        int n, int cin, int pad_left, int ct, int cpi,
                                                        int chunks_per_split, int tiles, int splits,
-                                                       float* __restrict__ ws) {
+                                                       float* __restrict__ ws, const int4* __restrict__ chunktab,
+                                                       const int64_t* __restrict__ counts) {
   constexpr int FA = 64 * TA, FB = 64 * TB;          // features per block tile
   constexpr int XR = KW == 1 ? 64 : 72;              // x rows per chunk incl. halo (KW - 1 <= 8)
   constexpr int NR = (8 + KW - 1 + 3) / 4;           // transpose reads per x window
@@ -251,10 +260,18 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const float* __restrict__
     split = blockIdx.x / tiles;
   }
   const int n0 = (tile / ct) * FA, c0 = (tile % ct) * FB;
-  const int64_t nchunks = (int64_t)B * cpi;
+  // Packed rows (pack.hip): the number of rows / chunks lives on the device (`counts`); the chunks are spread evenly
+  // over the launch's splits, and a split that gets none still writes its (zero) partial tile for the reduction.
+  // kw > 1 enumerates the item-aligned chunks of `chunktab`; kw == 1 (no shifts) is one flat item of counts[0] rows.
+  int64_t nchunks = (int64_t)B * cpi;
+  if (counts) {
+    nchunks = chunktab ? counts[1] : (counts[0] + WB_BK - 1) / WB_BK;
+    chunks_per_split = (int)((nchunks + splits - 1) / splits);
+    if (!chunktab) L = (int)counts[0];
+  }
   const int64_t ch0 = (int64_t)split * chunks_per_split;
   int64_t ch1 = ch0 + chunks_per_split; if (ch1 > nchunks) ch1 = nchunks;
-  if (ch0 >= ch1) return;
+  if (ch0 >= ch1 && !counts) return;
 
   // ---- staging coordinates ----
   const int aq = (tid % VA) * 4, ar = tid / VA;      // feature / first row of this thread's float4s (dz)
@@ -274,13 +291,19 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const float* __restrict__
   const uint32_t a_pstep = (uint32_t)(RPA * lddz * 4), b_pstep = (uint32_t)(RPB * ldx * 4);
   float4 ra0[PA], rb0[PB];
   auto load = [&](float4 (&ra)[PA], float4 (&rb)[PB], int ch) {
-    const int b = ch / cpi;
-    const int t0 = (ch - b * cpi) * WB_BK;
-    const int64_t rowb = (int64_t)b * L;
+    int t0, Li;
+    int64_t rowb;                                    // first row of the chunk's item, the item's length
+    if (chunktab) {
+      const int4 e = chunktab[ch];
+      t0 = e.y; Li = e.z; rowb = e.x - e.y;
+    } else {
+      const int b = ch / cpi;
+      t0 = (ch - b * cpi) * WB_BK; Li = L; rowb = (int64_t)b * L;
+    }
     const int tx = t0 - pad_left;                    // first x row of the chunk (halo included); may be < 0
     const int txb = tx > 0 ? tx : 0;
-    int64_t a_rec = ((int64_t)(L - t0 - 1) * lddz + n) * 4;
-    int64_t b_rec = ((int64_t)(L - txb - 1) * ldx + cinp) * 4;
+    int64_t a_rec = ((int64_t)(Li - t0 - 1) * lddz + n) * 4;
+    int64_t b_rec = ((int64_t)(Li - txb - 1) * ldx + cinp) * 4;
     a_rec = a_rec > REC_MAX ? REC_MAX : a_rec;
     b_rec = b_rec > REC_MAX ? REC_MAX : (b_rec < 0 ? 0 : b_rec);
     const __amdgpu_buffer_rsrc_t ra_rsrc =
@@ -382,8 +405,10 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const float* __restrict__
   };
 
   const int ich0 = (int)ch0, ich1 = (int)ch1;
-  load(ra0, rb0, ich0);
-  store(ra0, rb0, 0);
+  if (ich0 < ich1) {
+    load(ra0, rb0, ich0);
+    store(ra0, rb0, 0);
+  }
   __syncthreads();
   int buf = 0;
   for (int ch = ich0; ch < ich1; ++ch) {
@@ -484,9 +509,10 @@ extern "C" int64_t styler_wgrad_workspace_bytes(int B, int L, int n, int cin, in
   return (int64_t)splits * n * kw * cin * 4;
 }
 
-extern "C" int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db,
-                            float* db2, int64_t stride_n, int64_t stride_c, int64_t stride_j, int B, int L, int n, int cin, int kw,
-                            int pad_left, int prec, void* workspace, int defer_reduce, void* stream) {
+static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db, float* db2,
+                      int64_t stride_n, int64_t stride_c, int64_t stride_j, int B, int L, int n, int cin, int kw,
+                      int pad_left, int prec, void* workspace, int defer_reduce, const int32_t* rowinfo,
+                      const int32_t* chunktab, const int64_t* counts, void* stream) {
   if (!dz || !x || !dw || !workspace || B <= 0 || L <= 0 || n <= 0 || cin <= 0 || (db2 && !db)) return STYLER_EINVAL;
   if (kw != 1 && kw != 3 && kw != 5 && kw != 9) return STYLER_EINVAL;
   if ((lddz & 3) || (ldx & 3) || (n & 3) || ldx < ((cin + 3) & ~3) || ((uintptr_t)dz & 15) || ((uintptr_t)x & 15)) return STYLER_EALIGN;
@@ -503,7 +529,8 @@ extern "C" int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64
     const int tiles = nt * ct;
     const dim3 grid1((unsigned)(tiles * (splits >= 8 ? (splits + 7) / 8 * 8 : splits)));
 #define WT_LAUNCH(K, A_, B_) hipLaunchKernelGGL((wgrad_tr_kernel<K, A_, B_>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, \
-                                                db2, Be, Le, n, cin, pad_left, ct, cpi, cps, tiles, splits, ws)
+                                                db2, Be, Le, n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, \
+                                                kw > 1 ? reinterpret_cast<const int4*>(chunktab) : nullptr, counts)
     if (kw == 1) {
       if (TA == 2 && TB == 2) WT_LAUNCH(1, 2, 2); else if (TA == 2) WT_LAUNCH(1, 2, 1);
       else if (TB == 2) WT_LAUNCH(1, 1, 2); else WT_LAUNCH(1, 1, 1);
@@ -517,7 +544,8 @@ extern "C" int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64
 #undef WT_LAUNCH
   } else {
 #define WG_LAUNCH(K) hipLaunchKernelGGL(wgrad_kernel<K>, grid, dim3(256), 0, st, dz, lddz, x, ldx, dw, db, db2, stride_n, \
-                                        stride_c, stride_j, B, L, n, cin, pad_left, ct, cps, ws)
+                                        stride_c, stride_j, B, L, n, cin, pad_left, ct, cps, ws, \
+                                        reinterpret_cast<const int2*>(rowinfo), counts)
     if (kw == 1) WG_LAUNCH(1); else if (kw == 3) WG_LAUNCH(3); else if (kw == 5) WG_LAUNCH(5); else WG_LAUNCH(9);
 #undef WG_LAUNCH
   }
@@ -527,6 +555,24 @@ extern "C" int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, ws, dw, stride_n, stride_c, stride_j, n,
                      cin, kw, splits);
   return launch_status();
+}
+
+extern "C" int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db,
+                            float* db2, int64_t stride_n, int64_t stride_c, int64_t stride_j, int B, int L, int n, int cin,
+                            int kw, int pad_left, int prec, void* workspace, int defer_reduce, void* stream) {
+  return wgrad_impl(dz, lddz, x, ldx, dw, db, db2, stride_n, stride_c, stride_j, B, L, n, cin, kw, pad_left, prec, workspace,
+                    defer_reduce, nullptr, nullptr, nullptr, stream);
+}
+
+// Packed-rows variant (pack.hip): dz / x hold `rows` rows of capacity, the first counts[0] of them valid, items back to
+// back.  Workspace / split count are those of styler_wgrad_workspace_bytes / styler_wgrad_splits for (B = 1, L = rows).
+extern "C" int styler_wgrad_packed(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db,
+                                   int64_t stride_n, int64_t stride_c, int64_t stride_j, int rows, int n, int cin, int kw,
+                                   int prec, void* workspace, int defer_reduce, const int32_t* rowinfo,
+                                   const int32_t* chunktab, const int64_t* counts, void* stream) {
+  if (!rowinfo || !chunktab || !counts) return STYLER_EINVAL;
+  return wgrad_impl(dz, lddz, x, ldx, dw, db, nullptr, stride_n, stride_c, stride_j, 1, rows, n, cin, kw, kw / 2, prec,
+                    workspace, defer_reduce, rowinfo, chunktab, counts, stream);
 }
 
 extern "C" int styler_wgrad_splits(int B, int L, int n, int cin, int kw, int pad_left, int prec) {

@@ -20,9 +20,9 @@
 // MFMA step with ds_read_b128.  LDS rows are padded to 36 dwords: 16 consecutive rows then hit 16
 // distinct 16-byte slots of the 64-bank row (conflict-free ds_read_b128), for any tap shift.
 //
-// Block -> tile map is XCD-aware: workgroup b runs on XCD b % 8 (observed dispatch rule, speed only), so
-// each XCD is handed a CONTIGUOUS range of tiles with the n index fastest: the n-tiles that share an
-// activation tile run on the same L2.
+// Block -> tile map is XCD-aware: workgroup b runs on XCD b % 8 (observed dispatch rule, speed only); m-tiles are
+// dealt round-robin to the XCDs with the n index fastest inside an XCD: the n-tiles that share an activation tile run
+// on the same L2.
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
@@ -38,6 +38,7 @@ struct GemmArgs {
   int B, L, cin, n, kw, act, pad;
   const int64_t* len;
   int mt, nt;                                      // tile counts
+  const int2* rowinfo;                             // packed rows (styler_pack_plan): (t, len - 1 - t) per row, or null
 };
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
@@ -78,14 +79,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
 
-  // ---- XCD-aware tile assignment (bijective for any tile count) ----
+  // ---- XCD-aware tile assignment: workgroup b runs on XCD b % 8 (observed dispatch rule, speed only).  M-tiles are
+  // dealt round-robin to the XCDs and an XCD walks the n-tiles of its m-tile back to back, so the n-tiles that share an
+  // activation tile run on the same L2 -- and the tiles that carry work are spread over all eight XCDs when only a
+  // prefix of the rows is valid (packed decoder rows, masked tails).  The grid is padded to 8 * ceil(mt / 8) m-tiles.
   int tile;
   {
-    const int total = a.mt * a.nt;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, k = bid >> 3;
-    const int q = total >> 3, r = total & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    const int mtile = (k / a.nt) * 8 + xcd;
+    if (mtile >= a.mt) return;
+    tile = mtile * a.nt + k % a.nt;
   }
   const int64_t M = (int64_t)a.B * a.L;
   const int64_t m0 = (int64_t)(tile / a.nt) * BM;
@@ -95,6 +99,21 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
   const int ktot = kw * a.cin;
   const int ncc = (a.cin + BK - 1) / BK;           // channel chunks
   const int nsteps = ncc * kw;
+
+  // ---- tiles made only of rows at or past their item's length produce zeros: write them and leave (in the packed
+  // decoder layout B = 1 and len[0] = the number of packed rows: every tile behind the data is skipped) ----
+  if (a.len) {
+    const int64_t m1 = (m0 + BM < M ? m0 + BM : M) - 1;
+    const int64_t b0 = m0 / a.L;
+    if (b0 == m1 / a.L && m0 - b0 * a.L >= a.len[b0]) {
+      constexpr int QPR = BN / 4;                    // float4 per tile row
+      for (int i = tid; i < BM * QPR; i += 256) {
+        const int r = i / QPR, c = n0 + (i - r * QPR) * 4;
+        if (m0 + r < M && c < a.n) *reinterpret_cast<float4*>(a.y + (m0 + r) * a.ldy + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      return;
+    }
+  }
 
   // ---- operand fetch = raw buffer loads: (uniform descriptor) + (32-bit lane offset) ----
   // The descriptor of a load starts at the tile's first row inside the tensor and ends with the tensor (num_records):
@@ -131,10 +150,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     const int64_t m = m0 + (wm * TM + i) * 32 + li;
     uint32_t bits = 0;
     if (!KW1 && m < M) {
-      const int t = (int)(m % a.L);
+      int t, rem;                                    // rows before / after this one inside its item
+      if (a.rowinfo) { const int2 ri = a.rowinfo[m]; t = ri.x; rem = ri.y; }
+      else { t = (int)(m % a.L); rem = a.L - 1 - t; }
       for (int j = 0; j < kw; ++j) {
-        const int tt = t + j - pad;
-        if (tt >= 0 && tt < a.L) bits |= 1u << j;
+        const int o = j - pad;
+        if (o >= -t && o <= rem) bits |= 1u << j;
       }
     }
     tapmask[i] = bits;
@@ -328,7 +349,7 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   const int64_t M = (int64_t)a.B * a.L;
   a.mt = (int)((M + 64 * TM - 1) / (64 * TM));
   a.nt = (a.n + 64 * TN - 1) / (64 * TN);
-  const dim3 grid((unsigned)(a.mt * a.nt));
+  const dim3 grid((unsigned)(((a.mt + 7) / 8) * 8 * a.nt));
   // occupancy-3 layout pays when a chunk spans >= 5 taps (one extra barrier per chunk): measured +12..15 % on the
   // k = 9 / k = 5 convs, -5 % on k = 3.  STYLER_GEMM_OCC3=0/1 overrides for experiments.
   static const int occ3_env = [] { const char* e = getenv("STYLER_GEMM_OCC3"); return e ? atoi(e) : -1; }();
@@ -358,15 +379,28 @@ extern "C" int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, in
 
 // Internal entry with an explicit left padding (pad = kw/2 is the 'same' conv of the model; pad = 0 with an
 // even kw is the framing conv of the STFT, stft.hip).
+int styler_conv_gemm_impl2(const float* x, int64_t ldx, const void* w, const float* scale, const float* shift,
+                           const float* res, int64_t ldres, float* y, int64_t ldy, int B, int L, int cin, int n,
+                           int kw, int pad, int act, int prec, const int64_t* len, const int32_t* rowinfo, void* stream);
+
 int styler_conv_gemm_impl(const float* x, int64_t ldx, const void* w, const float* scale, const float* shift,
                           const float* res, int64_t ldres, float* y, int64_t ldy, int B, int L, int cin, int n,
                           int kw, int pad, int act, int prec, const int64_t* len, void* stream) {
+  return styler_conv_gemm_impl2(x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, pad, act, prec, len,
+                                nullptr, stream);
+}
+
+int styler_conv_gemm_impl2(const float* x, int64_t ldx, const void* w, const float* scale, const float* shift,
+                           const float* res, int64_t ldres, float* y, int64_t ldy, int B, int L, int cin, int n,
+                           int kw, int pad, int act, int prec, const int64_t* len, const int32_t* rowinfo, void* stream) {
   if (!x || !w || !y || B <= 0 || L <= 0 || cin <= 0 || n <= 0 || kw <= 0 || kw > 9 || pad < 0 || pad >= kw)
     return STYLER_EINVAL;
   if ((cin & 3) || (ldx & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return STYLER_EALIGN;
   if ((n & 3) || (ldy & 3) || ((uintptr_t)y & 15) || (res && ((ldres & 3) || ((uintptr_t)res & 15)))) return STYLER_EALIGN;
   if (prec == STYLER_PREC_BF16 && (cin & 7)) return STYLER_EALIGN;
-  GemmArgs a{x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, act, pad, len, 0, 0};
+  if (rowinfo && B != 1) return STYLER_EINVAL;
+  GemmArgs a{x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, act, pad, len, 0, 0,
+             reinterpret_cast<const int2*>(rowinfo)};
   hipStream_t st = (hipStream_t)stream;
   const bool big = styler_conv_gemm_variant(B, L, cin, n, kw, prec) & 1;
   if (prec == STYLER_PREC_BF16) return big ? launch_gemm<2, 2, true>(a, st) : launch_gemm<1, 1, true>(a, st);
@@ -438,6 +472,17 @@ extern "C" int styler_repack_conv_weight(const float* src, void* dst, int n, int
     hipLaunchKernelGGL(repack_conv_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src,
                        reinterpret_cast<float*>(dst), n, cin, kw, to_kernel_layout);
   return launch_status();
+}
+
+// Packed-rows variant (the decoder runs on the valid frames only): B = 1, L = row capacity, rowinfo = the
+// (t, len - 1 - t) pairs of styler_pack_plan, len = its row counter (tiles behind the data are skipped).
+extern "C" int styler_conv_gemm_packed(const float* x, int64_t ldx, const void* w, const float* scale,
+                                       const float* shift, const float* res, int64_t ldres, float* y, int64_t ldy,
+                                       int rows, int cin, int n, int kw, int act, int prec, const int64_t* nrows,
+                                       const int32_t* rowinfo, void* stream) {
+  if (!(kw & 1) || !nrows || !rowinfo) return STYLER_EINVAL;
+  return styler_conv_gemm_impl2(x, ldx, w, scale, shift, res, ldres, y, ldy, 1, rows, cin, n, kw, kw / 2, act, prec,
+                                nrows, rowinfo, stream);
 }
 
 extern "C" int styler_abi_version(void) { return 1; }

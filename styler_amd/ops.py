@@ -105,14 +105,16 @@ class GemmProfiler:
     measurement).  Events are recorded on the launch stream; elapsed times are read after a sync."""
 
     def __init__(self):
-        self.records = []          # (variant, flops, start_event, end_event)
+        self.records = []          # (variant, flops, start_event, end_event, packed)
 
-    def summary(self):
+    def summary(self, packed_fraction=1.0):
+        """`packed_fraction` = valid rows / row capacity of the packed decoder tensors: launches on packed rows are
+        recorded with the capacity (the valid count lives on the device) and scaled here to ALGORITHMIC flops."""
         out = {}
-        for var, flops, e0, e1 in self.records:
+        for var, flops, e0, e1, packed in self.records:
             d = out.setdefault(var, {"launches": 0, "flops": 0.0, "ms": 0.0})
             d["launches"] += 1
-            d["flops"] += flops
+            d["flops"] += flops * (packed_fraction if packed else 1.0)
             d["ms"] += e0.elapsed_time(e1)
         return out
 
@@ -120,8 +122,45 @@ class GemmProfiler:
 gemm_profiler = None
 
 
+class PackPlan:
+    """Index tables of the packed-rows layout (styler_pack_plan): the valid rows of all items back to back in a
+    [1, B*T, C] tensor.  `nrows` (int64 [1], device) is the `lens` argument of the row-wise ops on packed tensors."""
+
+    def __init__(self, lens, B, T):
+        dev = lens.device
+        assert lens.dtype == torch.int64 and lens.is_contiguous() and lens.numel() == B
+        self.B, self.T, self.rows, self.lens = B, T, B * T, lens
+        self.cu = torch.empty(B + 1, device=dev, dtype=torch.int32)
+        self.rowinfo = torch.empty(B * T, 2, device=dev, dtype=torch.int32)
+        self.chunktab = torch.empty(B * T // 64 + B + 1, 4, device=dev, dtype=torch.int32)
+        self.counts = torch.empty(2, device=dev, dtype=torch.int64)
+        _chk(lib.styler_pack_plan(lens.data_ptr(), B, T, self.cu.data_ptr(), self.rowinfo.data_ptr(),
+                                  self.chunktab.data_ptr(), self.counts.data_ptr(), _stream()), "styler_pack_plan")
+        self.nrows = self.counts[0:1]
+
+
+def pack_rows(x, plan, add=None):
+    """[B, T, C] padded -> [1, B*T, C] packed (+ add[t] per row, the positional table)."""
+    B, T, C = x.shape
+    assert (B, T) == (plan.B, plan.T) and (add is None or (add.shape[0] >= T and add.shape[1] == C and add.is_contiguous()))
+    out = torch.empty(1, B * T, C, device=x.device, dtype=torch.float32)
+    _chk(lib.styler_pack_rows(x.data_ptr(), _ld(x), out.data_ptr(), C, _ptr(add), plan.cu.data_ptr(), B, T, C, _stream()),
+         "styler_pack_rows")
+    return out
+
+
+def unpack_rows(xp, plan):
+    """[1, B*T, C] packed -> [B, T, C] padded with zeros at t >= len[b]."""
+    C = xp.shape[-1]
+    xp = _rows_view(xp)
+    out = torch.empty(plan.B, plan.T, C, device=xp.device, dtype=torch.float32)
+    _chk(lib.styler_unpack_rows(xp.data_ptr(), _ld(xp), out.data_ptr(), C, plan.cu.data_ptr(), plan.B, plan.T, C,
+                                _stream()), "styler_unpack_rows")
+    return out
+
+
 def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, scale=None, res=None,
-              out=None, lens=None):
+              out=None, lens=None, plan=None):
     """y = act(scale * conv1d_same(x, w) + bias) (+ res); x [B, L, cin] -> y [B, L, n].
     `w` is the kernel-layout weight [n, kw*cin] (fp32, or bf16 when prec == PREC_BF16)."""
     _f32(x)
@@ -135,13 +174,20 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _chk(lib.styler_conv_gemm(x.data_ptr(), _ld(x), w.data_ptr(), _ptr(scale), _ptr(bias), _ptr(res),
-                              _ld(res) if res is not None else 0, out.data_ptr(), _ld(out), B, L, cin, n,
-                              kw, act, prec, _ptr(lens), _stream()), "styler_conv_gemm")
+    if plan is not None:                             # packed rows: taps stay inside their item, tiles behind the data skip
+        assert B == 1 and L == plan.rows
+        _chk(lib.styler_conv_gemm_packed(x.data_ptr(), _ld(x), w.data_ptr(), _ptr(scale), _ptr(bias), _ptr(res),
+                                         _ld(res) if res is not None else 0, out.data_ptr(), _ld(out), L, cin, n, kw,
+                                         act, prec, plan.counts.data_ptr(), plan.rowinfo.data_ptr(), _stream()),
+             "styler_conv_gemm_packed")
+    else:
+        _chk(lib.styler_conv_gemm(x.data_ptr(), _ld(x), w.data_ptr(), _ptr(scale), _ptr(bias), _ptr(res),
+                                  _ld(res) if res is not None else 0, out.data_ptr(), _ld(out), B, L, cin, n,
+                                  kw, act, prec, _ptr(lens), _stream()), "styler_conv_gemm")
     if prof is not None:
         e1.record()
         prof.records.append((lib.styler_conv_gemm_variant(B, L, cin, n, kw, prec), 2.0 * B * L * n * kw * cin,
-                             e0, e1))
+                             e0, e1, plan is not None))
     return out
 
 
@@ -174,12 +220,17 @@ def _prec(prec):
     return prec
 
 
-def attention_fwd(qkv, lens, lse=None, prec=None):
-    B, L, _ = qkv.shape
+def attention_fwd(qkv, lens, lse=None, prec=None, plan=None):
+    """qkv [B, L, 768] (or, with `plan`, the packed [1, B*T, 768]); lse (optional) [B, 4, L] (packed: [B, 4, T])."""
     assert qkv.is_contiguous() and qkv.shape[2] == 768
-    out = torch.empty(B, L, 256, device=qkv.device, dtype=torch.float32)
+    out = torch.empty(qkv.shape[0], qkv.shape[1], 256, device=qkv.device, dtype=torch.float32)
     fn = lib.styler_attention_fwd_bf16 if _prec(prec) == PREC_BF16 else lib.styler_attention_fwd
-    _chk(fn(qkv.data_ptr(), out.data_ptr(), _ptr(lse), B, L, _ptr(lens), _stream()), "styler_attention_fwd")
+    if plan is not None:
+        _chk(fn(qkv.data_ptr(), out.data_ptr(), _ptr(lse), plan.B, plan.T, plan.lens.data_ptr(), plan.cu.data_ptr(),
+                _stream()), "styler_attention_fwd")
+    else:
+        B, L, _ = qkv.shape
+        _chk(fn(qkv.data_ptr(), out.data_ptr(), _ptr(lse), B, L, _ptr(lens), None, _stream()), "styler_attention_fwd")
     return out
 
 
@@ -432,7 +483,7 @@ def act_bwd(dy, y, act, lens=None):
     return dz
 
 
-def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=None, db2=None):
+def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=None, db2=None, plan=None):
     """dw (fp32, parameter layout [n, cin] or [n, cin, kw]) += dz^T x over all taps; db (and db2) += colsum(dz)."""
     B, L = dz.shape[0], dz.shape[1]
     if strides is None:
@@ -457,11 +508,19 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
                                 int(lib.styler_wgrad_splits(B, L, n, cin, kw, pad_left, prec))))
     if ws is None:
         ws = torch.empty(nfloats, device=dz.device, dtype=torch.float32)
-    _chk(lib.styler_wgrad(dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), dw.data_ptr(), _ptr(db), _ptr(db2), strides[0], strides[1],
-                          strides[2], B, L, n, cin, kw, pad_left, prec, ws.data_ptr(), defer, _stream()), "styler_wgrad")
+    if plan is not None:
+        assert B == 1 and L == plan.rows and db2 is None and pad_left == kw // 2
+        _chk(lib.styler_wgrad_packed(dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), dw.data_ptr(), _ptr(db), strides[0],
+                                     strides[1], strides[2], L, n, cin, kw, prec, ws.data_ptr(), defer,
+                                     plan.rowinfo.data_ptr(), plan.chunktab.data_ptr(), plan.counts.data_ptr(),
+                                     _stream()), "styler_wgrad_packed")
+    else:
+        _chk(lib.styler_wgrad(dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), dw.data_ptr(), _ptr(db), _ptr(db2), strides[0], strides[1],
+                              strides[2], B, L, n, cin, kw, pad_left, prec, ws.data_ptr(), defer, _stream()), "styler_wgrad")
     if prof is not None:
         e1.record()
-        prof.records.append(("wgrad_bf16" if prec == PREC_BF16 else "wgrad", 2.0 * B * L * n * kw * cin, e0, e1))
+        prof.records.append(("wgrad_bf16" if prec == PREC_BF16 else "wgrad", 2.0 * B * L * n * kw * cin, e0, e1,
+                             plan is not None))
 
 
 def colsum(dz, out, out2=None):
@@ -482,14 +541,18 @@ def repack_weight_bwd(w, bf16=False):
     return dst
 
 
-def attention_bwd(qkv, out, dout, lse, lens, prec=None):
-    B, L, _ = qkv.shape
+def attention_bwd(qkv, out, dout, lse, lens, prec=None, plan=None):
+    B, L = (plan.B, plan.T) if plan is not None else (qkv.shape[0], qkv.shape[1])
     dout = dout.contiguous()
     dqkv = torch.empty_like(qkv)
     ws = torch.empty(B * 4 * L, device=qkv.device, dtype=torch.float32)
     fn = lib.styler_attention_bwd_bf16 if _prec(prec) == PREC_BF16 else lib.styler_attention_bwd
+    if plan is not None:
+        lens, cu = plan.lens, plan.cu.data_ptr()
+    else:
+        cu = None
     _chk(fn(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), ws.data_ptr(), B, L,
-            _ptr(lens), _stream()), "styler_attention_bwd")
+            _ptr(lens), cu, _stream()), "styler_attention_bwd")
     return dqkv
 
 

@@ -13,6 +13,8 @@ class _Runtime:
         self.disable_dropout = False    # parity tests: train-mode BatchNorm / tape, dropout off (RNG streams
                                         # of the reference cannot be reproduced)
 
+    pack_decoder = True        # run the decoder's FFT blocks on the valid frames only (packed rows, pack.hip)
+
     def set_precision(self, name):
         self.prec = {"fp32": ops.PREC_F32, "bf16": ops.PREC_BF16}[name]
 

@@ -32,16 +32,16 @@ class _HipModule(nn.Module):
         object.__setattr__(self, "_derived", Derived())
 
     def _gemm(self, key, x, lin, *, kw=1, act=ops.ACT_NONE, res=None, out=None, lens=None, scale=None,
-              shift=None, neg_dx=False):
+              shift=None, neg_dx=False, plan=None):
         """conv_gemm with the weight of an nn.Linear / nn.Conv1d parameter holder.  Under autograd the call
         goes through ConvGemmFn (HIP backward: dX conv, wgrad, bias column sums)."""
         if (self.training and torch.is_grad_enabled()) and (lin.weight.requires_grad or x.requires_grad):
             assert out is None and scale is None and shift is None and lens is None
-            return AG.ConvGemmFn.apply(x, res, lin.weight, lin.bias, self._derived, key, kw, act, neg_dx)
+            return AG.ConvGemmFn.apply(x, res, lin.weight, lin.bias, self._derived, key, kw, act, neg_dx, plan)
         w, prec = gemm_weight(self._derived, key, lin.weight, x.shape[-1])
         bias = lin.bias if shift is None else shift
         return ops.conv_gemm(x, w, bias, kw=kw, n=lin.weight.shape[0], act=act, prec=prec, scale=scale, res=res,
-                             out=out, lens=lens)
+                             out=out, lens=lens, plan=plan)
 
     def _ln(self, x, res, ln, lens, out=None):
         """LayerNorm(x + res) + pad mask, tape-aware."""
@@ -76,20 +76,21 @@ class MultiHeadAttention(_HipModule):
         w = d.get("qkv_w", srcs_w, lambda *t: torch.cat([u.detach() for u in t]))
         return w, b, ops.PREC_F32
 
-    def forward(self, x, lens, out=None):
+    def forward(self, x, lens, out=None, plan=None):
         """x [B, L, 256]; lens int64 [B]; returns LayerNorm(dropout(fc(attn)) + x) with padded rows zeroed
-        (the masked_fill of Layers.py:29 is fused into the LayerNorm kernel)."""
+        (the masked_fill of Layers.py:29 is fused into the LayerNorm kernel).  With `plan` (ops.PackPlan) x is the
+        packed [1, B*T, 256] tensor and lens = plan.nrows."""
         grad = (self.training and torch.is_grad_enabled())
         drop = self.training and self.dropout.p > 0
         if grad:
-            ctx = AG.QkvAttentionFn.apply(x, self.w_qs.weight, self, lens)
+            ctx = AG.QkvAttentionFn.apply(x, self.w_qs.weight, self, lens, plan)
         else:
             w, b, prec = self._qkv()
-            ctx = ops.attention_fwd(ops.conv_gemm(x, w, b, n=768, prec=prec), lens)
+            ctx = ops.attention_fwd(ops.conv_gemm(x, w, b, n=768, prec=prec, plan=plan), lens, plan=plan)
         if grad or drop:
-            o = AG.dropout(self._gemm("fc", ctx, self.fc), self.dropout.p, self.training)
+            o = AG.dropout(self._gemm("fc", ctx, self.fc, plan=plan), self.dropout.p, self.training)
             return self._ln(o, x, self.layer_norm, lens, out)
-        o = self._gemm("fc", ctx, self.fc, res=x)            # eval: residual rides in the GEMM epilogue
+        o = self._gemm("fc", ctx, self.fc, res=x, plan=plan)  # eval: residual rides in the GEMM epilogue
         return ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out)
 
 
@@ -104,13 +105,13 @@ class PositionwiseFeedForward(_HipModule):
         self.layer_norm = nn.LayerNorm(d_in)
         self.dropout = nn.Dropout(dropout)
 
-    def forward(self, x, lens, out=None):
+    def forward(self, x, lens, out=None, plan=None):
         k = hp.fft_conv1d_kernel_size
-        h = self._gemm("w_1", x, self.w_1, kw=k[0], act=ops.ACT_RELU)
+        h = self._gemm("w_1", x, self.w_1, kw=k[0], act=ops.ACT_RELU, plan=plan)
         if (self.training and torch.is_grad_enabled()) or (self.training and self.dropout.p > 0):
-            o = AG.dropout(self._gemm("w_2", h, self.w_2, kw=k[1]), self.dropout.p, self.training)
+            o = AG.dropout(self._gemm("w_2", h, self.w_2, kw=k[1], plan=plan), self.dropout.p, self.training)
             return self._ln(o, x, self.layer_norm, lens, out)
-        o = self._gemm("w_2", h, self.w_2, kw=k[1], res=x)
+        o = self._gemm("w_2", h, self.w_2, kw=k[1], res=x, plan=plan)
         return ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out)
 
 
@@ -122,8 +123,8 @@ class FFTBlock(nn.Module):
         self.slf_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout)
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, dropout=dropout)
 
-    def forward(self, x, lens, out=None):
-        return self.pos_ffn(self.slf_attn(x, lens), lens, out=out)
+    def forward(self, x, lens, out=None, plan=None):
+        return self.pos_ffn(self.slf_attn(x, lens, plan=plan), lens, out=out, plan=plan)
 
 
 class _PositionMixin:
@@ -181,7 +182,17 @@ class Decoder(nn.Module, _PositionMixin):
 
     def forward(self, enc_seq, lens):
         pe = self._pe(enc_seq.shape[1], enc_seq.device)
-        x = AG.AddPosFn.apply(enc_seq, pe) if ((self.training and torch.is_grad_enabled()) and enc_seq.requires_grad) else ops.add_pos(enc_seq, pe)
+        tape = (self.training and torch.is_grad_enabled()) and enc_seq.requires_grad
+        if rt.pack_decoder and enc_seq.shape[0] <= 4096:
+            # Every block zeroes its padded rows (Layers.py:29,32) and masks padded keys: the four blocks run on the valid
+            # frames only, stored back to back (ops.PackPlan / csrc/pack.hip), and the result is padded again with zeros.
+            B, T, _ = enc_seq.shape
+            plan = ops.PackPlan(lens, B, T)
+            x = AG.PackRowsFn.apply(enc_seq, pe, plan) if tape else ops.pack_rows(enc_seq, plan, add=pe)
+            for layer in self.layer_stack:
+                x = layer(x, plan.nrows, plan=plan)
+            return AG.UnpackRowsFn.apply(x, plan) if tape else ops.unpack_rows(x, plan)
+        x = AG.AddPosFn.apply(enc_seq, pe) if tape else ops.add_pos(enc_seq, pe)
         for layer in self.layer_stack:
             x = layer(x, lens)
         return x

@@ -535,3 +535,47 @@ def test_c4_long_form_shape(dev, model, O, ref_state_dict):
     dur = torch.clamp(torch.round(torch.exp(fr[2].cpu()) - 1.0), min=0)
     assert torch.equal(fr[7].cpu(), dur.double().trunc().long().sum(1)) and int(fr[7].max()) > 1000
     assert fr[0][0].shape[1] == int(fr[7].max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_packed_decoder_matches_padded(dev, ref_state_dict, prec):
+    """The decoder on packed rows (valid frames only, csrc/pack.hip) must reproduce the padded-rectangle decoder: same
+    mel / postnet outputs in eval mode and the same gradients in train mode (dropout off), ragged batch incl. an item of
+    length 1 and one that fills the rectangle."""
+    from closed_form import make_batch
+    from styler_amd import STYLER, rt
+    from styler_amd.training import train_losses
+    b = make_batch(5, 8, 30, 1, 9, seed=77)
+    bd = {k: v.to(dev) for k, v in b.items()}
+    S, T = bd["text"].shape[1], bd["mel_target"].shape[1]
+    m = STYLER()
+    m.load_state_dict(ref_state_dict)
+    m = m.to(dev)
+    rt.set_precision(prec)
+    rt.disable_dropout = True
+    tol = 2e-5 if prec == "fp32" else 2e-2
+    try:
+        outs, grads = [], []
+        for packed in (False, True):
+            rt.pack_decoder = packed
+            m.eval()
+            with torch.no_grad():
+                o = m(bd["text"], bd["mel_target"], bd["mel_aug"], bd["f0_norm"], bd["energy_input"], bd["src_len"],
+                      bd["mel_len"], bd["D"], bd["f0"], bd["energy"], S, T, speaker_embed=bd["speaker_embed"])
+            outs.append([o[0][0], o[0][1], o[1][0], o[1][1]])
+            m.train()
+            m.zero_grad(set_to_none=True)
+            train_losses(m, bd)[0].backward()
+            grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        for a, c in zip(*outs):
+            e = float((a - c).abs().max()) / max(float(a.abs().max()), 1e-6)
+            assert e <= tol, f"eval outputs differ: {e:.3e}"
+        assert grads[0].keys() == grads[1].keys()
+        for k in grads[0]:
+            e = float((grads[0][k] - grads[1][k]).abs().max()) / max(float(grads[0][k].abs().max()), 1e-4)
+            assert e <= (1e-4 if prec == "fp32" else 5e-2), f"{k}: {e:.3e}"
+    finally:
+        rt.pack_decoder = True
+        rt.disable_dropout = False
+        rt.set_precision("fp32")
