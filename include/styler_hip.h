@@ -123,11 +123,16 @@ int styler_attention_bwd_bf16(const float* qkv, const float* out, const float* d
  * If dot_w != NULL the kernel instead writes the scalar out[b,t] = <y, dot_w> + dot_b[0]
  * (masked) -- the StylePredictor's LayerNorm -> dropout -> Linear(256,1) -> masked_fill
  * tail, modules.py:449-465 -- and y may be NULL; drop_p > 0 applies the train-mode dropout of
- * that tail with the counter-based stream of styler_dropout (seed drop_seed). */
+ * that tail with the counter-based stream of styler_dropout (seed drop_seed).
+ * in_drop_p > 0 (train mode) applies dropout to x BEFORE the residual add -- the nn.Dropout of
+ * SubLayers.py:58,86 -- with the stream styler_dropout(x [B*L, 256], seed in_drop_seed) would draw;
+ * sum_out (optional) receives the pre-norm sum dropout(x) + res that styler_layernorm_bwd consumes
+ * (defined on unmasked rows only). */
 int styler_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldres,
                          const float* gamma, const float* beta, float* y, int64_t ldy,
                          const float* dot_w, const float* dot_b, float* dot_out, int B, int L,
-                         int C, const int64_t* len, float drop_p, uint64_t drop_seed, void* stream);
+                         int C, const int64_t* len, float drop_p, uint64_t drop_seed, float in_drop_p,
+                         uint64_t in_drop_seed, float* sum_out, int64_t ldsum, void* stream);
 
 /* y = relu(GroupNorm(x)) with groups of 16 channels and statistics over 16 ch x the whole
  * padded L (modules.py:103-113,171-175; eps 1e-5).  In place allowed (y == x).
@@ -335,12 +340,15 @@ int styler_attention_bwd(const float* qkv, const float* out, const float* dout, 
                          const int32_t* cu, void* stream);
 
 /* LayerNorm(256) backward from the saved INPUT x (= pre-norm sum).  dx may be NULL.  With
- * dot_w (predictor tail) the incoming gradient is dout [B,L] and ddot_w/ddot_b accumulate. */
+ * dot_w (predictor tail) the incoming gradient is dout [B,L] and ddot_w/ddot_b accumulate.
+ * dx_drop (optional) = dx * the dropout mask of the forward's in_drop (the gradient of the branch that
+ * went through dropout; dx itself is the gradient of the residual). */
 int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy,
                          const float* gamma, const float* beta, float* dx, int64_t lddx,
                          float* dgamma, float* dbeta, const float* dot_w, const float* dout,
                          float* ddot_w, float* ddot_b, int B, int L, int C, const int64_t* len,
-                         float drop_p, uint64_t drop_seed, void* stream);
+                         float drop_p, uint64_t drop_seed, float in_drop_p, uint64_t in_drop_seed,
+                         float* dx_drop, int64_t lddxd, void* stream);
 
 /* stats = the forward's [B][C/16][2] (mean, rstd); workspace 2*B*C/16 doubles (scratch). */
 int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy,

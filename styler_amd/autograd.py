@@ -108,22 +108,32 @@ class LayerNormFn(Function):
     """LayerNorm(x + res) with pad mask (SubLayers.py:59,87 + Layers.py:29,32)."""
 
     @staticmethod
-    def forward(ctx, x, res, anchor, ln, lens):
-        if res is not None:
-            s = ops.add2(x, res)
+    def forward(ctx, x, res, anchor, ln, lens, drop_p=0.0):
+        """LayerNorm(dropout(x, drop_p) + res): the dropout, the residual add, the normalisation and the pad mask are
+        one kernel, which also writes the pre-norm sum the backward needs."""
+        drop_p = 0.0 if rt.disable_dropout else drop_p
+        seed = next_dropout_seed() if drop_p > 0 else 0
+        if res is not None or drop_p > 0:
+            s = torch.empty_like(x)
+            y = ops.add_layernorm(x, ln.weight, ln.bias, res=res, lens=lens, in_drop_p=drop_p, in_drop_seed=seed,
+                                  sum_out=s)
         else:
             s = x
-        y = ops.add_layernorm(s, ln.weight, ln.bias, lens=lens)
+            y = ops.add_layernorm(s, ln.weight, ln.bias, lens=lens)
         ctx.save_for_backward(s, lens)
-        ctx.ln, ctx.has_res = ln, res is not None
+        ctx.ln, ctx.has_res, ctx.drop = ln, res is not None, (drop_p, seed)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         s, lens = ctx.saved_tensors
         ln = ctx.ln
+        if ctx.drop[0] > 0:
+            dx, dxd = ops.layernorm_bwd(s, dy, ln.weight, ln.bias, G(ln.weight), G(ln.bias), lens=lens,
+                                        in_drop_p=ctx.drop[0], in_drop_seed=ctx.drop[1])
+            return dxd, (dx if ctx.has_res else None), None, None, None, None
         dx = ops.layernorm_bwd(s, dy, ln.weight, ln.bias, G(ln.weight), G(ln.bias), lens=lens)
-        return dx, (dx if ctx.has_res else None), None, None, None
+        return dx, (dx if ctx.has_res else None), None, None, None, None
 
 
 class LayerNormDotFn(Function):

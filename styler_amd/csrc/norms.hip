@@ -8,7 +8,8 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ res, int64_t ldres,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, int64_t ldy,
     const float* __restrict__ dot_w, const float* __restrict__ dot_b, float* __restrict__ dot_out, int64_t rows,
-    int L, const int64_t* __restrict__ len, float drop_p, uint64_t drop_seed_host, const uint64_t* __restrict__ epoch) {
+    int L, const int64_t* __restrict__ len, float drop_p, uint64_t drop_seed_host, const uint64_t* __restrict__ epoch,
+    float in_drop_p, uint64_t in_drop_seed_host, float* __restrict__ sum_out, int64_t ldsum) {
   const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -21,13 +22,24 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
   if (masked) {
     if (y) *reinterpret_cast<float4*>(y + row * ldy + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     if (dot_out && lane == 0) dot_out[row] = 0.f;
-    return;
+    return;                                              // (sum_out is only read back on unmasked rows)
   }
   float4 v = *reinterpret_cast<const float4*>(x + row * ldx + lane * 4);
+  if (in_drop_p > 0.f) {                                 // dropout(x) before the residual (SubLayers.py:58,86), same
+    const uint64_t sd = mix_drop_epoch(in_drop_seed_host, epoch);        // stream as styler_dropout on [rows, 256]
+    const uint32_t thr = (uint32_t)((double)in_drop_p * 4294967296.0);
+    const float sc = 1.f / (1.f - in_drop_p);
+    const uint64_t e = (uint64_t)row * 256 + lane * 4;
+    v.x = dropout_hash32(sd, e) >= thr ? v.x * sc : 0.f;
+    v.y = dropout_hash32(sd, e + 1) >= thr ? v.y * sc : 0.f;
+    v.z = dropout_hash32(sd, e + 2) >= thr ? v.z * sc : 0.f;
+    v.w = dropout_hash32(sd, e + 3) >= thr ? v.w * sc : 0.f;
+  }
   if (res) {
     const float4 r = *reinterpret_cast<const float4*>(res + row * ldres + lane * 4);
     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
   }
+  if (sum_out) *reinterpret_cast<float4*>(sum_out + row * ldsum + lane * 4) = v;     // the pre-norm sum, for the backward
   const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
   const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
   const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.f / 256.f);
@@ -56,15 +68,17 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
 extern "C" int styler_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldres,
                                     const float* gamma, const float* beta, float* y, int64_t ldy,
                                     const float* dot_w, const float* dot_b, float* dot_out, int B, int L, int C,
-                                    const int64_t* len, float drop_p, uint64_t drop_seed, void* stream) {
+                                    const int64_t* len, float drop_p, uint64_t drop_seed, float in_drop_p,
+                                    uint64_t in_drop_seed, float* sum_out, int64_t ldsum, void* stream) {
   if (!x || !gamma || !beta || (!y && !dot_out) || B <= 0 || L <= 0) return STYLER_EINVAL;
   if (C != 256) return STYLER_EINVAL;
   if (dot_out && (!dot_w || !dot_b)) return STYLER_EINVAL;
-  if ((ldx & 3) || (res && (ldres & 3)) || (y && (ldy & 3))) return STYLER_EALIGN;
+  if ((ldx & 3) || (res && (ldres & 3)) || (y && (ldy & 3)) || (sum_out && (ldsum & 3))) return STYLER_EALIGN;
+  if (in_drop_p < 0.f || in_drop_p >= 1.f) return STYLER_EINVAL;
   const int64_t rows = (int64_t)B * L;
   hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
                      ldx, res, ldres, gamma, beta, y, ldy, dot_w, dot_b, dot_out, rows, L, len, drop_p, drop_seed,
-                     g_styler_drop_epoch);
+                     g_styler_drop_epoch, in_drop_p, in_drop_seed, sum_out, ldsum);
   return launch_status();
 }
 

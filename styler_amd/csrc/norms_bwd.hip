@@ -12,7 +12,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dx, int64_t lddx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ dot_w,
     const float* __restrict__ dout, float* __restrict__ ddot_w, float* __restrict__ ddot_b, int64_t rows, int L,
-    const int64_t* __restrict__ len, float drop_p, uint64_t drop_seed_host, const uint64_t* __restrict__ epoch) {
+    const int64_t* __restrict__ len, float drop_p, uint64_t drop_seed_host, const uint64_t* __restrict__ epoch,
+    float in_drop_p, uint64_t in_drop_seed_host, float* __restrict__ dx_drop, int64_t lddxd) {
   const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   const int lane = threadIdx.x & 63;
   const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -27,6 +28,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     if (len) { const int64_t b = row / L; masked = (row - b * L) >= len[b]; }
     if (masked) {
       if (dx) *reinterpret_cast<float4*>(dx + row * lddx + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (dx_drop) *reinterpret_cast<float4*>(dx_drop + row * lddxd + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
       continue;
     }
     const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + lane * 4);
@@ -58,10 +60,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float ex = d.x * g.x, ey = d.y * g.y, ez = d.z * g.z, ew = d.w * g.w;
     const float m1 = wave_sum(ex + ey + ez + ew) * (1.f / 256.f);
     const float m2 = wave_sum(ex * hx + ey * hy + ez * hz + ew * hw) * (1.f / 256.f);
-    if (dx)
-      *reinterpret_cast<float4*>(dx + row * lddx + lane * 4) =
-          make_float4(rstd * (ex - m1 - hx * m2), rstd * (ey - m1 - hy * m2), rstd * (ez - m1 - hz * m2),
-                      rstd * (ew - m1 - hw * m2));
+    const float4 gx = make_float4(rstd * (ex - m1 - hx * m2), rstd * (ey - m1 - hy * m2), rstd * (ez - m1 - hz * m2),
+                                  rstd * (ew - m1 - hw * m2));
+    if (dx) *reinterpret_cast<float4*>(dx + row * lddx + lane * 4) = gx;
+    if (dx_drop) {                                       // gradient of the dropout(x) that fed the sum (same stream)
+      const uint64_t sd = mix_drop_epoch(in_drop_seed_host, epoch);
+      const uint32_t thr = (uint32_t)((double)in_drop_p * 4294967296.0);
+      const float sc = 1.f / (1.f - in_drop_p);
+      const uint64_t e = (uint64_t)row * 256 + lane * 4;
+      *reinterpret_cast<float4*>(dx_drop + row * lddxd + lane * 4) =
+          make_float4(dropout_hash32(sd, e) >= thr ? gx.x * sc : 0.f, dropout_hash32(sd, e + 1) >= thr ? gx.y * sc : 0.f,
+                      dropout_hash32(sd, e + 2) >= thr ? gx.z * sc : 0.f, dropout_hash32(sd, e + 3) >= thr ? gx.w * sc : 0.f);
+    }
   }
   // block-level reduction (4 waves) before the atomics: 256 + 256 (+ 256 + 1) atomics per block
   __shared__ float red[3][4][256];
@@ -85,7 +95,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
 extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* gamma,
                                     const float* beta, float* dx, int64_t lddx, float* dgamma, float* dbeta,
                                     const float* dot_w, const float* dout, float* ddot_w, float* ddot_b, int B, int L,
-                                    int C, const int64_t* len, float drop_p, uint64_t drop_seed, void* stream) {
+                                    int C, const int64_t* len, float drop_p, uint64_t drop_seed, float in_drop_p,
+                                    uint64_t in_drop_seed, float* dx_drop, int64_t lddxd, void* stream) {
   if (!x || !gamma || !dgamma || !dbeta || B <= 0 || L <= 0 || C != 256) return STYLER_EINVAL;
   if (!dot_w && !dy) return STYLER_EINVAL;
   if (dot_w && (!dout || !ddot_w || !ddot_b || !beta)) return STYLER_EINVAL;
@@ -96,7 +107,7 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy,
                      gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b, rows, L, len, drop_p, drop_seed,
-                     g_styler_drop_epoch);
+                     g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd);
   return launch_status();
 }
 

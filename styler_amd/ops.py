@@ -234,8 +234,10 @@ def attention_fwd(qkv, lens, lse=None, prec=None, plan=None):
     return out
 
 
-def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, dot_b=None, drop_p=0.0, drop_seed=0):
-    """LayerNorm(x + res) with pad-mask; with dot_w returns the [B, L] scalar head instead."""
+def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, dot_b=None, drop_p=0.0, drop_seed=0,
+                  in_drop_p=0.0, in_drop_seed=0, sum_out=None):
+    """LayerNorm(dropout(x) + res) with pad-mask; with dot_w returns the [B, L] scalar head instead.  `sum_out`
+    (optional) receives the pre-norm sum (what layernorm_bwd needs)."""
     B, L, C = x.shape
     dot_out = None
     if dot_w is not None:
@@ -245,7 +247,9 @@ def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, 
     _chk(lib.styler_add_layernorm(x.data_ptr(), _ld(x), _ptr(res), _ld(res) if res is not None else 0,
                                   gamma.data_ptr(), beta.data_ptr(), _ptr(out),
                                   _ld(out) if out is not None else 0, _ptr(dot_w), _ptr(dot_b),
-                                  _ptr(dot_out), B, L, C, _ptr(lens), float(drop_p), int(drop_seed), _stream()),
+                                  _ptr(dot_out), B, L, C, _ptr(lens), float(drop_p), int(drop_seed), float(in_drop_p),
+                                  int(in_drop_seed), _ptr(sum_out), _ld(sum_out) if sum_out is not None else 0,
+                                  _stream()),
          "styler_add_layernorm")
     return dot_out if dot_w is not None else out
 
@@ -557,9 +561,11 @@ def attention_bwd(qkv, out, dout, lse, lens, prec=None, plan=None):
 
 
 def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, dot_w=None, dout=None, ddot_w=None,
-                  ddot_b=None, drop_p=0.0, drop_seed=0):
+                  ddot_b=None, drop_p=0.0, drop_seed=0, in_drop_p=0.0, in_drop_seed=0):
+    """Returns dx, or (dx, dx_drop) when in_drop_p > 0 (dx_drop = dx through the forward's input-dropout mask)."""
     B, L, C = x.shape
     dx = torch.empty(B, L, C, device=x.device, dtype=torch.float32) if need_dx else None
+    dxd = torch.empty(B, L, C, device=x.device, dtype=torch.float32) if in_drop_p > 0 else None
     if dy is not None:
         dy = _rows_view(dy)
     if dout is not None:
@@ -567,8 +573,9 @@ def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, do
     _chk(lib.styler_layernorm_bwd(x.data_ptr(), _ld(x), _ptr(dy), _ld(dy) if dy is not None else 0, gamma.data_ptr(),
                                   _ptr(beta), _ptr(dx), C, dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dot_w),
                                   _ptr(dout), _ptr(ddot_w), _ptr(ddot_b), B, L, C, _ptr(lens), float(drop_p),
-                                  int(drop_seed), _stream()), "styler_layernorm_bwd")
-    return dx
+                                  int(drop_seed), float(in_drop_p), int(in_drop_seed), _ptr(dxd), C, _stream()),
+         "styler_layernorm_bwd")
+    return (dx, dxd) if dxd is not None else dx
 
 
 def groupnorm_relu_bwd(x, dy, gamma, beta, stats, dgamma, dbeta):

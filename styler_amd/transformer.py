@@ -43,10 +43,13 @@ class _HipModule(nn.Module):
         return ops.conv_gemm(x, w, bias, kw=kw, n=lin.weight.shape[0], act=act, prec=prec, scale=scale, res=res,
                              out=out, lens=lens, plan=plan)
 
-    def _ln(self, x, res, ln, lens, out=None):
-        """LayerNorm(x + res) + pad mask, tape-aware."""
+    def _ln(self, x, res, ln, lens, out=None, drop_p=0.0):
+        """LayerNorm(dropout(x) + res) + pad mask, tape-aware (drop_p only in train mode)."""
         if (self.training and torch.is_grad_enabled()) and (x.requires_grad or ln.weight.requires_grad):
-            return AG.LayerNormFn.apply(x, res, ln.weight, ln, lens)
+            return AG.LayerNormFn.apply(x, res, ln.weight, ln, lens, drop_p)
+        if drop_p > 0 and not rt.disable_dropout:
+            return ops.add_layernorm(x, ln.weight, ln.bias, res=res, lens=lens, out=out, in_drop_p=drop_p,
+                                     in_drop_seed=AG.next_dropout_seed())
         return ops.add_layernorm(x, ln.weight, ln.bias, res=res, lens=lens, out=out)
 
 
@@ -87,9 +90,9 @@ class MultiHeadAttention(_HipModule):
         else:
             w, b, prec = self._qkv()
             ctx = ops.attention_fwd(ops.conv_gemm(x, w, b, n=768, prec=prec, plan=plan), lens, plan=plan)
-        if grad or drop:
-            o = AG.dropout(self._gemm("fc", ctx, self.fc, plan=plan), self.dropout.p, self.training)
-            return self._ln(o, x, self.layer_norm, lens, out)
+        if grad or drop:                                      # dropout + residual + LayerNorm + mask: one kernel
+            return self._ln(self._gemm("fc", ctx, self.fc, plan=plan), x, self.layer_norm, lens, out,
+                            drop_p=self.dropout.p if self.training else 0.0)
         o = self._gemm("fc", ctx, self.fc, res=x, plan=plan)  # eval: residual rides in the GEMM epilogue
         return ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out)
 
@@ -109,8 +112,8 @@ class PositionwiseFeedForward(_HipModule):
         k = hp.fft_conv1d_kernel_size
         h = self._gemm("w_1", x, self.w_1, kw=k[0], act=ops.ACT_RELU, plan=plan)
         if (self.training and torch.is_grad_enabled()) or (self.training and self.dropout.p > 0):
-            o = AG.dropout(self._gemm("w_2", h, self.w_2, kw=k[1], plan=plan), self.dropout.p, self.training)
-            return self._ln(o, x, self.layer_norm, lens, out)
+            return self._ln(self._gemm("w_2", h, self.w_2, kw=k[1], plan=plan), x, self.layer_norm, lens, out,
+                            drop_p=self.dropout.p if self.training else 0.0)
         o = self._gemm("w_2", h, self.w_2, kw=k[1], res=x, plan=plan)
         return ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out)
 

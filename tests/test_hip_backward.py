@@ -486,3 +486,33 @@ def test_graphed_train_step_matches_eager(dev, ref_state_dict):
     lb = torch.stack([x.detach().float().reshape(()) for x in g(b)[0]]).cpu()
     assert torch.isfinite(la).all() and torch.isfinite(lb).all()
     assert float((la - lb).abs().max()) > 0, "two replays drew the same dropout masks"
+
+
+def test_fused_dropout_add_layernorm(dev):
+    """LayerNormFn with drop_p > 0 (dropout + residual + LayerNorm + mask in one kernel, mask regenerated in backward) vs
+    the unfused chain styler_dropout -> add -> LayerNorm with the SAME seed (the fused kernel draws the stream
+    styler_dropout would draw on the [rows, 256] tensor)."""
+    from styler_amd import autograd as AG, ops, rt
+    g = torch.Generator().manual_seed(5)
+    B, L, p = 3, 37, 0.2
+    lens = torch.tensor([37, 11, 30]).to(dev)
+    x = torch.randn(B, L, 256, generator=g).to(dev)
+    r = torch.randn(B, L, 256, generator=g).to(dev)
+    gy = torch.randn(B, L, 256, generator=g).to(dev)
+    ln = nn.LayerNorm(256).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(256, generator=g)); ln.bias.copy_(torch.randn(256, generator=g))
+    calls0 = rt.dropout_calls
+    xa, ra = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    ya = AG.LayerNormFn.apply(xa, ra, ln.weight, ln, lens, p)
+    ya.backward(gy)
+    ga, gb = ln.weight.grad.clone(), ln.bias.grad.clone()
+    seed = (rt.seed * 1000003 + calls0 + 1) & 0x7FFFFFFFFFFFFFFF          # what next_dropout_seed() handed out
+    ln.weight.grad = None; ln.bias.grad = None
+    xb, rb = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    yb = AG.LayerNormFn.apply(AG.DropoutFn.apply(xb, p, seed), rb, ln.weight, ln, lens, 0.0)
+    yb.backward(gy)
+    kept = float((ops.dropout(torch.ones_like(x), p, seed) > 0).float().mean())
+    assert 0.7 < kept < 0.9
+    check(ya, yb, 1e-6, "fwd"); check(xa.grad, xb.grad, 1e-6, "dx (through the mask)"); check(ra.grad, rb.grad, 1e-6, "dres")
+    check(ga, ln.weight.grad, 1e-5, "dgamma"); check(gb, ln.bias.grad, 1e-5, "dbeta")
