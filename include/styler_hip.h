@@ -307,6 +307,22 @@ int styler_wgrad_packed(const float* dz, int64_t lddz, const float* x, int64_t l
 /* Split count styler_wgrad uses for a shape (workspace = splits * n * kw * cin floats). */
 int styler_wgrad_splits(int B, int L, int n, int cin, int kw, int pad_left, int prec);
 
+/* Grouped launch of many small Linear weight gradients (bf16, kw = 1, 64x64 tile): the caller fills one
+ * descriptor per problem on the host with styler_wgrad_group_desc (same arguments as styler_wgrad; the
+ * return value is the member's block count, 0 = does not qualify, launch it with styler_wgrad), copies the
+ * array to the device and launches once.  Partial tiles land in each member's `workspace` exactly as
+ * styler_wgrad(defer_reduce = 1) leaves them: reduce with styler_wgrad_reduce_multi. */
+typedef struct {
+  uint64_t dz, x, db, db2, ws;         /* device pointers */
+  uint64_t counts;                     /* packed rows (styler_pack_plan counts) or 0 */
+  int64_t lddz, ldx;
+  int32_t B, L, n, cin, pad_left, ct, cpi, cps, tiles, splits, block_start, _pad;
+} StylerWgradGroupDesc;
+int styler_wgrad_group_desc(StylerWgradGroupDesc* out, const float* dz, int64_t lddz, const float* x,
+                            int64_t ldx, float* db, float* db2, int B, int L, int n, int cin, int pad_left,
+                            int prec, void* workspace, const int64_t* packed_counts, int block_start);
+int styler_wgrad_group(const StylerWgradGroupDesc* desc_dev, int count, int total_blocks, void* stream);
+
 /* Deferred reduction: with defer_reduce != 0 styler_wgrad leaves its partial tiles in `workspace`;
  * one styler_wgrad_reduce_multi launch then folds the partials of MANY gradients into their
  * parameter-layout buffers (dw[nn*stride_n + c*stride_c + j*stride_j] += sum_split ws[...]).

@@ -34,6 +34,8 @@ _SIGS = {
     "styler_lstm_bidir": [P, P, P, P, P, I, I, I, P],
     "styler_lstm_bidir_multi": [P, I, I, I, P],
     "styler_set_dropout_counter": [P],
+    "styler_wgrad_group_desc": [P, P, I64, P, I64, P, P, I, I, I, I, I, I, P, P, I],
+    "styler_wgrad_group": [P, I, I, P],
     "styler_pack_plan": [P, I, I, P, P, P, P, P],
     "styler_pack_rows": [P, I64, P, I64, P, P, I, I, I, P],
     "styler_unpack_rows": [P, I64, P, I64, P, I, I, I, P],
@@ -80,6 +82,14 @@ _SIGS = {
 class LstmDesc(ctypes.Structure):
     _fields_ = [("gx", P), ("w_hh", P), ("out", P), ("cell_out", P), ("gates_out", P), ("H", ctypes.c_int32),
                 ("_pad", ctypes.c_int32)]
+
+
+class WgradGroupDesc(ctypes.Structure):
+    _fields_ = [("dz", ctypes.c_uint64), ("x", ctypes.c_uint64), ("db", ctypes.c_uint64), ("db2", ctypes.c_uint64),
+                ("ws", ctypes.c_uint64), ("counts", ctypes.c_uint64), ("lddz", ctypes.c_int64),
+                ("ldx", ctypes.c_int64)] + \
+               [(k, ctypes.c_int32) for k in ("B", "L", "n", "cin", "pad_left", "ct", "cpi", "cps", "tiles", "splits",
+                                              "block_start", "_pad")]
 
 
 class LstmBwdDesc(ctypes.Structure):

@@ -224,13 +224,12 @@ __device__ __forceinline__ uint2 lds_tr_read(const uint16_t* p) {
 }
 
 template <int KW, int TA, int TB>
-__global__ __launch_bounds__(256) void wgrad_tr_kernel(const float* __restrict__ dz, int64_t lddz,
-                                                       const float* __restrict__ x, int64_t ldx,
-                                                       float* __restrict__ db, float* __restrict__ db2, int B, int L,
-                                                       int n, int cin, int pad_left, int ct, int cpi,
-                                                       int chunks_per_split, int tiles, int splits,
-                                                       float* __restrict__ ws, const int4* __restrict__ chunktab,
-                                                       const int64_t* __restrict__ counts) {
+__device__ __forceinline__ void wgrad_tr_body(const int bid, const float* __restrict__ dz, int64_t lddz,
+                                              const float* __restrict__ x, int64_t ldx, float* __restrict__ db,
+                                              float* __restrict__ db2, int B, int L, int n, int cin, int pad_left, int ct,
+                                              int cpi, int chunks_per_split, int tiles, int splits,
+                                              float* __restrict__ ws, const int4* __restrict__ chunktab,
+                                              const int64_t* __restrict__ counts) {
   constexpr int FA = 64 * TA, FB = 64 * TB;          // features per block tile
   constexpr int XR = KW == 1 ? 64 : 72;              // x rows per chunk incl. halo (KW - 1 <= 8)
   constexpr int NR = (8 + KW - 1 + 3) / 4;           // transpose reads per x window
@@ -251,13 +250,13 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const float* __restrict__
   // eight L2s: 40 % hit rate, 2.4x the algorithmic HBM bytes).
   int tile, split;
   if (splits >= 8) {
-    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int xcd = bid & 7, k = bid >> 3;
     split = xcd + 8 * (k / tiles);
     tile = k % tiles;
     if (split >= splits) return;
   } else {
-    tile = blockIdx.x % tiles;
-    split = blockIdx.x / tiles;
+    tile = bid % tiles;
+    split = bid / tiles;
   }
   const int n0 = (tile / ct) * FA, c0 = (tile % ct) * FB;
   // Packed rows (pack.hip): the number of rows / chunks lives on the device (`counts`); the chunks are spread evenly
@@ -449,6 +448,32 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const float* __restrict__
   }
 }
 
+template <int KW, int TA, int TB>
+__global__ __launch_bounds__(256) void wgrad_tr_kernel(const float* __restrict__ dz, int64_t lddz,
+                                                       const float* __restrict__ x, int64_t ldx,
+                                                       float* __restrict__ db, float* __restrict__ db2, int B, int L,
+                                                       int n, int cin, int pad_left, int ct, int cpi,
+                                                       int chunks_per_split, int tiles, int splits,
+                                                       float* __restrict__ ws, const int4* __restrict__ chunktab,
+                                                       const int64_t* __restrict__ counts) {
+  wgrad_tr_body<KW, TA, TB>(blockIdx.x, dz, lddz, x, ldx, db, db2, B, L, n, cin, pad_left, ct, cpi, chunks_per_split, tiles,
+                            splits, ws, chunktab, counts);
+}
+
+// Many small Linear weight gradients in ONE launch (kw = 1, 64x64 tile): the S-domain gradients of a backward pass
+// (style MLPs, LSTM matrices, classifier heads, text-encoder projections) are ~120 launches of 5-10 us each, i.e.
+// launch-latency-bound.  Descriptor i owns blocks [block_start[i], block_start[i+1]).
+__global__ __launch_bounds__(256) void wgrad_tr_group_kernel(const StylerWgradGroupDesc* __restrict__ desc, int count) {
+  int lo = 0, hi = count - 1;                        // last descriptor with block_start <= blockIdx.x
+  const int bid = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].block_start <= bid) lo = mid; else hi = mid - 1; }
+  const StylerWgradGroupDesc d = desc[lo];
+  wgrad_tr_body<1, 1, 1>(bid - d.block_start, reinterpret_cast<const float*>(d.dz), d.lddz,
+                         reinterpret_cast<const float*>(d.x), d.ldx, reinterpret_cast<float*>(d.db),
+                         reinterpret_cast<float*>(d.db2), d.B, d.L, d.n, d.cin, d.pad_left, d.ct, d.cpi, d.cps, d.tiles,
+                         d.splits, reinterpret_cast<float*>(d.ws), nullptr, reinterpret_cast<const int64_t*>(d.counts));
+}
+
 // dw[nn*sn + c*sc + j*sj] += sum over splits of ws[split][nn][j][c]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int64_t sn,
                                                            int64_t sc, int64_t sj, int n, int cin, int kw, int splits) {
@@ -573,6 +598,36 @@ extern "C" int styler_wgrad_packed(const float* dz, int64_t lddz, const float* x
   if (!rowinfo || !chunktab || !counts) return STYLER_EINVAL;
   return wgrad_impl(dz, lddz, x, ldx, dw, db, nullptr, stride_n, stride_c, stride_j, 1, rows, n, cin, kw, kw / 2, prec,
                     workspace, defer_reduce, rowinfo, chunktab, counts, stream);
+}
+
+// Host-side descriptor of one member of a grouped launch (styler_wgrad_group).  Returns the number of blocks the member
+// needs, 0 when the problem does not qualify (not a bf16 kw = 1 gradient on the 64x64 tile), < 0 on bad arguments.
+extern "C" int styler_wgrad_group_desc(StylerWgradGroupDesc* out, const float* dz, int64_t lddz, const float* x, int64_t ldx,
+                                       float* db, float* db2, int B, int L, int n, int cin, int pad_left, int prec,
+                                       void* workspace, const int64_t* packed_counts, int block_start) {
+  if (!out || !dz || !x || !workspace || B <= 0 || L <= 0 || n <= 0 || cin <= 0 || (db2 && !db)) return STYLER_EINVAL;
+  if ((lddz & 3) || (ldx & 3) || (n & 3) || ldx < ((cin + 3) & ~3) || ((uintptr_t)dz & 15) || ((uintptr_t)x & 15)) return STYLER_EALIGN;
+  if (prec != STYLER_PREC_BF16) return 0;
+  if (packed_counts && (B != 1 || pad_left != 0)) return STYLER_EINVAL;
+  int TA, TB;
+  wgrad_tile(n, cin, 1, prec, &TA, &TB);
+  if (TA != 1 || TB != 1) return 0;
+  int Be, Le, cpi, cps, splits;
+  wgrad_plan(B, L, n, cin, 1, pad_left, prec, &Be, &Le, &cpi, &cps, &splits);
+  const int nt = (n + 63) / 64, ct = (cin + 63) / 64, tiles = nt * ct;
+  out->dz = (uint64_t)(uintptr_t)dz; out->x = (uint64_t)(uintptr_t)x; out->db = (uint64_t)(uintptr_t)db;
+  out->db2 = (uint64_t)(uintptr_t)db2; out->ws = (uint64_t)(uintptr_t)workspace;
+  out->counts = (uint64_t)(uintptr_t)packed_counts;
+  out->lddz = lddz; out->ldx = ldx;
+  out->B = Be; out->L = Le; out->n = n; out->cin = cin; out->pad_left = pad_left; out->ct = ct; out->cpi = cpi;
+  out->cps = cps; out->tiles = tiles; out->splits = splits; out->block_start = block_start; out->_pad = 0;
+  return tiles * (splits >= 8 ? (splits + 7) / 8 * 8 : splits);
+}
+
+extern "C" int styler_wgrad_group(const StylerWgradGroupDesc* desc_dev, int count, int total_blocks, void* stream) {
+  if (!desc_dev || count <= 0 || total_blocks <= 0) return STYLER_EINVAL;
+  hipLaunchKernelGGL(wgrad_tr_group_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, count);
+  return launch_status();
 }
 
 extern "C" int styler_wgrad_splits(int B, int L, int n, int cin, int kw, int pad_left, int prec) {

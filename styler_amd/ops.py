@@ -49,6 +49,7 @@ class WgradArena:
     (calls reduce immediately); the arena is sized from it."""
 
     _DESC = None
+    GROUP_TABLE_BYTES = 1 << 16
 
     def __init__(self):
         self.buf = None
@@ -56,10 +57,17 @@ class WgradArena:
         self.need = 0
         self.descs = []
         self._cache = {}                             # descriptor tuple -> (device table, total blocks)
+        # small Linear gradients are not launched one by one: they are collected and run as ONE grouped launch at flush
+        self.group = []                              # WgradGroupDesc of the pending members
+        self.group_blocks = 0
+        self.group_keep = []                         # operand tensors, alive until the grouped launch has been enqueued
+        self._gcache = {}                            # descriptor bytes -> (pinned host table, device table)
+        self._pinned_pool = []
 
     def begin(self):
         self.used = 0
         self.descs = []
+        self.group, self.group_blocks, self.group_keep = [], 0, []
 
     def take(self, nfloats, device):
         nfloats = (nfloats + 3) & ~3
@@ -76,6 +84,28 @@ class WgradArena:
         if self.buf is None and self.need:
             self.buf = torch.empty(self.need, device=device, dtype=torch.float32)
         self.need = 0
+        if self.group:
+            from ._lib import WgradGroupDesc
+            arr = (WgradGroupDesc * len(self.group))(*self.group)
+            key = bytes(arr)
+            capturing = torch.cuda.is_current_stream_capturing()
+            if not capturing:                        # pinned staging buffers cannot be allocated while a hipGraph is
+                while len(self._pinned_pool) < 2:    # being captured: keep two in reserve from the eager steps
+                    self._pinned_pool.append(torch.empty(self.GROUP_TABLE_BYTES, dtype=torch.uint8).pin_memory())
+            if key not in self._gcache:
+                if len(self._gcache) > 8 and not capturing:
+                    self._gcache.clear()
+                if len(key) > self.GROUP_TABLE_BYTES or not self._pinned_pool:
+                    raise StylerHipError("grouped wgrad: no pinned staging buffer (run one eager step before capturing)")
+                host = self._pinned_pool.pop()       # owned by this cache entry from now on: a captured memcpy node
+                host[:len(key)].copy_(torch.frombuffer(bytearray(key), dtype=torch.uint8))   # re-reads it at every replay
+                dev_t = torch.empty(len(key), device=device, dtype=torch.uint8)
+                dev_t.copy_(host[:len(key)], non_blocking=True)
+                self._gcache[key] = (host, dev_t)
+            table = self._gcache[key][1]
+            _chk(lib.styler_wgrad_group(table.data_ptr(), len(self.group), self.group_blocks, _stream()),
+                 "styler_wgrad_group")
+            self.group, self.group_blocks, self.group_keep = [], 0, []
         if not self.descs:
             return
         key = tuple(self.descs)
@@ -512,7 +542,24 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
                                 int(lib.styler_wgrad_splits(B, L, n, cin, kw, pad_left, prec))))
     if ws is None:
         ws = torch.empty(nfloats, device=dz.device, dtype=torch.float32)
-    if plan is not None:
+    grouped = False
+    if defer and kw == 1 and prec == PREC_BF16 and prof is None:
+        from ._lib import WgradGroupDesc
+        import ctypes
+        d = WgradGroupDesc()
+        nb = lib.styler_wgrad_group_desc(ctypes.byref(d), dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), _ptr(db), _ptr(db2),
+                                         B, L, n, cin, pad_left, prec, ws.data_ptr(),
+                                         plan.counts.data_ptr() if plan is not None else None, arena.group_blocks)
+        if nb < 0:
+            _chk(nb, "styler_wgrad_group_desc")
+        if nb > 0:                                   # joins the grouped launch of WgradArena.flush
+            arena.group.append(d)
+            arena.group_blocks += nb
+            arena.group_keep.append((dz, x, plan))
+            grouped = True
+    if grouped:
+        pass
+    elif plan is not None:
         assert B == 1 and L == plan.rows and db2 is None and pad_left == kw // 2
         _chk(lib.styler_wgrad_packed(dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), dw.data_ptr(), _ptr(db), strides[0],
                                      strides[1], strides[2], L, n, cin, kw, prec, ws.data_ptr(), defer,
