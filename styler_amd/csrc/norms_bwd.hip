@@ -7,7 +7,8 @@
 // LayerNorm(256) backward.  y = LN(x) * g + b (rows t >= len[b] are zero in forward => zero gradient).
 //   dx = rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)),  dxh = dy * g
 // dot variant (predictor tail, out = <y, w> + b0): dy = dout[row] * w, dw += dout * y, db0 += dout.
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+#define LNB_WAVES 8         // waves per block: rows in flight per CU (the row loop is a latency chain of 4 wave reductions)
+__global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dx, int64_t lddx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ dot_w,
@@ -16,8 +17,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     float in_drop_p, uint64_t in_drop_seed_host, float* __restrict__ dx_drop, int64_t lddxd) {
   const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   const int lane = threadIdx.x & 63;
-  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t wstride = (int64_t)gridDim.x * 4;
+  const int64_t w0 = (int64_t)blockIdx.x * LNB_WAVES + (threadIdx.x >> 6);
+  const int64_t wstride = (int64_t)gridDim.x * LNB_WAVES;
   const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
   float4 bt = make_float4(0.f, 0.f, 0.f, 0.f), dw4 = bt;
   if (dot_w) { bt = *reinterpret_cast<const float4*>(beta + lane * 4); dw4 = *reinterpret_cast<const float4*>(dot_w + lane * 4); }
@@ -73,9 +74,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
                       dropout_hash32(sd, e + 2) >= thr ? gx.z * sc : 0.f, dropout_hash32(sd, e + 3) >= thr ? gx.w * sc : 0.f);
     }
   }
-  // block-level reduction (4 waves) before the atomics: 256 + 256 (+ 256 + 1) atomics per block
-  __shared__ float red[3][4][256];
-  __shared__ float redb[4];
+  // block-level reduction (LNB_WAVES waves) before the atomics: 256 + 256 (+ 256 + 1) atomics per block
+  __shared__ float red[3][LNB_WAVES][256];
+  __shared__ float redb[LNB_WAVES];
   const int wv = threadIdx.x >> 6;
   red[0][wv][lane * 4 + 0] = ag.x; red[0][wv][lane * 4 + 1] = ag.y; red[0][wv][lane * 4 + 2] = ag.z; red[0][wv][lane * 4 + 3] = ag.w;
   red[1][wv][lane * 4 + 0] = ab.x; red[1][wv][lane * 4 + 1] = ab.y; red[1][wv][lane * 4 + 2] = ab.z; red[1][wv][lane * 4 + 3] = ab.w;
@@ -83,12 +84,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   const float wsum = wave_sum(adb);
   if (lane == 0) redb[wv] = wsum;
   __syncthreads();
-  const int c = threadIdx.x;
-  atomicAdd(dgamma + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
-  atomicAdd(dbeta + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
-  if (dot_w) {
-    atomicAdd(ddot_w + c, (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]));
-    if (c == 0) atomicAdd(ddot_b, (redb[0] + redb[1]) + (redb[2] + redb[3]));
+  const int c = threadIdx.x & 255, which = threadIdx.x >> 8;            // 512 threads: 2 of the 3 sums at once
+  for (int q = which; q < (dot_w ? 3 : 2); q += (64 * LNB_WAVES) / 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < LNB_WAVES; ++w) t += red[q][w][c];
+    atomicAdd((q == 0 ? dgamma : q == 1 ? dbeta : ddot_w) + c, t);
+  }
+  if (dot_w && threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < LNB_WAVES; ++w) t += redb[w];
+    atomicAdd(ddot_b, t);
   }
 }
 
@@ -102,10 +109,10 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
   if (dot_w && (!dout || !ddot_w || !ddot_b || !beta)) return STYLER_EINVAL;
   if ((ldx & 3) || (dy && (lddy & 3)) || (dx && (lddx & 3))) return STYLER_EALIGN;
   const int64_t rows = (int64_t)B * L;
-  int64_t blocks = (rows + 3) / 4;
+  int64_t blocks = (rows + LNB_WAVES - 1) / LNB_WAVES;
   static const int cap = [] { const char* e = getenv("STYLER_LNBWD_BLOCKS"); return e ? atoi(e) : 512; }();
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy,
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(64 * LNB_WAVES), 0, (hipStream_t)stream, x, ldx, dy, lddy,
                      gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b, rows, L, len, drop_p, drop_seed,
                      g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd);
   return launch_status();

@@ -54,7 +54,7 @@ class WgradArena:
     def __init__(self):
         self.buf = None
         self.used = 0
-        self.need = 0
+        self.total = 0                               # floats requested by the current pass (taken or not)
         self.descs = []
         self._cache = {}                             # descriptor tuple -> (device table, total blocks)
         # small Linear gradients are not launched one by one: they are collected and run as ONE grouped launch at flush
@@ -64,16 +64,22 @@ class WgradArena:
         self._gcache = {}                            # descriptor bytes -> (pinned host table, device table)
         self._pinned_pool = []
 
-    def begin(self):
+    def begin(self, device=None):
+        """Start of a backward pass.  The buffer is (re)sized HERE, from what the previous pass asked for in total --
+        never inside a pass, where slices are in use (a pass may flush more than once: the decoder-side flush of the
+        overlapped all-reduce comes first)."""
+        if self.total > (self.buf.numel() if self.buf is not None else 0) and device is not None:
+            self.buf = torch.empty(self.total, device=device, dtype=torch.float32)
         self.used = 0
+        self.total = 0
         self.descs = []
         self.group, self.group_blocks, self.group_keep = [], 0, []
 
     def take(self, nfloats, device):
         nfloats = (nfloats + 3) & ~3
+        self.total += nfloats
         if self.buf is None or self.used + nfloats > self.buf.numel():
-            self.need += nfloats                     # measuring pass (or overflow): caller reduces immediately
-            return None
+            return None                              # measuring pass (or overflow): caller reduces immediately
         out = self.buf[self.used:self.used + nfloats]
         self.used += nfloats
         return out
@@ -81,9 +87,6 @@ class WgradArena:
     def flush(self, device):
         import ctypes
         import numpy as np
-        if self.buf is None and self.need:
-            self.buf = torch.empty(self.need, device=device, dtype=torch.float32)
-        self.need = 0
         if self.group:
             from ._lib import WgradGroupDesc
             arr = (WgradGroupDesc * len(self.group))(*self.group)

@@ -132,7 +132,7 @@ def forward_backward(model, state, batch, loss_fn=None, dat_fn=None):
     state.drop_epoch.add_(1)
     losses = train_losses(model, batch, loss_fn, dat_fn)
     rt.grad_ready_hook = state.on_decoder_grads_ready if state.overlap_allreduce else None
-    state.arena.begin()
+    state.arena.begin(state.flat_g.device)
     ops.wgrad_arena = state.arena
     try:
         (losses[0] / hp.acc_steps).backward()

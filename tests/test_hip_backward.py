@@ -401,7 +401,7 @@ def test_deferred_wgrad_reduce_matches_immediate(dev, train_model, ref_state_dic
         train_model.zero_grad(set_to_none=True)
         losses = train_losses(train_model, b)
         if mode != "immediate":
-            arena.begin()
+            arena.begin(dev)
             ops.wgrad_arena = arena
         try:
             losses[0].backward()
