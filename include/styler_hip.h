@@ -89,6 +89,18 @@ int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, int prec);
 /* fp32 -> bf16 (round-to-nearest-even) weight shadow for STYLER_PREC_BF16 */
 int styler_cast_bf16(const float* src, uint16_t* dst, int64_t count, void* stream);
 
+/* Many strided 3-D copies (fp32 source -> fp32 | bf16 destination) in one launch: the refresh of every derived
+ * weight layout after an optimiser step.  Descriptor i owns blocks [block_start[i], block_start[i+1]) of 1024
+ * elements; element (a0,a1,a2) of dims (d0,d1,d2): dst[a0*ds0+a1*ds1+a2*ds2] = src[a0*ss0+a1*ss1+a2*ss2]
+ * (+ src2[same index] when src2 != 0); strides in elements, may be negative with src pre-offset.
+ * flags: bit0 = bf16 destination. */
+typedef struct {
+  uint64_t src, src2, dst;
+  int64_t ss0, ss1, ss2, ds0, ds1, ds2, block_start;
+  int32_t d0, d1, d2, flags;
+} StylerCopyDesc;
+int styler_strided_copy_multi(const StylerCopyDesc* desc_dev, int count, int64_t total_blocks, void* stream);
+
 /* Conv1d weight repack [n, cin, kw] <-> [n, kw, cin] (state-dict layout <-> kernel layout);
  * out_bf16 != 0 writes the bf16 shadow directly (dst is uint16). */
 int styler_repack_conv_weight(const float* src, void* dst, int n, int cin, int kw,

@@ -34,6 +34,7 @@ _SIGS = {
     "styler_lstm_bidir": [P, P, P, P, P, I, I, I, P],
     "styler_lstm_bidir_multi": [P, I, I, I, P],
     "styler_set_dropout_counter": [P],
+    "styler_strided_copy_multi": [P, I, I64, P],
     "styler_wgrad_group_desc": [P, P, I64, P, I64, P, P, I, I, I, I, I, I, P, P, I],
     "styler_wgrad_group": [P, I, I, P],
     "styler_pack_plan": [P, I, I, P, P, P, P, P],
@@ -90,6 +91,12 @@ class WgradGroupDesc(ctypes.Structure):
                 ("ldx", ctypes.c_int64)] + \
                [(k, ctypes.c_int32) for k in ("B", "L", "n", "cin", "pad_left", "ct", "cpi", "cps", "tiles", "splits",
                                               "block_start", "_pad")]
+
+
+class CopyDesc(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_uint64), ("src2", ctypes.c_uint64), ("dst", ctypes.c_uint64)] + \
+               [(k, ctypes.c_int64) for k in ("ss0", "ss1", "ss2", "ds0", "ds1", "ds2", "block_start")] + \
+               [(k, ctypes.c_int32) for k in ("d0", "d1", "d2", "flags")]
 
 
 class LstmBwdDesc(ctypes.Structure):

@@ -8,7 +8,20 @@ import torch
 from torch.autograd import Function
 
 from . import ops
-from .runtime import gemm_weight, rt
+from .runtime import Seg, gemm_weight, gemm_weight_bwd, rt, seg_transposed
+
+
+def onehot_weight(cache, key, w):
+    """Conv1d(257 -> C, k5) weight [C, 257, 5] -> gather layout [5, 257, C] of styler_onehot_conv5."""
+    C, Q, K = w.shape
+    return cache.get_spec(key, (K, Q, C), False, lambda: [Seg(w, (K, Q, C), (1, K, Q * K), (Q * C, C, 1))])
+
+
+def lstm_wi_transposed(cache, key, wi, wir):
+    """[cin, 8H] = transposed cat of the two directions' input weights (dX of the fused input projection)."""
+    n4, cin = wi.shape
+    return cache.get_spec(key, (cin, 2 * n4), False,
+                          lambda: [seg_transposed(wi, 0, 2 * n4), seg_transposed(wir, n4, 2 * n4)])
 
 NONE, RELU, TANH = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_TANH
 
@@ -59,12 +72,9 @@ class ConvGemmFn(Function):
                       db=G(bias) if (bias is not None and bias.requires_grad) else None, plan=plan)
         dx = None
         if ctx.needs_input_grad[0]:
-            if rt.prec == ops.PREC_BF16 and n % 8 == 0:
-                wt = ctx.cache.get(ctx.key + ":T16", [weight], lambda w: ops.repack_weight_bwd(w.detach(), bf16=True))
-                prec = ops.PREC_BF16
-            else:
-                wt = ctx.cache.get(ctx.key + ":T", [weight], lambda w: ops.repack_weight_bwd(w.detach()))
-                prec = ops.PREC_F32
+            bf16 = rt.prec == ops.PREC_BF16 and n % 8 == 0
+            wt = gemm_weight_bwd(ctx.cache, ctx.key, weight, bf16)
+            prec = ops.PREC_BF16 if bf16 else ops.PREC_F32
             dx = ops.conv_gemm(dz, wt, None, kw=kw, n=cin, prec=prec,
                                scale=_neg(cin, dz.device) if ctx.neg_dx else None, plan=plan)
         return dx, (dy if ctx.has_res else None), None, None, None, None, None, None, None, None
@@ -94,12 +104,10 @@ class QkvAttentionFn(Function):
             ops.wgrad(sl, x, G(lin.weight), 256, 256, db=G(lin.bias), plan=plan)
         d = mha._derived
         srcs = [mha.w_qs.weight, mha.w_ks.weight, mha.w_vs.weight]
-        if rt.prec == ops.PREC_BF16:
-            wt = d.get("qkv_wT16", srcs, lambda *t: ops.cast_bf16(torch.cat([u.detach() for u in t]).t().contiguous()))
-            prec = ops.PREC_BF16
-        else:
-            wt = d.get("qkv_wT", srcs, lambda *t: torch.cat([u.detach() for u in t]).t().contiguous())
-            prec = ops.PREC_F32
+        bf16 = rt.prec == ops.PREC_BF16
+        wt = d.get_spec("qkv_wT16" if bf16 else "qkv_wT", (256, 768), bf16,
+                        lambda: [seg_transposed(w, k * 256, 768) for k, w in enumerate(srcs)])
+        prec = ops.PREC_BF16 if bf16 else ops.PREC_F32
         dx = ops.conv_gemm(dqkv, wt, None, n=256, prec=prec, plan=plan)
         return dx, None, None, None, None
 
@@ -205,7 +213,7 @@ class EmbedPosFn(Function):
 class OnehotConv5Fn(Function):
     @staticmethod
     def forward(ctx, v, anchor, conv, cache, key, err):
-        wt = cache.get(key, [conv.weight], lambda w: w.detach().permute(2, 1, 0).contiguous())
+        wt = onehot_weight(cache, key, conv.weight)
         B, L = v.shape
         y = torch.empty(B, L, conv.weight.shape[0], device=v.device, dtype=torch.float32)
         ops.onehot_conv5(v, wt, conv.bias, y, err_flag=err)
@@ -266,8 +274,7 @@ class LstmLayerFn(Function):
         if ctx.needs_input_grad[0]:
             names = [f"weight_ih_l{layer}", f"weight_ih_l{layer}_reverse"]
             srcs = [getattr(lstm, n) for n in names]
-            wt = ctx.enc._derived.get(ctx.key + "wiT", srcs,
-                                      lambda a, b: torch.cat([a.detach(), b.detach()]).t().contiguous())
+            wt = lstm_wi_transposed(ctx.enc._derived, ctx.key + "wiT", srcs[0], srcs[1])
             dx = ops.conv_gemm(dgp, wt, None, n=cin)
         return dx, None, None, None, None, None, None
 
@@ -310,8 +317,7 @@ class LstmMultiLayerFn(Function):
             dx = None
             if ctx.needs_input_grad[3 + s]:
                 srcs = [getattr(lstm, f"weight_ih_l{layer}"), getattr(lstm, f"weight_ih_l{layer}_reverse")]
-                wt = enc._derived.get(f"lstm{s}_{layer}wiT", srcs,
-                                      lambda a, b: torch.cat([a.detach(), b.detach()]).t().contiguous())
+                wt = lstm_wi_transposed(enc._derived, f"lstm{s}_{layer}wiT", srcs[0], srcs[1])
                 dx = ops.conv_gemm(dgp, wt, None, n=cin)
             dxs.append(dx)
         return (None, None, None, *dxs)

@@ -341,3 +341,38 @@ extern "C" int styler_length_mask(const int64_t* len, uint8_t* mask, int B, int 
                      (int64_t)B * L, L);
   return launch_status();
 }
+
+// ---- derived weight layouts: many strided 3-D copies (+ fp32 -> bf16) in ONE launch -------------------------------
+// Every kernel-side view of a parameter (bf16 shadow, [n, kw, cin] conv layout, tap-flipped transposed dX layout, fused
+// QKV / BiLSTM matrices, summed LSTM biases) is an index permutation of parameter elements, optionally cast or
+// summed with a second tensor of the same shape.  One descriptor = one source tensor walked as dims (d0, d1, d2) with element strides on both sides; the
+// optimiser refreshes ALL derived layouts of the model with one launch after each update (runtime.Derived).
+__global__ __launch_bounds__(256) void strided_copy_multi_kernel(const StylerCopyDesc* __restrict__ desc, int count) {
+  int lo = 0, hi = count - 1;                        // last descriptor with block_start <= blockIdx.x
+  const int64_t bid = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].block_start <= bid) lo = mid; else hi = mid - 1; }
+  const StylerCopyDesc d = desc[lo];
+  const int64_t total = (int64_t)d.d0 * d.d1 * d.d2;
+  const float* src = reinterpret_cast<const float*>(d.src);
+  const int64_t i0 = (bid - d.block_start) * 1024;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t i = i0 + k * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int a2 = (int)(i % d.d2); const int64_t r = i / d.d2;
+    const int a1 = (int)(r % d.d1); const int a0 = (int)(r / d.d1);
+    const int64_t si = a0 * d.ss0 + a1 * d.ss1 + a2 * d.ss2;
+    float v = src[si];
+    if (d.src2) v += reinterpret_cast<const float*>(d.src2)[si];
+    const int64_t o = a0 * d.ds0 + a1 * d.ds1 + a2 * d.ds2;
+    if (d.flags & 1) reinterpret_cast<uint16_t*>(d.dst)[o] = (uint16_t)f32_to_bf16_bits(v);
+    else reinterpret_cast<float*>(d.dst)[o] = v;
+  }
+}
+
+extern "C" int styler_strided_copy_multi(const StylerCopyDesc* desc_dev, int count, int64_t total_blocks, void* stream) {
+  if (!desc_dev || count <= 0 || total_blocks <= 0) return STYLER_EINVAL;
+  hipLaunchKernelGGL(strided_copy_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, desc_dev,
+                     count);
+  return launch_status();
+}

@@ -19,7 +19,7 @@ import torch.nn as nn
 from . import autograd as AG
 from . import hparams as hp
 from . import ops
-from .runtime import rt
+from .runtime import Seg, rt, seg_rows
 from .transformer import ConvNorm, Encoder, _HipModule
 
 EncoderInput = namedtuple("EncoderInput", "mel p_norm e_input mel_aug")
@@ -86,14 +86,14 @@ class AudioEncoder(_HipModule):
                  f"weight_hh_l{layer}_reverse", f"bias_ih_l{layer}", f"bias_hh_l{layer}",
                  f"bias_ih_l{layer}_reverse", f"bias_hh_l{layer}_reverse"]
         wi, wir, wh, whr, bi, bh, bir, bhr = [getattr(lstm, n) for n in names]
-        bias = d.get(key + "b", [bi, bh, bir, bhr],
-                     lambda a, b, c, e: torch.cat([a.detach() + b.detach(), c.detach() + e.detach()]))
-        w_hh = d.get(key + "wh", [wh, whr], lambda a, b: torch.stack([a.detach(), b.detach()]).contiguous())
-        if rt.prec == ops.PREC_BF16 and cin % 8 == 0:
-            w = d.get(key + "wi16", [wi, wir], lambda a, b: ops.cast_bf16(torch.cat([a.detach(), b.detach()])))
-            return w, bias, w_hh, ops.PREC_BF16
-        w = d.get(key + "wi", [wi, wir], lambda a, b: torch.cat([a.detach(), b.detach()]))
-        return w, bias, w_hh, ops.PREC_F32
+        n4, H = wh.shape
+        bias = d.get_spec(key + "b", (2 * n4,), False,
+                          lambda: [Seg(bi, (n4,), (1,), (1,), src2=bh), Seg(bir, (n4,), (1,), (1,), dst_off=n4, src2=bhr)])
+        w_hh = d.get_spec(key + "wh", (2, n4, H), False, lambda: [seg_rows(wh, 0), seg_rows(whr, n4)])
+        bf16 = rt.prec == ops.PREC_BF16 and cin % 8 == 0
+        w = d.get_spec(key + ("wi16" if bf16 else "wi"), (2 * n4, cin), bf16,
+                       lambda: [seg_rows(wi, 0), seg_rows(wir, n4)])
+        return w, bias, w_hh, ops.PREC_BF16 if bf16 else ops.PREC_F32
 
     def _lstm(self, s, x):
         """2-layer BiLSTM: per layer one MFMA GEMM for both directions' input projections, then the
@@ -135,8 +135,7 @@ class AudioEncoder(_HipModule):
                     if grad:
                         y = AG.OnehotConv5Fn.apply(v, conv.weight, conv, self._derived, f"oh{s}", err)
                     else:
-                        wt = self._derived.get(f"oh{s}", [conv.weight],
-                                               lambda w: w.detach().permute(2, 1, 0).contiguous())
+                        wt = AG.onehot_weight(self._derived, f"oh{s}", conv.weight)
                         y = torch.empty(B, T, W[s], device=dev, dtype=torch.float32)
                         ops.onehot_conv5(v, wt, conv.bias, y, err_flag=err)
                 else:

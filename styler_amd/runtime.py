@@ -1,5 +1,5 @@
 """Process-wide runtime switches of the HIP path."""
-from . import ops
+from . import _lib, ops
 
 
 class _Runtime:
@@ -22,10 +22,60 @@ class _Runtime:
 rt = _Runtime()
 
 
+class Seg:
+    """One strided 3-D copy of a derived layout (StylerCopyDesc): element (a0,a1,a2) of `dims` goes from
+    src.flat[src_off + a.sstr] (+ src2, same index) to out.flat[dst_off + a.dstr]."""
+
+    __slots__ = ("src", "src2", "src_off", "dims", "sstr", "dst_off", "dstr")
+
+    def __init__(self, src, dims, sstr, dstr, src_off=0, dst_off=0, src2=None):
+        self.src, self.src2, self.src_off, self.dst_off = src, src2, src_off, dst_off
+        self.dims = tuple(dims) + (1,) * (3 - len(dims))
+        self.sstr = tuple(sstr) + (0,) * (3 - len(sstr))
+        self.dstr = tuple(dstr) + (0,) * (3 - len(dstr))
+
+
+def seg_rows(w, row_off=0, ld=None):
+    """[n, cin] -> rows row_off.. of a [*, ld] matrix (cast / concatenation along rows)."""
+    n, cin = w.shape
+    ld = cin if ld is None else ld
+    return Seg(w, (n, cin), (cin, 1), (ld, 1), dst_off=row_off * ld)
+
+
+def seg_transposed(w, col_off, ld):
+    """[n, cin] -> columns col_off.. of a [cin, ld] matrix: out[c, col_off + r] = w[r, c]."""
+    n, cin = w.shape
+    return Seg(w, (cin, n), (1, cin), (ld, 1), dst_off=col_off)
+
+
+def seg_conv_fwd(w):
+    """nn.Conv1d weight [n, cin, kw] -> kernel layout [n, kw, cin] (a Linear [n, cin] is kw = 1)."""
+    if w.dim() == 2:
+        return seg_rows(w)
+    n, cin, kw = w.shape
+    return Seg(w, (n, kw, cin), (cin * kw, 1, kw), (kw * cin, cin, 1))
+
+
+def seg_conv_bwd(w):
+    """[n, cin, kw] -> the dX conv's weight [cin, kw, n] with taps flipped: out[c, j, nn] = w[nn, c, kw-1-j]."""
+    if w.dim() == 2:
+        n, cin, kw = w.shape[0], w.shape[1], 1
+    else:
+        n, cin, kw = w.shape
+    return Seg(w, (cin, kw, n), (kw, -1, cin * kw), (kw * n, n, 1), src_off=kw - 1)
+
+
 class Derived:
     """Cache of tensors derived from parameters (kernel-layout conv weights, fused QKV, bf16 shadows,
     folded BatchNorm).  An entry is rebuilt when any source's storage or in-place version changes
-    (optimizer steps and load_state_dict bump `_version`)."""
+    (optimizer steps and load_state_dict bump `_version`).
+
+    Entries declared with `get_spec` are index permutations of parameter elements (lists of `Seg`): their output tensor
+    is persistent, and ALL of them are refreshed by one multi-tensor launch (`refresh_all`, called by the optimiser right
+    after its update) instead of one small kernel per entry and step."""
+
+    _registry = []                                   # weak references to every spec entry of the process
+    _table = None                                    # (ids of the live specs, device table, descriptors, blocks)
 
     def __init__(self):
         self._store = {}
@@ -41,17 +91,114 @@ class Derived:
             return val
         return ent[1]
 
+    def get_spec(self, key, shape, bf16, make_segs):
+        """`make_segs()` -> list of Seg; called once (the recipe only depends on the parameters' identities)."""
+        spec = self._store.get(key)
+        if spec is None:
+            import torch
+            import weakref
+            segs = make_segs()
+            out = torch.empty(shape, device=segs[0].src.device, dtype=torch.bfloat16 if bf16 else torch.float32)
+            spec = self._store[key] = _Spec(segs, out, bf16)
+            Derived._registry.append(weakref.ref(spec))
+        stamp = spec.stamp()
+        if spec.fresh != stamp:
+            spec.refresh()                           # lazy path: one launch for this entry
+            spec.fresh = stamp
+        return spec.out
+
+    @staticmethod
+    def refresh_all():
+        """One launch refreshing every spec entry of the process (parameters were just updated in place)."""
+        import torch
+        Derived._registry[:] = [r for r in Derived._registry if r() is not None]
+        specs = [r() for r in Derived._registry]
+        specs = [sp for sp in specs if sp is not None]
+        if not specs:
+            return
+        tab = Derived._table
+        sig = tuple(id(sp) for sp in specs)
+        if tab is None or tab[0] != sig or any(sp.moved() for sp in specs):
+            descs = []
+            start = 0
+            for sp in specs:
+                start = sp.fill(descs, start)
+            arr = (_lib.CopyDesc * len(descs))(*descs)
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            Derived._table = tab = (sig, host.to(specs[0].out.device), len(descs), start)
+        # (specs of several devices in one process are not supported: one process per GPU)
+        ops._chk(ops.lib.styler_strided_copy_multi(tab[1].data_ptr(), tab[2], tab[3], ops._stream()),
+                 "styler_strided_copy_multi")
+        for sp in specs:
+            sp.fresh = sp.stamp()
+
     def clear(self):
         self._store.clear()
 
 
+class _Spec:
+    def __init__(self, segs, out, bf16):
+        self.segs, self.out, self.bf16 = segs, out, bf16
+        self.fresh = None
+        self.ptrs = None
+        self._tab = None
+
+    def _srcs(self):
+        for sg in self.segs:
+            yield sg.src
+            if sg.src2 is not None:
+                yield sg.src2
+
+    def stamp(self):
+        return (rt.weights_epoch,) + tuple((t.data_ptr(), t._version) for t in self._srcs())
+
+    def moved(self):
+        return self.ptrs != tuple(t.data_ptr() for t in self._srcs())
+
+    def fill(self, descs, start):
+        self.ptrs = tuple(t.data_ptr() for t in self._srcs())
+        esz = 2 if self.bf16 else 4
+        for sg in self.segs:
+            d = _lib.CopyDesc()
+            d.src = sg.src.data_ptr() + 4 * sg.src_off
+            d.src2 = (sg.src2.data_ptr() + 4 * sg.src_off) if sg.src2 is not None else 0
+            d.dst = self.out.data_ptr() + esz * sg.dst_off
+            d.ss0, d.ss1, d.ss2 = sg.sstr
+            d.ds0, d.ds1, d.ds2 = sg.dstr
+            d.d0, d.d1, d.d2 = sg.dims
+            d.flags = 1 if self.bf16 else 0
+            d.block_start = start
+            start += (sg.dims[0] * sg.dims[1] * sg.dims[2] + 1023) // 1024
+            descs.append(d)
+        return start
+
+    def refresh(self):
+        import torch
+        if self._tab is None or self.moved():
+            descs = []
+            blocks = self.fill(descs, 0)
+            arr = (_lib.CopyDesc * len(descs))(*descs)
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self._tab = (host.to(self.out.device), len(descs), blocks)
+        ops._chk(ops.lib.styler_strided_copy_multi(self._tab[0].data_ptr(), self._tab[1], self._tab[2], ops._stream()),
+                 "styler_strided_copy_multi")
+
+
 def gemm_weight(cache, key, weight, cin):
     """Kernel-layout weight for the current precision: ([n, kw*cin] tensor, prec)."""
-    import torch
+    n = weight.shape[0]
+    kdim = weight.numel() // n
     if rt.prec == ops.PREC_BF16 and cin % 8 == 0:
-        wb = cache.get(key + ":bf16", [weight], lambda w: ops.cast_bf16(w.detach()) if w.dim() == 2
-                       else ops.repack_conv_weight(w.detach(), bf16=True))
+        wb = cache.get_spec(key + ":bf16", (n, kdim), True, lambda: [seg_conv_fwd(weight)])
         return wb, ops.PREC_BF16
-    w32 = cache.get(key + ":k", [weight],
-                    lambda w: w.detach() if w.dim() == 2 else ops.repack_conv_weight(w.detach()))
-    return w32, ops.PREC_F32
+    if weight.dim() == 2:
+        return weight.detach(), ops.PREC_F32
+    return cache.get_spec(key + ":k", (n, kdim), False, lambda: [seg_conv_fwd(weight)]), ops.PREC_F32
+
+
+def gemm_weight_bwd(cache, key, weight, bf16):
+    """dX-conv weight [cin, kw*n] (taps flipped) of a Linear / Conv1d parameter."""
+    n = weight.shape[0]
+    cin = weight.shape[1]
+    kw = weight.shape[2] if weight.dim() == 3 else 1
+    return cache.get_spec(key + (":T16" if bf16 else ":T"), (cin, kw * n), bf16, lambda: [seg_conv_bwd(weight)])

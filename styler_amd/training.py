@@ -7,7 +7,10 @@ from . import hparams as hp
 from . import ops
 from .dist import allreduce_mean_
 from .loss import DomainAdversarialTrainingLoss, STYLERLoss
-from .runtime import rt
+from .runtime import Derived, rt
+
+
+_LAZY_DERIVED = bool(int(__import__("os").environ.get("STYLER_LAZY_DERIVED", "0")))   # A/B switch: per-entry refresh
 
 
 class TrainState:
@@ -90,6 +93,8 @@ class TrainState:
         ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.sumsq, hp.grad_clip_thresh, lr,
                       hp.betas[0], hp.betas[1], hp.eps, self.n_current_steps)
         rt.weights_epoch += 1       # the flat update bypasses torch's version counters: invalidate derived layouts
+        if not _LAZY_DERIVED:
+            Derived.refresh_all()   # ... and rebuild every declared one (bf16 shadows, kernel layouts) with ONE launch
         return lr
 
     def grad_norm(self):

@@ -8,7 +8,7 @@ import torch.nn as nn
 from . import hparams as hp
 from . import autograd as AG
 from . import ops
-from .runtime import Derived, gemm_weight, rt
+from .runtime import Derived, Seg, gemm_weight, rt, seg_rows
 
 
 def get_sinusoid_encoding_table(n_position, d_hid, padding_idx=None):
@@ -72,12 +72,12 @@ class MultiHeadAttention(_HipModule):
         d = self._derived
         srcs_w = [self.w_qs.weight, self.w_ks.weight, self.w_vs.weight]
         srcs_b = [self.w_qs.bias, self.w_ks.bias, self.w_vs.bias]
-        b = d.get("qkv_b", srcs_b, lambda *t: torch.cat([u.detach() for u in t]))
-        if rt.prec == ops.PREC_BF16:
-            w = d.get("qkv_w16", srcs_w, lambda *t: ops.cast_bf16(torch.cat([u.detach() for u in t])))
-            return w, b, ops.PREC_BF16
-        w = d.get("qkv_w", srcs_w, lambda *t: torch.cat([u.detach() for u in t]))
-        return w, b, ops.PREC_F32
+        b = d.get_spec("qkv_b", (768,), False, lambda: [Seg(u, (256,), (1,), (1,), dst_off=k * 256)
+                                                        for k, u in enumerate(srcs_b)])
+        bf16 = rt.prec == ops.PREC_BF16
+        w = d.get_spec("qkv_w16" if bf16 else "qkv_w", (768, 256), bf16,
+                       lambda: [seg_rows(u, k * 256) for k, u in enumerate(srcs_w)])
+        return w, b, ops.PREC_BF16 if bf16 else ops.PREC_F32
 
     def forward(self, x, lens, out=None, plan=None):
         """x [B, L, 256]; lens int64 [B]; returns LayerNorm(dropout(fc(attn)) + x) with padded rows zeroed
