@@ -148,11 +148,13 @@ int styler_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t 
 
 /* y = relu(GroupNorm(x)) with groups of 16 channels and statistics over 16 ch x the whole
  * padded L (modules.py:103-113,171-175; eps 1e-5).  In place allowed (y == x).
- * workspace: 2*B*C/16 doubles (scratch); stats (optional): [B][C/16][2] floats = mean, rstd of every
+ * workspace: 2*B*C/16 doubles (scratch; ws_zeroed != 0 = the caller hands it over already zeroed, e.g. a
+ * slice of one slab cleared once per step, and the entry point skips its memset -- same for the three
+ * other norm entry points with a workspace); stats (optional): [B][C/16][2] floats = mean, rstd of every
  * group, the input styler_groupnorm_relu_bwd needs. */
 int styler_groupnorm_relu(const float* x, int64_t ldx, const float* gamma, const float* beta,
-                          float* y, int64_t ldy, float* stats, double* workspace, int B, int L, int C,
-                          void* stream);
+                          float* y, int64_t ldy, float* stats, double* workspace, int ws_zeroed, int B,
+                          int L, int C, void* stream);
 
 /* BatchNorm1d folding for eval mode (Layers.py:91,105,118): scale = g * rsqrt(var + eps),
  * shift = (conv_bias - mean) * scale + b.  All [C]. */
@@ -167,7 +169,7 @@ int styler_bn_fold(const float* gamma, const float* beta, const float* running_m
  * column accumulator, spreading the fp64 atomics), zeroed here. */
 int styler_batchnorm_train(const float* x, const float* gamma, const float* beta, float* y,
                            float* save_mean, float* save_rstd, float* running_mean,
-                           float* running_var, double* workspace, int64_t rows, int C,
+                           float* running_var, double* workspace, int ws_zeroed, int64_t rows, int C,
                            int act, void* stream);
 
 /* ---- embeddings / positions ---------------------------------------------------------
@@ -381,13 +383,14 @@ int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t l
 /* stats = the forward's [B][C/16][2] (mean, rstd); workspace 2*B*C/16 doubles (scratch). */
 int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy,
                               const float* gamma, const float* beta, const float* stats, float* dx,
-                              int64_t lddx, float* dgamma, float* dbeta, double* workspace, int B, int L,
-                              int C, void* stream);
+                              int64_t lddx, float* dgamma, float* dbeta, double* workspace, int ws_zeroed,
+                              int B, int L, int C, void* stream);
 
 /* BatchNorm1d(train)+act backward; x, y, dy, dx contiguous [rows, C]; workspace 16 * 2*C doubles. */
 int styler_batchnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
                          const float* save_mean, const float* save_rstd, float* dx, float* dgamma,
-                         float* dbeta, double* workspace, int64_t rows, int C, int act, void* stream);
+                         float* dbeta, double* workspace, int ws_zeroed, int64_t rows, int C, int act,
+                         void* stream);
 
 int styler_embed_bwd(const int64_t* text, const float* dy, int64_t lddy, float* demb, int B, int L,
                      int C, void* stream);

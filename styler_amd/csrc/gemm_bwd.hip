@@ -519,7 +519,12 @@ static void wgrad_plan(int B, int L, int n, int cin, int kw, int pad_left, int p
     *cpi = 0;
     nchunks = ((int64_t)B * L + WG_BK - 1) / WG_BK;
   }
-  int64_t sp = (512 + nt * ct - 1) / (nt * ct);      // ~2 blocks per CU; every extra split costs a partial tile round trip
+  // ~2 blocks per CU for a problem that is launched alone; every extra split costs a partial tile round trip through HBM
+  // (the partials of one backward pass add up to GBs).  The small Linear gradients that run as members of ONE grouped
+  // launch (wgrad_tr_group_kernel: bf16, kw = 1, 64x64 tile) share the chip, so they get a quarter of the splits.
+  static const int grp_target = [] { const char* e = getenv("STYLER_WGRAD_GROUP_BLOCKS"); return e ? atoi(e) : 128; }();
+  const int target = (prec == STYLER_PREC_BF16 && kw == 1 && TA == 1 && TB == 1) ? grp_target : 512;
+  int64_t sp = (target + nt * ct - 1) / (nt * ct);
   if (sp >= 8 && prec == STYLER_PREC_BF16) sp = (sp + 4) / 8 * 8;          // whole splits per XCD (see wgrad_tr_kernel)
   if (sp > nchunks / 4) sp = nchunks / 4;
   if (sp < 1) sp = 1;

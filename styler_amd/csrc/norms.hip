@@ -153,12 +153,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 }
 
 extern "C" int styler_groupnorm_relu(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
-                                     int64_t ldy, float* stats, double* workspace, int B, int L, int C, void* stream) {
+                                     int64_t ldy, float* stats, double* workspace, int ws_zeroed, int B, int L, int C,
+                                     void* stream) {
   if (!x || !y || !gamma || !beta || !workspace || B <= 0 || L <= 0 || C <= 0 || (C & 63)) return STYLER_EINVAL;
   if ((ldx & 3) || (ldy & 3)) return STYLER_EALIGN;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * B * (C / 16), st);
-  if (e != hipSuccess) return (int)e;
+  if (!ws_zeroed) {
+    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * B * (C / 16), st);
+    if (e != hipSuccess) return (int)e;
+  }
   const int nseg = gn_segments_host(B, L, C);
   const int seg_rows = ((L + nseg - 1) / nseg + 15) & ~15;
   const dim3 grid(C / 64, B, (L + seg_rows - 1) / seg_rows);
@@ -258,9 +261,11 @@ __global__ void bn_fold_copies_kernel(double* __restrict__ ws, int C2) {
 }
 
 int styler_bn_colstats(bool bwd, const float* x, const float* y, const float* dy, const float* mean, const float* rstd,
-                       double* ws, int64_t rows, int C, int act, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * STYLER_BN_COPIES, st);
-  if (e != hipSuccess) return (int)e;
+                       double* ws, int ws_zeroed, int64_t rows, int C, int act, hipStream_t st) {
+  if (!ws_zeroed) {
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * STYLER_BN_COPIES, st);
+    if (e != hipSuccess) return (int)e;
+  }
   const dim3 grid((unsigned)((rows + BN_RPB - 1) / BN_RPB));
   if (bwd) hipLaunchKernelGGL(bn_colstats_kernel<true>, grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, rows, C, act);
   else hipLaunchKernelGGL(bn_colstats_kernel<false>, grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, rows, C, act);
@@ -309,11 +314,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 
 extern "C" int styler_batchnorm_train(const float* x, const float* gamma, const float* beta, float* y,
                                       float* save_mean, float* save_rstd, float* running_mean, float* running_var,
-                                      double* workspace, int64_t rows, int C, int act, void* stream) {
+                                      double* workspace, int ws_zeroed, int64_t rows, int C, int act, void* stream) {
   if (!x || !gamma || !beta || !y || !save_mean || !save_rstd || !workspace || rows <= 0 || C <= 0 || (C & 3))
     return STYLER_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int rc = styler_bn_colstats(false, x, nullptr, nullptr, nullptr, nullptr, workspace, rows, C, act, st);
+  const int rc = styler_bn_colstats(false, x, nullptr, nullptr, nullptr, nullptr, workspace, ws_zeroed, rows, C, act, st);
   if (rc) return rc;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, save_mean, save_rstd,
                      running_mean, running_var, rows, C);

@@ -211,15 +211,17 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 
 extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy,
                                          const float* gamma, const float* beta, const float* stats, float* dx,
-                                         int64_t lddx, float* dgamma, float* dbeta, double* workspace, int B, int L, int C,
-                                         void* stream) {
+                                         int64_t lddx, float* dgamma, float* dbeta, double* workspace, int ws_zeroed, int B,
+                                         int L, int C, void* stream) {
   if (!x || !dy || !gamma || !beta || !stats || !dx || !dgamma || !dbeta || !workspace || B <= 0 || L <= 0 || C <= 0 ||
       (C & 63))
     return STYLER_EINVAL;
   if ((ldx & 3) || (lddy & 3) || (lddx & 3)) return STYLER_EALIGN;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * B * (C / 16), st);
-  if (e != hipSuccess) return (int)e;
+  if (!ws_zeroed) {
+    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * B * (C / 16), st);
+    if (e != hipSuccess) return (int)e;
+  }
   const int nseg = gn_segments_host(B, L, C);
   const int seg_rows = ((L + nseg - 1) / nseg + 15) & ~15;
   const dim3 grid(C / 64, B, (L + seg_rows - 1) / seg_rows);
@@ -234,7 +236,7 @@ extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const floa
 // BatchNorm1d (train) + act backward over rows = B*L (pads included), channels-last contiguous [rows, C].
 //   dz = dy * act'(y); dgamma = sum dz*xh; dbeta = sum dz; dx = g*rstd*(dz - dbeta/N - xh*dgamma/N)
 int styler_bn_colstats(bool bwd, const float* x, const float* y, const float* dy, const float* mean, const float* rstd,
-                       double* ws, int64_t rows, int C, int act, hipStream_t st);   // norms.hip
+                       double* ws, int ws_zeroed, int64_t rows, int C, int act, hipStream_t st);   // norms.hip
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy, const float* __restrict__ gamma,
@@ -274,12 +276,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 extern "C" int styler_batchnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
                                     const float* save_mean, const float* save_rstd, float* dx, float* dgamma,
-                                    float* dbeta, double* workspace, int64_t rows, int C, int act, void* stream) {
+                                    float* dbeta, double* workspace, int ws_zeroed, int64_t rows, int C, int act,
+                                    void* stream) {
   if (!x || !dy || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || C <= 0 ||
       (C & 3) || (act == STYLER_ACT_TANH && !y))
     return STYLER_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int rc = styler_bn_colstats(true, x, y, dy, save_mean, save_rstd, workspace, rows, C, act, st);
+  const int rc = styler_bn_colstats(true, x, y, dy, save_mean, save_rstd, workspace, ws_zeroed, rows, C, act, st);
   if (rc) return rc;
   const int64_t total4 = rows * C / 4;
   int64_t blocks = (total4 + 255) / 256; if (blocks > 4096) blocks = 4096;

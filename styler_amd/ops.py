@@ -155,6 +155,45 @@ class GemmProfiler:
 gemm_profiler = None
 
 
+class ZeroSlab:
+    """One fp64 buffer cleared ONCE per step, from which the normalisation kernels take their (must-be-zero) statistics
+    workspaces: 68 memset launches per training step become one.  Sized from the previous step's demand."""
+
+    def __init__(self):
+        self.buf = None
+        self.used = 0
+        self.total = 0
+
+    def begin(self, device):
+        if self.total > (self.buf.numel() if self.buf is not None else 0):
+            self.buf = torch.empty(self.total, device=device, dtype=torch.float64)
+        if self.buf is not None:
+            self.buf.zero_()
+        self.used = 0
+        self.total = 0
+
+    def take(self, n):
+        n = (n + 1) & ~1
+        self.total += n
+        if self.buf is None or self.used + n > self.buf.numel():
+            return None
+        out = self.buf[self.used:self.used + n]
+        self.used += n
+        return out
+
+
+zero_slab = None            # set by training.forward_backward for the duration of a step
+
+
+def _norm_ws(n, device):
+    """(workspace of n doubles, already-zero flag)"""
+    if zero_slab is not None:
+        ws = zero_slab.take(n)
+        if ws is not None:
+            return ws, 1
+    return torch.empty(n, device=device, dtype=torch.float64), 0
+
+
 class PackPlan:
     """Index tables of the packed-rows layout (styler_pack_plan): the valid rows of all items back to back in a
     [1, B*T, C] tensor.  `nrows` (int64 [1], device) is the `lens` argument of the row-wise ops on packed tensors."""
@@ -292,9 +331,9 @@ def groupnorm_relu(x, gamma, beta, out=None, stats=None):
     B, L, C = x.shape
     if out is None:
         out = x
-    ws = torch.empty(B * (C // 16) * 2, device=x.device, dtype=torch.float64)
+    ws, z = _norm_ws(B * (C // 16) * 2, x.device)
     _chk(lib.styler_groupnorm_relu(x.data_ptr(), _ld(x), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
-                                   _ld(out), _ptr(stats), ws.data_ptr(), B, L, C, _stream()), "styler_groupnorm_relu")
+                                   _ld(out), _ptr(stats), ws.data_ptr(), z, B, L, C, _stream()), "styler_groupnorm_relu")
     return out
 
 
@@ -318,10 +357,10 @@ def batchnorm_train(x, gamma, beta, running_mean, running_var, act):
     y = torch.empty_like(x)
     mean = torch.empty(C, device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
-    ws = torch.empty(2 * C * BN_WS_COPIES, device=x.device, dtype=torch.float64)
+    ws, z = _norm_ws(2 * C * BN_WS_COPIES, x.device)
     _chk(lib.styler_batchnorm_train(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
                                     mean.data_ptr(), rstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
-                                    ws.data_ptr(), rows, C, act, _stream()), "styler_batchnorm_train")
+                                    ws.data_ptr(), z, rows, C, act, _stream()), "styler_batchnorm_train")
     return y, mean, rstd
 
 
@@ -632,10 +671,10 @@ def groupnorm_relu_bwd(x, dy, gamma, beta, stats, dgamma, dbeta):
     B, L, C = x.shape
     dy = _rows_view(dy)
     dx = torch.empty(B, L, C, device=x.device, dtype=torch.float32)
-    ws = torch.empty(B * (C // 16) * 2, device=x.device, dtype=torch.float64)
+    ws, z = _norm_ws(B * (C // 16) * 2, x.device)
     _chk(lib.styler_groupnorm_relu_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), gamma.data_ptr(), beta.data_ptr(),
                                        stats.data_ptr(), dx.data_ptr(), C, dgamma.data_ptr(), dbeta.data_ptr(),
-                                       ws.data_ptr(), B, L, C, _stream()),
+                                       ws.data_ptr(), z, B, L, C, _stream()),
          "styler_groupnorm_relu_bwd")
     return dx
 
@@ -645,9 +684,9 @@ def batchnorm_bwd(x, y, dy, gamma, mean, rstd, dgamma, dbeta, act):
     rows = x.numel() // C
     dy = dy.contiguous()
     dx = torch.empty_like(x)
-    ws = torch.empty(2 * C * BN_WS_COPIES, device=x.device, dtype=torch.float64)
+    ws, z = _norm_ws(2 * C * BN_WS_COPIES, x.device)
     _chk(lib.styler_batchnorm_bwd(x.data_ptr(), _ptr(y), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
-                                  rstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
+                                  rstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), z,
                                   rows, C, act, _stream()), "styler_batchnorm_bwd")
     return dx
 

@@ -45,6 +45,7 @@ class TrainState:
         self.n_current_steps = restore_step            # optimizer.py:10
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
         self.arena = ops.WgradArena()                  # split-K partials of every weight gradient of one backward
+        self.zero_slab = ops.ZeroSlab()
         self.overlap_allreduce = True                  # start the decoder-side all-reduce from inside backward
         # device step counter mixed into every dropout seed: host seeds are baked into a captured hipGraph, the
         # counter is what changes between replays (styler_set_dropout_counter)
@@ -135,16 +136,19 @@ def forward_backward(model, state, batch, loss_fn=None, dat_fn=None):
     ten losses, backward into the flat gradient (train.py:135-179).  Capturable in a hipGraph."""
     state.zero_grad()
     state.drop_epoch.add_(1)
-    losses = train_losses(model, batch, loss_fn, dat_fn)
-    rt.grad_ready_hook = state.on_decoder_grads_ready if state.overlap_allreduce else None
-    state.arena.begin(state.flat_g.device)
-    ops.wgrad_arena = state.arena
+    state.zero_slab.begin(state.flat_g.device)         # the norm kernels' statistics workspaces: one clear per step
+    ops.zero_slab = state.zero_slab
     try:
+        losses = train_losses(model, batch, loss_fn, dat_fn)
+        rt.grad_ready_hook = state.on_decoder_grads_ready if state.overlap_allreduce else None
+        state.arena.begin(state.flat_g.device)
+        ops.wgrad_arena = state.arena
         (losses[0] / hp.acc_steps).backward()
         state.arena.flush(state.flat_g.device)         # one launch folds all split-K partials into flat_g
     finally:
         rt.grad_ready_hook = None
         ops.wgrad_arena = None
+        ops.zero_slab = None
     return losses
 
 
