@@ -50,11 +50,14 @@ int styler_abi_version(void);
  * to bf16 (uint16) data of the same layout.  scale may be NULL (=1); shift is the bias
  * (or the folded BatchNorm shift, Layers.py:91); res may be NULL.  cin % 4 == 0,
  * ldx % 4 == 0 and 16-byte aligned x / w are required.
- * If len != NULL, output rows with t >= len[b] are written as 0 (masked_fill). */
+ * If len != NULL, output rows with t >= len[b] are written as 0 (masked_fill).
+ * mask (optional, [B,L,n] with row stride ldmask): the value is zeroed where mask <= 0, BEFORE the residual
+ * add -- the dX GEMM of a layer that feeds a ReLU takes the ReLU's forward output here, so
+ * dx = (dy W^T) * relu'(h) + res is one launch (autograd of SubLayers.py:86-89). */
 int styler_conv_gemm(const float* x, int64_t ldx, const void* w, const float* scale,
                      const float* shift, const float* res, int64_t ldres, float* y,
                      int64_t ldy, int B, int L, int cin, int n, int kw, int act, int prec,
-                     const int64_t* len, void* stream);
+                     const int64_t* len, const float* mask, int64_t ldmask, void* stream);
 
 /* ---- packed rows (the decoder runs on the valid frames only) --------------------------
  * Every FFT block of the decoder (transformer/Models.py:111-135) zeroes its padded rows
@@ -80,7 +83,8 @@ int styler_unpack_rows(const float* packed, int64_t ldk, float* padded, int64_t 
 int styler_conv_gemm_packed(const float* x, int64_t ldx, const void* w, const float* scale,
                             const float* shift, const float* res, int64_t ldres, float* y,
                             int64_t ldy, int rows, int cin, int n, int kw, int act, int prec,
-                            const int64_t* nrows, const int32_t* rowinfo, void* stream);
+                            const int64_t* nrows, const int32_t* rowinfo, const float* mask,
+                            int64_t ldmask, void* stream);
 
 /* Which tile engine styler_conv_gemm dispatches for a shape: bit0 = 128x128 block tile (else
  * 64x64), bit1 = bf16 MFMA (else fp32 MFMA).  Used by bench.py to attribute launches. */

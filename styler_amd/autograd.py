@@ -144,6 +144,99 @@ class LayerNormFn(Function):
         return dx, (dx if ctx.has_res else None), None, None, None, None
 
 
+def _ln_tail_fwd(o, x, ln, lens, drop_p):
+    """dropout(o) + x -> LayerNorm -> pad mask in one kernel; returns (y, pre-norm sum, (p, seed))."""
+    drop_p = 0.0 if rt.disable_dropout else drop_p
+    seed = next_dropout_seed() if drop_p > 0 else 0
+    s = torch.empty_like(x)
+    y = ops.add_layernorm(o, ln.weight, ln.bias, res=x, lens=lens, in_drop_p=drop_p, in_drop_seed=seed, sum_out=s)
+    return y, s, (drop_p, seed)
+
+
+def _ln_tail_bwd(s, dy, ln, lens, drop):
+    """-> (gradient of the residual input, gradient of the dropout branch)."""
+    if drop[0] > 0:
+        return ops.layernorm_bwd(s, dy, ln.weight, ln.bias, G(ln.weight), G(ln.bias), lens=lens, in_drop_p=drop[0],
+                                 in_drop_seed=drop[1])
+    dx = ops.layernorm_bwd(s, dy, ln.weight, ln.bias, G(ln.weight), G(ln.bias), lens=lens)
+    return dx, dx
+
+
+class FfnSublayerFn(Function):
+    """PositionwiseFeedForward with its residual (SubLayers.py:81-89) as ONE tape node: Conv1d(k=9)+ReLU, Conv1d(k=1),
+    dropout, + x, LayerNorm, pad mask.  Backward keeps everything in GEMM epilogues: the ReLU mask rides on the dX GEMM of
+    the second conv, the residual's gradient is added in the epilogue of the first conv's dX GEMM (no act_bwd launch, no
+    autograd accumulation kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, ffn, lens, plan, drop_p):
+        kw1, kw2 = ffn.w_1.weight.shape[2], ffn.w_2.weight.shape[2]
+        w1, p1 = gemm_weight(ffn._derived, "w_1", ffn.w_1.weight, x.shape[-1])
+        h = ops.conv_gemm(x, w1, ffn.w_1.bias, kw=kw1, n=ffn.w_1.weight.shape[0], act=RELU, prec=p1, plan=plan)
+        w2, p2 = gemm_weight(ffn._derived, "w_2", ffn.w_2.weight, h.shape[-1])
+        o = ops.conv_gemm(h, w2, ffn.w_2.bias, kw=kw2, n=ffn.w_2.weight.shape[0], prec=p2, plan=plan)
+        y, s, ctx.drop = _ln_tail_fwd(o, x, ffn.layer_norm, lens, drop_p)
+        ctx.save_for_backward(x, h, s, lens)
+        ctx.ffn, ctx.plan = ffn, plan
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h, s, lens = ctx.saved_tensors
+        ffn, plan = ctx.ffn, ctx.plan
+        w_1, w_2 = ffn.w_1, ffn.w_2
+        kw1, kw2 = w_1.weight.shape[2], w_2.weight.shape[2]
+        d_hid, d_in = w_1.weight.shape[0], w_2.weight.shape[0]
+        dx_res, d_o = _ln_tail_bwd(s, ops._rows_view(dy), ffn.layer_norm, lens, ctx.drop)
+        bf16 = rt.prec == ops.PREC_BF16
+        prec = ops.PREC_BF16 if bf16 else ops.PREC_F32
+        ops.wgrad(d_o, h, G(w_2.weight), d_in, d_hid, kw=kw2, db=G(w_2.bias), plan=plan)
+        dh = ops.conv_gemm(d_o, gemm_weight_bwd(ffn._derived, "w_2", w_2.weight, bf16), None, kw=kw2, n=d_hid, prec=prec,
+                           plan=plan, mask=h)
+        ops.wgrad(dh, x, G(w_1.weight), d_hid, d_in, kw=kw1, db=G(w_1.bias), plan=plan)
+        dx = ops.conv_gemm(dh, gemm_weight_bwd(ffn._derived, "w_1", w_1.weight, bf16), None, kw=kw1, n=d_in, prec=prec,
+                           plan=plan, res=dx_res)
+        return dx, None, None, None, None, None
+
+
+class AttnSublayerFn(Function):
+    """MultiHeadAttention with its residual (SubLayers.py:31-61) as ONE tape node: fused QKV GEMM, attention, output
+    projection, dropout, + x, LayerNorm, pad mask; the residual's gradient is added in the epilogue of the QKV dX GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, mha, lens, plan, drop_p):
+        w, b, prec = mha._qkv()
+        qkv = ops.conv_gemm(x, w, b, n=768, prec=prec, plan=plan)
+        B, L = (plan.B, plan.T) if plan is not None else x.shape[:2]
+        lse = torch.empty(B, 4, L, device=x.device, dtype=torch.float32)
+        att = ops.attention_fwd(qkv, lens, lse=lse, plan=plan)
+        wfc, pfc = gemm_weight(mha._derived, "fc", mha.fc.weight, 256)
+        o = ops.conv_gemm(att, wfc, mha.fc.bias, n=256, prec=pfc, plan=plan)
+        y, s, ctx.drop = _ln_tail_fwd(o, x, mha.layer_norm, lens, drop_p)
+        ctx.save_for_backward(x, qkv, att, lse, s, lens)
+        ctx.mha, ctx.plan = mha, plan
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, qkv, att, lse, s, lens = ctx.saved_tensors
+        mha, plan = ctx.mha, ctx.plan
+        dx_res, d_o = _ln_tail_bwd(s, ops._rows_view(dy), mha.layer_norm, lens, ctx.drop)
+        bf16 = rt.prec == ops.PREC_BF16
+        prec = ops.PREC_BF16 if bf16 else ops.PREC_F32
+        ops.wgrad(d_o, att, G(mha.fc.weight), 256, 256, db=G(mha.fc.bias), plan=plan)
+        d_att = ops.conv_gemm(d_o, gemm_weight_bwd(mha._derived, "fc", mha.fc.weight, bf16), None, n=256, prec=prec,
+                              plan=plan)
+        dqkv = ops.attention_bwd(qkv, att, d_att, lse, lens, plan=plan)
+        srcs = [mha.w_qs.weight, mha.w_ks.weight, mha.w_vs.weight]
+        for i, lin in enumerate((mha.w_qs, mha.w_ks, mha.w_vs)):
+            ops.wgrad(dqkv[..., i * 256:(i + 1) * 256], x, G(lin.weight), 256, 256, db=G(lin.bias), plan=plan)
+        wt = mha._derived.get_spec("qkv_wT16" if bf16 else "qkv_wT", (256, 768), bf16,
+                                   lambda: [seg_transposed(w, k * 256, 768) for k, w in enumerate(srcs)])
+        dx = ops.conv_gemm(dqkv, wt, None, n=256, prec=prec, plan=plan, res=dx_res)
+        return dx, None, None, None, None, None
+
+
 class LayerNormDotFn(Function):
     """StylePredictor tail: LayerNorm -> Linear(256,1) -> masked_fill (modules.py:449-465)."""
 

@@ -39,6 +39,7 @@ struct GemmArgs {
   const int64_t* len;
   int mt, nt;                                      // tile counts
   const int2* rowinfo;                             // packed rows (styler_pack_plan): (t, len - 1 - t) per row, or null
+  const float* mask; int64_t ldmask;               // epilogue: v = mask[row, col] > 0 ? v : 0 (ReLU backward), or null
 };
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
@@ -330,6 +331,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
         float4 v = *reinterpret_cast<const float4*>(&cst[rl * CLD + c4]);
         v.x = apply_act(v.x * sc.x + sf.x, a.act); v.y = apply_act(v.y * sc.y + sf.y, a.act);
         v.z = apply_act(v.z * sc.z + sf.z, a.act); v.w = apply_act(v.w * sc.w + sf.w, a.act);
+        if (a.mask) {                                 // dX of a ReLU layer: gradient only where the forward output was > 0
+          const float4 mk = *reinterpret_cast<const float4*>(a.mask + row * a.ldmask + col);
+          v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+          v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+        }
         if (a.res) {
           const float4 rr = *reinterpret_cast<const float4*>(a.res + row * a.ldres + col);
           v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
@@ -381,26 +387,29 @@ extern "C" int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, in
 // even kw is the framing conv of the STFT, stft.hip).
 int styler_conv_gemm_impl2(const float* x, int64_t ldx, const void* w, const float* scale, const float* shift,
                            const float* res, int64_t ldres, float* y, int64_t ldy, int B, int L, int cin, int n,
-                           int kw, int pad, int act, int prec, const int64_t* len, const int32_t* rowinfo, void* stream);
+                           int kw, int pad, int act, int prec, const int64_t* len, const int32_t* rowinfo,
+                           const float* mask, int64_t ldmask, void* stream);
 
 int styler_conv_gemm_impl(const float* x, int64_t ldx, const void* w, const float* scale, const float* shift,
                           const float* res, int64_t ldres, float* y, int64_t ldy, int B, int L, int cin, int n,
                           int kw, int pad, int act, int prec, const int64_t* len, void* stream) {
   return styler_conv_gemm_impl2(x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, pad, act, prec, len,
-                                nullptr, stream);
+                                nullptr, nullptr, 0, stream);
 }
 
 int styler_conv_gemm_impl2(const float* x, int64_t ldx, const void* w, const float* scale, const float* shift,
                            const float* res, int64_t ldres, float* y, int64_t ldy, int B, int L, int cin, int n,
-                           int kw, int pad, int act, int prec, const int64_t* len, const int32_t* rowinfo, void* stream) {
+                           int kw, int pad, int act, int prec, const int64_t* len, const int32_t* rowinfo,
+                           const float* mask, int64_t ldmask, void* stream) {
   if (!x || !w || !y || B <= 0 || L <= 0 || cin <= 0 || n <= 0 || kw <= 0 || kw > 9 || pad < 0 || pad >= kw)
     return STYLER_EINVAL;
   if ((cin & 3) || (ldx & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return STYLER_EALIGN;
   if ((n & 3) || (ldy & 3) || ((uintptr_t)y & 15) || (res && ((ldres & 3) || ((uintptr_t)res & 15)))) return STYLER_EALIGN;
   if (prec == STYLER_PREC_BF16 && (cin & 7)) return STYLER_EALIGN;
   if (rowinfo && B != 1) return STYLER_EINVAL;
+  if (mask && ((ldmask & 3) || ((uintptr_t)mask & 15))) return STYLER_EALIGN;
   GemmArgs a{x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, act, pad, len, 0, 0,
-             reinterpret_cast<const int2*>(rowinfo)};
+             reinterpret_cast<const int2*>(rowinfo), mask, ldmask};
   hipStream_t st = (hipStream_t)stream;
   const bool big = styler_conv_gemm_variant(B, L, cin, n, kw, prec) & 1;
   if (prec == STYLER_PREC_BF16) return big ? launch_gemm<2, 2, true>(a, st) : launch_gemm<1, 1, true>(a, st);
@@ -410,10 +419,10 @@ int styler_conv_gemm_impl2(const float* x, int64_t ldx, const void* w, const flo
 extern "C" int styler_conv_gemm(const float* x, int64_t ldx, const void* w, const float* scale,
                                 const float* shift, const float* res, int64_t ldres, float* y,
                                 int64_t ldy, int B, int L, int cin, int n, int kw, int act, int prec,
-                                const int64_t* len, void* stream) {
+                                const int64_t* len, const float* mask, int64_t ldmask, void* stream) {
   if (!(kw & 1)) return STYLER_EINVAL;
-  return styler_conv_gemm_impl(x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, kw / 2, act, prec, len,
-                               stream);
+  return styler_conv_gemm_impl2(x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, kw / 2, act, prec, len,
+                                nullptr, mask, ldmask, stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -479,10 +488,10 @@ extern "C" int styler_repack_conv_weight(const float* src, void* dst, int n, int
 extern "C" int styler_conv_gemm_packed(const float* x, int64_t ldx, const void* w, const float* scale,
                                        const float* shift, const float* res, int64_t ldres, float* y, int64_t ldy,
                                        int rows, int cin, int n, int kw, int act, int prec, const int64_t* nrows,
-                                       const int32_t* rowinfo, void* stream) {
+                                       const int32_t* rowinfo, const float* mask, int64_t ldmask, void* stream) {
   if (!(kw & 1) || !nrows || !rowinfo) return STYLER_EINVAL;
   return styler_conv_gemm_impl2(x, ldx, w, scale, shift, res, ldres, y, ldy, 1, rows, cin, n, kw, kw / 2, act, prec,
-                                nrows, rowinfo, stream);
+                                nrows, rowinfo, mask, ldmask, stream);
 }
 
 extern "C" int styler_abi_version(void) { return 1; }

@@ -232,7 +232,7 @@ def unpack_rows(xp, plan):
 
 
 def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, scale=None, res=None,
-              out=None, lens=None, plan=None):
+              out=None, lens=None, plan=None, mask=None):
     """y = act(scale * conv1d_same(x, w) + bias) (+ res); x [B, L, cin] -> y [B, L, n].
     `w` is the kernel-layout weight [n, kw*cin] (fp32, or bf16 when prec == PREC_BF16)."""
     _f32(x)
@@ -250,12 +250,14 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
         assert B == 1 and L == plan.rows
         _chk(lib.styler_conv_gemm_packed(x.data_ptr(), _ld(x), w.data_ptr(), _ptr(scale), _ptr(bias), _ptr(res),
                                          _ld(res) if res is not None else 0, out.data_ptr(), _ld(out), L, cin, n, kw,
-                                         act, prec, plan.counts.data_ptr(), plan.rowinfo.data_ptr(), _stream()),
+                                         act, prec, plan.counts.data_ptr(), plan.rowinfo.data_ptr(), _ptr(mask),
+                                         _ld(mask) if mask is not None else 0, _stream()),
              "styler_conv_gemm_packed")
     else:
         _chk(lib.styler_conv_gemm(x.data_ptr(), _ld(x), w.data_ptr(), _ptr(scale), _ptr(bias), _ptr(res),
                                   _ld(res) if res is not None else 0, out.data_ptr(), _ld(out), B, L, cin, n,
-                                  kw, act, prec, _ptr(lens), _stream()), "styler_conv_gemm")
+                                  kw, act, prec, _ptr(lens), _ptr(mask), _ld(mask) if mask is not None else 0,
+                                  _stream()), "styler_conv_gemm")
     if prof is not None:
         e1.record()
         prof.records.append((lib.styler_conv_gemm_variant(B, L, cin, n, kw, prec), 2.0 * B * L * n * kw * cin,

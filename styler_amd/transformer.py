@@ -85,8 +85,8 @@ class MultiHeadAttention(_HipModule):
         packed [1, B*T, 256] tensor and lens = plan.nrows."""
         grad = (self.training and torch.is_grad_enabled())
         drop = self.training and self.dropout.p > 0
-        if grad:
-            ctx = AG.QkvAttentionFn.apply(x, self.w_qs.weight, self, lens, plan)
+        if grad:                                              # the whole sublayer is one tape node
+            return AG.AttnSublayerFn.apply(x, self.w_qs.weight, self, lens, plan, self.dropout.p)
         else:
             w, b, prec = self._qkv()
             ctx = ops.attention_fwd(ops.conv_gemm(x, w, b, n=768, prec=prec, plan=plan), lens, plan=plan)
@@ -110,6 +110,8 @@ class PositionwiseFeedForward(_HipModule):
 
     def forward(self, x, lens, out=None, plan=None):
         k = hp.fft_conv1d_kernel_size
+        if self.training and torch.is_grad_enabled():        # the whole sublayer is one tape node
+            return AG.FfnSublayerFn.apply(x, self.w_1.weight, self, lens, plan, self.dropout.p)
         h = self._gemm("w_1", x, self.w_1, kw=k[0], act=ops.ACT_RELU, plan=plan)
         if (self.training and torch.is_grad_enabled()) or (self.training and self.dropout.p > 0):
             return self._ln(self._gemm("w_2", h, self.w_2, kw=k[1], plan=plan), x, self.layer_norm, lens, out,
