@@ -649,18 +649,32 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const StylerWgr
   const int64_t bid = blockIdx.x;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].block_start <= bid) lo = mid; else hi = mid - 1; }
   const StylerWgradDesc d = desc[lo];
-  const int64_t per = (int64_t)d.n * d.kw * d.cin;
+  const int64_t per = (int64_t)d.n * d.kw * d.cin;   // multiple of 4 (n % 4 == 0); every slice is 16-byte aligned
   const float* ws = reinterpret_cast<const float*>(d.ws);
   float* dw = reinterpret_cast<float*>(d.dw);
-  const int64_t i0 = (bid - d.block_start) * 1024;
+  const int64_t i = (bid - d.block_start) * 1024 + threadIdx.x * 4;      // four consecutive outputs per thread: the
+  if (i >= per) return;                                                   // partials stream as 16-byte loads
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* p = ws + i;
+  int sp = 0;
+  for (; sp + 4 <= d.splits; sp += 4) {              // four independent loads in flight per thread
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + per);
+    const float4 c = *reinterpret_cast<const float4*>(p + 2 * per), e = *reinterpret_cast<const float4*>(p + 3 * per);
+    s.x += (a.x + b.x) + (c.x + e.x); s.y += (a.y + b.y) + (c.y + e.y);
+    s.z += (a.z + b.z) + (c.z + e.z); s.w += (a.w + b.w) + (c.w + e.w);
+    p += 4 * per;
+  }
+  for (; sp < d.splits; ++sp) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    p += per;
+  }
+  const float v[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int64_t i = i0 + k * 256 + threadIdx.x;
-    if (i >= per) return;
-    float s = 0.f;
-    for (int sp = 0; sp < d.splits; ++sp) s += ws[(int64_t)sp * per + i];
-    const int c = (int)(i % d.cin); const int j = (int)((i / d.cin) % d.kw); const int64_t nn = i / ((int64_t)d.cin * d.kw);
-    dw[nn * d.stride_n + c * d.stride_c + j * d.stride_j] += s;
+    const int64_t ii = i + k;
+    const int c = (int)(ii % d.cin); const int j = (int)((ii / d.cin) % d.kw); const int64_t nn = ii / ((int64_t)d.cin * d.kw);
+    dw[nn * d.stride_n + c * d.stride_c + j * d.stride_j] += v[k];
   }
 }
 

@@ -579,3 +579,41 @@ def test_packed_decoder_matches_padded(dev, ref_state_dict, prec):
         rt.pack_decoder = True
         rt.disable_dropout = False
         rt.set_precision("fp32")
+
+
+@pytest.mark.gpu
+def test_batch_permutation_equivariance_full_c2(dev, ref_state_dict):
+    """Size-independent property at the full C2 batch (B = 48, VCTK-shape lengths, bf16 throughput mode): in eval mode no
+    op mixes utterances (GroupNorm / LayerNorm are per item, BatchNorm is folded, attention and the LengthRegulator work
+    per item), so permuting the batch must permute the outputs -- this moves every item to another slot of the padded
+    rectangle and another offset of the packed decoder rows.  Lengths / masks must match bit-exactly."""
+    from closed_form import make_batch
+    from styler_amd import STYLER, rt
+    b = make_batch(48, 20, 60, 2, 13, seed=1234)
+    bd = {k: v.to(dev) for k, v in b.items()}
+    S, T = bd["text"].shape[1], bd["mel_target"].shape[1]
+    perm = torch.randperm(48, generator=torch.Generator().manual_seed(3)).to(dev)
+    m = STYLER()
+    m.load_state_dict(ref_state_dict)
+    m = m.to(dev).eval()
+    rt.set_precision("bf16")
+    strict, rt.strict_inputs = rt.strict_inputs, False
+    try:
+        def run(d):
+            with torch.no_grad():
+                return m(d["text"], d["mel_target"], d["mel_aug"], d["f0_norm"], d["energy_input"], d["src_len"],
+                         d["mel_len"], d["D"], d["f0"], d["energy"], S, T, speaker_embed=d["speaker_embed"])
+        o1 = run(bd)
+        o2 = run({k: v[perm] for k, v in bd.items()})
+        for a, c in ((o1[0][0], o2[0][0]), (o1[0][1], o2[0][1]), (o1[1][0], o2[1][0]), (o1[1][1], o2[1][1]),
+                     (o1[2], o2[2]), (o1[3], o2[3]), (o1[4], o2[4])):
+            e = float((a[perm] - c).abs().max()) / max(float(a.abs().max()), 1e-6)
+            assert e <= 1e-5, f"not permutation-equivariant: {e:.3e}"          # same kernels, same per-item arithmetic
+        assert torch.equal(o1[5][perm], o2[5]) and torch.equal(o1[6][perm], o2[6]) and torch.equal(o1[7][perm], o2[7])
+        valid = int(bd["mel_len"].sum())
+        assert int((~o1[6]).sum()) == valid                                       # mask counts the valid frames
+        pad = o1[6][..., None].expand_as(o1[0][0])
+        assert torch.isfinite(o1[1][0]).all() and float(o1[0][0][pad].abs().max()) <= float(m.mel_linear.bias.detach().abs().max()) + 1e-6
+    finally:
+        rt.strict_inputs = strict
+        rt.set_precision("fp32")
