@@ -376,13 +376,16 @@ int styler_attention_bwd(const float* qkv, const float* out, const float* dout, 
 /* LayerNorm(256) backward from the saved INPUT x (= pre-norm sum).  dx may be NULL.  With
  * dot_w (predictor tail) the incoming gradient is dout [B,L] and ddot_w/ddot_b accumulate.
  * dx_drop (optional) = dx * the dropout mask of the forward's in_drop (the gradient of the branch that
- * went through dropout; dx itself is the gradient of the residual). */
+ * went through dropout; dx itself is the gradient of the residual).
+ * replicas > 1: dgamma / dbeta / ddot_w point to ZEROED scratch [replicas][256] instead of the gradients (block i
+ * adds into replica i % replicas; the caller folds them, e.g. with styler_wgrad_reduce_multi descriptors
+ * n = 256, cin = kw = 1, splits = replicas): hundreds of blocks adding into one 256-float vector serialise in L2. */
 int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy,
                          const float* gamma, const float* beta, float* dx, int64_t lddx,
                          float* dgamma, float* dbeta, const float* dot_w, const float* dout,
                          float* ddot_w, float* ddot_b, int B, int L, int C, const int64_t* len,
                          float drop_p, uint64_t drop_seed, float in_drop_p, uint64_t in_drop_seed,
-                         float* dx_drop, int64_t lddxd, void* stream);
+                         float* dx_drop, int64_t lddxd, int replicas, void* stream);
 
 /* stats = the forward's [B][C/16][2] (mean, rstd); workspace 2*B*C/16 doubles (scratch). */
 int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy,

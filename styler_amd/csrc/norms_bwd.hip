@@ -14,7 +14,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ dot_w,
     const float* __restrict__ dout, float* __restrict__ ddot_w, float* __restrict__ ddot_b, int64_t rows, int L,
     const int64_t* __restrict__ len, float drop_p, uint64_t drop_seed_host, const uint64_t* __restrict__ epoch,
-    float in_drop_p, uint64_t in_drop_seed_host, float* __restrict__ dx_drop, int64_t lddxd) {
+    float in_drop_p, uint64_t in_drop_seed_host, float* __restrict__ dx_drop, int64_t lddxd, int replicas) {
   const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   const int lane = threadIdx.x & 63;
   const int64_t w0 = (int64_t)blockIdx.x * LNB_WAVES + (threadIdx.x >> 6);
@@ -24,54 +24,105 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
   if (dot_w) { bt = *reinterpret_cast<const float4*>(beta + lane * 4); dw4 = *reinterpret_cast<const float4*>(dot_w + lane * 4); }
   float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag, aw = ag;
   float adb = 0.f;
-  for (int64_t row = w0; row < rows; row += wstride) {
-    bool masked = false;
-    if (len) { const int64_t b = row / L; masked = (row - b * L) >= len[b]; }
-    if (masked) {
-      if (dx) *reinterpret_cast<float4*>(dx + row * lddx + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (dx_drop) *reinterpret_cast<float4*>(dx_drop + row * lddxd + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-      continue;
-    }
-    const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + lane * 4);
-    const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
-    const float cx = v.x - mean, cy = v.y - mean, cz = v.z - mean, cw = v.w - mean;
-    const float var = wave_sum(cx * cx + cy * cy + cz * cz + cw * cw) * (1.f / 256.f);
-    const float rstd = 1.0f / sqrtf(var + 1e-5f);
-    const float hx = cx * rstd, hy = cy * rstd, hz = cz * rstd, hw = cw * rstd;
-    float4 d;
-    if (dot_w) {
-      const float go = dout[row];
-      float kx = 1.f, ky = 1.f, kz = 1.f, kw_ = 1.f;       // dropout keep * 1/(1-p) between LN and the dot
-      if (drop_p > 0.f) {
-        const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);
-        const float sc = 1.f / (1.f - drop_p);
-        const uint64_t e = (uint64_t)row * 256 + lane * 4;
-        kx = dropout_hash32(drop_seed, e) >= thr ? sc : 0.f; ky = dropout_hash32(drop_seed, e + 1) >= thr ? sc : 0.f;
-        kz = dropout_hash32(drop_seed, e + 2) >= thr ? sc : 0.f; kw_ = dropout_hash32(drop_seed, e + 3) >= thr ? sc : 0.f;
+  // Two rows per wave and iteration: a row is a latency chain (two loads, then mean -> variance -> two more wave
+  // reductions); the chains of the two rows are independent and interleave.
+#ifndef LNB_R
+#define LNB_R 2
+#endif
+  constexpr int R = LNB_R;
+  for (int64_t row0 = w0; row0 < rows; row0 += wstride * R) {
+    int64_t row[R];
+    bool live[R];
+    float4 v[R], d[R];
+    float go[R], kx[R][4];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      row[k] = row0 + k * wstride;
+      bool ok = row[k] < rows;
+      if (ok && len) {
+        const int64_t b = row[k] / L;
+        if ((row[k] - b * L) >= len[b]) {                // masked row: zero gradient, nothing else
+          ok = false;
+          if (dx) *reinterpret_cast<float4*>(dx + row[k] * lddx + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (dx_drop) *reinterpret_cast<float4*>(dx_drop + row[k] * lddxd + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
-      d = make_float4(go * dw4.x * kx, go * dw4.y * ky, go * dw4.z * kz, go * dw4.w * kw_);
-      aw.x += go * kx * (hx * g.x + bt.x); aw.y += go * ky * (hy * g.y + bt.y);
-      aw.z += go * kz * (hz * g.z + bt.z); aw.w += go * kw_ * (hw * g.w + bt.w);
-      if (lane == 0) adb += go;
-    } else {
-      d = *reinterpret_cast<const float4*>(dy + row * lddy + lane * 4);
+      live[k] = ok;
+      v[k] = ok ? *reinterpret_cast<const float4*>(x + row[k] * ldx + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      go[k] = 0.f;
+      kx[k][0] = kx[k][1] = kx[k][2] = kx[k][3] = 1.f;
+      if (dot_w) {
+        go[k] = ok ? dout[row[k]] : 0.f;
+        if (drop_p > 0.f) {                              // dropout keep * 1/(1-p) between LN and the dot
+          const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);
+          const float sc = 1.f / (1.f - drop_p);
+          const uint64_t e = (uint64_t)row[k] * 256 + lane * 4;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) kx[k][q] = dropout_hash32(drop_seed, e + q) >= thr ? sc : 0.f;
+        }
+        d[k] = make_float4(go[k] * dw4.x * kx[k][0], go[k] * dw4.y * kx[k][1], go[k] * dw4.z * kx[k][2],
+                           go[k] * dw4.w * kx[k][3]);
+      } else {
+        d[k] = ok ? *reinterpret_cast<const float4*>(dy + row[k] * lddy + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
-    ag.x += d.x * hx; ag.y += d.y * hy; ag.z += d.z * hz; ag.w += d.w * hw;
-    ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
-    const float ex = d.x * g.x, ey = d.y * g.y, ez = d.z * g.z, ew = d.w * g.w;
-    const float m1 = wave_sum(ex + ey + ez + ew) * (1.f / 256.f);
-    const float m2 = wave_sum(ex * hx + ey * hy + ez * hz + ew * hw) * (1.f / 256.f);
-    const float4 gx = make_float4(rstd * (ex - m1 - hx * m2), rstd * (ey - m1 - hy * m2), rstd * (ez - m1 - hz * m2),
-                                  rstd * (ew - m1 - hw * m2));
-    if (dx) *reinterpret_cast<float4*>(dx + row * lddx + lane * 4) = gx;
-    if (dx_drop) {                                       // gradient of the dropout(x) that fed the sum (same stream)
-      const uint64_t sd = mix_drop_epoch(in_drop_seed_host, epoch);
-      const uint32_t thr = (uint32_t)((double)in_drop_p * 4294967296.0);
-      const float sc = 1.f / (1.f - in_drop_p);
-      const uint64_t e = (uint64_t)row * 256 + lane * 4;
-      *reinterpret_cast<float4*>(dx_drop + row * lddxd + lane * 4) =
-          make_float4(dropout_hash32(sd, e) >= thr ? gx.x * sc : 0.f, dropout_hash32(sd, e + 1) >= thr ? gx.y * sc : 0.f,
-                      dropout_hash32(sd, e + 2) >= thr ? gx.z * sc : 0.f, dropout_hash32(sd, e + 3) >= thr ? gx.w * sc : 0.f);
+    float mean[R], rstd[R];
+    float4 h[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) mean[k] = v[k].x + v[k].y + v[k].z + v[k].w;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int k = 0; k < R; ++k) mean[k] += __shfl_xor(mean[k], o, 64);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      mean[k] *= (1.f / 256.f);
+      h[k] = make_float4(v[k].x - mean[k], v[k].y - mean[k], v[k].z - mean[k], v[k].w - mean[k]);
+      rstd[k] = h[k].x * h[k].x + h[k].y * h[k].y + h[k].z * h[k].z + h[k].w * h[k].w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int k = 0; k < R; ++k) rstd[k] += __shfl_xor(rstd[k], o, 64);
+    float m1[R], m2[R];
+    float4 ex[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      rstd[k] = 1.0f / sqrtf(rstd[k] * (1.f / 256.f) + 1e-5f);
+      h[k].x *= rstd[k]; h[k].y *= rstd[k]; h[k].z *= rstd[k]; h[k].w *= rstd[k];
+      if (live[k]) {
+        if (dot_w) {
+          aw.x += go[k] * kx[k][0] * (h[k].x * g.x + bt.x); aw.y += go[k] * kx[k][1] * (h[k].y * g.y + bt.y);
+          aw.z += go[k] * kx[k][2] * (h[k].z * g.z + bt.z); aw.w += go[k] * kx[k][3] * (h[k].w * g.w + bt.w);
+          if (lane == 0) adb += go[k];
+        }
+        ag.x += d[k].x * h[k].x; ag.y += d[k].y * h[k].y; ag.z += d[k].z * h[k].z; ag.w += d[k].w * h[k].w;
+        ab.x += d[k].x; ab.y += d[k].y; ab.z += d[k].z; ab.w += d[k].w;
+      }
+      ex[k] = make_float4(d[k].x * g.x, d[k].y * g.y, d[k].z * g.z, d[k].w * g.w);
+      m1[k] = ex[k].x + ex[k].y + ex[k].z + ex[k].w;
+      m2[k] = ex[k].x * h[k].x + ex[k].y * h[k].y + ex[k].z * h[k].z + ex[k].w * h[k].w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int k = 0; k < R; ++k) { m1[k] += __shfl_xor(m1[k], o, 64); m2[k] += __shfl_xor(m2[k], o, 64); }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (!live[k]) continue;
+      m1[k] *= (1.f / 256.f); m2[k] *= (1.f / 256.f);
+      const float4 gx = make_float4(rstd[k] * (ex[k].x - m1[k] - h[k].x * m2[k]), rstd[k] * (ex[k].y - m1[k] - h[k].y * m2[k]),
+                                    rstd[k] * (ex[k].z - m1[k] - h[k].z * m2[k]), rstd[k] * (ex[k].w - m1[k] - h[k].w * m2[k]));
+      if (dx) *reinterpret_cast<float4*>(dx + row[k] * lddx + lane * 4) = gx;
+      if (dx_drop) {                                     // gradient of the dropout(x) that fed the sum (same stream)
+        const uint64_t sd = mix_drop_epoch(in_drop_seed_host, epoch);
+        const uint32_t thr = (uint32_t)((double)in_drop_p * 4294967296.0);
+        const float sc = 1.f / (1.f - in_drop_p);
+        const uint64_t e = (uint64_t)row[k] * 256 + lane * 4;
+        *reinterpret_cast<float4*>(dx_drop + row[k] * lddxd + lane * 4) =
+            make_float4(dropout_hash32(sd, e) >= thr ? gx.x * sc : 0.f, dropout_hash32(sd, e + 1) >= thr ? gx.y * sc : 0.f,
+                        dropout_hash32(sd, e + 2) >= thr ? gx.z * sc : 0.f, dropout_hash32(sd, e + 3) >= thr ? gx.w * sc : 0.f);
+      }
     }
   }
   // block-level reduction (LNB_WAVES waves) before the atomics: 256 + 256 (+ 256 + 1) atomics per block
@@ -89,7 +140,9 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < LNB_WAVES; ++w) t += red[q][w][c];
-    atomicAdd((q == 0 ? dgamma : q == 1 ? dbeta : ddot_w) + c, t);
+    // `replicas` > 1: the three parameter-gradient vectors are [replicas][256] scratch (zeroed by the caller, folded
+    // later): 512 blocks adding into ONE 256-float vector serialise in L2 (that was 2/3 of this kernel's time)
+    atomicAdd((q == 0 ? dgamma : q == 1 ? dbeta : ddot_w) + (blockIdx.x % replicas) * 256 + c, t);
   }
   if (dot_w && threadIdx.x == 0) {
     float t = 0.f;
@@ -103,8 +156,8 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
                                     const float* beta, float* dx, int64_t lddx, float* dgamma, float* dbeta,
                                     const float* dot_w, const float* dout, float* ddot_w, float* ddot_b, int B, int L,
                                     int C, const int64_t* len, float drop_p, uint64_t drop_seed, float in_drop_p,
-                                    uint64_t in_drop_seed, float* dx_drop, int64_t lddxd, void* stream) {
-  if (!x || !gamma || !dgamma || !dbeta || B <= 0 || L <= 0 || C != 256) return STYLER_EINVAL;
+                                    uint64_t in_drop_seed, float* dx_drop, int64_t lddxd, int replicas, void* stream) {
+  if (!x || !gamma || !dgamma || !dbeta || B <= 0 || L <= 0 || C != 256 || replicas < 1) return STYLER_EINVAL;
   if (!dot_w && !dy) return STYLER_EINVAL;
   if (dot_w && (!dout || !ddot_w || !ddot_b || !beta)) return STYLER_EINVAL;
   if ((ldx & 3) || (dy && (lddy & 3)) || (dx && (lddx & 3))) return STYLER_EALIGN;
@@ -114,7 +167,7 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(64 * LNB_WAVES), 0, (hipStream_t)stream, x, ldx, dy, lddy,
                      gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b, rows, L, len, drop_p, drop_seed,
-                     g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd);
+                     g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd, replicas);
   return launch_status();
 }
 

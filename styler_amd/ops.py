@@ -348,6 +348,7 @@ def bn_fold(gamma, beta, running_mean, running_var, conv_bias):
     return scale, shift
 
 
+LN_REPLICAS = 16           # scratch replicas of LayerNorm's parameter gradients inside a training step
 BN_WS_COPIES = 16        # STYLER_BN_COPIES (norms.hip): replicas of the 2C-double column accumulator
 
 
@@ -661,10 +662,25 @@ def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, do
         dy = _rows_view(dy)
     if dout is not None:
         dout = dout.contiguous()
+    # inside a training step the three parameter-gradient vectors go to zeroed 16-replica scratch (zero slab) and are
+    # folded by the backward's single multi-tensor reduce launch (WgradArena)
+    rep, pg, pb, pw = 1, dgamma, dbeta, ddot_w
+    arena, slab = wgrad_arena, zero_slab
+    if slab is not None:
+        nvec = 3 if ddot_w is not None else 2
+        sc = slab.take(nvec * LN_REPLICAS * 128)     # doubles = nvec * 16 * 256 floats (asked for in every pass: sizing)
+        if sc is not None and arena is not None and arena.buf is not None:
+            sc = sc.view(torch.float32).view(nvec, LN_REPLICAS, 256)
+            rep, pg, pb = LN_REPLICAS, sc[0], sc[1]
+            arena.descs.append((pg.data_ptr(), dgamma.data_ptr(), 1, 0, 0, 256, 1, 1, rep))
+            arena.descs.append((pb.data_ptr(), dbeta.data_ptr(), 1, 0, 0, 256, 1, 1, rep))
+            if ddot_w is not None:
+                pw = sc[2]
+                arena.descs.append((pw.data_ptr(), ddot_w.data_ptr(), 1, 0, 0, 256, 1, 1, rep))
     _chk(lib.styler_layernorm_bwd(x.data_ptr(), _ld(x), _ptr(dy), _ld(dy) if dy is not None else 0, gamma.data_ptr(),
-                                  _ptr(beta), _ptr(dx), C, dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dot_w),
-                                  _ptr(dout), _ptr(ddot_w), _ptr(ddot_b), B, L, C, _ptr(lens), float(drop_p),
-                                  int(drop_seed), float(in_drop_p), int(in_drop_seed), _ptr(dxd), C, _stream()),
+                                  _ptr(beta), _ptr(dx), C, pg.data_ptr(), pb.data_ptr(), _ptr(dot_w),
+                                  _ptr(dout), _ptr(pw), _ptr(ddot_b), B, L, C, _ptr(lens), float(drop_p),
+                                  int(drop_seed), float(in_drop_p), int(in_drop_seed), _ptr(dxd), C, rep, _stream()),
          "styler_layernorm_bwd")
     return (dx, dxd) if dxd is not None else dx
 
