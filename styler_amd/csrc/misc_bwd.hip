@@ -199,27 +199,56 @@ extern "C" int styler_length_regulate_bwd(const float* dy, int64_t lddy, const i
   return launch_status();
 }
 
-// ---- bucketise/embed/add backward: scatter dy rows into the two embedding tables --------------------------
+// ---- bucketise/embed/add backward: demb[table][bucket] += sum of the dy rows that looked the bucket up ----------
+// A scatter with atomics serialises on the popular buckets (bucket 0 collects every unvoiced frame: ~4000 atomics per
+// address, 119 us).  Instead one block OWNS a (table, bucket, row-slice): it scans the slice's ids (L2-resident) and sums
+// the matching dy rows in registers -- each row is read once per table, a handful of atomics per block remain.
+#define BEB_SLICES 16
 __global__ __launch_bounds__(256) void bucket_embed_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ pid,
                                                                const int32_t* __restrict__ eid, float* __restrict__ dpe,
-                                                               float* __restrict__ dee, int64_t rows) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const float4 g = *reinterpret_cast<const float4*>(dy + row * 256 + lane * 4);
-  if (g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) return;      // padded frames carry exactly zero gradient
-  float* p = dpe + (int64_t)pid[row] * 256 + lane * 4;
-  float* e = dee + (int64_t)eid[row] * 256 + lane * 4;
-  atomicAdd(p, g.x); atomicAdd(p + 1, g.y); atomicAdd(p + 2, g.z); atomicAdd(p + 3, g.w);
-  atomicAdd(e, g.x); atomicAdd(e + 1, g.y); atomicAdd(e + 2, g.z); atomicAdd(e + 3, g.w);
+                                                               float* __restrict__ dee, int64_t rows, int nbuckets) {
+  __shared__ float red[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bucket = blockIdx.x % nbuckets, table = blockIdx.x / nbuckets, slice = blockIdx.y;
+  const int32_t* ids = table ? eid : pid;
+  const int64_t per = (rows + BEB_SLICES - 1) / BEB_SLICES;
+  const int64_t r0 = slice * per, r1 = min(rows, r0 + per);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool any = false;
+  for (int64_t base = r0 + wave * 64; base < r1; base += 256) {          // 64 ids per wave and step, one per lane
+    const int64_t r = base + lane;
+    const bool hit = r < r1 && ids[r] == bucket;
+    uint64_t m = __ballot(hit);
+    while (m) {                                                          // the wave walks its matching rows together,
+      float4 g[4];                                                       // four row loads in flight
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m) {
+          const int k = __ffsll((unsigned long long)m) - 1;
+          m &= m - 1;
+          g[u] = *reinterpret_cast<const float4*>(dy + (base + k) * 256 + lane * 4);
+        }
+      }
+      acc.x += (g[0].x + g[1].x) + (g[2].x + g[3].x); acc.y += (g[0].y + g[1].y) + (g[2].y + g[3].y);
+      acc.z += (g[0].z + g[1].z) + (g[2].z + g[3].z); acc.w += (g[0].w + g[1].w) + (g[2].w + g[3].w);
+      any = true;
+    }
+  }
+  red[wave][lane * 4 + 0] = acc.x; red[wave][lane * 4 + 1] = acc.y; red[wave][lane * 4 + 2] = acc.z; red[wave][lane * 4 + 3] = acc.w;
+  const int hits = __syncthreads_or(any);
+  if (!hits) return;
+  const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (t != 0.f) atomicAdd((table ? dee : dpe) + (int64_t)bucket * 256 + threadIdx.x, t);
 }
 
 extern "C" int styler_bucket_embed_bwd(const float* dy, const int32_t* p_ids, const int32_t* e_ids, float* dpitch_emb,
                                        float* denergy_emb, int B, int T, void* stream) {
   if (!dy || !p_ids || !e_ids || !dpitch_emb || !denergy_emb || B <= 0 || T <= 0) return STYLER_EINVAL;
   const int64_t rows = (int64_t)B * T;
-  hipLaunchKernelGGL(bucket_embed_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dy,
-                     p_ids, e_ids, dpitch_emb, denergy_emb, rows);
+  const int nbuckets = 256;                            // hparams.n_bins (modules.py:278-281)
+  hipLaunchKernelGGL(bucket_embed_bwd_kernel, dim3(2 * nbuckets, BEB_SLICES), dim3(256), 0, (hipStream_t)stream, dy, p_ids,
+                     e_ids, dpitch_emb, denergy_emb, rows, nbuckets);
   return launch_status();
 }
 
