@@ -148,18 +148,21 @@ def run(args, mode, rank, world, dev, dist):
     ms = elapsed / args.steps * 1e3
     value = total_frames * args.steps / elapsed
     ps = max(1, args.prof_steps)
-    if train:       # dominant kernel of the step by time: the weight-gradient MFMA GEMM
-        if args.prec == "bf16":
-            dom, dom_name, peak = "wgrad_bf16", "wgrad_tr_kernel<KW,TA,TB> (all tap counts)", MFMA_PEAK_TFLOPS["bf16"]
-        else:
-            dom, dom_name, peak = "wgrad", "wgrad_kernel<KW> (all tap counts)", MFMA_PEAK_TFLOPS["fp32"]
+    big = 3 if args.prec == "bf16" else 1               # conv_gemm_kernel<2,2,...>: forward and dX launches
+    wg = "wgrad_bf16" if args.prec == "bf16" else "wgrad"
+    peak = MFMA_PEAK_TFLOPS[args.prec]
+    # the dominant MFMA kernel family of the step BY TIME (train: forward+dX engine vs weight-gradient engine)
+    if train and gsum.get(wg, {"ms": 0.0})["ms"] > gsum.get(big, {"ms": 0.0})["ms"]:
+        dom = wg
+        dom_name = ("wgrad_tr_kernel<KW,TA,TB>" if args.prec == "bf16" else "wgrad_kernel<KW>") + " (all tap counts)"
     else:
-        dom = 3 if args.prec == "bf16" else 1
-        dom_name, peak = VARIANT_NAMES[dom], MFMA_PEAK_TFLOPS[args.prec]
+        dom, dom_name = big, VARIANT_NAMES[big]
     d = gsum.get(dom, {"launches": 0, "flops": 0.0, "ms": 1.0})
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["launches"] else 0.0
     roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(train, args.prec),
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "traffic": pmc_traffic("train_wgrad_bf16" if dom == wg else
+                                       ("train_conv_gemm_2x2_bf16" if train else "fwd_conv_gemm_2x2_bf16"), args.prec),
                 "launches_per_step": d["launches"] // ps, "avg_launch_us": round(d["ms"] * 1e3 / max(1, d["launches"]), 2),
                 "kernel_ms_per_step": round(d["ms"] / ps, 3),
                 "all_mfma_gemm_ms_per_step": round(sum(v["ms"] for v in gsum.values()) / ps, 3)}
@@ -220,13 +223,12 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(train, prec):
-    """HBM-side bytes per launch of the dominant kernel, from the SEPARATE rocprofv3 --pmc passes of this same command
+def pmc_traffic(want, prec):
+    """HBM-side bytes per launch of the dominant kernel family `want`, from the SEPARATE rocprofv3 --pmc passes of this same command
     (tools/pmc_run.sh -> tools/pmc_traffic.py, committed as profiles/r01_pmc_traffic.jsonl; FETCH_SIZE doubled per the
     gfx950 correction).  PMC collection cannot run inside the timed process, so the figure is read from that file;
     null when it is absent or was taken for another precision."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.jsonl")
-    want = "train_wgrad_bf16" if train else "fwd_conv_gemm_2x2_bf16"
     if prec != "bf16" or not os.path.exists(path):
         return None
     for line in open(path):
