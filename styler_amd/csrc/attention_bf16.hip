@@ -66,6 +66,45 @@ __device__ __forceinline__ void stage_transposed(uint32_t* dstT, const float* sr
       make_uint4(cvtpk(v[0].w, v[1].w), cvtpk(v[2].w, v[3].w), cvtpk(v[4].w, v[5].w), cvtpk(v[6].w, v[7].w));
 }
 
+// The same two stagers split into a register load and an LDS store: the next tile's global loads are issued BEFORE the
+// current tile is multiplied and land in LDS after it (single LDS buffer, the HBM/L2 latency hides behind the MFMAs).
+__device__ __forceinline__ void load_rows(float4 (&v)[4], const float* src, int64_t ld, int row0, int nrows_valid, int tid) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int idx = tid + p * 256;
+    const int r = idx >> 4, c4 = (idx & 15) * 4;
+    v[p] = (row0 + r < nrows_valid) ? *reinterpret_cast<const float4*>(src + (int64_t)(row0 + r) * ld + c4)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+__device__ __forceinline__ void store_rows(uint32_t* dst, const float4 (&v)[4], int tid) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int idx = tid + p * 256;
+    const int r = idx >> 4, c4 = (idx & 15) * 4;
+    *reinterpret_cast<uint2*>(&dst[r * ALD + c4 / 2]) = make_uint2(cvtpk(v[p].x, v[p].y), cvtpk(v[p].z, v[p].w));
+  }
+}
+__device__ __forceinline__ void load_transposed(float4 (&v)[8], const float* src, int64_t ld, int row0, int nrows_valid, int t) {
+  const int g = t >> 4, q4 = (t & 15) * 4;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int r = row0 + g * 8 + e;
+    v[e] = (r < nrows_valid) ? *reinterpret_cast<const float4*>(src + (int64_t)r * ld + q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+__device__ __forceinline__ void store_transposed(uint32_t* dstT, const float4 (&v)[8], int t) {
+  const int g = t >> 4, q4 = (t & 15) * 4;
+  *reinterpret_cast<uint4*>(&dstT[(q4 + 0) * ALD + g * 4]) =
+      make_uint4(cvtpk(v[0].x, v[1].x), cvtpk(v[2].x, v[3].x), cvtpk(v[4].x, v[5].x), cvtpk(v[6].x, v[7].x));
+  *reinterpret_cast<uint4*>(&dstT[(q4 + 1) * ALD + g * 4]) =
+      make_uint4(cvtpk(v[0].y, v[1].y), cvtpk(v[2].y, v[3].y), cvtpk(v[4].y, v[5].y), cvtpk(v[6].y, v[7].y));
+  *reinterpret_cast<uint4*>(&dstT[(q4 + 2) * ALD + g * 4]) =
+      make_uint4(cvtpk(v[0].z, v[1].z), cvtpk(v[2].z, v[3].z), cvtpk(v[4].z, v[5].z), cvtpk(v[6].z, v[7].z));
+  *reinterpret_cast<uint4*>(&dstT[(q4 + 3) * ALD + g * 4]) =
+      make_uint4(cvtpk(v[0].w, v[1].w), cvtpk(v[2].w, v[3].w), cvtpk(v[4].w, v[5].w), cvtpk(v[6].w, v[7].w));
+}
+
 // A operand from a transposed tile: row d = dt*32 + li, the two 4-row runs of 32-row block `blk`, step s2, half lh
 __device__ __forceinline__ bf16x8 fragT(const uint32_t* tT, int dt, int li, int blk, int s2, int lh) {
   const uint32_t* p = &tT[(dt * 32 + li) * ALD + blk * 16 + s2 * 8 + lh * 2];
@@ -132,6 +171,8 @@ __global__ __launch_bounds__(256) void attention_fwd_bf16_kernel(const float* __
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * 64;
     __syncthreads();
+    // (a register prefetch of the next tile was measured here: 37.8 -> 75.8 us -- occupancy 3 -> 2 waves per SIMD and the
+    // loads' waits land in front of the MFMAs; the dK/dV kernel, at one wave per SIMD anyway, keeps its prefetch)
     stage_rows(sK, kbase, 768, k0, Lr, tid);
     if (tid < 128) stage_transposed(sVT, vbase, 768, k0, Lr, tid);
     __syncthreads();
@@ -239,6 +280,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_bf16_kernel(const float*
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * 64;
     __syncthreads();
+    // (no register prefetch here: +50 VGPRs would halve this kernel's occupancy, 2 -> 1 wave per SIMD)
     stage_rows(sK, kbase, 768, k0, Lr, tid);
     stage_rows(sV, vbase, 768, k0, Lr, tid);
     if (tid < 128) stage_transposed(sKT, kbase, 768, k0, Lr, tid);
@@ -318,13 +360,26 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_bf16_kernel(const float
   // so the query loop stops at klen; rows of the last tile past L are staged as zeros (lse = delta = 0 there).
   const bool block_live = blockIdx.x * 128 < klen;
   const int ntiles = block_live ? (klen + 63) / 64 : 0;
+  float4 rq[4], rdo[4], rt[8];
+  if (ntiles > 0) {
+    load_rows(rq, qbase, 768, 0, Lr, tid);
+    load_rows(rdo, dobase, 256, 0, Lr, tid);
+    if (tid < 128) load_transposed(rt, qbase, 768, 0, Lr, tid);
+    else load_transposed(rt, dobase, 256, 0, Lr, tid - 128);
+  }
   for (int qt = 0; qt < ntiles; ++qt) {
     const int qb = qt * 64;
     __syncthreads();
-    stage_rows(sQ, qbase, 768, qb, Lr, tid);
-    stage_rows(sDO, dobase, 256, qb, Lr, tid);
-    if (tid < 128) stage_transposed(sQT, qbase, 768, qb, Lr, tid);
-    else stage_transposed(sDOT, dobase, 256, qb, Lr, tid - 128);
+    store_rows(sQ, rq, tid);
+    store_rows(sDO, rdo, tid);
+    if (tid < 128) store_transposed(sQT, rt, tid);
+    else store_transposed(sDOT, rt, tid - 128);
+    if (qt + 1 < ntiles) {                             // next tile: in flight while this one is multiplied
+      load_rows(rq, qbase, 768, qb + 64, Lr, tid);
+      load_rows(rdo, dobase, 256, qb + 64, Lr, tid);
+      if (tid < 128) load_transposed(rt, qbase, 768, qb + 64, Lr, tid);
+      else load_transposed(rt, dobase, 256, qb + 64, Lr, tid - 128);
+    }
     if (tid < 64) {
       const int qq = qb + tid;
       // rows at or past klen: lse = +huge makes p exactly 0 (whatever dO / the forward's lse hold there)
