@@ -107,6 +107,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     const int64_t m1 = (m0 + BM < M ? m0 + BM : M) - 1;
     const int64_t b0 = m0 / a.L;
     if (b0 == m1 / a.L && m0 - b0 * a.L >= a.len[b0]) {
+      // packed rows: nothing behind the data is ever read (every consumer is bounded by the same row counter), so the
+      // tile is not even zero-filled -- that fill was 36 % of the output bytes of every decoder GEMM at VCTK shapes
+      if (a.rowinfo) return;
       constexpr int QPR = BN / 4;                    // float4 per tile row
       for (int i = tid; i < BM * QPR; i += 256) {
         const int r = i / QPR, c = n0 + (i - r * QPR) * 4;
