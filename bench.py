@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--dual", action="store_true", help="also run the noisy-branch decode (styler.py:55)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--split-graph", action="store_true",
+                    help="train: capture the two-graph step (all-reduce overlap) even on one rank (default for N > 1)")
     ap.add_argument("--prof-steps", type=int, default=3, help="extra eager steps with HIP-event GEMM brackets")
     ap.add_argument("--aux", action="store_true", help="also time the other mode and report it under 'aux'")
     ap.add_argument("--shape", default="vctk", choices=["vctk", "c4"],
@@ -114,7 +116,7 @@ def run(args, mode, rank, world, dev, dist):
                 step()
         go = graph.replay if graph is not None else step
         if train and not args.no_graph:         # forward + losses + backward replayed from one hipGraph; the
-            graph = GraphedTrainStep(model, state, bd)   # all-reduce, lr and clip + Adam launch stay eager
+            graph = GraphedTrainStep(model, state, bd, split=True if args.split_graph else None)
             go = graph
 
         for _ in range(args.warmup):
@@ -172,7 +174,8 @@ def run(args, mode, rank, world, dev, dist):
                 f"C2: STYLER.forward eval teacher-forced, {'dual' if args.dual else 'clean'}-branch, "
                 f"B={args.batch}/GPU, S={S}, T={T}, valid frames={frames}/GPU")
     res = {"value": round(value, 1), "ms_per_step": round(ms, 4), "workload": workload,
-           "launch": "hipGraph replay" if graph is not None else "eager", "roofline": roofline}
+           "launch": ("hipGraph replay" + (" (2 graphs, all-reduce between)" if train and len(getattr(graph, "graphs", ())) == 2
+                                           else "")) if graph is not None else "eager", "roofline": roofline}
     if host_ms is not None:
         res["host_enqueue_ms_per_step"] = round(host_ms, 2)
     if not args.no_cpu and world == 1:              # reported at N = 1 only (rank 0's host cores)

@@ -80,38 +80,6 @@ class ConvGemmFn(Function):
         return dx, (dy if ctx.has_res else None), None, None, None, None, None, None, None, None
 
 
-class QkvAttentionFn(Function):
-    """Fused QKV projection + attention (SubLayers.py:41-56)."""
-
-    @staticmethod
-    def forward(ctx, x, anchor, mha, lens, plan=None):
-        w, b, prec = mha._qkv()
-        qkv = ops.conv_gemm(x, w, b, n=768, prec=prec, plan=plan)
-        B, L = (plan.B, plan.T) if plan is not None else x.shape[:2]
-        lse = torch.empty(B, 4, L, device=x.device, dtype=torch.float32)
-        out = ops.attention_fwd(qkv, lens, lse=lse, plan=plan)
-        ctx.save_for_backward(x, qkv, out, lse, lens)
-        ctx.mha, ctx.plan = mha, plan
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        x, qkv, out, lse, lens = ctx.saved_tensors
-        mha, plan = ctx.mha, ctx.plan
-        dqkv = ops.attention_bwd(qkv, out, dout, lse, lens, plan=plan)
-        for i, lin in enumerate((mha.w_qs, mha.w_ks, mha.w_vs)):
-            sl = dqkv[..., i * 256:(i + 1) * 256]
-            ops.wgrad(sl, x, G(lin.weight), 256, 256, db=G(lin.bias), plan=plan)
-        d = mha._derived
-        srcs = [mha.w_qs.weight, mha.w_ks.weight, mha.w_vs.weight]
-        bf16 = rt.prec == ops.PREC_BF16
-        wt = d.get_spec("qkv_wT16" if bf16 else "qkv_wT", (256, 768), bf16,
-                        lambda: [seg_transposed(w, k * 256, 768) for k, w in enumerate(srcs)])
-        prec = ops.PREC_BF16 if bf16 else ops.PREC_F32
-        dx = ops.conv_gemm(dqkv, wt, None, n=256, prec=prec, plan=plan)
-        return dx, None, None, None, None
-
-
 class LayerNormFn(Function):
     """LayerNorm(x + res) with pad mask (SubLayers.py:59,87 + Layers.py:29,32)."""
 

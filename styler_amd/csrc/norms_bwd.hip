@@ -25,11 +25,9 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
   float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag, aw = ag;
   float adb = 0.f;
   // Two rows per wave and iteration: a row is a latency chain (two loads, then mean -> variance -> two more wave
-  // reductions); the chains of the two rows are independent and interleave.
-#ifndef LNB_R
-#define LNB_R 2
-#endif
-  constexpr int R = LNB_R;
+  // reductions); the chains of the two rows are independent and interleave.  (Measured: 1, 2 and 4 rows take the same
+  // 25 us -- the kernel was bound by its parameter-gradient atomics, see `replicas`.)
+  constexpr int R = 2;
   for (int64_t row0 = w0; row0 < rows; row0 += wstride * R) {
     int64_t row[R];
     bool live[R];

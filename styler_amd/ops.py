@@ -84,6 +84,14 @@ class WgradArena:
         self.used += nfloats
         return out
 
+    def _top_up_pinned(self, capturing):
+        """Pinned staging buffers cannot be allocated while a hipGraph is being captured (and a captured memcpy node
+        re-reads its buffer at every replay, so each table owns one): keep a reserve from the eager steps -- a capture
+        may flush more than once (split step) and may be retried."""
+        if not capturing:
+            while len(self._pinned_pool) < 6:
+                self._pinned_pool.append(torch.empty(self.GROUP_TABLE_BYTES, dtype=torch.uint8).pin_memory())
+
     def flush(self, device):
         import ctypes
         import numpy as np
@@ -92,9 +100,7 @@ class WgradArena:
             arr = (WgradGroupDesc * len(self.group))(*self.group)
             key = bytes(arr)
             capturing = torch.cuda.is_current_stream_capturing()
-            if not capturing:                        # pinned staging buffers cannot be allocated while a hipGraph is
-                while len(self._pinned_pool) < 2:    # being captured: keep two in reserve from the eager steps
-                    self._pinned_pool.append(torch.empty(self.GROUP_TABLE_BYTES, dtype=torch.uint8).pin_memory())
+            self._top_up_pinned(capturing)
             if key not in self._gcache:
                 if len(self._gcache) > 8 and not capturing:
                     self._gcache.clear()
@@ -109,6 +115,7 @@ class WgradArena:
             _chk(lib.styler_wgrad_group(table.data_ptr(), len(self.group), self.group_blocks, _stream()),
                  "styler_wgrad_group")
             self.group, self.group_blocks, self.group_keep = [], 0, []
+            self._top_up_pinned(capturing)
         if not self.descs:
             return
         key = tuple(self.descs)
@@ -274,16 +281,6 @@ def set_dropout_counter(counter):
 def cast_bf16(src):
     dst = torch.empty(src.shape, device=src.device, dtype=torch.bfloat16)
     _chk(lib.styler_cast_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "styler_cast_bf16")
-    return dst
-
-
-def repack_conv_weight(w, to_kernel_layout=True, bf16=False):
-    """[n, cin, kw] -> [n, kw*cin] (kernel layout), fp32 or directly the bf16 shadow."""
-    assert to_kernel_layout
-    n, cin, kw = w.shape
-    dst = torch.empty(n, kw * cin, device=w.device, dtype=torch.bfloat16 if bf16 else torch.float32)
-    _chk(lib.styler_repack_conv_weight(w.data_ptr(), dst.data_ptr(), n, cin, kw, 1, int(bf16), _stream()),
-         "styler_repack_conv_weight")
     return dst
 
 
@@ -623,18 +620,6 @@ def colsum(dz, out, out2=None):
     C = dz.shape[-1]
     rows = dz.numel() // C
     _chk(lib.styler_colsum(dz.data_ptr(), _ld(dz), out.data_ptr(), _ptr(out2), rows, C, _stream()), "styler_colsum")
-
-
-def repack_weight_bwd(w, bf16=False):
-    """parameter layout [n, cin, kw] (or [n, cin]) -> dX-conv weight [cin, kw*n] (taps flipped), fp32 or bf16."""
-    if w.dim() == 2:
-        n, cin, kw = w.shape[0], w.shape[1], 1
-    else:
-        n, cin, kw = w.shape
-    dst = torch.empty(cin, kw * n, device=w.device, dtype=torch.bfloat16 if bf16 else torch.float32)
-    _chk(lib.styler_repack_weight_bwd(w.data_ptr(), dst.data_ptr(), n, cin, kw, int(bf16), _stream()),
-         "styler_repack_weight_bwd")
-    return dst
 
 
 def attention_bwd(qkv, out, dout, lse, lens, prec=None, plan=None):

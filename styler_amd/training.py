@@ -46,6 +46,7 @@ class TrainState:
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
         self.arena = ops.WgradArena()                  # split-K partials of every weight gradient of one backward
         self.zero_slab = ops.ZeroSlab()
+        self.split_hook = None                         # set while GraphedTrainStep captures its two graphs
         self.overlap_allreduce = True                  # start the decoder-side all-reduce from inside backward
         # device step counter mixed into every dropout seed: host seeds are baked into a captured hipGraph, the
         # counter is what changes between replays (styler_set_dropout_counter)
@@ -140,7 +141,7 @@ def forward_backward(model, state, batch, loss_fn=None, dat_fn=None):
     ops.zero_slab = state.zero_slab
     try:
         losses = train_losses(model, batch, loss_fn, dat_fn)
-        rt.grad_ready_hook = state.on_decoder_grads_ready if state.overlap_allreduce else None
+        rt.grad_ready_hook = state.split_hook or (state.on_decoder_grads_ready if state.overlap_allreduce else None)
         state.arena.begin(state.flat_g.device)
         ops.wgrad_arena = state.arena
         (losses[0] / hp.acc_steps).backward()
@@ -160,40 +161,101 @@ def train_step(model, state, batch, loss_fn=None, dat_fn=None):
 
 
 class GraphedTrainStep:
-    """The training step with forward + losses + backward replayed from ONE hipGraph (about 1300 kernel launches per
-    step; launched eagerly the host needs as long to enqueue them as the GPU needs to run them).  Outside the graph
-    stay the steps that take host decisions: the RCCL all-reduce of the flat gradient, the Noam learning rate and
-    the fused clip + Adam launch (`TrainState.step`).
+    """The training step with forward + losses + backward replayed from hipGraphs (about 900 kernel launches per step;
+    launched eagerly the host needs as long to enqueue them as the GPU needs to run them).  Outside the graphs stay the
+    steps that take host decisions: the RCCL all-reduce of the flat gradient, the Noam learning rate and the fused
+    clip + Adam launch (`TrainState.step`).
 
-    The graph is captured for the shapes of `batch`; `__call__(batch)` copies a new batch of the same shapes into the
+    `split=True` (default when torch.distributed runs with more than one rank) captures TWO graphs, cut where backward has
+    finished both decode branches (BucketEmbedAddFn.backward): the decoder + mel_linear + PostNet gradient range (55 % of
+    the bytes) is final there, so its bucketed all-reduce is launched between the two replays and runs on RCCL's stream
+    while the second graph back-propagates the style encoders and predictors.  `split=False`: one graph, the whole buffer
+    is reduced after it.
+
+    The graphs are captured for the shapes of `batch`; `__call__(batch)` copies a new batch of the same shapes into the
     static input tensors (callers bucket their batches by padded shape and keep one instance per bucket).  The
-    all-reduce is not started from inside backward in this mode (a captured step has no host hook), and the
-    reference's host-side range assertion on p_norm / e_input (utils.py:423) is not evaluated inside the graph."""
+    reference's host-side range assertion on p_norm / e_input (utils.py:423) is not evaluated inside the graphs."""
 
-    def __init__(self, model, state, batch, warmup=3, loss_fn=None, dat_fn=None):
+    def __init__(self, model, state, batch, warmup=3, loss_fn=None, dat_fn=None, split=None):
+        import torch.distributed as dist
         self.model, self.state = model, state
         self.static = {k: v.clone() for k, v in batch.items()}
+        if split is None:
+            split = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         state.overlap_allreduce = False
         strict, rt.strict_inputs = rt.strict_inputs, False    # the [0, 1] input assertion is a host sync (utils.py:423)
         try:
-            self._capture(model, state, warmup, loss_fn, dat_fn)
+            self._warmup(model, state, warmup, loss_fn, dat_fn, split)
+            self.graphs = None
+            if split:
+                try:
+                    self._capture_split(model, state, loss_fn, dat_fn)
+                except Exception as e:                  # keep training alive: fall back to the single graph
+                    import warnings
+                    warnings.warn(f"split hipGraph capture failed ({type(e).__name__}: {e}); using one graph")
+                    self.graphs = None
+                    torch.cuda.synchronize()
+            if self.graphs is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g), torch.enable_grad():
+                    self.losses = forward_backward(model, state, self.static, loss_fn, dat_fn)
+                self.graphs = (g,)
+            # a capture does not execute: its step-counter increment and BatchNorm momentum updates are part of the
+            # graph, nothing to undo
         finally:
             rt.strict_inputs = strict
 
-    def _capture(self, model, state, warmup, loss_fn, dat_fn):
+    def _warmup(self, model, state, warmup, loss_fn, dat_fn, split):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.enable_grad():
-            for _ in range(warmup):                     # sizes the wgrad arena, builds its descriptor table
-                forward_backward(model, state, self.static, loss_fn, dat_fn)
-                state.step()
+        if split:                                       # same flush pattern as the split capture: its descriptor tables
+            state.split_hook = lambda: state.arena.flush(state.flat_g.device)   # must exist before (no H2D in a capture)
+        try:
+            with torch.cuda.stream(side), torch.enable_grad():
+                for _ in range(warmup):                 # sizes the wgrad arena / zero slab, builds the descriptor tables
+                    forward_backward(model, state, self.static, loss_fn, dat_fn)
+                    state.step()
+        finally:
+            state.split_hook = None
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.enable_grad():
-            self.losses = forward_backward(model, state, self.static, loss_fn, dat_fn)
-        # the capture itself did not execute: its step counter increment and BatchNorm momentum updates are part of
-        # the graph, nothing to undo
+
+    def _capture_split(self, model, state, loss_fn, dat_fn):
+        """Two graphs sharing one memory pool, cut inside backward by the decoder-gradients-ready hook.  Backward must run
+        on the capturing thread for that (a stream capture is ended by the thread that began it)."""
+        import gc
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        cut = {"done": False}
+
+        def split_here():
+            if cut["done"]:
+                return
+            state.arena.flush(state.flat_g.device)      # fold the decoder-side split-K partials: that range is final now
+            ga.capture_end()
+            gb.capture_begin(pool=ga.pool())
+            cut["done"] = True
+
+        gc.collect()
+        torch.cuda.empty_cache()
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        mt = torch.autograd.is_multithreading_enabled()
+        torch.autograd.set_multithreading_enabled(False)
+        state.split_hook = split_here
+        try:
+            with torch.cuda.stream(stream), torch.enable_grad():
+                ga.capture_begin()
+                try:
+                    self.losses = forward_backward(model, state, self.static, loss_fn, dat_fn)
+                finally:
+                    (gb if cut["done"] else ga).capture_end()
+        finally:
+            state.split_hook = None
+            torch.autograd.set_multithreading_enabled(mt)
+        torch.cuda.current_stream().wait_stream(stream)
+        if not cut["done"]:
+            raise RuntimeError("backward never reached the decoder-gradients-ready hook")
+        self.graphs = (ga, gb)
 
     def __call__(self, batch=None):
         if batch is not None:
@@ -202,6 +264,10 @@ class GraphedTrainStep:
                     raise ValueError(f"GraphedTrainStep was captured for {k} of shape {tuple(self.static[k].shape)}, "
                                      f"got {tuple(v.shape)}")
                 self.static[k].copy_(v, non_blocking=True)
-        self.graph.replay()
-        lr = self.state.step()
+        st = self.state
+        self.graphs[0].replay()
+        if len(self.graphs) == 2:
+            st._tail_works = allreduce_mean_(st.flat_g[st.tail_start:])    # overlaps the second graph
+            self.graphs[1].replay()
+        lr = st.step()
         return self.losses, lr

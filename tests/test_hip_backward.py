@@ -516,3 +516,31 @@ def test_fused_dropout_add_layernorm(dev):
     assert 0.7 < kept < 0.9
     check(ya, yb, 1e-6, "fwd"); check(xa.grad, xb.grad, 1e-6, "dx (through the mask)"); check(ra.grad, rb.grad, 1e-6, "dres")
     check(ga, ln.weight.grad, 1e-5, "dgamma"); check(gb, ln.bias.grad, 1e-5, "dbeta")
+
+
+def test_split_graph_step_matches_single_graph(dev, ref_state_dict):
+    """GraphedTrainStep(split=True) -- two graphs cut where the decoder-side gradients are final, so that their all-reduce
+    can run between the replays -- must walk exactly the trajectory of the single-graph step (dropout off)."""
+    from closed_form import make_batch
+    from styler_amd import STYLER, rt
+    from styler_amd.training import GraphedTrainStep, TrainState
+    b = {k: v.to(dev) for k, v in make_batch(4, 20, 40, 2, 9, seed=36).items()}
+    rt.disable_dropout = True
+    try:
+        finals = []
+        for split in (False, True):
+            m = STYLER()
+            m.load_state_dict(ref_state_dict)
+            m = m.to(dev).train()
+            st = TrainState(m)
+            g = GraphedTrainStep(m, st, b, warmup=3, split=split)
+            assert len(g.graphs) == (2 if split else 1)
+            for _ in range(3):
+                losses, lr = g(b)
+            finals.append((torch.stack([x.detach().float().reshape(()) for x in losses]).cpu(), st.flat_p.clone(), lr))
+        (l1, p1, lr1), (l2, p2, lr2) = finals
+        assert lr1 == lr2
+        assert float((l1 - l2).abs().max()) <= 2e-4 * max(1.0, float(l1.abs().max())), (l1, l2)
+        assert float((p1 - p2).abs().max()) <= 1e-4
+    finally:
+        rt.disable_dropout = False
