@@ -170,11 +170,13 @@ int styler_bn_fold(const float* gamma, const float* beta, const float* running_m
  * var per channel of x (= conv output incl. bias), writes y = act((x-mean)*rstd*g + b),
  * saves mean / rstd [C] for backward and updates running stats with momentum 0.1
  * (unbiased var), as torch.nn.BatchNorm1d does.  workspace: 16 * 2*C doubles (16 replicas of the
- * column accumulator, spreading the fp64 atomics), zeroed here. */
+ * column accumulator, spreading the fp64 atomics), zeroed here.
+ * drop_p > 0: y = dropout(act(BN(x))) -- the F.dropout of Layers.py:126-128 in the same pass, with the stream
+ * styler_dropout(seed drop_seed) would draw on the [rows, C] tensor. */
 int styler_batchnorm_train(const float* x, const float* gamma, const float* beta, float* y,
                            float* save_mean, float* save_rstd, float* running_mean,
                            float* running_var, double* workspace, int ws_zeroed, int64_t rows, int C,
-                           int act, void* stream);
+                           int act, float drop_p, uint64_t drop_seed, void* stream);
 
 /* ---- embeddings / positions ---------------------------------------------------------
  * out[b,t,:] = emb[text[b,t],:] + pe[t,:]            (Models.py:73-74; emb [152,256])
@@ -393,11 +395,13 @@ int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const float* dy, int6
                               int64_t lddx, float* dgamma, float* dbeta, double* workspace, int ws_zeroed,
                               int B, int L, int C, void* stream);
 
-/* BatchNorm1d(train)+act backward; x, y, dy, dx contiguous [rows, C]; workspace 16 * 2*C doubles. */
+/* BatchNorm1d(train)+act(+dropout) backward; x, y, dy, dx contiguous [rows, C]; workspace 16 * 2*C doubles.
+ * y may be NULL when beta is given: the tanh output is then recomputed from x (one read less); drop_p / drop_seed
+ * must repeat the forward's (the mask is regenerated, dy is the gradient of the dropped output). */
 int styler_batchnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
                          const float* save_mean, const float* save_rstd, float* dx, float* dgamma,
                          float* dbeta, double* workspace, int ws_zeroed, int64_t rows, int C, int act,
-                         void* stream);
+                         const float* beta, float drop_p, uint64_t drop_seed, void* stream);
 
 int styler_embed_bwd(const int64_t* text, const float* dy, int64_t lddy, float* demb, int B, int L,
                      int C, void* stream);

@@ -243,18 +243,26 @@ class GroupNormReluFn(Function):
 
 
 class BatchNormActFn(Function):
+    """dropout(act(BatchNorm1d_train(x))) (Layers.py:91-128) in one pass; backward regenerates the dropout mask and
+    recomputes the tanh output from x instead of saving it."""
+
     @staticmethod
-    def forward(ctx, x, anchor, bn, act):
-        y, mean, rstd = ops.batchnorm_train(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, act)
-        ctx.save_for_backward(x, y, mean, rstd)
-        ctx.bn, ctx.act = bn, act
+    def forward(ctx, x, anchor, bn, act, drop_p=0.0):
+        drop_p = 0.0 if rt.disable_dropout else drop_p
+        seed = next_dropout_seed() if drop_p > 0 else 0
+        y, mean, rstd = ops.batchnorm_train(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, act,
+                                            drop_p=drop_p, drop_seed=seed)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.bn, ctx.act, ctx.drop = bn, act, (drop_p, seed)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, rstd = ctx.saved_tensors
+        x, mean, rstd = ctx.saved_tensors
         bn = ctx.bn
-        return ops.batchnorm_bwd(x, y, dy, bn.weight, mean, rstd, G(bn.weight), G(bn.bias), ctx.act), None, None, None
+        dx = ops.batchnorm_bwd(x, None, dy, bn.weight, mean, rstd, G(bn.weight), G(bn.bias), ctx.act, beta=bn.bias,
+                               drop_p=ctx.drop[0], drop_seed=ctx.drop[1])
+        return dx, None, None, None, None
 
 
 class EmbedPosFn(Function):

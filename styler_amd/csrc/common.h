@@ -76,3 +76,20 @@ __device__ __forceinline__ uint32_t dropout_hash32(uint64_t seed, uint64_t idx) 
   z ^= z >> 31;
   return (uint32_t)(z >> 32);
 }
+
+// Gradient w.r.t. the BatchNorm output of y = dropout(act(BN(x))) for one element: the dropout keep mask is regenerated
+// from (seed, element index), the tanh output is recomputed from x (gamma/beta/mean/rstd) unless `yv` supplies it.
+struct BnDrop { float p; uint64_t seed; };
+__device__ __forceinline__ float bn_dz_elem(float g, float xh, float ga, float be, int act, const float* yv, float drop_p,
+                                            uint64_t seed, uint64_t e) {
+  if (drop_p > 0.f) {
+    const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);
+    g = dropout_hash32(seed, e) >= thr ? g * (1.f / (1.f - drop_p)) : 0.f;
+  }
+  if (act == STYLER_ACT_TANH) {
+    const float o = yv ? *yv : tanhf(xh * ga + be);
+    g *= 1.f - o * o;
+  }
+  return g;
+}
+

@@ -201,7 +201,10 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                           const float* __restrict__ dy, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, double* __restrict__ ws,
-                                                          int64_t rows, int C, int act) {
+                                                          int64_t rows, int C, int act, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float drop_p,
+                                                          uint64_t drop_seed_host, const uint64_t* __restrict__ epoch) {
+  const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   __shared__ double red[256][8];
   const int nq = C / 4;
   const int nqt = nq < 256 ? nq : 256;               // threads across a row
@@ -215,19 +218,26 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restric
     const int q = q0 + ql;
     double s[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
     if (live && q < nq) {
-      float4 m = make_float4(0.f, 0.f, 0.f, 0.f), rs = m;
-      if (BWD) { m = *reinterpret_cast<const float4*>(mean + q * 4); rs = *reinterpret_cast<const float4*>(rstd + q * 4); }
+      float4 m = make_float4(0.f, 0.f, 0.f, 0.f), rs = m, ga = m, be = m;
+      if (BWD) {
+        m = *reinterpret_cast<const float4*>(mean + q * 4); rs = *reinterpret_cast<const float4*>(rstd + q * 4);
+        ga = *reinterpret_cast<const float4*>(gamma + q * 4);
+        if (beta) be = *reinterpret_cast<const float4*>(beta + q * 4);
+      }
       for (int64_t r = r0 + rl; r < r1; r += lanes) {
         const float4 v = *reinterpret_cast<const float4*>(x + r * C + q * 4);
         if (BWD) {
           float4 g = *reinterpret_cast<const float4*>(dy + r * C + q * 4);
-          if (act == STYLER_ACT_TANH) {
-            const float4 o = *reinterpret_cast<const float4*>(y + r * C + q * 4);
-            g.x *= 1.f - o.x * o.x; g.y *= 1.f - o.y * o.y; g.z *= 1.f - o.z * o.z; g.w *= 1.f - o.w * o.w;
-          }
+          float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (y && act == STYLER_ACT_TANH) o = *reinterpret_cast<const float4*>(y + r * C + q * 4);
+          const float hx = (v.x - m.x) * rs.x, hy = (v.y - m.y) * rs.y, hz = (v.z - m.z) * rs.z, hw = (v.w - m.w) * rs.w;
+          const uint64_t e = (uint64_t)(r * C + q * 4);
+          g.x = bn_dz_elem(g.x, hx, ga.x, be.x, act, y ? &o.x : nullptr, drop_p, drop_seed, e);
+          g.y = bn_dz_elem(g.y, hy, ga.y, be.y, act, y ? &o.y : nullptr, drop_p, drop_seed, e + 1);
+          g.z = bn_dz_elem(g.z, hz, ga.z, be.z, act, y ? &o.z : nullptr, drop_p, drop_seed, e + 2);
+          g.w = bn_dz_elem(g.w, hw, ga.w, be.w, act, y ? &o.w : nullptr, drop_p, drop_seed, e + 3);
           s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
-          t[0] += (double)g.x * ((v.x - m.x) * rs.x); t[1] += (double)g.y * ((v.y - m.y) * rs.y);
-          t[2] += (double)g.z * ((v.z - m.z) * rs.z); t[3] += (double)g.w * ((v.w - m.w) * rs.w);
+          t[0] += (double)g.x * hx; t[1] += (double)g.y * hy; t[2] += (double)g.z * hz; t[3] += (double)g.w * hw;
         } else {
           s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
           t[0] += (double)v.x * v.x; t[1] += (double)v.y * v.y; t[2] += (double)v.z * v.z; t[3] += (double)v.w * v.w;
@@ -261,14 +271,19 @@ __global__ void bn_fold_copies_kernel(double* __restrict__ ws, int C2) {
 }
 
 int styler_bn_colstats(bool bwd, const float* x, const float* y, const float* dy, const float* mean, const float* rstd,
-                       double* ws, int ws_zeroed, int64_t rows, int C, int act, hipStream_t st) {
+                       double* ws, int ws_zeroed, int64_t rows, int C, int act, const float* gamma, const float* beta,
+                       float drop_p, uint64_t drop_seed, hipStream_t st) {
   if (!ws_zeroed) {
     hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * STYLER_BN_COPIES, st);
     if (e != hipSuccess) return (int)e;
   }
   const dim3 grid((unsigned)((rows + BN_RPB - 1) / BN_RPB));
-  if (bwd) hipLaunchKernelGGL(bn_colstats_kernel<true>, grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, rows, C, act);
-  else hipLaunchKernelGGL(bn_colstats_kernel<false>, grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, rows, C, act);
+  if (bwd)
+    hipLaunchKernelGGL(bn_colstats_kernel<true>, grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, rows, C, act, gamma, beta,
+                       drop_p, drop_seed, g_styler_drop_epoch);
+  else
+    hipLaunchKernelGGL(bn_colstats_kernel<false>, grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, rows, C, act, gamma, beta,
+                       drop_p, drop_seed, g_styler_drop_epoch);
   hipLaunchKernelGGL(bn_fold_copies_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, ws, 2 * C);
   return 0;
 }
@@ -294,8 +309,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ beta,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, float* __restrict__ y,
-                                                       int64_t total4, int C, int act) {
+                                                       int64_t total4, int C, int act, float drop_p,
+                                                       uint64_t drop_seed_host, const uint64_t* __restrict__ epoch) {
   const int nq = C / 4;
+  const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
+  const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);
+  const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     const int q = (int)(i % nq);
     const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
@@ -308,23 +327,33 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     o.y = apply_act((v.y - m.y) * r.y * g.y + b.y, act);
     o.z = apply_act((v.z - m.z) * r.z * g.z + b.z, act);
     o.w = apply_act((v.w - m.w) * r.w * g.w + b.w, act);
+    if (drop_p > 0.f) {                              // F.dropout after the activation (Layers.py:126-128), the stream
+      const uint64_t e = (uint64_t)i * 4;            // styler_dropout would draw on the [rows, C] tensor
+      o.x = dropout_hash32(drop_seed, e) >= thr ? o.x * sc : 0.f;
+      o.y = dropout_hash32(drop_seed, e + 1) >= thr ? o.y * sc : 0.f;
+      o.z = dropout_hash32(drop_seed, e + 2) >= thr ? o.z * sc : 0.f;
+      o.w = dropout_hash32(drop_seed, e + 3) >= thr ? o.w * sc : 0.f;
+    }
     *reinterpret_cast<float4*>(y + i * 4) = o;
   }
 }
 
 extern "C" int styler_batchnorm_train(const float* x, const float* gamma, const float* beta, float* y,
                                       float* save_mean, float* save_rstd, float* running_mean, float* running_var,
-                                      double* workspace, int ws_zeroed, int64_t rows, int C, int act, void* stream) {
-  if (!x || !gamma || !beta || !y || !save_mean || !save_rstd || !workspace || rows <= 0 || C <= 0 || (C & 3))
+                                      double* workspace, int ws_zeroed, int64_t rows, int C, int act, float drop_p,
+                                      uint64_t drop_seed, void* stream) {
+  if (!x || !gamma || !beta || !y || !save_mean || !save_rstd || !workspace || rows <= 0 || C <= 0 || (C & 3) ||
+      drop_p < 0.f || drop_p >= 1.f)
     return STYLER_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int rc = styler_bn_colstats(false, x, nullptr, nullptr, nullptr, nullptr, workspace, ws_zeroed, rows, C, act, st);
+  const int rc = styler_bn_colstats(false, x, nullptr, nullptr, nullptr, nullptr, workspace, ws_zeroed, rows, C, act, nullptr,
+                                    nullptr, 0.f, 0, st);
   if (rc) return rc;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, save_mean, save_rstd,
                      running_mean, running_var, rows, C);
   const int64_t total4 = rows * C / 4;
   int64_t blocks = (total4 + 255) / 256; if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta, save_mean, save_rstd,
-                     y, total4, C, act);
+                     y, total4, C, act, drop_p, drop_seed, g_styler_drop_epoch);
   return launch_status();
 }

@@ -287,34 +287,39 @@ extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const floa
 // BatchNorm1d (train) + act backward over rows = B*L (pads included), channels-last contiguous [rows, C].
 //   dz = dy * act'(y); dgamma = sum dz*xh; dbeta = sum dz; dx = g*rstd*(dz - dbeta/N - xh*dgamma/N)
 int styler_bn_colstats(bool bwd, const float* x, const float* y, const float* dy, const float* mean, const float* rstd,
-                       double* ws, int ws_zeroed, int64_t rows, int C, int act, hipStream_t st);   // norms.hip
+                       double* ws, int ws_zeroed, int64_t rows, int C, int act, const float* gamma, const float* beta,
+                       float drop_p, uint64_t drop_seed, hipStream_t st);   // norms.hip
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const double* __restrict__ ws, float* __restrict__ dx,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           int64_t rows, int C, int act) {
+                                                           int64_t rows, int C, int act, const float* __restrict__ beta,
+                                                           float drop_p, uint64_t drop_seed_host,
+                                                           const uint64_t* __restrict__ epoch) {
   const int nq = C / 4;
   const int64_t total4 = rows * nq;
   const double inv_n = 1.0 / (double)rows;
+  const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     const int q = (int)(i % nq);
     const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
-    float4 g = *reinterpret_cast<const float4*>(dy + i * 4);
-    if (act == STYLER_ACT_TANH) {
-      const float4 o = *reinterpret_cast<const float4*>(y + i * 4);
-      g.x *= 1.f - o.x * o.x; g.y *= 1.f - o.y * o.y; g.z *= 1.f - o.z * o.z; g.w *= 1.f - o.w * o.w;
-    }
+    const float4 g = *reinterpret_cast<const float4*>(dy + i * 4);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y && act == STYLER_ACT_TANH) o = *reinterpret_cast<const float4*>(y + i * 4);
     const float4 ga = *reinterpret_cast<const float4*>(gamma + q * 4);
+    const float4 be = beta ? *reinterpret_cast<const float4*>(beta + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 m = *reinterpret_cast<const float4*>(mean + q * 4);
     const float4 rs = *reinterpret_cast<const float4*>(rstd + q * 4);
     float out[4];
-    const float gv[4] = {g.x, g.y, g.z, g.w}, xv[4] = {v.x, v.y, v.z, v.w};
+    float gv[4] = {g.x, g.y, g.z, g.w};
+    const float xv[4] = {v.x, v.y, v.z, v.w}, ov[4] = {o.x, o.y, o.z, o.w}, bev[4] = {be.x, be.y, be.z, be.w};
     const float gav[4] = {ga.x, ga.y, ga.z, ga.w}, mv[4] = {m.x, m.y, m.z, m.w}, rv[4] = {rs.x, rs.y, rs.z, rs.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float xh = (xv[k] - mv[k]) * rv[k];
+      gv[k] = bn_dz_elem(gv[k], xh, gav[k], bev[k], act, y ? &ov[k] : nullptr, drop_p, drop_seed, (uint64_t)i * 4 + k);
       const float sb = (float)(ws[q * 4 + k] * inv_n), sg = (float)(ws[C + q * 4 + k] * inv_n);
       out[k] = gav[k] * rv[k] * (gv[k] - sb - xh * sg);
     }
@@ -328,17 +333,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 extern "C" int styler_batchnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
                                     const float* save_mean, const float* save_rstd, float* dx, float* dgamma,
                                     float* dbeta, double* workspace, int ws_zeroed, int64_t rows, int C, int act,
-                                    void* stream) {
+                                    const float* beta, float drop_p, uint64_t drop_seed, void* stream) {
   if (!x || !dy || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || C <= 0 ||
-      (C & 3) || (act == STYLER_ACT_TANH && !y))
+      (C & 3) || (act == STYLER_ACT_TANH && !y && !beta) || drop_p < 0.f || drop_p >= 1.f)
     return STYLER_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int rc = styler_bn_colstats(true, x, y, dy, save_mean, save_rstd, workspace, ws_zeroed, rows, C, act, st);
+  const int rc = styler_bn_colstats(true, x, y, dy, save_mean, save_rstd, workspace, ws_zeroed, rows, C, act, gamma, beta,
+                                    drop_p, drop_seed, st);
   if (rc) return rc;
   const int64_t total4 = rows * C / 4;
   int64_t blocks = (total4 + 255) / 256; if (blocks > 4096) blocks = 4096;
   if (blocks * 256 < C) blocks = (C + 255) / 256;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd,
-                     workspace, dx, dgamma, dbeta, rows, C, act);
+                     workspace, dx, dgamma, dbeta, rows, C, act, beta, drop_p, drop_seed, g_styler_drop_epoch);
   return launch_status();
 }

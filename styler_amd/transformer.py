@@ -241,13 +241,15 @@ class PostNet(_HipModule):
             act = ops.ACT_NONE if last else ops.ACT_TANH
             if self.training:
                 y = self._gemm(f"c{i}", x, conv, kw=self.kernel_size)
+                # BatchNorm (batch statistics) + tanh + F.dropout(.., 0.5, self.training) (Layers.py:126-128): one pass
                 if (self.training and torch.is_grad_enabled()):
-                    y = AG.BatchNormActFn.apply(y, bn.weight, bn, act)
+                    y = AG.BatchNormActFn.apply(y, bn.weight, bn, act, 0.5)
                 else:
-                    y, _, _ = ops.batchnorm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, act)
+                    p = 0.0 if rt.disable_dropout else 0.5
+                    y, _, _ = ops.batchnorm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, act,
+                                                  drop_p=p, drop_seed=AG.next_dropout_seed() if p > 0 else 0)
                 with torch.no_grad():
                     bn.num_batches_tracked += 1
-                y = AG.dropout(y, 0.5, True)                     # F.dropout(.., 0.5, self.training), Layers.py:126-128
                 if last and add_residual is not None:
                     y = AG.Add2Fn.apply(y, add_residual) if (self.training and torch.is_grad_enabled()) else ops.add2(y, add_residual)
                 x = y

@@ -544,3 +544,33 @@ def test_split_graph_step_matches_single_graph(dev, ref_state_dict):
         assert float((p1 - p2).abs().max()) <= 1e-4
     finally:
         rt.disable_dropout = False
+
+
+def test_fused_batchnorm_tanh_dropout(dev):
+    """BatchNormActFn with drop_p > 0 (BatchNorm batch statistics + tanh + dropout in one pass; backward regenerates the
+    mask and recomputes tanh from x) vs the unfused chain BatchNormActFn(drop 0) -> DropoutFn with the SAME seed."""
+    from styler_amd import autograd as AG, rt
+    g = torch.Generator().manual_seed(9)
+    B, L, C, p = 3, 29, 512, 0.5
+    x = (torch.randn(B, L, C, generator=g) * 1.5 + 0.2).to(dev)
+    gy = torch.randn(B, L, C, generator=g).to(dev)
+    res = {}
+    for fused in (True, False):
+        bn = nn.BatchNorm1d(C).to(dev)
+        with torch.no_grad():
+            bn.weight.copy_(torch.randn(C, generator=torch.Generator().manual_seed(1)))
+            bn.bias.copy_(torch.randn(C, generator=torch.Generator().manual_seed(2)))
+        xa = x.clone().requires_grad_(True)
+        calls0 = rt.dropout_calls
+        if fused:
+            y = AG.BatchNormActFn.apply(xa, bn.weight, bn, AG.TANH, p)
+            seed = (rt.seed * 1000003 + calls0 + 1) & 0x7FFFFFFFFFFFFFFF
+        else:
+            y = AG.DropoutFn.apply(AG.BatchNormActFn.apply(xa, bn.weight, bn, AG.TANH, 0.0), p, res["seed"])
+        y.backward(gy)
+        res[fused] = (y.detach(), xa.grad, bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_var.clone())
+        if fused:
+            res["seed"] = seed
+    for a, c, what in zip(res[True], res[False], ("y", "dx", "dgamma", "dbeta", "running_var")):
+        check(a, c, 2e-5, what)
+    assert 0.4 < float((res[True][0] != 0).float().mean()) < 0.6
