@@ -110,8 +110,10 @@ __global__ __launch_bounds__(256) void aug_tail_bwd_kernel(const float* __restri
                                                            const float* __restrict__ b2, const float* __restrict__ dout,
                                                            float* __restrict__ dh, float* __restrict__ dg,
                                                            float* __restrict__ dbt, float* __restrict__ dw2,
-                                                           float* __restrict__ db2, int S) {
+                                                           float* __restrict__ db2, int S, int seg_rows) {
+  // grid (B, segments of the S axis): 48 blocks walking 60 rows each were a 45 us latency chain (6 wave reductions per row)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x;
+  const int s_lo = blockIdx.y * seg_rows, s_hi = min(S, s_lo + seg_rows);
   const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4);
   const float4 bb = *reinterpret_cast<const float4*>(bt + lane * 4);
   const float4 w0 = *reinterpret_cast<const float4*>(w2 + lane * 4);
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void aug_tail_bwd_kernel(const float* __restri
   const float go0 = dout[b * 2] / (float)S, go1 = dout[b * 2 + 1] / (float)S;
   float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag, aw0 = ag, aw1 = ag;
   float ab0 = 0.f, ab1 = 0.f;
-  for (int s = wave; s < S; s += 4) {
+  for (int s = s_lo + wave; s < s_hi; s += 4) {
     const float4 v = *reinterpret_cast<const float4*>(h + ((int64_t)b * S + s) * 256 + lane * 4);
     const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
     const float cx = v.x - mean, cy = v.y - mean, cz = v.z - mean, cw = v.w - mean;
@@ -149,13 +151,22 @@ __global__ __launch_bounds__(256) void aug_tail_bwd_kernel(const float* __restri
         make_float4(rstd * (ex - m1 - hx * m2), rstd * (ey - m1 - hy * m2), rstd * (ez - m1 - hz * m2),
                     rstd * (ew - m1 - hw * m2));
   }
+  // block-level reduction over the 4 waves, then one atomic per (vector, channel) and block
+  __shared__ float red[4][4][256];
+  __shared__ float redb[4][2];
   const float* srcs[4] = {&ag.x, &ab.x, &aw0.x, &aw1.x};
-  float* dsts[4] = {dg, dbt, dw2, dw2 + 256};
 #pragma unroll
   for (int k = 0; k < 4; ++k)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(dsts[k] + lane * 4 + e, srcs[k][e]);
-  if (lane == 0) { atomicAdd(db2, ab0); atomicAdd(db2 + 1, ab1); }
+    for (int e = 0; e < 4; ++e) red[k][wave][lane * 4 + e] = srcs[k][e];
+  if (lane == 0) { redb[wave][0] = ab0; redb[wave][1] = ab1; }
+  __syncthreads();
+  float* dsts[4] = {dg, dbt, dw2, dw2 + 256};
+  const int c = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    atomicAdd(dsts[k] + c, (red[k][0][c] + red[k][1][c]) + (red[k][2][c] + red[k][3][c]));
+  if (threadIdx.x < 2) atomicAdd(db2 + threadIdx.x, (redb[0][threadIdx.x] + redb[1][threadIdx.x]) + (redb[2][threadIdx.x] + redb[3][threadIdx.x]));
 }
 
 extern "C" int styler_aug_classifier_tail_bwd(const float* h, const float* ln_g, const float* ln_b, const float* w2,
@@ -163,8 +174,9 @@ extern "C" int styler_aug_classifier_tail_bwd(const float* h, const float* ln_g,
                                               float* dln_b, float* dw2, float* db2, int B, int S, void* stream) {
   if (!h || !ln_g || !ln_b || !w2 || !b2 || !dout || !dh || !dln_g || !dln_b || !dw2 || !db2 || B <= 0 || S <= 0)
     return STYLER_EINVAL;
-  hipLaunchKernelGGL(aug_tail_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, h, ln_g, ln_b, w2, b2, dout, dh,
-                     dln_g, dln_b, dw2, db2, S);
+  const int seg_rows = 16;
+  hipLaunchKernelGGL(aug_tail_bwd_kernel, dim3(B, (S + seg_rows - 1) / seg_rows), dim3(256), 0, (hipStream_t)stream, h, ln_g,
+                     ln_b, w2, b2, dout, dh, dln_g, dln_b, dw2, db2, S, seg_rows);
   return launch_status();
 }
 
