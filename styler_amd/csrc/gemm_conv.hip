@@ -62,7 +62,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
   constexpr int CLD = 32 * TN + 4;                 // epilogue staging row stride (floats)
   // OCC3 (occupancy-3 layout, 52.6 KB for the 128x128 bf16 tile => 3 blocks per CU): ONE activation buffer (re-staged
   // behind an extra barrier at chunk boundaries), weight rows unpadded (32 dwords) with the 16-byte slot index
-  // XOR-swizzled by (row & 7), epilogue staged in two halves.
+  // XOR-swizzled by (row & 7) ^ ((row >> 3) & 3) -- ds_read_b128 is served in 16-lane groups that pair rows r and r + 8
+  // (lanes 12-15 with 20-27 ...): with (row & 7) alone those pairs collided, 25 % of the LDS cycles of the k >= 5 convs --
+  // epilogue staged in two halves.
   constexpr int NABUF = OCC3 ? 1 : 2;
   constexpr int LDB = OCC3 ? 32 : LD;
   constexpr int EPI_H = OCC3 ? 2 : 1;              // epilogue passes
@@ -143,9 +145,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
   const uint32_t fb_off = OCC3 ? (wn * TN * 32 + li) * LDB : ((wn * TN * 32 + li) * LD + lh * (BF16 ? 4 : 16));
   uint32_t fb_sw[4];                               // OCC3: swizzled dword offset of MFMA step s inside the row
 #pragma unroll
-  for (int sx = 0; sx < 4; ++sx) fb_sw[sx] = (uint32_t)(((sx * 2 + lh) ^ (li & 7)) * 4);
+  for (int sx = 0; sx < 4; ++sx) fb_sw[sx] = (uint32_t)(((sx * 2 + lh) ^ ((li & 7) ^ ((li >> 3) & 3))) * 4);
   const uint32_t sa_off = a_r0 * LD + (BF16 ? a_col / 2 : a_col);
-  const uint32_t sb_off = OCC3 ? b_r0 * LDB + (((tid % B_V) ^ (b_r0 & 7)) * 4) : b_r0 * LD + (tid % B_V) * 4;
+  const uint32_t sb_off = OCC3 ? b_r0 * LDB + (((tid % B_V) ^ ((b_r0 & 7) ^ ((b_r0 >> 3) & 3))) * 4) : b_r0 * LD + (tid % B_V) * 4;
 
   // per-lane tap validity for the wave's output rows: bit j set <=> row t + j - pad lies in [0, L)
   uint32_t tapmask[TM];
