@@ -101,21 +101,23 @@ class WgradArena:
             key = bytes(arr)
             capturing = torch.cuda.is_current_stream_capturing()
             self._top_up_pinned(capturing)
-            if key not in self._gcache:
-                if len(self._gcache) > 8 and not capturing:
-                    self._gcache.clear()
-                if len(key) > self.GROUP_TABLE_BYTES or not self._pinned_pool:
-                    raise StylerHipError("grouped wgrad: no pinned staging buffer (run one eager step before capturing)")
-                host = self._pinned_pool.pop()       # owned by this cache entry from now on: a captured memcpy node
-                host[:len(key)].copy_(torch.frombuffer(bytearray(key), dtype=torch.uint8))   # re-reads it at every replay
-                dev_t = torch.empty(len(key), device=device, dtype=torch.uint8)
-                dev_t.copy_(host[:len(key)], non_blocking=True)
-                self._gcache[key] = (host, dev_t)
-            table = self._gcache[key][1]
+            if not capturing:
+                # eager step: operand addresses differ from step to step, so the table is simply uploaded (a blocking
+                # 12 KB copy); nothing is cached and no pinned buffer is consumed (pinning memory costs ~10 ms a piece)
+                table = torch.frombuffer(bytearray(key), dtype=torch.uint8).to(device)
+            else:
+                if key not in self._gcache:
+                    if len(key) > self.GROUP_TABLE_BYTES or not self._pinned_pool:
+                        raise StylerHipError("grouped wgrad: no pinned staging buffer (run one eager step before capturing)")
+                    host = self._pinned_pool.pop()   # owned by this cache entry from now on: the captured memcpy node
+                    host[:len(key)].copy_(torch.frombuffer(bytearray(key), dtype=torch.uint8))   # re-reads it at every replay
+                    dev_t = torch.empty(len(key), device=device, dtype=torch.uint8)
+                    dev_t.copy_(host[:len(key)], non_blocking=True)
+                    self._gcache[key] = (host, dev_t)
+                table = self._gcache[key][1]
             _chk(lib.styler_wgrad_group(table.data_ptr(), len(self.group), self.group_blocks, _stream()),
                  "styler_wgrad_group")
             self.group, self.group_blocks, self.group_keep = [], 0, []
-            self._top_up_pinned(capturing)
         if not self.descs:
             return
         key = tuple(self.descs)
