@@ -127,3 +127,44 @@ def test_collate_matches_reference(golden):
                 assert list(vv) == [str(x) for x in ref]
             else:
                 assert np.asarray(vv).shape == ref.shape and np.array_equal(np.asarray(vv, dtype=ref.dtype), ref), (k, kk)
+
+
+def test_derived_layout_specs_match_torch_permutes():
+    """The strided-copy recipes (runtime.Seg) that the one-launch refresh of the derived weight layouts executes on the
+    GPU, emulated element by element on the host against the torch expressions they replaced: conv kernel layout
+    [n, kw, cin], tap-flipped transposed dX layout [cin, kw, n], fused row / transposed-column concatenations and the
+    summed LSTM bias."""
+    import numpy as np
+    import torch
+    from styler_amd.runtime import Seg, seg_conv_bwd, seg_conv_fwd, seg_rows, seg_transposed
+
+    def run(segs, shape):
+        out = np.full(int(np.prod(shape)), np.nan, dtype=np.float32)
+        for sg in segs:
+            src = sg.src.detach().numpy().reshape(-1)
+            src2 = sg.src2.detach().numpy().reshape(-1) if sg.src2 is not None else None
+            for a0 in range(sg.dims[0]):
+                for a1 in range(sg.dims[1]):
+                    for a2 in range(sg.dims[2]):
+                        si = sg.src_off + a0 * sg.sstr[0] + a1 * sg.sstr[1] + a2 * sg.sstr[2]
+                        v = src[si] + (src2[si] if src2 is not None else 0.0)
+                        out[sg.dst_off + a0 * sg.dstr[0] + a1 * sg.dstr[1] + a2 * sg.dstr[2]] = v
+        assert not np.isnan(out).any(), "a derived layout has elements no segment writes"
+        return torch.from_numpy(out).view(shape)
+
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(6, 4, 5, generator=g)                                        # Conv1d weight [n, cin, kw]
+    assert torch.equal(run([seg_conv_fwd(w)], (6, 20)), w.permute(0, 2, 1).reshape(6, 20))
+    assert torch.equal(run([seg_conv_bwd(w)], (4, 30)), w.flip(2).permute(1, 2, 0).reshape(4, 30))
+    lin = torch.randn(6, 4, generator=g)                                          # Linear weight [n, cin]
+    assert torch.equal(run([seg_conv_fwd(lin)], (6, 4)), lin)
+    assert torch.equal(run([seg_conv_bwd(lin)], (4, 6)), lin.t())
+    q, k, v = (torch.randn(3, 4, generator=g) for _ in range(3))                  # fused QKV
+    assert torch.equal(run([seg_rows(u, i * 3) for i, u in enumerate((q, k, v))], (9, 4)), torch.cat([q, k, v]))
+    assert torch.equal(run([seg_transposed(u, i * 3, 9) for i, u in enumerate((q, k, v))], (4, 9)), torch.cat([q, k, v]).t())
+    bi, bh, bir, bhr = (torch.randn(8, generator=g) for _ in range(4))            # b_ih + b_hh, forward | reverse
+    segs = [Seg(bi, (8,), (1,), (1,), src2=bh), Seg(bir, (8,), (1,), (1,), dst_off=8, src2=bhr)]
+    assert torch.allclose(run(segs, (16,)), torch.cat([bi + bh, bir + bhr]))
+    oh = torch.randn(3, 7, 5, generator=g)                                        # one-hot conv weight [C, 257, 5] -> [5, 257, C]
+    C, Q, K = oh.shape
+    assert torch.equal(run([Seg(oh, (K, Q, C), (1, K, Q * K), (Q * C, C, 1))], (K, Q, C)), oh.permute(2, 1, 0).contiguous())
