@@ -34,6 +34,13 @@ extern "C" {
 #define STYLER_ACT_TANH 2
 #define STYLER_ACT_LOGCLAMP 3 /* log(max(v, 1e-5)): dynamic_range_compression, audio_processing.py:80-86 */
 
+/* io_flags of styler_conv_gemm[_packed] / styler_wgrad[_packed] (throughput mode only): the tensor behind the float
+ * pointer is bf16 (row strides stay in ELEMENTS).  Used for the FFN hidden activation and its gradient, which are only
+ * ever consumed as bf16 MFMA operands or as a sign mask. */
+#define STYLER_IO_X_BF16 1    /* conv_gemm: x;   wgrad: x  */
+#define STYLER_IO_Y_BF16 2    /* conv_gemm: y (no residual);   wgrad: dz */
+#define STYLER_IO_MASK_BF16 4 /* conv_gemm: mask */
+
 /* arithmetic of the MFMA GEMM core */
 #define STYLER_PREC_F32  0  /* v_mfma_f32_32x32x2_f32: exact fp32 (parity mode)            */
 #define STYLER_PREC_BF16 1  /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate    */
@@ -57,7 +64,7 @@ int styler_abi_version(void);
 int styler_conv_gemm(const float* x, int64_t ldx, const void* w, const float* scale,
                      const float* shift, const float* res, int64_t ldres, float* y,
                      int64_t ldy, int B, int L, int cin, int n, int kw, int act, int prec,
-                     const int64_t* len, const float* mask, int64_t ldmask, void* stream);
+                     const int64_t* len, const float* mask, int64_t ldmask, int io_flags, void* stream);
 
 /* ---- packed rows (the decoder runs on the valid frames only) --------------------------
  * Every FFT block of the decoder (transformer/Models.py:111-135) zeroes its padded rows
@@ -84,7 +91,7 @@ int styler_conv_gemm_packed(const float* x, int64_t ldx, const void* w, const fl
                             const float* shift, const float* res, int64_t ldres, float* y,
                             int64_t ldy, int rows, int cin, int n, int kw, int act, int prec,
                             const int64_t* nrows, const int32_t* rowinfo, const float* mask,
-                            int64_t ldmask, void* stream);
+                            int64_t ldmask, int io_flags, void* stream);
 
 /* Which tile engine styler_conv_gemm dispatches for a shape: bit0 = 128x128 block tile (else
  * 64x64), bit1 = bf16 MFMA (else fp32 MFMA).  Used by bench.py to attribute launches. */
@@ -317,13 +324,14 @@ int styler_act_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, f
  * LSTM W_hh: kw 1, pad_left = +1 / -1 selects h_{t-1} / h_{t+1}. */
 int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db,
                  float* db2, int64_t stride_n, int64_t stride_c, int64_t stride_j, int B, int L, int n, int cin,
-                 int kw, int pad_left, int prec, void* workspace, int defer_reduce, void* stream);
+                 int kw, int pad_left, int prec, void* workspace, int defer_reduce, int io_flags,
+                 void* stream);
 /* styler_wgrad on packed rows (`rows` = capacity, counts[0] valid).  Workspace / split count: those of
  * styler_wgrad_workspace_bytes / styler_wgrad_splits for (B = 1, L = rows, pad_left = kw/2). */
 int styler_wgrad_packed(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db,
                         int64_t stride_n, int64_t stride_c, int64_t stride_j, int rows, int n, int cin,
                         int kw, int prec, void* workspace, int defer_reduce, const int32_t* rowinfo,
-                        const int32_t* chunktab, const int64_t* counts, void* stream);
+                        const int32_t* chunktab, const int64_t* counts, int io_flags, void* stream);
 /* Split count styler_wgrad uses for a shape (workspace = splits * n * kw * cin floats). */
 int styler_wgrad_splits(int B, int L, int n, int cin, int kw, int pad_left, int prec);
 

@@ -15,7 +15,7 @@ F = ctypes.c_float
 
 _SIGS = {
     "styler_abi_version": [],
-    "styler_conv_gemm": [P, I64, P, P, P, P, I64, P, I64, I, I, I, I, I, I, I, P, P, I64, P],
+    "styler_conv_gemm": [P, I64, P, P, P, P, I64, P, I64, I, I, I, I, I, I, I, P, P, I64, I, P],
     "styler_conv_gemm_variant": [I, I, I, I, I, I],
     "styler_cast_bf16": [P, P, I64, P],
     "styler_repack_conv_weight": [P, P, I, I, I, I, I, P],
@@ -40,8 +40,8 @@ _SIGS = {
     "styler_pack_plan": [P, I, I, P, P, P, P, P],
     "styler_pack_rows": [P, I64, P, I64, P, P, I, I, I, P],
     "styler_unpack_rows": [P, I64, P, I64, P, I, I, I, P],
-    "styler_conv_gemm_packed": [P, I64, P, P, P, P, I64, P, I64, I, I, I, I, I, I, P, P, P, I64, P],
-    "styler_wgrad_packed": [P, I64, P, I64, P, P, I64, I64, I64, I, I, I, I, I, P, I, P, P, P, P],
+    "styler_conv_gemm_packed": [P, I64, P, P, P, P, I64, P, I64, I, I, I, I, I, I, P, P, P, I64, I, P],
+    "styler_wgrad_packed": [P, I64, P, I64, P, P, I64, I64, I64, I, I, I, I, I, P, I, P, P, P, I, P],
     "styler_lstm_bidir_bwd_multi": [P, I, I, I, P],
     "styler_aug_classifier_tail": [P, P, P, P, P, P, I, I, P],
     "styler_duration_scan": [P, I, P, F, P, P, P, I, I, P],
@@ -52,7 +52,7 @@ _SIGS = {
     "styler_length_mask": [P, P, I, I, P],
     "styler_masked_err_sum": [P, I64, P, I64, P, I, I, I, I, P, P],
     "styler_act_bwd": [P, I64, P, I64, P, I64, I, I, I, I, P, P],
-    "styler_wgrad": [P, I64, P, I64, P, P, P, I64, I64, I64, I, I, I, I, I, I, I, P, I, P],
+    "styler_wgrad": [P, I64, P, I64, P, P, P, I64, I64, I64, I, I, I, I, I, I, I, P, I, I, P],
     "styler_wgrad_splits": [I, I, I, I, I, I, I],
     "styler_wgrad_reduce_multi": [P, I, I64, P],
     "styler_wgrad_workspace_bytes": [I, I, I, I, I, I, I],

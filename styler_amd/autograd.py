@@ -140,7 +140,11 @@ class FfnSublayerFn(Function):
     def forward(ctx, x, anchor, ffn, lens, plan, drop_p):
         kw1, kw2 = ffn.w_1.weight.shape[2], ffn.w_2.weight.shape[2]
         w1, p1 = gemm_weight(ffn._derived, "w_1", ffn.w_1.weight, x.shape[-1])
-        h = ops.conv_gemm(x, w1, ffn.w_1.bias, kw=kw1, n=ffn.w_1.weight.shape[0], act=RELU, prec=p1, plan=plan)
+        # throughput mode: the hidden activation (and its gradient in backward) live in HBM as bf16 -- they are only ever
+        # consumed as bf16 MFMA operands or as a sign mask, so this changes no result and halves the widest tensors
+        h16 = p1 == ops.PREC_BF16 and ffn.w_1.weight.shape[0] % 8 == 0
+        h = ops.conv_gemm(x, w1, ffn.w_1.bias, kw=kw1, n=ffn.w_1.weight.shape[0], act=RELU, prec=p1, plan=plan,
+                          out_bf16=h16)
         w2, p2 = gemm_weight(ffn._derived, "w_2", ffn.w_2.weight, h.shape[-1])
         o = ops.conv_gemm(h, w2, ffn.w_2.bias, kw=kw2, n=ffn.w_2.weight.shape[0], prec=p2, plan=plan)
         y, s, ctx.drop = _ln_tail_fwd(o, x, ffn.layer_norm, lens, drop_p)
@@ -160,7 +164,7 @@ class FfnSublayerFn(Function):
         prec = ops.PREC_BF16 if bf16 else ops.PREC_F32
         ops.wgrad(d_o, h, G(w_2.weight), d_in, d_hid, kw=kw2, db=G(w_2.bias), plan=plan)
         dh = ops.conv_gemm(d_o, gemm_weight_bwd(ffn._derived, "w_2", w_2.weight, bf16), None, kw=kw2, n=d_hid, prec=prec,
-                           plan=plan, mask=h)
+                           plan=plan, mask=h, out_bf16=h.dtype == torch.bfloat16)
         ops.wgrad(dh, x, G(w_1.weight), d_hid, d_in, kw=kw1, db=G(w_1.bias), plan=plan)
         dx = ops.conv_gemm(dh, gemm_weight_bwd(ffn._derived, "w_1", w_1.weight, bf16), None, kw=kw1, n=d_in, prec=prec,
                            plan=plan, res=dx_res)

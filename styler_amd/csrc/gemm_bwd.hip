@@ -216,6 +216,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dz
 //   conflict-free.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint2 lds_tr_read(const uint16_t* p) {
   const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -223,9 +224,11 @@ __device__ __forceinline__ uint2 lds_tr_read(const uint16_t* p) {
   return *reinterpret_cast<const uint2*>(&v);
 }
 
-template <int KW, int TA, int TB>
-__device__ __forceinline__ void wgrad_tr_body(const int bid, const float* __restrict__ dz, int64_t lddz,
-                                              const float* __restrict__ x, int64_t ldx, float* __restrict__ db,
+// DZ16 / X16: the operand lives in HBM as bf16 already (the FFN hidden activation / its gradient in throughput mode):
+// 8-byte loads, no conversion on the staging path.
+template <int KW, int TA, int TB, bool DZ16 = false, bool X16 = false>
+__device__ __forceinline__ void wgrad_tr_body(const int bid, const void* __restrict__ dz, int64_t lddz,
+                                              const void* __restrict__ x, int64_t ldx, float* __restrict__ db,
                                               float* __restrict__ db2, int B, int L, int n, int cin, int pad_left, int ct,
                                               int cpi, int chunks_per_split, int tiles, int splits,
                                               float* __restrict__ ws, const int4* __restrict__ chunktab,
@@ -285,10 +288,11 @@ __device__ __forceinline__ void wgrad_tr_body(const int bid, const float* __rest
   constexpr uint32_t OOB = 0x80000000u;
   constexpr int64_t REC_MAX = (int64_t)1 << 30;      // chunk-relative offsets are < 3 MB; markers and wraps are > 2^30
   const int cinp = (cin + 3) & ~3;
-  const uint32_t va0 = n0 + aq < n ? (uint32_t)((ar * lddz + n0 + aq) * 4) : OOB;
-  const uint32_t vb0 = c0 + bq < cinp ? (uint32_t)((br * ldx + c0 + bq) * 4) : OOB;
-  const uint32_t a_pstep = (uint32_t)(RPA * lddz * 4), b_pstep = (uint32_t)(RPB * ldx * 4);
-  float4 ra0[PA], rb0[PB];
+  constexpr int AES = DZ16 ? 2 : 4, BES = X16 ? 2 : 4;       // bytes per operand element in HBM
+  const uint32_t va0 = n0 + aq < n ? (uint32_t)((ar * lddz + n0 + aq) * AES) : OOB;
+  const uint32_t vb0 = c0 + bq < cinp ? (uint32_t)((br * ldx + c0 + bq) * BES) : OOB;
+  const uint32_t a_pstep = (uint32_t)(RPA * lddz * AES), b_pstep = (uint32_t)(RPB * ldx * BES);
+  float4 ra0[PA], rb0[PB];                           // (bf16 operands use the first 8 bytes of each)
   auto load = [&](float4 (&ra)[PA], float4 (&rb)[PB], int ch) {
     int t0, Li;
     int64_t rowb;                                    // first row of the chunk's item, the item's length
@@ -301,25 +305,35 @@ __device__ __forceinline__ void wgrad_tr_body(const int bid, const float* __rest
     }
     const int tx = t0 - pad_left;                    // first x row of the chunk (halo included); may be < 0
     const int txb = tx > 0 ? tx : 0;
-    int64_t a_rec = ((int64_t)(Li - t0 - 1) * lddz + n) * 4;
-    int64_t b_rec = ((int64_t)(Li - txb - 1) * ldx + cinp) * 4;
+    int64_t a_rec = ((int64_t)(Li - t0 - 1) * lddz + n) * AES;
+    int64_t b_rec = ((int64_t)(Li - txb - 1) * ldx + cinp) * BES;
     a_rec = a_rec > REC_MAX ? REC_MAX : a_rec;
     b_rec = b_rec > REC_MAX ? REC_MAX : (b_rec < 0 ? 0 : b_rec);
-    const __amdgpu_buffer_rsrc_t ra_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz + (rowb + t0) * lddz), 0, (int)a_rec, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (rowb + txb) * ldx), 0, (int)b_rec, 0x00020000);
-    const uint32_t b_off = (uint32_t)((tx - txb) * (int)ldx * 4);        // <= 0: rows before the item wrap out of range
+    const char* a_base = reinterpret_cast<const char*>(dz) + (rowb + t0) * lddz * AES;
+    const char* b_base = reinterpret_cast<const char*>(x) + (rowb + txb) * ldx * BES;
+    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a_base), 0, (int)a_rec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b_base), 0, (int)b_rec, 0x00020000);
+    const uint32_t b_off = (uint32_t)((tx - txb) * (int)ldx * BES);      // <= 0: rows before the item wrap out of range
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, va0 + p * a_pstep, 0, 0);
-      ra[p] = *reinterpret_cast<const float4*>(&v);
+      if (DZ16) {
+        const i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(ra_rsrc, va0 + p * a_pstep, 0, 0);
+        ra[p].x = __int_as_float(v.x); ra[p].y = __int_as_float(v.y);
+      } else {
+        const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, va0 + p * a_pstep, 0, 0);
+        ra[p] = *reinterpret_cast<const float4*>(&v);
+      }
     }
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
       if (p * RPB >= XR) continue;
-      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rb_rsrc, vb0 + (b_off + p * b_pstep), 0, 0);
-      rb[p] = *reinterpret_cast<const float4*>(&v);
+      if (X16) {
+        const i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rb_rsrc, vb0 + (b_off + p * b_pstep), 0, 0);
+        rb[p].x = __int_as_float(v.x); rb[p].y = __int_as_float(v.y);
+      } else {
+        const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rb_rsrc, vb0 + (b_off + p * b_pstep), 0, 0);
+        rb[p] = *reinterpret_cast<const float4*>(&v);
+      }
     }
   };
   float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -328,15 +342,23 @@ __device__ __forceinline__ void wgrad_tr_body(const int bid, const float* __rest
     uint16_t* dbp = sB + buf * XR * FB + sb_off;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-      bs.x += ra[p].x; bs.y += ra[p].y; bs.z += ra[p].z; bs.w += ra[p].w;
-      *reinterpret_cast<uint2*>(da + p * (RPA / 4) * SA * 64) =
-          make_uint2(cvt_pk_bf16_b(ra[p].x, ra[p].y), cvt_pk_bf16_b(ra[p].z, ra[p].w));
+      if (DZ16) {                                    // 4 bf16 in .x/.y: stored as they are; widened only for the bias sum
+        const uint32_t lo = __float_as_uint(ra[p].x), hi = __float_as_uint(ra[p].y);
+        bs.x += __uint_as_float(lo << 16); bs.y += __uint_as_float(lo & 0xffff0000u);
+        bs.z += __uint_as_float(hi << 16); bs.w += __uint_as_float(hi & 0xffff0000u);
+        *reinterpret_cast<uint2*>(da + p * (RPA / 4) * SA * 64) = make_uint2(lo, hi);
+      } else {
+        bs.x += ra[p].x; bs.y += ra[p].y; bs.z += ra[p].z; bs.w += ra[p].w;
+        *reinterpret_cast<uint2*>(da + p * (RPA / 4) * SA * 64) =
+            make_uint2(cvt_pk_bf16_b(ra[p].x, ra[p].y), cvt_pk_bf16_b(ra[p].z, ra[p].w));
+      }
     }
 #pragma unroll
     for (int p = 0; p < PB; ++p)
       if (br + p * RPB < XR)
         *reinterpret_cast<uint2*>(dbp + p * (RPB / 4) * SB * 64) =
-            make_uint2(cvt_pk_bf16_b(rb[p].x, rb[p].y), cvt_pk_bf16_b(rb[p].z, rb[p].w));
+            X16 ? make_uint2(__float_as_uint(rb[p].x), __float_as_uint(rb[p].y))
+                : make_uint2(cvt_pk_bf16_b(rb[p].x, rb[p].y), cvt_pk_bf16_b(rb[p].z, rb[p].w));
   };
 
   // ---- fragment read coordinates: 16-lane group (ch = feature half, lh = k half), q = lane in the group ----
@@ -448,16 +470,16 @@ __device__ __forceinline__ void wgrad_tr_body(const int bid, const float* __rest
   }
 }
 
-template <int KW, int TA, int TB>
-__global__ __launch_bounds__(256) void wgrad_tr_kernel(const float* __restrict__ dz, int64_t lddz,
-                                                       const float* __restrict__ x, int64_t ldx,
+template <int KW, int TA, int TB, bool DZ16 = false, bool X16 = false>
+__global__ __launch_bounds__(256) void wgrad_tr_kernel(const void* __restrict__ dz, int64_t lddz,
+                                                       const void* __restrict__ x, int64_t ldx,
                                                        float* __restrict__ db, float* __restrict__ db2, int B, int L,
                                                        int n, int cin, int pad_left, int ct, int cpi,
                                                        int chunks_per_split, int tiles, int splits,
                                                        float* __restrict__ ws, const int4* __restrict__ chunktab,
                                                        const int64_t* __restrict__ counts) {
-  wgrad_tr_body<KW, TA, TB>(blockIdx.x, dz, lddz, x, ldx, db, db2, B, L, n, cin, pad_left, ct, cpi, chunks_per_split, tiles,
-                            splits, ws, chunktab, counts);
+  wgrad_tr_body<KW, TA, TB, DZ16, X16>(blockIdx.x, dz, lddz, x, ldx, db, db2, B, L, n, cin, pad_left, ct, cpi,
+                                       chunks_per_split, tiles, splits, ws, chunktab, counts);
 }
 
 // Many small Linear weight gradients in ONE launch (kw = 1, 64x64 tile): the S-domain gradients of a backward pass
@@ -542,8 +564,14 @@ extern "C" int64_t styler_wgrad_workspace_bytes(int B, int L, int n, int cin, in
 static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db, float* db2,
                       int64_t stride_n, int64_t stride_c, int64_t stride_j, int B, int L, int n, int cin, int kw,
                       int pad_left, int prec, void* workspace, int defer_reduce, const int32_t* rowinfo,
-                      const int32_t* chunktab, const int64_t* counts, void* stream) {
+                      const int32_t* chunktab, const int64_t* counts, int io_flags, void* stream) {
   if (!dz || !x || !dw || !workspace || B <= 0 || L <= 0 || n <= 0 || cin <= 0 || (db2 && !db)) return STYLER_EINVAL;
+  const bool dz16 = io_flags & STYLER_IO_Y_BF16, x16 = io_flags & STYLER_IO_X_BF16;
+  if (dz16 || x16) {                                 // bf16-resident operands: the two shapes of the FFN sublayer only
+    const bool ok = prec == STYLER_PREC_BF16 && !(dz16 && x16) && !(lddz & 7) && !(ldx & 7) &&
+                    ((x16 && kw == 1 && pad_left == 0) || (dz16 && kw == 9));
+    if (!ok) return STYLER_EINVAL;
+  }
   if (kw != 1 && kw != 3 && kw != 5 && kw != 9) return STYLER_EINVAL;
   if ((lddz & 3) || (ldx & 3) || (n & 3) || ldx < ((cin + 3) & ~3) || ((uintptr_t)dz & 15) || ((uintptr_t)x & 15)) return STYLER_EALIGN;
   int TA, TB;
@@ -562,14 +590,22 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
                                                 db2, Be, Le, n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, \
                                                 kw > 1 ? reinterpret_cast<const int4*>(chunktab) : nullptr, counts)
     if (kw == 1) {
-      if (TA == 2 && TB == 2) WT_LAUNCH(1, 2, 2); else if (TA == 2) WT_LAUNCH(1, 2, 1);
+      if (x16) {
+        if (TA != 2 || TB != 2) return STYLER_EINVAL;
+        hipLaunchKernelGGL((wgrad_tr_kernel<1, 2, 2, false, true>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, db2, Be, Le,
+                           n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, nullptr, counts);
+      } else if (TA == 2 && TB == 2) WT_LAUNCH(1, 2, 2); else if (TA == 2) WT_LAUNCH(1, 2, 1);
       else if (TB == 2) WT_LAUNCH(1, 1, 2); else WT_LAUNCH(1, 1, 1);
     } else if (kw == 3) {
       if (TA == 2) WT_LAUNCH(3, 2, 1); else WT_LAUNCH(3, 1, 1);
     } else if (kw == 5) {
       if (TA == 2) WT_LAUNCH(5, 2, 1); else WT_LAUNCH(5, 1, 1);
     } else {
-      WT_LAUNCH(9, 1, 1);
+      if (dz16)
+        hipLaunchKernelGGL((wgrad_tr_kernel<9, 1, 1, true, false>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, db2, Be, Le,
+                           n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, reinterpret_cast<const int4*>(chunktab), counts);
+      else
+        WT_LAUNCH(9, 1, 1);
     }
 #undef WT_LAUNCH
   } else {
@@ -589,9 +625,9 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
 
 extern "C" int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db,
                             float* db2, int64_t stride_n, int64_t stride_c, int64_t stride_j, int B, int L, int n, int cin,
-                            int kw, int pad_left, int prec, void* workspace, int defer_reduce, void* stream) {
+                            int kw, int pad_left, int prec, void* workspace, int defer_reduce, int io_flags, void* stream) {
   return wgrad_impl(dz, lddz, x, ldx, dw, db, db2, stride_n, stride_c, stride_j, B, L, n, cin, kw, pad_left, prec, workspace,
-                    defer_reduce, nullptr, nullptr, nullptr, stream);
+                    defer_reduce, nullptr, nullptr, nullptr, io_flags, stream);
 }
 
 // Packed-rows variant (pack.hip): dz / x hold `rows` rows of capacity, the first counts[0] of them valid, items back to
@@ -599,10 +635,10 @@ extern "C" int styler_wgrad(const float* dz, int64_t lddz, const float* x, int64
 extern "C" int styler_wgrad_packed(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db,
                                    int64_t stride_n, int64_t stride_c, int64_t stride_j, int rows, int n, int cin, int kw,
                                    int prec, void* workspace, int defer_reduce, const int32_t* rowinfo,
-                                   const int32_t* chunktab, const int64_t* counts, void* stream) {
+                                   const int32_t* chunktab, const int64_t* counts, int io_flags, void* stream) {
   if (!rowinfo || !chunktab || !counts) return STYLER_EINVAL;
   return wgrad_impl(dz, lddz, x, ldx, dw, db, nullptr, stride_n, stride_c, stride_j, 1, rows, n, cin, kw, kw / 2, prec,
-                    workspace, defer_reduce, rowinfo, chunktab, counts, stream);
+                    workspace, defer_reduce, rowinfo, chunktab, counts, io_flags, stream);
 }
 
 // Host-side descriptor of one member of a grouped launch (styler_wgrad_group).  Returns the number of blocks the member

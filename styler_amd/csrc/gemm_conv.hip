@@ -30,29 +30,36 @@
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
-  const float* x; int64_t ldx;
+  const void* x; int64_t ldx;                      // fp32, or bf16 with the A16 kernels (ldx in elements either way)
   const void* w;
   const float* scale; const float* shift;
   const float* res; int64_t ldres;
-  float* y; int64_t ldy;
+  void* y; int64_t ldy;                            // fp32, or bf16 with the Y16 kernels
   int B, L, cin, n, kw, act, pad;
   const int64_t* len;
   int mt, nt;                                      // tile counts
   const int2* rowinfo;                             // packed rows (styler_pack_plan): (t, len - 1 - t) per row, or null
-  const float* mask; int64_t ldmask;               // epilogue: v = mask[row, col] > 0 ? v : 0 (ReLU backward), or null
+  const void* mask; int64_t ldmask;                // epilogue: v = mask[row, col] > 0 ? v : 0 (ReLU backward), or null
+  int mask16;                                      // the mask tensor is bf16
 };
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   return cvt_pk_bf16_rne(lo, hi);
 }
 
-template <int TM, int TN, bool BF16, bool KW1, bool OCC3>
+// A16 / Y16: the activation operand / the output live in HBM as bf16 (the FFN hidden tensor and its gradient in throughput
+// mode: both are only ever consumed as bf16 MFMA operands or as a sign mask, so storing them rounded changes no result and
+// halves the bytes of the widest tensors of the model).
+template <int TM, int TN, bool BF16, bool KW1, bool OCC3, bool A16 = false, bool Y16 = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
+  static_assert(BF16 || (!A16 && !Y16), "bf16 storage only with the bf16 MFMA");
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int BK = BF16 ? 64 : 32;
   constexpr int LD = 36;                           // dwords per LDS row (32 data + 4 pad)
   constexpr int A_ROWS = BM + (KW1 ? 0 : 8);       // halo for kw <= 9
-  constexpr int A_V = BK / 4;                      // float4 per A row (global, fp32)
+  constexpr int A_EPV = A16 ? 8 : 4;               // elements per 16-byte vector of the A operand in HBM
+  constexpr int A_ES = A16 ? 2 : 4;                // bytes per element
+  constexpr int A_V = BK / A_EPV;                  // 16-byte vectors per A row
   constexpr int A_RPP = 256 / A_V;                 // rows per pass
   constexpr int A_P = (A_ROWS + A_RPP - 1) / A_RPP;
   constexpr int B_V = 8;                           // 16-byte vectors per B row
@@ -115,7 +122,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
       constexpr int QPR = BN / 4;                    // float4 per tile row
       for (int i = tid; i < BM * QPR; i += 256) {
         const int r = i / QPR, c = n0 + (i - r * QPR) * 4;
-        if (m0 + r < M && c < a.n) *reinterpret_cast<float4*>(a.y + (m0 + r) * a.ldy + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m0 + r < M && c < a.n) {
+          if (Y16) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.y) + (m0 + r) * a.ldy + c) = make_uint2(0u, 0u);
+          else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (m0 + r) * a.ldy + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
       return;
     }
@@ -128,12 +138,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
   // moves: one v_add per load.
   constexpr uint32_t OOB = 0x80000000u;
   constexpr int64_t REC_MAX = (int64_t)1 << 30;      // tile-relative offsets are < 5 MB; markers and wraps are > 2^30
-  const int a_col = (tid % A_V) * 4;
+  const int a_col = (tid % A_V) * A_EPV;
   const int a_r0 = tid / A_V;
   const int64_t mrow0 = m0 - pad;                    // first halo row of the tile (< 0 for the first tile)
   const int64_t mbase = mrow0 > 0 ? mrow0 : 0;
-  const uint32_t va0 = (uint32_t)(((a_r0 + (int)(mrow0 - mbase)) * (int)a.ldx + a_col) * 4);
-  const uint32_t a_pstep = (uint32_t)(A_RPP * (int)a.ldx * 4);
+  const uint32_t va0 = (uint32_t)(((a_r0 + (int)(mrow0 - mbase)) * (int)a.ldx + a_col) * A_ES);
+  const uint32_t a_pstep = (uint32_t)(A_RPP * (int)a.ldx * A_ES);
 
   const int b_col = (tid % B_V) * (BF16 ? 8 : 4);  // element offset inside the chunk
   const int b_r0 = tid / B_V;
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
   uint32_t fb_sw[4];                               // OCC3: swizzled dword offset of MFMA step s inside the row
 #pragma unroll
   for (int sx = 0; sx < 4; ++sx) fb_sw[sx] = (uint32_t)(((sx * 2 + lh) ^ ((li & 7) ^ ((li >> 3) & 3))) * 4);
-  const uint32_t sa_off = a_r0 * LD + (BF16 ? a_col / 2 : a_col);
+  const uint32_t sa_off = a_r0 * LD + (BF16 ? a_col / 2 : a_col);     // dwords (a bf16 pair per dword)
   const uint32_t sb_off = OCC3 ? b_r0 * LDB + (((tid % B_V) ^ ((b_r0 & 7) ^ ((b_r0 >> 3) & 3))) * 4) : b_r0 * LD + (tid % B_V) * 4;
 
   // per-lane tap validity for the wave's output rows: bit j set <=> row t + j - pad lies in [0, L)
@@ -167,20 +177,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     tapmask[i] = bits;
   }
 
-  float4 ra[A_P];
+  i32x4 ra[A_P];                                   // 16 raw bytes per pass: 4 floats, or 8 bf16 (A16)
   uint4 rb[B_P];
 
   auto load_a = [&](int cc) {
     const int c0 = cc * BK;
-    int64_t rec = ((M - mbase - 1) * a.ldx + (a.cin - c0)) * 4;
+    int64_t rec = ((M - mbase - 1) * a.ldx + (a.cin - c0)) * A_ES;
     rec = rec > REC_MAX ? REC_MAX : rec;
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + mbase * a.ldx + c0), 0, (int)rec, 0x00020000);
+    const char* abase = reinterpret_cast<const char*>(a.x) + (mbase * a.ldx + c0) * A_ES;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(abase), 0, (int)rec, 0x00020000);
     const uint32_t v = c0 + a_col < a.cin ? va0 : OOB;
 #pragma unroll
     for (int p = 0; p < A_P; ++p) {
-      const i32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v + p * a_pstep, 0, 0);
-      ra[p] = *reinterpret_cast<const float4*>(&t);
+      ra[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v + p * a_pstep, 0, 0);
     }
   };
   auto store_a = [&](int buf) {
@@ -188,11 +197,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
 #pragma unroll
     for (int p = 0; p < A_P; ++p) {
       if (a_r0 + p * A_RPP < A_ROWS) {
-        if (BF16) {
-          *reinterpret_cast<uint2*>(&dst[p * A_RPP * LD]) =
-              make_uint2(cvt_pk_bf16(ra[p].x, ra[p].y), cvt_pk_bf16(ra[p].z, ra[p].w));
+        if (A16) {
+          *reinterpret_cast<i32x4*>(&dst[p * A_RPP * LD]) = ra[p];      // already bf16: no conversion
+        } else if (BF16) {
+          const float4 f = *reinterpret_cast<const float4*>(&ra[p]);
+          *reinterpret_cast<uint2*>(&dst[p * A_RPP * LD]) = make_uint2(cvt_pk_bf16(f.x, f.y), cvt_pk_bf16(f.z, f.w));
         } else {
-          *reinterpret_cast<float4*>(&dst[p * A_RPP * LD]) = ra[p];
+          *reinterpret_cast<i32x4*>(&dst[p * A_RPP * LD]) = ra[p];
         }
       }
     }
@@ -337,9 +348,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
         v.x = apply_act(v.x * sc.x + sf.x, a.act); v.y = apply_act(v.y * sc.y + sf.y, a.act);
         v.z = apply_act(v.z * sc.z + sf.z, a.act); v.w = apply_act(v.w * sc.w + sf.w, a.act);
         if (a.mask) {                                 // dX of a ReLU layer: gradient only where the forward output was > 0
-          const float4 mk = *reinterpret_cast<const float4*>(a.mask + row * a.ldmask + col);
-          v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
-          v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+          if (a.mask16) {                             // bf16 mask: positive <=> sign clear and magnitude non-zero
+            const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(a.mask) + row * a.ldmask + col);
+            v.x = (int16_t)(mk.x & 0xffffu) > 0 ? v.x : 0.f; v.y = (int16_t)(mk.x >> 16) > 0 ? v.y : 0.f;
+            v.z = (int16_t)(mk.y & 0xffffu) > 0 ? v.z : 0.f; v.w = (int16_t)(mk.y >> 16) > 0 ? v.w : 0.f;
+          } else {
+            const float4 mk = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.mask) + row * a.ldmask + col);
+            v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+            v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+          }
         }
         if (a.res) {
           const float4 rr = *reinterpret_cast<const float4*>(a.res + row * a.ldres + col);
@@ -349,14 +366,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
           const int64_t b = row / a.L;
           if ((row - b * a.L) >= a.len[b]) v = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        *reinterpret_cast<float4*>(a.y + row * a.ldy + col) = v;
+        if (Y16)
+          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.y) + row * a.ldy + col) =
+              make_uint2(cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w));
+        else
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + row * a.ldy + col) = v;
       }
     }
   }
 }
 
 template <int TM, int TN, bool BF16>
-static int launch_gemm(GemmArgs a, hipStream_t st) {
+static int launch_gemm(GemmArgs a, hipStream_t st, int x16, int y16) {
   const int64_t M = (int64_t)a.B * a.L;
   a.mt = (int)((M + 64 * TM - 1) / (64 * TM));
   a.nt = (a.n + 64 * TN - 1) / (64 * TN);
@@ -365,13 +386,24 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   // k = 9 / k = 5 convs, -5 % on k = 3.  STYLER_GEMM_OCC3=0/1 overrides for experiments.
   static const int occ3_env = [] { const char* e = getenv("STYLER_GEMM_OCC3"); return e ? atoi(e) : -1; }();
   const bool occ3 = occ3_env >= 0 ? occ3_env != 0 : a.kw >= 5;
-  if (a.kw == 1) {
-    hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, BF16, true, false>), grid, dim3(256), 0, st, a);
-  } else if (BF16 && TM == 2 && occ3) {
-    hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, BF16, false, BF16 && TM == 2>), grid, dim3(256), 0, st, a);
-  } else {
-    hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, BF16, false, false>), grid, dim3(256), 0, st, a);
-  }
+#define GEMM_LAUNCH(KW1_, OCC_, A_, Y_) \
+  hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, BF16, KW1_, OCC_, A_, Y_>), grid, dim3(256), 0, st, a)
+#define GEMM_IO(KW1_, OCC_)                                                        \
+  do {                                                                              \
+    if constexpr (BF16) {                                                           \
+      if (x16) GEMM_LAUNCH(KW1_, OCC_, true, false);                                \
+      else if (y16) GEMM_LAUNCH(KW1_, OCC_, false, true);                           \
+      else GEMM_LAUNCH(KW1_, OCC_, false, false);                                   \
+    } else {                                                                        \
+      GEMM_LAUNCH(KW1_, OCC_, false, false);                                        \
+    }                                                                               \
+  } while (0)
+  if ((x16 || y16) && (!BF16 || (x16 && y16))) return STYLER_EINVAL;
+  if (a.kw == 1) GEMM_IO(true, false);
+  else if (BF16 && TM == 2 && occ3) GEMM_IO(false, (BF16 && TM == 2));
+  else GEMM_IO(false, false);
+#undef GEMM_IO
+#undef GEMM_LAUNCH
   return launch_status();
 }
 
@@ -393,19 +425,21 @@ extern "C" int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, in
 int styler_conv_gemm_impl2(const float* x, int64_t ldx, const void* w, const float* scale, const float* shift,
                            const float* res, int64_t ldres, float* y, int64_t ldy, int B, int L, int cin, int n,
                            int kw, int pad, int act, int prec, const int64_t* len, const int32_t* rowinfo,
-                           const float* mask, int64_t ldmask, void* stream);
+                           const float* mask, int64_t ldmask, int io_flags, void* stream);
 
 int styler_conv_gemm_impl(const float* x, int64_t ldx, const void* w, const float* scale, const float* shift,
                           const float* res, int64_t ldres, float* y, int64_t ldy, int B, int L, int cin, int n,
                           int kw, int pad, int act, int prec, const int64_t* len, void* stream) {
   return styler_conv_gemm_impl2(x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, pad, act, prec, len,
-                                nullptr, nullptr, 0, stream);
+                                nullptr, nullptr, 0, 0, stream);
 }
 
 int styler_conv_gemm_impl2(const float* x, int64_t ldx, const void* w, const float* scale, const float* shift,
                            const float* res, int64_t ldres, float* y, int64_t ldy, int B, int L, int cin, int n,
                            int kw, int pad, int act, int prec, const int64_t* len, const int32_t* rowinfo,
-                           const float* mask, int64_t ldmask, void* stream) {
+                           const float* mask, int64_t ldmask, int io_flags, void* stream) {
+  const int x16 = io_flags & STYLER_IO_X_BF16, y16 = io_flags & STYLER_IO_Y_BF16, m16 = io_flags & STYLER_IO_MASK_BF16;
+  if ((x16 || y16) && (prec != STYLER_PREC_BF16 || (y16 && (res || (ldy & 3))) || (x16 && (ldx & 7)))) return STYLER_EINVAL;
   if (!x || !w || !y || B <= 0 || L <= 0 || cin <= 0 || n <= 0 || kw <= 0 || kw > 9 || pad < 0 || pad >= kw)
     return STYLER_EINVAL;
   if ((cin & 3) || (ldx & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return STYLER_EALIGN;
@@ -414,20 +448,20 @@ int styler_conv_gemm_impl2(const float* x, int64_t ldx, const void* w, const flo
   if (rowinfo && B != 1) return STYLER_EINVAL;
   if (mask && ((ldmask & 3) || ((uintptr_t)mask & 15))) return STYLER_EALIGN;
   GemmArgs a{x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, act, pad, len, 0, 0,
-             reinterpret_cast<const int2*>(rowinfo), mask, ldmask};
+             reinterpret_cast<const int2*>(rowinfo), mask, ldmask, m16 ? 1 : 0};
   hipStream_t st = (hipStream_t)stream;
   const bool big = styler_conv_gemm_variant(B, L, cin, n, kw, prec) & 1;
-  if (prec == STYLER_PREC_BF16) return big ? launch_gemm<2, 2, true>(a, st) : launch_gemm<1, 1, true>(a, st);
-  return big ? launch_gemm<2, 2, false>(a, st) : launch_gemm<1, 1, false>(a, st);
+  if (prec == STYLER_PREC_BF16) return big ? launch_gemm<2, 2, true>(a, st, x16, y16) : launch_gemm<1, 1, true>(a, st, x16, y16);
+  return big ? launch_gemm<2, 2, false>(a, st, x16, y16) : launch_gemm<1, 1, false>(a, st, x16, y16);
 }
 
 extern "C" int styler_conv_gemm(const float* x, int64_t ldx, const void* w, const float* scale,
                                 const float* shift, const float* res, int64_t ldres, float* y,
                                 int64_t ldy, int B, int L, int cin, int n, int kw, int act, int prec,
-                                const int64_t* len, const float* mask, int64_t ldmask, void* stream) {
+                                const int64_t* len, const float* mask, int64_t ldmask, int io_flags, void* stream) {
   if (!(kw & 1)) return STYLER_EINVAL;
   return styler_conv_gemm_impl2(x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, kw / 2, act, prec, len,
-                                nullptr, mask, ldmask, stream);
+                                nullptr, mask, ldmask, io_flags, stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -493,10 +527,11 @@ extern "C" int styler_repack_conv_weight(const float* src, void* dst, int n, int
 extern "C" int styler_conv_gemm_packed(const float* x, int64_t ldx, const void* w, const float* scale,
                                        const float* shift, const float* res, int64_t ldres, float* y, int64_t ldy,
                                        int rows, int cin, int n, int kw, int act, int prec, const int64_t* nrows,
-                                       const int32_t* rowinfo, const float* mask, int64_t ldmask, void* stream) {
+                                       const int32_t* rowinfo, const float* mask, int64_t ldmask, int io_flags,
+                                       void* stream) {
   if (!(kw & 1) || !nrows || !rowinfo) return STYLER_EINVAL;
   return styler_conv_gemm_impl2(x, ldx, w, scale, shift, res, ldres, y, ldy, 1, rows, cin, n, kw, kw / 2, act, prec,
-                                nrows, rowinfo, mask, ldmask, stream);
+                                nrows, rowinfo, mask, ldmask, io_flags, stream);
 }
 
 extern "C" int styler_abi_version(void) { return 1; }

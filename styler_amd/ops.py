@@ -241,16 +241,24 @@ def unpack_rows(xp, plan):
 
 
 def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, scale=None, res=None,
-              out=None, lens=None, plan=None, mask=None):
+              out=None, lens=None, plan=None, mask=None, out_bf16=False):
     """y = act(scale * conv1d_same(x, w) + bias) (+ res); x [B, L, cin] -> y [B, L, n].
-    `w` is the kernel-layout weight [n, kw*cin] (fp32, or bf16 when prec == PREC_BF16)."""
-    _f32(x)
+    `w` is the kernel-layout weight [n, kw*cin] (fp32, or bf16 when prec == PREC_BF16).
+    Throughput mode only: x, the output (`out_bf16` / a bf16 `out`) and `mask` may be bf16 tensors (the FFN hidden
+    activation and its gradient are stored that way; no residual with a bf16 output)."""
     B, L, cin = x.shape
     n = w.shape[0] if n is None else n
     if prec == PREC_BF16 and (w.dtype != torch.bfloat16 or cin % 8):
         raise StylerHipError("bf16 GEMM needs a bf16 weight shadow and cin % 8 == 0")
     if out is None:
-        out = torch.empty(B, L, n, device=x.device, dtype=torch.float32)
+        out = torch.empty(B, L, n, device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    io = (1 if x.dtype == torch.bfloat16 else 0) | (2 if out.dtype == torch.bfloat16 else 0) | \
+         (4 if mask is not None and mask.dtype == torch.bfloat16 else 0)
+    if io:
+        if prec != PREC_BF16 or (io & 2 and res is not None):
+            raise StylerHipError("bf16 activations only in throughput mode (and no residual with a bf16 output)")
+    else:
+        _f32(x)
     prof = gemm_profiler
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -260,12 +268,12 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
         _chk(lib.styler_conv_gemm_packed(x.data_ptr(), _ld(x), w.data_ptr(), _ptr(scale), _ptr(bias), _ptr(res),
                                          _ld(res) if res is not None else 0, out.data_ptr(), _ld(out), L, cin, n, kw,
                                          act, prec, plan.counts.data_ptr(), plan.rowinfo.data_ptr(), _ptr(mask),
-                                         _ld(mask) if mask is not None else 0, _stream()),
+                                         _ld(mask) if mask is not None else 0, io, _stream()),
              "styler_conv_gemm_packed")
     else:
         _chk(lib.styler_conv_gemm(x.data_ptr(), _ld(x), w.data_ptr(), _ptr(scale), _ptr(bias), _ptr(res),
                                   _ld(res) if res is not None else 0, out.data_ptr(), _ld(out), B, L, cin, n,
-                                  kw, act, prec, _ptr(lens), _ptr(mask), _ld(mask) if mask is not None else 0,
+                                  kw, act, prec, _ptr(lens), _ptr(mask), _ld(mask) if mask is not None else 0, io,
                                   _stream()), "styler_conv_gemm")
     if prof is not None:
         e1.record()
@@ -588,8 +596,9 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
                                 int(lib.styler_wgrad_splits(B, L, n, cin, kw, pad_left, prec))))
     if ws is None:
         ws = torch.empty(nfloats, device=dz.device, dtype=torch.float32)
+    io = (2 if dz.dtype == torch.bfloat16 else 0) | (1 if x.dtype == torch.bfloat16 else 0)    # bf16-resident operands
     grouped = False
-    if defer and kw == 1 and prec == PREC_BF16 and prof is None:
+    if defer and kw == 1 and prec == PREC_BF16 and prof is None and not io:
         from ._lib import WgradGroupDesc
         import ctypes
         d = WgradGroupDesc()
@@ -609,11 +618,12 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
         assert B == 1 and L == plan.rows and db2 is None and pad_left == kw // 2
         _chk(lib.styler_wgrad_packed(dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), dw.data_ptr(), _ptr(db), strides[0],
                                      strides[1], strides[2], L, n, cin, kw, prec, ws.data_ptr(), defer,
-                                     plan.rowinfo.data_ptr(), plan.chunktab.data_ptr(), plan.counts.data_ptr(),
+                                     plan.rowinfo.data_ptr(), plan.chunktab.data_ptr(), plan.counts.data_ptr(), io,
                                      _stream()), "styler_wgrad_packed")
     else:
         _chk(lib.styler_wgrad(dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), dw.data_ptr(), _ptr(db), _ptr(db2), strides[0], strides[1],
-                              strides[2], B, L, n, cin, kw, pad_left, prec, ws.data_ptr(), defer, _stream()), "styler_wgrad")
+                              strides[2], B, L, n, cin, kw, pad_left, prec, ws.data_ptr(), defer, io, _stream()),
+             "styler_wgrad")
     if prof is not None:
         e1.record()
         prof.records.append(("wgrad_bf16" if prec == PREC_BF16 else "wgrad", 2.0 * B * L * n * kw * cin, e0, e1,

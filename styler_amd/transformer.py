@@ -32,7 +32,7 @@ class _HipModule(nn.Module):
         object.__setattr__(self, "_derived", Derived())
 
     def _gemm(self, key, x, lin, *, kw=1, act=ops.ACT_NONE, res=None, out=None, lens=None, scale=None,
-              shift=None, neg_dx=False, plan=None):
+              shift=None, neg_dx=False, plan=None, out_bf16=False):
         """conv_gemm with the weight of an nn.Linear / nn.Conv1d parameter holder.  Under autograd the call
         goes through ConvGemmFn (HIP backward: dX conv, wgrad, bias column sums)."""
         if (self.training and torch.is_grad_enabled()) and (lin.weight.requires_grad or x.requires_grad):
@@ -41,7 +41,7 @@ class _HipModule(nn.Module):
         w, prec = gemm_weight(self._derived, key, lin.weight, x.shape[-1])
         bias = lin.bias if shift is None else shift
         return ops.conv_gemm(x, w, bias, kw=kw, n=lin.weight.shape[0], act=act, prec=prec, scale=scale, res=res,
-                             out=out, lens=lens, plan=plan)
+                             out=out, lens=lens, plan=plan, out_bf16=out_bf16 and prec == ops.PREC_BF16)
 
     def _ln(self, x, res, ln, lens, out=None, drop_p=0.0):
         """LayerNorm(dropout(x) + res) + pad mask, tape-aware (drop_p only in train mode)."""
@@ -112,7 +112,7 @@ class PositionwiseFeedForward(_HipModule):
         k = hp.fft_conv1d_kernel_size
         if self.training and torch.is_grad_enabled():        # the whole sublayer is one tape node
             return AG.FfnSublayerFn.apply(x, self.w_1.weight, self, lens, plan, self.dropout.p)
-        h = self._gemm("w_1", x, self.w_1, kw=k[0], act=ops.ACT_RELU, plan=plan)
+        h = self._gemm("w_1", x, self.w_1, kw=k[0], act=ops.ACT_RELU, plan=plan, out_bf16=True)   # bf16 in throughput mode
         if (self.training and torch.is_grad_enabled()) or (self.training and self.dropout.p > 0):
             return self._ln(self._gemm("w_2", h, self.w_2, kw=k[1], plan=plan), x, self.layer_norm, lens, out,
                             drop_p=self.dropout.p if self.training else 0.0)
