@@ -33,6 +33,7 @@ extern "C" {
 #define STYLER_ACT_RELU 1
 #define STYLER_ACT_TANH 2
 #define STYLER_ACT_LOGCLAMP 3 /* log(max(v, 1e-5)): dynamic_range_compression, audio_processing.py:80-86 */
+#define STYLER_ACT_LEAKY 4    /* v > 0 ? v : 0.1 v: LRELU_SLOPE of the vocoder, hifigan/models.py:7,97 */
 
 /* io_flags of styler_conv_gemm[_packed] / styler_wgrad[_packed] (throughput mode only): the tensor behind the float
  * pointer is bf16 (row strides stay in ELEMENTS).  Used for the FFN hidden activation and its gradient, which are only
@@ -92,6 +93,17 @@ int styler_conv_gemm_packed(const float* x, int64_t ldx, const void* w, const fl
                             int64_t ldy, int rows, int cin, int n, int kw, int act, int prec,
                             const int64_t* nrows, const int32_t* rowinfo, const float* mask,
                             int64_t ldmask, int io_flags, void* stream);
+
+/* styler_conv_gemm with an explicit left padding and any kw <= 9 (even allowed):
+ *   y[b,t,:] = act(scale * sum_j x[b, t + j - pad, :] w[:, j, :] + shift) (+ res),  rows outside [0, L) read as 0.
+ * With row strides ldx = d * C (and B = 1) on the d phase views of a sequence this is a dilated Conv1d
+ * (hifigan/models.py:27-55); an 11-tap conv is two 6-tap calls (pad 5, then pad 0 accumulating through `res`); a
+ * ConvTranspose1d(k = 2u, stride u, padding u/2) is the 3-tap conv (pad 1) whose n axis is (phase, c_out)
+ * (hifigan/models.py:128-137). */
+int styler_conv_gemm_pad(const float* x, int64_t ldx, const void* w, const float* scale,
+                         const float* shift, const float* res, int64_t ldres, float* y, int64_t ldy,
+                         int B, int L, int cin, int n, int kw, int pad, int act, int prec,
+                         void* stream);
 
 /* Which tile engine styler_conv_gemm dispatches for a shape: bit0 = 128x128 block tile (else
  * 64x64), bit1 = bf16 MFMA (else fp32 MFMA).  Used by bench.py to attribute launches. */
@@ -276,6 +288,10 @@ int styler_add2(const float* a, int64_t lda, const float* b, int64_t ldb, float*
                 int64_t ldy, int64_t rows, int C, void* stream);
 int styler_add_rowvec(const float* a, int64_t lda, const float* v, int64_t ldv, float* y,
                       int64_t ldy, int B, int L, int C, void* stream);
+/* y = leaky_relu(scale * (a (+ b) (+ c)), slope) over `count` contiguous floats: the pre-activation of every vocoder
+ * conv (hifigan/models.py:96,98,157) fused with the resblock average `xs / num_kernels` (164). */
+int styler_leaky_sum(const float* a, const float* b, const float* c, float* y, int64_t count,
+                     float scale, float slope, void* stream);
 
 /* get_mask_from_lengths (utils.py:223-232): mask[b,t] = (t >= len[b]), 1 byte per element
  * (torch.bool storage), True = padding. */

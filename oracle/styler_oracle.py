@@ -591,3 +591,53 @@ def mel_spectrogram(wav: Tensor, mel_basis: Optional[Tensor] = None) -> Tuple[Te
     mb = mel_filterbank() if mel_basis is None else mel_basis
     mel = torch.log(torch.clamp(torch.matmul(mb, mag), min=1e-5))
     return mel, torch.norm(mag, dim=1)
+
+
+# ----------------------------------------------------------------------------------
+# HiFi-GAN generator, mel -> waveform
+# ----------------------------------------------------------------------------------
+HIFIGAN_V1 = dict(upsample_rates=(8, 8, 2, 2), upsample_kernel_sizes=(16, 16, 4, 4),
+                  upsample_initial_channel=512, resblock_kernel_sizes=(3, 7, 11),
+                  resblock_dilation_sizes=((1, 3, 5), (1, 3, 5), (1, 3, 5)))    # hifigan/config.json
+LRELU_SLOPE = 0.1                                                                # hifigan/models.py:7
+
+
+def resolve_weight_norm(P: Params) -> Params:
+    """`torch.nn.utils.weight_norm` (dim 0) as the checkpoints store it (hifigan/models.py:26-91,115-146;
+    utils.py:259-261): weight = weight_g * weight_v / ||weight_v|| with the norm over every dim but 0.
+    Keys already folded (`.weight`, after remove_weight_norm) pass through."""
+    out = {}
+    for k, v in P.items():
+        if k.endswith(".weight_g"):
+            base = k[:-len("_g")]
+            wv = P[base + "_v"]
+            norm = wv.reshape(wv.shape[0], -1).norm(dim=1).reshape([-1] + [1] * (wv.dim() - 1))
+            out[base] = v * wv / norm
+        elif not k.endswith(".weight_v"):
+            out[k] = v
+    return out
+
+
+def hifigan_generator(P: Params, mel: Tensor, h: dict = HIFIGAN_V1) -> Tensor:
+    """Generator.forward, hifigan/models.py:155-169 with ResBlock.forward (94-101).
+    mel [B, 80, T] -> wav [B, 1, T * prod(upsample_rates)]."""
+    P = resolve_weight_norm(P)
+    nk = len(h["resblock_kernel_sizes"])
+    x = F.conv1d(mel, P["conv_pre.weight"], P["conv_pre.bias"], padding=3)
+    for i, (u, k) in enumerate(zip(h["upsample_rates"], h["upsample_kernel_sizes"])):
+        x = F.conv_transpose1d(F.leaky_relu(x, LRELU_SLOPE), P[f"ups.{i}.weight"], P[f"ups.{i}.bias"], stride=u,
+                               padding=(k - u) // 2)
+        acc = None
+        for j, (ks, dil) in enumerate(zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"])):
+            pre = f"resblocks.{i * nk + j}"
+            r = x
+            for m, d in enumerate(dil):
+                t = F.conv1d(F.leaky_relu(r, LRELU_SLOPE), P[f"{pre}.convs1.{m}.weight"], P[f"{pre}.convs1.{m}.bias"],
+                             dilation=d, padding=(ks * d - d) // 2)
+                t = F.conv1d(F.leaky_relu(t, LRELU_SLOPE), P[f"{pre}.convs2.{m}.weight"], P[f"{pre}.convs2.{m}.bias"],
+                             padding=(ks - 1) // 2)
+                r = t + r
+            acc = r if acc is None else acc + r
+        x = acc / nk
+    x = F.conv1d(F.leaky_relu(x), P["conv_post.weight"], P["conv_post.bias"], padding=3)    # default slope 0.01 (165)
+    return torch.tanh(x)

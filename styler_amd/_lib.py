@@ -16,6 +16,8 @@ F = ctypes.c_float
 _SIGS = {
     "styler_abi_version": [],
     "styler_conv_gemm": [P, I64, P, P, P, P, I64, P, I64, I, I, I, I, I, I, I, P, P, I64, I, P],
+    "styler_conv_gemm_pad": [P, I64, P, P, P, P, I64, P, I64, I, I, I, I, I, I, I, I, P],
+    "styler_leaky_sum": [P, P, P, P, I64, F, F, P],
     "styler_conv_gemm_variant": [I, I, I, I, I, I],
     "styler_cast_bf16": [P, P, I64, P],
     "styler_repack_conv_weight": [P, P, I, I, I, I, I, P],

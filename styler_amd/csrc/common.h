@@ -57,6 +57,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == STYLER_ACT_RELU) return fmaxf(v, 0.f);
   if (act == STYLER_ACT_TANH) return tanhf(v);
   if (act == STYLER_ACT_LOGCLAMP) return logf(fmaxf(v, 1e-5f));
+  if (act == STYLER_ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
   return v;
 }
 

@@ -464,6 +464,13 @@ extern "C" int styler_conv_gemm(const float* x, int64_t ldx, const void* w, cons
                                 nullptr, mask, ldmask, io_flags, stream);
 }
 
+extern "C" int styler_conv_gemm_pad(const float* x, int64_t ldx, const void* w, const float* scale,
+                                    const float* shift, const float* res, int64_t ldres, float* y, int64_t ldy,
+                                    int B, int L, int cin, int n, int kw, int pad, int act, int prec, void* stream) {
+  return styler_conv_gemm_impl2(x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, pad, act, prec, nullptr,
+                                nullptr, nullptr, 0, 0, stream);
+}
+
 // ---------------------------------------------------------------------------------------
 __global__ void cast_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t count) {
   int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;

@@ -9,6 +9,7 @@ import torch
 from ._lib import lib
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+ACT_LEAKY = 4                      # leaky_relu(0.1), the vocoder's LRELU_SLOPE
 PREC_F32, PREC_BF16 = 0, 1
 
 
@@ -279,6 +280,32 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
         e1.record()
         prof.records.append((lib.styler_conv_gemm_variant(B, L, cin, n, kw, prec), 2.0 * B * L * n * kw * cin,
                              e0, e1, plan is not None))
+    return out
+
+
+def conv_gemm_pad(x, w, bias=None, *, kw, pad, act=ACT_NONE, prec=PREC_F32, res=None, out=None):
+    """y = act(sum_j x[t + j - pad] w[:, j, :] + bias) (+ res) with an explicit left padding and any kw <= 9; x, res and
+    out may be strided row views ([B, L, C] with row stride d*C: the phase views of a dilated conv)."""
+    B, L, cin = x.shape
+    n = w.shape[0]
+    if out is None:
+        out = torch.empty(B, L, n, device=x.device, dtype=torch.float32)
+    _f32(x), _f32(out)
+    if prec == PREC_BF16 and w.dtype != torch.bfloat16:
+        raise StylerHipError("bf16 GEMM needs a bf16 weight shadow")
+    _chk(lib.styler_conv_gemm_pad(x.data_ptr(), _ld(x), w.data_ptr(), None, _ptr(bias), _ptr(res),
+                                  _ld(res) if res is not None else 0, out.data_ptr(), _ld(out), B, L, cin, n, kw, pad,
+                                  act, prec, _stream()), "styler_conv_gemm_pad")
+    return out
+
+
+def leaky_sum(a, b=None, c=None, *, scale=1.0, slope=0.1, out=None):
+    """out = leaky_relu(scale * (a + b + c), slope) on contiguous fp32 tensors (out may alias a)."""
+    assert a.is_contiguous() and (b is None or b.is_contiguous()) and (c is None or c.is_contiguous())
+    if out is None:
+        out = torch.empty_like(a)
+    _chk(lib.styler_leaky_sum(_f32(a).data_ptr(), _ptr(b), _ptr(c), out.data_ptr(), a.numel(), float(scale),
+                              float(slope), _stream()), "styler_leaky_sum")
     return out
 
 

@@ -30,6 +30,8 @@ def closed_form_tensor(key: str, ref: torch.Tensor) -> torch.Tensor:
     u = hash_uniform(zlib.crc32(key.encode()), ref.numel()).reshape(tuple(ref.shape))
     if key == "style_modeling.duration_predictor.linear_layer.bias":
         v = np.full(tuple(ref.shape), 1.3)             # free-running durations ~ e^1.3 - 1 > 0
+    elif key.endswith(".weight_g"):                      # weight-norm gains of the vocoder (hifigan/models.py)
+        v = 0.5 + 0.25 * u
     elif key.endswith("running_var"):
         v = 0.6 + 0.4 * (u + 1.0)                      # [0.6, 1.4)
     elif key.endswith("running_mean"):

@@ -51,3 +51,19 @@ def _reference_state_dict():
 @pytest.fixture(scope="session")
 def ref_state_dict():
     return _reference_state_dict()
+
+
+def _hifigan_state_dict():
+    """Weight-normed generator checkpoint (weight_g / weight_v / bias) with closed-form weights, from the committed
+    key/shape table of the reference's `hifigan.Generator(config.json).state_dict()`."""
+    import json
+    import torch
+    from closed_form import closed_form_tensor
+    with open(os.path.join(ROOT, "tests", "golden", "hifigan_state_dict_shapes.json")) as f:
+        table = json.load(f)
+    return {k: closed_form_tensor(k, torch.zeros(shape)) for k, shape in table.items()}
+
+
+@pytest.fixture(scope="session")
+def hifigan_state_dict():
+    return _hifigan_state_dict()

@@ -617,3 +617,89 @@ def test_batch_permutation_equivariance_full_c2(dev, ref_state_dict):
     finally:
         rt.strict_inputs = strict
         rt.set_precision("fp32")
+
+
+# ----------------------------------------------------------------------------- vocoder
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,cin,n,kw,pad,d,act", [
+    (56, 256, 256, 3, 1, 3, 4), (56, 256, 256, 7, 3, 5, 0), (61, 64, 64, 6, 5, 5, 0), (61, 64, 64, 6, 0, 3, 0),
+    (448, 128, 128, 3, 1, 1, 4), (7, 512, 2048, 3, 1, 1, 0), (1792, 32, 4, 7, 3, 1, 2), (9, 80, 512, 7, 3, 1, 0),
+])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_conv_gemm_pad_strided_views(dev, L, cin, n, kw, pad, d, act, prec):
+    """styler_conv_gemm_pad on the d phase views of a sequence == a dilated conv with left padding pad*d (torch),
+    with bias, activation-before-residual and in-place residual."""
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(L * 7 + cin + n + kw + d)
+    x = torch.randn(L, cin, generator=g)
+    w = torch.randn(n, cin, kw, generator=g) / np.sqrt(cin * kw)
+    b = torch.randn(n, generator=g)
+    r = torch.randn(L, n, generator=g)
+    xq, wq = (x.bfloat16().float(), w.bfloat16().float()) if prec == "bf16" else (x, w)
+    xp = F.pad(xq.t()[None], (pad * d, (kw - 1 - pad) * d))
+    ref = F.conv1d(xp, wq, b, dilation=d)[0].t()
+    ref = {0: lambda v: v, 2: torch.tanh, 4: lambda v: F.leaky_relu(v, 0.1)}[act](ref) + r
+    p = ops.PREC_BF16 if prec == "bf16" else ops.PREC_F32
+    wk = w.permute(0, 2, 1).reshape(n, kw * cin).contiguous().to(dev)
+    wk = wk.bfloat16() if prec == "bf16" else wk
+    xd, out = x.to(dev), r.to(dev).clone()
+    for ph in range(d):
+        if xd[ph::d].shape[0]:
+            ops.conv_gemm_pad(xd[ph::d].unsqueeze(0), wk, b.to(dev), kw=kw, pad=pad, act=act, prec=p,
+                              res=out[ph::d].unsqueeze(0), out=out[ph::d].unsqueeze(0))
+    check(out, ref, 2e-5 if prec == "fp32" else 2e-3, f"conv_gemm_pad L={L} kw={kw} pad={pad} d={d}")
+
+
+@pytest.mark.gpu
+def test_leaky_sum(dev):
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for count in (4096, 1027):
+        a, b, c = (torch.randn(count, generator=g) for _ in range(3))
+        y = ops.leaky_sum(a.to(dev), b.to(dev), c.to(dev), scale=1.0 / 3.0, slope=0.01)
+        check(y, F.leaky_relu((a + b + c) * (1.0 / 3.0), 0.01), 1e-6, "leaky_sum3")
+        ad = a.to(dev)
+        ops.leaky_sum(ad, out=ad)
+        check(ad, F.leaky_relu(a, 0.1), 0, "leaky in place")
+
+
+@pytest.fixture(scope="module")
+def vocoder(dev, hifigan_state_dict):
+    import json
+    import os
+    from styler_amd import hifigan
+    cfg = os.path.join(os.path.dirname(hifigan.__file__), "hifigan_config.json")
+    gen = hifigan.Generator(hifigan.AttrDict(json.load(open(cfg))))
+    gen.load_state_dict(hifigan_state_dict)
+    return gen.to(dev).eval()
+
+
+@pytest.mark.gpu
+def test_hifigan_generator_golden(dev, vocoder, golden):
+    """Generator.forward (hifigan/models.py:155-169) vs the reference-generated fixture: fp32 mode 1e-5 abs on a
+    waveform of amplitude 0.17, bf16 mode 1 % of the amplitude."""
+    from styler_amd import ops
+    g = golden("hifigan")
+    mel = T(g["mel"]).to(dev)
+    vocoder.prec = ops.PREC_F32
+    wav = vocoder(mel)
+    assert wav.shape == (2, 1, 1792)
+    check(wav, g["wav"], 1e-5, "hifigan fp32")
+    vocoder.prec = ops.PREC_BF16
+    check(vocoder(mel), g["wav"], 2e-3, "hifigan bf16")
+    vocoder.prec = None
+
+
+@pytest.mark.gpu
+def test_hifigan_generator_vs_oracle_long(dev, vocoder, O, hifigan_state_dict):
+    """One utterance of 83 frames (21 248 samples; lengths not divisible by the dilations) vs the oracle, and a batch
+    equals its items run alone (the reference convolves every item over exactly T frames)."""
+    from closed_form import hash_uniform
+    from styler_amd import ops
+    mel = torch.from_numpy(hash_uniform(77, 2 * 80 * 83).reshape(2, 80, 83) * 3.0 - 4.0).float()
+    ref = O.hifigan_generator(hifigan_state_dict, mel)
+    vocoder.prec = ops.PREC_F32
+    wav = vocoder(mel.to(dev))
+    check(wav, ref, 2e-5, "hifigan long")
+    check(vocoder(mel[1].to(dev)), ref[1:2], 2e-5, "hifigan single 2-D input")
+    vocoder.prec = None

@@ -168,3 +168,73 @@ def test_derived_layout_specs_match_torch_permutes():
     oh = torch.randn(3, 7, 5, generator=g)                                        # one-hot conv weight [C, 257, 5] -> [5, 257, C]
     C, Q, K = oh.shape
     assert torch.equal(run([Seg(oh, (K, Q, C), (1, K, Q * K), (Q * C, C, 1))], (K, Q, C)), oh.permute(2, 1, 0).contiguous())
+
+
+def _emulated_conv_gemm_pad(x, w, bias=None, *, kw, pad, act=0, prec=0, res=None, out=None):
+    """What styler_conv_gemm_pad computes (include/styler_hip.h), in torch on the CPU, honouring strided row views."""
+    import torch.nn.functional as F
+    B, L, cin = x.shape
+    n = w.shape[0]
+    xp = F.pad(x, (0, 0, pad, kw - 1 - pad))
+    cols = torch.cat([xp[:, j:j + L] for j in range(kw)], dim=-1)          # [B, L, kw*cin], tap-major like the weight
+    y = cols @ w.float().t()
+    if bias is not None:
+        y = y + bias
+    y = {0: lambda v: v, 1: torch.relu, 2: torch.tanh, 4: lambda v: F.leaky_relu(v, 0.1)}[act](y)
+    if res is not None:
+        y = y + res
+    if out is None:
+        return y
+    out.copy_(y)
+    return out
+
+
+def test_hifigan_host_composition_matches_reference(golden, hifigan_state_dict, monkeypatch):
+    """The vocoder's host logic -- weight-norm folding, the ConvTranspose -> 3-tap (phase, c_out) rearrangement, dilation
+    by phase views, the 11-tap split, buffer reuse -- checked on the CPU with the two HIP entry points it calls
+    replaced by their torch definitions.  (The HIP kernels themselves: tests/test_hip_parity.py, -m gpu.)"""
+    import json
+    import numpy as np
+    import torch.nn.functional as F
+    from styler_amd import hifigan, ops
+    g = golden("hifigan")
+    h = hifigan.AttrDict(json.load(open(os.path.join(ROOT, "styler_amd", "hifigan_config.json"))))
+    gen = hifigan.Generator(h)
+    ref_shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "hifigan_state_dict_shapes.json")))
+    assert {k: list(v.shape) for k, v in gen.state_dict().items()} == ref_shapes
+    gen.load_state_dict(hifigan_state_dict)
+
+    calls = {"gemm": 0, "leaky": 0}
+
+    def gemm(*a, **k):
+        calls["gemm"] += 1
+        return _emulated_conv_gemm_pad(*a, **k)
+
+    def leaky(a, b=None, c=None, *, scale=1.0, slope=0.1, out=None):
+        calls["leaky"] += 1
+        v = a + (0 if b is None else b) + (0 if c is None else c)
+        v = F.leaky_relu(v * scale, slope)
+        if out is None:
+            return v
+        out.copy_(v)
+        return out
+
+    monkeypatch.setattr(ops, "conv_gemm_pad", gemm)
+    monkeypatch.setattr(ops, "leaky_sum", leaky)
+    mel = torch.from_numpy(g["mel"]).transpose(1, 2).contiguous()
+    for fold in (False, True):
+        if fold:
+            gen.remove_weight_norm()
+            assert "conv_pre.weight" in gen.state_dict() and "conv_pre.weight_g" not in gen.state_dict()
+        plan = gen._prepare(ops.PREC_F32)
+        with torch.no_grad():
+            wav = torch.stack([gen._item(mel[b], plan, ops.PREC_F32) for b in range(mel.shape[0])])
+        err = float((wav - torch.from_numpy(g["wav"])[:, 0]).abs().max())
+        assert err < 5e-6, err
+    assert calls["gemm"] > 0 and calls["leaky"] > 0
+    # a folded checkpoint loads into a fresh (weight-normed) generator
+    gen2 = hifigan.Generator(h)
+    gen2.load_state_dict(gen.state_dict())
+    assert torch.equal(gen2.conv_post.weight, gen.conv_post.weight)
+    with pytest.raises(RuntimeError):
+        gen2(torch.zeros(1, 80, 4))                      # no CPU fallback

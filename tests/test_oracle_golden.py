@@ -197,3 +197,13 @@ def test_stft_mel(golden):
     assert (np.diff(peaks) > 0).all() and fb[:, 372:].sum() == 0     # fmax 8000 Hz -> bin 371.5
     with pytest.raises(AssertionError):
         O.mel_spectrogram(torch.full((1, 2048), 1.5))
+
+
+def test_hifigan_generator(golden, hifigan_state_dict):
+    """hifigan/models.py:155-169 on the weight-normed checkpoint format; 7 mel frames -> 1792 samples."""
+    g = golden("hifigan")
+    wav = O.hifigan_generator(hifigan_state_dict, T(g["mel"]))
+    close(wav, g["wav"], 2e-6)
+    assert float(np.abs(g["wav"]).max()) < 0.5          # not saturated: the comparison is sensitive
+    # folded (remove_weight_norm) checkpoints give the same result
+    close(O.hifigan_generator(O.resolve_weight_norm(hifigan_state_dict), T(g["mel"])), g["wav"], 2e-6)
