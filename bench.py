@@ -195,7 +195,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if os.environ.get("STYLER_TEST_SHARED_GPU"):
+            # test hook for 1-GPU boxes: every rank on cuda:0, collectives over gloo (RCCL refuses two ranks on one
+            # device) -- exercises the N > 1 control flow (sharding, two-graph step, all-reduce between the replays,
+            # max-over-ranks timing); the numbers it prints are NOT a scaling measurement
+            local_rank = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
