@@ -147,7 +147,12 @@ class Generator(nn.Module):
                 self.resblocks.append(ResBlock(h, ch, k, d))
         self.conv_post = _WNConv((1, ch, 7), 1, 7)
         self.prec = None                 # None: follow runtime.rt.prec; ops.PREC_F32 / ops.PREC_BF16 to pin
+        self.use_graph = False           # replay one captured hipGraph per (B, T): the eager pass is ~250 launches of a
+                                         # few microseconds per utterance, i.e. bound by the host's enqueue rate
+        self.fork_streams = True         # the three resblocks of a stage on three HIP streams
         self._plan = None
+        self._graphs = {}
+        self._side = []
 
     def remove_weight_norm(self):
         for l in self.ups:
@@ -186,6 +191,7 @@ class Generator(nn.Module):
                         b = torch.cat([b, b.new_zeros(4 - b.numel() % 4)])
                     plan[name] = (conv_taps(w, prec), b.contiguous())
         self._plan = (key, plan)
+        self._graphs = {}                # captured graphs hold pointers into the previous plan
         return plan
 
     # ---- arithmetic ---------------------------------------------------------------------------------------------------
@@ -226,6 +232,27 @@ class Generator(nn.Module):
             x = self._conv(t, e2, prec, res=x, out=xt)           # xt is dead: reuse it for the new residual stream
         return x
 
+    def _resblocks(self, x, plan, i, prec):
+        """The num_kernels resblocks of a stage are independent (hifigan/models.py:158-163) and, at utterance lengths,
+        each of their GEMMs fills a fraction of the 256 CUs: run them on forked HIP streams (inside a hipGraph
+        capture they become parallel branches) and join before the average."""
+        nk = self.num_kernels
+        if not self.fork_streams or nk == 1:
+            return [self._resblock(x, plan, i * nk + j, prec) for j in range(nk)]
+        cur = torch.cuda.current_stream(x.device)
+        if len(self._side) < nk - 1:
+            self._side = [torch.cuda.Stream(device=x.device) for _ in range(nk - 1)]
+        rs = [None] * nk
+        for j in range(nk - 1, 0, -1):                           # the widest kernel size first
+            side = self._side[j - 1]
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                rs[j] = self._resblock(x, plan, i * nk + j, prec)
+        rs[0] = self._resblock(x, plan, i * nk, prec)
+        for side in self._side[:nk - 1]:
+            cur.wait_stream(side)                                # (the next fork waits for `cur` again before any
+        return rs                                                #  side-stream block can be reused)
+
     def _item(self, mel, plan, prec):
         """mel [T, 80] -> wav [T * prod(rates)]; hifigan/models.py:155-169."""
         x = self._conv(mel, plan["conv_pre"], prec)
@@ -234,7 +261,7 @@ class Generator(nn.Module):
             entry = plan[f"ups.{i}"]
             cout = entry[1].numel() // self.h.upsample_rates[i]
             x = self._conv(x, entry, prec).view(-1, cout)        # [L, u*cout] == [L*u, cout]
-            rs = [self._resblock(x, plan, i * self.num_kernels + j, prec) for j in range(self.num_kernels)]
+            rs = self._resblocks(x, plan, i, prec)
             assert 1 <= len(rs) <= 3, "styler_leaky_sum folds at most three resblocks"
             rs += [None] * (3 - len(rs))
             last = i == self.num_upsamples - 1                   # F.leaky_relu(x) before conv_post: default slope 0.01
@@ -253,6 +280,30 @@ class Generator(nn.Module):
             prec = rt.prec
         plan = self._prepare(prec)
         with torch.no_grad():
-            mel = x.float().transpose(1, 2).contiguous()         # [B, T, 80]
-            wavs = [self._item(mel[b], plan, prec) for b in range(mel.shape[0])]
-            return torch.stack(wavs, 0).unsqueeze(1)
+            if self.use_graph:
+                return self._replay(x, plan, prec)
+            return self._run(x, plan, prec)
+
+    def _run(self, x, plan, prec):
+        mel = x.float().transpose(1, 2).contiguous()             # [B, T, 80]
+        wavs = [self._item(mel[b], plan, prec) for b in range(mel.shape[0])]
+        return torch.stack(wavs, 0).unsqueeze(1)
+
+    def _replay(self, x, plan, prec):
+        key = (tuple(x.shape), x.dtype, x.device, prec)
+        hit = self._graphs.get(key)
+        if hit is None:
+            static_in = x.clone()
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side):                        # warm the allocator outside the capture
+                self._run(static_in, plan, prec)
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self._run(static_in, plan, prec)
+            hit = self._graphs[key] = (graph, static_in, static_out)
+        graph, static_in, static_out = hit
+        static_in.copy_(x)
+        graph.replay()
+        return static_out.clone()

@@ -21,3 +21,33 @@ def mel_calibrator(mel, mel_len, seq_len):
     """utils.py:355-384."""
     S = int(seq_len.max().item())
     return ops.mel_calibrate(mel, mel_len.contiguous(), seq_len.contiguous(), S)
+
+
+def get_vocoder(checkpoint=None, device="cuda"):
+    """utils.py:235-273, the `hp.vocoder == "HiFi-GAN"` branch: Generator(hifigan/config.json), optionally
+    `checkpoint["generator"]` (the released generator_*.pth.tar files, absent here: random init), eval,
+    remove_weight_norm, to(device)."""
+    import json
+    import os
+    from . import hifigan
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "hifigan_config.json")) as f:
+        vocoder = hifigan.Generator(hifigan.AttrDict(json.load(f)))
+    if checkpoint is not None:
+        ckpt = torch.load(checkpoint, map_location="cpu") if isinstance(checkpoint, str) else checkpoint
+        vocoder.load_state_dict(ckpt["generator"] if "generator" in ckpt else ckpt)
+    vocoder.eval()
+    vocoder.remove_weight_norm()
+    return vocoder.to(device)
+
+
+def vocoder_infer(mel, vocoder, path=None):
+    """utils.py:276-293 (HiFi-GAN branch): mel [B, 80, T] (or [80, T]) -> int16 waveform, written to `path` as a
+    22.05 kHz wav when given."""
+    from . import hparams as hp
+    with torch.no_grad():
+        wav = vocoder(mel).squeeze(1)
+    wav = (wav.squeeze().cpu().numpy() * hp.max_wav_value).astype("int16")
+    if path is not None:
+        from scipy.io import wavfile
+        wavfile.write(path, hp.sampling_rate, wav)
+    return wav

@@ -685,6 +685,18 @@ def test_hifigan_generator_golden(dev, vocoder, golden):
     wav = vocoder(mel)
     assert wav.shape == (2, 1, 1792)
     check(wav, g["wav"], 1e-5, "hifigan fp32")
+    vocoder.fork_streams = False                   # resblocks on one stream: same bits as the forked default
+    assert torch.equal(vocoder(mel), wav)
+    vocoder.fork_streams = True
+    vocoder.use_graph = True                       # one hipGraph per (B, T): same launches, same bits
+    for scale in (1.0, 0.5, 1.0):
+        eager_ref = wav if scale == 1.0 else None
+        got = vocoder(mel * scale)
+        if eager_ref is not None:
+            assert torch.equal(got, eager_ref)
+    vocoder.use_graph = False
+    half = vocoder(mel * 0.5)                       # eager path still works after graph mode
+    assert not torch.equal(half, wav)
     vocoder.prec = ops.PREC_BF16
     check(vocoder(mel), g["wav"], 2e-3, "hifigan bf16")
     vocoder.prec = None

@@ -203,6 +203,7 @@ def test_hifigan_host_composition_matches_reference(golden, hifigan_state_dict, 
     ref_shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "hifigan_state_dict_shapes.json")))
     assert {k: list(v.shape) for k, v in gen.state_dict().items()} == ref_shapes
     gen.load_state_dict(hifigan_state_dict)
+    gen.fork_streams = False                             # HIP streams: GPU tests
 
     calls = {"gemm": 0, "leaky": 0}
 
