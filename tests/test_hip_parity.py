@@ -715,3 +715,26 @@ def test_hifigan_generator_vs_oracle_long(dev, vocoder, O, hifigan_state_dict):
     check(wav, ref, 2e-5, "hifigan long")
     check(vocoder(mel[1].to(dev)), ref[1:2], 2e-5, "hifigan single 2-D input")
     vocoder.prec = None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,cin,kw", [(256, 1024, 1), (1024, 256, 9), (80, 512, 5)])
+def test_weight_repack_entry_points(dev, n, cin, kw):
+    """The stand-alone layout converters of the C ABI (a C caller's way to the kernel layouts; the Python host uses
+    strided-copy specs): [n,cin,kw] <-> [n,kw,cin] and the tap-flipped, transposed dX layout [cin,kw,n]."""
+    from styler_amd._lib import lib
+    from styler_amd import ops
+    w = torch.randn(n, cin, kw, generator=torch.Generator().manual_seed(n + cin + kw)).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for bf16 in (0, 1):
+        dt = torch.bfloat16 if bf16 else torch.float32
+        k = torch.empty(n, kw, cin, device=dev, dtype=dt)
+        ops._chk(lib.styler_repack_conv_weight(w.data_ptr(), k.data_ptr(), n, cin, kw, 1, bf16, st), "repack")
+        assert torch.equal(k, w.permute(0, 2, 1).to(dt))
+        b = torch.empty(cin, kw, n, device=dev, dtype=dt)
+        ops._chk(lib.styler_repack_weight_bwd(w.data_ptr(), b.data_ptr(), n, cin, kw, bf16, st), "repack_bwd")
+        assert torch.equal(b, w.flip(2).permute(1, 2, 0).to(dt))
+    back = torch.empty(n, cin, kw, device=dev)
+    k32 = w.permute(0, 2, 1).contiguous()
+    ops._chk(lib.styler_repack_conv_weight(k32.data_ptr(), back.data_ptr(), n, cin, kw, 0, 0, st), "repack back")
+    assert torch.equal(back, w)
