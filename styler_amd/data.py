@@ -69,3 +69,124 @@ def to_device(sub_batch, device, pinned=True):
             t = t.pin_memory()
         out[k] = t.to(device, non_blocking=True)
     return out, int(np.max(sub_batch["src_len"])), int(np.max(sub_batch["mel_len"]))
+
+
+# ---- feature store + prefetching feeder --------------------------------------------------------------------------------
+_STORE_FILES = (                                   # key, sub-directory, file tag (dataset.py:90-118)
+    ("mel_target", "mel_clean", "mel"), ("mel_aug", "mel_aug", "mel"), ("D", "alignment", "ali"),
+    ("f0", "f0", "f0"), ("f0_norm", "f0_norm", "f0"), ("f0_norm_aug", "f0_norm_aug", "f0"),
+    ("energy", "energy", "energy"), ("energy_input", "energy_0to1", "energy"),
+    ("energy_input_aug", "energy_0to1_aug", "energy"),
+)
+
+
+def process_meta(meta_path):
+    """utils.py:87-95: `basename|text` lines."""
+    names, texts = [], []
+    with open(meta_path, "r", encoding="utf-8") as f:
+        for line in f.readlines():
+            n, t = line.strip("\n").split("|")
+            names.append(n)
+            texts.append(t)
+    return names, texts
+
+
+class FeatureStore:
+    """`dataset.Dataset` (dataset.py:74-129) over the preprocessed `.npy` feature store: same directory / file naming
+    scheme, same item dict.  The text front end (`text.text_to_sequence`) is outside this path: pass it (or any
+    `str -> int array` callable) as `tokenizer`."""
+
+    def __init__(self, root, tokenizer, filename="train.txt", dataset="VCTK", sort=True):
+        import os
+        self.root, self.dataset, self.tokenizer, self.sort = root, dataset, tokenizer, sort
+        self.basename, self.text = process_meta(os.path.join(root, filename))
+
+    def __len__(self):
+        return len(self.text)
+
+    def _load(self, sub, tag, name):
+        import os
+        return np.load(os.path.join(self.root, sub, "{}-{}-{}.npy".format(self.dataset, tag, name)))
+
+    def __getitem__(self, idx):
+        basename = self.basename[idx]
+        item = {"id": basename, "text": np.array(self.tokenizer(self.text[idx])),
+                "speaker_embed": self._load("spker_embed", "spker_embed", str(basename.split("_")[0]))}
+        for key, sub, tag in _STORE_FILES:
+            item[key] = self._load(sub, tag, basename)
+        return item
+
+    def collate_fn(self, batch):
+        return collate_fn(batch, self.sort)
+
+
+class BatchFeeder:
+    """The training loop's data side (train.py:28-30, 99-132) for one rank: `batch_size^2` items per group (shuffled
+    order, last partial group dropped, as DataLoader(shuffle=True, drop_last=True)), groups dealt round-robin to the
+    ranks, each group collated into `batch_size` sorted sub-batches; a background thread reads and collates `depth`
+    sub-batches ahead and stages them through pinned memory on a copy stream, so the consumer never waits on `np.load`,
+    padding or the H2D copies.  Iterating yields `(tensors, max_src_len, max_mel_len)` like `to_device`."""
+
+    def __init__(self, store, device, batch_size=None, rank=0, world=1, shuffle=True, seed=0, depth=4):
+        self.store, self.device = store, torch.device(device)
+        self.batch_size = hp.batch_size if batch_size is None else batch_size
+        self.rank, self.world, self.shuffle, self.seed, self.depth = rank, world, shuffle, seed, depth
+        self.epoch = 0
+
+    def groups(self):
+        """Item indices of this rank's groups for the current epoch (every rank derives the same permutation)."""
+        n, g = len(self.store), self.batch_size ** 2
+        order = np.random.RandomState(self.seed + self.epoch).permutation(n) if self.shuffle else np.arange(n)
+        full = [order[i * g:(i + 1) * g] for i in range(n // g)]
+        return full[self.rank::self.world]
+
+    def __len__(self):
+        return len(self.groups()) * self.batch_size
+
+    def _produce(self, q, stop):
+        use_cuda = self.device.type == "cuda"
+        copy_stream = torch.cuda.Stream(device=self.device) if use_cuda else None
+        try:
+            for group in self.groups():
+                for sub in self.store.collate_fn([self.store[int(i)] for i in group]):
+                    if stop.is_set():
+                        return
+                    if use_cuda:
+                        with torch.cuda.stream(copy_stream):
+                            out = to_device(sub, self.device, pinned=True)
+                            ready = torch.cuda.Event()
+                            ready.record(copy_stream)
+                    else:
+                        out, ready = to_device(sub, self.device, pinned=False), None
+                    q.put((out, ready))
+            q.put(None)
+        except BaseException as e:                     # surface reader errors in the consumer
+            q.put(e)
+
+    def __iter__(self):
+        import queue
+        import threading
+        q, stop = queue.Queue(maxsize=self.depth), threading.Event()
+        worker = threading.Thread(target=self._produce, args=(q, stop), daemon=True)
+        worker.start()
+        try:
+            while True:
+                got = q.get()
+                if got is None:
+                    break
+                if isinstance(got, BaseException):
+                    raise got
+                (tensors, s, t), ready = got
+                if ready is not None:
+                    torch.cuda.current_stream(self.device).wait_event(ready)
+                    for v in tensors.values():         # allocated on the copy stream, consumed on this one
+                        v.record_stream(torch.cuda.current_stream(self.device))
+                yield tensors, s, t
+        finally:
+            stop.set()
+            while worker.is_alive():                   # unblock a producer waiting on a full queue
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    worker.join(timeout=0.05)
+            self.epoch += 1

@@ -738,3 +738,21 @@ def test_weight_repack_entry_points(dev, n, cin, kw):
     k32 = w.permute(0, 2, 1).contiguous()
     ops._chk(lib.styler_repack_conv_weight(k32.data_ptr(), back.data_ptr(), n, cin, kw, 0, 0, st), "repack back")
     assert torch.equal(back, w)
+
+
+@pytest.mark.gpu
+def test_batch_feeder_pinned_async_h2d(dev, tmp_path):
+    """The feeder's CUDA leg (pinned staging on a copy stream, event hand-over to the consumer stream) delivers the
+    same tensors as the synchronous path, and they feed a forward directly."""
+    from golden.make_golden_store import tokenizer, write_store
+    from styler_amd.data import BatchFeeder, FeatureStore, to_device
+    write_store(str(tmp_path))
+    ds = FeatureStore(str(tmp_path), tokenizer)
+    feeder = BatchFeeder(ds, dev, batch_size=2, seed=1, depth=3)
+    want = [to_device(sub, "cpu", pinned=False) for grp in feeder.groups() for sub in ds.collate_fn([ds[int(i)] for i in grp])]
+    got = list(feeder)
+    assert len(got) == len(want) == 10
+    for (a, sa, ta), (b, sb, tb) in zip(got, want):
+        assert (sa, ta) == (sb, tb)
+        for k in a:
+            assert a[k].is_cuda and torch.equal(a[k].cpu(), b[k]), k

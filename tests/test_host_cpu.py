@@ -239,3 +239,67 @@ def test_hifigan_host_composition_matches_reference(golden, hifigan_state_dict, 
     assert torch.equal(gen2.conv_post.weight, gen.conv_post.weight)
     with pytest.raises(RuntimeError):
         gen2(torch.zeros(1, 80, 4))                      # no CPU fallback
+
+
+def test_feature_store_matches_reference(golden, tmp_path):
+    """styler_amd.data.FeatureStore vs the reference `dataset.Dataset.__getitem__ / collate_fn` reading the same
+    synthetic `.npy` store (tests/golden/make_golden_store.py regenerates it here from the same seed)."""
+    import numpy as np
+    from golden.make_golden_store import tokenizer, write_store
+    from styler_amd.data import FeatureStore
+    write_store(str(tmp_path))
+    g = golden("store")
+    ds = FeatureStore(str(tmp_path), tokenizer)
+    assert len(ds) == int(g["n"])
+    for idx in (0, 7, 19):
+        item = ds[idx]
+        keys = {k[len(f"item{idx}_"):] for k in g.files if k.startswith(f"item{idx}_")}
+        assert set(item) == keys
+        for k in keys:
+            ref = g[f"item{idx}_{k}"]
+            if k == "id":
+                assert item[k] == str(ref)
+            else:
+                assert item[k].dtype == ref.dtype and np.array_equal(item[k], ref), k
+    subs = ds.collate_fn([ds[i] for i in range(16)])
+    assert len(subs) == int(g["n_sub"])
+    for j in (0, 3):
+        for k, v in subs[j].items():
+            ref = g[f"sub{j}_{k}"]
+            if k == "id":
+                assert list(v) == [str(x) for x in ref]
+            else:
+                assert np.array_equal(v, ref), k
+
+
+def test_batch_feeder_shards_prefetches_and_reshuffles(tmp_path):
+    import numpy as np
+    from golden.make_golden_store import tokenizer, write_store
+    from styler_amd.data import BatchFeeder, FeatureStore, to_device
+    write_store(str(tmp_path))
+    ds = FeatureStore(str(tmp_path), tokenizer)
+    feeders = [BatchFeeder(ds, "cpu", batch_size=2, rank=r, world=2, seed=3, depth=2) for r in range(2)]
+    groups = [f.groups() for f in feeders]
+    flat = np.concatenate([np.concatenate(g) for g in groups])
+    assert len(flat) == 20 and len(set(flat.tolist())) == 20            # 5 groups of 4: disjoint, nothing dropped
+    assert [len(g) for g in groups] == [3, 2] and len(feeders[0]) == 6
+    got = list(feeders[0])
+    want = [to_device(sub, "cpu", pinned=False) for grp in groups[0] for sub in ds.collate_fn([ds[int(i)] for i in grp])]
+    assert len(got) == len(want) == 6
+    for (a, sa, ta), (b, sb, tb) in zip(got, want):
+        assert (sa, ta) == (sb, tb) and a.keys() == b.keys()
+        assert all(torch.equal(a[k], b[k]) for k in a)
+        assert a["text"].dtype == torch.long and a["mel_target"].dtype == torch.float32
+    assert feeders[0].epoch == 1                                         # next epoch: another permutation
+    assert not all(np.array_equal(x, y) for x, y in zip(feeders[0].groups(), groups[0]))
+    it = iter(feeders[1])                                                # abandoning an epoch mid-way stops the reader
+    next(it)
+    it.close()
+    ordered = BatchFeeder(ds, "cpu", batch_size=2, shuffle=False)
+    assert np.array_equal(np.concatenate(ordered.groups()), np.arange(20))
+
+    class Broken(FeatureStore):
+        def __getitem__(self, idx):
+            raise OSError("unreadable feature file")
+    with pytest.raises(OSError):
+        list(BatchFeeder(Broken(str(tmp_path), tokenizer), "cpu", batch_size=2))
