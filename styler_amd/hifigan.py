@@ -30,6 +30,15 @@ class AttrDict(dict):
         self.__dict__ = self
 
 
+def config_v1():
+    """The generator fields of hifigan/config.json (the universal / LJSpeech V1 generator the reference loads,
+    utils.py:251-258)."""
+    return AttrDict(resblock="1", upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4],
+                    upsample_initial_channel=512, resblock_kernel_sizes=[3, 7, 11],
+                    resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], num_mels=80, hop_size=256,
+                    sampling_rate=22050)
+
+
 def get_padding(kernel_size, dilation=1):
     return int((kernel_size * dilation - dilation) / 2)
 

@@ -27,11 +27,8 @@ def get_vocoder(checkpoint=None, device="cuda"):
     """utils.py:235-273, the `hp.vocoder == "HiFi-GAN"` branch: Generator(hifigan/config.json), optionally
     `checkpoint["generator"]` (the released generator_*.pth.tar files, absent here: random init), eval,
     remove_weight_norm, to(device)."""
-    import json
-    import os
     from . import hifigan
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "hifigan_config.json")) as f:
-        vocoder = hifigan.Generator(hifigan.AttrDict(json.load(f)))
+    vocoder = hifigan.Generator(hifigan.config_v1())
     if checkpoint is not None:
         ckpt = torch.load(checkpoint, map_location="cpu") if isinstance(checkpoint, str) else checkpoint
         vocoder.load_state_dict(ckpt["generator"] if "generator" in ckpt else ckpt)

@@ -665,11 +665,8 @@ def test_leaky_sum(dev):
 
 @pytest.fixture(scope="module")
 def vocoder(dev, hifigan_state_dict):
-    import json
-    import os
     from styler_amd import hifigan
-    cfg = os.path.join(os.path.dirname(hifigan.__file__), "hifigan_config.json")
-    gen = hifigan.Generator(hifigan.AttrDict(json.load(open(cfg))))
+    gen = hifigan.Generator(hifigan.config_v1())
     gen.load_state_dict(hifigan_state_dict)
     return gen.to(dev).eval()
 

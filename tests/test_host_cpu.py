@@ -198,7 +198,7 @@ def test_hifigan_host_composition_matches_reference(golden, hifigan_state_dict, 
     import torch.nn.functional as F
     from styler_amd import hifigan, ops
     g = golden("hifigan")
-    h = hifigan.AttrDict(json.load(open(os.path.join(ROOT, "styler_amd", "hifigan_config.json"))))
+    h = hifigan.config_v1()
     gen = hifigan.Generator(h)
     ref_shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "hifigan_state_dict_shapes.json")))
     assert {k: list(v.shape) for k, v in gen.state_dict().items()} == ref_shapes
