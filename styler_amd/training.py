@@ -7,6 +7,7 @@ from . import hparams as hp
 from . import ops
 from .dist import allreduce_mean_
 from .loss import DomainAdversarialTrainingLoss, STYLERLoss
+from .optimizer import noam_lr
 from .runtime import Derived, rt
 
 
@@ -77,8 +78,7 @@ class TrainState:
     def lr(self):
         """optimizer.py:21-32: the counter is incremented BEFORE the rate is computed."""
         self.n_current_steps += 1
-        s = self.n_current_steps
-        return hp.encoder_hidden ** -0.5 * min(s ** -0.5, hp.n_warm_up_step ** -1.5 * s)
+        return noam_lr(self.n_current_steps, hp.encoder_hidden, hp.n_warm_up_step)
 
     def step(self):
         """nn.utils.clip_grad_norm_(params, 1.0) + ScheduledOptim.step_and_update_lr() (train.py:181-185)."""
