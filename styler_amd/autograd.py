@@ -477,6 +477,20 @@ class PackRowsFn(Function):
         return ops.unpack_rows(dy, ctx.plan), None, None
 
 
+class PackPairFn(Function):
+    """Two padded [B, T, C] tensors (+ positional table) -> one packed batch of 2B items; backward = unpack per half."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, pe, plan):
+        ctx.plan = plan
+        return ops.pack_rows_pair(xa, xb, plan, add=pe)
+
+    @staticmethod
+    def backward(ctx, dy):
+        da, db = ops.unpack_rows_pair(dy, ctx.plan)
+        return da, db, None, None
+
+
 class UnpackRowsFn(Function):
     """packed -> padded with zero rows at t >= len[b]; backward = pack."""
 

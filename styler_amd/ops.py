@@ -231,6 +231,33 @@ def pack_rows(x, plan, add=None):
     return out
 
 
+def pack_rows_pair(xa, xb, plan, add=None):
+    """Two padded [B, T, C] tensors -> one packed [1, 2B*T, C] tensor whose items 0..B-1 come from `xa` and B..2B-1 from
+    `xb` (`plan` is the PackPlan of the 2B items): the clean and the noisy decode of styler.py:52,55 as ONE batch."""
+    B, T, C = xa.shape
+    assert xb.shape == xa.shape and (2 * B, T) == (plan.B, plan.T)
+    assert add is None or (add.shape[0] >= T and add.shape[1] == C and add.is_contiguous())
+    out = torch.empty(1, 2 * B * T, C, device=xa.device, dtype=torch.float32)
+    for half, x in enumerate((xa, xb)):
+        _chk(lib.styler_pack_rows(_f32(x).data_ptr(), _ld(x), out.data_ptr(), C, _ptr(add),
+                                  plan.cu.data_ptr() + 4 * B * half, B, T, C, _stream()), "styler_pack_rows")
+    return out
+
+
+def unpack_rows_pair(xp, plan):
+    """Inverse of pack_rows_pair (also its backward): packed [1, 2B*T, C] -> two padded [B, T, C] tensors."""
+    C = xp.shape[-1]
+    xp = _rows_view(xp)
+    B = plan.B // 2
+    outs = []
+    for half in range(2):
+        out = torch.empty(B, plan.T, C, device=xp.device, dtype=torch.float32)
+        _chk(lib.styler_unpack_rows(xp.data_ptr(), _ld(xp), out.data_ptr(), C, plan.cu.data_ptr() + 4 * B * half, B,
+                                    plan.T, C, _stream()), "styler_unpack_rows")
+        outs.append(out)
+    return outs
+
+
 def unpack_rows(xp, plan):
     """[1, B*T, C] packed -> [B, T, C] padded with zeros at t >= len[b]."""
     C = xp.shape[-1]

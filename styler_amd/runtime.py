@@ -1,4 +1,6 @@
 """Process-wide runtime switches of the HIP path."""
+import os
+
 from . import _lib, ops
 
 
@@ -14,6 +16,8 @@ class _Runtime:
                                         # of the reference cannot be reproduced)
 
     pack_decoder = True        # run the decoder's FFT blocks on the valid frames only (packed rows, pack.hip)
+    # clean + noisy decode (styler.py:52,55) as one packed batch of 2B items (STYLER_PAIR_DECODES=0: two passes)
+    pair_decodes = os.environ.get("STYLER_PAIR_DECODES", "1") != "0"
 
     def set_precision(self, name):
         self.prec = {"fp32": ops.PREC_F32, "bf16": ops.PREC_BF16}[name]

@@ -39,6 +39,17 @@ class STYLER(_HipModule):
             mel_output_postnet = mel_output
         return mel_output, mel_output_postnet
 
+    def decode_pair(self, out_clean, out_noisy, mel_mask, mel_len=None):
+        """`decode(out_clean)` and `decode(out_noisy)` (styler.py:52,55) with the Decoder and mel_linear run once on the
+        stacked batch; PostNet stays per branch (its BatchNorm statistics are per call, Layers.py:126)."""
+        lens = mel_len if mel_len is not None else self._lens_from_mask(mel_mask)
+        B = out_clean.shape[0]
+        mel2 = self._gemm("mel_linear", self.decoder.forward_pair(out_clean, out_noisy, lens), self.mel_linear)
+        outs = []
+        for mel in (mel2[:B], mel2[B:]):
+            outs.append((mel, self.postnet(mel, add_residual=mel) if self.use_postnet else mel))
+        return outs
+
     def forward(self, src_seq, mel_target, mel_aug, p_norm, e_input, src_len, mel_len, d_target=None,
                 p_target=None, e_target=None, max_src_len=None, max_mel_len=None, speaker_embed=None,
                 d_control=1.0, p_control=1.0, e_control=1.0):
@@ -58,13 +69,18 @@ class STYLER(_HipModule):
         if d_target is None:
             mel_len, mel_mask = new_len, new_mask
 
-        mel_output, mel_output_postnet = self.decode(style_modeling_output, mel_mask, mel_len)
+        noisy_in = self.style_modeling._out_noisy
         if self.clean_only:
+            mel_output, mel_output_postnet = self.decode(style_modeling_output, mel_mask, mel_len)
             mel_output_noisy, mel_output_postnet_noisy = mel_output, mel_output_postnet
+        elif (rt.pair_decodes and rt.pack_decoder and 2 * src_seq.shape[0] <= 4096
+              and noisy_in.shape == style_modeling_output.shape):
+            # styler.py:52,55: decode(x) and decode(x.detach() + noise_encoding) as one stacked batch; the second input
+            # was produced by the bucketise/embed/add kernel in the same pass
+            (mel_output, mel_output_postnet), (mel_output_noisy, mel_output_postnet_noisy) = self.decode_pair(
+                style_modeling_output, noisy_in, mel_mask, mel_len)
         else:
-            # styler.py:55: decode(style_modeling_output.detach() + noise_encoding); the sum was produced by
-            # the bucketise/embed/add kernel in the same pass
-            mel_output_noisy, mel_output_postnet_noisy = self.decode(self.style_modeling._out_noisy, mel_mask,
-                                                                     mel_len)
+            mel_output, mel_output_postnet = self.decode(style_modeling_output, mel_mask, mel_len)
+            mel_output_noisy, mel_output_postnet_noisy = self.decode(noisy_in, mel_mask, mel_len)
         return ((mel_output, mel_output_noisy), (mel_output_postnet, mel_output_postnet_noisy), d_prediction,
                 p_prediction, e_prediction, src_mask, mel_mask, mel_len, aug)

@@ -202,6 +202,19 @@ class Decoder(nn.Module, _PositionMixin):
             x = layer(x, lens)
         return x
 
+    def forward_pair(self, seq_a, seq_b, lens):
+        """The clean and the noisy decode (styler.py:52,55) as ONE packed batch of 2B items: the FFT blocks are row- and
+        item-wise, so the result is the two separate calls stacked, [2B, T, C] -- with half the launches and twice
+        the rows per GEMM (at B=48 the N=256 GEMMs of one decode are 212 tiles on 256 CUs)."""
+        B, T, _ = seq_a.shape
+        pe = self._pe(T, seq_a.device)
+        tape = (self.training and torch.is_grad_enabled()) and (seq_a.requires_grad or seq_b.requires_grad)
+        plan = ops.PackPlan(torch.cat([lens, lens]), 2 * B, T)
+        x = AG.PackPairFn.apply(seq_a, seq_b, pe, plan) if tape else ops.pack_rows_pair(seq_a, seq_b, plan, add=pe)
+        for layer in self.layer_stack:
+            x = layer(x, plan.nrows, plan=plan)
+        return AG.UnpackRowsFn.apply(x, plan) if tape else ops.unpack_rows(x, plan)
+
 
 class ConvNorm(nn.Module):
     """Layers.py:37-64 (parameter holder: `.conv`)."""

@@ -753,3 +753,52 @@ def test_batch_feeder_pinned_async_h2d(dev, tmp_path):
         assert (sa, ta) == (sb, tb)
         for k in a:
             assert a[k].is_cuda and torch.equal(a[k].cpu(), b[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_paired_decodes_match_separate(dev, ref_state_dict, prec):
+    """Clean + noisy decode as one stacked packed batch (STYLER.decode_pair) vs two separate decodes: identical eval
+    outputs (every kernel is row- or item-wise), same gradients in train mode (dropout off) up to the summation order of
+    the weight-gradient GEMMs."""
+    from closed_form import make_batch
+    from styler_amd import STYLER, rt
+    from styler_amd.training import train_losses
+    b = make_batch(5, 8, 30, 1, 9, seed=78)
+    bd = {k: v.to(dev) for k, v in b.items()}
+    S, T = bd["text"].shape[1], bd["mel_target"].shape[1]
+    m = STYLER()
+    m.load_state_dict(ref_state_dict)
+    m = m.to(dev)
+    rt.set_precision(prec)
+    rt.disable_dropout = True
+    keep = rt.pair_decodes
+    try:
+        outs, grads, losses = [], [], []
+        for pair in (False, True):
+            rt.pair_decodes = pair
+            m.eval()
+            with torch.no_grad():
+                o = m(bd["text"], bd["mel_target"], bd["mel_aug"], bd["f0_norm"], bd["energy_input"], bd["src_len"],
+                      bd["mel_len"], bd["D"], bd["f0"], bd["energy"], S, T, speaker_embed=bd["speaker_embed"])
+            outs.append([o[0][0], o[0][1], o[1][0], o[1][1]])
+            m.train()
+            m.zero_grad(set_to_none=True)
+            ls = train_losses(m, bd)
+            ls[0].backward()
+            losses.append([float(x) for x in ls])
+            grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        for a, c in zip(*outs):
+            e = float((a - c).abs().max()) / max(float(a.abs().max()), 1e-6)
+            assert a.shape == c.shape and e <= (1e-5 if prec == "fp32" else 2e-2), f"eval outputs differ: {e:.3e}"
+        assert not torch.equal(outs[1][0], outs[1][1])                       # the noisy branch is a different signal
+        for x, y in zip(*losses):
+            assert abs(x - y) <= 1e-5 * max(1.0, abs(x)) if prec == "fp32" else abs(x - y) <= 2e-2 * max(1.0, abs(x))
+        assert grads[0].keys() == grads[1].keys()
+        for k in grads[0]:
+            e = float((grads[0][k] - grads[1][k]).abs().max()) / max(float(grads[0][k].abs().max()), 1e-4)
+            assert e <= (1e-4 if prec == "fp32" else 5e-2), f"{k}: {e:.3e}"
+    finally:
+        rt.pair_decodes = keep
+        rt.disable_dropout = False
+        rt.set_precision("fp32")
