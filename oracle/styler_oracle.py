@@ -21,7 +21,7 @@ Every function cites the reference file:line it restates (paths relative to
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional, Sequence, Tuple
+from typing import Dict, Optional, Tuple
 
 import numpy as np
 import torch

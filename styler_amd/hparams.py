@@ -1,7 +1,5 @@
 """Hyper-parameters of the STYLER hot path (values of the reference's hparams.py; the kernels are
 specialised for them: hidden 256, 4 heads x 64, FFN 1024 with k = (9, 1), predictors k = 3)."""
-import math
-
 # Quantization for F0 and energy (hparams.py:21-25)
 f0_min, f0_max = 71.0, 797.9
 energy_min, energy_max = 0.1, 525.43

@@ -4,7 +4,6 @@ import torch
 import torch.nn as nn
 
 from . import hparams as hp
-from . import ops
 from .modules import StyleModeling
 from .runtime import rt
 from .transformer import Decoder, PostNet, _HipModule

@@ -28,7 +28,6 @@ def _reference_state_dict():
     (tests/golden/state_dict_shapes.json); the three formula-defined buffers come from
     their defining formulas (Models.py:11-30, modules.py:278-281)."""
     import json
-    import math
     import numpy as np
     import torch
     from closed_form import closed_form_tensor

@@ -266,7 +266,6 @@ def test_small_op_backwards(dev):
     for k, v in clf.named_parameters():
         check(v.grad, P["c." + k].grad, 5e-5, "aug " + k)
     # masked losses + nll
-    from styler_amd.loss import STYLERLoss
     a = torch.randn(4, 9, 80, generator=g, dtype=torch.float64, requires_grad=True)
     b = torch.randn(4, 9, 80, generator=g, dtype=torch.float64)
     lens = torch.tensor([5, 1, 9, 3])

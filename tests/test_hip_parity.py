@@ -296,7 +296,6 @@ def test_bucket_embed_add(dev, golden):
 
 def test_masks_and_losses(dev, O):
     from styler_amd import ops
-    from styler_amd.loss import STYLERLoss
     lens = torch.tensor([5, 0, 9, 3])
     assert torch.equal(ops.length_mask(lens.to(dev), 9).cpu(), O.length_mask(lens, 9))
     gen = torch.Generator().manual_seed(13)

@@ -1,5 +1,5 @@
 """Where does an EAGER train step spend its time?  Wall time (device-synchronised) per phase + top host functions."""
-import sys, os, cProfile, pstats, io, time
+import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch

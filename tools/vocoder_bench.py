@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
-    from styler_amd import hifigan, ops, utils
+    from styler_amd import ops, utils
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     voc = utils.get_vocoder(device=dev)
