@@ -281,8 +281,12 @@ class Generator(nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("styler_amd.hifigan.Generator runs on the MI355X HIP path only (no CPU fallback)")
+        if self.conv_post.bias.device != x.device:
+            raise RuntimeError(f"vocoder weights on {self.conv_post.bias.device}, mel on {x.device}: call .to(device) first")
         if x.dim() == 2:
             x = x.unsqueeze(0)
+        if x.dim() != 3 or x.shape[1] != 80:
+            raise ValueError(f"expected mel [B, 80, T], got {tuple(x.shape)}")
         prec = self.prec
         if prec is None:
             from .runtime import rt
