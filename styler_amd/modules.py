@@ -179,6 +179,8 @@ class StyleEncoder(_HipModule):
         self.text_linear_down = nn.Sequential(nn.Linear(hp.encoder_hidden, hp.va_neck_hidden_t), nn.ReLU())
         self.speaker_linear_p = nn.Sequential(nn.Linear(hp.speaker_embed_dim, hp.va_neck_hidden_p * 2), nn.ReLU())
         self.speaker_linear = nn.Sequential(nn.Linear(hp.speaker_embed_dim, hp.encoder_hidden), nn.ReLU())
+        self.dat_inputs = None        # (mel_aug, f0_norm_aug, energy_input_aug) of the DAT pass, set by train_losses
+        self.dat_encodings = None     # its (d, p, e) encodings when the forward ran both passes as one batch
 
     def encoder_input_cat(self, mel_target, p_norm, e_input, mel_aug):
         return EncoderInput(mel_target.contiguous(), p_norm.contiguous(), e_input.contiguous(),
@@ -191,8 +193,22 @@ class StyleEncoder(_HipModule):
         spk_in = speaker_embed.unsqueeze(1)
         speaker_encoding_p = self._gemm("slp", spk_in, self.speaker_linear_p[0], act=ops.ACT_RELU).squeeze(1)
         speaker_encoding = self._gemm("sl", spk_in, self.speaker_linear[0], act=ops.ACT_RELU).squeeze(1)
-        enc_cat = self.encoder_input_cat(mel_target, p_norm, e_input, mel_aug)
-        d, p, e, n = self.audio_encoder(enc_cat, mel_len, src_len, mask=None, max_seq_len=text.shape[1])
+        dat = self.dat_inputs if (rt.pair_audio and self.training and torch.is_grad_enabled()) else None
+        self.dat_inputs, self.dat_encodings = None, None
+        if dat is not None:
+            # EXPERIMENTAL (rt.pair_audio, default off -- not yet validated on the GPU): the DAT pass of train.py:149-150
+            # runs the same AudioEncoder on (mel_aug, f0_norm_aug, energy_input_aug, mel_aug); every op in it is per
+            # item, so both passes are one batch of 2B items (one BiLSTM chain instead of two)
+            B = mel_target.shape[0]
+            enc_cat = self.encoder_input_cat(torch.cat([mel_target, dat[0]]), torch.cat([p_norm, dat[1]]),
+                                             torch.cat([e_input, dat[2]]), torch.cat([mel_aug, dat[0]]))
+            d, p, e, n = self.audio_encoder(enc_cat, torch.cat([mel_len, mel_len]), torch.cat([src_len, src_len]),
+                                            mask=None, max_seq_len=text.shape[1])
+            self.dat_encodings = (d[B:], p[B:], e[B:])
+            d, p, e, n = d[:B], p[:B], e[:B], n[:B]
+        else:
+            enc_cat = self.encoder_input_cat(mel_target, p_norm, e_input, mel_aug)
+            d, p, e, n = self.audio_encoder(enc_cat, mel_len, src_len, mask=None, max_seq_len=text.shape[1])
         return text_encoding, text_encoding_neck, speaker_encoding_p, speaker_encoding, d, p, e, n
 
 

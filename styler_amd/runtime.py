@@ -18,6 +18,9 @@ class _Runtime:
     pack_decoder = True        # run the decoder's FFT blocks on the valid frames only (packed rows, pack.hip)
     # clean + noisy decode (styler.py:52,55) as one packed batch of 2B items (STYLER_PAIR_DECODES=0: two passes)
     pair_decodes = os.environ.get("STYLER_PAIR_DECODES", "1") != "0"
+    # EXPERIMENTAL, default off (written after the round's GPU budget was spent: not validated on hardware yet): main
+    # forward + DAT pass of the AudioEncoder (train.py:149-150) as one batch of 2B items
+    pair_audio = os.environ.get("STYLER_PAIR_AUDIO", "0") == "1"
 
     def set_precision(self, name):
         self.prec = {"fp32": ops.PREC_F32, "bf16": ops.PREC_BF16}[name]

@@ -112,6 +112,9 @@ def train_losses(model, batch, loss_fn=None, dat_fn=None):
     B = batch["text"].shape[0]
     S, T = batch["text"].shape[1], batch["mel_target"].shape[1]
     dev = batch["text"].device
+    se = model.style_modeling.style_encoder
+    if rt.pair_audio:
+        se.dat_inputs = (batch["mel_aug"], batch["f0_norm_aug"], batch["energy_input_aug"])
     out = model(batch["text"], batch["mel_target"], batch["mel_aug"], batch["f0_norm"], batch["energy_input"],
                 batch["src_len"], batch["mel_len"], batch["D"], batch["f0"], batch["energy"], S, T,
                 speaker_embed=batch["speaker_embed"])
@@ -122,9 +125,12 @@ def train_losses(model, batch, loss_fn=None, dat_fn=None):
                                                 mel, post, batch["mel_target"], ~src_mask, ~mel_mask,
                                                 batch["src_len"], batch["mel_len"], aug, zeros)
     mel_nl, post_nl = loss_fn.cal_mel_loss(mel_n, post_n, batch["mel_aug"], ~mel_mask, batch["mel_len"])
-    se = model.style_modeling.style_encoder
-    enc_cat = se.encoder_input_cat(batch["mel_aug"], batch["f0_norm_aug"], batch["energy_input_aug"], batch["mel_aug"])
-    d, p, e, _ = se.audio_encoder(enc_cat, batch["mel_len"], batch["src_len"], mask=None, max_seq_len=S)
+    if se.dat_encodings is not None:                # the forward ran the DAT pass in the same AudioEncoder batch
+        (d, p, e), se.dat_encodings = se.dat_encodings, None
+    else:
+        enc_cat = se.encoder_input_cat(batch["mel_aug"], batch["f0_norm_aug"], batch["energy_input_aug"],
+                                       batch["mel_aug"])
+        d, p, e, _ = se.audio_encoder(enc_cat, batch["mel_len"], batch["src_len"], mask=None, max_seq_len=S)
     sm = model.style_modeling
     cls_dat = dat_fn((sm.augmentation_classifier_d(d), sm.augmentation_classifier_p(p),
                       sm.augmentation_classifier_e(e)), ones)

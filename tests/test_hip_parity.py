@@ -801,3 +801,42 @@ def test_paired_decodes_match_separate(dev, ref_state_dict, prec):
         rt.pair_decodes = keep
         rt.disable_dropout = False
         rt.set_precision("fp32")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(__import__("os").environ.get("STYLER_TEST_EXPERIMENTAL") != "1",
+                    reason="rt.pair_audio is experimental (default off): STYLER_TEST_EXPERIMENTAL=1 to run")
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_paired_audio_encoder_matches_separate(dev, ref_state_dict, prec):
+    """rt.pair_audio: main forward + DAT pass of the AudioEncoder as one batch of 2B items vs two passes -- same ten
+    losses and the same gradients (dropout off)."""
+    from closed_form import make_batch
+    from styler_amd import STYLER, rt
+    from styler_amd.training import train_losses
+    bd = {k: v.to(dev) for k, v in make_batch(5, 8, 30, 1, 9, seed=79).items()}
+    m = STYLER()
+    m.load_state_dict(ref_state_dict)
+    m = m.to(dev).train()
+    rt.set_precision(prec)
+    rt.disable_dropout = True
+    keep = rt.pair_audio
+    try:
+        losses, grads = [], []
+        for pair in (False, True):
+            rt.pair_audio = pair
+            m.zero_grad(set_to_none=True)
+            ls = train_losses(m, bd)
+            ls[0].backward()
+            losses.append([float(x) for x in ls])
+            grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        tol = 1e-5 if prec == "fp32" else 2e-2
+        for x, y in zip(*losses):
+            assert abs(x - y) <= tol * max(1.0, abs(x)), (x, y)
+        assert grads[0].keys() == grads[1].keys()
+        for k in grads[0]:
+            e = float((grads[0][k] - grads[1][k]).abs().max()) / max(float(grads[0][k].abs().max()), 1e-4)
+            assert e <= (1e-4 if prec == "fp32" else 5e-2), f"{k}: {e:.3e}"
+    finally:
+        rt.pair_audio = keep
+        rt.disable_dropout = False
+        rt.set_precision("fp32")
