@@ -477,6 +477,32 @@ class PackRowsFn(Function):
         return ops.unpack_rows(dy, ctx.plan), None, None
 
 
+class SplitChannelsFn(Function):
+    """x [B, T, k*H] -> its k channel slices (views).  EXPERIMENTAL (rt.fused_split, default off, not yet validated on
+    the GPU): native slicing makes autograd zero-fill k full-size tensors and add them pairwise -- for the
+    LengthRegulator output [B, T, 1280] that is 5 fills + 4 adds of 108 MB per step; here backward gathers the k slice
+    gradients into ONE buffer with k strided copies."""
+
+    @staticmethod
+    def forward(ctx, x, H):
+        ctx.meta = (x.shape, H, x.device)
+        return tuple(x[..., i * H:(i + 1) * H] for i in range(x.shape[-1] // H))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        shape, H, dev = ctx.meta
+        if all(g is None for g in gs):
+            return None, None
+        out = torch.empty(shape, device=dev, dtype=torch.float32)
+        for i, g in enumerate(gs):
+            dst = out[..., i * H:(i + 1) * H]
+            if g is None:
+                dst.zero_()
+            else:
+                ops.add2(ops._rows_view(g), None, out=dst)
+        return out, None
+
+
 class PackPairFn(Function):
     """Two padded [B, T, C] tensors (+ positional table) -> one packed batch of 2B items; backward = unpack per half."""
 

@@ -325,7 +325,10 @@ class StyleModeling(_HipModule):
             out_len, out_mask = mel_len, ops.length_mask(mel_len, T)
         grad = (self.training and torch.is_grad_enabled()) and encodings.requires_grad
         lr = AG.LengthRegulateFn.apply(encodings, csum, T) if grad else ops.length_regulate(encodings, csum, T)
-        t_e, p_e, s_e, e_e, n_e = (lr[..., i * H:(i + 1) * H] for i in range(5))           # [B, T, 1280] slices
+        if grad and rt.fused_split:
+            t_e, p_e, s_e, e_e, n_e = AG.SplitChannelsFn.apply(lr, H)
+        else:
+            t_e, p_e, s_e, e_e, n_e = (lr[..., i * H:(i + 1) * H] for i in range(5))       # [B, T, 1280] slices
 
         energy_prediction = self.energy_predictor(e_e, lens)
         if pitch_plus_speaker:

@@ -21,6 +21,9 @@ class _Runtime:
     # EXPERIMENTAL, default off (written after the round's GPU budget was spent: not validated on hardware yet): main
     # forward + DAT pass of the AudioEncoder (train.py:149-150) as one batch of 2B items
     pair_audio = os.environ.get("STYLER_PAIR_AUDIO", "0") == "1"
+    # EXPERIMENTAL, default off (same status): the five channel slices of the LengthRegulator output through
+    # autograd.SplitChannelsFn (one gathered gradient buffer instead of 5 zero-fills + 4 full-size adds per step)
+    fused_split = os.environ.get("STYLER_FUSED_SPLIT", "0") == "1"
 
     def set_precision(self, name):
         self.prec = {"fp32": ops.PREC_F32, "bf16": ops.PREC_BF16}[name]

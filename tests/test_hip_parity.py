@@ -807,9 +807,11 @@ def test_paired_decodes_match_separate(dev, ref_state_dict, prec):
 @pytest.mark.skipif(__import__("os").environ.get("STYLER_TEST_EXPERIMENTAL") != "1",
                     reason="rt.pair_audio is experimental (default off): STYLER_TEST_EXPERIMENTAL=1 to run")
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-def test_paired_audio_encoder_matches_separate(dev, ref_state_dict, prec):
-    """rt.pair_audio: main forward + DAT pass of the AudioEncoder as one batch of 2B items vs two passes -- same ten
-    losses and the same gradients (dropout off)."""
+@pytest.mark.parametrize("switch", ["pair_audio", "fused_split"])
+def test_experimental_switches_match_default(dev, ref_state_dict, prec, switch):
+    """rt.pair_audio (main forward + DAT pass of the AudioEncoder as one batch of 2B items) and rt.fused_split (gathered
+    gradient of the LengthRegulator output's channel slices) vs the default path: same ten losses and the same gradients
+    (dropout off)."""
     from closed_form import make_batch
     from styler_amd import STYLER, rt
     from styler_amd.training import train_losses
@@ -819,11 +821,11 @@ def test_paired_audio_encoder_matches_separate(dev, ref_state_dict, prec):
     m = m.to(dev).train()
     rt.set_precision(prec)
     rt.disable_dropout = True
-    keep = rt.pair_audio
+    keep = getattr(rt, switch)
     try:
         losses, grads = [], []
-        for pair in (False, True):
-            rt.pair_audio = pair
+        for on in (False, True):
+            setattr(rt, switch, on)
             m.zero_grad(set_to_none=True)
             ls = train_losses(m, bd)
             ls[0].backward()
@@ -837,6 +839,6 @@ def test_paired_audio_encoder_matches_separate(dev, ref_state_dict, prec):
             e = float((grads[0][k] - grads[1][k]).abs().max()) / max(float(grads[0][k].abs().max()), 1e-4)
             assert e <= (1e-4 if prec == "fp32" else 5e-2), f"{k}: {e:.3e}"
     finally:
-        rt.pair_audio = keep
+        setattr(rt, switch, keep)
         rt.disable_dropout = False
         rt.set_precision("fp32")

@@ -303,3 +303,23 @@ def test_batch_feeder_shards_prefetches_and_reshuffles(tmp_path):
             raise OSError("unreadable feature file")
     with pytest.raises(OSError):
         list(BatchFeeder(Broken(str(tmp_path), tokenizer), "cpu", batch_size=2))
+
+
+def test_split_channels_fn_gathers_slice_gradients(monkeypatch):
+    """autograd.SplitChannelsFn (rt.fused_split): views out, ONE gathered gradient buffer back (unused slices zero);
+    the strided-copy kernel is replaced by its torch definition here."""
+    from styler_amd import autograd as AG, ops
+
+    def add2(a, b, out=None):
+        out.copy_(a if b is None else a + b)
+        return out
+    monkeypatch.setattr(ops, "add2", add2)
+    x = torch.randn(2, 3, 10, requires_grad=True)
+    parts = AG.SplitChannelsFn.apply(x * 1.0, 2)
+    assert len(parts) == 5 and all(p.shape == (2, 3, 2) for p in parts)
+    ((parts[0] * 2).sum() + (parts[3] ** 2).sum() + parts[4][..., :1].sum()).backward()
+    ref = torch.zeros_like(x)
+    ref[..., 0:2] = 2
+    ref[..., 6:8] = 2 * x.detach()[..., 6:8]
+    ref[..., 8:9] = 1
+    assert torch.allclose(x.grad, ref)
