@@ -323,3 +323,19 @@ def test_split_channels_fn_gathers_slice_gradients(monkeypatch):
     ref[..., 6:8] = 2 * x.detach()[..., 6:8]
     ref[..., 8:9] = 1
     assert torch.allclose(x.grad, ref)
+
+
+def test_c_host_links_and_validates_arguments(tmp_path):
+    """The header is plain C99 and C++17, and a C host (tests/abi/abi_host.c) can load the library and gets the
+    documented negative codes for invalid arguments -- before any HIP call, so no GPU is needed."""
+    from styler_amd import _lib
+    hdr = os.path.join(ROOT, "include", "styler_hip.h")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr],
+                   check=True)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr], check=True)
+    exe = str(tmp_path / "abi_host")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "abi", "abi_host.c"), "-o", exe, "-ldl"], check=True)
+    out = subprocess.run([exe, _lib.LIB_PATH], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip() == "abi=1 null=-1 align=-2 kw=-1 plan=-1"
