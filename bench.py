@@ -116,8 +116,14 @@ def run(args, mode, rank, world, dev, dist):
                 step()
         go = graph.replay if graph is not None else step
         if train and not args.no_graph:         # forward + losses + backward replayed from one hipGraph; the
-            graph = GraphedTrainStep(model, state, bd, split=True if args.split_graph else None)
-            go = graph
+            try:
+                graph = GraphedTrainStep(model, state, bd, split=True if args.split_graph else None)
+                go = graph
+            except Exception as e:              # keep the measurement alive: eager launches (reported as "eager")
+                import warnings
+                warnings.warn(f"hipGraph capture of the train step failed ({type(e).__name__}: {e}); launching eagerly")
+                torch.cuda.synchronize()
+                graph, go = None, step
 
         for _ in range(args.warmup):
             go()
