@@ -422,6 +422,24 @@ def style_modeling(P: Params, text, speaker_embed, mel_target, mel_aug, p_norm, 
     return out, n_e, log_d, p_pred, e_pred, out_mel_len, mel_pad, aug
 
 
+def predict_inference(P: Params, text_enc, pitch_enc, energy_enc, duration_enc, speaker_enc, noise_enc, src_pad,
+                      max_len=None, speaker_normalized=True, d_control=1.0, p_control=1.0, e_control=1.0):
+    """StyleModeling.predict_inference, modules.py:285-309 (the synthesize.py inspection / control path): encodings
+    [B, S, 256] each -> (text, pitch_embedding, speaker, energy_embedding, noise) [B, T, 256], log_d [B, S],
+    pitch / energy predictions [B, T], mel_pad [B, T]."""
+    pre = "style_modeling"
+    enc = torch.cat((text_enc, pitch_enc, speaker_enc, energy_enc, noise_enc), dim=-1)
+    log_d = style_predictor(P, pre + ".duration_predictor", duration_enc, src_pad)
+    enc, mel_len = length_regulate(enc, rounded_duration(log_d, d_control), max_len)
+    mel_pad = length_mask(mel_len)
+    t_e, p_e, s_e, e_e, n_e = torch.split(enc, HIDDEN, dim=-1)
+    e_pred = style_predictor(P, pre + ".energy_predictor", e_e, mel_pad) * e_control
+    e_emb = F.embedding(torch.bucketize(e_pred, P[pre + ".energy_bins"]), P[pre + ".energy_embedding.weight"])
+    p_pred = style_predictor(P, pre + ".pitch_predictor", p_e if speaker_normalized else p_e + s_e, mel_pad) * p_control
+    p_emb = F.embedding(torch.bucketize(p_pred, P[pre + ".pitch_bins"]), P[pre + ".pitch_embedding.weight"])
+    return t_e, p_emb, s_e, e_emb, n_e, log_d, p_pred, e_pred, mel_pad
+
+
 def styler_forward(P: Params, src_seq, mel_target, mel_aug, p_norm, e_input, src_len, mel_len,
                    d_target=None, p_target=None, e_target=None, max_src_len=None,
                    max_mel_len=None, speaker_embed=None, d_control=1.0, p_control=1.0,

@@ -207,3 +207,19 @@ def test_hifigan_generator(golden, hifigan_state_dict):
     assert float(np.abs(g["wav"]).max()) < 0.5          # not saturated: the comparison is sensitive
     # folded (remove_weight_norm) checkpoints give the same result
     close(O.hifigan_generator(O.resolve_weight_norm(hifigan_state_dict), T(g["mel"])), g["wav"], 2e-6)
+
+
+def test_predict_inference(golden, ref_state_dict):
+    """StyleModeling.predict_inference (modules.py:285-309) for two control settings; durations `round(..) * 1.3` are
+    truncated by the LengthRegulator's int() (case b)."""
+    from golden.make_golden_inference import CASES, NAMES
+    g, P = golden("predict_inference"), ref_state_dict
+    enc = {k: T(g["in_" + k]) for k in ("text", "pitch", "energy", "duration", "speaker", "noise")}
+    for tag, kw in CASES.items():
+        out = O.predict_inference(P, enc["text"], enc["pitch"], enc["energy"], enc["duration"], enc["speaker"],
+                                  enc["noise"], T(g["src_mask"]), None, **kw)
+        for n, v in zip(NAMES, out):
+            if n == "mel_mask":
+                assert np.array_equal(v.numpy(), g[f"{tag}_{n}"])
+            else:
+                close(v, g[f"{tag}_{n}"], 2e-5)
