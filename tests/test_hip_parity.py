@@ -866,3 +866,28 @@ def test_predict_inference_golden(dev, model, golden):
                     assert np.array_equal(v.cpu().numpy(), ref)
                 else:
                     check(v, ref, 1e-4, f"predict_inference[{tag}].{n}")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(__import__("os").environ.get("STYLER_TEST_EXPERIMENTAL") != "1",
+                    reason="written after the round's GPU budget was spent, not yet run on hardware: "
+                           "STYLER_TEST_EXPERIMENTAL=1 to run")
+def test_decode_entry_point_vs_oracle(dev, model, O, ref_state_dict):
+    """`model.decode(x, mel_mask)` called directly (synthesize.py:202,313: lengths derived from the mask) and
+    `decode_pair` vs the oracle's decode on the same ragged batch."""
+    from closed_form import hash_uniform
+    B, Tm = 3, 37
+    lens = torch.tensor([37, 1, 20])
+    pad = O.length_mask(lens, Tm)
+    x = torch.from_numpy(0.3 * hash_uniform(41, B * Tm * 256).reshape(B, Tm, 256)).float() * (~pad)[..., None]
+    x2 = torch.from_numpy(0.3 * hash_uniform(42, B * Tm * 256).reshape(B, Tm, 256)).float() * (~pad)[..., None]
+    with torch.no_grad():
+        ref = O.decode(ref_state_dict, x, pad)
+        ref2 = O.decode(ref_state_dict, x2, pad)
+        mel, post = model.decode(x.to(dev), pad.to(dev))
+        (mel_a, post_a), (mel_b, post_b) = model.decode_pair(x.to(dev), x2.to(dev), pad.to(dev))
+    check(mel, ref[0], 1e-4, "decode mel")
+    check(post, ref[1], 1e-3, "decode postnet")
+    check(mel_a, ref[0], 1e-4, "decode_pair mel (clean slot)")
+    check(post_b, ref2[1], 1e-3, "decode_pair postnet (noisy slot)")
+    check(mel_b, ref2[0], 1e-4, "decode_pair mel (noisy slot)")
