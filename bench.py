@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the STYLER hot path on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W] [--mode train|fwd] [--prec bf16|fp32] [--aux] [--no-graph]
+    python bench.py [--gpus N --steps K --warmup W] [--mode train|fwd] [--prec bf16|fp32] [--no-aux] [--no-graph]
 
 Metric (BASELINE.json): valid mel-frames per second on a seeded synthetic VCTK-shape batch resident in HBM
 (B=48 per GPU, src_len~U{20..60}, D~U{2..13}, 80-bin mel), reported as the WHOLE-JOB
@@ -10,14 +10,23 @@ aggregate over N GPUs (one process per GPU, each rank its own batch: weak scalin
 One "step" is one pass of the hot path over one batch:
   --mode train (default): the full reference optimisation step, train.py:135-186 -- forward with both decodes,
         clean + noisy losses, the DAT pass, backward, gradient all-reduce (RCCL, N > 1), clip_grad_norm_(1.0),
-        Adam with the Noam schedule (BASELINE config 3 per-rank shape).  bf16 MFMA operands for forward / dX GEMMs,
-        exact-fp32 MFMA for the weight gradients, fp32 accumulate / activations / optimiser state.
+        Adam with the Noam schedule (BASELINE config 3 per-rank shape).  --prec bf16 (default, BASELINE config 2's
+        dtype): bf16 MFMA operands in every GEMM (forward, dX and weight gradients) and in attention, fp32 accumulate,
+        fp32 norms / softmax / losses / optimiser state.  --prec fp32: exact-fp32 MFMA everywhere (the 1e-3 parity mode).
   --mode fwd: BASELINE config 2 -- eval forward, teacher-forced, clean branch only, replayed from a hipGraph.
-  --aux adds the other mode's figure under "aux" in the same JSON line.
+  "aux" in the same JSON line (default on, --no-aux to skip): the SAME train step in fp32 parity mode ("train_fp32") and
+        the config-2 forward in the main precision ("forward_c2"), so that the arithmetic whose parity is 1e-3 has a
+        driver-timed number next to the throughput mode (both are pinned to the oracle at this shape by
+        tests/test_bf16_parity.py).
+
+`value` comes from EXACTLY --steps timed steps between two barriers; "repeat" reports further blocks of the same length
+(median / min / max ms per step) so that the spread of the short contract window is visible.
 
 Rank 0 prints ONE JSON line.  It also carries
   roofline     : the dominant kernel of the step -- algorithmic FLOPs of its launches / their HIP-event durations
-                 (events bracket each launch on the launch stream during extra eager steps);
+                 (events bracket each launch on the launch stream during extra eager steps); `traffic` = HBM-side bytes per
+                 launch from this round's separate rocprofv3 --pmc passes of this command (profiles/r02_pmc_traffic.jsonl;
+                 PMC collection cannot run inside the timed process), null if that file has no record for the kernel;
   cpu_baseline : the oracle (plain PyTorch-CPU restatement) timed on this host's cores on a bounded sample.
 """
 import argparse
@@ -53,15 +62,17 @@ def parse():
     ap.add_argument("--split-graph", action="store_true",
                     help="train: capture the two-graph step (all-reduce overlap) even on one rank (default for N > 1)")
     ap.add_argument("--prof-steps", type=int, default=3, help="extra eager steps with HIP-event GEMM brackets")
-    ap.add_argument("--aux", action="store_true", help="also time the other mode and report it under 'aux'")
+    ap.add_argument("--aux", action="store_true", help="(default on) kept for compatibility")
+    ap.add_argument("--no-aux", action="store_true", help="skip the aux legs (fp32-mode train step, config-2 forward)")
+    ap.add_argument("--repeat", type=int, default=4, help="extra timed blocks of --steps steps (spread diagnostic)")
     ap.add_argument("--shape", default="vctk", choices=["vctk", "c4"],
                     help="vctk: src_len~U{20..60}, D~U{2..13} (C1-C3); c4: long-form S=300, T=2000 (eval forward only)")
     return ap.parse_args()
 
 
-def run(args, mode, rank, world, dev, dist):
-    """Time `args.steps` steps of `mode` ("fwd" | "train") after `args.warmup` warm-up steps.  Returns the result
-    dict of rank 0 (None elsewhere)."""
+def run(args, mode, prec, rank, world, dev, dist, with_cpu=True, with_roofline=True):
+    """Time `args.steps` steps of `mode` ("fwd" | "train") in precision `prec` after `args.warmup` warm-up steps.  Returns
+    the result dict of rank 0 (None elsewhere)."""
     import styler_amd
     from styler_amd import ops, rt
     from styler_amd.dist import aggregate_throughput
@@ -72,7 +83,7 @@ def run(args, mode, rank, world, dev, dist):
     model = styler_amd.STYLER().to(dev)
     model = model.train() if train else model.eval()
     model.clean_only = (not args.dual) and not train
-    rt.set_precision(args.prec)
+    rt.set_precision(prec)
     rt.strict_inputs = False                   # no host sync inside the step
 
     if args.shape == "c4":
@@ -83,6 +94,7 @@ def run(args, mode, rank, world, dev, dist):
     S, T = batch["text"].shape[1], batch["mel_target"].shape[1]
     bd = {k: v.to(dev) for k, v in batch.items()}
     use_graph = (not args.no_graph) and not train
+    state = None
     if train:
         from styler_amd.training import GraphedTrainStep, TrainState, train_step
         state = TrainState(model)
@@ -100,6 +112,14 @@ def run(args, mode, rank, world, dev, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_block():
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            go()
+        barrier()
+        return time.perf_counter() - t0
+
     with (torch.enable_grad() if train else torch.no_grad()):
         for _ in range(3):                      # builds derived weights (bf16 shadows etc.)
             step()
@@ -115,7 +135,7 @@ def run(args, mode, rank, world, dev, dist):
             with torch.cuda.graph(graph):
                 step()
         go = graph.replay if graph is not None else step
-        if train and not args.no_graph:         # forward + losses + backward replayed from one hipGraph; the
+        if train and not args.no_graph:         # forward + losses + backward replayed from hipGraphs
             try:
                 graph = GraphedTrainStep(model, state, bd, split=True if args.split_graph else None)
                 go = graph
@@ -127,12 +147,8 @@ def run(args, mode, rank, world, dev, dist):
 
         for _ in range(args.warmup):
             go()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            go()
-        barrier()
-        elapsed = time.perf_counter() - t0
+        elapsed = timed_block()                 # THE measurement: exactly --steps steps between two barriers
+        blocks = [timed_block() for _ in range(max(0, args.repeat))]      # spread diagnostic, same length each
         host_ms = None
         if graph is None:                       # eager launch: how long the host needs to ENQUEUE one step (diagnostic)
             torch.cuda.synchronize()
@@ -142,51 +158,68 @@ def run(args, mode, rank, world, dev, dist):
             torch.cuda.synchronize()
 
         # ---- live roofline measurement: HIP events around every MFMA-GEMM launch, extra eager steps ----
-        prof = ops.GemmProfiler()
-        ops.gemm_profiler = prof
-        for _ in range(args.prof_steps):
-            step()
-        torch.cuda.synchronize()
-        ops.gemm_profiler = None
-        gsum = prof.summary(packed_fraction=frames / float(args.batch * T))
+        gsum = {}
+        if with_roofline and args.prof_steps > 0:
+            prof = ops.GemmProfiler()
+            ops.gemm_profiler = prof
+            for _ in range(args.prof_steps):
+                step()
+            torch.cuda.synchronize()
+            ops.gemm_profiler = None
+            gsum = prof.summary(packed_fraction=frames / float(args.batch * T))
 
     elapsed, total_frames = aggregate_throughput(elapsed, frames, dev)
+    blocks = [aggregate_throughput(b, frames, dev)[0] for b in blocks]
+    n_graphs = len(getattr(graph, "graphs", ())) if (train and graph is not None) else (1 if graph is not None else 0)
+    if state is not None:
+        ar = state.allreduce_info()
+        state.close()
     if rank != 0:
         return None
     ms = elapsed / args.steps * 1e3
     value = total_frames * args.steps / elapsed
-    ps = max(1, args.prof_steps)
-    big = 3 if args.prec == "bf16" else 1               # conv_gemm_kernel<2,2,...>: forward and dX launches
-    wg = "wgrad_bf16" if args.prec == "bf16" else "wgrad"
-    peak = MFMA_PEAK_TFLOPS[args.prec]
-    # the dominant MFMA kernel family of the step BY TIME (train: forward+dX engine vs weight-gradient engine)
-    if train and gsum.get(wg, {"ms": 0.0})["ms"] > gsum.get(big, {"ms": 0.0})["ms"]:
-        dom = wg
-        dom_name = ("wgrad_tr_kernel<KW,TA,TB>" if args.prec == "bf16" else "wgrad_kernel<KW>") + " (all tap counts)"
-    else:
-        dom, dom_name = big, VARIANT_NAMES[big]
-    d = gsum.get(dom, {"launches": 0, "flops": 0.0, "ms": 1.0})
-    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["launches"] else 0.0
-    roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": pmc_traffic("train_wgrad_bf16" if dom == wg else
-                                       ("train_conv_gemm_2x2_bf16" if train else "fwd_conv_gemm_2x2_bf16"), args.prec),
-                "launches_per_step": d["launches"] // ps, "avg_launch_us": round(d["ms"] * 1e3 / max(1, d["launches"]), 2),
-                "kernel_ms_per_step": round(d["ms"] / ps, 3),
-                "all_mfma_gemm_ms_per_step": round(sum(v["ms"] for v in gsum.values()) / ps, 3)}
     workload = (f"C3 per-rank shape: full reference train step (dual decode + DAT pass + 10 losses + backward + grad "
                 f"all-reduce + clip + Adam, train.py:135-186), B={args.batch}/GPU, S={S}, T={T}, valid frames={frames}/GPU"
                 if train else
                 f"C2: STYLER.forward eval teacher-forced, {'dual' if args.dual else 'clean'}-branch, "
                 f"B={args.batch}/GPU, S={S}, T={T}, valid frames={frames}/GPU")
-    res = {"value": round(value, 1), "ms_per_step": round(ms, 4), "workload": workload,
-           "launch": ("hipGraph replay" + (" (2 graphs, all-reduce between)" if train and len(getattr(graph, "graphs", ())) == 2
-                                           else "")) if graph is not None else "eager", "roofline": roofline}
+    res = {"value": round(value, 1), "ms_per_step": round(ms, 4), "workload": workload, "dtype": prec,
+           "launch": ("hipGraph replay" + (" (2 graphs, all-reduce between)" if train and n_graphs == 2 else ""))
+           if graph is not None else "eager", "graphs": n_graphs}
+    if blocks:
+        per = sorted(b / args.steps * 1e3 for b in blocks + [elapsed])
+        res["repeat"] = {"blocks": len(per), "steps_per_block": args.steps, "ms_per_step_median": round(per[len(per) // 2], 4),
+                         "ms_per_step_min": round(per[0], 4), "ms_per_step_max": round(per[-1], 4)}
+    if train:
+        res["allreduce"] = ar
     if host_ms is not None:
         res["host_enqueue_ms_per_step"] = round(host_ms, 2)
-    if not args.no_cpu and world == 1:              # reported at N = 1 only (rank 0's host cores)
+    if gsum:
+        res["roofline"] = roofline_of(gsum, train, prec, max(1, args.prof_steps))
+    if with_cpu and not args.no_cpu and world == 1:     # reported at N = 1 only (rank 0's host cores)
         res["cpu_baseline"] = cpu_baseline(model, batch, S, T, model.clean_only, train=train)
     return res
+
+
+def roofline_of(gsum, train, prec, ps):
+    """The dominant MFMA kernel family of the step BY TIME (train: forward + dX engine vs weight-gradient engine)."""
+    big = 3 if prec == "bf16" else 1               # conv_gemm_kernel<2,2,...>: forward and dX launches
+    wg = "wgrad_bf16" if prec == "bf16" else "wgrad"
+    peak = MFMA_PEAK_TFLOPS[prec]
+    if train and gsum.get(wg, {"ms": 0.0})["ms"] > gsum.get(big, {"ms": 0.0})["ms"]:
+        dom = wg
+        dom_name = ("wgrad_tr_kernel<KW,TA,TB>" if prec == "bf16" else "wgrad_kernel<KW>") + " (all tap counts)"
+    else:
+        dom, dom_name = big, VARIANT_NAMES[big]
+    d = gsum.get(dom, {"launches": 0, "flops": 0.0, "ms": 1.0})
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["launches"] else 0.0
+    return {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "traffic": pmc_traffic("train_wgrad_bf16" if dom == wg else
+                                   ("train_conv_gemm_2x2_bf16" if train else "fwd_conv_gemm_2x2_bf16"), prec),
+            "launches_per_step": d["launches"] // ps, "avg_launch_us": round(d["ms"] * 1e3 / max(1, d["launches"]), 2),
+            "kernel_ms_per_step": round(d["ms"] / ps, 3),
+            "all_mfma_gemm_ms_per_step": round(sum(v["ms"] for v in gsum.values()) / ps, 3)}
 
 
 def main():
@@ -212,28 +245,36 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    main_res = run(args, args.mode, rank, world, dev, dist)
-    aux = None
-    if args.aux:
-        other = "fwd" if args.mode == "train" else "train"
-        no_cpu, args.no_cpu = args.no_cpu, True
-        aux_steps, args.steps = args.steps, max(5, args.steps // 2)
-        aux = run(args, other, rank, world, dev, dist)
-        args.no_cpu, args.steps = no_cpu, aux_steps
+    main_res = run(args, args.mode, args.prec, rank, world, dev, dist)
+    aux = {}
+    if not args.no_aux:
+        keep = args.steps, args.warmup, args.repeat
+        args.steps, args.warmup, args.repeat = max(5, args.steps // 2), min(args.warmup, 3), 0
+        legs = []
+        if args.mode == "train" and args.prec == "bf16":
+            legs.append(("train_fp32", "train", "fp32"))        # the 1e-3 parity arithmetic, same step
+        legs.append(("forward_c2", "fwd", args.prec) if args.mode == "train" else ("train_c3", "train", args.prec))
+        for name, mode, prec in legs:
+            r = run(args, mode, prec, rank, world, dev, dist, with_cpu=False, with_roofline=(name != "train_fp32"))
+            if r is not None:
+                aux[name] = {k: r[k] for k in ("value", "ms_per_step", "workload", "dtype", "launch", "roofline") if k in r}
+                aux[name]["steps"] = args.steps
+        args.steps, args.warmup, args.repeat = keep
     if rank == 0:
+        cfg = {"workload": main_res["workload"], "launch": main_res["launch"], "graphs": main_res["graphs"],
+               "parallelism": f"dp{world}", "host_enqueue_ms_per_step": main_res.get("host_enqueue_ms_per_step")}
+        if "allreduce" in main_res:
+            cfg.update(main_res["allreduce"])
         line = {
             "metric": "mel_frames_per_sec", "value": main_res["value"],
             "unit": "valid mel-frames/s (80-bin mel, whole job)", "per_gpu": round(main_res["value"] / world, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.prec,
             "data": "synthetic (seeded VCTK-shape batch, random-init weights)",
-            "config": {"workload": main_res["workload"], "launch": main_res["launch"], "parallelism": f"dp{world}",
-                       "host_enqueue_ms_per_step": main_res.get("host_enqueue_ms_per_step")},
-            "roofline": main_res["roofline"], "cpu_baseline": main_res.get("cpu_baseline")}
-        if aux is not None:
-            line["aux"] = {("forward_c2" if args.mode == "train" else "train_c3"): {
-                "value": aux["value"], "ms_per_step": aux["ms_per_step"], "workload": aux["workload"],
-                "launch": aux["launch"], "roofline": aux["roofline"]}}
+            "config": cfg, "repeat": main_res.get("repeat"),
+            "roofline": main_res.get("roofline"), "cpu_baseline": main_res.get("cpu_baseline")}
+        if aux:
+            line["aux"] = aux
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
@@ -241,10 +282,10 @@ def main():
 
 def pmc_traffic(want, prec):
     """HBM-side bytes per launch of the dominant kernel family `want`, from the SEPARATE rocprofv3 --pmc passes of this same command
-    (tools/pmc_run.sh -> tools/pmc_traffic.py, committed as profiles/r01_pmc_traffic.jsonl; FETCH_SIZE doubled per the
-    gfx950 correction).  PMC collection cannot run inside the timed process, so the figure is read from that file;
-    null when it is absent or was taken for another precision."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.jsonl")
+    (tools/pmc_run.sh -> tools/pmc_traffic.py, committed as profiles/r02_pmc_traffic.jsonl for the kernels of THIS round;
+    FETCH_SIZE doubled per the gfx950 correction).  PMC collection cannot run inside the timed process, so the figure is
+    read from that file; null when the file has no record for the kernel or was taken for another precision."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.jsonl")
     if prec != "bf16" or not os.path.exists(path):
         return None
     for line in open(path):

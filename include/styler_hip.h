@@ -204,6 +204,9 @@ int styler_embed_pos(const int64_t* text, const float* emb, const float* pe, flo
                      int B, int L, int C, void* stream);
 int styler_add_pos(const float* x, int64_t ldx, const float* pe, float* out, int B, int L,
                    int C, void* stream);
+/* out[r,:] = table[ids[r],:] -- nn.Embedding lookup with the int32 bucket ids the bucketise kernel emits: the un-summed
+ * pitch_embedding / energy_embedding tensors StyleModeling.predict_inference returns (modules.py:300-303). */
+int styler_gather_rows(const int32_t* ids, const float* table, float* out, int64_t rows, int C, void* stream);
 /* Sinusoid table rows [0, L) x 256, angles in float64 then cast (Models.py:11-30); used
  * when L > 1000 in eval mode (Models.py:69-71,120-122). */
 int styler_sinusoid_table(float* pe, int L, int C, void* stream);
@@ -480,11 +483,14 @@ int styler_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t r
                    uint64_t seed, void* stream);
 /* out[0] += sum g^2 (fp64) -- the global gradient norm of clip_grad_norm_ (train.py:181-182). */
 int styler_sumsq(const float* g, int64_t n, double* out, void* stream);
-/* clip (coef = min(1, max_norm / (sqrt(sumsq) + 1e-6)), sumsq may be NULL) fused with Adam
- * (hparams.py:99-101; bias-corrected, no weight decay) over flat buffers; `step` >= 1. */
+/* clip (coef = min(1, max_norm / (norm + 1e-6)), sumsq may be NULL) fused with Adam
+ * (hparams.py:99-101; bias-corrected, no weight decay) over flat buffers; `step` >= 1 is Adam's own update count.
+ * `grad_scale` (> 0): g holds gradient / grad_scale -- the rank SUM of the data-parallel all-reduce with
+ * grad_scale = 1 / world (the mean over replicas that replaces nn.DataParallel's gather, train.py:33); the kernel
+ * uses grad_scale * g and norm = grad_scale * sqrt(sumsq), so no separate division pass exists.  1.0 on one rank. */
 int styler_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq,
                      float max_norm, float lr, float beta1, float beta2, float eps, int step,
-                     void* stream);
+                     float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,7 @@ _SIGS = {
     "styler_batchnorm_train": [P, P, P, P, P, P, P, P, P, I, I64, I, I, F, ctypes.c_uint64, P],
     "styler_embed_pos": [P, P, P, P, I, I, I, P],
     "styler_add_pos": [P, I64, P, P, I, I, I, P],
+    "styler_gather_rows": [P, P, P, I64, I, P],
     "styler_sinusoid_table": [P, I, I, P],
     "styler_onehot_conv5": [P, P, P, P, I64, P, P, I, I, I, P],
     "styler_mel_calibrate": [P, I64, P, I64, P, P, I, I, I, I, P],
@@ -76,7 +77,7 @@ _SIGS = {
     "styler_nll": [P, P, P, P, P, I, P],
     "styler_dropout": [P, I64, P, I64, I64, I, F, ctypes.c_uint64, P],
     "styler_sumsq": [P, I64, P, P],
-    "styler_adam_step": [P, P, P, P, I64, P, F, F, F, F, F, I, P],
+    "styler_adam_step": [P, P, P, P, I64, P, F, F, F, F, F, I, F, P],
     "styler_stft_mel_workspace_bytes": [I, I],
     "styler_stft_mel": [P, I64, P, P, P, P, P, P, P, I, I, I, P],
 }

@@ -478,10 +478,9 @@ class PackRowsFn(Function):
 
 
 class SplitChannelsFn(Function):
-    """x [B, T, k*H] -> its k channel slices (views).  EXPERIMENTAL (rt.fused_split, default off, not yet validated on
-    the GPU): native slicing makes autograd zero-fill k full-size tensors and add them pairwise -- for the
-    LengthRegulator output [B, T, 1280] that is 5 fills + 4 adds of 108 MB per step; here backward gathers the k slice
-    gradients into ONE buffer with k strided copies."""
+    """x [B, T, k*H] -> its k channel slices (views).  Native slicing makes autograd zero-fill k full-size tensors and add
+    them pairwise -- for the LengthRegulator output [B, T, 1280] that is 5 fills + 4 adds of 108 MB per step; here
+    backward gathers the k slice gradients into ONE buffer with k strided copies (rt.fused_split)."""
 
     @staticmethod
     def forward(ctx, x, H):

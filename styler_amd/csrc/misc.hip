@@ -46,6 +46,25 @@ extern "C" int styler_add_pos(const float* x, int64_t ldx, const float* pe, floa
   return launch_status();
 }
 
+// out[r, :] = table[ids[r], :] (the un-summed pitch / energy embeddings predict_inference returns, modules.py:300-303)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const int32_t* __restrict__ ids, const float* __restrict__ table,
+                                                          float* __restrict__ out, int64_t rows, int C) {
+  const int nq = C / 4;
+  const int64_t total = rows * nq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / nq; const int q = (int)(i - row * nq);
+    *reinterpret_cast<float4*>(out + row * C + q * 4) =
+        *reinterpret_cast<const float4*>(table + (int64_t)ids[row] * C + q * 4);
+  }
+}
+
+extern "C" int styler_gather_rows(const int32_t* ids, const float* table, float* out, int64_t rows, int C, void* stream) {
+  if (!ids || !table || !out || rows <= 0 || C <= 0 || (C & 3)) return STYLER_EINVAL;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, ids, table,
+                     out, rows, C);
+  return launch_status();
+}
+
 __global__ void sinusoid_kernel(float* pe, int L, int C) {
   const int64_t total = (int64_t)L * C;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {

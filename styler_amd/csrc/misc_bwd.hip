@@ -415,12 +415,14 @@ extern "C" int styler_sumsq(const float* g, int64_t n, double* out, void* stream
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                    const double* __restrict__ sumsq, float max_norm, float lr, float b1,
-                                                   float b2, float eps, float bc1, float bc2_sqrt) {
-  float coef = 1.f;
+                                                   float b2, float eps, float bc1, float bc2_sqrt, float grad_scale) {
+  // g holds grad_scale^-1 times the gradient (the SUM over ranks of a data-parallel all-reduce, grad_scale = 1 / world):
+  // the mean is never materialised, its norm is grad_scale * ||g||
+  float coef = grad_scale;
   if (sumsq) {
-    const float norm = (float)sqrt(sumsq[0]);
+    const float norm = (float)sqrt(sumsq[0]) * grad_scale;
     const float c = max_norm / (norm + 1e-6f);
-    coef = c < 1.f ? c : 1.f;
+    coef = (c < 1.f ? c : 1.f) * grad_scale;
   }
   const float step_size = lr / bc1;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -433,11 +435,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 extern "C" int styler_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq,
-                                float max_norm, float lr, float beta1, float beta2, float eps, int step, void* stream) {
-  if (!p || !g || !m || !v || n <= 0 || step <= 0) return STYLER_EINVAL;
+                                float max_norm, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                                void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step <= 0 || !(grad_scale > 0.f)) return STYLER_EINVAL;
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq,
-                     max_norm, lr, beta1, beta2, eps, bc1, bc2s);
+                     max_norm, lr, beta1, beta2, eps, bc1, bc2s, grad_scale);
   return launch_status();
 }

@@ -138,7 +138,8 @@ class BatchFeeder:
         n, g = len(self.store), self.batch_size ** 2
         order = np.random.RandomState(self.seed + self.epoch).permutation(n) if self.shuffle else np.arange(n)
         full = [order[i * g:(i + 1) * g] for i in range(n // g)]
-        return full[self.rank::self.world]
+        full = full[:len(full) // self.world * self.world]     # every rank runs the same number of steps per epoch (each
+        return full[self.rank::self.world]                     # step ends in a collective): the remainder is dropped
 
     def __len__(self):
         return len(self.groups()) * self.batch_size

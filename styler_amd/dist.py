@@ -34,17 +34,31 @@ def aggregate_throughput(elapsed_s, units, device="cpu"):
     return float(t.item()), float(u.item())
 
 
-def allreduce_mean_(flat_grads, bucket_bytes=32 << 20):
-    """Bucketed in-place SUM all-reduce then division by world size over a FLAT gradient buffer
-    (29.48 M fp32 = 117.9 MB -> 4 buckets of 32 MB).  Returns the async work handles so the caller can
-    overlap the tail with other work; call `.wait()` on each before the optimizer step."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+def world_size():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+BUCKET_BYTES = 32 << 20
+
+
+def allreduce_sum_(flat_grads, bucket_bytes=BUCKET_BYTES):
+    """Bucketed in-place SUM all-reduce over a FLAT gradient buffer (29.48 M fp32 = 117.9 MB -> 4 buckets of 32 MB),
+    launched back to back on the collective stream.  Returns the async work handles so the caller can overlap the range
+    with other work; call `.wait()` on each before the optimizer step.  The division by the world size is NOT a pass
+    over the buffer: `TrainState.step` folds 1 / world into the clip + Adam kernel (`grad_scale`)."""
+    if world_size() == 1:
         return []
-    world = dist.get_world_size()
     n = max(1, bucket_bytes // flat_grads.element_size())
-    works = []
-    for start in range(0, flat_grads.numel(), n):
-        chunk = flat_grads[start:start + n]
-        chunk.div_(world)
-        works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
-    return works
+    return [dist.all_reduce(flat_grads[start:start + n], op=dist.ReduceOp.SUM, async_op=True)
+            for start in range(0, flat_grads.numel(), n)]
+
+
+def allreduce_mean_(flat_grads, bucket_bytes=BUCKET_BYTES):
+    """`allreduce_sum_` followed (after the waits, by the caller's stream order) by one in-place division: for callers
+    that want the mean in the buffer itself (logging scalars; the train step uses the sum + grad_scale instead)."""
+    works = allreduce_sum_(flat_grads, bucket_bytes)
+    if works:
+        for w in works:
+            w.wait()
+        flat_grads.div_(world_size())
+    return []

@@ -196,9 +196,9 @@ class StyleEncoder(_HipModule):
         dat = self.dat_inputs if (rt.pair_audio and self.training and torch.is_grad_enabled()) else None
         self.dat_inputs, self.dat_encodings = None, None
         if dat is not None:
-            # EXPERIMENTAL (rt.pair_audio, default off -- not yet validated on the GPU): the DAT pass of train.py:149-150
-            # runs the same AudioEncoder on (mel_aug, f0_norm_aug, energy_input_aug, mel_aug); every op in it is per
-            # item, so both passes are one batch of 2B items (one BiLSTM chain instead of two)
+            # rt.pair_audio: the DAT pass of train.py:149-150 runs the same AudioEncoder on (mel_aug, f0_norm_aug,
+            # energy_input_aug, mel_aug); every op in it is per item, so both passes are one batch of 2B items (one BiLSTM
+            # chain instead of two; test_experimental_switches_match_default pins it to the two-pass result)
             B = mel_target.shape[0]
             enc_cat = self.encoder_input_cat(torch.cat([mel_target, dat[0]]), torch.cat([p_norm, dat[1]]),
                                              torch.cat([e_input, dat[2]]), torch.cat([mel_aug, dat[0]]))
@@ -447,7 +447,7 @@ class StyleModeling(_HipModule):
             pitch_plus_speaker=not speaker_normalized, want_noise_sum=False, ids=ids)
         t_e, _, s_e, _, _ = (lr[..., i * H:(i + 1) * H] for i in range(5))
         # inspection-only entry: the two embedding tables are returned un-summed, as the reference does
-        pitch_embedding = torch.nn.functional.embedding(ids[0].long(), self.pitch_embedding.weight)
-        energy_embedding = torch.nn.functional.embedding(ids[1].long(), self.energy_embedding.weight)
+        pitch_embedding = ops.gather_rows(ids[0], self.pitch_embedding.weight)
+        energy_embedding = ops.gather_rows(ids[1], self.energy_embedding.weight)
         return (t_e, pitch_embedding, s_e, energy_embedding, n_e, log_d, pitch_prediction, energy_prediction,
                 mel_mask)

@@ -336,10 +336,20 @@ def leaky_sum(a, b=None, c=None, *, scale=1.0, slope=0.1, out=None):
     return out
 
 
+_dropout_counter_ptr = None
+
+
 def set_dropout_counter(counter):
-    """Register (or, with None, unregister) the int64 device step counter mixed into every dropout seed."""
+    """Register (or, with None, unregister) the int64 device step counter mixed into every dropout seed.  The library
+    keeps the raw address: whoever registers a tensor unregisters it before the tensor dies (TrainState.close)."""
+    global _dropout_counter_ptr
     assert counter is None or (counter.dtype == torch.int64 and counter.is_cuda)
     _chk(lib.styler_set_dropout_counter(_ptr(counter)), "styler_set_dropout_counter")
+    _dropout_counter_ptr = _ptr(counter)
+
+
+def dropout_counter_is(counter):
+    return counter is not None and _dropout_counter_ptr == counter.data_ptr()
 
 
 def cast_bf16(src):
@@ -445,6 +455,15 @@ def add_pos(x, pe):
     out = torch.empty(B, L, C, device=x.device, dtype=torch.float32)
     _chk(lib.styler_add_pos(x.data_ptr(), _ld(x), pe.data_ptr(), out.data_ptr(), B, L, C, _stream()),
          "styler_add_pos")
+    return out
+
+
+def gather_rows(ids, table):
+    """nn.Embedding lookup: ids int32 [..] -> [.., C] rows of `table` [V, C]."""
+    assert ids.dtype == torch.int32 and ids.is_contiguous() and table.is_contiguous()
+    out = torch.empty(*ids.shape, table.shape[1], device=table.device, dtype=torch.float32)
+    _chk(lib.styler_gather_rows(ids.data_ptr(), _f32(table).data_ptr(), out.data_ptr(), ids.numel(), table.shape[1],
+                                _stream()), "styler_gather_rows")
     return out
 
 
@@ -873,7 +892,7 @@ def sumsq(flat, out):
     return out
 
 
-def adam_step(p, g, m, v, sumsq_buf, max_norm, lr, beta1, beta2, eps, step):
+def adam_step(p, g, m, v, sumsq_buf, max_norm, lr, beta1, beta2, eps, step, grad_scale=1.0):
     _chk(lib.styler_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), _ptr(sumsq_buf),
-                              float(max_norm), float(lr), float(beta1), float(beta2), float(eps), int(step), _stream()),
-         "styler_adam_step")
+                              float(max_norm), float(lr), float(beta1), float(beta2), float(eps), int(step),
+                              float(grad_scale), _stream()), "styler_adam_step")

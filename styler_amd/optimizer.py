@@ -9,7 +9,9 @@ clip + Adam path (`training.TrainState`) evaluates the same `noam_lr`; this wrap
 
 
 def noam_lr(step, d_model=256, warmup=4000):
-    """Learning rate of update number `step` (>= 1)."""
+    """Learning rate of update number `step`; 0 at step 0 (np.power(0, -0.5) = inf loses the min in optimizer.py:22-25)."""
+    if step <= 0:
+        return 0.0
     return d_model ** -0.5 * min(step ** -0.5, step * warmup ** -1.5)
 
 

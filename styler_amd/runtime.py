@@ -10,7 +10,8 @@ class _Runtime:
         self.strict_inputs = True       # raise like the reference's assert on p_norm / e_input outside [0, 1]
         self.grad_ready_hook = None     # set by training.train_step: called when the decoder-side gradients are final
         self.weights_epoch = 0          # bumped by TrainState.step(): invalidates every derived weight layout
-        self.seed = 0                   # dropout stream seed (train.py:22 seeds torch with 0)
+        self.base_seed = 0              # train.py:22 seeds torch with 0
+        self.seed = 0                   # dropout stream seed of this process: base_seed * world + rank (TrainState)
         self.dropout_calls = 0          # per-call counter mixed into the seed
         self.disable_dropout = False    # parity tests: train-mode BatchNorm / tape, dropout off (RNG streams
                                         # of the reference cannot be reproduced)
@@ -18,12 +19,12 @@ class _Runtime:
     pack_decoder = True        # run the decoder's FFT blocks on the valid frames only (packed rows, pack.hip)
     # clean + noisy decode (styler.py:52,55) as one packed batch of 2B items (STYLER_PAIR_DECODES=0: two passes)
     pair_decodes = os.environ.get("STYLER_PAIR_DECODES", "1") != "0"
-    # EXPERIMENTAL, default off (written after the round's GPU budget was spent: not validated on hardware yet): main
-    # forward + DAT pass of the AudioEncoder (train.py:149-150) as one batch of 2B items
-    pair_audio = os.environ.get("STYLER_PAIR_AUDIO", "0") == "1"
-    # EXPERIMENTAL, default off (same status): the five channel slices of the LengthRegulator output through
-    # autograd.SplitChannelsFn (one gathered gradient buffer instead of 5 zero-fills + 4 full-size adds per step)
-    fused_split = os.environ.get("STYLER_FUSED_SPLIT", "0") == "1"
+    # main forward + DAT pass of the AudioEncoder (train.py:149-150) as one batch of 2B items: one BiLSTM chain instead of
+    # two, GEMMs with twice the rows (same-box A/B: 16.63 -> 15.64 ms per train step; STYLER_PAIR_AUDIO=0: two passes)
+    pair_audio = os.environ.get("STYLER_PAIR_AUDIO", "1") != "0"
+    # the five channel slices of the LengthRegulator output through autograd.SplitChannelsFn: one gathered gradient buffer
+    # instead of autograd's 5 zero-fills + 4 full-size adds per step (16.62 -> 16.34 ms; STYLER_FUSED_SPLIT=0: native views)
+    fused_split = os.environ.get("STYLER_FUSED_SPLIT", "1") != "0"
 
     def set_precision(self, name):
         self.prec = {"fp32": ops.PREC_F32, "bf16": ops.PREC_BF16}[name]

@@ -5,7 +5,7 @@ import torch
 
 from . import hparams as hp
 from . import ops
-from .dist import allreduce_mean_
+from .dist import BUCKET_BYTES, allreduce_sum_, world_size
 from .loss import DomainAdversarialTrainingLoss, STYLERLoss
 from .optimizer import noam_lr
 from .runtime import Derived, rt
@@ -19,7 +19,10 @@ class TrainState:
     `flat_p`, its `.grad` a view of `flat_g` (so the backward kernels' atomics, the RCCL all-reduce, the global
     norm and the Adam update all run over one contiguous 117.9 MB buffer)."""
 
-    def __init__(self, model, restore_step=0):
+    def __init__(self, model, restore_step=0, broadcast=True):
+        import torch.distributed as dist
+        self.model = model.module if hasattr(model, "module") else model
+        model = self.model
         params = [p for p in model.parameters() if p.requires_grad]
         align = lambda k: (k + 3) & ~3                  # every view starts 16-byte aligned (float4 / MFMA staging loads)
         n = sum(align(p.numel()) for p in params)
@@ -43,7 +46,11 @@ class TrainState:
         # all-reduce is launched from there and overlaps the rest of backward (style encoders, predictors, DAT pass)
         self.tail_start = self._tail_offset(model, params, align)
         self._tail_works = None
-        self.n_current_steps = restore_step            # optimizer.py:10
+        self.n_current_steps = restore_step            # optimizer.py:10: the Noam counter (ScheduledOptim)
+        # torch.optim.Adam's own per-parameter `step` (bias correction): a separate counter in the reference -- a run
+        # resumed with restore_step > 0 but without optimizer state starts Adam at 0 while the schedule continues
+        self.adam_steps = 0
+        self._accum = 0                                # micro-batches accumulated since the last update (acc_steps)
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
         self.arena = ops.WgradArena()                  # split-K partials of every weight gradient of one backward
         self.zero_slab = ops.ZeroSlab()
@@ -53,6 +60,43 @@ class TrainState:
         # counter is what changes between replays (styler_set_dropout_counter)
         self.drop_epoch = torch.zeros(1, device=dev, dtype=torch.int64)
         ops.set_dropout_counter(self.drop_epoch)
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if world > 1:
+            # one dropout stream per rank (the per-process call counter and the device step counter are identical on
+            # every rank), and rank 0's initial weights everywhere (what DataParallel's replicate does every step)
+            rt.seed = rt.base_seed * world + dist.get_rank()
+            if broadcast:
+                dist.broadcast(self.flat_p, 0)
+                rt.weights_epoch += 1
+
+    def close(self):
+        """Unregister this state's device step counter from the library (the dropout kernels dereference the
+        registered address: it must not outlive the tensor)."""
+        if getattr(self, "drop_epoch", None) is not None and ops.dropout_counter_is(self.drop_epoch):
+            ops.set_dropout_counter(None)
+        self.drop_epoch = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- checkpoint (train.py:61-66, 221-224) -----------------------------------------------------------------------
+    def state_dict(self):
+        """`torch.optim.Adam(model.parameters(), ...).state_dict()` of the flat moments (checkpoint.py)."""
+        from .checkpoint import adam_state_from_flat
+        lr = noam_lr(max(self.n_current_steps, 1), hp.encoder_hidden, hp.n_warm_up_step)
+        return adam_state_from_flat(self.model, self.params, self.flat_m, self.flat_v, self.adam_steps, lr)
+
+    def load_state_dict(self, sd, restore_step=None):
+        """Consume a torch.optim.Adam state dict (e.g. `checkpoint['optimizer']` of a reference run) and set the Noam
+        counter as `ScheduledOptim(optimizer, d_model, n_warm_up_step, restore_step)` does (train.py:54-55)."""
+        from .checkpoint import flat_from_adam_state
+        self.adam_steps = flat_from_adam_state(sd, self.model, self.params, self.flat_m, self.flat_v)
+        self.n_current_steps = self.adam_steps if restore_step is None else int(restore_step)
+        self.flat_g.zero_()
+        self._accum = 0
 
     @staticmethod
     def _tail_offset(model, params, align):
@@ -67,13 +111,14 @@ class TrainState:
     def zero_grad(self):
         self.flat_g.zero_()
         self._tail_works = None
+        self._accum = 0
 
     def on_decoder_grads_ready(self):
         """Called from BucketEmbedAddFn.backward (both decode branches fully back-propagated): start the all-reduce
         of the decoder + mel_linear + PostNet gradient range (55 % of the bytes) while backward continues."""
         if self._tail_works is None:
             self.arena.flush(self.flat_g.device)      # fold the decoder-side split-K partials before they are reduced
-            self._tail_works = allreduce_mean_(self.flat_g[self.tail_start:])
+            self._tail_works = allreduce_sum_(self.flat_g[self.tail_start:])
 
     def lr(self):
         """optimizer.py:21-32: the counter is incremented BEFORE the rate is computed."""
@@ -83,26 +128,37 @@ class TrainState:
     def step(self):
         """nn.utils.clip_grad_norm_(params, 1.0) + ScheduledOptim.step_and_update_lr() (train.py:181-185)."""
         if self._tail_works is not None:                     # tail range already in flight: reduce only the head
-            works = self._tail_works + allreduce_mean_(self.flat_g[:self.tail_start])
+            works = self._tail_works + allreduce_sum_(self.flat_g[:self.tail_start])
         else:
-            works = allreduce_mean_(self.flat_g)
+            works = allreduce_sum_(self.flat_g)
         for w in works:
             w.wait()
         self._tail_works = None
+        self._accum = 0
         lr = self.lr()
+        self.adam_steps += 1
         self.sumsq.zero_()
         ops.sumsq(self.flat_g, self.sumsq)
         ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.sumsq, hp.grad_clip_thresh, lr,
-                      hp.betas[0], hp.betas[1], hp.eps, self.n_current_steps)
+                      hp.betas[0], hp.betas[1], hp.eps, self.adam_steps, grad_scale=1.0 / world_size())
         rt.weights_epoch += 1       # the flat update bypasses torch's version counters: invalidate derived layouts
         if not _LAZY_DERIVED:
             Derived.refresh_all()   # ... and rebuild every declared one (bf16 shadows, kernel layouts) with ONE launch
         return lr
 
     def grad_norm(self):
+        """Global L2 norm of what the flat gradient buffer holds (after `step()` on several ranks: the rank SUM)."""
         self.sumsq.zero_()
         ops.sumsq(self.flat_g, self.sumsq)
         return float(self.sumsq.sqrt().item())
+
+    def allreduce_info(self):
+        """What one step exchanges (bench.py prints it, so a silent fallback of the overlap is visible)."""
+        nb = lambda k: (k * 4 + BUCKET_BYTES - 1) // BUCKET_BYTES
+        tail = self.n - self.tail_start
+        return {"allreduce_bytes": self.n * 4, "allreduce_dtype": "fp32", "allreduce_bucket_bytes": BUCKET_BYTES,
+                "allreduce_buckets": nb(tail) + nb(self.tail_start), "allreduce_overlapped_bytes": tail * 4,
+                "allreduce_world": world_size()}
 
 
 def train_losses(model, batch, loss_fn=None, dat_fn=None):
@@ -139,9 +195,13 @@ def train_losses(model, batch, loss_fn=None, dat_fn=None):
 
 
 def forward_backward(model, state, batch, loss_fn=None, dat_fn=None):
-    """Everything of one step that runs on the device without host decisions: zero the flat gradient, forward, the
-    ten losses, backward into the flat gradient (train.py:135-179).  Capturable in a hipGraph."""
-    state.zero_grad()
+    """Everything of one step that runs on the device without host decisions: forward, the ten losses, backward into
+    the flat gradient (train.py:135-176).  Capturable in a hipGraph.  The gradient buffer is cleared at the start of an
+    accumulation window only (the reference zeroes after each optimiser update, train.py:185; with acc_steps > 1 the
+    micro-batches in between add up)."""
+    if state._accum == 0:
+        state.zero_grad()
+    state._accum += 1
     state.drop_epoch.add_(1)
     state.zero_slab.begin(state.flat_g.device)         # the norm kernels' statistics workspaces: one clear per step
     ops.zero_slab = state.zero_slab
@@ -160,8 +220,11 @@ def forward_backward(model, state, batch, loss_fn=None, dat_fn=None):
 
 
 def train_step(model, state, batch, loss_fn=None, dat_fn=None):
-    """One optimisation step (train.py:135-186).  Returns the 10 loss scalars (device tensors) and the lr."""
+    """One iteration of the reference loop (train.py:135-186).  Returns the 10 loss scalars (device tensors) and the lr of
+    the update -- None when the `acc_steps` gate (train.py:177-178) skipped it: the gradient keeps accumulating."""
     losses = forward_backward(model, state, batch, loss_fn, dat_fn)
+    if state._accum % hp.acc_steps != 0:
+        return losses, None
     lr = state.step()
     return losses, lr
 
@@ -188,6 +251,9 @@ class GraphedTrainStep:
         self.static = {k: v.clone() for k, v in batch.items()}
         if split is None:
             split = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if hp.acc_steps != 1:
+            raise ValueError("GraphedTrainStep replays a whole optimisation step: acc_steps must be 1 "
+                             "(use train_step for gradient accumulation)")
         state.overlap_allreduce = False
         strict, rt.strict_inputs = rt.strict_inputs, False    # the [0, 1] input assertion is a host sync (utils.py:423)
         try:
@@ -208,22 +274,39 @@ class GraphedTrainStep:
                 self.graphs = (g,)
             # a capture does not execute: its step-counter increment and BatchNorm momentum updates are part of the
             # graph, nothing to undo
+            state._accum = 0
         finally:
             rt.strict_inputs = strict
 
     def _warmup(self, model, state, warmup, loss_fn, dat_fn, split):
+        """Eager passes before the capture: they size the wgrad arena / zero slab and build the descriptor tables.  Side
+        effects are undone -- constructing an instance (one per padded batch shape) must not train: no optimiser step, no
+        all-reduce (ranks may construct instances at different times), and the state the passes do touch (BatchNorm
+        running statistics / `num_batches_tracked`, the dropout step counter, the gradient buffer) is restored."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         if split:                                       # same flush pattern as the split capture: its descriptor tables
             state.split_hook = lambda: state.arena.flush(state.flat_g.device)   # must exist before (no H2D in a capture)
+        keep = [(b, b.detach().clone()) for b in model.buffers()]
+        epoch, calls, accum = state.drop_epoch.clone(), rt.dropout_calls, state._accum
+        grads = state.flat_g.clone() if accum else None
         try:
             with torch.cuda.stream(side), torch.enable_grad():
-                for _ in range(warmup):                 # sizes the wgrad arena / zero slab, builds the descriptor tables
+                for _ in range(warmup):
+                    state._accum = 0
                     forward_backward(model, state, self.static, loss_fn, dat_fn)
-                    state.step()
         finally:
             state.split_hook = None
         torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():
+            for b, v in keep:
+                b.copy_(v)
+            state.drop_epoch.copy_(epoch)
+            if grads is not None:
+                state.flat_g.copy_(grads)
+            else:
+                state.flat_g.zero_()
+        rt.dropout_calls, state._accum = calls, accum
         torch.cuda.synchronize()
 
     def _capture_split(self, model, state, loss_fn, dat_fn):
@@ -271,9 +354,10 @@ class GraphedTrainStep:
                                      f"got {tuple(v.shape)}")
                 self.static[k].copy_(v, non_blocking=True)
         st = self.state
+        st._accum = 1                                   # the captured pass starts with its own zero_grad
         self.graphs[0].replay()
         if len(self.graphs) == 2:
-            st._tail_works = allreduce_mean_(st.flat_g[st.tail_start:])    # overlaps the second graph
+            st._tail_works = allreduce_sum_(st.flat_g[st.tail_start:])    # overlaps the second graph
             self.graphs[1].replay()
         lr = st.step()
         return self.losses, lr

@@ -435,12 +435,106 @@ def test_train_state_steps_and_bf16(dev, ref_state_dict):
     assert all(torch.isfinite(x).all() for x in l2) and torch.isfinite(st.flat_p).all()
     assert float((m.decoder.layer_stack[0].pos_ffn.w_1.weight - w0).abs().max()) > 0
     assert m.decoder.layer_stack[0].pos_ffn.w_1.weight.data_ptr() >= st.flat_p.data_ptr()
-    rt.set_precision("bf16")
+    # bf16 mode on the same weights and batch: same losses and the same flat gradient within the tolerance stated in
+    # tests/test_bf16_parity.py (which pins both modes to the oracle at the benched shape)
+    from styler_amd.training import forward_backward
+    rt.disable_dropout = True
     try:
+        lf = [float(x) for x in forward_backward(m, st, b)]
+        gf = st.flat_g.clone()
+        st.zero_grad()
+        rt.set_precision("bf16")
+        lb = [float(x) for x in forward_backward(m, st, b)]
+        gb = st.flat_g.clone()
+        st.zero_grad()
+        assert max(abs(x - y) / max(1.0, abs(x)) for x, y in zip(lf, lb)) <= 1e-2, (lf, lb)
+        assert float((gf - gb).norm() / gf.norm()) <= 5e-2
         l3, _ = train_step(m, st, b)
-        assert all(torch.isfinite(x).all() for x in l3)
+        assert all(torch.isfinite(x).all() for x in l3) and st.adam_steps == 3 and st.n_current_steps == 3
     finally:
         rt.set_precision("fp32")
+        rt.disable_dropout = False
+        st.close()
+
+
+def test_train_state_checkpoint_round_trip(dev, ref_state_dict, tmp_path):
+    """Reference-format checkpoint ({'model': module.-prefixed 328 keys, 'optimizer': torch.optim.Adam state},
+    train.py:221-224) written after two steps; a fresh model + TrainState restored from it (train.py:61-66) takes the same
+    third step as the original run (same parameters, same Noam rate, same Adam bias correction), and the optimizer half
+    loads into a stock torch.optim.Adam."""
+    from closed_form import make_batch
+    from styler_amd import STYLER, hparams as hp, rt
+    from styler_amd.checkpoint import load_checkpoint, save_checkpoint
+    from styler_amd.training import TrainState, train_step
+    b = {k: v.to(dev) for k, v in make_batch(4, 20, 40, 2, 9, seed=36).items()}
+    rt.disable_dropout = True
+    try:
+        m = STYLER()
+        m.load_state_dict(ref_state_dict)
+        m = m.to(dev).train()
+        st = TrainState(m)
+        for _ in range(2):
+            train_step(m, st, b)
+        path = str(tmp_path / "checkpoint_2.pth.tar")
+        save_checkpoint(path, m, st)
+        _, lr3 = train_step(m, st, b)
+        p3 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        st.close()
+
+        ckpt = torch.load(path, map_location="cpu")
+        assert len(ckpt["model"]) == 328 and all(k.startswith("module.") for k in ckpt["model"])
+        m2 = STYLER().to(dev).train()
+        st2 = TrainState(m2)
+        load_checkpoint(path, m2, st2)
+        assert st2.n_current_steps == 2 and st2.adam_steps == 2
+        _, lr3b = train_step(m2, st2, b)
+        assert lr3b == lr3
+        for k, v in m2.state_dict().items():
+            assert float((v.float() - p3[k].float()).abs().max()) <= 1e-6 * max(1.0, float(p3[k].float().abs().max())), k
+        opt = torch.optim.Adam(m2.parameters(), betas=hp.betas, eps=hp.eps, weight_decay=hp.weight_decay)
+        opt.load_state_dict(ckpt["optimizer"])
+        some = next(iter(opt.state.values()))
+        assert int(some["step"]) == 2 and some["exp_avg"].is_cuda
+        # resuming WITHOUT optimizer state: the schedule continues at restore_step, Adam's bias correction restarts
+        st3 = TrainState(STYLER().to(dev).train(), restore_step=1000)
+        assert st3.n_current_steps == 1000 and st3.adam_steps == 0
+        st2.close(); st3.close()
+    finally:
+        rt.disable_dropout = False
+
+
+def test_acc_steps_gate(dev, ref_state_dict, monkeypatch):
+    """train.py:175-185 with acc_steps = 2: the loss is halved, the first micro-batch only accumulates (no update, no
+    zero_grad), the second one updates with the sum of both gradients."""
+    from closed_form import make_batch
+    from styler_amd import STYLER, hparams as hp, rt
+    from styler_amd.training import TrainState, forward_backward, train_step
+    b1 = {k: v.to(dev) for k, v in make_batch(3, 20, 40, 2, 9, seed=37).items()}
+    b2 = {k: v.to(dev) for k, v in make_batch(3, 20, 40, 2, 9, seed=38).items()}
+    rt.disable_dropout = True
+    try:
+        m = STYLER()
+        m.load_state_dict(ref_state_dict)
+        m = m.to(dev).train()
+        st = TrainState(m)
+        forward_backward(m, st, b1)
+        g1 = st.flat_g.clone()
+        st.zero_grad()
+        forward_backward(m, st, b2)
+        g2 = st.flat_g.clone()
+        st.zero_grad()
+        p0 = st.flat_p.clone()
+        monkeypatch.setattr(hp, "acc_steps", 2)
+        _, lr = train_step(m, st, b1)
+        assert lr is None and st.n_current_steps == 0 and torch.equal(st.flat_p, p0)
+        assert float((st.flat_g - 0.5 * g1).abs().max()) <= 1e-6 * float(g1.abs().max())
+        _, lr = train_step(m, st, b2)
+        assert lr is not None and st.n_current_steps == 1 and not torch.equal(st.flat_p, p0)
+        want = 0.5 * (g1 + g2)
+        assert float((st.flat_g - want).abs().max()) <= 2e-5 * float(want.abs().max())
+        st.close()
+    finally:
+        rt.disable_dropout = False
 
 
 def test_graphed_train_step_matches_eager(dev, ref_state_dict):
@@ -463,8 +557,16 @@ def test_graphed_train_step_matches_eager(dev, ref_state_dict):
                 for _ in range(5):
                     losses, lr = train_step(m, st, b)
             else:
-                g = GraphedTrainStep(m, st, b, warmup=3)     # 3 optimiser steps happen during warm-up
-                for _ in range(2):
+                # constructing the graphed step must not train: no optimiser step, BatchNorm running statistics, the
+                # dropout step counter and the gradient buffer restored (one instance is built per padded batch shape)
+                snap = (st.flat_p.clone(), st.flat_m.clone(), st.flat_v.clone(), st.drop_epoch.clone(),
+                        [x.clone() for x in m.buffers()])
+                g = GraphedTrainStep(m, st, b, warmup=3)
+                assert st.n_current_steps == 0 and st.adam_steps == 0
+                assert torch.equal(st.flat_p, snap[0]) and torch.equal(st.flat_m, snap[1]) and torch.equal(st.flat_v, snap[2])
+                assert torch.equal(st.drop_epoch, snap[3]) and float(st.flat_g.abs().max()) == 0.0
+                assert all(torch.equal(x, y) for x, y in zip(m.buffers(), snap[4]))
+                for _ in range(5):
                     losses, lr = g(b)
             finals.append((torch.stack([x.detach().float().reshape(()) for x in losses]).cpu(), st.flat_p.clone(), lr,
                            st.n_current_steps))

@@ -804,8 +804,6 @@ def test_paired_decodes_match_separate(dev, ref_state_dict, prec):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(__import__("os").environ.get("STYLER_TEST_EXPERIMENTAL") != "1",
-                    reason="rt.pair_audio is experimental (default off): STYLER_TEST_EXPERIMENTAL=1 to run")
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("switch", ["pair_audio", "fused_split"])
 def test_experimental_switches_match_default(dev, ref_state_dict, prec, switch):
@@ -845,9 +843,6 @@ def test_experimental_switches_match_default(dev, ref_state_dict, prec, switch):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(__import__("os").environ.get("STYLER_TEST_EXPERIMENTAL") != "1",
-                    reason="written after the round's GPU budget was spent, not yet run on hardware: "
-                           "STYLER_TEST_EXPERIMENTAL=1 to run")
 def test_predict_inference_golden(dev, model, golden):
     """StyleModeling.predict_inference (modules.py:285-309; synthesize.py:171) vs the reference-generated fixture:
     lengths / mask bit-exact, embeddings and predictions to 1e-4."""
@@ -869,9 +864,6 @@ def test_predict_inference_golden(dev, model, golden):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(__import__("os").environ.get("STYLER_TEST_EXPERIMENTAL") != "1",
-                    reason="written after the round's GPU budget was spent, not yet run on hardware: "
-                           "STYLER_TEST_EXPERIMENTAL=1 to run")
 def test_decode_entry_point_vs_oracle(dev, model, O, ref_state_dict):
     """`model.decode(x, mel_mask)` called directly (synthesize.py:202,313: lengths derived from the mask) and
     `decode_pair` vs the oracle's decode on the same ragged batch."""

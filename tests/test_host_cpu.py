@@ -79,23 +79,24 @@ def test_shard_indices_balanced():
 _WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[3])
-from styler_amd.dist import aggregate_throughput, allreduce_mean_
+from styler_amd.dist import aggregate_throughput, allreduce_mean_, allreduce_sum_
 rank, world = int(sys.argv[1]), 2
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK=str(rank), WORLD_SIZE=str(world))
 dist.init_process_group("gloo", rank=rank, world_size=world)
 t, u = aggregate_throughput(1.0 + rank, 100 * (rank + 1))
 assert (t, u) == (2.0, 300.0), (t, u)
 g = torch.arange(10, dtype=torch.float32) * (rank + 1)
-for w in allreduce_mean_(g, bucket_bytes=16):
-    w.wait()
+assert allreduce_mean_(g, bucket_bytes=16) == []
 assert torch.allclose(g, torch.arange(10, dtype=torch.float32) * 1.5), g
-# two-phase (overlapped) reduction of a flat buffer: tail range first, head at step time -- same result as one pass
+# two-phase (overlapped) SUM reduction of a flat buffer: tail range first, head at step time -- same result as one
+# pass; the 1 / world of the mean is folded into the clip + Adam kernel (grad_scale), not a pass over the buffer
 flat = torch.arange(37, dtype=torch.float32) * (rank + 1)
-tail = allreduce_mean_(flat[20:], bucket_bytes=24)
-head = allreduce_mean_(flat[:20], bucket_bytes=24)
+tail = allreduce_sum_(flat[20:], bucket_bytes=24)
+head = allreduce_sum_(flat[:20], bucket_bytes=24)
+assert len(tail) == 3 and len(head) == 4
 for w in tail + head:
     w.wait()
-assert torch.allclose(flat, torch.arange(37, dtype=torch.float32) * 1.5), flat
+assert torch.allclose(flat, torch.arange(37, dtype=torch.float32) * 3.0), flat
 dist.destroy_process_group()
 print("ok", rank)
 """
@@ -281,11 +282,12 @@ def test_batch_feeder_shards_prefetches_and_reshuffles(tmp_path):
     feeders = [BatchFeeder(ds, "cpu", batch_size=2, rank=r, world=2, seed=3, depth=2) for r in range(2)]
     groups = [f.groups() for f in feeders]
     flat = np.concatenate([np.concatenate(g) for g in groups])
-    assert len(flat) == 20 and len(set(flat.tolist())) == 20            # 5 groups of 4: disjoint, nothing dropped
-    assert [len(g) for g in groups] == [3, 2] and len(feeders[0]) == 6
+    # 5 groups of 4 on 2 ranks: disjoint, and EQUAL counts (every step ends in a collective): the odd group is dropped
+    assert len(flat) == 16 and len(set(flat.tolist())) == 16
+    assert [len(g) for g in groups] == [2, 2] and len(feeders[0]) == len(feeders[1]) == 4
     got = list(feeders[0])
     want = [to_device(sub, "cpu", pinned=False) for grp in groups[0] for sub in ds.collate_fn([ds[int(i)] for i in grp])]
-    assert len(got) == len(want) == 6
+    assert len(got) == len(want) == 4
     for (a, sa, ta), (b, sb, tb) in zip(got, want):
         assert (sa, ta) == (sb, tb) and a.keys() == b.keys()
         assert all(torch.equal(a[k], b[k]) for k in a)
@@ -339,3 +341,123 @@ def test_c_host_links_and_validates_arguments(tmp_path):
     out = subprocess.run([exe, _lib.LIB_PATH], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.strip() == "abi=1 null=-1 align=-2 kw=-1 plan=-1"
+
+
+# ---- checkpoint round trip (train.py:54,61-66,221-224) -----------------------------------------------------------------
+def _flat_layout(params):
+    align = lambda k: (k + 3) & ~3
+    return sum(align(p.numel()) for p in params)
+
+
+def _flat_adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.98, eps=1e-9):
+    """adam_kernel (csrc/misc_bwd.hip) restated in torch on flat buffers, no clipping."""
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2s = 1 - b1 ** step, (1 - b2 ** step) ** 0.5
+    p.sub_((lr / bc1) * m / (v.sqrt() / bc2s + eps))
+
+
+def test_checkpoint_round_trip_with_torch_adam():
+    """A checkpoint written by the REFERENCE layout -- {'model': nn.DataParallel(model).state_dict() (module.-prefixed),
+    'optimizer': torch.optim.Adam(model.parameters(), ...).state_dict()} -- loads into the flat moment buffers, one more
+    (flat) Adam step matches torch's next step, and the dict written back loads into a fresh torch.optim.Adam."""
+    import copy
+    from styler_amd import STYLER, hparams as hp
+    from styler_amd import checkpoint as C
+    torch.manual_seed(3)
+    model = STYLER()
+    all_params = list(model.parameters())
+    train_params = [p for p in all_params if p.requires_grad]
+    unused = {id(p) for n, p in model.named_parameters() if "pitch_norm_linear" in n}
+    opt = torch.optim.Adam(model.parameters(), betas=hp.betas, eps=hp.eps, weight_decay=hp.weight_decay, lr=1e-3)
+    g = torch.Generator().manual_seed(5)
+
+    def fake_grads():
+        for p in train_params:           # the forward never calls pitch_norm_linear: grad stays None, torch skips it
+            p.grad = None if id(p) in unused else torch.randn(p.shape, generator=g) * 0.01
+    for _ in range(2):
+        fake_grads()
+        opt.step()
+    ckpt = {"model": {"module." + k: v.clone() for k, v in model.state_dict().items()},
+            "optimizer": copy.deepcopy(opt.state_dict())}
+    assert len(ckpt["model"]) == 328 and all(k.startswith("module.") for k in ckpt["model"])
+    assert len(ckpt["optimizer"]["state"]) == len(train_params) - len(unused)
+
+    # ---- load into a fresh model + flat buffers ----
+    model2 = STYLER()
+    C.load_model_state_dict(model2, ckpt["model"])
+    for a, b in zip(model.state_dict().values(), model2.state_dict().values()):
+        assert torch.equal(a, b)
+    params2 = [p for p in model2.parameters() if p.requires_grad]
+    n = _flat_layout(params2)
+    flat_m, flat_v = torch.full((n,), 7.0), torch.full((n,), 7.0)
+    steps = C.flat_from_adam_state(ckpt["optimizer"], model2, params2, flat_m, flat_v)
+    assert steps == 2
+    off = 0
+    for p_ref, p in zip(train_params, params2):
+        k = p.numel()
+        st = opt.state.get(p_ref)
+        if st is None:
+            assert float(flat_m[off:off + k].abs().max()) == 0.0 and float(flat_v[off:off + k].abs().max()) == 0.0
+        else:
+            assert torch.equal(flat_m[off:off + k].view(p.shape), st["exp_avg"])
+            assert torch.equal(flat_v[off:off + k].view(p.shape), st["exp_avg_sq"])
+        off += (k + 3) & ~3
+
+    # ---- one more step: torch on the original, the flat formula on the loaded state ----
+    fake_grads()
+    flat_p, flat_g = torch.zeros(n), torch.zeros(n)
+    off = 0
+    for p_ref, p in zip(train_params, params2):
+        k = p.numel()
+        flat_p[off:off + k] = p.detach().reshape(-1)
+        if p_ref.grad is not None:
+            flat_g[off:off + k] = p_ref.grad.reshape(-1)
+        off += (k + 3) & ~3
+    opt.step()
+    _flat_adam_step(flat_p, flat_g, flat_m, flat_v, 1e-3, steps + 1)
+    off = 0
+    for p_ref in train_params:
+        k = p_ref.numel()
+        assert torch.allclose(flat_p[off:off + k].view(p_ref.shape), p_ref.detach(), rtol=1e-5, atol=1e-7)
+        off += (k + 3) & ~3
+
+    # ---- write back in torch's layout and load it into a fresh torch.optim.Adam ----
+    sd = C.adam_state_from_flat(model2, params2, flat_m, flat_v, steps + 1, 1e-3)
+    assert sorted(sd["state"]) == sorted(ckpt["optimizer"]["state"])            # no entry for the never-used MLP
+    opt3 = torch.optim.Adam(model2.parameters(), betas=hp.betas, eps=hp.eps, weight_decay=hp.weight_decay, lr=1e-3)
+    opt3.load_state_dict(sd)
+    by_index = dict(enumerate(model2.parameters()))
+    for idx, st in opt.state_dict()["state"].items():
+        got = opt3.state[by_index[idx]]
+        assert int(got["step"]) == 3
+        assert torch.allclose(got["exp_avg"], st["exp_avg"], rtol=1e-5, atol=1e-9)        # torch lerps, the kernel FMAs
+        assert torch.allclose(got["exp_avg_sq"], st["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+    # torch 1.6 (the reference's pin) stored `step` as a python int: accepted too
+    legacy = copy.deepcopy(ckpt["optimizer"])
+    for st in legacy["state"].values():
+        st["step"] = int(st["step"])
+    assert C.flat_from_adam_state(legacy, model2, params2, flat_m, flat_v) == 2
+    assert set(C.model_state_dict(model2)) == set(ckpt["model"])
+
+
+def test_feeder_groups_equal_across_ranks():
+    """Every rank must run the same number of steps per epoch (each ends in a collective): with 5 groups and 2 ranks the
+    odd group is dropped, the ranks' groups are disjoint."""
+    from styler_amd.data import BatchFeeder
+
+    class Store:
+        def __len__(self):
+            return 5 * 4 + 3                                   # 5 full groups of batch_size^2 = 4 items, 3 left over
+    feeders = [BatchFeeder(Store(), "cpu", batch_size=2, rank=r, world=2, seed=1) for r in range(2)]
+    groups = [f.groups() for f in feeders]
+    assert len(groups[0]) == len(groups[1]) == 2 and len(feeders[0]) == len(feeders[1]) == 4
+    seen = [int(i) for gs in groups for g in gs for i in g]
+    assert len(seen) == len(set(seen)) == 16
+
+
+def test_noam_lr_at_step_zero():
+    from styler_amd.optimizer import ScheduledOptim, noam_lr
+    assert noam_lr(0) == 0.0
+    so = ScheduledOptim(torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))]), 256, 4000, 0)
+    assert so._get_lr_scale() == 0.0                           # optimizer.py:21-25 at n = 0: min(inf, 0) = 0
