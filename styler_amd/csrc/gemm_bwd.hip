@@ -545,7 +545,8 @@ static void wgrad_plan(int B, int L, int n, int cin, int kw, int pad_left, int p
   // (the partials of one backward pass add up to GBs).  The small Linear gradients that run as members of ONE grouped
   // launch (wgrad_tr_group_kernel: bf16, kw = 1, 64x64 tile) share the chip, so they get a quarter of the splits.
   static const int grp_target = [] { const char* e = getenv("STYLER_WGRAD_GROUP_BLOCKS"); return e ? atoi(e) : 128; }();
-  const int target = (prec == STYLER_PREC_BF16 && kw == 1 && TA == 1 && TB == 1) ? grp_target : 512;
+  static const int big_target = [] { const char* e = getenv("STYLER_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
+  const int target = (prec == STYLER_PREC_BF16 && kw == 1 && TA == 1 && TB == 1) ? grp_target : big_target;
   int64_t sp = (target + nt * ct - 1) / (nt * ct);
   if (sp >= 8 && prec == STYLER_PREC_BF16) sp = (sp + 4) / 8 * 8;          // whole splits per XCD (see wgrad_tr_kernel)
   if (sp > nchunks / 4) sp = nchunks / 4;

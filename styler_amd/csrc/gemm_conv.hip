@@ -391,14 +391,15 @@ static int launch_gemm(GemmArgs a, hipStream_t st, int x16, int y16) {
 #define GEMM_IO(KW1_, OCC_)                                                        \
   do {                                                                              \
     if constexpr (BF16) {                                                           \
-      if (x16) GEMM_LAUNCH(KW1_, OCC_, true, false);                                \
+      if (x16 && y16) GEMM_LAUNCH(KW1_, OCC_, true, true);                          \
+      else if (x16) GEMM_LAUNCH(KW1_, OCC_, true, false);                           \
       else if (y16) GEMM_LAUNCH(KW1_, OCC_, false, true);                           \
       else GEMM_LAUNCH(KW1_, OCC_, false, false);                                   \
     } else {                                                                        \
       GEMM_LAUNCH(KW1_, OCC_, false, false);                                        \
     }                                                                               \
   } while (0)
-  if ((x16 || y16) && (!BF16 || (x16 && y16))) return STYLER_EINVAL;
+  if ((x16 || y16) && !BF16) return STYLER_EINVAL;
   if (a.kw == 1) GEMM_IO(true, false);
   else if (BF16 && TM == 2 && occ3) GEMM_IO(false, (BF16 && TM == 2));
   else GEMM_IO(false, false);

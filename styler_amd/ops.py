@@ -64,6 +64,11 @@ class WgradArena:
         self.group_keep = []                         # operand tensors, alive until the grouped launch has been enqueued
         self._gcache = {}                            # descriptor bytes -> (pinned host table, device table)
         self._pinned_pool = []
+        # weight gradients on a side stream (rt.wgrad_stream): the dX chain of backward never reads a weight gradient, so
+        # the two chains only meet at flush(); operands stay referenced until then
+        self.side = None
+        self.side_used = False
+        self.side_keep = []
 
     def begin(self, device=None):
         """Start of a backward pass.  The buffer is (re)sized HERE, from what the previous pass asked for in total --
@@ -75,6 +80,15 @@ class WgradArena:
         self.total = 0
         self.descs = []
         self.group, self.group_blocks, self.group_keep = [], 0, []
+        self.side_used, self.side_keep = False, []
+
+    def side_stream(self, device):
+        """The weight-gradient stream, ordered behind everything enqueued so far on the current one."""
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=device)
+        self.side.wait_stream(torch.cuda.current_stream())
+        self.side_used = True
+        return self.side
 
     def take(self, nfloats, device):
         nfloats = (nfloats + 3) & ~3
@@ -96,6 +110,9 @@ class WgradArena:
     def flush(self, device):
         import ctypes
         import numpy as np
+        if self.side_used:                           # join: the partial tiles written on the side stream are read below
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.side_used, self.side_keep = False, []
         if self.group:
             from ._lib import WgradGroupDesc
             arr = (WgradGroupDesc * len(self.group))(*self.group)
@@ -685,9 +702,24 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
             arena.group_blocks += nb
             arena.group_keep.append((dz, x, plan))
             grouped = True
-    if grouped:
-        pass
-    elif plan is not None:
+    from .runtime import rt as _rt
+    side = None
+    if (not grouped) and defer and _rt.wgrad_stream and prof is None and prec == PREC_BF16:
+        side = arena.side_stream(dz.device)
+        arena.side_keep.append((dz, x, plan))
+    if side is not None:
+        with torch.cuda.stream(side):
+            _wgrad_launch(dz, x, dw, db, db2, strides, B, L, n, cin, kw, pad_left, prec, ws, defer, io, plan)
+    elif not grouped:
+        _wgrad_launch(dz, x, dw, db, db2, strides, B, L, n, cin, kw, pad_left, prec, ws, defer, io, plan)
+    if prof is not None:
+        e1.record()
+        prof.records.append(("wgrad_bf16" if prec == PREC_BF16 else "wgrad", 2.0 * B * L * n * kw * cin, e0, e1,
+                             plan is not None))
+
+
+def _wgrad_launch(dz, x, dw, db, db2, strides, B, L, n, cin, kw, pad_left, prec, ws, defer, io, plan):
+    if plan is not None:
         assert B == 1 and L == plan.rows and db2 is None and pad_left == kw // 2
         _chk(lib.styler_wgrad_packed(dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), dw.data_ptr(), _ptr(db), strides[0],
                                      strides[1], strides[2], L, n, cin, kw, prec, ws.data_ptr(), defer,
@@ -697,10 +729,6 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
         _chk(lib.styler_wgrad(dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), dw.data_ptr(), _ptr(db), _ptr(db2), strides[0], strides[1],
                               strides[2], B, L, n, cin, kw, pad_left, prec, ws.data_ptr(), defer, io, _stream()),
              "styler_wgrad")
-    if prof is not None:
-        e1.record()
-        prof.records.append(("wgrad_bf16" if prec == PREC_BF16 else "wgrad", 2.0 * B * L * n * kw * cin, e0, e1,
-                             plan is not None))
 
 
 def colsum(dz, out, out2=None):

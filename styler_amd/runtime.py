@@ -26,6 +26,10 @@ class _Runtime:
     # instead of autograd's 5 zero-fills + 4 full-size adds per step (16.62 -> 16.34 ms; STYLER_FUSED_SPLIT=0: native views)
     fused_split = os.environ.get("STYLER_FUSED_SPLIT", "1") != "0"
 
+    # EXPERIMENT: launch the (deferred-reduce) weight-gradient GEMMs of backward on a side stream: they form a chain of
+    # their own next to the dX chain (nothing in backward reads a weight gradient before the flush)
+    wgrad_stream = os.environ.get("STYLER_WGRAD_STREAM", "0") == "1"
+
     def set_precision(self, name):
         self.prec = {"fp32": ops.PREC_F32, "bf16": ops.PREC_BF16}[name]
 

@@ -10,6 +10,9 @@ SHAPES = [  # name, B, L, cin, n, kw
     ("attn_fc", 48, 441, 256, 256, 1), ("postnet_512_k5", 48, 441, 512, 512, 5), ("postnet_in", 48, 441, 80, 512, 5),
     ("postnet_out", 48, 441, 512, 80, 5), ("pred_k3", 48, 441, 256, 256, 3), ("aenc_320_k5", 48, 441, 320, 320, 5),
     ("enc_w1_k9", 48, 60, 256, 1024, 9), ("mel_linear", 48, 441, 256, 80, 1), ("big_w1", 128, 2000, 256, 1024, 9),
+    # the paired decode's row count (2 x 13 530 valid frames)
+    ("p_ffn_w1_k9", 1, 27060, 256, 1024, 9), ("p_ffn_w2_k1", 1, 27060, 1024, 256, 1), ("p_qkv", 1, 27060, 256, 768, 1),
+    ("p_attn_fc", 1, 27060, 256, 256, 1), ("p_dx_w1_k9", 1, 27060, 1024, 256, 9), ("p_dx_qkv", 1, 27060, 768, 256, 1),
 ]
 
 WGRAD_SHAPES = [  # name, B, L, cin, n, kw  (dw[n, cin, kw] += dz^T x)
@@ -48,7 +51,7 @@ def main():
         return wgrad_main()
     dev = torch.device("cuda")
     precs = [a for a in sys.argv[1:] if a in ("bf16", "fp32")] or ["bf16", "fp32"]
-    only = [a for a in sys.argv[1:] if a not in ("bf16", "fp32")]
+    only = [a for a in sys.argv[1:] if a not in ("bf16", "fp32", "io")]
     for name, B, L, cin, n, kw in SHAPES:
         if only and name not in only:
             continue
@@ -58,18 +61,25 @@ def main():
         for prec in precs:
             wk = ops.cast_bf16(w) if prec == "bf16" else w
             p = ops.PREC_BF16 if prec == "bf16" else ops.PREC_F32
-            y = torch.empty(B, L, n, device=dev)
-            for _ in range(3):
-                ops.conv_gemm(x, wk, b, kw=kw, prec=p, out=y)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            iters = 20
-            e0.record()
-            for _ in range(iters):
-                ops.conv_gemm(x, wk, b, kw=kw, prec=p, out=y)
-            e1.record(); torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / iters
-            fl = 2.0 * B * L * n * kw * cin
-            print(f"{name:16s} {prec:5s} M={B*L:6d} N={n:5d} K={kw*cin:5d}  {us:9.1f} us  {fl/us/1e6:8.1f} TFLOP/s", flush=True)
+            # storage variants of the activation operand / the output (bf16 mode only): fp32|bf16 x fp32|bf16
+            ios = [(False, False)] + ([(True, False), (False, True), (True, True)] if prec == "bf16" and "io" in sys.argv else [])
+            for x16, y16 in ios:
+                xx = x.to(torch.bfloat16) if x16 else x
+                y = torch.empty(B, L, n, device=dev, dtype=torch.bfloat16 if y16 else torch.float32)
+                for _ in range(3):
+                    ops.conv_gemm(xx, wk, b, kw=kw, prec=p, out=y)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                iters = 20
+                e0.record()
+                for _ in range(iters):
+                    ops.conv_gemm(xx, wk, b, kw=kw, prec=p, out=y)
+                e1.record(); torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / iters
+                fl = 2.0 * B * L * n * kw * cin
+                by = B * L * (cin * (2 if x16 else 4) + n * (2 if y16 else 4)) + n * kw * cin * 2
+                tag = f"x{'16' if x16 else '32'}y{'16' if y16 else '32'}"
+                print(f"{name:16s} {prec:5s} {tag} M={B*L:6d} N={n:5d} K={kw*cin:5d}  {us:9.1f} us  {fl/us/1e6:8.1f} TFLOP/s  "
+                      f"{by/us/1e6:6.2f} TB/s", flush=True)
 
 if __name__ == "__main__":
     main()
