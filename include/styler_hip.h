@@ -354,21 +354,27 @@ int styler_wgrad_packed(const float* dz, int64_t lddz, const float* x, int64_t l
 /* Split count styler_wgrad uses for a shape (workspace = splits * n * kw * cin floats). */
 int styler_wgrad_splits(int B, int L, int n, int cin, int kw, int pad_left, int prec);
 
-/* Grouped launch of many small Linear weight gradients (bf16, kw = 1, 64x64 tile): the caller fills one
- * descriptor per problem on the host with styler_wgrad_group_desc (same arguments as styler_wgrad; the
- * return value is the member's block count, 0 = does not qualify, launch it with styler_wgrad), copies the
- * array to the device and launches once.  Partial tiles land in each member's `workspace` exactly as
- * styler_wgrad(defer_reduce = 1) leaves them: reduce with styler_wgrad_reduce_multi. */
+/* Grouped launch of many weight gradients (bf16 mode): the caller fills one descriptor per problem on the host with
+ * styler_wgrad_group_desc (the return value is the member's block count, 0 = does not qualify, launch it with
+ * styler_wgrad), sorts the members by `variant`, copies the array to the device and launches once per variant.
+ * Partial tiles land in each member's `workspace` exactly as styler_wgrad(defer_reduce = 1) leaves them: reduce with
+ * styler_wgrad_reduce_multi. */
 typedef struct {
   uint64_t dz, x, db, db2, ws;         /* device pointers */
   uint64_t counts;                     /* packed rows (styler_pack_plan counts) or 0 */
+  uint64_t chunktab;                   /* packed rows, kw > 1: the item-aligned K-chunk table, else 0 */
   int64_t lddz, ldx;
-  int32_t B, L, n, cin, pad_left, ct, cpi, cps, tiles, splits, block_start, _pad;
+  int32_t B, L, n, cin, pad_left, ct, cpi, cps, tiles, splits, block_start, nblocks, variant, kw;
 } StylerWgradGroupDesc;
+/* Members may be any bf16-mode weight gradient styler_wgrad / styler_wgrad_packed accept (conv taps, packed rows,
+ * io_flags); `want_splits` > 0 caps the member's split-K count (a group fills the chip together, so its members need far
+ * fewer partial tiles than a stand-alone launch); the caller assigns block_start (cumulative nblocks, members with
+ * splits >= 8 aligned to a multiple of 8) and launches each variant's members with one styler_wgrad_group call. */
 int styler_wgrad_group_desc(StylerWgradGroupDesc* out, const float* dz, int64_t lddz, const float* x,
-                            int64_t ldx, float* db, float* db2, int B, int L, int n, int cin, int pad_left,
-                            int prec, void* workspace, const int64_t* packed_counts, int block_start);
-int styler_wgrad_group(const StylerWgradGroupDesc* desc_dev, int count, int total_blocks, void* stream);
+                            int64_t ldx, float* db, float* db2, int B, int L, int n, int cin, int kw, int pad_left,
+                            int prec, void* workspace, const int64_t* packed_counts, const int32_t* packed_chunktab,
+                            int io_flags, int want_splits);
+int styler_wgrad_group(const StylerWgradGroupDesc* desc_dev, int count, int total_blocks, int variant, void* stream);
 
 /* Deferred reduction: with defer_reduce != 0 styler_wgrad leaves its partial tiles in `workspace`;
  * one styler_wgrad_reduce_multi launch then folds the partials of MANY gradients into their
@@ -470,6 +476,20 @@ int styler_masked_err_bwd(const float* a, int64_t lda, const float* b, int64_t l
 /* NLLLoss(mean) on [B,2] log-probs (loss.py:46-48): loss[0] (optional) and/or dlogp. */
 int styler_nll(const float* logp, const int64_t* label, float* loss, const float* gscale,
                float* dlogp, int B, void* stream);
+/* ---- loss head without glue kernels (csrc/losses.hip) -------------------------------------------------------------
+ * Masked MSE (kind 0) / L1 (kind 1) term of loss.py:16-44 with the mean taken in the kernel: `acc` = 4 doubles, ZERO on
+ * entry (sum, count, arrival ticket, pad); mean_out[0] = sum / count, written by the last block (may be NULL: sums only). */
+int styler_masked_err_mean(const float* a, int64_t lda, const float* b, int64_t ldb, double* acc, float* mean_out,
+                           int kind, int B, int L, int C, const int64_t* len, void* stream);
+/* The three NLLLoss(mean) terms of one classifier triple, summed (loss.py:46-48, 60-68): loss[0] = sum_k -mean_b
+ * logp_k[b, label[b]] (label NULL: every label = label_const, the zeros / ones of train.py:139,152); with dlogp3
+ * ([3, B, 2]) also the gradient -gscale[0] / B at the label entry, 0 elsewhere. */
+int styler_nll3(const float* lp0, const float* lp1, const float* lp2, const int64_t* label, int label_const, float* loss,
+                const float* gscale, float* dlogp3, int B, void* stream);
+/* out[0] = sum_i weights[i] * terms[i][0] over n <= 16 scalar device tensors (`terms` and `weights` are HOST arrays): the
+ * total loss of train.py:156-160 in one launch; styler_scale_weights is its backward, out[i] = g[0] * weights[i]. */
+int styler_weighted_sum(const float* const* terms, const float* weights, int n, float* out, void* stream);
+int styler_scale_weights(const float* g, const float* weights, int n, float* out, void* stream);
 /* Registers the device address of a uint64 step counter (or NULL to unregister).  Every dropout-drawing entry
  * point (styler_dropout, styler_add_layernorm / styler_layernorm_bwd with drop_p > 0) then uses
  * seed + counter * odd-constant as its stream key, read on the device at execution time: a training step

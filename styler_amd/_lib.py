@@ -38,8 +38,8 @@ _SIGS = {
     "styler_lstm_bidir_multi": [P, I, I, I, P],
     "styler_set_dropout_counter": [P],
     "styler_strided_copy_multi": [P, I, I64, P],
-    "styler_wgrad_group_desc": [P, P, I64, P, I64, P, P, I, I, I, I, I, I, P, P, I],
-    "styler_wgrad_group": [P, I, I, P],
+    "styler_wgrad_group_desc": [P, P, I64, P, I64, P, P, I, I, I, I, I, I, I, P, P, P, I, I],
+    "styler_wgrad_group": [P, I, I, I, P],
     "styler_pack_plan": [P, I, I, P, P, P, P, P],
     "styler_pack_rows": [P, I64, P, I64, P, P, I, I, I, P],
     "styler_unpack_rows": [P, I64, P, I64, P, I, I, I, P],
@@ -75,6 +75,10 @@ _SIGS = {
     "styler_rowsum": [P, I64, P, I64, I, I, I, I, P],
     "styler_masked_err_bwd": [P, I64, P, I64, P, P, P, I, I, I, I, P, P],
     "styler_nll": [P, P, P, P, P, I, P],
+    "styler_masked_err_mean": [P, I64, P, I64, P, P, I, I, I, I, P, P],
+    "styler_nll3": [P, P, P, P, I, P, P, P, I, P],
+    "styler_weighted_sum": [P, P, I, P, P],
+    "styler_scale_weights": [P, P, I, P, P],
     "styler_dropout": [P, I64, P, I64, I64, I, F, ctypes.c_uint64, P],
     "styler_sumsq": [P, I64, P, P],
     "styler_adam_step": [P, P, P, P, I64, P, F, F, F, F, F, I, F, P],
@@ -90,10 +94,10 @@ class LstmDesc(ctypes.Structure):
 
 class WgradGroupDesc(ctypes.Structure):
     _fields_ = [("dz", ctypes.c_uint64), ("x", ctypes.c_uint64), ("db", ctypes.c_uint64), ("db2", ctypes.c_uint64),
-                ("ws", ctypes.c_uint64), ("counts", ctypes.c_uint64), ("lddz", ctypes.c_int64),
-                ("ldx", ctypes.c_int64)] + \
+                ("ws", ctypes.c_uint64), ("counts", ctypes.c_uint64), ("chunktab", ctypes.c_uint64),
+                ("lddz", ctypes.c_int64), ("ldx", ctypes.c_int64)] + \
                [(k, ctypes.c_int32) for k in ("B", "L", "n", "cin", "pad_left", "ct", "cpi", "cps", "tiles", "splits",
-                                              "block_start", "_pad")]
+                                              "block_start", "nblocks", "variant", "kw")]
 
 
 class CopyDesc(ctypes.Structure):

@@ -502,6 +502,61 @@ class SplitChannelsFn(Function):
         return out, None
 
 
+class SplitWidthsFn(Function):
+    """x [B, L, sum(widths)] -> channel slices of the given widths (views); backward gathers the slice gradients into one
+    buffer (SplitChannelsFn for unequal widths: the four streams of the mel calibrator's output)."""
+
+    @staticmethod
+    def forward(ctx, x, widths):
+        ctx.meta = (x.shape, widths, x.device)
+        outs, off = [], 0
+        for w in widths:
+            outs.append(x[..., off:off + w])
+            off += w
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        shape, widths, dev = ctx.meta
+        if all(g is None for g in gs):
+            return None, None
+        out = torch.empty(shape, device=dev, dtype=torch.float32)
+        off = 0
+        for g, w in zip(gs, widths):
+            dst = out[..., off:off + w]
+            if g is None:
+                dst.zero_()
+            else:
+                ops.add2(ops._rows_view(g), None, out=dst)
+            off += w
+        return out, None
+
+
+class SplitBatchFn(Function):
+    """x [2B, ...] -> (x[:B], x[B:]) (views); backward = one concatenation (native slicing: two zero-filled full-size
+    tensors, two copies and an add)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.meta = (x.shape, x.device)
+        B = x.shape[0] // 2
+        return x[:B], x[B:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        shape, dev = ctx.meta
+        if ga is None and gb is None:
+            return None
+        B = shape[0] // 2
+        out = torch.empty(shape, device=dev, dtype=torch.float32)
+        for dst, g in ((out[:B], ga), (out[B:], gb)):
+            if g is None:
+                dst.zero_()
+            else:
+                dst.copy_(g)
+        return out
+
+
 class PackPairFn(Function):
     """Two padded [B, T, C] tensors (+ positional table) -> one packed batch of 2B items; backward = unpack per half."""
 
@@ -588,21 +643,51 @@ class DropoutFn(Function):
 
 
 class MaskedErrFn(Function):
-    """mean over valid positions of (a-b)^2 (kind 0) or |a-b| (kind 1): masked_select + MSELoss/L1Loss."""
+    """mean over valid positions of (a-b)^2 (kind 0) or |a-b| (kind 1): masked_select + MSELoss/L1Loss.  The mean is
+    taken inside the kernel (no aten div / cast launches)."""
 
     @staticmethod
     def forward(ctx, a, b, kind, lens):
         a, b = a.contiguous(), b.contiguous()
-        acc = torch.zeros(2, dtype=torch.float64, device=a.device)
-        ops.masked_err_sum(a, b, acc, kind, lens)
+        mean, acc = ops.masked_err_mean(a, b, kind, lens)
         ctx.save_for_backward(a, b, acc, lens)
         ctx.kind = kind
-        return (acc[0] / acc[1]).float()
+        return mean.view(())
 
     @staticmethod
     def backward(ctx, g):
         a, b, acc, lens = ctx.saved_tensors
-        return ops.masked_err_bwd(a, b, acc, g.reshape(1).float().contiguous(), ctx.kind, lens), None, None, None
+        return ops.masked_err_bwd(a, b, acc, g.reshape(1), ctx.kind, lens), None, None, None
+
+
+class Nll3Fn(Function):
+    """3 x NLLLoss(mean) on [B, 2] log-probabilities, summed (loss.py:46-48 / 60-68): one launch each way."""
+
+    @staticmethod
+    def forward(ctx, p0, p1, p2, label):
+        lps = [p.contiguous() for p in (p0, p1, p2)]
+        ctx.lps, ctx.label = lps, label
+        return ops.nll3(lps, label).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        d3 = ops.nll3(ctx.lps, ctx.label, gscale=g.reshape(1), want_grad=True)
+        return d3[0], d3[1], d3[2], None
+
+
+class WeightedSumFn(Function):
+    """total = sum_i w_i * term_i over scalar tensors (train.py:156-160) in one launch; backward = one launch writing
+    g * w_i for every term (instead of a chain of single-element aten add / mul kernels both ways)."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        ctx.weights = weights
+        return ops.weighted_sum([t.reshape(1) for t in terms], weights).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        gw = ops.scale_weights(g.reshape(1), ctx.weights)
+        return (None, *[gw[i] for i in range(len(ctx.weights))])
 
 
 class NllFn(Function):

@@ -482,18 +482,23 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const void* __restrict__ 
                                        chunks_per_split, tiles, splits, ws, chunktab, counts);
 }
 
-// Many small Linear weight gradients in ONE launch (kw = 1, 64x64 tile): the S-domain gradients of a backward pass
-// (style MLPs, LSTM matrices, classifier heads, text-encoder projections) are ~120 launches of 5-10 us each, i.e.
-// launch-latency-bound.  Descriptor i owns blocks [block_start[i], block_start[i+1]).
+// Many weight gradients in ONE launch.  Launched one by one, a weight gradient is alone on the chip and needs >= 2 blocks
+// per CU of its own: 8..37 split-K partial tiles per output tile (2 GB of partials per training step).  As members of
+// one launch per kernel variant the gradients of a whole backward pass fill the chip together, so a member needs only
+// 1..3 splits (runtime: WgradArena picks the count from the group's size in the previous step).  Descriptor i owns
+// blocks [block_start[i], block_start[i] + nblocks[i]); gaps (alignment to the 8 XCDs) belong to no member.
+template <int KW, int TA, int TB, bool DZ16, bool X16>
 __global__ __launch_bounds__(256) void wgrad_tr_group_kernel(const StylerWgradGroupDesc* __restrict__ desc, int count) {
   int lo = 0, hi = count - 1;                        // last descriptor with block_start <= blockIdx.x
   const int bid = blockIdx.x;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].block_start <= bid) lo = mid; else hi = mid - 1; }
   const StylerWgradGroupDesc d = desc[lo];
-  wgrad_tr_body<1, 1, 1>(bid - d.block_start, reinterpret_cast<const float*>(d.dz), d.lddz,
-                         reinterpret_cast<const float*>(d.x), d.ldx, reinterpret_cast<float*>(d.db),
-                         reinterpret_cast<float*>(d.db2), d.B, d.L, d.n, d.cin, d.pad_left, d.ct, d.cpi, d.cps, d.tiles,
-                         d.splits, reinterpret_cast<float*>(d.ws), nullptr, reinterpret_cast<const int64_t*>(d.counts));
+  if (bid - d.block_start >= d.nblocks) return;
+  wgrad_tr_body<KW, TA, TB, DZ16, X16>(bid - d.block_start, reinterpret_cast<const void*>(d.dz), d.lddz,
+                                       reinterpret_cast<const void*>(d.x), d.ldx, reinterpret_cast<float*>(d.db),
+                                       reinterpret_cast<float*>(d.db2), d.B, d.L, d.n, d.cin, d.pad_left, d.ct, d.cpi, d.cps,
+                                       d.tiles, d.splits, reinterpret_cast<float*>(d.ws),
+                                       reinterpret_cast<const int4*>(d.chunktab), reinterpret_cast<const int64_t*>(d.counts));
 }
 
 // dw[nn*sn + c*sc + j*sj] += sum over splits of ws[split][nn][j][c]
@@ -526,7 +531,7 @@ static void wgrad_tile(int n, int cin, int kw, int prec, int* TA, int* TB) {
 }
 
 static void wgrad_plan(int B, int L, int n, int cin, int kw, int pad_left, int prec, int* Be, int* Le, int* cpi, int* cps,
-                       int* splits) {
+                       int* splits, int want_splits = 0) {
   int TA, TB;
   wgrad_tile(n, cin, kw, prec, &TA, &TB);
   const int fa = 64 * TA, fb = 64 * TB;
@@ -548,6 +553,7 @@ static void wgrad_plan(int B, int L, int n, int cin, int kw, int pad_left, int p
   static const int big_target = [] { const char* e = getenv("STYLER_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
   const int target = (prec == STYLER_PREC_BF16 && kw == 1 && TA == 1 && TB == 1) ? grp_target : big_target;
   int64_t sp = (target + nt * ct - 1) / (nt * ct);
+  if (want_splits > 0 && want_splits < sp) sp = want_splits;               // grouped launch: the group fills the chip
   if (sp >= 8 && prec == STYLER_PREC_BF16) sp = (sp + 4) / 8 * 8;          // whole splits per XCD (see wgrad_tr_kernel)
   if (sp > nchunks / 4) sp = nchunks / 4;
   if (sp < 1) sp = 1;
@@ -642,33 +648,77 @@ extern "C" int styler_wgrad_packed(const float* dz, int64_t lddz, const float* x
                     workspace, defer_reduce, rowinfo, chunktab, counts, io_flags, stream);
 }
 
-// Host-side descriptor of one member of a grouped launch (styler_wgrad_group).  Returns the number of blocks the member
-// needs, 0 when the problem does not qualify (not a bf16 kw = 1 gradient on the 64x64 tile), < 0 on bad arguments.
+// Kernel variants a grouped launch can run (index = StylerWgradGroupDesc.variant).
+//   0: Linear, 64x64 tile      1: Linear, 128x128 tile      2: Linear, 128x128 tile, x resident as bf16
+//   3: k = 3                   4: k = 5                     5: k = 9            6: k = 9, dz resident as bf16
+static int wgrad_variant(int kw, int TA, int TB, bool dz16, bool x16) {
+  if (kw == 1) {
+    if (dz16) return -1;
+    if (x16) return (TA == 2 && TB == 2) ? 2 : -1;
+    if (TA == 1 && TB == 1) return 0;
+    if (TA == 2 && TB == 2) return 1;
+    return -1;
+  }
+  if (TA != 1 || TB != 1 || x16) return -1;
+  if (kw == 3) return dz16 ? -1 : 3;
+  if (kw == 5) return dz16 ? -1 : 4;
+  if (kw == 9) return dz16 ? 6 : 5;
+  return -1;
+}
+
+// Host-side descriptor of one member of a grouped launch (styler_wgrad_group): any bf16-mode weight gradient the
+// stand-alone entry points accept (padded or packed rows, conv taps, bf16-resident operands).  `want_splits` > 0 caps the
+// split count (0: the stand-alone policy).  The caller provides `workspace` (splits * n * kw * cin floats; it may be NULL in
+// a first call that only asks for the plan, then be stored into out->ws) and assigns block_start when it lays out the
+// launch.  Returns the member's block count (also out->nblocks), 0 when the problem does not qualify (not bf16 mode, or
+// a tile / storage combination without a grouped variant: launch it with styler_wgrad), < 0 on bad arguments.
 extern "C" int styler_wgrad_group_desc(StylerWgradGroupDesc* out, const float* dz, int64_t lddz, const float* x, int64_t ldx,
-                                       float* db, float* db2, int B, int L, int n, int cin, int pad_left, int prec,
-                                       void* workspace, const int64_t* packed_counts, int block_start) {
-  if (!out || !dz || !x || !workspace || B <= 0 || L <= 0 || n <= 0 || cin <= 0 || (db2 && !db)) return STYLER_EINVAL;
+                                       float* db, float* db2, int B, int L, int n, int cin, int kw, int pad_left, int prec,
+                                       void* workspace, const int64_t* packed_counts, const int32_t* packed_chunktab,
+                                       int io_flags, int want_splits) {
+  if (!out || !dz || !x || B <= 0 || L <= 0 || n <= 0 || cin <= 0 || (db2 && !db)) return STYLER_EINVAL;
+  if (kw != 1 && kw != 3 && kw != 5 && kw != 9) return STYLER_EINVAL;
   if ((lddz & 3) || (ldx & 3) || (n & 3) || ldx < ((cin + 3) & ~3) || ((uintptr_t)dz & 15) || ((uintptr_t)x & 15)) return STYLER_EALIGN;
   if (prec != STYLER_PREC_BF16) return 0;
-  if (packed_counts && (B != 1 || pad_left != 0)) return STYLER_EINVAL;
+  const bool dz16 = io_flags & STYLER_IO_Y_BF16, x16 = io_flags & STYLER_IO_X_BF16;
+  if ((dz16 || x16) && ((lddz & 7) || (ldx & 7))) return STYLER_EALIGN;
+  if (packed_counts && (B != 1 || pad_left != kw / 2 || (kw > 1 && !packed_chunktab))) return STYLER_EINVAL;
   int TA, TB;
-  wgrad_tile(n, cin, 1, prec, &TA, &TB);
-  if (TA != 1 || TB != 1) return 0;
+  wgrad_tile(n, cin, kw, prec, &TA, &TB);
+  const int variant = wgrad_variant(kw, TA, TB, dz16, x16);
+  if (variant < 0) return 0;
   int Be, Le, cpi, cps, splits;
-  wgrad_plan(B, L, n, cin, 1, pad_left, prec, &Be, &Le, &cpi, &cps, &splits);
-  const int nt = (n + 63) / 64, ct = (cin + 63) / 64, tiles = nt * ct;
+  wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, want_splits);
+  const int nt = (n + 64 * TA - 1) / (64 * TA), ct = (cin + 64 * TB - 1) / (64 * TB), tiles = nt * ct;
   out->dz = (uint64_t)(uintptr_t)dz; out->x = (uint64_t)(uintptr_t)x; out->db = (uint64_t)(uintptr_t)db;
   out->db2 = (uint64_t)(uintptr_t)db2; out->ws = (uint64_t)(uintptr_t)workspace;
   out->counts = (uint64_t)(uintptr_t)packed_counts;
+  out->chunktab = (uint64_t)(uintptr_t)(kw > 1 ? packed_chunktab : nullptr);
   out->lddz = lddz; out->ldx = ldx;
   out->B = Be; out->L = Le; out->n = n; out->cin = cin; out->pad_left = pad_left; out->ct = ct; out->cpi = cpi;
-  out->cps = cps; out->tiles = tiles; out->splits = splits; out->block_start = block_start; out->_pad = 0;
-  return tiles * (splits >= 8 ? (splits + 7) / 8 * 8 : splits);
+  out->cps = cps; out->tiles = tiles; out->splits = splits; out->block_start = 0;
+  out->nblocks = tiles * (splits >= 8 ? (splits + 7) / 8 * 8 : splits);
+  out->variant = variant; out->kw = kw;
+  return out->nblocks;
 }
 
-extern "C" int styler_wgrad_group(const StylerWgradGroupDesc* desc_dev, int count, int total_blocks, void* stream) {
+extern "C" int styler_wgrad_group(const StylerWgradGroupDesc* desc_dev, int count, int total_blocks, int variant,
+                                  void* stream) {
   if (!desc_dev || count <= 0 || total_blocks <= 0) return STYLER_EINVAL;
-  hipLaunchKernelGGL(wgrad_tr_group_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, count);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)total_blocks), block(256);
+#define WGG(K, A_, B_, D_, X_) hipLaunchKernelGGL((wgrad_tr_group_kernel<K, A_, B_, D_, X_>), grid, block, 0, st, desc_dev, count)
+  switch (variant) {
+    case 0: WGG(1, 1, 1, false, false); break;
+    case 1: WGG(1, 2, 2, false, false); break;
+    case 2: WGG(1, 2, 2, false, true); break;
+    case 3: WGG(3, 1, 1, false, false); break;
+    case 4: WGG(5, 1, 1, false, false); break;
+    case 5: WGG(9, 1, 1, false, false); break;
+    case 6: WGG(9, 1, 1, true, false); break;
+    default: return STYLER_EINVAL;
+  }
+#undef WGG
   return launch_status();
 }
 

@@ -1,0 +1,137 @@
+// Loss head of the train step (loss.py:16-68, train.py:140-160) without torch glue kernels:
+//   masked_err_mean : masked MSE / L1 term with the mean taken IN the kernel (last block), fp64 accumulation
+//   nll3            : the three NLLLoss(mean) terms of a classifier triple, summed (loss.py:46-48, 60-68)
+//   weighted_sum    : total = sum_i w_i * term_i over scalar device tensors (train.py:156-160), and its backward
+//                     (g * w_i for every term in one launch)
+// Each of these replaced 2-10 single-element aten kernels (div, cast, add, mul) that cost a launch slot apiece on the
+// serial chain of the step.
+#include "common.h"
+
+static inline unsigned loss_grid(int64_t work, int per_block, int cap) {
+  int64_t b = (work + per_block - 1) / per_block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// acc: 4 doubles, zero on entry: [0] sum of errors, [1] count of valid elements, [2] arrival ticket (as uint64), [3] unused.
+// The block that draws the last ticket reads the two totals back through the same atomics path and writes the mean.
+__global__ __launch_bounds__(256) void masked_err_mean_kernel(const float* __restrict__ a, int64_t lda,
+                                                              const float* __restrict__ b, int64_t ldb,
+                                                              double* __restrict__ acc, float* __restrict__ mean_out,
+                                                              int kind, int64_t rows, int L, int C,
+                                                              const int64_t* __restrict__ len) {
+  __shared__ double red[4][2];
+  double s = 0.0, n = 0.0;
+  if ((C & 3) == 0 && (lda & 3) == 0 && (ldb & 3) == 0) {
+    const int nq = C >> 2;
+    const int64_t total = rows * nq;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t row = i / nq; const int q = (int)(i - row * nq);
+      const int64_t bb = row / L;
+      if (len && (row - bb * L) >= len[bb]) continue;
+      const float4 x = *reinterpret_cast<const float4*>(a + row * lda + q * 4);
+      const float4 y = *reinterpret_cast<const float4*>(b + row * ldb + q * 4);
+      const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+      if (kind == 0) s += ((double)d0 * d0 + (double)d1 * d1) + ((double)d2 * d2 + (double)d3 * d3);
+      else s += ((double)fabsf(d0) + (double)fabsf(d1)) + ((double)fabsf(d2) + (double)fabsf(d3));
+      n += 4.0;
+    }
+  } else {
+    const int64_t total = rows * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t row = i / C; const int c = (int)(i - row * C);
+      const int64_t bb = row / L;
+      if (len && (row - bb * L) >= len[bb]) continue;
+      const float d = a[row * lda + c] - b[row * ldb + c];
+      s += kind == 0 ? (double)d * d : (double)fabsf(d);
+      n += 1.0;
+    }
+  }
+  s = wave_sum_d(s); n = wave_sum_d(n);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave][0] = s; red[wave][1] = n; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&acc[0], red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+    atomicAdd(&acc[1], red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+    if (mean_out) {
+      __threadfence();
+      const unsigned long long t = atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2]), 1ull);
+      if (t == (unsigned long long)gridDim.x - 1) {
+        __threadfence();
+        const double tot = atomicAdd(&acc[0], 0.0), cnt = atomicAdd(&acc[1], 0.0);   // read at the atomics' coherence point
+        mean_out[0] = (float)(tot / cnt);
+      }
+    }
+  }
+}
+
+extern "C" int styler_masked_err_mean(const float* a, int64_t lda, const float* b, int64_t ldb, double* acc, float* mean_out,
+                                      int kind, int B, int L, int C, const int64_t* len, void* stream) {
+  if (!a || !b || !acc || B <= 0 || L <= 0 || C <= 0 || (kind != 0 && kind != 1)) return STYLER_EINVAL;
+  const int64_t rows = (int64_t)B * L;
+  hipLaunchKernelGGL(masked_err_mean_kernel, dim3(loss_grid(rows * C / ((C & 3) ? 1 : 4), 256, 1024)), dim3(256), 0,
+                     (hipStream_t)stream, a, lda, b, ldb, acc, mean_out, kind, rows, L, C, len);
+  return launch_status();
+}
+
+// ---- three NLL(mean) terms over [B,2] log-probabilities with one label vector, summed -----------------------------------
+// forward: loss[0] = sum_k -mean_b logp_k[b, label[b]];  backward (dlogp3 != null): dlogp3[k][b][:] = -g/B at the label.
+__global__ void nll3_kernel(const float* __restrict__ lp0, const float* __restrict__ lp1, const float* __restrict__ lp2,
+                            const int64_t* __restrict__ label, int label_const, float* __restrict__ loss,
+                            const float* __restrict__ gscale, float* __restrict__ dlogp3, int B) {
+  const float* lp[3] = {lp0, lp1, lp2};
+  float s = 0.f;
+  const float g = (dlogp3 && gscale) ? -gscale[0] / (float)B : 0.f;
+  for (int i = threadIdx.x; i < 3 * B; i += 64) {
+    const int k = i / B, b = i - k * B;
+    const int l = label ? (int)label[b] : label_const;
+    s -= lp[k][b * 2 + l];
+    if (dlogp3) { dlogp3[(k * B + b) * 2 + l] = g; dlogp3[(k * B + b) * 2 + 1 - l] = 0.f; }
+  }
+  s = wave_sum(s);
+  if (threadIdx.x == 0 && loss) loss[0] = s / (float)B;
+}
+
+extern "C" int styler_nll3(const float* lp0, const float* lp1, const float* lp2, const int64_t* label, int label_const,
+                           float* loss, const float* gscale, float* dlogp3, int B, void* stream) {
+  if (!lp0 || !lp1 || !lp2 || (!loss && !dlogp3) || (dlogp3 && !gscale) || B <= 0) return STYLER_EINVAL;
+  if (!label && label_const != 0 && label_const != 1) return STYLER_EINVAL;
+  hipLaunchKernelGGL(nll3_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, lp0, lp1, lp2, label, label_const, loss,
+                     gscale, dlogp3, B);
+  return launch_status();
+}
+
+// ---- total = sum_i w_i * term_i over up to 16 scalar device tensors; g_out[i] = g[0] * w_i ------------------------------
+struct ScalarTerms { const float* p[16]; float w[16]; int n; };
+
+__global__ void weighted_sum_kernel(ScalarTerms t, float* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < t.n; ++i) s += t.w[i] * t.p[i][0];       // left to right, like the chained adds it replaces
+    out[0] = s;
+  }
+}
+__global__ void scale_weights_kernel(ScalarTerms t, const float* __restrict__ g, float* __restrict__ out) {
+  if (threadIdx.x < t.n) out[threadIdx.x] = g[0] * t.w[threadIdx.x];
+}
+
+extern "C" int styler_weighted_sum(const float* const* terms, const float* weights, int n, float* out, void* stream) {
+  if (!terms || !weights || !out || n <= 0 || n > 16) return STYLER_EINVAL;
+  ScalarTerms t;
+  t.n = n;
+  for (int i = 0; i < 16; ++i) { t.p[i] = i < n ? terms[i] : nullptr; t.w[i] = i < n ? weights[i] : 0.f; }
+  for (int i = 0; i < n; ++i) if (!t.p[i]) return STYLER_EINVAL;
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, out);
+  return launch_status();
+}
+
+extern "C" int styler_scale_weights(const float* g, const float* weights, int n, float* out, void* stream) {
+  if (!g || !weights || !out || n <= 0 || n > 16) return STYLER_EINVAL;
+  ScalarTerms t;
+  t.n = n;
+  for (int i = 0; i < 16; ++i) { t.p[i] = nullptr; t.w[i] = i < n ? weights[i] : 0.f; }
+  hipLaunchKernelGGL(scale_weights_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, g, out);
+  return launch_status();
+}

@@ -14,17 +14,17 @@ from . import ops
 def _masked_mean(a, b, kind, lens):
     if torch.is_grad_enabled() and a.requires_grad:
         return AG.MaskedErrFn.apply(a, b.detach(), kind, lens)
-    acc = torch.zeros(2, dtype=torch.float64, device=a.device)
-    ops.masked_err_sum(a.contiguous(), b.contiguous(), acc, kind, lens)
-    return (acc[0] / acc[1]).float()
+    return ops.masked_err_mean(a.contiguous(), b.contiguous(), kind, lens)[0].view(())
 
 
 def _nll3(posteriors, label):
-    """3 x NLLLoss(mean) on [B, 2] log-probabilities (loss.py:46-48)."""
-    label = label.contiguous()
+    """3 x NLLLoss(mean) on [B, 2] log-probabilities, summed (loss.py:46-48): one kernel.  `label`: int64 [B] tensor as in
+    the reference call, or the python int 0 / 1 when every label is the same (train.py:139,152 builds zeros / ones)."""
+    if torch.is_tensor(label):
+        label = label.contiguous()
     if torch.is_grad_enabled() and any(p.requires_grad for p in posteriors):
-        return sum(AG.NllFn.apply(p, label) for p in posteriors)
-    return sum(ops.nll(p.contiguous(), label) for p in posteriors)
+        return AG.Nll3Fn.apply(posteriors[0], posteriors[1], posteriors[2], label)
+    return ops.nll3([p.contiguous() for p in posteriors], label).view(())
 
 
 class STYLERLoss(nn.Module):

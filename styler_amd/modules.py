@@ -154,7 +154,7 @@ class AudioEncoder(_HipModule):
         S = int(max_seq_len) if max_seq_len is not None else int(seq_len.max().item())
         cal = AG.MelCalibrateFn.apply(catbuf, len_org, seq_len, S) if grad else ops.mel_calibrate(catbuf, len_org, seq_len, S)
         # the four 2-layer BiLSTMs advance layer by layer together: 4 input GEMMs + ONE recurrent launch per layer
-        xs = [cal[..., offs[s]:offs[s] + W[s]] for s in range(4)]
+        xs = list(AG.SplitWidthsFn.apply(cal, tuple(W))) if grad else [cal[..., offs[s]:offs[s] + W[s]] for s in range(4)]
         for layer in range(2):
             if grad:
                 xs = list(AG.LstmMultiLayerFn.apply(self, layer, self.lstm_1.weight_hh_l0, *xs))
@@ -188,8 +188,20 @@ class StyleEncoder(_HipModule):
 
     def forward(self, text, speaker_embed, mel_target, p_norm, e_input, mel_aug, mel_len, src_len, src_mask,
                 text_out=None):
-        text_encoding = self.text_encoder(text, src_len, out=text_out)
-        text_encoding_neck = self._gemm("tld", text_encoding, self.text_linear_down[0], act=ops.ACT_RELU)
+        side = None
+        if rt.text_stream and self.training and torch.is_grad_enabled():
+            # EXPERIMENT: the text encoder (two FFT blocks on [B, S] rows: ~40 launch-latency-bound kernels) on a side
+            # stream next to the AudioEncoder's T-domain convolutions; autograd replays each node's backward on its
+            # forward stream, so the two backward chains overlap the same way
+            main = torch.cuda.current_stream()
+            side = self.__dict__.setdefault("_text_stream", torch.cuda.Stream(device=text.device))
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                text_encoding = self.text_encoder(text, src_len, out=text_out)
+                text_encoding_neck = self._gemm("tld", text_encoding, self.text_linear_down[0], act=ops.ACT_RELU)
+        else:
+            text_encoding = self.text_encoder(text, src_len, out=text_out)
+            text_encoding_neck = self._gemm("tld", text_encoding, self.text_linear_down[0], act=ops.ACT_RELU)
         spk_in = speaker_embed.unsqueeze(1)
         speaker_encoding_p = self._gemm("slp", spk_in, self.speaker_linear_p[0], act=ops.ACT_RELU).squeeze(1)
         speaker_encoding = self._gemm("sl", spk_in, self.speaker_linear[0], act=ops.ACT_RELU).squeeze(1)
@@ -204,11 +216,14 @@ class StyleEncoder(_HipModule):
                                              torch.cat([e_input, dat[2]]), torch.cat([mel_aug, dat[0]]))
             d, p, e, n = self.audio_encoder(enc_cat, torch.cat([mel_len, mel_len]), torch.cat([src_len, src_len]),
                                             mask=None, max_seq_len=text.shape[1])
-            self.dat_encodings = (d[B:], p[B:], e[B:])
-            d, p, e, n = d[:B], p[:B], e[:B], n[:B]
+            (d, d2), (p, p2), (e, e2) = (AG.SplitBatchFn.apply(t) for t in (d, p, e))
+            self.dat_encodings = (d2, p2, e2)
+            n = n[:B]                                  # the DAT pass has no use for the noise stream (train.py:150-153)
         else:
             enc_cat = self.encoder_input_cat(mel_target, p_norm, e_input, mel_aug)
             d, p, e, n = self.audio_encoder(enc_cat, mel_len, src_len, mask=None, max_seq_len=text.shape[1])
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         return text_encoding, text_encoding_neck, speaker_encoding_p, speaker_encoding, d, p, e, n
 
 

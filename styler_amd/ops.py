@@ -58,10 +58,12 @@ class WgradArena:
         self.total = 0                               # floats requested by the current pass (taken or not)
         self.descs = []
         self._cache = {}                             # descriptor tuple -> (device table, total blocks)
-        # small Linear gradients are not launched one by one: they are collected and run as ONE grouped launch at flush
+        # bf16 mode: weight gradients are not launched one by one -- they are collected and run as ONE grouped launch per
+        # kernel variant at flush (the group fills the chip together, so a member needs 1-3 split-K partials, not 8-37)
         self.group = []                              # WgradGroupDesc of the pending members
-        self.group_blocks = 0
-        self.group_keep = []                         # operand tensors, alive until the grouped launch has been enqueued
+        self.group_keep = []                         # operand tensors, alive until the grouped launches have been enqueued
+        self.flush_no = 0                            # flushes so far in this pass (the decoder-side one comes first)
+        self.hist = {}                               # (flush number, variant) -> tiles of that group in the previous pass
         self._gcache = {}                            # descriptor bytes -> (pinned host table, device table)
         self._pinned_pool = []
         # weight gradients on a side stream (rt.wgrad_stream): the dX chain of backward never reads a weight gradient, so
@@ -79,7 +81,8 @@ class WgradArena:
         self.used = 0
         self.total = 0
         self.descs = []
-        self.group, self.group_blocks, self.group_keep = [], 0, []
+        self.group, self.group_keep = [], []
+        self.flush_no = 0
         self.side_used, self.side_keep = False, []
 
     def side_stream(self, device):
@@ -99,12 +102,28 @@ class WgradArena:
         self.used += nfloats
         return out
 
+    # EXPERIMENT (measured, not the default): ALL bf16 weight gradients of a backward pass as members of one grouped launch
+    # per kernel variant, with a split count derived from the group's size (GROUP_BLOCKS / tiles of the group in the previous
+    # pass).  Fewer partial tiles, but at 1-3 splits a group is only ~1.5 rounds of blocks at 2 blocks per CU, and the tail
+    # costs more than the partial-tile traffic saves: 15.76 ms (768 blocks), 15.59 (1536), 15.49 (stand-alone split counts)
+    # vs 15.1-15.2 ms for the interleaved stand-alone launches on the same box type.
+    group_all = __import__("os").environ.get("STYLER_WGRAD_GROUP_ALL", "0") == "1"
+    GROUP_BLOCKS = int(__import__("os").environ.get("STYLER_WGRAD_GROUP_TOTAL", "1536"))   # blocks one grouped launch aims for
+
+    def want_splits(self, variant):
+        """Split-K count for a new member of the group (current flush, `variant`): GROUP_BLOCKS over the tiles that group
+        had in the previous pass; 0 (= the stand-alone policy) while there is no history."""
+        tiles = self.hist.get((self.flush_no, variant))
+        if not tiles:
+            return 0
+        return max(1, (self.GROUP_BLOCKS + tiles // 2) // tiles)
+
     def _top_up_pinned(self, capturing):
         """Pinned staging buffers cannot be allocated while a hipGraph is being captured (and a captured memcpy node
         re-reads its buffer at every replay, so each table owns one): keep a reserve from the eager steps -- a capture
         may flush more than once (split step) and may be retried."""
         if not capturing:
-            while len(self._pinned_pool) < 6:
+            while len(self._pinned_pool) < 8:
                 self._pinned_pool.append(torch.empty(self.GROUP_TABLE_BYTES, dtype=torch.uint8).pin_memory())
 
     def flush(self, device):
@@ -115,13 +134,30 @@ class WgradArena:
             self.side_used, self.side_keep = False, []
         if self.group:
             from ._lib import WgradGroupDesc
-            arr = (WgradGroupDesc * len(self.group))(*self.group)
+            # one launch per kernel variant; inside a launch the heavy members (long K loops) come first, members with
+            # >= 8 splits start on a multiple of 8 blocks (their split -> XCD map, gemm_bwd.hip)
+            members = sorted(self.group, key=lambda d: (d.variant, -d.cps * d.kw))
+            launches, tiles = [], {}
+            start, first = 0, 0
+            for i, d in enumerate(members):
+                if i and d.variant != members[i - 1].variant:
+                    launches.append((members[first].variant, first, i - first, start))
+                    start, first = 0, i
+                if d.splits >= 8:
+                    start = (start + 7) & ~7
+                d.block_start = start
+                start += d.nblocks
+                tiles[d.variant] = tiles.get(d.variant, 0) + d.tiles
+            launches.append((members[first].variant, first, len(members) - first, start))
+            for v, t in tiles.items():
+                self.hist[(self.flush_no, v)] = t
+            arr = (WgradGroupDesc * len(members))(*members)
             key = bytes(arr)
             capturing = torch.cuda.is_current_stream_capturing()
             self._top_up_pinned(capturing)
             if not capturing:
                 # eager step: operand addresses differ from step to step, so the table is simply uploaded (a blocking
-                # 12 KB copy); nothing is cached and no pinned buffer is consumed (pinning memory costs ~10 ms a piece)
+                # copy of a few KB); nothing is cached and no pinned buffer is consumed (pinning memory costs ~10 ms a piece)
                 table = torch.frombuffer(bytearray(key), dtype=torch.uint8).to(device)
             else:
                 if key not in self._gcache:
@@ -133,9 +169,12 @@ class WgradArena:
                     dev_t.copy_(host[:len(key)], non_blocking=True)
                     self._gcache[key] = (host, dev_t)
                 table = self._gcache[key][1]
-            _chk(lib.styler_wgrad_group(table.data_ptr(), len(self.group), self.group_blocks, _stream()),
-                 "styler_wgrad_group")
-            self.group, self.group_blocks, self.group_keep = [], 0, []
+            esz = ctypes.sizeof(WgradGroupDesc)
+            for variant, first, count, blocks in launches:
+                _chk(lib.styler_wgrad_group(table.data_ptr() + first * esz, count, blocks, variant, _stream()),
+                     "styler_wgrad_group")
+            self.group, self.group_keep = [], []
+        self.flush_no += 1
         if not self.descs:
             return
         key = tuple(self.descs)
@@ -675,8 +714,33 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    nfloats = int(lib.styler_wgrad_workspace_bytes(B, L, n, cin, kw, pad_left, prec)) // 4
     arena = wgrad_arena
+    io = (2 if dz.dtype == torch.bfloat16 else 0) | (1 if x.dtype == torch.bfloat16 else 0)    # bf16-resident operands
+    if (arena is not None and arena.buf is not None and prec == PREC_BF16 and prof is None and (plan is None or db2 is None)
+            and (arena.group_all or (kw == 1 and not io))):
+        # grouped path (default: the small Linear gradients, variant 0; STYLER_WGRAD_GROUP_ALL=1: every bf16 gradient):
+        # plan the member first (variant, tiles, split count), then give it its slice of the arena
+        from ._lib import WgradGroupDesc
+        import ctypes
+        d = WgradGroupDesc()
+        args = (dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), _ptr(db), _ptr(db2), B, L, n, cin, kw, pad_left, prec)
+        packed = (plan.counts.data_ptr(), plan.chunktab.data_ptr()) if plan is not None else (None, None)
+        nb = lib.styler_wgrad_group_desc(ctypes.byref(d), *args, None, *packed, io, 0)
+        if nb < 0:
+            _chk(nb, "styler_wgrad_group_desc")
+        if nb > 0 and (arena.group_all or d.variant == 0):
+            want = arena.want_splits(d.variant) if arena.group_all else 0
+            if want:
+                nb = lib.styler_wgrad_group_desc(ctypes.byref(d), *args, None, *packed, io, want)
+            ws = arena.take(d.splits * n * kw * cin, dz.device)
+            if ws is not None:
+                d.ws = ws.data_ptr()
+                arena.descs.append((ws.data_ptr(), dw.data_ptr(), strides[0], strides[1], strides[2], n, cin, kw, d.splits))
+                arena.group.append(d)
+                arena.group_keep.append((dz, x, plan))
+                return
+            arena.total -= (d.splits * n * kw * cin + 3) & ~3      # did not fit: the stand-alone request below is counted
+    nfloats = int(lib.styler_wgrad_workspace_bytes(B, L, n, cin, kw, pad_left, prec)) // 4
     ws, defer = None, 0
     if arena is not None:
         ws = arena.take(nfloats, dz.device)
@@ -686,22 +750,7 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
                                 int(lib.styler_wgrad_splits(B, L, n, cin, kw, pad_left, prec))))
     if ws is None:
         ws = torch.empty(nfloats, device=dz.device, dtype=torch.float32)
-    io = (2 if dz.dtype == torch.bfloat16 else 0) | (1 if x.dtype == torch.bfloat16 else 0)    # bf16-resident operands
     grouped = False
-    if defer and kw == 1 and prec == PREC_BF16 and prof is None and not io:
-        from ._lib import WgradGroupDesc
-        import ctypes
-        d = WgradGroupDesc()
-        nb = lib.styler_wgrad_group_desc(ctypes.byref(d), dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), _ptr(db), _ptr(db2),
-                                         B, L, n, cin, pad_left, prec, ws.data_ptr(),
-                                         plan.counts.data_ptr() if plan is not None else None, arena.group_blocks)
-        if nb < 0:
-            _chk(nb, "styler_wgrad_group_desc")
-        if nb > 0:                                   # joins the grouped launch of WgradArena.flush
-            arena.group.append(d)
-            arena.group_blocks += nb
-            arena.group_keep.append((dz, x, plan))
-            grouped = True
     from .runtime import rt as _rt
     side = None
     if (not grouped) and defer and _rt.wgrad_stream and prof is None and prec == PREC_BF16:
@@ -894,6 +943,58 @@ def masked_err_bwd(a, b, acc, gscale, kind, lens):
     _chk(lib.styler_masked_err_bwd(a.data_ptr(), lda, b.data_ptr(), ldb, acc.data_ptr(), gscale.data_ptr(),
                                    da.data_ptr(), kind, B, L, C, _ptr(lens), _stream()), "styler_masked_err_bwd")
     return da
+
+
+def masked_err_mean(a, b, kind, lens):
+    """-> (mean [1] fp32, acc [4] fp64): masked MSE (kind 0) / L1 (kind 1) over valid positions, mean taken in the kernel.
+    Inside a training step the accumulator comes from the per-step zero slab (no memset of its own)."""
+    if a.dim() == 2:
+        B, L = a.shape
+        C, lda, ldb = 1, 1, 1
+    else:
+        B, L, C = a.shape
+        lda, ldb = _ld(a), _ld(b)
+    acc = None
+    if zero_slab is not None:
+        acc = zero_slab.take(4)
+    if acc is None:
+        acc = torch.zeros(4, dtype=torch.float64, device=a.device)
+    out = torch.empty(1, device=a.device, dtype=torch.float32)
+    _chk(lib.styler_masked_err_mean(_f32(a).data_ptr(), lda, _f32(b).data_ptr(), ldb, acc.data_ptr(), out.data_ptr(), kind, B, L,
+                                    C, _ptr(lens), _stream()), "styler_masked_err_mean")
+    return out, acc
+
+
+def nll3(lps, label, gscale=None, want_grad=False):
+    """Three NLLLoss(mean) terms summed.  `label`: int64 [B] tensor, or the python int 0 / 1 (all labels equal)."""
+    B = lps[0].shape[0]
+    const = label if isinstance(label, int) else 0
+    lab = None if isinstance(label, int) else label
+    loss = torch.empty(1, device=lps[0].device, dtype=torch.float32) if not want_grad else None
+    d3 = torch.empty(3, B, 2, device=lps[0].device, dtype=torch.float32) if want_grad else None
+    _chk(lib.styler_nll3(lps[0].data_ptr(), lps[1].data_ptr(), lps[2].data_ptr(), _ptr(lab), const, _ptr(loss),
+                         _ptr(gscale), _ptr(d3), B, _stream()), "styler_nll3")
+    return d3 if want_grad else loss
+
+
+def weighted_sum(terms, weights):
+    """sum_i weights[i] * terms[i] over scalar fp32 device tensors -> [1]."""
+    import ctypes
+    n = len(terms)
+    ptrs = (ctypes.c_void_p * n)(*[_f32(t).data_ptr() for t in terms])
+    w = (ctypes.c_float * n)(*[float(x) for x in weights])
+    out = torch.empty(1, device=terms[0].device, dtype=torch.float32)
+    _chk(lib.styler_weighted_sum(ptrs, w, n, out.data_ptr(), _stream()), "styler_weighted_sum")
+    return out
+
+
+def scale_weights(g, weights):
+    import ctypes
+    n = len(weights)
+    w = (ctypes.c_float * n)(*[float(x) for x in weights])
+    out = torch.empty(n, device=g.device, dtype=torch.float32)
+    _chk(lib.styler_scale_weights(_f32(g).data_ptr(), w, n, out.data_ptr(), _stream()), "styler_scale_weights")
+    return out
 
 
 def nll(logp, label, gscale=None, want_grad=False):

@@ -30,6 +30,8 @@ class _Runtime:
     # their own next to the dX chain (nothing in backward reads a weight gradient before the flush)
     wgrad_stream = os.environ.get("STYLER_WGRAD_STREAM", "0") == "1"
 
+    text_stream = os.environ.get("STYLER_TEXT_STREAM", "0") == "1"      # EXPERIMENT: text encoder on a side stream
+
     def set_precision(self, name):
         self.prec = {"fp32": ops.PREC_F32, "bf16": ops.PREC_BF16}[name]
 

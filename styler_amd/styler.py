@@ -3,6 +3,7 @@ return, `.decode`, attribute tree and state-dict layout; all arithmetic in libst
 import torch
 import torch.nn as nn
 
+from . import autograd as AG
 from . import hparams as hp
 from .modules import StyleModeling
 from .runtime import rt
@@ -44,8 +45,10 @@ class STYLER(_HipModule):
         lens = mel_len if mel_len is not None else self._lens_from_mask(mel_mask)
         B = out_clean.shape[0]
         mel2 = self._gemm("mel_linear", self.decoder.forward_pair(out_clean, out_noisy, lens), self.mel_linear)
+        halves = AG.SplitBatchFn.apply(mel2) if (self.training and torch.is_grad_enabled() and mel2.requires_grad) \
+            else (mel2[:B], mel2[B:])
         outs = []
-        for mel in (mel2[:B], mel2[B:]):
+        for mel in halves:
             outs.append((mel, self.postnet(mel, add_residual=mel) if self.use_postnet else mel))
         return outs
 

@@ -4,6 +4,7 @@ clip_grad_norm_(1.0) + Adam with the Noam schedule -- the last two fused over FL
 import torch
 
 from . import hparams as hp
+from . import autograd as AG
 from . import ops
 from .dist import BUCKET_BYTES, allreduce_sum_, world_size
 from .loss import DomainAdversarialTrainingLoss, STYLERLoss
@@ -161,6 +162,16 @@ class TrainState:
                 "allreduce_world": world_size()}
 
 
+_seed_cache = {}
+
+
+def _seed_grad(value, device):
+    key = (float(value), str(device))
+    if key not in _seed_cache:
+        _seed_cache[key] = torch.full((), float(value), device=device, dtype=torch.float32)
+    return _seed_cache[key]
+
+
 def train_losses(model, batch, loss_fn=None, dat_fn=None):
     """The ten scalars of one step (total first), train.py:135-160.  `batch` holds CUDA tensors."""
     loss_fn = loss_fn or STYLERLoss()
@@ -175,12 +186,13 @@ def train_losses(model, batch, loss_fn=None, dat_fn=None):
                 batch["src_len"], batch["mel_len"], batch["D"], batch["f0"], batch["energy"], S, T,
                 speaker_embed=batch["speaker_embed"])
     (mel, mel_n), (post, post_n), log_d, p_pred, e_pred, src_mask, mel_mask, _, aug = out
-    zeros = torch.zeros(B, dtype=torch.long, device=dev)
-    ones = torch.ones(B, dtype=torch.long, device=dev)
+    # labels of train.py:139,152 (zeros for the clean pass, ones for the DAT pass): passed as python ints, the NLL kernel
+    # needs no label tensor then; the masks are consumed as lengths (loss.py docstring), so no ~mask launches either
+    zeros, ones = 0, 1
     mel_l, post_l, d_l, p_l, e_l, cls = loss_fn(log_d, batch["log_D"], p_pred, batch["f0"], e_pred, batch["energy"],
-                                                mel, post, batch["mel_target"], ~src_mask, ~mel_mask,
+                                                mel, post, batch["mel_target"], None, None,
                                                 batch["src_len"], batch["mel_len"], aug, zeros)
-    mel_nl, post_nl = loss_fn.cal_mel_loss(mel_n, post_n, batch["mel_aug"], ~mel_mask, batch["mel_len"])
+    mel_nl, post_nl = loss_fn.cal_mel_loss(mel_n, post_n, batch["mel_aug"], None, batch["mel_len"])
     if se.dat_encodings is not None:                # the forward ran the DAT pass in the same AudioEncoder batch
         (d, p, e), se.dat_encodings = se.dat_encodings, None
     else:
@@ -190,7 +202,12 @@ def train_losses(model, batch, loss_fn=None, dat_fn=None):
     sm = model.style_modeling
     cls_dat = dat_fn((sm.augmentation_classifier_d(d), sm.augmentation_classifier_p(p),
                       sm.augmentation_classifier_e(e)), ones)
-    total = mel_l + post_l + mel_nl + post_nl + d_l + p_l + e_l + hp.dat_weight * (cls + cls_dat)
+    terms = (mel_l, post_l, mel_nl, post_nl, d_l, p_l, e_l, cls, cls_dat)
+    weights = (1.0,) * 7 + (float(hp.dat_weight),) * 2
+    if torch.is_grad_enabled() and any(t.requires_grad for t in terms):
+        total = AG.WeightedSumFn.apply(weights, *terms)             # train.py:156-160 in one launch (and one in backward)
+    else:
+        total = ops.weighted_sum([t.reshape(1) for t in terms], weights).view(())
     return total, mel_l, post_l, mel_nl, post_nl, d_l, p_l, e_l, cls, cls_dat
 
 
@@ -210,7 +227,8 @@ def forward_backward(model, state, batch, loss_fn=None, dat_fn=None):
         rt.grad_ready_hook = state.split_hook or (state.on_decoder_grads_ready if state.overlap_allreduce else None)
         state.arena.begin(state.flat_g.device)
         ops.wgrad_arena = state.arena
-        (losses[0] / hp.acc_steps).backward()
+        # loss / acc_steps (train.py:175) as the seed gradient of backward: no division kernel, no ones_like
+        losses[0].backward(gradient=_seed_grad(1.0 / hp.acc_steps, losses[0].device))
         state.arena.flush(state.flat_g.device)         # one launch folds all split-K partials into flat_g
     finally:
         rt.grad_ready_hook = None

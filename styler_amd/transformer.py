@@ -261,8 +261,6 @@ class PostNet(_HipModule):
                     p = 0.0 if rt.disable_dropout else 0.5
                     y, _, _ = ops.batchnorm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, act,
                                                   drop_p=p, drop_seed=AG.next_dropout_seed() if p > 0 else 0)
-                with torch.no_grad():
-                    bn.num_batches_tracked += 1
                 if last and add_residual is not None:
                     y = AG.Add2Fn.apply(y, add_residual) if (self.training and torch.is_grad_enabled()) else ops.add2(y, add_residual)
                 x = y
@@ -272,4 +270,7 @@ class PostNet(_HipModule):
                     lambda g, b, rm, rv, cb: ops.bn_fold(g, b, rm, rv, cb))
                 x = self._gemm(f"c{i}", x, conv, kw=self.kernel_size, act=act, scale=scale, shift=shift,
                                res=add_residual if last else None)
+        if self.training:                                  # BatchNorm1d bookkeeping: one multi-tensor launch per call
+            with torch.no_grad():
+                torch._foreach_add_([seq[1].num_batches_tracked for seq in self.convolutions], 1)
         return x
