@@ -34,6 +34,10 @@ extern "C" {
 #define STYLER_ACT_TANH 2
 #define STYLER_ACT_LOGCLAMP 3 /* log(max(v, 1e-5)): dynamic_range_compression, audio_processing.py:80-86 */
 #define STYLER_ACT_LEAKY 4    /* v > 0 ? v : 0.1 v: LRELU_SLOPE of the vocoder, hifigan/models.py:7,97 */
+#define STYLER_ACT_CRELU 5    /* min(max(v, 0), 20): DeepSpeaker's clipped ReLU, deepspeaker/conv_models.py:83-86 */
+/* OR-ed into `act`: the residual input joins BEFORE scale / shift / activation, y = act(scale * (acc + res) + shift)
+ * -- the last call of a convolution that is summed over several GEMM calls (2-D taps of the ResCNN, conv_models.py) */
+#define STYLER_ACT_RES_FIRST 0x100
 
 /* io_flags of styler_conv_gemm[_packed] / styler_wgrad[_packed] (throughput mode only): the tensor behind the float
  * pointer is bf16 (row strides stay in ELEMENTS).  Used for the FFN hidden activation and its gradient, which are only
@@ -321,6 +325,46 @@ int64_t styler_stft_mel_workspace_bytes(int B, int N);
 int styler_stft_mel(const float* wav, int64_t ldw, const void* basis, const float* mel_basis,
                     float* mag, float* mel, float* energy, void* workspace, int32_t* err_flag,
                     int B, int N, int prec, void* stream);
+/* The same for a RAGGED batch (BASELINE config 5: utterances of 3-4 s in one batch): item b holds wav_len[b] <= N
+ * samples (int64 [B], device; NULL = all N).  Each item is reflected at ITS end and transformed as if alone
+ * (audio/tools.py:37-55 handles one utterance per call); frame_len[b] = 1 + wav_len[b] / 256 is written back (int64
+ * [B]) and frames at or past it are zeros in mel / energy / mag / e_scaled (the collate's padding, utils.py:296-329).
+ * e_scaled (optional, [B, F]) = clip((energy - e_min) / (e_max - e_min), 0, 1): utils.energy_rescaling
+ * (utils.py:410-414), the model's `e_input`. */
+int styler_stft_mel_varlen(const float* wav, int64_t ldw, const int64_t* wav_len, const void* basis,
+                           const float* mel_basis, float* mag, float* mel, float* energy, float* e_scaled,
+                           float e_min, float e_max, int64_t* frame_len, void* workspace, int32_t* err_flag,
+                           int B, int N, int prec, void* stream);
+
+/* ---- DeepSpeaker ResCNN speaker embedding (deepspeaker/audio_ds.py, batcher.py, conv_models.py) --------
+ * The reference computes it in TensorFlow from `python_speech_features.fbank` features; neither dependency nor the
+ * pretrained weights exist here (parity unpinned).  Every Conv2D except the first, the framing DFT, the mel
+ * projection and the Dense layer are calls of styler_conv_gemm_pad; these are the kernels in between.
+ *
+ * styler_ds_vad_bounds: read_mfcc's silence trim (audio_ds.py:36-41): bounds[b] = (offsets[0], offsets[-1]) of the samples
+ *   with |x| > np.percentile(|x|, 95) (exact order statistics, linear interpolation); wav_len (int64 [B], optional) gives
+ *   each utterance's own length; thr_out (optional) receives the thresholds.
+ * styler_ds_fbank: pre-emphasis 0.97, 551-sample rectangular frames every 221 samples, |rfft_1024|^2 / 1024, 64 HTK-mel
+ *   filters, zero -> eps, per-frame (v - mean) / max(std, 1e-12) (mfcc_fbank / normalize_frames, audio_ds.py:128-139), for
+ *   the 160-frame window starting at frame0[b] (crop_mode 0; batcher.py:23-29 draws it at random) or centred (crop_mode 1);
+ *   frames past the utterance's own count are zero (pad_mfcc).  out: [B, 160, 64].  basis [1028, 672], fb [64, 516].
+ * styler_ds_conv1: Conv2D(1 -> 64, 5x5, stride 2, TF 'same': pad 1 before / 2 after) + folded BatchNorm + clipped ReLU:
+ *   x [B, H, W] -> y [B, H/2 + 3, W/2, 64] with rows 1..H/2 live (the H-padded layout of the ResCNN activations).
+ * styler_ds_rows: dst [B, Hd + 3, W, C] <- src [B, Hsp, W, C]: dst row 1 + h = src row src_row0 + h * step, padding rows
+ *   (0, Hd + 1, Hd + 2) zeroed; src == dst (step 1, src_row0 1): only the padding rows are rewritten.
+ * styler_ds_crelu_add: out = min(max(a + b, 0), 20) (identity_block, conv_models.py:88-118).
+ * styler_l2_normalize_rows: K.l2_normalize(y, axis = 1) (conv_models.py:64). */
+int styler_ds_vad_bounds(const float* wav, int64_t ldw, const int64_t* wav_len, int B, int N, int64_t* bounds,
+                         float* thr_out, void* stream);
+int64_t styler_ds_fbank_workspace_bytes(int B);
+int styler_ds_fbank(const float* wav, int64_t ldw, const int64_t* bounds, const int64_t* frame0, int crop_mode,
+                    const void* basis, const float* fb, float* out, void* workspace, int B, int prec, void* stream);
+int styler_ds_conv1(const float* x, const float* w, const float* scale, const float* shift, float* y, int B, int H,
+                    int W, void* stream);
+int styler_ds_rows(const float* src, float* dst, int B, int Hd, int Hsp, int W, int C, int src_row0, int step,
+                   void* stream);
+int styler_ds_crelu_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+int styler_l2_normalize_rows(const float* x, float* y, int rows, int C, void* stream);
 
 /* ==== backward / training entry points ==================================================
  * Parameter gradients are ACCUMULATED (atomicAdd) into fp32 buffers in the PARAMETER layout

@@ -84,6 +84,14 @@ _SIGS = {
     "styler_adam_step": [P, P, P, P, I64, P, F, F, F, F, F, I, F, P],
     "styler_stft_mel_workspace_bytes": [I, I],
     "styler_stft_mel": [P, I64, P, P, P, P, P, P, P, I, I, I, P],
+    "styler_ds_vad_bounds": [P, I64, P, I, I, P, P, P],
+    "styler_ds_fbank_workspace_bytes": [I],
+    "styler_ds_fbank": [P, I64, P, P, I, P, P, P, P, I, I, P],
+    "styler_ds_conv1": [P, P, P, P, P, I, I, I, P],
+    "styler_ds_rows": [P, P, I, I, I, I, I, I, I, P],
+    "styler_ds_crelu_add": [P, P, P, I64, P],
+    "styler_l2_normalize_rows": [P, P, I, I, P],
+    "styler_stft_mel_varlen": [P, I64, P, P, P, P, P, P, P, F, F, P, P, P, I, I, I, P],
 }
 
 

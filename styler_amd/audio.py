@@ -86,23 +86,44 @@ class TacotronSTFT(nn.Module):
 
     def mel_spectrogram_cl(self, y, want_mag=False):
         """y [B, N] fp32 on the GPU -> (mel [B, T, 80], energy [B, T][, mag [B, T, 513] view])."""
+        out = self._run(y, None, want_mag, False)
+        return (out["mel"], out["energy"], out["mag"]) if want_mag else (out["mel"], out["energy"])
+
+    def _run(self, y, wav_len, want_mag, want_e_input):
         if not y.is_cuda:
             raise RuntimeError("styler_amd.audio runs on the MI355X HIP path only (no CPU fallback)")
         B, N = y.shape
         F = 1 + N // 256
-        basis, melb = self._pack(y.device, rt.prec)
-        ws = torch.empty(int(lib.styler_stft_mel_workspace_bytes(B, N)), device=y.device, dtype=torch.uint8)
-        mel = torch.empty(B, F, 80, device=y.device, dtype=torch.float32)
-        energy = torch.empty(B, F, device=y.device, dtype=torch.float32)
-        mag = torch.empty(B, F, 516, device=y.device, dtype=torch.float32) if want_mag else None
-        err = torch.zeros(1, device=y.device, dtype=torch.int32) if rt.strict_inputs else None
+        dev = y.device
+        basis, melb = self._pack(dev, rt.prec)
+        ws = torch.empty(int(lib.styler_stft_mel_workspace_bytes(B, N)), device=dev, dtype=torch.uint8)
+        mel = torch.empty(B, F, 80, device=dev, dtype=torch.float32)
+        energy = torch.empty(B, F, device=dev, dtype=torch.float32)
+        mag = torch.empty(B, F, 516, device=dev, dtype=torch.float32) if want_mag else None
+        e_in = torch.empty(B, F, device=dev, dtype=torch.float32) if want_e_input else None
+        flen = torch.empty(B, device=dev, dtype=torch.int64) if wav_len is not None else None
+        err = torch.zeros(1, device=dev, dtype=torch.int32) if rt.strict_inputs else None
         y = y if y.stride(1) == 1 else y.contiguous()
-        ops._chk(lib.styler_stft_mel(y.data_ptr(), y.stride(0), basis.data_ptr(), melb.data_ptr(), ops._ptr(mag),
-                                     mel.data_ptr(), energy.data_ptr(), ws.data_ptr(), ops._ptr(err), B, N,
-                                     rt.prec, ops._stream()), "styler_stft_mel")
+        if wav_len is not None:
+            assert wav_len.dtype == torch.int64 and wav_len.is_cuda and wav_len.is_contiguous() and wav_len.numel() == B
+        ops._chk(lib.styler_stft_mel_varlen(y.data_ptr(), y.stride(0), ops._ptr(wav_len), basis.data_ptr(), melb.data_ptr(),
+                                            ops._ptr(mag), mel.data_ptr(), energy.data_ptr(), ops._ptr(e_in),
+                                            float(hp.energy_min), float(hp.energy_max), ops._ptr(flen), ws.data_ptr(),
+                                            ops._ptr(err), B, N, rt.prec, ops._stream()), "styler_stft_mel_varlen")
         if err is not None and int(err.item()) != 0:
             raise AssertionError("mel_spectrogram: wav outside [-1, 1] (stft.py:151-152)")
-        return (mel, energy, mag[..., :513]) if want_mag else (mel, energy)
+        return {"mel": mel, "energy": energy, "mag": mag[..., :513] if want_mag else None, "e_input": e_in, "mel_len": flen}
+
+    def features(self, wavs, wav_len=None):
+        """A (ragged) batch of utterances -> what `STYLER.forward` consumes from the audio side (BASELINE config 5):
+        wavs [B, N_max] in [-1, 1], wav_len int64 [B] on the device (None: all N_max) ->
+        dict(mel [B, T, 80], energy [B, T], e_input [B, T] = utils.energy_rescaling(energy), mel_len int64 [B]).
+        Every item is transformed as if alone (tools.py:37-55), frames past its end are zero padding."""
+        out = self._run(wavs, wav_len, False, True)
+        if out["mel_len"] is None:
+            out["mel_len"] = torch.full((wavs.shape[0],), 1 + wavs.shape[1] // 256, device=wavs.device, dtype=torch.int64)
+        out.pop("mag")
+        return out
 
     def mel_spectrogram(self, y):
         """Reference layout: (mel [B, 80, T], energy [B, T])."""

@@ -58,6 +58,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == STYLER_ACT_TANH) return tanhf(v);
   if (act == STYLER_ACT_LOGCLAMP) return logf(fmaxf(v, 1e-5f));
   if (act == STYLER_ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
+  if (act == STYLER_ACT_CRELU) return fminf(fmaxf(v, 0.f), 20.f);
   return v;
 }
 

@@ -345,8 +345,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
         const int64_t row = m0 + wm * 32 * TM + hh * ROWS_H + rl;
         if (row >= M) break;
         float4 v = *reinterpret_cast<const float4*>(&cst[rl * CLD + c4]);
-        v.x = apply_act(v.x * sc.x + sf.x, a.act); v.y = apply_act(v.y * sc.y + sf.y, a.act);
-        v.z = apply_act(v.z * sc.z + sf.z, a.act); v.w = apply_act(v.w * sc.w + sf.w, a.act);
+        const bool res_first = a.act & STYLER_ACT_RES_FIRST;
+        const int actc = a.act & 0xff;
+        if (res_first && a.res) {                     // partial sums of a multi-call convolution: joined before the tail
+          const float4 rr = *reinterpret_cast<const float4*>(a.res + row * a.ldres + col);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        v.x = apply_act(v.x * sc.x + sf.x, actc); v.y = apply_act(v.y * sc.y + sf.y, actc);
+        v.z = apply_act(v.z * sc.z + sf.z, actc); v.w = apply_act(v.w * sc.w + sf.w, actc);
         if (a.mask) {                                 // dX of a ReLU layer: gradient only where the forward output was > 0
           if (a.mask16) {                             // bf16 mask: positive <=> sign clear and magnitude non-zero
             const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(a.mask) + row * a.ldmask + col);
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
             v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
           }
         }
-        if (a.res) {
+        if (a.res && !res_first) {
           const float4 rr = *reinterpret_cast<const float4*>(a.res + row * a.ldres + col);
           v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }

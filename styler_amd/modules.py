@@ -190,9 +190,9 @@ class StyleEncoder(_HipModule):
                 text_out=None):
         side = None
         if rt.text_stream and self.training and torch.is_grad_enabled():
-            # EXPERIMENT: the text encoder (two FFT blocks on [B, S] rows: ~40 launch-latency-bound kernels) on a side
-            # stream next to the AudioEncoder's T-domain convolutions; autograd replays each node's backward on its
-            # forward stream, so the two backward chains overlap the same way
+            # the text encoder (two FFT blocks on [B, S] rows: ~40 launch-latency-bound kernels) on a side stream next to
+            # the AudioEncoder's T-domain convolutions; autograd replays each node's backward on its forward stream, so
+            # the two backward chains overlap the same way (rt.text_stream)
             main = torch.cuda.current_stream()
             side = self.__dict__.setdefault("_text_stream", torch.cuda.Stream(device=text.device))
             side.wait_stream(main)

@@ -366,7 +366,11 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
     return out
 
 
-def conv_gemm_pad(x, w, bias=None, *, kw, pad, act=ACT_NONE, prec=PREC_F32, res=None, out=None):
+ACT_CRELU = 5                      # min(max(v, 0), 20): DeepSpeaker's clipped ReLU
+ACT_RES_FIRST = 0x100              # y = act(scale * (acc + res) + shift): last call of a conv summed over several calls
+
+
+def conv_gemm_pad(x, w, bias=None, *, kw, pad, act=ACT_NONE, prec=PREC_F32, res=None, out=None, scale=None):
     """y = act(sum_j x[t + j - pad] w[:, j, :] + bias) (+ res) with an explicit left padding and any kw <= 9; x, res and
     out may be strided row views ([B, L, C] with row stride d*C: the phase views of a dilated conv)."""
     B, L, cin = x.shape
@@ -376,7 +380,7 @@ def conv_gemm_pad(x, w, bias=None, *, kw, pad, act=ACT_NONE, prec=PREC_F32, res=
     _f32(x), _f32(out)
     if prec == PREC_BF16 and w.dtype != torch.bfloat16:
         raise StylerHipError("bf16 GEMM needs a bf16 weight shadow")
-    _chk(lib.styler_conv_gemm_pad(x.data_ptr(), _ld(x), w.data_ptr(), None, _ptr(bias), _ptr(res),
+    _chk(lib.styler_conv_gemm_pad(x.data_ptr(), _ld(x), w.data_ptr(), _ptr(scale), _ptr(bias), _ptr(res),
                                   _ld(res) if res is not None else 0, out.data_ptr(), _ld(out), B, L, cin, n, kw, pad,
                                   act, prec, _stream()), "styler_conv_gemm_pad")
     return out

@@ -223,3 +223,29 @@ def test_predict_inference(golden, ref_state_dict):
                 assert np.array_equal(v.numpy(), g[f"{tag}_{n}"])
             else:
                 close(v, g[f"{tag}_{n}"], 2e-5)
+
+
+def test_deepspeaker_restatement_sanity():
+    """oracle/deepspeaker_oracle.py is self-consistent only (PARITY UNPINNED: TensorFlow / python_speech_features / weights
+    absent).  What can be checked without them: the published structure of the python_speech_features filterbank, the
+    framing arithmetic, and the shapes / normalisation of the ResCNN."""
+    import numpy as np
+    import torch
+    from oracle import deepspeaker_oracle as D
+    fb = D.get_filterbanks()
+    assert fb.shape == (64, 513) and fb.min() >= 0 and fb.max() <= 1
+    peaks = fb.argmax(axis=1)
+    assert (np.diff(peaks) > 0).all() and peaks[0] >= 1 and peaks[-1] < 513        # triangular filters, increasing centres
+    assert D.round_half_up(0.025 * 22050) == 551 and D.round_half_up(0.010 * 22050) == 221
+    sig = np.random.RandomState(0).randn(22050).astype(np.float32)
+    feat, energy = D.fbank(sig)
+    assert feat.shape == (1 + int(np.ceil((22050 - 551) / 221)), 64) and (feat > 0).all()
+    mf = D.mfcc_fbank(sig)
+    assert np.abs(mf.mean(axis=1)).max() < 1e-4 and np.abs(mf.std(axis=1) - 1).max() < 1e-3
+    g = torch.Generator().manual_seed(0)
+    P = {k: (torch.rand(s, generator=g) * 0.2 + (0.9 if k.endswith(("gamma", "moving_variance")) else -0.1))
+         for k, s in D.layer_shapes().items()}
+    e = D.rescnn(P, torch.randn(2, 160, 64, generator=g))
+    assert e.shape == (2, 512) and float((e.norm(dim=1) - 1).abs().max()) < 1e-5
+    s, t = D.vad_bounds(np.concatenate([np.zeros(100), np.ones(50), np.zeros(100)]).astype(np.float32))
+    assert (s, t) == (0, 0) or s >= 100                                            # only the burst can exceed the percentile
