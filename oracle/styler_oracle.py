@@ -507,13 +507,16 @@ def dat_pass(P: Params, mel_aug, p_norm_aug, e_input_aug, mel_len, src_len):
             aug_classifier(P, "style_modeling.augmentation_classifier_e", e))
 
 
-def train_losses(P: Params, batch: Dict[str, Tensor], training=True):
-    """train.py:135-160: the ten scalars of one step (total first)."""
+def train_losses(P: Params, batch: Dict[str, Tensor], training=True, max_mel_len=None):
+    """train.py:135-160: the ten scalars of one step (total first).  `max_mel_len`: the padded mel extent when the batch
+    was collated to more than its own maximum (train.py:132 passes np.max(mel_len); a collate that pads further passes its
+    own extent -- the tensors must be padded to it)."""
     B = batch["text"].shape[0]
     out = styler_forward(P, batch["text"], batch["mel_target"], batch["mel_aug"],
                          batch["f0_norm"], batch["energy_input"], batch["src_len"],
                          batch["mel_len"], batch["D"], batch["f0"], batch["energy"],
-                         int(batch["src_len"].max()), int(batch["mel_len"].max()),
+                         int(batch["src_len"].max()),
+                         int(batch["mel_len"].max()) if max_mel_len is None else int(max_mel_len),
                          speaker_embed=batch["speaker_embed"], training=training)
     (mel, mel_n), (post, post_n), log_d, p_pred, e_pred, src_pad, mel_pad, _, aug = out
     zeros = torch.zeros(B, dtype=torch.long)

@@ -57,9 +57,38 @@ def collate_fn(batch, sort=True):
 _DTYPES = {"text": torch.long, "D": torch.long, "src_len": torch.long, "mel_len": torch.long}
 
 
-def to_device(sub_batch, device, pinned=True):
+def bucket_up(n, step, cap=hp.max_seq_len + 1):
+    """Smallest multiple of `step` >= n, capped at the position table (train mode forbids L > 1001, Models.py:124-125)."""
+    if step <= 1:
+        return n
+    return min(-(-n // step) * step, max(cap, n))
+
+
+def pad_to_rectangle(sub_batch, S, T):
+    """Zero-pad a collated sub-batch up to max_src_len = S, max_mel_len = T (the collate's own padding value, utils.py:
+    296-329); lengths are untouched, so every mask / loss sees the same valid positions."""
+    out = dict(sub_batch)
+    for k in _KEYS_1D + ("log_D",):
+        v = np.asarray(sub_batch[k])
+        want = S if k in ("text", "D", "log_D") else T
+        if v.shape[1] < want:
+            out[k] = np.pad(v, ((0, 0), (0, want - v.shape[1])), mode="constant")
+    for k in _KEYS_2D:
+        v = np.asarray(sub_batch[k])
+        if v.shape[1] < T:
+            out[k] = np.pad(v, ((0, 0), (0, T - v.shape[1]), (0, 0)), mode="constant")
+    return out
+
+
+def to_device(sub_batch, device, pinned=True, bucket=None):
     """train.py:107-132 in one shot: numpy -> pinned host tensors -> non-blocking H2D on the current stream.
-    Returns (tensors dict, max_src_len, max_mel_len)."""
+    Returns (tensors dict, max_src_len, max_mel_len).  `bucket` = (s_step, t_step): pad the rectangle up to multiples of
+    the steps, so that a few hipGraphs (training.GraphedStepCache) cover every batch of an epoch; the returned maxima are
+    the PADDED extents (what `STYLER.forward` must be given as max_src_len / max_mel_len)."""
+    S, T = int(np.max(sub_batch["src_len"])), int(np.max(sub_batch["mel_len"]))
+    if bucket is not None:
+        S, T = bucket_up(S, bucket[0]), bucket_up(T, bucket[1])
+        sub_batch = pad_to_rectangle(sub_batch, S, T)
     out = {}
     for k, v in sub_batch.items():
         if k == "id":
@@ -68,7 +97,7 @@ def to_device(sub_batch, device, pinned=True):
         if pinned and torch.cuda.is_available():
             t = t.pin_memory()
         out[k] = t.to(device, non_blocking=True)
-    return out, int(np.max(sub_batch["src_len"])), int(np.max(sub_batch["mel_len"]))
+    return out, S, T
 
 
 # ---- feature store + prefetching feeder --------------------------------------------------------------------------------
@@ -127,10 +156,14 @@ class BatchFeeder:
     sub-batches ahead and stages them through pinned memory on a copy stream, so the consumer never waits on `np.load`,
     padding or the H2D copies.  Iterating yields `(tensors, max_src_len, max_mel_len)` like `to_device`."""
 
-    def __init__(self, store, device, batch_size=None, rank=0, world=1, shuffle=True, seed=0, depth=4):
+    def __init__(self, store, device, batch_size=None, rank=0, world=1, shuffle=True, seed=0, depth=4, bucket=None):
         self.store, self.device = store, torch.device(device)
         self.batch_size = hp.batch_size if batch_size is None else batch_size
         self.rank, self.world, self.shuffle, self.seed, self.depth = rank, world, shuffle, seed, depth
+        # (s_step, t_step): pad every sub-batch up to multiples of these (None: the reference's exact maxima).  The real feed
+        # yields a different (S, T) for nearly every sub-batch; a graphed step is captured per shape, so without buckets it
+        # would be captured once and never replayed (training.GraphedStepCache)
+        self.bucket = bucket
         self.epoch = 0
 
     def groups(self):
@@ -154,11 +187,11 @@ class BatchFeeder:
                         return
                     if use_cuda:
                         with torch.cuda.stream(copy_stream):
-                            out = to_device(sub, self.device, pinned=True)
+                            out = to_device(sub, self.device, pinned=True, bucket=self.bucket)
                             ready = torch.cuda.Event()
                             ready.record(copy_stream)
                     else:
-                        out, ready = to_device(sub, self.device, pinned=False), None
+                        out, ready = to_device(sub, self.device, pinned=False, bucket=self.bucket), None
                     q.put((out, ready))
             q.put(None)
         except BaseException as e:                     # surface reader errors in the consumer

@@ -379,3 +379,41 @@ class GraphedTrainStep:
             self.graphs[1].replay()
         lr = st.step()
         return self.losses, lr
+
+
+class GraphedStepCache:
+    """One `GraphedTrainStep` per padded batch shape, least-recently-used eviction.
+
+    The graphed step is captured for fixed tensor shapes, while the reference's feed (dataset.py:188-207) pads every
+    sub-batch to its own maxima: fed as is, nearly every step would be a capture (seconds) instead of a replay.  With the
+    feeder's `bucket=(s_step, t_step)` option the rectangles fall on a small grid and this cache replays one graph per grid
+    cell.  Constructing an instance has no side effects on the training state (GraphedTrainStep._warmup), so a miss costs
+    time only.  With several ranks every rank owns its own cache; nothing collective happens at construction.
+
+    What padding up changes: the valid positions, masks and losses are identical; the statistics that the reference takes
+    over the padded rectangle (GroupNorm over padded T, PostNet BatchNorm over padded rows, the unpacked BiLSTMs, the
+    classifier's time mean -- SURVEY 8c trap 1) see the extra zero rows exactly as they see those of a longer co-batched
+    utterance: the result equals the reference run on the same padded rectangle (tests/test_hip_backward.py)."""
+
+    def __init__(self, model, state, max_graphs=24, **kw):
+        from collections import OrderedDict
+        self.model, self.state, self.max_graphs, self.kw = model, state, max_graphs, kw
+        self.steps = OrderedDict()
+        self.hits = self.misses = 0
+
+    @staticmethod
+    def key(batch):
+        return tuple(batch["text"].shape) + (batch["mel_target"].shape[1],)
+
+    def __call__(self, batch):
+        k = self.key(batch)
+        step = self.steps.get(k)
+        if step is None:
+            self.misses += 1
+            while len(self.steps) >= self.max_graphs:
+                self.steps.popitem(last=False)                       # frees the evicted graph's memory pool
+            step = self.steps[k] = GraphedTrainStep(self.model, self.state, batch, **self.kw)
+        else:
+            self.hits += 1
+            self.steps.move_to_end(k)
+        return step(batch)

@@ -537,6 +537,87 @@ def test_acc_steps_gate(dev, ref_state_dict, monkeypatch):
         rt.disable_dropout = False
 
 
+def test_bucketed_batches_oracle_on_same_rectangle_and_graph_cache(dev, ref_state_dict):
+    """A batch padded up to a shape bucket (data.to_device(bucket=...)): (1) the ten losses and sampled gradients equal the
+    oracle run on the SAME padded rectangle (T padding is expressible in the reference: its collate pads, train.py:132
+    passes the extent); (2) two batches with different exact shapes that fall into one bucket replay ONE captured graph
+    (GraphedStepCache) and walk the same trajectory as eager steps on the same padded tensors."""
+    from closed_form import make_batch
+    from oracle import styler_oracle as O
+    from styler_amd import STYLER, rt
+    from styler_amd.training import GraphedStepCache, TrainState, train_losses, train_step
+
+    def pad_t(b, T):
+        out = dict(b)
+        for k in ("mel_target", "mel_aug", "f0", "f0_norm", "f0_norm_aug", "energy", "energy_input", "energy_input_aug"):
+            v = b[k]
+            out[k] = torch.cat([v, v.new_zeros(v.shape[0], T - v.shape[1], *v.shape[2:])], dim=1)
+        return out
+
+    def pad_s(b, S):
+        out = dict(b)
+        for k in ("text", "D", "log_D"):
+            v = b[k]
+            out[k] = torch.cat([v, v.new_zeros(v.shape[0], S - v.shape[1])], dim=1)
+        return out
+
+    rt.disable_dropout = True
+    try:
+        b1 = make_batch(4, 16, 30, 2, 9, seed=51)
+        T1 = b1["mel_target"].shape[1]
+        Tb = -(-T1 // 64) * 64
+        assert Tb > T1
+        p1 = pad_t(b1, Tb)
+        P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "position_enc" not in k and "_bins" not in k
+                 and "running_" not in k else v.clone()) for k, v in ref_state_dict.items()}
+        ref = O.train_losses(P, p1, training="bn_only", max_mel_len=Tb)
+        ref[0].backward()
+        m = STYLER()
+        m.load_state_dict(ref_state_dict)
+        m = m.to(dev).train()
+        losses = train_losses(m, {k: v.to(dev) for k, v in p1.items()})
+        for a, e in zip(losses, ref):
+            assert abs(float(a) - float(e)) <= 2e-3 * max(1.0, abs(float(e))), (float(a), float(e))
+        losses[0].backward()
+        for k in ("decoder.layer_stack.0.slf_attn.w_qs.weight", "postnet.convolutions.2.0.conv.weight",
+                  "style_modeling.style_encoder.audio_encoder.convolutions_2.1.0.conv.weight",
+                  "style_modeling.pitch_embedding.weight"):
+            g, r = dict(m.named_parameters())[k].grad.cpu(), P[k].grad
+            assert float((g - r).abs().max()) <= 1e-2 * float(r.abs().max()), k
+        # and the exact-shape batch gives (slightly) different losses: the padded statistics are part of the model
+        exact = O.train_losses({k: v.detach() for k, v in P.items()}, b1, training="bn_only")
+        assert abs(float(exact[0]) - float(ref[0])) > 0
+
+        # ---- graph cache: two exact shapes, one bucket, one capture ----
+        b2 = make_batch(4, 16, 30, 2, 9, seed=52)
+        Sb = max(b1["text"].shape[1], b2["text"].shape[1])
+        Tb = -(-max(T1, b2["mel_target"].shape[1]) // 64) * 64
+        q1 = {k: v.to(dev) for k, v in pad_s(pad_t(b1, Tb), Sb).items()}
+        q2 = {k: v.to(dev) for k, v in pad_s(pad_t(b2, Tb), Sb).items()}
+        finals = []
+        for mode in ("eager", "cache"):
+            m = STYLER()
+            m.load_state_dict(ref_state_dict)
+            m = m.to(dev).train()
+            st = TrainState(m)
+            if mode == "eager":
+                for q in (q1, q2, q1):
+                    losses, lr = train_step(m, st, q)
+            else:
+                cache = GraphedStepCache(m, st, max_graphs=2)
+                for q in (q1, q2, q1):
+                    losses, lr = cache(q)
+                assert (cache.misses, cache.hits, len(cache.steps)) == (1, 2, 1)
+            finals.append((torch.stack([x.detach().float().reshape(()) for x in losses]).cpu(), st.flat_p.clone(), lr))
+            st.close()
+        (l_e, p_e, lr_e), (l_c, p_c, lr_c) = finals
+        assert lr_e == lr_c
+        assert float((l_e - l_c).abs().max()) <= 2e-4 * max(1.0, float(l_e.abs().max())), (l_e, l_c)
+        assert float((p_e - p_c).abs().max()) <= 1e-4
+    finally:
+        rt.disable_dropout = False
+
+
 def test_graphed_train_step_matches_eager(dev, ref_state_dict):
     """forward + losses + backward replayed from one hipGraph (GraphedTrainStep) must walk the same trajectory as the
     eager step: same losses and same parameters after the same number of optimiser steps (dropout off: the two modes

@@ -883,3 +883,84 @@ def test_decode_entry_point_vs_oracle(dev, model, O, ref_state_dict):
     check(mel_a, ref[0], 1e-4, "decode_pair mel (clean slot)")
     check(post_b, ref2[1], 1e-3, "decode_pair postnet (noisy slot)")
     check(mel_b, ref2[0], 1e-4, "decode_pair mel (noisy slot)")
+
+
+@pytest.mark.gpu
+def test_torch_library_ops(dev):
+    """The `torch.library` registrations (styler_amd/torch_ops.py): dispatcher-visible ops with autograd, against
+    stock PyTorch math in fp64 on the CPU (forward and gradients)."""
+    import torch.nn.functional as F
+    import styler_amd.torch_ops  # noqa: F401  (registers torch.ops.styler.*)
+    g = torch.Generator().manual_seed(21)
+    # ---- conv_gemm: Conv1d(k = 5) + ReLU and a Linear, with gradients ----
+    for shape_w, act in (((96, 64, 5), 1), ((48, 64), 0)):
+        x = torch.randn(3, 29, 64, generator=g, dtype=torch.float64, requires_grad=True)
+        w = (torch.randn(*shape_w, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+        b = torch.randn(shape_w[0], generator=g, dtype=torch.float64, requires_grad=True)
+        if len(shape_w) == 3:
+            ref = F.conv1d(x.transpose(1, 2), w, b, padding=2).transpose(1, 2)
+        else:
+            ref = x @ w.t() + b
+        ref = torch.relu(ref) if act else ref
+        gy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+        ref.backward(gy)
+        xd, wd, bd = (t.detach().float().to(dev).requires_grad_(True) for t in (x, w, b))
+        y = torch.ops.styler.conv_gemm(xd, wd, bd, act, 0)
+        check(y, ref, 1e-5, "styler::conv_gemm")
+        y.backward(gy.float().to(dev))
+        check(xd.grad, x.grad, 2e-5, "conv_gemm dx")
+        check(wd.grad, w.grad, 2e-5, "conv_gemm dw")
+        check(bd.grad, b.grad, 2e-5, "conv_gemm db")
+    # ---- attention ----
+    lens = torch.tensor([23, 40])
+    qkv = torch.randn(2, 40, 768, generator=g, dtype=torch.float64, requires_grad=True)
+    q, k, v = (t.view(2, 40, 4, 64).transpose(1, 2) for t in qkv.split(256, dim=-1))
+    sc = q @ k.transpose(-1, -2) / 8.0
+    sc = sc.masked_fill((torch.arange(40)[None] >= lens[:, None])[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(sc, dim=-1) @ v).transpose(1, 2).reshape(2, 40, 256)
+    valid = (torch.arange(40)[None] < lens[:, None])[..., None].double()
+    gy = torch.randn(2, 40, 256, generator=g, dtype=torch.float64) * valid      # padded query rows carry no gradient
+    (ref * 1.0).backward(gy)
+    qd = qkv.detach().float().to(dev).requires_grad_(True)
+    out, lse = torch.ops.styler.attention(qd, lens.to(dev), 0)
+    assert float(((out.detach().cpu().double() - ref.detach()) * valid).abs().max()) <= 1e-5
+    out.backward(gy.float().to(dev))
+    check(qd.grad, qkv.grad, 2e-4, "attention dqkv")               # padded rows: zero in both (masked keys, zero dout)
+    # ---- add_layernorm ----
+    x = torch.randn(2, 17, 256, generator=g, dtype=torch.float64, requires_grad=True)
+    r = torch.randn(2, 17, 256, generator=g, dtype=torch.float64, requires_grad=True)
+    ga = (1 + 0.1 * torch.randn(256, generator=g, dtype=torch.float64)).requires_grad_(True)
+    be = (0.1 * torch.randn(256, generator=g, dtype=torch.float64)).requires_grad_(True)
+    ln_len = torch.tensor([17, 9])
+    keep = (torch.arange(17)[None] < ln_len[:, None])[..., None].double()
+    ref = F.layer_norm(x + r, (256,), ga, be) * keep
+    gy = torch.randn(2, 17, 256, generator=g, dtype=torch.float64)
+    ref.backward(gy)
+    xd, rd, gd, bd = (t.detach().float().to(dev).requires_grad_(True) for t in (x, r, ga, be))
+    y, _ = torch.ops.styler.add_layernorm(xd, rd, gd, bd, ln_len.to(dev))
+    check(y, ref, 1e-5, "styler::add_layernorm")
+    y.backward(gy.float().to(dev))
+    check(xd.grad, x.grad, 2e-5, "add_layernorm dx")
+    check(rd.grad, r.grad, 2e-5, "add_layernorm dres")
+    check(gd.grad, ga.grad, 2e-5, "add_layernorm dgamma")
+    # ---- length_regulate ----
+    x = torch.randn(2, 6, 64, generator=g, dtype=torch.float64, requires_grad=True)
+    d = torch.tensor([[2, 0, 3, 1, 4, 1], [1, 1, 1, 0, 0, 0]])
+    T_ = 13
+    ref = torch.zeros(2, T_, 64, dtype=torch.float64)
+    rows = [torch.repeat_interleave(x[b], d[b], dim=0) for b in range(2)]
+    ref = torch.stack([torch.cat([r_, r_.new_zeros(T_ - r_.shape[0], 64)]) for r_ in rows])
+    gy = torch.randn(2, T_, 64, generator=g, dtype=torch.float64)
+    ref.backward(gy)
+    xd = x.detach().float().to(dev).requires_grad_(True)
+    y, ml = torch.ops.styler.length_regulate(xd, d.to(dev), T_)
+    assert torch.equal(ml.cpu(), d.sum(1))
+    check(y, ref, 1e-6, "styler::length_regulate")
+    y.backward(gy.float().to(dev))
+    check(xd.grad, x.grad, 1e-6, "length_regulate dx")
+    # ---- stft_mel ----
+    from styler_amd.audio import TacotronSTFT
+    wav = (torch.rand(2, 22050, generator=g) - 0.5).to(dev)
+    mel, energy, e_in, mel_len = torch.ops.styler.stft_mel(wav, None)
+    f = TacotronSTFT().to(dev).features(wav)
+    assert torch.equal(mel, f["mel"]) and torch.equal(energy, f["energy"]) and torch.equal(mel_len, f["mel_len"])

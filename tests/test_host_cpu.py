@@ -461,3 +461,43 @@ def test_noam_lr_at_step_zero():
     assert noam_lr(0) == 0.0
     so = ScheduledOptim(torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))]), 256, 4000, 0)
     assert so._get_lr_scale() == 0.0                           # optimizer.py:21-25 at n = 0: min(inf, 0) = 0
+
+
+def test_feeder_shape_buckets(tmp_path):
+    """`bucket=(s_step, t_step)`: every sub-batch is padded up to the grid (zeros, lengths untouched), the reported maxima are
+    the padded extents, and the number of distinct shapes an epoch produces collapses."""
+    import numpy as np
+    from golden.make_golden_store import tokenizer, write_store
+    from styler_amd.data import BatchFeeder, FeatureStore, bucket_up
+    write_store(str(tmp_path))
+    ds = FeatureStore(str(tmp_path), tokenizer)
+    exact = list(BatchFeeder(ds, "cpu", batch_size=2, shuffle=False, depth=2))
+    bucketed = list(BatchFeeder(ds, "cpu", batch_size=2, shuffle=False, depth=2, bucket=(8, 64)))
+    assert len(exact) == len(bucketed)
+    for (a, sa, ta), (b, sb, tb) in zip(exact, bucketed):
+        assert (sb, tb) == (bucket_up(sa, 8), bucket_up(ta, 64)) and sb % 8 == 0 and tb % 64 == 0
+        assert b["text"].shape[1] == sb and b["mel_target"].shape[1] == tb and b["f0"].shape[1] == tb and b["log_D"].shape[1] == sb
+        assert torch.equal(a["src_len"], b["src_len"]) and torch.equal(a["mel_len"], b["mel_len"])
+        assert torch.equal(b["text"][:, :sa], a["text"]) and float(b["text"][:, sa:].abs().sum()) == 0
+        assert torch.equal(b["mel_target"][:, :ta], a["mel_target"]) and float(b["mel_target"][:, ta:].abs().sum()) == 0
+        assert float(b["log_D"][:, sa:].abs().sum()) == 0                     # log(0 + 1): the padded durations stay zero
+    assert len({(s, t) for _, s, t in bucketed}) < len({(s, t) for _, s, t in exact})
+    assert bucket_up(990, 64) == 1001 and bucket_up(1001, 64) == 1001         # train mode: never past the position table
+
+
+def test_torch_library_schemas_and_fake_kernels():
+    """torch.ops.styler.* exist with fake (meta) kernels: shapes propagate without a GPU (tracing / torch.compile front end)."""
+    import styler_amd.torch_ops as T
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    assert all(hasattr(torch.ops.styler, n) for n in T.OPS)
+    with FakeTensorMode():
+        y = torch.ops.styler.conv_gemm(torch.empty(2, 10, 256), torch.empty(512, 256, 5), torch.empty(512), 1, 0)
+        assert tuple(y.shape) == (2, 10, 512)
+        o, lse = torch.ops.styler.attention(torch.empty(2, 10, 768), torch.empty(2, dtype=torch.int64), 0)
+        assert tuple(o.shape) == (2, 10, 256) and tuple(lse.shape) == (2, 4, 10)
+        y, s = torch.ops.styler.add_layernorm(torch.empty(2, 10, 256), None, torch.empty(256), torch.empty(256), None)
+        assert tuple(y.shape) == (2, 10, 256)
+        y, ml = torch.ops.styler.length_regulate(torch.empty(2, 5, 64), torch.empty(2, 5, dtype=torch.int64), 33)
+        assert tuple(y.shape) == (2, 33, 64) and tuple(ml.shape) == (2,)
+        mel, en, ei, fl = torch.ops.styler.stft_mel(torch.empty(3, 22050), None)
+        assert tuple(mel.shape) == (3, 87, 80) and tuple(fl.shape) == (3,)
