@@ -199,7 +199,11 @@ int styler_bn_fold(const float* gamma, const float* beta, const float* running_m
 int styler_batchnorm_train(const float* x, const float* gamma, const float* beta, float* y,
                            float* save_mean, float* save_rstd, float* running_mean,
                            float* running_var, double* workspace, int ws_zeroed, int64_t rows, int C,
-                           int act, float drop_p, uint64_t drop_seed, void* stream);
+                           int act, float drop_p, uint64_t drop_seed, int segs, void* stream);
+/* `segs` >= 1 (rows % segs == 0): rows [s * rows/segs, (s+1) * rows/segs) are normalised with THEIR OWN batch statistics,
+ * exactly as `segs` separate calls (the clean and the noisy decode of styler.py:52,55 run through the PostNet as one batch;
+ * Layers.py:126 uses per-call statistics); save_mean / save_rstd are [segs, C], workspace segs * 16 * 2*C doubles, the
+ * running statistics receive the segments' momentum updates in order. */
 
 /* ---- embeddings / positions ---------------------------------------------------------
  * out[b,t,:] = emb[text[b,t],:] + pe[t,:]            (Models.py:73-74; emb [152,256])
@@ -478,7 +482,7 @@ int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const float* dy, int6
 int styler_batchnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
                          const float* save_mean, const float* save_rstd, float* dx, float* dgamma,
                          float* dbeta, double* workspace, int ws_zeroed, int64_t rows, int C, int act,
-                         const float* beta, float drop_p, uint64_t drop_seed, void* stream);
+                         const float* beta, float drop_p, uint64_t drop_seed, int segs, void* stream);
 
 int styler_embed_bwd(const int64_t* text, const float* dy, int64_t lddy, float* demb, int B, int L,
                      int C, void* stream);

@@ -251,13 +251,13 @@ class BatchNormActFn(Function):
     recomputes the tanh output from x instead of saving it."""
 
     @staticmethod
-    def forward(ctx, x, anchor, bn, act, drop_p=0.0):
+    def forward(ctx, x, anchor, bn, act, drop_p=0.0, segs=1):
         drop_p = 0.0 if rt.disable_dropout else drop_p
         seed = next_dropout_seed() if drop_p > 0 else 0
         y, mean, rstd = ops.batchnorm_train(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, act,
-                                            drop_p=drop_p, drop_seed=seed)
+                                            drop_p=drop_p, drop_seed=seed, segs=segs)
         ctx.save_for_backward(x, mean, rstd)
-        ctx.bn, ctx.act, ctx.drop = bn, act, (drop_p, seed)
+        ctx.bn, ctx.act, ctx.drop, ctx.segs = bn, act, (drop_p, seed), segs
         return y
 
     @staticmethod
@@ -265,8 +265,8 @@ class BatchNormActFn(Function):
         x, mean, rstd = ctx.saved_tensors
         bn = ctx.bn
         dx = ops.batchnorm_bwd(x, None, dy, bn.weight, mean, rstd, G(bn.weight), G(bn.bias), ctx.act, beta=bn.bias,
-                               drop_p=ctx.drop[0], drop_seed=ctx.drop[1])
-        return dx, None, None, None, None
+                               drop_p=ctx.drop[0], drop_seed=ctx.drop[1], segs=ctx.segs)
+        return dx, None, None, None, None, None
 
 
 class EmbedPosFn(Function):

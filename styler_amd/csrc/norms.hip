@@ -1,6 +1,7 @@
 // Normalisation kernels: fused residual + LayerNorm(256) + pad mask (+ optional Linear(256,1) tail),
 // GroupNorm(16 ch / group, stats over the padded time axis) + ReLU, BatchNorm1d eval fold and train.
 // All HBM-bound: one read + one write of the activation (GroupNorm re-reads once from L2).
+#include <cstdlib>
 #include "common.h"
 
 // one wave per row; lane holds 4 consecutive channels (64 x 4 = 256)
@@ -203,7 +204,14 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restric
                                                           const float* __restrict__ rstd, double* __restrict__ ws,
                                                           int64_t rows, int C, int act, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float drop_p,
-                                                          uint64_t drop_seed_host, const uint64_t* __restrict__ epoch) {
+                                                          uint64_t drop_seed_host, const uint64_t* __restrict__ epoch,
+                                                          int rpb, int bps, int64_t rps) {
+  // Segments: rows [seg * rps, (seg + 1) * rps) carry their own statistics (the clean and the noisy decode of
+  // styler.py:52,55 run through the PostNet as ONE batch, but each call of the reference normalises with its own batch
+  // statistics, Layers.py:126).  Block = (segment, chunk of rpb rows); per-segment arrays are [segs][...].
+  const int seg = blockIdx.x / bps, chunk = blockIdx.x - seg * bps;
+  ws += (int64_t)seg * STYLER_BN_COPIES * 2 * C;
+  if (BWD) { mean += (int64_t)seg * C; rstd += (int64_t)seg * C; }
   const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   __shared__ double red[256][8];
   const int nq = C / 4;
@@ -211,9 +219,10 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restric
   const int lanes = 256 / nqt;                       // row-lanes
   const int rl = threadIdx.x / nqt, ql = threadIdx.x - rl * nqt;
   const bool live = rl < lanes;
-  const int64_t r0 = (int64_t)blockIdx.x * BN_RPB;
-  int64_t r1 = r0 + BN_RPB; if (r1 > rows) r1 = rows;
-  double* wsc = ws + (int64_t)(blockIdx.x % STYLER_BN_COPIES) * 2 * C;
+  const int64_t r0 = (int64_t)seg * rps + (int64_t)chunk * rpb;
+  int64_t r1 = r0 + rpb; if (r1 > (seg + 1) * rps) r1 = (seg + 1) * rps;
+  (void)rows;
+  double* wsc = ws + (int64_t)(chunk % STYLER_BN_COPIES) * 2 * C;
   for (int q0 = 0; q0 < nq; q0 += nqt) {
     const int q = q0 + ql;
     double s[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
@@ -224,7 +233,23 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restric
         ga = *reinterpret_cast<const float4*>(gamma + q * 4);
         if (beta) be = *reinterpret_cast<const float4*>(beta + q * 4);
       }
-      for (int64_t r = r0 + rl; r < r1; r += lanes) {
+      int64_t r = r0 + rl;
+      if (!BWD) {
+        // forward statistics: four rows' loads in flight per thread (the accumulation chain is fp64 and serial, the
+        // loads are not)
+        for (; r + 3 * (int64_t)lanes < r1; r += 4 * (int64_t)lanes) {
+          float4 v4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v4[u] = *reinterpret_cast<const float4*>(x + (r + (int64_t)u * lanes) * C + q * 4);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            s[0] += v4[u].x; s[1] += v4[u].y; s[2] += v4[u].z; s[3] += v4[u].w;
+            t[0] += (double)v4[u].x * v4[u].x; t[1] += (double)v4[u].y * v4[u].y;
+            t[2] += (double)v4[u].z * v4[u].z; t[3] += (double)v4[u].w * v4[u].w;
+          }
+        }
+      }
+      for (; r < r1; r += lanes) {
         const float4 v = *reinterpret_cast<const float4*>(x + r * C + q * 4);
         if (BWD) {
           float4 g = *reinterpret_cast<const float4*>(dy + r * C + q * 4);
@@ -261,9 +286,11 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restric
   }
 }
 
-__global__ void bn_fold_copies_kernel(double* __restrict__ ws, int C2) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= C2) return;
+__global__ void bn_fold_copies_kernel(double* __restrict__ ws, int C2, int segs) {
+  const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= C2 * segs) return;
+  const int seg = gi / C2, i = gi - seg * C2;
+  ws += (int64_t)seg * STYLER_BN_COPIES * C2;
   double t = 0.0;
 #pragma unroll
   for (int k = 0; k < STYLER_BN_COPIES; ++k) t += ws[(int64_t)k * C2 + i];
@@ -272,36 +299,43 @@ __global__ void bn_fold_copies_kernel(double* __restrict__ ws, int C2) {
 
 int styler_bn_colstats(bool bwd, const float* x, const float* y, const float* dy, const float* mean, const float* rstd,
                        double* ws, int ws_zeroed, int64_t rows, int C, int act, const float* gamma, const float* beta,
-                       float drop_p, uint64_t drop_seed, hipStream_t st) {
+                       float drop_p, uint64_t drop_seed, int segs, hipStream_t st) {
   if (!ws_zeroed) {
-    hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * STYLER_BN_COPIES, st);
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * STYLER_BN_COPIES * segs, st);
     if (e != hipSuccess) return (int)e;
   }
-  const dim3 grid((unsigned)((rows + BN_RPB - 1) / BN_RPB));
+  static const int rpb_env = [] { const char* e = getenv("STYLER_BN_RPB"); return e ? atoi(e) : BN_RPB; }();
+  const int rpb = rpb_env > 0 ? rpb_env : BN_RPB;
+  const int64_t rps = rows / segs;                   // rows per segment
+  const int bps = (int)((rps + rpb - 1) / rpb);      // blocks per segment
+  const dim3 grid((unsigned)(bps * segs));
   if (bwd)
     hipLaunchKernelGGL(bn_colstats_kernel<true>, grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, rows, C, act, gamma, beta,
-                       drop_p, drop_seed, g_styler_drop_epoch);
+                       drop_p, drop_seed, g_styler_drop_epoch, rpb, bps, rps);
   else
     hipLaunchKernelGGL(bn_colstats_kernel<false>, grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, rows, C, act, gamma, beta,
-                       drop_p, drop_seed, g_styler_drop_epoch);
-  hipLaunchKernelGGL(bn_fold_copies_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, ws, 2 * C);
+                       drop_p, drop_seed, g_styler_drop_epoch, rpb, bps, rps);
+  hipLaunchKernelGGL(bn_fold_copies_kernel, dim3((2 * C * segs + 255) / 256), dim3(256), 0, st, ws, 2 * C, segs);
   return 0;
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ ws, float* save_mean, float* save_rstd,
-                                   float* running_mean, float* running_var, int64_t rows, int C) {
+                                   float* running_mean, float* running_var, int64_t rows, int C, int segs) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double n = (double)rows;
-  const double mean = ws[c] / n;
-  double var = ws[C + c] / n - mean * mean;
-  if (var < 0.0) var = 0.0;
-  save_mean[c] = (float)mean;
-  save_rstd[c] = (float)(1.0 / sqrt(var + 1e-5));
-  if (running_mean) {
-    const double unbiased = rows > 1 ? var * n / (n - 1.0) : var;
-    running_mean[c] = 0.9f * running_mean[c] + 0.1f * (float)mean;
-    running_var[c] = 0.9f * running_var[c] + 0.1f * (float)unbiased;
+  const double n = (double)(rows / segs);
+  for (int seg = 0; seg < segs; ++seg) {             // the running statistics see the segments as consecutive calls
+    const double* w = ws + (int64_t)seg * STYLER_BN_COPIES * 2 * C;
+    const double mean = w[c] / n;
+    double var = w[C + c] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    save_mean[seg * C + c] = (float)mean;
+    save_rstd[seg * C + c] = (float)(1.0 / sqrt(var + 1e-5));
+    if (running_mean) {
+      const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+      running_mean[c] = 0.9f * running_mean[c] + 0.1f * (float)mean;
+      running_var[c] = 0.9f * running_var[c] + 0.1f * (float)unbiased;
+    }
   }
 }
 
@@ -310,18 +344,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, float* __restrict__ y,
                                                        int64_t total4, int C, int act, float drop_p,
-                                                       uint64_t drop_seed_host, const uint64_t* __restrict__ epoch) {
+                                                       uint64_t drop_seed_host, const uint64_t* __restrict__ epoch,
+                                                       int64_t rps) {
   const int nq = C / 4;
   const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     const int q = (int)(i % nq);
+    const int64_t so = ((i / nq) / rps) * C;        // offset of the row's segment in the [segs, C] statistics
     const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
     const float4 g = *reinterpret_cast<const float4*>(gamma + q * 4);
     const float4 b = *reinterpret_cast<const float4*>(beta + q * 4);
-    const float4 m = *reinterpret_cast<const float4*>(mean + q * 4);
-    const float4 r = *reinterpret_cast<const float4*>(rstd + q * 4);
+    const float4 m = *reinterpret_cast<const float4*>(mean + so + q * 4);
+    const float4 r = *reinterpret_cast<const float4*>(rstd + so + q * 4);
     float4 o;
     o.x = apply_act((v.x - m.x) * r.x * g.x + b.x, act);
     o.y = apply_act((v.y - m.y) * r.y * g.y + b.y, act);
@@ -341,19 +377,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 extern "C" int styler_batchnorm_train(const float* x, const float* gamma, const float* beta, float* y,
                                       float* save_mean, float* save_rstd, float* running_mean, float* running_var,
                                       double* workspace, int ws_zeroed, int64_t rows, int C, int act, float drop_p,
-                                      uint64_t drop_seed, void* stream) {
+                                      uint64_t drop_seed, int segs, void* stream) {
   if (!x || !gamma || !beta || !y || !save_mean || !save_rstd || !workspace || rows <= 0 || C <= 0 || (C & 3) ||
-      drop_p < 0.f || drop_p >= 1.f)
+      drop_p < 0.f || drop_p >= 1.f || segs < 1 || rows % segs)
     return STYLER_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int rc = styler_bn_colstats(false, x, nullptr, nullptr, nullptr, nullptr, workspace, ws_zeroed, rows, C, act, nullptr,
-                                    nullptr, 0.f, 0, st);
+                                    nullptr, 0.f, 0, segs, st);
   if (rc) return rc;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, save_mean, save_rstd,
-                     running_mean, running_var, rows, C);
+                     running_mean, running_var, rows, C, segs);
   const int64_t total4 = rows * C / 4;
   int64_t blocks = (total4 + 255) / 256; if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta, save_mean, save_rstd,
-                     y, total4, C, act, drop_p, drop_seed, g_styler_drop_epoch);
+                     y, total4, C, act, drop_p, drop_seed, g_styler_drop_epoch, rows / segs);
   return launch_status();
 }

@@ -8,6 +8,7 @@
 //   dx = rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)),  dxh = dy * g
 // dot variant (predictor tail, out = <y, w> + b0): dy = dout[row] * w, dw += dout * y, db0 += dout.
 #define LNB_WAVES 8         // waves per block: rows in flight per CU (the row loop is a latency chain of 4 wave reductions)
+template <int R>
 __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dx, int64_t lddx,
@@ -27,7 +28,6 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
   // Two rows per wave and iteration: a row is a latency chain (two loads, then mean -> variance -> two more wave
   // reductions); the chains of the two rows are independent and interleave.  (Measured: 1, 2 and 4 rows take the same
   // 25 us -- the kernel was bound by its parameter-gradient atomics, see `replicas`.)
-  constexpr int R = 2;
   for (int64_t row0 = w0; row0 < rows; row0 += wstride * R) {
     int64_t row[R];
     bool live[R];
@@ -163,9 +163,15 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
   int64_t blocks = (rows + LNB_WAVES - 1) / LNB_WAVES;
   static const int cap = [] { const char* e = getenv("STYLER_LNBWD_BLOCKS"); return e ? atoi(e) : 512; }();
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(64 * LNB_WAVES), 0, (hipStream_t)stream, x, ldx, dy, lddy,
-                     gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b, rows, L, len, drop_p, drop_seed,
-                     g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd, replicas);
+  static const int rows_per_iter = [] { const char* e = getenv("STYLER_LNBWD_ROWS"); return e ? atoi(e) : 2; }();
+  if (rows_per_iter == 4)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3((unsigned)blocks), dim3(64 * LNB_WAVES), 0, (hipStream_t)stream, x, ldx, dy,
+                       lddy, gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b, rows, L, len, drop_p, drop_seed,
+                       g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd, replicas);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3((unsigned)blocks), dim3(64 * LNB_WAVES), 0, (hipStream_t)stream, x, ldx, dy,
+                       lddy, gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b, rows, L, len, drop_p, drop_seed,
+                       g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd, replicas);
   return launch_status();
 }
 
@@ -288,7 +294,8 @@ extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const floa
 //   dz = dy * act'(y); dgamma = sum dz*xh; dbeta = sum dz; dx = g*rstd*(dz - dbeta/N - xh*dgamma/N)
 int styler_bn_colstats(bool bwd, const float* x, const float* y, const float* dy, const float* mean, const float* rstd,
                        double* ws, int ws_zeroed, int64_t rows, int C, int act, const float* gamma, const float* beta,
-                       float drop_p, uint64_t drop_seed, hipStream_t st);   // norms.hip
+                       float drop_p, uint64_t drop_seed, int segs, hipStream_t st);   // norms.hip
+#define STYLER_BN_COPIES 16                          // norms.hip
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy, const float* __restrict__ gamma,
@@ -297,21 +304,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            int64_t rows, int C, int act, const float* __restrict__ beta,
                                                            float drop_p, uint64_t drop_seed_host,
-                                                           const uint64_t* __restrict__ epoch) {
+                                                           const uint64_t* __restrict__ epoch, int segs) {
   const int nq = C / 4;
   const int64_t total4 = rows * nq;
-  const double inv_n = 1.0 / (double)rows;
+  const int64_t rps = rows / segs;                   // per-segment statistics (norms.hip)
+  const double inv_n = 1.0 / (double)rps;
   const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     const int q = (int)(i % nq);
+    const int seg = (int)((i / nq) / rps);
+    const double* wseg = ws + (int64_t)seg * STYLER_BN_COPIES * 2 * C;
     const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
     const float4 g = *reinterpret_cast<const float4*>(dy + i * 4);
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (y && act == STYLER_ACT_TANH) o = *reinterpret_cast<const float4*>(y + i * 4);
     const float4 ga = *reinterpret_cast<const float4*>(gamma + q * 4);
     const float4 be = beta ? *reinterpret_cast<const float4*>(beta + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 m = *reinterpret_cast<const float4*>(mean + q * 4);
-    const float4 rs = *reinterpret_cast<const float4*>(rstd + q * 4);
+    const float4 m = *reinterpret_cast<const float4*>(mean + (int64_t)seg * C + q * 4);
+    const float4 rs = *reinterpret_cast<const float4*>(rstd + (int64_t)seg * C + q * 4);
     float out[4];
     float gv[4] = {g.x, g.y, g.z, g.w};
     const float xv[4] = {v.x, v.y, v.z, v.w}, ov[4] = {o.x, o.y, o.z, o.w}, bev[4] = {be.x, be.y, be.z, be.w};
@@ -320,31 +330,35 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     for (int k = 0; k < 4; ++k) {
       const float xh = (xv[k] - mv[k]) * rv[k];
       gv[k] = bn_dz_elem(gv[k], xh, gav[k], bev[k], act, y ? &ov[k] : nullptr, drop_p, drop_seed, (uint64_t)i * 4 + k);
-      const float sb = (float)(ws[q * 4 + k] * inv_n), sg = (float)(ws[C + q * 4 + k] * inv_n);
+      const float sb = (float)(wseg[q * 4 + k] * inv_n), sg = (float)(wseg[C + q * 4 + k] * inv_n);
       out[k] = gav[k] * rv[k] * (gv[k] - sb - xh * sg);
     }
     *reinterpret_cast<float4*>(dx + i * 4) = make_float4(out[0], out[1], out[2], out[3]);
   }
   // parameter gradients: first C threads of the grid
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid < C) { atomicAdd(dbeta + gid, (float)ws[gid]); atomicAdd(dgamma + gid, (float)ws[C + gid]); }
+  if (gid < (int64_t)C * segs) {
+    const int seg = (int)(gid / C), c = (int)(gid - (int64_t)seg * C);
+    const double* wseg = ws + (int64_t)seg * STYLER_BN_COPIES * 2 * C;
+    atomicAdd(dbeta + c, (float)wseg[c]); atomicAdd(dgamma + c, (float)wseg[C + c]);
+  }
 }
 
 extern "C" int styler_batchnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
                                     const float* save_mean, const float* save_rstd, float* dx, float* dgamma,
                                     float* dbeta, double* workspace, int ws_zeroed, int64_t rows, int C, int act,
-                                    const float* beta, float drop_p, uint64_t drop_seed, void* stream) {
+                                    const float* beta, float drop_p, uint64_t drop_seed, int segs, void* stream) {
   if (!x || !dy || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || C <= 0 ||
-      (C & 3) || (act == STYLER_ACT_TANH && !y && !beta) || drop_p < 0.f || drop_p >= 1.f)
+      (C & 3) || (act == STYLER_ACT_TANH && !y && !beta) || drop_p < 0.f || drop_p >= 1.f || segs < 1 || rows % segs)
     return STYLER_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int rc = styler_bn_colstats(true, x, y, dy, save_mean, save_rstd, workspace, ws_zeroed, rows, C, act, gamma, beta,
-                                    drop_p, drop_seed, st);
+                                    drop_p, drop_seed, segs, st);
   if (rc) return rc;
   const int64_t total4 = rows * C / 4;
   int64_t blocks = (total4 + 255) / 256; if (blocks > 4096) blocks = 4096;
-  if (blocks * 256 < C) blocks = (C + 255) / 256;
+  if (blocks * 256 < (int64_t)C * segs) blocks = ((int64_t)C * segs + 255) / 256;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd,
-                     workspace, dx, dgamma, dbeta, rows, C, act, beta, drop_p, drop_seed, g_styler_drop_epoch);
+                     workspace, dx, dgamma, dbeta, rows, C, act, beta, drop_p, drop_seed, g_styler_drop_epoch, segs);
   return launch_status();
 }

@@ -483,19 +483,19 @@ LN_REPLICAS = 16           # scratch replicas of LayerNorm's parameter gradients
 BN_WS_COPIES = 16        # STYLER_BN_COPIES (norms.hip): replicas of the 2C-double column accumulator
 
 
-def batchnorm_train(x, gamma, beta, running_mean, running_var, act, drop_p=0.0, drop_seed=0):
+def batchnorm_train(x, gamma, beta, running_mean, running_var, act, drop_p=0.0, drop_seed=0, segs=1):
     """x [B, L, C] contiguous (conv output incl. bias). Returns y (= dropout(act(BN(x))) with drop_p > 0), save_mean,
-    save_rstd."""
+    save_rstd ([segs, C]: `segs` equal row ranges, each normalised with its own batch statistics)."""
     assert x.is_contiguous()
     C = x.shape[-1]
     rows = x.numel() // C
     y = torch.empty_like(x)
-    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+    mean = torch.empty(segs, C, device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
-    ws, z = _norm_ws(2 * C * BN_WS_COPIES, x.device)
+    ws, z = _norm_ws(2 * C * BN_WS_COPIES * segs, x.device)
     _chk(lib.styler_batchnorm_train(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
                                     mean.data_ptr(), rstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
-                                    ws.data_ptr(), z, rows, C, act, float(drop_p), int(drop_seed), _stream()),
+                                    ws.data_ptr(), z, rows, C, act, float(drop_p), int(drop_seed), int(segs), _stream()),
          "styler_batchnorm_train")
     return y, mean, rstd
 
@@ -850,16 +850,16 @@ def groupnorm_relu_bwd(x, dy, gamma, beta, stats, dgamma, dbeta):
     return dx
 
 
-def batchnorm_bwd(x, y, dy, gamma, mean, rstd, dgamma, dbeta, act, beta=None, drop_p=0.0, drop_seed=0):
+def batchnorm_bwd(x, y, dy, gamma, mean, rstd, dgamma, dbeta, act, beta=None, drop_p=0.0, drop_seed=0, segs=1):
     """`y` may be None when `beta` is given (the activation output is recomputed from x)."""
     C = x.shape[-1]
     rows = x.numel() // C
     dy = dy.contiguous()
     dx = torch.empty_like(x)
-    ws, z = _norm_ws(2 * C * BN_WS_COPIES, x.device)
+    ws, z = _norm_ws(2 * C * BN_WS_COPIES * segs, x.device)
     _chk(lib.styler_batchnorm_bwd(x.data_ptr(), _ptr(y), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                   rstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), z,
-                                  rows, C, act, _ptr(beta), float(drop_p), int(drop_seed), _stream()),
+                                  rows, C, act, _ptr(beta), float(drop_p), int(drop_seed), int(segs), _stream()),
          "styler_batchnorm_bwd")
     return dx
 

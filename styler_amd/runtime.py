@@ -34,6 +34,10 @@ class _Runtime:
     # forward and (through autograd's stream bookkeeping) backward: 15.11 -> 15.00, 15.20 -> 15.03 ms same-box A/B
     text_stream = os.environ.get("STYLER_TEXT_STREAM", "1") != "0"
 
+    # clean + noisy branch through the PostNet as one batch (per-branch BatchNorm statistics in the kernels): half the
+    # GEMM / norm launches of the PostNet, weight gradients with twice the rows (STYLER_PAIR_POSTNET=0: two passes)
+    pair_postnet = os.environ.get("STYLER_PAIR_POSTNET", "1") != "0"
+
     def set_precision(self, name):
         self.prec = {"fp32": ops.PREC_F32, "bf16": ops.PREC_BF16}[name]
 

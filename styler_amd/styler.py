@@ -45,10 +45,14 @@ class STYLER(_HipModule):
         lens = mel_len if mel_len is not None else self._lens_from_mask(mel_mask)
         B = out_clean.shape[0]
         mel2 = self._gemm("mel_linear", self.decoder.forward_pair(out_clean, out_noisy, lens), self.mel_linear)
-        halves = AG.SplitBatchFn.apply(mel2) if (self.training and torch.is_grad_enabled() and mel2.requires_grad) \
-            else (mel2[:B], mel2[B:])
+        tape = self.training and torch.is_grad_enabled() and mel2.requires_grad
+        split = (lambda t: AG.SplitBatchFn.apply(t)) if tape else (lambda t: (t[:B], t[B:]))
+        if self.use_postnet and rt.pair_postnet:
+            # both branches through the PostNet as one batch of 2B items, BatchNorm statistics per branch (segs = 2)
+            post2 = self.postnet(mel2, add_residual=mel2, segs=2)
+            return list(zip(split(mel2), split(post2)))
         outs = []
-        for mel in halves:
+        for mel in split(mel2):
             outs.append((mel, self.postnet(mel, add_residual=mel) if self.use_postnet else mel))
         return outs
 

@@ -245,8 +245,11 @@ class PostNet(_HipModule):
                 nn.BatchNorm1d(dims[i + 1])))
         self.kernel_size = postnet_kernel_size
 
-    def forward(self, x, add_residual=None):
-        """x [B, T, 80] channels-last -> [B, T, 80]; `add_residual` (the mel) is added to the output."""
+    def forward(self, x, add_residual=None, segs=1):
+        """x [B, T, 80] channels-last -> [B, T, 80]; `add_residual` (the mel) is added to the output.  `segs` > 1: x stacks
+        the inputs of `segs` calls along the batch axis (clean + noisy decode, styler.py:52,55); train-mode BatchNorm then
+        normalises each of them with its own batch statistics and updates the running statistics once per segment, i.e.
+        the result is that of `segs` separate calls, with one GEMM / norm launch per layer instead of `segs`."""
         n = len(self.convolutions)
         for i, seq in enumerate(self.convolutions):
             conv, bn = seq[0].conv, seq[1]
@@ -256,11 +259,11 @@ class PostNet(_HipModule):
                 y = self._gemm(f"c{i}", x, conv, kw=self.kernel_size)
                 # BatchNorm (batch statistics) + tanh + F.dropout(.., 0.5, self.training) (Layers.py:126-128): one pass
                 if (self.training and torch.is_grad_enabled()):
-                    y = AG.BatchNormActFn.apply(y, bn.weight, bn, act, 0.5)
+                    y = AG.BatchNormActFn.apply(y, bn.weight, bn, act, 0.5, segs)
                 else:
                     p = 0.0 if rt.disable_dropout else 0.5
                     y, _, _ = ops.batchnorm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, act,
-                                                  drop_p=p, drop_seed=AG.next_dropout_seed() if p > 0 else 0)
+                                                  drop_p=p, drop_seed=AG.next_dropout_seed() if p > 0 else 0, segs=segs)
                 if last and add_residual is not None:
                     y = AG.Add2Fn.apply(y, add_residual) if (self.training and torch.is_grad_enabled()) else ops.add2(y, add_residual)
                 x = y
@@ -272,5 +275,5 @@ class PostNet(_HipModule):
                                res=add_residual if last else None)
         if self.training:                                  # BatchNorm1d bookkeeping: one multi-tensor launch per call
             with torch.no_grad():
-                torch._foreach_add_([seq[1].num_batches_tracked for seq in self.convolutions], 1)
+                torch._foreach_add_([seq[1].num_batches_tracked for seq in self.convolutions], segs)
         return x

@@ -1,0 +1,12 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r02k
+timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 > gpurun_out/r02k/t.txt
+run() { env "$@" timeout 300 python bench.py --no-cpu --no-aux --steps 40 --warmup 5 --prof-steps 0 --repeat 2 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', d['ms_per_step'], d['repeat']['ms_per_step_median'])"; }
+{
+run STYLER_PAIR_POSTNET=0
+run STYLER_PAIR_POSTNET=1
+run STYLER_PAIR_POSTNET=0
+run STYLER_PAIR_POSTNET=1
+} > gpurun_out/r02k/ab.txt 2>&1
+cat gpurun_out/r02k/t.txt gpurun_out/r02k/ab.txt
