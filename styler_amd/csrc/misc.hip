@@ -371,20 +371,108 @@ __global__ __launch_bounds__(256) void strided_copy_multi_kernel(const StylerCop
   const int64_t bid = blockIdx.x;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].block_start <= bid) lo = mid; else hi = mid - 1; }
   const StylerCopyDesc d = desc[lo];
-  const int64_t total = (int64_t)d.d0 * d.d1 * d.d2;
+  if (d.flags & 2) {
+    // Tiled transpose (flags bit1, set by the host when the pattern holds): dst is contiguous along a2, the source is
+    // contiguous along the MERGED (a0, a1) index m (ss0 == d1, ss1 == +-1) and strided along a2 -- the tap-flipped
+    // transposed dX weights [cin, kw, n] <- [n, cin, kw] and the transposed Linear / fused-QKV layouts.  Walked one
+    // destination element per thread, a wave touched 64 different cache lines for 256 useful bytes (32x the bytes through
+    // L1 / L2: this launch took 300 us for 59 M elements).  Here a block moves a [32 a2] x [64 m] tile through LDS: reads
+    // are 256-byte runs along m, writes 32-element runs along a2.
+    __shared__ float tile[32][65];
+    const uint32_t M = (uint32_t)d.d0 * (uint32_t)d.d1, N2 = (uint32_t)d.d2;
+    const uint32_t mt = (M + 63u) / 64u;
+    const uint32_t t = (uint32_t)(bid - d.block_start);
+    const uint32_t n0 = (t / mt) * 32u, m0 = (t % mt) * 64u;
+    const float* srcp = reinterpret_cast<const float*>(d.src) + (d.ss1 < 0 ? -(int64_t)(d.d1 - 1) : 0);
+    const float* src2p = d.src2 ? reinterpret_cast<const float*>(d.src2) + (d.ss1 < 0 ? -(int64_t)(d.d1 - 1) : 0) : nullptr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const uint32_t nn = n0 + wave * 8 + rr, m = m0 + lane;
+      float v = 0.f;
+      if (nn < N2 && m < M) {
+        const int64_t si = (int64_t)nn * d.ss2 + m;
+        v = srcp[si];
+        if (src2p) v += src2p[si];
+      }
+      tile[wave * 8 + rr][lane] = v;
+    }
+    __syncthreads();
+    const uint32_t nl = threadIdx.x & 31, ms = threadIdx.x >> 5;       // 32 a2 values x 8 m values per pass
+    const uint32_t ud1t = (uint32_t)d.d1;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const uint32_t ml = p * 8 + ms, m = m0 + ml, nn = n0 + nl;
+      if (m >= M || nn >= N2) continue;
+      const uint32_t a0 = m / ud1t, tt = m % ud1t;
+      const uint32_t a1 = d.ss1 < 0 ? ud1t - 1u - tt : tt;
+      const int64_t o = (int64_t)a0 * d.ds0 + (int64_t)a1 * d.ds1 + nn;
+      const float v = tile[nl][ml];
+      if (d.flags & 1) reinterpret_cast<uint16_t*>(d.dst)[o] = (uint16_t)f32_to_bf16_bits(v);
+      else reinterpret_cast<float*>(d.dst)[o] = v;
+    }
+    return;
+  }
+  if (d.flags & 4) {
+    // Tap interleave (flags bit2): dst [a0][a1][a2] <- src[a0 * ss0 + a2 * d1 + a1]: the [n, kw, cin] conv layout from the
+    // parameter's [n, cin, kw].  Inside one a0 the source is ONE contiguous run of d1 * d2 elements; a block moves 128
+    // a2 values x all d1 taps of one a0 through LDS (read as a contiguous run, written as d1 runs of 128).
+    __shared__ float run[128 * 9 + 8];
+    const uint32_t ud1k = (uint32_t)d.d1, ud2k = (uint32_t)d.d2;
+    const uint32_t ct = (ud2k + 127u) / 128u;
+    const uint32_t t = (uint32_t)(bid - d.block_start);
+    const uint32_t a0 = t / ct, c0 = (t % ct) * 128u;
+    const uint32_t cn = ud2k - c0 < 128u ? ud2k - c0 : 128u;
+    const float* sp = reinterpret_cast<const float*>(d.src) + (int64_t)a0 * d.ss0 + (int64_t)c0 * ud1k;
+    const float* sp2 = d.src2 ? reinterpret_cast<const float*>(d.src2) + (int64_t)a0 * d.ss0 + (int64_t)c0 * ud1k : nullptr;
+    for (uint32_t i = threadIdx.x; i < cn * ud1k; i += 256u) run[i] = sp[i] + (sp2 ? sp2[i] : 0.f);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cn * ud1k; i += 256u) {
+      const uint32_t a1 = i / cn, c = i - a1 * cn;
+      const float v = run[c * ud1k + a1];
+      const int64_t o = (int64_t)a0 * d.ds0 + (int64_t)a1 * d.ds1 + c0 + c;
+      if (d.flags & 1) reinterpret_cast<uint16_t*>(d.dst)[o] = (uint16_t)f32_to_bf16_bits(v);
+      else reinterpret_cast<float*>(d.dst)[o] = v;
+    }
+    return;
+  }
+  // 32-bit index arithmetic (a descriptor covers < 2^31 elements): the three 64-bit divisions per element that decoded
+  // (a0, a1, a2) were what bound this kernel (300 us for the 59 M derived elements of the model)
+  const uint32_t total = (uint32_t)d.d0 * (uint32_t)d.d1 * (uint32_t)d.d2;
   const float* src = reinterpret_cast<const float*>(d.src);
-  const int64_t i0 = (bid - d.block_start) * 1024;
+  const float* src2 = reinterpret_cast<const float*>(d.src2);
+  const uint32_t i0 = (uint32_t)(bid - d.block_start) * 1024u;
+  const uint32_t ud1 = (uint32_t)d.d1, ud2 = (uint32_t)d.d2;
+  const bool bf = d.flags & 1;
+  // destination-contiguous pairs leave as one 4-byte (bf16 x 2) or 8-byte (fp32 x 2) store
+  const bool pair = d.ds2 == 1 && !(ud2 & 1u) && !(d.ds0 & 1) && !(d.ds1 & 1) && !((uintptr_t)d.dst & (bf ? 3 : 7));
+  if (pair) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t i = i0 + (uint32_t)(k * 256 + threadIdx.x) * 2u;
+      if (i >= total) return;
+      const uint32_t a2 = i % ud2, r = i / ud2;
+      const uint32_t a1 = r % ud1, a0 = r / ud1;
+      const int64_t si = (int64_t)a0 * d.ss0 + (int64_t)a1 * d.ss1 + (int64_t)a2 * d.ss2;
+      float v0 = src[si], v1 = src[si + d.ss2];
+      if (src2) { v0 += src2[si]; v1 += src2[si + d.ss2]; }
+      const int64_t o = (int64_t)a0 * d.ds0 + (int64_t)a1 * d.ds1 + a2;
+      if (bf) *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(d.dst) + o) = pack_bf16x2(v0, v1);
+      else *reinterpret_cast<float2*>(reinterpret_cast<float*>(d.dst) + o) = make_float2(v0, v1);
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int64_t i = i0 + k * 256 + threadIdx.x;
+    const uint32_t i = i0 + (uint32_t)(k * 256) + threadIdx.x;
     if (i >= total) return;
-    const int a2 = (int)(i % d.d2); const int64_t r = i / d.d2;
-    const int a1 = (int)(r % d.d1); const int a0 = (int)(r / d.d1);
-    const int64_t si = a0 * d.ss0 + a1 * d.ss1 + a2 * d.ss2;
+    const uint32_t a2 = i % ud2, r = i / ud2;
+    const uint32_t a1 = r % ud1, a0 = r / ud1;
+    const int64_t si = (int64_t)a0 * d.ss0 + (int64_t)a1 * d.ss1 + (int64_t)a2 * d.ss2;
     float v = src[si];
-    if (d.src2) v += reinterpret_cast<const float*>(d.src2)[si];
-    const int64_t o = a0 * d.ds0 + a1 * d.ds1 + a2 * d.ds2;
-    if (d.flags & 1) reinterpret_cast<uint16_t*>(d.dst)[o] = (uint16_t)f32_to_bf16_bits(v);
+    if (src2) v += src2[si];
+    const int64_t o = (int64_t)a0 * d.ds0 + (int64_t)a1 * d.ds1 + (int64_t)a2 * d.ds2;
+    if (bf) reinterpret_cast<uint16_t*>(d.dst)[o] = (uint16_t)f32_to_bf16_bits(v);
     else reinterpret_cast<float*>(d.dst)[o] = v;
   }
 }

@@ -159,6 +159,9 @@ class Derived:
         self._store.clear()
 
 
+TILED_COPY_OFF = os.environ.get("STYLER_TILED_COPY", "1") == "0"     # A/B switch of the tiled transposes
+
+
 class _Spec:
     def __init__(self, segs, out, bf16):
         self.segs, self.out, self.bf16 = segs, out, bf16
@@ -182,16 +185,32 @@ class _Spec:
         self.ptrs = tuple(t.data_ptr() for t in self._srcs())
         esz = 2 if self.bf16 else 4
         for sg in self.segs:
+            dims, sstr, dstr = sg.dims, sg.sstr, sg.dstr
+            if dims[2] == 1 and dims[0] > 1 and dims[1] > 1:          # 2-D segment: put its axes last (a0 becomes 1)
+                dims, sstr, dstr = (1, dims[0], dims[1]), (0, sstr[0], sstr[1]), (0, dstr[0], dstr[1])
             d = _lib.CopyDesc()
             d.src = sg.src.data_ptr() + 4 * sg.src_off
             d.src2 = (sg.src2.data_ptr() + 4 * sg.src_off) if sg.src2 is not None else 0
             d.dst = self.out.data_ptr() + esz * sg.dst_off
-            d.ss0, d.ss1, d.ss2 = sg.sstr
-            d.ds0, d.ds1, d.ds2 = sg.dstr
-            d.d0, d.d1, d.d2 = sg.dims
+            d.ss0, d.ss1, d.ss2 = sstr
+            d.ds0, d.ds1, d.ds2 = dstr
+            d.d0, d.d1, d.d2 = dims
             d.flags = 1 if self.bf16 else 0
             d.block_start = start
-            start += (sg.dims[0] * sg.dims[1] * sg.dims[2] + 1023) // 1024
+            # transposes (destination contiguous along a2, source contiguous along the merged (a0, a1) index, strided
+            # along a2): tiled through LDS by the kernel (flags bit1)
+            tiled = (dstr[2] == 1 and abs(sstr[1]) == 1 and (dims[0] == 1 or sstr[0] == dims[1]) and abs(sstr[2]) > 1
+                     and dims[2] >= 16 and dims[0] * dims[1] >= 16 and not TILED_COPY_OFF)
+            taps = (dstr[2] == 1 and sstr[1] == 1 and 1 < dims[1] <= 9 and sstr[2] == dims[1] and dims[2] >= 16
+                    and not TILED_COPY_OFF)
+            if tiled:
+                d.flags |= 2
+                start += ((dims[2] + 31) // 32) * ((dims[0] * dims[1] + 63) // 64)
+            elif taps:
+                d.flags |= 4
+                start += dims[0] * ((dims[2] + 127) // 128)
+            else:
+                start += (dims[0] * dims[1] * dims[2] + 1023) // 1024
             descs.append(d)
         return start
 
