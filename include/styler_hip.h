@@ -442,6 +442,9 @@ typedef struct StylerWgradDesc {
 } StylerWgradDesc;
 int styler_wgrad_reduce_multi(const StylerWgradDesc* desc_dev, int count, int64_t total_blocks,
                               void* stream);
+/* Blocks descriptor i owns (block_start[i+1] - block_start[i]): ceil(n*kw*cin / 1024), or -- conv taps reduced into the
+ * parameter layout (stride_j == 1, stride_c == kw) -- n * ceil(cin / 128): one block per (n, 128 channels, all taps). */
+int64_t styler_wgrad_reduce_blocks(int n, int cin, int kw, int64_t stride_c, int64_t stride_j);
 /* bytes of `workspace` styler_wgrad needs for a shape (split-K partial tiles, reduced without atomics) */
 int64_t styler_wgrad_workspace_bytes(int B, int L, int n, int cin, int kw, int pad_left, int prec);
 

@@ -71,7 +71,7 @@ extern "C" int styler_masked_err_mean(const float* a, int64_t lda, const float* 
                                       int kind, int B, int L, int C, const int64_t* len, void* stream) {
   if (!a || !b || !acc || B <= 0 || L <= 0 || C <= 0 || (kind != 0 && kind != 1)) return STYLER_EINVAL;
   const int64_t rows = (int64_t)B * L;
-  hipLaunchKernelGGL(masked_err_mean_kernel, dim3(loss_grid(rows * C / ((C & 3) ? 1 : 4), 256, 1024)), dim3(256), 0,
+  hipLaunchKernelGGL(masked_err_mean_kernel, dim3(loss_grid(rows * C / ((C & 3) ? 1 : 4), 1024, 256)), dim3(256), 0,
                      (hipStream_t)stream, a, lda, b, ldb, acc, mean_out, kind, rows, L, C, len);
   return launch_status();
 }

@@ -186,7 +186,7 @@ class WgradArena:
             start = 0
             for i, (ws, dw, sn, sc, sj, n, cin, kw, splits) in enumerate(self.descs):
                 arr[i] = (ws, dw, sn, sc, sj, start, n, cin, kw, splits)
-                start += (n * cin * kw + 1023) // 1024
+                start += int(lib.styler_wgrad_reduce_blocks(n, cin, kw, sc, sj))
             if len(self._cache) > 8:
                 self._cache.clear()
             self._cache[key] = (torch.from_numpy(arr.view(np.uint8).copy()).to(device), start)
