@@ -110,8 +110,7 @@ int styler_conv_gemm_pad(const float* x, int64_t ldx, const void* w, const float
                          void* stream);
 
 /* Which tile engine styler_conv_gemm dispatches for a shape: bit0 = 128x128 block tile (else
- * 64x64), bit1 = bf16 MFMA (else fp32 MFMA), bit2 = the A-stationary short-K kernel (kw = 1, cin <= 256, bf16 mode,
- * >= 8192 rows: one block keeps a 128-row activation tile in LDS for all of n).  Used by bench.py to attribute launches. */
+ * 64x64), bit1 = bf16 MFMA (else fp32 MFMA).  Used by bench.py to attribute launches. */
 int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, int prec);
 
 /* fp32 -> bf16 (round-to-nearest-even) weight shadow for STYLER_PREC_BF16 */

@@ -382,249 +382,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// A-stationary GEMM for short K (kw = 1, cin <= 256, bf16 MFMA): y[m, :] = act(scale * x[m, :] W^T + shift) (+ res).
-//
-// On the 128 x 128 engine above a K = 256 problem is four k-steps per block, each gated by one L2 / HBM round trip, then an
-// epilogue: the QKV / output projections and the k = 1 dX GEMMs of the FFT blocks ran at 2.7 TB/s of their own bytes and
-// 7-12 % of the MFMA peak however the operands were stored (profiles/r02_gemm_io_storage.txt).  Here ONE block owns a
-// 128-row tile of x for ALL of n: the whole [128 x K] activation tile is fetched once (every load of the block in flight at
-// once: a single latency exposure), converted to bf16 and kept in LDS; the block then walks the n-tiles of 64 columns,
-// streaming W (L2-resident: <= 512 KB) through a double-buffered LDS tile whose loads are issued one n-tile ahead, and
-// stores each [128 x 64] result straight from the accumulators (a lane owns one column: bias / scale are scalars, the
-// 32 lanes of a half-wave write one 128-byte row segment).  x is read from HBM exactly once and y written once: the launch
-// is bound by those bytes.  One block per CU (147 KB of LDS), 4 waves as 2 x 2, wave tile 64 x 32.
-// EXTRA: the epilogue has optional inputs (residual, ReLU mask, per-item length mask); without it the epilogue is 32 plain
-// stores per n-tile.  Packed rows (rowinfo) need no length mask: rows behind the data are never read.
-template <bool A16, bool Y16, bool EXTRA>
-__global__ __launch_bounds__(256) void gemm_astat_kernel(GemmArgs a) {
-  constexpr int BM = 128, BN = 64, LD = 36, KC = 4;              // KC planes of 64 channels
-  __shared__ __attribute__((aligned(16))) uint32_t smem[KC * BM * LD + 2 * KC * BN * LD];
-  uint32_t* const sA = smem;                                     // [KC][BM][LD]
-  uint32_t* const sB = smem + KC * BM * LD;                      // 2 x [KC][BN][LD]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
-  const int64_t M = (int64_t)a.B * a.L;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
-  const int ncc = (a.cin + 63) / 64;
-  const int ntn = (a.n + BN - 1) / BN;
-  if (a.len) {                                                   // tiles behind the (packed) data: see conv_gemm_kernel
-    const int64_t m1 = (m0 + BM < M ? m0 + BM : M) - 1;
-    const int64_t b0 = m0 / a.L;
-    if (b0 == m1 / a.L && m0 - b0 * a.L >= a.len[b0]) {
-      if (a.rowinfo) return;
-      for (int i = tid; i < BM * (a.n / 4); i += 256) {
-        const int r = i / (a.n / 4), c = (i - r * (a.n / 4)) * 4;
-        if (m0 + r < M) {
-          if (Y16) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.y) + (m0 + r) * a.ldy + c) = make_uint2(0u, 0u);
-          else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (m0 + r) * a.ldy + c) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
-      return;
-    }
-  }
-  constexpr uint32_t OOB = 0x80000000u;
-  constexpr int64_t REC_MAX = (int64_t)1 << 30;
-  // ---- activation tile: every chunk's loads in flight together ----
-  constexpr int A_EPV = A16 ? 8 : 4, A_ES = A16 ? 2 : 4, A_V = 64 / A_EPV, A_RPP = 256 / A_V, A_P = BM / A_RPP;
-  {
-    const int a_col = (tid % A_V) * A_EPV, a_r0 = tid / A_V;
-    i32x4 ra[KC][A_P];
-    int64_t arec = ((M - m0 - 1) * a.ldx + a.cin) * A_ES;
-    arec = arec > REC_MAX ? REC_MAX : arec;
-    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(a.x) + m0 * a.ldx * A_ES), 0, (int)arec, 0x00020000);
-#pragma unroll
-    for (int cc = 0; cc < KC; ++cc) {
-      if (cc >= ncc) break;
-      const int c0 = cc * 64;
-      const uint32_t v = c0 + a_col < a.cin ? (uint32_t)((a_r0 * (int)a.ldx + c0 + a_col) * A_ES) : OOB;
-#pragma unroll
-      for (int p = 0; p < A_P; ++p)
-        ra[cc][p] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, v + (uint32_t)(p * A_RPP * (int)a.ldx * A_ES), 0, 0);
-    }
-#pragma unroll
-    for (int cc = 0; cc < KC; ++cc) {
-      if (cc >= ncc) break;
-      uint32_t* dst = sA + cc * BM * LD + a_r0 * LD + (A16 ? a_col / 2 : a_col / 2);
-#pragma unroll
-      for (int p = 0; p < A_P; ++p) {
-        if (A16) {
-          *reinterpret_cast<i32x4*>(&dst[p * A_RPP * LD]) = ra[cc][p];
-        } else {
-          const float4 f = *reinterpret_cast<const float4*>(&ra[cc][p]);
-          *reinterpret_cast<uint2*>(&dst[p * A_RPP * LD]) = make_uint2(cvt_pk_bf16(f.x, f.y), cvt_pk_bf16(f.z, f.w));
-        }
-      }
-    }
-  }
-  // ---- weight tile loader: [BN rows of W] x [cin] bf16, 8 sixteen-byte vectors per (row, chunk) ----
-  const int b_col = (tid & 7) * 8, b_r0 = tid >> 3;              // 32 rows per pass, 2 passes per chunk
-  uint4 rb[KC][2];
-  const int ktot = a.cin;
-  auto load_b = [&](int nt) {
-    const int n0 = nt * BN;
-    int64_t rec = ((int64_t)(a.n - n0 - 1) * ktot + a.cin) * 2;
-    rec = rec > REC_MAX ? REC_MAX : rec;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(a.w) + (int64_t)n0 * ktot * 2), 0, (int)rec, 0x00020000);
-#pragma unroll
-    for (int cc = 0; cc < KC; ++cc) {
-      if (cc >= ncc) break;
-      const int c0 = cc * 64;
-      const uint32_t v = c0 + b_col < a.cin ? (uint32_t)((b_r0 * ktot + c0 + b_col) * 2) : OOB;
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const i32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v + (uint32_t)(p * 32 * ktot * 2), 0, 0);
-        rb[cc][p] = *reinterpret_cast<const uint4*>(&t);
-      }
-    }
-  };
-  auto store_b = [&](int buf) {
-#pragma unroll
-    for (int cc = 0; cc < KC; ++cc) {
-      if (cc >= ncc) break;
-      uint32_t* dst = sB + (buf * KC + cc) * BN * LD + b_r0 * LD + (tid & 7) * 4;
-#pragma unroll
-      for (int p = 0; p < 2; ++p) *reinterpret_cast<uint4*>(&dst[p * 32 * LD]) = rb[cc][p];
-    }
-  };
-  load_b(0);
-  store_b(0);
-  __syncthreads();
-
-  const uint32_t fa_off = (wm * 64 + li) * LD + lh * 4;
-  const uint32_t fb_off = (wn * 32 + li) * LD + lh * 4;
-  const int actc = a.act & 0xff;
-  const bool res_first = a.act & STYLER_ACT_RES_FIRST;
-  for (int nt = 0; nt < ntn; ++nt) {
-    const bool more = nt + 1 < ntn;
-    if (more) load_b(nt + 1);
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    const uint32_t* cB = sB + (nt & 1) * KC * BN * LD + fb_off;
-#pragma unroll
-    for (int cc = 0; cc < KC; ++cc) {
-      if (cc >= ncc) break;
-      const uint32_t* pa = sA + cc * BM * LD + fa_off;
-      const uint32_t* pb = cB + cc * BN * LD;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(&pb[s * 8]);
-        const bf16x8 f0 = *reinterpret_cast<const bf16x8*>(&pa[s * 8]);
-        const bf16x8 f1 = *reinterpret_cast<const bf16x8*>(&pa[32 * LD + s * 8]);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, fb, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, fb, acc[1], 0, 0, 0);
-      }
-    }
-    // the next weight tile goes to LDS BEFORE this tile's results are stored: stores and loads share the in-order memory
-    // counter, so waiting for the prefetched loads behind 32 fresh stores would wait for the stores' round trip as well
-    // (first version: 4.6 us per n-tile); placed here the loads had the MFMA phase to land and the stores drain behind the
-    // next tile's MFMAs
-    if (more) store_b((nt + 1) & 1);
-    // ---- epilogue from the accumulators: lane = column, register r = row (r&3) + 8 (r>>2) + 4 lh ----
-    // Optional inputs (residual, ReLU mask, length mask) are fetched in a load phase of their own under block-uniform
-    // branches: a conditional load per element makes the compiler wait for ALL outstanding memory operations -- the
-    // previous element's store and the prefetched weight tile included -- 32 times per n-tile (first version: 9 us each).
-    const int col = nt * BN + wn * 32 + li;
-    if (col < a.n) {
-      const float sc = a.scale ? a.scale[col] : 1.f, sf = a.shift ? a.shift[col] : 0.f;
-      float extra[2][16];                            // residual values
-      uint32_t keep = 0xffffffffu;                   // bit (i * 16 + r): element survives the masks
-      if constexpr (EXTRA) {
-        const int64_t rmax = M - 1;
-        if (a.res) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-              row = row < rmax ? row : rmax;         // clamped: the load is unconditional, the store below is guarded
-              extra[i][r] = a.res[row * a.ldres + col];
-            }
-        }
-        if (a.mask) {                                // all 32 loads first, then the bit tests: one wait for the lot
-          if (a.mask16) {
-            uint16_t mk[2][16];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                row = row < rmax ? row : rmax;
-                mk[i][r] = reinterpret_cast<const uint16_t*>(a.mask)[row * a.ldmask + col];
-              }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) keep &= (int16_t)mk[i][r] > 0 ? 0xffffffffu : ~(1u << (i * 16 + r));
-          } else {
-            float mk[2][16];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                row = row < rmax ? row : rmax;
-                mk[i][r] = reinterpret_cast<const float*>(a.mask)[row * a.ldmask + col];
-              }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) keep &= mk[i][r] > 0.f ? 0xffffffffu : ~(1u << (i * 16 + r));
-          }
-        }
-        if (a.len && !a.rowinfo) {
-          const int64_t b0 = m0 / a.L;               // one 64-bit division per block; rows use 32-bit arithmetic
-          const uint32_t base = (uint32_t)(m0 - b0 * a.L), Lu = (uint32_t)a.L;
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const uint32_t rel = base + (uint32_t)(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
-              const uint32_t db = rel / Lu;
-              int64_t b = b0 + db;
-              b = b < a.B ? b : a.B - 1;
-              const bool ok = (int64_t)(rel - db * Lu) < a.len[b];
-              keep &= ok ? 0xffffffffu : ~(1u << (i * 16 + r));
-            }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          float v = acc[i][r];
-          if constexpr (EXTRA) { if (a.res && res_first) v += extra[i][r]; }
-          v = apply_act(v * sc + sf, actc);
-          if constexpr (EXTRA) {
-            if (a.res && !res_first) v += extra[i][r];
-            v = ((keep >> (i * 16 + r)) & 1u) ? v : 0.f;
-          }
-          if (row < M) {
-            if (Y16) reinterpret_cast<uint16_t*>(a.y)[row * a.ldy + col] = (uint16_t)(cvt_pk_bf16(v, 0.f) & 0xffffu);
-            else reinterpret_cast<float*>(a.y)[row * a.ldy + col] = v;
-          }
-        }
-    }
-    __syncthreads();
-  }
-}
-
-// Does the A-stationary kernel take this problem?  (STYLER_GEMM_ASTAT=0 switches it off for A/B runs.)
-static bool use_astat_shape(int64_t M, int cin, int n, int kw, int prec) {
-  static const int env = [] { const char* e = getenv("STYLER_GEMM_ASTAT"); return e ? atoi(e) : 1; }();
-  if (!env || prec != STYLER_PREC_BF16 || kw != 1) return false;
-  return cin <= 256 && n >= 64 && M >= 8192;
-}
-static bool use_astat(const GemmArgs& a, int prec) {
-  return use_astat_shape((int64_t)a.B * a.L, a.cin, a.n, a.kw, prec);
-}
-
 template <int TM, int TN, bool BF16>
 static int launch_gemm(GemmArgs a, hipStream_t st, int x16, int y16) {
   const int64_t M = (int64_t)a.B * a.L;
@@ -659,10 +416,9 @@ static int launch_gemm(GemmArgs a, hipStream_t st, int x16, int y16) {
 
 // Tile choice: the 128x128 tile needs >= ~1 block per CU to pay; otherwise 64x64 (4x the blocks).
 // Returns bit0 = 128x128 tile (else 64x64), bit1 = bf16 MFMA (else fp32 MFMA).
-static bool use_astat_shape(int64_t M, int cin, int n, int kw, int prec);
 extern "C" int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, int prec) {
+  (void)cin; (void)kw;
   const int64_t M = (int64_t)B * L;
-  if (use_astat_shape(M, cin, n, kw, prec)) return 4 | 2;        // bit2: the A-stationary short-K kernel (bf16 only)
   const int64_t big_blocks = ((M + 127) / 128) * ((n + 127) / 128);
   int big = (big_blocks >= 192 && n >= 96) ? 1 : 0;
   static const int force = [] { const char* e = getenv("STYLER_GEMM_TILE"); return e ? atoi(e) : 0; }();
@@ -701,16 +457,6 @@ int styler_conv_gemm_impl2(const float* x, int64_t ldx, const void* w, const flo
   GemmArgs a{x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, act, pad, len, 0, 0,
              reinterpret_cast<const int2*>(rowinfo), mask, ldmask, m16 ? 1 : 0};
   hipStream_t st = (hipStream_t)stream;
-  if (use_astat(a, prec)) {
-    const int64_t M = (int64_t)B * L;
-    const dim3 grid((unsigned)((M + 127) / 128));
-    const bool extra = a.res || a.mask || (a.len && !a.rowinfo);
-#define ASTAT(A_, Y_) do { if (extra) hipLaunchKernelGGL((gemm_astat_kernel<A_, Y_, true>), grid, dim3(256), 0, st, a); \
-                           else hipLaunchKernelGGL((gemm_astat_kernel<A_, Y_, false>), grid, dim3(256), 0, st, a); } while (0)
-    if (x16 && y16) ASTAT(true, true); else if (x16) ASTAT(true, false); else if (y16) ASTAT(false, true); else ASTAT(false, false);
-#undef ASTAT
-    return launch_status();
-  }
   const bool big = styler_conv_gemm_variant(B, L, cin, n, kw, prec) & 1;
   if (prec == STYLER_PREC_BF16) return big ? launch_gemm<2, 2, true>(a, st, x16, y16) : launch_gemm<1, 1, true>(a, st, x16, y16);
   return big ? launch_gemm<2, 2, false>(a, st, x16, y16) : launch_gemm<1, 1, false>(a, st, x16, y16);
