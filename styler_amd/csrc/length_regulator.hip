@@ -82,23 +82,35 @@ __global__ __launch_bounds__(256) void length_regulate_kernel(const float* __res
   const int32_t* c = in_lds ? cs : gcs;
   const int total = c[S - 1];
   const int t0 = blockIdx.x * LR_TT;
-  for (int f = wave; f < LR_TT; f += 4) {
-    const int t = t0 + f;
-    if (t >= T) break;
-    int idx = -1;
-    if (t < total) {                                  // upper bound: first i with csum[i] > t
+  // A wave owns 8 consecutive frames.  Their source rows are found by 8 lanes in parallel (one binary search each, not
+  // the same search repeated by all 64 lanes frame after frame) and broadcast; the copy then keeps the 8 frames' loads of
+  // a 1 KB column chunk in flight together before the 8 stores (frame by frame, every 16-byte load was a dependent round
+  // trip in front of its store: 3.2 TB/s).
+  constexpr int FPW = LR_TT / 4;                      // frames per wave
+  const int tw = t0 + wave * FPW;
+  int my_idx = -1;
+  if (lane < FPW) {
+    const int t = tw + lane;
+    if (t < T && t < total) {                         // upper bound: first i with csum[i] > t
       int lo = 0, hi = S - 1;
       while (lo < hi) { const int mid = (lo + hi) >> 1; if (c[mid] > t) hi = mid; else lo = mid + 1; }
-      idx = lo;
+      my_idx = lo;
     }
-    float* op = out + ((int64_t)b * T + t) * ldo;
-    if (idx >= 0) {
-      const float* xp = x + ((int64_t)b * S + idx) * ldx;
-      for (int q = lane * 4; q < C; q += 256) *reinterpret_cast<float4*>(op + q) = *reinterpret_cast<const float4*>(xp + q);
-    } else {
-      for (int q = lane * 4; q < C; q += 256) *reinterpret_cast<float4*>(op + q) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (frame_idx && lane == 0) frame_idx[(int64_t)b * T + t] = idx;
+    if (frame_idx && t < T) frame_idx[(int64_t)b * T + t] = my_idx;
+  }
+  int idx[FPW];
+#pragma unroll
+  for (int k = 0; k < FPW; ++k) idx[k] = __shfl(my_idx, k, 64);
+  const float* xb = x + (int64_t)b * S * ldx;
+  float* ob = out + ((int64_t)b * T + tw) * ldo;
+  for (int q = lane * 4; q < C; q += 256) {
+    float4 v[FPW];
+#pragma unroll
+    for (int k = 0; k < FPW; ++k)
+      v[k] = idx[k] >= 0 ? *reinterpret_cast<const float4*>(xb + (int64_t)idx[k] * ldx + q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < FPW; ++k)
+      if (tw + k < T) *reinterpret_cast<float4*>(ob + (int64_t)k * ldo + q) = v[k];
   }
 }
 
