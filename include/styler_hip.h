@@ -112,6 +112,10 @@ int styler_conv_gemm_pad(const float* x, int64_t ldx, const void* w, const float
 /* Which tile engine styler_conv_gemm dispatches for a shape: bit0 = 128x128 block tile (else
  * 64x64), bit1 = bf16 MFMA (else fp32 MFMA).  Used by bench.py to attribute launches. */
 int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, int prec);
+/* Measurement hook (tools/gemm_trace.py): while `buf` is non-null every styler_conv_gemm block writes 8 uint64 words at
+ * buf[8 * blockIdx]: block, then 100 MHz timestamps at entry / first tile staged / main loop done / stores issued /
+ * stores acknowledged, the hardware id register and the tile index.  Pass NULL to switch it off (the default). */
+int styler_gemm_set_trace(void* buf);
 
 /* fp32 -> bf16 (round-to-nearest-even) weight shadow for STYLER_PREC_BF16 */
 int styler_cast_bf16(const float* src, uint16_t* dst, int64_t count, void* stream);

@@ -28,6 +28,7 @@
 #include "common.h"
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 struct GemmArgs {
   const void* x; int64_t ldx;                      // fp32, or bf16 with the A16 kernels (ldx in elements either way)
@@ -41,7 +42,14 @@ struct GemmArgs {
   const int2* rowinfo;                             // packed rows (styler_pack_plan): (t, len - 1 - t) per row, or null
   const void* mask; int64_t ldmask;                // epilogue: v = mask[row, col] > 0 ? v : 0 (ReLU backward), or null
   int mask16;                                      // the mask tensor is bf16
+  uint64_t* trace;                                 // styler_gemm_set_trace: 8 words per block (phase timestamps), or null
 };
+
+// Phase timestamps (constant 100 MHz counter, s_memrealtime) of every block of the launches that follow
+// styler_gemm_set_trace(buf): [block, entry, first tile staged, main loop done, stores issued, stores acknowledged,
+// hardware id, tile].  A measurement hook (tools/gemm_trace.py), off (null) by default.
+static uint64_t* g_gemm_trace = nullptr;
+extern "C" int styler_gemm_set_trace(void* buf) { g_gemm_trace = reinterpret_cast<uint64_t*>(buf); return 0; }
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   return cvt_pk_bf16_rne(lo, hi);
@@ -88,6 +96,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
+  uint64_t stamp[5];
+  if (a.trace) stamp[0] = wall_clock64();
 
   // ---- XCD-aware tile assignment: workgroup b runs on XCD b % 8 (observed dispatch rule, speed only).  M-tiles are
   // dealt round-robin to the XCDs and an XCD walks the n-tiles of its m-tile back to back, so the n-tiles that share an
@@ -113,9 +123,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
   // ---- tiles made only of rows at or past their item's length produce zeros: write them and leave (in the packed
   // decoder layout B = 1 and len[0] = the number of packed rows: every tile behind the data is skipped) ----
   if (a.len) {
-    const int64_t m1 = (m0 + BM < M ? m0 + BM : M) - 1;
-    const int64_t b0 = m0 / a.L;
-    if (b0 == m1 / a.L && m0 - b0 * a.L >= a.len[b0]) {
+    // (32-bit arithmetic: the host side rejects B * L >= 2^31)
+    const uint32_t span = (uint32_t)((m0 + BM < M ? m0 + BM : M) - 1 - m0);
+    const uint32_t b0 = (uint32_t)m0 / (uint32_t)a.L, t0 = (uint32_t)m0 - b0 * (uint32_t)a.L;
+    if (t0 + span < (uint32_t)a.L && (int64_t)t0 >= a.len[b0]) {
       // packed rows: nothing behind the data is ever read (every consumer is bounded by the same row counter), so the
       // tile is not even zero-filled -- that fill was 36 % of the output bytes of every decoder GEMM at VCTK shapes
       if (a.rowinfo) return;
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     if (!KW1 && m < M) {
       int t, rem;                                    // rows before / after this one inside its item
       if (a.rowinfo) { const int2 ri = a.rowinfo[m]; t = ri.x; rem = ri.y; }
-      else { t = (int)(m % a.L); rem = a.L - 1 - t; }
+      else { t = (int)((uint32_t)m % (uint32_t)a.L); rem = a.L - 1 - t; }
       for (int j = 0; j < kw; ++j) {
         const int o = j - pad;
         if (o >= -t && o <= rem) bits |= 1u << j;
@@ -242,6 +253,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
   store_a(0);
   store_b(0);
   __syncthreads();
+  if (a.trace) stamp[1] = wall_clock64();
 
   int cc = 0, j = 0;
   for (int step = 0; step < nsteps; ++step) {
@@ -311,73 +323,177 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     cc = ccn; j = jn;
   }
 
+  if (a.trace) stamp[2] = wall_clock64();
   // ---- epilogue: accumulators -> per-wave LDS tile -> coalesced float4 rows ----
   // C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  //
+  // Everything the tail needs from memory (residual, ReLU mask, item lengths) is fetched in batches of up to 8 rows per
+  // lane BEFORE the rows are finished and stored: a load placed next to its row's store waits on vmcnt(0), which also waits
+  // for the previous row's store to be acknowledged -- one memory round trip per row, 16 rows per lane, was most of the
+  // life of a short-K block.  Rows and columns outside the tensor are dropped by the buffer descriptors (rows past M are
+  // past num_records; lanes whose columns are past n carry an out-of-range offset), so no lane branches.  The activation
+  // is a template argument of the tail (one uniform switch per block instead of a branch ladder per element).
   constexpr int LPR = 8 * TN;                      // lanes per output row (float4 each)
   constexpr int RPP = 64 / LPR;                    // rows per pass
   constexpr int ROWS_H = 32 * TM / EPI_H;          // tile rows staged per epilogue pass
+  constexpr int NP = ROWS_H / RPP;                 // rows per lane per pass
+  constexpr int UB = OCC3 ? 4 : (NP > 8 ? 8 : NP); // rows per batch (the occupancy-3 kernels must stay within 168 registers)
+  constexpr int NPT = NP * EPI_H;                  // rows per lane per tile
+  constexpr int Y_ES = Y16 ? 2 : 4;
   float* cst = reinterpret_cast<float*>(smem) + wave * (ROWS_H * CLD);
+  const int lrow = lane / LPR;
   const int c4 = (lane % LPR) * 4;
   const int col = n0 + wn * 32 * TN + c4;
+  const bool col_ok = col < a.n;
+  const int wrow0 = wm * 32 * TM + lrow;           // tile-relative row of this lane's first row
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (col < a.n) {
+  if (col_ok) {
     if (a.scale) sc = *reinterpret_cast<const float4*>(a.scale + col);
     if (a.shift) sf = *reinterpret_cast<const float4*>(a.shift + col);
   }
+  const bool res_first = a.act & STYLER_ACT_RES_FIRST;
+  const int actc = a.act & 0xff;
+
+  // bit p of `live`: the lane's p-th row lies inside its item's length (rows at or past it are written as zeros)
+  uint32_t live = 0xffffffffu;
+  if (a.len) {
+    live = 0u;
+    if (a.B == 1) {                                  // packed rows / a single item: one uniform bound
+      int64_t lim64 = a.len[0] - m0;
+      const int lim = lim64 > BM ? BM : (lim64 < 0 ? 0 : (int)lim64);
 #pragma unroll
-  for (int hh = 0; hh < EPI_H; ++hh) {
-    if (hh) __syncthreads();
-    static_assert(EPI_H == 1 || TM == 2, "two-pass epilogue stages one 32-row MFMA tile row per pass");
+      for (int p = 0; p < NPT; ++p) live |= (uint32_t)(wrow0 + p * RPP < lim) << p;
+    } else {
+      const uint32_t Lu = (uint32_t)a.L;
+      const uint32_t magic = 0xffffffffu / Lu;       // floor(n / L) = umulhi(n, magic) or that + 1 (one fix-up)
+      const uint32_t b0 = (uint32_t)m0 / Lu, t0 = (uint32_t)m0 - b0 * Lu;
+      uint32_t rem[NPT];
+      int lv[NPT];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      if (EPI_H == 2 && i != hh) continue;
+      for (int p = 0; p < NPT; ++p) {
+        const uint32_t nn = t0 + (uint32_t)(wrow0 + p * RPP);
+        uint32_t q = __umulhi(nn, magic), r = nn - q * Lu;
+        if (r >= Lu) { ++q; r -= Lu; }
+        uint32_t bi = b0 + q;
+        bi = bi < (uint32_t)a.B ? bi : (uint32_t)a.B - 1u;        // rows past M are dropped by the store anyway
+        rem[p] = r;
+        lv[p] = reinterpret_cast<const int*>(a.len)[2 * bi];      // low dword of the int64 length
+      }
 #pragma unroll
-      for (int jj = 0; jj < TN; ++jj)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          cst[((EPI_H == 2 ? 0 : i * 32) + (r & 3) + 8 * (r >> 2) + 4 * lh) * CLD + jj * 32 + li] = acc[i][jj][r];
+      for (int p = 0; p < NPT; ++p) live |= (uint32_t)((int)rem[p] < lv[p]) << p;
     }
-    __syncthreads();
-    if (col < a.n) {
-#pragma unroll 4
-      for (int p = 0; p < ROWS_H / RPP; ++p) {
-        const int rl = p * RPP + lane / LPR;
-        const int64_t row = m0 + wm * 32 * TM + hh * ROWS_H + rl;
-        if (row >= M) break;
-        float4 v = *reinterpret_cast<const float4*>(&cst[rl * CLD + c4]);
-        const bool res_first = a.act & STYLER_ACT_RES_FIRST;
-        const int actc = a.act & 0xff;
-        if (res_first && a.res) {                     // partial sums of a multi-call convolution: joined before the tail
-          const float4 rr = *reinterpret_cast<const float4*>(a.res + row * a.ldres + col);
-          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+  }
+
+  // descriptors relative to the tile's first row: rows at or past M start at or past num_records
+  auto tile_rsrc = [&](const void* base, int64_t ld, int es) {
+    int64_t rec = ((M - m0 - 1) * ld + a.n) * es;
+    rec = rec > REC_MAX ? REC_MAX : rec;
+    const char* b = reinterpret_cast<const char*>(base) + m0 * ld * es;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b), 0, (int)rec, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t y_rs = tile_rsrc(a.y, a.ldy, Y_ES);
+  const __amdgpu_buffer_rsrc_t r_rs = tile_rsrc(a.res ? (const void*)a.res : a.y, a.res ? a.ldres : a.ldy, 4);
+  const int m_es = a.mask16 ? 2 : 4;
+  const __amdgpu_buffer_rsrc_t m_rs = tile_rsrc(a.mask ? a.mask : a.y, a.mask ? a.ldmask : a.ldy, a.mask ? m_es : Y_ES);
+  const uint32_t oy0 = col_ok ? (uint32_t)((wrow0 * (int)a.ldy + col) * Y_ES) : OOB;
+  const uint32_t or0 = col_ok ? (uint32_t)((wrow0 * (int)a.ldres + col) * 4) : OOB;
+  const uint32_t om0 = col_ok ? (uint32_t)((wrow0 * (int)a.ldmask + col) * m_es) : OOB;
+  const uint32_t ystep = (uint32_t)(RPP * (int)a.ldy * Y_ES), rstep = (uint32_t)(RPP * (int)a.ldres * 4),
+                 mstep = (uint32_t)(RPP * (int)a.ldmask * m_es);
+
+  auto tail = [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+    for (int hh = 0; hh < EPI_H; ++hh) {
+      if (hh) __syncthreads();
+      static_assert(EPI_H == 1 || TM == 2, "two-pass epilogue stages one 32-row MFMA tile row per pass");
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (EPI_H == 2 && i != hh) continue;
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            cst[((EPI_H == 2 ? 0 : i * 32) + (r & 3) + 8 * (r >> 2) + 4 * lh) * CLD + jj * 32 + li] = acc[i][jj][r];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int pb = 0; pb < NP / UB; ++pb) {
+        const int p0 = hh * NP + pb * UB;            // index of the batch's first row among the lane's rows
+        i32x4 rr[UB], mk[UB];
+        if (a.res) {
+#pragma unroll
+          for (int u = 0; u < UB; ++u) rr[u] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, or0 + (p0 + u) * rstep, 0, 0);
         }
-        v.x = apply_act(v.x * sc.x + sf.x, actc); v.y = apply_act(v.y * sc.y + sf.y, actc);
-        v.z = apply_act(v.z * sc.z + sf.z, actc); v.w = apply_act(v.w * sc.w + sf.w, actc);
-        if (a.mask) {                                 // dX of a ReLU layer: gradient only where the forward output was > 0
-          if (a.mask16) {                             // bf16 mask: positive <=> sign clear and magnitude non-zero
-            const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(a.mask) + row * a.ldmask + col);
-            v.x = (int16_t)(mk.x & 0xffffu) > 0 ? v.x : 0.f; v.y = (int16_t)(mk.x >> 16) > 0 ? v.y : 0.f;
-            v.z = (int16_t)(mk.y & 0xffffu) > 0 ? v.z : 0.f; v.w = (int16_t)(mk.y >> 16) > 0 ? v.w : 0.f;
+        if (a.mask) {
+          if (a.mask16) {
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+              const i32x2 t = __builtin_amdgcn_raw_buffer_load_b64(m_rs, om0 + (p0 + u) * mstep, 0, 0);
+              mk[u] = i32x4{t.x, t.y, 0, 0};
+            }
           } else {
-            const float4 mk = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.mask) + row * a.ldmask + col);
-            v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
-            v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+#pragma unroll
+            for (int u = 0; u < UB; ++u) mk[u] = __builtin_amdgcn_raw_buffer_load_b128(m_rs, om0 + (p0 + u) * mstep, 0, 0);
           }
         }
-        if (a.res && !res_first) {
-          const float4 rr = *reinterpret_cast<const float4*>(a.res + row * a.ldres + col);
-          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        float4 v[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) v[u] = *reinterpret_cast<const float4*>(&cst[((pb * UB + u) * RPP + lrow) * CLD + c4]);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          float4 w = v[u];
+          if (res_first && a.res) {                   // partial sums of a multi-call convolution: joined before the tail
+            const float4 q = *reinterpret_cast<const float4*>(&rr[u]);
+            w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w;
+          }
+          w.x = apply_act(w.x * sc.x + sf.x, ACT); w.y = apply_act(w.y * sc.y + sf.y, ACT);
+          w.z = apply_act(w.z * sc.z + sf.z, ACT); w.w = apply_act(w.w * sc.w + sf.w, ACT);
+          if (a.mask) {                               // dX of a ReLU layer: gradient only where the forward output was > 0
+            if (a.mask16) {                           // bf16 mask: positive <=> sign clear and magnitude non-zero
+              const uint32_t m0w = (uint32_t)mk[u].x, m1w = (uint32_t)mk[u].y;
+              w.x = (int16_t)(m0w & 0xffffu) > 0 ? w.x : 0.f; w.y = (int16_t)(m0w >> 16) > 0 ? w.y : 0.f;
+              w.z = (int16_t)(m1w & 0xffffu) > 0 ? w.z : 0.f; w.w = (int16_t)(m1w >> 16) > 0 ? w.w : 0.f;
+            } else {
+              const float4 q = *reinterpret_cast<const float4*>(&mk[u]);
+              w.x = q.x > 0.f ? w.x : 0.f; w.y = q.y > 0.f ? w.y : 0.f;
+              w.z = q.z > 0.f ? w.z : 0.f; w.w = q.w > 0.f ? w.w : 0.f;
+            }
+          }
+          if (a.res && !res_first) {
+            const float4 q = *reinterpret_cast<const float4*>(&rr[u]);
+            w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w;
+          }
+          if (!((live >> (p0 + u)) & 1u)) w = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (Y16) {
+            const i32x2 o = {(int)cvt_pk_bf16(w.x, w.y), (int)cvt_pk_bf16(w.z, w.w)};
+            __builtin_amdgcn_raw_buffer_store_b64(o, y_rs, oy0 + (p0 + u) * ystep, 0, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const i32x4*>(&w), y_rs, oy0 + (p0 + u) * ystep, 0, 0);
+          }
         }
-        if (a.len) {
-          const int64_t b = row / a.L;
-          if ((row - b * a.L) >= a.len[b]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (Y16)
-          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.y) + row * a.ldy + col) =
-              make_uint2(cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w));
-        else
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + row * a.ldy + col) = v;
       }
+    }
+  };
+  switch (actc) {
+    case STYLER_ACT_RELU: tail(std::integral_constant<int, STYLER_ACT_RELU>{}); break;
+    case STYLER_ACT_TANH: tail(std::integral_constant<int, STYLER_ACT_TANH>{}); break;
+    case STYLER_ACT_LOGCLAMP: tail(std::integral_constant<int, STYLER_ACT_LOGCLAMP>{}); break;
+    case STYLER_ACT_LEAKY: tail(std::integral_constant<int, STYLER_ACT_LEAKY>{}); break;
+    case STYLER_ACT_CRELU: tail(std::integral_constant<int, STYLER_ACT_CRELU>{}); break;
+    default: tail(std::integral_constant<int, STYLER_ACT_NONE>{}); break;
+  }
+  if (a.trace) {
+    stamp[3] = wall_clock64();
+    __builtin_amdgcn_s_waitcnt(0);                   // every store of this wave acknowledged
+    stamp[4] = wall_clock64();
+    if (tid == 0) {
+      uint64_t* t = a.trace + (int64_t)blockIdx.x * 8;
+      t[0] = blockIdx.x;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) t[1 + i] = stamp[i];
+      t[6] = __builtin_amdgcn_s_getreg((3 << 11) | 4);   // HW_ID (wave, simd, cu, sh, se)
+      t[7] = (uint64_t)tile;
     }
   }
 }
@@ -453,9 +569,10 @@ int styler_conv_gemm_impl2(const float* x, int64_t ldx, const void* w, const flo
   if ((n & 3) || (ldy & 3) || ((uintptr_t)y & 15) || (res && ((ldres & 3) || ((uintptr_t)res & 15)))) return STYLER_EALIGN;
   if (prec == STYLER_PREC_BF16 && (cin & 7)) return STYLER_EALIGN;
   if (rowinfo && B != 1) return STYLER_EINVAL;
+  if ((int64_t)B * L >= ((int64_t)1 << 31) || ldy >= (1 << 22) || ldres >= (1 << 22) || ldmask >= (1 << 22)) return STYLER_EINVAL;
   if (mask && ((ldmask & 3) || ((uintptr_t)mask & 15))) return STYLER_EALIGN;
   GemmArgs a{x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, act, pad, len, 0, 0,
-             reinterpret_cast<const int2*>(rowinfo), mask, ldmask, m16 ? 1 : 0};
+             reinterpret_cast<const int2*>(rowinfo), mask, ldmask, m16 ? 1 : 0, g_gemm_trace};
   hipStream_t st = (hipStream_t)stream;
   const bool big = styler_conv_gemm_variant(B, L, cin, n, kw, prec) & 1;
   if (prec == STYLER_PREC_BF16) return big ? launch_gemm<2, 2, true>(a, st, x16, y16) : launch_gemm<1, 1, true>(a, st, x16, y16);
