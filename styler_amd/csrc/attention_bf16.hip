@@ -7,12 +7,21 @@
 // the key (or query) axis (P V, dS K, P^T dO, dS^T Q) the register operand is the packed P / dS accumulator, whose lane
 // holds rows (r&3) + 8*(r>>2) + 4*h of the 32-row block; MFMA step s2 takes registers 8*s2 .. 8*s2+7, i.e. the rows
 // {16*s2 + 4h + 0..3} and {16*s2 + 8 + 4h + 0..3}.  The k <-> row map only has to agree between the two operands, so the
-// LDS operand is a TRANSPOSED tile [d][row] read as two ds_read_b64 at exactly those two row runs -- no shuffles.
-// Transposed tiles are produced while staging by an in-register 8x4 transpose (8 float4 rows -> 4 x ds_write_b128).
+// LDS operand is the SAME row-major tile read through gfx950's LDS transpose read (ds_read_b64_tr_b16: a 16-lane group
+// addresses a [4 rows][16 features] block and every lane receives the 4 rows of ITS feature): two reads at exactly
+// those two row runs -- no transposed copy of any tile exists, not in LDS and not in registers.
+//
+// Tiles are fetched with raw buffer loads against a per-item descriptor (rows at or past the item's length are past
+// num_records and read as zeros): no lane branches, so all loads of a tile are in flight together and ONE wait precedes
+// the LDS stores.  (Conditional loads compiled to a branch + s_waitcnt vmcnt(0) per load: 5 serial memory round trips
+// per tile in the forward, 8 -- plus scratch traffic -- in the dK/dV kernel.)
 #include "common.h"
 
 #define AD 64
 #define ALD 36            // dwords per LDS row (64 bf16 + 16 B pad)
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t cvtpk(float lo, float hi) {
   return cvt_pk_bf16_rne(lo, hi);
@@ -34,83 +43,40 @@ __device__ __forceinline__ bf16x8 pack_acc(const f32x16& a, int s2) {
   return *reinterpret_cast<bf16x8*>(&v);
 }
 
-// row-major tile: 64 rows x 64 floats (global row stride ld, column offset folded into src) -> bf16 [64][ALD]
-__device__ __forceinline__ void stage_rows(uint32_t* dst, const float* src, int64_t ld, int row0, int nrows_valid, int tid) {
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int idx = tid + p * 256;
-    const int r = idx >> 4, c4 = (idx & 15) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row0 + r < nrows_valid) v = *reinterpret_cast<const float4*>(src + (int64_t)(row0 + r) * ld + c4);
-    *reinterpret_cast<uint2*>(&dst[r * ALD + c4 / 2]) = make_uint2(cvtpk(v.x, v.y), cvtpk(v.z, v.w));
-  }
+// Descriptor of one item's [nrows][64] slice of a row-major tensor (`base` = the item's first row at the head's first
+// column, ld in floats): rows >= nrows are out of range and read as zeros.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const float* base, int64_t ld, int nrows) {
+  int64_t rec = ((int64_t)(nrows - 1) * ld + AD) * 4;
+  rec = rec > 0x7fffffff ? 0x7fffffff : rec;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)rec, 0x00020000);
 }
 
-// transposed tile [64 d][64 rows] from the same source, by 128 threads (t = 0..127): thread (g = t>>4, q4 = (t&15)*4)
-// loads rows g*8 .. g*8+7, columns q4 .. q4+3 and writes 4 x 16 B
-__device__ __forceinline__ void stage_transposed(uint32_t* dstT, const float* src, int64_t ld, int row0, int nrows_valid, int t) {
-  const int g = t >> 4, q4 = (t & 15) * 4;
-  float4 v[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int r = row0 + g * 8 + e;
-    v[e] = (r < nrows_valid) ? *reinterpret_cast<const float4*>(src + (int64_t)r * ld + q4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  *reinterpret_cast<uint4*>(&dstT[(q4 + 0) * ALD + g * 4]) =
-      make_uint4(cvtpk(v[0].x, v[1].x), cvtpk(v[2].x, v[3].x), cvtpk(v[4].x, v[5].x), cvtpk(v[6].x, v[7].x));
-  *reinterpret_cast<uint4*>(&dstT[(q4 + 1) * ALD + g * 4]) =
-      make_uint4(cvtpk(v[0].y, v[1].y), cvtpk(v[2].y, v[3].y), cvtpk(v[4].y, v[5].y), cvtpk(v[6].y, v[7].y));
-  *reinterpret_cast<uint4*>(&dstT[(q4 + 2) * ALD + g * 4]) =
-      make_uint4(cvtpk(v[0].z, v[1].z), cvtpk(v[2].z, v[3].z), cvtpk(v[4].z, v[5].z), cvtpk(v[6].z, v[7].z));
-  *reinterpret_cast<uint4*>(&dstT[(q4 + 3) * ALD + g * 4]) =
-      make_uint4(cvtpk(v[0].w, v[1].w), cvtpk(v[2].w, v[3].w), cvtpk(v[4].w, v[5].w), cvtpk(v[6].w, v[7].w));
-}
-
-// The same two stagers split into a register load and an LDS store: the next tile's global loads are issued BEFORE the
-// current tile is multiplied and land in LDS after it (single LDS buffer, the HBM/L2 latency hides behind the MFMAs).
-__device__ __forceinline__ void load_rows(float4 (&v)[4], const float* src, int64_t ld, int row0, int nrows_valid, int tid) {
+// 64 rows x 64 floats starting at row0: thread tid fetches rows (tid >> 4) + 16 p, columns (tid & 15) * 4 .. + 3
+__device__ __forceinline__ void load_rows(float4 (&v)[4], __amdgpu_buffer_rsrc_t rs, int ld, int row0, int tid) {
+  const uint32_t off = (uint32_t)(((row0 + (tid >> 4)) * ld + (tid & 15) * 4) * 4);
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const int idx = tid + p * 256;
-    const int r = idx >> 4, c4 = (idx & 15) * 4;
-    v[p] = (row0 + r < nrows_valid) ? *reinterpret_cast<const float4*>(src + (int64_t)(row0 + r) * ld + c4)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    const i32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off + (uint32_t)(p * 16 * ld * 4), 0, 0);
+    v[p] = *reinterpret_cast<const float4*>(&t);
   }
 }
+// ... -> bf16 [64][ALD]
 __device__ __forceinline__ void store_rows(uint32_t* dst, const float4 (&v)[4], int tid) {
+  uint32_t* d = dst + (tid >> 4) * ALD + (tid & 15) * 2;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int idx = tid + p * 256;
-    const int r = idx >> 4, c4 = (idx & 15) * 4;
-    *reinterpret_cast<uint2*>(&dst[r * ALD + c4 / 2]) = make_uint2(cvtpk(v[p].x, v[p].y), cvtpk(v[p].z, v[p].w));
-  }
-}
-__device__ __forceinline__ void load_transposed(float4 (&v)[8], const float* src, int64_t ld, int row0, int nrows_valid, int t) {
-  const int g = t >> 4, q4 = (t & 15) * 4;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int r = row0 + g * 8 + e;
-    v[e] = (r < nrows_valid) ? *reinterpret_cast<const float4*>(src + (int64_t)r * ld + q4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-}
-__device__ __forceinline__ void store_transposed(uint32_t* dstT, const float4 (&v)[8], int t) {
-  const int g = t >> 4, q4 = (t & 15) * 4;
-  *reinterpret_cast<uint4*>(&dstT[(q4 + 0) * ALD + g * 4]) =
-      make_uint4(cvtpk(v[0].x, v[1].x), cvtpk(v[2].x, v[3].x), cvtpk(v[4].x, v[5].x), cvtpk(v[6].x, v[7].x));
-  *reinterpret_cast<uint4*>(&dstT[(q4 + 1) * ALD + g * 4]) =
-      make_uint4(cvtpk(v[0].y, v[1].y), cvtpk(v[2].y, v[3].y), cvtpk(v[4].y, v[5].y), cvtpk(v[6].y, v[7].y));
-  *reinterpret_cast<uint4*>(&dstT[(q4 + 2) * ALD + g * 4]) =
-      make_uint4(cvtpk(v[0].z, v[1].z), cvtpk(v[2].z, v[3].z), cvtpk(v[4].z, v[5].z), cvtpk(v[6].z, v[7].z));
-  *reinterpret_cast<uint4*>(&dstT[(q4 + 3) * ALD + g * 4]) =
-      make_uint4(cvtpk(v[0].w, v[1].w), cvtpk(v[2].w, v[3].w), cvtpk(v[4].w, v[5].w), cvtpk(v[6].w, v[7].w));
+  for (int p = 0; p < 4; ++p)
+    *reinterpret_cast<uint2*>(&d[p * 16 * ALD]) = make_uint2(cvtpk(v[p].x, v[p].y), cvtpk(v[p].z, v[p].w));
 }
 
-// A operand from a transposed tile: row d = dt*32 + li, the two 4-row runs of 32-row block `blk`, step s2, half lh
-__device__ __forceinline__ bf16x8 fragT(const uint32_t* tT, int dt, int li, int blk, int s2, int lh) {
-  const uint32_t* p = &tT[(dt * 32 + li) * ALD + blk * 16 + s2 * 8 + lh * 2];
-  const uint2 a = *reinterpret_cast<const uint2*>(p);
-  const uint2 b = *reinterpret_cast<const uint2*>(p + 4);
-  uint4 v = make_uint4(a.x, a.y, b.x, b.y);
+// A operand of a product over the ROW axis of a row-major tile: feature d = dt*32 + (lane & 31), the two 4-row runs
+// {16*s2 + 4*lh + 0..3} and {.. + 8} of 32-row block `blk`.  tq = lane & 15, tc = (lane >> 4) & 1 (the 16-lane group's
+// feature half).  Lane tq addresses row (tq >> 2), features (tq & 3) * 4 .. + 3 of its group's [4][16] block.
+__device__ __forceinline__ bf16x8 fragT(const uint32_t* tile, int dt, int tq, int tc, int blk, int s2, int lh) {
+  const uint32_t* p = &tile[(blk * 32 + s2 * 16 + lh * 4 + (tq >> 2)) * ALD + dt * 16 + tc * 8 + (tq & 3) * 2];
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(const_cast<uint32_t*>(p)));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(const_cast<uint32_t*>(p + 8 * ALD)));
+  const uint2 ua = *reinterpret_cast<const uint2*>(&a), ub = *reinterpret_cast<const uint2*>(&b);
+  uint4 v = make_uint4(ua.x, ua.y, ub.x, ub.y);
   return *reinterpret_cast<bf16x8*>(&v);
 }
 
@@ -131,8 +97,9 @@ __global__ __launch_bounds__(256) void attention_fwd_bf16_kernel(const float* __
                                                                  const int64_t* __restrict__ len,
                                                                  const int* __restrict__ cu) {
   __shared__ __attribute__((aligned(16))) uint32_t sK[64 * ALD];
-  __shared__ __attribute__((aligned(16))) uint32_t sVT[64 * ALD];
+  __shared__ __attribute__((aligned(16))) uint32_t sV[64 * ALD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int tq = lane & 15, tc = (lane >> 4) & 1;
   const int head = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const int64_t rowbase = cu ? (int64_t)cu[b] : (int64_t)b * L;     // packed rows (pack.hip): items back to back
@@ -165,16 +132,20 @@ __global__ __launch_bounds__(256) void attention_fwd_bf16_kernel(const float* __
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
 
-  const float* kbase = qkv + rowbase * 768 + 256 + head * AD;
-  const float* vbase = qkv + rowbase * 768 + 512 + head * AD;
+  const __amdgpu_buffer_rsrc_t krs = rows_rsrc(qkv + rowbase * 768 + 256 + head * AD, 768, Lr);
+  const __amdgpu_buffer_rsrc_t vrs = rows_rsrc(qkv + rowbase * 768 + 512 + head * AD, 768, Lr);
   const int ntiles = (klen + 63) / 64;
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * 64;
+    // (a register prefetch of the next tile across the MFMAs was measured in round 1: occupancy 3 -> 2 waves per SIMD
+    // lost more than it hid.  The loads are issued ahead of the barrier instead: they fly while the block's other waves
+    // finish the previous tile.)
+    float4 rk[4], rv[4];
+    load_rows(rk, krs, 768, k0, tid);
+    load_rows(rv, vrs, 768, k0, tid);
     __syncthreads();
-    // (a register prefetch of the next tile was measured here: 37.8 -> 75.8 us -- occupancy 3 -> 2 waves per SIMD and the
-    // loads' waits land in front of the MFMAs; the dK/dV kernel, at one wave per SIMD anyway, keeps its prefetch)
-    stage_rows(sK, kbase, 768, k0, Lr, tid);
-    if (tid < 128) stage_transposed(sVT, vbase, 768, k0, Lr, tid);
+    store_rows(sK, rk, tid);
+    store_rows(sV, rv, tid);
     __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -211,8 +182,8 @@ __global__ __launch_bounds__(256) void attention_fwd_bf16_kernel(const float* __
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 pb = pack_acc(s, s2);
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sVT, 0, li, kb, s2, lh), pb, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sVT, 1, li, kb, s2, lh), pb, o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sV, 0, tq, tc, kb, s2, lh), pb, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sV, 1, tq, tc, kb, s2, lh), pb, o1, 0, 0, 0);
       }
     }
   }
@@ -232,8 +203,8 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_bf16_kernel(const float*
                                                                     const int* __restrict__ cu) {
   __shared__ __attribute__((aligned(16))) uint32_t sK[64 * ALD];
   __shared__ __attribute__((aligned(16))) uint32_t sV[64 * ALD];
-  __shared__ __attribute__((aligned(16))) uint32_t sKT[64 * ALD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int tq = lane & 15, tc = (lane >> 4) & 1;
   const int head = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const int64_t rowbase = cu ? (int64_t)cu[b] : (int64_t)b * L;
@@ -274,16 +245,17 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_bf16_kernel(const float*
   f32x16 dq0, dq1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
-  const float* kbase = qkv + rowbase * 768 + 256 + head * AD;
-  const float* vbase = qkv + rowbase * 768 + 512 + head * AD;
+  const __amdgpu_buffer_rsrc_t krs = rows_rsrc(qkv + rowbase * 768 + 256 + head * AD, 768, Lr);
+  const __amdgpu_buffer_rsrc_t vrs = rows_rsrc(qkv + rowbase * 768 + 512 + head * AD, 768, Lr);
   const int ntiles = (klen + 63) / 64;
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * 64;
+    float4 rk[4], rv[4];
+    load_rows(rk, krs, 768, k0, tid);
+    load_rows(rv, vrs, 768, k0, tid);
     __syncthreads();
-    // (no register prefetch here: +50 VGPRs would halve this kernel's occupancy, 2 -> 1 wave per SIMD)
-    stage_rows(sK, kbase, 768, k0, Lr, tid);
-    stage_rows(sV, vbase, 768, k0, Lr, tid);
-    if (tid < 128) stage_transposed(sKT, kbase, 768, k0, Lr, tid);
+    store_rows(sK, rk, tid);
+    store_rows(sV, rv, tid);
     __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -310,8 +282,8 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_bf16_kernel(const float*
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 dsb = pack_acc(s, s2);
-        dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sKT, 0, li, kb, s2, lh), dsb, dq0, 0, 0, 0);
-        dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sKT, 1, li, kb, s2, lh), dsb, dq1, 0, 0, 0);
+        dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sK, 0, tq, tc, kb, s2, lh), dsb, dq0, 0, 0, 0);
+        dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sK, 1, tq, tc, kb, s2, lh), dsb, dq1, 0, 0, 0);
       }
     }
   }
@@ -328,10 +300,9 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_bf16_kernel(const float
                                                                      const int* __restrict__ cu) {
   __shared__ __attribute__((aligned(16))) uint32_t sQ[64 * ALD];
   __shared__ __attribute__((aligned(16))) uint32_t sDO[64 * ALD];
-  __shared__ __attribute__((aligned(16))) uint32_t sQT[64 * ALD];
-  __shared__ __attribute__((aligned(16))) uint32_t sDOT[64 * ALD];
-  __shared__ float sLse[64], sDl[64];
+  __shared__ __attribute__((aligned(16))) float sLse[64], sDl[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int tq = lane & 15, tc = (lane >> 4) & 1;
   const int head = blockIdx.y, b = blockIdx.z;
   const int key0 = blockIdx.x * 128 + wave * 32;
   const int64_t rowbase = cu ? (int64_t)cu[b] : (int64_t)b * L;
@@ -353,39 +324,38 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_bf16_kernel(const float
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
 
-  const float* qbase = qkv + rowbase * 768 + head * AD;
-  const float* dobase = dout + rowbase * 256 + head * AD;
   // A lane owns one key column, so an invalid key only pollutes its own dK / dV, which are written as zeros below.
   // Query rows at or past klen have dO = 0 and delta = 0 (no gradient reaches them): they add nothing to any dK / dV,
-  // so the query loop stops at klen; rows of the last tile past L are staged as zeros (lse = delta = 0 there).
+  // so the query loop stops at klen; rows of the last tile past the item are fetched as zeros (lse = +huge there).
+  const __amdgpu_buffer_rsrc_t qrs = rows_rsrc(qkv + rowbase * 768 + head * AD, 768, Lr);
+  const __amdgpu_buffer_rsrc_t drs = rows_rsrc(dout + rowbase * 256 + head * AD, 256, Lr);
+  const float* lse_row = lse + ((int64_t)b * 4 + head) * L;
+  const float* dl_row = delta + ((int64_t)b * 4 + head) * L;
   const bool block_live = blockIdx.x * 128 < klen;
   const int ntiles = block_live ? (klen + 63) / 64 : 0;
-  float4 rq[4], rdo[4], rt[8];
-  if (ntiles > 0) {
-    load_rows(rq, qbase, 768, 0, Lr, tid);
-    load_rows(rdo, dobase, 256, 0, Lr, tid);
-    if (tid < 128) load_transposed(rt, qbase, 768, 0, Lr, tid);
-    else load_transposed(rt, dobase, 256, 0, Lr, tid - 128);
-  }
+  float4 rq[4], rdo[4];
+  float r_lse = 0.f, r_dl = 0.f;                       // tid < 64: row tid of the tile
+  auto fetch = [&](int qb) {
+    if (tid < 64) {                                    // issued first: their wait must not cover the tile loads below
+      const int qq = qb + tid, qi = qq < klen ? qq : klen - 1;
+      r_lse = lse_row[qi]; r_dl = dl_row[qi];
+    }
+    load_rows(rq, qrs, 768, qb, tid);
+    load_rows(rdo, drs, 256, qb, tid);
+  };
+  if (ntiles > 0) fetch(0);
   for (int qt = 0; qt < ntiles; ++qt) {
     const int qb = qt * 64;
     __syncthreads();
     store_rows(sQ, rq, tid);
     store_rows(sDO, rdo, tid);
-    if (tid < 128) store_transposed(sQT, rt, tid);
-    else store_transposed(sDOT, rt, tid - 128);
-    if (qt + 1 < ntiles) {                             // next tile: in flight while this one is multiplied
-      load_rows(rq, qbase, 768, qb + 64, Lr, tid);
-      load_rows(rdo, dobase, 256, qb + 64, Lr, tid);
-      if (tid < 128) load_transposed(rt, qbase, 768, qb + 64, Lr, tid);
-      else load_transposed(rt, dobase, 256, qb + 64, Lr, tid - 128);
-    }
     if (tid < 64) {
-      const int qq = qb + tid;
       // rows at or past klen: lse = +huge makes p exactly 0 (whatever dO / the forward's lse hold there)
-      sLse[tid] = qq < klen ? lse[((int64_t)b * 4 + head) * L + qq] * LOG2E : 1e30f;
-      sDl[tid] = qq < klen ? delta[((int64_t)b * 4 + head) * L + qq] : 0.f;
+      const bool okq = qb + tid < klen;
+      sLse[tid] = okq ? r_lse * LOG2E : 1e30f;
+      sDl[tid] = okq ? r_dl : 0.f;
     }
+    if (qt + 1 < ntiles) fetch(qb + 64);               // next tile: in flight while this one is multiplied
     __syncthreads();
 #pragma unroll
     for (int qk = 0; qk < 2; ++qk) {
@@ -401,19 +371,26 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_bf16_kernel(const float
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dv, vf[st], dp, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ql = qk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float p = __builtin_amdgcn_exp2f(s[r] - sLse[ql]);
-        s[r] = p;
-        dp[r] = p * (dp[r] - sDl[ql]);
+      for (int g = 0; g < 4; ++g) {                    // the lane's 16 query rows are four runs of 4: two ds_read_b128 per run
+        const int ql = qk * 32 + 8 * g + 4 * lh;
+        const float4 l4 = *reinterpret_cast<const float4*>(&sLse[ql]);
+        const float4 d4 = *reinterpret_cast<const float4*>(&sDl[ql]);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = g * 4 + e;
+          const float p = __builtin_amdgcn_exp2f(s[r] - lv[e]);
+          s[r] = p;
+          dp[r] = p * (dp[r] - dvv[e]);
+        }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 pb = pack_acc(s, s2), dsb = pack_acc(dp, s2);
-        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sDOT, 0, li, qk, s2, lh), pb, dv0, 0, 0, 0);
-        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sDOT, 1, li, qk, s2, lh), pb, dv1, 0, 0, 0);
-        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sQT, 0, li, qk, s2, lh), dsb, dk0, 0, 0, 0);
-        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sQT, 1, li, qk, s2, lh), dsb, dk1, 0, 0, 0);
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sDO, 0, tq, tc, qk, s2, lh), pb, dv0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sDO, 1, tq, tc, qk, s2, lh), pb, dv1, 0, 0, 0);
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sQ, 0, tq, tc, qk, s2, lh), dsb, dk0, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sQ, 1, tq, tc, qk, s2, lh), dsb, dk1, 0, 0, 0);
       }
     }
   }
