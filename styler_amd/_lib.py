@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstyler_hip.so")
+LIB_PATH = os.environ.get("STYLER_LIB") or os.path.join(_HERE, "libstyler_hip.so")     # STYLER_LIB: A/B builds
 
 P = ctypes.c_void_p
 I = ctypes.c_int

@@ -15,10 +15,31 @@ static inline int launch_status() {
   return e == hipSuccess ? 0 : (int)e;
 }
 
+// Wave-wide sum without the LDS crossbar: the xor butterfly 32, 16, 8, 4, 2, 1 as gfx950's half / row swaps
+// (v_permlane32_swap, v_permlane16_swap: with both operands = v the two results are v and its partner half / row) and
+// four DPP adds (row_ror:8, row_ror:4 -- after the first three steps a value depends on lane & 7 only, so the rotation IS
+// the xor -- and the two quad permutes).  Same partners in the same order as six `v += __shfl_xor(v, o)` steps, i.e. the
+// same bits in every lane, at six VALU-rate instructions instead of six dependent ds_bpermute round trips.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
+#ifdef STYLER_WAVE_SUM_SHFL                            // A/B builds only: the ds_bpermute butterfly
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+#else
+  const auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(h[0]) + __uint_as_float(h[1]);
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  v += dpp_f32<0x128>(v);                              // row_ror:8
+  v += dpp_f32<0x124>(v);                              // row_ror:4
+  v += dpp_f32<0x4E>(v);                               // quad_perm [2,3,0,1]
+  v += dpp_f32<0xB1>(v);                               // quad_perm [1,0,3,2]
+  return v;
+#endif
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -70,26 +91,32 @@ __device__ __forceinline__ uint64_t mix_drop_epoch(uint64_t seed, const uint64_t
   return epoch ? seed + *epoch * 0xD6E8FEB86659FD93ull : seed;
 }
 
-// counter-based dropout stream: keep element e of a tensor iff dropout_hash32(seed, e) >= p * 2^32
+// Counter-based dropout stream: keep element e of a tensor iff dropout_hash32(seed, e) >= p * 2^32.  A keyed 32-bit
+// mixer: the key schedule (splitmix64 of the seed) is uniform -- scalar ALU, hoisted out of element loops -- and the
+// per-element part is two 32-bit multiplies with the key entering before the first and between the two (the 64-bit
+// splitmix per element it replaces was ~50 issue slots per element: the BatchNorm backward kernels were VALU-bound on it).
 __device__ __forceinline__ uint32_t dropout_hash32(uint64_t seed, uint64_t idx) {
-  uint64_t z = idx + seed * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (uint32_t)(z >> 32);
+  uint64_t k = seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+  k = (k ^ (k >> 30)) * 0xBF58476D1CE4E5B9ull;
+  k = (k ^ (k >> 27)) * 0x94D049BB133111EBull;
+  k ^= k >> 31;
+  uint32_t h = (uint32_t)idx ^ (uint32_t)k;
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15;
+  h += (uint32_t)(k >> 32) + (uint32_t)(idx >> 32) * 0x9E3779B1u;
+  h *= 0x846ca68bu; h ^= h >> 16;
+  return h;
 }
 
 // Gradient w.r.t. the BatchNorm output of y = dropout(act(BN(x))) for one element: the dropout keep mask is regenerated
 // from (seed, element index), the tanh output is recomputed from x (gamma/beta/mean/rstd) unless `yv` supplies it.
-struct BnDrop { float p; uint64_t seed; };
-__device__ __forceinline__ float bn_dz_elem(float g, float xh, float ga, float be, int act, const float* yv, float drop_p,
-                                            uint64_t seed, uint64_t e) {
+__device__ __forceinline__ float bn_dz_elem(float g, float xh, float ga, float be, int act, bool has_y, float yv,
+                                            float drop_p, uint64_t seed, uint64_t e) {
   if (drop_p > 0.f) {
     const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);
     g = dropout_hash32(seed, e) >= thr ? g * (1.f / (1.f - drop_p)) : 0.f;
   }
   if (act == STYLER_ACT_TANH) {
-    const float o = yv ? *yv : tanhf(xh * ga + be);
+    const float o = has_y ? yv : tanhf(xh * ga + be);
     g *= 1.f - o * o;
   }
   return g;

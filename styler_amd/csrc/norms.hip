@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restric
                                                           int64_t rows, int C, int act, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float drop_p,
                                                           uint64_t drop_seed_host, const uint64_t* __restrict__ epoch,
-                                                          int rpb, int bps, int64_t rps) {
+                                                          int rpb, int bps, int64_t rps, int dbg) {
   // Segments: rows [seg * rps, (seg + 1) * rps) carry their own statistics (the clean and the noisy decode of
   // styler.py:52,55 run through the PostNet as ONE batch, but each call of the reference normalises with its own batch
   // statistics, Layers.py:126).  Block = (segment, chunk of rpb rows); per-segment arrays are [segs][...].
@@ -233,39 +233,43 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restric
         ga = *reinterpret_cast<const float4*>(gamma + q * 4);
         if (beta) be = *reinterpret_cast<const float4*>(beta + q * 4);
       }
-      int64_t r = r0 + rl;
-      if (!BWD) {
-        // forward statistics: four rows' loads in flight per thread (the accumulation chain is fp64 and serial, the
-        // loads are not)
-        for (; r + 3 * (int64_t)lanes < r1; r += 4 * (int64_t)lanes) {
-          float4 v4[4];
+      const bool has_y = BWD && y && act == STYLER_ACT_TANH;
+      // U rows' loads in flight per thread and batch (the accumulation chain is fp64 and serial, the loads are not): a
+      // row-at-a-time loop is one memory round trip per row -- 16 in a row at 32 rows per block
+      constexpr int U = BWD ? 4 : 8;
+      for (int64_t r = r0 + rl; r < r1; r += (int64_t)U * lanes) {
+        float4 v4[U], g4[U], o4[U];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) v4[u] = *reinterpret_cast<const float4*>(x + (r + (int64_t)u * lanes) * C + q * 4);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            s[0] += v4[u].x; s[1] += v4[u].y; s[2] += v4[u].z; s[3] += v4[u].w;
-            t[0] += (double)v4[u].x * v4[u].x; t[1] += (double)v4[u].y * v4[u].y;
-            t[2] += (double)v4[u].z * v4[u].z; t[3] += (double)v4[u].w * v4[u].w;
+        for (int u = 0; u < U; ++u) {
+          int64_t ru = r + (int64_t)u * lanes;
+          ru = ru < r1 ? ru : r1 - 1;                      // clamped, discarded below: no lane branches around loads
+          v4[u] = *reinterpret_cast<const float4*>(x + ru * C + q * 4);
+          if (BWD) {
+            g4[u] = *reinterpret_cast<const float4*>(dy + ru * C + q * 4);
+            if (has_y) o4[u] = *reinterpret_cast<const float4*>(y + ru * C + q * 4);
           }
         }
-      }
-      for (; r < r1; r += lanes) {
-        const float4 v = *reinterpret_cast<const float4*>(x + r * C + q * 4);
-        if (BWD) {
-          float4 g = *reinterpret_cast<const float4*>(dy + r * C + q * 4);
-          float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (y && act == STYLER_ACT_TANH) o = *reinterpret_cast<const float4*>(y + r * C + q * 4);
-          const float hx = (v.x - m.x) * rs.x, hy = (v.y - m.y) * rs.y, hz = (v.z - m.z) * rs.z, hw = (v.w - m.w) * rs.w;
-          const uint64_t e = (uint64_t)(r * C + q * 4);
-          g.x = bn_dz_elem(g.x, hx, ga.x, be.x, act, y ? &o.x : nullptr, drop_p, drop_seed, e);
-          g.y = bn_dz_elem(g.y, hy, ga.y, be.y, act, y ? &o.y : nullptr, drop_p, drop_seed, e + 1);
-          g.z = bn_dz_elem(g.z, hz, ga.z, be.z, act, y ? &o.z : nullptr, drop_p, drop_seed, e + 2);
-          g.w = bn_dz_elem(g.w, hw, ga.w, be.w, act, y ? &o.w : nullptr, drop_p, drop_seed, e + 3);
-          s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
-          t[0] += (double)g.x * hx; t[1] += (double)g.y * hy; t[2] += (double)g.z * hz; t[3] += (double)g.w * hw;
-        } else {
-          s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-          t[0] += (double)v.x * v.x; t[1] += (double)v.y * v.y; t[2] += (double)v.z * v.z; t[3] += (double)v.w * v.w;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t ru = r + (int64_t)u * lanes;
+          const bool okr = ru < r1;                        // a select, not a branch: a branch lets the loads sink to it
+          float4 v = v4[u];
+          if (!okr) v = make_float4(BWD ? m.x : 0.f, BWD ? m.y : 0.f, BWD ? m.z : 0.f, BWD ? m.w : 0.f);
+          if (BWD) {
+            float4 g = okr ? g4[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 o = has_y ? o4[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float hx = (v.x - m.x) * rs.x, hy = (v.y - m.y) * rs.y, hz = (v.z - m.z) * rs.z, hw = (v.w - m.w) * rs.w;
+            const uint64_t e = (uint64_t)(ru * C + q * 4);
+            g.x = bn_dz_elem(g.x, hx, ga.x, be.x, act, has_y, o.x, drop_p, drop_seed, e);
+            g.y = bn_dz_elem(g.y, hy, ga.y, be.y, act, has_y, o.y, drop_p, drop_seed, e + 1);
+            g.z = bn_dz_elem(g.z, hz, ga.z, be.z, act, has_y, o.z, drop_p, drop_seed, e + 2);
+            g.w = bn_dz_elem(g.w, hw, ga.w, be.w, act, has_y, o.w, drop_p, drop_seed, e + 3);
+            s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
+            t[0] += (double)g.x * hx; t[1] += (double)g.y * hy; t[2] += (double)g.z * hz; t[3] += (double)g.w * hw;
+          } else {
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            t[0] += (double)v.x * v.x; t[1] += (double)v.y * v.y; t[2] += (double)v.z * v.z; t[3] += (double)v.w * v.w;
+          }
         }
       }
     }
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restric
           for (int k = 0; k < 4; ++k) { s[k] += red[l * nqt + ql][k]; t[k] += red[l * nqt + ql][4 + k]; }
       __syncthreads();
     }
-    if (rl == 0 && q < nq) {
+    if (rl == 0 && q < nq && !(dbg & 1)) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) { atomicAdd(&wsc[q * 4 + k], s[k]); atomicAdd(&wsc[C + q * 4 + k], t[k]); }
     }
@@ -306,15 +310,16 @@ int styler_bn_colstats(bool bwd, const float* x, const float* y, const float* dy
   }
   static const int rpb_env = [] { const char* e = getenv("STYLER_BN_RPB"); return e ? atoi(e) : BN_RPB; }();
   const int rpb = rpb_env > 0 ? rpb_env : BN_RPB;
+  static const int dbg = [] { const char* e = getenv("STYLER_BN_DBG"); return e ? atoi(e) : 0; }();   // timing experiments
   const int64_t rps = rows / segs;                   // rows per segment
   const int bps = (int)((rps + rpb - 1) / rpb);      // blocks per segment
   const dim3 grid((unsigned)(bps * segs));
   if (bwd)
     hipLaunchKernelGGL(bn_colstats_kernel<true>, grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, rows, C, act, gamma, beta,
-                       drop_p, drop_seed, g_styler_drop_epoch, rpb, bps, rps);
+                       drop_p, drop_seed, g_styler_drop_epoch, rpb, bps, rps, dbg);
   else
     hipLaunchKernelGGL(bn_colstats_kernel<false>, grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, rows, C, act, gamma, beta,
-                       drop_p, drop_seed, g_styler_drop_epoch, rpb, bps, rps);
+                       drop_p, drop_seed, g_styler_drop_epoch, rpb, bps, rps, dbg);
   hipLaunchKernelGGL(bn_fold_copies_kernel, dim3((2 * C * segs + 255) / 256), dim3(256), 0, st, ws, 2 * C, segs);
   return 0;
 }
@@ -339,38 +344,62 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, float* save_me
   }
 }
 
+// Normalise + activation + dropout.  Same geometry as the column statistics: block = (segment, chunk of rpb rows), thread =
+// (row-lane, float4 column): the per-channel constants are fetched once per thread, the rows in batches of four, and no
+// index is ever divided.
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, float* __restrict__ y,
-                                                       int64_t total4, int C, int act, float drop_p,
-                                                       uint64_t drop_seed_host, const uint64_t* __restrict__ epoch,
-                                                       int64_t rps) {
+                                                       int C, int act, float drop_p, uint64_t drop_seed_host,
+                                                       const uint64_t* __restrict__ epoch, int rpb, int bps, int64_t rps) {
+  const int seg = blockIdx.x / bps, chunk = blockIdx.x - seg * bps;
   const int nq = C / 4;
+  const int nqt = nq < 256 ? nq : 256;
+  const int lanes = 256 / nqt;
+  const int rl = threadIdx.x / nqt, ql = threadIdx.x - rl * nqt;
+  if (rl >= lanes) return;
   const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
-    const int q = (int)(i % nq);
-    const int64_t so = ((i / nq) / rps) * C;        // offset of the row's segment in the [segs, C] statistics
-    const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+  const int64_t r0 = (int64_t)seg * rps + (int64_t)chunk * rpb;
+  int64_t r1 = r0 + rpb; if (r1 > (seg + 1) * rps) r1 = (seg + 1) * rps;
+  for (int q = ql; q < nq; q += nqt) {
     const float4 g = *reinterpret_cast<const float4*>(gamma + q * 4);
     const float4 b = *reinterpret_cast<const float4*>(beta + q * 4);
-    const float4 m = *reinterpret_cast<const float4*>(mean + so + q * 4);
-    const float4 r = *reinterpret_cast<const float4*>(rstd + so + q * 4);
-    float4 o;
-    o.x = apply_act((v.x - m.x) * r.x * g.x + b.x, act);
-    o.y = apply_act((v.y - m.y) * r.y * g.y + b.y, act);
-    o.z = apply_act((v.z - m.z) * r.z * g.z + b.z, act);
-    o.w = apply_act((v.w - m.w) * r.w * g.w + b.w, act);
-    if (drop_p > 0.f) {                              // F.dropout after the activation (Layers.py:126-128), the stream
-      const uint64_t e = (uint64_t)i * 4;            // styler_dropout would draw on the [rows, C] tensor
-      o.x = dropout_hash32(drop_seed, e) >= thr ? o.x * sc : 0.f;
-      o.y = dropout_hash32(drop_seed, e + 1) >= thr ? o.y * sc : 0.f;
-      o.z = dropout_hash32(drop_seed, e + 2) >= thr ? o.z * sc : 0.f;
-      o.w = dropout_hash32(drop_seed, e + 3) >= thr ? o.w * sc : 0.f;
+    const float4 m = *reinterpret_cast<const float4*>(mean + (int64_t)seg * C + q * 4);
+    const float4 r = *reinterpret_cast<const float4*>(rstd + (int64_t)seg * C + q * 4);
+    // y = (x - m) * r * g + b = x * a + c
+    const float4 a = make_float4(r.x * g.x, r.y * g.y, r.z * g.z, r.w * g.w);
+    constexpr int U = 4;
+    for (int64_t row = r0 + rl; row < r1; row += (int64_t)U * lanes) {
+      float4 v4[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int64_t ru = row + (int64_t)u * lanes;
+        ru = ru < r1 ? ru : r1 - 1;
+        v4[u] = *reinterpret_cast<const float4*>(x + ru * C + q * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t ru = row + (int64_t)u * lanes;
+        if (ru >= r1) break;
+        const float4 v = v4[u];
+        float4 o;
+        o.x = apply_act((v.x - m.x) * a.x + b.x, act);
+        o.y = apply_act((v.y - m.y) * a.y + b.y, act);
+        o.z = apply_act((v.z - m.z) * a.z + b.z, act);
+        o.w = apply_act((v.w - m.w) * a.w + b.w, act);
+        if (drop_p > 0.f) {                              // F.dropout after the activation (Layers.py:126-128), the stream
+          const uint64_t e = (uint64_t)(ru * C + q * 4); // styler_dropout would draw on the [rows, C] tensor
+          o.x = dropout_hash32(drop_seed, e) >= thr ? o.x * sc : 0.f;
+          o.y = dropout_hash32(drop_seed, e + 1) >= thr ? o.y * sc : 0.f;
+          o.z = dropout_hash32(drop_seed, e + 2) >= thr ? o.z * sc : 0.f;
+          o.w = dropout_hash32(drop_seed, e + 3) >= thr ? o.w * sc : 0.f;
+        }
+        *reinterpret_cast<float4*>(y + ru * C + q * 4) = o;
+      }
     }
-    *reinterpret_cast<float4*>(y + i * 4) = o;
   }
 }
 
@@ -387,9 +416,9 @@ extern "C" int styler_batchnorm_train(const float* x, const float* gamma, const 
   if (rc) return rc;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, save_mean, save_rstd,
                      running_mean, running_var, rows, C, segs);
-  const int64_t total4 = rows * C / 4;
-  int64_t blocks = (total4 + 255) / 256; if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, beta, save_mean, save_rstd,
-                     y, total4, C, act, drop_p, drop_seed, g_styler_drop_epoch, rows / segs);
+  const int64_t rps = rows / segs;
+  const int bps = (int)((rps + BN_RPB - 1) / BN_RPB);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)(bps * segs)), dim3(256), 0, st, x, gamma, beta, save_mean, save_rstd,
+                     y, C, act, drop_p, drop_seed, g_styler_drop_epoch, BN_RPB, bps, rps);
   return launch_status();
 }

@@ -33,24 +33,41 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     bool live[R];
     float4 v[R], d[R];
     float go[R], kx[R][4];
+    // Every load of the iteration is issued before anything waits: the rows' item lengths first, then x / dy (/ dout) of
+    // all R rows from clamped addresses -- a load under a lane condition compiles to a branch with its own vmcnt(0), which
+    // chained the rows' memory round trips one behind the other.  Masked rows are fetched and discarded.
+    int64_t rc[R];
+    uint32_t tt[R];
+    int lv[R];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       row[k] = row0 + k * wstride;
-      bool ok = row[k] < rows;
-      if (ok && len) {
-        const int64_t b = row[k] / L;
-        if ((row[k] - b * L) >= len[b]) {                // masked row: zero gradient, nothing else
-          ok = false;
-          if (dx) *reinterpret_cast<float4*>(dx + row[k] * lddx + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (dx_drop) *reinterpret_cast<float4*>(dx_drop + row[k] * lddxd + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+      live[k] = row[k] < rows;
+      rc[k] = live[k] ? row[k] : rows - 1;
+      tt[k] = 0u; lv[k] = 1;
+      if (len) {
+        const uint32_t b = (uint32_t)rc[k] / (uint32_t)L;              // rows < 2^31 (checked by the host wrapper)
+        tt[k] = (uint32_t)rc[k] - b * (uint32_t)L;
+        lv[k] = reinterpret_cast<const int*>(len)[2 * b];             // low dword of the int64 length
       }
-      live[k] = ok;
-      v[k] = ok ? *reinterpret_cast<const float4*>(x + row[k] * ldx + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      v[k] = *reinterpret_cast<const float4*>(x + rc[k] * ldx + lane * 4);
       go[k] = 0.f;
+      if (dot_w) go[k] = dout[rc[k]];
+      else d[k] = *reinterpret_cast<const float4*>(dy + rc[k] * lddy + lane * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (live[k] && (int)tt[k] >= lv[k]) {               // masked row: zero gradient, nothing else
+        live[k] = false;
+        if (dx) *reinterpret_cast<float4*>(dx + row[k] * lddx + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dx_drop) *reinterpret_cast<float4*>(dx_drop + row[k] * lddxd + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (!live[k]) { v[k] = make_float4(0.f, 0.f, 0.f, 0.f); go[k] = 0.f; }
       kx[k][0] = kx[k][1] = kx[k][2] = kx[k][3] = 1.f;
       if (dot_w) {
-        go[k] = ok ? dout[row[k]] : 0.f;
         if (drop_p > 0.f) {                              // dropout keep * 1/(1-p) between LN and the dot
           const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);
           const float sc = 1.f / (1.f - drop_p);
@@ -60,8 +77,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
         }
         d[k] = make_float4(go[k] * dw4.x * kx[k][0], go[k] * dw4.y * kx[k][1], go[k] * dw4.z * kx[k][2],
                            go[k] * dw4.w * kx[k][3]);
-      } else {
-        d[k] = ok ? *reinterpret_cast<const float4*>(dy + row[k] * lddy + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if (!live[k]) {
+        d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
     float mean[R], rstd[R];
@@ -69,9 +86,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
 #pragma unroll
     for (int k = 0; k < R; ++k) mean[k] = v[k].x + v[k].y + v[k].z + v[k].w;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-      for (int k = 0; k < R; ++k) mean[k] += __shfl_xor(mean[k], o, 64);
+    for (int k = 0; k < R; ++k) mean[k] = wave_sum(mean[k]);
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       mean[k] *= (1.f / 256.f);
@@ -79,9 +94,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
       rstd[k] = h[k].x * h[k].x + h[k].y * h[k].y + h[k].z * h[k].z + h[k].w * h[k].w;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-      for (int k = 0; k < R; ++k) rstd[k] += __shfl_xor(rstd[k], o, 64);
+    for (int k = 0; k < R; ++k) rstd[k] = wave_sum(rstd[k]);
     float m1[R], m2[R];
     float4 ex[R];
 #pragma unroll
@@ -102,9 +115,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
       m2[k] = ex[k].x * h[k].x + ex[k].y * h[k].y + ex[k].z * h[k].z + ex[k].w * h[k].w;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-      for (int k = 0; k < R; ++k) { m1[k] += __shfl_xor(m1[k], o, 64); m2[k] += __shfl_xor(m2[k], o, 64); }
+    for (int k = 0; k < R; ++k) { m1[k] = wave_sum(m1[k]); m2[k] = wave_sum(m2[k]); }
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       if (!live[k]) continue;
@@ -156,6 +167,7 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
                                     int C, const int64_t* len, float drop_p, uint64_t drop_seed, float in_drop_p,
                                     uint64_t in_drop_seed, float* dx_drop, int64_t lddxd, int replicas, void* stream) {
   if (!x || !gamma || !dgamma || !dbeta || B <= 0 || L <= 0 || C != 256 || replicas < 1) return STYLER_EINVAL;
+  if ((int64_t)B * L >= ((int64_t)1 << 31)) return STYLER_EINVAL;
   if (!dot_w && !dy) return STYLER_EINVAL;
   if (dot_w && (!dout || !ddot_w || !ddot_b || !beta)) return STYLER_EINVAL;
   if ((ldx & 3) || (dy && (lddy & 3)) || (dx && (lddx & 3))) return STYLER_EALIGN;
@@ -297,50 +309,78 @@ int styler_bn_colstats(bool bwd, const float* x, const float* y, const float* dy
                        float drop_p, uint64_t drop_seed, int segs, hipStream_t st);   // norms.hip
 #define STYLER_BN_COPIES 16                          // norms.hip
 
+// Same geometry as the forward's column statistics / apply kernels (norms.hip): block = (segment, chunk of rpb rows),
+// thread = (row-lane, float4 column); per-channel constants (incl. the two fp64 column sums) once per thread, rows in
+// batches of four, no index divisions.
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const double* __restrict__ ws, float* __restrict__ dx,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           int64_t rows, int C, int act, const float* __restrict__ beta,
+                                                           int C, int act, const float* __restrict__ beta,
                                                            float drop_p, uint64_t drop_seed_host,
-                                                           const uint64_t* __restrict__ epoch, int segs) {
+                                                           const uint64_t* __restrict__ epoch, int segs, int rpb, int bps,
+                                                           int64_t rps) {
+  // parameter gradients: first C * segs threads of the grid
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < (int64_t)C * segs) {
+    const int sg = (int)(gid / C), c = (int)(gid - (int64_t)sg * C);
+    const double* wseg = ws + (int64_t)sg * STYLER_BN_COPIES * 2 * C;
+    atomicAdd(dbeta + c, (float)wseg[c]); atomicAdd(dgamma + c, (float)wseg[C + c]);
+  }
+  const int seg = blockIdx.x / bps, chunk = blockIdx.x - seg * bps;
+  if (seg >= segs) return;                           // (blocks added only to carry the parameter-gradient threads)
   const int nq = C / 4;
-  const int64_t total4 = rows * nq;
-  const int64_t rps = rows / segs;                   // per-segment statistics (norms.hip)
+  const int nqt = nq < 256 ? nq : 256;
+  const int lanes = 256 / nqt;
+  const int rl = threadIdx.x / nqt, ql = threadIdx.x - rl * nqt;
+  if (rl >= lanes) return;
   const double inv_n = 1.0 / (double)rps;
   const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
-    const int q = (int)(i % nq);
-    const int seg = (int)((i / nq) / rps);
-    const double* wseg = ws + (int64_t)seg * STYLER_BN_COPIES * 2 * C;
-    const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
-    const float4 g = *reinterpret_cast<const float4*>(dy + i * 4);
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (y && act == STYLER_ACT_TANH) o = *reinterpret_cast<const float4*>(y + i * 4);
+  const double* wseg = ws + (int64_t)seg * STYLER_BN_COPIES * 2 * C;
+  const bool has_y = y && act == STYLER_ACT_TANH;
+  const int64_t r0 = (int64_t)seg * rps + (int64_t)chunk * rpb;
+  int64_t r1 = r0 + rpb; if (r1 > (seg + 1) * rps) r1 = (seg + 1) * rps;
+  for (int q = ql; q < nq; q += nqt) {
     const float4 ga = *reinterpret_cast<const float4*>(gamma + q * 4);
     const float4 be = beta ? *reinterpret_cast<const float4*>(beta + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 m = *reinterpret_cast<const float4*>(mean + (int64_t)seg * C + q * 4);
     const float4 rs = *reinterpret_cast<const float4*>(rstd + (int64_t)seg * C + q * 4);
-    float out[4];
-    float gv[4] = {g.x, g.y, g.z, g.w};
-    const float xv[4] = {v.x, v.y, v.z, v.w}, ov[4] = {o.x, o.y, o.z, o.w}, bev[4] = {be.x, be.y, be.z, be.w};
-    const float gav[4] = {ga.x, ga.y, ga.z, ga.w}, mv[4] = {m.x, m.y, m.z, m.w}, rv[4] = {rs.x, rs.y, rs.z, rs.w};
+    const float gav[4] = {ga.x, ga.y, ga.z, ga.w}, bev[4] = {be.x, be.y, be.z, be.w};
+    const float mv[4] = {m.x, m.y, m.z, m.w}, rv[4] = {rs.x, rs.y, rs.z, rs.w};
+    float sb[4], sg[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float xh = (xv[k] - mv[k]) * rv[k];
-      gv[k] = bn_dz_elem(gv[k], xh, gav[k], bev[k], act, y ? &ov[k] : nullptr, drop_p, drop_seed, (uint64_t)i * 4 + k);
-      const float sb = (float)(wseg[q * 4 + k] * inv_n), sg = (float)(wseg[C + q * 4 + k] * inv_n);
-      out[k] = gav[k] * rv[k] * (gv[k] - sb - xh * sg);
+    for (int k = 0; k < 4; ++k) { sb[k] = (float)(wseg[q * 4 + k] * inv_n); sg[k] = (float)(wseg[C + q * 4 + k] * inv_n); }
+    constexpr int U = 4;
+    for (int64_t row = r0 + rl; row < r1; row += (int64_t)U * lanes) {
+      float4 v4[U], g4[U], o4[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int64_t ru = row + (int64_t)u * lanes;
+        ru = ru < r1 ? ru : r1 - 1;
+        v4[u] = *reinterpret_cast<const float4*>(x + ru * C + q * 4);
+        g4[u] = *reinterpret_cast<const float4*>(dy + ru * C + q * 4);
+        if (has_y) o4[u] = *reinterpret_cast<const float4*>(y + ru * C + q * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t ru = row + (int64_t)u * lanes;
+        if (ru >= r1) break;
+        const float xv[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+        const float gv[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
+        const float4 oo = has_y ? o4[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float ov[4] = {oo.x, oo.y, oo.z, oo.w};
+        float out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xh = (xv[k] - mv[k]) * rv[k];
+          const float g = bn_dz_elem(gv[k], xh, gav[k], bev[k], act, has_y, ov[k], drop_p, drop_seed,
+                                     (uint64_t)(ru * C + q * 4) + k);
+          out[k] = gav[k] * rv[k] * (g - sb[k] - xh * sg[k]);
+        }
+        *reinterpret_cast<float4*>(dx + ru * C + q * 4) = make_float4(out[0], out[1], out[2], out[3]);
+      }
     }
-    *reinterpret_cast<float4*>(dx + i * 4) = make_float4(out[0], out[1], out[2], out[3]);
-  }
-  // parameter gradients: first C threads of the grid
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid < (int64_t)C * segs) {
-    const int seg = (int)(gid / C), c = (int)(gid - (int64_t)seg * C);
-    const double* wseg = ws + (int64_t)seg * STYLER_BN_COPIES * 2 * C;
-    atomicAdd(dbeta + c, (float)wseg[c]); atomicAdd(dgamma + c, (float)wseg[C + c]);
   }
 }
 
@@ -355,10 +395,12 @@ extern "C" int styler_batchnorm_bwd(const float* x, const float* y, const float*
   const int rc = styler_bn_colstats(true, x, y, dy, save_mean, save_rstd, workspace, ws_zeroed, rows, C, act, gamma, beta,
                                     drop_p, drop_seed, segs, st);
   if (rc) return rc;
-  const int64_t total4 = rows * C / 4;
-  int64_t blocks = (total4 + 255) / 256; if (blocks > 4096) blocks = 4096;
+  constexpr int RPB = 32;
+  const int64_t rps = rows / segs;
+  const int bps = (int)((rps + RPB - 1) / RPB);
+  int64_t blocks = (int64_t)bps * segs;
   if (blocks * 256 < (int64_t)C * segs) blocks = ((int64_t)C * segs + 255) / 256;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd,
-                     workspace, dx, dgamma, dbeta, rows, C, act, beta, drop_p, drop_seed, g_styler_drop_epoch, segs);
+                     workspace, dx, dgamma, dbeta, C, act, beta, drop_p, drop_seed, g_styler_drop_epoch, segs, RPB, bps, rps);
   return launch_status();
 }
