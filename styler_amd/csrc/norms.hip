@@ -196,7 +196,9 @@ extern "C" int styler_bn_fold(const float* gamma, const float* beta, const float
 // folded across the row-lanes in LDS and leave as fp64 atomics into one of STYLER_BN_COPIES replicas of the 2C-double
 // accumulator (replica = block % COPIES: 16x fewer collisions per address); bn_fold_copies_kernel sums the replicas.
 #define STYLER_BN_COPIES 16
-#define BN_RPB 32
+#define BN_RPB 32                                  // rows per block of the apply kernels
+#define BN_STAT_RPB 128                            // rows per block of the column statistics
+#define BN_CT 32                                   // float4 columns per block of the column statistics
 
 template <bool BWD>
 __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restrict__ x, const float* __restrict__ y,
@@ -209,13 +211,19 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restric
   // Segments: rows [seg * rps, (seg + 1) * rps) carry their own statistics (the clean and the noisy decode of
   // styler.py:52,55 run through the PostNet as ONE batch, but each call of the reference normalises with its own batch
   // statistics, Layers.py:126).  Block = (segment, chunk of rpb rows); per-segment arrays are [segs][...].
-  const int seg = blockIdx.x / bps, chunk = blockIdx.x - seg * bps;
+  // The column axis is cut into tiles of BN_CT float4 columns (128 channels): a block is (segment, chunk of rpb rows, column
+  // tile) = 8 row-lanes x 32 column quads.  The fp64 atomics that carry the block's sums away are what this kernel's time is
+  // made of (41 us with them, 14 us without, at [42 336, 512]); their number is rows / rpb * 2C whatever the column split, so
+  // tall narrow blocks (128 rows) cut them 4x against full-width blocks of 32 rows at the same block count.
+  const int nq = C / 4;
+  const int nqt = nq < BN_CT ? nq : BN_CT;           // threads across a row
+  const int ct = (nq + nqt - 1) / nqt;               // column tiles
+  const int ctile = blockIdx.x % ct, bc = blockIdx.x / ct;
+  const int seg = bc / bps, chunk = bc - seg * bps;
   ws += (int64_t)seg * STYLER_BN_COPIES * 2 * C;
   if (BWD) { mean += (int64_t)seg * C; rstd += (int64_t)seg * C; }
   const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   __shared__ double red[256][8];
-  const int nq = C / 4;
-  const int nqt = nq < 256 ? nq : 256;               // threads across a row
   const int lanes = 256 / nqt;                       // row-lanes
   const int rl = threadIdx.x / nqt, ql = threadIdx.x - rl * nqt;
   const bool live = rl < lanes;
@@ -223,8 +231,8 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restric
   int64_t r1 = r0 + rpb; if (r1 > (seg + 1) * rps) r1 = (seg + 1) * rps;
   (void)rows;
   double* wsc = ws + (int64_t)(chunk % STYLER_BN_COPIES) * 2 * C;
-  for (int q0 = 0; q0 < nq; q0 += nqt) {
-    const int q = q0 + ql;
+  {
+    const int q = ctile * nqt + ql;
     double s[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
     if (live && q < nq) {
       float4 m = make_float4(0.f, 0.f, 0.f, 0.f), rs = m, ga = m, be = m;
@@ -308,12 +316,13 @@ int styler_bn_colstats(bool bwd, const float* x, const float* y, const float* dy
     hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * STYLER_BN_COPIES * segs, st);
     if (e != hipSuccess) return (int)e;
   }
-  static const int rpb_env = [] { const char* e = getenv("STYLER_BN_RPB"); return e ? atoi(e) : BN_RPB; }();
-  const int rpb = rpb_env > 0 ? rpb_env : BN_RPB;
+  static const int rpb_env = [] { const char* e = getenv("STYLER_BN_RPB"); return e ? atoi(e) : BN_STAT_RPB; }();
+  const int rpb = rpb_env > 0 ? rpb_env : BN_STAT_RPB;
   static const int dbg = [] { const char* e = getenv("STYLER_BN_DBG"); return e ? atoi(e) : 0; }();   // timing experiments
   const int64_t rps = rows / segs;                   // rows per segment
   const int bps = (int)((rps + rpb - 1) / rpb);      // blocks per segment
-  const dim3 grid((unsigned)(bps * segs));
+  const int nq = C / 4, nqt = nq < BN_CT ? nq : BN_CT;
+  const dim3 grid((unsigned)(bps * segs * ((nq + nqt - 1) / nqt)));
   if (bwd)
     hipLaunchKernelGGL(bn_colstats_kernel<true>, grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, rows, C, act, gamma, beta,
                        drop_p, drop_seed, g_styler_drop_epoch, rpb, bps, rps, dbg);
