@@ -188,8 +188,13 @@ int styler_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t 
  * other norm entry points with a workspace); stats (optional): [B][C/16][2] floats = mean, rstd of every
  * group, the input styler_groupnorm_relu_bwd needs. */
 int styler_groupnorm_relu(const float* x, int64_t ldx, const float* gamma, const float* beta,
-                          float* y, int64_t ldy, float* stats, double* workspace, int ws_zeroed, int B,
-                          int L, int C, void* stream);
+                          void* y, int64_t ldy, float* stats, double* workspace, int ws_zeroed, int B,
+                          int L, int C, int io_flags, void* stream);
+/* io_flags & STYLER_IO_Y_BF16 (here and in styler_batchnorm_train; STYLER_IO_Y_BF16 on the two backward entry points means
+ * dx, and STYLER_IO_X_BF16 there means the incoming dy is bf16): the output tensor is bf16 (ldy in elements).  Throughput mode stores the activations between the convolutions of
+ * the AudioEncoder / PostNet stacks -- and the gradients w.r.t. those convolutions' outputs -- that way: their only
+ * consumers (the next convolution, the dX GEMM, the weight gradient) round to bf16 first, so no result changes and
+ * every one of them moves half the bytes. */
 
 /* BatchNorm1d folding for eval mode (Layers.py:91,105,118): scale = g * rsqrt(var + eps),
  * shift = (conv_bias - mean) * scale + b.  All [C]. */
@@ -204,10 +209,10 @@ int styler_bn_fold(const float* gamma, const float* beta, const float* running_m
  * column accumulator, spreading the fp64 atomics), zeroed here.
  * drop_p > 0: y = dropout(act(BN(x))) -- the F.dropout of Layers.py:126-128 in the same pass, with the stream
  * styler_dropout(seed drop_seed) would draw on the [rows, C] tensor. */
-int styler_batchnorm_train(const float* x, const float* gamma, const float* beta, float* y,
+int styler_batchnorm_train(const float* x, const float* gamma, const float* beta, void* y,
                            float* save_mean, float* save_rstd, float* running_mean,
                            float* running_var, double* workspace, int ws_zeroed, int64_t rows, int C,
-                           int act, float drop_p, uint64_t drop_seed, int segs, void* stream);
+                           int act, float drop_p, uint64_t drop_seed, int segs, int io_flags, void* stream);
 /* `segs` >= 1 (rows % segs == 0): rows [s * rows/segs, (s+1) * rows/segs) are normalised with THEIR OWN batch statistics,
  * exactly as `segs` separate calls (the clean and the noisy decode of styler.py:52,55 run through the PostNet as one batch;
  * Layers.py:126 uses per-call statistics); save_mean / save_rstd are [segs, C], workspace segs * 16 * 2*C doubles, the
@@ -482,18 +487,18 @@ int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t l
                          float* dx_drop, int64_t lddxd, int replicas, void* stream);
 
 /* stats = the forward's [B][C/16][2] (mean, rstd); workspace 2*B*C/16 doubles (scratch). */
-int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy,
-                              const float* gamma, const float* beta, const float* stats, float* dx,
+int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void* dy, int64_t lddy,
+                              const float* gamma, const float* beta, const float* stats, void* dx,
                               int64_t lddx, float* dgamma, float* dbeta, double* workspace, int ws_zeroed,
-                              int B, int L, int C, void* stream);
+                              int B, int L, int C, int io_flags, void* stream);
 
 /* BatchNorm1d(train)+act(+dropout) backward; x, y, dy, dx contiguous [rows, C]; workspace 16 * 2*C doubles.
  * y may be NULL when beta is given: the tanh output is then recomputed from x (one read less); drop_p / drop_seed
  * must repeat the forward's (the mask is regenerated, dy is the gradient of the dropped output). */
-int styler_batchnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
-                         const float* save_mean, const float* save_rstd, float* dx, float* dgamma,
+int styler_batchnorm_bwd(const float* x, const float* y, const void* dy, const float* gamma,
+                         const float* save_mean, const float* save_rstd, void* dx, float* dgamma,
                          float* dbeta, double* workspace, int ws_zeroed, int64_t rows, int C, int act,
-                         const float* beta, float drop_p, uint64_t drop_seed, int segs, void* stream);
+                         const float* beta, float drop_p, uint64_t drop_seed, int segs, int io_flags, void* stream);
 
 int styler_embed_bwd(const int64_t* text, const float* dy, int64_t lddy, float* demb, int B, int L,
                      int C, void* stream);

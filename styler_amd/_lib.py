@@ -26,9 +26,9 @@ _SIGS = {
     "styler_attention_fwd_bf16": [P, P, P, I, I, P, P, P],
     "styler_attention_bwd_bf16": [P, P, P, P, P, P, I, I, P, P, P],
     "styler_add_layernorm": [P, I64, P, I64, P, P, P, I64, P, P, P, I, I, I, P, F, ctypes.c_uint64, F, ctypes.c_uint64, P, I64, P],
-    "styler_groupnorm_relu": [P, I64, P, P, P, I64, P, P, I, I, I, I, P],
+    "styler_groupnorm_relu": [P, I64, P, P, P, I64, P, P, I, I, I, I, I, P],
     "styler_bn_fold": [P, P, P, P, P, P, P, I, P],
-    "styler_batchnorm_train": [P, P, P, P, P, P, P, P, P, I, I64, I, I, F, ctypes.c_uint64, I, P],
+    "styler_batchnorm_train": [P, P, P, P, P, P, P, P, P, I, I64, I, I, F, ctypes.c_uint64, I, I, P],
     "styler_embed_pos": [P, P, P, P, I, I, I, P],
     "styler_add_pos": [P, I64, P, P, I, I, I, P],
     "styler_gather_rows": [P, P, P, I64, I, P],
@@ -65,8 +65,8 @@ _SIGS = {
     "styler_repack_weight_bwd": [P, P, I, I, I, I, P],
     "styler_attention_bwd": [P, P, P, P, P, P, I, I, P, P, P],
     "styler_layernorm_bwd": [P, I64, P, I64, P, P, P, I64, P, P, P, P, P, P, I, I, I, P, F, ctypes.c_uint64, F, ctypes.c_uint64, P, I64, I, P],
-    "styler_groupnorm_relu_bwd": [P, I64, P, I64, P, P, P, P, I64, P, P, P, I, I, I, I, P],
-    "styler_batchnorm_bwd": [P, P, P, P, P, P, P, P, P, P, I, I64, I, I, P, F, ctypes.c_uint64, I, P],
+    "styler_groupnorm_relu_bwd": [P, I64, P, I64, P, P, P, P, I64, P, P, P, I, I, I, I, I, P],
+    "styler_batchnorm_bwd": [P, P, P, P, P, P, P, P, P, P, I, I64, I, I, P, F, ctypes.c_uint64, I, I, P],
     "styler_embed_bwd": [P, P, I64, P, I, I, I, P],
     "styler_onehot_expand": [P, P, I64, P],
     "styler_mel_calibrate_bwd": [P, I64, P, I64, P, P, I, I, I, I, P],

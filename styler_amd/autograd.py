@@ -75,8 +75,11 @@ class ConvGemmFn(Function):
             bf16 = rt.prec == ops.PREC_BF16 and n % 8 == 0
             wt = gemm_weight_bwd(ctx.cache, ctx.key, weight, bf16)
             prec = ops.PREC_BF16 if bf16 else ops.PREC_F32
+            # a bf16 activation gets a bf16 gradient (autograd would cast an fp32 one to the input's dtype anyway -- with a
+            # kernel of its own): written as bf16 by the GEMM, read as bf16 by the norm backward that consumes it
             dx = ops.conv_gemm(dz, wt, None, kw=kw, n=cin, prec=prec,
-                               scale=_neg(cin, dz.device) if ctx.neg_dx else None, plan=plan)
+                               scale=_neg(cin, dz.device) if ctx.neg_dx else None, plan=plan,
+                               out_bf16=x.dtype == torch.bfloat16 and prec == ops.PREC_BF16)
         return dx, (dy if ctx.has_res else None), None, None, None, None, None, None, None, None
 
 
@@ -230,34 +233,97 @@ class LayerNormDotFn(Function):
         return dx, None, None, None, None, None, None
 
 
-class GroupNormReluFn(Function):
+class ConvNormFn(Function):
+    """norm_act(conv_same(x, W) + b) as ONE tape node: Conv1d -> GroupNorm + ReLU (AudioEncoder, modules.py:103-113) or
+    Conv1d -> train-mode BatchNorm1d (+ tanh) + dropout (PostNet, Layers.py:91-128).
+
+    One node because of what lives between its kernels in throughput mode: the gradient w.r.t. the convolution's output is
+    consumed only by the dX GEMM and the weight-gradient kernel, which round it to bf16 first, so the norm backward writes
+    it as bf16 (same results, half the bytes for all three kernels).  As a gradient crossing the tape it would be cast back
+    to the fp32 of the convolution's output by autograd.  `out_bf16`: the activation y is stored as bf16 as well (its only
+    consumers are the next convolution and that convolution's weight gradient); the gradient that comes back for it is then
+    bf16 too (written by the next node's dX GEMM, read here by the norm backward)."""
+
     @staticmethod
-    def forward(ctx, x, anchor, gn):
+    def forward(ctx, x, weight, bias, cache, key, kw, norm, kind, act, drop_p, segs, out_bf16):
+        w, prec = gemm_weight(cache, key, weight, x.shape[-1])
+        z = ops.conv_gemm(x, w, bias, kw=kw, n=weight.shape[0], prec=prec)
+        b16 = prec == ops.PREC_BF16 and rt.bf16_acts and weight.shape[0] % 8 == 0
+        out_bf16 = out_bf16 and b16
+        if kind == "gn":
+            aux = torch.empty(z.shape[0], z.shape[2] // 16, 2, device=z.device, dtype=torch.float32)
+            y = ops.groupnorm_relu(z, norm.weight, norm.bias, stats=aux,
+                                   out=torch.empty_like(z, dtype=torch.bfloat16) if out_bf16 else torch.empty_like(z))
+            ctx.save_for_backward(x, z, aux)
+            ctx.drop = (0.0, 0)
+        else:
+            drop_p = 0.0 if rt.disable_dropout else drop_p
+            seed = next_dropout_seed() if drop_p > 0 else 0
+            y, mean, rstd = ops.batchnorm_train(z, norm.weight, norm.bias, norm.running_mean, norm.running_var, act,
+                                                drop_p=drop_p, drop_seed=seed, segs=segs, out_bf16=out_bf16)
+            ctx.save_for_backward(x, z, mean, rstd)
+            ctx.drop = (drop_p, seed)
+        ctx.weight, ctx.bias, ctx.cache, ctx.key, ctx.kw = weight, bias, cache, key, kw
+        ctx.norm, ctx.kind, ctx.act, ctx.segs, ctx.b16 = norm, kind, act, segs, b16
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        norm, weight, bias, kw = ctx.norm, ctx.weight, ctx.bias, ctx.kw
+        if ctx.kind == "gn":
+            x, z, stats = ctx.saved_tensors
+            dz = ops.groupnorm_relu_bwd(z, dy, norm.weight, norm.bias, stats, G(norm.weight), G(norm.bias), dx_bf16=ctx.b16)
+        else:
+            x, z, mean, rstd = ctx.saved_tensors
+            dz = ops.batchnorm_bwd(z, None, dy, norm.weight, mean, rstd, G(norm.weight), G(norm.bias), ctx.act,
+                                   beta=norm.bias, drop_p=ctx.drop[0], drop_seed=ctx.drop[1], segs=ctx.segs,
+                                   dx_bf16=ctx.b16)
+        n, cin = weight.shape[0], x.shape[-1]
+        if weight.requires_grad:
+            ops.wgrad(dz, x, G(weight), n, cin, kw=kw, db=G(bias) if (bias is not None and bias.requires_grad) else None)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            bf16 = rt.prec == ops.PREC_BF16 and n % 8 == 0
+            wt = gemm_weight_bwd(ctx.cache, ctx.key, weight, bf16)
+            dx = ops.conv_gemm(dz, wt, None, kw=kw, n=cin, prec=ops.PREC_BF16 if bf16 else ops.PREC_F32,
+                               out_bf16=bf16 and x.dtype == torch.bfloat16)
+        return (dx,) + (None,) * 11
+
+
+class GroupNormReluFn(Function):
+    """relu(GroupNorm(x)).  `out_bf16`: y is stored as bf16 (throughput mode, when the only consumer is the next convolution
+    -- which rounds its activation operand to bf16 anyway); `dx_bf16`: so is the gradient handed to the convolution that
+    produced x (its dX GEMM and weight gradient round it to bf16 anyway)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, gn, out_bf16=False, dx_bf16=False):
         stats = torch.empty(x.shape[0], x.shape[2] // 16, 2, device=x.device, dtype=torch.float32)
-        y = ops.groupnorm_relu(x, gn.weight, gn.bias, out=torch.empty_like(x), stats=stats)
+        out = torch.empty_like(x, dtype=torch.bfloat16) if out_bf16 else torch.empty_like(x)
+        y = ops.groupnorm_relu(x, gn.weight, gn.bias, out=out, stats=stats)
         ctx.save_for_backward(x, stats)
-        ctx.gn = gn
+        ctx.gn, ctx.dx_bf16 = gn, dx_bf16
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, stats = ctx.saved_tensors
         gn = ctx.gn
-        return ops.groupnorm_relu_bwd(x, dy, gn.weight, gn.bias, stats, G(gn.weight), G(gn.bias)), None, None
+        return ops.groupnorm_relu_bwd(x, dy, gn.weight, gn.bias, stats, G(gn.weight), G(gn.bias),
+                                      dx_bf16=ctx.dx_bf16), None, None, None, None
 
 
 class BatchNormActFn(Function):
     """dropout(act(BatchNorm1d_train(x))) (Layers.py:91-128) in one pass; backward regenerates the dropout mask and
-    recomputes the tanh output from x instead of saving it."""
+    recomputes the tanh output from x instead of saving it.  `out_bf16` / `dx_bf16` as in GroupNormReluFn."""
 
     @staticmethod
-    def forward(ctx, x, anchor, bn, act, drop_p=0.0, segs=1):
+    def forward(ctx, x, anchor, bn, act, drop_p=0.0, segs=1, out_bf16=False, dx_bf16=False):
         drop_p = 0.0 if rt.disable_dropout else drop_p
         seed = next_dropout_seed() if drop_p > 0 else 0
         y, mean, rstd = ops.batchnorm_train(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, act,
-                                            drop_p=drop_p, drop_seed=seed, segs=segs)
+                                            drop_p=drop_p, drop_seed=seed, segs=segs, out_bf16=out_bf16)
         ctx.save_for_backward(x, mean, rstd)
-        ctx.bn, ctx.act, ctx.drop, ctx.segs = bn, act, (drop_p, seed), segs
+        ctx.bn, ctx.act, ctx.drop, ctx.segs, ctx.dx_bf16 = bn, act, (drop_p, seed), segs, dx_bf16
         return y
 
     @staticmethod
@@ -265,8 +331,8 @@ class BatchNormActFn(Function):
         x, mean, rstd = ctx.saved_tensors
         bn = ctx.bn
         dx = ops.batchnorm_bwd(x, None, dy, bn.weight, mean, rstd, G(bn.weight), G(bn.bias), ctx.act, beta=bn.bias,
-                               drop_p=ctx.drop[0], drop_seed=ctx.drop[1], segs=ctx.segs)
-        return dx, None, None, None, None, None
+                               drop_p=ctx.drop[0], drop_seed=ctx.drop[1], segs=ctx.segs, dx_bf16=ctx.dx_bf16)
+        return dx, None, None, None, None, None, None, None
 
 
 class EmbedPosFn(Function):

@@ -70,6 +70,16 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16_rne(float lo, float hi) {
   return *reinterpret_cast<const uint32_t*>(&b);
 }
 
+// four consecutive elements at element index `idx` of a tensor stored as fp32 or (is16) bf16
+__device__ __forceinline__ float4 load4_f32_or_bf16(const void* base, int64_t idx, bool is16) {
+  if (is16) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + idx);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+  }
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
+}
+
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
 }

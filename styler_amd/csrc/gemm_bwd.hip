@@ -574,9 +574,10 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
                       const int32_t* chunktab, const int64_t* counts, int io_flags, void* stream) {
   if (!dz || !x || !dw || !workspace || B <= 0 || L <= 0 || n <= 0 || cin <= 0 || (db2 && !db)) return STYLER_EINVAL;
   const bool dz16 = io_flags & STYLER_IO_Y_BF16, x16 = io_flags & STYLER_IO_X_BF16;
-  if (dz16 || x16) {                                 // bf16-resident operands: the two shapes of the FFN sublayer only
-    const bool ok = prec == STYLER_PREC_BF16 && !(dz16 && x16) && !(lddz & 7) && !(ldx & 7) &&
-                    ((x16 && kw == 1 && pad_left == 0) || (dz16 && kw == 9));
+  if (dz16 || x16) {                                 // bf16-resident operands: the two shapes of the FFN sublayer, and the
+    // k = 5 convolutions of the AudioEncoder / PostNet stacks (any combination of the two operands)
+    const bool ok = prec == STYLER_PREC_BF16 && (!dz16 || !(lddz & 7)) && (!x16 || !(ldx & 7)) &&
+                    ((x16 && !dz16 && kw == 1 && pad_left == 0) || (dz16 && !x16 && kw == 9) || kw == 5);
     if (!ok) return STYLER_EINVAL;
   }
   if (kw != 1 && kw != 3 && kw != 5 && kw != 9) return STYLER_EINVAL;
@@ -606,7 +607,14 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
     } else if (kw == 3) {
       if (TA == 2) WT_LAUNCH(3, 2, 1); else WT_LAUNCH(3, 1, 1);
     } else if (kw == 5) {
-      if (TA == 2) WT_LAUNCH(5, 2, 1); else WT_LAUNCH(5, 1, 1);
+#define WT5(D_, X_) hipLaunchKernelGGL((wgrad_tr_kernel<5, 1, 1, D_, X_>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, db2, Be, \
+                                       Le, n, cin, pad_left, ct, cpi, cps, tiles, splits, ws,                                  \
+                                       reinterpret_cast<const int4*>(chunktab), counts)
+      if (dz16 || x16) {
+        if (TA != 1 || TB != 1) return STYLER_EINVAL;
+        if (dz16 && x16) WT5(true, true); else if (dz16) WT5(true, false); else WT5(false, true);
+      } else if (TA == 2) WT_LAUNCH(5, 2, 1); else WT_LAUNCH(5, 1, 1);
+#undef WT5
     } else {
       if (dz16)
         hipLaunchKernelGGL((wgrad_tr_kernel<9, 1, 1, true, false>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, db2, Be, Le,

@@ -125,8 +125,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int64_t ldx,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const double* __restrict__ ws, float* __restrict__ y, int64_t ldy,
-                                                       float* __restrict__ stats, int L, int C, int seg_rows) {
+                                                       const double* __restrict__ ws, void* __restrict__ y, int64_t ldy,
+                                                       float* __restrict__ stats, int L, int C, int seg_rows, int y16) {
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int t0 = blockIdx.z * seg_rows;
@@ -141,7 +141,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   const float4 g = *reinterpret_cast<const float4*>(gamma + c0 + cq * 4);
   const float4 bt = *reinterpret_cast<const float4*>(beta + c0 + cq * 4);
   const float* xp = x + (int64_t)b * L * ldx + c0 + cq * 4;
-  float* yp = y + (int64_t)b * L * ldy + c0 + cq * 4;
+  // y16: the output lives as bf16 (throughput mode: its only consumers, the next convolution and that convolution's
+  // weight gradient, round it to bf16 anyway -- same results, half the bytes written here and read there)
+  float* yp = reinterpret_cast<float*>(y) + (int64_t)b * L * ldy + c0 + cq * 4;
+  uint16_t* yp16 = reinterpret_cast<uint16_t*>(y) + (int64_t)b * L * ldy + c0 + cq * 4;
   for (int t = t0 + rl; t < t1; t += 16) {
     const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
     float4 o;
@@ -149,13 +152,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     o.y = fmaxf((v.y - mean) * rstd * g.y + bt.y, 0.f);
     o.z = fmaxf((v.z - mean) * rstd * g.z + bt.z, 0.f);
     o.w = fmaxf((v.w - mean) * rstd * g.w + bt.w, 0.f);
-    *reinterpret_cast<float4*>(yp + (int64_t)t * ldy) = o;
+    if (y16) *reinterpret_cast<uint2*>(yp16 + (int64_t)t * ldy) = make_uint2(cvt_pk_bf16_rne(o.x, o.y), cvt_pk_bf16_rne(o.z, o.w));
+    else *reinterpret_cast<float4*>(yp + (int64_t)t * ldy) = o;
   }
 }
 
-extern "C" int styler_groupnorm_relu(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
+extern "C" int styler_groupnorm_relu(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y,
                                      int64_t ldy, float* stats, double* workspace, int ws_zeroed, int B, int L, int C,
-                                     void* stream) {
+                                     int io_flags, void* stream) {
   if (!x || !y || !gamma || !beta || !workspace || B <= 0 || L <= 0 || C <= 0 || (C & 63)) return STYLER_EINVAL;
   if ((ldx & 3) || (ldy & 3)) return STYLER_EALIGN;
   hipStream_t st = (hipStream_t)stream;
@@ -168,7 +172,7 @@ extern "C" int styler_groupnorm_relu(const float* x, int64_t ldx, const float* g
   const dim3 grid(C / 64, B, (L + seg_rows - 1) / seg_rows);
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, st, x, ldx, workspace, L, C, seg_rows);
   hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, st, x, ldx, gamma, beta, workspace, y, ldy, stats, L, C,
-                     seg_rows);
+                     seg_rows, (io_flags & STYLER_IO_Y_BF16) ? 1 : 0);
   return launch_status();
 }
 
@@ -202,12 +206,12 @@ extern "C" int styler_bn_fold(const float* gamma, const float* beta, const float
 
 template <bool BWD>
 __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                          const float* __restrict__ dy, const float* __restrict__ mean,
+                                                          const void* __restrict__ dy, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, double* __restrict__ ws,
                                                           int64_t rows, int C, int act, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float drop_p,
                                                           uint64_t drop_seed_host, const uint64_t* __restrict__ epoch,
-                                                          int rpb, int bps, int64_t rps, int dbg) {
+                                                          int rpb, int bps, int64_t rps, int dbg, int dy16) {
   // Segments: rows [seg * rps, (seg + 1) * rps) carry their own statistics (the clean and the noisy decode of
   // styler.py:52,55 run through the PostNet as ONE batch, but each call of the reference normalises with its own batch
   // statistics, Layers.py:126).  Block = (segment, chunk of rpb rows); per-segment arrays are [segs][...].
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restric
           ru = ru < r1 ? ru : r1 - 1;                      // clamped, discarded below: no lane branches around loads
           v4[u] = *reinterpret_cast<const float4*>(x + ru * C + q * 4);
           if (BWD) {
-            g4[u] = *reinterpret_cast<const float4*>(dy + ru * C + q * 4);
+            g4[u] = load4_f32_or_bf16(dy, ru * C + q * 4, dy16);
             if (has_y) o4[u] = *reinterpret_cast<const float4*>(y + ru * C + q * 4);
           }
         }
@@ -309,9 +313,9 @@ __global__ void bn_fold_copies_kernel(double* __restrict__ ws, int C2, int segs)
   ws[i] = t;
 }
 
-int styler_bn_colstats(bool bwd, const float* x, const float* y, const float* dy, const float* mean, const float* rstd,
+int styler_bn_colstats(bool bwd, const float* x, const float* y, const void* dy, const float* mean, const float* rstd,
                        double* ws, int ws_zeroed, int64_t rows, int C, int act, const float* gamma, const float* beta,
-                       float drop_p, uint64_t drop_seed, int segs, hipStream_t st) {
+                       float drop_p, uint64_t drop_seed, int segs, int dy16, hipStream_t st) {
   if (!ws_zeroed) {
     hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * STYLER_BN_COPIES * segs, st);
     if (e != hipSuccess) return (int)e;
@@ -325,10 +329,10 @@ int styler_bn_colstats(bool bwd, const float* x, const float* y, const float* dy
   const dim3 grid((unsigned)(bps * segs * ((nq + nqt - 1) / nqt)));
   if (bwd)
     hipLaunchKernelGGL(bn_colstats_kernel<true>, grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, rows, C, act, gamma, beta,
-                       drop_p, drop_seed, g_styler_drop_epoch, rpb, bps, rps, dbg);
+                       drop_p, drop_seed, g_styler_drop_epoch, rpb, bps, rps, dbg, dy16);
   else
     hipLaunchKernelGGL(bn_colstats_kernel<false>, grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, rows, C, act, gamma, beta,
-                       drop_p, drop_seed, g_styler_drop_epoch, rpb, bps, rps, dbg);
+                       drop_p, drop_seed, g_styler_drop_epoch, rpb, bps, rps, dbg, dy16);
   hipLaunchKernelGGL(bn_fold_copies_kernel, dim3((2 * C * segs + 255) / 256), dim3(256), 0, st, ws, 2 * C, segs);
   return 0;
 }
@@ -359,9 +363,12 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, float* save_me
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
                                                        const float* __restrict__ mean,
-                                                       const float* __restrict__ rstd, float* __restrict__ y,
+                                                       const float* __restrict__ rstd, void* __restrict__ yv,
                                                        int C, int act, float drop_p, uint64_t drop_seed_host,
-                                                       const uint64_t* __restrict__ epoch, int rpb, int bps, int64_t rps) {
+                                                       const uint64_t* __restrict__ epoch, int rpb, int bps, int64_t rps,
+                                                       int y16) {
+  float* const y = reinterpret_cast<float*>(yv);
+  uint16_t* const yh = reinterpret_cast<uint16_t*>(yv);    // y16: bf16 output (see gn_apply_kernel)
   const int seg = blockIdx.x / bps, chunk = blockIdx.x - seg * bps;
   const int nq = C / 4;
   const int nqt = nq < 256 ? nq : 256;
@@ -406,28 +413,29 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
           o.z = dropout_hash32(drop_seed, e + 2) >= thr ? o.z * sc : 0.f;
           o.w = dropout_hash32(drop_seed, e + 3) >= thr ? o.w * sc : 0.f;
         }
-        *reinterpret_cast<float4*>(y + ru * C + q * 4) = o;
+        if (y16) *reinterpret_cast<uint2*>(yh + ru * C + q * 4) = make_uint2(cvt_pk_bf16_rne(o.x, o.y), cvt_pk_bf16_rne(o.z, o.w));
+        else *reinterpret_cast<float4*>(y + ru * C + q * 4) = o;
       }
     }
   }
 }
 
-extern "C" int styler_batchnorm_train(const float* x, const float* gamma, const float* beta, float* y,
+extern "C" int styler_batchnorm_train(const float* x, const float* gamma, const float* beta, void* y,
                                       float* save_mean, float* save_rstd, float* running_mean, float* running_var,
                                       double* workspace, int ws_zeroed, int64_t rows, int C, int act, float drop_p,
-                                      uint64_t drop_seed, int segs, void* stream) {
+                                      uint64_t drop_seed, int segs, int io_flags, void* stream) {
   if (!x || !gamma || !beta || !y || !save_mean || !save_rstd || !workspace || rows <= 0 || C <= 0 || (C & 3) ||
       drop_p < 0.f || drop_p >= 1.f || segs < 1 || rows % segs)
     return STYLER_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int rc = styler_bn_colstats(false, x, nullptr, nullptr, nullptr, nullptr, workspace, ws_zeroed, rows, C, act, nullptr,
-                                    nullptr, 0.f, 0, segs, st);
+                                    nullptr, 0.f, 0, segs, 0, st);
   if (rc) return rc;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, save_mean, save_rstd,
                      running_mean, running_var, rows, C, segs);
   const int64_t rps = rows / segs;
   const int bps = (int)((rps + BN_RPB - 1) / BN_RPB);
   hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)(bps * segs)), dim3(256), 0, st, x, gamma, beta, save_mean, save_rstd,
-                     y, C, act, drop_p, drop_seed, g_styler_drop_epoch, BN_RPB, bps, rps);
+                     y, C, act, drop_p, drop_seed, g_styler_drop_epoch, BN_RPB, bps, rps, (io_flags & STYLER_IO_Y_BF16) ? 1 : 0);
   return launch_status();
 }

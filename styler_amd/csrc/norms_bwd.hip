@@ -196,12 +196,12 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
 int gn_segments_host(int B, int L, int C);
 
 __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restrict__ x, int64_t ldx,
-                                                           const float* __restrict__ dy, int64_t lddy,
+                                                           const void* __restrict__ dy, int64_t lddy,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ stats, double* __restrict__ ws,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int L,
-                                                           int C, int seg_rows) {
+                                                           int C, int seg_rows, int dy16) {
   __shared__ double red[2][16][16];
   __shared__ float pg[2][16][64];
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
@@ -211,14 +211,14 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
   const int64_t gi = ((int64_t)b * (C / 16) + c0 / 16 + (cq >> 2)) * 2;
   const float mean = stats[gi], rstd = stats[gi + 1];
   const float* xp = x + (int64_t)b * L * ldx + c0 + cq * 4;
-  const float* gp = dy + (int64_t)b * L * lddy + c0 + cq * 4;
+  const int64_t gbase = (int64_t)b * L * lddy + c0 + cq * 4;       // dy16: the incoming gradient is bf16
   const float4 ga = *reinterpret_cast<const float4*>(gamma + c0 + cq * 4);
   const float4 be = *reinterpret_cast<const float4*>(beta + c0 + cq * 4);
   double s1 = 0.0, s2 = 0.0;
   float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
   for (int t = t0 + rl; t < t1; t += 16) {
     const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
-    float4 g = *reinterpret_cast<const float4*>(gp + (int64_t)t * lddy);
+    float4 g = load4_f32_or_bf16(dy, gbase + (int64_t)t * lddy, dy16);
     const float hx = (v.x - mean) * rstd, hy = (v.y - mean) * rstd, hz = (v.z - mean) * rstd, hw = (v.w - mean) * rstd;
     g.x = (hx * ga.x + be.x) > 0.f ? g.x : 0.f; g.y = (hy * ga.y + be.y) > 0.f ? g.y : 0.f;
     g.z = (hz * ga.z + be.z) > 0.f ? g.z : 0.f; g.w = (hw * ga.w + be.w) > 0.f ? g.w : 0.f;
@@ -247,12 +247,12 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, int64_t ldx,
-                                                           const float* __restrict__ dy, int64_t lddy,
+                                                           const void* __restrict__ dy, int64_t lddy,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ stats,
-                                                           const double* __restrict__ ws, float* __restrict__ dx,
-                                                           int64_t lddx, int L, int C, int seg_rows) {
+                                                           const double* __restrict__ ws, void* __restrict__ dx,
+                                                           int64_t lddx, int L, int C, int seg_rows, int dx16, int dy16) {
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int t0 = blockIdx.z * seg_rows;
@@ -262,26 +262,30 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   const double n = 16.0 * L;
   const float m1 = (float)(ws[gi] / n), m2 = (float)(ws[gi + 1] / n);
   const float* xp = x + (int64_t)b * L * ldx + c0 + cq * 4;
-  const float* gp = dy + (int64_t)b * L * lddy + c0 + cq * 4;
-  float* dxp = dx + (int64_t)b * L * lddx + c0 + cq * 4;
+  const int64_t gbase = (int64_t)b * L * lddy + c0 + cq * 4;
+  // dx16: the gradient w.r.t. the convolution's output is stored as bf16 (throughput mode: its consumers, the dX GEMM and
+  // the weight gradient, round it to bf16 anyway)
+  float* dxp = reinterpret_cast<float*>(dx) + (int64_t)b * L * lddx + c0 + cq * 4;
+  uint16_t* dxp16 = reinterpret_cast<uint16_t*>(dx) + (int64_t)b * L * lddx + c0 + cq * 4;
   const float4 ga = *reinterpret_cast<const float4*>(gamma + c0 + cq * 4);
   const float4 be = *reinterpret_cast<const float4*>(beta + c0 + cq * 4);
   for (int t = t0 + rl; t < t1; t += 16) {
     const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
-    float4 g = *reinterpret_cast<const float4*>(gp + (int64_t)t * lddy);
+    float4 g = load4_f32_or_bf16(dy, gbase + (int64_t)t * lddy, dy16);
     const float hx = (v.x - mean) * rstd, hy = (v.y - mean) * rstd, hz = (v.z - mean) * rstd, hw = (v.w - mean) * rstd;
     g.x = (hx * ga.x + be.x) > 0.f ? g.x * ga.x : 0.f; g.y = (hy * ga.y + be.y) > 0.f ? g.y * ga.y : 0.f;
     g.z = (hz * ga.z + be.z) > 0.f ? g.z * ga.z : 0.f; g.w = (hw * ga.w + be.w) > 0.f ? g.w * ga.w : 0.f;
-    *reinterpret_cast<float4*>(dxp + (int64_t)t * lddx) =
-        make_float4(rstd * (g.x - m1 - hx * m2), rstd * (g.y - m1 - hy * m2), rstd * (g.z - m1 - hz * m2),
-                    rstd * (g.w - m1 - hw * m2));
+    const float4 o = make_float4(rstd * (g.x - m1 - hx * m2), rstd * (g.y - m1 - hy * m2), rstd * (g.z - m1 - hz * m2),
+                                 rstd * (g.w - m1 - hw * m2));
+    if (dx16) *reinterpret_cast<uint2*>(dxp16 + (int64_t)t * lddx) = make_uint2(cvt_pk_bf16_rne(o.x, o.y), cvt_pk_bf16_rne(o.z, o.w));
+    else *reinterpret_cast<float4*>(dxp + (int64_t)t * lddx) = o;
   }
 }
 
-extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy,
-                                         const float* gamma, const float* beta, const float* stats, float* dx,
+extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void* dy, int64_t lddy,
+                                         const float* gamma, const float* beta, const float* stats, void* dx,
                                          int64_t lddx, float* dgamma, float* dbeta, double* workspace, int ws_zeroed, int B,
-                                         int L, int C, void* stream) {
+                                         int L, int C, int io_flags, void* stream) {
   if (!x || !dy || !gamma || !beta || !stats || !dx || !dgamma || !dbeta || !workspace || B <= 0 || L <= 0 || C <= 0 ||
       (C & 63))
     return STYLER_EINVAL;
@@ -294,33 +298,36 @@ extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const floa
   const int nseg = gn_segments_host(B, L, C);
   const int seg_rows = ((L + nseg - 1) / nseg + 15) & ~15;
   const dim3 grid(C / 64, B, (L + seg_rows - 1) / seg_rows);
+  const int dy16 = (io_flags & STYLER_IO_X_BF16) ? 1 : 0;
   hipLaunchKernelGGL(gn_bwd_stats_kernel, grid, dim3(256), 0, st, x, ldx, dy, lddy, gamma, beta, stats, workspace, dgamma,
-                     dbeta, L, C, seg_rows);
+                     dbeta, L, C, seg_rows, dy16);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, dim3(256), 0, st, x, ldx, dy, lddy, gamma, beta, stats, workspace, dx,
-                     lddx, L, C, seg_rows);
+                     lddx, L, C, seg_rows, (io_flags & STYLER_IO_Y_BF16) ? 1 : 0, dy16);
   return launch_status();
 }
 
 // ---------------------------------------------------------------------------------------------------
 // BatchNorm1d (train) + act backward over rows = B*L (pads included), channels-last contiguous [rows, C].
 //   dz = dy * act'(y); dgamma = sum dz*xh; dbeta = sum dz; dx = g*rstd*(dz - dbeta/N - xh*dgamma/N)
-int styler_bn_colstats(bool bwd, const float* x, const float* y, const float* dy, const float* mean, const float* rstd,
+int styler_bn_colstats(bool bwd, const float* x, const float* y, const void* dy, const float* mean, const float* rstd,
                        double* ws, int ws_zeroed, int64_t rows, int C, int act, const float* gamma, const float* beta,
-                       float drop_p, uint64_t drop_seed, int segs, hipStream_t st);   // norms.hip
+                       float drop_p, uint64_t drop_seed, int segs, int dy16, hipStream_t st);   // norms.hip
 #define STYLER_BN_COPIES 16                          // norms.hip
 
 // Same geometry as the forward's column statistics / apply kernels (norms.hip): block = (segment, chunk of rpb rows),
 // thread = (row-lane, float4 column); per-channel constants (incl. the two fp64 column sums) once per thread, rows in
 // batches of four, no index divisions.
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                           const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                           const void* __restrict__ dy, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                           const double* __restrict__ ws, float* __restrict__ dx,
+                                                           const double* __restrict__ ws, void* __restrict__ dxv,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            int C, int act, const float* __restrict__ beta,
                                                            float drop_p, uint64_t drop_seed_host,
                                                            const uint64_t* __restrict__ epoch, int segs, int rpb, int bps,
-                                                           int64_t rps) {
+                                                           int64_t rps, int dx16, int dy16) {
+  float* const dx = reinterpret_cast<float*>(dxv);
+  uint16_t* const dxh = reinterpret_cast<uint16_t*>(dxv);  // dx16: bf16 output (see gn_bwd_apply_kernel)
   // parameter gradients: first C * segs threads of the grid
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid < (int64_t)C * segs) {
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         int64_t ru = row + (int64_t)u * lanes;
         ru = ru < r1 ? ru : r1 - 1;
         v4[u] = *reinterpret_cast<const float4*>(x + ru * C + q * 4);
-        g4[u] = *reinterpret_cast<const float4*>(dy + ru * C + q * 4);
+        g4[u] = load4_f32_or_bf16(dy, ru * C + q * 4, dy16);
         if (has_y) o4[u] = *reinterpret_cast<const float4*>(y + ru * C + q * 4);
       }
 #pragma unroll
@@ -378,22 +385,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                      (uint64_t)(ru * C + q * 4) + k);
           out[k] = gav[k] * rv[k] * (g - sb[k] - xh * sg[k]);
         }
-        *reinterpret_cast<float4*>(dx + ru * C + q * 4) = make_float4(out[0], out[1], out[2], out[3]);
+        if (dx16) *reinterpret_cast<uint2*>(dxh + ru * C + q * 4) = make_uint2(cvt_pk_bf16_rne(out[0], out[1]), cvt_pk_bf16_rne(out[2], out[3]));
+        else *reinterpret_cast<float4*>(dx + ru * C + q * 4) = make_float4(out[0], out[1], out[2], out[3]);
       }
     }
   }
 }
 
-extern "C" int styler_batchnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
-                                    const float* save_mean, const float* save_rstd, float* dx, float* dgamma,
+extern "C" int styler_batchnorm_bwd(const float* x, const float* y, const void* dy, const float* gamma,
+                                    const float* save_mean, const float* save_rstd, void* dx, float* dgamma,
                                     float* dbeta, double* workspace, int ws_zeroed, int64_t rows, int C, int act,
-                                    const float* beta, float drop_p, uint64_t drop_seed, int segs, void* stream) {
+                                    const float* beta, float drop_p, uint64_t drop_seed, int segs, int io_flags, void* stream) {
   if (!x || !dy || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || C <= 0 ||
       (C & 3) || (act == STYLER_ACT_TANH && !y && !beta) || drop_p < 0.f || drop_p >= 1.f || segs < 1 || rows % segs)
     return STYLER_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  const int dy16 = (io_flags & STYLER_IO_X_BF16) ? 1 : 0;
   const int rc = styler_bn_colstats(true, x, y, dy, save_mean, save_rstd, workspace, ws_zeroed, rows, C, act, gamma, beta,
-                                    drop_p, drop_seed, segs, st);
+                                    drop_p, drop_seed, segs, dy16, st);
   if (rc) return rc;
   constexpr int RPB = 32;
   const int64_t rps = rows / segs;
@@ -401,6 +410,7 @@ extern "C" int styler_batchnorm_bwd(const float* x, const float* y, const float*
   int64_t blocks = (int64_t)bps * segs;
   if (blocks * 256 < (int64_t)C * segs) blocks = ((int64_t)C * segs + 255) / 256;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd,
-                     workspace, dx, dgamma, dbeta, C, act, beta, drop_p, drop_seed, g_styler_drop_epoch, segs, RPB, bps, rps);
+                     workspace, dx, dgamma, dbeta, C, act, beta, drop_p, drop_seed, g_styler_drop_epoch, segs, RPB, bps, rps,
+                     (io_flags & STYLER_IO_Y_BF16) ? 1 : 0, dy16);
   return launch_status();
 }

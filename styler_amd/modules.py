@@ -140,9 +140,15 @@ class AudioEncoder(_HipModule):
                         ops.onehot_conv5(v, wt, conv.bias, y, err_flag=err)
                 else:
                     src = (mel if s == 0 else mel_aug) if i == 0 else x
+                    if grad:                             # conv + GroupNorm + ReLU as one tape node (bf16 between the convs)
+                        x = AG.ConvNormFn.apply(src, conv.weight, conv.bias, self._derived, f"c{s}_{i}", 5, gn, "gn",
+                                                ops.ACT_RELU, 0.0, 1, i < 2)
+                        continue
                     y = self._gemm(f"c{s}_{i}", src, conv, kw=5)
                 if grad:
-                    x = AG.GroupNormReluFn.apply(y, gn.weight, gn)
+                    # after a one-hot convolution (its backward takes an fp32 gradient): bf16 output only
+                    b16 = rt.bf16_acts and rt.prec == ops.PREC_BF16 and W[s] % 8 == 0
+                    x = AG.GroupNormReluFn.apply(y, gn.weight, gn, b16 and i < 2, False)
                 else:
                     out = catbuf[..., offs[s]:offs[s] + W[s]] if i == 2 else y
                     x = ops.groupnorm_relu(y, gn.weight, gn.bias, out=out)

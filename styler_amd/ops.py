@@ -466,7 +466,8 @@ def groupnorm_relu(x, gamma, beta, out=None, stats=None):
         out = x
     ws, z = _norm_ws(B * (C // 16) * 2, x.device)
     _chk(lib.styler_groupnorm_relu(x.data_ptr(), _ld(x), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
-                                   _ld(out), _ptr(stats), ws.data_ptr(), z, B, L, C, _stream()), "styler_groupnorm_relu")
+                                   _ld(out), _ptr(stats), ws.data_ptr(), z, B, L, C, 2 if out.dtype == torch.bfloat16 else 0,
+                                   _stream()), "styler_groupnorm_relu")
     return out
 
 
@@ -483,19 +484,20 @@ LN_REPLICAS = 16           # scratch replicas of LayerNorm's parameter gradients
 BN_WS_COPIES = 16        # STYLER_BN_COPIES (norms.hip): replicas of the 2C-double column accumulator
 
 
-def batchnorm_train(x, gamma, beta, running_mean, running_var, act, drop_p=0.0, drop_seed=0, segs=1):
+def batchnorm_train(x, gamma, beta, running_mean, running_var, act, drop_p=0.0, drop_seed=0, segs=1, out_bf16=False):
     """x [B, L, C] contiguous (conv output incl. bias). Returns y (= dropout(act(BN(x))) with drop_p > 0), save_mean,
     save_rstd ([segs, C]: `segs` equal row ranges, each normalised with its own batch statistics)."""
     assert x.is_contiguous()
     C = x.shape[-1]
     rows = x.numel() // C
-    y = torch.empty_like(x)
+    y = torch.empty_like(x, dtype=torch.bfloat16) if out_bf16 else torch.empty_like(x)
     mean = torch.empty(segs, C, device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
     ws, z = _norm_ws(2 * C * BN_WS_COPIES * segs, x.device)
     _chk(lib.styler_batchnorm_train(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
                                     mean.data_ptr(), rstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
-                                    ws.data_ptr(), z, rows, C, act, float(drop_p), int(drop_seed), int(segs), _stream()),
+                                    ws.data_ptr(), z, rows, C, act, float(drop_p), int(drop_seed), int(segs),
+                                    2 if out_bf16 else 0, _stream()),
          "styler_batchnorm_train")
     return y, mean, rstd
 
@@ -838,28 +840,31 @@ def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, do
     return (dx, dxd) if dxd is not None else dx
 
 
-def groupnorm_relu_bwd(x, dy, gamma, beta, stats, dgamma, dbeta):
+def groupnorm_relu_bwd(x, dy, gamma, beta, stats, dgamma, dbeta, dx_bf16=False):
     B, L, C = x.shape
     dy = _rows_view(dy)
-    dx = torch.empty(B, L, C, device=x.device, dtype=torch.float32)
+    dx = torch.empty(B, L, C, device=x.device, dtype=torch.bfloat16 if dx_bf16 else torch.float32)
     ws, z = _norm_ws(B * (C // 16) * 2, x.device)
     _chk(lib.styler_groupnorm_relu_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), gamma.data_ptr(), beta.data_ptr(),
                                        stats.data_ptr(), dx.data_ptr(), C, dgamma.data_ptr(), dbeta.data_ptr(),
-                                       ws.data_ptr(), z, B, L, C, _stream()),
+                                       ws.data_ptr(), z, B, L, C,
+                                       (2 if dx_bf16 else 0) | (1 if dy.dtype == torch.bfloat16 else 0), _stream()),
          "styler_groupnorm_relu_bwd")
     return dx
 
 
-def batchnorm_bwd(x, y, dy, gamma, mean, rstd, dgamma, dbeta, act, beta=None, drop_p=0.0, drop_seed=0, segs=1):
+def batchnorm_bwd(x, y, dy, gamma, mean, rstd, dgamma, dbeta, act, beta=None, drop_p=0.0, drop_seed=0, segs=1,
+                  dx_bf16=False):
     """`y` may be None when `beta` is given (the activation output is recomputed from x)."""
     C = x.shape[-1]
     rows = x.numel() // C
     dy = dy.contiguous()
-    dx = torch.empty_like(x)
+    dx = torch.empty_like(x, dtype=torch.bfloat16) if dx_bf16 else torch.empty_like(x)
     ws, z = _norm_ws(2 * C * BN_WS_COPIES * segs, x.device)
     _chk(lib.styler_batchnorm_bwd(x.data_ptr(), _ptr(y), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                   rstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), z,
-                                  rows, C, act, _ptr(beta), float(drop_p), int(drop_seed), int(segs), _stream()),
+                                  rows, C, act, _ptr(beta), float(drop_p), int(drop_seed), int(segs),
+                                  (2 if dx_bf16 else 0) | (1 if dy.dtype == torch.bfloat16 else 0), _stream()),
          "styler_batchnorm_bwd")
     return dx
 

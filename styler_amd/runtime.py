@@ -38,6 +38,11 @@ class _Runtime:
     # GEMM / norm launches of the PostNet, weight gradients with twice the rows (STYLER_PAIR_POSTNET=0: two passes)
     pair_postnet = os.environ.get("STYLER_PAIR_POSTNET", "1") != "0"
 
+    # throughput mode: the activations between the convolutions of the AudioEncoder / PostNet stacks and the gradients w.r.t.
+    # those convolutions' outputs are STORED as bf16 (norm kernels write bf16, GEMM / weight-gradient kernels read it): every
+    # consumer rounds them to bf16 first, so no result changes and each moves half the bytes (STYLER_BF16_ACTS=0: fp32)
+    bf16_acts = os.environ.get("STYLER_BF16_ACTS", "1") != "0"
+
     def set_precision(self, name):
         self.prec = {"fp32": ops.PREC_F32, "bf16": ops.PREC_BF16}[name]
 

@@ -256,11 +256,13 @@ class PostNet(_HipModule):
             last = i == n - 1
             act = ops.ACT_NONE if last else ops.ACT_TANH
             if self.training:
-                y = self._gemm(f"c{i}", x, conv, kw=self.kernel_size)
-                # BatchNorm (batch statistics) + tanh + F.dropout(.., 0.5, self.training) (Layers.py:126-128): one pass
-                if (self.training and torch.is_grad_enabled()):
-                    y = AG.BatchNormActFn.apply(y, bn.weight, bn, act, 0.5, segs)
+                if torch.is_grad_enabled():
+                    # conv + BatchNorm (batch statistics) + tanh + F.dropout(.., 0.5, self.training) (Layers.py:126-128) as
+                    # one tape node; throughput mode keeps the activations between the convolutions as bf16
+                    y = AG.ConvNormFn.apply(x, conv.weight, conv.bias, self._derived, f"c{i}", self.kernel_size, bn, "bn", act,
+                                            0.5, segs, not last)
                 else:
+                    y = self._gemm(f"c{i}", x, conv, kw=self.kernel_size)
                     p = 0.0 if rt.disable_dropout else 0.5
                     y, _, _ = ops.batchnorm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, act,
                                                   drop_p=p, drop_seed=AG.next_dropout_seed() if p > 0 else 0, segs=segs)
