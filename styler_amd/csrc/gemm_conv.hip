@@ -255,16 +255,26 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
   __syncthreads();
   if (a.trace) stamp[1] = wall_clock64();
 
+#ifdef STYLER_GEMM_TRACE_STEPS                          // diagnosis builds (-DSTYLER_GEMM_TRACE_STEPS, loaded through STYLER_LIB):
+  uint64_t ph[4] = {0, 0, 0, 0};                       // shader-clock cycles wave 0 spends in each phase of the main loop
+#define PH_MARK(i, t0) { const uint64_t t1_ = __builtin_readcyclecounter(); ph[i] += t1_ - t0; t0 = t1_; }
+#else
+#define PH_MARK(i, t0)
+#endif
   int cc = 0, j = 0;
   for (int step = 0; step < nsteps; ++step) {
     // next step's coordinates; its global loads are issued now and land in LDS after this step's MFMAs
     int ccn = cc, jn = j + 1;
     if (jn == kw) { jn = 0; ccn = cc + 1; }
     const bool more = step + 1 < nsteps;
+#ifdef STYLER_GEMM_TRACE_STEPS
+    uint64_t tp = __builtin_readcyclecounter();
+#endif
     if (more) {
       load_b(ccn, jn);
       if (jn == 0) load_a(ccn);
     }
+    PH_MARK(0, tp)
 
     const uint32_t* cA = sA + (OCC3 ? 0 : (cc & 1)) * A_ROWS * LD + j * LD + fa_off;
     const uint32_t* cB = sB + (step & 1) * BN * LDB + fb_off;
@@ -312,6 +322,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
                                                               acc[i][jj], 0, 0, 0);
     }
 
+#ifdef STYLER_GEMM_TRACE_STEPS
+    asm volatile("s_nop 0" ::: "memory");
+#endif
+    PH_MARK(1, tp)
     if (more) {
       store_b((step + 1) & 1);
       if (jn == 0) {
@@ -319,7 +333,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
         store_a(ccn & 1);
       }
     }
+    PH_MARK(2, tp)
     __syncthreads();
+    PH_MARK(3, tp)
     cc = ccn; j = jn;
   }
 
@@ -494,6 +510,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
       for (int i = 0; i < 5; ++i) t[1 + i] = stamp[i];
       t[6] = __builtin_amdgcn_s_getreg((3 << 11) | 4);   // HW_ID (wave, simd, cu, sh, se)
       t[7] = (uint64_t)tile;
+#ifdef STYLER_GEMM_TRACE_STEPS                          // words 6, 7: (issue | ds_read + MFMA) and (wait + ds_write | barrier) cycles
+      t[6] = (ph[0] << 32) | (ph[1] & 0xffffffffu);
+      t[7] = (ph[2] << 32) | (ph[3] & 0xffffffffu);
+#endif
     }
   }
 }

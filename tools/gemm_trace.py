@@ -11,7 +11,7 @@ from styler_amd import ops
 
 SHAPES = [  # name, B, L, cin, n, kw
     ("p_qkv", 1, 27060, 256, 768, 1), ("p_attn_fc", 1, 27060, 256, 256, 1), ("p_ffn_w2_k1", 1, 27060, 1024, 256, 1),
-    ("p_ffn_w1_k9", 1, 27060, 256, 1024, 9), ("postnet_512_k5", 96, 441, 512, 512, 5),
+    ("p_ffn_w1_k9", 1, 27060, 256, 1024, 9), ("postnet_512_k5", 96, 441, 512, 512, 5), ("p_dx_w1_k9", 1, 27060, 1024, 256, 9),
 ]
 
 
@@ -48,6 +48,12 @@ def main():
             print(f"    {lab:28s} {q(ph[:, i])}")
         starts = np.sort(st[:, 0] - t0)
         print("    block start offsets (us) p10/p50/p90/max: %.2f %.2f %.2f %.2f" % (*np.percentile(starts, [10, 50, 90]), starts[-1]))
+        if os.environ.get("STYLER_LIB", "").endswith("_steps.so"):      # diagnosis build: per-phase cycle totals of the main loop
+            p0, p1, p2, p3 = t[:, 6] >> 32, t[:, 6] & 0xffffffff, t[:, 7] >> 32, t[:, 7] & 0xffffffff
+            nst = ((cin + 63) // 64) * kw
+            print("    main-loop cycles per step (median): issue loads %.0f, ds_read + MFMA %.0f, wait loads + ds_write %.0f, barrier %.0f"
+                  % tuple(np.median(x) / nst for x in (p0, p1, p2, p3)))
+            continue
         hw = t[:, 6]
         cu = ((hw >> 8) & 0xf) | (((hw >> 13) & 0x7) << 4)          # cu_id | se_id << 4 (per XCD)
         key = (t[:, 0] % 8) * 1000 + cu
