@@ -556,7 +556,8 @@ extern "C" int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, in
   (void)cin; (void)kw;
   const int64_t M = (int64_t)B * L;
   const int64_t big_blocks = ((M + 127) / 128) * ((n + 127) / 128);
-  int big = (big_blocks >= 192 && n >= 96) ? 1 : 0;
+  static const int nmin = [] { const char* e = getenv("STYLER_GEMM_BIG_NMIN"); return e ? atoi(e) : 96; }();
+  int big = (big_blocks >= 192 && n >= nmin) ? 1 : 0;
   static const int force = [] { const char* e = getenv("STYLER_GEMM_TILE"); return e ? atoi(e) : 0; }();
   if (force == 1) big = 0;
   if (force == 2) big = 1;

@@ -1,0 +1,121 @@
+"""bf16 storage of the activations / gradients between the convolutions of the AudioEncoder and PostNet stacks (throughput
+mode): the claim is that nothing but the storage format changes.  Checked here kernel by kernel: a bf16 output is the
+round-to-nearest-even of the fp32 output, a kernel fed the bf16 tensor gives what it gives when fed the same values as fp32,
+and the one-node conv + norm Function equals the two-node chain."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda")
+
+
+def _bn_inputs(dev, rows=2 * 3 * 131, C=512):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(6, rows // 6, C, generator=g).to(dev)
+    dy = torch.randn(6, rows // 6, C, generator=g).to(dev)
+    w = (1.0 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    b = (0.1 * torch.randn(C, generator=g)).to(dev)
+    return x, dy, w, b
+
+
+def test_batchnorm_bf16_output_is_rounded_fp32(dev):
+    from styler_amd import ops
+    x, dy, w, b = _bn_inputs(dev)
+    C = x.shape[-1]
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    y32, m, r = ops.batchnorm_train(x, w, b, rm.clone(), rv.clone(), ops.ACT_TANH, drop_p=0.5, drop_seed=5, segs=2)
+    y16, m2, r2 = ops.batchnorm_train(x, w, b, rm.clone(), rv.clone(), ops.ACT_TANH, drop_p=0.5, drop_seed=5, segs=2, out_bf16=True)
+    assert y16.dtype == torch.bfloat16 and torch.equal(y16, y32.to(torch.bfloat16))
+    assert torch.equal(m, m2) and torch.equal(r, r2)
+    # backward: bf16 dy in == the same values as fp32 in; bf16 dx out == rounded fp32 dx
+    dy16 = dy.to(torch.bfloat16)
+    outs = []
+    for dyv, o16 in ((dy16.float(), False), (dy16, False), (dy16, True)):
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        dx = ops.batchnorm_bwd(x, None, dyv, w, m, r, dg, db, ops.ACT_TANH, beta=b, drop_p=0.5, drop_seed=5, segs=2, dx_bf16=o16)
+        outs.append((dx, dg, db))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[2][0], outs[0][0].to(torch.bfloat16))
+    for k in (1, 2):                       # parameter gradients: fp64 atomics, order-dependent in the last bits only
+        assert torch.allclose(outs[0][k], outs[1][k], rtol=1e-5, atol=1e-5) and torch.allclose(outs[0][k], outs[2][k], rtol=1e-5, atol=1e-5)
+
+
+def test_groupnorm_bf16_output_is_rounded_fp32(dev):
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(12)
+    B, L, C = 6, 137, 320
+    x = torch.randn(B, L, C, generator=g).to(dev)
+    dy = torch.randn(B, L, C, generator=g).to(dev)
+    w = (1.0 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    b = (0.1 * torch.randn(C, generator=g)).to(dev)
+    st = torch.empty(B, C // 16, 2, device=dev)
+    y32 = ops.groupnorm_relu(x, w, b, out=torch.empty_like(x), stats=st)
+    y16 = ops.groupnorm_relu(x, w, b, out=torch.empty_like(x, dtype=torch.bfloat16), stats=torch.empty_like(st))
+    assert torch.equal(y16, y32.to(torch.bfloat16))
+    dy16 = dy.to(torch.bfloat16)
+    res = []
+    for dyv, o16 in ((dy16.float(), False), (dy16, False), (dy16, True)):
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        res.append((ops.groupnorm_relu_bwd(x, dyv, w, b, st, dg, db, dx_bf16=o16), dg, db))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[2][0], res[0][0].to(torch.bfloat16))
+    for k in (1, 2):
+        assert torch.allclose(res[0][k], res[1][k], rtol=1e-5, atol=1e-5) and torch.allclose(res[0][k], res[2][k], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dz16,x16", [(True, True), (True, False), (False, True)])
+def test_wgrad_k5_bf16_operands_equal_fp32_operands(dev, dz16, x16):
+    """The k = 5 weight gradient rounds its operands to bf16 while staging: operands that already ARE bf16 give the same dW."""
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(13)
+    B, L, n, cin = 6, 211, 320, 320
+    dz = torch.randn(B, L, n, generator=g).to(dev).to(torch.bfloat16)
+    x = torch.randn(B, L, cin, generator=g).to(dev).to(torch.bfloat16)
+    ref_dw, ref_db = torch.zeros(n, cin, 5, device=dev), torch.zeros(n, device=dev)
+    ops.wgrad(dz.float(), x.float(), ref_dw, n, cin, kw=5, db=ref_db, prec=ops.PREC_BF16)
+    dw, db = torch.zeros(n, cin, 5, device=dev), torch.zeros(n, device=dev)
+    ops.wgrad(dz if dz16 else dz.float(), x if x16 else x.float(), dw, n, cin, kw=5, db=db, prec=ops.PREC_BF16)
+    assert torch.equal(dw, ref_dw)
+    assert torch.allclose(db, ref_db, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("kind", ["bn", "gn"])
+def test_conv_norm_node_equals_two_nodes(dev, kind):
+    """ConvNormFn (one tape node) == ConvGemmFn followed by the norm Function, fp32 mode (same kernels, same order)."""
+    import torch.nn as nn
+    from styler_amd import autograd as AG, ops
+    from styler_amd.runtime import Derived, rt
+    assert rt.prec == ops.PREC_F32
+    g = torch.Generator().manual_seed(14)
+    B, L, cin, n = 4, 97, 80, 320
+    conv = nn.Conv1d(cin, n, 5, padding=2).to(dev)
+    norm = (nn.BatchNorm1d(n) if kind == "bn" else nn.GroupNorm(n // 16, n)).to(dev)
+    x0 = torch.randn(B, L, cin, generator=g).to(dev)
+    dy = torch.randn(B, L, n, generator=g).to(dev)
+    saved = rt.disable_dropout
+    rt.disable_dropout = True
+    try:
+        outs = []
+        for fused in (True, False):
+            for p in list(conv.parameters()) + list(norm.parameters()):
+                p.grad = None
+            if kind == "bn":
+                norm.running_mean.zero_(); norm.running_var.fill_(1.0)
+            x = x0.clone().requires_grad_(True)
+            cache = Derived()
+            if fused:
+                y = AG.ConvNormFn.apply(x, conv.weight, conv.bias, cache, "c", 5, norm, kind, ops.ACT_TANH, 0.5, 2, False)
+            else:
+                z = AG.ConvGemmFn.apply(x, None, conv.weight, conv.bias, cache, "c", 5, ops.ACT_NONE, False, None)
+                y = (AG.BatchNormActFn.apply(z, norm.weight, norm, ops.ACT_TANH, 0.5, 2) if kind == "bn"
+                     else AG.GroupNormReluFn.apply(z, norm.weight, norm))
+            y.backward(dy)
+            outs.append([y.detach(), x.grad] + [p.grad.clone() for p in list(conv.parameters()) + list(norm.parameters())])
+    finally:
+        rt.disable_dropout = saved
+    for i, (a, b) in enumerate(zip(*outs)):            # y, dx exact up to nothing; parameter gradients leave as fp32 atomics
+        assert torch.allclose(a, b, rtol=1e-5 if i < 2 else 2e-4, atol=1e-6 if i < 2 else 1e-4), i
