@@ -777,6 +777,47 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const StylerWgr
     }
     return;
   }
+  if (per <= 512 && d.splits >= 16) {
+    // a short vector with many partials (LayerNorm's parameter gradients: one slot per block of the backward kernel, 256
+    // slots of 256 floats): one block, but all of its threads -- 256 / (per / 4) groups share the slots, LDS joins them
+    __shared__ float4 part[256];
+    const int nq = (int)(per / 4), groups = 256 / nq;
+    const int g = threadIdx.x / nq, qi = threadIdx.x - g * nq;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g < groups) {
+      const float* p = ws + qi * 4 + (int64_t)g * per;
+      int sp = g;
+      for (; sp + 3 * groups < d.splits; sp += 4 * groups) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + (int64_t)groups * per);
+        const float4 c = *reinterpret_cast<const float4*>(p + 2 * (int64_t)groups * per);
+        const float4 e = *reinterpret_cast<const float4*>(p + 3 * (int64_t)groups * per);
+        s.x += (a.x + b.x) + (c.x + e.x); s.y += (a.y + b.y) + (c.y + e.y);
+        s.z += (a.z + b.z) + (c.z + e.z); s.w += (a.w + b.w) + (c.w + e.w);
+        p += 4 * (int64_t)groups * per;
+      }
+      for (; sp < d.splits; sp += groups) {
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        p += (int64_t)groups * per;
+      }
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0) {
+      for (int gg = 1; gg < groups; ++gg) {
+        const float4 a = part[gg * nq + qi];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      }
+      const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t ii = (int64_t)qi * 4 + k;
+        const int c = (int)(ii % d.cin); const int j = (int)((ii / d.cin) % d.kw); const int64_t nn = ii / ((int64_t)d.cin * d.kw);
+        dw[nn * d.stride_n + c * d.stride_c + j * d.stride_j] += v[k];
+      }
+    }
+    return;
+  }
   const int64_t i = (bid - d.block_start) * 1024 + threadIdx.x * 4;      // four consecutive outputs per thread: the
   if (i >= per) return;                                                   // partials stream as 16-byte loads
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -480,7 +480,8 @@ def bn_fold(gamma, beta, running_mean, running_var, conv_bias):
     return scale, shift
 
 
-LN_REPLICAS = 16           # scratch replicas of LayerNorm's parameter gradients inside a training step
+LN_REPLICAS = 256          # scratch replicas of LayerNorm's parameter gradients inside a training step: one per block
+                           # (styler_layernorm_bwd launches <= 256 blocks), so the blocks store instead of adding atomically
 BN_WS_COPIES = 16        # STYLER_BN_COPIES (norms.hip): replicas of the 2C-double column accumulator
 
 
