@@ -576,7 +576,9 @@ def mel_filterbank(sr=22050, n_fft=1024, n_mels=80, fmin=0.0, fmax=8000.0) -> Te
     stft.py:128-129 (third-party, absent from /root/reference and from this image):
     Slaney mel scale (htk=False), triangular filters, Slaney area normalisation
     (norm=1: each filter scaled by 2 / (f_hi - f_lo)).  PARITY UNPINNED at this boundary:
-    the reference holds no vector for mel_basis; self-checks in
+    the reference holds no vector for mel_basis.  Cross-checked (not pinned) against a second, independent derivation --
+    HF transformers' librosa-compatible `audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney")`, fixture
+    tests/golden/mel_filterbank_hf.npz: max |diff| = 3.5e-8 of the peak weight -- plus self-checks in
     tests/test_oracle_golden.py (peaks monotone, area norm)."""
     fft_f = np.linspace(0, sr / 2.0, 1 + n_fft // 2)
     mel_pts = np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2)

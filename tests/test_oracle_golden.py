@@ -199,6 +199,21 @@ def test_stft_mel(golden):
         O.mel_spectrogram(torch.full((1, 2048), 1.5))
 
 
+def test_mel_filterbank_independent_derivation(golden):
+    """The Slaney filterbank restatement (audio/stft.py:141-143 -> librosa_mel_fn(22050, 1024, 80, 0, 8000)) against a second,
+    independent implementation: HF transformers' librosa-compatible `mel_filter_bank` (fixture + script:
+    tests/golden/make_golden_melbasis.py).  A cross-check of the restated formula -- librosa 0.7.2 itself is still absent."""
+    g = golden("mel_filterbank_hf")
+    fb = O.mel_filterbank().double().numpy()
+    ref = g["mel_basis"]
+    assert ref.shape == fb.shape == (80, 513)
+    assert np.abs(fb - ref).max() <= 1e-7 * ref.max()                # measured 3.5e-8 (the oracle builds it in fp32)
+    # the device-side basis is this matrix: styler_amd/audio.py takes it from the same restated formula
+    from styler_amd.audio import slaney_mel_filterbank
+    dev_fb = np.asarray(slaney_mel_filterbank(22050, 1024, 80, 0.0, 8000.0), dtype=np.float64)
+    assert np.abs(dev_fb - ref).max() <= 1e-7 * ref.max()
+
+
 def test_hifigan_generator(golden, hifigan_state_dict):
     """hifigan/models.py:155-169 on the weight-normed checkpoint format; 7 mel frames -> 1792 samples."""
     g = golden("hifigan")
