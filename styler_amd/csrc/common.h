@@ -70,14 +70,24 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16_rne(float lo, float hi) {
   return *reinterpret_cast<const uint32_t*>(&b);
 }
 
-// four consecutive elements at element index `idx` of a tensor stored as fp32 or (is16) bf16
-__device__ __forceinline__ float4 load4_f32_or_bf16(const void* base, int64_t idx, bool is16) {
-  if (is16) {
-    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + idx);
-    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                       __uint_as_float(u.y & 0xffff0000u));
-  }
-  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
+// Four consecutive elements at element index `idx` of a tensor stored as fp32 or (IS16) bf16, as a raw load and a separate
+// conversion: loops issue the raw loads of a batch first and convert afterwards (a conversion next to its load puts a wait
+// behind every load).
+template <bool IS16> struct Raw4 { typedef float4 T; };
+template <> struct Raw4<true> { typedef uint2 T; };
+template <bool IS16>
+__device__ __forceinline__ typename Raw4<IS16>::T raw4_load(const void* base, int64_t idx) {
+  if constexpr (IS16) return *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + idx);
+  else return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
+}
+// Pin a batch of loaded values: an empty asm that "modifies" them sits between the load loop and the consume loop, so the
+// compiler cannot sink a load to its use (it does that to shorten live ranges, and then waits behind every load).
+__device__ __forceinline__ void pin_loaded(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void pin_loaded(uint2& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
+__device__ __forceinline__ float4 raw4_f32(const float4& v) { return v; }
+__device__ __forceinline__ float4 raw4_f32(const uint2& u) {
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
 }
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {

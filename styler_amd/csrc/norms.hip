@@ -204,14 +204,14 @@ extern "C" int styler_bn_fold(const float* gamma, const float* beta, const float
 #define BN_STAT_RPB 128                            // rows per block of the column statistics
 #define BN_CT 32                                   // float4 columns per block of the column statistics
 
-template <bool BWD>
+template <bool BWD, bool DY16 = false>
 __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                           const void* __restrict__ dy, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, double* __restrict__ ws,
                                                           int64_t rows, int C, int act, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float drop_p,
                                                           uint64_t drop_seed_host, const uint64_t* __restrict__ epoch,
-                                                          int rpb, int bps, int64_t rps, int dbg, int dy16) {
+                                                          int rpb, int bps, int64_t rps, int dbg) {
   // Segments: rows [seg * rps, (seg + 1) * rps) carry their own statistics (the clean and the noisy decode of
   // styler.py:52,55 run through the PostNet as ONE batch, but each call of the reference normalises with its own batch
   // statistics, Layers.py:126).  Block = (segment, chunk of rpb rows); per-segment arrays are [segs][...].
@@ -250,14 +250,15 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restric
       // row-at-a-time loop is one memory round trip per row -- 16 in a row at 32 rows per block
       constexpr int U = BWD ? 4 : 8;
       for (int64_t r = r0 + rl; r < r1; r += (int64_t)U * lanes) {
-        float4 v4[U], g4[U], o4[U];
+        float4 v4[U], o4[U];
+        typename Raw4<DY16>::T g4[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           int64_t ru = r + (int64_t)u * lanes;
           ru = ru < r1 ? ru : r1 - 1;                      // clamped, discarded below: no lane branches around loads
           v4[u] = *reinterpret_cast<const float4*>(x + ru * C + q * 4);
           if (BWD) {
-            g4[u] = load4_f32_or_bf16(dy, ru * C + q * 4, dy16);
+            g4[u] = raw4_load<DY16>(dy, ru * C + q * 4);
             if (has_y) o4[u] = *reinterpret_cast<const float4*>(y + ru * C + q * 4);
           }
         }
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restric
           float4 v = v4[u];
           if (!okr) v = make_float4(BWD ? m.x : 0.f, BWD ? m.y : 0.f, BWD ? m.z : 0.f, BWD ? m.w : 0.f);
           if (BWD) {
-            float4 g = okr ? g4[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 g = okr ? raw4_f32(g4[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 o = has_y ? o4[u] : make_float4(0.f, 0.f, 0.f, 0.f);
             const float hx = (v.x - m.x) * rs.x, hy = (v.y - m.y) * rs.y, hz = (v.z - m.z) * rs.z, hw = (v.w - m.w) * rs.w;
             const uint64_t e = (uint64_t)(ru * C + q * 4);
@@ -327,12 +328,12 @@ int styler_bn_colstats(bool bwd, const float* x, const float* y, const void* dy,
   const int bps = (int)((rps + rpb - 1) / rpb);      // blocks per segment
   const int nq = C / 4, nqt = nq < BN_CT ? nq : BN_CT;
   const dim3 grid((unsigned)(bps * segs * ((nq + nqt - 1) / nqt)));
-  if (bwd)
-    hipLaunchKernelGGL(bn_colstats_kernel<true>, grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, rows, C, act, gamma, beta,
-                       drop_p, drop_seed, g_styler_drop_epoch, rpb, bps, rps, dbg, dy16);
-  else
-    hipLaunchKernelGGL(bn_colstats_kernel<false>, grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, rows, C, act, gamma, beta,
-                       drop_p, drop_seed, g_styler_drop_epoch, rpb, bps, rps, dbg, dy16);
+#define BN_STATS_LAUNCH(...) hipLaunchKernelGGL((bn_colstats_kernel<__VA_ARGS__>), grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, \
+                                                 rows, C, act, gamma, beta, drop_p, drop_seed, g_styler_drop_epoch, rpb, bps, rps, dbg)
+  if (bwd && dy16) BN_STATS_LAUNCH(true, true);
+  else if (bwd) BN_STATS_LAUNCH(true, false);
+  else BN_STATS_LAUNCH(false, false);
+#undef BN_STATS_LAUNCH
   hipLaunchKernelGGL(bn_fold_copies_kernel, dim3((2 * C * segs + 255) / 256), dim3(256), 0, st, ws, 2 * C, segs);
   return 0;
 }

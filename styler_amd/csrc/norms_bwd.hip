@@ -198,13 +198,14 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
 //   gn_bwd_apply : dx.
 int gn_segments_host(int B, int L, int C);
 
+template <bool DY16>
 __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restrict__ x, int64_t ldx,
                                                            const void* __restrict__ dy, int64_t lddy,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ stats, double* __restrict__ ws,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int L,
-                                                           int C, int seg_rows, int dy16) {
+                                                           int C, int seg_rows) {
   __shared__ double red[2][16][16];
   __shared__ float pg[2][16][64];
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
@@ -219,17 +220,33 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
   const float4 be = *reinterpret_cast<const float4*>(beta + c0 + cq * 4);
   double s1 = 0.0, s2 = 0.0;
   float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
-  for (int t = t0 + rl; t < t1; t += 16) {
-    const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
-    float4 g = load4_f32_or_bf16(dy, gbase + (int64_t)t * lddy, dy16);
-    const float hx = (v.x - mean) * rstd, hy = (v.y - mean) * rstd, hz = (v.z - mean) * rstd, hw = (v.w - mean) * rstd;
-    g.x = (hx * ga.x + be.x) > 0.f ? g.x : 0.f; g.y = (hy * ga.y + be.y) > 0.f ? g.y : 0.f;
-    g.z = (hz * ga.z + be.z) > 0.f ? g.z : 0.f; g.w = (hw * ga.w + be.w) > 0.f ? g.w : 0.f;
-    ag.x += g.x * hx; ag.y += g.y * hy; ag.z += g.z * hz; ag.w += g.w * hw;
-    ab.x += g.x; ab.y += g.y; ab.z += g.z; ab.w += g.w;
-    const float ex = g.x * ga.x, ey = g.y * ga.y, ez = g.z * ga.z, ew = g.w * ga.w;
-    s1 += (double)ex + (double)ey + (double)ez + (double)ew;
-    s2 += (double)ex * hx + (double)ey * hy + (double)ez * hz + (double)ew * hw;
+  // four rows' loads in flight per thread (clamped rows, discarded by a select: a row-at-a-time loop is one memory round
+  // trip per row, ten in a row at these segment lengths)
+  for (int tb = t0 + rl; tb < t1; tb += 64) {
+    float4 v4[4];
+    typename Raw4<DY16>::T g4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = tb + 16 * u < t1 ? tb + 16 * u : t1 - 1;
+      v4[u] = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
+      g4[u] = raw4_load<DY16>(dy, gbase + (int64_t)t * lddy);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { pin_loaded(v4[u]); pin_loaded(g4[u]); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4 v = v4[u];
+      float4 g = raw4_f32(g4[u]);
+      if (tb + 16 * u >= t1) g = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float hx = (v.x - mean) * rstd, hy = (v.y - mean) * rstd, hz = (v.z - mean) * rstd, hw = (v.w - mean) * rstd;
+      g.x = (hx * ga.x + be.x) > 0.f ? g.x : 0.f; g.y = (hy * ga.y + be.y) > 0.f ? g.y : 0.f;
+      g.z = (hz * ga.z + be.z) > 0.f ? g.z : 0.f; g.w = (hw * ga.w + be.w) > 0.f ? g.w : 0.f;
+      ag.x += g.x * hx; ag.y += g.y * hy; ag.z += g.z * hz; ag.w += g.w * hw;
+      ab.x += g.x; ab.y += g.y; ab.z += g.z; ab.w += g.w;
+      const float ex = g.x * ga.x, ey = g.y * ga.y, ez = g.z * ga.z, ew = g.w * ga.w;
+      s1 += (double)ex + (double)ey + (double)ez + (double)ew;
+      s2 += (double)ex * hx + (double)ey * hy + (double)ez * hz + (double)ew * hw;
+    }
   }
   red[0][rl][cq] = s1; red[1][rl][cq] = s2;
   pg[0][rl][cq * 4 + 0] = ag.x; pg[0][rl][cq * 4 + 1] = ag.y; pg[0][rl][cq * 4 + 2] = ag.z; pg[0][rl][cq * 4 + 3] = ag.w;
@@ -249,13 +266,14 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
   }
 }
 
+template <bool DY16>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, int64_t ldx,
                                                            const void* __restrict__ dy, int64_t lddy,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ stats,
                                                            const double* __restrict__ ws, void* __restrict__ dx,
-                                                           int64_t lddx, int L, int C, int seg_rows, int dx16, int dy16) {
+                                                           int64_t lddx, int L, int C, int seg_rows, int dx16) {
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int t0 = blockIdx.z * seg_rows;
@@ -272,16 +290,30 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   uint16_t* dxp16 = reinterpret_cast<uint16_t*>(dx) + (int64_t)b * L * lddx + c0 + cq * 4;
   const float4 ga = *reinterpret_cast<const float4*>(gamma + c0 + cq * 4);
   const float4 be = *reinterpret_cast<const float4*>(beta + c0 + cq * 4);
-  for (int t = t0 + rl; t < t1; t += 16) {
-    const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
-    float4 g = load4_f32_or_bf16(dy, gbase + (int64_t)t * lddy, dy16);
-    const float hx = (v.x - mean) * rstd, hy = (v.y - mean) * rstd, hz = (v.z - mean) * rstd, hw = (v.w - mean) * rstd;
-    g.x = (hx * ga.x + be.x) > 0.f ? g.x * ga.x : 0.f; g.y = (hy * ga.y + be.y) > 0.f ? g.y * ga.y : 0.f;
-    g.z = (hz * ga.z + be.z) > 0.f ? g.z * ga.z : 0.f; g.w = (hw * ga.w + be.w) > 0.f ? g.w * ga.w : 0.f;
-    const float4 o = make_float4(rstd * (g.x - m1 - hx * m2), rstd * (g.y - m1 - hy * m2), rstd * (g.z - m1 - hz * m2),
-                                 rstd * (g.w - m1 - hw * m2));
-    if (dx16) *reinterpret_cast<uint2*>(dxp16 + (int64_t)t * lddx) = make_uint2(cvt_pk_bf16_rne(o.x, o.y), cvt_pk_bf16_rne(o.z, o.w));
-    else *reinterpret_cast<float4*>(dxp + (int64_t)t * lddx) = o;
+  for (int tb = t0 + rl; tb < t1; tb += 64) {
+    float4 v4[4];
+    typename Raw4<DY16>::T g4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = tb + 16 * u < t1 ? tb + 16 * u : t1 - 1;
+      v4[u] = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
+      g4[u] = raw4_load<DY16>(dy, gbase + (int64_t)t * lddy);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = tb + 16 * u;
+      const float4 v = v4[u];
+      float4 g = raw4_f32(g4[u]);
+      const float hx = (v.x - mean) * rstd, hy = (v.y - mean) * rstd, hz = (v.z - mean) * rstd, hw = (v.w - mean) * rstd;
+      g.x = (hx * ga.x + be.x) > 0.f ? g.x * ga.x : 0.f; g.y = (hy * ga.y + be.y) > 0.f ? g.y * ga.y : 0.f;
+      g.z = (hz * ga.z + be.z) > 0.f ? g.z * ga.z : 0.f; g.w = (hw * ga.w + be.w) > 0.f ? g.w * ga.w : 0.f;
+      const float4 o = make_float4(rstd * (g.x - m1 - hx * m2), rstd * (g.y - m1 - hy * m2), rstd * (g.z - m1 - hz * m2),
+                                   rstd * (g.w - m1 - hw * m2));
+      if (t < t1) {                                      // (the store is predicated, the loads above are not)
+        if (dx16) *reinterpret_cast<uint2*>(dxp16 + (int64_t)t * lddx) = make_uint2(cvt_pk_bf16_rne(o.x, o.y), cvt_pk_bf16_rne(o.z, o.w));
+        else *reinterpret_cast<float4*>(dxp + (int64_t)t * lddx) = o;
+      }
+    }
   }
 }
 
@@ -302,10 +334,18 @@ extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void
   const int seg_rows = ((L + nseg - 1) / nseg + 15) & ~15;
   const dim3 grid(C / 64, B, (L + seg_rows - 1) / seg_rows);
   const int dy16 = (io_flags & STYLER_IO_X_BF16) ? 1 : 0;
-  hipLaunchKernelGGL(gn_bwd_stats_kernel, grid, dim3(256), 0, st, x, ldx, dy, lddy, gamma, beta, stats, workspace, dgamma,
-                     dbeta, L, C, seg_rows, dy16);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, dim3(256), 0, st, x, ldx, dy, lddy, gamma, beta, stats, workspace, dx,
-                     lddx, L, C, seg_rows, (io_flags & STYLER_IO_Y_BF16) ? 1 : 0, dy16);
+  const int dx16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
+  if (dy16) {
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, grid, dim3(256), 0, st, x, ldx, dy, lddy, gamma, beta, stats, workspace,
+                       dgamma, dbeta, L, C, seg_rows);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, grid, dim3(256), 0, st, x, ldx, dy, lddy, gamma, beta, stats, workspace, dx,
+                       lddx, L, C, seg_rows, dx16);
+  } else {
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, grid, dim3(256), 0, st, x, ldx, dy, lddy, gamma, beta, stats, workspace,
+                       dgamma, dbeta, L, C, seg_rows);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, grid, dim3(256), 0, st, x, ldx, dy, lddy, gamma, beta, stats, workspace, dx,
+                       lddx, L, C, seg_rows, dx16);
+  }
   return launch_status();
 }
 
@@ -320,6 +360,7 @@ int styler_bn_colstats(bool bwd, const float* x, const float* y, const void* dy,
 // Same geometry as the forward's column statistics / apply kernels (norms.hip): block = (segment, chunk of rpb rows),
 // thread = (row-lane, float4 column); per-channel constants (incl. the two fp64 column sums) once per thread, rows in
 // batches of four, no index divisions.
+template <bool DY16>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const void* __restrict__ dy, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -328,7 +369,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            int C, int act, const float* __restrict__ beta,
                                                            float drop_p, uint64_t drop_seed_host,
                                                            const uint64_t* __restrict__ epoch, int segs, int rpb, int bps,
-                                                           int64_t rps, int dx16, int dy16) {
+                                                           int64_t rps, int dx16) {
   float* const dx = reinterpret_cast<float*>(dxv);
   uint16_t* const dxh = reinterpret_cast<uint16_t*>(dxv);  // dx16: bf16 output (see gn_bwd_apply_kernel)
   // parameter gradients: first C * segs threads of the grid
@@ -363,13 +404,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     for (int k = 0; k < 4; ++k) { sb[k] = (float)(wseg[q * 4 + k] * inv_n); sg[k] = (float)(wseg[C + q * 4 + k] * inv_n); }
     constexpr int U = 4;
     for (int64_t row = r0 + rl; row < r1; row += (int64_t)U * lanes) {
-      float4 v4[U], g4[U], o4[U];
+      float4 v4[U], o4[U];
+      typename Raw4<DY16>::T g4[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         int64_t ru = row + (int64_t)u * lanes;
         ru = ru < r1 ? ru : r1 - 1;
         v4[u] = *reinterpret_cast<const float4*>(x + ru * C + q * 4);
-        g4[u] = load4_f32_or_bf16(dy, ru * C + q * 4, dy16);
+        g4[u] = raw4_load<DY16>(dy, ru * C + q * 4);
         if (has_y) o4[u] = *reinterpret_cast<const float4*>(y + ru * C + q * 4);
       }
 #pragma unroll
@@ -377,7 +419,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const int64_t ru = row + (int64_t)u * lanes;
         if (ru >= r1) break;
         const float xv[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
-        const float gv[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
+        const float4 gf = raw4_f32(g4[u]);
+        const float gv[4] = {gf.x, gf.y, gf.z, gf.w};
         const float4 oo = has_y ? o4[u] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float ov[4] = {oo.x, oo.y, oo.z, oo.w};
         float out[4];
@@ -412,8 +455,12 @@ extern "C" int styler_batchnorm_bwd(const float* x, const float* y, const void* 
   const int bps = (int)((rps + RPB - 1) / RPB);
   int64_t blocks = (int64_t)bps * segs;
   if (blocks * 256 < (int64_t)C * segs) blocks = ((int64_t)C * segs + 255) / 256;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd,
-                     workspace, dx, dgamma, dbeta, C, act, beta, drop_p, drop_seed, g_styler_drop_epoch, segs, RPB, bps, rps,
-                     (io_flags & STYLER_IO_Y_BF16) ? 1 : 0, dy16);
+  const int dx16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
+  if (dy16)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd,
+                       workspace, dx, dgamma, dbeta, C, act, beta, drop_p, drop_seed, g_styler_drop_epoch, segs, RPB, bps, rps, dx16);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd,
+                       workspace, dx, dgamma, dbeta, C, act, beta, drop_p, drop_seed, g_styler_drop_epoch, segs, RPB, bps, rps, dx16);
   return launch_status();
 }
