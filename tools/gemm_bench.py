@@ -13,6 +13,9 @@ SHAPES = [  # name, B, L, cin, n, kw
     # the paired decode's row count (2 x 13 530 valid frames)
     ("p_ffn_w1_k9", 1, 27060, 256, 1024, 9), ("p_ffn_w2_k1", 1, 27060, 1024, 256, 1), ("p_qkv", 1, 27060, 256, 768, 1),
     ("p_attn_fc", 1, 27060, 256, 256, 1), ("p_dx_w1_k9", 1, 27060, 1024, 256, 9), ("p_dx_qkv", 1, 27060, 768, 256, 1),
+    # the stacked AudioEncoder / PostNet passes (2 x 48 items)
+    ("s_aenc_320_k5", 96, 441, 320, 320, 5), ("s_aenc_256_k5", 96, 441, 256, 256, 5), ("s_postnet_512_k5", 96, 441, 512, 512, 5),
+    ("s_postnet_out", 96, 441, 512, 80, 5),
 ]
 
 WGRAD_SHAPES = [  # name, B, L, cin, n, kw  (dw[n, cin, kw] += dz^T x)
