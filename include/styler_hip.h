@@ -576,6 +576,10 @@ int styler_adam_step(float* p, const float* g, float* m, float* v, int64_t n, co
                      float max_norm, float lr, float beta1, float beta2, float eps, int step,
                      float grad_scale, void* stream);
 
+/* Self-test: out_swap / out_shfl [groups * 64] receive, for every 64-value group of `in`, the wave-wide sum computed by the
+ * library's reduction (v_permlane32/16_swap + DPP) and by the six-step __shfl_xor butterfly; the two must be bit-identical. */
+int styler_wave_sum_selftest(const float* in, float* out_swap, float* out_shfl, int groups, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,3 +135,21 @@ extern "C" int styler_scale_weights(const float* g, const float* weights, int n,
   hipLaunchKernelGGL(scale_weights_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, g, out);
   return launch_status();
 }
+
+// Self-test of common.h's wave_sum (half / row swaps + DPP) against the __shfl_xor butterfly it replaces: both sums of every
+// 64-value group of `in`, for a bitwise comparison by the caller (tests/test_hip_parity.py).
+__global__ void wave_sum_selftest_kernel(const float* __restrict__ in, float* __restrict__ out_swap, float* __restrict__ out_shfl) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const float v = in[i];
+  float w = v;
+  out_swap[i] = wave_sum(v);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+  out_shfl[i] = w;
+}
+
+extern "C" int styler_wave_sum_selftest(const float* in, float* out_swap, float* out_shfl, int groups, void* stream) {
+  if (!in || !out_swap || !out_shfl || groups <= 0) return STYLER_EINVAL;
+  hipLaunchKernelGGL(wave_sum_selftest_kernel, dim3(groups), dim3(64), 0, (hipStream_t)stream, in, out_swap, out_shfl);
+  return launch_status();
+}

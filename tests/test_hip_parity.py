@@ -890,6 +890,20 @@ def test_decode_entry_point_vs_oracle(dev, model, O, ref_state_dict):
 
 
 @pytest.mark.gpu
+def test_wave_sum_is_the_shuffle_butterfly(dev):
+    """common.h's wave_sum (v_permlane32_swap / v_permlane16_swap + four DPP adds) == six `v += __shfl_xor(v, o)` steps, bit
+    for bit, in every lane -- LayerNorm and the other wave reductions did not change a bit when they dropped ds_bpermute."""
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(4096 * 64, generator=g) * torch.exp(4 * torch.randn(4096 * 64, generator=g))).to(dev)
+    a, b = torch.empty_like(x), torch.empty_like(x)
+    rc = ops.lib.styler_wave_sum_selftest(x.data_ptr(), a.data_ptr(), b.data_ptr(), 4096, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert torch.allclose(a.view(4096, 64)[:, 0].double(), x.view(4096, 64).double().sum(1), rtol=1e-4, atol=1e-3)
+
+
 def test_torch_library_ops(dev):
     """The `torch.library` registrations (styler_amd/torch_ops.py): dispatcher-visible ops with autograd, against
     stock PyTorch math in fp64 on the CPU (forward and gradients)."""
