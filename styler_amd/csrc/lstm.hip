@@ -37,15 +37,17 @@ __device__ __forceinline__ void lstm_fwd_body(const float* __restrict__ gx, cons
   const int dt = dir ? -1 : 1;
   float gnext = gxp[(int64_t)t * gx_ld];
   for (int step = 0; step < S; ++step, t += dt) {
-    float a0 = gnext, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // two packed accumulators (v_pk_fma_f32: H / 2 VALU instructions for the H-term dot product instead of H)
+    f32x2_t a01 = {gnext, 0.f}, a23 = {0.f, 0.f};
     if (step + 1 < S) gnext = gxp[(int64_t)(t + dt) * gx_ld];        // prefetch next step's row
 #pragma unroll
     for (int k = 0; k < H; k += 4) {
       const float4 hv = *reinterpret_cast<const float4*>(&hbuf[k]);
-      a0 = fmaf(w[k], hv.x, a0); a1 = fmaf(w[k + 1], hv.y, a1);
-      a2 = fmaf(w[k + 2], hv.z, a2); a3 = fmaf(w[k + 3], hv.w, a3);
+      const f32x2_t w01 = {w[k], w[k + 1]}, w23 = {w[k + 2], w[k + 3]}, h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
+      a01 = __builtin_elementwise_fma(w01, h01, a01);
+      a23 = __builtin_elementwise_fma(w23, h23, a23);
     }
-    const float pre = (a0 + a1) + (a2 + a3);
+    const float pre = (a01.x + a01.y) + (a23.x + a23.y);
     const bool is_g = (j >= 2 * H) && (j < 3 * H);
     const float act = is_g ? tanhf(pre) : 1.0f / (1.0f + expf(-pre));
     gbuf[j] = act;
@@ -141,16 +143,32 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ dout, co
   // reverse of the forward processing order: forward dir processed t = 0..S-1, so walk S-1..0 (and vice versa)
   int t = dir ? 0 : S - 1;
   const int dt = dir ? 1 : -1;
+  // The step's inputs (four gates, dout, cell) do not depend on the recurrence: they are fetched one step ahead -- the cell
+  // state two steps ahead, because c_prev of step t is the cell of the step the walk visits next -- so the recurrence never
+  // waits for memory (it did, seven dependent loads at the top of every step: ~40 % of the 0.47 us step).
+  const bool unit = tid < H;
+  const int u = unit ? tid : 0;
+  auto goff = [&](int tt) { return ((int64_t)b * S + tt) * g_ld + dir * 4 * H + u; };
+  auto ooff = [&](int tt) { return ((int64_t)b * S + tt) * o_ld + dir * H + u; };
+  float gi = 0.f, gf = 0.f, gg = 0.f, gout = 0.f, dov = 0.f, c = 0.f, c_n1 = 0.f;
+  float n_gi = 0.f, n_gf = 0.f, n_gg = 0.f, n_gout = 0.f, n_dov = 0.f, c_n2 = 0.f;
+  if (unit) {
+    const int64_t go = goff(t);
+    gi = gates[go]; gf = gates[go + H]; gg = gates[go + 2 * H]; gout = gates[go + 3 * H];
+    dov = dout[ooff(t)]; c = cell[ooff(t)];
+    if (S > 1) c_n1 = cell[ooff(t + dt)];
+  }
   for (int step = 0; step < S; ++step, t += dt) {
-    if (tid < H) {
-      const int u = tid;
-      const int64_t go = ((int64_t)b * S + t) * g_ld + dir * 4 * H;
-      const int64_t oo = ((int64_t)b * S + t) * o_ld + dir * H;
-      const float gi = gates[go + u], gf = gates[go + H + u], gg = gates[go + 2 * H + u], gout = gates[go + 3 * H + u];
-      const float c = cell[oo + u];
-      const int tp = t - (dir ? -1 : 1);                           // previous step in forward processing order
-      const float c_prev = (tp >= 0 && tp < S) ? cell[((int64_t)b * S + tp) * o_ld + dir * H + u] : 0.f;
-      const float dh = dout[oo + u] + dh_rec;
+    if (unit) {
+      if (step + 1 < S) {                                // next step's gates / dout, the cell two steps ahead
+        const int64_t gn = goff(t + dt);
+        n_gi = gates[gn]; n_gf = gates[gn + H]; n_gg = gates[gn + 2 * H]; n_gout = gates[gn + 3 * H];
+        n_dov = dout[ooff(t + dt)];
+      }
+      c_n2 = step + 2 < S ? cell[ooff(t + 2 * dt)] : 0.f;
+      const int64_t go = goff(t);
+      const float c_prev = step + 1 < S ? c_n1 : 0.f;    // previous step in forward processing order = the walk's next
+      const float dh = dov + dh_rec;
       const float tc = tanhf(c);
       const float d_o = dh * tc;
       const float dc = dc_next + dh * gout * (1.f - tc * tc);
@@ -159,7 +177,7 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ dout, co
       const float pi = di * gi * (1.f - gi), pf = df * gf * (1.f - gf), pg = dg * (1.f - gg * gg),
                   po = d_o * gout * (1.f - gout);
       sdg[u] = pi; sdg[H + u] = pf; sdg[2 * H + u] = pg; sdg[3 * H + u] = po;
-      dgp[go + u] = pi; dgp[go + H + u] = pf; dgp[go + 2 * H + u] = pg; dgp[go + 3 * H + u] = po;
+      dgp[go] = pi; dgp[go + H] = pf; dgp[go + 2 * H] = pg; dgp[go + 3 * H] = po;
     }
     __syncthreads();
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -170,7 +188,10 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ dout, co
     }
     part[q][k] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (tid < H) dh_rec = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    if (unit) {
+      dh_rec = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+      gi = n_gi; gf = n_gf; gg = n_gg; gout = n_gout; dov = n_dov; c = c_n1; c_n1 = c_n2;
+    }
     __syncthreads();
   }
 }
