@@ -762,7 +762,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const StylerWgr
       if (q * 4 < cn) {
         const float* p = ws + ((int64_t)nn * d.kw + j) * d.cin + c0 + q * 4;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int sp = 0; sp < d.splits; ++sp) {
+        int sp = 0;
+        for (; sp + 4 <= d.splits; sp += 4) {          // four partials in flight per thread (a one-at-a-time loop is
+          const float4 a = *reinterpret_cast<const float4*>(p + (int64_t)sp * per);      // one memory round trip per split)
+          const float4 b = *reinterpret_cast<const float4*>(p + (int64_t)(sp + 1) * per);
+          const float4 c = *reinterpret_cast<const float4*>(p + (int64_t)(sp + 2) * per);
+          const float4 e = *reinterpret_cast<const float4*>(p + (int64_t)(sp + 3) * per);
+          s.x += (a.x + b.x) + (c.x + e.x); s.y += (a.y + b.y) + (c.y + e.y);
+          s.z += (a.z + b.z) + (c.z + e.z); s.w += (a.w + b.w) + (c.w + e.w);
+        }
+        for (; sp < d.splits; ++sp) {
           const float4 a = *reinterpret_cast<const float4*>(p + (int64_t)sp * per);
           s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
         }
