@@ -16,6 +16,9 @@ SHAPES = [  # name, B, L, cin, n, kw
     # the stacked AudioEncoder / PostNet passes (2 x 48 items)
     ("s_aenc_320_k5", 96, 441, 320, 320, 5), ("s_aenc_256_k5", 96, 441, 256, 256, 5), ("s_postnet_512_k5", 96, 441, 512, 512, 5),
     ("s_postnet_out", 96, 441, 512, 80, 5),
+    # round quantisation probes: 768 / 993 / 1536 tiles of 128 x 128 on the AudioEncoder shape, 1536 / 1696 / 2304 on the FFN's
+    ("q_aenc_768", 1, 32768, 320, 320, 5), ("q_aenc_993", 1, 42336, 320, 320, 5), ("q_aenc_1536", 1, 65536, 320, 320, 5),
+    ("q_ffn_1536", 1, 24576, 256, 1024, 9), ("q_ffn_1696", 1, 27136, 256, 1024, 9), ("q_ffn_2304", 1, 36864, 256, 1024, 9),
 ]
 
 WGRAD_SHAPES = [  # name, B, L, cin, n, kw  (dw[n, cin, kw] += dz^T x)
