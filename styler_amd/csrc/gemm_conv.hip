@@ -542,7 +542,13 @@ static int launch_gemm(GemmArgs a, hipStream_t st, int x16, int y16) {
     }                                                                               \
   } while (0)
   if ((x16 || y16) && !BF16) return STYLER_EINVAL;
-  if (a.kw == 1) GEMM_IO(true, false);
+  // kw = 1: the occupancy-3 layout (one activation buffer, hence an extra barrier per step) pays when the launch has more
+  // blocks than two per CU can hold at once (the QKV projection: 34.3 -> 30.1 us); with fewer blocks the barrier only costs
+  // (output projection, k = 1 FFN: +2..6 %).  STYLER_GEMM_OCC3_K1=0/1 overrides.
+  static const int occ3_k1_env = [] { const char* e = getenv("STYLER_GEMM_OCC3_K1"); return e ? atoi(e) : -1; }();
+  const bool occ3_k1 = occ3_k1_env >= 0 ? occ3_k1_env != 0 : (int64_t)a.mt * a.nt > 512;
+  if (a.kw == 1 && BF16 && TM == 2 && occ3_k1) GEMM_IO(true, (BF16 && TM == 2));
+  else if (a.kw == 1) GEMM_IO(true, false);
   else if (BF16 && TM == 2 && occ3) GEMM_IO(false, (BF16 && TM == 2));
   else GEMM_IO(false, false);
 #undef GEMM_IO
