@@ -524,10 +524,11 @@ static int launch_gemm(GemmArgs a, hipStream_t st, int x16, int y16) {
   a.mt = (int)((M + 64 * TM - 1) / (64 * TM));
   a.nt = (a.n + 64 * TN - 1) / (64 * TN);
   const dim3 grid((unsigned)(((a.mt + 7) / 8) * 8 * a.nt));
-  // occupancy-3 layout pays when a chunk spans >= 5 taps (one extra barrier per chunk): measured +12..15 % on the
-  // k = 9 / k = 5 convs, -5 % on k = 3.  STYLER_GEMM_OCC3=0/1 overrides for experiments.
+  // occupancy-3 layout (one extra barrier per chunk): measured +12..15 % on the k = 9 / k = 5 convs; on k = 3 it lost 5 %
+  // with the round-1 epilogue and is a small gain with the present one (train step 11.989 -> 11.972 ms same-box).
+  // STYLER_GEMM_OCC3=0/1 overrides for experiments.
   static const int occ3_env = [] { const char* e = getenv("STYLER_GEMM_OCC3"); return e ? atoi(e) : -1; }();
-  const bool occ3 = occ3_env >= 0 ? occ3_env != 0 : a.kw >= 5;
+  const bool occ3 = occ3_env >= 0 ? occ3_env != 0 : a.kw >= 3;
 #define GEMM_LAUNCH(KW1_, OCC_, A_, Y_) \
   hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, BF16, KW1_, OCC_, A_, Y_>), grid, dim3(256), 0, st, a)
 #define GEMM_IO(KW1_, OCC_)                                                        \
