@@ -19,6 +19,18 @@
 
 #define AD 64
 #define ALD 36            // dwords per LDS row (64 bf16 + 16 B pad)
+// Register budgets are stated, not left to the compiler: without the second __launch_bounds__ argument hipcc took 296
+// registers for the dK/dV kernel (one wave per SIMD) and 192 for the dQ kernel (two) where 168 / 168 do without spills --
+// dQ + dK/dV of a decoder layer 97 -> 81 us from that alone.
+#ifndef STYLER_ATTN_DKV_WAVES
+#define STYLER_ATTN_DKV_WAVES 3
+#endif
+#ifndef STYLER_ATTN_DQ_WAVES
+#define STYLER_ATTN_DQ_WAVES 3
+#endif
+#ifndef STYLER_ATTN_FWD_WAVES
+#define STYLER_ATTN_FWD_WAVES 3
+#endif
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -92,7 +104,7 @@ __device__ __forceinline__ void store_accT(float* op, const f32x16& a0, const f3
 }
 
 // ------------------------------------------------------------------------------------------------- forward
-__global__ __launch_bounds__(256) void attention_fwd_bf16_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+__global__ __launch_bounds__(256, STYLER_ATTN_FWD_WAVES) void attention_fwd_bf16_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                  float* __restrict__ lse, int B, int L,
                                                                  const int64_t* __restrict__ len,
                                                                  const int* __restrict__ cu) {
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(256) void attention_fwd_bf16_kernel(const float* __
 }
 
 // ------------------------------------------------------------------------------------------------- dQ
-__global__ __launch_bounds__(256) void attention_bwd_dq_bf16_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(256, STYLER_ATTN_DQ_WAVES) void attention_bwd_dq_bf16_kernel(const float* __restrict__ qkv,
                                                                     const float* __restrict__ o,
                                                                     const float* __restrict__ dout,
                                                                     const float* __restrict__ lse,
@@ -291,7 +303,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_bf16_kernel(const float*
 }
 
 // ------------------------------------------------------------------------------------------------- dK, dV
-__global__ __launch_bounds__(256) void attention_bwd_dkv_bf16_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(256, STYLER_ATTN_DKV_WAVES) void attention_bwd_dkv_bf16_kernel(const float* __restrict__ qkv,
                                                                      const float* __restrict__ dout,
                                                                      const float* __restrict__ lse,
                                                                      const float* __restrict__ delta,
@@ -343,9 +355,13 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_bf16_kernel(const float
     load_rows(rq, qrs, 768, qb, tid);
     load_rows(rdo, drs, 256, qb, tid);
   };
-  if (ntiles > 0) fetch(0);
+#ifndef STYLER_ATTN_DKV_PREFETCH                       // 1: next tile's loads in registers across the MFMAs (no better at 2-3 waves
+#define STYLER_ATTN_DKV_PREFETCH 0                     // per SIMD: 84.4 vs 80.7 us), 0: loads issued ahead of the barrier
+#endif
+  if (STYLER_ATTN_DKV_PREFETCH && ntiles > 0) fetch(0);
   for (int qt = 0; qt < ntiles; ++qt) {
     const int qb = qt * 64;
+    if (!STYLER_ATTN_DKV_PREFETCH) fetch(qb);          // (variant without the register prefetch: loads ahead of the barrier)
     __syncthreads();
     store_rows(sQ, rq, tid);
     store_rows(sDO, rdo, tid);
@@ -355,7 +371,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_bf16_kernel(const float
       sLse[tid] = okq ? r_lse * LOG2E : 1e30f;
       sDl[tid] = okq ? r_dl : 0.f;
     }
-    if (qt + 1 < ntiles) fetch(qb + 64);               // next tile: in flight while this one is multiplied
+    if (STYLER_ATTN_DKV_PREFETCH && qt + 1 < ntiles) fetch(qb + 64);   // next tile: in flight while this one is multiplied
     __syncthreads();
 #pragma unroll
     for (int qk = 0; qk < 2; ++qk) {

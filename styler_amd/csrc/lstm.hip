@@ -209,7 +209,9 @@ __global__ __launch_bounds__(4 * H) void lstm_bidir_bwd_kernel(const float* __re
 
 struct LstmBwdMultiArgs { StylerLstmBwdDesc d[4]; };
 
-__global__ __launch_bounds__(320) void lstm_bidir_bwd_multi_kernel(LstmBwdMultiArgs a, int S) {
+// 4 waves per SIMD stated (<= 128 registers): 768 blocks of 5 waves are then ONE round of three blocks per CU; left to itself
+// hipcc takes 130 registers, i.e. two blocks per CU and 1.5 rounds of a kernel that is 441 sequential steps long (198 -> 157 us)
+__global__ __launch_bounds__(320, 4) void lstm_bidir_bwd_multi_kernel(LstmBwdMultiArgs a, int S) {
   __shared__ __attribute__((aligned(16))) float sdg[4 * 80];
   __shared__ float part[4][80];
   const StylerLstmBwdDesc d = a.d[blockIdx.z];
