@@ -890,6 +890,20 @@ def test_decode_entry_point_vs_oracle(dev, model, O, ref_state_dict):
 
 
 @pytest.mark.gpu
+def test_fast_tanh_accuracy(dev):
+    """common.h's fast_tanh (exp2 + rcp) through the GEMM epilogue (fp32 MFMA against an identity weight is exact): absolute
+    error vs double tanh over [-12, 12] and around 0."""
+    from styler_amd import ops
+    n = 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.cat([(torch.rand(40000, n, generator=g) * 24 - 12), torch.randn(8000, n, generator=g) * 1e-3,
+                   torch.randn(8000, n, generator=g) * 0.3]).to(dev)[None]
+    eye = torch.eye(n, device=dev)
+    y = ops.conv_gemm(x, eye, None, kw=1, act=ops.ACT_TANH, prec=ops.PREC_F32)
+    err = (y.double() - torch.tanh(x.double())).abs().max().item()
+    assert err <= 2.5e-7, err
+
+
 def test_wave_sum_is_the_shuffle_butterfly(dev):
     """common.h's wave_sum (v_permlane32_swap / v_permlane16_swap + four DPP adds) == six `v += __shfl_xor(v, o)` steps, bit
     for bit, in every lane -- LayerNorm and the other wave reductions did not change a bit when they dropped ds_bpermute."""
