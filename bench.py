@@ -235,6 +235,9 @@ def main():
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
+    if rank != 0:
+        sys.stdout.flush()
+        os.dup2(2, 1)                                   # nothing but rank 0's JSON line belongs on the job's stdout
     if world > 1 or os.environ.get("STYLER_FORCE_PG"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -280,9 +283,16 @@ def main():
             "roofline": main_res.get("roofline"), "cpu_baseline": main_res.get("cpu_baseline")}
         if aux:
             line["aux"] = aux
-        print(json.dumps(line))
+    # The JSON line must be the LAST line of the job's stdout.  RCCL writes a version banner to the C-level stdout of every
+    # process that creates a communicator; behind a pipe it sits in the stdio buffer until exit, i.e. it used to land AFTER
+    # the line.  So: tear the group down first, push whatever C code buffered out, and only then print (ranks other than 0
+    # had their stdout pointed at stderr in main()).
     if dist is not None:
         dist.destroy_process_group()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 def pmc_traffic(want, prec):

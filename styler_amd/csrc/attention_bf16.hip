@@ -31,6 +31,12 @@
 #ifndef STYLER_ATTN_FWD_WAVES
 #define STYLER_ATTN_FWD_WAVES 3
 #endif
+#ifndef STYLER_ATTN_FWD_PREFETCH
+#define STYLER_ATTN_FWD_PREFETCH 0
+#endif
+#ifndef STYLER_ATTN_DQ_PREFETCH
+#define STYLER_ATTN_DQ_PREFETCH 0
+#endif
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -174,17 +180,18 @@ __global__ __launch_bounds__(256, STYLER_ATTN_FWD_WAVES) void attention_fwd_bf16
   const __amdgpu_buffer_rsrc_t krs = rows_rsrc(qkv + rowbase * 768 + 256 + head * AD, 768, Lr);
   const __amdgpu_buffer_rsrc_t vrs = rows_rsrc(qkv + rowbase * 768 + 512 + head * AD, 768, Lr);
   const int ntiles = (klen + 63) / 64;
+  float4 rk[4], rv[4];
+  if (STYLER_ATTN_FWD_PREFETCH) { load_rows(rk, krs, 768, 0, tid); load_rows(rv, vrs, 768, 0, tid); }
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * 64;
     // (a register prefetch of the next tile across the MFMAs was measured in round 1: occupancy 3 -> 2 waves per SIMD
     // lost more than it hid.  The loads are issued ahead of the barrier instead: they fly while the block's other waves
     // finish the previous tile.)
-    float4 rk[4], rv[4];
-    load_rows(rk, krs, 768, k0, tid);
-    load_rows(rv, vrs, 768, k0, tid);
+    if (!STYLER_ATTN_FWD_PREFETCH) { load_rows(rk, krs, 768, k0, tid); load_rows(rv, vrs, 768, k0, tid); }
     __syncthreads();
     store_rows(sK, rk, tid);
     store_rows(sV, rv, tid);
+    if (STYLER_ATTN_FWD_PREFETCH && kt + 1 < ntiles) { load_rows(rk, krs, 768, k0 + 64, tid); load_rows(rv, vrs, 768, k0 + 64, tid); }
     __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -288,14 +295,15 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DQ_WAVES) void attention_bwd_dq_bf
   const __amdgpu_buffer_rsrc_t krs = rows_rsrc(qkv + rowbase * 768 + 256 + head * AD, 768, Lr);
   const __amdgpu_buffer_rsrc_t vrs = rows_rsrc(qkv + rowbase * 768 + 512 + head * AD, 768, Lr);
   const int ntiles = (klen + 63) / 64;
+  float4 rk[4], rv[4];
+  if (STYLER_ATTN_DQ_PREFETCH) { load_rows(rk, krs, 768, 0, tid); load_rows(rv, vrs, 768, 0, tid); }
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * 64;
-    float4 rk[4], rv[4];
-    load_rows(rk, krs, 768, k0, tid);
-    load_rows(rv, vrs, 768, k0, tid);
+    if (!STYLER_ATTN_DQ_PREFETCH) { load_rows(rk, krs, 768, k0, tid); load_rows(rv, vrs, 768, k0, tid); }
     __syncthreads();
     store_rows(sK, rk, tid);
     store_rows(sV, rv, tid);
+    if (STYLER_ATTN_DQ_PREFETCH && kt + 1 < ntiles) { load_rows(rk, krs, 768, k0 + 64, tid); load_rows(rv, vrs, 768, k0 + 64, tid); }
     __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {

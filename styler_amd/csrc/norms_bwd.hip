@@ -7,7 +7,9 @@
 // LayerNorm(256) backward.  y = LN(x) * g + b (rows t >= len[b] are zero in forward => zero gradient).
 //   dx = rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)),  dxh = dy * g
 // dot variant (predictor tail, out = <y, w> + b0): dy = dout[row] * w, dw += dout * y, db0 += dout.
+#ifndef LNB_WAVES
 #define LNB_WAVES 8         // waves per block: rows in flight per CU (the row loop is a latency chain of 4 wave reductions)
+#endif
 template <int R>
 __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,

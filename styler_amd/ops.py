@@ -4,6 +4,8 @@ PyTorch supplies device memory (caching allocator), the current HIP stream and n
 function here hands raw device pointers + sizes to libstyler_hip.so.  Activations are fp32
 channels-last [B, L, C]; a channel slice `x[..., a:b]` of a wider buffer is a legal argument (the row
 stride travels as `ld`), which is how torch.cat / torch.split copies of the reference disappear."""
+import os
+
 import torch
 
 from ._lib import lib
@@ -480,7 +482,7 @@ def bn_fold(gamma, beta, running_mean, running_var, conv_bias):
     return scale, shift
 
 
-LN_REPLICAS = 256          # scratch replicas of LayerNorm's parameter gradients inside a training step: one per block
+LN_REPLICAS = int(os.environ.get("STYLER_LN_REPLICAS", "256"))          # scratch replicas of LayerNorm's parameter gradients inside a training step: one per block
                            # (styler_layernorm_bwd launches <= 256 blocks), so the blocks store instead of adding atomically
 BN_WS_COPIES = 16        # STYLER_BN_COPIES (norms.hip): replicas of the 2C-double column accumulator
 
