@@ -525,9 +525,13 @@ static void wgrad_tile(int n, int cin, int kw, int prec, int* TA, int* TB) {
     if (kw == 1 && cin > 64) *TB = 2;
     return;
   }
-  // measured (C2 shapes): the 128x128 tile pays only for Linear gradients with >= 48 64x64 tiles; with fewer tiles, or
-  // with taps (whose operand reuse already is KW-fold), the extra split-K partials and the lower occupancy cost more
-  if (kw == 1 && ((n + 63) / 64) * ((cin + 63) / 64) >= 48) { *TA = 2; *TB = 2; }
+  // Linear gradients: the 128x128 tile from 16 64x64 tiles (256 x 256) up.  A 64x64 tile loads 32 KB of operands per 64-row
+  // chunk for 4 MFMAs per wave -- the grouped launch of the small gradients ran at the CU's vector-memory rate, not at the
+  // MFMA rate; the 128x128 tile halves the bytes per FLOP.  Gradients below 48 tiles still run as members of the grouped
+  // launch, at 8 split-K partials (ops.wgrad): train step 11.515 -> 11.446 ms same-box.  With taps the operand reuse
+  // already is KW-fold and the larger tile only costs occupancy.  STYLER_WGRAD_LIN128_TILES overrides the bound.
+  static const int lin128 = [] { const char* e = getenv("STYLER_WGRAD_LIN128_TILES"); return e ? atoi(e) : 16; }();
+  if (kw == 1 && ((n + 63) / 64) * ((cin + 63) / 64) >= lin128 && n > 64 && cin > 64) { *TA = 2; *TB = 2; }
 }
 
 static void wgrad_plan(int B, int L, int n, int cin, int kw, int pad_left, int prec, int* Be, int* Le, int* cpi, int* cps,
@@ -551,7 +555,8 @@ static void wgrad_plan(int B, int L, int n, int cin, int kw, int pad_left, int p
   // launch (wgrad_tr_group_kernel: bf16, kw = 1, 64x64 tile) share the chip, so they get a quarter of the splits.
   static const int grp_target = [] { const char* e = getenv("STYLER_WGRAD_GROUP_BLOCKS"); return e ? atoi(e) : 128; }();
   static const int big_target = [] { const char* e = getenv("STYLER_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
-  const int target = (prec == STYLER_PREC_BF16 && kw == 1 && TA == 1 && TB == 1) ? grp_target : big_target;
+  const bool group_member = prec == STYLER_PREC_BF16 && kw == 1 && ((n + 63) / 64) * ((cin + 63) / 64) < 48;
+  const int target = group_member ? grp_target : big_target;
   int64_t sp = (target + nt * ct - 1) / (nt * ct);
   if (want_splits > 0 && want_splits < sp) sp = want_splits;               // grouped launch: the group fills the chip
   if (sp >= 8 && prec == STYLER_PREC_BF16) sp = (sp + 4) / 8 * 8;          // whole splits per XCD (see wgrad_tr_kernel)

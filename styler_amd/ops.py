@@ -709,6 +709,9 @@ def act_bwd(dy, y, act, lens=None):
     return dz
 
 
+LIN128_SPLITS = int(os.environ.get("STYLER_WGRAD_LIN128_SPLITS", "8"))
+
+
 def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=None, db2=None, plan=None):
     """dw (fp32, parameter layout [n, cin] or [n, cin, kw]) += dz^T x over all taps; db (and db2) += colsum(dz)."""
     B, L = dz.shape[0], dz.shape[1]
@@ -737,8 +740,9 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
         nb = lib.styler_wgrad_group_desc(ctypes.byref(d), *args, None, *packed, io, 0)
         if nb < 0:
             _chk(nb, "styler_wgrad_group_desc")
-        if nb > 0 and (arena.group_all or d.variant == 0):
-            want = arena.want_splits(d.variant) if arena.group_all else 0
+        small = ((n + 63) // 64) * ((cin + 63) // 64) < 48
+        if nb > 0 and (arena.group_all or d.variant == 0 or (d.variant == 1 and small)):
+            want = arena.want_splits(d.variant) if arena.group_all else (LIN128_SPLITS if d.variant == 1 else 0)
             if want:
                 nb = lib.styler_wgrad_group_desc(ctypes.byref(d), *args, None, *packed, io, want)
             ws = arena.take(d.splits * n * kw * cin, dz.device)
