@@ -319,6 +319,96 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// Single-pass backward for L <= 64 * GNB_IT rows per item (same block shape as gn_fused_kernel, norms.hip): x and dy are
+// loaded once and stay in registers between the group sums and dx -- 3 tensor passes over HBM instead of 5.
+#define GNB_IT 8
+int gn_fused_ok(int L);                              // norms.hip
+template <bool DY16>
+__global__ __launch_bounds__(1024) void gn_bwd_fused_kernel(const float* __restrict__ x, int64_t ldx,
+                                                            const void* __restrict__ dy, int64_t lddy,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ stats, void* __restrict__ dx,
+                                                            int64_t lddx, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int L, int C, int dx16) {
+  __shared__ float red[2][16][4];
+  __shared__ float pg[2][16][64];
+  const int b = blockIdx.y, c0 = blockIdx.x * 64;
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4, wave = threadIdx.x >> 6, grp = cq >> 2, lane = threadIdx.x & 63;
+  const int64_t gi = ((int64_t)b * (C / 16) + c0 / 16 + grp) * 2;
+  const float* xp = x + (int64_t)b * L * ldx + c0 + cq * 4;
+  const int64_t gbase = (int64_t)b * L * lddy + c0 + cq * 4;
+  const float mean = stats[gi], rstd = stats[gi + 1];
+  float4 ga = *reinterpret_cast<const float4*>(gamma + c0 + cq * 4);
+  float4 be = *reinterpret_cast<const float4*>(beta + c0 + cq * 4);
+  float4 v[GNB_IT];
+  typename Raw4<DY16>::T g4[GNB_IT];
+#pragma unroll
+  for (int i = 0; i < GNB_IT; ++i) {
+    const int t = rl + 64 * i < L ? rl + 64 * i : L - 1;
+    v[i] = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
+    g4[i] = raw4_load<DY16>(dy, gbase + (int64_t)t * lddy);
+  }
+  pin_loaded(ga); pin_loaded(be);                    // (the compiler sinks these two loads behind the waits otherwise)
+#pragma unroll
+  for (int i = 0; i < GNB_IT; ++i) { pin_loaded(v[i]); pin_loaded(g4[i]); }
+  float s1 = 0.f, s2 = 0.f;
+  float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
+  // v becomes xh, g4 stays raw: dxh = relu-masked dy * gamma is formed here and again (two multiplies) for dx
+#pragma unroll
+  for (int i = 0; i < GNB_IT; ++i) {
+    v[i].x = (v[i].x - mean) * rstd; v[i].y = (v[i].y - mean) * rstd; v[i].z = (v[i].z - mean) * rstd; v[i].w = (v[i].w - mean) * rstd;
+    float4 g = raw4_f32(g4[i]);
+    if (rl + 64 * i >= L) g = make_float4(0.f, 0.f, 0.f, 0.f);
+    g.x = (v[i].x * ga.x + be.x) > 0.f ? g.x : 0.f; g.y = (v[i].y * ga.y + be.y) > 0.f ? g.y : 0.f;
+    g.z = (v[i].z * ga.z + be.z) > 0.f ? g.z : 0.f; g.w = (v[i].w * ga.w + be.w) > 0.f ? g.w : 0.f;
+    ag.x += g.x * v[i].x; ag.y += g.y * v[i].y; ag.z += g.z * v[i].z; ag.w += g.w * v[i].w;
+    ab.x += g.x; ab.y += g.y; ab.z += g.z; ab.w += g.w;
+  }
+  // per-thread group sums from the per-channel ones: sum dxh = sum_c gamma_c ab_c, sum dxh xh = sum_c gamma_c ag_c
+  s1 = (ab.x * ga.x + ab.y * ga.y) + (ab.z * ga.z + ab.w * ga.w);
+  s2 = (ag.x * ga.x + ag.y * ga.y) + (ag.z * ga.z + ag.w * ga.w);
+  s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+  s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {
+    s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64);
+    ag.x += __shfl_xor(ag.x, o, 64); ag.y += __shfl_xor(ag.y, o, 64); ag.z += __shfl_xor(ag.z, o, 64); ag.w += __shfl_xor(ag.w, o, 64);
+    ab.x += __shfl_xor(ab.x, o, 64); ab.y += __shfl_xor(ab.y, o, 64); ab.z += __shfl_xor(ab.z, o, 64); ab.w += __shfl_xor(ab.w, o, 64);
+  }
+  if ((lane & 0x33) == 0) { red[0][wave][grp] = s1; red[1][wave][grp] = s2; }
+  if (lane < 16) {
+    *reinterpret_cast<float4*>(&pg[0][wave][cq * 4]) = ag;
+    *reinterpret_cast<float4*>(&pg[1][wave][cq * 4]) = ab;
+  }
+  __syncthreads();
+  float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { t1 += red[0][w][grp]; t2 += red[1][w][grp]; }
+  if (threadIdx.x < 128) {
+    const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += pg[which][w][c];
+    atomicAdd((which ? dbeta : dgamma) + c0 + c, t);
+  }
+  const float inv_n = 1.f / (16.f * (float)L);
+  const float m1 = t1 * inv_n, m2 = t2 * inv_n;
+  float* dxp = reinterpret_cast<float*>(dx) + (int64_t)b * L * lddx + c0 + cq * 4;
+  uint16_t* dxp16 = reinterpret_cast<uint16_t*>(dx) + (int64_t)b * L * lddx + c0 + cq * 4;
+#pragma unroll
+  for (int i = 0; i < GNB_IT; ++i) {
+    const int t = rl + 64 * i;
+    if (t >= L) break;
+    float4 g = raw4_f32(g4[i]);
+    g.x = (v[i].x * ga.x + be.x) > 0.f ? g.x * ga.x : 0.f; g.y = (v[i].y * ga.y + be.y) > 0.f ? g.y * ga.y : 0.f;
+    g.z = (v[i].z * ga.z + be.z) > 0.f ? g.z * ga.z : 0.f; g.w = (v[i].w * ga.w + be.w) > 0.f ? g.w * ga.w : 0.f;
+    const float4 o = make_float4(rstd * (g.x - m1 - v[i].x * m2), rstd * (g.y - m1 - v[i].y * m2),
+                                 rstd * (g.z - m1 - v[i].z * m2), rstd * (g.w - m1 - v[i].w * m2));
+    if (dx16) *reinterpret_cast<uint2*>(dxp16 + (int64_t)t * lddx) = make_uint2(cvt_pk_bf16_rne(o.x, o.y), cvt_pk_bf16_rne(o.z, o.w));
+    else *reinterpret_cast<float4*>(dxp + (int64_t)t * lddx) = o;
+  }
+}
+
 extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void* dy, int64_t lddy,
                                          const float* gamma, const float* beta, const float* stats, void* dx,
                                          int64_t lddx, float* dgamma, float* dbeta, double* workspace, int ws_zeroed, int B,
@@ -328,6 +418,17 @@ extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void
     return STYLER_EINVAL;
   if ((ldx & 3) || (lddy & 3) || (lddx & 3)) return STYLER_EALIGN;
   hipStream_t st = (hipStream_t)stream;
+  const int dy16 = (io_flags & STYLER_IO_X_BF16) ? 1 : 0;
+  const int dx16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
+  if (gn_fused_ok(L)) {
+    if (dy16)
+      hipLaunchKernelGGL(gn_bwd_fused_kernel<true>, dim3(C / 64, B), dim3(1024), 0, st, x, ldx, dy, lddy, gamma, beta, stats, dx,
+                         lddx, dgamma, dbeta, L, C, dx16);
+    else
+      hipLaunchKernelGGL(gn_bwd_fused_kernel<false>, dim3(C / 64, B), dim3(1024), 0, st, x, ldx, dy, lddy, gamma, beta, stats, dx,
+                         lddx, dgamma, dbeta, L, C, dx16);
+    return launch_status();
+  }
   if (!ws_zeroed) {
     hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * B * (C / 16), st);
     if (e != hipSuccess) return (int)e;
@@ -335,8 +436,6 @@ extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void
   const int nseg = gn_segments_host(B, L, C);
   const int seg_rows = ((L + nseg - 1) / nseg + 15) & ~15;
   const dim3 grid(C / 64, B, (L + seg_rows - 1) / seg_rows);
-  const int dy16 = (io_flags & STYLER_IO_X_BF16) ? 1 : 0;
-  const int dx16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
   if (dy16) {
     hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, grid, dim3(256), 0, st, x, ldx, dy, lddy, gamma, beta, stats, workspace,
                        dgamma, dbeta, L, C, seg_rows);

@@ -163,16 +163,17 @@ def test_layernorm_backward(dev):
     check(lind.bias.grad, lin.bias.grad, 3e-5, "dot db"); check(lnd.weight.grad, ln.weight.grad, 3e-5, "dot dgamma")
 
 
-@pytest.mark.parametrize("C", [256, 320])
-def test_groupnorm_backward(dev, C):
+@pytest.mark.parametrize("C,L", [(256, 53), (320, 53), (320, 441), (256, 512), (320, 700)])
+def test_groupnorm_backward(dev, C, L):
+    """L <= 512: single-pass backward; longer items: the statistics + apply pair."""
     from styler_amd import autograd as AG
-    g = torch.Generator().manual_seed(C)
-    x = (torch.randn(2, 53, C, generator=g, dtype=torch.float64) * 2 + 0.3).requires_grad_(True)
+    g = torch.Generator().manual_seed(C + L)
+    x = (torch.randn(2, L, C, generator=g, dtype=torch.float64) * 2 + 0.3).requires_grad_(True)
     gn = nn.GroupNorm(C // 16, C).double()
     with torch.no_grad():
         gn.weight.copy_(torch.randn(C, generator=g)); gn.bias.copy_(torch.randn(C, generator=g))
     y = torch.relu(gn(x.transpose(1, 2))).transpose(1, 2)
-    gy = torch.randn(2, 53, C, generator=g, dtype=torch.float64)
+    gy = torch.randn(2, L, C, generator=g, dtype=torch.float64)
     y.backward(gy)
     gnd = nn.GroupNorm(C // 16, C).to(dev)
     with torch.no_grad():

@@ -128,14 +128,15 @@ def test_add_layernorm(dev):
     check(d, ref2, 5e-5, "layernorm-dot")
 
 
-@pytest.mark.parametrize("C", [256, 320])
-def test_groupnorm_relu(dev, C):
+@pytest.mark.parametrize("C,L", [(256, 77), (320, 77), (320, 441), (256, 512), (320, 513), (256, 1100)])
+def test_groupnorm_relu(dev, C, L):
+    """L <= 512: the single-pass kernel (rows in registers); longer items: statistics kernel + apply kernel."""
     from styler_amd import ops
-    g = torch.Generator().manual_seed(C)
-    x = torch.randn(3, 77, C, generator=g) * 2 + 0.5
+    g = torch.Generator().manual_seed(C + L)
+    x = torch.randn(3, L, C, generator=g) * 2 + 0.5
     ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
     ref = F.relu(F.group_norm(x.transpose(1, 2), C // 16, ga, be)).transpose(1, 2)
-    wide = torch.zeros(3, 77, 1152, device=dev)
+    wide = torch.zeros(3, L, 1152, device=dev)
     ops.groupnorm_relu(x.to(dev), ga.to(dev), be.to(dev), out=wide[..., 256:256 + C])
     check(wide[..., 256:256 + C], ref, 1e-5, "groupnorm")
 
