@@ -23,19 +23,50 @@ __global__ __launch_bounds__(256) void masked_err_mean_kernel(const float* __res
                                                               const int64_t* __restrict__ len) {
   __shared__ double red[4][2];
   double s = 0.0, n = 0.0;
-  if ((C & 3) == 0 && (lda & 3) == 0 && (ldb & 3) == 0) {
-    const int nq = C >> 2;
-    const int64_t total = rows * nq;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-      const int64_t row = i / nq; const int q = (int)(i - row * nq);
-      const int64_t bb = row / L;
-      if (len && (row - bb * L) >= len[bb]) continue;
-      const float4 x = *reinterpret_cast<const float4*>(a + row * lda + q * 4);
-      const float4 y = *reinterpret_cast<const float4*>(b + row * ldb + q * 4);
-      const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
-      if (kind == 0) s += ((double)d0 * d0 + (double)d1 * d1) + ((double)d2 * d2 + (double)d3 * d3);
-      else s += ((double)fabsf(d0) + (double)fabsf(d1)) + ((double)fabsf(d2) + (double)fabsf(d3));
-      n += 4.0;
+  if ((C & 3) == 0 && C <= 1024 && (lda & 3) == 0 && (ldb & 3) == 0 && rows < ((int64_t)1 << 31)) {
+    // thread = (row-lane, float4 column); four rows per thread in flight, fetched from clamped addresses and dropped by a
+    // select; a row's item comes from one 32-bit division (the flat loop this replaces paid two 64-bit divisions per
+    // element and a branch around its loads: thirteen dependent round trips per thread on the mel tensors)
+    const int nq = C >> 2, lanes = 256 / nq;
+    const int rl = threadIdx.x / nq, ql = threadIdx.x - rl * nq;
+    const int64_t stride = (int64_t)gridDim.x * lanes;
+    if (rl < lanes) {
+      for (int64_t row0 = (int64_t)blockIdx.x * lanes + rl; row0 < rows; row0 += 4 * stride) {
+        float4 x[4], y[4];
+        int64_t rc[4], lv[4];
+        uint32_t tt[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t r = row0 + u * stride;
+          rc[u] = r < rows ? r : rows - 1;
+          tt[u] = 0u; lv[u] = 1;
+        }
+        if (len) {                                       // the lengths first, as one batch: a load next to its use inside
+#pragma unroll                                           // this branch put a wait in front of the row loads
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t bb = (uint32_t)rc[u] / (uint32_t)L;
+            tt[u] = (uint32_t)rc[u] - bb * (uint32_t)L;
+            lv[u] = len[bb];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          x[u] = *reinterpret_cast<const float4*>(a + rc[u] * lda + ql * 4);
+          y[u] = *reinterpret_cast<const float4*>(b + rc[u] * ldb + ql * 4);
+        }
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ok[u] = (row0 + u * stride < rows) & ((int64_t)tt[u] < lv[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float d0 = x[u].x - y[u].x, d1 = x[u].y - y[u].y, d2 = x[u].z - y[u].z, d3 = x[u].w - y[u].w;
+          double e;
+          if (kind == 0) e = ((double)d0 * d0 + (double)d1 * d1) + ((double)d2 * d2 + (double)d3 * d3);
+          else e = ((double)fabsf(d0) + (double)fabsf(d1)) + ((double)fabsf(d2) + (double)fabsf(d3));
+          s += ok[u] ? e : 0.0;
+          n += ok[u] ? 4.0 : 0.0;
+        }
+      }
     }
   } else {
     const int64_t total = rows * C;
@@ -71,6 +102,7 @@ extern "C" int styler_masked_err_mean(const float* a, int64_t lda, const float* 
                                       int kind, int B, int L, int C, const int64_t* len, void* stream) {
   if (!a || !b || !acc || B <= 0 || L <= 0 || C <= 0 || (kind != 0 && kind != 1)) return STYLER_EINVAL;
   const int64_t rows = (int64_t)B * L;
+  if (!(C & 3) && (((uintptr_t)a | (uintptr_t)b) & 15)) return STYLER_EALIGN;
   hipLaunchKernelGGL(masked_err_mean_kernel, dim3(loss_grid(rows * C / ((C & 3) ? 1 : 4), 1024, 256)), dim3(256), 0,
                      (hipStream_t)stream, a, lda, b, ldb, acc, mean_out, kind, rows, L, C, len);
   return launch_status();

@@ -87,7 +87,10 @@ __device__ __forceinline__ int quant_index(float v, int* bad) {
   return (int)rintf(v * 255.f) + 1;        // rintf = round-half-to-even, as torch.round
 }
 
-// one wave per frame; lanes stride the output channels (coalesced 256-B rows of wt)
+// one wave per frame; lanes stride the output channels (coalesced 256-B rows of wt).  Nothing is loaded under a condition:
+// the five neighbour values come from clamped addresses and the five weight rows from a clamped index, invalid taps are
+// dropped by a select -- so the loads of a frame are in flight together (under `if (valid)` each one was its own memory
+// round trip: 45 us for 42 k frames).
 __global__ __launch_bounds__(256) void onehot_conv5_kernel(const float* __restrict__ v, const float* __restrict__ wt,
                                                            const float* __restrict__ bias, float* __restrict__ y,
                                                            int64_t ldy, int32_t* __restrict__ idx_out,
@@ -98,19 +101,31 @@ __global__ __launch_bounds__(256) void onehot_conv5_kernel(const float* __restri
   if (row >= rows) return;
   const int t = (int)(row % L);
   int bad = 0;
+  float vv[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int tt = t + j - 2;
+    vv[j] = v[row + ((tt >= 0 && tt < L) ? j - 2 : 0)];
+  }
   int idx[5];
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     const int tt = t + j - 2;
-    idx[j] = (tt >= 0 && tt < L) ? quant_index(v[row + j - 2], &bad) : -1;
+    int bj = 0;
+    const int q = quant_index(vv[j], &bj);
+    const bool ok = tt >= 0 && tt < L;
+    idx[j] = ok ? q : -1;
+    bad |= ok ? bj : 0;
   }
   if (bad && lane == 0 && err_flag) atomicOr(err_flag, 1);
   if (idx_out && lane == 0) idx_out[row] = idx[2];
   for (int c = lane; c < C; c += 64) {
+    float w[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) w[j] = wt[((int64_t)j * 257 + (idx[j] >= 0 ? idx[j] : 0)) * C + c];
     float acc = bias[c];
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
-      if (idx[j] >= 0) acc += wt[((int64_t)j * 257 + idx[j]) * C + c];
+    for (int j = 0; j < 5; ++j) acc += idx[j] >= 0 ? w[j] : 0.f;
     y[row * ldy + c] = acc;
   }
 }
@@ -129,12 +144,17 @@ extern "C" int styler_onehot_conv5(const float* v, const float* wt, const float*
 //   ml > sl : mean of frames [start, start+n), n = ml/sl + (s < ml%sl), start = s*(ml/sl) + min(s, ml%sl)
 //   ml < sl : frame f with f*(q) + min(f, r) <= s, q = sl/ml, r = sl%ml
 //   ml == sl: copy;   s >= sl: zeros
+// Block = 256 / (C / 4) output rows of one item (C = 80: 12 rows, 240 threads busy; a block per row kept 20 of 256 lanes
+// busy and paid a block launch per 320 bytes), thread = (row, float4 column); the frames of a mean are fetched four at a time.
 __global__ __launch_bounds__(256) void mel_calibrate_kernel(const float* __restrict__ x, int64_t ldx,
                                                             float* __restrict__ y, int64_t ldy,
                                                             const int64_t* __restrict__ mel_len,
                                                             const int64_t* __restrict__ src_len, int T, int S,
                                                             int C) {
-  const int s = blockIdx.x, b = blockIdx.y;
+  const int nq = C >> 2, cpr = nq < 256 ? nq : 256, rpb = 256 / cpr;
+  const int rl = threadIdx.x / cpr, ql = threadIdx.x - rl * cpr;
+  const int s = blockIdx.x * rpb + rl, b = blockIdx.y;
+  if (rl >= rpb || s >= S) return;
   const int ml = (int)mel_len[b], sl = (int)src_len[b];
   float* yp = y + ((int64_t)b * S + s) * ldy;
   const float* xb = x + (int64_t)b * T * ldx;
@@ -150,23 +170,30 @@ __global__ __launch_bounds__(256) void mel_calibrate_kernel(const float* __restr
       start = f; n = 1;
     }
   }
-  for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
+  for (int q4 = ql; q4 < nq; q4 += cpr) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int f = 0; f < n; ++f) {
-      const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)(start + f) * ldx + c);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    for (int f0 = 0; f0 < n; f0 += 4) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xb + (int64_t)(start + (f0 + u < n ? f0 + u : n - 1)) * ldx + q4 * 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (f0 + u < n) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
     }
     if (n > 1) { const float d = (float)n; acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d; }
-    *reinterpret_cast<float4*>(yp + c) = acc;
+    *reinterpret_cast<float4*>(yp + q4 * 4) = acc;
   }
 }
+
+static inline int mel_cal_rows_per_block(int C) { const int nq = C >> 2; return 256 / (nq < 256 ? nq : 256); }
 
 extern "C" int styler_mel_calibrate(const float* x, int64_t ldx, float* y, int64_t ldy, const int64_t* mel_len,
                                     const int64_t* src_len, int B, int T, int S, int C, void* stream) {
   if (!x || !y || !mel_len || !src_len || B <= 0 || T <= 0 || S <= 0 || C <= 0 || (C & 3)) return STYLER_EINVAL;
   if ((ldx & 3) || (ldy & 3)) return STYLER_EALIGN;
-  hipLaunchKernelGGL(mel_calibrate_kernel, dim3(S, B), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, mel_len,
-                     src_len, T, S, C);
+  const int rpb = mel_cal_rows_per_block(C);
+  hipLaunchKernelGGL(mel_calibrate_kernel, dim3((S + rpb - 1) / rpb, B), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
+                     mel_len, src_len, T, S, C);
   return launch_status();
 }
 

@@ -57,11 +57,15 @@ extern "C" int styler_onehot_expand(const float* v, float* onehot, int64_t rows,
 }
 
 // ---- mel calibrator backward: grid (T, B) over INPUT frames -----------------------------------------------
+// (block = 256 / (C / 4) input frames of one item, thread = (frame, float4 column): see mel_calibrate_kernel)
 __global__ __launch_bounds__(256) void mel_calibrate_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
                                                                 float* __restrict__ dx, int64_t lddx,
                                                                 const int64_t* __restrict__ mel_len,
                                                                 const int64_t* __restrict__ src_len, int T, int S, int C) {
-  const int t = blockIdx.x, b = blockIdx.y;
+  const int nq = C >> 2, cpr = nq < 256 ? nq : 256, rpb = 256 / cpr;
+  const int rl = threadIdx.x / cpr, ql = threadIdx.x - rl * cpr;
+  const int t = blockIdx.x * rpb + rl, b = blockIdx.y;
+  if (rl >= rpb || t >= T) return;
   const int ml = (int)mel_len[b], sl = (int)src_len[b];
   float* dxp = dx + ((int64_t)b * T + t) * lddx;
   const float* dyb = dy + (int64_t)b * S * lddy;
@@ -79,18 +83,19 @@ __global__ __launch_bounds__(256) void mel_calibrate_bwd_kernel(const float* __r
       s0 = t * q + (t < r ? t : r);
     }
   }
-  for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
+  const int n = div > 0 ? 1 : cnt;                    // rows of dy that reach this frame
+  for (int q4 = ql; q4 < nq; q4 += cpr) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (div > 0) {
-      acc = *reinterpret_cast<const float4*>(dyb + (int64_t)s0 * lddy + c);
-      if (div > 1) { const float d = (float)div; acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d; }
-    } else {
-      for (int k = 0; k < cnt; ++k) {
-        const float4 g = *reinterpret_cast<const float4*>(dyb + (int64_t)(s0 + k) * lddy + c);
-        acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
-      }
+    for (int k0 = 0; k0 < n; k0 += 4) {
+      float4 g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) g[u] = *reinterpret_cast<const float4*>(dyb + (int64_t)(s0 + (k0 + u < n ? k0 + u : n - 1)) * lddy + q4 * 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k0 + u < n) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
     }
-    *reinterpret_cast<float4*>(dxp + c) = acc;
+    if (div > 1) { const float d = (float)div; acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d; }
+    *reinterpret_cast<float4*>(dxp + q4 * 4) = acc;
   }
 }
 
@@ -98,8 +103,9 @@ extern "C" int styler_mel_calibrate_bwd(const float* dy, int64_t lddy, float* dx
                                         const int64_t* src_len, int B, int T, int S, int C, void* stream) {
   if (!dy || !dx || !mel_len || !src_len || B <= 0 || T <= 0 || S <= 0 || C <= 0 || (C & 3)) return STYLER_EINVAL;
   if ((lddy & 3) || (lddx & 3)) return STYLER_EALIGN;
-  hipLaunchKernelGGL(mel_calibrate_bwd_kernel, dim3(T, B), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx, lddx, mel_len,
-                     src_len, T, S, C);
+  const int nq = C >> 2, rpb = 256 / (nq < 256 ? nq : 256);
+  hipLaunchKernelGGL(mel_calibrate_bwd_kernel, dim3((T + rpb - 1) / rpb, B), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx,
+                     lddx, mel_len, src_len, T, S, C);
   return launch_status();
 }
 
@@ -265,17 +271,31 @@ extern "C" int styler_bucket_embed_bwd(const float* dy, const int32_t* p_ids, co
 }
 
 // ---- per-item row sum: out[b,:] (+)= sum_t x[b,t,:]  (gradient of the speaker row broadcast) ----------------
+// Block = (64 float4 columns, item): its four waves take rows t = wave, wave + 4, ... eight loads in flight each, and
+// meet in LDS (one wave walking all L rows alone was a chain of L dependent round trips on 96 waves chip-wide).
 __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ out,
                                                      int64_t ldo, int L, int C, int accumulate) {
-  const int b = blockIdx.y;
-  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (c >= C) return;
+  __shared__ float4 red[4][64];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 4;
+  const bool okc = c < C;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float* xp = x + (int64_t)b * L * ldx + c;
-  for (int t = 0; t < L; ++t) {
-    const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  const float* xp = x + (int64_t)b * L * ldx + (okc ? c : 0);
+  for (int t0 = wave; t0 < L; t0 += 32) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(xp + (int64_t)(t0 + 4 * u < L ? t0 + 4 * u : L - 1) * ldx);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (t0 + 4 * u < L) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
   }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave != 0 || !okc) return;
+  acc.x = (red[0][lane].x + red[1][lane].x) + (red[2][lane].x + red[3][lane].x);
+  acc.y = (red[0][lane].y + red[1][lane].y) + (red[2][lane].y + red[3][lane].y);
+  acc.z = (red[0][lane].z + red[1][lane].z) + (red[2][lane].z + red[3][lane].z);
+  acc.w = (red[0][lane].w + red[1][lane].w) + (red[2][lane].w + red[3][lane].w);
   float4* o = reinterpret_cast<float4*>(out + (int64_t)b * ldo + c);
   if (accumulate) { const float4 p = *o; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
   *o = acc;
@@ -284,12 +304,16 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ x
 extern "C" int styler_rowsum(const float* x, int64_t ldx, float* out, int64_t ldo, int B, int L, int C, int accumulate,
                              void* stream) {
   if (!x || !out || B <= 0 || L <= 0 || C <= 0 || (C & 3) || (ldx & 3) || (ldo & 3)) return STYLER_EINVAL;
-  hipLaunchKernelGGL(rowsum_kernel, dim3((C / 4 + 63) / 64, B), dim3(64), 0, (hipStream_t)stream, x, ldx, out, ldo, L, C,
+  hipLaunchKernelGGL(rowsum_kernel, dim3((C / 4 + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, L, C,
                      accumulate);
   return launch_status();
 }
 
 // ---- masked error gradient: da = gscale * d/da err(a-b) / count on valid rows, 0 elsewhere -------------------
+// Row geometry (C % 4 == 0, C <= 1024): thread = (row-lane, float4 column), four rows per thread in flight, the item length
+// of a row from one 32-bit division per row -- the flat element loop it replaces paid two 64-bit divisions and a branch
+// around its loads per ELEMENT.  Other shapes take the flat loop.
+template <bool VEC>
 __global__ __launch_bounds__(256) void masked_err_bwd_kernel(const float* __restrict__ a, int64_t lda,
                                                              const float* __restrict__ b, int64_t ldb,
                                                              const double* __restrict__ acc,
@@ -297,16 +321,63 @@ __global__ __launch_bounds__(256) void masked_err_bwd_kernel(const float* __rest
                                                              int kind, int64_t rows, int L, int C,
                                                              const int64_t* __restrict__ len) {
   const float k = gscale[0] / (float)acc[1];
-  const int64_t total = rows * C;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i / C; const int c = (int)(i - row * C);
-    const int64_t bb = row / L;
-    float g = 0.f;
-    if (!len || (row - bb * L) < len[bb]) {
-      const float d = a[row * lda + c] - b[row * ldb + c];
-      g = kind == 0 ? 2.f * d * k : (d > 0.f ? k : (d < 0.f ? -k : 0.f));
+  if constexpr (VEC) {
+    const int nq = C >> 2, lanes = 256 / nq;
+    const int rl = threadIdx.x / nq, ql = threadIdx.x - rl * nq;
+    if (rl >= lanes) return;
+    const int64_t stride = (int64_t)gridDim.x * lanes;
+    for (int64_t row0 = (int64_t)blockIdx.x * lanes + rl; row0 < rows; row0 += 4 * stride) {
+      float4 x[4], y[4];
+      int64_t rc[4], lv[4];
+      uint32_t tt[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = row0 + u * stride;
+        rc[u] = r < rows ? r : rows - 1;
+        tt[u] = 0u; lv[u] = 1;
+      }
+      if (len) {                                         // lengths first, as one batch (see masked_err_mean_kernel)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t bb = (uint32_t)rc[u] / (uint32_t)L;
+          tt[u] = (uint32_t)rc[u] - bb * (uint32_t)L;
+          lv[u] = len[bb];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        x[u] = *reinterpret_cast<const float4*>(a + rc[u] * lda + ql * 4);
+        y[u] = *reinterpret_cast<const float4*>(b + rc[u] * ldb + ql * 4);
+      }
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ok[u] = (int64_t)tt[u] < lv[u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = row0 + u * stride;
+        if (r >= rows) break;
+        const float d[4] = {x[u].x - y[u].x, x[u].y - y[u].y, x[u].z - y[u].z, x[u].w - y[u].w};
+        float g[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          g[e] = kind == 0 ? 2.f * d[e] * k : (d[e] > 0.f ? k : (d[e] < 0.f ? -k : 0.f));
+          g[e] = ok[u] ? g[e] : 0.f;
+        }
+        *reinterpret_cast<float4*>(da + r * C + ql * 4) = make_float4(g[0], g[1], g[2], g[3]);
+      }
     }
-    da[i] = g;
+  } else {
+    const int64_t total = rows * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t row = i / C; const int c = (int)(i - row * C);
+      const int64_t bb = row / L;
+      float g = 0.f;
+      if (!len || (row - bb * L) < len[bb]) {
+        const float d = a[row * lda + c] - b[row * ldb + c];
+        g = kind == 0 ? 2.f * d * k : (d > 0.f ? k : (d < 0.f ? -k : 0.f));
+      }
+      da[i] = g;
+    }
   }
 }
 
@@ -315,8 +386,18 @@ extern "C" int styler_masked_err_bwd(const float* a, int64_t lda, const float* b
                                      void* stream) {
   if (!a || !b || !acc || !gscale || !da || B <= 0 || L <= 0 || C <= 0) return STYLER_EINVAL;
   const int64_t rows = (int64_t)B * L;
-  hipLaunchKernelGGL(masked_err_bwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb,
-                     acc, gscale, da, kind, rows, L, C, len);
+  const bool vec = !(C & 3) && C <= 1024 && !(lda & 3) && !(ldb & 3) && rows < ((int64_t)1 << 31) &&
+                   !(((uintptr_t)a | (uintptr_t)b | (uintptr_t)da) & 15);
+  if (vec) {
+    const int lanes = 256 / (C >> 2);
+    int64_t blocks = (rows + (int64_t)lanes * 4 - 1) / ((int64_t)lanes * 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(masked_err_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb,
+                       acc, gscale, da, kind, rows, L, C, len);
+  } else {
+    hipLaunchKernelGGL(masked_err_bwd_kernel<false>, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, a, lda, b,
+                       ldb, acc, gscale, da, kind, rows, L, C, len);
+  }
   return launch_status();
 }
 
