@@ -104,6 +104,12 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return copysignf(r, x);
 }
 
+// sigmoid(x) = 1 / (1 + exp2(-x log2 e)): v_exp_f32 + v_rcp_f32 (expf + an IEEE division are ~25 instructions; the LSTM
+// kernels are bound by their VALU instruction count).  Absolute error <= 3e-7.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == STYLER_ACT_RELU) return fmaxf(v, 0.f);
   if (act == STYLER_ACT_TANH) return fast_tanh(v);

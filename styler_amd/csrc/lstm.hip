@@ -48,14 +48,18 @@ __device__ __forceinline__ void lstm_fwd_body(const float* __restrict__ gx, cons
       a23 = __builtin_elementwise_fma(w23, h23, a23);
     }
     const float pre = (a01.x + a01.y) + (a23.x + a23.y);
+    // one exp2 + one rcp per gate, no divergence where a wave straddles two gates: sigmoid(x) = 0.5 + 0.5 tanh(x / 2).
+    // (The library tanhf / expf + division were ~60 of the ~100 VALU instructions of a step, and with three blocks per CU
+    // the step time IS the VALU instruction count.)
     const bool is_g = (j >= 2 * H) && (j < 3 * H);
-    const float act = is_g ? tanhf(pre) : 1.0f / (1.0f + expf(-pre));
+    const float th = fast_tanh(is_g ? pre : 0.5f * pre);
+    const float act = is_g ? th : fmaf(0.5f, th, 0.5f);
     gbuf[j] = act;
     if (gates_out) gates_out[((int64_t)b * S + t) * gx_ld + dir * 4 * H + j] = act;
     __syncthreads();
     if (j < H) {
       c = gbuf[H + j] * c + gbuf[j] * gbuf[2 * H + j];
-      const float h = gbuf[3 * H + j] * tanhf(c);
+      const float h = gbuf[3 * H + j] * fast_tanh(c);
       hbuf[j] = h;
       out[((int64_t)b * S + t) * out_ld + dir * H + j] = h;
       if (cell_out) cell_out[((int64_t)b * S + t) * out_ld + dir * H + j] = c;
@@ -129,7 +133,7 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ dout, co
   const int tid = threadIdx.x, q = tid / H, k = tid % H;
   const int b = blockIdx.x, dir = blockIdx.y;
   if (tid >= 4 * H) {                        // surplus threads of a shared launch only take part in the barriers
-    for (int step = 0; step < S; ++step) { __syncthreads(); __syncthreads(); __syncthreads(); }
+    for (int step = 0; step < S; ++step) { __syncthreads(); __syncthreads(); }
     return;
   }
   float w[H];
@@ -169,7 +173,7 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ dout, co
       const int64_t go = goff(t);
       const float c_prev = step + 1 < S ? c_n1 : 0.f;    // previous step in forward processing order = the walk's next
       const float dh = dov + dh_rec;
-      const float tc = tanhf(c);
+      const float tc = fast_tanh(c);
       const float d_o = dh * tc;
       const float dc = dc_next + dh * gout * (1.f - tc * tc);
       const float di = dc * gg, dg = dc * gi, df = dc * c_prev;
@@ -180,19 +184,23 @@ __device__ __forceinline__ void lstm_bwd_body(const float* __restrict__ dout, co
       dgp[go] = pi; dgp[go + H] = pf; dgp[go + 2 * H] = pg; dgp[go + 3 * H] = po;
     }
     __syncthreads();
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    f32x2_t a01 = {0.f, 0.f}, a23 = {0.f, 0.f};        // packed FMAs: H / 2 VALU instructions for the H-term product
 #pragma unroll
     for (int j = 0; j < H; j += 4) {
       const float4 d = *reinterpret_cast<const float4*>(&sdg[q * H + j]);
-      a0 = fmaf(w[j], d.x, a0); a1 = fmaf(w[j + 1], d.y, a1); a2 = fmaf(w[j + 2], d.z, a2); a3 = fmaf(w[j + 3], d.w, a3);
+      const f32x2_t w01 = {w[j], w[j + 1]}, w23 = {w[j + 2], w[j + 3]}, d01 = {d.x, d.y}, d23 = {d.z, d.w};
+      a01 = __builtin_elementwise_fma(w01, d01, a01);
+      a23 = __builtin_elementwise_fma(w23, d23, a23);
     }
-    part[q][k] = (a0 + a1) + (a2 + a3);
+    part[q][k] = (a01.x + a01.y) + (a23.x + a23.y);
     __syncthreads();
+    // (two barriers per step are enough: sdg is rewritten only after the second one, which every reader of sdg has
+    // passed; part is rewritten only after the next step's first one, which its readers -- the unit threads, right
+    // below -- reach after reading it)
     if (unit) {
       dh_rec = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
       gi = n_gi; gf = n_gf; gg = n_gg; gout = n_gout; dov = n_dov; c = c_n1; c_n1 = c_n2;
     }
-    __syncthreads();
   }
 }
 
