@@ -34,3 +34,14 @@ xs = torch.randn(1, 27060, 256, device=dev); dys = torch.randn_like(xs)
 g2, b2 = torch.ones(256, device=dev), torch.zeros(256, device=dev)
 dg2, db2 = torch.zeros(256, device=dev), torch.zeros(256, device=dev)
 print(f"LN bwd    [27060, 256]                      : {t(lambda: ops.layernorm_bwd(xs, dys, g2, b2, dg2, db2)):7.1f} us  ({xs.numel() * 12 / 1e6:.1f} MB)")
+# GroupNorm + ReLU at the AudioEncoder shape (96 items x 441 frames x 320 channels; bf16 output / gradient as in the step)
+Cg = 320
+xg = torch.randn(96, 441, Cg, device=dev)
+gg, bg = torch.ones(Cg, device=dev), torch.zeros(Cg, device=dev)
+st = torch.empty(96, Cg // 16, 2, device=dev)
+yg = torch.empty_like(xg, dtype=torch.bfloat16)
+dyg = torch.randn_like(xg).to(torch.bfloat16)
+dgg, dbg = torch.zeros(Cg, device=dev), torch.zeros(Cg, device=dev)
+mode = "two kernels" if os.environ.get("STYLER_GN_FUSED") == "0" else "single pass"
+print(f"GN fwd    [96, 441, {Cg}] bf16 out ({mode}): {t(lambda: ops.groupnorm_relu(xg, gg, bg, out=yg, stats=st)):7.1f} us  (x = {xg.numel() * 4 / 1e6:.1f} MB)")
+print(f"GN bwd    same, bf16 dy / dx ({mode})      : {t(lambda: ops.groupnorm_relu_bwd(xg, dyg, gg, bg, st, dgg, dbg, dx_bf16=True)):7.1f} us")
