@@ -169,8 +169,8 @@ int styler_attention_bwd_bf16(const float* qkv, const float* out, const float* d
  * (SubLayers.py:58-59,86-87 + Layers.py:29,32).  res, len may be NULL.  C must be 256.
  * If dot_w != NULL the kernel instead writes the scalar out[b,t] = <y, dot_w> + dot_b[0]
  * (masked) -- the StylePredictor's LayerNorm -> dropout -> Linear(256,1) -> masked_fill
- * tail, modules.py:449-465 -- and y may be NULL; drop_p > 0 applies the train-mode dropout of
- * that tail with the counter-based stream of styler_dropout (seed drop_seed).
+ * tail, modules.py:449-465 -- and y may be NULL; drop_p > 0 applies the train-mode dropout behind the
+ * LayerNorm (to y, and to what the tail sees) with the counter-based stream of styler_dropout (seed drop_seed).
  * in_drop_p > 0 (train mode) applies dropout to x BEFORE the residual add -- the nn.Dropout of
  * SubLayers.py:58,86 -- with the stream styler_dropout(x [B*L, 256], seed in_drop_seed) would draw;
  * sum_out (optional) receives the pre-norm sum dropout(x) + res that styler_layernorm_bwd consumes
@@ -478,13 +478,17 @@ int styler_attention_bwd(const float* qkv, const float* out, const float* dout, 
  * went through dropout; dx itself is the gradient of the residual).
  * replicas > 1: dgamma / dbeta / ddot_w point to ZEROED scratch [replicas][256] instead of the gradients (block i
  * adds into replica i % replicas; the caller folds them, e.g. with styler_wgrad_reduce_multi descriptors
- * n = 256, cin = kw = 1, splits = replicas): hundreds of blocks adding into one 256-float vector serialise in L2. */
+ * n = 256, cin = kw = 1, splits = replicas): hundreds of blocks adding into one 256-float vector serialise in L2.
+ * drop_p > 0 without dot_w: dy is the gradient w.r.t. dropout(LayerNorm(x)) (styler_add_layernorm's drop_p written to y).
+ * flags & STYLER_LNB_RELU_INPUT: x is the output of a ReLU (StylePredictor: Conv1d -> ReLU -> LayerNorm,
+ * modules.py:430-447) and dx is returned as the gradient w.r.t. the ReLU's INPUT (dx where x > 0, else 0). */
+#define STYLER_LNB_RELU_INPUT 1
 int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy,
                          const float* gamma, const float* beta, float* dx, int64_t lddx,
                          float* dgamma, float* dbeta, const float* dot_w, const float* dout,
                          float* ddot_w, float* ddot_b, int B, int L, int C, const int64_t* len,
                          float drop_p, uint64_t drop_seed, float in_drop_p, uint64_t in_drop_seed,
-                         float* dx_drop, int64_t lddxd, int replicas, void* stream);
+                         float* dx_drop, int64_t lddxd, int replicas, int flags, void* stream);
 
 /* stats = the forward's [B][C/16][2] (mean, rstd); workspace 2*B*C/16 doubles (scratch). */
 int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void* dy, int64_t lddy,

@@ -233,6 +233,50 @@ class LayerNormDotFn(Function):
         return dx, None, None, None, None, None, None
 
 
+class PredictorStageFn(Function):
+    """One stage of the StylePredictor (modules.py:430-447) as ONE tape node: Conv1d(k) -> ReLU -> LayerNorm -> dropout,
+    and with `lin` the second stage with its tail -> Linear(256, 1) -> pad mask.  Forward: the conv GEMM (ReLU in its
+    epilogue) and one LayerNorm kernel that also drops.  Backward: ONE LayerNorm-backward kernel regenerates the dropout
+    mask, and -- its input being the ReLU output -- hands back the gradient w.r.t. the conv's pre-activation output; as
+    separate nodes this was a dropout kernel forward and backward and an act_bwd pass per stage."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cache, key, kw, ln, lin, lens, drop_p):
+        drop_p = 0.0 if rt.disable_dropout else drop_p
+        seed = next_dropout_seed() if drop_p > 0 else 0
+        w, prec = gemm_weight(cache, key, weight, x.shape[-1])
+        h = ops.conv_gemm(x, w, bias, kw=kw, n=weight.shape[0], act=RELU, prec=prec)
+        if lin is None:
+            out = ops.add_layernorm(h, ln.weight, ln.bias, drop_p=drop_p, drop_seed=seed)
+        else:
+            out = ops.add_layernorm(h, ln.weight, ln.bias, lens=lens, dot_w=lin.weight, dot_b=lin.bias, drop_p=drop_p,
+                                    drop_seed=seed)
+        ctx.save_for_backward(x, h, lens)
+        ctx.weight, ctx.bias, ctx.cache, ctx.key, ctx.kw = weight, bias, cache, key, kw
+        ctx.ln, ctx.lin, ctx.drop = ln, lin, (drop_p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, h, lens = ctx.saved_tensors
+        weight, bias, kw, ln, lin = ctx.weight, ctx.bias, ctx.kw, ctx.ln, ctx.lin
+        if lin is None:
+            dz = ops.layernorm_bwd(h, dout, ln.weight, ln.bias, G(ln.weight), G(ln.bias), drop_p=ctx.drop[0],
+                                   drop_seed=ctx.drop[1], relu_input=True)
+        else:
+            dz = ops.layernorm_bwd(h, None, ln.weight, ln.bias, G(ln.weight), G(ln.bias), lens=lens, dot_w=lin.weight,
+                                   dout=dout, ddot_w=G(lin.weight), ddot_b=G(lin.bias), drop_p=ctx.drop[0],
+                                   drop_seed=ctx.drop[1], relu_input=True)
+        n, cin = weight.shape[0], x.shape[-1]
+        ops.wgrad(dz, x, G(weight), n, cin, kw=kw, db=G(bias) if bias is not None else None)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            bf16 = rt.prec == ops.PREC_BF16 and n % 8 == 0
+            dx = ops.conv_gemm(dz, gemm_weight_bwd(ctx.cache, ctx.key, weight, bf16), None, kw=kw, n=cin,
+                               prec=ops.PREC_BF16 if bf16 else ops.PREC_F32)
+        return dx, None, None, None, None, None, None, None, None, None
+
+
 class ConvNormFn(Function):
     """norm_act(conv_same(x, W) + b) as ONE tape node: Conv1d -> GroupNorm + ReLU (AudioEncoder, modules.py:103-113) or
     Conv1d -> train-mode BatchNorm1d (+ tanh) + dropout (PostNet, Layers.py:91-128).

@@ -49,17 +49,17 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
   const float4 bt = *reinterpret_cast<const float4*>(beta + lane * 4);
   float4 o = make_float4(dx * rstd * g.x + bt.x, dy * rstd * g.y + bt.y, dz * rstd * g.z + bt.z,
                          dw * rstd * g.w + bt.w);
+  if (drop_p > 0.f) {                                    // dropout behind the LayerNorm (train mode): what y and the
+    const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);     // Linear(256,1) tail see (modules.py:436-447)
+    const float sc = 1.f / (1.f - drop_p);
+    const uint64_t e = (uint64_t)row * 256 + lane * 4;
+    o.x = dropout_hash32(drop_seed, e) >= thr ? o.x * sc : 0.f;
+    o.y = dropout_hash32(drop_seed, e + 1) >= thr ? o.y * sc : 0.f;
+    o.z = dropout_hash32(drop_seed, e + 2) >= thr ? o.z * sc : 0.f;
+    o.w = dropout_hash32(drop_seed, e + 3) >= thr ? o.w * sc : 0.f;
+  }
   if (y) *reinterpret_cast<float4*>(y + row * ldy + lane * 4) = o;
   if (dot_out) {
-    if (drop_p > 0.f) {                                  // dropout between LayerNorm and Linear(256,1) (train mode)
-      const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);
-      const float sc = 1.f / (1.f - drop_p);
-      const uint64_t e = (uint64_t)row * 256 + lane * 4;
-      o.x = dropout_hash32(drop_seed, e) >= thr ? o.x * sc : 0.f;
-      o.y = dropout_hash32(drop_seed, e + 1) >= thr ? o.y * sc : 0.f;
-      o.z = dropout_hash32(drop_seed, e + 2) >= thr ? o.z * sc : 0.f;
-      o.w = dropout_hash32(drop_seed, e + 3) >= thr ? o.w * sc : 0.f;
-    }
     const float4 w = *reinterpret_cast<const float4*>(dot_w + lane * 4);
     const float d = wave_sum(o.x * w.x + o.y * w.y + o.z * w.z + o.w * w.w);
     if (lane == 0) dot_out[row] = d + dot_b[0];

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ dot_w,
     const float* __restrict__ dout, float* __restrict__ ddot_w, float* __restrict__ ddot_b, int64_t rows, int L,
     const int64_t* __restrict__ len, float drop_p, uint64_t drop_seed_host, const uint64_t* __restrict__ epoch,
-    float in_drop_p, uint64_t in_drop_seed_host, float* __restrict__ dx_drop, int64_t lddxd, int replicas) {
+    float in_drop_p, uint64_t in_drop_seed_host, float* __restrict__ dx_drop, int64_t lddxd, int replicas, int flags) {
   const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   const int lane = threadIdx.x & 63;
   const int64_t w0 = (int64_t)blockIdx.x * LNB_WAVES + (threadIdx.x >> 6);
@@ -69,18 +69,20 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
       }
       if (!live[k]) { v[k] = make_float4(0.f, 0.f, 0.f, 0.f); go[k] = 0.f; }
       kx[k][0] = kx[k][1] = kx[k][2] = kx[k][3] = 1.f;
-      if (dot_w) {
-        if (drop_p > 0.f) {                              // dropout keep * 1/(1-p) between LN and the dot
-          const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);
-          const float sc = 1.f / (1.f - drop_p);
-          const uint64_t e = (uint64_t)row[k] * 256 + lane * 4;
+      if (drop_p > 0.f) {                                // dropout keep * 1/(1-p) behind the LayerNorm (forward's drop_p)
+        const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);
+        const float sc = 1.f / (1.f - drop_p);
+        const uint64_t e = (uint64_t)row[k] * 256 + lane * 4;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) kx[k][q] = dropout_hash32(drop_seed, e + q) >= thr ? sc : 0.f;
-        }
+        for (int q = 0; q < 4; ++q) kx[k][q] = dropout_hash32(drop_seed, e + q) >= thr ? sc : 0.f;
+      }
+      if (dot_w) {
         d[k] = make_float4(go[k] * dw4.x * kx[k][0], go[k] * dw4.y * kx[k][1], go[k] * dw4.z * kx[k][2],
                            go[k] * dw4.w * kx[k][3]);
       } else if (!live[k]) {
         d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if (drop_p > 0.f) {                         // dy is the gradient w.r.t. the DROPPED output
+        d[k].x *= kx[k][0]; d[k].y *= kx[k][1]; d[k].z *= kx[k][2]; d[k].w *= kx[k][3];
       }
     }
     float mean[R], rstd[R];
@@ -122,8 +124,12 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     for (int k = 0; k < R; ++k) {
       if (!live[k]) continue;
       m1[k] *= (1.f / 256.f); m2[k] *= (1.f / 256.f);
-      const float4 gx = make_float4(rstd[k] * (ex[k].x - m1[k] - h[k].x * m2[k]), rstd[k] * (ex[k].y - m1[k] - h[k].y * m2[k]),
-                                    rstd[k] * (ex[k].z - m1[k] - h[k].z * m2[k]), rstd[k] * (ex[k].w - m1[k] - h[k].w * m2[k]));
+      float4 gx = make_float4(rstd[k] * (ex[k].x - m1[k] - h[k].x * m2[k]), rstd[k] * (ex[k].y - m1[k] - h[k].y * m2[k]),
+                              rstd[k] * (ex[k].z - m1[k] - h[k].z * m2[k]), rstd[k] * (ex[k].w - m1[k] - h[k].w * m2[k]));
+      if (flags & STYLER_LNB_RELU_INPUT) {               // x = relu(z): dx is handed on as dz (no separate act_bwd pass)
+        gx.x = v[k].x > 0.f ? gx.x : 0.f; gx.y = v[k].y > 0.f ? gx.y : 0.f;
+        gx.z = v[k].z > 0.f ? gx.z : 0.f; gx.w = v[k].w > 0.f ? gx.w : 0.f;
+      }
       if (dx) *reinterpret_cast<float4*>(dx + row[k] * lddx + lane * 4) = gx;
       if (dx_drop) {                                     // gradient of the dropout(x) that fed the sum (same stream)
         const uint64_t sd = mix_drop_epoch(in_drop_seed_host, epoch);
@@ -170,7 +176,8 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
                                     const float* beta, float* dx, int64_t lddx, float* dgamma, float* dbeta,
                                     const float* dot_w, const float* dout, float* ddot_w, float* ddot_b, int B, int L,
                                     int C, const int64_t* len, float drop_p, uint64_t drop_seed, float in_drop_p,
-                                    uint64_t in_drop_seed, float* dx_drop, int64_t lddxd, int replicas, void* stream) {
+                                    uint64_t in_drop_seed, float* dx_drop, int64_t lddxd, int replicas, int flags,
+                                    void* stream) {
   if (!x || !gamma || !dgamma || !dbeta || B <= 0 || L <= 0 || C != 256 || replicas < 1) return STYLER_EINVAL;
   if ((int64_t)B * L >= ((int64_t)1 << 31)) return STYLER_EINVAL;
   if (!dot_w && !dy) return STYLER_EINVAL;
@@ -184,11 +191,11 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
   if (rows_per_iter == 4)
     hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3((unsigned)blocks), dim3(64 * LNB_WAVES), 0, (hipStream_t)stream, x, ldx, dy,
                        lddy, gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b, rows, L, len, drop_p, drop_seed,
-                       g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd, replicas);
+                       g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd, replicas, flags);
   else
     hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3((unsigned)blocks), dim3(64 * LNB_WAVES), 0, (hipStream_t)stream, x, ldx, dy,
                        lddy, gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b, rows, L, len, drop_p, drop_seed,
-                       g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd, replicas);
+                       g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd, replicas, flags);
   return launch_status();
 }
 

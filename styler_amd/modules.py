@@ -279,6 +279,14 @@ class StylePredictor(_HipModule):
         p = hp.style_predictor_dropout
         grad = (self.training and torch.is_grad_enabled())
         drop = self.training and p > 0 and not rt.disable_dropout
+        if grad and rt.fused_predictor:
+            # each stage one tape node: conv (+ ReLU) GEMM and one LayerNorm kernel forward; one LayerNorm-backward kernel
+            # (dropout mask + ReLU mask inside), weight gradient and dX GEMM backward
+            c1, c2 = c.conv1d_1.conv, c.conv1d_2.conv
+            h = AG.PredictorStageFn.apply(encoder_output, c1.weight, c1.bias, self._derived, "c1", k, c.layer_norm_1,
+                                          None, None, p if drop else 0.0)
+            return AG.PredictorStageFn.apply(h, c2.weight, c2.bias, self._derived, "c2", k, c.layer_norm_2,
+                                             self.linear_layer, lens, p if drop else 0.0)
         h = self._gemm("c1", encoder_output, c.conv1d_1.conv, kw=k, act=ops.ACT_RELU)
         h = self._ln(h, None, c.layer_norm_1, None)
         h = AG.dropout(h, p, self.training)

@@ -815,8 +815,9 @@ def attention_bwd(qkv, out, dout, lse, lens, prec=None, plan=None):
 
 
 def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, dot_w=None, dout=None, ddot_w=None,
-                  ddot_b=None, drop_p=0.0, drop_seed=0, in_drop_p=0.0, in_drop_seed=0):
-    """Returns dx, or (dx, dx_drop) when in_drop_p > 0 (dx_drop = dx through the forward's input-dropout mask)."""
+                  ddot_b=None, drop_p=0.0, drop_seed=0, in_drop_p=0.0, in_drop_seed=0, relu_input=False):
+    """Returns dx, or (dx, dx_drop) when in_drop_p > 0 (dx_drop = dx through the forward's input-dropout mask).
+    relu_input: x is a ReLU output and dx comes back as the gradient w.r.t. the ReLU's input."""
     B, L, C = x.shape
     dx = torch.empty(B, L, C, device=x.device, dtype=torch.float32) if need_dx else None
     dxd = torch.empty(B, L, C, device=x.device, dtype=torch.float32) if in_drop_p > 0 else None
@@ -842,7 +843,8 @@ def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, do
     _chk(lib.styler_layernorm_bwd(x.data_ptr(), _ld(x), _ptr(dy), _ld(dy) if dy is not None else 0, gamma.data_ptr(),
                                   _ptr(beta), _ptr(dx), C, pg.data_ptr(), pb.data_ptr(), _ptr(dot_w),
                                   _ptr(dout), _ptr(pw), _ptr(ddot_b), B, L, C, _ptr(lens), float(drop_p),
-                                  int(drop_seed), float(in_drop_p), int(in_drop_seed), _ptr(dxd), C, rep, _stream()),
+                                  int(drop_seed), float(in_drop_p), int(in_drop_seed), _ptr(dxd), C, rep, 1 if relu_input else 0,
+                                  _stream()),
          "styler_layernorm_bwd")
     return (dx, dxd) if dxd is not None else dx
 

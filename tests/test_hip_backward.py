@@ -763,3 +763,57 @@ def test_fused_batchnorm_tanh_dropout(dev):
     for a, c, what in zip(res[True], res[False], ("y", "dx", "dgamma", "dbeta", "running_var")):
         check(a, c, 2e-5, what)
     assert 0.4 < float((res[True][0] != 0).float().mean()) < 0.6
+
+
+def test_predictor_stage_kernels_equal_their_parts(dev):
+    """The fused StylePredictor stage: LayerNorm with dropout on its output == dropout(LayerNorm), and ONE LayerNorm-backward
+    kernel (dropout mask regenerated, ReLU mask of its input applied) == dropout backward -> LayerNorm backward -> act_bwd."""
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(21)
+    B, L, p, seed = 5, 173, 0.5, 77
+    h = torch.relu(torch.randn(B, L, 256, generator=g)).to(dev)             # a ReLU output, as the conv epilogue leaves it
+    dy = torch.randn(B, L, 256, generator=g).to(dev)
+    ga, be = (1 + 0.1 * torch.randn(256, generator=g)).to(dev), (0.1 * torch.randn(256, generator=g)).to(dev)
+    y1 = ops.add_layernorm(h, ga, be, drop_p=p, drop_seed=seed)
+    y2 = ops.dropout(ops.add_layernorm(h, ga, be), p, seed)
+    assert torch.equal(y1, y2)
+    assert 0.4 < float((y1 == 0).float().mean()) < 0.6
+    dg1, db1, dg2, db2 = (torch.zeros(256, device=dev) for _ in range(4))
+    dz1 = ops.layernorm_bwd(h, dy, ga, be, dg1, db1, drop_p=p, drop_seed=seed, relu_input=True)
+    keep = (y2 != 0) | (ops.add_layernorm(h, ga, be) == 0)                  # the mask of the same stream
+    d_ln = ops.layernorm_bwd(h, dy * keep / (1 - p), ga, be, dg2, db2)
+    dz2 = ops.act_bwd(d_ln, h, ops.ACT_RELU)
+    assert torch.equal(dz1, dz2)
+    assert torch.allclose(dg1, dg2, rtol=1e-5, atol=1e-5) and torch.allclose(db1, db2, rtol=1e-5, atol=1e-5)
+
+
+def test_fused_predictor_equals_separate_nodes(dev, ref_state_dict):
+    """StylePredictor under autograd: the two-node-per-predictor tape (rt.fused_predictor) gives the outputs and gradients
+    of the node-per-op tape."""
+    from styler_amd import rt
+    from styler_amd.modules import StylePredictor
+    g = torch.Generator().manual_seed(22)
+    x0 = torch.randn(4, 61, 256, generator=g)
+    lens = torch.tensor([61, 40, 17, 55])
+    go = torch.randn(4, 61, generator=g).to(dev)
+    sd = {k[len("style_modeling.pitch_predictor."):]: v for k, v in ref_state_dict.items()
+          if k.startswith("style_modeling.pitch_predictor.")}
+    res = []
+    keep = rt.fused_predictor, rt.disable_dropout
+    try:
+        rt.disable_dropout = True
+        for fused in (True, False):
+            rt.fused_predictor = fused
+            m = StylePredictor()
+            m.load_state_dict(sd)
+            m = m.to(dev).train()
+            x = x0.to(dev).requires_grad_(True)
+            out = m(x, lens.to(dev))
+            out.backward(go)
+            res.append((out.detach(), x.grad, {k: v.grad.clone() for k, v in m.named_parameters()}))
+    finally:
+        rt.fused_predictor, rt.disable_dropout = keep
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-6)
+    for k in res[0][2]:
+        assert torch.allclose(res[0][2][k], res[1][2][k], rtol=1e-4, atol=1e-5), k
