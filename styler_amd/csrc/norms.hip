@@ -157,18 +157,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
-// Single-pass GroupNorm + ReLU for L <= 64 * GNF_IT rows per item: block = (64 channels = 4 groups, item), 1024 threads
+// Single-pass GroupNorm + ReLU for items of up to 64 * IT rows (IT = 8 or 16 float4 rows per thread): block = (64 channels = 4 groups, item), 1024 threads
 // = 64 row-lanes x 16 channel-quads.  Every thread loads ALL its rows up front (GNF_IT float4 in flight per thread, 16
 // waves per CU) and keeps them in registers across the statistics -- mean, then the centred second moment, each one
 // wave-shuffle step + one LDS exchange between the block's 16 waves -- so x is read from HBM once (the two-kernel form
 // reads it twice: 9.3 + 14.2 us per layer at the C2 shape).  Statistics in fp32 from centred values (the two-kernel form
 // needs fp64 sums because it forms E[x^2] - mean^2).
-#define GNF_IT 8
+#define GNF_IT 8                                    // rows per thread of the short variant; the long one holds 16
 __device__ __forceinline__ float gn_group_sum_wave(float s) {    // over the lanes of one group: bits 0,1 (channel quad
   s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);          // within the group) and bits 4,5 (row-lane) of the lane id
   s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
   return s;
 }
+template <int IT>
 __global__ __launch_bounds__(1024) void gn_fused_kernel(const float* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         void* __restrict__ y, int64_t ldy, float* __restrict__ stats, int L,
@@ -178,16 +179,16 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const float* __restrict_
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4, wave = threadIdx.x >> 6, grp = cq >> 2;
   const bool writer = (threadIdx.x & 0x33) == 0;                  // one lane per (wave, group)
   const float* xp = x + (int64_t)b * L * ldx + c0 + cq * 4;
-  float4 v[GNF_IT];
+  float4 v[IT];
 #pragma unroll
-  for (int i = 0; i < GNF_IT; ++i) {
+  for (int i = 0; i < IT; ++i) {
     const int t = rl + 64 * i < L ? rl + 64 * i : L - 1;          // clamped, masked below: no load sits behind a branch
     v[i] = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
   }
   const float inv_n = 1.f / (16.f * (float)L);
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < GNF_IT; ++i)
+  for (int i = 0; i < IT; ++i)
     if (rl + 64 * i < L) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   s = gn_group_sum_wave(s);
   if (writer) red[0][wave][grp] = s;
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const float* __restrict_
   const float mean = tot * inv_n;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < GNF_IT; ++i) {
+  for (int i = 0; i < IT; ++i) {
     v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
     if (rl + 64 * i < L) q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
   }
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const float* __restrict_
   float* yp = reinterpret_cast<float*>(y) + (int64_t)b * L * ldy + c0 + cq * 4;
   uint16_t* yp16 = reinterpret_cast<uint16_t*>(y) + (int64_t)b * L * ldy + c0 + cq * 4;
 #pragma unroll
-  for (int i = 0; i < GNF_IT; ++i) {
+  for (int i = 0; i < IT; ++i) {
     const int t = rl + 64 * i;
     if (t >= L) break;
     float4 o;
@@ -229,9 +230,14 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const float* __restrict_
     else *reinterpret_cast<float4*>(yp + (int64_t)t * ldy) = o;
   }
 }
-int gn_fused_ok(int L) {
+// 0: two-kernel form; otherwise the rows per thread of the single-pass variant that holds an item of L rows.  The backward
+// keeps x AND dy in registers: it has no 16-row variant (85 registers spilled at the 128 a 1024-thread block may use).
+int gn_fused_iters(int L, bool bwd) {
   static const int on = [] { const char* e = getenv("STYLER_GN_FUSED"); return e ? atoi(e) : 1; }();
-  return on && L <= 64 * GNF_IT;
+  if (!on) return 0;
+  if (L <= 64 * GNF_IT) return GNF_IT;
+  if (L <= 128 * GNF_IT && !bwd) return 2 * GNF_IT;
+  return 0;
 }
 
 extern "C" int styler_groupnorm_relu(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y,
@@ -240,9 +246,13 @@ extern "C" int styler_groupnorm_relu(const float* x, int64_t ldx, const float* g
   if (!x || !y || !gamma || !beta || !workspace || B <= 0 || L <= 0 || C <= 0 || (C & 63)) return STYLER_EINVAL;
   if ((ldx & 3) || (ldy & 3)) return STYLER_EALIGN;
   hipStream_t st = (hipStream_t)stream;
-  if (gn_fused_ok(L)) {
-    hipLaunchKernelGGL(gn_fused_kernel, dim3(C / 64, B), dim3(1024), 0, st, x, ldx, gamma, beta, y, ldy, stats, L, C,
-                       (io_flags & STYLER_IO_Y_BF16) ? 1 : 0);
+  if (const int it = gn_fused_iters(L, false)) {
+    const int y16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
+    if (it == GNF_IT)
+      hipLaunchKernelGGL(gn_fused_kernel<GNF_IT>, dim3(C / 64, B), dim3(1024), 0, st, x, ldx, gamma, beta, y, ldy, stats, L, C, y16);
+    else
+      hipLaunchKernelGGL(gn_fused_kernel<2 * GNF_IT>, dim3(C / 64, B), dim3(1024), 0, st, x, ldx, gamma, beta, y, ldy, stats, L, C,
+                         y16);
     return launch_status();
   }
   if (!ws_zeroed) {

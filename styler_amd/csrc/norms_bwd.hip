@@ -329,8 +329,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 // Single-pass backward for L <= 64 * GNB_IT rows per item (same block shape as gn_fused_kernel, norms.hip): x and dy are
 // loaded once and stay in registers between the group sums and dx -- 3 tensor passes over HBM instead of 5.
 #define GNB_IT 8
-int gn_fused_ok(int L);                              // norms.hip
-template <bool DY16>
+int gn_fused_iters(int L, bool bwd);                // norms.hip
+template <bool DY16, int IT>
 __global__ __launch_bounds__(1024) void gn_bwd_fused_kernel(const float* __restrict__ x, int64_t ldx,
                                                             const void* __restrict__ dy, int64_t lddy,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -347,22 +347,22 @@ __global__ __launch_bounds__(1024) void gn_bwd_fused_kernel(const float* __restr
   const float mean = stats[gi], rstd = stats[gi + 1];
   float4 ga = *reinterpret_cast<const float4*>(gamma + c0 + cq * 4);
   float4 be = *reinterpret_cast<const float4*>(beta + c0 + cq * 4);
-  float4 v[GNB_IT];
-  typename Raw4<DY16>::T g4[GNB_IT];
+  float4 v[IT];
+  typename Raw4<DY16>::T g4[IT];
 #pragma unroll
-  for (int i = 0; i < GNB_IT; ++i) {
+  for (int i = 0; i < IT; ++i) {
     const int t = rl + 64 * i < L ? rl + 64 * i : L - 1;
     v[i] = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
     g4[i] = raw4_load<DY16>(dy, gbase + (int64_t)t * lddy);
   }
   pin_loaded(ga); pin_loaded(be);                    // (the compiler sinks these two loads behind the waits otherwise)
 #pragma unroll
-  for (int i = 0; i < GNB_IT; ++i) { pin_loaded(v[i]); pin_loaded(g4[i]); }
+  for (int i = 0; i < IT; ++i) { pin_loaded(v[i]); pin_loaded(g4[i]); }
   float s1 = 0.f, s2 = 0.f;
   float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
   // v becomes xh, g4 stays raw: dxh = relu-masked dy * gamma is formed here and again (two multiplies) for dx
 #pragma unroll
-  for (int i = 0; i < GNB_IT; ++i) {
+  for (int i = 0; i < IT; ++i) {
     v[i].x = (v[i].x - mean) * rstd; v[i].y = (v[i].y - mean) * rstd; v[i].z = (v[i].z - mean) * rstd; v[i].w = (v[i].w - mean) * rstd;
     float4 g = raw4_f32(g4[i]);
     if (rl + 64 * i >= L) g = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_fused_kernel(const float* __restr
   float* dxp = reinterpret_cast<float*>(dx) + (int64_t)b * L * lddx + c0 + cq * 4;
   uint16_t* dxp16 = reinterpret_cast<uint16_t*>(dx) + (int64_t)b * L * lddx + c0 + cq * 4;
 #pragma unroll
-  for (int i = 0; i < GNB_IT; ++i) {
+  for (int i = 0; i < IT; ++i) {
     const int t = rl + 64 * i;
     if (t >= L) break;
     float4 g = raw4_f32(g4[i]);
@@ -427,13 +427,11 @@ extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void
   hipStream_t st = (hipStream_t)stream;
   const int dy16 = (io_flags & STYLER_IO_X_BF16) ? 1 : 0;
   const int dx16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
-  if (gn_fused_ok(L)) {
-    if (dy16)
-      hipLaunchKernelGGL(gn_bwd_fused_kernel<true>, dim3(C / 64, B), dim3(1024), 0, st, x, ldx, dy, lddy, gamma, beta, stats, dx,
-                         lddx, dgamma, dbeta, L, C, dx16);
-    else
-      hipLaunchKernelGGL(gn_bwd_fused_kernel<false>, dim3(C / 64, B), dim3(1024), 0, st, x, ldx, dy, lddy, gamma, beta, stats, dx,
-                         lddx, dgamma, dbeta, L, C, dx16);
+  if (gn_fused_iters(L, true)) {
+#define GNB_LAUNCH(D_, I_) hipLaunchKernelGGL((gn_bwd_fused_kernel<D_, I_>), dim3(C / 64, B), dim3(1024), 0, st, x, ldx, dy, lddy, \
+                                              gamma, beta, stats, dx, lddx, dgamma, dbeta, L, C, dx16)
+    if (dy16) GNB_LAUNCH(true, GNB_IT); else GNB_LAUNCH(false, GNB_IT);
+#undef GNB_LAUNCH
     return launch_status();
   }
   if (!ws_zeroed) {

@@ -130,7 +130,7 @@ def test_add_layernorm(dev):
 
 @pytest.mark.parametrize("C,L", [(256, 77), (320, 77), (320, 441), (256, 512), (320, 513), (256, 1100)])
 def test_groupnorm_relu(dev, C, L):
-    """L <= 512: the single-pass kernel (rows in registers); longer items: statistics kernel + apply kernel."""
+    """L <= 512 / <= 1024: the single-pass kernel (8 / 16 rows per thread in registers); longer items: statistics kernel + apply kernel."""
     from styler_amd import ops
     g = torch.Generator().manual_seed(C + L)
     x = torch.randn(3, L, C, generator=g) * 2 + 0.5
