@@ -160,9 +160,11 @@ int styler_attention_fwd(const float* qkv, float* out, float* lse, int B, int L,
  * forward may leave zeros in `out` / `lse` there, and the backward treats their dout as zero. */
 int styler_attention_fwd_bf16(const float* qkv, float* out, float* lse, int B, int L,
                               const int64_t* len, const int32_t* cu, void* stream);
+/* io_flags & STYLER_IO_Y_BF16: dqkv is written as bf16 [B,L,768] (what its consumers -- the QKV dX GEMM and the three
+ * weight gradients -- round it to anyway). */
 int styler_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse,
-                              float* dqkv, float* delta_ws, int B, int L, const int64_t* len,
-                              const int32_t* cu, void* stream);
+                              void* dqkv, float* delta_ws, int B, int L, const int64_t* len,
+                              const int32_t* cu, int io_flags, void* stream);
 
 /* ---- normalisation / epilogues ------------------------------------------------------
  * y = LayerNorm_256(x + res) * gamma + beta, then rows t >= len[b] set to 0

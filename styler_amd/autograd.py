@@ -202,7 +202,7 @@ class AttnSublayerFn(Function):
         ops.wgrad(d_o, att, G(mha.fc.weight), 256, 256, db=G(mha.fc.bias), plan=plan)
         d_att = ops.conv_gemm(d_o, gemm_weight_bwd(mha._derived, "fc", mha.fc.weight, bf16), None, n=256, prec=prec,
                               plan=plan)
-        dqkv = ops.attention_bwd(qkv, att, d_att, lse, lens, plan=plan)
+        dqkv = ops.attention_bwd(qkv, att, d_att, lse, lens, plan=plan, out_bf16=bf16 and rt.bf16_acts and rt.bf16_dqkv)
         srcs = [mha.w_qs.weight, mha.w_ks.weight, mha.w_vs.weight]
         for i, lin in enumerate((mha.w_qs, mha.w_ks, mha.w_vs)):
             ops.wgrad(dqkv[..., i * 256:(i + 1) * 256], x, G(lin.weight), 256, 256, db=G(lin.bias), plan=plan)

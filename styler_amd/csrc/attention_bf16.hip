@@ -98,6 +98,30 @@ __device__ __forceinline__ bf16x8 fragT(const uint32_t* tile, int dt, int tq, in
   return *reinterpret_cast<bf16x8*>(&v);
 }
 
+// the same 64 features as bf16 (dqkv stored as bf16: its consumers -- the QKV dX GEMM and the weight gradients -- round
+// it to bf16 while staging, so nothing changes but the bytes)
+__device__ __forceinline__ void store_accT16(uint16_t* op, const f32x16& a0, const f32x16& a1, int lh, float scale) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int d = 8 * g + 4 * lh;
+    *reinterpret_cast<uint2*>(op + d) = make_uint2(cvtpk(a0[g * 4 + 0] * scale, a0[g * 4 + 1] * scale),
+                                                   cvtpk(a0[g * 4 + 2] * scale, a0[g * 4 + 3] * scale));
+    *reinterpret_cast<uint2*>(op + 32 + d) = make_uint2(cvtpk(a1[g * 4 + 0] * scale, a1[g * 4 + 1] * scale),
+                                                        cvtpk(a1[g * 4 + 2] * scale, a1[g * 4 + 3] * scale));
+  }
+}
+// 32 zeros at element offset `off` of a dqkv row (fp32 or bf16 storage)
+__device__ __forceinline__ void zero32(void* base, int64_t off, int out16) {
+  if (out16) {
+    uint16_t* op = reinterpret_cast<uint16_t*>(base) + off;
+#pragma unroll
+    for (int d = 0; d < 32; d += 8) *reinterpret_cast<uint4*>(op + d) = make_uint4(0u, 0u, 0u, 0u);
+  } else {
+    float* op = reinterpret_cast<float*>(base) + off;
+#pragma unroll
+    for (int d = 0; d < 32; d += 4) *reinterpret_cast<float4*>(op + d) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
 __device__ __forceinline__ void store_accT(float* op, const f32x16& a0, const f32x16& a1, int lh, float scale) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -244,9 +268,9 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DQ_WAVES) void attention_bwd_dq_bf
                                                                     const float* __restrict__ o,
                                                                     const float* __restrict__ dout,
                                                                     const float* __restrict__ lse,
-                                                                    float* __restrict__ dqkv, float* __restrict__ delta,
+                                                                    void* __restrict__ dqkv, float* __restrict__ delta,
                                                                     int B, int L, const int64_t* __restrict__ len,
-                                                                    const int* __restrict__ cu) {
+                                                                    const int* __restrict__ cu, int out16) {
   __shared__ __attribute__((aligned(16))) uint32_t sK[64 * ALD];
   __shared__ __attribute__((aligned(16))) uint32_t sV[64 * ALD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -265,9 +289,7 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DQ_WAVES) void attention_bwd_dq_bf
   // blocks made only of such rows write dQ = 0, delta = 0 and leave
   if (bx * 128 >= klen) {
     if (q < Lr) {
-      float* op = dqkv + (rowbase + q) * 768 + head * AD + lh * 32;
-#pragma unroll
-      for (int d = 0; d < 32; d += 4) *reinterpret_cast<float4*>(op + d) = make_float4(0.f, 0.f, 0.f, 0.f);
+      zero32(dqkv, (rowbase + q) * 768 + head * AD + lh * 32, out16);
       if (lh == 0) delta[((int64_t)b * 4 + head) * L + q] = 0.f;
     }
     return;
@@ -335,7 +357,11 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DQ_WAVES) void attention_bwd_dq_bf
       }
     }
   }
-  if (q < Lr) store_accT(dqkv + (rowbase + q) * 768 + head * AD, dq0, dq1, lh, 0.125f);
+  if (q < Lr) {
+    const int64_t off = (rowbase + q) * 768 + head * AD;
+    if (out16) store_accT16(reinterpret_cast<uint16_t*>(dqkv) + off, dq0, dq1, lh, 0.125f);
+    else store_accT(reinterpret_cast<float*>(dqkv) + off, dq0, dq1, lh, 0.125f);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------- dK, dV
@@ -343,9 +369,9 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DKV_WAVES) void attention_bwd_dkv_
                                                                      const float* __restrict__ dout,
                                                                      const float* __restrict__ lse,
                                                                      const float* __restrict__ delta,
-                                                                     float* __restrict__ dqkv, int B, int L,
+                                                                     void* __restrict__ dqkv, int B, int L,
                                                                      const int64_t* __restrict__ len,
-                                                                     const int* __restrict__ cu) {
+                                                                     const int* __restrict__ cu, int out16) {
   __shared__ __attribute__((aligned(16))) uint32_t sQ[64 * ALD];
   __shared__ __attribute__((aligned(16))) uint32_t sDO[64 * ALD];
   __shared__ __attribute__((aligned(16))) float sLse[64], sDl[64];
@@ -450,16 +476,18 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DKV_WAVES) void attention_bwd_dkv_
   if (key < Lr) {
     // dK = dS^T (Q / sqrt(d_k)): the staged Q tiles are unscaled, so the 1/8 is applied here; invalid keys get zeros
     // (their accumulators may hold anything, inf included: written as literal zeros, never multiplied by 0)
+    const int64_t off = (rowbase + key) * 768 + head * AD;
     if (key_ok) {
-      store_accT(dqkv + (rowbase + key) * 768 + 256 + head * AD, dk0, dk1, lh, 0.125f);
-      store_accT(dqkv + (rowbase + key) * 768 + 512 + head * AD, dv0, dv1, lh, 1.0f);
-    } else {
-#pragma unroll
-      for (int part = 1; part <= 2; ++part) {
-        float* op = dqkv + (rowbase + key) * 768 + part * 256 + head * AD + lh * 32;
-#pragma unroll
-        for (int d = 0; d < 32; d += 4) *reinterpret_cast<float4*>(op + d) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (out16) {
+        store_accT16(reinterpret_cast<uint16_t*>(dqkv) + off + 256, dk0, dk1, lh, 0.125f);
+        store_accT16(reinterpret_cast<uint16_t*>(dqkv) + off + 512, dv0, dv1, lh, 1.0f);
+      } else {
+        store_accT(reinterpret_cast<float*>(dqkv) + off + 256, dk0, dk1, lh, 0.125f);
+        store_accT(reinterpret_cast<float*>(dqkv) + off + 512, dv0, dv1, lh, 1.0f);
       }
+    } else {
+      zero32(dqkv, off + 256 + lh * 32, out16);
+      zero32(dqkv, off + 512 + lh * 32, out16);
     }
   }
 }
@@ -474,13 +502,14 @@ extern "C" int styler_attention_fwd_bf16(const float* qkv, float* out, float* ls
 }
 
 extern "C" int styler_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse,
-                                         float* dqkv, float* delta_ws, int B, int L, const int64_t* len,
-                                         const int32_t* cu, void* stream) {
+                                         void* dqkv, float* delta_ws, int B, int L, const int64_t* len,
+                                         const int32_t* cu, int io_flags, void* stream) {
   if (!qkv || !out || !dout || !lse || !dqkv || !delta_ws || B <= 0 || L <= 0) return STYLER_EINVAL;
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 15)) return STYLER_EALIGN;
   const dim3 grid = attn_grid(L, B);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(attention_bwd_dq_bf16_kernel, grid, dim3(256), 0, st, qkv, out, dout, lse, dqkv, delta_ws, B, L, len, cu);
-  hipLaunchKernelGGL(attention_bwd_dkv_bf16_kernel, grid, dim3(256), 0, st, qkv, dout, lse, delta_ws, dqkv, B, L, len, cu);
+  const int out16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
+  hipLaunchKernelGGL(attention_bwd_dq_bf16_kernel, grid, dim3(256), 0, st, qkv, out, dout, lse, dqkv, delta_ws, B, L, len, cu, out16);
+  hipLaunchKernelGGL(attention_bwd_dkv_bf16_kernel, grid, dim3(256), 0, st, qkv, dout, lse, delta_ws, dqkv, B, L, len, cu, out16);
   return launch_status();
 }

@@ -582,7 +582,7 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
   if (dz16 || x16) {                                 // bf16-resident operands: the two shapes of the FFN sublayer, and the
     // k = 5 convolutions of the AudioEncoder / PostNet stacks (any combination of the two operands)
     const bool ok = prec == STYLER_PREC_BF16 && (!dz16 || !(lddz & 7)) && (!x16 || !(ldx & 7)) &&
-                    ((x16 && !dz16 && kw == 1 && pad_left == 0) || (dz16 && !x16 && kw == 9) || kw == 5);
+                    ((x16 != dz16 && kw == 1 && pad_left == 0) || (dz16 && !x16 && kw == 9) || kw == 5);
     if (!ok) return STYLER_EINVAL;
   }
   if (kw != 1 && kw != 3 && kw != 5 && kw != 9) return STYLER_EINVAL;
@@ -603,10 +603,14 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
                                                 db2, Be, Le, n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, \
                                                 kw > 1 ? reinterpret_cast<const int4*>(chunktab) : nullptr, counts)
     if (kw == 1) {
-      if (x16) {
+      if (x16 || dz16) {                             // (x16: the FFN hidden activation; dz16: the attention's dqkv)
         if (TA != 2 || TB != 2) return STYLER_EINVAL;
-        hipLaunchKernelGGL((wgrad_tr_kernel<1, 2, 2, false, true>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, db2, Be, Le,
-                           n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, nullptr, counts);
+        if (x16)
+          hipLaunchKernelGGL((wgrad_tr_kernel<1, 2, 2, false, true>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, db2, Be, Le,
+                             n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, nullptr, counts);
+        else
+          hipLaunchKernelGGL((wgrad_tr_kernel<1, 2, 2, true, false>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, db2, Be, Le,
+                             n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, nullptr, counts);
       } else if (TA == 2 && TB == 2) WT_LAUNCH(1, 2, 2); else if (TA == 2) WT_LAUNCH(1, 2, 1);
       else if (TB == 2) WT_LAUNCH(1, 1, 2); else WT_LAUNCH(1, 1, 1);
     } else if (kw == 3) {
@@ -664,9 +668,10 @@ extern "C" int styler_wgrad_packed(const float* dz, int64_t lddz, const float* x
 // Kernel variants a grouped launch can run (index = StylerWgradGroupDesc.variant).
 //   0: Linear, 64x64 tile      1: Linear, 128x128 tile      2: Linear, 128x128 tile, x resident as bf16
 //   3: k = 3                   4: k = 5                     5: k = 9            6: k = 9, dz resident as bf16
+//   7: Linear, 128x128 tile, dz resident as bf16
 static int wgrad_variant(int kw, int TA, int TB, bool dz16, bool x16) {
   if (kw == 1) {
-    if (dz16) return -1;
+    if (dz16) return (!x16 && TA == 2 && TB == 2) ? 7 : -1;
     if (x16) return (TA == 2 && TB == 2) ? 2 : -1;
     if (TA == 1 && TB == 1) return 0;
     if (TA == 2 && TB == 2) return 1;
@@ -729,6 +734,7 @@ extern "C" int styler_wgrad_group(const StylerWgradGroupDesc* desc_dev, int coun
     case 4: WGG(5, 1, 1, false, false); break;
     case 5: WGG(9, 1, 1, false, false); break;
     case 6: WGG(9, 1, 1, true, false); break;
+    case 7: WGG(1, 2, 2, true, false); break;
     default: return STYLER_EINVAL;
   }
 #undef WGG

@@ -729,7 +729,7 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
     arena = wgrad_arena
     io = (2 if dz.dtype == torch.bfloat16 else 0) | (1 if x.dtype == torch.bfloat16 else 0)    # bf16-resident operands
     if (arena is not None and arena.buf is not None and prec == PREC_BF16 and prof is None and (plan is None or db2 is None)
-            and (arena.group_all or (kw == 1 and not io))):
+            and (arena.group_all or (kw == 1 and io in (0, 2)))):
         # grouped path (default: the small Linear gradients, variant 0; STYLER_WGRAD_GROUP_ALL=1: every bf16 gradient):
         # plan the member first (variant, tiles, split count), then give it its slice of the arena
         from ._lib import WgradGroupDesc
@@ -741,8 +741,8 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
         if nb < 0:
             _chk(nb, "styler_wgrad_group_desc")
         small = ((n + 63) // 64) * ((cin + 63) // 64) < 48
-        if nb > 0 and (arena.group_all or d.variant == 0 or (d.variant == 1 and small)):
-            want = arena.want_splits(d.variant) if arena.group_all else (LIN128_SPLITS if d.variant == 1 else 0)
+        if nb > 0 and (arena.group_all or d.variant == 0 or (d.variant in (1, 7) and small)):
+            want = arena.want_splits(d.variant) if arena.group_all else (LIN128_SPLITS if d.variant in (1, 7) else 0)
             if want:
                 nb = lib.styler_wgrad_group_desc(ctypes.byref(d), *args, None, *packed, io, want)
             ws = arena.take(d.splits * n * kw * cin, dz.device)
@@ -799,18 +799,24 @@ def colsum(dz, out, out2=None):
     _chk(lib.styler_colsum(dz.data_ptr(), _ld(dz), out.data_ptr(), _ptr(out2), rows, C, _stream()), "styler_colsum")
 
 
-def attention_bwd(qkv, out, dout, lse, lens, prec=None, plan=None):
+def attention_bwd(qkv, out, dout, lse, lens, prec=None, plan=None, out_bf16=False):
+    """out_bf16 (throughput mode only): dqkv comes back as bf16 -- what the QKV dX GEMM and the weight gradients round it to."""
     B, L = (plan.B, plan.T) if plan is not None else (qkv.shape[0], qkv.shape[1])
     dout = dout.contiguous()
-    dqkv = torch.empty_like(qkv)
+    bf16 = _prec(prec) == PREC_BF16
+    dqkv = torch.empty_like(qkv, dtype=torch.bfloat16 if (out_bf16 and bf16) else torch.float32)
     ws = torch.empty(B * 4 * L, device=qkv.device, dtype=torch.float32)
-    fn = lib.styler_attention_bwd_bf16 if _prec(prec) == PREC_BF16 else lib.styler_attention_bwd
     if plan is not None:
         lens, cu = plan.lens, plan.cu.data_ptr()
     else:
         cu = None
-    _chk(fn(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), ws.data_ptr(), B, L,
-            _ptr(lens), cu, _stream()), "styler_attention_bwd")
+    if bf16:
+        _chk(lib.styler_attention_bwd_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                           ws.data_ptr(), B, L, _ptr(lens), cu, 2 if dqkv.dtype == torch.bfloat16 else 0,
+                                           _stream()), "styler_attention_bwd_bf16")
+    else:
+        _chk(lib.styler_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                      ws.data_ptr(), B, L, _ptr(lens), cu, _stream()), "styler_attention_bwd")
     return dqkv
 
 

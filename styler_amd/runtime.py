@@ -43,6 +43,10 @@ class _Runtime:
     # consumer rounds them to bf16 first, so no result changes and each moves half the bytes (STYLER_BF16_ACTS=0: fp32)
     bf16_acts = os.environ.get("STYLER_BF16_ACTS", "1") != "0"
 
+    # throughput mode: the attention backward writes dqkv as bf16 (read as bf16 by the QKV dX GEMM and the weight gradients;
+    # STYLER_BF16_DQKV=0: fp32)
+    bf16_dqkv = os.environ.get("STYLER_BF16_DQKV", "1") != "0"
+
     # each StylePredictor stage (conv -> ReLU -> LayerNorm -> dropout [-> Linear -> mask]) as one tape node whose backward
     # is one LayerNorm-backward kernel + weight gradient + dX GEMM (STYLER_FUSED_PREDICTOR=0: separate nodes)
     fused_predictor = os.environ.get("STYLER_FUSED_PREDICTOR", "1") != "0"

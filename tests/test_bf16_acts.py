@@ -120,3 +120,20 @@ def test_conv_norm_node_equals_two_nodes(dev, kind):
         rt.disable_dropout = saved
     for i, (a, b) in enumerate(zip(*outs)):            # y, dx exact up to nothing; parameter gradients leave as fp32 atomics
         assert torch.allclose(a, b, rtol=1e-5 if i < 2 else 2e-4, atol=1e-6 if i < 2 else 1e-4), i
+
+
+def test_wgrad_linear_bf16_dz_equals_fp32_dz(dev):
+    """Linear weight gradient (128 x 128 tile) with the gradient operand resident as bf16 -- the attention's dqkv -- against
+    the same values handed over as fp32: the kernel rounds to bf16 while staging, so dW and the bias gradient are the same."""
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(14)
+    B, L = 3, 517
+    dqkv = torch.randn(B, L, 768, generator=g).to(dev).to(torch.bfloat16)
+    x = torch.randn(B, L, 256, generator=g).to(dev)
+    for i in range(3):
+        dz = dqkv[..., i * 256:(i + 1) * 256]
+        ref_dw, ref_db = torch.zeros(256, 256, device=dev), torch.zeros(256, device=dev)
+        ops.wgrad(dz.float(), x, ref_dw, 256, 256, db=ref_db, prec=ops.PREC_BF16)
+        dw, db = torch.zeros(256, 256, device=dev), torch.zeros(256, device=dev)
+        ops.wgrad(dz, x, dw, 256, 256, db=db, prec=ops.PREC_BF16)
+        assert torch.allclose(dw, ref_dw, rtol=1e-5, atol=1e-4) and torch.allclose(db, ref_db, rtol=1e-5, atol=1e-4)

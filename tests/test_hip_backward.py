@@ -119,6 +119,11 @@ def test_attention_backward(dev, B, L, lens):
     od16 = ops.attention_fwd(qd, ln.to(dev), lse=lse, prec=ops.PREC_BF16)
     dq16 = ops.attention_bwd(qd, od16, gy.float().to(dev), lse, ln.to(dev), prec=ops.PREC_BF16)
     check(dq16, qkv.grad, 3e-2, "dqkv bf16")
+    # bf16 storage of dqkv: the fp32 result rounded (valid rows; rows past an item's length are don't-care in both)
+    dq16s = ops.attention_bwd(qd, od16, gy.float().to(dev), lse, ln.to(dev), prec=ops.PREC_BF16, out_bf16=True)
+    assert dq16s.dtype == torch.bfloat16
+    valid = (torch.arange(L)[None, :] < ln[:, None]).to(dev)
+    assert torch.equal(dq16s[valid], dq16.to(torch.bfloat16)[valid])
 
 
 def test_layernorm_backward(dev):
