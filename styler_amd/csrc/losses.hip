@@ -20,10 +20,10 @@ __global__ __launch_bounds__(256) void masked_err_mean_kernel(const float* __res
                                                               const float* __restrict__ b, int64_t ldb,
                                                               double* __restrict__ acc, float* __restrict__ mean_out,
                                                               int kind, int64_t rows, int L, int C,
-                                                              const int64_t* __restrict__ len) {
+                                                              const int64_t* __restrict__ len, int vec) {
   __shared__ double red[4][2];
   double s = 0.0, n = 0.0;
-  if ((C & 3) == 0 && C <= 1024 && (lda & 3) == 0 && (ldb & 3) == 0 && rows < ((int64_t)1 << 31)) {
+  if (vec) {                                             // host: C % 4 == 0, C <= 1024, 16-byte aligned rows, rows < 2^31
     // thread = (row-lane, float4 column); four rows per thread in flight, fetched from clamped addresses and dropped by a
     // select; a row's item comes from one 32-bit division (the flat loop this replaces paid two 64-bit divisions per
     // element and a branch around its loads: thirteen dependent round trips per thread on the mel tensors)
@@ -102,9 +102,10 @@ extern "C" int styler_masked_err_mean(const float* a, int64_t lda, const float* 
                                       int kind, int B, int L, int C, const int64_t* len, void* stream) {
   if (!a || !b || !acc || B <= 0 || L <= 0 || C <= 0 || (kind != 0 && kind != 1)) return STYLER_EINVAL;
   const int64_t rows = (int64_t)B * L;
-  if (!(C & 3) && (((uintptr_t)a | (uintptr_t)b) & 15)) return STYLER_EALIGN;
-  hipLaunchKernelGGL(masked_err_mean_kernel, dim3(loss_grid(rows * C / ((C & 3) ? 1 : 4), 1024, 256)), dim3(256), 0,
-                     (hipStream_t)stream, a, lda, b, ldb, acc, mean_out, kind, rows, L, C, len);
+  const int vec = !(C & 3) && C <= 1024 && !(lda & 3) && !(ldb & 3) && rows < ((int64_t)1 << 31) &&
+                  !(((uintptr_t)a | (uintptr_t)b) & 15);
+  hipLaunchKernelGGL(masked_err_mean_kernel, dim3(loss_grid(rows * C / (vec ? 4 : 1), 1024, 256)), dim3(256), 0,
+                     (hipStream_t)stream, a, lda, b, ldb, acc, mean_out, kind, rows, L, C, len, vec);
   return launch_status();
 }
 
