@@ -63,13 +63,10 @@ def test_groupnorm_bf16_output_is_rounded_fp32(dev, L):
     for dyv, o16 in ((dy16.float(), False), (dy16, False), (dy16, True)):
         dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
         res.append((ops.groupnorm_relu_bwd(x, dyv, w, b, st, dg, db, dx_bf16=o16), dg, db))
-    if L <= 512:                           # single-pass backward: no atomics on the way to dx, bit-reproducible
-        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[2][0], res[0][0].to(torch.bfloat16))
-    else:                                  # two-kernel backward: the group sums are fp64 atomics (order-dependent last bits)
-        assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=1e-6)
-        assert torch.allclose(res[2][0].float(), res[0][0], rtol=1e-2, atol=1e-6)
-    for k in (1, 2):
-        assert torch.allclose(res[0][k], res[1][k], rtol=1e-5, atol=1e-5) and torch.allclose(res[0][k], res[2][k], rtol=1e-5, atol=1e-5)
+    # dx: bit-equal across the storage variants in both forms (tools/gn_determinism.py: 30 repeats, 0 differing elements)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[2][0], res[0][0].to(torch.bfloat16))
+    for k in (1, 2):                       # parameter gradients: fp32 atomics (114 per channel at L = 600), order-dependent
+        assert torch.allclose(res[0][k], res[1][k], rtol=1e-4, atol=1e-4) and torch.allclose(res[0][k], res[2][k], rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("dz16,x16", [(True, True), (True, False), (False, True)])
