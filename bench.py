@@ -232,8 +232,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` launches its own ranks (one process per GPU, train.py:33's DataParallel replaced):
+        # re-exec this command under torch.distributed.run on a free local port; rank 0 of the children prints the JSON
+        # line (the other ranks' stdout goes to stderr), this parent prints nothing and hands the exit code through
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        raise SystemExit(subprocess.call(cmd, env=env))
+    if world != max(1, args.gpus):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     if rank != 0:
         sys.stdout.flush()

@@ -492,6 +492,13 @@ int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t l
                          float drop_p, uint64_t drop_seed, float in_drop_p, uint64_t in_drop_seed,
                          float* dx_drop, int64_t lddxd, int replicas, int flags, void* stream);
 
+/* dst_k[c] += sum_{r < replicas} src_k[r * n + c] in replica order, k = 0..2 (src_1/dst_1, src_2/dst_2 optional): the
+ * deterministic fold of the per-block parameter-gradient slots styler_layernorm_bwd writes with replicas >= 256 (autograd
+ * of nn.LayerNorm's weight / bias, SubLayers.py:29,61; modules.py:441-447).  Stand-alone calls use it; inside a training
+ * step the same fold is a member of styler_wgrad_reduce_multi. */
+int styler_fold_replicas(const float* src0, const float* src1, const float* src2, float* dst0, float* dst1,
+                         float* dst2, int replicas, int n, void* stream);
+
 /* stats = the forward's [B][C/16][2] (mean, rstd); workspace 2*B*C/16 doubles (scratch). */
 int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void* dy, int64_t lddy,
                               const float* gamma, const float* beta, const float* stats, void* dx,

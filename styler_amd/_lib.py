@@ -66,6 +66,7 @@ _SIGS = {
     "styler_repack_weight_bwd": [P, P, I, I, I, I, P],
     "styler_attention_bwd": [P, P, P, P, P, P, I, I, P, P, P],
     "styler_layernorm_bwd": [P, I64, P, I64, P, P, P, I64, P, P, P, P, P, P, I, I, I, P, F, ctypes.c_uint64, F, ctypes.c_uint64, P, I64, I, I, P],
+    "styler_fold_replicas": [P, P, P, P, P, P, I, I, P],
     "styler_groupnorm_relu_bwd": [P, I64, P, I64, P, P, P, P, I64, P, P, P, I, I, I, I, I, P],
     "styler_batchnorm_bwd": [P, P, P, P, P, P, P, P, P, P, I, I64, I, I, P, F, ctypes.c_uint64, I, I, P],
     "styler_embed_bwd": [P, P, I64, P, I, I, I, P],

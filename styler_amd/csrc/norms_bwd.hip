@@ -199,6 +199,30 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
   return launch_status();
 }
 
+// Folds [replicas][n] per-block partial sums (styler_layernorm_bwd with replicas >= its block count: stores, no atomics)
+// into up to three destination vectors, dst[c] += sum_r src[r][c] in replica order: a fixed summation order, so the
+// stand-alone LayerNorm backward gives the same bits on every launch and on every box (inside a training step the
+// multi-tensor reduce of the weight gradients does this fold).
+__global__ void fold_replicas_kernel(const float* __restrict__ s0, const float* __restrict__ s1, const float* __restrict__ s2,
+                                     float* __restrict__ d0, float* __restrict__ d1, float* __restrict__ d2, int replicas, int n) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const float* s = blockIdx.y == 0 ? s0 : blockIdx.y == 1 ? s1 : s2;
+  float* d = blockIdx.y == 0 ? d0 : blockIdx.y == 1 ? d1 : d2;
+  if (!s || !d) return;
+  float t = 0.f;
+  for (int r = 0; r < replicas; ++r) t += s[(int64_t)r * n + c];
+  d[c] += t;
+}
+
+extern "C" int styler_fold_replicas(const float* s0, const float* s1, const float* s2, float* d0, float* d1, float* d2,
+                                    int replicas, int n, void* stream) {
+  if (!s0 || !d0 || replicas < 1 || n < 1) return STYLER_EINVAL;
+  hipLaunchKernelGGL(fold_replicas_kernel, dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, (hipStream_t)stream, s0, s1, s2,
+                     d0, d1, d2, replicas, n);
+  return launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // GroupNorm(16 ch/group over padded L) + ReLU backward, segmented over time like the forward (norms.hip):
 //   g = dy * (y > 0);  dxh = g * gamma;  dx = rstd * (dxh - mean_g(dxh) - xh * mean_g(dxh * xh))

@@ -73,12 +73,18 @@ class WgradArena:
         self.side = None
         self.side_used = False
         self.side_keep = []
+        # an arena whose buffer / tables are addressed by a captured hipGraph (training.GraphedTrainStep owns one per
+        # graph): descriptor tables are never evicted, and once `frozen` the buffer must not be re-sized
+        self.owned_by_graph = False
+        self.frozen = False
 
     def begin(self, device=None):
         """Start of a backward pass.  The buffer is (re)sized HERE, from what the previous pass asked for in total --
         never inside a pass, where slices are in use (a pass may flush more than once: the decoder-side flush of the
         overlapped all-reduce comes first)."""
         if self.total > (self.buf.numel() if self.buf is not None else 0) and device is not None:
+            if self.frozen:
+                raise StylerHipError("WgradArena: a captured hipGraph addresses this buffer; it cannot be re-sized")
             self.buf = torch.empty(self.total, device=device, dtype=torch.float32)
         self.used = 0
         self.total = 0
@@ -189,8 +195,8 @@ class WgradArena:
             for i, (ws, dw, sn, sc, sj, n, cin, kw, splits) in enumerate(self.descs):
                 arr[i] = (ws, dw, sn, sc, sj, start, n, cin, kw, splits)
                 start += int(lib.styler_wgrad_reduce_blocks(n, cin, kw, sc, sj))
-            if len(self._cache) > 8:
-                self._cache.clear()
+            if len(self._cache) > 8 and not self.owned_by_graph:
+                self._cache.clear()                  # eager steps only: a graph's tables live as long as its arena
             self._cache[key] = (torch.from_numpy(arr.view(np.uint8).copy()).to(device), start)
         table, blocks = self._cache[key]
         _chk(lib.styler_wgrad_reduce_multi(table.data_ptr(), len(self.descs), blocks, _stream()),
@@ -231,9 +237,12 @@ class ZeroSlab:
         self.buf = None
         self.used = 0
         self.total = 0
+        self.frozen = False                          # set once a captured hipGraph addresses `buf`
 
     def begin(self, device):
         if self.total > (self.buf.numel() if self.buf is not None else 0):
+            if self.frozen:
+                raise StylerHipError("ZeroSlab: a captured hipGraph addresses this buffer; it cannot be re-sized")
             self.buf = torch.empty(self.total, device=device, dtype=torch.float64)
         if self.buf is not None:
             self.buf.zero_()
@@ -846,12 +855,26 @@ def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, do
             if ddot_w is not None:
                 pw = sc[2]
                 arena.descs.append((pw.data_ptr(), ddot_w.data_ptr(), 1, 0, 0, 256, 1, 1, rep))
+    fold = None
+    if rep == 1:
+        # stand-alone call (no training step around it): the blocks still store into per-block slots -- never fp32 atomics
+        # into one vector, whose order (and therefore the last bits of the sum) changes from launch to launch -- and a
+        # fixed-order fold adds them to the gradients
+        nvec = 3 if ddot_w is not None else 2
+        fold = torch.zeros(nvec, LN_REPLICAS, 256, device=x.device, dtype=torch.float32)
+        rep, pg, pb = LN_REPLICAS, fold[0], fold[1]
+        if ddot_w is not None:
+            pw = fold[2]
     _chk(lib.styler_layernorm_bwd(x.data_ptr(), _ld(x), _ptr(dy), _ld(dy) if dy is not None else 0, gamma.data_ptr(),
                                   _ptr(beta), _ptr(dx), C, pg.data_ptr(), pb.data_ptr(), _ptr(dot_w),
                                   _ptr(dout), _ptr(pw), _ptr(ddot_b), B, L, C, _ptr(lens), float(drop_p),
                                   int(drop_seed), float(in_drop_p), int(in_drop_seed), _ptr(dxd), C, rep, 1 if relu_input else 0,
                                   _stream()),
          "styler_layernorm_bwd")
+    if fold is not None:
+        _chk(lib.styler_fold_replicas(fold[0].data_ptr(), fold[1].data_ptr(), _ptr(fold[2]) if ddot_w is not None else None,
+                                      dgamma.data_ptr(), dbeta.data_ptr(), _ptr(ddot_w), LN_REPLICAS, 256, _stream()),
+             "styler_fold_replicas")
     return (dx, dxd) if dxd is not None else dx
 
 

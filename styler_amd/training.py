@@ -224,7 +224,12 @@ def forward_backward(model, state, batch, loss_fn=None, dat_fn=None):
     ops.zero_slab = state.zero_slab
     try:
         losses = train_losses(model, batch, loss_fn, dat_fn)
-        rt.grad_ready_hook = state.split_hook or (state.on_decoder_grads_ready if state.overlap_allreduce else None)
+        # The decoder-side all-reduce may only start from the LAST micro-batch of an accumulation window: an earlier one
+        # would reduce a partial sum while the next micro-batch is still adding to it (and those additions would never be
+        # reduced) -- round-2 advisor finding.  `state._accum` already counts this micro-batch.
+        last_micro = state._accum % hp.acc_steps == 0
+        rt.grad_ready_hook = state.split_hook or (state.on_decoder_grads_ready
+                                                  if (state.overlap_allreduce and last_micro) else None)
         state.arena.begin(state.flat_g.device)
         ops.wgrad_arena = state.arena
         # loss / acc_steps (train.py:175) as the seed gradient of backward: no division kernel, no ones_like
@@ -272,7 +277,16 @@ class GraphedTrainStep:
         if hp.acc_steps != 1:
             raise ValueError("GraphedTrainStep replays a whole optimisation step: acc_steps must be 1 "
                              "(use train_step for gradient accumulation)")
-        state.overlap_allreduce = False
+        # Everything a captured graph addresses by raw pointer must live exactly as long as the graph.  The split-K
+        # workspace arena (its buffer, its reduce / group descriptor tables) and the zero slab are per-pass scratch that
+        # the shared TrainState re-sizes when a later, larger batch shape asks for more -- so every graphed step OWNS its
+        # own pair: a second bucket's warm-up can neither free nor re-use memory this graph writes to on replay
+        # (round-2 advisor finding; tests/test_20_hip_backward.py::test_graph_cache_two_buckets_small_then_large).
+        self.arena, self.zero_slab = ops.WgradArena(), ops.ZeroSlab()
+        self.arena.owned_by_graph = True
+        shared = state.arena, state.zero_slab, state.overlap_allreduce
+        state.arena, state.zero_slab = self.arena, self.zero_slab
+        state.overlap_allreduce = False                       # inside a graph the cut is the split hook, not the eager hook
         strict, rt.strict_inputs = rt.strict_inputs, False    # the [0, 1] input assertion is a host sync (utils.py:423)
         try:
             self._warmup(model, state, warmup, loss_fn, dat_fn, split)
@@ -293,8 +307,10 @@ class GraphedTrainStep:
             # a capture does not execute: its step-counter increment and BatchNorm momentum updates are part of the
             # graph, nothing to undo
             state._accum = 0
+            self.arena.frozen = self.zero_slab.frozen = True    # the graphs hold their addresses: no re-sizing from here on
         finally:
             rt.strict_inputs = strict
+            state.arena, state.zero_slab, state.overlap_allreduce = shared
 
     def _warmup(self, model, state, warmup, loss_fn, dat_fn, split):
         """Eager passes before the capture: they size the wgrad arena / zero slab and build the descriptor tables.  Side

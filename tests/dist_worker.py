@@ -1,7 +1,7 @@
-"""Worker of tests/test_dist_gpu.py: one rank of a two-rank data-parallel train step on ONE GPU (both ranks on cuda:0,
+"""Worker of tests/test_95_dist_gpu.py: one rank of a two-rank data-parallel train step on ONE GPU (both ranks on cuda:0,
 collectives over gloo -- RCCL refuses two ranks on one device; the control flow is the N > 1 path of bench.py).
 
-    python dist_worker.py <rank> <world> <port> <out_dir>
+    python dist_worker.py <rank> <world> <port> <out_dir> [graph|acc2|buckets]
 """
 import os
 import sys
@@ -31,16 +31,28 @@ def global_batch():
     return make_batch(8, 10, 30, 2, 9, seed=91)
 
 
+def micro_batches(gb, idx):
+    """A rank's shard cut into two micro-batches (gradient accumulation, train.py:175-178)."""
+    h = len(idx) // 2
+    return [shard_batch(gb, idx[:h]), shard_batch(gb, idx[h:])]
+
+
+def second_batch():
+    from closed_form import make_batch
+    return make_batch(8, 24, 44, 3, 11, seed=92)
+
+
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    mode = sys.argv[5] if len(sys.argv) > 5 else "graph"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
     from conftest import _reference_state_dict
-    from styler_amd import STYLER, rt
+    from styler_amd import STYLER, hparams as hp, rt
     from styler_amd.dist import shard_indices
-    from styler_amd.training import GraphedTrainStep, TrainState
+    from styler_amd.training import GraphedStepCache, GraphedTrainStep, TrainState, train_step
 
     rt.disable_dropout = True
     model = STYLER()
@@ -53,14 +65,39 @@ def main():
     state = TrainState(model)
     gb = global_batch()
     idx = shard_indices(gb["text"].shape[0], rank, world, gb["mel_len"].tolist())
-    local = {k: v.to(dev) for k, v in shard_batch(gb, idx).items()}
-    step = GraphedTrainStep(model, state, local)                  # N > 1: two graphs, tail all-reduce between the replays
-    n_graphs = len(step.graphs)
-    losses, lr = step(local)
+    res = {"idx": idx, "seed": rt.seed, "info": state.allreduce_info()}
+    if mode == "graph":
+        local = {k: v.to(dev) for k, v in shard_batch(gb, idx).items()}
+        step = GraphedTrainStep(model, state, local)              # N > 1: two graphs, tail all-reduce between the replays
+        res["graphs"] = len(step.graphs)
+        losses, lr = step(local)
+    elif mode == "acc2":
+        # eager steps with gradient accumulation AND the hook-driven overlapped all-reduce (round-2 advisor finding: the
+        # hook must fire on the last micro-batch of the window only)
+        hp.acc_steps = 2
+        assert state.overlap_allreduce
+        fired = []
+        orig = state.on_decoder_grads_ready
+        state.on_decoder_grads_ready = lambda: (fired.append(state._accum), orig())[1]
+        for mb in micro_batches(gb, idx):
+            losses, lr = train_step(model, state, {k: v.to(dev) for k, v in mb.items()})
+        res["hook_fired_at"] = fired
+    elif mode == "buckets":
+        # two consecutive optimisation steps through the graph cache, every rank with its own padded shapes per step
+        cache = GraphedStepCache(model, state)
+        gb2 = second_batch()
+        idx2 = shard_indices(gb2["text"].shape[0], rank, world, gb2["mel_len"].tolist())
+        res["idx2"] = idx2
+        for g_, i_ in ((gb, idx), (gb2, idx2)):
+            losses, lr = cache({k: v.to(dev) for k, v in shard_batch(g_, i_).items()})
+        res["graphs"] = [len(s_.graphs) for s_ in cache.steps.values()]
+        res["misses"] = cache.misses
+    else:
+        raise SystemExit(f"unknown mode {mode}")
     torch.cuda.synchronize()
-    torch.save({"idx": idx, "graphs": n_graphs, "flat_g": state.flat_g.cpu(), "flat_p": state.flat_p.cpu(), "lr": lr,
-                "losses": [float(x) for x in losses], "seed": rt.seed, "info": state.allreduce_info()},
-               os.path.join(out, f"rank{rank}.pt"))
+    res.update(flat_g=state.flat_g.cpu(), flat_p=state.flat_p.cpu(), lr=lr, losses=[float(x) for x in losses],
+               steps=state.n_current_steps)
+    torch.save(res, os.path.join(out, f"rank{rank}.pt"))
     state.close()
     dist.barrier()
     dist.destroy_process_group()

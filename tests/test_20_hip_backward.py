@@ -398,37 +398,6 @@ def test_train_step_vs_oracle_vctk_shape(dev, train_model, ref_state_dict):
     train_model.load_state_dict(ref_state_dict)
 
 
-def test_deferred_wgrad_reduce_matches_immediate(dev, train_model, ref_state_dict):
-    """The arena path of train_step (every split-K reduction deferred to one multi-tensor launch) must produce the same
-    flat gradient as the immediate per-call reduction."""
-    from closed_form import make_batch
-    from styler_amd import ops
-    from styler_amd.training import train_losses
-    b = {k: v.to(dev) for k, v in make_batch(3, 20, 40, 2, 9, seed=33).items()}
-    train_model.load_state_dict(ref_state_dict)
-    grads = []
-    arena = ops.WgradArena()
-    for mode in ("immediate", "measure", "arena"):
-        train_model.zero_grad(set_to_none=True)
-        losses = train_losses(train_model, b)
-        if mode != "immediate":
-            arena.begin(dev)
-            ops.wgrad_arena = arena
-        try:
-            losses[0].backward()
-            if mode != "immediate":
-                arena.flush(dev)
-        finally:
-            ops.wgrad_arena = None
-        grads.append({k: p.grad.clone() for k, p in train_model.named_parameters() if p.grad is not None})
-    assert arena.buf is not None and arena.used > 0
-    for k in grads[0]:
-        for other in grads[1:]:
-            e = float((grads[0][k] - other[k]).abs().max()) / max(float(grads[0][k].abs().max()), 1e-4)
-            assert e <= 1e-4, f"{k}: {e:.3e}"
-    train_model.load_state_dict(ref_state_dict)
-
-
 def test_train_state_steps_and_bf16(dev, ref_state_dict):
     """Flat-buffer optimiser: two steps reduce nothing to NaN, parameters move, derived layouts refresh; bf16 mode
     gradients stay close to fp32 ones."""
@@ -628,197 +597,3 @@ def test_bucketed_batches_oracle_on_same_rectangle_and_graph_cache(dev, ref_stat
         assert float((p_e - p_c).abs().max()) <= 1e-4
     finally:
         rt.disable_dropout = False
-
-
-def test_graphed_train_step_matches_eager(dev, ref_state_dict):
-    """forward + losses + backward replayed from one hipGraph (GraphedTrainStep) must walk the same trajectory as the
-    eager step: same losses and same parameters after the same number of optimiser steps (dropout off: the two modes
-    draw different masks).  With dropout on, two replays must draw DIFFERENT masks (device step counter)."""
-    from closed_form import make_batch
-    from styler_amd import STYLER, rt
-    from styler_amd.training import GraphedTrainStep, TrainState, train_step
-    b = {k: v.to(dev) for k, v in make_batch(4, 20, 40, 2, 9, seed=35).items()}
-    rt.disable_dropout = True
-    try:
-        finals = []
-        for mode in ("eager", "graph"):
-            m = STYLER()
-            m.load_state_dict(ref_state_dict)
-            m = m.to(dev).train()
-            st = TrainState(m)
-            if mode == "eager":
-                for _ in range(5):
-                    losses, lr = train_step(m, st, b)
-            else:
-                # constructing the graphed step must not train: no optimiser step, BatchNorm running statistics, the
-                # dropout step counter and the gradient buffer restored (one instance is built per padded batch shape)
-                snap = (st.flat_p.clone(), st.flat_m.clone(), st.flat_v.clone(), st.drop_epoch.clone(),
-                        [x.clone() for x in m.buffers()])
-                g = GraphedTrainStep(m, st, b, warmup=3)
-                assert st.n_current_steps == 0 and st.adam_steps == 0
-                assert torch.equal(st.flat_p, snap[0]) and torch.equal(st.flat_m, snap[1]) and torch.equal(st.flat_v, snap[2])
-                assert torch.equal(st.drop_epoch, snap[3]) and float(st.flat_g.abs().max()) == 0.0
-                assert all(torch.equal(x, y) for x, y in zip(m.buffers(), snap[4]))
-                for _ in range(5):
-                    losses, lr = g(b)
-            finals.append((torch.stack([x.detach().float().reshape(()) for x in losses]).cpu(), st.flat_p.clone(), lr,
-                           st.n_current_steps))
-        (l_e, p_e, lr_e, n_e), (l_g, p_g, lr_g, n_g) = finals
-        assert n_e == n_g == 5 and lr_e == lr_g
-        assert float((l_e - l_g).abs().max()) <= 2e-4 * max(1.0, float(l_e.abs().max())), (l_e, l_g)
-        assert float((p_e - p_g).abs().max()) <= 1e-4
-    finally:
-        rt.disable_dropout = False
-    m = STYLER()
-    m.load_state_dict(ref_state_dict)
-    m = m.to(dev).train()
-    st = TrainState(m)
-    g = GraphedTrainStep(m, st, b, warmup=2)
-    p0, m0, v0, n0 = st.flat_p.clone(), st.flat_m.clone(), st.flat_v.clone(), st.n_current_steps
-    la = torch.stack([x.detach().float().reshape(()) for x in g(b)[0]]).cpu()
-    st.flat_p.copy_(p0); st.flat_m.copy_(m0); st.flat_v.copy_(v0); st.n_current_steps = n0      # same weights again
-    lb = torch.stack([x.detach().float().reshape(()) for x in g(b)[0]]).cpu()
-    assert torch.isfinite(la).all() and torch.isfinite(lb).all()
-    assert float((la - lb).abs().max()) > 0, "two replays drew the same dropout masks"
-
-
-def test_fused_dropout_add_layernorm(dev):
-    """LayerNormFn with drop_p > 0 (dropout + residual + LayerNorm + mask in one kernel, mask regenerated in backward) vs
-    the unfused chain styler_dropout -> add -> LayerNorm with the SAME seed (the fused kernel draws the stream
-    styler_dropout would draw on the [rows, 256] tensor)."""
-    from styler_amd import autograd as AG, ops, rt
-    g = torch.Generator().manual_seed(5)
-    B, L, p = 3, 37, 0.2
-    lens = torch.tensor([37, 11, 30]).to(dev)
-    x = torch.randn(B, L, 256, generator=g).to(dev)
-    r = torch.randn(B, L, 256, generator=g).to(dev)
-    gy = torch.randn(B, L, 256, generator=g).to(dev)
-    ln = nn.LayerNorm(256).to(dev)
-    with torch.no_grad():
-        ln.weight.copy_(torch.randn(256, generator=g)); ln.bias.copy_(torch.randn(256, generator=g))
-    calls0 = rt.dropout_calls
-    xa, ra = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
-    ya = AG.LayerNormFn.apply(xa, ra, ln.weight, ln, lens, p)
-    ya.backward(gy)
-    ga, gb = ln.weight.grad.clone(), ln.bias.grad.clone()
-    seed = (rt.seed * 1000003 + calls0 + 1) & 0x7FFFFFFFFFFFFFFF          # what next_dropout_seed() handed out
-    ln.weight.grad = None; ln.bias.grad = None
-    xb, rb = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
-    yb = AG.LayerNormFn.apply(AG.DropoutFn.apply(xb, p, seed), rb, ln.weight, ln, lens, 0.0)
-    yb.backward(gy)
-    kept = float((ops.dropout(torch.ones_like(x), p, seed) > 0).float().mean())
-    assert 0.7 < kept < 0.9
-    check(ya, yb, 1e-6, "fwd"); check(xa.grad, xb.grad, 1e-6, "dx (through the mask)"); check(ra.grad, rb.grad, 1e-6, "dres")
-    check(ga, ln.weight.grad, 1e-5, "dgamma"); check(gb, ln.bias.grad, 1e-5, "dbeta")
-
-
-def test_split_graph_step_matches_single_graph(dev, ref_state_dict):
-    """GraphedTrainStep(split=True) -- two graphs cut where the decoder-side gradients are final, so that their all-reduce
-    can run between the replays -- must walk exactly the trajectory of the single-graph step (dropout off)."""
-    from closed_form import make_batch
-    from styler_amd import STYLER, rt
-    from styler_amd.training import GraphedTrainStep, TrainState
-    b = {k: v.to(dev) for k, v in make_batch(4, 20, 40, 2, 9, seed=36).items()}
-    rt.disable_dropout = True
-    try:
-        finals = []
-        for split in (False, True):
-            m = STYLER()
-            m.load_state_dict(ref_state_dict)
-            m = m.to(dev).train()
-            st = TrainState(m)
-            g = GraphedTrainStep(m, st, b, warmup=3, split=split)
-            assert len(g.graphs) == (2 if split else 1)
-            for _ in range(3):
-                losses, lr = g(b)
-            finals.append((torch.stack([x.detach().float().reshape(()) for x in losses]).cpu(), st.flat_p.clone(), lr))
-        (l1, p1, lr1), (l2, p2, lr2) = finals
-        assert lr1 == lr2
-        assert float((l1 - l2).abs().max()) <= 2e-4 * max(1.0, float(l1.abs().max())), (l1, l2)
-        assert float((p1 - p2).abs().max()) <= 1e-4
-    finally:
-        rt.disable_dropout = False
-
-
-def test_fused_batchnorm_tanh_dropout(dev):
-    """BatchNormActFn with drop_p > 0 (BatchNorm batch statistics + tanh + dropout in one pass; backward regenerates the
-    mask and recomputes tanh from x) vs the unfused chain BatchNormActFn(drop 0) -> DropoutFn with the SAME seed."""
-    from styler_amd import autograd as AG, rt
-    g = torch.Generator().manual_seed(9)
-    B, L, C, p = 3, 29, 512, 0.5
-    x = (torch.randn(B, L, C, generator=g) * 1.5 + 0.2).to(dev)
-    gy = torch.randn(B, L, C, generator=g).to(dev)
-    res = {}
-    for fused in (True, False):
-        bn = nn.BatchNorm1d(C).to(dev)
-        with torch.no_grad():
-            bn.weight.copy_(torch.randn(C, generator=torch.Generator().manual_seed(1)))
-            bn.bias.copy_(torch.randn(C, generator=torch.Generator().manual_seed(2)))
-        xa = x.clone().requires_grad_(True)
-        calls0 = rt.dropout_calls
-        if fused:
-            y = AG.BatchNormActFn.apply(xa, bn.weight, bn, AG.TANH, p)
-            seed = (rt.seed * 1000003 + calls0 + 1) & 0x7FFFFFFFFFFFFFFF
-        else:
-            y = AG.DropoutFn.apply(AG.BatchNormActFn.apply(xa, bn.weight, bn, AG.TANH, 0.0), p, res["seed"])
-        y.backward(gy)
-        res[fused] = (y.detach(), xa.grad, bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_var.clone())
-        if fused:
-            res["seed"] = seed
-    for a, c, what in zip(res[True], res[False], ("y", "dx", "dgamma", "dbeta", "running_var")):
-        check(a, c, 2e-5, what)
-    assert 0.4 < float((res[True][0] != 0).float().mean()) < 0.6
-
-
-def test_predictor_stage_kernels_equal_their_parts(dev):
-    """The fused StylePredictor stage: LayerNorm with dropout on its output == dropout(LayerNorm), and ONE LayerNorm-backward
-    kernel (dropout mask regenerated, ReLU mask of its input applied) == dropout backward -> LayerNorm backward -> act_bwd."""
-    from styler_amd import ops
-    g = torch.Generator().manual_seed(21)
-    B, L, p, seed = 5, 173, 0.5, 77
-    h = torch.relu(torch.randn(B, L, 256, generator=g)).to(dev)             # a ReLU output, as the conv epilogue leaves it
-    dy = torch.randn(B, L, 256, generator=g).to(dev)
-    ga, be = (1 + 0.1 * torch.randn(256, generator=g)).to(dev), (0.1 * torch.randn(256, generator=g)).to(dev)
-    y1 = ops.add_layernorm(h, ga, be, drop_p=p, drop_seed=seed)
-    y2 = ops.dropout(ops.add_layernorm(h, ga, be), p, seed)
-    assert torch.equal(y1, y2)
-    assert 0.4 < float((y1 == 0).float().mean()) < 0.6
-    dg1, db1, dg2, db2 = (torch.zeros(256, device=dev) for _ in range(4))
-    dz1 = ops.layernorm_bwd(h, dy, ga, be, dg1, db1, drop_p=p, drop_seed=seed, relu_input=True)
-    keep = (y2 != 0) | (ops.add_layernorm(h, ga, be) == 0)                  # the mask of the same stream
-    d_ln = ops.layernorm_bwd(h, dy * keep / (1 - p), ga, be, dg2, db2)
-    dz2 = ops.act_bwd(d_ln, h, ops.ACT_RELU)
-    assert torch.equal(dz1, dz2)
-    assert torch.allclose(dg1, dg2, rtol=1e-5, atol=1e-5) and torch.allclose(db1, db2, rtol=1e-5, atol=1e-5)
-
-
-def test_fused_predictor_equals_separate_nodes(dev, ref_state_dict):
-    """StylePredictor under autograd: the two-node-per-predictor tape (rt.fused_predictor) gives the outputs and gradients
-    of the node-per-op tape."""
-    from styler_amd import rt
-    from styler_amd.modules import StylePredictor
-    g = torch.Generator().manual_seed(22)
-    x0 = torch.randn(4, 61, 256, generator=g)
-    lens = torch.tensor([61, 40, 17, 55])
-    go = torch.randn(4, 61, generator=g).to(dev)
-    sd = {k[len("style_modeling.pitch_predictor."):]: v for k, v in ref_state_dict.items()
-          if k.startswith("style_modeling.pitch_predictor.")}
-    res = []
-    keep = rt.fused_predictor, rt.disable_dropout
-    try:
-        rt.disable_dropout = True
-        for fused in (True, False):
-            rt.fused_predictor = fused
-            m = StylePredictor()
-            m.load_state_dict(sd)
-            m = m.to(dev).train()
-            x = x0.to(dev).requires_grad_(True)
-            out = m(x, lens.to(dev))
-            out.backward(go)
-            res.append((out.detach(), x.grad, {k: v.grad.clone() for k, v in m.named_parameters()}))
-    finally:
-        rt.fused_predictor, rt.disable_dropout = keep
-    assert torch.equal(res[0][0], res[1][0])
-    assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-6)
-    for k in res[0][2]:
-        assert torch.allclose(res[0][2][k], res[1][2][k], rtol=1e-4, atol=1e-5), k

@@ -1,0 +1,267 @@
+"""Model-level HIP-vs-HIP equivalences (packed vs padded decoder, paired vs separate decodes / PostNet segments, batch
+permutation, experimental switches).  Run after every oracle / golden parity test: see tests/test_90_equivalences.py."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import styler_oracle
+    return styler_oracle
+
+
+@pytest.fixture(scope="module")
+def model(dev, ref_state_dict):
+    from styler_amd import STYLER
+    m = STYLER()
+    m.load_state_dict(ref_state_dict)
+    return m.to(dev).eval()
+
+
+def maxerr(a, b):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu() if isinstance(b, torch.Tensor) else torch.from_numpy(np.asarray(b)).float()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max()) if a.numel() else 0.0
+
+
+def check(a, b, tol, what=""):
+    e = maxerr(a, b)
+    assert e <= tol, f"{what}: max abs err {e:.3e} > {tol}"
+
+
+def _to(b, dev):
+    return {k: v.to(dev) for k, v in b.items()}
+
+
+def _golden_batch(g):
+    return {k[3:]: T(g[k]) for k in g.files if k.startswith("in_")}
+
+
+def _forward(model, b, teacher=True, **kw):
+    S, Tm = b["text"].shape[1], b["mel_target"].shape[1]
+    if teacher:
+        return model(b["text"], b["mel_target"], b["mel_aug"], b["f0_norm"], b["energy_input"], b["src_len"],
+                     b["mel_len"], b["D"], b["f0"], b["energy"], S, Tm, speaker_embed=b["speaker_embed"], **kw)
+    return model(b["text"], b["mel_target"], b["mel_target"], b["f0_norm"], b["energy_input"], b["src_len"],
+                 b["mel_len"], None, None, None, S, None, speaker_embed=b["speaker_embed"], **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_packed_decoder_matches_padded(dev, ref_state_dict, prec):
+    """The decoder on packed rows (valid frames only, csrc/pack.hip) must reproduce the padded-rectangle decoder: same
+    mel / postnet outputs in eval mode and the same gradients in train mode (dropout off), ragged batch incl. an item of
+    length 1 and one that fills the rectangle."""
+    from closed_form import make_batch
+    from styler_amd import STYLER, rt
+    from styler_amd.training import train_losses
+    b = make_batch(5, 8, 30, 1, 9, seed=77)
+    bd = {k: v.to(dev) for k, v in b.items()}
+    S, T = bd["text"].shape[1], bd["mel_target"].shape[1]
+    m = STYLER()
+    m.load_state_dict(ref_state_dict)
+    m = m.to(dev)
+    rt.set_precision(prec)
+    rt.disable_dropout = True
+    tol = 2e-5 if prec == "fp32" else 2e-2
+    try:
+        outs, grads = [], []
+        for packed in (False, True):
+            rt.pack_decoder = packed
+            m.eval()
+            with torch.no_grad():
+                o = m(bd["text"], bd["mel_target"], bd["mel_aug"], bd["f0_norm"], bd["energy_input"], bd["src_len"],
+                      bd["mel_len"], bd["D"], bd["f0"], bd["energy"], S, T, speaker_embed=bd["speaker_embed"])
+            outs.append([o[0][0], o[0][1], o[1][0], o[1][1]])
+            m.train()
+            m.zero_grad(set_to_none=True)
+            train_losses(m, bd)[0].backward()
+            grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        for a, c in zip(*outs):
+            e = float((a - c).abs().max()) / max(float(a.abs().max()), 1e-6)
+            assert e <= tol, f"eval outputs differ: {e:.3e}"
+        assert grads[0].keys() == grads[1].keys()
+        for k in grads[0]:
+            if k.startswith("postnet.convolutions") and k.endswith("0.conv.bias"):
+                continue      # analytically zero (train-mode BatchNorm removes the column mean): both sides hold rounding noise
+            e = float((grads[0][k] - grads[1][k]).abs().max()) / max(float(grads[0][k].abs().max()), 1e-4)
+            assert e <= (1e-4 if prec == "fp32" else 5e-2), f"{k}: {e:.3e}"
+    finally:
+        rt.pack_decoder = True
+        rt.disable_dropout = False
+        rt.set_precision("fp32")
+
+
+@pytest.mark.gpu
+def test_batch_permutation_equivariance_full_c2(dev, ref_state_dict):
+    """Size-independent property at the full C2 batch (B = 48, VCTK-shape lengths, bf16 throughput mode): in eval mode no
+    op mixes utterances (GroupNorm / LayerNorm are per item, BatchNorm is folded, attention and the LengthRegulator work
+    per item), so permuting the batch must permute the outputs -- this moves every item to another slot of the padded
+    rectangle and another offset of the packed decoder rows.  Lengths / masks must match bit-exactly."""
+    from closed_form import make_batch
+    from styler_amd import STYLER, rt
+    b = make_batch(48, 20, 60, 2, 13, seed=1234)
+    bd = {k: v.to(dev) for k, v in b.items()}
+    S, T = bd["text"].shape[1], bd["mel_target"].shape[1]
+    perm = torch.randperm(48, generator=torch.Generator().manual_seed(3)).to(dev)
+    m = STYLER()
+    m.load_state_dict(ref_state_dict)
+    m = m.to(dev).eval()
+    rt.set_precision("bf16")
+    strict, rt.strict_inputs = rt.strict_inputs, False
+    try:
+        def run(d):
+            with torch.no_grad():
+                return m(d["text"], d["mel_target"], d["mel_aug"], d["f0_norm"], d["energy_input"], d["src_len"],
+                         d["mel_len"], d["D"], d["f0"], d["energy"], S, T, speaker_embed=d["speaker_embed"])
+        o1 = run(bd)
+        o2 = run({k: v[perm] for k, v in bd.items()})
+        for a, c in ((o1[0][0], o2[0][0]), (o1[0][1], o2[0][1]), (o1[1][0], o2[1][0]), (o1[1][1], o2[1][1]),
+                     (o1[2], o2[2]), (o1[3], o2[3]), (o1[4], o2[4])):
+            e = float((a[perm] - c).abs().max()) / max(float(a.abs().max()), 1e-6)
+            assert e <= 1e-5, f"not permutation-equivariant: {e:.3e}"          # same kernels, same per-item arithmetic
+        assert torch.equal(o1[5][perm], o2[5]) and torch.equal(o1[6][perm], o2[6]) and torch.equal(o1[7][perm], o2[7])
+        valid = int(bd["mel_len"].sum())
+        assert int((~o1[6]).sum()) == valid                                       # mask counts the valid frames
+        pad = o1[6][..., None].expand_as(o1[0][0])
+        assert torch.isfinite(o1[1][0]).all() and float(o1[0][0][pad].abs().max()) <= float(m.mel_linear.bias.detach().abs().max()) + 1e-6
+    finally:
+        rt.strict_inputs = strict
+        rt.set_precision("fp32")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_paired_decodes_match_separate(dev, ref_state_dict, prec):
+    """Clean + noisy decode as one stacked packed batch (STYLER.decode_pair) vs two separate decodes: identical eval
+    outputs (every kernel is row- or item-wise), same gradients in train mode (dropout off) up to the summation order of
+    the weight-gradient GEMMs."""
+    from closed_form import make_batch
+    from styler_amd import STYLER, rt
+    from styler_amd.training import train_losses
+    b = make_batch(5, 8, 30, 1, 9, seed=78)
+    bd = {k: v.to(dev) for k, v in b.items()}
+    S, T = bd["text"].shape[1], bd["mel_target"].shape[1]
+    m = STYLER()
+    m.load_state_dict(ref_state_dict)
+    m = m.to(dev)
+    rt.set_precision(prec)
+    rt.disable_dropout = True
+    keep = rt.pair_decodes
+    try:
+        outs, grads, losses = [], [], []
+        for pair in (False, True):
+            rt.pair_decodes = pair
+            m.eval()
+            with torch.no_grad():
+                o = m(bd["text"], bd["mel_target"], bd["mel_aug"], bd["f0_norm"], bd["energy_input"], bd["src_len"],
+                      bd["mel_len"], bd["D"], bd["f0"], bd["energy"], S, T, speaker_embed=bd["speaker_embed"])
+            outs.append([o[0][0], o[0][1], o[1][0], o[1][1]])
+            m.train()
+            m.zero_grad(set_to_none=True)
+            ls = train_losses(m, bd)
+            ls[0].backward()
+            losses.append([float(x) for x in ls])
+            grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        for a, c in zip(*outs):
+            e = float((a - c).abs().max()) / max(float(a.abs().max()), 1e-6)
+            assert a.shape == c.shape and e <= (1e-5 if prec == "fp32" else 2e-2), f"eval outputs differ: {e:.3e}"
+        assert not torch.equal(outs[1][0], outs[1][1])                       # the noisy branch is a different signal
+        for x, y in zip(*losses):
+            assert abs(x - y) <= 1e-5 * max(1.0, abs(x)) if prec == "fp32" else abs(x - y) <= 2e-2 * max(1.0, abs(x))
+        assert grads[0].keys() == grads[1].keys()
+        for k in grads[0]:
+            if k.startswith("postnet.convolutions") and k.endswith("0.conv.bias"):
+                continue      # analytically zero (train-mode BatchNorm removes the column mean): rounding noise on both sides
+            e = float((grads[0][k] - grads[1][k]).abs().max()) / max(float(grads[0][k].abs().max()), 1e-4)
+            assert e <= (1e-4 if prec == "fp32" else 5e-2), f"{k}: {e:.3e}"
+    finally:
+        rt.pair_decodes = keep
+        rt.disable_dropout = False
+        rt.set_precision("fp32")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("switch", ["pair_audio", "fused_split"])
+def test_experimental_switches_match_default(dev, ref_state_dict, prec, switch):
+    """rt.pair_audio (main forward + DAT pass of the AudioEncoder as one batch of 2B items) and rt.fused_split (gathered
+    gradient of the LengthRegulator output's channel slices) vs the default path: same ten losses and the same gradients
+    (dropout off)."""
+    from closed_form import make_batch
+    from styler_amd import STYLER, rt
+    from styler_amd.training import train_losses
+    bd = {k: v.to(dev) for k, v in make_batch(5, 8, 30, 1, 9, seed=79).items()}
+    m = STYLER()
+    m.load_state_dict(ref_state_dict)
+    m = m.to(dev).train()
+    rt.set_precision(prec)
+    rt.disable_dropout = True
+    keep = getattr(rt, switch)
+    try:
+        losses, grads = [], []
+        for on in (False, True):
+            setattr(rt, switch, on)
+            m.zero_grad(set_to_none=True)
+            ls = train_losses(m, bd)
+            ls[0].backward()
+            losses.append([float(x) for x in ls])
+            grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        tol = 1e-5 if prec == "fp32" else 2e-2
+        for x, y in zip(*losses):
+            assert abs(x - y) <= tol * max(1.0, abs(x)), (x, y)
+        assert grads[0].keys() == grads[1].keys()
+        for k in grads[0]:
+            e = float((grads[0][k] - grads[1][k]).abs().max()) / max(float(grads[0][k].abs().max()), 1e-4)
+            assert e <= (1e-4 if prec == "fp32" else 5e-2), f"{k}: {e:.3e}"
+    finally:
+        setattr(rt, switch, keep)
+        rt.disable_dropout = False
+        rt.set_precision("fp32")
+
+
+@pytest.mark.gpu
+def test_postnet_segments_match_separate_calls(dev, ref_state_dict):
+    """PostNet over the stacked clean + noisy batch with per-segment BatchNorm statistics (segs = 2) == two separate calls
+    (Layers.py:126: per-call statistics): outputs, every gradient, and the running statistics after both momentum updates."""
+    from styler_amd import STYLER, rt
+    g = torch.Generator().manual_seed(77)
+    xa = torch.randn(3, 41, 80, generator=g).to(dev)
+    xb = (torch.randn(3, 41, 80, generator=g) * 1.7 + 0.3).to(dev)
+    rt.disable_dropout = True
+    try:
+        res = []
+        for paired in (False, True):
+            m = STYLER()
+            m.load_state_dict(ref_state_dict)
+            pn = m.postnet.to(dev).train()
+            a, b = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+            if paired:
+                y = pn(torch.cat([a, b]), add_residual=torch.cat([a, b]), segs=2)
+                ya, yb = y[:3], y[3:]
+            else:
+                ya, yb = pn(a, add_residual=a), pn(b, add_residual=b)
+            ((ya * 0.7).sum() + (yb ** 2).sum()).backward()
+            res.append((ya.detach(), yb.detach(), a.grad, b.grad, {k: v.grad.clone() for k, v in pn.named_parameters()},
+                        {k: v.clone() for k, v in pn.named_buffers()}))
+        for x, y in zip(res[0][:4], res[1][:4]):
+            check(y, x, 1e-5, "paired PostNet output / input gradient")
+        for k in res[0][4]:
+            check(res[1][4][k], res[0][4][k], 1e-4, f"paired PostNet grad {k}")
+        for k in res[0][5]:
+            check(res[1][5][k].float(), res[0][5][k].float(), 1e-5, f"paired PostNet buffer {k}")
+    finally:
+        rt.disable_dropout = False

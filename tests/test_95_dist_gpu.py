@@ -1,0 +1,133 @@
+"""Data-parallel train step on real device code with more than one rank (train.py:33 replaced by one process per
+GPU + gradient all-reduce).  The 1-GPU box cannot run RCCL with two ranks, so both ranks share cuda:0 and the collectives
+go over gloo: everything except the transport is the N > 1 path (utterance sharding, per-rank padding, parameter
+broadcast, two-graph step with the decoder-side all-reduce between the replays, 1 / world folded into clip + Adam)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_ranks(tmp_path, mode):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r), "2", port,
+                               str(tmp_path), mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(2))
+    assert torch.equal(r0["flat_g"], r1["flat_g"]) and torch.equal(r0["flat_p"], r1["flat_p"]) and r0["lr"] == r1["lr"]
+    assert (r0["seed"], r1["seed"]) == (0, 1)                       # one dropout stream per rank
+    assert r0["info"]["allreduce_world"] == 2 and r0["info"]["allreduce_bytes"] == r0["flat_g"].numel() * 4
+    return r0, r1
+
+
+def _single_rank(ref_state_dict, monkeypatch, micro_batch_windows):
+    """ONE rank that walks the same optimisation steps with every window's micro-batches accumulated (acc_steps = their
+    count: loss / n each -> the mean of the per-micro-batch gradients, which is what the all-reduce mean computes; per-
+    micro-batch BatchNorm statistics, as per replica in the reference's DataParallel)."""
+    from styler_amd import STYLER, hparams as hp, rt
+    from styler_amd.training import TrainState, train_step
+    dev = torch.device("cuda:0")
+    rt.disable_dropout = True
+    try:
+        m = STYLER()
+        m.load_state_dict(ref_state_dict)
+        m = m.to(dev).train()
+        st = TrainState(m)
+        for window in micro_batch_windows:
+            monkeypatch.setattr(hp, "acc_steps", len(window))
+            for mb in window:
+                _, lr = train_step(m, st, {k: v.to(dev) for k, v in mb.items()})
+            assert lr is not None
+        torch.cuda.synchronize()
+        out = st.flat_g.cpu(), st.flat_p.cpu(), lr
+        st.close()
+        return out
+    finally:
+        rt.disable_dropout = False
+
+
+def test_two_rank_step_equals_single_rank_accumulation(tmp_path, ref_state_dict, monkeypatch):
+    """Two ranks, each on its shard of one global batch, against ONE rank that accumulates the two shards as micro-batches.
+    Same summed gradient, same parameters after the update; the step really ran as two graphs; the ranks drew their
+    weights from rank 0."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_worker import global_batch, shard_batch
+    r0, r1 = _run_ranks(tmp_path, "graph")
+    assert r0["graphs"] == r1["graphs"] == 2, "the split (overlapped all-reduce) capture fell back to one graph"
+    assert sorted(r0["idx"] + r1["idx"]) == list(range(8))
+    gb = global_batch()
+    mean_g, flat_p, lr = _single_rank(ref_state_dict, monkeypatch, [[shard_batch(gb, r["idx"]) for r in (r0, r1)]])
+    err_g = float((0.5 * r0["flat_g"] - mean_g).abs().max()) / float(mean_g.abs().max())
+    assert err_g <= 1e-5, err_g                                     # 0.5 * (g_shard0 + g_shard1)
+    assert lr == r0["lr"]
+    err_p = float((r0["flat_p"] - flat_p).abs().max())
+    assert err_p <= 1e-6, err_p
+
+
+def test_two_rank_accumulation_with_overlapped_allreduce(tmp_path, ref_state_dict, monkeypatch):
+    """acc_steps = 2 on two ranks, eager steps with the hook-driven overlap (round-2 advisor finding): the decoder-side
+    all-reduce must start from the LAST micro-batch of the window only -- started from the first it reduces a partial sum
+    and the second micro-batch's decoder gradients are never reduced (the ranks' weights diverge).  Pinned to one rank that
+    accumulates the four micro-batches."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_worker import global_batch, micro_batches
+    r0, r1 = _run_ranks(tmp_path, "acc2")
+    assert r0["hook_fired_at"] == r1["hook_fired_at"] == [2], r0["hook_fired_at"]
+    assert r0["steps"] == 1
+    gb = global_batch()
+    window = [mb for r in (r0, r1) for mb in micro_batches(gb, r["idx"])]
+    mean_g, flat_p, lr = _single_rank(ref_state_dict, monkeypatch, [window])
+    err_g = float((0.5 * r0["flat_g"] - mean_g).abs().max()) / float(mean_g.abs().max())
+    assert err_g <= 1e-5, err_g
+    assert lr == r0["lr"]
+    assert float((r0["flat_p"] - flat_p).abs().max()) <= 1e-6
+
+
+def test_two_rank_graph_cache_two_steps_different_shapes(tmp_path, ref_state_dict, monkeypatch):
+    """Two consecutive optimisation steps through GraphedStepCache on two ranks, each rank with its own padded shapes in
+    each step (two captures per rank, at different times relative to the peer's collectives): same trajectory as one
+    rank accumulating the shards."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_worker import global_batch, second_batch, shard_batch
+    r0, r1 = _run_ranks(tmp_path, "buckets")
+    assert r0["graphs"] == r1["graphs"] == [2, 2] and r0["misses"] == r1["misses"] == 2
+    assert r0["steps"] == 2
+    gb, gb2 = global_batch(), second_batch()
+    windows = [[shard_batch(gb, r["idx"]) for r in (r0, r1)], [shard_batch(gb2, r["idx2"]) for r in (r0, r1)]]
+    mean_g, flat_p, lr = _single_rank(ref_state_dict, monkeypatch, windows)
+    err_g = float((0.5 * r0["flat_g"] - mean_g).abs().max()) / float(mean_g.abs().max())
+    assert err_g <= 2e-5, err_g
+    assert lr == r0["lr"]
+    assert float((r0["flat_p"] - flat_p).abs().max()) <= 2e-6
+
+
+def test_bench_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher around it (what the driver's scaling run executes): the command
+    re-execs itself under torch.distributed.run, both ranks run the two-graph step with the all-reduce between the
+    replays, rank 0 prints exactly one JSON line, last.  STYLER_TEST_SHARED_GPU puts both ranks on cuda:0 over gloo (a 1-GPU
+    box; RCCL refuses two ranks on one device): the control flow is the N > 1 path, the number is not a scaling figure."""
+    import json
+    env = dict(os.environ, STYLER_TEST_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu", "--no-aux", "--repeat", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    json_lines = [l for l in lines if l.lstrip().startswith("{")]
+    assert len(json_lines) == 1 and lines[-1] == json_lines[0], lines[-5:]
+    rec = json.loads(json_lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["config"]["graphs"] == 2 and rec["config"]["allreduce_world"] == 2
+    assert rec["config"]["parallelism"] == "dp2" and rec["value"] > 0
+    assert abs(rec["per_gpu"] * 2 - rec["value"]) <= 1.0
