@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--prof-steps", type=int, default=3, help="extra eager steps with HIP-event GEMM brackets")
     ap.add_argument("--aux", action="store_true", help="(default on) kept for compatibility")
     ap.add_argument("--no-aux", action="store_true", help="skip the aux legs (fp32-mode train step, config-2 forward)")
+    ap.add_argument("--no-hbm", action="store_true", help="skip the HBM-bound kernel rooflines (roofline.hbm)")
     ap.add_argument("--repeat", type=int, default=4, help="extra timed blocks of --steps steps (spread diagnostic)")
     ap.add_argument("--shape", default="vctk", choices=["vctk", "c4"],
                     help="vctk: src_len~U{20..60}, D~U{2..13} (C1-C3); c4: long-form S=300, T=2000 (eval forward only)")
@@ -205,8 +206,9 @@ def _family(gsum, key, name, traffic_label, prec, ps):
     peak = MFMA_PEAK_TFLOPS[prec]
     d = gsum.get(key, {"launches": 0, "flops": 0.0, "ms": 1.0})
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["launches"] else 0.0
+    traffic, source = pmc_traffic(traffic_label, prec)
     return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(traffic_label, prec),
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": source,
             "launches_per_step": d["launches"] // ps, "avg_launch_us": round(d["ms"] * 1e3 / max(1, d["launches"]), 2),
             "kernel_ms_per_step": round(d["ms"] / ps, 3)}
 
@@ -225,6 +227,212 @@ def roofline_of(gsum, train, prec, ps):
         name = ("wgrad_tr_kernel<KW,TA,TB>" if prec == "bf16" else "wgrad_kernel<KW>") + " (all tap counts, stand-alone launches)"
         r["weight_gradient"] = _family(gsum, wg, name, "train_wgrad_bf16", prec, ps)
     return r
+
+
+HBM_PEAK_TBS = 8.0                                        # MI355X_MICROARCH.md: HBM3E, ~8 TB/s
+
+
+def _graph_loop_us(make_call, nsets, reps=4, replays=3):
+    """Average duration (us) of one launch of a memory-bound entry point, cold in the 256 MB Infinity Cache: `make_call(i)`
+    returns a closure over the i-th of `nsets` disjoint operand sets (their total footprint exceeds the cache, so no launch
+    finds its operands resident from the previous one); the reps x nsets launches are captured into ONE hipGraph (no host
+    enqueue gaps between 10-20 us kernels) and the replay is bracketed by HIP events on its stream."""
+    from styler_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    calls = [make_call(i) for i in range(nsets)]
+    keep = []
+    # as inside a training step: statistics workspaces come from ONE slab cleared once per graph (not a memset per launch),
+    # LayerNorm's parameter-gradient slots are folded later by the step's multi-tensor reduce (not timed here)
+    slab, arena = ops.ZeroSlab(), ops.WgradArena()
+    arena.buf = torch.empty(4, device=dev)
+    ops.zero_slab, ops.wgrad_arena = slab, arena
+    try:
+        slab.begin(dev)
+        for c in calls:
+            keep.append(c())
+        torch.cuda.synchronize()
+        keep.clear()
+        slab.total *= reps
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                slab.begin(dev)
+                for _ in range(reps):
+                    for c in calls:
+                        keep.append(c())        # outputs stay alive through the capture: every launch writes its own block
+            g.replay()
+            side.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            for _ in range(replays):
+                g.replay()
+            e1.record(side)
+            side.synchronize()
+        torch.cuda.current_stream().wait_stream(side)
+    finally:
+        ops.zero_slab, ops.wgrad_arena = None, None
+    us = e0.elapsed_time(e1) * 1e3 / (replays * reps * nsets)
+    del g, keep
+    return us
+
+
+def hbm_rooflines(dev, B, S, T, frames, tag):
+    """Achieved HBM-side rate of the memory-bound kernels north_star names (LengthRegulator, LayerNorm) and of the other
+    normalisation kernels of the step, measured in THIS process.  `bytes` = the COMPULSORY traffic of one launch (every
+    operand read once, every result written once, in the storage types the bf16-mode step uses; SURVEY 8d's per-position
+    figures where the kernel moves exactly those), `frac` = bytes / avg_us / 8 TB/s.  Operand sets rotate so that the
+    working set exceeds the Infinity Cache (`_graph_loop_us`)."""
+    from styler_amd import ops
+    out = []
+    g = torch.Generator().manual_seed(7)
+
+    def nsets_for(nbytes):
+        return int(max(2, min(16, -(-(640 << 20) // max(1, nbytes)))))
+
+    def add(kernel, shape, nbytes, make_call, survey=None):
+        us = _graph_loop_us(make_call, nsets_for(nbytes))
+        rec = {"kernel": kernel, "shape": shape, "bytes": int(nbytes), "avg_us": round(us, 2),
+               "achieved_TBs": round(nbytes / us / 1e6, 3), "frac": round(nbytes / us / 1e6 / HBM_PEAK_TBS, 4)}
+        if survey:
+            rec["bytes_model"] = survey
+        out.append(rec)
+
+    # LengthRegulator (modules.py:396-423): write 5120 B per output frame (zero fill included) + read 5120 B per phoneme
+    d = torch.randint(2, 14, (B, S), generator=g) if tag != "c4" else torch.randint(5, 9, (B, S), generator=g)
+    csum, _, _ = ops.duration_scan(B, S, dev, dur=d.to(dev))
+    lr_bytes = B * T * 5120 + B * S * 5120 + B * S * 4
+    xs = [torch.randn(B, S, 1280, device=dev) for _ in range(nsets_for(lr_bytes))]
+    add("length_regulate_kernel", f"[B={B},S={S}]->[T={T}] x 1280 ch fp32", lr_bytes,
+        lambda i: (lambda: ops.length_regulate(xs[i], csum, T)), "5120 B/frame written + 5120 B/phoneme read (SURVEY 8d)")
+    dys = [torch.randn(B, T, 1280, device=dev) for _ in range(nsets_for(lr_bytes))]
+    add("length_regulate_bwd_kernel", f"[B={B},T={T}]->[S={S}] x 1280 ch fp32", lr_bytes,
+        lambda i: (lambda: ops.length_regulate_bwd(dys[i], csum, S)), "5120 B/frame read + 5120 B/phoneme written")
+    del xs, dys
+    if tag == "c4":
+        return out
+    # LayerNorm at the decoder's row count (clean + noisy decode packed: 2 x valid frames)
+    rows = 2 * frames
+    gam, bet = torch.randn(256, device=dev), torch.randn(256, device=dev)
+    n = nsets_for(rows * 4096)
+    a = [torch.randn(1, rows, 256, device=dev) for _ in range(n)]
+    r = [torch.randn(1, rows, 256, device=dev) for _ in range(n)]
+    so = [torch.empty(1, rows, 256, device=dev) for _ in range(n)]
+    yo = [torch.empty(1, rows, 256, device=dev) for _ in range(n)]
+    add("add_layernorm_kernel (train: x + res -> y, pre-norm sum kept)", f"rows={rows} x 256 fp32", rows * 4096,
+        lambda i: (lambda: ops.add_layernorm(a[i], gam, bet, res=r[i], sum_out=so[i], out=yo[i])),
+        "2 reads + 2 writes of 1 KB per row (eval form: 3072 B/pos, SURVEY 8d)")
+    dg, db = torch.zeros(256, device=dev), torch.zeros(256, device=dev)
+    add("layernorm_bwd_kernel (s, dy -> dx)", f"rows={rows} x 256 fp32", rows * 3072,
+        lambda i: (lambda: ops.layernorm_bwd(a[i], r[i], gam, bet, dg, db)), "2 reads + 1 write of 1 KB per row")
+    del a, r, so, yo
+    # GroupNorm + ReLU of the AudioEncoder (main + DAT pass stacked: 2B items), C = 320, fp32 conv output -> bf16
+    Bg, C = 2 * B, 320
+    gnb = Bg * T * C
+    n = nsets_for(gnb * 6)
+    gx = [torch.randn(Bg, T, C, device=dev) for _ in range(n)]
+    gy = [torch.empty(Bg, T, C, device=dev, dtype=torch.bfloat16) for _ in range(n)]
+    gst = [torch.empty(Bg, C // 16, 2, device=dev) for _ in range(n)]
+    ggam, gbet = torch.randn(C, device=dev), torch.randn(C, device=dev)
+    add("gn_fused_kernel (GroupNorm + ReLU, single pass)", f"[{Bg},{T},{C}] fp32 -> bf16", gnb * 6,
+        lambda i: (lambda: ops.groupnorm_relu(gx[i], ggam, gbet, out=gy[i], stats=gst[i])),
+        "1 read (4 B) + 1 write (2 B) per element; SURVEY 8d's two-pass figure is 2 reads + 1 write")
+    gdy = [torch.randn(Bg, T, C, device=dev).to(torch.bfloat16) for _ in range(n)]
+    for i in range(n):
+        ops.groupnorm_relu(gx[i], ggam, gbet, out=gy[i], stats=gst[i])
+    gdg, gdb = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    add("gn_bwd_fused_kernel", f"[{Bg},{T},{C}] x fp32 + dy bf16 -> dx bf16", gnb * 8,
+        lambda i: (lambda: ops.groupnorm_relu_bwd(gx[i], gdy[i], ggam, gbet, gst[i], gdg, gdb, dx_bf16=True)),
+        "x read once (4 B), dy read once (2 B), dx written (2 B)")
+    del gx, gy, gdy
+    # PostNet BatchNorm (train statistics) + tanh + dropout, clean + noisy mel as two segments
+    rows_b, Cb = 2 * B * T, 512
+    n = nsets_for(rows_b * Cb * 10)
+    bx = [torch.randn(B * 2, T, Cb, device=dev) for _ in range(n)]
+    bgam, bbet = torch.randn(Cb, device=dev), torch.randn(Cb, device=dev)
+    add("bn_colstats + bn_apply (BatchNorm train + tanh + dropout)", f"[{rows_b},{Cb}] fp32 -> bf16, 2 segments",
+        rows_b * Cb * 10,
+        lambda i: (lambda: ops.batchnorm_train(bx[i], bgam, bbet, None, None, ops.ACT_TANH, 0.5, 11, segs=2, out_bf16=True)),
+        "2 reads of x (statistics, then apply) + 1 write (SURVEY 8d)")
+    del bx
+    return out
+
+
+def forward_c4(args, dev, steps=5):
+    """BASELINE config 4 (synthetic long form: B = 128, S = 300, T = 2000, eval mode), both ways SURVEY 8d asks for:
+    teacher-forced (durations given: the LengthRegulator stress, replayed from a hipGraph) and free-running
+    (synthesize.py:348-349: durations predicted, rounded on the device, T from one host read as in the reference -- eager).
+    Random-init weights predict log-durations around 0, i.e. empty mels; the duration head's bias is set to log(7.67) and
+    its weight scaled by 1/4 so that the free-running durations fall in 5..9 frames per phoneme (sum ~ 2000 per item)."""
+    import math
+    import styler_amd
+    from styler_amd import rt
+    from closed_form import make_batch
+    torch.manual_seed(0)
+    model = styler_amd.STYLER().to(dev).eval()
+    with torch.no_grad():
+        head = model.style_modeling.duration_predictor.linear_layer
+        head.weight.mul_(0.25)
+        head.bias.fill_(math.log(7.67))
+    rt.weights_epoch += 1
+    rt.set_precision(args.prec)
+    rt.strict_inputs = False
+    B = 128
+    batch = make_batch(B, 300, 300, 5, 8, seed=4321, fix_src=300, fix_mel=2000)
+    bd = {k: v.to(dev) for k, v in batch.items()}
+    S, T = bd["text"].shape[1], bd["mel_target"].shape[1]
+
+    def teacher():
+        return model(bd["text"], bd["mel_target"], bd["mel_aug"], bd["f0_norm"], bd["energy_input"], bd["src_len"],
+                     bd["mel_len"], bd["D"], bd["f0"], bd["energy"], S, T, speaker_embed=bd["speaker_embed"])
+
+    def free():
+        return model(bd["text"], bd["mel_target"], bd["mel_target"], bd["f0_norm"], bd["energy_input"], bd["src_len"],
+                     bd["mel_len"], None, None, None, S, None, speaker_embed=bd["speaker_embed"])
+
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    res = {"workload": f"C4: STYLER.forward eval, dual branch, B={B}, S={S}, T={T} (synthetic long form)", "dtype": args.prec,
+           "steps": steps}
+    with torch.no_grad():
+        for _ in range(2):
+            teacher()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            teacher()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            teacher()
+        g.replay()
+        ms = timed(g.replay, steps)
+        fr = int(batch["mel_len"].sum())
+        res["teacher_forced"] = {"ms_per_step": round(ms, 3), "valid_frames": fr, "value": round(fr / ms * 1e3, 1),
+                                 "launch": "hipGraph replay"}
+        del g
+        out = free()
+        torch.cuda.synchronize()
+        mel_len = out[7]
+        fr = int(mel_len.sum().item())
+        for _ in range(2):
+            free()
+        ms = timed(free, steps)
+        res["free_running"] = {"ms_per_step": round(ms, 3), "valid_frames": fr, "T": int(out[0][0].shape[1]),
+                               "frames_per_phoneme": round(fr / float(B * S), 3), "value": round(fr / ms * 1e3, 1),
+                               "launch": "eager (one host read of max(mel_len) per forward, as modules.py:360)"}
+    res["hbm"] = hbm_rooflines(dev, B, S, T, int(batch["mel_len"].sum()), "c4")
+    del model
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -284,6 +492,13 @@ def main():
                 aux[name] = {k: r[k] for k in ("value", "ms_per_step", "workload", "dtype", "launch", "roofline") if k in r}
                 aux[name]["steps"] = args.steps
         args.steps, args.warmup, args.repeat = keep
+        if world == 1 and args.mode == "train" and args.shape == "vctk":
+            aux["forward_c4"] = forward_c4(args, dev)
+    hbm = None
+    if rank == 0 and world == 1 and not args.no_hbm and args.shape == "vctk":
+        from closed_form import make_batch
+        b0 = make_batch(args.batch, 20, 60, 2, 13, seed=1234)
+        hbm = hbm_rooflines(dev, args.batch, b0["text"].shape[1], b0["mel_target"].shape[1], int(b0["mel_len"].sum()), "c3")
     if rank == 0:
         cfg = {"workload": main_res["workload"], "launch": main_res["launch"], "graphs": main_res["graphs"],
                "parallelism": f"dp{world}", "host_enqueue_ms_per_step": main_res.get("host_enqueue_ms_per_step")}
@@ -297,6 +512,8 @@ def main():
             "data": "synthetic (seeded VCTK-shape batch, random-init weights)",
             "config": cfg, "repeat": main_res.get("repeat"),
             "roofline": main_res.get("roofline"), "cpu_baseline": main_res.get("cpu_baseline")}
+        if hbm is not None and line["roofline"] is not None:
+            line["roofline"]["hbm"] = hbm
         if aux:
             line["aux"] = aux
     # The JSON line must be the LAST line of the job's stdout.  RCCL writes a version banner to the C-level stdout of every
@@ -316,17 +533,20 @@ def pmc_traffic(want, prec):
     (tools/pmc_run.sh -> tools/pmc_traffic.py, committed as profiles/r02_pmc_traffic.jsonl for the kernels of THIS round;
     FETCH_SIZE doubled per the gfx950 correction).  PMC collection cannot run inside the timed process, so the figure is
     read from that file; null when the file has no record for the kernel or was taken for another precision."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.jsonl")
-    if prec != "bf16" or not os.path.exists(path):
-        return None
-    for line in open(path):
-        try:
-            rec = json.loads(line)
-        except ValueError:
+    if prec != "bf16":
+        return None, None
+    for name in ("r03_pmc_traffic.jsonl", "r02_pmc_traffic.jsonl"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
             continue
-        if rec.get("label") == want:
-            return rec["traffic_bytes_per_launch"]
-    return None
+        for line in open(path):
+            try:
+                rec = json.loads(line)
+            except ValueError:
+                continue
+            if rec.get("label") == want:
+                return rec["traffic_bytes_per_launch"], f"committed file profiles/{name} (separate rocprofv3 --pmc pass of this command)"
+    return None, None
 
 
 def cpu_baseline(model, batch, S, T, clean_only, sample_items=16, thread_counts=(16, 32, 64), train=False):
