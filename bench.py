@@ -291,8 +291,8 @@ def hbm_rooflines(dev, B, S, T, frames, tag):
     def nsets_for(nbytes):
         return int(max(2, min(16, -(-(640 << 20) // max(1, nbytes)))))
 
-    def add(kernel, shape, nbytes, make_call, survey=None):
-        us = _graph_loop_us(make_call, nsets_for(nbytes))
+    def add(kernel, shape, nbytes, make_call, survey=None, nsets=None):
+        us = _graph_loop_us(make_call, nsets or nsets_for(nbytes))
         rec = {"kernel": kernel, "shape": shape, "bytes": int(nbytes), "avg_us": round(us, 2),
                "achieved_TBs": round(nbytes / us / 1e6, 3), "frac": round(nbytes / us / 1e6 / HBM_PEAK_TBS, 4)}
         if survey:
@@ -325,7 +325,7 @@ def hbm_rooflines(dev, B, S, T, frames, tag):
         "2 reads + 2 writes of 1 KB per row (eval form: 3072 B/pos, SURVEY 8d)")
     dg, db = torch.zeros(256, device=dev), torch.zeros(256, device=dev)
     add("layernorm_bwd_kernel (s, dy -> dx)", f"rows={rows} x 256 fp32", rows * 3072,
-        lambda i: (lambda: ops.layernorm_bwd(a[i], r[i], gam, bet, dg, db)), "2 reads + 1 write of 1 KB per row")
+        lambda i: (lambda: ops.layernorm_bwd(a[i], r[i], gam, bet, dg, db)), "2 reads + 1 write of 1 KB per row", nsets=n)
     del a, r, so, yo
     # GroupNorm + ReLU of the AudioEncoder (main + DAT pass stacked: 2B items), C = 320, fp32 conv output -> bf16
     Bg, C = 2 * B, 320
@@ -344,7 +344,7 @@ def hbm_rooflines(dev, B, S, T, frames, tag):
     gdg, gdb = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
     add("gn_bwd_fused_kernel", f"[{Bg},{T},{C}] x fp32 + dy bf16 -> dx bf16", gnb * 8,
         lambda i: (lambda: ops.groupnorm_relu_bwd(gx[i], gdy[i], ggam, gbet, gst[i], gdg, gdb, dx_bf16=True)),
-        "x read once (4 B), dy read once (2 B), dx written (2 B)")
+        "x read once (4 B), dy read once (2 B), dx written (2 B)", nsets=n)
     del gx, gy, gdy
     # PostNet BatchNorm (train statistics) + tanh + dropout, clean + noisy mel as two segments
     rows_b, Cb = 2 * B * T, 512
