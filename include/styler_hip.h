@@ -112,6 +112,14 @@ int styler_conv_gemm_pad(const float* x, int64_t ldx, const void* w, const float
 /* Which tile engine styler_conv_gemm dispatches for a shape: bit0 = 128x128 block tile (else
  * 64x64), bit1 = bf16 MFMA (else fp32 MFMA).  Used by bench.py to attribute launches. */
 int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, int prec);
+/* The engine a styler_conv_gemm call with these arguments runs on: 0..3 = styler_conv_gemm_variant, 4 = the
+ * 256 x 256 eight-wave LDS-DMA engine (csrc/gemm256.hip: bf16 MFMA mode, x stored as bf16 -- io_flags &
+ * STYLER_IO_X_BF16 --, cin % 64 == 0, at least 1.5 tiles of 256 x 256 per CU).  Same arithmetic either way: both
+ * engines accumulate the same v_mfma_f32_32x32x16_bf16 sequence, results are bit-equal. */
+int styler_conv_gemm_engine(int B, int L, int cin, int n, int kw, int prec, int io_flags, int64_t ldx);
+/* Test / tuning hook of that engine: enabled (0 / 1) and the smallest tile count it takes; -1 keeps a value (defaults:
+ * STYLER_GEMM256, STYLER_GEMM256_MIN_TILES or 1, 384).  Returns the previous state as enabled | min_tiles << 1. */
+int styler_gemm256_config(int enabled, int min_tiles);
 /* Measurement hook (tools/gemm_trace.py): while `buf` is non-null every styler_conv_gemm block writes 8 uint64 words at
  * buf[8 * blockIdx]: block, then 100 MHz timestamps at entry / first tile staged / main loop done / stores issued /
  * stores acknowledged, the hardware id register and the tile index.  Pass NULL to switch it off (the default). */
@@ -176,12 +184,14 @@ int styler_attention_bwd_bf16(const float* qkv, const float* out, const float* d
  * in_drop_p > 0 (train mode) applies dropout to x BEFORE the residual add -- the nn.Dropout of
  * SubLayers.py:58,86 -- with the stream styler_dropout(x [B*L, 256], seed in_drop_seed) would draw;
  * sum_out (optional) receives the pre-norm sum dropout(x) + res that styler_layernorm_bwd consumes
- * (defined on unmasked rows only). */
+ * (defined on unmasked rows only).  y16 (optional, with y): a second copy of y as bf16 (round to nearest even; zeros on
+ * masked rows) for the GEMMs that consume it as their activation operand (styler_conv_gemm with STYLER_IO_X_BF16). */
 int styler_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldres,
                          const float* gamma, const float* beta, float* y, int64_t ldy,
                          const float* dot_w, const float* dot_b, float* dot_out, int B, int L,
                          int C, const int64_t* len, float drop_p, uint64_t drop_seed, float in_drop_p,
-                         uint64_t in_drop_seed, float* sum_out, int64_t ldsum, void* stream);
+                         uint64_t in_drop_seed, float* sum_out, int64_t ldsum, uint16_t* y16, int64_t ldy16,
+                         void* stream);
 
 /* y = relu(GroupNorm(x)) with groups of 16 channels and statistics over 16 ch x the whole
  * padded L (modules.py:103-113,171-175; eps 1e-5).  In place allowed (y == x).

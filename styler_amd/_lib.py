@@ -19,6 +19,7 @@ _SIGS = {
     "styler_conv_gemm_pad": [P, I64, P, P, P, P, I64, P, I64, I, I, I, I, I, I, I, I, P],
     "styler_leaky_sum": [P, P, P, P, I64, F, F, P],
     "styler_conv_gemm_variant": [I, I, I, I, I, I],
+    "styler_conv_gemm_engine": [I, I, I, I, I, I, I, I64],
     "styler_gemm_set_trace": [P],
     "styler_wave_sum_selftest": [P, P, P, I, P],
     "styler_cast_bf16": [P, P, I64, P],
@@ -26,7 +27,7 @@ _SIGS = {
     "styler_attention_fwd": [P, P, P, I, I, P, P, P],
     "styler_attention_fwd_bf16": [P, P, P, I, I, P, P, P],
     "styler_attention_bwd_bf16": [P, P, P, P, P, P, I, I, P, P, I, P],
-    "styler_add_layernorm": [P, I64, P, I64, P, P, P, I64, P, P, P, I, I, I, P, F, ctypes.c_uint64, F, ctypes.c_uint64, P, I64, P],
+    "styler_add_layernorm": [P, I64, P, I64, P, P, P, I64, P, P, P, I, I, I, P, F, ctypes.c_uint64, F, ctypes.c_uint64, P, I64, P, I64, P],
     "styler_groupnorm_relu": [P, I64, P, P, P, I64, P, P, I, I, I, I, I, P],
     "styler_bn_fold": [P, P, P, P, P, P, P, I, P],
     "styler_batchnorm_train": [P, P, P, P, P, P, P, P, P, I, I64, I, I, F, ctypes.c_uint64, I, I, P],
@@ -66,6 +67,7 @@ _SIGS = {
     "styler_repack_weight_bwd": [P, P, I, I, I, I, P],
     "styler_attention_bwd": [P, P, P, P, P, P, I, I, P, P, P],
     "styler_layernorm_bwd": [P, I64, P, I64, P, P, P, I64, P, P, P, P, P, P, I, I, I, P, F, ctypes.c_uint64, F, ctypes.c_uint64, P, I64, I, I, P],
+    "styler_gemm256_config": [I, I],
     "styler_fold_replicas": [P, P, P, P, P, P, I, I, P],
     "styler_groupnorm_relu_bwd": [P, I64, P, I64, P, P, P, P, I64, P, P, P, I, I, I, I, I, P],
     "styler_batchnorm_bwd": [P, P, P, P, P, P, P, P, P, P, I, I64, I, I, P, F, ctypes.c_uint64, I, I, P],

@@ -115,13 +115,16 @@ class LayerNormFn(Function):
         return dx, (dx if ctx.has_res else None), None, None, None, None
 
 
-def _ln_tail_fwd(o, x, ln, lens, drop_p):
-    """dropout(o) + x -> LayerNorm -> pad mask in one kernel; returns (y, pre-norm sum, (p, seed))."""
+def _ln_tail_fwd(o, x, ln, lens, drop_p, want16=False):
+    """dropout(o) + x -> LayerNorm -> pad mask in one kernel; returns (y, pre-norm sum, (p, seed)) -- and with `want16` a
+    fourth value, the bf16 copy of y for the GEMM that consumes it."""
     drop_p = 0.0 if rt.disable_dropout else drop_p
     seed = next_dropout_seed() if drop_p > 0 else 0
     s = torch.empty_like(x)
-    y = ops.add_layernorm(o, ln.weight, ln.bias, res=x, lens=lens, in_drop_p=drop_p, in_drop_seed=seed, sum_out=s)
-    return y, s, (drop_p, seed)
+    y16 = torch.empty_like(x, dtype=torch.bfloat16) if want16 else None
+    y = ops.add_layernorm(o, ln.weight, ln.bias, res=x, lens=lens, in_drop_p=drop_p, in_drop_seed=seed, sum_out=s,
+                          out16=y16)
+    return (y, s, (drop_p, seed), y16) if want16 else (y, s, (drop_p, seed))
 
 
 def _ln_tail_bwd(s, dy, ln, lens, drop):
@@ -140,13 +143,15 @@ class FfnSublayerFn(Function):
     autograd accumulation kernel)."""
 
     @staticmethod
-    def forward(ctx, x, anchor, ffn, lens, plan, drop_p):
+    def forward(ctx, x, anchor, ffn, lens, plan, drop_p, x16=None):
         kw1, kw2 = ffn.w_1.weight.shape[2], ffn.w_2.weight.shape[2]
         w1, p1 = gemm_weight(ffn._derived, "w_1", ffn.w_1.weight, x.shape[-1])
         # throughput mode: the hidden activation (and its gradient in backward) live in HBM as bf16 -- they are only ever
         # consumed as bf16 MFMA operands or as a sign mask, so this changes no result and halves the widest tensors
         h16 = p1 == ops.PREC_BF16 and ffn.w_1.weight.shape[0] % 8 == 0
-        h = ops.conv_gemm(x, w1, ffn.w_1.bias, kw=kw1, n=ffn.w_1.weight.shape[0], act=RELU, prec=p1, plan=plan,
+        # x16: the bf16 copy of x written by the LayerNorm that produced it (same values the GEMM would round x to)
+        xa = x16 if (x16 is not None and p1 == ops.PREC_BF16) else x
+        h = ops.conv_gemm(xa, w1, ffn.w_1.bias, kw=kw1, n=ffn.w_1.weight.shape[0], act=RELU, prec=p1, plan=plan,
                           out_bf16=h16)
         w2, p2 = gemm_weight(ffn._derived, "w_2", ffn.w_2.weight, h.shape[-1])
         o = ops.conv_gemm(h, w2, ffn.w_2.bias, kw=kw2, n=ffn.w_2.weight.shape[0], prec=p2, plan=plan)
@@ -171,7 +176,7 @@ class FfnSublayerFn(Function):
         ops.wgrad(dh, x, G(w_1.weight), d_hid, d_in, kw=kw1, db=G(w_1.bias), plan=plan)
         dx = ops.conv_gemm(dh, gemm_weight_bwd(ffn._derived, "w_1", w_1.weight, bf16), None, kw=kw1, n=d_in, prec=prec,
                            plan=plan, res=dx_res)
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 class AttnSublayerFn(Function):
@@ -179,7 +184,7 @@ class AttnSublayerFn(Function):
     projection, dropout, + x, LayerNorm, pad mask; the residual's gradient is added in the epilogue of the QKV dX GEMM."""
 
     @staticmethod
-    def forward(ctx, x, anchor, mha, lens, plan, drop_p):
+    def forward(ctx, x, anchor, mha, lens, plan, drop_p, want16=False):
         w, b, prec = mha._qkv()
         qkv = ops.conv_gemm(x, w, b, n=768, prec=prec, plan=plan)
         B, L = (plan.B, plan.T) if plan is not None else x.shape[:2]
@@ -187,13 +192,20 @@ class AttnSublayerFn(Function):
         att = ops.attention_fwd(qkv, lens, lse=lse, plan=plan)
         wfc, pfc = gemm_weight(mha._derived, "fc", mha.fc.weight, 256)
         o = ops.conv_gemm(att, wfc, mha.fc.bias, n=256, prec=pfc, plan=plan)
-        y, s, ctx.drop = _ln_tail_fwd(o, x, mha.layer_norm, lens, drop_p)
+        want16 = want16 and prec == ops.PREC_BF16
+        if want16:
+            y, s, ctx.drop, y16 = _ln_tail_fwd(o, x, mha.layer_norm, lens, drop_p, want16=True)
+        else:
+            y, s, ctx.drop = _ln_tail_fwd(o, x, mha.layer_norm, lens, drop_p)
         ctx.save_for_backward(x, qkv, att, lse, s, lens)
         ctx.mha, ctx.plan = mha, plan
+        if want16:
+            ctx.mark_non_differentiable(y16)
+            return y, y16
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         x, qkv, att, lse, s, lens = ctx.saved_tensors
         mha, plan = ctx.mha, ctx.plan
         dx_res, d_o = _ln_tail_bwd(s, ops._rows_view(dy), mha.layer_norm, lens, ctx.drop)
@@ -209,7 +221,7 @@ class AttnSublayerFn(Function):
         wt = mha._derived.get_spec("qkv_wT16" if bf16 else "qkv_wT", (256, 768), bf16,
                                    lambda: [seg_transposed(w, k * 256, 768) for k, w in enumerate(srcs)])
         dx = ops.conv_gemm(dqkv, wt, None, n=256, prec=prec, plan=plan, res=dx_res)
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 class LayerNormDotFn(Function):

@@ -1,0 +1,468 @@
+// 256 x 256 implicit-GEMM Conv1d / Linear engine for gfx950: eight waves, LDS-DMA operand loads, counted vmcnt.
+//
+//   y[m, n] = act(scale[n] * sum_{j<kw, c<cin} x[row(m) + j - pad, c] * w[n, j*cin + c] + shift[n]) (+ res)
+//
+// Same contract as gemm_conv.hip (same GemmArgs, same epilogue features); it takes the launches whose activation operand
+// already lives in HBM as bf16, with cin % 64 == 0 and enough 256 x 256 tiles to fill the chip more than once
+// (styler_gemm256_try).  Replaces: nn.Conv1d / nn.Linear forward and dX (transformer/SubLayers.py:72-89,
+// transformer/Layers.py:78-118, modules.py:103-161).
+//
+// Why a second engine.  The 128 x 128 kernel stages operands through registers (global -> VGPR -> ds_write) and meets a
+// barrier per K step; at 3 blocks per CU that structure tops out at 0.8-1.0 PFLOP/s.  Here:
+//   * block = 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 4 x 2 MFMA tiles of 32 x 32 (v_mfma_f32_32x32x16_bf16): 24
+//     ds_read_b128 feed 32 MFMAs per K step (the 64 x 64 wave tile of the other engine needs 32);
+//   * operands go HBM/L2 -> LDS directly (buffer_load_dwordx4 ... lds): no staging registers, no ds_write pass.  The
+//     convolution is implicit in the per-lane SOURCE address: K step (chunk cc, tap j) reads activation row m + j - pad,
+//     channels cc*64 .. +64; a row that falls outside its own item ('same' zero padding, item boundaries inside the flat
+//     rectangle, rows past M) gets an out-of-range offset and the DMA writes zeros;
+//   * a K step (BK = 64) is four phases, one output quadrant (64 x 32 per wave, 8 MFMAs) each.  The operands of a step are
+//     fetched as four 16 KB UNITS laid out by what a phase consumes -- UB0 / UB1 = the first / second 32 weight rows of
+//     every wave column, UA0 / UA1 = the first / second 64 activation rows of both wave rows -- one unit per phase, one
+//     step ahead, into the other of two LDS stages (128 KB).  A unit is awaited with `s_waitcnt vmcnt(4)`: two younger
+//     units (2 DMA instructions per wave each) stay in flight across the barriers; vmcnt never drains inside the loop;
+//   * the two wave rows run one barrier apart (wr == 1 waits once more before the loop): on every SIMD the wave of one row
+//     issues its 8 MFMAs while the wave of the other row issues ds_reads and DMA -- the matrix pipe alternates between them.
+//
+// LDS image of a unit: 128 rows x 128 B (64 bf16 of K), written linearly by the DMA (lane l of piece p lands at
+// p*1024 + l*16).  Fragment reads take 16 B per lane from 16 rows at once (ds_read_b128 lane groups pair rows r, r+12,
+// r+20..): with the 16-byte chunk index XORed by (row >> 1) & 7 -- applied to the DMA's SOURCE address and to the read
+// address, never to the DMA destination -- every lane group touches 16 distinct 16-byte slots.
+//
+// Ordering rules this file relies on (MI355X_MICROARCH.md, "Two waves per SIMD" item 7):
+//   RAW  a unit is read one phase after the phase in which EVERY wave waited (vmcnt) for its own pieces and then met a barrier;
+//   WAR  a unit is overwritten at least two phases after the phase of its last ds_read (here: four or more).
+#include <cstdlib>
+#include <type_traits>
+#include "gemm_args.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int UNIT_BYTES = 128 * 128;               // 128 rows x 64 bf16
+constexpr int STAGE_BYTES = 4 * UNIT_BYTES;         // UA0, UA1, UB0, UB1
+constexpr int U_A0 = 0, U_A1 = UNIT_BYTES, U_B0 = 2 * UNIT_BYTES, U_B1 = 3 * UNIT_BYTES;
+constexpr int SMEM_BYTES = 2 * STAGE_BYTES;         // 128 KB
+constexpr int CLD = 68;                             // epilogue staging row stride (floats): 64 + 4
+constexpr uint32_t OOB = 0x80000000u;               // beyond every descriptor's num_records (< 2^31)
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t lds_byte, uint32_t voff, char* smem) {
+  // 64 lanes x 16 B -> LDS bytes [lds_byte, lds_byte + 1024), lane l at + 16 l (wave-uniform destination base)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + lds_byte), 16, voff, 0, 0, 0);
+}
+
+template <bool Y16>
+__global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];       // the ONLY LDS object of the kernel
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // ---- XCD-aware tile assignment (as gemm_conv.hip): workgroup b runs on XCD b % 8; an XCD walks the n-tiles of its
+  // m-tile back to back, so the n-tiles that share an activation tile hit the same L2.
+  int mtile, ntile;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, k = bid >> 3;
+    mtile = (k / a.nt) * 8 + xcd;
+    if (mtile >= a.mt) return;
+    ntile = k % a.nt;
+  }
+  const int64_t M = (int64_t)a.B * a.L;
+  const int64_t m0 = (int64_t)mtile * BM;
+  const int n0 = ntile * BN;
+  const int kw = a.kw, pad = a.pad;
+  const int ktot = kw * a.cin;
+  const int ncc = a.cin / BK;
+  const int nsteps = ncc * kw;
+
+  // ---- tiles made only of rows at or past their item's length: zeros (packed rows: nothing behind the data is read) ----
+  if (a.len) {
+    const uint32_t span = (uint32_t)((m0 + BM < M ? m0 + BM : M) - 1 - m0);
+    const uint32_t b0 = (uint32_t)m0 / (uint32_t)a.L, t0 = (uint32_t)m0 - b0 * (uint32_t)a.L;
+    if (t0 + span < (uint32_t)a.L && (int64_t)t0 >= a.len[b0]) {
+      if (a.rowinfo) return;
+      constexpr int QPR = BN / 4;
+      for (int i = tid; i < BM * QPR; i += 512) {
+        const int r = i / QPR, c = n0 + (i - r * QPR) * 4;
+        if (m0 + r < M && c < a.n) {
+          if (Y16) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.y) + (m0 + r) * a.ldy + c) = make_uint2(0u, 0u);
+          else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (m0 + r) * a.ldy + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      return;
+    }
+  }
+
+  // ---- DMA source addresses.  A unit = 16 pieces of 1 KB (8 rows x 128 B); wave w issues pieces w and w + 8.  Lane l of
+  // piece p: unit row i = 8 p + (l >> 3), physical 16-byte chunk l & 7 = logical chunk ^ ((i >> 1) & 7).
+  // UA0 row i -> tile row (i < 64 ? i : 128 + i - 64), UA1: + 64.  UB0 row i -> weight row (i >> 5) * 64 + (i & 31), UB1: + 32.
+  const __amdgpu_buffer_rsrc_t x_rs = [&] {
+    int64_t rec = ((M - 1) * a.ldx + a.cin) * 2;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)(rec > 0x7fffffff ? 0x7fffffff : rec), 0x00020000);
+  }();
+  const __amdgpu_buffer_rsrc_t w_rs = [&] {
+    const int64_t rec = (int64_t)a.n * ktot * 2;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, (int)rec, 0x00020000);
+  }();
+  uint32_t va[2][2];                                  // [unit UA0 / UA1][piece]: byte offset of (row, logical chunk) at tap 0, chunk 0
+  uint32_t tapmask[2][2];                             // bit j: row + j - pad lies inside the row's own item
+  uint32_t vb[2][2];                                  // [unit UB0 / UB1][piece]
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int p = wave + 8 * q;
+    const int i = 8 * p + (lane >> 3);
+    const int cl = (lane & 7) ^ ((i >> 1) & 7);       // logical 16-byte chunk this lane fetches
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int trow = (i < 64 ? i : 64 + i) + 64 * u;
+      const int64_t m = m0 + trow;
+      uint32_t bits = 0;
+      if (m < M) {
+        int t, rem;
+        if (a.rowinfo) { const int2 ri = a.rowinfo[m]; t = ri.x; rem = ri.y; }
+        else { t = (int)((uint32_t)m % (uint32_t)a.L); rem = a.L - 1 - t; }
+        for (int j = 0; j < kw; ++j) {
+          const int o = j - pad;
+          if (o >= -t && o <= rem) bits |= 1u << j;
+        }
+      }
+      tapmask[u][q] = bits;
+      va[u][q] = (uint32_t)((m - pad) * a.ldx * 2 + cl * 16);        // wraps for the rows before row 0: masked by `bits`
+      const int nrow = n0 + (i >> 5) * 64 + (i & 31) + 32 * u;
+      vb[u][q] = nrow < a.n ? (uint32_t)((int64_t)nrow * ktot * 2 + cl * 16) : OOB;
+    }
+  }
+  const uint32_t lds_piece0 = (uint32_t)wave * 1024u, lds_piece1 = (uint32_t)(wave + 8) * 1024u;
+
+  // one unit of K step (cc, j) into stage `st`: 2 DMA instructions per wave
+  auto issue_a = [&](int u, int cc, int j, uint32_t st) {
+    const uint32_t sh = (uint32_t)(j * (int)a.ldx * 2 + cc * (BK * 2));
+    const uint32_t base = st + (u ? U_A1 : U_A0);
+    dma16(x_rs, base + lds_piece0, ((tapmask[u][0] >> j) & 1u) ? va[u][0] + sh : OOB, smem);
+    dma16(x_rs, base + lds_piece1, ((tapmask[u][1] >> j) & 1u) ? va[u][1] + sh : OOB, smem);
+  };
+  auto issue_b = [&](int u, int cc, int j, uint32_t st) {
+    const uint32_t sh = (uint32_t)((j * a.cin + cc * BK) * 2);
+    const uint32_t base = st + (u ? U_B1 : U_B0);
+    dma16(w_rs, base + lds_piece0, vb[u][0] == OOB ? OOB : vb[u][0] + sh, smem);
+    dma16(w_rs, base + lds_piece1, vb[u][1] == OOB ? OOB : vb[u][1] + sh, smem);
+  };
+
+  // ---- fragment read addresses: lane (li, lh), MFMA sub-step s (16 of the 64 k): logical chunk 2 s + lh of unit row
+  // base + li; (row >> 1) & 7 == (li >> 1) & 7 because every base is a multiple of 32
+  uint32_t ra[4], rb[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint32_t ch = (uint32_t)(((2 * s + lh) ^ ((li >> 1) & 7)) * 16);
+    ra[s] = (uint32_t)((wr * 64 + li) * 128) + ch;      // + unit + i * 4096 (32 rows) + stage
+    rb[s] = (uint32_t)((wc * 32 + li) * 128) + ch;
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+  // ---- prologue: the four units of step 0 into stage 0 (UB0, UA0 first: phase 0 reads them) ----
+  issue_b(0, 0, 0, 0u);
+  issue_a(0, 0, 0, 0u);
+  issue_b(1, 0, 0, 0u);
+  issue_a(1, 0, 0, 0u);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (wr == 1) {                                      // the second wave row runs one barrier behind the first
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+#define LDS_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
+#define PHASE_SYNC()                         \
+  do {                                       \
+    __builtin_amdgcn_sched_barrier(0);       \
+    __builtin_amdgcn_s_barrier();            \
+    __builtin_amdgcn_sched_barrier(0);       \
+  } while (0)
+
+  int cc = 0, j = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    const uint32_t st = (uint32_t)(step & 1) * STAGE_BYTES;
+    const uint32_t sn = STAGE_BYTES - st;               // the other stage: operands of step + 1
+    int ccn = cc, jn = j + 1;
+    if (jn == kw) { jn = 0; ccn = cc + 1; }
+    const bool more = step + 1 < nsteps;
+    bf16x8 fa[2][4], fb0[4], fb1[4];
+
+    // ---------------- phase 0: rows 0..63 x cols 0..31 of the wave tile ----------------
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fb0[s] = LDS_FRAG(st + U_B0 + rb[s]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) fa[i][s] = LDS_FRAG(st + U_A0 + i * 4096 + ra[s]);
+    if (more) {
+      issue_b(0, ccn, jn, sn);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // UB1(step) landed (UA1(step), UB0(step + 1) may be in flight)
+    } else {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // UB1(step) landed (UA1(step) may be in flight)
+    }
+    PHASE_SYNC();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb0[s], acc[i][0], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    PHASE_SYNC();
+
+    // ---------------- phase 1: rows 0..63 x cols 32..63 ----------------
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fb1[s] = LDS_FRAG(st + U_B1 + rb[s]);
+    if (more) {
+      issue_a(0, ccn, jn, sn);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // UA1(step) landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    PHASE_SYNC();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb1[s], acc[i][1], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    PHASE_SYNC();
+
+    // ---------------- phase 2: rows 64..127 x cols 32..63 ----------------
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) fa[i][s] = LDS_FRAG(st + U_A1 + i * 4096 + ra[s]);
+    if (more) issue_b(1, ccn, jn, sn);                  // nothing new is read in phase 3: no wait here
+    PHASE_SYNC();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[2 + i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb1[s], acc[2 + i][1], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    PHASE_SYNC();
+
+    // ---------------- phase 3: rows 64..127 x cols 0..31 (weight fragments of phase 0 still in registers) ----------------
+    if (more) {
+      issue_a(1, ccn, jn, sn);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // UB0(step + 1), UA0(step + 1) landed: phase 0 of the next step reads them
+    }
+    PHASE_SYNC();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[2 + i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb0[s], acc[2 + i][0], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    PHASE_SYNC();
+    cc = ccn; j = jn;
+  }
+  if (wr == 0) {                                        // catch up with the second wave row
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef LDS_FRAG
+#undef PHASE_SYNC
+  __syncthreads();                                      // every wave is done with the operand stages: LDS becomes the epilogue's
+
+  // ---- epilogue: per wave, one 32-row MFMA tile row (32 x 64) at a time through LDS -> coalesced 16-byte rows ----
+  // C layout of v_mfma_f32_32x32x16: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+  // Tail loads (residual, ReLU mask) are batched ahead of the stores, out-of-range rows / columns are dropped by the buffer
+  // descriptors, the activation is a template argument of the tail (as in gemm_conv.hip).
+  constexpr int LPR = 16;                               // lanes per output row (4 columns each)
+  constexpr int RPP = 4;                                // rows per pass of a wave
+  constexpr int NP = 32 / RPP;                          // passes per tile row = rows per lane per tile row
+  constexpr int Y_ES = Y16 ? 2 : 4;
+  constexpr int64_t REC_MAX = (int64_t)1 << 30;
+  float* cst = reinterpret_cast<float*>(smem) + wave * (32 * CLD);
+  const int lrow = lane / LPR;
+  const int c4 = (lane % LPR) * 4;
+  const int col = n0 + wc * 64 + c4;
+  const bool col_ok = col < a.n;
+  const int wrow0 = wr * 128 + lrow;                    // tile-relative row of this lane's first row
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col_ok) {
+    if (a.scale) sc = *reinterpret_cast<const float4*>(a.scale + col);
+    if (a.shift) sf = *reinterpret_cast<const float4*>(a.shift + col);
+  }
+  const bool res_first = a.act & STYLER_ACT_RES_FIRST;
+  const int actc = a.act & 0xff;
+
+  // bit (8 i + p) of `live`: the lane's row (tile row i, pass p) lies inside its item's length
+  uint32_t live = 0xffffffffu;
+  if (a.len) {
+    live = 0u;
+    if (a.B == 1) {
+      const int64_t lim64 = a.len[0] - m0;
+      const int lim = lim64 > BM ? BM : (lim64 < 0 ? 0 : (int)lim64);
+#pragma unroll
+      for (int q = 0; q < 32; ++q) live |= (uint32_t)(wrow0 + (q >> 3) * 32 + (q & 7) * RPP < lim) << q;
+    } else {
+      const uint32_t Lu = (uint32_t)a.L;
+      const uint32_t b0 = (uint32_t)m0 / Lu, t0 = (uint32_t)m0 - b0 * Lu;
+      for (int q = 0; q < 32; ++q) {
+        const uint32_t nn = t0 + (uint32_t)(wrow0 + (q >> 3) * 32 + (q & 7) * RPP);
+        const uint32_t qq = nn / Lu, r = nn - qq * Lu;
+        uint32_t bi = b0 + qq;
+        bi = bi < (uint32_t)a.B ? bi : (uint32_t)a.B - 1u;
+        live |= (uint32_t)((int)r < reinterpret_cast<const int*>(a.len)[2 * bi]) << q;
+      }
+    }
+  }
+
+  auto tile_rsrc = [&](const void* base, int64_t ld, int es) {
+    int64_t rec = ((M - m0 - 1) * ld + a.n) * es;
+    rec = rec > REC_MAX ? REC_MAX : rec;
+    const char* b = reinterpret_cast<const char*>(base) + m0 * ld * es;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b), 0, (int)rec, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t y_rs = tile_rsrc(a.y, a.ldy, Y_ES);
+  const __amdgpu_buffer_rsrc_t r_rs = tile_rsrc(a.res ? (const void*)a.res : a.y, a.res ? a.ldres : a.ldy, 4);
+  const int m_es = a.mask16 ? 2 : 4;
+  const __amdgpu_buffer_rsrc_t m_rs = tile_rsrc(a.mask ? a.mask : a.y, a.mask ? a.ldmask : a.ldy, a.mask ? m_es : Y_ES);
+  const uint32_t oy0 = col_ok ? (uint32_t)((wrow0 * (int)a.ldy + col) * Y_ES) : OOB;
+  const uint32_t or0 = col_ok ? (uint32_t)((wrow0 * (int)a.ldres + col) * 4) : OOB;
+  const uint32_t om0 = col_ok ? (uint32_t)((wrow0 * (int)a.ldmask + col) * m_es) : OOB;
+  const uint32_t ystep = (uint32_t)(RPP * (int)a.ldy * Y_ES), rstep = (uint32_t)(RPP * (int)a.ldres * 4),
+                 mstep = (uint32_t)(RPP * (int)a.ldmask * m_es);
+
+  auto tail = [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i) __syncthreads();
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cst[((r & 3) + 8 * (r >> 2) + 4 * lh) * CLD + jj * 32 + li] = acc[i][jj][r];
+      __syncthreads();
+      i32x4 rr[NP], mk[NP];
+      if (a.res) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) rr[u] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, or0 + (i * 8 + u) * rstep, 0, 0);
+      }
+      if (a.mask) {
+        if (a.mask16) {
+#pragma unroll
+          for (int u = 0; u < NP; ++u) {
+            const i32x2 t = __builtin_amdgcn_raw_buffer_load_b64(m_rs, om0 + (i * 8 + u) * mstep, 0, 0);
+            mk[u] = i32x4{t.x, t.y, 0, 0};
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < NP; ++u) mk[u] = __builtin_amdgcn_raw_buffer_load_b128(m_rs, om0 + (i * 8 + u) * mstep, 0, 0);
+        }
+      }
+      float4 v[NP];
+#pragma unroll
+      for (int u = 0; u < NP; ++u) v[u] = *reinterpret_cast<const float4*>(&cst[(u * RPP + lrow) * CLD + c4]);
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        float4 w = v[u];
+        if (res_first && a.res) {
+          const float4 q = *reinterpret_cast<const float4*>(&rr[u]);
+          w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w;
+        }
+        w.x = apply_act(w.x * sc.x + sf.x, ACT); w.y = apply_act(w.y * sc.y + sf.y, ACT);
+        w.z = apply_act(w.z * sc.z + sf.z, ACT); w.w = apply_act(w.w * sc.w + sf.w, ACT);
+        if (a.mask) {
+          if (a.mask16) {
+            const uint32_t m0w = (uint32_t)mk[u].x, m1w = (uint32_t)mk[u].y;
+            w.x = (int16_t)(m0w & 0xffffu) > 0 ? w.x : 0.f; w.y = (int16_t)(m0w >> 16) > 0 ? w.y : 0.f;
+            w.z = (int16_t)(m1w & 0xffffu) > 0 ? w.z : 0.f; w.w = (int16_t)(m1w >> 16) > 0 ? w.w : 0.f;
+          } else {
+            const float4 q = *reinterpret_cast<const float4*>(&mk[u]);
+            w.x = q.x > 0.f ? w.x : 0.f; w.y = q.y > 0.f ? w.y : 0.f;
+            w.z = q.z > 0.f ? w.z : 0.f; w.w = q.w > 0.f ? w.w : 0.f;
+          }
+        }
+        if (a.res && !res_first) {
+          const float4 q = *reinterpret_cast<const float4*>(&rr[u]);
+          w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w;
+        }
+        if (!((live >> (i * 8 + u)) & 1u)) w = make_float4(0.f, 0.f, 0.f, 0.f);
+        // rows of this lane: wrow0 + 32 i + 4 u  ==  wrow0 + RPP * (8 i + u)
+        if (Y16) {
+          const i32x2 o = {(int)cvt_pk_bf16_rne(w.x, w.y), (int)cvt_pk_bf16_rne(w.z, w.w)};
+          __builtin_amdgcn_raw_buffer_store_b64(o, y_rs, oy0 + (i * 8 + u) * ystep, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const i32x4*>(&w), y_rs, oy0 + (i * 8 + u) * ystep, 0, 0);
+        }
+      }
+    }
+  };
+  switch (actc) {
+    case STYLER_ACT_RELU: tail(std::integral_constant<int, STYLER_ACT_RELU>{}); break;
+    case STYLER_ACT_TANH: tail(std::integral_constant<int, STYLER_ACT_TANH>{}); break;
+    case STYLER_ACT_LOGCLAMP: tail(std::integral_constant<int, STYLER_ACT_LOGCLAMP>{}); break;
+    case STYLER_ACT_LEAKY: tail(std::integral_constant<int, STYLER_ACT_LEAKY>{}); break;
+    case STYLER_ACT_CRELU: tail(std::integral_constant<int, STYLER_ACT_CRELU>{}); break;
+    default: tail(std::integral_constant<int, STYLER_ACT_NONE>{}); break;
+  }
+}
+
+}  // namespace
+
+// Eligibility: bf16 MFMA mode with the activation operand stored as bf16, whole 64-channel chunks, 16-byte aligned rows,
+// every byte offset below 2^31, and at least `min_tiles` 256 x 256 tiles (default 1.5 per CU: below that a launch is one
+// partial round of 8-wave blocks and the 128 x 128 engine's 3 blocks per CU fill the chip better).  STYLER_GEMM256=0
+// switches the engine off, STYLER_GEMM256_MIN_TILES overrides the bound.
+static int g_enabled = [] { const char* e = getenv("STYLER_GEMM256"); return e ? atoi(e) : 1; }();
+static int g_min_tiles = [] { const char* e = getenv("STYLER_GEMM256_MIN_TILES"); return e ? atoi(e) : 384; }();
+
+// Test / tuning hook: set the switch and the tile bound (-1 keeps a value); returns the previous state as
+// enabled | min_tiles << 1.
+extern "C" int styler_gemm256_config(int enabled, int min_tiles) {
+  const int prev = (g_enabled ? 1 : 0) | (g_min_tiles << 1);
+  if (enabled >= 0) g_enabled = enabled;
+  if (min_tiles >= 0) g_min_tiles = min_tiles;
+  return prev;
+}
+
+static bool gemm256_eligible(int B, int L, int cin, int n, int kw, int64_t ldx, int x16, int* mt_out, int* nt_out) {
+  const int enabled = g_enabled, min_tiles = g_min_tiles;
+  if (!enabled || !x16) return false;
+  if ((cin % BK) || (ldx & 7) || (n & 3) || kw > 9) return false;
+  const int64_t M = (int64_t)B * L;
+  const int mt = (int)((M + BM - 1) / BM), nt = (n + BN - 1) / BN;
+  if ((int64_t)mt * nt < min_tiles) return false;
+  if ((n % BN) > 0 && (n % BN) < 192) return false;                // a mostly empty last column tile wastes its MFMAs
+  if (((M + 8) * ldx * 2) >= ((int64_t)1 << 31) || ((int64_t)n * kw * cin * 2) >= ((int64_t)1 << 31)) return false;
+  *mt_out = mt; *nt_out = nt;
+  return true;
+}
+
+int styler_gemm256_try(const GemmArgs& a0, int x16, int y16, hipStream_t st) {
+  int mt, nt;
+  if (a0.trace || !gemm256_eligible(a0.B, a0.L, a0.cin, a0.n, a0.kw, a0.ldx, x16, &mt, &nt)) return 0;
+  GemmArgs a = a0;
+  a.mt = mt; a.nt = nt;
+  const dim3 grid((unsigned)(((mt + 7) / 8) * 8 * nt));
+  if (y16) hipLaunchKernelGGL(conv_gemm256_kernel<true>, grid, dim3(512), 0, st, a);
+  else hipLaunchKernelGGL(conv_gemm256_kernel<false>, grid, dim3(512), 0, st, a);
+  const int rc = launch_status();
+  return rc ? (rc < 0 ? rc : -rc) : 1;
+}
+
+// Which engine / tile a styler_conv_gemm call with these arguments runs on: 0..3 = styler_conv_gemm_variant (bit 0: 128 x 128
+// tile, bit 1: bf16 MFMA), 4 = the 256 x 256 LDS-DMA engine of this file.
+extern "C" int styler_conv_gemm_engine(int B, int L, int cin, int n, int kw, int prec, int io_flags, int64_t ldx) {
+  int mt, nt;
+  if (prec == STYLER_PREC_BF16 && gemm256_eligible(B, L, cin, n, kw, ldx, io_flags & STYLER_IO_X_BF16, &mt, &nt)) return 4;
+  return styler_conv_gemm_variant(B, L, cin, n, kw, prec);
+}

@@ -1,0 +1,26 @@
+// Argument block shared by the two MFMA GEMM / implicit-conv engines (gemm_conv.hip: 128x128 / 64x64 tiles, register-staged
+// operands; gemm256.hip: 256x256 tile, eight waves, LDS-DMA operand loads).
+#pragma once
+#include "common.h"
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+struct GemmArgs {
+  const void* x; int64_t ldx;                      // fp32, or bf16 with the A16 kernels (ldx in elements either way)
+  const void* w;
+  const float* scale; const float* shift;
+  const float* res; int64_t ldres;
+  void* y; int64_t ldy;                            // fp32, or bf16 with the Y16 kernels
+  int B, L, cin, n, kw, act, pad;
+  const int64_t* len;
+  int mt, nt;                                      // tile counts
+  const int2* rowinfo;                             // packed rows (styler_pack_plan): (t, len - 1 - t) per row, or null
+  const void* mask; int64_t ldmask;                // epilogue: v = mask[row, col] > 0 ? v : 0 (ReLU backward), or null
+  int mask16;                                      // the mask tensor is bf16
+  uint64_t* trace;                                 // styler_gemm_set_trace: 8 words per block (phase timestamps), or null
+};
+
+// gemm256.hip: returns 1 when the 256x256 LDS-DMA engine takes the launch (and has enqueued it), 0 when the shape is not
+// eligible, < 0 on a launch error.
+int styler_gemm256_try(const GemmArgs& a, int x16, int y16, hipStream_t st);

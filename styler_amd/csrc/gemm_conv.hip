@@ -27,23 +27,7 @@
 #include <type_traits>
 #include "common.h"
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x2 __attribute__((ext_vector_type(2)));
-
-struct GemmArgs {
-  const void* x; int64_t ldx;                      // fp32, or bf16 with the A16 kernels (ldx in elements either way)
-  const void* w;
-  const float* scale; const float* shift;
-  const float* res; int64_t ldres;
-  void* y; int64_t ldy;                            // fp32, or bf16 with the Y16 kernels
-  int B, L, cin, n, kw, act, pad;
-  const int64_t* len;
-  int mt, nt;                                      // tile counts
-  const int2* rowinfo;                             // packed rows (styler_pack_plan): (t, len - 1 - t) per row, or null
-  const void* mask; int64_t ldmask;                // epilogue: v = mask[row, col] > 0 ? v : 0 (ReLU backward), or null
-  int mask16;                                      // the mask tensor is bf16
-  uint64_t* trace;                                 // styler_gemm_set_trace: 8 words per block (phase timestamps), or null
-};
+#include "gemm_args.h"
 
 // Phase timestamps (constant 100 MHz counter, s_memrealtime) of every block of the launches that follow
 // styler_gemm_set_trace(buf): [block, entry, first tile staged, main loop done, stores issued, stores acknowledged,
@@ -602,6 +586,10 @@ int styler_conv_gemm_impl2(const float* x, int64_t ldx, const void* w, const flo
   GemmArgs a{x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, act, pad, len, 0, 0,
              reinterpret_cast<const int2*>(rowinfo), mask, ldmask, m16 ? 1 : 0, g_gemm_trace};
   hipStream_t st = (hipStream_t)stream;
+  if (prec == STYLER_PREC_BF16) {                  // large launches on bf16 activations: the 256 x 256 LDS-DMA engine (gemm256.hip)
+    const int r = styler_gemm256_try(a, x16, y16, st);
+    if (r) return r < 0 ? r : 0;
+  }
   const bool big = styler_conv_gemm_variant(B, L, cin, n, kw, prec) & 1;
   if (prec == STYLER_PREC_BF16) return big ? launch_gemm<2, 2, true>(a, st, x16, y16) : launch_gemm<1, 1, true>(a, st, x16, y16);
   return big ? launch_gemm<2, 2, false>(a, st, x16, y16) : launch_gemm<1, 1, false>(a, st, x16, y16);

@@ -10,7 +10,8 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, int64_t ldy,
     const float* __restrict__ dot_w, const float* __restrict__ dot_b, float* __restrict__ dot_out, int64_t rows,
     int L, const int64_t* __restrict__ len, float drop_p, uint64_t drop_seed_host, const uint64_t* __restrict__ epoch,
-    float in_drop_p, uint64_t in_drop_seed_host, float* __restrict__ sum_out, int64_t ldsum) {
+    float in_drop_p, uint64_t in_drop_seed_host, float* __restrict__ sum_out, int64_t ldsum, uint16_t* __restrict__ y16,
+    int64_t ldy16) {
   const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -22,6 +23,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
   }
   if (masked) {
     if (y) *reinterpret_cast<float4*>(y + row * ldy + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y16) *reinterpret_cast<uint2*>(y16 + row * ldy16 + lane * 4) = make_uint2(0u, 0u);
     if (dot_out && lane == 0) dot_out[row] = 0.f;
     return;                                              // (sum_out is only read back on unmasked rows)
   }
@@ -59,6 +61,9 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
     o.w = dropout_hash32(drop_seed, e + 3) >= thr ? o.w * sc : 0.f;
   }
   if (y) *reinterpret_cast<float4*>(y + row * ldy + lane * 4) = o;
+  // y16: a second copy of the output as bf16 (round to nearest even) for the GEMMs that consume it -- they round their
+  // activation operand to bf16 anyway, so results do not change; the 256 x 256 engine (gemm256.hip) DMAs it straight into LDS
+  if (y16) *reinterpret_cast<uint2*>(y16 + row * ldy16 + lane * 4) = make_uint2(cvt_pk_bf16_rne(o.x, o.y), cvt_pk_bf16_rne(o.z, o.w));
   if (dot_out) {
     const float4 w = *reinterpret_cast<const float4*>(dot_w + lane * 4);
     const float d = wave_sum(o.x * w.x + o.y * w.y + o.z * w.z + o.w * w.w);
@@ -70,8 +75,10 @@ extern "C" int styler_add_layernorm(const float* x, int64_t ldx, const float* re
                                     const float* gamma, const float* beta, float* y, int64_t ldy,
                                     const float* dot_w, const float* dot_b, float* dot_out, int B, int L, int C,
                                     const int64_t* len, float drop_p, uint64_t drop_seed, float in_drop_p,
-                                    uint64_t in_drop_seed, float* sum_out, int64_t ldsum, void* stream) {
+                                    uint64_t in_drop_seed, float* sum_out, int64_t ldsum, uint16_t* y16, int64_t ldy16,
+                                    void* stream) {
   if (!x || !gamma || !beta || (!y && !dot_out) || B <= 0 || L <= 0) return STYLER_EINVAL;
+  if (y16 && ((ldy16 & 3) || ((uintptr_t)y16 & 7))) return STYLER_EALIGN;
   if (C != 256) return STYLER_EINVAL;
   if (dot_out && (!dot_w || !dot_b)) return STYLER_EINVAL;
   if ((ldx & 3) || (res && (ldres & 3)) || (y && (ldy & 3)) || (sum_out && (ldsum & 3))) return STYLER_EALIGN;
@@ -79,7 +86,7 @@ extern "C" int styler_add_layernorm(const float* x, int64_t ldx, const float* re
   const int64_t rows = (int64_t)B * L;
   hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
                      ldx, res, ldres, gamma, beta, y, ldy, dot_w, dot_b, dot_out, rows, L, len, drop_p, drop_seed,
-                     g_styler_drop_epoch, in_drop_p, in_drop_seed, sum_out, ldsum);
+                     g_styler_drop_epoch, in_drop_p, in_drop_seed, sum_out, ldsum, y16, ldy16);
   return launch_status();
 }
 

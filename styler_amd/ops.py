@@ -372,7 +372,7 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
                                   _stream()), "styler_conv_gemm")
     if prof is not None:
         e1.record()
-        prof.records.append((lib.styler_conv_gemm_variant(B, L, cin, n, kw, prec), 2.0 * B * L * n * kw * cin,
+        prof.records.append((lib.styler_conv_gemm_engine(B, L, cin, n, kw, prec, io, _ld(x)), 2.0 * B * L * n * kw * cin,
                              e0, e1, plan is not None))
     return out
 
@@ -429,6 +429,14 @@ def cast_bf16(src):
     return dst
 
 
+def gemm256_config(enabled=-1, min_tiles=-1):
+    """Test / tuning hook of the 256 x 256 LDS-DMA GEMM engine (csrc/gemm256.hip): switch it on / off and set the tile
+    count from which it takes a launch (-1 keeps a value).  Returns the previous (enabled, min_tiles)."""
+    prev = lib.styler_gemm256_config(-1, -1)
+    lib.styler_gemm256_config(int(enabled), int(min_tiles))
+    return prev & 1, prev >> 1
+
+
 def _prec(prec):
     if prec is None:
         from .runtime import rt
@@ -451,9 +459,10 @@ def attention_fwd(qkv, lens, lse=None, prec=None, plan=None):
 
 
 def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, dot_b=None, drop_p=0.0, drop_seed=0,
-                  in_drop_p=0.0, in_drop_seed=0, sum_out=None):
+                  in_drop_p=0.0, in_drop_seed=0, sum_out=None, out16=None):
     """LayerNorm(dropout(x) + res) with pad-mask; with dot_w returns the [B, L] scalar head instead.  `sum_out`
-    (optional) receives the pre-norm sum (what layernorm_bwd needs)."""
+    (optional) receives the pre-norm sum (what layernorm_bwd needs); `out16` (optional, a bf16 [B, L, C] tensor) a second
+    copy of the output rounded to bf16, for the GEMMs that take it as their activation operand."""
     B, L, C = x.shape
     dot_out = None
     if dot_w is not None:
@@ -465,7 +474,7 @@ def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, 
                                   _ld(out) if out is not None else 0, _ptr(dot_w), _ptr(dot_b),
                                   _ptr(dot_out), B, L, C, _ptr(lens), float(drop_p), int(drop_seed), float(in_drop_p),
                                   int(in_drop_seed), _ptr(sum_out), _ld(sum_out) if sum_out is not None else 0,
-                                  _stream()),
+                                  _ptr(out16), _ld(out16) if out16 is not None else 0, _stream()),
          "styler_add_layernorm")
     return dot_out if dot_w is not None else out
 

@@ -46,6 +46,10 @@ class _Runtime:
     # throughput mode: the attention backward writes dqkv as bf16 (read as bf16 by the QKV dX GEMM and the weight gradients;
     # STYLER_BF16_DQKV=0: fp32)
     bf16_dqkv = os.environ.get("STYLER_BF16_DQKV", "1") != "0"
+    # throughput mode: the LayerNorm that closes an attention sublayer also writes its output as bf16, and the FFN's k = 9
+    # convolution takes that copy as its activation operand (it rounds the operand to bf16 anyway: same results) -- which
+    # is what lets the 256 x 256 LDS-DMA engine (csrc/gemm256.hip) fetch it straight into LDS
+    ln_bf16_copy = os.environ.get("STYLER_LN_BF16_COPY", "1") != "0"
 
     # each StylePredictor stage (conv -> ReLU -> LayerNorm -> dropout [-> Linear -> mask]) as one tape node whose backward
     # is one LayerNorm-backward kernel + weight gradient + dX GEMM (STYLER_FUSED_PREDICTOR=0: separate nodes)

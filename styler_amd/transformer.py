@@ -79,22 +79,32 @@ class MultiHeadAttention(_HipModule):
                        lambda: [seg_rows(u, k * 256) for k, u in enumerate(srcs_w)])
         return w, b, ops.PREC_BF16 if bf16 else ops.PREC_F32
 
-    def forward(self, x, lens, out=None, plan=None):
+    def forward(self, x, lens, out=None, plan=None, want16=False):
         """x [B, L, 256]; lens int64 [B]; returns LayerNorm(dropout(fc(attn)) + x) with padded rows zeroed
         (the masked_fill of Layers.py:29 is fused into the LayerNorm kernel).  With `plan` (ops.PackPlan) x is the
-        packed [1, B*T, 256] tensor and lens = plan.nrows."""
+        packed [1, B*T, 256] tensor and lens = plan.nrows.  `want16` (throughput mode): returns (y, y16) -- y16 the bf16
+        copy of y the LayerNorm kernel writes for the FFN's first convolution (None when not produced)."""
         grad = (self.training and torch.is_grad_enabled())
         drop = self.training and self.dropout.p > 0
+        asked = want16                                        # the caller unpacks a pair whenever it asked for one
+        want16 = want16 and rt.prec == ops.PREC_BF16 and rt.ln_bf16_copy
+        y16 = None
         if grad:                                              # the whole sublayer is one tape node
-            return AG.AttnSublayerFn.apply(x, self.w_qs.weight, self, lens, plan, self.dropout.p)
-        else:
-            w, b, prec = self._qkv()
-            ctx = ops.attention_fwd(ops.conv_gemm(x, w, b, n=768, prec=prec, plan=plan), lens, plan=plan)
-        if grad or drop:                                      # dropout + residual + LayerNorm + mask: one kernel
-            return self._ln(self._gemm("fc", ctx, self.fc, plan=plan), x, self.layer_norm, lens, out,
-                            drop_p=self.dropout.p if self.training else 0.0)
+            y = AG.AttnSublayerFn.apply(x, self.w_qs.weight, self, lens, plan, self.dropout.p, want16)
+            if want16:
+                y, y16 = y
+            return (y, y16) if asked else y
+        w, b, prec = self._qkv()
+        ctx = ops.attention_fwd(ops.conv_gemm(x, w, b, n=768, prec=prec, plan=plan), lens, plan=plan)
+        if drop:                                              # dropout + residual + LayerNorm + mask: one kernel
+            y = self._ln(self._gemm("fc", ctx, self.fc, plan=plan), x, self.layer_norm, lens, out,
+                         drop_p=self.dropout.p if self.training else 0.0)
+            return (y, None) if asked else y
         o = self._gemm("fc", ctx, self.fc, res=x, plan=plan)  # eval: residual rides in the GEMM epilogue
-        return ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out)
+        if want16:
+            y16 = torch.empty_like(o, dtype=torch.bfloat16)
+        y = ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out, out16=y16)
+        return (y, y16) if asked else y
 
 
 class PositionwiseFeedForward(_HipModule):
@@ -108,11 +118,14 @@ class PositionwiseFeedForward(_HipModule):
         self.layer_norm = nn.LayerNorm(d_in)
         self.dropout = nn.Dropout(dropout)
 
-    def forward(self, x, lens, out=None, plan=None):
+    def forward(self, x, lens, out=None, plan=None, x16=None):
+        """`x16` (optional): the bf16 copy of x (MultiHeadAttention.forward(want16=True)) -- the k = 9 convolution reads it
+        instead of x (same values after the operand rounding)."""
         k = hp.fft_conv1d_kernel_size
         if self.training and torch.is_grad_enabled():        # the whole sublayer is one tape node
-            return AG.FfnSublayerFn.apply(x, self.w_1.weight, self, lens, plan, self.dropout.p)
-        h = self._gemm("w_1", x, self.w_1, kw=k[0], act=ops.ACT_RELU, plan=plan, out_bf16=True)   # bf16 in throughput mode
+            return AG.FfnSublayerFn.apply(x, self.w_1.weight, self, lens, plan, self.dropout.p, x16)
+        xa = x16 if (x16 is not None and rt.prec == ops.PREC_BF16) else x
+        h = self._gemm("w_1", xa, self.w_1, kw=k[0], act=ops.ACT_RELU, plan=plan, out_bf16=True)   # bf16 in throughput mode
         if (self.training and torch.is_grad_enabled()) or (self.training and self.dropout.p > 0):
             return self._ln(self._gemm("w_2", h, self.w_2, kw=k[1], plan=plan), x, self.layer_norm, lens, out,
                             drop_p=self.dropout.p if self.training else 0.0)
@@ -129,7 +142,8 @@ class FFTBlock(nn.Module):
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, dropout=dropout)
 
     def forward(self, x, lens, out=None, plan=None):
-        return self.pos_ffn(self.slf_attn(x, lens, plan=plan), lens, out=out, plan=plan)
+        a, a16 = self.slf_attn(x, lens, plan=plan, want16=True)
+        return self.pos_ffn(a, lens, out=out, plan=plan, x16=a16)
 
 
 class _PositionMixin:

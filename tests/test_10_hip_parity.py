@@ -89,6 +89,113 @@ def test_conv_gemm_epilogue_and_slices(dev):
     assert float(outwide[..., :256].min()) == -7.0 and float(outwide[..., 512:].max()) == -7.0
 
 
+GEMM256_CASES = {
+    # name: (B, L, cin, n, kw, lens, act, y_bf16, with_res, with_mask)
+    "ffn_k9_relu_bf16_out_ragged": (3, 520, 256, 1024, 9, [520, 401, 77], 1, True, False, False),
+    "postnet_k5_res_fp32_out": (2, 700, 512, 512, 5, None, 0, False, True, False),
+    "ffn_k1_dx_relu_mask": (2, 600, 1024, 256, 1, None, 0, False, False, True),
+    "single_k_step": (2, 300, 64, 256, 1, [300, 123], 2, False, False, False),
+    "n_tail_448_k3": (2, 333, 128, 448, 3, [333, 5], 0, False, True, False),
+    "one_row_items_k9": (5, 1, 64, 256, 9, None, 0, False, False, False),
+}
+
+
+def _conv_ref64(x, w, kw, lens=None):
+    """fp64 'same' conv of [B, L, cin] with w [n, cin, kw], zero padded per item; rows t >= lens[b] are inputs like any other
+    (the callers hand in zeros there), the OUTPUT mask is applied by the caller."""
+    return F.conv1d(x.double().transpose(1, 2), w.double(), None, padding=kw // 2).transpose(1, 2)
+
+
+@pytest.mark.parametrize("case", sorted(GEMM256_CASES))
+def test_gemm256_engine_vs_math_and_vs_128_engine(dev, case):
+    """The 256 x 256 eight-wave LDS-DMA engine (csrc/gemm256.hip): (a) against fp64 math on the bf16-rounded operands,
+    (b) bit for bit against the 128 x 128 engine (both accumulate the same v_mfma_f32_32x32x16_bf16 sequence), (c) the same
+    bits on repeated launches (its LDS hand-offs are ordered by counted vmcnt + barriers: a race would show up as a
+    flicker).  Conv taps at item boundaries, ragged lengths, rows past M inside a tile, a partial column tile, a single
+    K step, every epilogue input."""
+    from styler_amd import ops
+    B, L, cin, n, kw, lens, act, y16, with_res, with_mask = GEMM256_CASES[case]
+    g = torch.Generator().manual_seed(sum(map(ord, case)))
+    x = torch.randn(B, L, cin, generator=g)
+    if lens is not None:
+        x = x * (torch.arange(L)[None, :, None] < torch.tensor(lens)[:, None, None])
+    x16 = x.to(torch.bfloat16)
+    w = (torch.randn(n, cin, kw, generator=g) / np.sqrt(cin * kw))
+    w16 = w.to(torch.bfloat16)
+    b = torch.randn(n, generator=g)
+    res = torch.randn(B, L, n, generator=g) if with_res else None
+    mask = torch.randn(B, L, n, generator=g).to(torch.bfloat16) if with_mask else None
+    ref = _conv_ref64(x16.float(), w16.float(), kw) + b.double()
+    ref = {0: ref, 1: torch.relu(ref), 2: torch.tanh(ref)}[act]
+    if mask is not None:
+        ref = ref * (mask.double() > 0)
+    if res is not None:
+        ref = ref + res.double()
+    if lens is not None:
+        ref = ref * (torch.arange(L)[None, :, None] < torch.tensor(lens)[:, None, None])
+    wk = w16.permute(0, 2, 1).reshape(n, -1).contiguous().to(dev)
+    args = dict(kw=kw, act=act, prec=ops.PREC_BF16, res=res.to(dev) if with_res else None,
+                lens=torch.tensor(lens).to(dev) if lens is not None else None, mask=mask.to(dev) if with_mask else None,
+                out_bf16=y16)
+    xd, bd = x16.to(dev), b.to(dev)
+    prev = ops.gemm256_config(1, 1)
+    try:
+        assert ops.lib.styler_conv_gemm_engine(B, L, cin, n, kw, ops.PREC_BF16, 1, cin) == 4
+        ys = [ops.conv_gemm(xd, wk, bd, **args).clone() for _ in range(4)]
+        ops.gemm256_config(0, -1)
+        assert ops.lib.styler_conv_gemm_engine(B, L, cin, n, kw, ops.PREC_BF16, 1, cin) != 4
+        y128 = ops.conv_gemm(xd, wk, bd, **args)
+    finally:
+        ops.gemm256_config(*prev)
+    tol = 1e-2 if y16 else 1e-4                       # bf16 output: 2^-9 relative rounding of values up to ~4
+    e = float((ys[0].double().cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert e <= tol, f"{case}: max err / max|ref| = {e:.3e}"
+    for k, y in enumerate(ys[1:]):
+        assert torch.equal(y, ys[0]), f"{case}: launch {k + 1} differs from launch 0 (LDS hand-off race?)"
+    assert torch.equal(ys[0], y128), f"{case}: 256 engine != 128 engine, max diff {float((ys[0].float() - y128.float()).abs().max()):.3e}"
+
+
+def test_gemm256_engine_packed_rows(dev):
+    """The engine on the decoder's packed-rows layout (ops.PackPlan): taps stop at item boundaries (rowinfo), tiles behind
+    the data are skipped, rows at or past the device row counter are written as zeros."""
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(77)
+    B, T, cin, n, kw = 4, 300, 256, 256, 9
+    lens = torch.tensor([300, 211, 40, 1])
+    xs = torch.randn(B, T, cin, generator=g) * (torch.arange(T)[None, :, None] < lens[:, None, None])
+    w16 = (torch.randn(n, cin, kw, generator=g) / np.sqrt(cin * kw)).to(torch.bfloat16)
+    ref = _conv_ref64(xs.to(torch.bfloat16).float(), w16.float(), kw) * (torch.arange(T)[None, :, None] < lens[:, None, None])
+    plan = ops.PackPlan(lens.to(dev), B, T)
+    xp = ops.pack_rows(xs.to(dev), plan).to(torch.bfloat16)
+    wk = w16.permute(0, 2, 1).reshape(n, -1).contiguous().to(dev)
+    prev = ops.gemm256_config(1, 1)
+    try:
+        yp = [ops.conv_gemm(xp, wk, None, kw=kw, prec=ops.PREC_BF16, plan=plan).clone() for _ in range(3)]
+        ops.gemm256_config(0, -1)
+        y128 = ops.conv_gemm(xp, wk, None, kw=kw, prec=ops.PREC_BF16, plan=plan)
+    finally:
+        ops.gemm256_config(*prev)
+    nvalid = int(lens.sum())
+    assert torch.equal(yp[0][:, :nvalid], y128[:, :nvalid]) and torch.equal(yp[0][:, :nvalid], yp[1][:, :nvalid]) \
+        and torch.equal(yp[0][:, :nvalid], yp[2][:, :nvalid])
+    y = ops.unpack_rows(yp[0], plan)
+    check(y, ref.float(), 1e-4 * float(ref.abs().max()), "packed rows")
+
+
+def test_layernorm_bf16_copy(dev):
+    """styler_add_layernorm's second output: the bf16 copy is the round-to-nearest-even of the fp32 output, zeros on masked
+    rows (what the FFN's first convolution reads in throughput mode)."""
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(8)
+    B, L = 3, 61
+    x, r = torch.randn(B, L, 256, generator=g) * 2, torch.randn(B, L, 256, generator=g)
+    ga, be = torch.randn(256, generator=g), torch.randn(256, generator=g)
+    lens = torch.tensor([61, 9, 30]).to(dev)
+    y16 = torch.full((B, L, 256), 7.0, device=dev, dtype=torch.bfloat16)
+    y = ops.add_layernorm(x.to(dev), ga.to(dev), be.to(dev), res=r.to(dev), lens=lens, out16=y16)
+    assert torch.equal(y16, y.to(torch.bfloat16))
+
+
 @pytest.mark.parametrize("B,L,lens", [(2, 24, [24, 17]), (3, 200, [200, 130, 1]), (1, 333, [333]), (2, 64, [64, 33])])
 def test_attention(dev, B, L, lens):
     from styler_amd import ops
