@@ -176,15 +176,19 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
   issue_a(0, 0, 0, 0u);
   issue_b(1, 0, 0, 0u);
   issue_a(1, 0, 0, 0u);
+#define LDS_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
+  bf16x8 fbA[4], fbB[4];                              // phase-0 weight fragments of the current / the next step
+#pragma unroll
+  for (int s = 0; s < 4; ++s) fbA[s] = LDS_FRAG(U_B0 + rb[s]);
   if (wr == 1) {                                      // the second wave row runs one barrier behind the first
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
 
-#define LDS_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
 #define PHASE_SYNC()                         \
   do {                                       \
     __builtin_amdgcn_sched_barrier(0);       \
@@ -192,18 +196,19 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);       \
   } while (0)
 
+  // One K step, stage parity PAR (compile time).  Fragment reads per LOAD segment: 8 / 4 / 8 / 4 (the weight fragments of
+  // phase 0 are read one phase early, in phase 3 of the step before, into the other of two register sets).
+  // DMA issue order: L(t,0) UB0(t+1), L(t,1) UA0(t+1), L(t,2) UB1(t+1), L(t,3) UA1(t+1); every wait is vmcnt(4) = "all but
+  // the two youngest units": L(t,0) -> UB1(t), L(t,1) -> UA1(t), L(t,2) -> UB0(t+1), L(t,3) -> UA0(t+1).
   int cc = 0, j = 0;
-  for (int step = 0; step < nsteps; ++step) {
-    const uint32_t st = (uint32_t)(step & 1) * STAGE_BYTES;
-    const uint32_t sn = STAGE_BYTES - st;               // the other stage: operands of step + 1
+  auto k_step = [&](auto par_tag, bf16x8 (&fbc)[4], bf16x8 (&fbn)[4], const bool more) {
+    constexpr uint32_t st = decltype(par_tag)::value * STAGE_BYTES;
+    constexpr uint32_t sn = STAGE_BYTES - st;           // the other stage: operands of step + 1
     int ccn = cc, jn = j + 1;
     if (jn == kw) { jn = 0; ccn = cc + 1; }
-    const bool more = step + 1 < nsteps;
-    bf16x8 fa[2][4], fb0[4], fb1[4];
+    bf16x8 fa[2][4], fb1[4];
 
     // ---------------- phase 0: rows 0..63 x cols 0..31 of the wave tile ----------------
-#pragma unroll
-    for (int s = 0; s < 4; ++s) fb0[s] = LDS_FRAG(st + U_B0 + rb[s]);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb0[s], acc[i][0], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fbc[s], acc[i][0], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     PHASE_SYNC();
 
@@ -246,7 +251,10 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int s = 0; s < 4; ++s) fa[i][s] = LDS_FRAG(st + U_A1 + i * 4096 + ra[s]);
-    if (more) issue_b(1, ccn, jn, sn);                  // nothing new is read in phase 3: no wait here
+    if (more) {
+      issue_b(1, ccn, jn, sn);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // UB0(step + 1) landed: phase 3 reads the next step's weight fragments
+    }
     PHASE_SYNC();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -256,20 +264,30 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
     __builtin_amdgcn_s_setprio(0);
     PHASE_SYNC();
 
-    // ---------------- phase 3: rows 64..127 x cols 0..31 (weight fragments of phase 0 still in registers) ----------------
+    // ---------------- phase 3: rows 64..127 x cols 0..31 (this step's phase-0 weight fragments, still in registers) ----------------
     if (more) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) fbn[s] = LDS_FRAG(sn + U_B0 + rb[s]);
       issue_a(1, ccn, jn, sn);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // UB0(step + 1), UA0(step + 1) landed: phase 0 of the next step reads them
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // UA0(step + 1) landed: phase 0 of the next step reads it
     }
     PHASE_SYNC();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[2 + i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb0[s], acc[2 + i][0], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[2 + i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fbc[s], acc[2 + i][0], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     PHASE_SYNC();
     cc = ccn; j = jn;
+  };
+  {
+    int step = 0;
+    for (; step + 1 < nsteps; step += 2) {
+      k_step(std::integral_constant<uint32_t, 0>{}, fbA, fbB, true);
+      k_step(std::integral_constant<uint32_t, 1>{}, fbB, fbA, step + 2 < nsteps);
+    }
+    if (step < nsteps) k_step(std::integral_constant<uint32_t, 0>{}, fbA, fbB, false);
   }
   if (wr == 0) {                                        // catch up with the second wave row
     __builtin_amdgcn_sched_barrier(0);

@@ -20,6 +20,7 @@ SHAPES = [  # name, B, L, cin, n, kw, y_bf16
     ("c4_ffn_w1_k9 (8000 tiles)", 1, 512000, 256, 1024, 9, True),
     ("c4_postnet_512_k5 (4000 tiles)", 256, 2000, 512, 512, 5, False),
     ("c4_aenc_256_k5 (1000 tiles)", 128, 2000, 256, 256, 5, False),
+    ("overhead probe: 1 K step, 8000 tiles", 1, 512000, 64, 1024, 1, True),
     ("square 4096 (256 tiles)", 1, 4096, 4096, 4096, 1, False),
     ("square 8192 x 4096 (512 tiles)", 1, 8192, 4096, 4096, 1, False),
 ]
