@@ -18,10 +18,13 @@ def onehot_weight(cache, key, w):
 
 
 def lstm_wi_transposed(cache, key, wi, wir):
-    """[cin, 8H] = transposed cat of the two directions' input weights (dX of the fused input projection)."""
+    """[cin, 8H] = transposed cat of the two directions' input weights (dX of the fused input projection); a bf16 shadow in
+    throughput mode (rt.lstm_dx_bf16), like the dX weight of every other Linear.  Returns (weight, precision)."""
     n4, cin = wi.shape
-    return cache.get_spec(key, (cin, 2 * n4), False,
-                          lambda: [seg_transposed(wi, 0, 2 * n4), seg_transposed(wir, n4, 2 * n4)])
+    bf16 = rt.prec == ops.PREC_BF16 and rt.lstm_dx_bf16 and (2 * n4) % 8 == 0 and cin % 4 == 0
+    w = cache.get_spec(key + ("16" if bf16 else ""), (cin, 2 * n4), bf16,
+                       lambda: [seg_transposed(wi, 0, 2 * n4), seg_transposed(wir, n4, 2 * n4)])
+    return w, (ops.PREC_BF16 if bf16 else ops.PREC_F32)
 
 NONE, RELU, TANH = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_TANH
 
@@ -469,8 +472,8 @@ class LstmLayerFn(Function):
         if ctx.needs_input_grad[0]:
             names = [f"weight_ih_l{layer}", f"weight_ih_l{layer}_reverse"]
             srcs = [getattr(lstm, n) for n in names]
-            wt = lstm_wi_transposed(ctx.enc._derived, ctx.key + "wiT", srcs[0], srcs[1])
-            dx = ops.conv_gemm(dgp, wt, None, n=cin)
+            wt, wp = lstm_wi_transposed(ctx.enc._derived, ctx.key + "wiT", srcs[0], srcs[1])
+            dx = ops.conv_gemm(dgp, wt, None, n=cin, prec=wp)
         return dx, None, None, None, None, None, None
 
 
@@ -512,8 +515,8 @@ class LstmMultiLayerFn(Function):
             dx = None
             if ctx.needs_input_grad[3 + s]:
                 srcs = [getattr(lstm, f"weight_ih_l{layer}"), getattr(lstm, f"weight_ih_l{layer}_reverse")]
-                wt = lstm_wi_transposed(enc._derived, f"lstm{s}_{layer}wiT", srcs[0], srcs[1])
-                dx = ops.conv_gemm(dgp, wt, None, n=cin)
+                wt, wp = lstm_wi_transposed(enc._derived, f"lstm{s}_{layer}wiT", srcs[0], srcs[1])
+                dx = ops.conv_gemm(dgp, wt, None, n=cin, prec=wp)
             dxs.append(dx)
         return (None, None, None, *dxs)
 

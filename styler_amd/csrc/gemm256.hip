@@ -437,11 +437,13 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
 }  // namespace
 
 // Eligibility: bf16 MFMA mode with the activation operand stored as bf16, whole 64-channel chunks, 16-byte aligned rows,
-// every byte offset below 2^31, and at least `min_tiles` 256 x 256 tiles (default 1.5 per CU: below that a launch is one
-// partial round of 8-wave blocks and the 128 x 128 engine's 3 blocks per CU fill the chip better).  STYLER_GEMM256=0
-// switches the engine off, STYLER_GEMM256_MIN_TILES overrides the bound.
+// every byte offset below 2^31, at least 8 K steps and at least `min_tiles` 256 x 256 tiles.  Measured against the
+// 128 x 128 engine on the same bf16 operands (tools/gemm256_bench.py, profiles/r03_gemm256_bench.txt): x1.15 at 424 tiles
+// (FFN k = 9, M = 27 060), x1.02-1.06 at 166-848 tiles, x1.11-1.17 at 1000-8000 tiles (config 4), x1.55 on a square
+// 4096^3 GEMM (1.26 PFLOP/s); x0.92-0.96 at 106 tiles (N = 256 at M = 27 060: fewer tiles than CUs) -- hence the bound of
+// 160.  STYLER_GEMM256=0 switches the engine off, STYLER_GEMM256_MIN_TILES overrides the bound (styler_gemm256_config at run time).
 static int g_enabled = [] { const char* e = getenv("STYLER_GEMM256"); return e ? atoi(e) : 1; }();
-static int g_min_tiles = [] { const char* e = getenv("STYLER_GEMM256_MIN_TILES"); return e ? atoi(e) : 384; }();
+static int g_min_tiles = [] { const char* e = getenv("STYLER_GEMM256_MIN_TILES"); return e ? atoi(e) : 160; }();
 
 // Test / tuning hook: set the switch and the tile bound (-1 keeps a value); returns the previous state as
 // enabled | min_tiles << 1.
@@ -458,7 +460,7 @@ static bool gemm256_eligible(int B, int L, int cin, int n, int kw, int64_t ldx, 
   if ((cin % BK) || (ldx & 7) || (n & 3) || kw > 9) return false;
   const int64_t M = (int64_t)B * L;
   const int mt = (int)((M + BM - 1) / BM), nt = (n + BN - 1) / BN;
-  if ((int64_t)mt * nt < min_tiles) return false;
+  if ((int64_t)mt * nt < min_tiles || (cin / BK) * kw < 8) return false;   // short K: prologue + epilogue dominate a 1-block-per-CU tile
   if ((n % BN) > 0 && (n % BN) < 192) return false;                // a mostly empty last column tile wastes its MFMAs
   if (((M + 8) * ldx * 2) >= ((int64_t)1 << 31) || ((int64_t)n * kw * cin * 2) >= ((int64_t)1 << 31)) return false;
   *mt_out = mt; *nt_out = nt;

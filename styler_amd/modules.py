@@ -150,7 +150,12 @@ class AudioEncoder(_HipModule):
                     b16 = rt.bf16_acts and rt.prec == ops.PREC_BF16 and W[s] % 8 == 0
                     x = AG.GroupNormReluFn.apply(y, gn.weight, gn, b16 and i < 2, False)
                 else:
-                    out = catbuf[..., offs[s]:offs[s] + W[s]] if i == 2 else y
+                    if i == 2:
+                        out = catbuf[..., offs[s]:offs[s] + W[s]]
+                    elif rt.bf16_acts and rt.prec == ops.PREC_BF16 and W[s] % 8 == 0:
+                        out = torch.empty_like(y, dtype=torch.bfloat16)      # consumed only by the next conv (bf16 operand)
+                    else:
+                        out = y
                     x = ops.groupnorm_relu(y, gn.weight, gn.bias, out=out)
             finals.append(x)
         if grad:

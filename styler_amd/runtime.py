@@ -50,6 +50,9 @@ class _Runtime:
     # convolution takes that copy as its activation operand (it rounds the operand to bf16 anyway: same results) -- which
     # is what lets the 256 x 256 LDS-DMA engine (csrc/gemm256.hip) fetch it straight into LDS
     ln_bf16_copy = os.environ.get("STYLER_LN_BF16_COPY", "1") != "0"
+    # throughput mode: the dX GEMM of the BiLSTM input projections (gate gradients x W_ih) on bf16 operands like every
+    # other dX GEMM of the step (round 2 left these eight launches on the fp32 MFMA path: 0.2 ms per step)
+    lstm_dx_bf16 = os.environ.get("STYLER_LSTM_DX_BF16", "1") != "0"
 
     # each StylePredictor stage (conv -> ReLU -> LayerNorm -> dropout [-> Linear -> mask]) as one tape node whose backward
     # is one LayerNorm-backward kernel + weight gradient + dX GEMM (STYLER_FUSED_PREDICTOR=0: separate nodes)

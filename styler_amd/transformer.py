@@ -287,8 +287,10 @@ class PostNet(_HipModule):
                 scale, shift = self._derived.get(
                     f"bn{i}", [bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.bias],
                     lambda g, b, rm, rv, cb: ops.bn_fold(g, b, rm, rv, cb))
+                # throughput mode: the activation between two convolutions is stored as bf16 (the next GEMM rounds its
+                # operand to bf16 anyway: same values, half the bytes, and the 256 x 256 LDS-DMA engine can take it)
                 x = self._gemm(f"c{i}", x, conv, kw=self.kernel_size, act=act, scale=scale, shift=shift,
-                               res=add_residual if last else None)
+                               res=add_residual if last else None, out_bf16=(not last) and rt.bf16_acts)
         if self.training:                                  # BatchNorm1d bookkeeping: one multi-tensor launch per call
             with torch.no_grad():
                 torch._foreach_add_([seq[1].num_batches_tracked for seq in self.convolutions], segs)
