@@ -114,9 +114,10 @@ int styler_conv_gemm_pad(const float* x, int64_t ldx, const void* w, const float
 int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, int prec);
 /* The engine a styler_conv_gemm call with these arguments runs on: 0..3 = styler_conv_gemm_variant, 4 = the
  * 256 x 256 eight-wave LDS-DMA engine (csrc/gemm256.hip: bf16 MFMA mode, x stored as bf16 -- io_flags &
- * STYLER_IO_X_BF16 --, cin % 64 == 0, at least 1.5 tiles of 256 x 256 per CU).  Same arithmetic either way: both
+ * STYLER_IO_X_BF16 --, cin % 64 == 0, at least 8 K steps and 1.5 tiles of 256 x 256 per CU; `packed` != 0: the call is
+ * styler_conv_gemm_packed, whose row count is a capacity).  Same arithmetic either way: both
  * engines accumulate the same v_mfma_f32_32x32x16_bf16 sequence, results are bit-equal. */
-int styler_conv_gemm_engine(int B, int L, int cin, int n, int kw, int prec, int io_flags, int64_t ldx);
+int styler_conv_gemm_engine(int B, int L, int cin, int n, int kw, int prec, int io_flags, int64_t ldx, int packed);
 /* Test / tuning hook of that engine: enabled (0 / 1) and the smallest tile count it takes; -1 keeps a value (defaults:
  * STYLER_GEMM256, STYLER_GEMM256_MIN_TILES or 1, 384).  Returns the previous state as enabled | min_tiles << 1. */
 int styler_gemm256_config(int enabled, int min_tiles);

@@ -19,7 +19,7 @@ _SIGS = {
     "styler_conv_gemm_pad": [P, I64, P, P, P, P, I64, P, I64, I, I, I, I, I, I, I, I, P],
     "styler_leaky_sum": [P, P, P, P, I64, F, F, P],
     "styler_conv_gemm_variant": [I, I, I, I, I, I],
-    "styler_conv_gemm_engine": [I, I, I, I, I, I, I, I64],
+    "styler_conv_gemm_engine": [I, I, I, I, I, I, I, I64, I],
     "styler_gemm_set_trace": [P],
     "styler_wave_sum_selftest": [P, P, P, I, P],
     "styler_cast_bf16": [P, P, I64, P],

@@ -52,6 +52,8 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t lds_
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + lds_byte), 16, voff, 0, 0, 0);
 }
 
+}  // namespace
+
 template <bool Y16>
 __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];       // the ONLY LDS object of the kernel
@@ -434,16 +436,17 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
   }
 }
 
-}  // namespace
-
 // Eligibility: bf16 MFMA mode with the activation operand stored as bf16, whole 64-channel chunks, 16-byte aligned rows,
-// every byte offset below 2^31, at least 8 K steps and at least `min_tiles` 256 x 256 tiles.  Measured against the
-// 128 x 128 engine on the same bf16 operands (tools/gemm256_bench.py, profiles/r03_gemm256_bench.txt): x1.15 at 424 tiles
-// (FFN k = 9, M = 27 060), x1.02-1.06 at 166-848 tiles, x1.11-1.17 at 1000-8000 tiles (config 4), x1.55 on a square
-// 4096^3 GEMM (1.26 PFLOP/s); x0.92-0.96 at 106 tiles (N = 256 at M = 27 060: fewer tiles than CUs) -- hence the bound of
-// 160.  STYLER_GEMM256=0 switches the engine off, STYLER_GEMM256_MIN_TILES overrides the bound (styler_gemm256_config at run time).
+// every byte offset below 2^31, at least 8 K steps and at least `min_tiles` (384 = 1.5 per CU) 256 x 256 tiles that carry
+// data.  Measured against the 128 x 128 engine on the same bf16 operands, stand-alone (tools/gemm256_bench.py,
+// profiles/r03_gemm256_bench.txt): x1.15 at 424 tiles (FFN k = 9, M = 27 060), x1.02-1.06 at 166-848 tiles, x1.11-1.17 at
+// 1000-8000 tiles (config 4), x1.55 on a square 4096^3 GEMM (1.26 PFLOP/s); x0.92-0.96 at 106 tiles.  Inside the training
+// step the 166 / 332-tile launches of the AudioEncoder / PostNet run next to the text encoder's side stream, whose blocks
+// hold CUs that a 128 KB-LDS block then cannot enter: with a bound of 160 the step was 0.4 ms SLOWER than without the
+// engine (profiles/r03_g256_in_step.txt), hence 384.  STYLER_GEMM256=0 switches the engine off, STYLER_GEMM256_MIN_TILES
+// overrides the bound (styler_gemm256_config at run time).
 static int g_enabled = [] { const char* e = getenv("STYLER_GEMM256"); return e ? atoi(e) : 1; }();
-static int g_min_tiles = [] { const char* e = getenv("STYLER_GEMM256_MIN_TILES"); return e ? atoi(e) : 160; }();
+static int g_min_tiles = [] { const char* e = getenv("STYLER_GEMM256_MIN_TILES"); return e ? atoi(e) : 384; }();
 
 // Test / tuning hook: set the switch and the tile bound (-1 keeps a value); returns the previous state as
 // enabled | min_tiles << 1.
@@ -454,13 +457,18 @@ extern "C" int styler_gemm256_config(int enabled, int min_tiles) {
   return prev;
 }
 
-static bool gemm256_eligible(int B, int L, int cin, int n, int kw, int64_t ldx, int x16, int* mt_out, int* nt_out) {
+static bool gemm256_eligible(int B, int L, int cin, int n, int kw, int64_t ldx, int x16, bool packed, int* mt_out, int* nt_out) {
   const int enabled = g_enabled, min_tiles = g_min_tiles;
   if (!enabled || !x16) return false;
   if ((cin % BK) || (ldx & 7) || (n & 3) || kw > 9) return false;
   const int64_t M = (int64_t)B * L;
   const int mt = (int)((M + BM - 1) / BM), nt = (n + BN - 1) / BN;
-  if ((int64_t)mt * nt < min_tiles || (cin / BK) * kw < 8) return false;   // short K: prologue + epilogue dominate a 1-block-per-CU tile
+  // packed decoder rows: M is the row CAPACITY (B * T); the valid prefix is known on the device only and is ~64 % of it at
+  // VCTK shapes -- tiles behind the data exit at once, so the bound is applied to 60 % of the m-tiles
+  const int64_t mt_eff = packed ? (mt * 3 + 4) / 5 : mt;
+  if (mt_eff * nt < min_tiles) return false;
+  if (min_tiles > 1 && (cin / BK) * kw < 8) return false;          // short K: prologue + epilogue dominate a 1-block-per-CU tile
+                                                                   // (min_tiles == 1 = the tests' "take everything" setting)
   if ((n % BN) > 0 && (n % BN) < 192) return false;                // a mostly empty last column tile wastes its MFMAs
   if (((M + 8) * ldx * 2) >= ((int64_t)1 << 31) || ((int64_t)n * kw * cin * 2) >= ((int64_t)1 << 31)) return false;
   *mt_out = mt; *nt_out = nt;
@@ -469,7 +477,7 @@ static bool gemm256_eligible(int B, int L, int cin, int n, int kw, int64_t ldx, 
 
 int styler_gemm256_try(const GemmArgs& a0, int x16, int y16, hipStream_t st) {
   int mt, nt;
-  if (a0.trace || !gemm256_eligible(a0.B, a0.L, a0.cin, a0.n, a0.kw, a0.ldx, x16, &mt, &nt)) return 0;
+  if (a0.trace || !gemm256_eligible(a0.B, a0.L, a0.cin, a0.n, a0.kw, a0.ldx, x16, a0.rowinfo != nullptr, &mt, &nt)) return 0;
   GemmArgs a = a0;
   a.mt = mt; a.nt = nt;
   const dim3 grid((unsigned)(((mt + 7) / 8) * 8 * nt));
@@ -481,8 +489,8 @@ int styler_gemm256_try(const GemmArgs& a0, int x16, int y16, hipStream_t st) {
 
 // Which engine / tile a styler_conv_gemm call with these arguments runs on: 0..3 = styler_conv_gemm_variant (bit 0: 128 x 128
 // tile, bit 1: bf16 MFMA), 4 = the 256 x 256 LDS-DMA engine of this file.
-extern "C" int styler_conv_gemm_engine(int B, int L, int cin, int n, int kw, int prec, int io_flags, int64_t ldx) {
+extern "C" int styler_conv_gemm_engine(int B, int L, int cin, int n, int kw, int prec, int io_flags, int64_t ldx, int packed) {
   int mt, nt;
-  if (prec == STYLER_PREC_BF16 && gemm256_eligible(B, L, cin, n, kw, ldx, io_flags & STYLER_IO_X_BF16, &mt, &nt)) return 4;
+  if (prec == STYLER_PREC_BF16 && gemm256_eligible(B, L, cin, n, kw, ldx, io_flags & STYLER_IO_X_BF16, packed != 0, &mt, &nt)) return 4;
   return styler_conv_gemm_variant(B, L, cin, n, kw, prec);
 }

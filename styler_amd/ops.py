@@ -372,7 +372,7 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
                                   _stream()), "styler_conv_gemm")
     if prof is not None:
         e1.record()
-        prof.records.append((lib.styler_conv_gemm_engine(B, L, cin, n, kw, prec, io, _ld(x)), 2.0 * B * L * n * kw * cin,
+        prof.records.append((lib.styler_conv_gemm_engine(B, L, cin, n, kw, prec, io, _ld(x), int(plan is not None)), 2.0 * B * L * n * kw * cin,
                              e0, e1, plan is not None))
     return out
 

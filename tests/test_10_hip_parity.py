@@ -140,10 +140,10 @@ def test_gemm256_engine_vs_math_and_vs_128_engine(dev, case):
     xd, bd = x16.to(dev), b.to(dev)
     prev = ops.gemm256_config(1, 1)
     try:
-        assert ops.lib.styler_conv_gemm_engine(B, L, cin, n, kw, ops.PREC_BF16, 1, cin) == 4
+        assert ops.lib.styler_conv_gemm_engine(B, L, cin, n, kw, ops.PREC_BF16, 1, cin, 0) == 4
         ys = [ops.conv_gemm(xd, wk, bd, **args).clone() for _ in range(4)]
         ops.gemm256_config(0, -1)
-        assert ops.lib.styler_conv_gemm_engine(B, L, cin, n, kw, ops.PREC_BF16, 1, cin) != 4
+        assert ops.lib.styler_conv_gemm_engine(B, L, cin, n, kw, ops.PREC_BF16, 1, cin, 0) != 4
         y128 = ops.conv_gemm(xd, wk, bd, **args)
     finally:
         ops.gemm256_config(*prev)
