@@ -264,3 +264,84 @@ def test_deepspeaker_restatement_sanity():
     assert e.shape == (2, 512) and float((e.norm(dim=1) - 1).abs().max()) < 1e-5
     s, t = D.vad_bounds(np.concatenate([np.zeros(100), np.ones(50), np.zeros(100)]).astype(np.float32))
     assert (s, t) == (0, 0) or s >= 100                                            # only the burst can exceed the percentile
+
+
+def test_mel_filterbank_published_closed_forms():
+    """The librosa-0.7.2 filterbank stays PARITY UNPINNED (librosa is absent; stft.py:128-129).  What librosa documents in closed
+    form is pinned here, so a regression of the restatement is visible: the Slaney scale (linear 200/3 Hz per mel below 1 kHz,
+    log above with 27 mels per factor 6.4), band edges equally spaced on that scale between 0 and 8000 Hz, triangles that peak at
+    their centre frequency, `2 / (f[i+2] - f[i])` area normalisation, nothing above fmax."""
+    sr, n_fft, n_mels, fmax = 22050, 1024, 80, 8000.0
+    fb = O.mel_filterbank(sr, n_fft, n_mels, 0.0, fmax).double().numpy()
+    assert fb.shape == (80, 513) and fb.min() >= 0.0
+    # the scale itself, written out independently of the oracle's helpers
+    f_sp, min_log_hz, logstep = 200.0 / 3.0, 1000.0, np.log(6.4) / 27.0
+
+    def hz2mel(f):
+        return f / f_sp if f < min_log_hz else 15.0 + np.log(f / min_log_hz) / logstep
+
+    def mel2hz(m):
+        return f_sp * m if m < 15.0 else min_log_hz * np.exp(logstep * (m - 15.0))
+
+    assert hz2mel(1000.0) == 15.0 and abs(hz2mel(6400.0) - 42.0) < 1e-12 and abs(mel2hz(42.0) - 6400.0) < 1e-9
+    edges = np.array([mel2hz(m) for m in np.linspace(0.0, hz2mel(fmax), n_mels + 2)])
+    assert edges[0] == 0.0 and abs(edges[-1] - fmax) < 1e-9
+    assert np.allclose(np.diff(edges[edges <= 1000.0]), np.diff(edges)[0])           # linear region: equal steps in Hz
+    hi = edges[edges >= 1000.0]
+    assert np.allclose(hi[1:] / hi[:-1], hi[1] / hi[0])                              # log region: equal ratios
+    df = sr / n_fft
+    freqs = np.arange(513) * df
+    for i in range(n_mels):
+        lo, c, up = edges[i], edges[i + 1], edges[i + 2]
+        norm = 2.0 / (up - lo)
+        # the triangle evaluated at the FFT bin frequencies, scaled by the Slaney area normalisation
+        tri = np.maximum(0.0, np.minimum((freqs - lo) / (c - lo), (up - freqs) / (up - c))) * norm
+        assert np.abs(fb[i] - tri).max() <= 1e-6 * norm, i                          # fp32 storage of the oracle's matrix
+        nz = np.nonzero(fb[i])[0]
+        assert nz.size and freqs[nz[0]] > lo and freqs[nz[-1]] < up                  # support strictly inside (lo, up)
+        assert abs(freqs[fb[i].argmax()] - c) < df                                   # peak at a bin adjacent to the centre
+        assert fb[i].max() <= norm * (1 + 1e-6)
+        if up - lo > 12 * df:                                                        # wide filters: unit area under the triangle
+            assert abs(fb[i].sum() * df - 1.0) < 0.02, (i, fb[i].sum() * df)
+    assert fb[:, freqs >= fmax].max() == 0.0                                         # bins 372.. (>= 8000 Hz) carry nothing
+    assert np.all(np.diff(fb.argmax(axis=1)) >= 0)
+
+
+def test_deepspeaker_keras_weight_dump_round_trip():
+    """f2 stays PARITY UNPINNED (TensorFlow / the pretrained .h5 are absent; deepspeaker/conv_models.py:28-135).  The loader is
+    pinned to the Keras layouts it claims: a synthetic `get_weights()`-style dump (Conv2D kernels [kh, kw, cin, cout], Dense
+    [in, out], BatchNormalization gamma / beta / moving_mean / moving_variance) loads by name, a wrong shape is refused, the GEMM
+    repacking [taps, cin, cout] -> [cout, taps * cin] agrees with an einsum over the Keras kernel, and the folded BatchNorm
+    scale / shift equal Keras' inference formula with eps = 1e-3."""
+    import torch
+    from styler_amd import deepspeaker as DS
+    rs = np.random.RandomState(3)
+    shapes = DS.layer_shapes()
+    dump = {k: (rs.rand(*s).astype(np.float32) + 0.5 if k.endswith(("gamma", "moving_variance"))
+                else rs.randn(*s).astype(np.float32) * 0.1) for k, s in shapes.items()}
+    m = DS.DeepSpeaker()
+    m.load_keras_weights(dump)
+    for k, v in dump.items():
+        assert np.array_equal(m.weight(k).numpy(), v), k
+    bad = dict(dump)
+    bad["affine/kernel"] = dump["affine/kernel"].T.copy()
+    with pytest.raises(ValueError):
+        DS.DeepSpeaker().load_keras_weights(bad)
+    P = m._pack(torch.device("cpu"), 0)                                              # fp32 packing runs on the host
+    k = dump["res2_1_branch_2a/kernel"]                                              # [3, 3, 128, 128]
+    x = rs.randn(3, 128).astype(np.float32)                                          # one output position: 3 taps x cin
+    for i in range(3):
+        want = np.einsum("wc,wco->o", x, k[i])                                       # Keras: sum over (kw, cin) of x * kernel[kh=i]
+        got = P["res2_1_branch_2a"][i].numpy() @ x.reshape(-1)
+        assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+    k5 = dump["conv128-s/kernel"]                                                    # [5, 5, 64, 128]: even / odd column phases
+    ev, od = P["s2"][2]
+    assert np.array_equal(ev.numpy(), np.transpose(k5[2, 0::2], (2, 0, 1)).reshape(128, -1))
+    assert np.array_equal(od.numpy(), np.transpose(k5[2, 1::2], (2, 0, 1)).reshape(128, -1))
+    scale, shift = P["res2_1_branch_2a_ss"]
+    g, b = dump["res2_1_branch_2a_bn/gamma"], dump["res2_1_branch_2a_bn/beta"]
+    mu, var = dump["res2_1_branch_2a_bn/moving_mean"], dump["res2_1_branch_2a_bn/moving_variance"]
+    z = rs.randn(128).astype(np.float32)                                             # conv output before bias
+    keras = g * ((z + dump["res2_1_branch_2a/bias"]) - mu) / np.sqrt(var + 1e-3) + b
+    assert np.abs((z * scale.numpy() + shift.numpy()) - keras).max() <= 1e-5
+    assert np.array_equal(P["affine"].numpy(), dump["affine/kernel"].T * np.float32(0.1))
