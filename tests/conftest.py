@@ -13,6 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_addoption(parser):
+    parser.addoption("--shuffle", type=int, default=None, metavar="SEED",
+                     help="run the collected tests in a seeded random order (order-dependence screen; the default order is "
+                          "the file order: oracle / golden parity first, HIP-vs-HIP equivalences last)")
+
+
+def pytest_collection_modifyitems(config, items):
+    seed = config.getoption("--shuffle")
+    if seed is not None:
+        import random
+        random.Random(seed).shuffle(items)
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
