@@ -43,7 +43,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense, MI355X_MICROARCH.md
 VARIANT_NAMES = {0: "conv_gemm_kernel<1,1,f32>", 1: "conv_gemm_kernel<2,2,f32>",
-                 2: "conv_gemm_kernel<1,1,bf16>", 3: "conv_gemm_kernel<2,2,bf16>"}
+                 2: "conv_gemm_kernel<1,1,bf16>", 3: "conv_gemm_kernel<2,2,bf16>", 4: "conv_gemm256_kernel"}
 
 
 def parse():
@@ -204,7 +204,13 @@ def run(args, mode, prec, rank, world, dev, dist, with_cpu=True, with_roofline=T
 
 def _family(gsum, key, name, traffic_label, prec, ps):
     peak = MFMA_PEAK_TFLOPS[prec]
-    d = gsum.get(key, {"launches": 0, "flops": 0.0, "ms": 1.0})
+    keys = key if isinstance(key, (tuple, list)) else (key,)
+    d = {"launches": 0, "flops": 0.0, "ms": 0.0}
+    for k in keys:
+        for f in d:
+            d[f] += gsum.get(k, {}).get(f, 0)
+    if not d["launches"]:
+        d["ms"] = 1.0
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["launches"] else 0.0
     traffic, source = pmc_traffic(traffic_label, prec)
     return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
@@ -219,8 +225,17 @@ def roofline_of(gsum, train, prec, ps):
     weight-gradient engine is reported next to it (`weight_gradient`): in the eager profiling steps, where every gradient
     is launched stand-alone with its own split-K reduce instead of through the grouped / deferred path of the graph, its
     bracketed time is about as large, and the two used to trade places from run to run."""
-    big = 3 if prec == "bf16" else 1               # conv_gemm_kernel<2,2,...>: forward and dX launches
-    r = _family(gsum, big, VARIANT_NAMES[big], "train_conv_gemm_2x2_bf16" if train else "fwd_conv_gemm_2x2_bf16", prec, ps)
+    # the large-tile forward + dX engines: conv_gemm_kernel<2,2,...> (128 x 128) and, in bf16 mode, conv_gemm256_kernel (256 x 256
+    # LDS-DMA, csrc/gemm256.hip) -- one family: which of the two takes a launch is a dispatch decision (styler_conv_gemm_engine)
+    big = (3, 4) if prec == "bf16" else 1
+    name = "conv_gemm_kernel<2,2,bf16> + conv_gemm256_kernel" if prec == "bf16" else VARIANT_NAMES[1]
+    r = _family(gsum, big, name, "train_conv_gemm_2x2_bf16" if train else "fwd_conv_gemm_2x2_bf16", prec, ps)
+    if prec == "bf16" and 4 in gsum:
+        g = gsum[4]
+        r["gemm256"] = {"kernel": "conv_gemm256_kernel", "launches_per_step": g["launches"] // ps,
+                        "avg_launch_us": round(g["ms"] * 1e3 / max(1, g["launches"]), 2),
+                        "achieved": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                        "frac": round(g["flops"] / (g["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[prec], 4)}
     r["all_mfma_gemm_ms_per_step"] = round(sum(v["ms"] for v in gsum.values()) / ps, 3)
     if train:
         wg = "wgrad_bf16" if prec == "bf16" else "wgrad"

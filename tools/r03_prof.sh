@@ -1,0 +1,35 @@
+#!/bin/bash
+# round-3 profiles of the final launch mix: kernel traces (the default bench command = hipGraph replay, the C2 forward, the C4
+# forward), separate PMC passes, the GEMM engine A/B, the default bench line.  Everything lands in gpurun_out/r03prof/.
+cd $GRAFT_REPO_ROOT
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r03prof
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+trace() {   # trace <name> <bench args...>
+  name=$1; shift
+  timeout 600 rocprofv3 --kernel-trace -d $O/trace_$name -o t -- python $R/bench.py --no-cpu --no-aux --no-hbm --prof-steps 0 --repeat 0 "$@" > $O/trace_$name.log 2>&1
+  db=$(find $O/trace_$name -name "*.db" | head -1)
+  python $R/tools/prof_summary.py $db $O/r03_${name}_kernel_stats.txt > /dev/null
+  rm -rf $O/trace_$name
+}
+trace train_bf16_graph --mode train --steps 20 --warmup 5
+trace fwd_bf16_graph --mode fwd --steps 20 --warmup 5
+trace c4_fwd_dual --mode fwd --shape c4 --batch 128 --dual --steps 5 --warmup 2
+cd $R
+bash tools/pmc_run.sh r03prof/pmc_train -- python $R/bench.py --mode train --no-cpu --no-aux --no-hbm --steps 4 --warmup 2 --prof-steps 0 --repeat 0 > /dev/null 2>&1
+{
+python tools/pmc_traffic.py gpurun_out/r03prof/pmc_train "conv_gemm_kernel<2, 2, true|conv_gemm256_kernel" train_conv_gemm_2x2_bf16
+python tools/pmc_traffic.py gpurun_out/r03prof/pmc_train "conv_gemm256_kernel" train_conv_gemm256
+python tools/pmc_traffic.py gpurun_out/r03prof/pmc_train "wgrad_tr_kernel" train_wgrad_bf16
+python tools/pmc_traffic.py gpurun_out/r03prof/pmc_train "wgrad_reduce_multi" train_wgrad_reduce_multi
+python tools/pmc_traffic.py gpurun_out/r03prof/pmc_train "length_regulate_kernel" train_length_regulate
+python tools/pmc_traffic.py gpurun_out/r03prof/pmc_train "add_layernorm_kernel" train_add_layernorm
+python tools/pmc_traffic.py gpurun_out/r03prof/pmc_train "layernorm_bwd_kernel" train_layernorm_bwd
+} > $O/r03_pmc_traffic.jsonl 2> $O/pmc_traffic.err
+python tools/pmc_summary.py $(find gpurun_out/r03prof/pmc_train -name "*counter_collection.csv") > $O/r03_pmc_train_counters.txt 2>&1
+rm -rf gpurun_out/r03prof/pmc_train
+timeout 300 python tools/gemm256_bench.py 3 > $O/r03_gemm256_bench.txt 2>&1
+timeout 300 python tools/gemm_bench.py bf16 > $O/r03_gemm_bench.txt 2>&1
+timeout 600 python bench.py > $O/r03_bench_default.json 2> $O/r03_bench_default.err
+cat $O/r03_pmc_traffic.jsonl; head -8 $O/r03_train_bf16_graph_kernel_stats.txt; tail -c 600 $O/r03_bench_default.json
