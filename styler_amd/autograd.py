@@ -791,12 +791,19 @@ class Nll3Fn(Function):
     @staticmethod
     def forward(ctx, p0, p1, p2, label):
         lps = [p.contiguous() for p in (p0, p1, p2)]
-        ctx.lps, ctx.label = lps, label
+        if isinstance(label, int):                   # python int label: nothing but tensors goes through save_for_backward
+            ctx.save_for_backward(*lps)
+            ctx.label = label
+        else:
+            ctx.save_for_backward(*lps, label)
+            ctx.label = None
         return ops.nll3(lps, label).view(())
 
     @staticmethod
     def backward(ctx, g):
-        d3 = ops.nll3(ctx.lps, ctx.label, gscale=g.reshape(1), want_grad=True)
+        saved = ctx.saved_tensors
+        lps, label = list(saved[:3]), (ctx.label if ctx.label is not None else saved[3])
+        d3 = ops.nll3(lps, label, gscale=g.reshape(1), want_grad=True)
         return d3[0], d3[1], d3[2], None
 
 

@@ -411,25 +411,77 @@ class GraphedStepCache:
     classifier's time mean -- SURVEY 8c trap 1) see the extra zero rows exactly as they see those of a longer co-batched
     utterance: the result equals the reference run on the same padded rectangle (tests/test_hip_backward.py)."""
 
-    def __init__(self, model, state, max_graphs=24, **kw):
+    def __init__(self, model, state, max_graphs=24, sync_misses=False, **kw):
+        """`sync_misses` (several ranks): before every step the ranks exchange their batch shapes (one 3-int all-gather) and
+        every rank captures, in the same step, the graph of EVERY shape some rank is about to miss -- its own with its batch,
+        a peer's with a synthetic batch of that shape.  Without it each rank stalls its peers (they wait in the step's
+        all-reduce) once per shape IT sees for the first time; with it a shape costs one capture stall for the whole job."""
         from collections import OrderedDict
         self.model, self.state, self.max_graphs, self.kw = model, state, max_graphs, kw
         self.steps = OrderedDict()
-        self.hits = self.misses = 0
+        self.hits = self.misses = self.prefetched = 0
+        self.sync_misses = sync_misses and world_size() > 1
 
     @staticmethod
     def key(batch):
         return tuple(batch["text"].shape) + (batch["mel_target"].shape[1],)
 
+    def _capture(self, k, batch):
+        while len(self.steps) >= self.max_graphs:
+            self.steps.popitem(last=False)                           # frees the evicted graph's memory pool and arena
+        step = self.steps[k] = GraphedTrainStep(self.model, self.state, batch, **self.kw)
+        return step
+
+    def prefetch(self, keys):
+        """Capture the graphs of the given (B, S, T) shapes up front (e.g. the feeder's bucket grid) on synthetic batches:
+        constructing a graphed step has no side effects on the training state, so nothing trains; with several ranks every
+        rank calls this with the same list and the capture stalls happen once, together, before the loop."""
+        dev = self.state.flat_g.device
+        for k in keys:
+            k = tuple(int(x) for x in k)
+            if k not in self.steps:
+                self._capture(k, synthetic_batch(*k, device=dev))
+                self.prefetched += 1
+
+    def _exchange(self, k):
+        """Shapes the job is about to run this step that at least one rank has no graph for (all ranks get the same list)."""
+        import torch.distributed as dist
+        dev = self.state.flat_g.device
+        mine = torch.tensor(list(k) + [0 if k in self.steps else 1], device=dev, dtype=torch.int64)
+        allk = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(allk, mine)
+        rows = torch.stack(allk).cpu().tolist()
+        return sorted({tuple(r[:3]) for r in rows if r[3]})
+
     def __call__(self, batch):
         k = self.key(batch)
+        if self.sync_misses:
+            for other in self._exchange(k):
+                if other != k and other not in self.steps:
+                    self._capture(other, synthetic_batch(*other, device=self.state.flat_g.device))
+                    self.prefetched += 1
         step = self.steps.get(k)
         if step is None:
             self.misses += 1
-            while len(self.steps) >= self.max_graphs:
-                self.steps.popitem(last=False)                       # frees the evicted graph's memory pool
-            step = self.steps[k] = GraphedTrainStep(self.model, self.state, batch, **self.kw)
+            step = self._capture(k, batch)
         else:
             self.hits += 1
             self.steps.move_to_end(k)
         return step(batch)
+
+
+def synthetic_batch(B, S, T, device="cpu", seed=0):
+    """A batch of the collate's keys, dtypes and padded shapes (dataset.py:188-207; tests/closed_form.make_batch) with every
+    item at full length: what GraphedStepCache captures a shape with when no real batch of that shape is at hand (the
+    capture only needs shapes; its warm-up passes restore everything they touch)."""
+    g = torch.Generator().manual_seed(seed)
+    D = torch.full((B, S), T // S, dtype=torch.int64)
+    D[:, -1] += T - int(D[0].sum())
+    ru = lambda *s: torch.rand(*s, generator=g)
+    spk = torch.randn(B, 512, generator=g)
+    b = dict(text=torch.randint(1, 152, (B, S), generator=g), mel_target=torch.randn(B, T, 80, generator=g),
+             mel_aug=torch.randn(B, T, 80, generator=g), D=D, log_D=torch.log(D.float() + hp.log_offset),
+             f0=80.0 + 300.0 * ru(B, T), f0_norm=ru(B, T), f0_norm_aug=ru(B, T), energy=100.0 * ru(B, T),
+             energy_input=ru(B, T), energy_input_aug=ru(B, T), speaker_embed=spk / spk.norm(dim=1, keepdim=True),
+             src_len=torch.full((B,), S, dtype=torch.int64), mel_len=torch.full((B,), T, dtype=torch.int64))
+    return {k: v.to(device) for k, v in b.items()}

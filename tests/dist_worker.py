@@ -1,7 +1,7 @@
 """Worker of tests/test_95_dist_gpu.py: one rank of a two-rank data-parallel train step on ONE GPU (both ranks on cuda:0,
 collectives over gloo -- RCCL refuses two ranks on one device; the control flow is the N > 1 path of bench.py).
 
-    python dist_worker.py <rank> <world> <port> <out_dir> [graph|acc2|buckets]
+    python dist_worker.py <rank> <world> <port> <out_dir> [graph|acc2|buckets|buckets_sync]
 """
 import os
 import sys
@@ -82,16 +82,17 @@ def main():
         for mb in micro_batches(gb, idx):
             losses, lr = train_step(model, state, {k: v.to(dev) for k, v in mb.items()})
         res["hook_fired_at"] = fired
-    elif mode == "buckets":
-        # two consecutive optimisation steps through the graph cache, every rank with its own padded shapes per step
-        cache = GraphedStepCache(model, state)
+    elif mode in ("buckets", "buckets_sync"):
+        # two consecutive optimisation steps through the graph cache, every rank with its own padded shapes per step;
+        # "buckets_sync": the ranks exchange their shapes and capture every missing shape of the job in the same step
+        cache = GraphedStepCache(model, state, sync_misses=(mode == "buckets_sync"))
         gb2 = second_batch()
         idx2 = shard_indices(gb2["text"].shape[0], rank, world, gb2["mel_len"].tolist())
         res["idx2"] = idx2
         for g_, i_ in ((gb, idx), (gb2, idx2)):
             losses, lr = cache({k: v.to(dev) for k, v in shard_batch(g_, i_).items()})
         res["graphs"] = [len(s_.graphs) for s_ in cache.steps.values()]
-        res["misses"] = cache.misses
+        res["misses"], res["prefetched"], res["keys"] = cache.misses, cache.prefetched, sorted(cache.steps)
     else:
         raise SystemExit(f"unknown mode {mode}")
     torch.cuda.synchronize()

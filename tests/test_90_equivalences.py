@@ -329,3 +329,40 @@ def test_graph_cache_two_buckets_small_then_large(dev, ref_state_dict):
         assert float((p_e - p_c).abs().max()) <= 1e-4
     finally:
         rt.disable_dropout = False
+
+
+def test_graph_cache_prefetch_has_no_side_effects(dev, ref_state_dict):
+    """GraphedStepCache.prefetch captures shapes on synthetic batches before the loop (what several ranks do together so
+    that no rank stalls its peers later): nothing trains, and a real batch of a prefetched shape is a cache hit whose step
+    equals the eager step."""
+    from closed_form import make_batch
+    from styler_amd import STYLER, rt
+    from styler_amd.training import GraphedStepCache, TrainState, synthetic_batch, train_step
+    b = {k: v.to(dev) for k, v in make_batch(3, 10, 20, 2, 6, seed=51).items()}
+    key = GraphedStepCache.key(b)
+    sb = synthetic_batch(*key)
+    assert {k: (tuple(v.shape), v.dtype) for k, v in sb.items()} == {k: (tuple(v.shape), v.dtype) for k, v in b.items()}
+    rt.disable_dropout = True
+    try:
+        outs = []
+        for mode in ("eager", "prefetched"):
+            m = STYLER()
+            m.load_state_dict(ref_state_dict)
+            m = m.to(dev).train()
+            st = TrainState(m)
+            if mode == "prefetched":
+                cache = GraphedStepCache(m, st, warmup=2)
+                snap = (st.flat_p.clone(), [x.clone() for x in m.buffers()])
+                cache.prefetch([key, (4, 24, 96)])
+                assert cache.prefetched == 2 and st.n_current_steps == 0 and torch.equal(st.flat_p, snap[0])
+                assert all(torch.equal(x, y) for x, y in zip(m.buffers(), snap[1]))
+                losses, lr = cache(b)
+                assert (cache.hits, cache.misses) == (1, 0)
+            else:
+                losses, lr = train_step(m, st, b)
+            torch.cuda.synchronize()
+            outs.append((torch.stack([x.detach().float().reshape(()) for x in losses]).cpu(), st.flat_p.clone()))
+        assert float((outs[0][0] - outs[1][0]).abs().max()) <= 2e-4 * max(1.0, float(outs[0][0].abs().max()))
+        assert float((outs[0][1] - outs[1][1]).abs().max()) <= 1e-5
+    finally:
+        rt.disable_dropout = False

@@ -110,6 +110,25 @@ def test_two_rank_graph_cache_two_steps_different_shapes(tmp_path, ref_state_dic
     assert float((r0["flat_p"] - flat_p).abs().max()) <= 2e-6
 
 
+def test_two_rank_graph_cache_collective_misses(tmp_path, ref_state_dict, monkeypatch):
+    """GraphedStepCache(sync_misses=True): the ranks exchange their batch shapes before each step and every rank captures,
+    in that step, every shape some rank is about to miss (a peer's shape on a synthetic batch) -- the job stalls once per
+    shape, not once per shape and rank.  Both ranks end up holding the same set of graphs, and the trajectory is that of
+    the plain cache (captures have no side effects on the training state)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_worker import global_batch, second_batch, shard_batch
+    r0, r1 = _run_ranks(tmp_path, "buckets_sync")
+    assert r0["keys"] == r1["keys"] and len(r0["keys"]) >= 2
+    assert r0["misses"] + r0["prefetched"] == len(r0["keys"]) == r1["misses"] + r1["prefetched"]
+    assert r0["steps"] == 2
+    gb, gb2 = global_batch(), second_batch()
+    windows = [[shard_batch(gb, r["idx"]) for r in (r0, r1)], [shard_batch(gb2, r["idx2"]) for r in (r0, r1)]]
+    mean_g, flat_p, lr = _single_rank(ref_state_dict, monkeypatch, windows)
+    err_g = float((0.5 * r0["flat_g"] - mean_g).abs().max()) / float(mean_g.abs().max())
+    assert err_g <= 2e-5, err_g
+    assert float((r0["flat_p"] - flat_p).abs().max()) <= 2e-6
+
+
 def test_bench_command_launches_its_own_ranks():
     """`python bench.py --gpus 2 ...` with no launcher around it (what the driver's scaling run executes): the command
     re-execs itself under torch.distributed.run, both ranks run the two-graph step with the all-reduce between the
