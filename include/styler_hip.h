@@ -121,6 +121,14 @@ int styler_conv_gemm_engine(int B, int L, int cin, int n, int kw, int prec, int 
 /* Test / tuning hook of that engine: enabled (0 / 1) and the smallest tile count it takes; -1 keeps a value (defaults:
  * STYLER_GEMM256, STYLER_GEMM256_MIN_TILES or 1, 384).  Returns the previous state as enabled | min_tiles << 1. */
 int styler_gemm256_config(int enabled, int min_tiles);
+/* Split-K scratch of the 256 x 256 engine.  styler_conv_gemm_workspace_bytes: bytes of fp32 partial tiles a
+ * styler_conv_gemm / styler_conv_gemm_packed call with these arguments wants (0: none; today only launches with 96..160
+ * data-carrying tiles and >= 64 K steps and a plain epilogue: the dX of the FFN's k = 9 convolution,
+ * transformer/SubLayers.py:72-76).  styler_gemm_set_workspace registers [ptr, ptr + bytes) for the NEXT conv_gemm call of
+ * the calling host thread (consumed by it); without a registration the call runs unsplit. */
+int64_t styler_conv_gemm_workspace_bytes(int B, int L, int cin, int n, int kw, int act, int prec, int io_flags,
+                                         int64_t ldx, int packed, int has_mask);
+int styler_gemm_set_workspace(void* ptr, int64_t bytes);
 /* Measurement hook (tools/gemm_trace.py): while `buf` is non-null every styler_conv_gemm block writes 8 uint64 words at
  * buf[8 * blockIdx]: block, then 100 MHz timestamps at entry / first tile staged / main loop done / stores issued /
  * stores acknowledged, the hardware id register and the tile index.  Pass NULL to switch it off (the default). */

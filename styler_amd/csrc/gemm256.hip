@@ -80,7 +80,20 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
   const int kw = a.kw, pad = a.pad;
   const int ktot = kw * a.cin;
   const int ncc = a.cin / BK;
-  const int nsteps = ncc * kw;
+  // split-K (a.ksplit == 2: launches with fewer tiles than CUs and a long K, the FFN's k = 9 dX): blockIdx.y takes half of
+  // the (chunk, tap) steps and stores its raw fp32 accumulators to a.part[blockIdx.y]; gemm256_combine_kernel adds the two
+  // halves in a fixed order and applies the epilogue (deterministic: no atomics)
+  const int all_steps = ncc * kw;
+  const int split = a.ksplit > 1 ? (int)blockIdx.y : 0;
+  const int step0 = split * (all_steps / a.ksplit);
+  const int nsteps = (split + 1 == a.ksplit ? all_steps : (split + 1) * (all_steps / a.ksplit)) - step0;
+  if (a.ksplit > 1) {                                 // partial tiles: plain fp32 rows, the epilogue proper runs in the combine pass
+    a.y = a.part + (int64_t)split * M * a.n;
+    a.ldy = a.n;
+    a.scale = a.shift = a.res = nullptr;
+    a.mask = nullptr;
+    a.act = STYLER_ACT_NONE;
+  }
 
   // ---- tiles made only of rows at or past their item's length: zeros (packed rows: nothing behind the data is read) ----
   if (a.len) {
@@ -174,10 +187,11 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
   // ---- prologue: the four units of step 0 into stage 0 (UB0, UA0 first: phase 0 reads them) ----
-  issue_b(0, 0, 0, 0u);
-  issue_a(0, 0, 0, 0u);
-  issue_b(1, 0, 0, 0u);
-  issue_a(1, 0, 0, 0u);
+  const int cc0 = step0 / kw, j0 = step0 - cc0 * kw;   // K steps run chunk-major, taps inside a chunk
+  issue_b(0, cc0, j0, 0u);
+  issue_a(0, cc0, j0, 0u);
+  issue_b(1, cc0, j0, 0u);
+  issue_a(1, cc0, j0, 0u);
 #define LDS_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
   // phase 0 are read one phase early, in phase 3 of the step before, into the other of two register sets).
   // DMA issue order: L(t,0) UB0(t+1), L(t,1) UA0(t+1), L(t,2) UB1(t+1), L(t,3) UA1(t+1); every wait is vmcnt(4) = "all but
   // the two youngest units": L(t,0) -> UB1(t), L(t,1) -> UA1(t), L(t,2) -> UB0(t+1), L(t,3) -> UA0(t+1).
-  int cc = 0, j = 0;
+  int cc = cc0, j = j0;
   auto k_step = [&](auto par_tag, bf16x8 (&fbc)[4], bf16x8 (&fbn)[4], const bool more) {
     constexpr uint32_t st = decltype(par_tag)::value * STAGE_BYTES;
     constexpr uint32_t sn = STAGE_BYTES - st;           // the other stage: operands of step + 1
@@ -436,6 +450,32 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
   }
 }
 
+// Second pass of a split-K launch: y = scale * (P0 + P1) + shift (+ res), one float4 per thread, fixed summation order.
+// `nrows` (packed rows): rows at or past the device row counter are not touched (nothing behind the data is ever read).
+template <bool Y16>
+__global__ __launch_bounds__(256) void gemm256_combine_kernel(const float* __restrict__ part, int64_t M, int n, int ksplit,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              const float* __restrict__ res, int64_t ldres, void* __restrict__ y,
+                                                              int64_t ldy, const int64_t* __restrict__ nrows) {
+  const int q = n >> 2;                                                      // float4 per row
+  const int64_t lim = nrows ? (nrows[0] < M ? nrows[0] : M) : M;
+  const int64_t total = lim * q;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / q;
+    const int c = (int)(i - r * q) * 4;
+    float4 v = *reinterpret_cast<const float4*>(part + r * n + c);
+    for (int k = 1; k < ksplit; ++k) {
+      const float4 w = *reinterpret_cast<const float4*>(part + (int64_t)k * M * n + r * n + c);
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    if (scale) { const float4 t = *reinterpret_cast<const float4*>(scale + c); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
+    if (shift) { const float4 t = *reinterpret_cast<const float4*>(shift + c); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    if (res) { const float4 t = *reinterpret_cast<const float4*>(res + r * ldres + c); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    if (Y16) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(y) + r * ldy + c) = make_uint2(cvt_pk_bf16_rne(v.x, v.y), cvt_pk_bf16_rne(v.z, v.w));
+    else *reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + r * ldy + c) = v;
+  }
+}
+
 // Eligibility: bf16 MFMA mode with the activation operand stored as bf16, whole 64-channel chunks, 16-byte aligned rows,
 // every byte offset below 2^31, at least 8 K steps and at least `min_tiles` (384 = 1.5 per CU) 256 x 256 tiles that carry
 // data.  Measured against the 128 x 128 engine on the same bf16 operands, stand-alone (tools/gemm256_bench.py,
@@ -458,7 +498,7 @@ extern "C" int styler_gemm256_config(int enabled, int min_tiles) {
 }
 
 static bool gemm256_eligible(int B, int L, int cin, int n, int kw, int64_t ldx, int x16, bool packed, int* mt_out, int* nt_out) {
-  const int enabled = g_enabled, min_tiles = g_min_tiles;
+  const int enabled = g_enabled, min_tiles = g_min_tiles > 1 ? g_min_tiles : 1;
   if (!enabled || !x16) return false;
   if ((cin % BK) || (ldx & 7) || (n & 3) || kw > 9) return false;
   const int64_t M = (int64_t)B * L;
@@ -467,7 +507,7 @@ static bool gemm256_eligible(int B, int L, int cin, int n, int kw, int64_t ldx, 
   // VCTK shapes -- tiles behind the data exit at once, so the bound is applied to 60 % of the m-tiles
   const int64_t mt_eff = packed ? (mt * 3 + 4) / 5 : mt;
   if (mt_eff * nt < min_tiles) return false;
-  if (min_tiles > 1 && (cin / BK) * kw < 8) return false;          // short K: prologue + epilogue dominate a 1-block-per-CU tile
+  if (g_min_tiles > 1 && (cin / BK) * kw < 8) return false;          // short K: prologue + epilogue dominate a 1-block-per-CU tile
                                                                    // (min_tiles == 1 = the tests' "take everything" setting)
   if ((n % BN) > 0 && (n % BN) < 192) return false;                // a mostly empty last column tile wastes its MFMAs
   if (((M + 8) * ldx * 2) >= ((int64_t)1 << 31) || ((int64_t)n * kw * cin * 2) >= ((int64_t)1 << 31)) return false;
@@ -475,9 +515,64 @@ static bool gemm256_eligible(int B, int L, int cin, int n, int kw, int64_t ldx, 
   return true;
 }
 
+// Split-K = 2: launches whose data-carrying tiles are fewer than the CUs while K is long (the FFN's k = 9 dX at M = 27 060:
+// 106 tiles x 144 K steps) run as two half-K launches in ONE grid (212 blocks) writing fp32 partial tiles, plus the combine
+// pass.  Only plain epilogues (no activation, no ReLU mask, n == 256-multiple rows of float4), and only when the caller
+// handed over a workspace for THIS call (styler_gemm_set_workspace).
+static thread_local void* t_ws = nullptr;
+static thread_local int64_t t_ws_bytes = 0;
+
+// The next styler_conv_gemm / styler_conv_gemm_packed call of this host thread may use [ptr, ptr + bytes) as scratch (fp32
+// split-K partial tiles); the registration is consumed by that call.  styler_conv_gemm_workspace_bytes tells how much a
+// call wants (0: none).  The memory must stay valid until the call's kernels have run (stream order).
+extern "C" int styler_gemm_set_workspace(void* ptr, int64_t bytes) {
+  t_ws = ptr; t_ws_bytes = ptr ? bytes : 0;
+  return 0;
+}
+
+static int gemm256_ksplit(int B, int L, int cin, int n, int kw, int64_t ldx, int x16, bool packed, int act, bool has_mask) {
+  static const int split_on = [] { const char* e = getenv("STYLER_GEMM256_SPLITK"); return e ? atoi(e) : 1; }();
+  if (!g_enabled || !split_on || !x16 || g_min_tiles == 1) return 1;      // min_tiles == 1: the tests' "one engine, unsplit" setting
+  if ((cin % BK) || (ldx & 7) || (n % BN) || kw > 9 || (act & 0xff) != STYLER_ACT_NONE || (act & STYLER_ACT_RES_FIRST) || has_mask) return 1;
+  const int64_t M = (int64_t)B * L;
+  const int64_t mt = (M + BM - 1) / BM, nt = n / BN;
+  const int64_t tiles = (packed ? (mt * 3 + 4) / 5 : mt) * nt;
+  if (g_min_tiles != 0 && (tiles < 96 || tiles > 160 || (cin / BK) * kw < 64)) return 1;   // min_tiles == 0: tests force the split
+  if (((M + 8) * ldx * 2) >= ((int64_t)1 << 31) || ((int64_t)n * kw * cin * 2) >= ((int64_t)1 << 31)) return 1;
+  return 2;
+}
+
+extern "C" int64_t styler_conv_gemm_workspace_bytes(int B, int L, int cin, int n, int kw, int act, int prec, int io_flags,
+                                                    int64_t ldx, int packed, int has_mask) {
+  if (prec != STYLER_PREC_BF16) return 0;
+  const int ks = gemm256_ksplit(B, L, cin, n, kw, ldx, io_flags & STYLER_IO_X_BF16, packed != 0, act, has_mask != 0);
+  return ks > 1 ? (int64_t)ks * B * L * n * 4 : 0;
+}
+
 int styler_gemm256_try(const GemmArgs& a0, int x16, int y16, hipStream_t st) {
+  void* ws = t_ws;
+  const int64_t ws_bytes = t_ws_bytes;
+  t_ws = nullptr; t_ws_bytes = 0;                                    // consumed by this call, whatever engine takes it
+  if (a0.trace) return 0;
   int mt, nt;
-  if (a0.trace || !gemm256_eligible(a0.B, a0.L, a0.cin, a0.n, a0.kw, a0.ldx, x16, a0.rowinfo != nullptr, &mt, &nt)) return 0;
+  const int64_t M = (int64_t)a0.B * a0.L;
+  const int ks = gemm256_ksplit(a0.B, a0.L, a0.cin, a0.n, a0.kw, a0.ldx, x16, a0.rowinfo != nullptr, a0.act, a0.mask != nullptr);
+  if (ks > 1 && ws && ws_bytes >= (int64_t)ks * M * a0.n * 4 && !((uintptr_t)ws & 15) && !(a0.ldy & 3) &&
+      (!a0.len || (a0.rowinfo && a0.B == 1))) {                        // (length zeroing other than the packed row counter: not in the combine pass)
+    GemmArgs a = a0;
+    a.mt = (int)((M + BM - 1) / BM); a.nt = a0.n / BN;
+    a.ksplit = ks; a.part = reinterpret_cast<float*>(ws);
+    const dim3 grid((unsigned)(((a.mt + 7) / 8) * 8 * a.nt), (unsigned)ks);
+    hipLaunchKernelGGL(conv_gemm256_kernel<false>, grid, dim3(512), 0, st, a);
+    const int64_t quads = M * (a0.n >> 2);
+    const unsigned cb = (unsigned)((quads + 255) / 256 > 4096 ? 4096 : (quads + 255) / 256);
+    const int64_t* nrows = (a0.rowinfo && a0.B == 1) ? a0.len : nullptr;
+    if (y16) hipLaunchKernelGGL(gemm256_combine_kernel<true>, dim3(cb), dim3(256), 0, st, a.part, M, a0.n, ks, a0.scale, a0.shift, a0.res, a0.ldres, a0.y, a0.ldy, nrows);
+    else hipLaunchKernelGGL(gemm256_combine_kernel<false>, dim3(cb), dim3(256), 0, st, a.part, M, a0.n, ks, a0.scale, a0.shift, a0.res, a0.ldres, a0.y, a0.ldy, nrows);
+    const int rc = launch_status();
+    return rc ? (rc < 0 ? rc : -rc) : 1;
+  }
+  if (!gemm256_eligible(a0.B, a0.L, a0.cin, a0.n, a0.kw, a0.ldx, x16, a0.rowinfo != nullptr, &mt, &nt)) return 0;
   GemmArgs a = a0;
   a.mt = mt; a.nt = nt;
   const dim3 grid((unsigned)(((mt + 7) / 8) * 8 * nt));

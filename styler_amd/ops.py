@@ -358,6 +358,13 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    ws = None
+    if prec == PREC_BF16 and (io & 1):               # split-K launches of the 256 x 256 engine want scratch for their partial tiles
+        need = lib.styler_conv_gemm_workspace_bytes(B, L, cin, n, kw, act, prec, io, _ld(x), int(plan is not None),
+                                                    int(mask is not None))
+        if need and lens is None:
+            ws = torch.empty(need, device=x.device, dtype=torch.uint8)
+            lib.styler_gemm_set_workspace(ws.data_ptr(), need)
     if plan is not None:                             # packed rows: taps stay inside their item, tiles behind the data skip
         assert B == 1 and L == plan.rows
         _chk(lib.styler_conv_gemm_packed(x.data_ptr(), _ld(x), w.data_ptr(), _ptr(scale), _ptr(bias), _ptr(res),

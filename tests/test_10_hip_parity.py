@@ -182,6 +182,54 @@ def test_gemm256_engine_packed_rows(dev):
     check(y, ref.float(), 1e-4 * float(ref.abs().max()), "packed rows")
 
 
+@pytest.mark.parametrize("packed", [False, True])
+def test_gemm256_split_k(dev, packed):
+    """Split-K = 2 of the 256 x 256 engine (launches with fewer tiles than CUs and a long K: the dX of the FFN's k = 9
+    convolution): two half-K launches in one grid write fp32 partial tiles, a combine pass adds them in a fixed order and
+    applies bias + residual.  Against fp64 math and against the unsplit engines (same terms, one more rounding of the
+    halves' sums), same bits on repeated launches."""
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(91 + packed)
+    B, T, cin, n, kw = 3, 200, 1024, 256, 9
+    lens = torch.tensor([200, 131, 18])
+    x = torch.randn(B, T, cin, generator=g) * (torch.arange(T)[None, :, None] < lens[:, None, None])
+    w16 = (torch.randn(n, cin, kw, generator=g) / np.sqrt(cin * kw)).to(torch.bfloat16)
+    b = torch.randn(n, generator=g)
+    res = torch.randn(B, T, n, generator=g)
+    ref = (_conv_ref64(x.to(torch.bfloat16).float(), w16.float(), kw) + b.double() + res.double())
+    wk = w16.permute(0, 2, 1).reshape(n, -1).contiguous().to(dev)
+    if packed:
+        plan = ops.PackPlan(lens.to(dev), B, T)
+        xd = ops.pack_rows(x.to(dev), plan).to(torch.bfloat16)
+        rd = ops.pack_rows(res.to(dev), plan)
+        run = lambda: ops.conv_gemm(xd, wk, b.to(dev), kw=kw, prec=ops.PREC_BF16, plan=plan, res=rd)
+        shape = (1, B * T)
+    else:
+        xd, rd = x.to(torch.bfloat16).to(dev), res.to(dev)
+        run = lambda: ops.conv_gemm(xd, wk, b.to(dev), kw=kw, prec=ops.PREC_BF16, res=rd)
+        shape = (B, T)
+    prev = ops.gemm256_config(1, 0)                     # 0 = force the split wherever the epilogue allows it
+    try:
+        assert ops.lib.styler_conv_gemm_workspace_bytes(shape[0], shape[1], cin, n, kw, 0, ops.PREC_BF16, 1, cin, int(packed), 0) \
+            == 2 * shape[0] * shape[1] * n * 4
+        ys = [run().clone() for _ in range(3)]
+        ops.gemm256_config(1, 1)
+        y1 = run()
+        ops.gemm256_config(0, -1)
+        y128 = run()
+    finally:
+        ops.gemm256_config(*prev)
+    nv = int(lens.sum()) if packed else B * T
+    flat = (lambda t: t.reshape(-1, n)[:nv])
+    assert torch.equal(flat(ys[0]), flat(ys[1])) and torch.equal(flat(ys[0]), flat(ys[2]))
+    assert torch.equal(flat(y1), flat(y128))
+    scale = float(ref.abs().max())
+    assert float((flat(ys[0]) - flat(y1)).abs().max()) <= 1e-5 * scale
+    yy = ops.unpack_rows(ys[0], plan) if packed else ys[0]
+    want = ref * (torch.arange(T)[None, :, None] < lens[:, None, None]) if packed else ref
+    check(yy, want.float(), 1e-4 * scale, "split-K vs fp64 math")
+
+
 def test_layernorm_bf16_copy(dev):
     """styler_add_layernorm's second output: the bf16 copy is the round-to-nearest-even of the fp32 output, zeros on masked
     rows (what the FFN's first convolution reads in throughput mode)."""

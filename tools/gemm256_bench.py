@@ -35,6 +35,7 @@ def main():
         b = torch.randn(n, device=dev)
         y = torch.empty(B, L, n, device=dev, dtype=torch.bfloat16 if y16 else torch.float32)
         fl = 2.0 * B * L * n * kw * cin
+        act = ops.ACT_NONE if "dx" in name else ops.ACT_RELU     # dX launches have a plain epilogue (and may run split-K)
         res = {0: [], 1: []}
         prev = ops.gemm256_config(-1, -1)
         try:
@@ -42,12 +43,12 @@ def main():
                 for eng in (0, 1):
                     ops.gemm256_config(eng, 1)
                     for _ in range(2):
-                        ops.conv_gemm(x, w, b, kw=kw, act=ops.ACT_RELU, prec=ops.PREC_BF16, out=y)
+                        ops.conv_gemm(x, w, b, kw=kw, act=act, prec=ops.PREC_BF16, out=y)
                     iters = max(3, min(20, int(4e-3 / (fl / 0.9e15))))
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(iters):
-                        ops.conv_gemm(x, w, b, kw=kw, act=ops.ACT_RELU, prec=ops.PREC_BF16, out=y)
+                        ops.conv_gemm(x, w, b, kw=kw, act=act, prec=ops.PREC_BF16, out=y)
                     e1.record()
                     torch.cuda.synchronize()
                     res[eng].append(e0.elapsed_time(e1) * 1e3 / iters)
