@@ -210,9 +210,16 @@ __global__ void fold_replicas_kernel(const float* __restrict__ s0, const float* 
   const float* s = blockIdx.y == 0 ? s0 : blockIdx.y == 1 ? s1 : s2;
   float* d = blockIdx.y == 0 ? d0 : blockIdx.y == 1 ? d1 : d2;
   if (!s || !d) return;
-  float t = 0.f;
-  for (int r = 0; r < replicas; ++r) t += s[(int64_t)r * n + c];
-  d[c] += t;
+  // eight interleaved partial sums (eight loads in flight instead of a 256-deep dependent chain: 62 -> ~10 us), combined in
+  // a fixed tree: the order is a function of (replicas, c) only
+  float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int r = 0;
+  for (; r + 8 <= replicas; r += 8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] += s[(int64_t)(r + k) * n + c];
+  }
+  for (int k = 0; r < replicas; ++r, ++k) t[k] += s[(int64_t)r * n + c];
+  d[c] += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
 }
 
 extern "C" int styler_fold_replicas(const float* s0, const float* s1, const float* s2, float* d0, float* d1, float* d2,
