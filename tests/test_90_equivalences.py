@@ -72,9 +72,13 @@ def test_deferred_wgrad_reduce_matches_immediate(dev, train_model, ref_state_dic
             ops.wgrad_arena = None
         grads.append({k: p.grad.clone() for k, p in train_model.named_parameters() if p.grad is not None})
     assert arena.buf is not None and arena.used > 0
+    # error of a tensor against max(its own largest entry, 1e-3 x the largest gradient entry of the model): a tensor whose
+    # exact gradient is zero (a conv bias in front of a BatchNorm) holds only the rounding noise of its fp32-atomics sum,
+    # which changes with the order the blocks arrive in (tests/test_92_model_equivalences.py::grads_close)
+    gmax = max(float(v.abs().max()) for v in grads[0].values())
     for k in grads[0]:
         for other in grads[1:]:
-            e = float((grads[0][k] - other[k]).abs().max()) / max(float(grads[0][k].abs().max()), 1e-4)
+            e = float((grads[0][k] - other[k]).abs().max()) / max(float(grads[0][k].abs().max()), 1e-3 * gmax, 1e-4)
             assert e <= 1e-4, f"{k}: {e:.3e}"
     train_model.load_state_dict(ref_state_dict)
 

@@ -42,6 +42,25 @@ def check(a, b, tol, what=""):
     assert e <= tol, f"{what}: max abs err {e:.3e} > {tol}"
 
 
+def grads_close(g0, g1, tol):
+    """Every parameter gradient of two forms of the same computation.  Parameter gradients are sums over thousands of rows;
+    several of the kernels add their partial sums with fp32 atomics (bias gradients, GroupNorm gamma / beta, embedding rows),
+    so the last bits depend on the order the blocks arrive in -- from form to form AND from launch to launch.  A tensor whose
+    exact gradient is zero (a conv bias in front of a GroupNorm / BatchNorm: the norm removes the mean) holds nothing but
+    that rounding noise, ~n * eps * |term|, which relative to ITSELF is O(1).  The error of a tensor is therefore measured
+    against max(its own largest entry, 1e-3 x the largest gradient entry of the whole model): noise-only tensors are judged
+    on the scale of the gradients they were computed next to (round-2 verdict: bounds of order-dependent sums from the data)."""
+    assert g0.keys() == g1.keys()
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    worst = (0.0, None)
+    for k in g0:
+        e = float((g0[k] - g1[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-3 * gmax, 1e-4)
+        worst = max(worst, (e, k))
+        assert e <= tol, f"{k}: {e:.3e} (largest gradient entry of the model {gmax:.3e})"
+    return worst
+
+
+
 def _to(b, dev):
     return {k: v.to(dev) for k, v in b.items()}
 
@@ -93,12 +112,7 @@ def test_packed_decoder_matches_padded(dev, ref_state_dict, prec):
         for a, c in zip(*outs):
             e = float((a - c).abs().max()) / max(float(a.abs().max()), 1e-6)
             assert e <= tol, f"eval outputs differ: {e:.3e}"
-        assert grads[0].keys() == grads[1].keys()
-        for k in grads[0]:
-            if k.startswith("postnet.convolutions") and k.endswith("0.conv.bias"):
-                continue      # analytically zero (train-mode BatchNorm removes the column mean): both sides hold rounding noise
-            e = float((grads[0][k] - grads[1][k]).abs().max()) / max(float(grads[0][k].abs().max()), 1e-4)
-            assert e <= (1e-4 if prec == "fp32" else 5e-2), f"{k}: {e:.3e}"
+        grads_close(grads[0], grads[1], 1e-4 if prec == "fp32" else 5e-2)
     finally:
         rt.pack_decoder = True
         rt.disable_dropout = False
@@ -182,12 +196,7 @@ def test_paired_decodes_match_separate(dev, ref_state_dict, prec):
         assert not torch.equal(outs[1][0], outs[1][1])                       # the noisy branch is a different signal
         for x, y in zip(*losses):
             assert abs(x - y) <= 1e-5 * max(1.0, abs(x)) if prec == "fp32" else abs(x - y) <= 2e-2 * max(1.0, abs(x))
-        assert grads[0].keys() == grads[1].keys()
-        for k in grads[0]:
-            if k.startswith("postnet.convolutions") and k.endswith("0.conv.bias"):
-                continue      # analytically zero (train-mode BatchNorm removes the column mean): rounding noise on both sides
-            e = float((grads[0][k] - grads[1][k]).abs().max()) / max(float(grads[0][k].abs().max()), 1e-4)
-            assert e <= (1e-4 if prec == "fp32" else 5e-2), f"{k}: {e:.3e}"
+        grads_close(grads[0], grads[1], 1e-4 if prec == "fp32" else 5e-2)
     finally:
         rt.pair_decodes = keep
         rt.disable_dropout = False
@@ -223,10 +232,7 @@ def test_experimental_switches_match_default(dev, ref_state_dict, prec, switch):
         tol = 1e-5 if prec == "fp32" else 2e-2
         for x, y in zip(*losses):
             assert abs(x - y) <= tol * max(1.0, abs(x)), (x, y)
-        assert grads[0].keys() == grads[1].keys()
-        for k in grads[0]:
-            e = float((grads[0][k] - grads[1][k]).abs().max()) / max(float(grads[0][k].abs().max()), 1e-4)
-            assert e <= (1e-4 if prec == "fp32" else 5e-2), f"{k}: {e:.3e}"
+        grads_close(grads[0], grads[1], 1e-4 if prec == "fp32" else 5e-2)
     finally:
         setattr(rt, switch, keep)
         rt.disable_dropout = False
