@@ -17,7 +17,7 @@ One "step" is one pass of the hot path over one batch:
   "aux" in the same JSON line (default on, --no-aux to skip): the SAME train step in fp32 parity mode ("train_fp32") and
         the config-2 forward in the main precision ("forward_c2"), so that the arithmetic whose parity is 1e-3 has a
         driver-timed number next to the throughput mode (both are pinned to the oracle at this shape by
-        tests/test_bf16_parity.py).
+        tests/test_11_oracle_c2c3.py).
 
 `value` comes from EXACTLY --steps timed steps between two barriers; "repeat" reports further blocks of the same length
 (median / min / max ms per step) so that the spread of the short contract window is visible.

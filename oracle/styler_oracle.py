@@ -12,7 +12,7 @@ this module, and only as the checker / the timed CPU baseline.  Nothing under
 Pinning: the reference ships no tests or golden vectors, so this
 oracle is pinned against outputs of the reference itself, generated in the build
 container by `tests/golden/make_golden.py` (imports /root/reference, closed-form
-weights) and committed as `tests/golden/*.npz`; `tests/test_oracle_golden.py` checks
+weights) and committed as `tests/golden/*.npz`; `tests/test_00_oracle_golden.py` checks
 every function below against them.
 
 Every function cites the reference file:line it restates (paths relative to
@@ -579,7 +579,7 @@ def mel_filterbank(sr=22050, n_fft=1024, n_mels=80, fmin=0.0, fmax=8000.0) -> Te
     the reference holds no vector for mel_basis.  Cross-checked (not pinned) against a second, independent derivation --
     HF transformers' librosa-compatible `audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney")`, fixture
     tests/golden/mel_filterbank_hf.npz: max |diff| = 3.5e-8 of the peak weight -- plus self-checks in
-    tests/test_oracle_golden.py (peaks monotone, area norm)."""
+    tests/test_00_oracle_golden.py (peaks monotone, area norm)."""
     fft_f = np.linspace(0, sr / 2.0, 1 + n_fft // 2)
     mel_pts = np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2)
     hz = _mel_to_hz(mel_pts)

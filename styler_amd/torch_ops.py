@@ -11,7 +11,7 @@ the kernels compose with stock PyTorch code (`torch.ops.styler.conv_gemm(...)`, 
 Weights are the reference's parameter layouts ([n, cin] or [n, cin, kw]); the kernel layouts are derived inside the op.
 `styler_amd`'s own modules do NOT route through the dispatcher: a Python-registered operator costs tens of microseconds of
 host time per call, and the train step issues ~700 launches (they call the same C entry points directly, with the derived
-layouts cached per optimiser step -- runtime.Derived).  The two routes are the same kernels; tests/test_hip_parity.py
+layouts cached per optimiser step -- runtime.Derived).  The two routes are the same kernels; tests/test_10_hip_parity.py
 checks them against each other."""
 import torch
 from torch.library import Library, impl, register_autograd, register_fake

@@ -193,7 +193,7 @@ def _emulated_conv_gemm_pad(x, w, bias=None, *, kw, pad, act=0, prec=0, res=None
 def test_hifigan_host_composition_matches_reference(golden, hifigan_state_dict, monkeypatch):
     """The vocoder's host logic -- weight-norm folding, the ConvTranspose -> 3-tap (phase, c_out) rearrangement, dilation
     by phase views, the 11-tap split, buffer reuse -- checked on the CPU with the two HIP entry points it calls
-    replaced by their torch definitions.  (The HIP kernels themselves: tests/test_hip_parity.py, -m gpu.)"""
+    replaced by their torch definitions.  (The HIP kernels themselves: tests/test_10_hip_parity.py, -m gpu.)"""
     import json
     import numpy as np
     import torch.nn.functional as F

@@ -367,7 +367,7 @@ def test_train_step_golden(dev, train_model, golden, ref_state_dict):
             # 1e-3 on the attention projections) in one and the same build, and two builds that differ only in how
             # LayerNorm's wave reduction is scheduled land on either side of it (tools/dbg_grads.py reproduces both).
             # The bound covers the two states; the gradient norm above and the oracle comparison at the benched shape
-            # (tests/test_bf16_parity.py, 1e-4-level) are the tight checks.
+            # (tests/test_11_oracle_c2c3.py, 1e-4-level) are the tight checks.
             assert err <= 1.5e-2, f"{k}: rel err {err:.3e}"
     train_model.load_state_dict(ref_state_dict)
 
@@ -417,7 +417,7 @@ def test_train_state_steps_and_bf16(dev, ref_state_dict):
     assert float((m.decoder.layer_stack[0].pos_ffn.w_1.weight - w0).abs().max()) > 0
     assert m.decoder.layer_stack[0].pos_ffn.w_1.weight.data_ptr() >= st.flat_p.data_ptr()
     # bf16 mode on the same weights and batch: same losses and the same flat gradient within the tolerance stated in
-    # tests/test_bf16_parity.py (which pins both modes to the oracle at the benched shape)
+    # tests/test_11_oracle_c2c3.py (which pins both modes to the oracle at the benched shape)
     from styler_amd.training import forward_backward
     rt.disable_dropout = True
     try:

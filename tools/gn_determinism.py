@@ -25,7 +25,7 @@ for L in (137, 600, 1100):
         if dx0 is None: dx0 = dx.clone()
         bwd_bad += int((dx != dx0).sum()); bwd_max = max(bwd_max, float((dx - dx0).abs().max()))
     print(f"L={L}: fwd mismatching elements {fwd_bad} (max diff {fwd_max:.3e}); bwd mismatching {bwd_bad} (max diff {bwd_max:.3e}; |dx| max {float(dx0.abs().max()):.3f})")
-# the three storage variants of the backward against each other (what tests/test_bf16_acts.py asserts), repeated
+# the three storage variants of the backward against each other (what tests/test_91_bf16_acts.py asserts), repeated
 for L in (137, 600):
     B, C = 6, 320
     g = torch.Generator().manual_seed(12)
