@@ -377,6 +377,8 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
                                   _ld(res) if res is not None else 0, out.data_ptr(), _ld(out), B, L, cin, n,
                                   kw, act, prec, _ptr(lens), _ptr(mask), _ld(mask) if mask is not None else 0, io,
                                   _stream()), "styler_conv_gemm")
+    if ws is not None:
+        lib.styler_gemm_set_workspace(None, 0)       # (consumed by the call above; cleared again in case it never got there)
     if prof is not None:
         e1.record()
         prof.records.append((lib.styler_conv_gemm_engine(B, L, cin, n, kw, prec, io, _ld(x), int(plan is not None)), 2.0 * B * L * n * kw * cin,
