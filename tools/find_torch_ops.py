@@ -18,9 +18,16 @@ import styler_amd
 from styler_amd import rt
 from styler_amd.training import TrainState, train_step
 
-VIEWS = ("view", "reshape", "slice", "select", "transpose", "expand", "unsqueeze", "squeeze", "detach", "alias",
-         "as_strided", "empty", "permute", "unbind", "split", "_local_scalar_dense", "t.default", "is_", "sym_", "stride",
-         "size", "numel", "lift_fresh", "_to_copy_noop", "record_stream", "unflatten", "flatten", "_reshape_alias", "narrow")
+VIEWS = {"view", "_unsafe_view", "reshape", "slice", "select", "transpose", "expand", "unsqueeze", "squeeze", "detach", "alias",
+         "as_strided", "empty", "empty_like", "empty_strided", "new_empty", "permute", "unbind", "split", "split_with_sizes",
+         "_local_scalar_dense", "t", "is_same_size", "sym_size", "sym_stride", "sym_numel", "stride", "size", "numel",
+         "lift_fresh", "record_stream", "unflatten", "flatten", "_reshape_alias", "narrow", "is_pinned", "set_", "resize_"}
+
+
+def is_view(name):
+    """aten.<op>.<overload> -> True for metadata-only ops (exact op names: 'cat' must not match 't')."""
+    parts = name.split(".")
+    return len(parts) >= 2 and parts[1] in VIEWS
 
 
 class Tracer(TorchDispatchMode):
@@ -31,7 +38,7 @@ class Tracer(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         out = func(*args, **(kwargs or {}))
         name = str(func)
-        if any(v in name for v in VIEWS):
+        if is_view(name):
             return out
         flat = [a for a in torch.utils._pytree.tree_leaves((args, kwargs)) if torch.is_tensor(a)]
         if not any(a.is_cuda for a in flat):
