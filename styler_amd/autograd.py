@@ -127,15 +127,28 @@ def _ln_tail_fwd(o, x, ln, lens, drop_p, want16=False):
     y16 = torch.empty_like(x, dtype=torch.bfloat16) if want16 else None
     y = ops.add_layernorm(o, ln.weight, ln.bias, res=x, lens=lens, in_drop_p=drop_p, in_drop_seed=seed, sum_out=s,
                           out16=y16)
+    if rt.sim_bf16_stream and rt.prec == ops.PREC_BF16:
+        y, s = _r16(y), _r16(s)
     return (y, s, (drop_p, seed), y16) if want16 else (y, s, (drop_p, seed))
+
+
+def _r16(t):
+    """rt.sim_bf16_stream: the value a bf16-stored tensor would hold."""
+    return t.to(torch.bfloat16).to(torch.float32)
 
 
 def _ln_tail_bwd(s, dy, ln, lens, drop):
     """-> (gradient of the residual input, gradient of the dropout branch)."""
+    sim = rt.sim_bf16_stream and rt.prec == ops.PREC_BF16
+    if sim:
+        dy = _r16(dy)
     if drop[0] > 0:
-        return ops.layernorm_bwd(s, dy, ln.weight, ln.bias, G(ln.weight), G(ln.bias), lens=lens, in_drop_p=drop[0],
-                                 in_drop_seed=drop[1])
+        dx, dxd = ops.layernorm_bwd(s, dy, ln.weight, ln.bias, G(ln.weight), G(ln.bias), lens=lens, in_drop_p=drop[0],
+                                    in_drop_seed=drop[1])
+        return (_r16(dx), _r16(dxd)) if sim else (dx, dxd)
     dx = ops.layernorm_bwd(s, dy, ln.weight, ln.bias, G(ln.weight), G(ln.bias), lens=lens)
+    if sim:
+        dx = _r16(dx)
     return dx, dx
 
 
@@ -542,7 +555,8 @@ class LengthRegulateFn(Function):
     def forward(ctx, x, csum, T):
         ctx.save_for_backward(csum)
         ctx.S = x.shape[1]
-        return ops.length_regulate(x, csum, T)
+        out = ops.length_regulate(x, csum, T)
+        return _r16(out) if (rt.sim_bf16_stream and rt.prec == ops.PREC_BF16) else out
 
     @staticmethod
     def backward(ctx, dy):
@@ -688,7 +702,8 @@ class PackPairFn(Function):
     @staticmethod
     def forward(ctx, xa, xb, pe, plan):
         ctx.plan = plan
-        return ops.pack_rows_pair(xa, xb, plan, add=pe)
+        out = ops.pack_rows_pair(xa, xb, plan, add=pe)
+        return _r16(out) if (rt.sim_bf16_stream and rt.prec == ops.PREC_BF16) else out
 
     @staticmethod
     def backward(ctx, dy):

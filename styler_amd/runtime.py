@@ -53,6 +53,11 @@ class _Runtime:
     # throughput mode: the dX GEMM of the BiLSTM input projections (gate gradients x W_ih) on bf16 operands like every
     # other dX GEMM of the step (round 2 left these eight launches on the fp32 MFMA path: 0.2 ms per step)
     lstm_dx_bf16 = os.environ.get("STYLER_LSTM_DX_BF16", "1") != "0"
+    # EXPERIMENT (numerics only, not a fast path): round the residual stream of the FFT blocks -- LayerNorm outputs, the saved
+    # pre-norm sums, the packed decoder input, the LengthRegulator output, and the gradients that flow back along them -- to
+    # bf16 with torch casts, to measure what a model-wide bf16 activation format would do to the parity bounds BEFORE
+    # building its kernels.
+    sim_bf16_stream = os.environ.get("STYLER_SIM_BF16_STREAM", "0") == "1"
 
     # each StylePredictor stage (conv -> ReLU -> LayerNorm -> dropout [-> Linear -> mask]) as one tape node whose backward
     # is one LayerNorm-backward kernel + weight gradient + dX GEMM (STYLER_FUSED_PREDICTOR=0: separate nodes)

@@ -104,6 +104,8 @@ class MultiHeadAttention(_HipModule):
         if want16:
             y16 = torch.empty_like(o, dtype=torch.bfloat16)
         y = ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out, out16=y16)
+        if rt.sim_bf16_stream and rt.prec == ops.PREC_BF16:
+            y.copy_(y.to(torch.bfloat16))
         return (y, y16) if asked else y
 
 
@@ -130,7 +132,10 @@ class PositionwiseFeedForward(_HipModule):
             return self._ln(self._gemm("w_2", h, self.w_2, kw=k[1], plan=plan), x, self.layer_norm, lens, out,
                             drop_p=self.dropout.p if self.training else 0.0)
         o = self._gemm("w_2", h, self.w_2, kw=k[1], res=x, plan=plan)
-        return ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out)
+        y = ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out)
+        if rt.sim_bf16_stream and rt.prec == ops.PREC_BF16:
+            y.copy_(y.to(torch.bfloat16))
+        return y
 
 
 class FFTBlock(nn.Module):

@@ -54,8 +54,12 @@ def grads_close(g0, g1, tol):
     gmax = max(float(v.abs().max()) for v in g0.values())
     worst = (0.0, None)
     for k in g0:
+        if k.startswith("postnet.convolutions") and k.endswith("0.conv.bias"):
+            continue      # analytically zero (train-mode BatchNorm removes the column mean): rounding noise on both sides -- in
+                          # bf16 mode the noise of a sum of bf16-rounded terms, which has nothing in common between two forms
         e = float((g0[k] - g1[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-3 * gmax, 1e-4)
-        worst = max(worst, (e, k))
+        if e > worst[0]:
+            worst = (e, k)
         assert e <= tol, f"{k}: {e:.3e} (largest gradient entry of the model {gmax:.3e})"
     return worst
 
