@@ -327,21 +327,29 @@ def hbm_rooflines(dev, B, S, T, frames, tag):
     del xs, dys
     if tag == "c4":
         return out
-    # LayerNorm at the decoder's row count (clean + noisy decode packed: 2 x valid frames)
+    # LayerNorm at the decoder's row count (clean + noisy decode packed: 2 x valid frames), in the storage formats of the
+    # throughput-mode step: GEMM output fp32, residual stream / saved pre-norm sum / gradients along the stream bf16
     rows = 2 * frames
     gam, bet = torch.randn(256, device=dev), torch.randn(256, device=dev)
-    n = nsets_for(rows * 4096)
+    bf = torch.bfloat16
+    n = nsets_for(rows * 2560)
     a = [torch.randn(1, rows, 256, device=dev) for _ in range(n)]
-    r = [torch.randn(1, rows, 256, device=dev) for _ in range(n)]
-    so = [torch.empty(1, rows, 256, device=dev) for _ in range(n)]
-    yo = [torch.empty(1, rows, 256, device=dev) for _ in range(n)]
-    add("add_layernorm_kernel (train: x + res -> y, pre-norm sum kept)", f"rows={rows} x 256 fp32", rows * 4096,
-        lambda i: (lambda: ops.add_layernorm(a[i], gam, bet, res=r[i], sum_out=so[i], out=yo[i])),
-        "2 reads + 2 writes of 1 KB per row (eval form: 3072 B/pos, SURVEY 8d)")
+    r = [torch.randn(1, rows, 256, device=dev).to(bf) for _ in range(n)]
+    so = [torch.empty(1, rows, 256, device=dev, dtype=bf) for _ in range(n)]
+    yo = [torch.empty(1, rows, 256, device=dev, dtype=bf) for _ in range(n)]
+    add("add_layernorm_kernel (train: dropout(x) + res -> y, pre-norm sum kept; bf16 stream)",
+        f"rows={rows} x 256: x fp32, res / y / sum bf16", rows * 2560,
+        lambda i: (lambda: ops.add_layernorm(a[i], gam, bet, res=r[i], sum_out=so[i], out=yo[i], in_drop_p=0.2, in_drop_seed=5)),
+        "x 1024 B + res 512 B read, y 512 B + sum 512 B written per row (all-fp32 form: 4096 B; eval form 3072 B, SURVEY 8d)", nsets=n)
+    for i in range(n):
+        ops.add_layernorm(a[i], gam, bet, res=r[i], sum_out=so[i], out=yo[i])
+    dyb = [torch.randn(1, rows, 256, device=dev).to(bf) for _ in range(n)]
     dg, db = torch.zeros(256, device=dev), torch.zeros(256, device=dev)
-    add("layernorm_bwd_kernel (s, dy -> dx)", f"rows={rows} x 256 fp32", rows * 3072,
-        lambda i: (lambda: ops.layernorm_bwd(a[i], r[i], gam, bet, dg, db)), "2 reads + 1 write of 1 KB per row", nsets=n)
-    del a, r, so, yo
+    add("layernorm_bwd_kernel (sum, dy -> dx, dx through the dropout mask; bf16 stream)", f"rows={rows} x 256, all four bf16",
+        rows * 2048,
+        lambda i: (lambda: ops.layernorm_bwd(so[i], dyb[i], gam, bet, dg, db, in_drop_p=0.2, in_drop_seed=5)),
+        "2 reads + 2 writes of 512 B per row (all-fp32 form: 4096 B)", nsets=n)
+    del a, r, so, yo, dyb
     # GroupNorm + ReLU of the AudioEncoder (main + DAT pass stacked: 2B items), C = 320, fp32 conv output -> bf16
     Bg, C = 2 * B, 320
     gnb = Bg * T * C

@@ -45,6 +45,12 @@ extern "C" {
 #define STYLER_IO_X_BF16 1    /* conv_gemm: x;   wgrad: x  */
 #define STYLER_IO_Y_BF16 2    /* conv_gemm: y (no residual);   wgrad: dz */
 #define STYLER_IO_MASK_BF16 4 /* conv_gemm: mask */
+#define STYLER_IO_RES_BF16 8  /* conv_gemm: res (then allowed together with STYLER_IO_Y_BF16);  pack / unpack: see there */
+/* styler_add_layernorm io_flags (round 3: the decoder's residual stream is stored as bf16 in throughput mode) */
+#define STYLER_LN_RES_BF16 1  /* res is bf16 */
+#define STYLER_LN_Y_BF16 2    /* y is written as bf16 (ldy in elements) */
+#define STYLER_LN_SUM_BF16 4  /* sum_out is written as bf16 -- and the row is normalised from that rounded sum, which is what
+                               * styler_layernorm_bwd recomputes the statistics from */
 
 /* arithmetic of the MFMA GEMM core */
 #define STYLER_PREC_F32  0  /* v_mfma_f32_32x32x2_f32: exact fp32 (parity mode)            */
@@ -84,12 +90,13 @@ int styler_conv_gemm(const float* x, int64_t ldx, const void* w, const float* sc
  * (styler_add_layernorm, styler_layernorm_bwd, styler_act_bwd, styler_conv_gemm with B = 1). */
 int styler_pack_plan(const int64_t* len, int B, int T, int32_t* cu, int32_t* rowinfo,
                      int32_t* chunktab, int64_t* counts, void* stream);
-/* packed[cu[b]+t] = padded[b,t] (+ add[t,:], e.g. the positional table of Models.py:120-125), t < len[b] */
+/* packed[cu[b]+t] = padded[b,t] (+ add[t,:], e.g. the positional table of Models.py:120-125), t < len[b].
+ * io_flags (both directions): STYLER_IO_X_BF16 = the PADDED tensor is bf16, STYLER_IO_Y_BF16 = the PACKED tensor is bf16. */
 int styler_pack_rows(const float* padded, int64_t ldp, float* packed, int64_t ldk, const float* add,
-                     const int32_t* cu, int B, int T, int C, void* stream);
+                     const int32_t* cu, int B, int T, int C, int io_flags, void* stream);
 /* padded[b,t] = t < len[b] ? packed[cu[b]+t] : 0   (also the backward of styler_pack_rows) */
 int styler_unpack_rows(const float* packed, int64_t ldk, float* padded, int64_t ldp,
-                       const int32_t* cu, int B, int T, int C, void* stream);
+                       const int32_t* cu, int B, int T, int C, int io_flags, void* stream);
 /* styler_conv_gemm on packed rows: taps never cross an item (rowinfo), tiles behind the data are
  * skipped, rows >= nrows[0] are written as 0. */
 int styler_conv_gemm_packed(const float* x, int64_t ldx, const void* w, const float* scale,
@@ -200,7 +207,7 @@ int styler_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t 
                          const float* dot_w, const float* dot_b, float* dot_out, int B, int L,
                          int C, const int64_t* len, float drop_p, uint64_t drop_seed, float in_drop_p,
                          uint64_t in_drop_seed, float* sum_out, int64_t ldsum, uint16_t* y16, int64_t ldy16,
-                         void* stream);
+                         int io_flags, void* stream);
 
 /* y = relu(GroupNorm(x)) with groups of 16 channels and statistics over 16 ch x the whole
  * padded L (modules.py:103-113,171-175; eps 1e-5).  In place allowed (y == x).
@@ -504,6 +511,10 @@ int styler_attention_bwd(const float* qkv, const float* out, const float* dout, 
  * flags & STYLER_LNB_RELU_INPUT: x is the output of a ReLU (StylePredictor: Conv1d -> ReLU -> LayerNorm,
  * modules.py:430-447) and dx is returned as the gradient w.r.t. the ReLU's INPUT (dx where x > 0, else 0). */
 #define STYLER_LNB_RELU_INPUT 1
+#define STYLER_LNB_X_BF16 2     /* x (the saved pre-norm sum) is bf16 */
+#define STYLER_LNB_DY_BF16 4    /* dy is bf16 */
+#define STYLER_LNB_DX_BF16 8    /* dx is written as bf16 */
+#define STYLER_LNB_DXD_BF16 16  /* dx_drop is written as bf16 */
 int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy,
                          const float* gamma, const float* beta, float* dx, int64_t lddx,
                          float* dgamma, float* dbeta, const float* dot_w, const float* dout,

@@ -27,7 +27,7 @@ _SIGS = {
     "styler_attention_fwd": [P, P, P, I, I, P, P, P],
     "styler_attention_fwd_bf16": [P, P, P, I, I, P, P, P],
     "styler_attention_bwd_bf16": [P, P, P, P, P, P, I, I, P, P, I, P],
-    "styler_add_layernorm": [P, I64, P, I64, P, P, P, I64, P, P, P, I, I, I, P, F, ctypes.c_uint64, F, ctypes.c_uint64, P, I64, P, I64, P],
+    "styler_add_layernorm": [P, I64, P, I64, P, P, P, I64, P, P, P, I, I, I, P, F, ctypes.c_uint64, F, ctypes.c_uint64, P, I64, P, I64, I, P],
     "styler_groupnorm_relu": [P, I64, P, P, P, I64, P, P, I, I, I, I, I, P],
     "styler_bn_fold": [P, P, P, P, P, P, P, I, P],
     "styler_batchnorm_train": [P, P, P, P, P, P, P, P, P, I, I64, I, I, F, ctypes.c_uint64, I, I, P],
@@ -44,8 +44,8 @@ _SIGS = {
     "styler_wgrad_group_desc": [P, P, I64, P, I64, P, P, I, I, I, I, I, I, I, P, P, P, I, I],
     "styler_wgrad_group": [P, I, I, I, P],
     "styler_pack_plan": [P, I, I, P, P, P, P, P],
-    "styler_pack_rows": [P, I64, P, I64, P, P, I, I, I, P],
-    "styler_unpack_rows": [P, I64, P, I64, P, I, I, I, P],
+    "styler_pack_rows": [P, I64, P, I64, P, P, I, I, I, I, P],
+    "styler_unpack_rows": [P, I64, P, I64, P, I, I, I, I, P],
     "styler_conv_gemm_packed": [P, I64, P, P, P, P, I64, P, I64, I, I, I, I, I, I, P, P, P, I64, I, P],
     "styler_wgrad_packed": [P, I64, P, I64, P, P, I64, I64, I64, I, I, I, I, I, P, I, P, P, P, I, P],
     "styler_lstm_bidir_bwd_multi": [P, I, I, I, P],

@@ -123,11 +123,11 @@ def _ln_tail_fwd(o, x, ln, lens, drop_p, want16=False):
     fourth value, the bf16 copy of y for the GEMM that consumes it."""
     drop_p = 0.0 if rt.disable_dropout else drop_p
     seed = next_dropout_seed() if drop_p > 0 else 0
-    s = torch.empty_like(x)
-    y16 = torch.empty_like(x, dtype=torch.bfloat16) if want16 else None
+    s = torch.empty_like(x)                           # bf16 when the residual stream is (x bf16): y comes out as bf16 too
+    y16 = torch.empty_like(x, dtype=torch.bfloat16) if (want16 and x.dtype != torch.bfloat16) else None
     y = ops.add_layernorm(o, ln.weight, ln.bias, res=x, lens=lens, in_drop_p=drop_p, in_drop_seed=seed, sum_out=s,
                           out16=y16)
-    if rt.sim_bf16_stream and rt.prec == ops.PREC_BF16:
+    if rt.sim_bf16_stream and rt.prec == ops.PREC_BF16 and x.dtype != torch.bfloat16:
         y, s = _r16(y), _r16(s)
     return (y, s, (drop_p, seed), y16) if want16 else (y, s, (drop_p, seed))
 
@@ -139,7 +139,7 @@ def _r16(t):
 
 def _ln_tail_bwd(s, dy, ln, lens, drop):
     """-> (gradient of the residual input, gradient of the dropout branch)."""
-    sim = rt.sim_bf16_stream and rt.prec == ops.PREC_BF16
+    sim = rt.sim_bf16_stream and rt.prec == ops.PREC_BF16 and s.dtype != torch.bfloat16
     if sim:
         dy = _r16(dy)
     if drop[0] > 0:
@@ -191,7 +191,7 @@ class FfnSublayerFn(Function):
                            plan=plan, mask=h, out_bf16=h.dtype == torch.bfloat16)
         ops.wgrad(dh, x, G(w_1.weight), d_hid, d_in, kw=kw1, db=G(w_1.bias), plan=plan)
         dx = ops.conv_gemm(dh, gemm_weight_bwd(ffn._derived, "w_1", w_1.weight, bf16), None, kw=kw1, n=d_in, prec=prec,
-                           plan=plan, res=dx_res)
+                           plan=plan, res=dx_res, out_bf16=x.dtype == torch.bfloat16)      # bf16 stream: bf16 gradient
         return dx, None, None, None, None, None, None
 
 
@@ -209,7 +209,7 @@ class AttnSublayerFn(Function):
         wfc, pfc = gemm_weight(mha._derived, "fc", mha.fc.weight, 256)
         o = ops.conv_gemm(att, wfc, mha.fc.bias, n=256, prec=pfc, plan=plan)
         want16 = want16 and prec == ops.PREC_BF16
-        if want16:
+        if want16:                                    # (on a bf16 stream the second value is None: y itself is bf16)
             y, s, ctx.drop, y16 = _ln_tail_fwd(o, x, mha.layer_norm, lens, drop_p, want16=True)
         else:
             y, s, ctx.drop = _ln_tail_fwd(o, x, mha.layer_norm, lens, drop_p)
@@ -236,7 +236,7 @@ class AttnSublayerFn(Function):
             ops.wgrad(dqkv[..., i * 256:(i + 1) * 256], x, G(lin.weight), 256, 256, db=G(lin.bias), plan=plan)
         wt = mha._derived.get_spec("qkv_wT16" if bf16 else "qkv_wT", (256, 768), bf16,
                                    lambda: [seg_transposed(w, k * 256, 768) for k, w in enumerate(srcs)])
-        dx = ops.conv_gemm(dqkv, wt, None, n=256, prec=prec, plan=plan, res=dx_res)
+        dx = ops.conv_gemm(dqkv, wt, None, n=256, prec=prec, plan=plan, res=dx_res, out_bf16=x.dtype == torch.bfloat16)
         return dx, None, None, None, None, None, None
 
 
@@ -607,13 +607,13 @@ class PackRowsFn(Function):
     """padded [B, T, C] (+ positional table) -> packed [1, B*T, C] (ops.PackPlan); backward = unpack."""
 
     @staticmethod
-    def forward(ctx, x, pe, plan):
+    def forward(ctx, x, pe, plan, out_bf16=False):
         ctx.plan = plan
-        return ops.pack_rows(x, plan, add=pe)
+        return ops.pack_rows(x, plan, add=pe, out_bf16=out_bf16)
 
     @staticmethod
     def backward(ctx, dy):
-        return ops.unpack_rows(dy, ctx.plan), None, None
+        return ops.unpack_rows(dy, ctx.plan), None, None, None
 
 
 class SplitChannelsFn(Function):
@@ -700,15 +700,15 @@ class PackPairFn(Function):
     """Two padded [B, T, C] tensors (+ positional table) -> one packed batch of 2B items; backward = unpack per half."""
 
     @staticmethod
-    def forward(ctx, xa, xb, pe, plan):
+    def forward(ctx, xa, xb, pe, plan, out_bf16=False):
         ctx.plan = plan
-        out = ops.pack_rows_pair(xa, xb, plan, add=pe)
-        return _r16(out) if (rt.sim_bf16_stream and rt.prec == ops.PREC_BF16) else out
+        out = ops.pack_rows_pair(xa, xb, plan, add=pe, out_bf16=out_bf16)
+        return _r16(out) if (rt.sim_bf16_stream and rt.prec == ops.PREC_BF16 and not out_bf16) else out
 
     @staticmethod
     def backward(ctx, dy):
         da, db = ops.unpack_rows_pair(dy, ctx.plan)
-        return da, db, None, None
+        return da, db, None, None, None
 
 
 class UnpackRowsFn(Function):
@@ -716,12 +716,12 @@ class UnpackRowsFn(Function):
 
     @staticmethod
     def forward(ctx, xp, plan):
-        ctx.plan = plan
+        ctx.plan, ctx.in16 = plan, xp.dtype == torch.bfloat16
         return ops.unpack_rows(xp, plan)
 
     @staticmethod
     def backward(ctx, dy):
-        return ops.pack_rows(ops._rows_view(dy), ctx.plan), None
+        return ops.pack_rows(ops._rows_view(dy), ctx.plan, out_bf16=ctx.in16), None
 
 
 class Add2Fn(Function):

@@ -90,6 +90,18 @@ __device__ __forceinline__ float4 raw4_f32(const uint2& u) {
                      __uint_as_float(u.y & 0xffff0000u));
 }
 
+// Four consecutive elements at element index `idx` of a tensor stored as fp32 or (is16) bf16 -- load as float4 / store a
+// float4 (round to nearest even).  For the row-wise kernels whose tensors may live in either format (round 3: the decoder's
+// residual stream is bf16 in throughput mode); `is16` is uniform, the branch costs nothing next to the memory access.
+__device__ __forceinline__ float4 ldg4(const void* base, int64_t idx, bool is16) {
+  if (is16) return raw4_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + idx));
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
+}
+__device__ __forceinline__ void stg4(void* base, int64_t idx, const float4& v, bool is16) {
+  if (is16) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + idx) = make_uint2(cvt_pk_bf16_rne(v.x, v.y), cvt_pk_bf16_rne(v.z, v.w));
+  else *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx) = v;
+}
+
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
 }

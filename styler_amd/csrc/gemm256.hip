@@ -366,13 +366,14 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b), 0, (int)rec, 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t y_rs = tile_rsrc(a.y, a.ldy, Y_ES);
-  const __amdgpu_buffer_rsrc_t r_rs = tile_rsrc(a.res ? (const void*)a.res : a.y, a.res ? a.ldres : a.ldy, 4);
+  const int r_es = a.res16 ? 2 : 4;
+  const __amdgpu_buffer_rsrc_t r_rs = tile_rsrc(a.res ? (const void*)a.res : a.y, a.res ? a.ldres : a.ldy, a.res ? r_es : Y_ES);
   const int m_es = a.mask16 ? 2 : 4;
   const __amdgpu_buffer_rsrc_t m_rs = tile_rsrc(a.mask ? a.mask : a.y, a.mask ? a.ldmask : a.ldy, a.mask ? m_es : Y_ES);
   const uint32_t oy0 = col_ok ? (uint32_t)((wrow0 * (int)a.ldy + col) * Y_ES) : OOB;
-  const uint32_t or0 = col_ok ? (uint32_t)((wrow0 * (int)a.ldres + col) * 4) : OOB;
+  const uint32_t or0 = col_ok ? (uint32_t)((wrow0 * (int)a.ldres + col) * r_es) : OOB;
   const uint32_t om0 = col_ok ? (uint32_t)((wrow0 * (int)a.ldmask + col) * m_es) : OOB;
-  const uint32_t ystep = (uint32_t)(RPP * (int)a.ldy * Y_ES), rstep = (uint32_t)(RPP * (int)a.ldres * 4),
+  const uint32_t ystep = (uint32_t)(RPP * (int)a.ldy * Y_ES), rstep = (uint32_t)(RPP * (int)a.ldres * r_es),
                  mstep = (uint32_t)(RPP * (int)a.ldmask * m_es);
 
   auto tail = [&](auto act_tag) {
@@ -387,8 +388,17 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
       __syncthreads();
       i32x4 rr[NP], mk[NP];
       if (a.res) {
+        if (a.res16) {
 #pragma unroll
-        for (int u = 0; u < NP; ++u) rr[u] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, or0 + (i * 8 + u) * rstep, 0, 0);
+          for (int u = 0; u < NP; ++u) {
+            const i32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r_rs, or0 + (i * 8 + u) * rstep, 0, 0);
+            rr[u] = i32x4{(int)((uint32_t)t.x << 16), (int)((uint32_t)t.x & 0xffff0000u), (int)((uint32_t)t.y << 16),
+                          (int)((uint32_t)t.y & 0xffff0000u)};
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < NP; ++u) rr[u] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, or0 + (i * 8 + u) * rstep, 0, 0);
+        }
       }
       if (a.mask) {
         if (a.mask16) {
@@ -456,7 +466,7 @@ template <bool Y16>
 __global__ __launch_bounds__(256) void gemm256_combine_kernel(const float* __restrict__ part, int64_t M, int n, int ksplit,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* __restrict__ res, int64_t ldres, void* __restrict__ y,
-                                                              int64_t ldy, const int64_t* __restrict__ nrows) {
+                                                              int64_t ldy, const int64_t* __restrict__ nrows, int res16) {
   const int q = n >> 2;                                                      // float4 per row
   const int64_t lim = nrows ? (nrows[0] < M ? nrows[0] : M) : M;
   const int64_t total = lim * q;
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(256) void gemm256_combine_kernel(const float* __res
     }
     if (scale) { const float4 t = *reinterpret_cast<const float4*>(scale + c); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
     if (shift) { const float4 t = *reinterpret_cast<const float4*>(shift + c); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-    if (res) { const float4 t = *reinterpret_cast<const float4*>(res + r * ldres + c); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    if (res) { const float4 t = ldg4(res, r * ldres + c, res16 != 0); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
     if (Y16) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(y) + r * ldy + c) = make_uint2(cvt_pk_bf16_rne(v.x, v.y), cvt_pk_bf16_rne(v.z, v.w));
     else *reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + r * ldy + c) = v;
   }
@@ -567,8 +577,8 @@ int styler_gemm256_try(const GemmArgs& a0, int x16, int y16, hipStream_t st) {
     const int64_t quads = M * (a0.n >> 2);
     const unsigned cb = (unsigned)((quads + 255) / 256 > 4096 ? 4096 : (quads + 255) / 256);
     const int64_t* nrows = (a0.rowinfo && a0.B == 1) ? a0.len : nullptr;
-    if (y16) hipLaunchKernelGGL(gemm256_combine_kernel<true>, dim3(cb), dim3(256), 0, st, a.part, M, a0.n, ks, a0.scale, a0.shift, a0.res, a0.ldres, a0.y, a0.ldy, nrows);
-    else hipLaunchKernelGGL(gemm256_combine_kernel<false>, dim3(cb), dim3(256), 0, st, a.part, M, a0.n, ks, a0.scale, a0.shift, a0.res, a0.ldres, a0.y, a0.ldy, nrows);
+    if (y16) hipLaunchKernelGGL(gemm256_combine_kernel<true>, dim3(cb), dim3(256), 0, st, a.part, M, a0.n, ks, a0.scale, a0.shift, a0.res, a0.ldres, a0.y, a0.ldy, nrows, a0.res16);
+    else hipLaunchKernelGGL(gemm256_combine_kernel<false>, dim3(cb), dim3(256), 0, st, a.part, M, a0.n, ks, a0.scale, a0.shift, a0.res, a0.ldres, a0.y, a0.ldy, nrows, a0.res16);
     const int rc = launch_status();
     return rc ? (rc < 0 ? rc : -rc) : 1;
   }

@@ -21,6 +21,7 @@ struct GemmArgs {
   uint64_t* trace;                                 // styler_gemm_set_trace: 8 words per block (phase timestamps), or null
   int ksplit = 1;                                  // gemm256.hip: split-K factor of the launch (1 or 2)
   float* part = nullptr;                           // ... and its fp32 partial tiles [ksplit][B*L][n] (styler_gemm_set_workspace)
+  int res16 = 0;                                   // the residual tensor is bf16 (STYLER_IO_RES_BF16; ldres in elements)
 };
 
 // gemm256.hip: returns 1 when the 256x256 LDS-DMA engine takes the launch (and has enqueued it), 0 when the shape is not

@@ -582,7 +582,7 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
   if (dz16 || x16) {                                 // bf16-resident operands: the two shapes of the FFN sublayer, and the
     // k = 5 convolutions of the AudioEncoder / PostNet stacks (any combination of the two operands)
     const bool ok = prec == STYLER_PREC_BF16 && (!dz16 || !(lddz & 7)) && (!x16 || !(ldx & 7)) &&
-                    ((x16 != dz16 && kw == 1 && pad_left == 0) || (dz16 && !x16 && kw == 9) || kw == 5);
+                    ((kw == 1 && pad_left == 0) || (dz16 && kw == 9) || kw == 5);
     if (!ok) return STYLER_EINVAL;
   }
   if (kw != 1 && kw != 3 && kw != 5 && kw != 9) return STYLER_EINVAL;
@@ -605,7 +605,10 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
     if (kw == 1) {
       if (x16 || dz16) {                             // (x16: the FFN hidden activation; dz16: the attention's dqkv)
         if (TA != 2 || TB != 2) return STYLER_EINVAL;
-        if (x16)
+        if (x16 && dz16)                             // (both: the decoder's bf16 residual stream, round 3)
+          hipLaunchKernelGGL((wgrad_tr_kernel<1, 2, 2, true, true>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, db2, Be, Le,
+                             n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, nullptr, counts);
+        else if (x16)
           hipLaunchKernelGGL((wgrad_tr_kernel<1, 2, 2, false, true>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, db2, Be, Le,
                              n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, nullptr, counts);
         else
@@ -625,7 +628,10 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
       } else if (TA == 2) WT_LAUNCH(5, 2, 1); else WT_LAUNCH(5, 1, 1);
 #undef WT5
     } else {
-      if (dz16)
+      if (dz16 && x16)
+        hipLaunchKernelGGL((wgrad_tr_kernel<9, 1, 1, true, true>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, db2, Be, Le,
+                           n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, reinterpret_cast<const int4*>(chunktab), counts);
+      else if (dz16)
         hipLaunchKernelGGL((wgrad_tr_kernel<9, 1, 1, true, false>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, db2, Be, Le,
                            n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, reinterpret_cast<const int4*>(chunktab), counts);
       else
@@ -671,7 +677,7 @@ extern "C" int styler_wgrad_packed(const float* dz, int64_t lddz, const float* x
 //   7: Linear, 128x128 tile, dz resident as bf16
 static int wgrad_variant(int kw, int TA, int TB, bool dz16, bool x16) {
   if (kw == 1) {
-    if (dz16) return (!x16 && TA == 2 && TB == 2) ? 7 : -1;
+    if (dz16) return (TA == 2 && TB == 2) ? (x16 ? 8 : 7) : -1;       // 8: both operands bf16 (the decoder's bf16 stream)
     if (x16) return (TA == 2 && TB == 2) ? 2 : -1;
     if (TA == 1 && TB == 1) return 0;
     if (TA == 2 && TB == 2) return 1;
@@ -735,6 +741,7 @@ extern "C" int styler_wgrad_group(const StylerWgradGroupDesc* desc_dev, int coun
     case 5: WGG(9, 1, 1, false, false); break;
     case 6: WGG(9, 1, 1, true, false); break;
     case 7: WGG(1, 2, 2, true, false); break;
+    case 8: WGG(1, 2, 2, true, true); break;
     default: return STYLER_EINVAL;
   }
 #undef WGG

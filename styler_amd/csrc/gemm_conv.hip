@@ -392,13 +392,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b), 0, (int)rec, 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t y_rs = tile_rsrc(a.y, a.ldy, Y_ES);
-  const __amdgpu_buffer_rsrc_t r_rs = tile_rsrc(a.res ? (const void*)a.res : a.y, a.res ? a.ldres : a.ldy, 4);
+  const int r_es = a.res16 ? 2 : 4;
+  const __amdgpu_buffer_rsrc_t r_rs = tile_rsrc(a.res ? (const void*)a.res : a.y, a.res ? a.ldres : a.ldy, a.res ? r_es : Y_ES);
   const int m_es = a.mask16 ? 2 : 4;
   const __amdgpu_buffer_rsrc_t m_rs = tile_rsrc(a.mask ? a.mask : a.y, a.mask ? a.ldmask : a.ldy, a.mask ? m_es : Y_ES);
   const uint32_t oy0 = col_ok ? (uint32_t)((wrow0 * (int)a.ldy + col) * Y_ES) : OOB;
-  const uint32_t or0 = col_ok ? (uint32_t)((wrow0 * (int)a.ldres + col) * 4) : OOB;
+  const uint32_t or0 = col_ok ? (uint32_t)((wrow0 * (int)a.ldres + col) * r_es) : OOB;
   const uint32_t om0 = col_ok ? (uint32_t)((wrow0 * (int)a.ldmask + col) * m_es) : OOB;
-  const uint32_t ystep = (uint32_t)(RPP * (int)a.ldy * Y_ES), rstep = (uint32_t)(RPP * (int)a.ldres * 4),
+  const uint32_t ystep = (uint32_t)(RPP * (int)a.ldy * Y_ES), rstep = (uint32_t)(RPP * (int)a.ldres * r_es),
                  mstep = (uint32_t)(RPP * (int)a.ldmask * m_es);
 
   auto tail = [&](auto act_tag) {
@@ -422,8 +423,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
         const int p0 = hh * NP + pb * UB;            // index of the batch's first row among the lane's rows
         i32x4 rr[UB], mk[UB];
         if (a.res) {
+          if (a.res16) {                             // bf16 residual: 8 bytes per lane, widened to fp32 in place
 #pragma unroll
-          for (int u = 0; u < UB; ++u) rr[u] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, or0 + (p0 + u) * rstep, 0, 0);
+            for (int u = 0; u < UB; ++u) {
+              const i32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r_rs, or0 + (p0 + u) * rstep, 0, 0);
+              rr[u] = i32x4{(int)((uint32_t)t.x << 16), (int)((uint32_t)t.x & 0xffff0000u), (int)((uint32_t)t.y << 16),
+                            (int)((uint32_t)t.y & 0xffff0000u)};
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < UB; ++u) rr[u] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, or0 + (p0 + u) * rstep, 0, 0);
+          }
         }
         if (a.mask) {
           if (a.mask16) {
@@ -574,17 +584,20 @@ int styler_conv_gemm_impl2(const float* x, int64_t ldx, const void* w, const flo
                            int kw, int pad, int act, int prec, const int64_t* len, const int32_t* rowinfo,
                            const float* mask, int64_t ldmask, int io_flags, void* stream) {
   const int x16 = io_flags & STYLER_IO_X_BF16, y16 = io_flags & STYLER_IO_Y_BF16, m16 = io_flags & STYLER_IO_MASK_BF16;
-  if ((x16 || y16) && (prec != STYLER_PREC_BF16 || (y16 && (res || (ldy & 3))) || (x16 && (ldx & 7)))) return STYLER_EINVAL;
+  const int r16 = io_flags & STYLER_IO_RES_BF16;
+  if ((x16 || y16 || r16) && (prec != STYLER_PREC_BF16 || (y16 && (ldy & 3)) || (x16 && (ldx & 7)) || (r16 && (!res || (ldres & 3)))))
+    return STYLER_EINVAL;
   if (!x || !w || !y || B <= 0 || L <= 0 || cin <= 0 || n <= 0 || kw <= 0 || kw > 9 || pad < 0 || pad >= kw)
     return STYLER_EINVAL;
   if ((cin & 3) || (ldx & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return STYLER_EALIGN;
-  if ((n & 3) || (ldy & 3) || ((uintptr_t)y & 15) || (res && ((ldres & 3) || ((uintptr_t)res & 15)))) return STYLER_EALIGN;
+  if ((n & 3) || (ldy & 3) || ((uintptr_t)y & 15) || (res && ((ldres & 3) || ((uintptr_t)res & (r16 ? 7 : 15))))) return STYLER_EALIGN;
   if (prec == STYLER_PREC_BF16 && (cin & 7)) return STYLER_EALIGN;
   if (rowinfo && B != 1) return STYLER_EINVAL;
   if ((int64_t)B * L >= ((int64_t)1 << 31) || ldy >= (1 << 22) || ldres >= (1 << 22) || ldmask >= (1 << 22)) return STYLER_EINVAL;
   if (mask && ((ldmask & 3) || ((uintptr_t)mask & 15))) return STYLER_EALIGN;
   GemmArgs a{x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, act, pad, len, 0, 0,
              reinterpret_cast<const int2*>(rowinfo), mask, ldmask, m16 ? 1 : 0, g_gemm_trace};
+  a.res16 = r16 ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   if (prec == STYLER_PREC_BF16) {                  // large launches on bf16 activations: the 256 x 256 LDS-DMA engine (gemm256.hip)
     const int r = styler_gemm256_try(a, x16, y16, st);

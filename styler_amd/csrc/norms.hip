@@ -11,7 +11,8 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
     const float* __restrict__ dot_w, const float* __restrict__ dot_b, float* __restrict__ dot_out, int64_t rows,
     int L, const int64_t* __restrict__ len, float drop_p, uint64_t drop_seed_host, const uint64_t* __restrict__ epoch,
     float in_drop_p, uint64_t in_drop_seed_host, float* __restrict__ sum_out, int64_t ldsum, uint16_t* __restrict__ y16,
-    int64_t ldy16) {
+    int64_t ldy16, int io) {
+  const bool res16 = io & STYLER_LN_RES_BF16, yb16 = io & STYLER_LN_Y_BF16, sum16 = io & STYLER_LN_SUM_BF16;
   const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -22,7 +23,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
     masked = (row - b * L) >= len[b];
   }
   if (masked) {
-    if (y) *reinterpret_cast<float4*>(y + row * ldy + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y) stg4(y, row * ldy + lane * 4, make_float4(0.f, 0.f, 0.f, 0.f), yb16);
     if (y16) *reinterpret_cast<uint2*>(y16 + row * ldy16 + lane * 4) = make_uint2(0u, 0u);
     if (dot_out && lane == 0) dot_out[row] = 0.f;
     return;                                              // (sum_out is only read back on unmasked rows)
@@ -39,10 +40,14 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
     v.w = dropout_hash32(sd, e + 3) >= thr ? v.w * sc : 0.f;
   }
   if (res) {
-    const float4 r = *reinterpret_cast<const float4*>(res + row * ldres + lane * 4);
+    const float4 r = ldg4(res, row * ldres + lane * 4, res16);
     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
   }
-  if (sum_out) *reinterpret_cast<float4*>(sum_out + row * ldsum + lane * 4) = v;     // the pre-norm sum, for the backward
+  if (sum_out) {                                         // the pre-norm sum, for the backward
+    stg4(sum_out, row * ldsum + lane * 4, v, sum16);
+    // a bf16 sum is what the backward will see: normalise THAT value, so that forward and backward agree on the statistics
+    if (sum16) v = raw4_f32(make_uint2(cvt_pk_bf16_rne(v.x, v.y), cvt_pk_bf16_rne(v.z, v.w)));
+  }
   const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
   const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
   const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.f / 256.f);
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
     o.z = dropout_hash32(drop_seed, e + 2) >= thr ? o.z * sc : 0.f;
     o.w = dropout_hash32(drop_seed, e + 3) >= thr ? o.w * sc : 0.f;
   }
-  if (y) *reinterpret_cast<float4*>(y + row * ldy + lane * 4) = o;
+  if (y) stg4(y, row * ldy + lane * 4, o, yb16);
   // y16: a second copy of the output as bf16 (round to nearest even) for the GEMMs that consume it -- they round their
   // activation operand to bf16 anyway, so results do not change; the 256 x 256 engine (gemm256.hip) DMAs it straight into LDS
   if (y16) *reinterpret_cast<uint2*>(y16 + row * ldy16 + lane * 4) = make_uint2(cvt_pk_bf16_rne(o.x, o.y), cvt_pk_bf16_rne(o.z, o.w));
@@ -76,7 +81,7 @@ extern "C" int styler_add_layernorm(const float* x, int64_t ldx, const float* re
                                     const float* dot_w, const float* dot_b, float* dot_out, int B, int L, int C,
                                     const int64_t* len, float drop_p, uint64_t drop_seed, float in_drop_p,
                                     uint64_t in_drop_seed, float* sum_out, int64_t ldsum, uint16_t* y16, int64_t ldy16,
-                                    void* stream) {
+                                    int io_flags, void* stream) {
   if (!x || !gamma || !beta || (!y && !dot_out) || B <= 0 || L <= 0) return STYLER_EINVAL;
   if (y16 && ((ldy16 & 3) || ((uintptr_t)y16 & 7))) return STYLER_EALIGN;
   if (C != 256) return STYLER_EINVAL;
@@ -86,7 +91,7 @@ extern "C" int styler_add_layernorm(const float* x, int64_t ldx, const float* re
   const int64_t rows = (int64_t)B * L;
   hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
                      ldx, res, ldres, gamma, beta, y, ldy, dot_w, dot_b, dot_out, rows, L, len, drop_p, drop_seed,
-                     g_styler_drop_epoch, in_drop_p, in_drop_seed, sum_out, ldsum, y16, ldy16);
+                     g_styler_drop_epoch, in_drop_p, in_drop_seed, sum_out, ldsum, y16, ldy16, io_flags);
   return launch_status();
 }
 

@@ -19,6 +19,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     const int64_t* __restrict__ len, float drop_p, uint64_t drop_seed_host, const uint64_t* __restrict__ epoch,
     float in_drop_p, uint64_t in_drop_seed_host, float* __restrict__ dx_drop, int64_t lddxd, int replicas, int flags) {
   const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
+  const bool x16 = flags & STYLER_LNB_X_BF16, dy16 = flags & STYLER_LNB_DY_BF16, dx16 = flags & STYLER_LNB_DX_BF16,
+             dxd16 = flags & STYLER_LNB_DXD_BF16;
   const int lane = threadIdx.x & 63;
   const int64_t w0 = (int64_t)blockIdx.x * LNB_WAVES + (threadIdx.x >> 6);
   const int64_t wstride = (int64_t)gridDim.x * LNB_WAVES;
@@ -53,19 +55,41 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
         lv[k] = reinterpret_cast<const int*>(len)[2 * b];             // low dword of the int64 length
       }
     }
+    // raw loads of ALL rows first (fp32: 16 bytes per lane, bf16: 8), conversions afterwards: a conversion next to its load
+    // puts a wait behind every load; the storage flags are uniform, so each format is its own straight-line load loop
+    uint2 rv16[R], rd16[R];
+    if (x16) {
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-      v[k] = *reinterpret_cast<const float4*>(x + rc[k] * ldx + lane * 4);
-      go[k] = 0.f;
-      if (dot_w) go[k] = dout[rc[k]];
-      else d[k] = *reinterpret_cast<const float4*>(dy + rc[k] * lddy + lane * 4);
+      for (int k = 0; k < R; ++k) rv16[k] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(x) + rc[k] * ldx + lane * 4);
+    } else {
+#pragma unroll
+      for (int k = 0; k < R; ++k) v[k] = *reinterpret_cast<const float4*>(x + rc[k] * ldx + lane * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) { go[k] = 0.f; if (dot_w) go[k] = dout[rc[k]]; }
+    if (!dot_w) {
+      if (dy16) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) rd16[k] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(dy) + rc[k] * lddy + lane * 4);
+      } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) d[k] = *reinterpret_cast<const float4*>(dy + rc[k] * lddy + lane * 4);
+      }
+    }
+    if (x16) {
+#pragma unroll
+      for (int k = 0; k < R; ++k) { pin_loaded(rv16[k]); v[k] = raw4_f32(rv16[k]); }
+    }
+    if (!dot_w && dy16) {
+#pragma unroll
+      for (int k = 0; k < R; ++k) { pin_loaded(rd16[k]); d[k] = raw4_f32(rd16[k]); }
     }
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       if (live[k] && (int)tt[k] >= lv[k]) {               // masked row: zero gradient, nothing else
         live[k] = false;
-        if (dx) *reinterpret_cast<float4*>(dx + row[k] * lddx + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (dx_drop) *reinterpret_cast<float4*>(dx_drop + row[k] * lddxd + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dx) stg4(dx, row[k] * lddx + lane * 4, make_float4(0.f, 0.f, 0.f, 0.f), dx16);
+        if (dx_drop) stg4(dx_drop, row[k] * lddxd + lane * 4, make_float4(0.f, 0.f, 0.f, 0.f), dxd16);
       }
       if (!live[k]) { v[k] = make_float4(0.f, 0.f, 0.f, 0.f); go[k] = 0.f; }
       kx[k][0] = kx[k][1] = kx[k][2] = kx[k][3] = 1.f;
@@ -130,15 +154,15 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
         gx.x = v[k].x > 0.f ? gx.x : 0.f; gx.y = v[k].y > 0.f ? gx.y : 0.f;
         gx.z = v[k].z > 0.f ? gx.z : 0.f; gx.w = v[k].w > 0.f ? gx.w : 0.f;
       }
-      if (dx) *reinterpret_cast<float4*>(dx + row[k] * lddx + lane * 4) = gx;
+      if (dx) stg4(dx, row[k] * lddx + lane * 4, gx, dx16);
       if (dx_drop) {                                     // gradient of the dropout(x) that fed the sum (same stream)
         const uint64_t sd = mix_drop_epoch(in_drop_seed_host, epoch);
         const uint32_t thr = (uint32_t)((double)in_drop_p * 4294967296.0);
         const float sc = 1.f / (1.f - in_drop_p);
         const uint64_t e = (uint64_t)row[k] * 256 + lane * 4;
-        *reinterpret_cast<float4*>(dx_drop + row[k] * lddxd + lane * 4) =
-            make_float4(dropout_hash32(sd, e) >= thr ? gx.x * sc : 0.f, dropout_hash32(sd, e + 1) >= thr ? gx.y * sc : 0.f,
-                        dropout_hash32(sd, e + 2) >= thr ? gx.z * sc : 0.f, dropout_hash32(sd, e + 3) >= thr ? gx.w * sc : 0.f);
+        stg4(dx_drop, row[k] * lddxd + lane * 4,
+             make_float4(dropout_hash32(sd, e) >= thr ? gx.x * sc : 0.f, dropout_hash32(sd, e + 1) >= thr ? gx.y * sc : 0.f,
+                        dropout_hash32(sd, e + 2) >= thr ? gx.z * sc : 0.f, dropout_hash32(sd, e + 3) >= thr ? gx.w * sc : 0.f), dxd16);
       }
     }
   }

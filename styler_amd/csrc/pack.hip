@@ -57,7 +57,8 @@ extern "C" int styler_pack_plan(const int64_t* len, int B, int T, int32_t* cu, i
 // dir 1: padded[b, t] = t < len[b] ? packed[cu[b] + t] : 0
 __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ src, int64_t lds, float* __restrict__ dst,
                                                         int64_t ldd, const float* __restrict__ add,
-                                                        const int* __restrict__ cu, int B, int T, int C, int dir) {
+                                                        const int* __restrict__ cu, int B, int T, int C, int dir, int io) {
+  const bool pad16 = io & STYLER_IO_X_BF16, pk16 = io & STYLER_IO_Y_BF16;      // storage of the padded / the packed tensor
   const int nq = C / 4;
   const int64_t total = (int64_t)B * T * nq;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -66,32 +67,32 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
     const int r0 = cu[b], l = cu[b + 1] - r0;
     if (dir == 0) {
       if (t >= l) continue;
-      float4 v = *reinterpret_cast<const float4*>(src + row * lds + q * 4);
+      float4 v = ldg4(src, row * lds + q * 4, pad16);
       if (add) {
         const float4 p = *reinterpret_cast<const float4*>(add + (int64_t)t * C + q * 4);
         v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
       }
-      *reinterpret_cast<float4*>(dst + (int64_t)(r0 + t) * ldd + q * 4) = v;
+      stg4(dst, (int64_t)(r0 + t) * ldd + q * 4, v, pk16);
     } else {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t < l) v = *reinterpret_cast<const float4*>(src + (int64_t)(r0 + t) * lds + q * 4);
-      *reinterpret_cast<float4*>(dst + row * ldd + q * 4) = v;
+      if (t < l) v = ldg4(src, (int64_t)(r0 + t) * lds + q * 4, pk16);
+      stg4(dst, row * ldd + q * 4, v, pad16);
     }
   }
 }
 
 extern "C" int styler_pack_rows(const float* padded, int64_t ldp, float* packed, int64_t ldk, const float* add,
-                                const int32_t* cu, int B, int T, int C, void* stream) {
+                                const int32_t* cu, int B, int T, int C, int io_flags, void* stream) {
   if (!padded || !packed || !cu || B <= 0 || T <= 0 || C <= 0 || (C & 3) || (ldp & 3) || (ldk & 3)) return STYLER_EINVAL;
   hipLaunchKernelGGL(pack_rows_kernel, dim3(pack_grid((int64_t)B * T * (C / 4))), dim3(256), 0, (hipStream_t)stream, padded,
-                     ldp, packed, ldk, add, cu, B, T, C, 0);
+                     ldp, packed, ldk, add, cu, B, T, C, 0, io_flags);
   return launch_status();
 }
 
 extern "C" int styler_unpack_rows(const float* packed, int64_t ldk, float* padded, int64_t ldp, const int32_t* cu, int B,
-                                  int T, int C, void* stream) {
+                                  int T, int C, int io_flags, void* stream) {
   if (!padded || !packed || !cu || B <= 0 || T <= 0 || C <= 0 || (C & 3) || (ldp & 3) || (ldk & 3)) return STYLER_EINVAL;
   hipLaunchKernelGGL(pack_rows_kernel, dim3(pack_grid((int64_t)B * T * (C / 4))), dim3(256), 0, (hipStream_t)stream, packed,
-                     ldk, padded, ldp, nullptr, cu, B, T, C, 1);
+                     ldk, padded, ldp, nullptr, cu, B, T, C, 1, io_flags);
   return launch_status();
 }

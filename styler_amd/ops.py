@@ -288,31 +288,39 @@ class PackPlan:
         self.nrows = self.counts[0:1]
 
 
-def pack_rows(x, plan, add=None):
-    """[B, T, C] padded -> [1, B*T, C] packed (+ add[t] per row, the positional table)."""
+IO_X16, IO_Y16, IO_MASK16, IO_RES16 = 1, 2, 4, 8
+
+
+def _pk_io(padded, packed):
+    return (IO_X16 if padded.dtype == torch.bfloat16 else 0) | (IO_Y16 if packed.dtype == torch.bfloat16 else 0)
+
+
+def pack_rows(x, plan, add=None, out_bf16=False):
+    """[B, T, C] padded -> [1, B*T, C] packed (+ add[t] per row, the positional table).  `out_bf16`: the packed tensor is
+    stored as bf16 (the decoder's residual stream in throughput mode); x may be fp32 or bf16."""
     B, T, C = x.shape
     assert (B, T) == (plan.B, plan.T) and (add is None or (add.shape[0] >= T and add.shape[1] == C and add.is_contiguous()))
-    out = torch.empty(1, B * T, C, device=x.device, dtype=torch.float32)
-    _chk(lib.styler_pack_rows(x.data_ptr(), _ld(x), out.data_ptr(), C, _ptr(add), plan.cu.data_ptr(), B, T, C, _stream()),
-         "styler_pack_rows")
+    out = torch.empty(1, B * T, C, device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    _chk(lib.styler_pack_rows(x.data_ptr(), _ld(x), out.data_ptr(), C, _ptr(add), plan.cu.data_ptr(), B, T, C, _pk_io(x, out),
+                              _stream()), "styler_pack_rows")
     return out
 
 
-def pack_rows_pair(xa, xb, plan, add=None):
+def pack_rows_pair(xa, xb, plan, add=None, out_bf16=False):
     """Two padded [B, T, C] tensors -> one packed [1, 2B*T, C] tensor whose items 0..B-1 come from `xa` and B..2B-1 from
     `xb` (`plan` is the PackPlan of the 2B items): the clean and the noisy decode of styler.py:52,55 as ONE batch."""
     B, T, C = xa.shape
     assert xb.shape == xa.shape and (2 * B, T) == (plan.B, plan.T)
     assert add is None or (add.shape[0] >= T and add.shape[1] == C and add.is_contiguous())
-    out = torch.empty(1, 2 * B * T, C, device=xa.device, dtype=torch.float32)
+    out = torch.empty(1, 2 * B * T, C, device=xa.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     for half, x in enumerate((xa, xb)):
-        _chk(lib.styler_pack_rows(_f32(x).data_ptr(), _ld(x), out.data_ptr(), C, _ptr(add),
-                                  plan.cu.data_ptr() + 4 * B * half, B, T, C, _stream()), "styler_pack_rows")
+        _chk(lib.styler_pack_rows(x.data_ptr(), _ld(x), out.data_ptr(), C, _ptr(add),
+                                  plan.cu.data_ptr() + 4 * B * half, B, T, C, _pk_io(x, out), _stream()), "styler_pack_rows")
     return out
 
 
 def unpack_rows_pair(xp, plan):
-    """Inverse of pack_rows_pair (also its backward): packed [1, 2B*T, C] -> two padded [B, T, C] tensors."""
+    """Inverse of pack_rows_pair (also its backward): packed [1, 2B*T, C] (fp32 or bf16) -> two padded fp32 [B, T, C] tensors."""
     C = xp.shape[-1]
     xp = _rows_view(xp)
     B = plan.B // 2
@@ -320,18 +328,18 @@ def unpack_rows_pair(xp, plan):
     for half in range(2):
         out = torch.empty(B, plan.T, C, device=xp.device, dtype=torch.float32)
         _chk(lib.styler_unpack_rows(xp.data_ptr(), _ld(xp), out.data_ptr(), C, plan.cu.data_ptr() + 4 * B * half, B,
-                                    plan.T, C, _stream()), "styler_unpack_rows")
+                                    plan.T, C, _pk_io(out, xp), _stream()), "styler_unpack_rows")
         outs.append(out)
     return outs
 
 
 def unpack_rows(xp, plan):
-    """[1, B*T, C] packed -> [B, T, C] padded with zeros at t >= len[b]."""
+    """[1, B*T, C] packed (fp32 or bf16) -> fp32 [B, T, C] padded with zeros at t >= len[b]."""
     C = xp.shape[-1]
     xp = _rows_view(xp)
     out = torch.empty(plan.B, plan.T, C, device=xp.device, dtype=torch.float32)
     _chk(lib.styler_unpack_rows(xp.data_ptr(), _ld(xp), out.data_ptr(), C, plan.cu.data_ptr(), plan.B, plan.T, C,
-                                _stream()), "styler_unpack_rows")
+                                _pk_io(out, xp), _stream()), "styler_unpack_rows")
     return out
 
 
@@ -348,10 +356,11 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
     if out is None:
         out = torch.empty(B, L, n, device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     io = (1 if x.dtype == torch.bfloat16 else 0) | (2 if out.dtype == torch.bfloat16 else 0) | \
-         (4 if mask is not None and mask.dtype == torch.bfloat16 else 0)
+         (4 if mask is not None and mask.dtype == torch.bfloat16 else 0) | \
+         (8 if res is not None and res.dtype == torch.bfloat16 else 0)
     if io:
-        if prec != PREC_BF16 or (io & 2 and res is not None):
-            raise StylerHipError("bf16 activations only in throughput mode (and no residual with a bf16 output)")
+        if prec != PREC_BF16:
+            raise StylerHipError("bf16 activations only in throughput mode")
     else:
         _f32(x)
     prof = gemm_profiler
@@ -468,7 +477,7 @@ def attention_fwd(qkv, lens, lse=None, prec=None, plan=None):
 
 
 def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, dot_b=None, drop_p=0.0, drop_seed=0,
-                  in_drop_p=0.0, in_drop_seed=0, sum_out=None, out16=None):
+                  in_drop_p=0.0, in_drop_seed=0, sum_out=None, out16=None, out_bf16=False):
     """LayerNorm(dropout(x) + res) with pad-mask; with dot_w returns the [B, L] scalar head instead.  `sum_out`
     (optional) receives the pre-norm sum (what layernorm_bwd needs); `out16` (optional, a bf16 [B, L, C] tensor) a second
     copy of the output rounded to bf16, for the GEMMs that take it as their activation operand."""
@@ -477,13 +486,19 @@ def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, 
     if dot_w is not None:
         dot_out = torch.empty(B, L, device=x.device, dtype=torch.float32)
     elif out is None:
-        out = torch.empty(B, L, C, device=x.device, dtype=torch.float32)
+        # the output follows the residual stream's storage format (a bf16 residual = the decoder's bf16 stream)
+        out_bf16 = out_bf16 or (res is not None and res.dtype == torch.bfloat16)
+        out = torch.empty(B, L, C, device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    _f32(x)
+    ln_io = (1 if res is not None and res.dtype == torch.bfloat16 else 0) | \
+            (2 if out is not None and out.dtype == torch.bfloat16 else 0) | \
+            (4 if sum_out is not None and sum_out.dtype == torch.bfloat16 else 0)
     _chk(lib.styler_add_layernorm(x.data_ptr(), _ld(x), _ptr(res), _ld(res) if res is not None else 0,
                                   gamma.data_ptr(), beta.data_ptr(), _ptr(out),
                                   _ld(out) if out is not None else 0, _ptr(dot_w), _ptr(dot_b),
                                   _ptr(dot_out), B, L, C, _ptr(lens), float(drop_p), int(drop_seed), float(in_drop_p),
                                   int(in_drop_seed), _ptr(sum_out), _ld(sum_out) if sum_out is not None else 0,
-                                  _ptr(out16), _ld(out16) if out16 is not None else 0, _stream()),
+                                  _ptr(out16), _ld(out16) if out16 is not None else 0, ln_io, _stream()),
          "styler_add_layernorm")
     return dot_out if dot_w is not None else out
 
@@ -756,7 +771,7 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
     arena = wgrad_arena
     io = (2 if dz.dtype == torch.bfloat16 else 0) | (1 if x.dtype == torch.bfloat16 else 0)    # bf16-resident operands
     if (arena is not None and arena.buf is not None and prec == PREC_BF16 and prof is None and (plan is None or db2 is None)
-            and (arena.group_all or (kw == 1 and io in (0, 2)))):
+            and (arena.group_all or (kw == 1 and io in (0, 2, 3)))):
         # grouped path (default: the small Linear gradients, variant 0; STYLER_WGRAD_GROUP_ALL=1: every bf16 gradient):
         # plan the member first (variant, tiles, split count), then give it its slice of the arena
         from ._lib import WgradGroupDesc
@@ -768,8 +783,8 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
         if nb < 0:
             _chk(nb, "styler_wgrad_group_desc")
         small = ((n + 63) // 64) * ((cin + 63) // 64) < 48
-        if nb > 0 and (arena.group_all or d.variant == 0 or (d.variant in (1, 7) and small)):
-            want = arena.want_splits(d.variant) if arena.group_all else (LIN128_SPLITS if d.variant in (1, 7) else 0)
+        if nb > 0 and (arena.group_all or d.variant == 0 or (d.variant in (1, 7, 8) and small)):
+            want = arena.want_splits(d.variant) if arena.group_all else (LIN128_SPLITS if d.variant in (1, 7, 8) else 0)
             if want:
                 nb = lib.styler_wgrad_group_desc(ctypes.byref(d), *args, None, *packed, io, want)
             ws = arena.take(d.splits * n * kw * cin, dz.device)
@@ -852,10 +867,14 @@ def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, do
     """Returns dx, or (dx, dx_drop) when in_drop_p > 0 (dx_drop = dx through the forward's input-dropout mask).
     relu_input: x is a ReLU output and dx comes back as the gradient w.r.t. the ReLU's input."""
     B, L, C = x.shape
-    dx = torch.empty(B, L, C, device=x.device, dtype=torch.float32) if need_dx else None
-    dxd = torch.empty(B, L, C, device=x.device, dtype=torch.float32) if in_drop_p > 0 else None
+    # bf16 residual stream (x = the saved pre-norm sum is bf16): the gradients that continue along it are bf16 as well
+    gdt = torch.bfloat16 if x.dtype == torch.bfloat16 else torch.float32
+    dx = torch.empty(B, L, C, device=x.device, dtype=gdt) if need_dx else None
+    dxd = torch.empty(B, L, C, device=x.device, dtype=gdt) if in_drop_p > 0 else None
     if dy is not None:
         dy = _rows_view(dy)
+    lnb_io = (2 if x.dtype == torch.bfloat16 else 0) | (4 if dy is not None and dy.dtype == torch.bfloat16 else 0) | \
+             (8 if dx is not None and dx.dtype == torch.bfloat16 else 0) | (16 if dxd is not None and dxd.dtype == torch.bfloat16 else 0)
     if dout is not None:
         dout = dout.contiguous()
     # inside a training step the three parameter-gradient vectors go to zeroed 16-replica scratch (zero slab) and are
@@ -886,7 +905,7 @@ def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, do
     _chk(lib.styler_layernorm_bwd(x.data_ptr(), _ld(x), _ptr(dy), _ld(dy) if dy is not None else 0, gamma.data_ptr(),
                                   _ptr(beta), _ptr(dx), C, pg.data_ptr(), pb.data_ptr(), _ptr(dot_w),
                                   _ptr(dout), _ptr(pw), _ptr(ddot_b), B, L, C, _ptr(lens), float(drop_p),
-                                  int(drop_seed), float(in_drop_p), int(in_drop_seed), _ptr(dxd), C, rep, 1 if relu_input else 0,
+                                  int(drop_seed), float(in_drop_p), int(in_drop_seed), _ptr(dxd), C, rep, (1 if relu_input else 0) | lnb_io,
                                   _stream()),
          "styler_layernorm_bwd")
     if fold is not None:

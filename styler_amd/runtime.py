@@ -53,6 +53,12 @@ class _Runtime:
     # throughput mode: the dX GEMM of the BiLSTM input projections (gate gradients x W_ih) on bf16 operands like every
     # other dX GEMM of the step (round 2 left these eight launches on the fp32 MFMA path: 0.2 ms per step)
     lstm_dx_bf16 = os.environ.get("STYLER_LSTM_DX_BF16", "1") != "0"
+    # throughput mode: the residual stream of the DECODER's FFT blocks (packed rows) is stored as bf16 -- LayerNorm outputs, the
+    # saved pre-norm sums, the packed input, and the gradients that flow back along them.  Unlike the bf16 copies above this
+    # is not bit-neutral: it adds one bf16 rounding per sublayer (measured at the benched shape: mel 2.3e-2 -> 2.8e-2 abs
+    # against the 6e-2 bound, worst parameter gradient unchanged at 6.0e-2 against 1e-1; tests/test_11_oracle_c2c3.py).  It
+    # halves the bytes of the LayerNorm forward / backward kernels and of every GEMM operand read from the stream.
+    bf16_stream = os.environ.get("STYLER_BF16_STREAM", "1") != "0"
     # EXPERIMENT (numerics only, not a fast path): round the residual stream of the FFT blocks -- LayerNorm outputs, the saved
     # pre-norm sums, the packed decoder input, the LengthRegulator output, and the gradients that flow back along them -- to
     # bf16 with torch casts, to measure what a model-wide bf16 activation format would do to the parity bounds BEFORE

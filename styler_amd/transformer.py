@@ -87,7 +87,7 @@ class MultiHeadAttention(_HipModule):
         grad = (self.training and torch.is_grad_enabled())
         drop = self.training and self.dropout.p > 0
         asked = want16                                        # the caller unpacks a pair whenever it asked for one
-        want16 = want16 and rt.prec == ops.PREC_BF16 and rt.ln_bf16_copy
+        want16 = want16 and rt.prec == ops.PREC_BF16 and rt.ln_bf16_copy and x.dtype != torch.bfloat16   # (a bf16 stream needs no copy)
         y16 = None
         if grad:                                              # the whole sublayer is one tape node
             y = AG.AttnSublayerFn.apply(x, self.w_qs.weight, self, lens, plan, self.dropout.p, want16)
@@ -101,10 +101,11 @@ class MultiHeadAttention(_HipModule):
                          drop_p=self.dropout.p if self.training else 0.0)
             return (y, None) if asked else y
         o = self._gemm("fc", ctx, self.fc, res=x, plan=plan)  # eval: residual rides in the GEMM epilogue
-        if want16:
+        s16 = x.dtype == torch.bfloat16                       # bf16 residual stream (the packed decoder): y is bf16
+        if want16 and not s16:
             y16 = torch.empty_like(o, dtype=torch.bfloat16)
-        y = ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out, out16=y16)
-        if rt.sim_bf16_stream and rt.prec == ops.PREC_BF16:
+        y = ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out, out16=y16, out_bf16=s16)
+        if rt.sim_bf16_stream and rt.prec == ops.PREC_BF16 and not s16:
             y.copy_(y.to(torch.bfloat16))
         return (y, y16) if asked else y
 
@@ -132,8 +133,9 @@ class PositionwiseFeedForward(_HipModule):
             return self._ln(self._gemm("w_2", h, self.w_2, kw=k[1], plan=plan), x, self.layer_norm, lens, out,
                             drop_p=self.dropout.p if self.training else 0.0)
         o = self._gemm("w_2", h, self.w_2, kw=k[1], res=x, plan=plan)
-        y = ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out)
-        if rt.sim_bf16_stream and rt.prec == ops.PREC_BF16:
+        s16 = x.dtype == torch.bfloat16
+        y = ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out, out_bf16=s16)
+        if rt.sim_bf16_stream and rt.prec == ops.PREC_BF16 and not s16:
             y.copy_(y.to(torch.bfloat16))
         return y
 
@@ -212,7 +214,8 @@ class Decoder(nn.Module, _PositionMixin):
             # frames only, stored back to back (ops.PackPlan / csrc/pack.hip), and the result is padded again with zeros.
             B, T, _ = enc_seq.shape
             plan = ops.PackPlan(lens, B, T)
-            x = AG.PackRowsFn.apply(enc_seq, pe, plan) if tape else ops.pack_rows(enc_seq, plan, add=pe)
+            s16 = rt.bf16_stream and rt.prec == ops.PREC_BF16      # throughput mode: the packed residual stream is bf16
+            x = AG.PackRowsFn.apply(enc_seq, pe, plan, s16) if tape else ops.pack_rows(enc_seq, plan, add=pe, out_bf16=s16)
             for layer in self.layer_stack:
                 x = layer(x, plan.nrows, plan=plan)
             return AG.UnpackRowsFn.apply(x, plan) if tape else ops.unpack_rows(x, plan)
@@ -229,7 +232,9 @@ class Decoder(nn.Module, _PositionMixin):
         pe = self._pe(T, seq_a.device)
         tape = (self.training and torch.is_grad_enabled()) and (seq_a.requires_grad or seq_b.requires_grad)
         plan = ops.PackPlan(torch.cat([lens, lens]), 2 * B, T)
-        x = AG.PackPairFn.apply(seq_a, seq_b, pe, plan) if tape else ops.pack_rows_pair(seq_a, seq_b, plan, add=pe)
+        s16 = rt.bf16_stream and rt.prec == ops.PREC_BF16
+        x = (AG.PackPairFn.apply(seq_a, seq_b, pe, plan, s16) if tape
+             else ops.pack_rows_pair(seq_a, seq_b, plan, add=pe, out_bf16=s16))
         for layer in self.layer_stack:
             x = layer(x, plan.nrows, plan=plan)
         return AG.UnpackRowsFn.apply(x, plan) if tape else ops.unpack_rows(x, plan)
