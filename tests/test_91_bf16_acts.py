@@ -138,3 +138,62 @@ def test_wgrad_linear_bf16_dz_equals_fp32_dz(dev):
         dw, db = torch.zeros(256, 256, device=dev), torch.zeros(256, device=dev)
         ops.wgrad(dz, x, dw, 256, 256, db=db, prec=ops.PREC_BF16)
         assert torch.allclose(dw, ref_dw, rtol=1e-5, atol=1e-4) and torch.allclose(db, ref_db, rtol=1e-5, atol=1e-4)
+
+
+def test_bf16_stream_kernels_equal_fp32_kernels_on_the_same_values(dev):
+    """The decoder's bf16 residual stream (round 3): every kernel that reads or writes the stream in bf16 computes exactly what
+    its fp32 form computes on the same (bf16-representable) values -- outputs are the round-to-nearest-even of the fp32
+    outputs, parameter gradients identical sums."""
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(31)
+    bf = torch.bfloat16
+    B, L = 3, 77
+    lens = torch.tensor([77, 40, 5]).to(dev)
+    o = torch.randn(B, L, 256, generator=g).to(dev)                                  # GEMM output (fp32 either way)
+    x16 = torch.randn(B, L, 256, generator=g).to(dev).to(bf)                          # the stream
+    ga, be = (1 + 0.1 * torch.randn(256, generator=g)).to(dev), (0.1 * torch.randn(256, generator=g)).to(dev)
+    # forward: y16, s16 from the bf16 kernel; the fp32 kernel on the same residual gives the unrounded sum
+    s16 = torch.empty(B, L, 256, device=dev, dtype=bf)
+    y16 = ops.add_layernorm(o, ga, be, res=x16, lens=lens, sum_out=s16, in_drop_p=0.2, in_drop_seed=9)
+    s32 = torch.empty(B, L, 256, device=dev)
+    ops.add_layernorm(o, ga, be, res=x16.float(), lens=lens, sum_out=s32, in_drop_p=0.2, in_drop_seed=9)
+    valid = torch.arange(L, device=dev)[None, :] < lens[:, None]                      # (the sum is defined on unmasked rows only)
+    assert y16.dtype == bf and torch.equal(s16[valid], s32[valid].to(bf))
+    # ... and y is the LayerNorm of the ROUNDED sum (what the backward recomputes its statistics from)
+    s_clean = torch.where(valid[..., None], s16.float(), torch.zeros((), device=dev))
+    y_ref = ops.add_layernorm(s_clean, ga, be, lens=lens)
+    assert torch.equal(y16, y_ref.to(bf))
+    s16 = s_clean.to(bf)                                                              # defined everywhere for the backward calls below
+    # backward: all four streams bf16 vs the fp32 kernel on the same values
+    dy16 = torch.randn(B, L, 256, generator=g).to(dev).to(bf)
+    dg1, db1, dg2, db2 = (torch.zeros(256, device=dev) for _ in range(4))
+    dx16, dxd16 = ops.layernorm_bwd(s16, dy16, ga, be, dg1, db1, lens=lens, in_drop_p=0.2, in_drop_seed=9)
+    dx32, dxd32 = ops.layernorm_bwd(s16.float(), dy16.float(), ga, be, dg2, db2, lens=lens, in_drop_p=0.2, in_drop_seed=9)
+    assert dx16.dtype == bf and dxd16.dtype == bf
+    assert torch.equal(dx16, dx32.to(bf)) and torch.equal(dxd16, dxd32.to(bf))
+    assert torch.equal(dg1, dg2) and torch.equal(db1, db2)
+    # pack / unpack of a bf16 stream
+    T = L
+    plan = ops.PackPlan(lens, B, T)
+    xp16 = ops.pack_rows(o, plan, out_bf16=True)
+    xp32 = ops.pack_rows(o, plan)
+    nv = int(lens.sum())
+    assert xp16.dtype == bf and torch.equal(xp16[:, :nv], xp32[:, :nv].to(bf))
+    assert torch.equal(ops.unpack_rows(xp16, plan), ops.unpack_rows(xp16.float(), plan))
+    # GEMM epilogue: bf16 residual + bf16 output
+    w = (torch.randn(256, 256, generator=g) / 16).to(dev).to(bf)
+    a16 = torch.randn(B, L, 256, generator=g).to(dev).to(bf)
+    y_a = ops.conv_gemm(a16, w, None, prec=ops.PREC_BF16, res=x16, out_bf16=True)
+    y_b = ops.conv_gemm(a16, w, None, prec=ops.PREC_BF16, res=x16.float())
+    assert y_a.dtype == bf and torch.equal(y_a, y_b.to(bf))
+    # weight gradients with both operands bf16 (k = 1 and the FFN's k = 9) vs fp32 operands holding the same values
+    for kw, n, cin in ((1, 256, 256), (9, 128, 256)):
+        dz = torch.randn(2, 300, n, generator=g).to(dev).to(bf)
+        xx = torch.randn(2, 300, cin, generator=g).to(dev).to(bf)
+        shape = (n, cin) if kw == 1 else (n, cin, kw)
+        dw_a, dw_b = torch.zeros(shape, device=dev), torch.zeros(shape, device=dev)
+        b_a, b_b = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        ops.wgrad(dz, xx, dw_a, n, cin, kw=kw, db=b_a, prec=ops.PREC_BF16)
+        ops.wgrad(dz, xx.float(), dw_b, n, cin, kw=kw, db=b_b, prec=ops.PREC_BF16)
+        assert torch.equal(dw_a, dw_b), kw
+        assert float((b_a - b_b).abs().max()) <= 1e-4 * float(b_b.abs().max())
