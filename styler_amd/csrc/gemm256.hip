@@ -20,8 +20,13 @@
 //     every wave column, UA0 / UA1 = the first / second 64 activation rows of both wave rows -- one unit per phase, one
 //     step ahead, into the other of two LDS stages (128 KB).  A unit is awaited with `s_waitcnt vmcnt(4)`: two younger
 //     units (2 DMA instructions per wave each) stay in flight across the barriers; vmcnt never drains inside the loop;
+//   * fragment reads are balanced 8 / 4 / 8 / 4 over the phases: the weight fragments of phase 0 are read one phase early
+//     (phase 3 of the step before) into the other of two register sets (251 VGPRs, no spill);
 //   * the two wave rows run one barrier apart (wr == 1 waits once more before the loop): on every SIMD the wave of one row
 //     issues its 8 MFMAs while the wave of the other row issues ds_reads and DMA -- the matrix pipe alternates between them.
+//
+// Split-K = 2 (launches with fewer data-carrying tiles than CUs and >= 64 K steps): blockIdx.y takes half of the K steps and
+// writes raw fp32 partial tiles; gemm256_combine_kernel adds the halves in a fixed order and applies the epilogue.
 //
 // LDS image of a unit: 128 rows x 128 B (64 bf16 of K), written linearly by the DMA (lane l of piece p lands at
 // p*1024 + l*16).  Fragment reads take 16 B per lane from 16 rows at once (ds_read_b128 lane groups pair rows r, r+12,
