@@ -22,11 +22,17 @@ One "step" is one pass of the hot path over one batch:
 `value` comes from EXACTLY --steps timed steps between two barriers; "repeat" reports further blocks of the same length
 (median / min / max ms per step) so that the spread of the short contract window is visible.
 
-Rank 0 prints ONE JSON line.  It also carries
-  roofline     : the dominant kernel of the step -- algorithmic FLOPs of its launches / their HIP-event durations
-                 (events bracket each launch on the launch stream during extra eager steps); `traffic` = HBM-side bytes per
-                 launch from this round's separate rocprofv3 --pmc passes of this command (profiles/r02_pmc_traffic.jsonl;
-                 PMC collection cannot run inside the timed process), null if that file has no record for the kernel;
+`python bench.py --gpus N` launches its own N ranks (re-exec under torch.distributed.run on a free local port) unless a
+launcher already did (WORLD_SIZE set); rank 0 prints ONE JSON line, last.  It also carries
+  roofline     : the dominant kernel family of the step (the two large-tile forward + dX GEMM engines) -- algorithmic FLOPs of
+                 its launches / their HIP-event durations (events bracket each launch on the launch stream during extra eager
+                 steps); `gemm256` = the 256 x 256 LDS-DMA engine alone; `traffic` = HBM-side bytes per launch from this
+                 round's separate rocprofv3 --pmc passes of this command (`traffic_source` names the committed file: PMC
+                 collection cannot run inside the timed process), null if that file has no record for the kernel;
+  roofline.hbm : achieved HBM-side rate of the memory-bound kernels (LengthRegulator, LayerNorm, GroupNorm, BatchNorm) at the
+                 step's shapes and storage formats, cache-cold (rotating operand sets inside one hipGraph), N = 1 only;
+  aux          : train_fp32 (the same step in the fp32 parity mode), forward_c2, forward_c4 (BASELINE config 4, teacher-forced
+                 and free-running, with the LengthRegulator's rate at that shape), N = 1 only for forward_c4;
   cpu_baseline : the oracle (plain PyTorch-CPU restatement) timed on this host's cores on a bounded sample.
 """
 import argparse
