@@ -496,9 +496,8 @@ __global__ __launch_bounds__(256) void gemm256_combine_kernel(const float* __res
 // data.  Measured against the 128 x 128 engine on the same bf16 operands, stand-alone (tools/gemm256_bench.py,
 // profiles/r03_gemm256_bench.txt): x1.15 at 424 tiles (FFN k = 9, M = 27 060), x1.02-1.06 at 166-848 tiles, x1.11-1.17 at
 // 1000-8000 tiles (config 4), x1.55 on a square 4096^3 GEMM (1.26 PFLOP/s); x0.92-0.96 at 106 tiles.  Inside the training
-// step the 166 / 332-tile launches of the AudioEncoder / PostNet run next to the text encoder's side stream, whose blocks
-// hold CUs that a 128 KB-LDS block then cannot enter: with a bound of 160 the step was 0.4 ms SLOWER than without the
-// engine (profiles/r03_g256_in_step.txt), hence 384.  STYLER_GEMM256=0 switches the engine off, STYLER_GEMM256_MIN_TILES
+// step (operands warm from the kernel before) the 166 / 332-tile launches of the AudioEncoder / PostNet lose on this engine:
+// 10.79 ms per step at a bound of 384, 10.82 at 300, 10.85 at 160 (profiles/r03_g256_in_step.txt), hence 384.  STYLER_GEMM256=0 switches the engine off, STYLER_GEMM256_MIN_TILES
 // overrides the bound (styler_gemm256_config at run time).
 static int g_enabled = [] { const char* e = getenv("STYLER_GEMM256"); return e ? atoi(e) : 1; }();
 static int g_min_tiles = [] { const char* e = getenv("STYLER_GEMM256_MIN_TILES"); return e ? atoi(e) : 384; }();
