@@ -281,7 +281,7 @@ class GraphedTrainStep:
         # workspace arena (its buffer, its reduce / group descriptor tables) and the zero slab are per-pass scratch that
         # the shared TrainState re-sizes when a later, larger batch shape asks for more -- so every graphed step OWNS its
         # own pair: a second bucket's warm-up can neither free nor re-use memory this graph writes to on replay
-        # (round-2 advisor finding; tests/test_20_hip_backward.py::test_graph_cache_two_buckets_small_then_large).
+        # (round-2 advisor finding; tests/test_90_equivalences.py::test_graph_cache_two_buckets_small_then_large).
         self.arena, self.zero_slab = ops.WgradArena(), ops.ZeroSlab()
         self.arena.owned_by_graph = True
         shared = state.arena, state.zero_slab, state.overlap_allreduce
