@@ -143,16 +143,23 @@ __device__ __forceinline__ uint64_t mix_drop_epoch(uint64_t seed, const uint64_t
 // mixer: the key schedule (splitmix64 of the seed) is uniform -- scalar ALU, hoisted out of element loops -- and the
 // per-element part is two 32-bit multiplies with the key entering before the first and between the two (the 64-bit
 // splitmix per element it replaces was ~50 issue slots per element: the BatchNorm backward kernels were VALU-bound on it).
-__device__ __forceinline__ uint32_t dropout_hash32(uint64_t seed, uint64_t idx) {
+__device__ __forceinline__ uint2 dropout_key(uint64_t seed) {
   uint64_t k = seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
   k = (k ^ (k >> 30)) * 0xBF58476D1CE4E5B9ull;
   k = (k ^ (k >> 27)) * 0x94D049BB133111EBull;
   k ^= k >> 31;
-  uint32_t h = (uint32_t)idx ^ (uint32_t)k;
+  return make_uint2((uint32_t)k, (uint32_t)(k >> 32));
+}
+// the per-element part with the key (and, where the caller has it as a scalar, the high index word) already in hand
+__device__ __forceinline__ uint32_t dropout_hash32_keyed(uint2 key, uint32_t idx_lo, uint32_t idx_hi) {
+  uint32_t h = idx_lo ^ key.x;
   h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15;
-  h += (uint32_t)(k >> 32) + (uint32_t)(idx >> 32) * 0x9E3779B1u;
+  h += key.y + idx_hi * 0x9E3779B1u;
   h *= 0x846ca68bu; h ^= h >> 16;
   return h;
+}
+__device__ __forceinline__ uint32_t dropout_hash32(uint64_t seed, uint64_t idx) {
+  return dropout_hash32_keyed(dropout_key(seed), (uint32_t)idx, (uint32_t)(idx >> 32));
 }
 
 // Gradient w.r.t. the BatchNorm output of y = dropout(act(BN(x))) for one element: the dropout keep mask is regenerated

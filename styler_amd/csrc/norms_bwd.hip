@@ -10,7 +10,19 @@
 #ifndef LNB_WAVES
 #define LNB_WAVES 8         // waves per block: rows in flight per CU (the row loop is a latency chain of 4 wave reductions)
 #endif
-template <int R>
+// The kernel is VALU-issue bound (measured round 3: ~340 wave-instructions per row at two waves per SIMD; neither more
+// blocks, more waves nor deeper load pipelining moved it), so the instruction stream is what is designed here:
+//   * the row index is a WAVE-uniform scalar (readfirstlane of the wave id): row * ld, the item / time split, the length
+//     lookup and the "row is masked / past the end" tests run on the scalar unit, loads and stores are scalar base +
+//     one per-lane offset (the per-lane 64-bit address arithmetic was ~1/4 of the stream);
+//   * the storage formats and the optional parts (dot tail, dropout behind / in front, lengths, ReLU input) are template
+//     bits M for the combinations the model uses (one straight-line body each, the two rows' chains interleave across
+//     what used to be ~70 uniform branches per iteration); M < 0 is the same body driven by the run-time flags;
+//   * the dropout key schedule and thresholds are computed once per kernel.
+// Same expressions in the same order as before: the results are bit-identical to the round-2 kernel.
+enum { LNM_ALL16 = 1, LNM_DOT = 2, LNM_DROP = 4, LNM_INDROP = 8, LNM_LEN = 16, LNM_RELU = 32 };
+
+template <int R, int M>
 __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dx, int64_t lddx,
@@ -18,29 +30,49 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     const float* __restrict__ dout, float* __restrict__ ddot_w, float* __restrict__ ddot_b, int64_t rows, int L,
     const int64_t* __restrict__ len, float drop_p, uint64_t drop_seed_host, const uint64_t* __restrict__ epoch,
     float in_drop_p, uint64_t in_drop_seed_host, float* __restrict__ dx_drop, int64_t lddxd, int replicas, int flags) {
-  const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
-  const bool x16 = flags & STYLER_LNB_X_BF16, dy16 = flags & STYLER_LNB_DY_BF16, dx16 = flags & STYLER_LNB_DX_BF16,
-             dxd16 = flags & STYLER_LNB_DXD_BF16;
+  constexpr bool GEN = M < 0;
+  const bool x16 = GEN ? (flags & STYLER_LNB_X_BF16) != 0 : (M & LNM_ALL16) != 0;
+  const bool dy16 = GEN ? (flags & STYLER_LNB_DY_BF16) != 0 : (M & LNM_ALL16) != 0;
+  const bool dx16 = GEN ? (flags & STYLER_LNB_DX_BF16) != 0 : (M & LNM_ALL16) != 0;
+  const bool dxd16 = GEN ? (flags & STYLER_LNB_DXD_BF16) != 0 : (M & LNM_ALL16) != 0;
+  const bool has_dot = GEN ? dot_w != nullptr : (M & LNM_DOT) != 0;
+  const bool has_drop = GEN ? drop_p > 0.f : (M & LNM_DROP) != 0;
+  const bool has_indrop = GEN ? dx_drop != nullptr : (M & LNM_INDROP) != 0;
+  const bool has_len = GEN ? len != nullptr : (M & LNM_LEN) != 0;
+  const bool relu_in = GEN ? (flags & STYLER_LNB_RELU_INPUT) != 0 : (M & LNM_RELU) != 0;
   const int lane = threadIdx.x & 63;
-  const int64_t w0 = (int64_t)blockIdx.x * LNB_WAVES + (threadIdx.x >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t w0 = (int64_t)blockIdx.x * LNB_WAVES + wv;
   const int64_t wstride = (int64_t)gridDim.x * LNB_WAVES;
   const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
   float4 bt = make_float4(0.f, 0.f, 0.f, 0.f), dw4 = bt;
-  if (dot_w) { bt = *reinterpret_cast<const float4*>(beta + lane * 4); dw4 = *reinterpret_cast<const float4*>(dot_w + lane * 4); }
+  if (has_dot) { bt = *reinterpret_cast<const float4*>(beta + lane * 4); dw4 = *reinterpret_cast<const float4*>(dot_w + lane * 4); }
+  // dropout streams: keys, thresholds and scales once per kernel
+  uint2 key_out = make_uint2(0u, 0u), key_in = key_out;
+  uint32_t thr_out = 0u, thr_in = 0u;
+  float sc_out = 1.f, sc_in = 1.f;
+  if (has_drop) {
+    key_out = dropout_key(mix_drop_epoch(drop_seed_host, epoch));
+    thr_out = (uint32_t)((double)drop_p * 4294967296.0);
+    sc_out = 1.f / (1.f - drop_p);
+  }
+  if (has_indrop) {
+    key_in = dropout_key(mix_drop_epoch(in_drop_seed_host, epoch));
+    thr_in = (uint32_t)((double)in_drop_p * 4294967296.0);
+    sc_in = 1.f / (1.f - in_drop_p);
+  }
+  const uint32_t l4 = lane * 4;
   float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag, aw = ag;
   float adb = 0.f;
-  // Two rows per wave and iteration: a row is a latency chain (two loads, then mean -> variance -> two more wave
-  // reductions); the chains of the two rows are independent and interleave.  (Measured: 1, 2 and 4 rows take the same
-  // 25 us -- the kernel was bound by its parameter-gradient atomics, see `replicas`.)
+  // Two rows per wave and iteration: a row is a chain (two loads, then mean -> variance -> two more wave reductions);
+  // the chains of the two rows are independent and interleave.
   for (int64_t row0 = w0; row0 < rows; row0 += wstride * R) {
-    int64_t row[R];
+    int64_t row[R], rc[R];
     bool live[R];
     float4 v[R], d[R];
     float go[R], kx[R][4];
-    // Every load of the iteration is issued before anything waits: the rows' item lengths first, then x / dy (/ dout) of
-    // all R rows from clamped addresses -- a load under a lane condition compiles to a branch with its own vmcnt(0), which
-    // chained the rows' memory round trips one behind the other.  Masked rows are fetched and discarded.
-    int64_t rc[R];
+    // Every load of the iteration is issued before anything waits: the rows' item lengths first (scalar loads), then
+    // x / dy (/ dout) of all R rows from clamped rows; masked rows are fetched and discarded.
     uint32_t tt[R];
     int lv[R];
 #pragma unroll
@@ -49,38 +81,37 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
       live[k] = row[k] < rows;
       rc[k] = live[k] ? row[k] : rows - 1;
       tt[k] = 0u; lv[k] = 1;
-      if (len) {
+      if (has_len) {
         const uint32_t b = (uint32_t)rc[k] / (uint32_t)L;              // rows < 2^31 (checked by the host wrapper)
         tt[k] = (uint32_t)rc[k] - b * (uint32_t)L;
         lv[k] = reinterpret_cast<const int*>(len)[2 * b];             // low dword of the int64 length
       }
     }
-    // raw loads of ALL rows first (fp32: 16 bytes per lane, bf16: 8), conversions afterwards: a conversion next to its load
-    // puts a wait behind every load; the storage flags are uniform, so each format is its own straight-line load loop
+    // raw loads of ALL rows first (fp32: 16 bytes per lane, bf16: 8), conversions afterwards
     uint2 rv16[R], rd16[R];
     if (x16) {
 #pragma unroll
-      for (int k = 0; k < R; ++k) rv16[k] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(x) + rc[k] * ldx + lane * 4);
+      for (int k = 0; k < R; ++k) rv16[k] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(x) + rc[k] * ldx + l4);
     } else {
 #pragma unroll
-      for (int k = 0; k < R; ++k) v[k] = *reinterpret_cast<const float4*>(x + rc[k] * ldx + lane * 4);
+      for (int k = 0; k < R; ++k) v[k] = *reinterpret_cast<const float4*>(x + rc[k] * ldx + l4);
     }
 #pragma unroll
-    for (int k = 0; k < R; ++k) { go[k] = 0.f; if (dot_w) go[k] = dout[rc[k]]; }
-    if (!dot_w) {
+    for (int k = 0; k < R; ++k) { go[k] = 0.f; if (has_dot) go[k] = dout[rc[k]]; }
+    if (!has_dot) {
       if (dy16) {
 #pragma unroll
-        for (int k = 0; k < R; ++k) rd16[k] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(dy) + rc[k] * lddy + lane * 4);
+        for (int k = 0; k < R; ++k) rd16[k] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(dy) + rc[k] * lddy + l4);
       } else {
 #pragma unroll
-        for (int k = 0; k < R; ++k) d[k] = *reinterpret_cast<const float4*>(dy + rc[k] * lddy + lane * 4);
+        for (int k = 0; k < R; ++k) d[k] = *reinterpret_cast<const float4*>(dy + rc[k] * lddy + l4);
       }
     }
     if (x16) {
 #pragma unroll
       for (int k = 0; k < R; ++k) { pin_loaded(rv16[k]); v[k] = raw4_f32(rv16[k]); }
     }
-    if (!dot_w && dy16) {
+    if (!has_dot && dy16) {
 #pragma unroll
       for (int k = 0; k < R; ++k) { pin_loaded(rd16[k]); d[k] = raw4_f32(rd16[k]); }
     }
@@ -88,24 +119,22 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     for (int k = 0; k < R; ++k) {
       if (live[k] && (int)tt[k] >= lv[k]) {               // masked row: zero gradient, nothing else
         live[k] = false;
-        if (dx) stg4(dx, row[k] * lddx + lane * 4, make_float4(0.f, 0.f, 0.f, 0.f), dx16);
-        if (dx_drop) stg4(dx_drop, row[k] * lddxd + lane * 4, make_float4(0.f, 0.f, 0.f, 0.f), dxd16);
+        if (dx) stg4(dx, row[k] * lddx + l4, make_float4(0.f, 0.f, 0.f, 0.f), dx16);
+        if (has_indrop) stg4(dx_drop, row[k] * lddxd + l4, make_float4(0.f, 0.f, 0.f, 0.f), dxd16);
       }
       if (!live[k]) { v[k] = make_float4(0.f, 0.f, 0.f, 0.f); go[k] = 0.f; }
       kx[k][0] = kx[k][1] = kx[k][2] = kx[k][3] = 1.f;
-      if (drop_p > 0.f) {                                // dropout keep * 1/(1-p) behind the LayerNorm (forward's drop_p)
-        const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);
-        const float sc = 1.f / (1.f - drop_p);
-        const uint64_t e = (uint64_t)row[k] * 256 + lane * 4;
+      if (has_drop) {                                    // dropout keep * 1/(1-p) behind the LayerNorm (forward's drop_p)
+        const uint32_t elo = ((uint32_t)row[k] << 8) | l4, ehi = (uint32_t)((uint64_t)row[k] >> 24);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) kx[k][q] = dropout_hash32(drop_seed, e + q) >= thr ? sc : 0.f;
+        for (int q = 0; q < 4; ++q) kx[k][q] = dropout_hash32_keyed(key_out, elo + q, ehi) >= thr_out ? sc_out : 0.f;
       }
-      if (dot_w) {
+      if (has_dot) {
         d[k] = make_float4(go[k] * dw4.x * kx[k][0], go[k] * dw4.y * kx[k][1], go[k] * dw4.z * kx[k][2],
                            go[k] * dw4.w * kx[k][3]);
       } else if (!live[k]) {
         d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      } else if (drop_p > 0.f) {                         // dy is the gradient w.r.t. the DROPPED output
+      } else if (has_drop) {                             // dy is the gradient w.r.t. the DROPPED output
         d[k].x *= kx[k][0]; d[k].y *= kx[k][1]; d[k].z *= kx[k][2]; d[k].w *= kx[k][3];
       }
     }
@@ -130,7 +159,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
       rstd[k] = 1.0f / sqrtf(rstd[k] * (1.f / 256.f) + 1e-5f);
       h[k].x *= rstd[k]; h[k].y *= rstd[k]; h[k].z *= rstd[k]; h[k].w *= rstd[k];
       if (live[k]) {
-        if (dot_w) {
+        if (has_dot) {
           aw.x += go[k] * kx[k][0] * (h[k].x * g.x + bt.x); aw.y += go[k] * kx[k][1] * (h[k].y * g.y + bt.y);
           aw.z += go[k] * kx[k][2] * (h[k].z * g.z + bt.z); aw.w += go[k] * kx[k][3] * (h[k].w * g.w + bt.w);
           if (lane == 0) adb += go[k];
@@ -150,26 +179,24 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
       m1[k] *= (1.f / 256.f); m2[k] *= (1.f / 256.f);
       float4 gx = make_float4(rstd[k] * (ex[k].x - m1[k] - h[k].x * m2[k]), rstd[k] * (ex[k].y - m1[k] - h[k].y * m2[k]),
                               rstd[k] * (ex[k].z - m1[k] - h[k].z * m2[k]), rstd[k] * (ex[k].w - m1[k] - h[k].w * m2[k]));
-      if (flags & STYLER_LNB_RELU_INPUT) {               // x = relu(z): dx is handed on as dz (no separate act_bwd pass)
+      if (relu_in) {                                     // x = relu(z): dx is handed on as dz (no separate act_bwd pass)
         gx.x = v[k].x > 0.f ? gx.x : 0.f; gx.y = v[k].y > 0.f ? gx.y : 0.f;
         gx.z = v[k].z > 0.f ? gx.z : 0.f; gx.w = v[k].w > 0.f ? gx.w : 0.f;
       }
-      if (dx) stg4(dx, row[k] * lddx + lane * 4, gx, dx16);
-      if (dx_drop) {                                     // gradient of the dropout(x) that fed the sum (same stream)
-        const uint64_t sd = mix_drop_epoch(in_drop_seed_host, epoch);
-        const uint32_t thr = (uint32_t)((double)in_drop_p * 4294967296.0);
-        const float sc = 1.f / (1.f - in_drop_p);
-        const uint64_t e = (uint64_t)row[k] * 256 + lane * 4;
-        stg4(dx_drop, row[k] * lddxd + lane * 4,
-             make_float4(dropout_hash32(sd, e) >= thr ? gx.x * sc : 0.f, dropout_hash32(sd, e + 1) >= thr ? gx.y * sc : 0.f,
-                        dropout_hash32(sd, e + 2) >= thr ? gx.z * sc : 0.f, dropout_hash32(sd, e + 3) >= thr ? gx.w * sc : 0.f), dxd16);
+      if (dx) stg4(dx, row[k] * lddx + l4, gx, dx16);
+      if (has_indrop) {                                  // gradient of the dropout(x) that fed the sum (same stream)
+        const uint32_t elo = ((uint32_t)row[k] << 8) | l4, ehi = (uint32_t)((uint64_t)row[k] >> 24);
+        stg4(dx_drop, row[k] * lddxd + l4,
+             make_float4(dropout_hash32_keyed(key_in, elo, ehi) >= thr_in ? gx.x * sc_in : 0.f,
+                         dropout_hash32_keyed(key_in, elo + 1, ehi) >= thr_in ? gx.y * sc_in : 0.f,
+                         dropout_hash32_keyed(key_in, elo + 2, ehi) >= thr_in ? gx.z * sc_in : 0.f,
+                         dropout_hash32_keyed(key_in, elo + 3, ehi) >= thr_in ? gx.w * sc_in : 0.f), dxd16);
       }
     }
   }
   // block-level reduction (LNB_WAVES waves) before the atomics: 256 + 256 (+ 256 + 1) atomics per block
   __shared__ float red[3][LNB_WAVES][256];
   __shared__ float redb[LNB_WAVES];
-  const int wv = threadIdx.x >> 6;
   red[0][wv][lane * 4 + 0] = ag.x; red[0][wv][lane * 4 + 1] = ag.y; red[0][wv][lane * 4 + 2] = ag.z; red[0][wv][lane * 4 + 3] = ag.w;
   red[1][wv][lane * 4 + 0] = ab.x; red[1][wv][lane * 4 + 1] = ab.y; red[1][wv][lane * 4 + 2] = ab.z; red[1][wv][lane * 4 + 3] = ab.w;
   red[2][wv][lane * 4 + 0] = aw.x; red[2][wv][lane * 4 + 1] = aw.y; red[2][wv][lane * 4 + 2] = aw.z; red[2][wv][lane * 4 + 3] = aw.w;
@@ -177,7 +204,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
   if (lane == 0) redb[wv] = wsum;
   __syncthreads();
   const int c = threadIdx.x & 255, which = threadIdx.x >> 8;            // 512 threads: 2 of the 3 sums at once
-  for (int q = which; q < (dot_w ? 3 : 2); q += (64 * LNB_WAVES) / 256) {
+  for (int q = which; q < (has_dot ? 3 : 2); q += (64 * LNB_WAVES) / 256) {
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < LNB_WAVES; ++w) t += red[q][w][c];
@@ -188,7 +215,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     if (replicas >= (int)gridDim.x) dst[(int64_t)blockIdx.x * 256 + c] = t;
     else atomicAdd(dst + (blockIdx.x % replicas) * 256 + c, t);
   }
-  if (dot_w && threadIdx.x == 0) {
+  if (has_dot && threadIdx.x == 0) {
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < LNB_WAVES; ++w) t += redb[w];
@@ -211,15 +238,36 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
   int64_t blocks = (rows + LNB_WAVES - 1) / LNB_WAVES;
   static const int cap = [] { const char* e = getenv("STYLER_LNBWD_BLOCKS"); return e ? atoi(e) : 256; }();
   if (blocks > cap) blocks = cap;
-  static const int rows_per_iter = [] { const char* e = getenv("STYLER_LNBWD_ROWS"); return e ? atoi(e) : 2; }();
-  if (rows_per_iter == 4)
-    hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3((unsigned)blocks), dim3(64 * LNB_WAVES), 0, (hipStream_t)stream, x, ldx, dy,
-                       lddy, gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b, rows, L, len, drop_p, drop_seed,
-                       g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd, replicas, flags);
-  else
-    hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3((unsigned)blocks), dim3(64 * LNB_WAVES), 0, (hipStream_t)stream, x, ldx, dy,
-                       lddy, gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b, rows, L, len, drop_p, drop_seed,
-                       g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd, replicas, flags);
+  // Specialised bodies for the combinations the model launches (all tensors of one storage format); anything else -- and
+  // everything under STYLER_LNBWD_GENERIC=1, the A/B switch of the tests -- runs the flag-driven body (same arithmetic).
+  static const bool generic_only = [] { const char* e = getenv("STYLER_LNBWD_GENERIC"); return e && atoi(e) != 0; }();
+  const int fmt = flags & (STYLER_LNB_X_BF16 | STYLER_LNB_DY_BF16 | STYLER_LNB_DX_BF16 | STYLER_LNB_DXD_BF16);
+  int want16 = STYLER_LNB_X_BF16;                       // the format bits of the tensors this launch has
+  if (dy && !dot_w) want16 |= STYLER_LNB_DY_BF16;
+  if (dx) want16 |= STYLER_LNB_DX_BF16;
+  if (dx_drop) want16 |= STYLER_LNB_DXD_BF16;
+  int mode = -1;
+  if (!generic_only && ((fmt & want16) == 0 || (fmt & want16) == want16))
+    mode = ((fmt & want16) ? LNM_ALL16 : 0) | (dot_w ? LNM_DOT : 0) | (drop_p > 0.f ? LNM_DROP : 0) |
+           (dx_drop ? LNM_INDROP : 0) | (len ? LNM_LEN : 0) | ((flags & STYLER_LNB_RELU_INPUT) ? LNM_RELU : 0);
+#define LNB_LAUNCH(MODE)                                                                                                       \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<2, MODE>), dim3((unsigned)blocks), dim3(64 * LNB_WAVES), 0, (hipStream_t)stream, x,  \
+                     ldx, dy, lddy, gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b, rows, L, len, drop_p,    \
+                     drop_seed, g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd, replicas, flags)
+#define LNB_CASE(MODE) case (MODE): LNB_LAUNCH(MODE); break
+  switch (mode) {
+    // attention / FFN sublayer tails (decoder: packed bf16 stream, encoder: fp32 with lengths), with and without dropout
+    LNB_CASE(0); LNB_CASE(LNM_INDROP); LNB_CASE(LNM_LEN); LNB_CASE(LNM_LEN | LNM_INDROP);
+    LNB_CASE(LNM_ALL16); LNB_CASE(LNM_ALL16 | LNM_INDROP); LNB_CASE(LNM_ALL16 | LNM_LEN);
+    LNB_CASE(LNM_ALL16 | LNM_LEN | LNM_INDROP);
+    // predictor stages: conv -> ReLU -> LN -> dropout (-> Linear(256, 1) tail)
+    LNB_CASE(LNM_DROP | LNM_RELU); LNB_CASE(LNM_RELU);
+    LNB_CASE(LNM_DOT | LNM_DROP | LNM_LEN | LNM_RELU); LNB_CASE(LNM_DOT | LNM_LEN | LNM_RELU);
+    LNB_CASE(LNM_DOT | LNM_DROP | LNM_LEN); LNB_CASE(LNM_DOT | LNM_LEN);
+    default: LNB_LAUNCH(-1); break;
+  }
+#undef LNB_CASE
+#undef LNB_LAUNCH
   return launch_status();
 }
 
