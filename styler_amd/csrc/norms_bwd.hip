@@ -62,6 +62,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     sc_in = 1.f / (1.f - in_drop_p);
   }
   const uint32_t l4 = lane * 4;
+  const bool one_item = has_len && (int64_t)L >= rows;
+  const int lv_one = one_item ? reinterpret_cast<const int*>(len)[0] : 0;
   float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag, aw = ag;
   float adb = 0.f;
   // Two rows per wave and iteration: a row is a chain (two loads, then mean -> variance -> two more wave reductions);
@@ -82,9 +84,30 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
       rc[k] = live[k] ? row[k] : rows - 1;
       tt[k] = 0u; lv[k] = 1;
       if (has_len) {
-        const uint32_t b = (uint32_t)rc[k] / (uint32_t)L;              // rows < 2^31 (checked by the host wrapper)
-        tt[k] = (uint32_t)rc[k] - b * (uint32_t)L;
-        lv[k] = reinterpret_cast<const int*>(len)[2 * b];             // low dword of the int64 length
+        if (one_item) {                                               // packed rows: no division, the length is loop-invariant
+          tt[k] = (uint32_t)rc[k]; lv[k] = lv_one;
+        } else {
+          const uint32_t b = (uint32_t)rc[k] / (uint32_t)L;            // rows < 2^31 (checked by the host wrapper)
+          tt[k] = (uint32_t)rc[k] - b * (uint32_t)L;
+          lv[k] = reinterpret_cast<const int*>(len)[2 * b];           // low dword of the int64 length
+        }
+      }
+    }
+    if (has_len) {
+      // All rows of this iteration masked (a wave-uniform fact): zero gradients and nothing else -- no loads, no arithmetic.
+      // The packed decoder launches cover the row CAPACITY of the batch (2 B T rows, ~36 % of them behind the last valid
+      // row at the training shapes); padded [B, L] launches have whole waves in the padding just as often.
+      bool none = true;
+#pragma unroll
+      for (int k = 0; k < R; ++k) none = none && (!live[k] || (int)tt[k] >= lv[k]);
+      if (none) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          if (!live[k]) continue;
+          if (dx) stg4(dx, row[k] * lddx + l4, make_float4(0.f, 0.f, 0.f, 0.f), dx16);
+          if (has_indrop) stg4(dx_drop, row[k] * lddxd + l4, make_float4(0.f, 0.f, 0.f, 0.f), dxd16);
+        }
+        continue;
       }
     }
     // raw loads of ALL rows first (fp32: 16 bytes per lane, bf16: 8), conversions afterwards

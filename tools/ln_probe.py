@@ -40,3 +40,21 @@ for dt in (torch.float32, torch.bfloat16):
                                           torch.cuda.current_stream().cuda_stream)
             assert rc == 0
         print(f"blocks<={blocks} dtype={str(dt)[6:]} in_drop_p={p}: {t(call):.1f} us", flush=True)
+
+# the packed decoder launch: row capacity 42 336 (2 B T), 27 060 valid rows, lengths given (one item)
+cap = 42336
+lens = torch.tensor([rows], device=dev, dtype=torch.int64)
+s = torch.randn(1, cap, 256, device=dev).bfloat16()
+dy = torch.randn(1, cap, 256, device=dev).bfloat16()
+dx, dxd = torch.empty_like(s), torch.empty_like(s)
+
+
+def call_packed():
+    rc = lib.styler_layernorm_bwd(s.data_ptr(), 256, dy.data_ptr(), 256, gam.data_ptr(), bet.data_ptr(), dx.data_ptr(), 256,
+                                  slots[0].data_ptr(), slots[1].data_ptr(), None, None, None, None, 1, cap, 256, lens.data_ptr(),
+                                  0.0, 0, 0.2, 5, dxd.data_ptr(), 256, max(blocks, 256), 2 | 4 | 8 | 16,
+                                  torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+
+
+print(f"packed capacity {cap} rows, {rows} valid, bf16, in_drop_p=0.2: {t(call_packed):.1f} us", flush=True)
