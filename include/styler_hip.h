@@ -128,6 +128,12 @@ int styler_conv_gemm_engine(int B, int L, int cin, int n, int kw, int prec, int 
 /* Test / tuning hook of that engine: enabled (0 / 1) and the smallest tile count it takes; -1 keeps a value (defaults:
  * STYLER_GEMM256, STYLER_GEMM256_MIN_TILES or 1, 384).  Returns the previous state as enabled | min_tiles << 1. */
 int styler_gemm256_config(int enabled, int min_tiles);
+/* The narrow-output tile of styler_conv_gemm (bf16 MFMA mode, 64 < n <= 96 -- the 80 mel channels of PostNet's last
+ * convolution, of the dX of its first one and of mel_linear, Layers.py:78-118, styler.py:22): one 128 x 96 block tile per
+ * row block instead of two 64 x 64 tiles.  enabled (0 / 1) and the smallest row count B * L it takes; -1 keeps a value
+ * (defaults: STYLER_GEMM_N96 or 1, 32768).  Returns the previous state as enabled | min_rows << 1.  Same MFMA sequence per
+ * output element as the other tiles: results are bit-equal. */
+int styler_gemm_n96_config(int enabled, int min_rows);
 /* Split-K scratch of the 256 x 256 engine.  styler_conv_gemm_workspace_bytes: bytes of fp32 partial tiles a
  * styler_conv_gemm / styler_conv_gemm_packed call with these arguments wants (0: none; today only launches with 96..160
  * data-carrying tiles and >= 64 K steps and a plain epilogue: the dX of the FFN's k = 9 convolution,

@@ -455,6 +455,14 @@ def gemm256_config(enabled=-1, min_tiles=-1):
     return prev & 1, prev >> 1
 
 
+def gemm_n96_config(enabled=-1, min_rows=-1):
+    """Test / tuning hook of the narrow-output GEMM tile (128 x 96, bf16 mode, 64 < n <= 96): on / off and the smallest row
+    count it takes (-1 keeps a value).  Returns the previous (enabled, min_rows)."""
+    prev = lib.styler_gemm_n96_config(-1, -1)
+    lib.styler_gemm_n96_config(int(enabled), int(min_rows))
+    return prev & 1, prev >> 1
+
+
 def _prec(prec):
     if prec is None:
         from .runtime import rt

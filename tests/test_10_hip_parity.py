@@ -155,6 +155,56 @@ def test_gemm256_engine_vs_math_and_vs_128_engine(dev, case):
     assert torch.equal(ys[0], y128), f"{case}: 256 engine != 128 engine, max diff {float((ys[0].float() - y128.float()).abs().max()):.3e}"
 
 
+N96_CASES = {
+    # name: (B, L, cin, n, kw, lens, act, x_bf16, y_bf16, with_res)
+    "postnet_out_k5_ragged": (3, 333, 512, 80, 5, [333, 200, 7], 0, True, False, True),
+    "postnet_in_dx_k5_fp32_x": (2, 257, 512, 80, 5, None, 0, False, False, False),
+    "mel_linear_k1": (2, 300, 256, 80, 1, [300, 123], 0, True, False, False),
+    "n96_exact_tanh_bf16_out": (2, 130, 64, 96, 3, None, 2, True, True, False),
+    "n68_one_row_items": (5, 1, 64, 68, 9, None, 1, False, False, False),
+}
+
+
+@pytest.mark.parametrize("case", sorted(N96_CASES))
+def test_gemm_narrow_output_tile_vs_math_and_vs_64_tile(dev, case):
+    """The 128 x 96 tile (conv_gemm_kernel<1, 3, ..., WM = 4>) that takes the bf16-mode launches with 64 < n <= 96 (the 80
+    mel channels: PostNet's last conv, the dX of its first, mel_linear): against fp64 math on the bf16-rounded operands, and
+    bit for bit against the 64 x 64 tile (same MFMA sequence per output element).  Ragged lengths, taps at item
+    boundaries, rows past M inside a tile, columns past n inside the tile, fp32 and bf16 operands / outputs."""
+    from styler_amd import ops
+    B, L, cin, n, kw, lens, act, x_bf16, y16, with_res = N96_CASES[case]
+    g = torch.Generator().manual_seed(sum(map(ord, case)))
+    x = torch.randn(B, L, cin, generator=g)
+    if lens is not None:
+        x = x * (torch.arange(L)[None, :, None] < torch.tensor(lens)[:, None, None])
+    x16 = x.to(torch.bfloat16)
+    w16 = (torch.randn(n, cin, kw, generator=g) / np.sqrt(cin * kw)).to(torch.bfloat16)
+    b = torch.randn(n, generator=g)
+    res = torch.randn(B, L, n, generator=g) if with_res else None
+    ref = _conv_ref64(x16.float(), w16.float(), kw) + b.double()
+    ref = {0: ref, 1: torch.relu(ref), 2: torch.tanh(ref)}[act]
+    if res is not None:
+        ref = ref + res.double()
+    if lens is not None:
+        ref = ref * (torch.arange(L)[None, :, None] < torch.tensor(lens)[:, None, None])
+    wk = w16.permute(0, 2, 1).reshape(n, -1).contiguous().to(dev)
+    args = dict(kw=kw, act=act, prec=ops.PREC_BF16, res=res.to(dev) if with_res else None,
+                lens=torch.tensor(lens).to(dev) if lens is not None else None, out_bf16=y16)
+    xd = (x16 if x_bf16 else x16.float()).to(dev)     # fp32 storage of bf16-representable values: same products
+    prev = ops.gemm_n96_config(1, 1)
+    try:
+        ys = [ops.conv_gemm(xd, wk, b.to(dev), **args).clone() for _ in range(3)]
+        ops.gemm_n96_config(0, -1)
+        y64 = ops.conv_gemm(xd, wk, b.to(dev), **args)
+    finally:
+        ops.gemm_n96_config(*prev)
+    tol = 1e-2 if y16 else 1e-4
+    e = float((ys[0].double().cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert e <= tol, f"{case}: max err / max|ref| = {e:.3e}"
+    assert torch.equal(ys[1], ys[0]) and torch.equal(ys[2], ys[0]), f"{case}: repeated launches differ"
+    assert torch.equal(ys[0], y64), f"{case}: 128x96 tile != 64x64 tile, max diff {float((ys[0].float() - y64.float()).abs().max()):.3e}"
+
+
 def test_gemm256_engine_packed_rows(dev):
     """The engine on the decoder's packed-rows layout (ops.PackPlan): taps stop at item boundaries (rowinfo), tiles behind
     the data are skipped, rows at or past the device row counter are written as zeros."""
