@@ -305,7 +305,7 @@ def hbm_rooflines(dev, B, S, T, frames, tag):
     operand read once, every result written once, in the storage types the bf16-mode step uses; SURVEY 8d's per-position
     figures where the kernel moves exactly those), `frac` = bytes / avg_us / 8 TB/s.  Operand sets rotate so that the
     working set exceeds the Infinity Cache (`_graph_loop_us`)."""
-    from styler_amd import ops
+    from styler_amd import ops, rt
     out = []
     g = torch.Generator().manual_seed(7)
 
@@ -356,34 +356,41 @@ def hbm_rooflines(dev, B, S, T, frames, tag):
         lambda i: (lambda: ops.layernorm_bwd(so[i], dyb[i], gam, bet, dg, db, in_drop_p=0.2, in_drop_seed=5)),
         "2 reads + 2 writes of 512 B per row (all-fp32 form: 4096 B)", nsets=n)
     del a, r, so, yo, dyb
-    # GroupNorm + ReLU of the AudioEncoder (main + DAT pass stacked: 2B items), C = 320, fp32 conv output -> bf16
+    # GroupNorm + ReLU of the AudioEncoder (main + DAT pass stacked: 2B items), C = 320; throughput-mode storage: the conv
+    # output is bf16 (rt.bf16_z) whenever the item fits the single-pass kernels, as at this shape
+    zdt = torch.bfloat16 if (rt.bf16_z and ops.groupnorm_z_bf16_ok(T)) else torch.float32
+    zb = 2 if zdt == torch.bfloat16 else 4
+    zname = "bf16" if zb == 2 else "fp32"
     Bg, C = 2 * B, 320
     gnb = Bg * T * C
-    n = nsets_for(gnb * 6)
-    gx = [torch.randn(Bg, T, C, device=dev) for _ in range(n)]
+    n = nsets_for(gnb * (zb + 2))
+    gx = [torch.randn(Bg, T, C, device=dev).to(zdt) for _ in range(n)]
     gy = [torch.empty(Bg, T, C, device=dev, dtype=torch.bfloat16) for _ in range(n)]
     gst = [torch.empty(Bg, C // 16, 2, device=dev) for _ in range(n)]
     ggam, gbet = torch.randn(C, device=dev), torch.randn(C, device=dev)
-    add("gn_fused_kernel (GroupNorm + ReLU, single pass)", f"[{Bg},{T},{C}] fp32 -> bf16", gnb * 6,
+    add("gn_fused_kernel (GroupNorm + ReLU, single pass)", f"[{Bg},{T},{C}] {zname} -> bf16", gnb * (zb + 2),
         lambda i: (lambda: ops.groupnorm_relu(gx[i], ggam, gbet, out=gy[i], stats=gst[i])),
-        "1 read (4 B) + 1 write (2 B) per element; SURVEY 8d's two-pass figure is 2 reads + 1 write")
+        f"1 read ({zb} B) + 1 write (2 B) per element; SURVEY 8d's two-pass fp32 figure is 2 reads + 1 write of 4 B", nsets=n)
     gdy = [torch.randn(Bg, T, C, device=dev).to(torch.bfloat16) for _ in range(n)]
     for i in range(n):
         ops.groupnorm_relu(gx[i], ggam, gbet, out=gy[i], stats=gst[i])
     gdg, gdb = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
-    add("gn_bwd_fused_kernel", f"[{Bg},{T},{C}] x fp32 + dy bf16 -> dx bf16", gnb * 8,
+    add("gn_bwd_fused_kernel", f"[{Bg},{T},{C}] x {zname} + dy bf16 -> dx bf16", gnb * (zb + 4),
         lambda i: (lambda: ops.groupnorm_relu_bwd(gx[i], gdy[i], ggam, gbet, gst[i], gdg, gdb, dx_bf16=True)),
-        "x read once (4 B), dy read once (2 B), dx written (2 B)", nsets=n)
+        f"x read once ({zb} B), dy read once (2 B), dx written (2 B)", nsets=n)
     del gx, gy, gdy
     # PostNet BatchNorm (train statistics) + tanh + dropout, clean + noisy mel as two segments
     rows_b, Cb = 2 * B * T, 512
-    n = nsets_for(rows_b * Cb * 10)
-    bx = [torch.randn(B * 2, T, Cb, device=dev) for _ in range(n)]
+    zdt = torch.bfloat16 if rt.bf16_z else torch.float32
+    zb = 2 if zdt == torch.bfloat16 else 4
+    zname = "bf16" if zb == 2 else "fp32"
+    n = nsets_for(rows_b * Cb * (2 * zb + 2))
+    bx = [torch.randn(B * 2, T, Cb, device=dev).to(zdt) for _ in range(n)]
     bgam, bbet = torch.randn(Cb, device=dev), torch.randn(Cb, device=dev)
-    add("bn_colstats + bn_apply (BatchNorm train + tanh + dropout)", f"[{rows_b},{Cb}] fp32 -> bf16, 2 segments",
-        rows_b * Cb * 10,
+    add("bn_colstats + bn_apply (BatchNorm train + tanh + dropout)", f"[{rows_b},{Cb}] {zname} -> bf16, 2 segments",
+        rows_b * Cb * (2 * zb + 2),
         lambda i: (lambda: ops.batchnorm_train(bx[i], bgam, bbet, None, None, ops.ACT_TANH, 0.5, 11, segs=2, out_bf16=True)),
-        "2 reads of x (statistics, then apply) + 1 write (SURVEY 8d)")
+        f"2 reads of x ({zb} B each: statistics, then apply) + 1 write of 2 B (SURVEY 8d: the fp32 form)", nsets=n)
     del bx
     return out
 

@@ -46,6 +46,9 @@ extern "C" {
 #define STYLER_IO_Y_BF16 2    /* conv_gemm: y (no residual);   wgrad: dz */
 #define STYLER_IO_MASK_BF16 4 /* conv_gemm: mask */
 #define STYLER_IO_RES_BF16 8  /* conv_gemm: res (then allowed together with STYLER_IO_Y_BF16);  pack / unpack: see there */
+#define STYLER_IO_Z_BF16 16   /* GroupNorm / BatchNorm forward and backward: the normalised tensor x (a convolution's output,
+                                 kept for the backward) is stored as bf16 -- throughput mode; the statistics are those of the
+                                 rounded values, forward and backward agree on them */
 /* styler_add_layernorm io_flags (round 3: the decoder's residual stream is stored as bf16 in throughput mode) */
 #define STYLER_LN_RES_BF16 1  /* res is bf16 */
 #define STYLER_LN_Y_BF16 2    /* y is written as bf16 (ldy in elements) */
@@ -229,6 +232,11 @@ int styler_groupnorm_relu(const float* x, int64_t ldx, const float* gamma, const
  * the AudioEncoder / PostNet stacks -- and the gradients w.r.t. those convolutions' outputs -- that way: their only
  * consumers (the next convolution, the dX GEMM, the weight gradient) round to bf16 first, so no result changes and
  * every one of them moves half the bytes. */
+
+/* io_flags & STYLER_IO_Z_BF16 (the same four entry points): x itself -- the convolution output the norm reads, kept for
+ * the backward -- is bf16 (ldx in elements; pass the bf16 pointer as `x`).  GroupNorm accepts it in its single-pass variants
+ * only: items of up to styler_groupnorm_fused_rows(bwd) rows (1024 forward, 512 backward; 0 = variants switched off). */
+int styler_groupnorm_fused_rows(int bwd);
 
 /* BatchNorm1d folding for eval mode (Layers.py:91,105,118): scale = g * rsqrt(var + eps),
  * shift = (conv_bias - mean) * scale + b.  All [C]. */

@@ -69,6 +69,7 @@ _SIGS = {
     "styler_layernorm_bwd": [P, I64, P, I64, P, P, P, I64, P, P, P, P, P, P, I, I, I, P, F, ctypes.c_uint64, F, ctypes.c_uint64, P, I64, I, I, P],
     "styler_gemm256_config": [I, I],
     "styler_gemm_n96_config": [I, I],
+    "styler_groupnorm_fused_rows": [I],
     "styler_conv_gemm_workspace_bytes": [I, I, I, I, I, I, I, I, I64, I, I],
     "styler_gemm_set_workspace": [P, I64],
     "styler_fold_replicas": [P, P, P, P, P, P, I, I, P],

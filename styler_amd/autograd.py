@@ -319,13 +319,15 @@ class ConvNormFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, cache, key, kw, norm, kind, act, drop_p, segs, out_bf16):
         w, prec = gemm_weight(cache, key, weight, x.shape[-1])
-        z = ops.conv_gemm(x, w, bias, kw=kw, n=weight.shape[0], prec=prec)
         b16 = prec == ops.PREC_BF16 and rt.bf16_acts and weight.shape[0] % 8 == 0
+        # the convolution output itself as bf16 (rt.bf16_z): read by the norm forward and again by its backward
+        z16 = b16 and rt.bf16_z and (kind != "gn" or ops.groupnorm_z_bf16_ok(x.shape[1]))
+        z = ops.conv_gemm(x, w, bias, kw=kw, n=weight.shape[0], prec=prec, out_bf16=z16)
         out_bf16 = out_bf16 and b16
         if kind == "gn":
             aux = torch.empty(z.shape[0], z.shape[2] // 16, 2, device=z.device, dtype=torch.float32)
             y = ops.groupnorm_relu(z, norm.weight, norm.bias, stats=aux,
-                                   out=torch.empty_like(z, dtype=torch.bfloat16) if out_bf16 else torch.empty_like(z))
+                                   out=torch.empty_like(z, dtype=torch.bfloat16 if out_bf16 else torch.float32))
             ctx.save_for_backward(x, z, aux)
             ctx.drop = (0.0, 0)
         else:

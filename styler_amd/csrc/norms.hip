@@ -181,8 +181,9 @@ __device__ __forceinline__ float gn_group_sum_wave(float s) {    // over the lan
   s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
   return s;
 }
-template <int IT>
-__global__ __launch_bounds__(1024) void gn_fused_kernel(const float* __restrict__ x, int64_t ldx,
+// X16: x (the convolution output, kept for the backward) is stored as bf16 (STYLER_IO_Z_BF16).
+template <int IT, bool X16 = false>
+__global__ __launch_bounds__(1024) void gn_fused_kernel(const void* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         void* __restrict__ y, int64_t ldy, float* __restrict__ stats, int L,
                                                         int C, int y16) {
@@ -190,12 +191,17 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const float* __restrict_
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4, wave = threadIdx.x >> 6, grp = cq >> 2;
   const bool writer = (threadIdx.x & 0x33) == 0;                  // one lane per (wave, group)
-  const float* xp = x + (int64_t)b * L * ldx + c0 + cq * 4;
+  const int64_t xoff = (int64_t)b * L * ldx + c0 + cq * 4;
   float4 v[IT];
+  {
+    typename Raw4<X16>::T rv[IT];
 #pragma unroll
-  for (int i = 0; i < IT; ++i) {
-    const int t = rl + 64 * i < L ? rl + 64 * i : L - 1;          // clamped, masked below: no load sits behind a branch
-    v[i] = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
+    for (int i = 0; i < IT; ++i) {
+      const int t = rl + 64 * i < L ? rl + 64 * i : L - 1;        // clamped, masked below: no load sits behind a branch
+      rv[i] = raw4_load<X16>(x, xoff + (int64_t)t * ldx);
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) v[i] = raw4_f32(rv[i]);
   }
   const float inv_n = 1.f / (16.f * (float)L);
   float s = 0.f;
@@ -252,21 +258,30 @@ int gn_fused_iters(int L, bool bwd) {
   return 0;
 }
 
+// Longest item (rows) the single-pass GroupNorm kernels take (forward / backward); 0 when they are switched off.  A bf16
+// x (STYLER_IO_Z_BF16) is accepted up to this length only.
+extern "C" int styler_groupnorm_fused_rows(int bwd) {
+  if (!gn_fused_iters(1, bwd != 0)) return 0;
+  return bwd ? 64 * GNF_IT : 128 * GNF_IT;
+}
+
 extern "C" int styler_groupnorm_relu(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y,
                                      int64_t ldy, float* stats, double* workspace, int ws_zeroed, int B, int L, int C,
                                      int io_flags, void* stream) {
   if (!x || !y || !gamma || !beta || !workspace || B <= 0 || L <= 0 || C <= 0 || (C & 63)) return STYLER_EINVAL;
   if ((ldx & 3) || (ldy & 3)) return STYLER_EALIGN;
   hipStream_t st = (hipStream_t)stream;
+  const bool x16 = (io_flags & STYLER_IO_Z_BF16) != 0;
   if (const int it = gn_fused_iters(L, false)) {
     const int y16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
-    if (it == GNF_IT)
-      hipLaunchKernelGGL(gn_fused_kernel<GNF_IT>, dim3(C / 64, B), dim3(1024), 0, st, x, ldx, gamma, beta, y, ldy, stats, L, C, y16);
-    else
-      hipLaunchKernelGGL(gn_fused_kernel<2 * GNF_IT>, dim3(C / 64, B), dim3(1024), 0, st, x, ldx, gamma, beta, y, ldy, stats, L, C,
-                         y16);
+#define GNF_LAUNCH(IT_, X_) hipLaunchKernelGGL((gn_fused_kernel<IT_, X_>), dim3(C / 64, B), dim3(1024), 0, st, x, ldx, gamma, beta, y, \
+                                               ldy, stats, L, C, y16)
+    if (it == GNF_IT) { if (x16) GNF_LAUNCH(GNF_IT, true); else GNF_LAUNCH(GNF_IT, false); }
+    else { if (x16) GNF_LAUNCH(2 * GNF_IT, true); else GNF_LAUNCH(2 * GNF_IT, false); }
+#undef GNF_LAUNCH
     return launch_status();
   }
+  if (x16) return STYLER_EINVAL;                     // bf16 x: single-pass variant only (styler_groupnorm_fused_rows)
   if (!ws_zeroed) {
     hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * B * (C / 16), st);
     if (e != hipSuccess) return (int)e;
@@ -308,8 +323,8 @@ extern "C" int styler_bn_fold(const float* gamma, const float* beta, const float
 #define BN_STAT_RPB 128                            // rows per block of the column statistics
 #define BN_CT 32                                   // float4 columns per block of the column statistics
 
-template <bool BWD, bool DY16 = false>
-__global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restrict__ x, const float* __restrict__ y,
+template <bool BWD, bool DY16 = false, bool X16 = false>
+__global__ __launch_bounds__(256) void bn_colstats_kernel(const void* __restrict__ x, const float* __restrict__ y,
                                                           const void* __restrict__ dy, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, double* __restrict__ ws,
                                                           int64_t rows, int C, int act, const float* __restrict__ gamma,
@@ -354,13 +369,14 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restric
       // row-at-a-time loop is one memory round trip per row -- 16 in a row at 32 rows per block
       constexpr int U = BWD ? 4 : 8;
       for (int64_t r = r0 + rl; r < r1; r += (int64_t)U * lanes) {
-        float4 v4[U], o4[U];
+        float4 o4[U];
+        typename Raw4<X16>::T v4[U];
         typename Raw4<DY16>::T g4[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           int64_t ru = r + (int64_t)u * lanes;
           ru = ru < r1 ? ru : r1 - 1;                      // clamped, discarded below: no lane branches around loads
-          v4[u] = *reinterpret_cast<const float4*>(x + ru * C + q * 4);
+          v4[u] = raw4_load<X16>(x, ru * C + q * 4);
           if (BWD) {
             g4[u] = raw4_load<DY16>(dy, ru * C + q * 4);
             if (has_y) o4[u] = *reinterpret_cast<const float4*>(y + ru * C + q * 4);
@@ -370,7 +386,7 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restric
         for (int u = 0; u < U; ++u) {
           const int64_t ru = r + (int64_t)u * lanes;
           const bool okr = ru < r1;                        // a select, not a branch: a branch lets the loads sink to it
-          float4 v = v4[u];
+          float4 v = raw4_f32(v4[u]);
           if (!okr) v = make_float4(BWD ? m.x : 0.f, BWD ? m.y : 0.f, BWD ? m.z : 0.f, BWD ? m.w : 0.f);
           if (BWD) {
             float4 g = okr ? raw4_f32(g4[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -418,9 +434,9 @@ __global__ void bn_fold_copies_kernel(double* __restrict__ ws, int C2, int segs)
   ws[i] = t;
 }
 
-int styler_bn_colstats(bool bwd, const float* x, const float* y, const void* dy, const float* mean, const float* rstd,
+int styler_bn_colstats(bool bwd, const void* x, const float* y, const void* dy, const float* mean, const float* rstd,
                        double* ws, int ws_zeroed, int64_t rows, int C, int act, const float* gamma, const float* beta,
-                       float drop_p, uint64_t drop_seed, int segs, int dy16, hipStream_t st) {
+                       float drop_p, uint64_t drop_seed, int segs, int dy16, int x16, hipStream_t st) {
   if (!ws_zeroed) {
     hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * STYLER_BN_COPIES * segs, st);
     if (e != hipSuccess) return (int)e;
@@ -434,9 +450,12 @@ int styler_bn_colstats(bool bwd, const float* x, const float* y, const void* dy,
   const dim3 grid((unsigned)(bps * segs * ((nq + nqt - 1) / nqt)));
 #define BN_STATS_LAUNCH(...) hipLaunchKernelGGL((bn_colstats_kernel<__VA_ARGS__>), grid, dim3(256), 0, st, x, y, dy, mean, rstd, ws, \
                                                  rows, C, act, gamma, beta, drop_p, drop_seed, g_styler_drop_epoch, rpb, bps, rps, dbg)
-  if (bwd && dy16) BN_STATS_LAUNCH(true, true);
-  else if (bwd) BN_STATS_LAUNCH(true, false);
-  else BN_STATS_LAUNCH(false, false);
+  if (bwd && dy16 && x16) BN_STATS_LAUNCH(true, true, true);
+  else if (bwd && dy16) BN_STATS_LAUNCH(true, true, false);
+  else if (bwd && x16) BN_STATS_LAUNCH(true, false, true);
+  else if (bwd) BN_STATS_LAUNCH(true, false, false);
+  else if (x16) BN_STATS_LAUNCH(false, false, true);
+  else BN_STATS_LAUNCH(false, false, false);
 #undef BN_STATS_LAUNCH
   hipLaunchKernelGGL(bn_fold_copies_kernel, dim3((2 * C * segs + 255) / 256), dim3(256), 0, st, ws, 2 * C, segs);
   return 0;
@@ -465,7 +484,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, float* save_me
 // Normalise + activation + dropout.  Same geometry as the column statistics: block = (segment, chunk of rpb rows), thread =
 // (row-lane, float4 column): the per-channel constants are fetched once per thread, the rows in batches of four, and no
 // index is ever divided.
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+template <bool X16>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, void* __restrict__ yv,
@@ -494,18 +514,18 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const float4 a = make_float4(r.x * g.x, r.y * g.y, r.z * g.z, r.w * g.w);
     constexpr int U = 4;
     for (int64_t row = r0 + rl; row < r1; row += (int64_t)U * lanes) {
-      float4 v4[U];
+      typename Raw4<X16>::T v4[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         int64_t ru = row + (int64_t)u * lanes;
         ru = ru < r1 ? ru : r1 - 1;
-        v4[u] = *reinterpret_cast<const float4*>(x + ru * C + q * 4);
+        v4[u] = raw4_load<X16>(x, ru * C + q * 4);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t ru = row + (int64_t)u * lanes;
         if (ru >= r1) break;
-        const float4 v = v4[u];
+        const float4 v = raw4_f32(v4[u]);
         float4 o;
         o.x = apply_act((v.x - m.x) * a.x + b.x, act);
         o.y = apply_act((v.y - m.y) * a.y + b.y, act);
@@ -533,14 +553,19 @@ extern "C" int styler_batchnorm_train(const float* x, const float* gamma, const 
       drop_p < 0.f || drop_p >= 1.f || segs < 1 || rows % segs)
     return STYLER_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  const int x16 = (io_flags & STYLER_IO_Z_BF16) ? 1 : 0;
   const int rc = styler_bn_colstats(false, x, nullptr, nullptr, nullptr, nullptr, workspace, ws_zeroed, rows, C, act, nullptr,
-                                    nullptr, 0.f, 0, segs, 0, st);
+                                    nullptr, 0.f, 0, segs, 0, x16, st);
   if (rc) return rc;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, save_mean, save_rstd,
                      running_mean, running_var, rows, C, segs);
   const int64_t rps = rows / segs;
   const int bps = (int)((rps + BN_RPB - 1) / BN_RPB);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)(bps * segs)), dim3(256), 0, st, x, gamma, beta, save_mean, save_rstd,
-                     y, C, act, drop_p, drop_seed, g_styler_drop_epoch, BN_RPB, bps, rps, (io_flags & STYLER_IO_Y_BF16) ? 1 : 0);
+  if (x16)
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3((unsigned)(bps * segs)), dim3(256), 0, st, x, gamma, beta, save_mean, save_rstd,
+                       y, C, act, drop_p, drop_seed, g_styler_drop_epoch, BN_RPB, bps, rps, (io_flags & STYLER_IO_Y_BF16) ? 1 : 0);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3((unsigned)(bps * segs)), dim3(256), 0, st, x, gamma, beta, save_mean, save_rstd,
+                       y, C, act, drop_p, drop_seed, g_styler_drop_epoch, BN_RPB, bps, rps, (io_flags & STYLER_IO_Y_BF16) ? 1 : 0);
   return launch_status();
 }

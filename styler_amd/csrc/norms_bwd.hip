@@ -456,8 +456,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 // loaded once and stay in registers between the group sums and dx -- 3 tensor passes over HBM instead of 5.
 #define GNB_IT 8
 int gn_fused_iters(int L, bool bwd);                // norms.hip
-template <bool DY16, int IT>
-__global__ __launch_bounds__(1024) void gn_bwd_fused_kernel(const float* __restrict__ x, int64_t ldx,
+template <bool DY16, int IT, bool X16 = false>
+__global__ __launch_bounds__(1024) void gn_bwd_fused_kernel(const void* __restrict__ x, int64_t ldx,
                                                             const void* __restrict__ dy, int64_t lddy,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ stats, void* __restrict__ dx,
@@ -468,22 +468,25 @@ __global__ __launch_bounds__(1024) void gn_bwd_fused_kernel(const float* __restr
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4, wave = threadIdx.x >> 6, grp = cq >> 2, lane = threadIdx.x & 63;
   const int64_t gi = ((int64_t)b * (C / 16) + c0 / 16 + grp) * 2;
-  const float* xp = x + (int64_t)b * L * ldx + c0 + cq * 4;
+  const int64_t xbase = (int64_t)b * L * ldx + c0 + cq * 4;
   const int64_t gbase = (int64_t)b * L * lddy + c0 + cq * 4;
   const float mean = stats[gi], rstd = stats[gi + 1];
   float4 ga = *reinterpret_cast<const float4*>(gamma + c0 + cq * 4);
   float4 be = *reinterpret_cast<const float4*>(beta + c0 + cq * 4);
   float4 v[IT];
+  typename Raw4<X16>::T xr[IT];
   typename Raw4<DY16>::T g4[IT];
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
     const int t = rl + 64 * i < L ? rl + 64 * i : L - 1;
-    v[i] = *reinterpret_cast<const float4*>(xp + (int64_t)t * ldx);
+    xr[i] = raw4_load<X16>(x, xbase + (int64_t)t * ldx);
     g4[i] = raw4_load<DY16>(dy, gbase + (int64_t)t * lddy);
   }
   pin_loaded(ga); pin_loaded(be);                    // (the compiler sinks these two loads behind the waits otherwise)
 #pragma unroll
-  for (int i = 0; i < IT; ++i) { pin_loaded(v[i]); pin_loaded(g4[i]); }
+  for (int i = 0; i < IT; ++i) { pin_loaded(xr[i]); pin_loaded(g4[i]); }
+#pragma unroll
+  for (int i = 0; i < IT; ++i) v[i] = raw4_f32(xr[i]);
   float s1 = 0.f, s2 = 0.f;
   float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
   // v becomes xh, g4 stays raw: dxh = relu-masked dy * gamma is formed here and again (two multiplies) for dx
@@ -553,13 +556,18 @@ extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void
   hipStream_t st = (hipStream_t)stream;
   const int dy16 = (io_flags & STYLER_IO_X_BF16) ? 1 : 0;
   const int dx16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
+  const bool x16 = (io_flags & STYLER_IO_Z_BF16) != 0;
   if (gn_fused_iters(L, true)) {
-#define GNB_LAUNCH(D_, I_) hipLaunchKernelGGL((gn_bwd_fused_kernel<D_, I_>), dim3(C / 64, B), dim3(1024), 0, st, x, ldx, dy, lddy, \
-                                              gamma, beta, stats, dx, lddx, dgamma, dbeta, L, C, dx16)
-    if (dy16) GNB_LAUNCH(true, GNB_IT); else GNB_LAUNCH(false, GNB_IT);
+#define GNB_LAUNCH(D_, I_, X_) hipLaunchKernelGGL((gn_bwd_fused_kernel<D_, I_, X_>), dim3(C / 64, B), dim3(1024), 0, st, x, ldx, dy, \
+                                                  lddy, gamma, beta, stats, dx, lddx, dgamma, dbeta, L, C, dx16)
+    if (dy16 && x16) GNB_LAUNCH(true, GNB_IT, true);
+    else if (dy16) GNB_LAUNCH(true, GNB_IT, false);
+    else if (x16) GNB_LAUNCH(false, GNB_IT, true);
+    else GNB_LAUNCH(false, GNB_IT, false);
 #undef GNB_LAUNCH
     return launch_status();
   }
+  if (x16) return STYLER_EINVAL;                     // bf16 x: single-pass variant only (styler_groupnorm_fused_rows)
   if (!ws_zeroed) {
     hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * B * (C / 16), st);
     if (e != hipSuccess) return (int)e;
@@ -584,16 +592,16 @@ extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void
 // ---------------------------------------------------------------------------------------------------
 // BatchNorm1d (train) + act backward over rows = B*L (pads included), channels-last contiguous [rows, C].
 //   dz = dy * act'(y); dgamma = sum dz*xh; dbeta = sum dz; dx = g*rstd*(dz - dbeta/N - xh*dgamma/N)
-int styler_bn_colstats(bool bwd, const float* x, const float* y, const void* dy, const float* mean, const float* rstd,
+int styler_bn_colstats(bool bwd, const void* x, const float* y, const void* dy, const float* mean, const float* rstd,
                        double* ws, int ws_zeroed, int64_t rows, int C, int act, const float* gamma, const float* beta,
-                       float drop_p, uint64_t drop_seed, int segs, int dy16, hipStream_t st);   // norms.hip
+                       float drop_p, uint64_t drop_seed, int segs, int dy16, int x16, hipStream_t st);   // norms.hip
 #define STYLER_BN_COPIES 16                          // norms.hip
 
 // Same geometry as the forward's column statistics / apply kernels (norms.hip): block = (segment, chunk of rpb rows),
 // thread = (row-lane, float4 column); per-channel constants (incl. the two fp64 column sums) once per thread, rows in
 // batches of four, no index divisions.
-template <bool DY16>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+template <bool DY16, bool X16 = false>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restrict__ x, const float* __restrict__ y,
                                                            const void* __restrict__ dy, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const double* __restrict__ ws, void* __restrict__ dxv,
@@ -636,13 +644,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     for (int k = 0; k < 4; ++k) { sb[k] = (float)(wseg[q * 4 + k] * inv_n); sg[k] = (float)(wseg[C + q * 4 + k] * inv_n); }
     constexpr int U = 4;
     for (int64_t row = r0 + rl; row < r1; row += (int64_t)U * lanes) {
-      float4 v4[U], o4[U];
+      float4 o4[U];
+      typename Raw4<X16>::T v4[U];
       typename Raw4<DY16>::T g4[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         int64_t ru = row + (int64_t)u * lanes;
         ru = ru < r1 ? ru : r1 - 1;
-        v4[u] = *reinterpret_cast<const float4*>(x + ru * C + q * 4);
+        v4[u] = raw4_load<X16>(x, ru * C + q * 4);
         g4[u] = raw4_load<DY16>(dy, ru * C + q * 4);
         if (has_y) o4[u] = *reinterpret_cast<const float4*>(y + ru * C + q * 4);
       }
@@ -650,7 +659,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       for (int u = 0; u < U; ++u) {
         const int64_t ru = row + (int64_t)u * lanes;
         if (ru >= r1) break;
-        const float xv[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+        const float4 xf = raw4_f32(v4[u]);
+        const float xv[4] = {xf.x, xf.y, xf.z, xf.w};
         const float4 gf = raw4_f32(g4[u]);
         const float gv[4] = {gf.x, gf.y, gf.z, gf.w};
         const float4 oo = has_y ? o4[u] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -679,8 +689,9 @@ extern "C" int styler_batchnorm_bwd(const float* x, const float* y, const void* 
     return STYLER_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int dy16 = (io_flags & STYLER_IO_X_BF16) ? 1 : 0;
+  const int x16 = (io_flags & STYLER_IO_Z_BF16) ? 1 : 0;
   const int rc = styler_bn_colstats(true, x, y, dy, save_mean, save_rstd, workspace, ws_zeroed, rows, C, act, gamma, beta,
-                                    drop_p, drop_seed, segs, dy16, st);
+                                    drop_p, drop_seed, segs, dy16, x16, st);
   if (rc) return rc;
   constexpr int RPB = 32;
   const int64_t rps = rows / segs;
@@ -688,11 +699,13 @@ extern "C" int styler_batchnorm_bwd(const float* x, const float* y, const void* 
   int64_t blocks = (int64_t)bps * segs;
   if (blocks * 256 < (int64_t)C * segs) blocks = ((int64_t)C * segs + 255) / 256;
   const int dx16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
-  if (dy16)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd,
-                       workspace, dx, dgamma, dbeta, C, act, beta, drop_p, drop_seed, g_styler_drop_epoch, segs, RPB, bps, rps, dx16);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd,
-                       workspace, dx, dgamma, dbeta, C, act, beta, drop_p, drop_seed, g_styler_drop_epoch, segs, RPB, bps, rps, dx16);
+#define BNB_LAUNCH(D_, X_)                                                                                                      \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<D_, X_>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd, \
+                     workspace, dx, dgamma, dbeta, C, act, beta, drop_p, drop_seed, g_styler_drop_epoch, segs, RPB, bps, rps, dx16)
+  if (dy16 && x16) BNB_LAUNCH(true, true);
+  else if (dy16) BNB_LAUNCH(true, false);
+  else if (x16) BNB_LAUNCH(false, true);
+  else BNB_LAUNCH(false, false);
+#undef BNB_LAUNCH
   return launch_status();
 }

@@ -144,7 +144,11 @@ class AudioEncoder(_HipModule):
                         x = AG.ConvNormFn.apply(src, conv.weight, conv.bias, self._derived, f"c{s}_{i}", 5, gn, "gn",
                                                 ops.ACT_RELU, 0.0, 1, i < 2)
                         continue
-                    y = self._gemm(f"c{s}_{i}", src, conv, kw=5)
+                    # eval: the conv output is read once, by GroupNorm -- as bf16 in throughput mode (rt.bf16_z) when the item
+                    # fits the single-pass kernel (styler_groupnorm_fused_rows)
+                    z16 = (rt.bf16_z and rt.bf16_acts and rt.prec == ops.PREC_BF16 and W[s] % 8 == 0
+                           and 0 < T <= ops.lib.styler_groupnorm_fused_rows(0))
+                    y = self._gemm(f"c{s}_{i}", src, conv, kw=5, out_bf16=z16)
                 if grad:
                     # after a one-hot convolution (its backward takes an fp32 gradient): bf16 output only
                     b16 = rt.bf16_acts and rt.prec == ops.PREC_BF16 and W[s] % 8 == 0

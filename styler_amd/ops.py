@@ -511,15 +511,24 @@ def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, 
     return dot_out if dot_w is not None else out
 
 
+IO_Z_BF16 = 16       # STYLER_IO_Z_BF16: the tensor a norm kernel normalises (a convolution's output) is stored as bf16
+
+
+def groupnorm_z_bf16_ok(L):
+    """A bf16 convolution output can go through GroupNorm forward AND backward (single-pass kernels only)."""
+    return 0 < L <= lib.styler_groupnorm_fused_rows(1)
+
+
 def groupnorm_relu(x, gamma, beta, out=None, stats=None):
-    """`stats` (optional, [B, C/16, 2] fp32) receives mean / rstd of every group for the backward."""
+    """`stats` (optional, [B, C/16, 2] fp32) receives mean / rstd of every group for the backward.  x may be bf16
+    (groupnorm_z_bf16_ok) -- then `out` must be given."""
     B, L, C = x.shape
     if out is None:
         out = x
     ws, z = _norm_ws(B * (C // 16) * 2, x.device)
+    io = (2 if out.dtype == torch.bfloat16 else 0) | (IO_Z_BF16 if x.dtype == torch.bfloat16 else 0)
     _chk(lib.styler_groupnorm_relu(x.data_ptr(), _ld(x), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
-                                   _ld(out), _ptr(stats), ws.data_ptr(), z, B, L, C, 2 if out.dtype == torch.bfloat16 else 0,
-                                   _stream()), "styler_groupnorm_relu")
+                                   _ld(out), _ptr(stats), ws.data_ptr(), z, B, L, C, io, _stream()), "styler_groupnorm_relu")
     return out
 
 
@@ -543,14 +552,14 @@ def batchnorm_train(x, gamma, beta, running_mean, running_var, act, drop_p=0.0, 
     assert x.is_contiguous()
     C = x.shape[-1]
     rows = x.numel() // C
-    y = torch.empty_like(x, dtype=torch.bfloat16) if out_bf16 else torch.empty_like(x)
+    y = torch.empty_like(x, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     mean = torch.empty(segs, C, device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
     ws, z = _norm_ws(2 * C * BN_WS_COPIES * segs, x.device)
     _chk(lib.styler_batchnorm_train(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
                                     mean.data_ptr(), rstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
                                     ws.data_ptr(), z, rows, C, act, float(drop_p), int(drop_seed), int(segs),
-                                    2 if out_bf16 else 0, _stream()),
+                                    (2 if out_bf16 else 0) | (IO_Z_BF16 if x.dtype == torch.bfloat16 else 0), _stream()),
          "styler_batchnorm_train")
     return y, mean, rstd
 
@@ -931,7 +940,8 @@ def groupnorm_relu_bwd(x, dy, gamma, beta, stats, dgamma, dbeta, dx_bf16=False):
     _chk(lib.styler_groupnorm_relu_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), gamma.data_ptr(), beta.data_ptr(),
                                        stats.data_ptr(), dx.data_ptr(), C, dgamma.data_ptr(), dbeta.data_ptr(),
                                        ws.data_ptr(), z, B, L, C,
-                                       (2 if dx_bf16 else 0) | (1 if dy.dtype == torch.bfloat16 else 0), _stream()),
+                                       (2 if dx_bf16 else 0) | (1 if dy.dtype == torch.bfloat16 else 0) |
+                                       (IO_Z_BF16 if x.dtype == torch.bfloat16 else 0), _stream()),
          "styler_groupnorm_relu_bwd")
     return dx
 
@@ -942,12 +952,13 @@ def batchnorm_bwd(x, y, dy, gamma, mean, rstd, dgamma, dbeta, act, beta=None, dr
     C = x.shape[-1]
     rows = x.numel() // C
     dy = dy.contiguous()
-    dx = torch.empty_like(x, dtype=torch.bfloat16) if dx_bf16 else torch.empty_like(x)
+    dx = torch.empty_like(x, dtype=torch.bfloat16 if dx_bf16 else torch.float32)
     ws, z = _norm_ws(2 * C * BN_WS_COPIES * segs, x.device)
     _chk(lib.styler_batchnorm_bwd(x.data_ptr(), _ptr(y), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                   rstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), z,
                                   rows, C, act, _ptr(beta), float(drop_p), int(drop_seed), int(segs),
-                                  (2 if dx_bf16 else 0) | (1 if dy.dtype == torch.bfloat16 else 0), _stream()),
+                                  (2 if dx_bf16 else 0) | (1 if dy.dtype == torch.bfloat16 else 0) |
+                                  (IO_Z_BF16 if x.dtype == torch.bfloat16 else 0), _stream()),
          "styler_batchnorm_bwd")
     return dx
 

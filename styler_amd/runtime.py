@@ -59,6 +59,11 @@ class _Runtime:
     # against the 6e-2 bound, worst parameter gradient unchanged at 6.0e-2 against 1e-1; tests/test_11_oracle_c2c3.py).  It
     # halves the bytes of the LayerNorm forward / backward kernels and of every GEMM operand read from the stream.
     bf16_stream = os.environ.get("STYLER_BF16_STREAM", "1") != "0"
+    # throughput mode: the convolution OUTPUTS that GroupNorm / BatchNorm normalise (AudioEncoder, PostNet) are stored as bf16
+    # as well -- the conv epilogue writes 2 bytes, the norm forward reads 2 (BatchNorm: twice), the norm backward reads 2
+    # again.  Not bit-neutral: the statistics and the normalised values come from the rounded tensor (forward and backward
+    # agree on it); STYLER_BF16_Z=0 keeps them fp32.  GroupNorm takes it in its single-pass kernels only (items <= 512 rows).
+    bf16_z = os.environ.get("STYLER_BF16_Z", "1") != "0"
     # EXPERIMENT (numerics only, not a fast path): round the residual stream of the FFT blocks -- LayerNorm outputs, the saved
     # pre-norm sums, the packed decoder input, the LengthRegulator output, and the gradients that flow back along them -- to
     # bf16 with torch casts, to measure what a model-wide bf16 activation format would do to the parity bounds BEFORE

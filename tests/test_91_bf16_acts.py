@@ -197,3 +197,48 @@ def test_bf16_stream_kernels_equal_fp32_kernels_on_the_same_values(dev):
         ops.wgrad(dz, xx.float(), dw_b, n, cin, kw=kw, db=b_b, prec=ops.PREC_BF16)
         assert torch.equal(dw_a, dw_b), kw
         assert float((b_a - b_b).abs().max()) <= 1e-4 * float(b_b.abs().max())
+
+
+def test_bf16_z_norm_kernels_equal_fp32_kernels_on_the_same_values(dev):
+    """Round 3, rt.bf16_z: GroupNorm / BatchNorm forward and backward reading the convolution output as bf16
+    (STYLER_IO_Z_BF16) compute exactly what they compute on an fp32 tensor holding the same (bf16-representable) values --
+    same statistics, same outputs, same gradients.  GroupNorm: both single-pass item lengths (<= 512 and <= 1024 rows
+    forward); BatchNorm: two segments, tanh + dropout, and the plain last layer."""
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(47)
+    bf = torch.bfloat16
+    assert ops.groupnorm_z_bf16_ok(512) and not ops.groupnorm_z_bf16_ok(513)
+    for B, L, C in ((3, 441, 320), (2, 77, 256), (2, 900, 64)):
+        z16 = (2.0 * torch.randn(B, L, C, generator=g) + 0.5).to(dev).to(bf)
+        ga, be = (1 + 0.1 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+        st_a = torch.empty(B, C // 16, 2, device=dev)
+        st_b = torch.empty_like(st_a)
+        y_a = ops.groupnorm_relu(z16, ga, be, out=torch.empty(B, L, C, device=dev, dtype=bf), stats=st_a)
+        y_b = ops.groupnorm_relu(z16.float(), ga, be, out=torch.empty(B, L, C, device=dev, dtype=bf), stats=st_b)
+        assert torch.equal(st_a, st_b) and torch.equal(y_a, y_b), (B, L, C)
+        if not ops.groupnorm_z_bf16_ok(L):
+            continue
+        dy = torch.randn(B, L, C, generator=g).to(dev).to(bf)
+        dg_a, db_a, dg_b, db_b = (torch.zeros(C, device=dev) for _ in range(4))
+        dx_a = ops.groupnorm_relu_bwd(z16, dy, ga, be, st_a, dg_a, db_a, dx_bf16=True)
+        dx_b = ops.groupnorm_relu_bwd(z16.float(), dy, ga, be, st_b, dg_b, db_b, dx_bf16=True)
+        assert torch.equal(dx_a, dx_b), (B, L, C)
+        # (the parameter gradients leave the blocks as fp32 atomics: the order, hence the last bits, varies between launches)
+        for a, b in ((dg_a, dg_b), (db_a, db_b)):
+            assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()), (B, L, C)
+    for rows_b, L, C, act, p, segs in ((4, 150, 512, ops.ACT_TANH, 0.5, 2), (2, 333, 80, ops.ACT_NONE, 0.0, 1)):
+        z16 = (1.5 * torch.randn(rows_b, L, C, generator=g) - 0.3).to(dev).to(bf)
+        ga, be = (1 + 0.1 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+        y_a, m_a, r_a = ops.batchnorm_train(z16, ga, be, None, None, act, drop_p=p, drop_seed=11, segs=segs, out_bf16=True)
+        y_b, m_b, r_b = ops.batchnorm_train(z16.float(), ga, be, None, None, act, drop_p=p, drop_seed=11, segs=segs, out_bf16=True)
+        # column sums are fp64 atomics: mean / rstd agree to fp32 rounding of sums whose order varies
+        assert torch.allclose(m_a, m_b, rtol=0, atol=1e-6) and torch.allclose(r_a, r_b, rtol=1e-6, atol=0), (C, act)
+        assert float((y_a.float() - y_b.float()).abs().max()) <= 2 ** -7 * float(y_b.float().abs().max()), (C, act)
+        dy = torch.randn(rows_b, L, C, generator=g).to(dev).to(bf)
+        dg_a, db_a, dg_b, db_b = (torch.zeros(C, device=dev) for _ in range(4))
+        dx_a = ops.batchnorm_bwd(z16, None, dy, ga, m_a, r_a, dg_a, db_a, act, beta=be, drop_p=p, drop_seed=11, segs=segs, dx_bf16=True)
+        dx_b = ops.batchnorm_bwd(z16.float(), None, dy, ga, m_a, r_a, dg_b, db_b, act, beta=be, drop_p=p, drop_seed=11, segs=segs,
+                                 dx_bf16=True)
+        assert float((dx_a.float() - dx_b.float()).abs().max()) <= 2 ** -7 * float(dx_b.float().abs().max()), (C, act)
+        for a, b in ((dg_a, dg_b), (db_a, db_b)):
+            assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1e-3), (C, act)
