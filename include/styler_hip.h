@@ -193,8 +193,14 @@ int styler_attention_fwd(const float* qkv, float* out, float* lse, int B, int L,
  * forward may leave zeros in `out` / `lse` there, and the backward treats their dout as zero. */
 int styler_attention_fwd_bf16(const float* qkv, float* out, float* lse, int B, int L,
                               const int64_t* len, const int32_t* cu, void* stream);
+/* The same forward with io_flags.  STYLER_IO_X_BF16: qkv is STORED as bf16 ([rows][768] elements; pass the bf16 pointer) --
+ * throughput mode writes it that way from the QKV GEMM's epilogue, its only readers are these kernels.  The 1/sqrt(d_k)
+ * scale is then applied to the raw scores inside the exponent (one fma) instead of to q before its rounding: every
+ * operand is still rounded once (SubLayers.py:44-52, Modules.py:14-25). */
+int styler_attention_fwd_bf16_io(const void* qkv, float* out, float* lse, int B, int L,
+                                 const int64_t* len, const int32_t* cu, int io_flags, void* stream);
 /* io_flags & STYLER_IO_Y_BF16: dqkv is written as bf16 [B,L,768] (what its consumers -- the QKV dX GEMM and the three
- * weight gradients -- round it to anyway). */
+ * weight gradients -- round it to anyway).  io_flags & STYLER_IO_X_BF16: qkv is stored as bf16 (as above). */
 int styler_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse,
                               void* dqkv, float* delta_ws, int B, int L, const int64_t* len,
                               const int32_t* cu, int io_flags, void* stream);

@@ -26,6 +26,7 @@ _SIGS = {
     "styler_repack_conv_weight": [P, P, I, I, I, I, I, P],
     "styler_attention_fwd": [P, P, P, I, I, P, P, P],
     "styler_attention_fwd_bf16": [P, P, P, I, I, P, P, P],
+    "styler_attention_fwd_bf16_io": [P, P, P, I, I, P, P, I, P],
     "styler_attention_bwd_bf16": [P, P, P, P, P, P, I, I, P, P, I, P],
     "styler_add_layernorm": [P, I64, P, I64, P, P, P, I64, P, P, P, I, I, I, P, F, ctypes.c_uint64, F, ctypes.c_uint64, P, I64, P, I64, I, P],
     "styler_groupnorm_relu": [P, I64, P, P, P, I64, P, P, I, I, I, I, I, P],

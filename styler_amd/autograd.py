@@ -202,7 +202,7 @@ class AttnSublayerFn(Function):
     @staticmethod
     def forward(ctx, x, anchor, mha, lens, plan, drop_p, want16=False):
         w, b, prec = mha._qkv()
-        qkv = ops.conv_gemm(x, w, b, n=768, prec=prec, plan=plan)
+        qkv = ops.conv_gemm(x, w, b, n=768, prec=prec, plan=plan, out_bf16=prec == ops.PREC_BF16 and rt.bf16_qkv)
         B, L = (plan.B, plan.T) if plan is not None else x.shape[:2]
         lse = torch.empty(B, 4, L, device=x.device, dtype=torch.float32)
         att = ops.attention_fwd(qkv, lens, lse=lse, plan=plan)

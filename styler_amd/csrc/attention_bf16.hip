@@ -54,6 +54,17 @@ __device__ __forceinline__ bf16x8 load8_bf16(const float* p, float scale) {
   return *reinterpret_cast<bf16x8*>(&v);
 }
 
+// Q16 kernels (the fused q | k | v tensor stored as bf16, STYLER_IO_X_BF16): 8 consecutive bf16 as they are.  The
+// 1 / sqrt(d_k) * log2(e) scale that the fp32-input kernels multiply into q (or k) BEFORE the rounding to bf16 cannot be
+// applied to a stored bf16 value without a second rounding, so these kernels multiply the raw scores instead -- inside the
+// exponent's argument, exp2(fma(s, c, -m c)): a v_fma where the other form has a v_sub, no extra instruction, and every
+// operand is still rounded exactly once.
+__device__ __forceinline__ bf16x8 load8_raw16(const void* base, int64_t idx) {
+  const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + idx);
+  return *reinterpret_cast<const bf16x8*>(&v);
+}
+#define ATTN_SCALE_LOG2 (0.125f * 1.44269504088896f)
+
 // accumulator registers 8*s2 .. 8*s2+7 -> bf16x8 (the B operand of MFMA step s2)
 __device__ __forceinline__ bf16x8 pack_acc(const f32x16& a, int s2) {
   uint4 v = make_uint4(cvtpk(a[s2 * 8 + 0], a[s2 * 8 + 1]), cvtpk(a[s2 * 8 + 2], a[s2 * 8 + 3]),
@@ -69,6 +80,27 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const float* base, i
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)rec, 0x00020000);
 }
 
+// the same for a bf16 tensor (ld in elements)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc16(const void* base, int64_t idx, int64_t ld, int nrows) {
+  int64_t rec = ((int64_t)(nrows - 1) * ld + AD) * 2;
+  rec = rec > 0x7fffffff ? 0x7fffffff : rec;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(reinterpret_cast<const uint16_t*>(base) + idx), 0, (int)rec, 0x00020000);
+}
+// 64 rows x 64 bf16 starting at row0: thread tid fetches rows (tid >> 3) + 32 p, columns (tid & 7) * 8 .. + 7 (16 bytes)
+__device__ __forceinline__ void load_rows16(uint4 (&v)[2], __amdgpu_buffer_rsrc_t rs, int ld, int row0, int tid) {
+  const uint32_t off = (uint32_t)(((row0 + (tid >> 3)) * ld + (tid & 7) * 8) * 2);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const i32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off + (uint32_t)(p * 32 * ld * 2), 0, 0);
+    v[p] = *reinterpret_cast<const uint4*>(&t);
+  }
+}
+// ... -> the same bf16 [64][ALD] tile, no conversion
+__device__ __forceinline__ void store_rows16(uint32_t* dst, const uint4 (&v)[2], int tid) {
+  uint32_t* d = dst + (tid >> 3) * ALD + (tid & 7) * 4;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) *reinterpret_cast<uint4*>(&d[p * 32 * ALD]) = v[p];
+}
 // 64 rows x 64 floats starting at row0: thread tid fetches rows (tid >> 4) + 16 p, columns (tid & 15) * 4 .. + 3
 __device__ __forceinline__ void load_rows(float4 (&v)[4], __amdgpu_buffer_rsrc_t rs, int ld, int row0, int tid) {
   const uint32_t off = (uint32_t)(((row0 + (tid >> 4)) * ld + (tid & 15) * 4) * 4);
@@ -85,6 +117,18 @@ __device__ __forceinline__ void store_rows(uint32_t* dst, const float4 (&v)[4], 
   for (int p = 0; p < 4; ++p)
     *reinterpret_cast<uint2*>(&d[p * 16 * ALD]) = make_uint2(cvtpk(v[p].x, v[p].y), cvtpk(v[p].z, v[p].w));
 }
+// registers of one staged tile in either storage format
+template <bool Q16> struct TileRegs { float4 v[4]; };
+template <> struct TileRegs<true> { uint4 v[2]; };
+template <bool Q16>
+__device__ __forceinline__ void tile_load(TileRegs<Q16>& r, __amdgpu_buffer_rsrc_t rs, int ld, int row0, int tid) {
+  if constexpr (Q16) load_rows16(r.v, rs, ld, row0, tid); else load_rows(r.v, rs, ld, row0, tid);
+}
+template <bool Q16>
+__device__ __forceinline__ void tile_store(uint32_t* dst, const TileRegs<Q16>& r, int tid) {
+  if constexpr (Q16) store_rows16(dst, r.v, tid); else store_rows(dst, r.v, tid);
+}
+
 
 // A operand of a product over the ROW axis of a row-major tile: feature d = dt*32 + (lane & 31), the two 4-row runs
 // {16*s2 + 4*lh + 0..3} and {.. + 8} of 32-row block `blk`.  tq = lane & 15, tc = (lane >> 4) & 1 (the 16-lane group's
@@ -160,6 +204,7 @@ __device__ __forceinline__ bool attn_block(int L, int B, int& bx, int& head, int
 static inline dim3 attn_grid(int L, int B) { return dim3((unsigned)((((L + 127) / 128) * 4 * B + 7) / 8 * 8)); }
 
 // ------------------------------------------------------------------------------------------------- forward
+template <bool Q16>
 __global__ __launch_bounds__(256, STYLER_ATTN_FWD_WAVES) void attention_fwd_bf16_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                  float* __restrict__ lse, int B, int L,
                                                                  const int64_t* __restrict__ len,
@@ -193,29 +238,34 @@ __global__ __launch_bounds__(256, STYLER_ATTN_FWD_WAVES) void attention_fwd_bf16
   // v_exp_f32 (no range fix-ups: p underflowing to zero is exactly what softmax wants)
   bf16x8 qf[4];
 #pragma unroll
-  for (int st = 0; st < 4; ++st)
-    qf[st] = load8_bf16(qkv + (rowbase + qc) * 768 + head * AD + st * 16 + lh * 8, 0.125f * 1.44269504088896f);
+  for (int st = 0; st < 4; ++st) {
+    if constexpr (Q16) qf[st] = load8_raw16(qkv, (rowbase + qc) * 768 + head * AD + st * 16 + lh * 8);
+    else qf[st] = load8_bf16(qkv + (rowbase + qc) * 768 + head * AD + st * 16 + lh * 8, ATTN_SCALE_LOG2);
+  }
+  constexpr float SC = Q16 ? ATTN_SCALE_LOG2 : 1.f;    // Q16: the scale lives in the exponent's fma (see load8_raw16)
 
   f32x16 o0, o1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
 
-  const __amdgpu_buffer_rsrc_t krs = rows_rsrc(qkv + rowbase * 768 + 256 + head * AD, 768, Lr);
-  const __amdgpu_buffer_rsrc_t vrs = rows_rsrc(qkv + rowbase * 768 + 512 + head * AD, 768, Lr);
+  const __amdgpu_buffer_rsrc_t krs = Q16 ? rows_rsrc16(qkv, rowbase * 768 + 256 + head * AD, 768, Lr)
+                                          : rows_rsrc(qkv + rowbase * 768 + 256 + head * AD, 768, Lr);
+  const __amdgpu_buffer_rsrc_t vrs = Q16 ? rows_rsrc16(qkv, rowbase * 768 + 512 + head * AD, 768, Lr)
+                                          : rows_rsrc(qkv + rowbase * 768 + 512 + head * AD, 768, Lr);
   const int ntiles = (klen + 63) / 64;
-  float4 rk[4], rv[4];
-  if (STYLER_ATTN_FWD_PREFETCH) { load_rows(rk, krs, 768, 0, tid); load_rows(rv, vrs, 768, 0, tid); }
+  TileRegs<Q16> rk, rv;
+  if (STYLER_ATTN_FWD_PREFETCH) { tile_load<Q16>(rk, krs, 768, 0, tid); tile_load<Q16>(rv, vrs, 768, 0, tid); }
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * 64;
     // (a register prefetch of the next tile across the MFMAs was measured in round 1: occupancy 3 -> 2 waves per SIMD
     // lost more than it hid.  The loads are issued ahead of the barrier instead: they fly while the block's other waves
     // finish the previous tile.)
-    if (!STYLER_ATTN_FWD_PREFETCH) { load_rows(rk, krs, 768, k0, tid); load_rows(rv, vrs, 768, k0, tid); }
+    if (!STYLER_ATTN_FWD_PREFETCH) { tile_load<Q16>(rk, krs, 768, k0, tid); tile_load<Q16>(rv, vrs, 768, k0, tid); }
     __syncthreads();
-    store_rows(sK, rk, tid);
-    store_rows(sV, rv, tid);
-    if (STYLER_ATTN_FWD_PREFETCH && kt + 1 < ntiles) { load_rows(rk, krs, 768, k0 + 64, tid); load_rows(rv, vrs, 768, k0 + 64, tid); }
+    tile_store<Q16>(sK, rk, tid);
+    tile_store<Q16>(sV, rv, tid);
+    if (STYLER_ATTN_FWD_PREFETCH && kt + 1 < ntiles) { tile_load<Q16>(rk, krs, 768, k0 + 64, tid); tile_load<Q16>(rv, vrs, 768, k0 + 64, tid); }
     __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -240,10 +290,16 @@ __global__ __launch_bounds__(256, STYLER_ATTN_FWD_WAVES) void attention_fwd_bf16
       for (int r = 0; r < 16; ++r) mb = fmaxf(mb, s[r]);
       mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
       const float m_new = fmaxf(m_run, mb);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      const float alpha = __builtin_amdgcn_exp2f(Q16 ? (m_run - m_new) * SC : m_run - m_new);
       float rs = 0.f;
+      if constexpr (Q16) {
+        const float mneg = -m_new * SC;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); rs += s[r]; }
+        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], SC, mneg)); rs += s[r]; }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); rs += s[r]; }
+      }
       rs += __shfl_xor(rs, 32, 64);
       l_run = l_run * alpha + rs;
       m_run = m_new;
@@ -259,11 +315,12 @@ __global__ __launch_bounds__(256, STYLER_ATTN_FWD_WAVES) void attention_fwd_bf16
   }
   if (q < Lr) {
     store_accT(out + (rowbase + q) * 256 + head * AD, o0, o1, lh, 1.f / l_run);
-    if (lse && lh == 0) lse[((int64_t)b * 4 + head) * L + q] = (m_run + log2f(l_run)) * 0.693147180559945f;   // natural log
+    if (lse && lh == 0) lse[((int64_t)b * 4 + head) * L + q] = (m_run * SC + log2f(l_run)) * 0.693147180559945f;   // natural log
   }
 }
 
 // ------------------------------------------------------------------------------------------------- dQ
+template <bool Q16>
 __global__ __launch_bounds__(256, STYLER_ATTN_DQ_WAVES) void attention_bwd_dq_bf16_kernel(const float* __restrict__ qkv,
                                                                     const float* __restrict__ o,
                                                                     const float* __restrict__ dout,
@@ -300,7 +357,8 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DQ_WAVES) void attention_bwd_dq_bf
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
     const int off = head * AD + st * 16 + lh * 8;
-    qf[st] = load8_bf16(qkv + (rowbase + qc) * 768 + off, 0.125f * LOG2E);     // log2-domain scores, see forward
+    if constexpr (Q16) qf[st] = load8_raw16(qkv, (rowbase + qc) * 768 + off);    // (scale: in the exponent below)
+    else qf[st] = load8_bf16(qkv + (rowbase + qc) * 768 + off, 0.125f * LOG2E);  // log2-domain scores, see forward
     const float* dp = dout + (rowbase + qc) * 256 + off;
     const float* op = o + (rowbase + qc) * 256 + off;
     dof[st] = load8_bf16(dp, 1.0f);
@@ -314,18 +372,20 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DQ_WAVES) void attention_bwd_dq_bf
   f32x16 dq0, dq1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
-  const __amdgpu_buffer_rsrc_t krs = rows_rsrc(qkv + rowbase * 768 + 256 + head * AD, 768, Lr);
-  const __amdgpu_buffer_rsrc_t vrs = rows_rsrc(qkv + rowbase * 768 + 512 + head * AD, 768, Lr);
+  const __amdgpu_buffer_rsrc_t krs = Q16 ? rows_rsrc16(qkv, rowbase * 768 + 256 + head * AD, 768, Lr)
+                                          : rows_rsrc(qkv + rowbase * 768 + 256 + head * AD, 768, Lr);
+  const __amdgpu_buffer_rsrc_t vrs = Q16 ? rows_rsrc16(qkv, rowbase * 768 + 512 + head * AD, 768, Lr)
+                                          : rows_rsrc(qkv + rowbase * 768 + 512 + head * AD, 768, Lr);
   const int ntiles = (klen + 63) / 64;
-  float4 rk[4], rv[4];
-  if (STYLER_ATTN_DQ_PREFETCH) { load_rows(rk, krs, 768, 0, tid); load_rows(rv, vrs, 768, 0, tid); }
+  TileRegs<Q16> rk, rv;
+  if (STYLER_ATTN_DQ_PREFETCH) { tile_load<Q16>(rk, krs, 768, 0, tid); tile_load<Q16>(rv, vrs, 768, 0, tid); }
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * 64;
-    if (!STYLER_ATTN_DQ_PREFETCH) { load_rows(rk, krs, 768, k0, tid); load_rows(rv, vrs, 768, k0, tid); }
+    if (!STYLER_ATTN_DQ_PREFETCH) { tile_load<Q16>(rk, krs, 768, k0, tid); tile_load<Q16>(rv, vrs, 768, k0, tid); }
     __syncthreads();
-    store_rows(sK, rk, tid);
-    store_rows(sV, rv, tid);
-    if (STYLER_ATTN_DQ_PREFETCH && kt + 1 < ntiles) { load_rows(rk, krs, 768, k0 + 64, tid); load_rows(rv, vrs, 768, k0 + 64, tid); }
+    tile_store<Q16>(sK, rk, tid);
+    tile_store<Q16>(sV, rv, tid);
+    if (STYLER_ATTN_DQ_PREFETCH && kt + 1 < ntiles) { tile_load<Q16>(rk, krs, 768, k0 + 64, tid); tile_load<Q16>(rv, vrs, 768, k0 + 64, tid); }
     __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -341,7 +401,8 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DQ_WAVES) void attention_bwd_dq_bf
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[st], dp, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] - my_lse) * (dp[r] - dl);
+      for (int r = 0; r < 16; ++r)
+        s[r] = __builtin_amdgcn_exp2f(Q16 ? fmaf(s[r], 0.125f * LOG2E, -my_lse) : s[r] - my_lse) * (dp[r] - dl);
       if (k0 + kb * 32 + 32 > klen) {                  // only the block holding the length boundary masks keys
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -365,6 +426,7 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DQ_WAVES) void attention_bwd_dq_bf
 }
 
 // ------------------------------------------------------------------------------------------------- dK, dV
+template <bool Q16>
 __global__ __launch_bounds__(256, STYLER_ATTN_DKV_WAVES) void attention_bwd_dkv_bf16_kernel(const float* __restrict__ qkv,
                                                                      const float* __restrict__ dout,
                                                                      const float* __restrict__ lse,
@@ -392,8 +454,13 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DKV_WAVES) void attention_bwd_dkv_
   bf16x8 kf[4], vf[4];
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
-    kf[st] = load8_bf16(qkv + (rowbase + keyc) * 768 + 256 + head * AD + st * 16 + lh * 8, 0.125f * LOG2E);
-    vf[st] = load8_bf16(qkv + (rowbase + keyc) * 768 + 512 + head * AD + st * 16 + lh * 8, 1.0f);
+    if constexpr (Q16) {
+      kf[st] = load8_raw16(qkv, (rowbase + keyc) * 768 + 256 + head * AD + st * 16 + lh * 8);
+      vf[st] = load8_raw16(qkv, (rowbase + keyc) * 768 + 512 + head * AD + st * 16 + lh * 8);
+    } else {
+      kf[st] = load8_bf16(qkv + (rowbase + keyc) * 768 + 256 + head * AD + st * 16 + lh * 8, 0.125f * LOG2E);
+      vf[st] = load8_bf16(qkv + (rowbase + keyc) * 768 + 512 + head * AD + st * 16 + lh * 8, 1.0f);
+    }
   }
   f32x16 dk0, dk1, dv0, dv1;
 #pragma unroll
@@ -402,20 +469,22 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DKV_WAVES) void attention_bwd_dkv_
   // A lane owns one key column, so an invalid key only pollutes its own dK / dV, which are written as zeros below.
   // Query rows at or past klen have dO = 0 and delta = 0 (no gradient reaches them): they add nothing to any dK / dV,
   // so the query loop stops at klen; rows of the last tile past the item are fetched as zeros (lse = +huge there).
-  const __amdgpu_buffer_rsrc_t qrs = rows_rsrc(qkv + rowbase * 768 + head * AD, 768, Lr);
+  const __amdgpu_buffer_rsrc_t qrs = Q16 ? rows_rsrc16(qkv, rowbase * 768 + head * AD, 768, Lr)
+                                          : rows_rsrc(qkv + rowbase * 768 + head * AD, 768, Lr);
   const __amdgpu_buffer_rsrc_t drs = rows_rsrc(dout + rowbase * 256 + head * AD, 256, Lr);
   const float* lse_row = lse + ((int64_t)b * 4 + head) * L;
   const float* dl_row = delta + ((int64_t)b * 4 + head) * L;
   const bool block_live = bx * 128 < klen;
   const int ntiles = block_live ? (klen + 63) / 64 : 0;
-  float4 rq[4], rdo[4];
+  TileRegs<Q16> rq;
+  float4 rdo[4];
   float r_lse = 0.f, r_dl = 0.f;                       // tid < 64: row tid of the tile
   auto fetch = [&](int qb) {
     if (tid < 64) {                                    // issued first: their wait must not cover the tile loads below
       const int qq = qb + tid, qi = qq < klen ? qq : klen - 1;
       r_lse = lse_row[qi]; r_dl = dl_row[qi];
     }
-    load_rows(rq, qrs, 768, qb, tid);
+    tile_load<Q16>(rq, qrs, 768, qb, tid);
     load_rows(rdo, drs, 256, qb, tid);
   };
 #ifndef STYLER_ATTN_DKV_PREFETCH                       // 1: next tile's loads in registers across the MFMAs (no better at 2-3 waves
@@ -426,7 +495,7 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DKV_WAVES) void attention_bwd_dkv_
     const int qb = qt * 64;
     if (!STYLER_ATTN_DKV_PREFETCH) fetch(qb);          // (variant without the register prefetch: loads ahead of the barrier)
     __syncthreads();
-    store_rows(sQ, rq, tid);
+    tile_store<Q16>(sQ, rq, tid);
     store_rows(sDO, rdo, tid);
     if (tid < 64) {
       // rows at or past klen: lse = +huge makes p exactly 0 (whatever dO / the forward's lse hold there)
@@ -458,7 +527,7 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DKV_WAVES) void attention_bwd_dkv_
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = g * 4 + e;
-          const float p = __builtin_amdgcn_exp2f(s[r] - lv[e]);
+          const float p = __builtin_amdgcn_exp2f(Q16 ? fmaf(s[r], 0.125f * LOG2E, -lv[e]) : s[r] - lv[e]);
           s[r] = p;
           dp[r] = p * (dp[r] - dvv[e]);
         }
@@ -492,13 +561,23 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DKV_WAVES) void attention_bwd_dkv_
   }
 }
 
-extern "C" int styler_attention_fwd_bf16(const float* qkv, float* out, float* lse, int B, int L, const int64_t* len,
-                                         const int32_t* cu, void* stream) {
+// io_flags & STYLER_IO_X_BF16: qkv is stored as bf16 ([rows][768] elements; throughput mode writes it that way from the QKV
+// GEMM's epilogue -- its only readers are these three kernels, which round it to bf16 anyway).
+extern "C" int styler_attention_fwd_bf16_io(const void* qkv, float* out, float* lse, int B, int L, const int64_t* len,
+                                            const int32_t* cu, int io_flags, void* stream) {
   if (!qkv || !out || B <= 0 || L <= 0 || (cu && !len)) return STYLER_EINVAL;
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return STYLER_EALIGN;
-  hipLaunchKernelGGL(attention_fwd_bf16_kernel, attn_grid(L, B), dim3(256), 0, (hipStream_t)stream, qkv, out,
-                     lse, B, L, len, cu);
+  const float* q = reinterpret_cast<const float*>(qkv);
+  if (io_flags & STYLER_IO_X_BF16)
+    hipLaunchKernelGGL(attention_fwd_bf16_kernel<true>, attn_grid(L, B), dim3(256), 0, (hipStream_t)stream, q, out, lse, B, L, len, cu);
+  else
+    hipLaunchKernelGGL(attention_fwd_bf16_kernel<false>, attn_grid(L, B), dim3(256), 0, (hipStream_t)stream, q, out, lse, B, L, len, cu);
   return launch_status();
+}
+
+extern "C" int styler_attention_fwd_bf16(const float* qkv, float* out, float* lse, int B, int L, const int64_t* len,
+                                         const int32_t* cu, void* stream) {
+  return styler_attention_fwd_bf16_io(qkv, out, lse, B, L, len, cu, 0, stream);
 }
 
 extern "C" int styler_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse,
@@ -509,7 +588,12 @@ extern "C" int styler_attention_bwd_bf16(const float* qkv, const float* out, con
   const dim3 grid = attn_grid(L, B);
   hipStream_t st = (hipStream_t)stream;
   const int out16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
-  hipLaunchKernelGGL(attention_bwd_dq_bf16_kernel, grid, dim3(256), 0, st, qkv, out, dout, lse, dqkv, delta_ws, B, L, len, cu, out16);
-  hipLaunchKernelGGL(attention_bwd_dkv_bf16_kernel, grid, dim3(256), 0, st, qkv, dout, lse, delta_ws, dqkv, B, L, len, cu, out16);
+  if (io_flags & STYLER_IO_X_BF16) {                  // qkv stored as bf16 (pass the bf16 pointer as `qkv`)
+    hipLaunchKernelGGL(attention_bwd_dq_bf16_kernel<true>, grid, dim3(256), 0, st, qkv, out, dout, lse, dqkv, delta_ws, B, L, len, cu, out16);
+    hipLaunchKernelGGL(attention_bwd_dkv_bf16_kernel<true>, grid, dim3(256), 0, st, qkv, dout, lse, delta_ws, dqkv, B, L, len, cu, out16);
+  } else {
+    hipLaunchKernelGGL(attention_bwd_dq_bf16_kernel<false>, grid, dim3(256), 0, st, qkv, out, dout, lse, dqkv, delta_ws, B, L, len, cu, out16);
+    hipLaunchKernelGGL(attention_bwd_dkv_bf16_kernel<false>, grid, dim3(256), 0, st, qkv, dout, lse, delta_ws, dqkv, B, L, len, cu, out16);
+  }
   return launch_status();
 }

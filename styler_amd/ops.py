@@ -474,7 +474,11 @@ def attention_fwd(qkv, lens, lse=None, prec=None, plan=None):
     """qkv [B, L, 768] (or, with `plan`, the packed [1, B*T, 768]); lse (optional) [B, 4, L] (packed: [B, 4, T])."""
     assert qkv.is_contiguous() and qkv.shape[2] == 768
     out = torch.empty(qkv.shape[0], qkv.shape[1], 256, device=qkv.device, dtype=torch.float32)
-    fn = lib.styler_attention_fwd_bf16 if _prec(prec) == PREC_BF16 else lib.styler_attention_fwd
+    if qkv.dtype == torch.bfloat16:                     # stored bf16 (throughput mode, rt.bf16_qkv): bf16 kernels only
+        assert _prec(prec) == PREC_BF16
+        fn = lambda *a: lib.styler_attention_fwd_bf16_io(*a[:-1], 1, a[-1])
+    else:
+        fn = lib.styler_attention_fwd_bf16 if _prec(prec) == PREC_BF16 else lib.styler_attention_fwd
     if plan is not None:
         _chk(fn(qkv.data_ptr(), out.data_ptr(), _ptr(lse), plan.B, plan.T, plan.lens.data_ptr(), plan.cu.data_ptr(),
                 _stream()), "styler_attention_fwd")
@@ -871,7 +875,8 @@ def attention_bwd(qkv, out, dout, lse, lens, prec=None, plan=None, out_bf16=Fals
         cu = None
     if bf16:
         _chk(lib.styler_attention_bwd_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
-                                           ws.data_ptr(), B, L, _ptr(lens), cu, 2 if dqkv.dtype == torch.bfloat16 else 0,
+                                           ws.data_ptr(), B, L, _ptr(lens), cu,
+                                           (2 if dqkv.dtype == torch.bfloat16 else 0) | (1 if qkv.dtype == torch.bfloat16 else 0),
                                            _stream()), "styler_attention_bwd_bf16")
     else:
         _chk(lib.styler_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),

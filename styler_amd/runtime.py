@@ -64,6 +64,11 @@ class _Runtime:
     # again.  Not bit-neutral: the statistics and the normalised values come from the rounded tensor (forward and backward
     # agree on it); STYLER_BF16_Z=0 keeps them fp32.  GroupNorm takes it in its single-pass kernels only (items <= 512 rows).
     bf16_z = os.environ.get("STYLER_BF16_Z", "1") != "0"
+    # throughput mode: the fused q | k | v tensor is stored as bf16 (the QKV GEMM's epilogue writes it, the three attention
+    # kernels -- its only readers -- stage it into LDS without a conversion).  K and V are rounded exactly as before; the
+    # 1 / sqrt(d_k) scale moves from q (before its rounding) to the raw scores (inside the exponent's fma), so q is rounded
+    # once as well.  STYLER_BF16_QKV=0: fp32.
+    bf16_qkv = os.environ.get("STYLER_BF16_QKV", "1") != "0"
     # EXPERIMENT (numerics only, not a fast path): round the residual stream of the FFT blocks -- LayerNorm outputs, the saved
     # pre-norm sums, the packed decoder input, the LengthRegulator output, and the gradients that flow back along them -- to
     # bf16 with torch casts, to measure what a model-wide bf16 activation format would do to the parity bounds BEFORE
