@@ -364,6 +364,57 @@ class ConvNormFn(Function):
         return (dx,) + (None,) * 11
 
 
+class ConvNormCatFn(Function):
+    """The LAST conv -> GroupNorm -> ReLU stage of the AudioEncoder's four streams (modules.py:128-160) as one tape node
+    whose GroupNorm kernels write straight into the channel slices of the concatenated [B, T, sum C] buffer the
+    mel calibrator reads (modules.py:176-177) -- the reference's torch.cat, and the four strided copies that stood in for
+    it here (0.1 ms per step), are gone; the backward hands each stream its slice of the incoming gradient as a view.
+    apply(cache, keys, norms, x0, w0, b0, x1, w1, b1, ...)."""
+
+    @staticmethod
+    def forward(ctx, cache, keys, norms, *flat):
+        xs, ws, bs = flat[0::3], flat[1::3], flat[2::3]
+        B, L = xs[0].shape[:2]
+        widths = [w.shape[0] for w in ws]
+        out = torch.empty(B, L, sum(widths), device=xs[0].device, dtype=torch.float32)
+        saved, b16s, off = [], [], 0
+        for x, weight, bias, key, norm, wd in zip(xs, ws, bs, keys, norms, widths):
+            w, prec = gemm_weight(cache, key, weight, x.shape[-1])
+            b16 = prec == ops.PREC_BF16 and rt.bf16_acts and wd % 8 == 0
+            z16 = b16 and rt.bf16_z and ops.groupnorm_z_bf16_ok(L)
+            z = ops.conv_gemm(x, w, bias, kw=5, n=wd, prec=prec, out_bf16=z16)
+            aux = torch.empty(B, wd // 16, 2, device=z.device, dtype=torch.float32)
+            ops.groupnorm_relu(z, norm.weight, norm.bias, stats=aux, out=out[..., off:off + wd])
+            saved += [x, z, aux]
+            b16s.append(b16)
+            off += wd
+        ctx.save_for_backward(*saved)
+        ctx.meta = (cache, keys, norms, ws, bs, widths, b16s)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        cache, keys, norms, ws, bs, widths, b16s = ctx.meta
+        saved = ctx.saved_tensors
+        grads, off = [], 0
+        for i, (weight, bias, key, norm, wd, b16) in enumerate(zip(ws, bs, keys, norms, widths, b16s)):
+            x, z, stats = saved[3 * i:3 * i + 3]
+            dz = ops.groupnorm_relu_bwd(z, dy[..., off:off + wd], norm.weight, norm.bias, stats, G(norm.weight), G(norm.bias),
+                                        dx_bf16=b16)
+            off += wd
+            n, cin = weight.shape[0], x.shape[-1]
+            if weight.requires_grad:
+                ops.wgrad(dz, x, G(weight), n, cin, kw=5, db=G(bias) if (bias is not None and bias.requires_grad) else None)
+            dx = None
+            if ctx.needs_input_grad[3 + 3 * i]:
+                bf16 = rt.prec == ops.PREC_BF16 and n % 8 == 0
+                wt = gemm_weight_bwd(cache, key, weight, bf16)
+                dx = ops.conv_gemm(dz, wt, None, kw=5, n=cin, prec=ops.PREC_BF16 if bf16 else ops.PREC_F32,
+                                   out_bf16=bf16 and x.dtype == torch.bfloat16)
+            grads += [dx, None, None]
+        return (None, None, None) + tuple(grads)
+
+
 class GroupNormReluFn(Function):
     """relu(GroupNorm(x)).  `out_bf16`: y is stored as bf16 (throughput mode, when the only consumer is the next convolution
     -- which rounds its activation operand to bf16 anyway); `dx_bf16`: so is the gradient handed to the convolution that

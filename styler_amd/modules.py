@@ -124,7 +124,7 @@ class AudioEncoder(_HipModule):
         grad = (self.training and torch.is_grad_enabled())
         catbuf = None if grad else torch.empty(B, T, sum(W), device=dev, dtype=torch.float32)
         err = torch.zeros(1, device=dev, dtype=torch.int32) if rt.strict_inputs else None
-        finals = []
+        finals, last = [], []
         for s in range(4):
             convs = getattr(self, f"convolutions_{s + 1}")
             x = None
@@ -140,6 +140,9 @@ class AudioEncoder(_HipModule):
                         ops.onehot_conv5(v, wt, conv.bias, y, err_flag=err)
                 else:
                     src = (mel if s == 0 else mel_aug) if i == 0 else x
+                    if grad and i == 2 and rt.fused_cat:    # the four last stages: one node writing into the concatenation
+                        last.append((src, conv, gn, f"c{s}_{i}"))
+                        continue
                     if grad:                             # conv + GroupNorm + ReLU as one tape node (bf16 between the convs)
                         x = AG.ConvNormFn.apply(src, conv.weight, conv.bias, self._derived, f"c{s}_{i}", 5, gn, "gn",
                                                 ops.ACT_RELU, 0.0, 1, i < 2)
@@ -162,7 +165,12 @@ class AudioEncoder(_HipModule):
                         out = y
                     x = ops.groupnorm_relu(y, gn.weight, gn.bias, out=out)
             finals.append(x)
-        if grad:
+        if grad and len(last) == 4:
+            flat = []
+            for src, conv, gn, key in last:
+                flat += [src, conv.weight, conv.bias]
+            catbuf = AG.ConvNormCatFn.apply(self._derived, tuple(k for _, _, _, k in last), tuple(g for _, _, g, _ in last), *flat)
+        elif grad:
             catbuf = AG.CatFn.apply(*finals)
         if err is not None and int(err.item()) != 0:
             raise AssertionError("quantize_1D_torch: input outside [0, 1] (utils.py:423)")

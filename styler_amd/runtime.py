@@ -69,6 +69,9 @@ class _Runtime:
     # 1 / sqrt(d_k) scale moves from q (before its rounding) to the raw scores (inside the exponent's fma), so q is rounded
     # once as well.  STYLER_BF16_QKV=0: fp32.
     bf16_qkv = os.environ.get("STYLER_BF16_QKV", "1") != "0"
+    # training: the last conv -> GroupNorm -> ReLU stage of the AudioEncoder's four streams as ONE tape node that writes into the
+    # concatenated buffer (autograd.ConvNormCatFn) instead of four nodes + a concatenation copy (STYLER_FUSED_CAT=0)
+    fused_cat = os.environ.get("STYLER_FUSED_CAT", "1") != "0"
     # EXPERIMENT (numerics only, not a fast path): round the residual stream of the FFT blocks -- LayerNorm outputs, the saved
     # pre-norm sums, the packed decoder input, the LengthRegulator output, and the gradients that flow back along them -- to
     # bf16 with torch casts, to measure what a model-wide bf16 activation format would do to the parity bounds BEFORE

@@ -209,11 +209,12 @@ def test_paired_decodes_match_separate(dev, ref_state_dict, prec):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("switch", ["pair_audio", "fused_split"])
+@pytest.mark.parametrize("switch", ["pair_audio", "fused_split", "fused_cat"])
 def test_experimental_switches_match_default(dev, ref_state_dict, prec, switch):
-    """rt.pair_audio (main forward + DAT pass of the AudioEncoder as one batch of 2B items) and rt.fused_split (gathered
-    gradient of the LengthRegulator output's channel slices) vs the default path: same ten losses and the same gradients
-    (dropout off)."""
+    """rt.pair_audio (main forward + DAT pass of the AudioEncoder as one batch of 2B items), rt.fused_split (gathered
+    gradient of the LengthRegulator output's channel slices) and rt.fused_cat (the AudioEncoder's four last conv + GroupNorm
+    stages as one tape node writing into the concatenated buffer) vs the path without them: same ten losses and the same
+    gradients (dropout off)."""
     from closed_form import make_batch
     from styler_amd import STYLER, rt
     from styler_amd.training import train_losses
