@@ -296,6 +296,11 @@ int styler_onehot_conv5(const float* v, const float* wt, const float* bias, floa
 int styler_mel_calibrate(const float* x, int64_t ldx, float* y, int64_t ldy,
                          const int64_t* mel_len, const int64_t* src_len, int B, int T, int S,
                          int C, void* stream);
+/* The same with io_flags.  STYLER_IO_X_BF16: x is stored as bf16 (ldx in elements) -- throughput-mode training keeps the
+ * concatenated output of the AudioEncoder's conv stacks (modules.py:176-177) that way; the means are taken in fp32. */
+int styler_mel_calibrate_io(const void* x, int64_t ldx, float* y, int64_t ldy,
+                            const int64_t* mel_len, const int64_t* src_len, int B, int T, int S,
+                            int C, int io_flags, void* stream);
 
 /* One direction-pair of one nn.LSTM layer (modules.py:117,179-182; gate order i,f,g,o; zero
  * initial state; run over the whole padded S).  gx [B, S, 2*4H] holds the input
@@ -572,6 +577,10 @@ int styler_onehot_expand(const float* v, float* onehot, int64_t rows, void* stre
 int styler_mel_calibrate_bwd(const float* dy, int64_t lddy, float* dx, int64_t lddx,
                              const int64_t* mel_len, const int64_t* src_len, int B, int T, int S,
                              int C, void* stream);
+/* io_flags & STYLER_IO_Y_BF16: dx is written as bf16 (lddx in elements). */
+int styler_mel_calibrate_bwd_io(const float* dy, int64_t lddy, void* dx, int64_t lddx,
+                                const int64_t* mel_len, const int64_t* src_len, int B, int T, int S,
+                                int C, int io_flags, void* stream);
 int styler_lstm_bidir_bwd(const float* dout, const float* gates, const float* cell,
                           const float* w_hh, float* dgp, int B, int S, int H, void* stream);
 /* Backward of up to 4 BiLSTM layers in one launch (HOST descriptor array). */

@@ -38,6 +38,7 @@ _SIGS = {
     "styler_sinusoid_table": [P, I, I, P],
     "styler_onehot_conv5": [P, P, P, P, I64, P, P, I, I, I, P],
     "styler_mel_calibrate": [P, I64, P, I64, P, P, I, I, I, I, P],
+    "styler_mel_calibrate_io": [P, I64, P, I64, P, P, I, I, I, I, I, P],
     "styler_lstm_bidir": [P, P, P, P, P, I, I, I, P],
     "styler_lstm_bidir_multi": [P, I, I, I, P],
     "styler_set_dropout_counter": [P],
@@ -79,6 +80,7 @@ _SIGS = {
     "styler_embed_bwd": [P, P, I64, P, I, I, I, P],
     "styler_onehot_expand": [P, P, I64, P],
     "styler_mel_calibrate_bwd": [P, I64, P, I64, P, P, I, I, I, I, P],
+    "styler_mel_calibrate_bwd_io": [P, I64, P, I64, P, P, I, I, I, I, I, P],
     "styler_lstm_bidir_bwd": [P, P, P, P, P, I, I, I, P],
     "styler_aug_classifier_tail_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, P],
     "styler_length_regulate_bwd": [P, I64, P, P, I64, I, I, I, I, P],

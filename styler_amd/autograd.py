@@ -376,7 +376,10 @@ class ConvNormCatFn(Function):
         xs, ws, bs = flat[0::3], flat[1::3], flat[2::3]
         B, L = xs[0].shape[:2]
         widths = [w.shape[0] for w in ws]
-        out = torch.empty(B, L, sum(widths), device=xs[0].device, dtype=torch.float32)
+        # throughput mode (rt.bf16_cat): the concatenation itself is bf16 -- its only reader, the mel calibrator, averages it in
+        # fp32, and the gradient that comes back for it is bf16 too (read by the four GroupNorm backwards)
+        cat16 = rt.bf16_cat and rt.bf16_acts and rt.prec == ops.PREC_BF16 and all(wd % 8 == 0 for wd in widths)
+        out = torch.empty(B, L, sum(widths), device=xs[0].device, dtype=torch.bfloat16 if cat16 else torch.float32)
         saved, b16s, off = [], [], 0
         for x, weight, bias, key, norm, wd in zip(xs, ws, bs, keys, norms, widths):
             w, prec = gemm_weight(cache, key, weight, x.shape[-1])
@@ -496,13 +499,13 @@ class MelCalibrateFn(Function):
     @staticmethod
     def forward(ctx, x, mel_len, src_len, S):
         ctx.save_for_backward(mel_len, src_len)
-        ctx.T = x.shape[1]
+        ctx.T, ctx.x16 = x.shape[1], x.dtype == torch.bfloat16
         return ops.mel_calibrate(x, mel_len, src_len, S)
 
     @staticmethod
     def backward(ctx, dy):
-        mel_len, src_len = ctx.saved_tensors
-        return ops.mel_calibrate_bwd(dy, mel_len, src_len, ctx.T), None, None, None
+        mel_len, src_len = ctx.saved_tensors                 # (a bf16 input gets its gradient in bf16)
+        return ops.mel_calibrate_bwd(dy, mel_len, src_len, ctx.T, out_bf16=ctx.x16), None, None, None
 
 
 class LstmLayerFn(Function):

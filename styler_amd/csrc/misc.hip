@@ -146,7 +146,8 @@ extern "C" int styler_onehot_conv5(const float* v, const float* wt, const float*
 //   ml == sl: copy;   s >= sl: zeros
 // Block = 256 / (C / 4) output rows of one item (C = 80: 12 rows, 240 threads busy; a block per row kept 20 of 256 lanes
 // busy and paid a block launch per 320 bytes), thread = (row, float4 column); the frames of a mean are fetched four at a time.
-__global__ __launch_bounds__(256) void mel_calibrate_kernel(const float* __restrict__ x, int64_t ldx,
+template <bool X16>                                  // x (the concatenated AudioEncoder streams) stored as bf16
+__global__ __launch_bounds__(256) void mel_calibrate_kernel(const void* __restrict__ x, int64_t ldx,
                                                             float* __restrict__ y, int64_t ldy,
                                                             const int64_t* __restrict__ mel_len,
                                                             const int64_t* __restrict__ src_len, int T, int S,
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void mel_calibrate_kernel(const float* __restr
   if (rl >= rpb || s >= S) return;
   const int ml = (int)mel_len[b], sl = (int)src_len[b];
   float* yp = y + ((int64_t)b * S + s) * ldy;
-  const float* xb = x + (int64_t)b * T * ldx;
+  const int64_t xb = (int64_t)b * T * ldx;
   int start = 0, n = 0;
   if (s < sl && ml > 0) {
     if (ml >= sl) {
@@ -173,12 +174,14 @@ __global__ __launch_bounds__(256) void mel_calibrate_kernel(const float* __restr
   for (int q4 = ql; q4 < nq; q4 += cpr) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int f0 = 0; f0 < n; f0 += 4) {
-      float4 v[4];
+      typename Raw4<X16>::T rv[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xb + (int64_t)(start + (f0 + u < n ? f0 + u : n - 1)) * ldx + q4 * 4);
+      for (int u = 0; u < 4; ++u) rv[u] = raw4_load<X16>(x, xb + (int64_t)(start + (f0 + u < n ? f0 + u : n - 1)) * ldx + q4 * 4);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (f0 + u < n) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+      for (int u = 0; u < 4; ++u) {
+        const float4 v = raw4_f32(rv[u]);
+        if (f0 + u < n) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+      }
     }
     if (n > 1) { const float d = (float)n; acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d; }
     *reinterpret_cast<float4*>(yp + q4 * 4) = acc;
@@ -187,14 +190,25 @@ __global__ __launch_bounds__(256) void mel_calibrate_kernel(const float* __restr
 
 static inline int mel_cal_rows_per_block(int C) { const int nq = C >> 2; return 256 / (nq < 256 ? nq : 256); }
 
-extern "C" int styler_mel_calibrate(const float* x, int64_t ldx, float* y, int64_t ldy, const int64_t* mel_len,
-                                    const int64_t* src_len, int B, int T, int S, int C, void* stream) {
+// io_flags & STYLER_IO_X_BF16: x is stored as bf16 (ldx in elements) -- throughput mode keeps the concatenated output of
+// the AudioEncoder's conv stacks that way (its only reader is this kernel, which averages it in fp32).
+extern "C" int styler_mel_calibrate_io(const void* x, int64_t ldx, float* y, int64_t ldy, const int64_t* mel_len,
+                                       const int64_t* src_len, int B, int T, int S, int C, int io_flags, void* stream) {
   if (!x || !y || !mel_len || !src_len || B <= 0 || T <= 0 || S <= 0 || C <= 0 || (C & 3)) return STYLER_EINVAL;
   if ((ldx & 3) || (ldy & 3)) return STYLER_EALIGN;
   const int rpb = mel_cal_rows_per_block(C);
-  hipLaunchKernelGGL(mel_calibrate_kernel, dim3((S + rpb - 1) / rpb, B), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
-                     mel_len, src_len, T, S, C);
+  if (io_flags & STYLER_IO_X_BF16)
+    hipLaunchKernelGGL(mel_calibrate_kernel<true>, dim3((S + rpb - 1) / rpb, B), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
+                       mel_len, src_len, T, S, C);
+  else
+    hipLaunchKernelGGL(mel_calibrate_kernel<false>, dim3((S + rpb - 1) / rpb, B), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
+                       mel_len, src_len, T, S, C);
   return launch_status();
+}
+
+extern "C" int styler_mel_calibrate(const float* x, int64_t ldx, float* y, int64_t ldy, const int64_t* mel_len,
+                                    const int64_t* src_len, int B, int T, int S, int C, void* stream) {
+  return styler_mel_calibrate_io(x, ldx, y, ldy, mel_len, src_len, B, T, S, C, 0, stream);
 }
 
 // ---- augmentation classifier tail ------------------------------------------------------------

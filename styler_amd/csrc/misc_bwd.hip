@@ -58,8 +58,9 @@ extern "C" int styler_onehot_expand(const float* v, float* onehot, int64_t rows,
 
 // ---- mel calibrator backward: grid (T, B) over INPUT frames -----------------------------------------------
 // (block = 256 / (C / 4) input frames of one item, thread = (frame, float4 column): see mel_calibrate_kernel)
+template <bool DX16>                                 // dx (the gradient of the concatenated streams) written as bf16
 __global__ __launch_bounds__(256) void mel_calibrate_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
-                                                                float* __restrict__ dx, int64_t lddx,
+                                                                void* __restrict__ dx, int64_t lddx,
                                                                 const int64_t* __restrict__ mel_len,
                                                                 const int64_t* __restrict__ src_len, int T, int S, int C) {
   const int nq = C >> 2, cpr = nq < 256 ? nq : 256, rpb = 256 / cpr;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void mel_calibrate_bwd_kernel(const float* __r
   const int t = blockIdx.x * rpb + rl, b = blockIdx.y;
   if (rl >= rpb || t >= T) return;
   const int ml = (int)mel_len[b], sl = (int)src_len[b];
-  float* dxp = dx + ((int64_t)b * T + t) * lddx;
+  const int64_t dxo = ((int64_t)b * T + t) * lddx;
   const float* dyb = dy + (int64_t)b * S * lddy;
   // div > 0: frame t lies in exactly one segment (compression / copy): grad = dy[s0] / div
   // div == 0: frame t was repeated `cnt` times (expansion): grad = sum of those output rows
@@ -95,18 +96,28 @@ __global__ __launch_bounds__(256) void mel_calibrate_bwd_kernel(const float* __r
         if (k0 + u < n) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
     }
     if (div > 1) { const float d = (float)div; acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d; }
-    *reinterpret_cast<float4*>(dxp + q4 * 4) = acc;
+    stg4(dx, dxo + q4 * 4, acc, DX16);
   }
+}
+
+// io_flags & STYLER_IO_Y_BF16: dx is written as bf16 (lddx in elements; its reader, the GroupNorm backward, takes a bf16 dy).
+extern "C" int styler_mel_calibrate_bwd_io(const float* dy, int64_t lddy, void* dx, int64_t lddx, const int64_t* mel_len,
+                                           const int64_t* src_len, int B, int T, int S, int C, int io_flags, void* stream) {
+  if (!dy || !dx || !mel_len || !src_len || B <= 0 || T <= 0 || S <= 0 || C <= 0 || (C & 3)) return STYLER_EINVAL;
+  if ((lddy & 3) || (lddx & 3)) return STYLER_EALIGN;
+  const int nq = C >> 2, rpb = 256 / (nq < 256 ? nq : 256);
+  if (io_flags & STYLER_IO_Y_BF16)
+    hipLaunchKernelGGL(mel_calibrate_bwd_kernel<true>, dim3((T + rpb - 1) / rpb, B), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx,
+                       lddx, mel_len, src_len, T, S, C);
+  else
+    hipLaunchKernelGGL(mel_calibrate_bwd_kernel<false>, dim3((T + rpb - 1) / rpb, B), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx,
+                       lddx, mel_len, src_len, T, S, C);
+  return launch_status();
 }
 
 extern "C" int styler_mel_calibrate_bwd(const float* dy, int64_t lddy, float* dx, int64_t lddx, const int64_t* mel_len,
                                         const int64_t* src_len, int B, int T, int S, int C, void* stream) {
-  if (!dy || !dx || !mel_len || !src_len || B <= 0 || T <= 0 || S <= 0 || C <= 0 || (C & 3)) return STYLER_EINVAL;
-  if ((lddy & 3) || (lddx & 3)) return STYLER_EALIGN;
-  const int nq = C >> 2, rpb = 256 / (nq < 256 ? nq : 256);
-  hipLaunchKernelGGL(mel_calibrate_bwd_kernel, dim3((T + rpb - 1) / rpb, B), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx,
-                     lddx, mel_len, src_len, T, S, C);
-  return launch_status();
+  return styler_mel_calibrate_bwd_io(dy, lddy, dx, lddx, mel_len, src_len, B, T, S, C, 0, stream);
 }
 
 // ---- augmentation classifier tail backward ----------------------------------------------------------------

@@ -613,8 +613,9 @@ def onehot_conv5(v, wt, bias, out, err_flag=None, idx_out=None):
 def mel_calibrate(x, mel_len, src_len, S):
     B, T, C = x.shape
     y = torch.empty(B, S, C, device=x.device, dtype=torch.float32)
-    _chk(lib.styler_mel_calibrate(x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), mel_len.data_ptr(),
-                                  src_len.data_ptr(), B, T, S, C, _stream()), "styler_mel_calibrate")
+    _chk(lib.styler_mel_calibrate_io(x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), mel_len.data_ptr(),
+                                     src_len.data_ptr(), B, T, S, C, 1 if x.dtype == torch.bfloat16 else 0, _stream()),
+         "styler_mel_calibrate")
     return y
 
 
@@ -985,12 +986,12 @@ def onehot_conv5_bwd(v, dy, dw, db):
     wgrad(dy, oh, dw, C, 257, kw=5, db=db, strides=(257 * 5, 5, 1))
 
 
-def mel_calibrate_bwd(dy, mel_len, src_len, T):
+def mel_calibrate_bwd(dy, mel_len, src_len, T, out_bf16=False):
     dy = _rows_view(dy)
     B, S, C = dy.shape
-    dx = torch.empty(B, T, C, device=dy.device, dtype=torch.float32)
-    _chk(lib.styler_mel_calibrate_bwd(dy.data_ptr(), _ld(dy), dx.data_ptr(), C, mel_len.data_ptr(), src_len.data_ptr(),
-                                      B, T, S, C, _stream()), "styler_mel_calibrate_bwd")
+    dx = torch.empty(B, T, C, device=dy.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    _chk(lib.styler_mel_calibrate_bwd_io(dy.data_ptr(), _ld(dy), dx.data_ptr(), C, mel_len.data_ptr(), src_len.data_ptr(),
+                                         B, T, S, C, 2 if out_bf16 else 0, _stream()), "styler_mel_calibrate_bwd")
     return dx
 
 

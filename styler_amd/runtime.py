@@ -72,6 +72,11 @@ class _Runtime:
     # training: the last conv -> GroupNorm -> ReLU stage of the AudioEncoder's four streams as ONE tape node that writes into the
     # concatenated buffer (autograd.ConvNormCatFn) instead of four nodes + a concatenation copy (STYLER_FUSED_CAT=0)
     fused_cat = os.environ.get("STYLER_FUSED_CAT", "1") != "0"
+    # ... and that buffer (the AudioEncoder's [2B, T, 1152] output, read once by the mel calibrator) and its gradient as bf16:
+    # OFF -- measured -0.03 ms per step (10.29 -> 10.26), and the extra rounding of the gradient pushed a noise-only tensor
+    # (the key bias of an encoder attention layer, whose true gradient is zero) past the 5e-2 packed-vs-padded bound.
+    # The kernels (styler_mel_calibrate_io / _bwd_io) are kept and tested; STYLER_BF16_CAT=1 switches the storage on.
+    bf16_cat = os.environ.get("STYLER_BF16_CAT", "0") == "1"
     # EXPERIMENT (numerics only, not a fast path): round the residual stream of the FFT blocks -- LayerNorm outputs, the saved
     # pre-norm sums, the packed decoder input, the LengthRegulator output, and the gradients that flow back along them -- to
     # bf16 with torch casts, to measure what a model-wide bf16 activation format would do to the parity bounds BEFORE

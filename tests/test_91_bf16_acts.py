@@ -242,3 +242,23 @@ def test_bf16_z_norm_kernels_equal_fp32_kernels_on_the_same_values(dev):
         assert float((dx_a.float() - dx_b.float()).abs().max()) <= 2 ** -7 * float(dx_b.float().abs().max()), (C, act)
         for a, b in ((dg_a, dg_b), (db_a, db_b)):
             assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1e-3), (C, act)
+
+
+def test_mel_calibrator_bf16_storage(dev):
+    """rt.bf16_cat: the mel calibrator on a bf16 input gives exactly what it gives on an fp32 tensor holding the same values
+    (the means are taken in fp32 either way); its backward with a bf16 output is the round-to-nearest-even of the fp32 one.
+    Compression (mel_len > src_len), expansion (mel_len < src_len), equal lengths, an empty item."""
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(5)
+    bf = torch.bfloat16
+    B, T, S, C = 4, 50, 12, 1152
+    mel_len = torch.tensor([50, 7, 12, 0]).to(dev)
+    src_len = torch.tensor([12, 10, 12, 3]).to(dev)
+    x16 = torch.randn(B, T, C, generator=g).to(dev).to(bf)
+    y_a = ops.mel_calibrate(x16, mel_len, src_len, S)
+    y_b = ops.mel_calibrate(x16.float(), mel_len, src_len, S)
+    assert y_a.dtype == torch.float32 and torch.equal(y_a, y_b)
+    dy = torch.randn(B, S, C, generator=g).to(dev)
+    d_a = ops.mel_calibrate_bwd(dy, mel_len, src_len, T, out_bf16=True)
+    d_b = ops.mel_calibrate_bwd(dy, mel_len, src_len, T)
+    assert d_a.dtype == bf and torch.equal(d_a, d_b.to(bf))
