@@ -197,10 +197,13 @@ int styler_attention_fwd_bf16(const float* qkv, float* out, float* lse, int B, i
  * throughput mode writes it that way from the QKV GEMM's epilogue, its only readers are these kernels.  The 1/sqrt(d_k)
  * scale is then applied to the raw scores inside the exponent (one fma) instead of to q before its rounding: every
  * operand is still rounded once (SubLayers.py:44-52, Modules.py:14-25). */
-int styler_attention_fwd_bf16_io(const void* qkv, float* out, float* lse, int B, int L,
+int styler_attention_fwd_bf16_io(const void* qkv, void* out, float* lse, int B, int L,
                                  const int64_t* len, const int32_t* cu, int io_flags, void* stream);
-/* io_flags & STYLER_IO_Y_BF16: dqkv is written as bf16 [B,L,768] (what its consumers -- the QKV dX GEMM and the three
- * weight gradients -- round it to anyway).  io_flags & STYLER_IO_X_BF16: qkv is stored as bf16 (as above). */
+/* ... STYLER_IO_Y_BF16 on the forward: `out` is written as bf16 (its readers -- the output projection, that projection's
+ * weight gradient, the backward's delta -- round it to bf16 or accept it rounded).
+ * Backward: io_flags & STYLER_IO_Y_BF16: dqkv is written as bf16 [B,L,768] (what its consumers -- the QKV dX GEMM and the three
+ * weight gradients -- round it to anyway); STYLER_IO_X_BF16: qkv is stored as bf16 (as above); STYLER_IO_MASK_BF16: `out` is
+ * stored as bf16; STYLER_IO_RES_BF16: `dout` is stored as bf16 (pass the bf16 pointers in their places). */
 int styler_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse,
                               void* dqkv, float* delta_ws, int B, int L, const int64_t* len,
                               const int32_t* cu, int io_flags, void* stream);

@@ -205,7 +205,7 @@ class AttnSublayerFn(Function):
         qkv = ops.conv_gemm(x, w, b, n=768, prec=prec, plan=plan, out_bf16=prec == ops.PREC_BF16 and rt.bf16_qkv)
         B, L = (plan.B, plan.T) if plan is not None else x.shape[:2]
         lse = torch.empty(B, 4, L, device=x.device, dtype=torch.float32)
-        att = ops.attention_fwd(qkv, lens, lse=lse, plan=plan)
+        att = ops.attention_fwd(qkv, lens, lse=lse, plan=plan, out_bf16=prec == ops.PREC_BF16 and rt.bf16_att)
         wfc, pfc = gemm_weight(mha._derived, "fc", mha.fc.weight, 256)
         o = ops.conv_gemm(att, wfc, mha.fc.bias, n=256, prec=pfc, plan=plan)
         want16 = want16 and prec == ops.PREC_BF16
@@ -229,7 +229,7 @@ class AttnSublayerFn(Function):
         prec = ops.PREC_BF16 if bf16 else ops.PREC_F32
         ops.wgrad(d_o, att, G(mha.fc.weight), 256, 256, db=G(mha.fc.bias), plan=plan)
         d_att = ops.conv_gemm(d_o, gemm_weight_bwd(mha._derived, "fc", mha.fc.weight, bf16), None, n=256, prec=prec,
-                              plan=plan)
+                              plan=plan, out_bf16=bf16 and att.dtype == torch.bfloat16)
         dqkv = ops.attention_bwd(qkv, att, d_att, lse, lens, plan=plan, out_bf16=bf16 and rt.bf16_acts and rt.bf16_dqkv)
         srcs = [mha.w_qs.weight, mha.w_ks.weight, mha.w_vs.weight]
         for i, lin in enumerate((mha.w_qs, mha.w_ks, mha.w_vs)):

@@ -208,7 +208,7 @@ template <bool Q16>
 __global__ __launch_bounds__(256, STYLER_ATTN_FWD_WAVES) void attention_fwd_bf16_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                  float* __restrict__ lse, int B, int L,
                                                                  const int64_t* __restrict__ len,
-                                                                 const int* __restrict__ cu) {
+                                                                 const int* __restrict__ cu, int out16) {
   __shared__ __attribute__((aligned(16))) uint32_t sK[64 * ALD];
   __shared__ __attribute__((aligned(16))) uint32_t sV[64 * ALD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -226,9 +226,7 @@ __global__ __launch_bounds__(256, STYLER_ATTN_FWD_WAVES) void attention_fwd_bf16
   // LayerNorm, Layers.py:29): blocks made only of such rows write zeros and leave.
   if (bx * 128 >= klen) {
     if (q < Lr) {
-      float* op = out + (rowbase + q) * 256 + head * AD + lh * 32;
-#pragma unroll
-      for (int d = 0; d < 32; d += 4) *reinterpret_cast<float4*>(op + d) = make_float4(0.f, 0.f, 0.f, 0.f);
+      zero32(out, (rowbase + q) * 256 + head * AD + lh * 32, out16);
       if (lse && lh == 0) lse[((int64_t)b * 4 + head) * L + q] = 0.f;
     }
     return;
@@ -314,7 +312,10 @@ __global__ __launch_bounds__(256, STYLER_ATTN_FWD_WAVES) void attention_fwd_bf16
     }
   }
   if (q < Lr) {
-    store_accT(out + (rowbase + q) * 256 + head * AD, o0, o1, lh, 1.f / l_run);
+    // out16: the attention output stored as bf16 (its readers -- the output projection, that projection's weight gradient
+    // and the backward's delta -- take it rounded to bf16 or, the delta, accept it)
+    if (out16) store_accT16(reinterpret_cast<uint16_t*>(out) + (rowbase + q) * 256 + head * AD, o0, o1, lh, 1.f / l_run);
+    else store_accT(out + (rowbase + q) * 256 + head * AD, o0, o1, lh, 1.f / l_run);
     if (lse && lh == 0) lse[((int64_t)b * 4 + head) * L + q] = (m_run * SC + log2f(l_run)) * 0.693147180559945f;   // natural log
   }
 }
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DQ_WAVES) void attention_bwd_dq_bf
                                                                     const float* __restrict__ lse,
                                                                     void* __restrict__ dqkv, float* __restrict__ delta,
                                                                     int B, int L, const int64_t* __restrict__ len,
-                                                                    const int* __restrict__ cu, int out16) {
+                                                                    const int* __restrict__ cu, int out16, int o16, int do16) {
   __shared__ __attribute__((aligned(16))) uint32_t sK[64 * ALD];
   __shared__ __attribute__((aligned(16))) uint32_t sV[64 * ALD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -359,11 +360,33 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DQ_WAVES) void attention_bwd_dq_bf
     const int off = head * AD + st * 16 + lh * 8;
     if constexpr (Q16) qf[st] = load8_raw16(qkv, (rowbase + qc) * 768 + off);    // (scale: in the exponent below)
     else qf[st] = load8_bf16(qkv + (rowbase + qc) * 768 + off, 0.125f * LOG2E);  // log2-domain scores, see forward
-    const float* dp = dout + (rowbase + qc) * 256 + off;
-    const float* op = o + (rowbase + qc) * 256 + off;
-    dof[st] = load8_bf16(dp, 1.0f);
+    // o16 / do16: the forward's output / the incoming gradient stored as bf16 (8 elements = one 16-byte load each)
+    const int64_t ro = (rowbase + qc) * 256 + off;
+    float dv8[8], ov8[8];
+    if (do16) {
+      const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(dout) + ro);
+      dof[st] = *reinterpret_cast<const bf16x8*>(&r);
+      const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dl += dp[e] * op[e];
+      for (int e = 0; e < 4; ++e) { dv8[2 * e] = __uint_as_float(w[e] << 16); dv8[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+    } else {
+      const float* dp = dout + ro;
+      dof[st] = load8_bf16(dp, 1.0f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dv8[e] = dp[e];
+    }
+    if (o16) {
+      const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(o) + ro);
+      const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ov8[2 * e] = __uint_as_float(w[e] << 16); ov8[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+    } else {
+      const float* op = o + ro;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ov8[e] = op[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl += dv8[e] * ov8[e];
   }
   dl += __shfl_xor(dl, 32, 64);
   const float my_lse = lse[((int64_t)b * 4 + head) * L + qc] * LOG2E;
@@ -426,7 +449,7 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DQ_WAVES) void attention_bwd_dq_bf
 }
 
 // ------------------------------------------------------------------------------------------------- dK, dV
-template <bool Q16>
+template <bool Q16, bool DO16>
 __global__ __launch_bounds__(256, STYLER_ATTN_DKV_WAVES) void attention_bwd_dkv_bf16_kernel(const float* __restrict__ qkv,
                                                                      const float* __restrict__ dout,
                                                                      const float* __restrict__ lse,
@@ -471,13 +494,14 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DKV_WAVES) void attention_bwd_dkv_
   // so the query loop stops at klen; rows of the last tile past the item are fetched as zeros (lse = +huge there).
   const __amdgpu_buffer_rsrc_t qrs = Q16 ? rows_rsrc16(qkv, rowbase * 768 + head * AD, 768, Lr)
                                           : rows_rsrc(qkv + rowbase * 768 + head * AD, 768, Lr);
-  const __amdgpu_buffer_rsrc_t drs = rows_rsrc(dout + rowbase * 256 + head * AD, 256, Lr);
+  const __amdgpu_buffer_rsrc_t drs = DO16 ? rows_rsrc16(dout, rowbase * 256 + head * AD, 256, Lr)
+                                           : rows_rsrc(dout + rowbase * 256 + head * AD, 256, Lr);
   const float* lse_row = lse + ((int64_t)b * 4 + head) * L;
   const float* dl_row = delta + ((int64_t)b * 4 + head) * L;
   const bool block_live = bx * 128 < klen;
   const int ntiles = block_live ? (klen + 63) / 64 : 0;
   TileRegs<Q16> rq;
-  float4 rdo[4];
+  TileRegs<DO16> rdo;
   float r_lse = 0.f, r_dl = 0.f;                       // tid < 64: row tid of the tile
   auto fetch = [&](int qb) {
     if (tid < 64) {                                    // issued first: their wait must not cover the tile loads below
@@ -485,7 +509,7 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DKV_WAVES) void attention_bwd_dkv_
       r_lse = lse_row[qi]; r_dl = dl_row[qi];
     }
     tile_load<Q16>(rq, qrs, 768, qb, tid);
-    load_rows(rdo, drs, 256, qb, tid);
+    tile_load<DO16>(rdo, drs, 256, qb, tid);
   };
 #ifndef STYLER_ATTN_DKV_PREFETCH                       // 1: next tile's loads in registers across the MFMAs (no better at 2-3 waves
 #define STYLER_ATTN_DKV_PREFETCH 0                     // per SIMD: 84.4 vs 80.7 us), 0: loads issued ahead of the barrier
@@ -496,7 +520,7 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DKV_WAVES) void attention_bwd_dkv_
     if (!STYLER_ATTN_DKV_PREFETCH) fetch(qb);          // (variant without the register prefetch: loads ahead of the barrier)
     __syncthreads();
     tile_store<Q16>(sQ, rq, tid);
-    store_rows(sDO, rdo, tid);
+    tile_store<DO16>(sDO, rdo, tid);
     if (tid < 64) {
       // rows at or past klen: lse = +huge makes p exactly 0 (whatever dO / the forward's lse hold there)
       const bool okq = qb + tid < klen;
@@ -562,16 +586,19 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DKV_WAVES) void attention_bwd_dkv_
 }
 
 // io_flags & STYLER_IO_X_BF16: qkv is stored as bf16 ([rows][768] elements; throughput mode writes it that way from the QKV
-// GEMM's epilogue -- its only readers are these three kernels, which round it to bf16 anyway).
-extern "C" int styler_attention_fwd_bf16_io(const void* qkv, float* out, float* lse, int B, int L, const int64_t* len,
+// GEMM's epilogue -- its only readers are these three kernels, which round it to bf16 anyway).  io_flags & STYLER_IO_Y_BF16:
+// `out` is written as bf16.
+extern "C" int styler_attention_fwd_bf16_io(const void* qkv, void* out, float* lse, int B, int L, const int64_t* len,
                                             const int32_t* cu, int io_flags, void* stream) {
   if (!qkv || !out || B <= 0 || L <= 0 || (cu && !len)) return STYLER_EINVAL;
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return STYLER_EALIGN;
   const float* q = reinterpret_cast<const float*>(qkv);
+  float* o = reinterpret_cast<float*>(out);
+  const int out16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
   if (io_flags & STYLER_IO_X_BF16)
-    hipLaunchKernelGGL(attention_fwd_bf16_kernel<true>, attn_grid(L, B), dim3(256), 0, (hipStream_t)stream, q, out, lse, B, L, len, cu);
+    hipLaunchKernelGGL(attention_fwd_bf16_kernel<true>, attn_grid(L, B), dim3(256), 0, (hipStream_t)stream, q, o, lse, B, L, len, cu, out16);
   else
-    hipLaunchKernelGGL(attention_fwd_bf16_kernel<false>, attn_grid(L, B), dim3(256), 0, (hipStream_t)stream, q, out, lse, B, L, len, cu);
+    hipLaunchKernelGGL(attention_fwd_bf16_kernel<false>, attn_grid(L, B), dim3(256), 0, (hipStream_t)stream, q, o, lse, B, L, len, cu, out16);
   return launch_status();
 }
 
@@ -580,6 +607,8 @@ extern "C" int styler_attention_fwd_bf16(const float* qkv, float* out, float* ls
   return styler_attention_fwd_bf16_io(qkv, out, lse, B, L, len, cu, 0, stream);
 }
 
+// io_flags: STYLER_IO_X_BF16 = qkv stored as bf16, STYLER_IO_Y_BF16 = dqkv written as bf16, STYLER_IO_MASK_BF16 = `out` (the
+// forward's output) stored as bf16, STYLER_IO_RES_BF16 = `dout` stored as bf16 (pass the bf16 pointers in their places).
 extern "C" int styler_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse,
                                          void* dqkv, float* delta_ws, int B, int L, const int64_t* len,
                                          const int32_t* cu, int io_flags, void* stream) {
@@ -588,12 +617,15 @@ extern "C" int styler_attention_bwd_bf16(const float* qkv, const float* out, con
   const dim3 grid = attn_grid(L, B);
   hipStream_t st = (hipStream_t)stream;
   const int out16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
-  if (io_flags & STYLER_IO_X_BF16) {                  // qkv stored as bf16 (pass the bf16 pointer as `qkv`)
-    hipLaunchKernelGGL(attention_bwd_dq_bf16_kernel<true>, grid, dim3(256), 0, st, qkv, out, dout, lse, dqkv, delta_ws, B, L, len, cu, out16);
-    hipLaunchKernelGGL(attention_bwd_dkv_bf16_kernel<true>, grid, dim3(256), 0, st, qkv, dout, lse, delta_ws, dqkv, B, L, len, cu, out16);
-  } else {
-    hipLaunchKernelGGL(attention_bwd_dq_bf16_kernel<false>, grid, dim3(256), 0, st, qkv, out, dout, lse, dqkv, delta_ws, B, L, len, cu, out16);
-    hipLaunchKernelGGL(attention_bwd_dkv_bf16_kernel<false>, grid, dim3(256), 0, st, qkv, dout, lse, delta_ws, dqkv, B, L, len, cu, out16);
-  }
+  const int o16 = (io_flags & STYLER_IO_MASK_BF16) ? 1 : 0, do16 = (io_flags & STYLER_IO_RES_BF16) ? 1 : 0;
+  const bool q16 = (io_flags & STYLER_IO_X_BF16) != 0;
+  if (q16) hipLaunchKernelGGL(attention_bwd_dq_bf16_kernel<true>, grid, dim3(256), 0, st, qkv, out, dout, lse, dqkv, delta_ws, B, L, len, cu, out16, o16, do16);
+  else hipLaunchKernelGGL(attention_bwd_dq_bf16_kernel<false>, grid, dim3(256), 0, st, qkv, out, dout, lse, dqkv, delta_ws, B, L, len, cu, out16, o16, do16);
+#define DKV_LAUNCH(Q_, D_) hipLaunchKernelGGL((attention_bwd_dkv_bf16_kernel<Q_, D_>), grid, dim3(256), 0, st, qkv, dout, lse, delta_ws, dqkv, B, L, len, cu, out16)
+  if (q16 && do16) DKV_LAUNCH(true, true);
+  else if (q16) DKV_LAUNCH(true, false);
+  else if (do16) DKV_LAUNCH(false, true);
+  else DKV_LAUNCH(false, false);
+#undef DKV_LAUNCH
   return launch_status();
 }

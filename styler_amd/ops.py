@@ -470,13 +470,16 @@ def _prec(prec):
     return prec
 
 
-def attention_fwd(qkv, lens, lse=None, prec=None, plan=None):
-    """qkv [B, L, 768] (or, with `plan`, the packed [1, B*T, 768]); lse (optional) [B, 4, L] (packed: [B, 4, T])."""
+def attention_fwd(qkv, lens, lse=None, prec=None, plan=None, out_bf16=False):
+    """qkv [B, L, 768] (or, with `plan`, the packed [1, B*T, 768]); lse (optional) [B, 4, L] (packed: [B, 4, T]).
+    out_bf16 (throughput mode): the output is stored as bf16."""
     assert qkv.is_contiguous() and qkv.shape[2] == 768
-    out = torch.empty(qkv.shape[0], qkv.shape[1], 256, device=qkv.device, dtype=torch.float32)
-    if qkv.dtype == torch.bfloat16:                     # stored bf16 (throughput mode, rt.bf16_qkv): bf16 kernels only
+    out_bf16 = out_bf16 and _prec(prec) == PREC_BF16
+    out = torch.empty(qkv.shape[0], qkv.shape[1], 256, device=qkv.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    if qkv.dtype == torch.bfloat16 or out_bf16:         # stored bf16 (throughput mode, rt.bf16_qkv / bf16_att): bf16 kernels only
         assert _prec(prec) == PREC_BF16
-        fn = lambda *a: lib.styler_attention_fwd_bf16_io(*a[:-1], 1, a[-1])
+        io = (1 if qkv.dtype == torch.bfloat16 else 0) | (2 if out_bf16 else 0)
+        fn = lambda *a: lib.styler_attention_fwd_bf16_io(*a[:-1], io, a[-1])
     else:
         fn = lib.styler_attention_fwd_bf16 if _prec(prec) == PREC_BF16 else lib.styler_attention_fwd
     if plan is not None:
@@ -877,7 +880,8 @@ def attention_bwd(qkv, out, dout, lse, lens, prec=None, plan=None, out_bf16=Fals
     if bf16:
         _chk(lib.styler_attention_bwd_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
                                            ws.data_ptr(), B, L, _ptr(lens), cu,
-                                           (2 if dqkv.dtype == torch.bfloat16 else 0) | (1 if qkv.dtype == torch.bfloat16 else 0),
+                                           (2 if dqkv.dtype == torch.bfloat16 else 0) | (1 if qkv.dtype == torch.bfloat16 else 0) |
+                                           (4 if out.dtype == torch.bfloat16 else 0) | (8 if dout.dtype == torch.bfloat16 else 0),
                                            _stream()), "styler_attention_bwd_bf16")
     else:
         _chk(lib.styler_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),

@@ -69,6 +69,10 @@ class _Runtime:
     # 1 / sqrt(d_k) scale moves from q (before its rounding) to the raw scores (inside the exponent's fma), so q is rounded
     # once as well.  STYLER_BF16_QKV=0: fp32.
     bf16_qkv = os.environ.get("STYLER_BF16_QKV", "1") != "0"
+    # throughput mode: the attention output and the gradient that comes back for it are stored as bf16.  Their GEMM-side
+    # readers (output projection, its weight gradient; the backward's dO operand) round to bf16 anyway; only the backward's
+    # delta = rowsum(dO * O) sees the rounded values.  STYLER_BF16_ATT=0: fp32.
+    bf16_att = os.environ.get("STYLER_BF16_ATT", "1") != "0"
     # training: the last conv -> GroupNorm -> ReLU stage of the AudioEncoder's four streams as ONE tape node that writes into the
     # concatenated buffer (autograd.ConvNormCatFn) instead of four nodes + a concatenation copy (STYLER_FUSED_CAT=0)
     fused_cat = os.environ.get("STYLER_FUSED_CAT", "1") != "0"

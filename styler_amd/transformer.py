@@ -96,7 +96,8 @@ class MultiHeadAttention(_HipModule):
             return (y, y16) if asked else y
         w, b, prec = self._qkv()
         ctx = ops.attention_fwd(ops.conv_gemm(x, w, b, n=768, prec=prec, plan=plan,
-                                              out_bf16=prec == ops.PREC_BF16 and rt.bf16_qkv), lens, plan=plan)
+                                              out_bf16=prec == ops.PREC_BF16 and rt.bf16_qkv), lens, plan=plan,
+                                out_bf16=prec == ops.PREC_BF16 and rt.bf16_att)
         if drop:                                              # dropout + residual + LayerNorm + mask: one kernel
             y = self._ln(self._gemm("fc", ctx, self.fc, plan=plan), x, self.layer_norm, lens, out,
                          drop_p=self.dropout.p if self.training else 0.0)

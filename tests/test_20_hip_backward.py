@@ -148,6 +148,15 @@ def test_attention_backward(dev, B, L, lens):
     assert d_a.dtype == torch.bfloat16 and d_a.shape == d_b.shape
     ea, eb = err(d_a, qr.grad, vq), err(d_b, qr.grad, vq)
     assert ea <= 3e-2 and ea <= 1.5 * eb + 1e-3, (ea, eb)
+    # the forward's output and the incoming gradient stored as bf16 too (rt.bf16_att): the output is the RNE of the fp32 one;
+    # the backward's MFMA operands are unchanged, only delta = rowsum(dO * O) sees rounded values
+    o_c = ops.attention_fwd(q16, ln.to(dev), lse=lse_a, prec=ops.PREC_BF16, out_bf16=True)
+    assert o_c.dtype == torch.bfloat16 and torch.equal(o_c[valid], o_a.to(torch.bfloat16)[valid])
+    gy16 = gy.float().to(dev).to(torch.bfloat16)
+    d_c = ops.attention_bwd(q16, o_c, gy16, lse_a, ln.to(dev), prec=ops.PREC_BF16, out_bf16=True)
+    d_d = ops.attention_bwd(q16, o_a, gy16.float(), lse_a, ln.to(dev), prec=ops.PREC_BF16, out_bf16=True)
+    ec, ed = err(d_c, qr.grad, vq), err(d_d, qr.grad, vq)
+    assert ec <= 3e-2 and ec <= 1.5 * ed + 1e-3, (ec, ed)
 
 
 def test_layernorm_backward(dev):
