@@ -31,5 +31,6 @@ python tools/pmc_summary.py $(find gpurun_out/r03prof/pmc_train -name "*counter_
 rm -rf gpurun_out/r03prof/pmc_train
 timeout 300 python tools/gemm256_bench.py 3 > $O/r03_gemm256_bench.txt 2>&1
 timeout 300 python tools/gemm_bench.py bf16 > $O/r03_gemm_bench.txt 2>&1
+cp $O/r03_pmc_traffic.jsonl $R/profiles/r03_pmc_traffic.jsonl    # the default line below embeds THIS pass as roofline.traffic
 timeout 600 python bench.py > $O/r03_bench_default.json 2> $O/r03_bench_default.err
 cat $O/r03_pmc_traffic.jsonl; head -8 $O/r03_train_bf16_graph_kernel_stats.txt; tail -c 600 $O/r03_bench_default.json
