@@ -15,12 +15,15 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
   const bool res16 = io & STYLER_LN_RES_BF16, yb16 = io & STYLER_LN_Y_BF16, sum16 = io & STYLER_LN_SUM_BF16;
   const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // the row is a wave-uniform scalar (see layernorm_bwd_kernel): row * ld, the item / time split and the length lookup run on
+  // the scalar unit; one-item launches (packed rows: L >= rows) need no division, the others a 32-bit one (rows < 2^31)
+  const int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (row >= rows) return;
   bool masked = false;
   if (len) {
-    const int64_t b = row / L;
-    masked = (row - b * L) >= len[b];
+    uint32_t b = 0, t = (uint32_t)row;
+    if ((int64_t)L < rows) { b = (uint32_t)row / (uint32_t)L; t = (uint32_t)row - b * (uint32_t)L; }
+    masked = (int64_t)t >= len[b];
   }
   if (masked) {
     if (y) stg4(y, row * ldy + lane * 4, make_float4(0.f, 0.f, 0.f, 0.f), yb16);
@@ -89,6 +92,7 @@ extern "C" int styler_add_layernorm(const float* x, int64_t ldx, const float* re
   if ((ldx & 3) || (res && (ldres & 3)) || (y && (ldy & 3)) || (sum_out && (ldsum & 3))) return STYLER_EALIGN;
   if (in_drop_p < 0.f || in_drop_p >= 1.f) return STYLER_EINVAL;
   const int64_t rows = (int64_t)B * L;
+  if (rows >= ((int64_t)1 << 31)) return STYLER_EINVAL;
   hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
                      ldx, res, ldres, gamma, beta, y, ldy, dot_w, dot_b, dot_out, rows, L, len, drop_p, drop_seed,
                      g_styler_drop_epoch, in_drop_p, in_drop_seed, sum_out, ldsum, y16, ldy16, io_flags);
