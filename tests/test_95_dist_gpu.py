@@ -14,6 +14,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# Bound on the gradient of the SECOND optimisation step, two ranks vs one rank accumulating (relative to the largest entry).
+# The first step's gradients agree to fp32 summation order (~1e-6); Adam's first update is lr * g / |g| per entry, so an
+# entry whose gradient is rounding noise can take its step in either direction, and the two runs enter step two with
+# parameters up to 2 lr_1 = 5e-7 apart in those entries.  What that does to the next gradient was measured over eight runs
+# on one box: 5.6e-6 or, when a particular entry flips, 1.96e-5 .. 2.22e-5 (bimodal) -- the 2e-5 this bound used to be sat
+# inside the second mode and failed one run in four.  1e-4 = 4.5x the largest value seen.
+SECOND_STEP_TOL = 1e-4
+
+
 def _run_ranks(tmp_path, mode):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -105,7 +114,7 @@ def test_two_rank_graph_cache_two_steps_different_shapes(tmp_path, ref_state_dic
     windows = [[shard_batch(gb, r["idx"]) for r in (r0, r1)], [shard_batch(gb2, r["idx2"]) for r in (r0, r1)]]
     mean_g, flat_p, lr = _single_rank(ref_state_dict, monkeypatch, windows)
     err_g = float((0.5 * r0["flat_g"] - mean_g).abs().max()) / float(mean_g.abs().max())
-    assert err_g <= 2e-5, err_g
+    assert err_g <= SECOND_STEP_TOL, err_g
     assert lr == r0["lr"]
     assert float((r0["flat_p"] - flat_p).abs().max()) <= 2e-6
 
@@ -125,7 +134,7 @@ def test_two_rank_graph_cache_collective_misses(tmp_path, ref_state_dict, monkey
     windows = [[shard_batch(gb, r["idx"]) for r in (r0, r1)], [shard_batch(gb2, r["idx2"]) for r in (r0, r1)]]
     mean_g, flat_p, lr = _single_rank(ref_state_dict, monkeypatch, windows)
     err_g = float((0.5 * r0["flat_g"] - mean_g).abs().max()) / float(mean_g.abs().max())
-    assert err_g <= 2e-5, err_g
+    assert err_g <= SECOND_STEP_TOL, err_g
     assert float((r0["flat_p"] - flat_p).abs().max()) <= 2e-6
 
 
