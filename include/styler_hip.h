@@ -468,6 +468,11 @@ int styler_wgrad_packed(const float* dz, int64_t lddz, const float* x, int64_t l
                         int64_t stride_n, int64_t stride_c, int64_t stride_j, int rows, int n, int cin,
                         int kw, int prec, void* workspace, int defer_reduce, const int32_t* rowinfo,
                         const int32_t* chunktab, const int64_t* counts, int io_flags, void* stream);
+/* bf16 mode, BOTH operands resident as bf16 (io_flags X | Y), n % 8 == cin % 8 == 0: the operands are fetched by LDS-DMA
+ * into a three-stage ring (wgrad_dma_kernel, gemm_bwd.hip) instead of through registers; same split plan, same partial
+ * tiles bit for bit.  styler_wgrad_dma_config(enabled, stages128): -1 / 0 keep a value (stages128 in {2, 3}: ring depth of
+ * the 128 x 128 Linear tile); returns the previous setting as enabled | (stages128 << 1).  Env: STYLER_WGRAD_DMA=0. */
+int styler_wgrad_dma_config(int enabled, int stages128);
 /* Split count styler_wgrad uses for a shape (workspace = splits * n * kw * cin floats). */
 int styler_wgrad_splits(int B, int L, int n, int cin, int kw, int pad_left, int prec);
 

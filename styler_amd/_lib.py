@@ -62,6 +62,7 @@ _SIGS = {
     "styler_act_bwd": [P, I64, P, I64, P, I64, I, I, I, I, P, P],
     "styler_wgrad": [P, I64, P, I64, P, P, P, I64, I64, I64, I, I, I, I, I, I, I, P, I, I, P],
     "styler_wgrad_splits": [I, I, I, I, I, I, I],
+    "styler_wgrad_dma_config": [I, I],
     "styler_wgrad_reduce_multi": [P, I, I64, P],
     "styler_wgrad_reduce_blocks": [I, I, I, I64, I64],
     "styler_wgrad_workspace_bytes": [I, I, I, I, I, I, I],

@@ -482,6 +482,269 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const void* __restrict__ 
                                        chunks_per_split, tiles, splits, ws, chunktab, counts);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 4: the same engine with its operands fetched by LDS-DMA (buffer_load_dwordx4 ... lds) into a ring of NST stages
+// -- for launches whose BOTH operands already live in HBM as bf16 (the decoder's FFN / attention / projection
+// gradients on the bf16 residual stream, the k = 5 gradients of the AudioEncoder / PostNet stacks: 70 % of the step's
+// weight-gradient time).  What changes against wgrad_tr_body, and only that:
+//   * no staging registers, no ds_write pass, no conversion: a 16-byte piece (8 features of one time row) goes from L2
+//     straight to its slot of the [k/4][f/16][4 rows][16 features] image.  The DMA writes lane l of a piece at
+//     base + 16 l, so the IMAGE order is produced on the SOURCE side: lane l of piece p fetches sub-tile 8p + (l >> 3),
+//     32-byte slot (l & 7) >> 1 = (row + sub-tile) & 3, feature half l & 1 -- the slot rotation that keeps the transpose
+//     reads conflict-free is a per-lane source address, computed once;
+//   * the chunk that is computed was requested NST - 1 iterations earlier: `s_waitcnt vmcnt(pieces still allowed in
+//     flight)` + ONE raw s_barrier per chunk, the refill of the stage read in the previous iteration is issued right
+//     behind that barrier (every wave has left its reads of it), vmcnt never drains inside the loop;
+//   * rows outside the item (ragged last chunk, halo rows before / after the item) and feature columns past the edge
+//     are out of range of the per-chunk buffer descriptor: the DMA writes zeros (as the register loads read zeros);
+//   * the bias gradient has no staging registers to come from: one extra MFMA per A fragment against a vector of ones
+//     (c-tile 0, wave column 0 only) accumulates colsum(dz) in fp32 -- products with 1.0 are exact.
+// compute() is wgrad_tr_body's, on the same LDS image: the partial tiles are BIT-IDENTICAL to the register-staged kernel's
+// for the same split plan (tests/test_91_bf16_acts.py keeps both forms and compares with torch.equal).
+typedef __attribute__((address_space(3))) void wg_lds_void;
+template <int N> __device__ __forceinline__ void wg_vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int KW, int TA, int TB, int NST>
+__device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __restrict__ dz, int64_t lddz,
+                                               const void* __restrict__ x, int64_t ldx, float* __restrict__ db,
+                                               float* __restrict__ db2, int B, int L, int n, int cin, int pad_left, int ct,
+                                               int cpi, int chunks_per_split, int tiles, int splits,
+                                               float* __restrict__ ws, const int4* __restrict__ chunktab,
+                                               const int64_t* __restrict__ counts) {
+  constexpr int FA = 64 * TA, FB = 64 * TB;
+  constexpr int XR = KW == 1 ? 64 : 72;
+  constexpr int NR = (8 + KW - 1 + 3) / 4;
+  constexpr int SA = FA / 16, SB = FB / 16;
+  constexpr int A_BYTES = 64 * FA * 2, B_BYTES = XR * FB * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int PA = A_BYTES / 4096;                 // 1 KB pieces per wave: dz image
+  constexpr int PB = (64 * FB * 2) / 4096;           //                       x image, rows 0..63
+  constexpr bool HALO = KW > 1;                      // rows 64..71 of the x image: one more piece (FB == 64), wave 3's
+  static_assert(!HALO || FB == 64, "the halo piece assumes a 64-feature x tile");
+  constexpr int D = NST - 1;                         // prefetch distance in chunks
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];     // the ONLY LDS object of the kernel
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  int tile, split;
+  if (splits >= 8) {                                 // an XCD owns whole splits (see wgrad_tr_body)
+    const int xcd = bid & 7, k = bid >> 3;
+    split = xcd + 8 * (k / tiles);
+    tile = k % tiles;
+    if (split >= splits) return;
+  } else {
+    tile = bid % tiles;
+    split = bid / tiles;
+  }
+  const int n0 = (tile / ct) * FA, c0 = (tile % ct) * FB;
+  int64_t nchunks = (int64_t)B * cpi;
+  if (counts) {
+    nchunks = chunktab ? counts[1] : (counts[0] + WB_BK - 1) / WB_BK;
+    chunks_per_split = (int)((nchunks + splits - 1) / splits);
+    if (!chunktab) L = (int)counts[0];
+  }
+  const int64_t ch0 = (int64_t)split * chunks_per_split;
+  int64_t ch1 = ch0 + chunks_per_split; if (ch1 > nchunks) ch1 = nchunks;
+  if (ch0 >= ch1 && !counts) return;
+
+  // ---- DMA source offsets (bytes, relative to the chunk's descriptor base), one per piece of this wave ----
+  constexpr uint32_t OOB = 0x80000000u;
+  constexpr int64_t REC_MAX = (int64_t)1 << 30;
+  auto piece_off = [&](int p, int S, int64_t ld, int f0, int flim) -> uint32_t {
+    const int st = 8 * p + (lane >> 3);              // sub-tile of the image
+    const int k4 = st / S, fs = st - k4 * S;
+    const int w = lane & 7, slot = w >> 1, half = w & 1;
+    const int r = (slot - fs) & 3;                   // row r of sub-tile fs sits in 32-byte slot (r + fs) & 3
+    const int row = 4 * k4 + r, feat = f0 + 16 * fs + 8 * half;
+    return feat + 8 <= flim ? (uint32_t)((row * ld + feat) * 2) : OOB;
+  };
+  uint32_t va[PA], vb[PB], vh = OOB;
+#pragma unroll
+  for (int q = 0; q < PA; ++q) va[q] = piece_off(wave + 4 * q, SA, lddz, n0, n);
+#pragma unroll
+  for (int q = 0; q < PB; ++q) vb[q] = piece_off(wave + 4 * q, SB, ldx, c0, cin);
+  if (HALO) vh = piece_off(4 * PB, SB, ldx, c0, cin);
+  const uint32_t lds_w = (uint32_t)wave * 1024u;
+
+  // chunk table entry of chunk `ch` (packed / item-aligned chunks), fetched one iteration before it is needed: the scalar
+  // load's latency would otherwise sit between the barrier and the DMA issue of every iteration
+  auto entry = [&](int ch) -> int4 {
+    return (chunktab && ch < (int)ch1) ? chunktab[ch] : make_int4(0, 0, 0, 0);
+  };
+  auto issue = [&](int ch, int stage, const int4 e) {
+    int t0, Li;
+    int64_t rowb;
+    if (chunktab) {
+      t0 = e.y; Li = e.z; rowb = e.x - e.y;
+    } else {
+      const int b = ch / cpi;
+      t0 = (ch - b * cpi) * WB_BK; Li = L; rowb = (int64_t)b * L;
+    }
+    const int tx = t0 - pad_left;
+    const int txb = tx > 0 ? tx : 0;
+    int64_t a_rec = ((int64_t)(Li - t0 - 1) * lddz + n) * 2;
+    int64_t b_rec = ((int64_t)(Li - txb - 1) * ldx + cin) * 2;
+    a_rec = a_rec > REC_MAX ? REC_MAX : a_rec;
+    b_rec = b_rec > REC_MAX ? REC_MAX : (b_rec < 0 ? 0 : b_rec);
+    const char* a_base = reinterpret_cast<const char*>(dz) + (rowb + t0) * lddz * 2;
+    const char* b_base = reinterpret_cast<const char*>(x) + (rowb + txb) * ldx * 2;
+    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a_base), 0, (int)a_rec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b_base), 0, (int)b_rec, 0x00020000);
+    const uint32_t b_off = (uint32_t)((tx - txb) * (int)ldx * 2);        // <= 0: rows before the item wrap out of range
+    unsigned char* sa = smem + stage * STAGE + lds_w;
+    unsigned char* sb = smem + stage * STAGE + A_BYTES + lds_w;
+#pragma unroll
+    for (int q = 0; q < PA; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_rsrc, (wg_lds_void*)(sa + q * 4096), 16, va[q], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_rsrc, (wg_lds_void*)(sb + q * 4096), 16, vb[q] + b_off, 0, 0, 0);
+    if (HALO && wave == 3)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_rsrc, (wg_lds_void*)(smem + stage * STAGE + A_BYTES + 4 * PB * 1024), 16,
+                                               vh + b_off, 0, 0, 0);
+  };
+
+  // ---- fragment read coordinates (wgrad_tr_body's) ----
+  const int q16 = lane & 15, chf = (lane >> 4) & 1;
+  uint32_t fa_off[TA], fb_off[TB];
+#pragma unroll
+  for (int i = 0; i < TA; ++i) {
+    const int fs = 2 * (wm * TA + i) + chf;
+    fa_off[i] = (lh * 2 * SA + fs) * 64 + (((q16 >> 2) + fs) & 3) * 16 + (q16 & 3) * 4;
+  }
+#pragma unroll
+  for (int i = 0; i < TB; ++i) {
+    const int fs = 2 * (wn * TB + i) + chf;
+    fb_off[i] = (lh * 2 * SB + fs) * 64 + (((q16 >> 2) + fs) & 3) * 16 + (q16 & 3) * 4;
+  }
+
+  f32x16 acc[TA][TB][KW];
+  f32x16 accb[TA];
+#pragma unroll
+  for (int i = 0; i < TA; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < TB; ++jt)
+#pragma unroll
+      for (int j = 0; j < KW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][jt][j][r] = 0.f;
+  }
+  const bool do_bias = db && (tile % ct) == 0 && wn == 0;
+  const uint4 ones4 = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+  const bf16x8 ones = *reinterpret_cast<const bf16x8*>(&ones4);
+
+  auto compute = [&](int stage) {
+    const uint16_t* pa = reinterpret_cast<const uint16_t*>(smem + stage * STAGE);
+    const uint16_t* pb = reinterpret_cast<const uint16_t*>(smem + stage * STAGE + A_BYTES);
+#pragma unroll
+    for (int s = 0; s < WB_BK / 16; ++s) {
+      bf16x8 fa[TA];
+#pragma unroll
+      for (int i = 0; i < TA; ++i) {
+        const uint2 lo = lds_tr_read(pa + fa_off[i] + (s * 4 + 0) * SA * 64);
+        const uint2 hi = lds_tr_read(pa + fa_off[i] + (s * 4 + 1) * SA * 64);
+        const uint4 a4 = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        fa[i] = *reinterpret_cast<const bf16x8*>(&a4);
+      }
+#pragma unroll
+      for (int jt = 0; jt < TB; ++jt) {
+        uint32_t win[2 * NR + 1];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const uint2 v = lds_tr_read(pb + fb_off[jt] + (s * 4 + r) * SB * 64);
+          win[2 * r] = v.x; win[2 * r + 1] = v.y;
+        }
+        win[2 * NR] = 0u;
+#pragma unroll
+        for (int j = 0; j < KW; ++j) {
+          uint4 b4;
+          const int o = j / 2;
+          if ((j & 1) == 0) {
+            b4 = make_uint4(win[o], win[o + 1], win[o + 2], win[o + 3]);
+          } else {
+            b4 = make_uint4(__builtin_amdgcn_alignbit(win[o + 1], win[o], 16), __builtin_amdgcn_alignbit(win[o + 2], win[o + 1], 16),
+                            __builtin_amdgcn_alignbit(win[o + 3], win[o + 2], 16), __builtin_amdgcn_alignbit(win[o + 4], win[o + 3], 16));
+          }
+          const bf16x8 fb = *reinterpret_cast<const bf16x8*>(&b4);
+#pragma unroll
+          for (int i = 0; i < TA; ++i) acc[i][jt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb, acc[i][jt][j], 0, 0, 0);
+        }
+      }
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < TA; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, accb[i], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- the ring ----
+  const int ich0 = (int)ch0, nch = (int)(ch1 - ch0);
+  constexpr int PW = PA + PB;                        // pieces per chunk of waves 0..2 (wave 3: + the halo piece)
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < nch) issue(ich0 + d, d, entry(ich0 + d));
+  int4 e_next = entry(ich0 + D);
+  int st_c = 0, st_i = D % NST;                      // stage computed / stage refilled in the current iteration
+  for (int i = 0; i < nch; ++i) {
+    const int rem = nch - 1 - i < D - 1 ? nch - 1 - i : D - 1;          // chunks requested after chunk i
+    if (HALO && wave == 3) {
+      if (rem >= 2) wg_vm_wait<2 * (PW + 1)>(); else if (rem == 1) wg_vm_wait<PW + 1>(); else wg_vm_wait<0>();
+    } else {
+      if (rem >= 2) wg_vm_wait<2 * PW>(); else if (rem == 1) wg_vm_wait<PW>(); else wg_vm_wait<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + D < nch) {                               // the stage read in iteration i - 1: every wave is past those reads
+      issue(ich0 + i + D, st_i, e_next);
+      e_next = entry(ich0 + i + D + 1);
+    }
+    compute(st_c);
+    st_c = st_c + 1 == NST ? 0 : st_c + 1;
+    st_i = st_i + 1 == NST ? 0 : st_i + 1;
+  }
+  // partial tile -> workspace [split][n][KW][cin] (as wgrad_tr_body)
+  float* wp = ws + (int64_t)split * n * KW * cin;
+#pragma unroll
+  for (int jt = 0; jt < TB; ++jt) {
+    const int c = c0 + (wn * TB + jt) * 32 + li;
+    if (c >= cin) continue;
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+      for (int j = 0; j < KW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int nn = n0 + (wm * TA + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (nn < n) wp[((int64_t)nn * KW + j) * cin + c] = acc[i][jt][j][r];
+        }
+  }
+  if (do_bias && li == 0) {                          // every column of accb holds the row sums: lanes 0 / 32 own 16 rows each
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nn = n0 + (wm * TA + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (nn < n) {
+          atomicAdd(db + nn, accb[i][r]);
+          if (db2) atomicAdd(db2 + nn, accb[i][r]);
+        }
+      }
+  }
+}
+
+template <int KW, int TA, int TB, int NST>
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(const void* __restrict__ dz, int64_t lddz,
+                                                        const void* __restrict__ x, int64_t ldx,
+                                                        float* __restrict__ db, float* __restrict__ db2, int B, int L,
+                                                        int n, int cin, int pad_left, int ct, int cpi,
+                                                        int chunks_per_split, int tiles, int splits,
+                                                        float* __restrict__ ws, const int4* __restrict__ chunktab,
+                                                        const int64_t* __restrict__ counts) {
+  wgrad_dma_body<KW, TA, TB, NST>(blockIdx.x, dz, lddz, x, ldx, db, db2, B, L, n, cin, pad_left, ct, cpi,
+                                  chunks_per_split, tiles, splits, ws, chunktab, counts);
+}
+
 // Many weight gradients in ONE launch.  Launched one by one, a weight gradient is alone on the chip and needs >= 2 blocks
 // per CU of its own: 8..37 split-K partial tiles per output tile (2 GB of partials per training step).  As members of
 // one launch per kernel variant the gradients of a whole backward pass fill the chip together, so a member needs only
@@ -573,6 +836,17 @@ extern "C" int64_t styler_wgrad_workspace_bytes(int B, int L, int n, int cin, in
   return (int64_t)splits * n * kw * cin * 4;
 }
 
+// The LDS-DMA ring for bf16-resident operands (wgrad_dma_kernel): on by default, STYLER_WGRAD_DMA=0 / styler_wgrad_dma_config
+// select the register-staged kernel (same partial tiles bit for bit: the A/B switch of the parity tests and of the bench).
+static int g_wgrad_dma = [] { const char* e = getenv("STYLER_WGRAD_DMA"); return (!e || atoi(e) != 0) ? 1 : 0; }();
+static int g_wgrad_dma_nst128 = [] { const char* e = getenv("STYLER_WGRAD_DMA_NST128"); return e ? atoi(e) : 2; }();
+extern "C" int styler_wgrad_dma_config(int enabled, int stages128) {
+  const int prev = g_wgrad_dma | (g_wgrad_dma_nst128 << 1);
+  if (enabled >= 0) g_wgrad_dma = enabled ? 1 : 0;
+  if (stages128 == 2 || stages128 == 3) g_wgrad_dma_nst128 = stages128;
+  return prev;
+}
+
 static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db, float* db2,
                       int64_t stride_n, int64_t stride_c, int64_t stride_j, int B, int L, int n, int cin, int kw,
                       int pad_left, int prec, void* workspace, int defer_reduce, const int32_t* rowinfo,
@@ -602,6 +876,19 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
 #define WT_LAUNCH(K, A_, B_) hipLaunchKernelGGL((wgrad_tr_kernel<K, A_, B_>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, \
                                                 db2, Be, Le, n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, \
                                                 kw > 1 ? reinterpret_cast<const int4*>(chunktab) : nullptr, counts)
+    // both operands bf16-resident, rows and feature counts in whole 16-byte pieces: the LDS-DMA ring (wgrad_dma_kernel)
+    const bool dma = g_wgrad_dma && dz16 && x16 && !(n & 7) && !(cin & 7) && !((uintptr_t)dz & 15) && !((uintptr_t)x & 15);
+#define WD_LAUNCH(K, A_, B_, S_) hipLaunchKernelGGL((wgrad_dma_kernel<K, A_, B_, S_>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, \
+                                                    db, db2, Be, Le, n, cin, pad_left, ct, cpi, cps, tiles, splits, ws,        \
+                                                    kw > 1 ? reinterpret_cast<const int4*>(chunktab) : nullptr, counts)
+    if (dma && kw == 1 && TA == 2 && TB == 2) {
+      if (g_wgrad_dma_nst128 == 3) WD_LAUNCH(1, 2, 2, 3); else WD_LAUNCH(1, 2, 2, 2);
+    } else if (dma && kw == 5 && TA == 1 && TB == 1) {
+      WD_LAUNCH(5, 1, 1, 3);
+    } else if (dma && kw == 9 && TA == 1 && TB == 1) {
+      WD_LAUNCH(9, 1, 1, 3);
+    } else
+#undef WD_LAUNCH
     if (kw == 1) {
       if (x16 || dz16) {                             // (x16: the FFN hidden activation; dz16: the attention's dqkv)
         if (TA != 2 || TB != 2) return STYLER_EINVAL;
