@@ -103,8 +103,9 @@ def run(args, mode, prec, rank, world, dev, dist, with_cpu=True, with_roofline=T
     use_graph = (not args.no_graph) and not train
     state = None
     if train:
-        from styler_amd.training import GraphedTrainStep, TrainState, train_step
+        from styler_amd.training import GraphedTrainStep, TrainState, add_pair_inputs, train_step
         state = TrainState(model)
+        add_pair_inputs(bd)                    # the feed's layout of the AudioEncoder inputs (data.BatchFeeder collates it)
 
     def step():
         if train:

@@ -368,6 +368,17 @@ int styler_add2(const float* a, int64_t lda, const float* b, int64_t ldb, float*
                 int64_t ldy, int64_t rows, int C, void* stream);
 int styler_add_rowvec(const float* a, int64_t lda, const float* v, int64_t ldv, float* y,
                       int64_t ldy, int B, int L, int C, void* stream);
+/* Up to 8 strided row copies in one launch (the descriptors travel in the kernel arguments): segment k copies `rows` rows of
+ * `C` floats (C % 4 == 0) from src (row stride ld_src; NULL = zero fill) to dst (row stride ld_dst).  The torch.cat /
+ * torch.split plumbing of modules.py:218-223,350,362 and the gathered slice gradients of their backward: one launch per
+ * concatenation instead of one copy per part. */
+typedef struct StylerCopySeg {
+  const void* src;
+  void* dst;
+  int64_t ld_src, ld_dst, rows;
+  int32_t C, _pad;
+} StylerCopySeg;
+int styler_copy_rows_multi(const StylerCopySeg* segs, int count, void* stream);
 /* y = leaky_relu(scale * (a (+ b) (+ c)), slope) over `count` contiguous floats: the pre-activation of every vocoder
  * conv (hifigan/models.py:96,98,157) fused with the resblock average `xs / num_kernels` (164). */
 int styler_leaky_sum(const float* a, const float* b, const float* c, float* y, int64_t count,

@@ -56,6 +56,7 @@ _SIGS = {
     "styler_length_regulate": [P, I64, P, P, I64, P, I, I, I, I, P],
     "styler_bucket_embed_add": [P, I64, P, I64, P, F, P, F, P, P, P, P, P, P, I64, P, P, P, I, I, P],
     "styler_add2": [P, I64, P, I64, P, I64, I64, I, P],
+    "styler_copy_rows_multi": [P, I, P],
     "styler_add_rowvec": [P, I64, P, I64, P, I64, I, I, I, P],
     "styler_length_mask": [P, P, I, I, P],
     "styler_masked_err_sum": [P, I64, P, I64, P, I, I, I, I, P, P],
@@ -120,6 +121,11 @@ class WgradGroupDesc(ctypes.Structure):
                 ("lddz", ctypes.c_int64), ("ldx", ctypes.c_int64)] + \
                [(k, ctypes.c_int32) for k in ("B", "L", "n", "cin", "pad_left", "ct", "cpi", "cps", "tiles", "splits",
                                               "block_start", "nblocks", "variant", "kw")]
+
+
+class CopySeg(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("ld_src", ctypes.c_int64), ("ld_dst", ctypes.c_int64),
+                ("rows", ctypes.c_int64), ("C", ctypes.c_int32), ("_pad", ctypes.c_int32)]
 
 
 class CopyDesc(ctypes.Structure):

@@ -352,6 +352,52 @@ extern "C" int styler_add_rowvec(const float* a, int64_t lda, const float* v, in
   return launch_status();
 }
 
+// ---- up to 8 strided row copies in ONE launch (round 4: the launch tail) -------------------------------------------
+// Segment k copies rows_k rows of C_k floats from src_k (row stride lds_k; NULL = zeros) to dst_k (row stride ldd_k).  The
+// segments travel BY VALUE in the kernel arguments (no descriptor table to upload -- inside a captured hipGraph a table
+// upload is a memcpy node with 6-8 us of idle time in front of it).  Replaces the per-slice copy launches of the
+// concatenations / gathered slice gradients of autograd.py (SplitBatchFn: two aten copy_ = two memcpy nodes per call).
+struct CopySegs {
+  const float* src[8];
+  float* dst[8];
+  int64_t lds[8], ldd[8], rows[8];
+  int32_t C[8];
+  int32_t n;
+};
+__global__ __launch_bounds__(256) void copy_rows_multi_kernel(const CopySegs g) {
+  const int k = blockIdx.y;
+  if (k >= g.n) return;
+  const float* __restrict__ src = g.src[k];
+  float* __restrict__ dst = g.dst[k];
+  const int nq = g.C[k] / 4;
+  const int64_t total = g.rows[k] * nq, lds = g.lds[k], ldd = g.ldd[k];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / nq; const int q = (int)(i - row * nq);
+    const float4 v = src ? *reinterpret_cast<const float4*>(src + row * lds + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(dst + row * ldd + q * 4) = v;
+  }
+}
+
+extern "C" int styler_copy_rows_multi(const StylerCopySeg* segs, int count, void* stream) {
+  if (!segs || count <= 0 || count > 8) return STYLER_EINVAL;
+  CopySegs g;
+  int64_t most = 0;
+  for (int k = 0; k < count; ++k) {
+    const StylerCopySeg& s = segs[k];
+    if (!s.dst || s.rows <= 0 || s.C <= 0 || (s.C & 3)) return STYLER_EINVAL;
+    if ((s.ld_src & 3) || (s.ld_dst & 3) || ((uintptr_t)s.src & 15) || ((uintptr_t)s.dst & 15)) return STYLER_EALIGN;
+    g.src[k] = reinterpret_cast<const float*>(s.src); g.dst[k] = reinterpret_cast<float*>(s.dst);
+    g.lds[k] = s.ld_src; g.ldd[k] = s.ld_dst; g.rows[k] = s.rows; g.C[k] = s.C;
+    const int64_t t = s.rows * (s.C / 4);
+    most = t > most ? t : most;
+  }
+  g.n = count;
+  int64_t bx = (most + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(copy_rows_multi_kernel, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, (hipStream_t)stream, g);
+  return launch_status();
+}
+
 // ---- masked error sums ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void masked_err_kernel(const float* __restrict__ a, int64_t lda,
                                                          const float* __restrict__ b, int64_t ldb,

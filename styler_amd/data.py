@@ -54,7 +54,8 @@ def collate_fn(batch, sort=True):
     return [reprocess(batch, c) for c in cuts]
 
 
-_DTYPES = {"text": torch.long, "D": torch.long, "src_len": torch.long, "mel_len": torch.long}
+_DTYPES = {"text": torch.long, "D": torch.long, "src_len": torch.long, "mel_len": torch.long,
+           "pair_src_len": torch.long, "pair_mel_len": torch.long}
 
 
 def bucket_up(n, step, cap=hp.max_seq_len + 1):
@@ -85,7 +86,12 @@ def pad_to_rectangle(sub_batch, S, T):
     return out
 
 
-def to_device(sub_batch, device, pinned=True, bucket=None):
+_PAIRS = (("pair_mel", "mel_target", "mel_aug"), ("pair_f0n", "f0_norm", "f0_norm_aug"),
+          ("pair_ein", "energy_input", "energy_input_aug"), ("pair_mela", "mel_aug", "mel_aug"),
+          ("pair_mel_len", "mel_len", "mel_len"), ("pair_src_len", "src_len", "src_len"))
+
+
+def to_device(sub_batch, device, pinned=True, bucket=None, pairs=False):
     """train.py:107-132 in one shot: numpy -> pinned host tensors -> non-blocking H2D on the current stream.
     Returns (tensors dict, max_src_len, max_mel_len).  `bucket` = (s_step, t_step): pad the rectangle up to multiples of
     the steps, so that a few hipGraphs (training.GraphedStepCache) cover every batch of an epoch; the returned maxima are
@@ -94,6 +100,10 @@ def to_device(sub_batch, device, pinned=True, bucket=None):
     if bucket is not None:
         S, T = bucket_up(S, bucket[0]), bucket_up(T, bucket[1])
         sub_batch = pad_to_rectangle(sub_batch, S, T)
+    if pairs:                                      # the stacked [2B, ...] AudioEncoder inputs (training.add_pair_inputs) are a
+        sub_batch = dict(sub_batch)                # host-side collate layout: no concatenation kernels inside the step
+        for k, a, b in _PAIRS:
+            sub_batch[k] = np.concatenate([sub_batch[a], sub_batch[b]], axis=0)
     out = {}
     for k, v in sub_batch.items():
         if k == "id":
@@ -161,7 +171,8 @@ class BatchFeeder:
     sub-batches ahead and stages them through pinned memory on a copy stream, so the consumer never waits on `np.load`,
     padding or the H2D copies.  Iterating yields `(tensors, max_src_len, max_mel_len)` like `to_device`."""
 
-    def __init__(self, store, device, batch_size=None, rank=0, world=1, shuffle=True, seed=0, depth=4, bucket=None):
+    def __init__(self, store, device, batch_size=None, rank=0, world=1, shuffle=True, seed=0, depth=4, bucket=None,
+                 pairs=False):
         self.store, self.device = store, torch.device(device)
         self.batch_size = hp.batch_size if batch_size is None else batch_size
         self.rank, self.world, self.shuffle, self.seed, self.depth = rank, world, shuffle, seed, depth
@@ -169,6 +180,7 @@ class BatchFeeder:
         # yields a different (S, T) for nearly every sub-batch; a graphed step is captured per shape, so without buckets it
         # would be captured once and never replayed (training.GraphedStepCache)
         self.bucket = bucket
+        self.pairs = pairs                         # also collate the stacked AudioEncoder inputs (to_device)
         self.epoch = 0
 
     def groups(self):
@@ -192,11 +204,11 @@ class BatchFeeder:
                         return
                     if use_cuda:
                         with torch.cuda.stream(copy_stream):
-                            out = to_device(sub, self.device, pinned=True, bucket=self.bucket)
+                            out = to_device(sub, self.device, pinned=True, bucket=self.bucket, pairs=self.pairs)
                             ready = torch.cuda.Event()
                             ready.record(copy_stream)
                     else:
-                        out, ready = to_device(sub, self.device, pinned=False, bucket=self.bucket), None
+                        out, ready = to_device(sub, self.device, pinned=False, bucket=self.bucket, pairs=self.pairs), None
                     q.put((out, ready))
             q.put(None)
         except BaseException as e:                     # surface reader errors in the consumer

@@ -235,10 +235,17 @@ class StyleEncoder(_HipModule):
             # energy_input_aug, mel_aug); every op in it is per item, so both passes are one batch of 2B items (one BiLSTM
             # chain instead of two; test_experimental_switches_match_default pins it to the two-pass result)
             B = mel_target.shape[0]
-            enc_cat = self.encoder_input_cat(torch.cat([mel_target, dat[0]]), torch.cat([p_norm, dat[1]]),
-                                             torch.cat([e_input, dat[2]]), torch.cat([mel_aug, dat[0]]))
-            d, p, e, n = self.audio_encoder(enc_cat, torch.cat([mel_len, mel_len]), torch.cat([src_len, src_len]),
-                                            mask=None, max_seq_len=text.shape[1])
+            pr = dat[3] if len(dat) > 3 else None
+            if pr is not None:
+                # the stacked [2B, ...] inputs come with the batch (training.add_pair_inputs / the feeder's collate): no
+                # concatenation kernels on the step (six aten cat launches behind idle gaps: 55 us per step)
+                enc_cat = self.encoder_input_cat(pr["pair_mel"], pr["pair_f0n"], pr["pair_ein"], pr["pair_mela"])
+                len2, src2 = pr["pair_mel_len"], pr["pair_src_len"]
+            else:
+                enc_cat = self.encoder_input_cat(torch.cat([mel_target, dat[0]]), torch.cat([p_norm, dat[1]]),
+                                                 torch.cat([e_input, dat[2]]), torch.cat([mel_aug, dat[0]]))
+                len2, src2 = torch.cat([mel_len, mel_len]), torch.cat([src_len, src_len])
+            d, p, e, n = self.audio_encoder(enc_cat, len2, src2, mask=None, max_seq_len=text.shape[1])
             (d, d2), (p, p2), (e, e2) = (AG.SplitBatchFn.apply(t) for t in (d, p, e))
             self.dat_encodings = (d2, p2, e2)
             n = n[:B]                                  # the DAT pass has no use for the noise stream (train.py:150-153)

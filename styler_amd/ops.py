@@ -723,6 +723,26 @@ def add2(a, b, out=None):
     return out
 
 
+def copy_rows_multi(pairs):
+    """[(src or None, dst), ...] (<= 8 per launch): dst[..] = src[..] (zeros for None) over [.., C] fp32 views with contiguous
+    channels -- ONE launch for all parts of a concatenation / gathered slice gradient (styler_copy_rows_multi)."""
+    import ctypes
+    from ._lib import CopySeg
+    for i in range(0, len(pairs), 8):
+        part = pairs[i:i + 8]
+        arr = (CopySeg * len(part))()
+        for k, (src, dst) in enumerate(part):
+            C = dst.shape[-1]
+            assert dst.dtype == torch.float32 and (src is None or (src.dtype == torch.float32 and src.shape == dst.shape))
+            arr[k].src = src.data_ptr() if src is not None else None
+            arr[k].dst = dst.data_ptr()
+            arr[k].ld_src = (_ld(src) if src.dim() > 1 else C) if src is not None else 0
+            arr[k].ld_dst = _ld(dst) if dst.dim() > 1 else C
+            arr[k].rows = dst.numel() // C
+            arr[k].C = C
+        _chk(lib.styler_copy_rows_multi(arr, len(part), _stream()), "styler_copy_rows_multi")
+
+
 def add_rowvec(a, v, L, out=None):
     """out[b,t,:] = (a[b,t,:] if a is not None else 0) + v[b,:]"""
     B, C = v.shape

@@ -13,6 +13,7 @@ class _Runtime:
         self.base_seed = 0              # train.py:22 seeds torch with 0
         self.seed = 0                   # dropout stream seed of this process: base_seed * world + rank (TrainState)
         self.dropout_calls = 0          # per-call counter mixed into the seed
+        self.pair_lens = None           # (mel_len, stacked [2B] copy) of the batch in flight (training.train_losses)
         self.disable_dropout = False    # parity tests: train-mode BatchNorm / tape, dropout off (RNG streams
                                         # of the reference cannot be reproduced)
 

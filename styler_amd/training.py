@@ -172,6 +172,22 @@ def _seed_grad(value, device):
     return _seed_cache[key]
 
 
+PAIR_KEYS = {"pair_mel": ("mel_target", "mel_aug"), "pair_f0n": ("f0_norm", "f0_norm_aug"),
+             "pair_ein": ("energy_input", "energy_input_aug"), "pair_mela": ("mel_aug", "mel_aug"),
+             "pair_mel_len": ("mel_len", "mel_len"), "pair_src_len": ("src_len", "src_len")}
+
+
+def add_pair_inputs(batch):
+    """The stacked [2B, ...] inputs of the AudioEncoder's combined main + DAT pass (rt.pair_audio; train.py:135-136 and
+    149-150 feed the same module with (mel_target, f0_norm, energy_input, mel_aug) and with (mel_aug, f0_norm_aug,
+    energy_input_aug, mel_aug)) as part of the batch: a layout the FEED produces once per batch (data.BatchFeeder collates
+    into it), not six concatenation kernels inside every step.  Adds the keys in place; returns the batch."""
+    for k, (a, b) in PAIR_KEYS.items():
+        if k not in batch:
+            batch[k] = torch.cat([batch[a], batch[b]])
+    return batch
+
+
 def train_losses(model, batch, loss_fn=None, dat_fn=None):
     """The ten scalars of one step (total first), train.py:135-160.  `batch` holds CUDA tensors."""
     loss_fn = loss_fn or STYLERLoss()
@@ -181,10 +197,15 @@ def train_losses(model, batch, loss_fn=None, dat_fn=None):
     dev = batch["text"].device
     se = model.style_modeling.style_encoder
     if rt.pair_audio:
-        se.dat_inputs = (batch["mel_aug"], batch["f0_norm_aug"], batch["energy_input_aug"])
-    out = model(batch["text"], batch["mel_target"], batch["mel_aug"], batch["f0_norm"], batch["energy_input"],
-                batch["src_len"], batch["mel_len"], batch["D"], batch["f0"], batch["energy"], S, T,
-                speaker_embed=batch["speaker_embed"])
+        se.dat_inputs = (batch["mel_aug"], batch["f0_norm_aug"], batch["energy_input_aug"],
+                         batch if "pair_mel" in batch else None)
+    rt.pair_lens = (batch["mel_len"], batch["pair_mel_len"]) if "pair_mel_len" in batch else None
+    try:
+        out = model(batch["text"], batch["mel_target"], batch["mel_aug"], batch["f0_norm"], batch["energy_input"],
+                    batch["src_len"], batch["mel_len"], batch["D"], batch["f0"], batch["energy"], S, T,
+                    speaker_embed=batch["speaker_embed"])
+    finally:
+        rt.pair_lens = None
     (mel, mel_n), (post, post_n), log_d, p_pred, e_pred, src_mask, mel_mask, _, aug = out
     # labels of train.py:139,152 (zeros for the clean pass, ones for the DAT pass): passed as python ints, the NLL kernel
     # needs no label tensor then; the masks are consumed as lengths (loss.py docstring), so no ~mask launches either
@@ -272,6 +293,8 @@ class GraphedTrainStep:
         import torch.distributed as dist
         self.model, self.state = model, state
         self.static = {k: v.clone() for k, v in batch.items()}
+        if rt.pair_audio:
+            add_pair_inputs(self.static)                      # the stacked AudioEncoder inputs: static buffers of the graph
         if split is None:
             split = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         if hp.acc_steps != 1:
@@ -387,6 +410,11 @@ class GraphedTrainStep:
                     raise ValueError(f"GraphedTrainStep was captured for {k} of shape {tuple(self.static[k].shape)}, "
                                      f"got {tuple(v.shape)}")
                 self.static[k].copy_(v, non_blocking=True)
+            if rt.pair_audio and "pair_mel" not in batch:     # a feed that does not collate the stacked layout itself
+                B = batch["text"].shape[0]
+                for k, (a, b) in PAIR_KEYS.items():
+                    self.static[k][:B].copy_(batch[a], non_blocking=True)
+                    self.static[k][B:].copy_(batch[b], non_blocking=True)
         st = self.state
         st._accum = 1                                   # the captured pass starts with its own zero_grad
         self.graphs[0].replay()

@@ -233,7 +233,9 @@ class Decoder(nn.Module, _PositionMixin):
         B, T, _ = seq_a.shape
         pe = self._pe(T, seq_a.device)
         tape = (self.training and torch.is_grad_enabled()) and (seq_a.requires_grad or seq_b.requires_grad)
-        plan = ops.PackPlan(torch.cat([lens, lens]), 2 * B, T)
+        pl = getattr(rt, "pair_lens", None)            # (mel_len, its stacked copy) of the current batch, training.train_losses
+        lens2 = pl[1] if (pl is not None and pl[0] is lens) else torch.cat([lens, lens])
+        plan = ops.PackPlan(lens2, 2 * B, T)
         s16 = rt.bf16_stream and rt.prec == ops.PREC_BF16
         x = (AG.PackPairFn.apply(seq_a, seq_b, pe, plan, s16) if tape
              else ops.pack_rows_pair(seq_a, seq_b, plan, add=pe, out_bf16=s16))

@@ -742,6 +742,32 @@ def test_c4_long_form_shape(dev, model, O, ref_state_dict):
     assert fr[0][0].shape[1] == int(fr[7].max())
 
 
+def test_c4_long_form_shape_bf16(dev, model, O, ref_state_dict):
+    """The arithmetic bench.py's `aux.forward_c4` leg is timed in -- bf16 throughput mode, dual branch -- at the config-4
+    shape (S = 300, T = 2000: 2000-key softmax rows, the position table regenerated for L > 1000, long-form PostNet):
+    two utterances against the oracle with the bf16 bounds of the VCTK-shape test above (max error / max |ref| <= 0.15,
+    relative L2 <= 2e-2), both decode branches; lengths and masks are integer work and stay exact."""
+    from closed_form import make_batch
+    from styler_amd import rt
+    b2 = make_batch(2, 300, 300, 5, 8, seed=401, fix_src=300, fix_mel=2000)
+    S, Tm = 300, 2000
+    with torch.no_grad():
+        ref = O.styler_forward(ref_state_dict, b2["text"], b2["mel_target"], b2["mel_aug"], b2["f0_norm"],
+                               b2["energy_input"], b2["src_len"], b2["mel_len"], b2["D"], b2["f0"], b2["energy"], S, Tm,
+                               speaker_embed=b2["speaker_embed"])
+        rt.set_precision("bf16")
+        try:
+            out = _forward(model, _to(b2, dev))
+        finally:
+            rt.set_precision("fp32")
+    for br, name in ((0, "clean"), (1, "noisy")):
+        check(out[0][br], ref[0][br], 0.15, f"C4 bf16 mel ({name})")
+        check(out[1][br], ref[1][br], 0.15, f"C4 bf16 postnet mel ({name})")
+        rel = float((out[1][br].cpu() - ref[1][br]).norm() / ref[1][br].norm())
+        assert rel < 2e-2, f"C4 bf16 {name} branch relative L2 error {rel}"
+    assert torch.equal(out[7].cpu(), ref[7]) and torch.equal(out[6].cpu(), ref[6]) and torch.equal(out[5].cpu(), ref[5])
+
+
 # ----------------------------------------------------------------------------- vocoder (SURVEY 8f-4)
 @pytest.mark.gpu
 @pytest.mark.parametrize("L,cin,n,kw,pad,d,act", [
