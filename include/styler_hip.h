@@ -480,10 +480,16 @@ int styler_wgrad_packed(const float* dz, int64_t lddz, const float* x, int64_t l
                         int kw, int prec, void* workspace, int defer_reduce, const int32_t* rowinfo,
                         const int32_t* chunktab, const int64_t* counts, int io_flags, void* stream);
 /* bf16 mode, BOTH operands resident as bf16 (io_flags X | Y), n % 8 == cin % 8 == 0: the operands are fetched by LDS-DMA
- * into a three-stage ring (wgrad_dma_kernel, gemm_bwd.hip) instead of through registers; same split plan, same partial
- * tiles bit for bit.  styler_wgrad_dma_config(enabled, stages128): -1 / 0 keep a value (stages128 in {2, 3}: ring depth of
- * the 128 x 128 Linear tile); returns the previous setting as enabled | (stages128 << 1).  Env: STYLER_WGRAD_DMA=0. */
-int styler_wgrad_dma_config(int enabled, int stages128);
+ * into a ring of stages (wgrad_dma_kernel, gemm_bwd.hip) instead of through registers.
+ * styler_wgrad_dma_config(mode, stages128): mode 2 (default) = 512-thread blocks of two K groups that add their
+ * accumulators through LDS, i.e. HALF the split-K partial tiles of the other kernels; 1 = 256-thread blocks with the
+ * register-staged kernel's split plan and its partial tiles bit for bit; 0 = the register-staged kernel; -1 keeps the
+ * value.  stages128 in {2, 3}: ring depth of the 128 x 128 Linear tile in mode 1 (0 keeps it).  Returns the previous
+ * setting as mode | (stages128 << 2).  Env: STYLER_WGRAD_DMA=0|1|2.  The split count / workspace of a launch depend on its
+ * operand formats: use the _io forms below with the io_flags the launch will be given. */
+int styler_wgrad_dma_config(int mode, int stages128);
+int styler_wgrad_splits_io(int B, int L, int n, int cin, int kw, int pad_left, int prec, int io_flags);
+int64_t styler_wgrad_workspace_bytes_io(int B, int L, int n, int cin, int kw, int pad_left, int prec, int io_flags);
 /* Split count styler_wgrad uses for a shape (workspace = splits * n * kw * cin floats). */
 int styler_wgrad_splits(int B, int L, int n, int cin, int kw, int pad_left, int prec);
 

@@ -64,6 +64,8 @@ _SIGS = {
     "styler_wgrad": [P, I64, P, I64, P, P, P, I64, I64, I64, I, I, I, I, I, I, I, P, I, I, P],
     "styler_wgrad_splits": [I, I, I, I, I, I, I],
     "styler_wgrad_dma_config": [I, I],
+    "styler_wgrad_splits_io": [I, I, I, I, I, I, I, I],
+    "styler_wgrad_workspace_bytes_io": [I, I, I, I, I, I, I, I],
     "styler_wgrad_reduce_multi": [P, I, I64, P],
     "styler_wgrad_reduce_blocks": [I, I, I, I64, I64],
     "styler_wgrad_workspace_bytes": [I, I, I, I, I, I, I],
@@ -148,7 +150,7 @@ def _load():
     for name, argtypes in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int64 if name.endswith(("_bytes", "_blocks")) else ctypes.c_int
+        fn.restype = ctypes.c_int64 if name.endswith(("_bytes", "_blocks", "_bytes_io")) else ctypes.c_int
     return lib
 
 

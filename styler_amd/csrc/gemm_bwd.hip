@@ -248,15 +248,19 @@ __device__ __forceinline__ void wgrad_tr_body(const int bid, const void* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
   // Block -> (split, tile): workgroup b runs on XCD b % 8 (observed dispatch rule, speed only).  With >= 8 splits an
-  // XCD owns whole splits: all tiles of a split read the SAME time rows of dz and x, so each operand slice is fetched
-  // into that XCD's L2 once and re-read from there by the other tiles (tile-major order scattered them over all
-  // eight L2s: 40 % hit rate, 2.4x the algorithmic HBM bytes).
+  // XCD owns a contiguous run of the (split, tile) pairs in split-major order, i.e. whole splits (plus at most two
+  // partial ones when the split count is not a multiple of 8): all tiles of a split read the SAME time rows of dz and
+  // x, so each operand slice is fetched into that XCD's L2 once and re-read from there by the other tiles (tile-major
+  // order scattered them over all eight L2s: 40 % hit rate, 2.4x the algorithmic HBM bytes).  Round 4: the run form
+  // replaced "XCD = split % 8", which needed split counts in multiples of 8 to balance the XCDs -- 25 tiles could only
+  // be launched as 200 or 400 blocks, never as one full round of the chip.
   int tile, split;
   if (splits >= 8) {
-    const int xcd = bid & 7, k = bid >> 3;
-    split = xcd + 8 * (k / tiles);
-    tile = k % tiles;
-    if (split >= splits) return;
+    const int total = tiles * splits, per = (total + 7) >> 3;
+    const int i = (bid & 7) * per + (bid >> 3);
+    if (i >= total) return;
+    split = i / tiles;
+    tile = i - split * tiles;
   } else {
     tile = bid % tiles;
     split = bid / tiles;
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const void* __restrict__ 
 typedef __attribute__((address_space(3))) void wg_lds_void;
 template <int N> __device__ __forceinline__ void wg_vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <int KW, int TA, int TB, int NST>
+template <int KW, int TA, int TB, int NST, int KG>
 __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __restrict__ dz, int64_t lddz,
                                                const void* __restrict__ x, int64_t ldx, float* __restrict__ db,
                                                float* __restrict__ db2, int B, int L, int n, int cin, int pad_left, int ct,
@@ -521,16 +525,27 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
   constexpr bool HALO = KW > 1;                      // rows 64..71 of the x image: one more piece (FB == 64), wave 3's
   static_assert(!HALO || FB == 64, "the halo piece assumes a 64-feature x tile");
   constexpr int D = NST - 1;                         // prefetch distance in chunks
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];     // the ONLY LDS object of the kernel
+  // KG = 2: the block is TWO groups of four waves that split the block's K range (group g takes the chunks ch0 + g, + 2,
+  // ...) with a ring each, and add their accumulators through LDS at the end: the same two-blocks-per-CU occupancy as two
+  // independent blocks, but ONE partial tile instead of two leaves the CU (the split-K partials of a training step and the
+  // pass that folds them: 1.39 GB -> 0.7 GB).
+  constexpr int RING = NST * STAGE;
+  constexpr int NACC = TA * TB * KW * 16 + TA * 16;    // accumulator registers per lane (tiles + bias)
+  constexpr int XCH = KG == 2 ? ((NACC + 1) / 2) * 1024 : 0;            // LDS of one half of the exchange
+  constexpr int SMEM = KG * RING > XCH ? KG * RING : XCH;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_all[SMEM];        // the ONLY LDS object of the kernel
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = KG == 2 ? wave8 >> 2 : 0, wave = wave8 & 3;
+  unsigned char* const smem = smem_all + grp * RING;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
   int tile, split;
-  if (splits >= 8) {                                 // an XCD owns whole splits (see wgrad_tr_body)
-    const int xcd = bid & 7, k = bid >> 3;
-    split = xcd + 8 * (k / tiles);
-    tile = k % tiles;
-    if (split >= splits) return;
+  if (splits >= 8) {                                 // an XCD owns a contiguous run of (split, tile) pairs (see wgrad_tr_body)
+    const int total = tiles * splits, per = (total + 7) >> 3;
+    const int i = (bid & 7) * per + (bid >> 3);
+    if (i >= total) return;
+    split = i / tiles;
+    tile = i - split * tiles;
   } else {
     tile = bid % tiles;
     split = bid / tiles;
@@ -678,30 +693,82 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
     }
   };
 
-  // ---- the ring ----
-  const int ich0 = (int)ch0, nch = (int)(ch1 - ch0);
+  // ---- the ring ----  (group g owns the block's chunks ch0 + g + KG * k; the trip count is group 0's, a group that has
+  // run out of chunks only keeps meeting the barriers)
+  const int ich0 = (int)ch0 + grp, nall = (int)(ch1 - ch0);
+  const int nch = nall > grp ? (nall - grp + KG - 1) / KG : 0, trips = (nall + KG - 1) / KG;
   constexpr int PW = PA + PB;                        // pieces per chunk of waves 0..2 (wave 3: + the halo piece)
 #pragma unroll
   for (int d = 0; d < D; ++d)
-    if (d < nch) issue(ich0 + d, d, entry(ich0 + d));
-  int4 e_next = entry(ich0 + D);
+    if (d < nch) issue(ich0 + KG * d, d, entry(ich0 + KG * d));
+  int4 e_next = entry(ich0 + KG * D);
   int st_c = 0, st_i = D % NST;                      // stage computed / stage refilled in the current iteration
-  for (int i = 0; i < nch; ++i) {
-    const int rem = nch - 1 - i < D - 1 ? nch - 1 - i : D - 1;          // chunks requested after chunk i
-    if (HALO && wave == 3) {
-      if (rem >= 2) wg_vm_wait<2 * (PW + 1)>(); else if (rem == 1) wg_vm_wait<PW + 1>(); else wg_vm_wait<0>();
-    } else {
-      if (rem >= 2) wg_vm_wait<2 * PW>(); else if (rem == 1) wg_vm_wait<PW>(); else wg_vm_wait<0>();
+  for (int i = 0; i < trips; ++i) {
+    const bool live = i < nch;
+    if (live) {
+      const int rem = nch - 1 - i < D - 1 ? nch - 1 - i : D - 1;        // chunks requested after chunk i
+      if (HALO && wave == 3) {
+        if (rem >= 2) wg_vm_wait<2 * (PW + 1)>(); else if (rem == 1) wg_vm_wait<PW + 1>(); else wg_vm_wait<0>();
+      } else {
+        if (rem >= 2) wg_vm_wait<2 * PW>(); else if (rem == 1) wg_vm_wait<PW>(); else wg_vm_wait<0>();
+      }
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (i + D < nch) {                               // the stage read in iteration i - 1: every wave is past those reads
-      issue(ich0 + i + D, st_i, e_next);
-      e_next = entry(ich0 + i + D + 1);
+    if (live) {
+      if (i + D < nch) {                             // the stage read in iteration i - 1: every wave is past those reads
+        issue(ich0 + KG * (i + D), st_i, e_next);
+        e_next = entry(ich0 + KG * (i + D + 1));
+      }
+      compute(st_c);
     }
-    compute(st_c);
     st_c = st_c + 1 == NST ? 0 : st_c + 1;
     st_i = st_i + 1 == NST ? 0 : st_i + 1;
+  }
+  if (KG == 2) {
+    // group 1 hands its accumulators to group 0 through LDS, half of the registers at a time ([register][lane of the
+    // group]: consecutive lanes, conflict-free); group 0 adds in a fixed order -- own + other -- and carries on alone
+    float* const xch = reinterpret_cast<float*>(smem_all);
+    const int t256 = tid & 255;
+    constexpr int HALF = (NACC + 1) / 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      __syncthreads();                               // the rings (h = 0) / the first half (h = 1) are no longer read
+      if (grp == 1) {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < TA; ++i) {
+#pragma unroll
+          for (int jt = 0; jt < TB; ++jt)
+#pragma unroll
+            for (int j = 0; j < KW; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r, ++k)
+                if (k >= h * HALF && k < (h + 1) * HALF) xch[(k - h * HALF) * 256 + t256] = acc[i][jt][j][r];
+#pragma unroll
+          for (int r = 0; r < 16; ++r, ++k)
+            if (k >= h * HALF && k < (h + 1) * HALF) xch[(k - h * HALF) * 256 + t256] = accb[i][r];
+        }
+      }
+      __syncthreads();
+      if (grp == 0) {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < TA; ++i) {
+#pragma unroll
+          for (int jt = 0; jt < TB; ++jt)
+#pragma unroll
+            for (int j = 0; j < KW; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r, ++k)
+                if (k >= h * HALF && k < (h + 1) * HALF) acc[i][jt][j][r] += xch[(k - h * HALF) * 256 + t256];
+#pragma unroll
+          for (int r = 0; r < 16; ++r, ++k)
+            if (k >= h * HALF && k < (h + 1) * HALF) accb[i][r] += xch[(k - h * HALF) * 256 + t256];
+        }
+      }
+    }
+    if (grp == 1) return;
   }
   // partial tile -> workspace [split][n][KW][cin] (as wgrad_tr_body)
   float* wp = ws + (int64_t)split * n * KW * cin;
@@ -733,16 +800,16 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
   }
 }
 
-template <int KW, int TA, int TB, int NST>
-__global__ __launch_bounds__(256) void wgrad_dma_kernel(const void* __restrict__ dz, int64_t lddz,
+template <int KW, int TA, int TB, int NST, int KG>
+__global__ __launch_bounds__(256 * KG) void wgrad_dma_kernel(const void* __restrict__ dz, int64_t lddz,
                                                         const void* __restrict__ x, int64_t ldx,
                                                         float* __restrict__ db, float* __restrict__ db2, int B, int L,
                                                         int n, int cin, int pad_left, int ct, int cpi,
                                                         int chunks_per_split, int tiles, int splits,
                                                         float* __restrict__ ws, const int4* __restrict__ chunktab,
                                                         const int64_t* __restrict__ counts) {
-  wgrad_dma_body<KW, TA, TB, NST>(blockIdx.x, dz, lddz, x, ldx, db, db2, B, L, n, cin, pad_left, ct, cpi,
-                                  chunks_per_split, tiles, splits, ws, chunktab, counts);
+  wgrad_dma_body<KW, TA, TB, NST, KG>(blockIdx.x, dz, lddz, x, ldx, db, db2, B, L, n, cin, pad_left, ct, cpi,
+                                      chunks_per_split, tiles, splits, ws, chunktab, counts);
 }
 
 // Many weight gradients in ONE launch.  Launched one by one, a weight gradient is alone on the chip and needs >= 2 blocks
@@ -797,8 +864,30 @@ static void wgrad_tile(int n, int cin, int kw, int prec, int* TA, int* TB) {
   if (kw == 1 && ((n + 63) / 64) * ((cin + 63) / 64) >= lin128 && n > 64 && cin > 64) { *TA = 2; *TB = 2; }
 }
 
+// The LDS-DMA ring for bf16-resident operands (wgrad_dma_kernel).  Mode 2 (default): 512-thread blocks of two K groups --
+// half the split-K partial tiles; mode 1: 256-thread blocks, the register-staged kernel's split plan and its partial
+// tiles bit for bit (the A/B switch of the parity tests); mode 0 / STYLER_WGRAD_DMA=0: the register-staged kernel.
+static int g_wgrad_dma = [] { const char* e = getenv("STYLER_WGRAD_DMA"); return e ? atoi(e) : 2; }();
+static int g_wgrad_dma_nst128 = [] { const char* e = getenv("STYLER_WGRAD_DMA_NST128"); return e ? atoi(e) : 2; }();
+extern "C" int styler_wgrad_dma_config(int mode, int stages128) {
+  const int prev = g_wgrad_dma | (g_wgrad_dma_nst128 << 2);
+  if (mode >= 0 && mode <= 2) g_wgrad_dma = mode;
+  if (stages128 == 2 || stages128 == 3) g_wgrad_dma_nst128 = stages128;
+  return prev;
+}
+static void wgrad_tile(int n, int cin, int kw, int prec, int* TA, int* TB);
+// K groups per block of a launch with these operand formats (1: every other kernel)
+static int wgrad_kgroups(int n, int cin, int kw, int prec, int io_flags) {
+  if (g_wgrad_dma != 2 || prec != STYLER_PREC_BF16) return 1;
+  if (!(io_flags & STYLER_IO_Y_BF16) || !(io_flags & STYLER_IO_X_BF16) || (n & 7) || (cin & 7)) return 1;
+  int TA, TB;
+  wgrad_tile(n, cin, kw, prec, &TA, &TB);
+  if (kw == 1) return (TA == 2 && TB == 2) ? 2 : 1;
+  return ((kw == 5 || kw == 9) && TA == 1 && TB == 1) ? 2 : 1;
+}
+
 static void wgrad_plan(int B, int L, int n, int cin, int kw, int pad_left, int prec, int* Be, int* Le, int* cpi, int* cps,
-                       int* splits, int want_splits = 0) {
+                       int* splits, int want_splits = 0, int kg = 1) {
   int TA, TB;
   wgrad_tile(n, cin, kw, prec, &TA, &TB);
   const int fa = 64 * TA, fb = 64 * TB;
@@ -819,32 +908,24 @@ static void wgrad_plan(int B, int L, int n, int cin, int kw, int pad_left, int p
   static const int grp_target = [] { const char* e = getenv("STYLER_WGRAD_GROUP_BLOCKS"); return e ? atoi(e) : 128; }();
   static const int big_target = [] { const char* e = getenv("STYLER_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
   const bool group_member = prec == STYLER_PREC_BF16 && kw == 1 && ((n + 63) / 64) * ((cin + 63) / 64) < 48;
-  const int target = group_member ? grp_target : big_target;
-  int64_t sp = (target + nt * ct - 1) / (nt * ct);
+  const int target = (group_member ? grp_target : big_target) / kg;     // two K groups per block: half the blocks
+  // as many splits as fit the target WITHOUT exceeding it (a few blocks over a full round of the chip run a second round)
+  int64_t sp = prec == STYLER_PREC_BF16 ? target / (nt * ct) : (target + nt * ct - 1) / (nt * ct);
   if (want_splits > 0 && want_splits < sp) sp = want_splits;               // grouped launch: the group fills the chip
-  if (sp >= 8 && prec == STYLER_PREC_BF16) sp = (sp + 4) / 8 * 8;          // whole splits per XCD (see wgrad_tr_kernel)
   if (sp > nchunks / 4) sp = nchunks / 4;
   if (sp < 1) sp = 1;
   *cps = (int)((nchunks + sp - 1) / sp);
   *splits = (int)((nchunks + *cps - 1) / *cps);
 }
 
-extern "C" int64_t styler_wgrad_workspace_bytes(int B, int L, int n, int cin, int kw, int pad_left, int prec) {
+extern "C" int64_t styler_wgrad_workspace_bytes_io(int B, int L, int n, int cin, int kw, int pad_left, int prec, int io_flags) {
   if (B <= 0 || L <= 0 || n <= 0 || cin <= 0 || kw <= 0) return 0;
   int Be, Le, cpi, cps, splits;
-  wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits);
+  wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, 0, wgrad_kgroups(n, cin, kw, prec, io_flags));
   return (int64_t)splits * n * kw * cin * 4;
 }
-
-// The LDS-DMA ring for bf16-resident operands (wgrad_dma_kernel): on by default, STYLER_WGRAD_DMA=0 / styler_wgrad_dma_config
-// select the register-staged kernel (same partial tiles bit for bit: the A/B switch of the parity tests and of the bench).
-static int g_wgrad_dma = [] { const char* e = getenv("STYLER_WGRAD_DMA"); return (!e || atoi(e) != 0) ? 1 : 0; }();
-static int g_wgrad_dma_nst128 = [] { const char* e = getenv("STYLER_WGRAD_DMA_NST128"); return e ? atoi(e) : 2; }();
-extern "C" int styler_wgrad_dma_config(int enabled, int stages128) {
-  const int prev = g_wgrad_dma | (g_wgrad_dma_nst128 << 1);
-  if (enabled >= 0) g_wgrad_dma = enabled ? 1 : 0;
-  if (stages128 == 2 || stages128 == 3) g_wgrad_dma_nst128 = stages128;
-  return prev;
+extern "C" int64_t styler_wgrad_workspace_bytes(int B, int L, int n, int cin, int kw, int pad_left, int prec) {
+  return styler_wgrad_workspace_bytes_io(B, L, n, cin, kw, pad_left, prec, 0);
 }
 
 static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, float* db, float* db2,
@@ -867,26 +948,28 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
   const int nt = (n + fa - 1) / fa, ct = (cin + fb - 1) / fb;
   hipStream_t st = (hipStream_t)stream;
   int Be, Le, cpi, cps, splits;
-  wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits);
+  const int kg = wgrad_kgroups(n, cin, kw, prec, io_flags);
+  wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, 0, kg);
   float* ws = reinterpret_cast<float*>(workspace);
   const dim3 grid(nt * ct, (unsigned)splits);
   if (prec == STYLER_PREC_BF16) {
     const int tiles = nt * ct;
-    const dim3 grid1((unsigned)(tiles * (splits >= 8 ? (splits + 7) / 8 * 8 : splits)));
+    const dim3 grid1((unsigned)(splits >= 8 ? (tiles * splits + 7) / 8 * 8 : tiles * splits));
 #define WT_LAUNCH(K, A_, B_) hipLaunchKernelGGL((wgrad_tr_kernel<K, A_, B_>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, \
                                                 db2, Be, Le, n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, \
                                                 kw > 1 ? reinterpret_cast<const int4*>(chunktab) : nullptr, counts)
     // both operands bf16-resident, rows and feature counts in whole 16-byte pieces: the LDS-DMA ring (wgrad_dma_kernel)
     const bool dma = g_wgrad_dma && dz16 && x16 && !(n & 7) && !(cin & 7) && !((uintptr_t)dz & 15) && !((uintptr_t)x & 15);
-#define WD_LAUNCH(K, A_, B_, S_) hipLaunchKernelGGL((wgrad_dma_kernel<K, A_, B_, S_>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, \
-                                                    db, db2, Be, Le, n, cin, pad_left, ct, cpi, cps, tiles, splits, ws,        \
-                                                    kw > 1 ? reinterpret_cast<const int4*>(chunktab) : nullptr, counts)
+#define WD_LAUNCH(K, A_, B_, S_, G_) hipLaunchKernelGGL((wgrad_dma_kernel<K, A_, B_, S_, G_>), grid1, dim3(256 * G_), 0, st, dz, lddz, \
+                                                        x, ldx, db, db2, Be, Le, n, cin, pad_left, ct, cpi, cps, tiles, splits, ws,  \
+                                                        kw > 1 ? reinterpret_cast<const int4*>(chunktab) : nullptr, counts)
     if (dma && kw == 1 && TA == 2 && TB == 2) {
-      if (g_wgrad_dma_nst128 == 3) WD_LAUNCH(1, 2, 2, 3); else WD_LAUNCH(1, 2, 2, 2);
+      if (kg == 2) WD_LAUNCH(1, 2, 2, 2, 2);
+      else if (g_wgrad_dma_nst128 == 3) WD_LAUNCH(1, 2, 2, 3, 1); else WD_LAUNCH(1, 2, 2, 2, 1);
     } else if (dma && kw == 5 && TA == 1 && TB == 1) {
-      WD_LAUNCH(5, 1, 1, 3);
+      if (kg == 2) WD_LAUNCH(5, 1, 1, 3, 2); else WD_LAUNCH(5, 1, 1, 3, 1);
     } else if (dma && kw == 9 && TA == 1 && TB == 1) {
-      WD_LAUNCH(9, 1, 1, 3);
+      if (kg == 2) WD_LAUNCH(9, 1, 1, 3, 2); else WD_LAUNCH(9, 1, 1, 3, 1);
     } else
 #undef WD_LAUNCH
     if (kw == 1) {
@@ -1008,7 +1091,7 @@ extern "C" int styler_wgrad_group_desc(StylerWgradGroupDesc* out, const float* d
   out->lddz = lddz; out->ldx = ldx;
   out->B = Be; out->L = Le; out->n = n; out->cin = cin; out->pad_left = pad_left; out->ct = ct; out->cpi = cpi;
   out->cps = cps; out->tiles = tiles; out->splits = splits; out->block_start = 0;
-  out->nblocks = tiles * (splits >= 8 ? (splits + 7) / 8 * 8 : splits);
+  out->nblocks = splits >= 8 ? (tiles * splits + 7) / 8 * 8 : tiles * splits;
   out->variant = variant; out->kw = kw;
   return out->nblocks;
 }
@@ -1035,11 +1118,14 @@ extern "C" int styler_wgrad_group(const StylerWgradGroupDesc* desc_dev, int coun
   return launch_status();
 }
 
-extern "C" int styler_wgrad_splits(int B, int L, int n, int cin, int kw, int pad_left, int prec) {
+extern "C" int styler_wgrad_splits_io(int B, int L, int n, int cin, int kw, int pad_left, int prec, int io_flags) {
   if (B <= 0 || L <= 0 || n <= 0 || cin <= 0 || kw <= 0) return 0;
   int Be, Le, cpi, cps, splits;
-  wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits);
+  wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, 0, wgrad_kgroups(n, cin, kw, prec, io_flags));
   return splits;
+}
+extern "C" int styler_wgrad_splits(int B, int L, int n, int cin, int kw, int pad_left, int prec) {
+  return styler_wgrad_splits_io(B, L, n, cin, kw, pad_left, prec, 0);
 }
 
 // One launch reducing the split-K partials of MANY weight gradients (a whole backward pass): descriptor i covers

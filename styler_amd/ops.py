@@ -840,14 +840,14 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
                 arena.group_keep.append((dz, x, plan))
                 return
             arena.total -= (d.splits * n * kw * cin + 3) & ~3      # did not fit: the stand-alone request below is counted
-    nfloats = int(lib.styler_wgrad_workspace_bytes(B, L, n, cin, kw, pad_left, prec)) // 4
+    nfloats = int(lib.styler_wgrad_workspace_bytes_io(B, L, n, cin, kw, pad_left, prec, io)) // 4
     ws, defer = None, 0
     if arena is not None:
         ws = arena.take(nfloats, dz.device)
         if ws is not None:
             defer = 1
             arena.descs.append((ws.data_ptr(), dw.data_ptr(), strides[0], strides[1], strides[2], n, cin, kw,
-                                int(lib.styler_wgrad_splits(B, L, n, cin, kw, pad_left, prec))))
+                                int(lib.styler_wgrad_splits_io(B, L, n, cin, kw, pad_left, prec, io))))
     if ws is None:
         ws = torch.empty(nfloats, device=dz.device, dtype=torch.float32)
     grouped = False

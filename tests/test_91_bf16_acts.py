@@ -79,10 +79,20 @@ def test_wgrad_k5_bf16_operands_equal_fp32_operands(dev, dz16, x16):
     x = torch.randn(B, L, cin, generator=g).to(dev).to(torch.bfloat16)
     ref_dw, ref_db = torch.zeros(n, cin, 5, device=dev), torch.zeros(n, device=dev)
     ops.wgrad(dz.float(), x.float(), ref_dw, n, cin, kw=5, db=ref_db, prec=ops.PREC_BF16)
-    dw, db = torch.zeros(n, cin, 5, device=dev), torch.zeros(n, device=dev)
-    ops.wgrad(dz if dz16 else dz.float(), x if x16 else x.float(), dw, n, cin, kw=5, db=db, prec=ops.PREC_BF16)
-    assert torch.equal(dw, ref_dw)
-    assert torch.allclose(db, ref_db, rtol=1e-5, atol=1e-4)
+    # mode 1 of the LDS-DMA ring (both operands bf16) keeps the register-staged kernel's split plan: bit-equal partial tiles;
+    # mode 2 (default: two K groups per block, half the partial tiles) adds the same products in another grouping
+    for mode, exact in ((1, True), (2, False)):
+        prev = ops.lib.styler_wgrad_dma_config(mode, 0)
+        try:
+            dw, db = torch.zeros(n, cin, 5, device=dev), torch.zeros(n, device=dev)
+            ops.wgrad(dz if dz16 else dz.float(), x if x16 else x.float(), dw, n, cin, kw=5, db=db, prec=ops.PREC_BF16)
+        finally:
+            ops.lib.styler_wgrad_dma_config(prev & 3, 0)
+        if exact or not (dz16 and x16):
+            assert torch.equal(dw, ref_dw)
+        else:
+            assert float((dw - ref_dw).abs().max()) <= 2e-6 * float(ref_dw.abs().max())
+        assert torch.allclose(db, ref_db, rtol=1e-5, atol=1e-4)
 
 
 @pytest.mark.parametrize("kind", ["bn", "gn"])
@@ -193,10 +203,18 @@ def test_bf16_stream_kernels_equal_fp32_kernels_on_the_same_values(dev):
         shape = (n, cin) if kw == 1 else (n, cin, kw)
         dw_a, dw_b = torch.zeros(shape, device=dev), torch.zeros(shape, device=dev)
         b_a, b_b = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
-        ops.wgrad(dz, xx, dw_a, n, cin, kw=kw, db=b_a, prec=ops.PREC_BF16)
+        prev = ops.lib.styler_wgrad_dma_config(1, 0)       # the DMA ring with the register-staged kernel's split plan
+        try:
+            ops.wgrad(dz, xx, dw_a, n, cin, kw=kw, db=b_a, prec=ops.PREC_BF16)
+        finally:
+            ops.lib.styler_wgrad_dma_config(prev & 3, 0)
         ops.wgrad(dz, xx.float(), dw_b, n, cin, kw=kw, db=b_b, prec=ops.PREC_BF16)
         assert torch.equal(dw_a, dw_b), kw
         assert float((b_a - b_b).abs().max()) <= 1e-4 * float(b_b.abs().max())
+        dw_c, b_c = torch.zeros(shape, device=dev), torch.zeros(n, device=dev)
+        ops.wgrad(dz, xx, dw_c, n, cin, kw=kw, db=b_c, prec=ops.PREC_BF16)       # default mode: two K groups per block
+        assert float((dw_c - dw_b).abs().max()) <= 2e-6 * float(dw_b.abs().max()), kw
+        assert float((b_c - b_b).abs().max()) <= 1e-4 * float(b_b.abs().max())
 
 
 def test_bf16_z_norm_kernels_equal_fp32_kernels_on_the_same_values(dev):
