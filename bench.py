@@ -47,7 +47,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense, MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0}      # dense, MI355X_MICROARCH.md
 VARIANT_NAMES = {0: "conv_gemm_kernel<1,1,f32>", 1: "conv_gemm_kernel<2,2,f32>",
                  2: "conv_gemm_kernel<1,1,bf16>", 3: "conv_gemm_kernel<2,2,bf16>", 4: "conv_gemm256_kernel"}
 
@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=48)
-    ap.add_argument("--prec", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--prec", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--mode", default="train", choices=["fwd", "train"],
                     help="fwd: C2 eval forward; train: full reference step (dual decode + DAT pass + losses + backward "
                          "+ grad all-reduce + clip + Adam), train.py:135-186")

@@ -368,6 +368,16 @@ int styler_add2(const float* a, int64_t lda, const float* b, int64_t ldb, float*
                 int64_t ldy, int64_t rows, int C, void* stream);
 int styler_add_rowvec(const float* a, int64_t lda, const float* v, int64_t ldv, float* y,
                       int64_t ldy, int B, int L, int C, void* stream);
+/* bf16x3 arithmetic (precision STYLER_PREC_BF16X3 of the host layer): fp32-class products on the bf16 matrix cores.  An
+ * operand is carried as hi + lo (hi = bf16(v), lo = bf16(v - hi)); a x w = a_hi w_hi + a_hi w_lo + a_lo w_hi is ONE bf16
+ * GEMM over a three times longer contraction axis: styler_split3_bf16 writes the activation row [hi | hi | lo] (bf16,
+ * [rows, 3C]), the weight row is [w_hi | w_lo | w_hi] (StylerCopyDesc.flags bit 3 = low part), and styler_conv_gemm runs
+ * it with prec = STYLER_PREC_BF16, cin = 3C.  Replaces the fp32 arithmetic of every nn.Linear / nn.Conv1d of the path
+ * (transformer/SubLayers.py:41-61,72-89; modules.py; transformer/Layers.py:78-118) at ~3x the bf16 cost instead of 16x.
+ * `count` (optional, device int64): only rows < count[0] are written (packed rows).  styler_lo_part: y = bf16(x - hi)
+ * stored as fp32, the low operand of the three styler_wgrad calls that make a weight gradient in this arithmetic. */
+int styler_split3_bf16(const float* x, int64_t ldx, void* y, int64_t rows, int C, const int64_t* count, void* stream);
+int styler_lo_part(const float* x, int64_t ldx, float* y, int64_t rows, int C, const int64_t* count, void* stream);
 /* Up to 8 strided row copies in one launch (the descriptors travel in the kernel arguments): segment k copies `rows` rows of
  * `C` floats (C % 4 == 0) from src (row stride ld_src; NULL = zero fill) to dst (row stride ld_dst).  The torch.cat /
  * torch.split plumbing of modules.py:218-223,350,362 and the gathered slice gradients of their backward: one launch per

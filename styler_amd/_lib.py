@@ -57,6 +57,8 @@ _SIGS = {
     "styler_bucket_embed_add": [P, I64, P, I64, P, F, P, F, P, P, P, P, P, P, I64, P, P, P, I, I, P],
     "styler_add2": [P, I64, P, I64, P, I64, I64, I, P],
     "styler_copy_rows_multi": [P, I, P],
+    "styler_split3_bf16": [P, I64, P, I64, I, P, P],
+    "styler_lo_part": [P, I64, P, I64, I, P, P],
     "styler_add_rowvec": [P, I64, P, I64, P, I64, I, I, I, P],
     "styler_length_mask": [P, P, I, I, P],
     "styler_masked_err_sum": [P, I64, P, I64, P, I, I, I, I, P, P],

@@ -95,7 +95,7 @@ class TacotronSTFT(nn.Module):
         B, N = y.shape
         F = 1 + N // 256
         dev = y.device
-        basis, melb = self._pack(dev, rt.prec)
+        basis, melb = self._pack(dev, rt.kernel_prec())
         ws = torch.empty(int(lib.styler_stft_mel_workspace_bytes(B, N)), device=dev, dtype=torch.uint8)
         mel = torch.empty(B, F, 80, device=dev, dtype=torch.float32)
         energy = torch.empty(B, F, device=dev, dtype=torch.float32)
@@ -109,7 +109,7 @@ class TacotronSTFT(nn.Module):
         ops._chk(lib.styler_stft_mel_varlen(y.data_ptr(), y.stride(0), ops._ptr(wav_len), basis.data_ptr(), melb.data_ptr(),
                                             ops._ptr(mag), mel.data_ptr(), energy.data_ptr(), ops._ptr(e_in),
                                             float(hp.energy_min), float(hp.energy_max), ops._ptr(flen), ws.data_ptr(),
-                                            ops._ptr(err), B, N, rt.prec, ops._stream()), "styler_stft_mel_varlen")
+                                            ops._ptr(err), B, N, rt.kernel_prec(), ops._stream()), "styler_stft_mel_varlen")
         if err is not None and int(err.item()) != 0:
             raise AssertionError("mel_spectrogram: wav outside [-1, 1] (stft.py:151-152)")
         return {"mel": mel, "energy": energy, "mag": mag[..., :513] if want_mag else None, "e_input": e_in, "mel_len": flen}

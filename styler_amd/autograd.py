@@ -8,7 +8,7 @@ import torch
 from torch.autograd import Function
 
 from . import ops
-from .runtime import Seg, gemm_weight, gemm_weight_bwd, rt, seg_transposed
+from .runtime import Seg, gemm_weight, gemm_weight_bwd, gemm_weight_bwd_auto, rt, seg_transposed, x3
 
 
 def onehot_weight(cache, key, w):
@@ -21,12 +21,26 @@ def lstm_wi_transposed(cache, key, wi, wir):
     """[cin, 8H] = transposed cat of the two directions' input weights (dX of the fused input projection); a bf16 shadow in
     throughput mode (rt.lstm_dx_bf16), like the dX weight of every other Linear.  Returns (weight, precision)."""
     n4, cin = wi.shape
+    if rt.prec == ops.PREC_BF16X3 and (2 * n4) % 8 == 0 and cin % 4 == 0:
+        w = cache.get_spec(key + "x3", (cin, 6 * n4), True,
+                           lambda: x3([seg_transposed(wi, 0, 2 * n4), seg_transposed(wir, n4, 2 * n4)], 2 * n4))
+        return w, ops.PREC_BF16X3
     bf16 = rt.prec == ops.PREC_BF16 and rt.lstm_dx_bf16 and (2 * n4) % 8 == 0 and cin % 4 == 0
     w = cache.get_spec(key + ("16" if bf16 else ""), (cin, 2 * n4), bf16,
                        lambda: [seg_transposed(wi, 0, 2 * n4), seg_transposed(wir, n4, 2 * n4)])
     return w, (ops.PREC_BF16 if bf16 else ops.PREC_F32)
 
 NONE, RELU, TANH = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_TANH
+
+
+def _x3_split(t, n, plan=None):
+    """bf16x3 arithmetic: a gradient that feeds BOTH the weight gradient and the dX GEMM of its node is split into
+    [hi | hi | lo] once -> (the tensor to hand to ops.conv_gemm, the (hi, lo) views to hand to ops.wgrad as `dz_parts`).
+    Any other arithmetic (or a width the bf16 engines do not take): (t, None)."""
+    if rt.prec == ops.PREC_BF16X3 and n % 8 == 0 and t.dtype == torch.float32:
+        t3 = ops.split3(t, plan)
+        return t3, ops.split3_parts(t3, n)
+    return t, None
 
 
 def G(p):
@@ -70,14 +84,14 @@ class ConvGemmFn(Function):
         dy = ops._rows_view(dy)
         plan = ctx.plan
         dz = ops.act_bwd(dy, y, ctx.act, lens=plan.nrows if plan is not None else None) if ctx.act != NONE else dy
+        dzg, dzp = _x3_split(dz, n, plan)
         if weight.requires_grad:
             ops.wgrad(dz, x, G(weight), n, cin, kw=kw,
-                      db=G(bias) if (bias is not None and bias.requires_grad) else None, plan=plan)
+                      db=G(bias) if (bias is not None and bias.requires_grad) else None, plan=plan, dz_parts=dzp)
         dx = None
         if ctx.needs_input_grad[0]:
-            bf16 = rt.prec == ops.PREC_BF16 and n % 8 == 0
-            wt = gemm_weight_bwd(ctx.cache, ctx.key, weight, bf16)
-            prec = ops.PREC_BF16 if bf16 else ops.PREC_F32
+            wt, prec = gemm_weight_bwd_auto(ctx.cache, ctx.key, weight)
+            dz = dzg if prec == ops.PREC_BF16X3 else dz
             # a bf16 activation gets a bf16 gradient (autograd would cast an fp32 one to the input's dtype anyway -- with a
             # kernel of its own): written as bf16 by the GEMM, read as bf16 by the norm backward that consumes it
             dx = ops.conv_gemm(dz, wt, None, kw=kw, n=cin, prec=prec,
@@ -184,14 +198,16 @@ class FfnSublayerFn(Function):
         kw1, kw2 = w_1.weight.shape[2], w_2.weight.shape[2]
         d_hid, d_in = w_1.weight.shape[0], w_2.weight.shape[0]
         dx_res, d_o = _ln_tail_bwd(s, ops._rows_view(dy), ffn.layer_norm, lens, ctx.drop)
-        bf16 = rt.prec == ops.PREC_BF16
-        prec = ops.PREC_BF16 if bf16 else ops.PREC_F32
-        ops.wgrad(d_o, h, G(w_2.weight), d_in, d_hid, kw=kw2, db=G(w_2.bias), plan=plan)
-        dh = ops.conv_gemm(d_o, gemm_weight_bwd(ffn._derived, "w_2", w_2.weight, bf16), None, kw=kw2, n=d_hid, prec=prec,
-                           plan=plan, mask=h, out_bf16=h.dtype == torch.bfloat16)
-        ops.wgrad(dh, x, G(w_1.weight), d_hid, d_in, kw=kw1, db=G(w_1.bias), plan=plan)
-        dx = ops.conv_gemm(dh, gemm_weight_bwd(ffn._derived, "w_1", w_1.weight, bf16), None, kw=kw1, n=d_in, prec=prec,
-                           plan=plan, res=dx_res, out_bf16=x.dtype == torch.bfloat16)      # bf16 stream: bf16 gradient
+        d_og, d_op = _x3_split(d_o, d_in, plan)
+        ops.wgrad(d_o, h, G(w_2.weight), d_in, d_hid, kw=kw2, db=G(w_2.bias), plan=plan, dz_parts=d_op)
+        wt2, prec2 = gemm_weight_bwd_auto(ffn._derived, "w_2", w_2.weight)
+        dh = ops.conv_gemm(d_og if prec2 == ops.PREC_BF16X3 else d_o, wt2, None, kw=kw2, n=d_hid, prec=prec2, plan=plan,
+                           mask=h, out_bf16=h.dtype == torch.bfloat16)
+        dhg, dhp = _x3_split(dh, d_hid, plan)
+        ops.wgrad(dh, x, G(w_1.weight), d_hid, d_in, kw=kw1, db=G(w_1.bias), plan=plan, dz_parts=dhp)
+        wt1, prec1 = gemm_weight_bwd_auto(ffn._derived, "w_1", w_1.weight)
+        dx = ops.conv_gemm(dhg if prec1 == ops.PREC_BF16X3 else dh, wt1, None, kw=kw1, n=d_in, prec=prec1, plan=plan,
+                           res=dx_res, out_bf16=x.dtype == torch.bfloat16)      # bf16 stream: bf16 gradient
         return dx, None, None, None, None, None, None
 
 
@@ -227,16 +243,28 @@ class AttnSublayerFn(Function):
         dx_res, d_o = _ln_tail_bwd(s, ops._rows_view(dy), mha.layer_norm, lens, ctx.drop)
         bf16 = rt.prec == ops.PREC_BF16
         prec = ops.PREC_BF16 if bf16 else ops.PREC_F32
-        ops.wgrad(d_o, att, G(mha.fc.weight), 256, 256, db=G(mha.fc.bias), plan=plan)
-        d_att = ops.conv_gemm(d_o, gemm_weight_bwd(mha._derived, "fc", mha.fc.weight, bf16), None, n=256, prec=prec,
-                              plan=plan, out_bf16=bf16 and att.dtype == torch.bfloat16)
+        d_og, d_op = _x3_split(d_o, 256, plan)
+        ops.wgrad(d_o, att, G(mha.fc.weight), 256, 256, db=G(mha.fc.bias), plan=plan, dz_parts=d_op)
+        wfc, pfc = gemm_weight_bwd_auto(mha._derived, "fc", mha.fc.weight)
+        d_att = ops.conv_gemm(d_og if pfc == ops.PREC_BF16X3 else d_o, wfc, None, n=256, prec=pfc, plan=plan,
+                              out_bf16=bf16 and att.dtype == torch.bfloat16)
         dqkv = ops.attention_bwd(qkv, att, d_att, lse, lens, plan=plan, out_bf16=bf16 and rt.bf16_acts and rt.bf16_dqkv)
         srcs = [mha.w_qs.weight, mha.w_ks.weight, mha.w_vs.weight]
+        dqg, _ = _x3_split(dqkv, 768, plan)           # [hi(768) | hi(768) | lo(768)]: per projection, slices of both parts
+        x3p = ops.split3_parts(ops.split3(x, plan), 256) if dqg is not dqkv else None
         for i, lin in enumerate((mha.w_qs, mha.w_ks, mha.w_vs)):
-            ops.wgrad(dqkv[..., i * 256:(i + 1) * 256], x, G(lin.weight), 256, 256, db=G(lin.bias), plan=plan)
-        wt = mha._derived.get_spec("qkv_wT16" if bf16 else "qkv_wT", (256, 768), bf16,
-                                   lambda: [seg_transposed(w, k * 256, 768) for k, w in enumerate(srcs)])
-        dx = ops.conv_gemm(dqkv, wt, None, n=256, prec=prec, plan=plan, res=dx_res, out_bf16=x.dtype == torch.bfloat16)
+            dzp = ((dqg[..., i * 256:(i + 1) * 256], dqg[..., 1536 + i * 256:1536 + (i + 1) * 256]) if dqg is not dqkv else None)
+            ops.wgrad(dqkv[..., i * 256:(i + 1) * 256], x, G(lin.weight), 256, 256, db=G(lin.bias), plan=plan,
+                      dz_parts=dzp, x_parts=x3p)
+        if rt.prec == ops.PREC_BF16X3:
+            prec = ops.PREC_BF16X3
+            wt = mha._derived.get_spec("qkv_wTx3", (256, 3 * 768), True,
+                                       lambda: x3([seg_transposed(w, k * 256, 768) for k, w in enumerate(srcs)], 768))
+        else:
+            wt = mha._derived.get_spec("qkv_wT16" if bf16 else "qkv_wT", (256, 768), bf16,
+                                       lambda: [seg_transposed(w, k * 256, 768) for k, w in enumerate(srcs)])
+        dx = ops.conv_gemm(dqg if prec == ops.PREC_BF16X3 else dqkv, wt, None, n=256, prec=prec, plan=plan, res=dx_res,
+                           out_bf16=x.dtype == torch.bfloat16)
         return dx, None, None, None, None, None, None
 
 
@@ -296,12 +324,12 @@ class PredictorStageFn(Function):
                                    dout=dout, ddot_w=G(lin.weight), ddot_b=G(lin.bias), drop_p=ctx.drop[0],
                                    drop_seed=ctx.drop[1], relu_input=True)
         n, cin = weight.shape[0], x.shape[-1]
-        ops.wgrad(dz, x, G(weight), n, cin, kw=kw, db=G(bias) if bias is not None else None)
+        dzg, dzp = _x3_split(dz, n)
+        ops.wgrad(dz, x, G(weight), n, cin, kw=kw, db=G(bias) if bias is not None else None, dz_parts=dzp)
         dx = None
         if ctx.needs_input_grad[0]:
-            bf16 = rt.prec == ops.PREC_BF16 and n % 8 == 0
-            dx = ops.conv_gemm(dz, gemm_weight_bwd(ctx.cache, ctx.key, weight, bf16), None, kw=kw, n=cin,
-                               prec=ops.PREC_BF16 if bf16 else ops.PREC_F32)
+            wt, wprec = gemm_weight_bwd_auto(ctx.cache, ctx.key, weight)
+            dx = ops.conv_gemm(dzg if wprec == ops.PREC_BF16X3 else dz, wt, None, kw=kw, n=cin, prec=wprec)
         return dx, None, None, None, None, None, None, None, None, None
 
 
@@ -353,14 +381,15 @@ class ConvNormFn(Function):
                                    beta=norm.bias, drop_p=ctx.drop[0], drop_seed=ctx.drop[1], segs=ctx.segs,
                                    dx_bf16=ctx.b16)
         n, cin = weight.shape[0], x.shape[-1]
+        dzg, dzp = _x3_split(dz, n)
         if weight.requires_grad:
-            ops.wgrad(dz, x, G(weight), n, cin, kw=kw, db=G(bias) if (bias is not None and bias.requires_grad) else None)
+            ops.wgrad(dz, x, G(weight), n, cin, kw=kw, db=G(bias) if (bias is not None and bias.requires_grad) else None,
+                      dz_parts=dzp)
         dx = None
         if ctx.needs_input_grad[0]:
-            bf16 = rt.prec == ops.PREC_BF16 and n % 8 == 0
-            wt = gemm_weight_bwd(ctx.cache, ctx.key, weight, bf16)
-            dx = ops.conv_gemm(dz, wt, None, kw=kw, n=cin, prec=ops.PREC_BF16 if bf16 else ops.PREC_F32,
-                               out_bf16=bf16 and x.dtype == torch.bfloat16)
+            wt, wprec = gemm_weight_bwd_auto(ctx.cache, ctx.key, weight)
+            dx = ops.conv_gemm(dzg if wprec == ops.PREC_BF16X3 else dz, wt, None, kw=kw, n=cin, prec=wprec,
+                               out_bf16=wprec == ops.PREC_BF16 and x.dtype == torch.bfloat16)
         return (dx,) + (None,) * 11
 
 
@@ -406,14 +435,15 @@ class ConvNormCatFn(Function):
                                         dx_bf16=b16)
             off += wd
             n, cin = weight.shape[0], x.shape[-1]
+            dzg, dzp = _x3_split(dz, n)
             if weight.requires_grad:
-                ops.wgrad(dz, x, G(weight), n, cin, kw=5, db=G(bias) if (bias is not None and bias.requires_grad) else None)
+                ops.wgrad(dz, x, G(weight), n, cin, kw=5, db=G(bias) if (bias is not None and bias.requires_grad) else None,
+                          dz_parts=dzp)
             dx = None
             if ctx.needs_input_grad[3 + 3 * i]:
-                bf16 = rt.prec == ops.PREC_BF16 and n % 8 == 0
-                wt = gemm_weight_bwd(cache, key, weight, bf16)
-                dx = ops.conv_gemm(dz, wt, None, kw=5, n=cin, prec=ops.PREC_BF16 if bf16 else ops.PREC_F32,
-                                   out_bf16=bf16 and x.dtype == torch.bfloat16)
+                wt, wprec = gemm_weight_bwd_auto(cache, key, weight)
+                dx = ops.conv_gemm(dzg if wprec == ops.PREC_BF16X3 else dz, wt, None, kw=5, n=cin, prec=wprec,
+                                   out_bf16=wprec == ops.PREC_BF16 and x.dtype == torch.bfloat16)
             grads += [dx, None, None]
         return (None, None, None) + tuple(grads)
 

@@ -102,6 +102,9 @@ __device__ __forceinline__ void stg4(void* base, int64_t idx, const float4& v, b
   else *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx) = v;
 }
 
+// v - float(bf16(v)): the low part of the hi + lo split of the bf16x3 arithmetic (exact in fp32)
+__device__ __forceinline__ float bf16_lo_part(float v) { return v - __uint_as_float(f32_to_bf16_bits(v) << 16); }
+
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
 }

@@ -398,6 +398,67 @@ extern "C" int styler_copy_rows_multi(const StylerCopySeg* segs, int count, void
   return launch_status();
 }
 
+// ---- bf16x3 operand split (round 4) ------------------------------------------------------------------------------------
+// The parity-grade arithmetic on the bf16 matrix cores: a value is carried as hi + lo (hi = bf16(v), lo = bf16(v - hi): 16
+// mantissa bits) and a product a * w as a_hi w_hi + a_hi w_lo + a_lo w_hi (fp32 accumulate; the dropped a_lo w_lo term is
+// 2^-18 relative).  The three products are ONE bf16 GEMM over a contraction axis three times as long: the activation
+// row [hi | hi | lo] (this kernel) against the weight row [w_hi | w_lo | w_hi] (runtime.gemm_weight), so every bf16 GEMM
+// engine of the library -- 128 x 128, 256 x 256 LDS-DMA -- computes it unchanged.
+//   y[row, 0:C] = y[row, C:2C] = bf16(x[row]);  y[row, 2C:3C] = bf16(x[row] - float(bf16(x[row])))
+// `count` (optional, device): rows at or past count[0] are skipped (packed rows: only the valid prefix is ever read).
+__global__ __launch_bounds__(256) void split3_bf16_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y,
+                                                          int64_t rows, int C, const int64_t* __restrict__ count) {
+  const int nq = C / 4;
+  if (count && count[0] < rows) rows = count[0];
+  const int64_t total = rows * nq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / nq; const int q = (int)(i - row * nq);
+    const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + q * 4);
+    const uint32_t h01 = cvt_pk_bf16_rne(v.x, v.y), h23 = cvt_pk_bf16_rne(v.z, v.w);
+    const float l0 = v.x - __uint_as_float(h01 << 16), l1 = v.y - __uint_as_float(h01 & 0xffff0000u);
+    const float l2 = v.z - __uint_as_float(h23 << 16), l3 = v.w - __uint_as_float(h23 & 0xffff0000u);
+    uint16_t* yr = y + row * (int64_t)(3 * C) + q * 4;
+    const uint2 hi = make_uint2(h01, h23);
+    *reinterpret_cast<uint2*>(yr) = hi;
+    *reinterpret_cast<uint2*>(yr + C) = hi;
+    *reinterpret_cast<uint2*>(yr + 2 * C) = make_uint2(cvt_pk_bf16_rne(l0, l1), cvt_pk_bf16_rne(l2, l3));
+  }
+}
+
+extern "C" int styler_split3_bf16(const float* x, int64_t ldx, void* y, int64_t rows, int C, const int64_t* count,
+                                  void* stream) {
+  if (!x || !y || rows <= 0 || C <= 0 || (C & 3)) return STYLER_EINVAL;
+  if ((ldx & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return STYLER_EALIGN;
+  hipLaunchKernelGGL(split3_bf16_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     reinterpret_cast<uint16_t*>(y), rows, C, count);
+  return launch_status();
+}
+
+// y = x - float(bf16(x)), rounded to bf16 and stored as fp32 (exactly representable): the low part of an operand of the
+// weight-gradient GEMMs in the bf16x3 arithmetic, in the format every wgrad kernel variant accepts.
+__global__ __launch_bounds__(256) void lo_part_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
+                                                      int64_t rows, int C, const int64_t* __restrict__ count) {
+  const int nq = C / 4;
+  if (count && count[0] < rows) rows = count[0];
+  const int64_t total = rows * nq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / nq; const int q = (int)(i - row * nq);
+    const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + q * 4);
+    float4 o;
+    o.x = __uint_as_float(f32_to_bf16_bits(bf16_lo_part(v.x)) << 16); o.y = __uint_as_float(f32_to_bf16_bits(bf16_lo_part(v.y)) << 16);
+    o.z = __uint_as_float(f32_to_bf16_bits(bf16_lo_part(v.z)) << 16); o.w = __uint_as_float(f32_to_bf16_bits(bf16_lo_part(v.w)) << 16);
+    *reinterpret_cast<float4*>(y + row * (int64_t)C + q * 4) = o;
+  }
+}
+
+extern "C" int styler_lo_part(const float* x, int64_t ldx, float* y, int64_t rows, int C, const int64_t* count, void* stream) {
+  if (!x || !y || rows <= 0 || C <= 0 || (C & 3)) return STYLER_EINVAL;
+  if ((ldx & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return STYLER_EALIGN;
+  hipLaunchKernelGGL(lo_part_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, y, rows, C,
+                     count);
+  return launch_status();
+}
+
 // ---- masked error sums ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void masked_err_kernel(const float* __restrict__ a, int64_t lda,
                                                          const float* __restrict__ b, int64_t ldb,
@@ -453,6 +514,8 @@ extern "C" int styler_length_mask(const int64_t* len, uint8_t* mask, int B, int 
 // QKV / BiLSTM matrices, summed LSTM biases) is an index permutation of parameter elements, optionally cast or
 // summed with a second tensor of the same shape.  One descriptor = one source tensor walked as dims (d0, d1, d2) with element strides on both sides; the
 // optimiser refreshes ALL derived layouts of the model with one launch after each update (runtime.Derived).
+// flags bit3 (round 4, the bf16x3 arithmetic): the element written is the LOW part of the source value, v - float(bf16(v)) --
+// together with the plain bf16 cast (the high part) it represents v to 16 mantissa bits (runtime.gemm_weight's x3 layouts).
 __global__ __launch_bounds__(256) void strided_copy_multi_kernel(const StylerCopyDesc* __restrict__ desc, int count) {
   int lo = 0, hi = count - 1;                        // last descriptor with block_start <= blockIdx.x
   const int64_t bid = blockIdx.x;
@@ -494,7 +557,8 @@ __global__ __launch_bounds__(256) void strided_copy_multi_kernel(const StylerCop
       const uint32_t a0 = m / ud1t, tt = m % ud1t;
       const uint32_t a1 = d.ss1 < 0 ? ud1t - 1u - tt : tt;
       const int64_t o = (int64_t)a0 * d.ds0 + (int64_t)a1 * d.ds1 + nn;
-      const float v = tile[nl][ml];
+      float v = tile[nl][ml];
+      if (d.flags & 8) v = bf16_lo_part(v);
       if (d.flags & 1) reinterpret_cast<uint16_t*>(d.dst)[o] = (uint16_t)f32_to_bf16_bits(v);
       else reinterpret_cast<float*>(d.dst)[o] = v;
     }
@@ -516,7 +580,8 @@ __global__ __launch_bounds__(256) void strided_copy_multi_kernel(const StylerCop
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < cn * ud1k; i += 256u) {
       const uint32_t a1 = i / cn, c = i - a1 * cn;
-      const float v = run[c * ud1k + a1];
+      float v = run[c * ud1k + a1];
+      if (d.flags & 8) v = bf16_lo_part(v);
       const int64_t o = (int64_t)a0 * d.ds0 + (int64_t)a1 * d.ds1 + c0 + c;
       if (d.flags & 1) reinterpret_cast<uint16_t*>(d.dst)[o] = (uint16_t)f32_to_bf16_bits(v);
       else reinterpret_cast<float*>(d.dst)[o] = v;
@@ -543,6 +608,7 @@ __global__ __launch_bounds__(256) void strided_copy_multi_kernel(const StylerCop
       const int64_t si = (int64_t)a0 * d.ss0 + (int64_t)a1 * d.ss1 + (int64_t)a2 * d.ss2;
       float v0 = src[si], v1 = src[si + d.ss2];
       if (src2) { v0 += src2[si]; v1 += src2[si + d.ss2]; }
+      if (d.flags & 8) { v0 = bf16_lo_part(v0); v1 = bf16_lo_part(v1); }
       const int64_t o = (int64_t)a0 * d.ds0 + (int64_t)a1 * d.ds1 + a2;
       if (bf) *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(d.dst) + o) = pack_bf16x2(v0, v1);
       else *reinterpret_cast<float2*>(reinterpret_cast<float*>(d.dst) + o) = make_float2(v0, v1);
@@ -558,6 +624,7 @@ __global__ __launch_bounds__(256) void strided_copy_multi_kernel(const StylerCop
     const int64_t si = (int64_t)a0 * d.ss0 + (int64_t)a1 * d.ss1 + (int64_t)a2 * d.ss2;
     float v = src[si];
     if (src2) v += src2[si];
+    if (d.flags & 8) v = bf16_lo_part(v);
     const int64_t o = (int64_t)a0 * d.ds0 + (int64_t)a1 * d.ds1 + (int64_t)a2 * d.ds2;
     if (bf) reinterpret_cast<uint16_t*>(d.dst)[o] = (uint16_t)f32_to_bf16_bits(v);
     else reinterpret_cast<float*>(d.dst)[o] = v;

@@ -164,12 +164,12 @@ class DeepSpeaker(nn.Module):
         """-> [B, 160, 64]: the standardised filterbank features of the chosen 160-frame window (frame0 int64 [B] on the
         device; None = the centre window -- the reference draws it at random, batcher.py:25)."""
         B = wavs.shape[0]
-        P = self._pack(wavs.device, rt.prec)
+        P = self._pack(wavs.device, rt.kernel_prec())
         ws = torch.empty(int(lib.styler_ds_fbank_workspace_bytes(B)), device=wavs.device, dtype=torch.uint8)
         out = torch.empty(B, NUM_FRAMES, NUM_FBANKS, device=wavs.device, dtype=torch.float32)
         ops._chk(lib.styler_ds_fbank(wavs.data_ptr(), wavs.stride(0), bounds.data_ptr(), ops._ptr(frame0),
                                      0 if frame0 is not None else 1, P["basis"].data_ptr(), P["fb"].data_ptr(),
-                                     out.data_ptr(), ws.data_ptr(), B, rt.prec, ops._stream()), "styler_ds_fbank")
+                                     out.data_ptr(), ws.data_ptr(), B, rt.kernel_prec(), ops._stream()), "styler_ds_fbank")
         return out
 
     # -- ResCNN -----------------------------------------------------------------------------------------------------------
@@ -220,7 +220,7 @@ class DeepSpeaker(nn.Module):
             raise RuntimeError("styler_amd.deepspeaker runs on the MI355X HIP path only (no CPU fallback)")
         B, H, W = feats.shape
         assert (H, W) == (NUM_FRAMES, NUM_FBANKS)
-        dev, prec = feats.device, rt.prec
+        dev, prec = feats.device, rt.kernel_prec()
         P = self._pack(dev, prec)
         H, W = H // 2, W // 2
         x = torch.empty(B, H + 3, W, 64, device=dev, dtype=torch.float32)

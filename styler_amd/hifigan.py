@@ -290,7 +290,7 @@ class Generator(nn.Module):
         prec = self.prec
         if prec is None:
             from .runtime import rt
-            prec = rt.prec
+            prec = rt.kernel_prec()
         plan = self._prepare(prec)
         with torch.no_grad():
             if self.use_graph:

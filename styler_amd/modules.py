@@ -19,7 +19,7 @@ import torch.nn as nn
 from . import autograd as AG
 from . import hparams as hp
 from . import ops
-from .runtime import Seg, rt, seg_rows
+from .runtime import Seg, rt, seg_rows, x3
 from .transformer import ConvNorm, Encoder, _HipModule
 
 EncoderInput = namedtuple("EncoderInput", "mel p_norm e_input mel_aug")
@@ -90,6 +90,9 @@ class AudioEncoder(_HipModule):
         bias = d.get_spec(key + "b", (2 * n4,), False,
                           lambda: [Seg(bi, (n4,), (1,), (1,), src2=bh), Seg(bir, (n4,), (1,), (1,), dst_off=n4, src2=bhr)])
         w_hh = d.get_spec(key + "wh", (2, n4, H), False, lambda: [seg_rows(wh, 0), seg_rows(whr, n4)])
+        if rt.prec == ops.PREC_BF16X3 and cin % 8 == 0:
+            w = d.get_spec(key + "wix3", (2 * n4, 3 * cin), True, lambda: x3([seg_rows(wi, 0), seg_rows(wir, n4)], cin))
+            return w, bias, w_hh, ops.PREC_BF16X3
         bf16 = rt.prec == ops.PREC_BF16 and cin % 8 == 0
         w = d.get_spec(key + ("wi16" if bf16 else "wi"), (2 * n4, cin), bf16,
                        lambda: [seg_rows(wi, 0), seg_rows(wir, n4)])

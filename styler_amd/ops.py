@@ -13,6 +13,7 @@ from ._lib import lib
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT_LEAKY = 4                      # leaky_relu(0.1), the vocoder's LRELU_SLOPE
 PREC_F32, PREC_BF16 = 0, 1
+PREC_BF16X3 = 2                    # host-level arithmetic: fp32-class products as three bf16 MFMA products (split3 / lo_part)
 
 
 class StylerHipError(RuntimeError):
@@ -185,23 +186,46 @@ class WgradArena:
         self.flush_no += 1
         if not self.descs:
             return
-        key = tuple(self.descs)
-        if key not in self._cache:
-            dt = np.dtype([("ws", np.uint64), ("dw", np.uint64), ("sn", np.int64), ("sc", np.int64), ("sj", np.int64),
-                           ("block_start", np.int64), ("n", np.int32), ("cin", np.int32), ("kw", np.int32),
-                           ("splits", np.int32)])
-            arr = np.zeros(len(self.descs), dtype=dt)
-            start = 0
-            for i, (ws, dw, sn, sc, sj, n, cin, kw, splits) in enumerate(self.descs):
-                arr[i] = (ws, dw, sn, sc, sj, start, n, cin, kw, splits)
-                start += int(lib.styler_wgrad_reduce_blocks(n, cin, kw, sc, sj))
-            if len(self._cache) > 8 and not self.owned_by_graph:
-                self._cache.clear()                  # eager steps only: a graph's tables live as long as its arena
-            self._cache[key] = (torch.from_numpy(arr.view(np.uint8).copy()).to(device), start)
-        table, blocks = self._cache[key]
-        _chk(lib.styler_wgrad_reduce_multi(table.data_ptr(), len(self.descs), blocks, _stream()),
-             "styler_wgrad_reduce_multi")
+        # Descriptors that add into the SAME gradient from adjacent workspace slices (the three calls of a bf16x3 weight
+        # gradient) become one descriptor with the split counts summed; other repeats (a module applied twice in one step:
+        # the augmentation classifiers of the main and the DAT pass) go to a FOLLOWING launch -- two blocks of one launch
+        # must never read-modify-write the same dw elements (until round 4 such pairs shared a launch and were correct
+        # only because their blocks ran thousands of blocks apart).
+        merged = []
+        for d in self.descs:
+            ws, dw, sn, sc, sj, n, cin, kw, splits = d
+            if merged:
+                pw, pdw, psn, psc, psj, pn, pcin, pkw, psp = merged[-1]
+                if (pdw, psn, psc, psj, pn, pcin, pkw) == (dw, sn, sc, sj, n, cin, kw) and ws == pw + psp * n * cin * kw * 4:
+                    merged[-1] = (pw, pdw, psn, psc, psj, pn, pcin, pkw, psp + splits)
+                    continue
+            merged.append(d)
+        rounds = []
+        for d in merged:
+            for r in rounds:
+                if d[1] not in r[1]:
+                    r[0].append(d); r[1].add(d[1])
+                    break
+            else:
+                rounds.append(([d], {d[1]}))
         self.descs = []
+        for descs, _ in rounds:
+            key = tuple(descs)
+            if key not in self._cache:
+                dt = np.dtype([("ws", np.uint64), ("dw", np.uint64), ("sn", np.int64), ("sc", np.int64), ("sj", np.int64),
+                               ("block_start", np.int64), ("n", np.int32), ("cin", np.int32), ("kw", np.int32),
+                               ("splits", np.int32)])
+                arr = np.zeros(len(descs), dtype=dt)
+                start = 0
+                for i, (ws, dw, sn, sc, sj, n, cin, kw, splits) in enumerate(descs):
+                    arr[i] = (ws, dw, sn, sc, sj, start, n, cin, kw, splits)
+                    start += int(lib.styler_wgrad_reduce_blocks(n, cin, kw, sc, sj))
+                if len(self._cache) > 8 and not self.owned_by_graph:
+                    self._cache.clear()              # eager steps only: a graph's tables live as long as its arena
+                self._cache[key] = (torch.from_numpy(arr.view(np.uint8).copy()).to(device), start)
+            table, blocks = self._cache[key]
+            _chk(lib.styler_wgrad_reduce_multi(table.data_ptr(), len(descs), blocks, _stream()),
+                 "styler_wgrad_reduce_multi")
 
 
 wgrad_arena = None
@@ -343,12 +367,42 @@ def unpack_rows(xp, plan):
     return out
 
 
+def split3(x, plan=None):
+    """[.., C] fp32 -> [.., 3C] bf16 rows [hi | hi | lo] (styler_split3_bf16): the activation operand of a bf16x3 GEMM.  With
+    `plan` (packed rows) only the valid prefix is written."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty(*x.shape[:-1], 3 * C, device=x.device, dtype=torch.bfloat16)
+    _chk(lib.styler_split3_bf16(_f32(x).data_ptr(), _ld(x), y.data_ptr(), rows, C,
+                                plan.counts.data_ptr() if plan is not None else None, _stream()), "styler_split3_bf16")
+    return y
+
+
+def lo_part(x, plan=None):
+    """bf16(x - float(bf16(x))) stored as fp32 (styler_lo_part): the low operand of a bf16x3 weight gradient."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty(x.shape, device=x.device, dtype=torch.float32)   # (rows behind a packed prefix are never read: the
+    # weight-gradient kernels address an item through a descriptor that ends with the item)
+    _chk(lib.styler_lo_part(_f32(x).data_ptr(), _ld(x), y.data_ptr(), rows, C,
+                            plan.counts.data_ptr() if plan is not None else None, _stream()), "styler_lo_part")
+    return y
+
+
 def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, scale=None, res=None,
               out=None, lens=None, plan=None, mask=None, out_bf16=False):
     """y = act(scale * conv1d_same(x, w) + bias) (+ res); x [B, L, cin] -> y [B, L, n].
     `w` is the kernel-layout weight [n, kw*cin] (fp32, or bf16 when prec == PREC_BF16).
     Throughput mode only: x, the output (`out_bf16` / a bf16 `out`) and `mask` may be bf16 tensors (the FFN hidden
     activation and its gradient are stored that way; no residual with a bf16 output)."""
+    if prec == PREC_BF16X3:
+        # fp32-class products on the bf16 engines: x -> [hi | hi | lo] (3 cin channels) against the weight's [w_hi | w_lo | w_hi]
+        # rows (runtime.gemm_weight); everything behind the contraction -- bias, activation, residual, masks -- is unchanged
+        x3 = x if x.dtype == torch.bfloat16 else split3(x, plan)      # (a bf16 x is a split3 tensor the caller shares)
+        if w.dtype != torch.bfloat16 or w.shape[-1] != kw * x3.shape[-1] or x3.shape[-1] % 3:
+            raise StylerHipError("bf16x3 GEMM needs the x3 weight layout [n, kw * 3 cin]")
+        return conv_gemm(x3, w, bias, kw=kw, n=n, act=act, prec=PREC_BF16, scale=scale, res=res, out=out,
+                         lens=lens, plan=plan, mask=mask, out_bf16=False)
     B, L, cin = x.shape
     n = w.shape[0] if n is None else n
     if prec == PREC_BF16 and (w.dtype != torch.bfloat16 or cin % 8):
@@ -799,7 +853,13 @@ def act_bwd(dy, y, act, lens=None):
 LIN128_SPLITS = int(os.environ.get("STYLER_WGRAD_LIN128_SPLITS", "8"))
 
 
-def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=None, db2=None, plan=None):
+def split3_parts(t3, C):
+    """(hi, lo) bf16 views [.., C] (row stride 3C) of a split3 tensor [.., 3C] = [hi | hi | lo]."""
+    return t3[..., 0:C], t3[..., 2 * C:3 * C]
+
+
+def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=None, db2=None, plan=None, dz_parts=None,
+          x_parts=None, x_exact=False):
     """dw (fp32, parameter layout [n, cin] or [n, cin, kw]) += dz^T x over all taps; db (and db2) += colsum(dz)."""
     B, L = dz.shape[0], dz.shape[1]
     if strides is None:
@@ -809,6 +869,35 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
     if prec is None:
         from .runtime import rt
         prec = rt.prec
+    if prec == PREC_BF16X3:
+        # dz^T x = dz_hi^T x_hi + dz_hi^T x_lo + dz_lo^T x_hi: three calls of the bf16 engine accumulating into dw.
+        if n % 4:
+            prec = PREC_F32
+        else:
+            kwargs = dict(kw=kw, pad_left=pad_left, strides=strides, prec=PREC_BF16, plan=plan)
+            tiles = ((n + 63) // 64) * ((cin + 63) // 64)
+            resident = (n % 8 == 0 and cin % 8 == 0 and not x_exact and
+                        ((kw == 1 and pad_left == 0 and tiles >= 16 and n > 64 and cin > 64) or kw in (5, 9)))
+            if resident:
+                # both operands as bf16 views of their [hi | hi | lo] splits (the dX GEMM of the same node needs dz's split
+                # anyway: callers hand it over as `dz_parts`): the LDS-DMA kernels take them.  The bias sums need both
+                # parts of dz: colsum(dz_hi) from the first call, colsum(dz_lo) from the third.
+                dzh, dzl = dz_parts if dz_parts is not None else split3_parts(split3(dz, plan), n)
+                xh, xl = x_parts if x_parts is not None else split3_parts(split3(x, plan), cin)
+                wgrad(dzh, xh, dw, n, cin, db=db, db2=db2, **kwargs)
+                wgrad(dzh, xl, dw, n, cin, **kwargs)
+                wgrad(dzl, xh, dw, n, cin, db=db, db2=db2, **kwargs)
+                return
+            # any other shape: fp32-typed operands (the kernels round an fp32 operand to bf16 while staging = its high part;
+            # the low parts are materialised as fp32 holding bf16-representable values).  The bias sums come from the first
+            # call, which adds the fp32 values of dz before rounding them.
+            if dz.dtype != torch.float32 or x.dtype != torch.float32:
+                raise StylerHipError("bf16x3 weight gradient: fp32 operands expected")
+            wgrad(dz, x, dw, n, cin, db=db, db2=db2, **kwargs)
+            if not x_exact:                           # (a one-hot x is exact in bf16: its low part is zero)
+                wgrad(dz, lo_part(x, plan), dw, n, cin, **kwargs)
+            wgrad(lo_part(dz, plan), x, dw, n, cin, **kwargs)
+            return
     prof = gemm_profiler
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1007,7 +1096,7 @@ def onehot_conv5_bwd(v, dy, dw, db):
     C = db.numel()
     oh = torch.empty(B, L, 260, device=v.device, dtype=torch.float32)
     _chk(lib.styler_onehot_expand(v.data_ptr(), oh.data_ptr(), B * L, _stream()), "styler_onehot_expand")
-    wgrad(dy, oh, dw, C, 257, kw=5, db=db, strides=(257 * 5, 5, 1))
+    wgrad(dy, oh, dw, C, 257, kw=5, db=db, strides=(257 * 5, 5, 1), x_exact=True)
 
 
 def mel_calibrate_bwd(dy, mel_len, src_len, T, out_bf16=False):

@@ -92,8 +92,16 @@ class _Runtime:
     # is one LayerNorm-backward kernel + weight gradient + dX GEMM (STYLER_FUSED_PREDICTOR=0: separate nodes)
     fused_predictor = os.environ.get("STYLER_FUSED_PREDICTOR", "1") != "0"
 
+    def kernel_prec(self):
+        """The precision code of the C entry points that take one (STFT, DeepSpeaker, vocoder): bf16x3 is a host-level
+        arithmetic of the Linear / Conv1d GEMMs of the model; those pipelines run their fp32 form in it."""
+        return ops.PREC_F32 if self.prec == ops.PREC_BF16X3 else self.prec
+
     def set_precision(self, name):
-        self.prec = {"fp32": ops.PREC_F32, "bf16": ops.PREC_BF16}[name]
+        """fp32: exact-fp32 MFMA (parity mode); bf16: throughput mode (bf16 operands, bf16 activation storage); bf16x3: fp32-class
+        products on the bf16 matrix cores (operands split hi + lo, three bf16 products per fp32 product, fp32 accumulate, fp32
+        activation storage): the parity-grade arithmetic at ~3x the bf16 GEMM cost instead of the fp32 MFMA's 16x."""
+        self.prec = {"fp32": ops.PREC_F32, "bf16": ops.PREC_BF16, "bf16x3": ops.PREC_BF16X3}[name]
 
 
 rt = _Runtime()
@@ -103,10 +111,11 @@ class Seg:
     """One strided 3-D copy of a derived layout (StylerCopyDesc): element (a0,a1,a2) of `dims` goes from
     src.flat[src_off + a.sstr] (+ src2, same index) to out.flat[dst_off + a.dstr]."""
 
-    __slots__ = ("src", "src2", "src_off", "dims", "sstr", "dst_off", "dstr")
+    __slots__ = ("src", "src2", "src_off", "dims", "sstr", "dst_off", "dstr", "lo")
 
-    def __init__(self, src, dims, sstr, dstr, src_off=0, dst_off=0, src2=None):
+    def __init__(self, src, dims, sstr, dstr, src_off=0, dst_off=0, src2=None, lo=False):
         self.src, self.src2, self.src_off, self.dst_off = src, src2, src_off, dst_off
+        self.lo = lo                                 # write the LOW part v - float(bf16(v)) (bf16x3 layouts, CopyDesc.flags bit 3)
         self.dims = tuple(dims) + (1,) * (3 - len(dims))
         self.sstr = tuple(sstr) + (0,) * (3 - len(sstr))
         self.dstr = tuple(dstr) + (0,) * (3 - len(dstr))
@@ -249,7 +258,7 @@ class _Spec:
             d.ss0, d.ss1, d.ss2 = sstr
             d.ds0, d.ds1, d.ds2 = dstr
             d.d0, d.d1, d.d2 = dims
-            d.flags = 1 if self.bf16 else 0
+            d.flags = (1 if self.bf16 else 0) | (8 if sg.lo else 0)
             d.block_start = start
             # transposes (destination contiguous along a2, source contiguous along the merged (a0, a1) index, strided
             # along a2): tiled through LDS by the kernel (flags bit1)
@@ -280,16 +289,58 @@ class _Spec:
                  "styler_strided_copy_multi")
 
 
+def x3(segs, g, W=None):
+    """The bf16x3 layout of a derived weight matrix [R, W] whose contraction axis is the minor one, tripled at granularity
+    `g` (W = kw * g for conv taps, W = g otherwise): every block [w] of g elements becomes [w_hi | w_lo | w_hi] -- the partner
+    of the activation block [a_hi | a_hi | a_lo] written by styler_split3_bf16.  `segs` are the Segs of the plain layout; a
+    destination offset r * W + t * g + c maps to r * 3W + t * 3g + part * g + c, strides that step rows or blocks triple."""
+    W = g if W is None else W
+
+    def off(o):
+        r, rem = divmod(o, W)
+        t, c = divmod(rem, g)
+        return r * 3 * W + t * 3 * g + c
+
+    def stride(st):
+        return 3 * st if (st != 0 and (st % W == 0 or st % g == 0)) else st
+
+    out = []
+    for sg in segs:
+        assert all(st == 0 or st % g == 0 or abs(st) == 1 for st in sg.dstr), (sg.dstr, g)
+        for part, lo in ((0, False), (1, True), (2, False)):
+            out.append(Seg(sg.src, sg.dims, sg.sstr, tuple(stride(st) for st in sg.dstr), src_off=sg.src_off,
+                           dst_off=off(sg.dst_off) + part * g, src2=sg.src2, lo=lo))
+    return out
+
+
 def gemm_weight(cache, key, weight, cin):
     """Kernel-layout weight for the current precision: ([n, kw*cin] tensor, prec)."""
     n = weight.shape[0]
     kdim = weight.numel() // n
+    if rt.prec == ops.PREC_BF16X3 and cin % 8 == 0:
+        # [n, kw, 3 cin]: per tap [w_hi | w_lo | w_hi] (x3): rows of `cin` elements inside a destination row of kw * cin
+        wx = cache.get_spec(key + ":x3", (n, 3 * kdim), True, lambda: x3([seg_conv_fwd(weight)], cin, kdim))
+        return wx, ops.PREC_BF16X3
     if rt.prec == ops.PREC_BF16 and cin % 8 == 0:
         wb = cache.get_spec(key + ":bf16", (n, kdim), True, lambda: [seg_conv_fwd(weight)])
         return wb, ops.PREC_BF16
     if weight.dim() == 2:
         return weight.detach(), ops.PREC_F32
     return cache.get_spec(key + ":k", (n, kdim), False, lambda: [seg_conv_fwd(weight)]), ops.PREC_F32
+
+
+def gemm_weight_bwd_auto(cache, key, weight):
+    """(dX-conv weight, precision of the dX GEMM) for the current arithmetic: bf16 shadow in throughput mode, the x3 layout
+    [cin, kw, 3 n] in bf16x3 mode (n % 8 == 0 in both), else the fp32 layout."""
+    n = weight.shape[0]
+    if rt.prec == ops.PREC_BF16 and n % 8 == 0:
+        return gemm_weight_bwd(cache, key, weight, True), ops.PREC_BF16
+    if rt.prec == ops.PREC_BF16X3 and n % 8 == 0:
+        cin = weight.shape[1]
+        kw = weight.shape[2] if weight.dim() == 3 else 1
+        return (cache.get_spec(key + ":Tx3", (cin, 3 * kw * n), True, lambda: x3([seg_conv_bwd(weight)], n, kw * n)),
+                ops.PREC_BF16X3)
+    return gemm_weight_bwd(cache, key, weight, False), ops.PREC_F32
 
 
 def gemm_weight_bwd(cache, key, weight, bf16):

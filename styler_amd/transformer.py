@@ -8,7 +8,7 @@ import torch.nn as nn
 from . import hparams as hp
 from . import autograd as AG
 from . import ops
-from .runtime import Derived, Seg, gemm_weight, rt, seg_rows
+from .runtime import Derived, Seg, gemm_weight, rt, seg_rows, x3
 
 
 def get_sinusoid_encoding_table(n_position, d_hid, padding_idx=None):
@@ -74,6 +74,9 @@ class MultiHeadAttention(_HipModule):
         srcs_b = [self.w_qs.bias, self.w_ks.bias, self.w_vs.bias]
         b = d.get_spec("qkv_b", (768,), False, lambda: [Seg(u, (256,), (1,), (1,), dst_off=k * 256)
                                                         for k, u in enumerate(srcs_b)])
+        if rt.prec == ops.PREC_BF16X3:                       # [768, 3 * 256]: rows [w_hi | w_lo | w_hi] (runtime.x3)
+            w = d.get_spec("qkv_wx3", (768, 768), True, lambda: x3([seg_rows(u, k * 256) for k, u in enumerate(srcs_w)], 256))
+            return w, b, ops.PREC_BF16X3
         bf16 = rt.prec == ops.PREC_BF16
         w = d.get_spec("qkv_w16" if bf16 else "qkv_w", (768, 256), bf16,
                        lambda: [seg_rows(u, k * 256) for k, u in enumerate(srcs_w)])

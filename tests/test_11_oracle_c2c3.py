@@ -10,6 +10,7 @@ Stated tolerances (also in DESIGN.md section 2); measured values are written to 
 
     mode   mel abs    losses rel   grad-norm rel   per-tensor gradient rel-L2: worst tensor / median over tensors
     fp32   1e-3       1e-4         1e-4            2e-3 / 1e-4
+    bf16x3 1e-3       1e-4         1e-4            4e-3 / 1e-4      (three bf16 products per fp32 product, round 4)
     bf16   6e-2       1e-2         1e-2            1e-1 / 2e-2
 
 Measured on MI355X (round 2): fp32 mel 5e-6 abs, losses 1e-7, worst tensor 7e-4 (embedding-table scatter), median 1.3e-5;
@@ -32,6 +33,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = {   # mode: (mel abs, loss rel, grad-norm rel, worst per-tensor grad rel-L2, median per-tensor grad rel-L2)
     "fp32": (1e-3, 1e-4, 1e-4, 2e-3, 1e-4),
     "bf16": (6e-2, 1e-2, 1e-2, 1e-1, 2e-2),
+    # round 4: fp32-class products on the bf16 matrix cores (operands split hi + lo, three bf16 products, fp32 accumulate and
+    # fp32 storage) -- held to the fp32 mode's bounds: this is the parity arithmetic that is not 16x slower per GEMM
+    # -- except the worst single tensor, 4e-3: the operands carry 16 mantissa bits, and the parameter with the longest
+    # backward path (first Conv1d of the AudioEncoder's mel stream) measures 2.4e-3 (1.6e-3 for the next tensor)
+    "bf16x3": (1e-3, 1e-4, 1e-4, 4e-3, 1e-4),
 }
 
 
@@ -85,7 +91,7 @@ def oracle_forward(bench_batch, ref_state_dict):
                                 speaker_embed=b["speaker_embed"], noisy_branch=False)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16x3"])
 def test_c2_forward_vs_oracle(dev, bench_batch, ref_state_dict, oracle_forward, prec):
     """BASELINE config 2: eval, teacher-forced, clean branch, B = 48 -- the `--mode fwd` workload of bench.py."""
     from styler_amd import STYLER, rt
@@ -117,7 +123,7 @@ def test_c2_forward_vs_oracle(dev, bench_batch, ref_state_dict, oracle_forward, 
         assert rep[k]["max_abs"] <= mel_abs, (k, rep[k])
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16x3"])
 def test_c3_train_step_vs_oracle(dev, bench_batch, ref_state_dict, oracle_train, prec):
     """BASELINE config 3 per-rank step (dual decode + DAT pass + ten losses + backward), B = 48: the default workload
     of bench.py, through the same TrainState / forward_backward path (flat gradient buffer, deferred split-K reduce)."""
