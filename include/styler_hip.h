@@ -128,6 +128,14 @@ int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, int prec);
  * styler_conv_gemm_packed, whose row count is a capacity).  Same arithmetic either way: both
  * engines accumulate the same v_mfma_f32_32x32x16_bf16 sequence, results are bit-equal. */
 int styler_conv_gemm_engine(int B, int L, int cin, int n, int kw, int prec, int io_flags, int64_t ldx, int packed);
+/* ... with the epilogue inputs that decide whether the 256 x 256 engine runs the launch as split-K = 2 (plain epilogue, no
+ * ReLU mask): 4 for those launches as well. */
+int styler_conv_gemm_engine2(int B, int L, int cin, int n, int kw, int prec, int io_flags, int64_t ldx, int packed,
+                             int act, int has_mask);
+/* Test-only policy overrides of that engine: split_mode 0 = policy, 1 = never split-K, 2 = split-K wherever the epilogue
+ * allows it; take_all 1 = no tile bound and no short-K guard (-1 keeps a value).  Returns the previous pair as
+ * split_mode | take_all << 2.  (The tile bound of styler_gemm256_config is only a bound.) */
+int styler_gemm256_policy(int split_mode, int take_all);
 /* Test / tuning hook of that engine: enabled (0 / 1) and the smallest tile count it takes; -1 keeps a value (defaults:
  * STYLER_GEMM256, STYLER_GEMM256_MIN_TILES or 1, 384).  Returns the previous state as enabled | min_tiles << 1. */
 int styler_gemm256_config(int enabled, int min_tiles);

@@ -76,6 +76,8 @@ _SIGS = {
     "styler_attention_bwd": [P, P, P, P, P, P, I, I, P, P, P],
     "styler_layernorm_bwd": [P, I64, P, I64, P, P, P, I64, P, P, P, P, P, P, I, I, I, P, F, ctypes.c_uint64, F, ctypes.c_uint64, P, I64, I, I, P],
     "styler_gemm256_config": [I, I],
+    "styler_gemm256_policy": [I, I],
+    "styler_conv_gemm_engine2": [I, I, I, I, I, I, I, I64, I, I, I],
     "styler_gemm_n96_config": [I, I],
     "styler_groupnorm_fused_rows": [I],
     "styler_conv_gemm_workspace_bytes": [I, I, I, I, I, I, I, I, I64, I, I],

@@ -502,17 +502,31 @@ __global__ __launch_bounds__(256) void gemm256_combine_kernel(const float* __res
 static int g_enabled = [] { const char* e = getenv("STYLER_GEMM256"); return e ? atoi(e) : 1; }();
 static int g_min_tiles = [] { const char* e = getenv("STYLER_GEMM256_MIN_TILES"); return e ? atoi(e) : 384; }();
 
+// Test-only policy overrides (round-3 advisor finding: the tile bound used to double as a mode switch -- 1 meant "take
+// everything, never split", 0 "force split-K" -- so tuning STYLER_GEMM256_MIN_TILES silently changed the split policy):
+//   g_split_mode: 0 = the policy below, 1 = never split-K, 2 = split-K wherever the epilogue allows it;
+//   g_take_all:   1 = every launch the kernel CAN run takes this engine (no tile bound, no short-K guard).
+static int g_split_mode = 0;
+static int g_take_all = 0;
+
 // Test / tuning hook: set the switch and the tile bound (-1 keeps a value); returns the previous state as
-// enabled | min_tiles << 1.
+// enabled | min_tiles << 1.  The tile bound is only a bound.
 extern "C" int styler_gemm256_config(int enabled, int min_tiles) {
   const int prev = (g_enabled ? 1 : 0) | (g_min_tiles << 1);
   if (enabled >= 0) g_enabled = enabled;
   if (min_tiles >= 0) g_min_tiles = min_tiles;
   return prev;
 }
+// split_mode / take_all as above (-1 keeps a value); returns the previous pair as split_mode | take_all << 2.
+extern "C" int styler_gemm256_policy(int split_mode, int take_all) {
+  const int prev = g_split_mode | (g_take_all << 2);
+  if (split_mode >= 0 && split_mode <= 2) g_split_mode = split_mode;
+  if (take_all >= 0) g_take_all = take_all ? 1 : 0;
+  return prev;
+}
 
 static bool gemm256_eligible(int B, int L, int cin, int n, int kw, int64_t ldx, int x16, bool packed, int* mt_out, int* nt_out) {
-  const int enabled = g_enabled, min_tiles = g_min_tiles > 1 ? g_min_tiles : 1;
+  const int enabled = g_enabled, min_tiles = g_take_all ? 1 : (g_min_tiles > 1 ? g_min_tiles : 1);
   if (!enabled || !x16) return false;
   if ((cin % BK) || (ldx & 7) || (n & 3) || kw > 9) return false;
   const int64_t M = (int64_t)B * L;
@@ -521,8 +535,7 @@ static bool gemm256_eligible(int B, int L, int cin, int n, int kw, int64_t ldx, 
   // VCTK shapes -- tiles behind the data exit at once, so the bound is applied to 60 % of the m-tiles
   const int64_t mt_eff = packed ? (mt * 3 + 4) / 5 : mt;
   if (mt_eff * nt < min_tiles) return false;
-  if (g_min_tiles > 1 && (cin / BK) * kw < 8) return false;          // short K: prologue + epilogue dominate a 1-block-per-CU tile
-                                                                   // (min_tiles == 1 = the tests' "take everything" setting)
+  if (!g_take_all && (cin / BK) * kw < 8) return false;             // short K: prologue + epilogue dominate a 1-block-per-CU tile
   if ((n % BN) > 0 && (n % BN) < 192) return false;                // a mostly empty last column tile wastes its MFMAs
   if (((M + 8) * ldx * 2) >= ((int64_t)1 << 31) || ((int64_t)n * kw * cin * 2) >= ((int64_t)1 << 31)) return false;
   *mt_out = mt; *nt_out = nt;
@@ -546,12 +559,12 @@ extern "C" int styler_gemm_set_workspace(void* ptr, int64_t bytes) {
 
 static int gemm256_ksplit(int B, int L, int cin, int n, int kw, int64_t ldx, int x16, bool packed, int act, bool has_mask) {
   static const int split_on = [] { const char* e = getenv("STYLER_GEMM256_SPLITK"); return e ? atoi(e) : 1; }();
-  if (!g_enabled || !split_on || !x16 || g_min_tiles == 1) return 1;      // min_tiles == 1: the tests' "one engine, unsplit" setting
+  if (!g_enabled || !split_on || !x16 || g_split_mode == 1) return 1;
   if ((cin % BK) || (ldx & 7) || (n % BN) || kw > 9 || (act & 0xff) != STYLER_ACT_NONE || (act & STYLER_ACT_RES_FIRST) || has_mask) return 1;
   const int64_t M = (int64_t)B * L;
   const int64_t mt = (M + BM - 1) / BM, nt = n / BN;
   const int64_t tiles = (packed ? (mt * 3 + 4) / 5 : mt) * nt;
-  if (g_min_tiles != 0 && (tiles < 96 || tiles > 160 || (cin / BK) * kw < 64)) return 1;   // min_tiles == 0: tests force the split
+  if (g_split_mode != 2 && (tiles < 96 || tiles > 160 || (cin / BK) * kw < 64)) return 1;
   if (((M + 8) * ldx * 2) >= ((int64_t)1 << 31) || ((int64_t)n * kw * cin * 2) >= ((int64_t)1 << 31)) return 1;
   return 2;
 }
@@ -598,8 +611,17 @@ int styler_gemm256_try(const GemmArgs& a0, int x16, int y16, hipStream_t st) {
 
 // Which engine / tile a styler_conv_gemm call with these arguments runs on: 0..3 = styler_conv_gemm_variant (bit 0: 128 x 128
 // tile, bit 1: bf16 MFMA), 4 = the 256 x 256 LDS-DMA engine of this file.
-extern "C" int styler_conv_gemm_engine(int B, int L, int cin, int n, int kw, int prec, int io_flags, int64_t ldx, int packed) {
+extern "C" int styler_conv_gemm_engine2(int B, int L, int cin, int n, int kw, int prec, int io_flags, int64_t ldx, int packed,
+                                        int act, int has_mask) {
   int mt, nt;
-  if (prec == STYLER_PREC_BF16 && gemm256_eligible(B, L, cin, n, kw, ldx, io_flags & STYLER_IO_X_BF16, packed != 0, &mt, &nt)) return 4;
+  if (prec == STYLER_PREC_BF16) {
+    // a split-K launch runs on this engine too (it bypasses the tile bound); it needs the caller's workspace, which the
+    // host layer supplies whenever styler_conv_gemm_workspace_bytes asks for one
+    if (gemm256_ksplit(B, L, cin, n, kw, ldx, io_flags & STYLER_IO_X_BF16, packed != 0, act, has_mask != 0) > 1) return 4;
+    if (gemm256_eligible(B, L, cin, n, kw, ldx, io_flags & STYLER_IO_X_BF16, packed != 0, &mt, &nt)) return 4;
+  }
   return styler_conv_gemm_variant(B, L, cin, n, kw, prec);
+}
+extern "C" int styler_conv_gemm_engine(int B, int L, int cin, int n, int kw, int prec, int io_flags, int64_t ldx, int packed) {
+  return styler_conv_gemm_engine2(B, L, cin, n, kw, prec, io_flags, ldx, packed, STYLER_ACT_NONE, 0);
 }

@@ -444,8 +444,10 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
         lib.styler_gemm_set_workspace(None, 0)       # (consumed by the call above; cleared again in case it never got there)
     if prof is not None:
         e1.record()
-        prof.records.append((lib.styler_conv_gemm_engine(B, L, cin, n, kw, prec, io, _ld(x), int(plan is not None)), 2.0 * B * L * n * kw * cin,
-                             e0, e1, plan is not None))
+        prof.records.append((lib.styler_conv_gemm_engine2(B, L, cin, n, kw, prec, io, _ld(x), int(plan is not None), act,
+                                                          int(mask is not None)) if ws is not None or not (io & 1)
+                             else lib.styler_conv_gemm_engine(B, L, cin, n, kw, prec, io, _ld(x), int(plan is not None)),
+                             2.0 * B * L * n * kw * cin, e0, e1, plan is not None))
     return out
 
 
@@ -501,12 +503,16 @@ def cast_bf16(src):
     return dst
 
 
-def gemm256_config(enabled=-1, min_tiles=-1):
-    """Test / tuning hook of the 256 x 256 LDS-DMA GEMM engine (csrc/gemm256.hip): switch it on / off and set the tile
-    count from which it takes a launch (-1 keeps a value).  Returns the previous (enabled, min_tiles)."""
+def gemm256_config(enabled=-1, min_tiles=-1, split=-1, take_all=-1):
+    """Test / tuning hook of the 256 x 256 LDS-DMA GEMM engine (csrc/gemm256.hip): switch it on / off, set the tile count
+    from which it takes a launch, and the test-only policy overrides `split` (0 policy, 1 never split-K, 2 split-K wherever
+    the epilogue allows it) and `take_all` (1: no tile bound, no short-K guard); -1 keeps a value.  Returns the previous
+    (enabled, min_tiles, split, take_all)."""
     prev = lib.styler_gemm256_config(-1, -1)
+    pol = lib.styler_gemm256_policy(-1, -1)
     lib.styler_gemm256_config(int(enabled), int(min_tiles))
-    return prev & 1, prev >> 1
+    lib.styler_gemm256_policy(int(split), int(take_all))
+    return prev & 1, prev >> 1, pol & 3, pol >> 2
 
 
 def gemm_n96_config(enabled=-1, min_rows=-1):

@@ -138,11 +138,11 @@ def test_gemm256_engine_vs_math_and_vs_128_engine(dev, case):
                 lens=torch.tensor(lens).to(dev) if lens is not None else None, mask=mask.to(dev) if with_mask else None,
                 out_bf16=y16)
     xd, bd = x16.to(dev), b.to(dev)
-    prev = ops.gemm256_config(1, 1)
+    prev = ops.gemm256_config(1, -1, split=1, take_all=1)
     try:
         assert ops.lib.styler_conv_gemm_engine(B, L, cin, n, kw, ops.PREC_BF16, 1, cin, 0) == 4
         ys = [ops.conv_gemm(xd, wk, bd, **args).clone() for _ in range(4)]
-        ops.gemm256_config(0, -1)
+        ops.gemm256_config(0)
         assert ops.lib.styler_conv_gemm_engine(B, L, cin, n, kw, ops.PREC_BF16, 1, cin, 0) != 4
         y128 = ops.conv_gemm(xd, wk, bd, **args)
     finally:
@@ -218,10 +218,10 @@ def test_gemm256_engine_packed_rows(dev):
     plan = ops.PackPlan(lens.to(dev), B, T)
     xp = ops.pack_rows(xs.to(dev), plan).to(torch.bfloat16)
     wk = w16.permute(0, 2, 1).reshape(n, -1).contiguous().to(dev)
-    prev = ops.gemm256_config(1, 1)
+    prev = ops.gemm256_config(1, -1, split=1, take_all=1)
     try:
         yp = [ops.conv_gemm(xp, wk, None, kw=kw, prec=ops.PREC_BF16, plan=plan).clone() for _ in range(3)]
-        ops.gemm256_config(0, -1)
+        ops.gemm256_config(0)
         y128 = ops.conv_gemm(xp, wk, None, kw=kw, prec=ops.PREC_BF16, plan=plan)
     finally:
         ops.gemm256_config(*prev)
@@ -258,14 +258,14 @@ def test_gemm256_split_k(dev, packed):
         xd, rd = x.to(torch.bfloat16).to(dev), res.to(dev)
         run = lambda: ops.conv_gemm(xd, wk, b.to(dev), kw=kw, prec=ops.PREC_BF16, res=rd)
         shape = (B, T)
-    prev = ops.gemm256_config(1, 0)                     # 0 = force the split wherever the epilogue allows it
+    prev = ops.gemm256_config(1, -1, split=2, take_all=1)     # force the split wherever the epilogue allows it
     try:
         assert ops.lib.styler_conv_gemm_workspace_bytes(shape[0], shape[1], cin, n, kw, 0, ops.PREC_BF16, 1, cin, int(packed), 0) \
             == 2 * shape[0] * shape[1] * n * 4
         ys = [run().clone() for _ in range(3)]
-        ops.gemm256_config(1, 1)
+        ops.gemm256_config(1, -1, split=1, take_all=1)
         y1 = run()
-        ops.gemm256_config(0, -1)
+        ops.gemm256_config(0)
         y128 = run()
     finally:
         ops.gemm256_config(*prev)

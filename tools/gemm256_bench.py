@@ -41,7 +41,7 @@ def main():
         try:
             for r in range(rounds):
                 for eng in (0, 1):
-                    ops.gemm256_config(eng, 1)
+                    ops.gemm256_config(eng, -1, split=1, take_all=1)
                     for _ in range(2):
                         ops.conv_gemm(x, w, b, kw=kw, act=act, prec=ops.PREC_BF16, out=y)
                     iters = max(3, min(20, int(4e-3 / (fl / 0.9e15))))
