@@ -660,6 +660,17 @@ int styler_nll(const float* logp, const int64_t* label, float* loss, const float
  * entry (sum, count, arrival ticket, pad); mean_out[0] = sum / count, written by the last block (may be NULL: sums only). */
 int styler_masked_err_mean(const float* a, int64_t lda, const float* b, int64_t ldb, double* acc, float* mean_out,
                            int kind, int B, int L, int C, const int64_t* len, void* stream);
+/* Up to 8 masked-error terms per launch (forward: mean + accumulator per term; backward: da = gscale * d mean / d a):
+ * loss.py:16-50 calls MSELoss / L1Loss on masked_select copies five times per STYLERLoss.forward and twice per
+ * cal_mel_loss -- here one launch each way per call.  Fields as the arguments of styler_masked_err_mean / _bwd
+ * (a, b [B, L, C] with row strides lda / ldb; acc 4 doubles, zero on entry of the forward; len int64 [B] or NULL). */
+typedef struct StylerMaskedTerm {
+  const void* a; const void* b; void* acc; void* mean; const void* len; const void* gscale; void* da;
+  int64_t lda, ldb;
+  int32_t B, L, C, kind;
+} StylerMaskedTerm;
+int styler_masked_err_mean_multi(const StylerMaskedTerm* terms, int count, void* stream);
+int styler_masked_err_bwd_multi(const StylerMaskedTerm* terms, int count, void* stream);
 /* The three NLLLoss(mean) terms of one classifier triple, summed (loss.py:46-48, 60-68): loss[0] = sum_k -mean_b
  * logp_k[b, label[b]] (label NULL: every label = label_const, the zeros / ones of train.py:139,152); with dlogp3
  * ([3, B, 2]) also the gradient -gscale[0] / B at the label entry, 0 elsewhere. */

@@ -57,6 +57,8 @@ _SIGS = {
     "styler_bucket_embed_add": [P, I64, P, I64, P, F, P, F, P, P, P, P, P, P, I64, P, P, P, I, I, P],
     "styler_add2": [P, I64, P, I64, P, I64, I64, I, P],
     "styler_copy_rows_multi": [P, I, P],
+    "styler_masked_err_mean_multi": [P, I, P],
+    "styler_masked_err_bwd_multi": [P, I, P],
     "styler_split3_bf16": [P, I64, P, I64, I, P, P],
     "styler_lo_part": [P, I64, P, I64, I, P, P],
     "styler_add_rowvec": [P, I64, P, I64, P, I64, I, I, I, P],
@@ -127,6 +129,11 @@ class WgradGroupDesc(ctypes.Structure):
                 ("lddz", ctypes.c_int64), ("ldx", ctypes.c_int64)] + \
                [(k, ctypes.c_int32) for k in ("B", "L", "n", "cin", "pad_left", "ct", "cpi", "cps", "tiles", "splits",
                                               "block_start", "nblocks", "variant", "kw")]
+
+
+class MaskedTerm(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_void_p) for k in ("a", "b", "acc", "mean", "len", "gscale", "da")] + \
+               [("lda", ctypes.c_int64), ("ldb", ctypes.c_int64)] + [(k, ctypes.c_int32) for k in ("B", "L", "C", "kind")]
 
 
 class CopySeg(ctypes.Structure):

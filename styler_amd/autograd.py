@@ -889,6 +889,34 @@ class MaskedErrFn(Function):
         return ops.masked_err_bwd(a, b, acc, g.reshape(1), ctx.kind, lens), None, None, None
 
 
+class MaskedErrMultiFn(Function):
+    """Several masked MSE / L1 means (loss.py:16-50) as ONE tape node: one launch forward, one backward.
+    apply(kinds, lens_list, a0, b0, a1, b1, ...) -> tuple of scalar means."""
+
+    @staticmethod
+    def forward(ctx, kinds, lens_list, *ab):
+        a_s = [t.contiguous() for t in ab[0::2]]
+        b_s = [t.contiguous() for t in ab[1::2]]
+        means, accs = ops.masked_err_mean_multi([(a, b, k, l) for a, b, k, l in zip(a_s, b_s, kinds, lens_list)])
+        ctx.save_for_backward(*a_s, *b_s, *accs, *[l for l in lens_list if l is not None])
+        ctx.kinds, ctx.has_len, ctx.n = kinds, [l is not None for l in lens_list], len(a_s)
+        return tuple(m.view(()) for m in means)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n = ctx.n
+        t = ctx.saved_tensors
+        a_s, b_s, accs, rest = t[0:n], t[n:2 * n], t[2 * n:3 * n], list(t[3 * n:])
+        lens = [rest.pop(0) if h else None for h in ctx.has_len]
+        live = [i for i in range(n) if gs[i] is not None and ctx.needs_input_grad[2 + 2 * i]]
+        das = ops.masked_err_bwd_multi([(a_s[i], b_s[i], accs[i], gs[i].reshape(1), ctx.kinds[i], lens[i]) for i in live]) if live else []
+        out = [None, None]
+        it = iter(das)
+        for i in range(n):
+            out += [next(it) if i in live else None, None]
+        return tuple(out)
+
+
 class Nll3Fn(Function):
     """3 x NLLLoss(mean) on [B, 2] log-probabilities, summed (loss.py:46-48 / 60-68): one launch each way."""
 

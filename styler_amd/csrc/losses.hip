@@ -16,11 +16,12 @@ static inline unsigned loss_grid(int64_t work, int per_block, int cap) {
 
 // acc: 4 doubles, zero on entry: [0] sum of errors, [1] count of valid elements, [2] arrival ticket (as uint64), [3] unused.
 // The block that draws the last ticket reads the two totals back through the same atomics path and writes the mean.
-__global__ __launch_bounds__(256) void masked_err_mean_kernel(const float* __restrict__ a, int64_t lda,
-                                                              const float* __restrict__ b, int64_t ldb,
-                                                              double* __restrict__ acc, float* __restrict__ mean_out,
-                                                              int kind, int64_t rows, int L, int C,
-                                                              const int64_t* __restrict__ len, int vec) {
+__device__ __forceinline__ void masked_err_mean_body(const float* __restrict__ a, int64_t lda,
+                                                     const float* __restrict__ b, int64_t ldb,
+                                                     double* __restrict__ acc, float* __restrict__ mean_out,
+                                                     int kind, int64_t rows, int L, int C,
+                                                     const int64_t* __restrict__ len, int vec, const unsigned bx,
+                                                     const unsigned nbx) {
   __shared__ double red[4][2];
   double s = 0.0, n = 0.0;
   if (vec) {                                             // host: C % 4 == 0, C <= 1024, 16-byte aligned rows, rows < 2^31
@@ -29,9 +30,9 @@ __global__ __launch_bounds__(256) void masked_err_mean_kernel(const float* __res
     // element and a branch around its loads: thirteen dependent round trips per thread on the mel tensors)
     const int nq = C >> 2, lanes = 256 / nq;
     const int rl = threadIdx.x / nq, ql = threadIdx.x - rl * nq;
-    const int64_t stride = (int64_t)gridDim.x * lanes;
+    const int64_t stride = (int64_t)nbx * lanes;
     if (rl < lanes) {
-      for (int64_t row0 = (int64_t)blockIdx.x * lanes + rl; row0 < rows; row0 += 4 * stride) {
+      for (int64_t row0 = (int64_t)bx * lanes + rl; row0 < rows; row0 += 4 * stride) {
         float4 x[4], y[4];
         int64_t rc[4], lv[4];
         uint32_t tt[4];
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void masked_err_mean_kernel(const float* __res
     }
   } else {
     const int64_t total = rows * C;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < total; i += (int64_t)nbx * blockDim.x) {
       const int64_t row = i / C; const int c = (int)(i - row * C);
       const int64_t bb = row / L;
       if (len && (row - bb * L) >= len[bb]) continue;
@@ -89,13 +90,61 @@ __global__ __launch_bounds__(256) void masked_err_mean_kernel(const float* __res
     if (mean_out) {
       __threadfence();
       const unsigned long long t = atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2]), 1ull);
-      if (t == (unsigned long long)gridDim.x - 1) {
+      if (t == (unsigned long long)nbx - 1) {
         __threadfence();
         const double tot = atomicAdd(&acc[0], 0.0), cnt = atomicAdd(&acc[1], 0.0);   // read at the atomics' coherence point
         mean_out[0] = (float)(tot / cnt);
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void masked_err_mean_kernel(const float* __restrict__ a, int64_t lda,
+                                                              const float* __restrict__ b, int64_t ldb,
+                                                              double* __restrict__ acc, float* __restrict__ mean_out,
+                                                              int kind, int64_t rows, int L, int C,
+                                                              const int64_t* __restrict__ len, int vec) {
+  masked_err_mean_body(a, lda, b, ldb, acc, mean_out, kind, rows, L, C, len, vec, blockIdx.x, gridDim.x);
+}
+
+// Up to 8 masked-error terms in ONE launch (blockIdx.y = term; the descriptors travel in the kernel arguments): the five
+// terms of STYLERLoss.forward (loss.py:26-50) and the two of cal_mel_loss (16-24) were seven launches of 7-15 us each on the
+// serial chain between the forward and the backward of a step.
+struct MaskedTerms {
+  const float* a[8]; const float* b[8];
+  double* acc[8]; float* mean[8];
+  const int64_t* len[8];
+  int64_t lda[8], ldb[8], rows[8];
+  int32_t L[8], C[8], kind[8], vec[8], nblk[8];
+  int32_t n;
+};
+__global__ __launch_bounds__(256) void masked_err_mean_multi_kernel(const MaskedTerms t) {
+  const int k = blockIdx.y;
+  if (k >= t.n || (int)blockIdx.x >= t.nblk[k]) return;
+  masked_err_mean_body(t.a[k], t.lda[k], t.b[k], t.ldb[k], t.acc[k], t.mean[k], t.kind[k], t.rows[k], t.L[k], t.C[k], t.len[k],
+                       t.vec[k], blockIdx.x, (unsigned)t.nblk[k]);
+}
+
+extern "C" int styler_masked_err_mean_multi(const StylerMaskedTerm* terms, int count, void* stream) {
+  if (!terms || count <= 0 || count > 8) return STYLER_EINVAL;
+  MaskedTerms t;
+  int most = 0;
+  for (int k = 0; k < count; ++k) {
+    const StylerMaskedTerm& m = terms[k];
+    if (!m.a || !m.b || !m.acc || !m.mean || m.B <= 0 || m.L <= 0 || m.C <= 0 || (m.kind != 0 && m.kind != 1)) return STYLER_EINVAL;
+    const int64_t rows = (int64_t)m.B * m.L;
+    const int vec = !(m.C & 3) && m.C <= 1024 && !(m.lda & 3) && !(m.ldb & 3) && rows < ((int64_t)1 << 31) &&
+                    !(((uintptr_t)m.a | (uintptr_t)m.b) & 15);
+    t.a[k] = reinterpret_cast<const float*>(m.a); t.b[k] = reinterpret_cast<const float*>(m.b);
+    t.acc[k] = reinterpret_cast<double*>(m.acc); t.mean[k] = reinterpret_cast<float*>(m.mean);
+    t.len[k] = reinterpret_cast<const int64_t*>(m.len);
+    t.lda[k] = m.lda; t.ldb[k] = m.ldb; t.rows[k] = rows; t.L[k] = m.L; t.C[k] = m.C; t.kind[k] = m.kind; t.vec[k] = vec;
+    t.nblk[k] = (int)loss_grid(rows * m.C / (vec ? 4 : 1), 1024, 256);
+    most = t.nblk[k] > most ? t.nblk[k] : most;
+  }
+  t.n = count;
+  hipLaunchKernelGGL(masked_err_mean_multi_kernel, dim3((unsigned)most, (unsigned)count), dim3(256), 0, (hipStream_t)stream, t);
+  return launch_status();
 }
 
 extern "C" int styler_masked_err_mean(const float* a, int64_t lda, const float* b, int64_t ldb, double* acc, float* mean_out,

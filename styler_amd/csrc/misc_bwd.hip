@@ -325,19 +325,19 @@ extern "C" int styler_rowsum(const float* x, int64_t ldx, float* out, int64_t ld
 // of a row from one 32-bit division per row -- the flat element loop it replaces paid two 64-bit divisions and a branch
 // around its loads per ELEMENT.  Other shapes take the flat loop.
 template <bool VEC>
-__global__ __launch_bounds__(256) void masked_err_bwd_kernel(const float* __restrict__ a, int64_t lda,
-                                                             const float* __restrict__ b, int64_t ldb,
-                                                             const double* __restrict__ acc,
-                                                             const float* __restrict__ gscale, float* __restrict__ da,
-                                                             int kind, int64_t rows, int L, int C,
-                                                             const int64_t* __restrict__ len) {
+__device__ __forceinline__ void masked_err_bwd_body(const float* __restrict__ a, int64_t lda,
+                                                    const float* __restrict__ b, int64_t ldb,
+                                                    const double* __restrict__ acc,
+                                                    const float* __restrict__ gscale, float* __restrict__ da,
+                                                    int kind, int64_t rows, int L, int C,
+                                                    const int64_t* __restrict__ len, const unsigned bx, const unsigned nbx) {
   const float k = gscale[0] / (float)acc[1];
   if constexpr (VEC) {
     const int nq = C >> 2, lanes = 256 / nq;
     const int rl = threadIdx.x / nq, ql = threadIdx.x - rl * nq;
     if (rl >= lanes) return;
-    const int64_t stride = (int64_t)gridDim.x * lanes;
-    for (int64_t row0 = (int64_t)blockIdx.x * lanes + rl; row0 < rows; row0 += 4 * stride) {
+    const int64_t stride = (int64_t)nbx * lanes;
+    for (int64_t row0 = (int64_t)bx * lanes + rl; row0 < rows; row0 += 4 * stride) {
       float4 x[4], y[4];
       int64_t rc[4], lv[4];
       uint32_t tt[4];
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void masked_err_bwd_kernel(const float* __rest
     }
   } else {
     const int64_t total = rows * C;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < total; i += (int64_t)nbx * blockDim.x) {
       const int64_t row = i / C; const int c = (int)(i - row * C);
       const int64_t bb = row / L;
       float g = 0.f;
@@ -390,6 +390,66 @@ __global__ __launch_bounds__(256) void masked_err_bwd_kernel(const float* __rest
       da[i] = g;
     }
   }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void masked_err_bwd_kernel(const float* __restrict__ a, int64_t lda,
+                                                             const float* __restrict__ b, int64_t ldb,
+                                                             const double* __restrict__ acc,
+                                                             const float* __restrict__ gscale, float* __restrict__ da,
+                                                             int kind, int64_t rows, int L, int C,
+                                                             const int64_t* __restrict__ len) {
+  masked_err_bwd_body<VEC>(a, lda, b, ldb, acc, gscale, da, kind, rows, L, C, len, blockIdx.x, gridDim.x);
+}
+
+// The backward of up to 8 masked-error terms in one launch (blockIdx.y = term), see styler_masked_err_mean_multi.
+struct MaskedBwdTerms {
+  const float* a[8]; const float* b[8]; const double* acc[8]; const float* g[8]; float* da[8];
+  const int64_t* len[8];
+  int64_t lda[8], ldb[8], rows[8];
+  int32_t L[8], C[8], kind[8], vec[8], nblk[8];
+  int32_t n;
+};
+__global__ __launch_bounds__(256) void masked_err_bwd_multi_kernel(const MaskedBwdTerms t) {
+  const int k = blockIdx.y;
+  if (k >= t.n || (int)blockIdx.x >= t.nblk[k]) return;
+  if (t.vec[k])
+    masked_err_bwd_body<true>(t.a[k], t.lda[k], t.b[k], t.ldb[k], t.acc[k], t.g[k], t.da[k], t.kind[k], t.rows[k], t.L[k], t.C[k],
+                              t.len[k], blockIdx.x, (unsigned)t.nblk[k]);
+  else
+    masked_err_bwd_body<false>(t.a[k], t.lda[k], t.b[k], t.ldb[k], t.acc[k], t.g[k], t.da[k], t.kind[k], t.rows[k], t.L[k], t.C[k],
+                               t.len[k], blockIdx.x, (unsigned)t.nblk[k]);
+}
+
+extern "C" int styler_masked_err_bwd_multi(const StylerMaskedTerm* terms, int count, void* stream) {
+  if (!terms || count <= 0 || count > 8) return STYLER_EINVAL;
+  MaskedBwdTerms t;
+  int most = 0;
+  for (int k = 0; k < count; ++k) {
+    const StylerMaskedTerm& m = terms[k];
+    if (!m.a || !m.b || !m.acc || !m.gscale || !m.da || m.B <= 0 || m.L <= 0 || m.C <= 0 || (m.kind != 0 && m.kind != 1)) return STYLER_EINVAL;
+    const int64_t rows = (int64_t)m.B * m.L;
+    const bool vec = !(m.C & 3) && m.C <= 1024 && !(m.lda & 3) && !(m.ldb & 3) && rows < ((int64_t)1 << 31) &&
+                     !(((uintptr_t)m.a | (uintptr_t)m.b | (uintptr_t)m.da) & 15);
+    t.a[k] = reinterpret_cast<const float*>(m.a); t.b[k] = reinterpret_cast<const float*>(m.b);
+    t.acc[k] = reinterpret_cast<const double*>(m.acc); t.g[k] = reinterpret_cast<const float*>(m.gscale);
+    t.da[k] = reinterpret_cast<float*>(m.da); t.len[k] = reinterpret_cast<const int64_t*>(m.len);
+    t.lda[k] = m.lda; t.ldb[k] = m.ldb; t.rows[k] = rows; t.L[k] = m.L; t.C[k] = m.C; t.kind[k] = m.kind; t.vec[k] = vec ? 1 : 0;
+    int64_t blocks;
+    if (vec) {
+      const int lanes = 256 / (m.C >> 2);
+      blocks = (rows + (int64_t)lanes * 4 - 1) / ((int64_t)lanes * 4);
+      if (blocks > 2048) blocks = 2048;
+    } else {
+      blocks = (rows * m.C + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+    }
+    t.nblk[k] = (int)(blocks < 1 ? 1 : blocks);
+    most = t.nblk[k] > most ? t.nblk[k] : most;
+  }
+  t.n = count;
+  hipLaunchKernelGGL(masked_err_bwd_multi_kernel, dim3((unsigned)most, (unsigned)count), dim3(256), 0, (hipStream_t)stream, t);
+  return launch_status();
 }
 
 extern "C" int styler_masked_err_bwd(const float* a, int64_t lda, const float* b, int64_t ldb, const double* acc,

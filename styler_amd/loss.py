@@ -17,6 +17,19 @@ def _masked_mean(a, b, kind, lens):
     return ops.masked_err_mean(a.contiguous(), b.contiguous(), kind, lens)[0].view(())
 
 
+def _masked_means(terms):
+    """[(a, b, kind, lens), ...] -> tuple of scalar means: ONE launch for all terms of a loss call (and one in backward)."""
+    if torch.is_grad_enabled() and all(a.requires_grad for a, _, _, _ in terms):
+        flat = []
+        for a, b, _, _ in terms:
+            flat += [a, b.detach()]
+        return AG.MaskedErrMultiFn.apply(tuple(k for _, _, k, _ in terms), tuple(l for _, _, _, l in terms), *flat)
+    if any(a.requires_grad for a, _, _, _ in terms) and torch.is_grad_enabled():
+        return tuple(_masked_mean(a, b, k, l) for a, b, k, l in terms)
+    means, _ = ops.masked_err_mean_multi([(a.contiguous(), b.contiguous(), k, l) for a, b, k, l in terms])
+    return tuple(m.view(()) for m in means)
+
+
 def _nll3(posteriors, label):
     """3 x NLLLoss(mean) on [B, 2] log-probabilities, summed (loss.py:46-48): one kernel.  `label`: int64 [B] tensor as in
     the reference call, or the python int 0 / 1 when every label is the same (train.py:139,152 builds zeros / ones)."""
@@ -32,14 +45,15 @@ class STYLERLoss(nn.Module):
 
     def cal_mel_loss(self, mel, mel_postnet, mel_target, mel_mask, mel_len=None):
         lens = mel_len if mel_len is not None else mel_mask.sum(dim=1).to(torch.int64)
-        return _masked_mean(mel, mel_target, 0, lens), _masked_mean(mel_postnet, mel_target, 0, lens)
+        return _masked_means([(mel, mel_target, 0, lens), (mel_postnet, mel_target, 0, lens)])
 
     def forward(self, log_d_predicted, log_d_target, p_predicted, p_target, e_predicted, e_target, mel, mel_postnet,
                 mel_target, src_mask, mel_mask, src_len, mel_len, aug_posteriors, aug_label):
-        mel_loss, mel_postnet_loss = self.cal_mel_loss(mel, mel_postnet, mel_target, mel_mask, mel_len)
-        d_loss = _masked_mean(log_d_predicted, log_d_target, 1, src_len)
-        p_loss = _masked_mean(p_predicted, p_target, 1, mel_len)
-        e_loss = _masked_mean(e_predicted, e_target, 1, mel_len)
+        lens = mel_len if mel_len is not None else mel_mask.sum(dim=1).to(torch.int64)
+        slens = src_len if src_len is not None else src_mask.sum(dim=1).to(torch.int64)
+        mel_loss, mel_postnet_loss, d_loss, p_loss, e_loss = _masked_means([
+            (mel, mel_target, 0, lens), (mel_postnet, mel_target, 0, lens), (log_d_predicted, log_d_target, 1, slens),
+            (p_predicted, p_target, 1, lens), (e_predicted, e_target, 1, lens)])
         return mel_loss, mel_postnet_loss, d_loss, p_loss, e_loss, _nll3(aug_posteriors, aug_label)
 
 

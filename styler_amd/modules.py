@@ -251,7 +251,8 @@ class StyleEncoder(_HipModule):
             d, p, e, n = self.audio_encoder(enc_cat, len2, src2, mask=None, max_seq_len=text.shape[1])
             (d, d2), (p, p2), (e, e2) = (AG.SplitBatchFn.apply(t) for t in (d, p, e))
             self.dat_encodings = (d2, p2, e2)
-            n = n[:B]                                  # the DAT pass has no use for the noise stream (train.py:150-153)
+            n, _ = AG.SplitBatchFn.apply(n)            # the DAT pass has no use for the noise stream (train.py:150-153);
+            # (a plain n[:B] makes autograd zero-fill the full tensor and copy the half into it: a fill + a memcpy node)
         else:
             enc_cat = self.encoder_input_cat(mel_target, p_norm, e_input, mel_aug)
             d, p, e, n = self.audio_encoder(enc_cat, mel_len, src_len, mask=None, max_seq_len=text.shape[1])

@@ -1193,6 +1193,48 @@ def masked_err_mean(a, b, kind, lens):
     return out, acc
 
 
+def _masked_dims(a, b):
+    if a.dim() == 2:
+        return a.shape[0], a.shape[1], 1, 1, 1
+    return a.shape[0], a.shape[1], a.shape[2], _ld(a), _ld(b)
+
+
+def masked_err_mean_multi(terms):
+    """[(a, b, kind, lens), ...] (<= 8) -> ([mean [1] fp32, ...], [acc [4] fp64, ...]): the masked MSE / L1 terms of one loss
+    call in ONE launch (styler_masked_err_mean_multi)."""
+    from ._lib import MaskedTerm
+    arr = (MaskedTerm * len(terms))()
+    means = torch.empty(len(terms), device=terms[0][0].device, dtype=torch.float32)
+    accs = []
+    for k, (a, b, kind, lens) in enumerate(terms):
+        B, L, C, lda, ldb = _masked_dims(a, b)
+        acc = zero_slab.take(4) if zero_slab is not None else None
+        if acc is None:
+            acc = torch.zeros(4, dtype=torch.float64, device=a.device)
+        accs.append(acc)
+        m = arr[k]
+        m.a, m.b, m.acc, m.mean, m.len = _f32(a).data_ptr(), _f32(b).data_ptr(), acc.data_ptr(), means[k:k + 1].data_ptr(), _ptr(lens)
+        m.lda, m.ldb, m.B, m.L, m.C, m.kind = lda, ldb, B, L, C, kind
+    _chk(lib.styler_masked_err_mean_multi(arr, len(terms), _stream()), "styler_masked_err_mean_multi")
+    return [means[k:k + 1] for k in range(len(terms))], accs
+
+
+def masked_err_bwd_multi(terms):
+    """[(a, b, acc, gscale [1], kind, lens), ...] -> [da, ...] in one launch."""
+    from ._lib import MaskedTerm
+    arr = (MaskedTerm * len(terms))()
+    outs = []
+    for k, (a, b, acc, g, kind, lens) in enumerate(terms):
+        B, L, C, lda, ldb = _masked_dims(a, b)
+        da = torch.empty(a.shape, device=a.device, dtype=torch.float32)
+        outs.append(da)
+        m = arr[k]
+        m.a, m.b, m.acc, m.gscale, m.da, m.len = a.data_ptr(), b.data_ptr(), acc.data_ptr(), g.data_ptr(), da.data_ptr(), _ptr(lens)
+        m.lda, m.ldb, m.B, m.L, m.C, m.kind = lda, ldb, B, L, C, kind
+    _chk(lib.styler_masked_err_bwd_multi(arr, len(terms), _stream()), "styler_masked_err_bwd_multi")
+    return outs
+
+
 def nll3(lps, label, gscale=None, want_grad=False):
     """Three NLLLoss(mean) terms summed.  `label`: int64 [B] tensor, or the python int 0 / 1 (all labels equal)."""
     B = lps[0].shape[0]
