@@ -440,7 +440,7 @@ __global__ void bn_fold_copies_kernel(double* __restrict__ ws, int C2, int segs)
 
 int styler_bn_colstats(bool bwd, const void* x, const float* y, const void* dy, const float* mean, const float* rstd,
                        double* ws, int ws_zeroed, int64_t rows, int C, int act, const float* gamma, const float* beta,
-                       float drop_p, uint64_t drop_seed, int segs, int dy16, int x16, hipStream_t st) {
+                       float drop_p, uint64_t drop_seed, int segs, int dy16, int x16, hipStream_t st, bool fold) {
   if (!ws_zeroed) {
     hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * STYLER_BN_COPIES * segs, st);
     if (e != hipSuccess) return (int)e;
@@ -461,7 +461,8 @@ int styler_bn_colstats(bool bwd, const void* x, const float* y, const void* dy, 
   else if (x16) BN_STATS_LAUNCH(false, false, true);
   else BN_STATS_LAUNCH(false, false, false);
 #undef BN_STATS_LAUNCH
-  hipLaunchKernelGGL(bn_fold_copies_kernel, dim3((2 * C * segs + 255) / 256), dim3(256), 0, st, ws, 2 * C, segs);
+  // (the forward's finalize kernel sums the replicas itself: one launch less per BatchNorm layer)
+  if (fold) hipLaunchKernelGGL(bn_fold_copies_kernel, dim3((2 * C * segs + 255) / 256), dim3(256), 0, st, ws, 2 * C, segs);
   return 0;
 }
 
@@ -472,8 +473,11 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, float* save_me
   const double n = (double)(rows / segs);
   for (int seg = 0; seg < segs; ++seg) {             // the running statistics see the segments as consecutive calls
     const double* w = ws + (int64_t)seg * STYLER_BN_COPIES * 2 * C;
-    const double mean = w[c] / n;
-    double var = w[C + c] / n - mean * mean;
+    double s1 = 0.0, s2 = 0.0;                       // the replicas of the column sums, in replica order (bn_fold_copies' sum)
+#pragma unroll
+    for (int k = 0; k < STYLER_BN_COPIES; ++k) { s1 += w[(int64_t)k * 2 * C + c]; s2 += w[(int64_t)k * 2 * C + C + c]; }
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
     if (var < 0.0) var = 0.0;
     save_mean[seg * C + c] = (float)mean;
     save_rstd[seg * C + c] = (float)(1.0 / sqrt(var + 1e-5));
@@ -559,7 +563,7 @@ extern "C" int styler_batchnorm_train(const float* x, const float* gamma, const 
   hipStream_t st = (hipStream_t)stream;
   const int x16 = (io_flags & STYLER_IO_Z_BF16) ? 1 : 0;
   const int rc = styler_bn_colstats(false, x, nullptr, nullptr, nullptr, nullptr, workspace, ws_zeroed, rows, C, act, nullptr,
-                                    nullptr, 0.f, 0, segs, 0, x16, st);
+                                    nullptr, 0.f, 0, segs, 0, x16, st, /*fold=*/false);
   if (rc) return rc;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, save_mean, save_rstd,
                      running_mean, running_var, rows, C, segs);

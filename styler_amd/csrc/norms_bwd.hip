@@ -594,7 +594,7 @@ extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void
 //   dz = dy * act'(y); dgamma = sum dz*xh; dbeta = sum dz; dx = g*rstd*(dz - dbeta/N - xh*dgamma/N)
 int styler_bn_colstats(bool bwd, const void* x, const float* y, const void* dy, const float* mean, const float* rstd,
                        double* ws, int ws_zeroed, int64_t rows, int C, int act, const float* gamma, const float* beta,
-                       float drop_p, uint64_t drop_seed, int segs, int dy16, int x16, hipStream_t st);   // norms.hip
+                       float drop_p, uint64_t drop_seed, int segs, int dy16, int x16, hipStream_t st, bool fold);   // norms.hip
 #define STYLER_BN_COPIES 16                          // norms.hip
 
 // Same geometry as the forward's column statistics / apply kernels (norms.hip): block = (segment, chunk of rpb rows),
@@ -691,7 +691,7 @@ extern "C" int styler_batchnorm_bwd(const float* x, const float* y, const void* 
   const int dy16 = (io_flags & STYLER_IO_X_BF16) ? 1 : 0;
   const int x16 = (io_flags & STYLER_IO_Z_BF16) ? 1 : 0;
   const int rc = styler_bn_colstats(true, x, y, dy, save_mean, save_rstd, workspace, ws_zeroed, rows, C, act, gamma, beta,
-                                    drop_p, drop_seed, segs, dy16, x16, st);
+                                    drop_p, drop_seed, segs, dy16, x16, st, /*fold=*/true);
   if (rc) return rc;
   constexpr int RPB = 32;
   const int64_t rps = rows / segs;
