@@ -191,6 +191,9 @@ def run(args, mode, prec, rank, world, dev, dist, with_cpu=True, with_roofline=T
     n_graphs = len(getattr(graph, "graphs", ())) if (train and graph is not None) else (1 if graph is not None else 0)
     if state is not None:
         ar = state.allreduce_info()
+        if world > 1:                               # what a gradient all-reduce costs on this job's links (after the timed
+            from styler_amd.dist import allreduce_preflight      # region: it must not perturb the measurement)
+            ar["allreduce_preflight"] = allreduce_preflight(dev)
         state.close()
     if rank != 0:
         return None

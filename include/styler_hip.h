@@ -160,6 +160,9 @@ int styler_gemm_set_trace(void* buf);
 
 /* fp32 -> bf16 (round-to-nearest-even) weight shadow for STYLER_PREC_BF16 */
 int styler_cast_bf16(const float* src, uint16_t* dst, int64_t count, void* stream);
+/* bf16 -> fp32 (exact): the way back of the optional bf16 gradient all-reduce (the data-parallel replacement of
+ * train.py:33's nn.DataParallel reduce; STYLER_ALLREDUCE_BF16=1). */
+int styler_cast_from_bf16(const uint16_t* src, float* dst, int64_t count, void* stream);
 
 /* Many strided 3-D copies (fp32 source -> fp32 | bf16 destination) in one launch: the refresh of every derived
  * weight layout after an optimiser step.  Descriptor i owns blocks [block_start[i], block_start[i+1]) of 1024

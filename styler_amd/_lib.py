@@ -23,6 +23,7 @@ _SIGS = {
     "styler_gemm_set_trace": [P],
     "styler_wave_sum_selftest": [P, P, P, I, P],
     "styler_cast_bf16": [P, P, I64, P],
+    "styler_cast_from_bf16": [P, P, I64, P],
     "styler_repack_conv_weight": [P, P, I, I, I, I, I, P],
     "styler_attention_fwd": [P, P, P, I, I, P, P, P],
     "styler_attention_fwd_bf16": [P, P, P, I, I, P, P, P],

@@ -674,6 +674,32 @@ extern "C" int styler_cast_bf16(const float* src, uint16_t* dst, int64_t count, 
   return launch_status();
 }
 
+// bf16 -> fp32 (exact): the way back of the optional bf16 gradient all-reduce (training.TrainState, STYLER_ALLREDUCE_BF16)
+__global__ void cast_from_bf16_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, int64_t count) {
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (; i < count; i += stride) {
+    if (i + 3 < count) {
+      const uint2 u = *reinterpret_cast<const uint2*>(src + i);
+      *reinterpret_cast<float4*>(dst + i) = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                                        __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    } else {
+      for (int64_t k = i; k < count; ++k) dst[k] = __uint_as_float((uint32_t)src[k] << 16);
+    }
+  }
+}
+
+extern "C" int styler_cast_from_bf16(const uint16_t* src, float* dst, int64_t count, void* stream) {
+  if (!src || !dst || count < 0) return STYLER_EINVAL;
+  if (count == 0) return 0;
+  if (((uintptr_t)dst & 15) || ((uintptr_t)src & 7)) return STYLER_EALIGN;
+  int64_t blocks = (count / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(cast_from_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, count);
+  return launch_status();
+}
+
 template <typename OutT>
 __global__ void repack_conv_kernel(const float* __restrict__ src, OutT* __restrict__ dst, int n, int cin, int kw,
                                    int to_kernel) {

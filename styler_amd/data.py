@@ -78,7 +78,7 @@ def pad_to_rectangle(sub_batch, S, T):
         v = np.asarray(sub_batch[k])
         if v.shape[1] < T:
             out[k] = np.pad(v, ((0, 0), (0, T - v.shape[1]), (0, 0)), mode="constant")
-    # the collate computes log_D over the PADDED D (dataset.py:203: np.log(D + hp.log_offset)), so padded positions hold
+    # the collate computes log_D over the PADDED D (dataset.py:167: np.log(Ds + hparams.log_offset)), so padded positions hold
     # log(log_offset), not 0: recompute it from the padded D (round-2 advisor finding; the duration loss is length-masked,
     # so this only keeps bucketed and exact batches identical cell for cell)
     if "D" in out and "log_D" in out:

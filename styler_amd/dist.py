@@ -62,3 +62,82 @@ def allreduce_mean_(flat_grads, bucket_bytes=BUCKET_BYTES):
             w.wait()
         flat_grads.div_(world_size())
     return []
+
+
+class Bf16Reducer:
+    """Optional bf16 transport for the gradient all-reduce (STYLER_ALLREDUCE_BF16=1; off by default: it changes the update
+    arithmetic the parity tests pin).  The fp32 range is cast into a persistent bf16 shadow (one pass: 4 B read + 2 B
+    written per element), the shadow is all-reduced in `BUCKET_BYTES` buckets -- half the bytes on every xGMI link -- and
+    cast back into the fp32 buffer after the waits (exact).  The sum itself is formed in bf16 by the collective: with N
+    ranks each element carries up to N - 1 bf16 roundings (2^-9 relative each), the same order as the bf16 operand rounding
+    of the throughput mode's GEMMs; tests/test_01_host_cpu.py pins the two-rank delta."""
+
+    def __init__(self, flat_grads):
+        self.flat = flat_grads
+        self.shadow = torch.empty(flat_grads.numel(), device=flat_grads.device, dtype=torch.bfloat16)
+        self.pending = []
+
+    def _cast_down(self, lo, hi):
+        if self.flat.is_cuda:
+            from . import ops
+            ops._chk(ops.lib.styler_cast_bf16(self.flat[lo:hi].data_ptr(), self.shadow[lo:hi].data_ptr(), hi - lo, ops._stream()),
+                     "styler_cast_bf16")
+        else:
+            self.shadow[lo:hi].copy_(self.flat[lo:hi])
+
+    def _cast_up(self, lo, hi):
+        if self.flat.is_cuda:
+            from . import ops
+            ops._chk(ops.lib.styler_cast_from_bf16(self.shadow[lo:hi].data_ptr(), self.flat[lo:hi].data_ptr(), hi - lo,
+                                                   ops._stream()), "styler_cast_from_bf16")
+        else:
+            self.flat[lo:hi].copy_(self.shadow[lo:hi])
+
+    def start(self, lo, hi):
+        """Begin the all-reduce of flat[lo:hi] (lo, hi multiples of 4 elements); returns the async work handles."""
+        if world_size() == 1:
+            return []
+        self._cast_down(lo, hi)
+        self.pending.append((lo, hi))
+        return allreduce_sum_(self.shadow[lo:hi])
+
+    def finish(self):
+        """After the handles have been waited for: the reduced values back into the fp32 buffer."""
+        for lo, hi in self.pending:
+            self._cast_up(lo, hi)
+        self.pending = []
+
+
+def allreduce_preflight(device, nbytes=117_930_804, reps=5):
+    """What one gradient all-reduce costs on this job's links, measured before the timed steps (bench.py prints it in
+    `config`): ranks seen, milliseconds and bus bandwidth (algbw * 2 (N - 1) / N) of an fp32 SUM all-reduce of `nbytes` in
+    BUCKET_BYTES buckets, and of the bf16 transport of the same gradient (half the bytes)."""
+    import time
+    n = world_size()
+    out = {"ranks": n}
+    if n == 1:
+        return out
+    for name, dtype, elems in (("fp32", torch.float32, nbytes // 4), ("bf16", torch.bfloat16, nbytes // 4)):
+        buf = torch.zeros(elems, device=device, dtype=dtype)
+        try:
+            for w in allreduce_sum_(buf):
+                w.wait()
+            if buf.is_cuda:
+                torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                for w in allreduce_sum_(buf):
+                    w.wait()
+            if buf.is_cuda:
+                torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / reps * 1e3
+        except RuntimeError as e:                    # (a backend without this dtype: say so instead of dying)
+            out[name] = {"error": str(e)[:120]}
+            continue
+        t = torch.tensor([ms], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+        b = elems * buf.element_size()
+        out[name] = {"bytes": b, "ms": round(ms, 3), "busbw_GBs": round(b / (ms * 1e-3) * 2 * (n - 1) / n / 1e9, 1)}
+    return out

@@ -6,7 +6,7 @@ import torch
 from . import hparams as hp
 from . import autograd as AG
 from . import ops
-from .dist import BUCKET_BYTES, allreduce_sum_, world_size
+from .dist import BUCKET_BYTES, Bf16Reducer, allreduce_sum_, world_size
 from .loss import DomainAdversarialTrainingLoss, STYLERLoss
 from .optimizer import noam_lr
 from .runtime import Derived, rt
@@ -47,6 +47,9 @@ class TrainState:
         # all-reduce is launched from there and overlaps the rest of backward (style encoders, predictors, DAT pass)
         self.tail_start = self._tail_offset(model, params, align)
         self._tail_works = None
+        # optional bf16 transport of the gradient all-reduce (dist.Bf16Reducer; off by default)
+        self.reducer = (Bf16Reducer(self.flat_g) if __import__("os").environ.get("STYLER_ALLREDUCE_BF16", "0") == "1"
+                        else None)
         self.n_current_steps = restore_step            # optimizer.py:10: the Noam counter (ScheduledOptim)
         # torch.optim.Adam's own per-parameter `step` (bias correction): a separate counter in the reference -- a run
         # resumed with restore_step > 0 but without optimizer state starts Adam at 0 while the schedule continues
@@ -114,12 +117,18 @@ class TrainState:
         self._tail_works = None
         self._accum = 0
 
+    def _start_allreduce(self, lo, hi):
+        """Begin the SUM all-reduce of flat_g[lo:hi] -> work handles (fp32 in place, or through the bf16 shadow)."""
+        if self.reducer is not None:
+            return self.reducer.start(lo, hi)
+        return allreduce_sum_(self.flat_g[lo:hi])
+
     def on_decoder_grads_ready(self):
         """Called from BucketEmbedAddFn.backward (both decode branches fully back-propagated): start the all-reduce
         of the decoder + mel_linear + PostNet gradient range (55 % of the bytes) while backward continues."""
         if self._tail_works is None:
             self.arena.flush(self.flat_g.device)      # fold the decoder-side split-K partials before they are reduced
-            self._tail_works = allreduce_sum_(self.flat_g[self.tail_start:])
+            self._tail_works = self._start_allreduce(self.tail_start, self.n)
 
     def lr(self):
         """optimizer.py:21-32: the counter is incremented BEFORE the rate is computed."""
@@ -129,11 +138,13 @@ class TrainState:
     def step(self):
         """nn.utils.clip_grad_norm_(params, 1.0) + ScheduledOptim.step_and_update_lr() (train.py:181-185)."""
         if self._tail_works is not None:                     # tail range already in flight: reduce only the head
-            works = self._tail_works + allreduce_sum_(self.flat_g[:self.tail_start])
+            works = self._tail_works + self._start_allreduce(0, self.tail_start)
         else:
-            works = allreduce_sum_(self.flat_g)
+            works = self._start_allreduce(0, self.n)
         for w in works:
             w.wait()
+        if self.reducer is not None:
+            self.reducer.finish()
         self._tail_works = None
         self._accum = 0
         lr = self.lr()
@@ -155,11 +166,12 @@ class TrainState:
 
     def allreduce_info(self):
         """What one step exchanges (bench.py prints it, so a silent fallback of the overlap is visible)."""
-        nb = lambda k: (k * 4 + BUCKET_BYTES - 1) // BUCKET_BYTES
         tail = self.n - self.tail_start
-        return {"allreduce_bytes": self.n * 4, "allreduce_dtype": "fp32", "allreduce_bucket_bytes": BUCKET_BYTES,
-                "allreduce_buckets": nb(tail) + nb(self.tail_start), "allreduce_overlapped_bytes": tail * 4,
-                "allreduce_world": world_size()}
+        es = 2 if self.reducer is not None else 4
+        nb = lambda k: (k * es + BUCKET_BYTES - 1) // BUCKET_BYTES
+        return {"allreduce_bytes": self.n * es, "allreduce_dtype": "bf16" if es == 2 else "fp32",
+                "allreduce_bucket_bytes": BUCKET_BYTES, "allreduce_buckets": nb(tail) + nb(self.tail_start),
+                "allreduce_overlapped_bytes": tail * es, "allreduce_world": world_size()}
 
 
 _seed_cache = {}
@@ -311,8 +323,14 @@ class GraphedTrainStep:
         state.arena, state.zero_slab = self.arena, self.zero_slab
         state.overlap_allreduce = False                       # inside a graph the cut is the split hook, not the eager hook
         strict, rt.strict_inputs = rt.strict_inputs, False    # the [0, 1] input assertion is a host sync (utils.py:423)
+        # The host-side dropout call counter advances during the capture pass and its values are baked into the graph as
+        # seeds: left advanced, the dropout streams of every later eager or captured step would depend on how many shapes
+        # had been captured before (round-3 advisor finding).  Every graph is captured from the SAME counter value (the
+        # device step counter is what makes replays differ) and the counter is restored afterwards.
+        calls0 = rt.dropout_calls
         try:
             self._warmup(model, state, warmup, loss_fn, dat_fn, split)
+            rt.dropout_calls = calls0
             self.graphs = None
             if split:
                 try:
@@ -333,6 +351,7 @@ class GraphedTrainStep:
             self.arena.frozen = self.zero_slab.frozen = True    # the graphs hold their addresses: no re-sizing from here on
         finally:
             rt.strict_inputs = strict
+            rt.dropout_calls = calls0
             state.arena, state.zero_slab, state.overlap_allreduce = shared
 
     def _warmup(self, model, state, warmup, loss_fn, dat_fn, split):
@@ -419,7 +438,7 @@ class GraphedTrainStep:
         st._accum = 1                                   # the captured pass starts with its own zero_grad
         self.graphs[0].replay()
         if len(self.graphs) == 2:
-            st._tail_works = allreduce_sum_(st.flat_g[st.tail_start:])    # overlaps the second graph
+            st._tail_works = st._start_allreduce(st.tail_start, st.n)     # overlaps the second graph
             self.graphs[1].replay()
         lr = st.step()
         return self.losses, lr
@@ -454,9 +473,16 @@ class GraphedStepCache:
     def key(batch):
         return tuple(batch["text"].shape) + (batch["mel_target"].shape[1],)
 
-    def _capture(self, k, batch):
+    def _capture(self, k, batch, keep=()):
+        """`keep`: shapes of the current exchange (sync_misses) -- never evicted to make room (round-3 advisor finding: at
+        capacity, capturing a peer's shape could evict the very graph this rank was about to replay, and with per-rank LRU
+        orders every rank then re-captured on most steps)."""
         while len(self.steps) >= self.max_graphs:
-            self.steps.popitem(last=False)                           # frees the evicted graph's memory pool and arena
+            victim = next((key for key in self.steps if key != k and key not in keep), None)
+            if victim is None:
+                raise RuntimeError(f"GraphedStepCache: max_graphs = {self.max_graphs} is smaller than the {len(keep) + 1} "
+                                   "shapes one step of this job needs")
+            del self.steps[victim]                                   # frees the evicted graph's memory pool and arena
         step = self.steps[k] = GraphedTrainStep(self.model, self.state, batch, **self.kw)
         return step
 
@@ -484,9 +510,13 @@ class GraphedStepCache:
     def __call__(self, batch):
         k = self.key(batch)
         if self.sync_misses:
-            for other in self._exchange(k):
+            if k in self.steps:
+                self.steps.move_to_end(k)                            # this rank's own graph first: most recently used
+            missing = self._exchange(k)
+            keep = set(missing) | {k}
+            for other in missing:
                 if other != k and other not in self.steps:
-                    self._capture(other, synthetic_batch(*other, device=self.state.flat_g.device))
+                    self._capture(other, synthetic_batch(*other, device=self.state.flat_g.device), keep=keep)
                     self.prefetched += 1
         step = self.steps.get(k)
         if step is None:

@@ -97,6 +97,21 @@ assert len(tail) == 3 and len(head) == 4
 for w in tail + head:
     w.wait()
 assert torch.allclose(flat, torch.arange(37, dtype=torch.float32) * 3.0), flat
+# the optional bf16 transport (STYLER_ALLREDUCE_BF16): two launch points, cast down -> bf16 SUM -> cast back; the result
+# is the bf16 sum of the two ranks' bf16-rounded values: three roundings of 2^-9, i.e. within 2^-7 of the fp32 sum (pinned)
+from styler_amd.dist import Bf16Reducer, allreduce_preflight
+g32 = (torch.linspace(-3.0, 5.0, 64) ** 3) * (rank + 1)
+exact = (torch.linspace(-3.0, 5.0, 64) ** 3) * 3.0
+red = Bf16Reducer(g32)
+works = red.start(40, 64) + red.start(0, 40)
+for w in works:
+    w.wait()
+red.finish()
+want = (((torch.linspace(-3.0, 5.0, 64) ** 3) * 1.0).bfloat16() + ((torch.linspace(-3.0, 5.0, 64) ** 3) * 2.0).bfloat16()).float()
+assert torch.equal(g32, want), (g32 - want).abs().max()
+assert float(((g32 - exact).abs() / exact.abs().clamp_min(1e-2)).max()) <= 2.0 ** -7
+pf = allreduce_preflight("cpu", nbytes=1 << 16, reps=2)
+assert pf["ranks"] == 2 and pf["fp32"]["bytes"] == 1 << 16 and pf["fp32"]["ms"] > 0 and "bf16" in pf
 dist.destroy_process_group()
 print("ok", rank)
 """
