@@ -11,6 +11,7 @@
 // transposition of dz or x is ever materialised.  dw is addressed with explicit strides so the result
 // lands directly in the PARAMETER layout ([n, cin, kw] for conv taps, [n, cin] for Linear).
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16_b(float lo, float hi) {
@@ -651,11 +652,12 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
   const uint4 ones4 = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
   const bf16x8 ones = *reinterpret_cast<const bf16x8*>(&ones4);
 
-  auto compute = [&](int stage) {
+  auto compute = [&](int stage, auto s_lo_tag, auto s_hi_tag) {
+    constexpr int S_LO = decltype(s_lo_tag)::value, S_HI = decltype(s_hi_tag)::value;
     const uint16_t* pa = reinterpret_cast<const uint16_t*>(smem + stage * STAGE);
     const uint16_t* pb = reinterpret_cast<const uint16_t*>(smem + stage * STAGE + A_BYTES);
 #pragma unroll
-    for (int s = 0; s < WB_BK / 16; ++s) {
+    for (int s = S_LO; s < S_HI; ++s) {
       bf16x8 fa[TA];
 #pragma unroll
       for (int i = 0; i < TA; ++i) {
@@ -705,6 +707,19 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
     if (d < nch) issue(ich0 + KG * d, d, entry(ich0 + KG * d));
   int4 e_next = entry(ich0 + KG * D);
   int st_c = 0, st_i = D % NST;                      // stage computed / stage refilled in the current iteration
+  // KG = 2: the two groups run ONE BARRIER APART (group 1 meets one extra barrier before the loop, group 0 one behind it),
+  // and an iteration has two phases -- [wait, barrier, refill the ring, first half of the chunk's MFMAs] and [barrier, second
+  // half]: while one group waits for its DMA and issues the next, the other group of the same SIMDs is inside its pure-MFMA
+  // phase (in lockstep both groups left the matrix pipe idle during that part of every iteration).
+  using std::integral_constant;
+  constexpr int NS = WB_BK / 16;
+  // (only where a half chunk is still a long MFMA run -- k = 9: 18 MFMAs per wave and phase; measured: k = 9 123 -> 117 us,
+  //  k = 5 (10 per phase) 122 -> 127 us, the Linear tile unchanged)
+  constexpr bool STAG = KG == 2 && KW == 9;
+  if (STAG && grp == 1) {
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
   for (int i = 0; i < trips; ++i) {
     const bool live = i < nch;
     if (live) {
@@ -722,10 +737,22 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
         issue(ich0 + KG * (i + D), st_i, e_next);
         e_next = entry(ich0 + KG * (i + D + 1));
       }
-      compute(st_c);
+      if (STAG) compute(st_c, integral_constant<int, 0>{}, integral_constant<int, NS / 2>{});
+      else compute(st_c, integral_constant<int, 0>{}, integral_constant<int, NS>{});
+    }
+    if (STAG) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (live) compute(st_c, integral_constant<int, NS / 2>{}, integral_constant<int, NS>{});
     }
     st_c = st_c + 1 == NST ? 0 : st_c + 1;
     st_i = st_i + 1 == NST ? 0 : st_i + 1;
+  }
+  if (STAG && grp == 0) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
   }
   if (KG == 2) {
     // group 1 hands its accumulators to group 0 through LDS, half of the registers at a time ([register][lane of the

@@ -58,7 +58,8 @@ m = styler_amd.STYLER().to(dev).train()
 rt.set_precision("bf16")
 rt.strict_inputs = False
 st = TrainState(m)
-b = {k: v.to(dev) for k, v in make_batch(48, 20, 60, 2, 13, seed=1234).items()}
+from styler_amd.training import add_pair_inputs
+b = add_pair_inputs({k: v.to(dev) for k, v in make_batch(48, 20, 60, 2, 13, seed=1234).items()})
 for _ in range(3):
     train_step(m, st, b)
 torch.cuda.synchronize()
