@@ -768,19 +768,21 @@ class SplitBatchFn(Function):
         B = shape[0] // 2
         out = torch.empty(shape, device=dev, dtype=torch.float32)
         # one kernel launch (two aten copy_ calls were two memcpy NODES of the captured graph, each behind 6-8 us of idle time)
-        flat = lambda t: t.reshape(-1, t.shape[-1]) if t.dim() > 2 else t
+        # each half is one contiguous run: narrow tensors (the classifiers' [2B, 2] log-probabilities) go as one long row
+        wide = shape[-1] % 4 == 0
+        half = out[:B].numel()
+        flat = (lambda t: t.reshape(-1, t.shape[-1])) if wide else (lambda t: t.reshape(1, -1))
+        ok = wide or (half % 4 == 0)
         pairs = []
         for dst, g in ((out[:B], ga), (out[B:], gb)):
-            if g is not None and (g.dtype != torch.float32 or not g.is_contiguous() or g.shape[-1] % 4 or g.data_ptr() % 16):
+            if g is not None and (g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() % 16 or not ok):
                 dst.copy_(g)                                  # (not the step's case: any layout / dtype)
+            elif g is None and not ok:
+                dst.zero_()
             else:
                 pairs.append((None if g is None else flat(g), flat(dst)))
         if pairs:
-            if shape[-1] % 4 == 0:
-                ops.copy_rows_multi(pairs)
-            else:
-                for src, dst in pairs:
-                    dst.zero_() if src is None else dst.copy_(src)
+            ops.copy_rows_multi(pairs)
         return out
 
 

@@ -207,6 +207,7 @@ class StyleEncoder(_HipModule):
         self.speaker_linear = nn.Sequential(nn.Linear(hp.speaker_embed_dim, hp.encoder_hidden), nn.ReLU())
         self.dat_inputs = None        # (mel_aug, f0_norm_aug, energy_input_aug) of the DAT pass, set by train_losses
         self.dat_encodings = None     # its (d, p, e) encodings when the forward ran both passes as one batch
+        self.stacked_encodings = None # (rt.pair_classifiers) the [2B, S, C] encodings of both passes, for the classifiers
 
     def encoder_input_cat(self, mel_target, p_norm, e_input, mel_aug):
         return EncoderInput(mel_target.contiguous(), p_norm.contiguous(), e_input.contiguous(),
@@ -232,7 +233,7 @@ class StyleEncoder(_HipModule):
         speaker_encoding_p = self._gemm("slp", spk_in, self.speaker_linear_p[0], act=ops.ACT_RELU).squeeze(1)
         speaker_encoding = self._gemm("sl", spk_in, self.speaker_linear[0], act=ops.ACT_RELU).squeeze(1)
         dat = self.dat_inputs if (rt.pair_audio and self.training and torch.is_grad_enabled()) else None
-        self.dat_inputs, self.dat_encodings = None, None
+        self.dat_inputs, self.dat_encodings, self.stacked_encodings = None, None, None
         if dat is not None:
             # rt.pair_audio: the DAT pass of train.py:149-150 runs the same AudioEncoder on (mel_aug, f0_norm_aug,
             # energy_input_aug, mel_aug); every op in it is per item, so both passes are one batch of 2B items (one BiLSTM
@@ -249,8 +250,16 @@ class StyleEncoder(_HipModule):
                                                  torch.cat([e_input, dat[2]]), torch.cat([mel_aug, dat[0]]))
                 len2, src2 = torch.cat([mel_len, mel_len]), torch.cat([src_len, src_len])
             d, p, e, n = self.audio_encoder(enc_cat, len2, src2, mask=None, max_seq_len=text.shape[1])
-            (d, d2), (p, p2), (e, e2) = (AG.SplitBatchFn.apply(t) for t in (d, p, e))
-            self.dat_encodings = (d2, p2, e2)
+            if rt.pair_classifiers:
+                # round 4: the augmentation classifiers run ONCE on the stacked [2B, S, C] encodings (StyleModeling.forward;
+                # every op of a classifier is per item) -- half the classifier launches, and the DAT halves never need to be
+                # cut out: their only consumer is the classifier.  The main halves are views whose gradient comes back
+                # zero-extended (SplitBatchFn with an unused second output).
+                self.stacked_encodings = (d, p, e)
+                d, p, e = (AG.SplitBatchFn.apply(t)[0] for t in (d, p, e))
+            else:
+                (d, d2), (p, p2), (e, e2) = (AG.SplitBatchFn.apply(t) for t in (d, p, e))
+                self.dat_encodings = (d2, p2, e2)
             n, _ = AG.SplitBatchFn.apply(n)            # the DAT pass has no use for the noise stream (train.py:150-153);
             # (a plain n[:B] makes autograd zero-fill the full tensor and copy the half into it: a fill + a memcpy node)
         else:
@@ -433,9 +442,21 @@ class StyleModeling(_HipModule):
             text, speaker_embed, mel_target, p_norm, e_input, mel_aug, mel_len, src_len, src_mask, text_out=sl[0])
         max_seq_len = S
 
-        aug_posterior_d = self.augmentation_classifier_d(duration_encoding)
-        aug_posterior_p = self.augmentation_classifier_p(pitch_encoding)
-        aug_posterior_e = self.augmentation_classifier_e(energy_encoding)
+        se = self.style_encoder
+        self.dat_posteriors = None
+        if se.stacked_encodings is not None:
+            # main + DAT pass of the classifiers (train.py:135-136 and 149-153) as one batch of 2B items; the rows of the two
+            # passes are cut apart on the [2B, 2] log-probabilities
+            (d_all, p_all, e_all), se.stacked_encodings = se.stacked_encodings, None
+            post = [AG.SplitBatchFn.apply(c(t)) for c, t in ((self.augmentation_classifier_d, d_all),
+                                                             (self.augmentation_classifier_p, p_all),
+                                                             (self.augmentation_classifier_e, e_all))]
+            aug_posterior_d, aug_posterior_p, aug_posterior_e = (pp[0] for pp in post)
+            self.dat_posteriors = tuple(pp[1] for pp in post)
+        else:
+            aug_posterior_d = self.augmentation_classifier_d(duration_encoding)
+            aug_posterior_p = self.augmentation_classifier_p(pitch_encoding)
+            aug_posterior_e = self.augmentation_classifier_e(energy_encoding)
 
         # for the inspection (modules.py:327-333)
         self.max_seq_len = max_seq_len

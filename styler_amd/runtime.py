@@ -88,6 +88,11 @@ class _Runtime:
     # building its kernels.
     sim_bf16_stream = os.environ.get("STYLER_SIM_BF16_STREAM", "0") == "1"
 
+    # round 4: the three augmentation classifiers take the main and the DAT pass (train.py:135-136, 149-153) as ONE batch of 2B
+    # items (needs pair_audio: the stacked AudioEncoder pass) -- 3 instead of 6 classifier passes forward and backward
+    # (STYLER_PAIR_CLASSIFIERS=0: two passes)
+    pair_classifiers = os.environ.get("STYLER_PAIR_CLASSIFIERS", "1") != "0"
+
     # each StylePredictor stage (conv -> ReLU -> LayerNorm -> dropout [-> Linear -> mask]) as one tape node whose backward
     # is one LayerNorm-backward kernel + weight gradient + dX GEMM (STYLER_FUSED_PREDICTOR=0: separate nodes)
     fused_predictor = os.environ.get("STYLER_FUSED_PREDICTOR", "1") != "0"

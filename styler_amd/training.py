@@ -226,15 +226,18 @@ def train_losses(model, batch, loss_fn=None, dat_fn=None):
                                                 mel, post, batch["mel_target"], None, None,
                                                 batch["src_len"], batch["mel_len"], aug, zeros)
     mel_nl, post_nl = loss_fn.cal_mel_loss(mel_n, post_n, batch["mel_aug"], None, batch["mel_len"])
-    if se.dat_encodings is not None:                # the forward ran the DAT pass in the same AudioEncoder batch
-        (d, p, e), se.dat_encodings = se.dat_encodings, None
-    else:
-        enc_cat = se.encoder_input_cat(batch["mel_aug"], batch["f0_norm_aug"], batch["energy_input_aug"],
-                                       batch["mel_aug"])
-        d, p, e, _ = se.audio_encoder(enc_cat, batch["mel_len"], batch["src_len"], mask=None, max_seq_len=S)
     sm = model.style_modeling
-    cls_dat = dat_fn((sm.augmentation_classifier_d(d), sm.augmentation_classifier_p(p),
-                      sm.augmentation_classifier_e(e)), ones)
+    if getattr(sm, "dat_posteriors", None) is not None:   # the forward ran the classifiers on both passes' encodings at once
+        dat_post, sm.dat_posteriors = sm.dat_posteriors, None
+    else:
+        if se.dat_encodings is not None:            # the forward ran the DAT pass in the same AudioEncoder batch
+            (d, p, e), se.dat_encodings = se.dat_encodings, None
+        else:
+            enc_cat = se.encoder_input_cat(batch["mel_aug"], batch["f0_norm_aug"], batch["energy_input_aug"],
+                                           batch["mel_aug"])
+            d, p, e, _ = se.audio_encoder(enc_cat, batch["mel_len"], batch["src_len"], mask=None, max_seq_len=S)
+        dat_post = (sm.augmentation_classifier_d(d), sm.augmentation_classifier_p(p), sm.augmentation_classifier_e(e))
+    cls_dat = dat_fn(dat_post, ones)
     terms = (mel_l, post_l, mel_nl, post_nl, d_l, p_l, e_l, cls, cls_dat)
     weights = (1.0,) * 7 + (float(hp.dat_weight),) * 2
     if torch.is_grad_enabled() and any(t.requires_grad for t in terms):
