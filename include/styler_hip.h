@@ -127,6 +127,16 @@ int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, int prec);
  * STYLER_IO_X_BF16 --, cin % 64 == 0, at least 8 K steps and 1.5 tiles of 256 x 256 per CU; `packed` != 0: the call is
  * styler_conv_gemm_packed, whose row count is a capacity).  Same arithmetic either way: both
  * engines accumulate the same v_mfma_f32_32x32x16_bf16 sequence, results are bit-equal. */
+/* Up to 8 INDEPENDENT small GEMMs in one launch (bf16 MFMA, 64 x 64 tile, k = 1, fp32 activations in / out; bf16 weight
+ * shadows [n, cin], cin % 8 == 0): y_p = act(scale_p * x_p w_p^T + shift_p) (+ res_p), as styler_conv_gemm computes each.
+ * The nn.Linear launches of the S-domain that do not depend on one another (modules.py:179-182 -- the four BiLSTMs' input
+ * projections; 250-271, 335-348 -- the style MLPs; 23-45 -- the classifiers' first Linear). */
+typedef struct StylerGemmProblem {
+  const void* x; const void* w; const void* scale; const void* shift; const void* res; void* y; const void* len;
+  int64_t ldx, ldres, ldy;
+  int32_t B, L, cin, n, act, _pad;
+} StylerGemmProblem;
+int styler_conv_gemm_group(const StylerGemmProblem* probs, int count, void* stream);
 int styler_conv_gemm_engine(int B, int L, int cin, int n, int kw, int prec, int io_flags, int64_t ldx, int packed);
 /* ... with the epilogue inputs that decide whether the 256 x 256 engine runs the launch as split-K = 2 (plain epilogue, no
  * ReLU mask): 4 for those launches as well. */

@@ -100,6 +100,52 @@ class ConvGemmFn(Function):
         return dx, (dy if ctx.has_res else None), None, None, None, None, None, None, None, None
 
 
+class ConvGemmMultiFn(Function):
+    """K INDEPENDENT Linear layers y_k = act_k(x_k W_k^T + b_k) as ONE tape node: one grouped launch forward
+    (ops.conv_gemm_multi), one grouped launch for the K dX GEMMs backward; the weight gradients join the step's grouped
+    weight-gradient launch as before.  apply(metas, x_0, W_0, b_0, x_1, W_1, b_1, ...) with metas[k] = (cache, key, act,
+    neg_dx) -> tuple of K outputs.  (The first / second Linear of the four style MLPs, modules.py:250-271,335-348; the three
+    classifiers' first Linear, modules.py:38-45.)"""
+
+    @staticmethod
+    def forward(ctx, metas, *flat):
+        xs, ws, bs = flat[0::3], flat[1::3], flat[2::3]
+        calls = []
+        for (cache, key, act, _), x, weight, bias in zip(metas, xs, ws, bs):
+            w, prec = gemm_weight(cache, key, weight, x.shape[-1])
+            calls.append(dict(x=x, w=w, bias=bias, n=weight.shape[0], act=act, prec=prec))
+        ys = ops.conv_gemm_multi(calls)
+        ctx.save_for_backward(*xs, *[y if m[2] != NONE else x.new_empty(0) for y, m, x in zip(ys, metas, xs)])
+        ctx.metas, ctx.ws, ctx.bs = metas, ws, bs
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        K = len(ctx.metas)
+        saved = ctx.saved_tensors
+        xs, ys = saved[:K], saved[K:]
+        calls, slots = [], []
+        grads = [None] * (3 * K)
+        for k, ((cache, key, act, neg_dx), x, y, weight, bias, dy) in enumerate(zip(ctx.metas, xs, ys, ctx.ws, ctx.bs, dys)):
+            if dy is None:
+                continue
+            n, cin = weight.shape[0], x.shape[-1]
+            dy = ops._rows_view(dy)
+            dz = ops.act_bwd(dy, y, act) if act != NONE else dy
+            dzg, dzp = _x3_split(dz, n)
+            if weight.requires_grad:
+                ops.wgrad(dz, x, G(weight), n, cin, db=G(bias) if (bias is not None and bias.requires_grad) else None,
+                          dz_parts=dzp)
+            if ctx.needs_input_grad[1 + 3 * k]:
+                wt, prec = gemm_weight_bwd_auto(cache, key, weight)
+                calls.append(dict(x=dzg if prec == ops.PREC_BF16X3 else dz, w=wt, n=cin, prec=prec,
+                                  scale=_neg(cin, dz.device) if neg_dx else None))
+                slots.append(k)
+        for k, dx in zip(slots, ops.conv_gemm_multi(calls) if calls else []):
+            grads[3 * k] = dx
+        return (None, *grads)
+
+
 class LayerNormFn(Function):
     """LayerNorm(x + res) with pad mask (SubLayers.py:59,87 + Layers.py:29,32)."""
 
@@ -583,12 +629,13 @@ class LstmMultiLayerFn(Function):
     @staticmethod
     def forward(ctx, enc, layer, anchor, *xs):
         Hs = enc.necks
-        gxs, w_hhs = [], []
+        calls, w_hhs = [], []
         for s, x in enumerate(xs):
             lstm = getattr(enc, f"lstm_{s + 1}")
             w, bias, w_hh, prec = enc._lstm_weights(lstm, layer, f"lstm{s}_{layer}", x.shape[-1])
-            gxs.append(ops.conv_gemm(x, w, bias, n=8 * Hs[s], prec=prec))
+            calls.append(dict(x=x, w=w, bias=bias, n=8 * Hs[s], prec=prec))
             w_hhs.append(w_hh)
+        gxs = ops.conv_gemm_multi(calls)             # the four input projections: one grouped launch
         outs, cells, gates = ops.lstm_bidir_multi(gxs, w_hhs, Hs, save=True)
         ctx.save_for_backward(*xs, *outs, *cells, *gates, *w_hhs)
         ctx.enc, ctx.layer = enc, layer
@@ -601,7 +648,7 @@ class LstmMultiLayerFn(Function):
         t = ctx.saved_tensors
         xs, outs, cells, gates, w_hhs = t[0:4], t[4:8], t[8:12], t[12:16], t[16:20]
         dgps = ops.lstm_bidir_bwd_multi(douts, gates, cells, w_hhs, Hs)
-        dxs = []
+        dxs, dx_calls, dx_slots = [], [], []
         for s in range(4):
             lstm = getattr(enc, f"lstm_{s + 1}")
             H, x, dgp, cin = Hs[s], xs[s], dgps[s], xs[s].shape[-1]
@@ -611,12 +658,14 @@ class LstmMultiLayerFn(Function):
                           db=G(getattr(lstm, f"bias_ih_l{layer}{sfx}")), db2=G(getattr(lstm, f"bias_hh_l{layer}{sfx}")))
                 ops.wgrad(sl, outs[s][..., d * H:(d + 1) * H], G(getattr(lstm, f"weight_hh_l{layer}{sfx}")), 4 * H, H,
                           pad_left=1 if d == 0 else -1)
-            dx = None
+            dxs.append(None)
             if ctx.needs_input_grad[3 + s]:
                 srcs = [getattr(lstm, f"weight_ih_l{layer}"), getattr(lstm, f"weight_ih_l{layer}_reverse")]
                 wt, wp = lstm_wi_transposed(enc._derived, f"lstm{s}_{layer}wiT", srcs[0], srcs[1])
-                dx = ops.conv_gemm(dgp, wt, None, n=cin, prec=wp)
-            dxs.append(dx)
+                dx_calls.append(dict(x=dgp, w=wt, n=cin, prec=wp))
+                dx_slots.append(s)
+        for s, dx in zip(dx_slots, ops.conv_gemm_multi(dx_calls) if dx_calls else []):       # one grouped launch
+            dxs[s] = dx
         return (None, None, None, *dxs)
 
 

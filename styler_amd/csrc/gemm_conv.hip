@@ -49,8 +49,10 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 // in use, and every activation row is staged twice; one 96-wide tile covers the row once (12 MFMAs per wave and step
 // instead of 4).  Measured (M = 42 336, K = 2560, bf16 in): 52.3 -> 40.3 us alone, training step -0.04 ms; at 21 168 rows
 // (166 blocks) the two tiles tie, so the variant takes launches of >= 32 768 rows.
-template <int TM, int TN, bool BF16, bool KW1, bool OCC3, bool A16 = false, bool Y16 = false, int WM = 2>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
+// (the body is a device function: conv_gemm_kernel runs one problem per launch, conv_gemm_group_kernel up to eight small ones;
+// TAG only keeps the two kernels' body specialisations distinct for hipcc's host pass)
+template <int TM, int TN, bool BF16, bool KW1, bool OCC3, bool A16 = false, bool Y16 = false, int WM = 2, int TAG = 0>
+__device__ __forceinline__ void conv_gemm_body(const GemmArgs& a, const int bid_in) {
   static_assert(BF16 || (!A16 && !Y16), "bf16 storage only with the bf16 MFMA");
   static_assert(WM == 2 || (WM == 4 && !OCC3), "wave grids: 2 x 2, or 4 x 1 (double-buffered layout only)");
   constexpr int WN = 4 / WM;
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
   // prefix of the rows is valid (packed decoder rows, masked tails).  The grid is padded to 8 * ceil(mt / 8) m-tiles.
   int tile;
   {
-    const int bid = blockIdx.x;
+    const int bid = bid_in;
     const int xcd = bid & 7, k = bid >> 3;
     const int mtile = (k / a.nt) * 8 + xcd;
     if (mtile >= a.mt) return;
@@ -507,8 +509,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     __builtin_amdgcn_s_waitcnt(0);                   // every store of this wave acknowledged
     stamp[4] = wall_clock64();
     if (tid == 0) {
-      uint64_t* t = a.trace + (int64_t)blockIdx.x * 8;
-      t[0] = blockIdx.x;
+      uint64_t* t = a.trace + (int64_t)bid_in * 8;
+      t[0] = bid_in;
 #pragma unroll
       for (int i = 0; i < 5; ++i) t[1 + i] = stamp[i];
       t[6] = __builtin_amdgcn_s_getreg((3 << 11) | 4);   // HW_ID (wave, simd, cu, sh, se)
@@ -519,6 +521,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
 #endif
     }
   }
+}
+
+template <int TM, int TN, bool BF16, bool KW1, bool OCC3, bool A16 = false, bool Y16 = false, int WM = 2>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
+  conv_gemm_body<TM, TN, BF16, KW1, OCC3, A16, Y16, WM, 0>(a, blockIdx.x);
+}
+
+// Up to 8 small GEMMs (64 x 64 tile, k = 1, fp32 activations in and out, bf16 MFMA) in ONE launch: problem p owns blocks
+// [start[p], start[p + 1]).  The S-domain of a training step is a chain of such launches of 5-8 us each (the four BiLSTM
+// input projections of a layer, the first / second Linear of the four style MLPs, the three classifier projections: the
+// members of a group are independent of each other) -- launch latency, not arithmetic.
+struct GemmGroup {
+  GemmArgs a[8];
+  int start[9];
+  int n;
+};
+__global__ __launch_bounds__(256) void conv_gemm_group_kernel(const GemmGroup g) {
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i) p += (i < g.n && (int)blockIdx.x >= g.start[i]) ? 1 : 0;
+  conv_gemm_body<1, 1, true, true, false, false, false, 2, 1>(g.a[p], (int)blockIdx.x - g.start[p]);
 }
 
 template <int TM, int TN, bool BF16, int WM = 2>
@@ -558,6 +581,33 @@ static int launch_gemm(GemmArgs a, hipStream_t st, int x16, int y16) {
   else GEMM_IO(false, false);
 #undef GEMM_IO
 #undef GEMM_LAUNCH
+  return launch_status();
+}
+
+extern "C" int styler_conv_gemm_group(const StylerGemmProblem* probs, int count, void* stream) {
+  if (!probs || count <= 0 || count > 8) return STYLER_EINVAL;
+  GemmGroup g;
+  int start = 0;
+  for (int k = 0; k < count; ++k) {
+    const StylerGemmProblem& p = probs[k];
+    if (!p.x || !p.w || !p.y || p.B <= 0 || p.L <= 0 || p.cin <= 0 || p.n <= 0) return STYLER_EINVAL;
+    if ((p.cin & 7) || (p.ldx & 3) || ((uintptr_t)p.x & 15) || ((uintptr_t)p.w & 15)) return STYLER_EALIGN;
+    if ((p.n & 3) || (p.ldy & 3) || ((uintptr_t)p.y & 15) || (p.res && ((p.ldres & 3) || ((uintptr_t)p.res & 15)))) return STYLER_EALIGN;
+    if ((int64_t)p.B * p.L >= ((int64_t)1 << 31) || p.ldy >= (1 << 22) || p.ldres >= (1 << 22)) return STYLER_EINVAL;
+    GemmArgs a{p.x, p.ldx, p.w, reinterpret_cast<const float*>(p.scale), reinterpret_cast<const float*>(p.shift),
+               reinterpret_cast<const float*>(p.res), p.ldres, p.y, p.ldy, p.B, p.L, p.cin, p.n, 1, p.act, 0,
+               reinterpret_cast<const int64_t*>(p.len), 0, 0, nullptr, nullptr, 0, 0, nullptr};
+    const int64_t M = (int64_t)p.B * p.L;
+    a.mt = (int)((M + 63) / 64);
+    a.nt = (p.n + 63) / 64;
+    g.a[k] = a;
+    g.start[k] = start;
+    start += ((a.mt + 7) / 8) * 8 * a.nt;
+  }
+  for (int k = count; k < 9; ++k) g.start[k] = start;
+  for (int k = count; k < 8; ++k) g.a[k] = g.a[0];
+  g.n = count;
+  hipLaunchKernelGGL(conv_gemm_group_kernel, dim3((unsigned)start), dim3(256), 0, (hipStream_t)stream, g);
   return launch_status();
 }
 

@@ -371,6 +371,18 @@ class StyleModeling(_HipModule):
         h = self._gemm(key + "0", x, seq[0], act=ops.ACT_RELU)
         return self._gemm(key + "2", h, seq[2], act=ops.ACT_RELU, res=res, out=out)
 
+    def _mlp2_multi(self, specs):
+        """[(key, Sequential(Linear, ReLU, Linear, ReLU), x), ...] -> their outputs: the first Linears of all MLPs as one tape
+        node / grouped launch, then the second ones (autograd.ConvGemmMultiFn; the MLPs are independent of one another)."""
+        for layer in (0, 2):
+            flat = []
+            for (key, seq, x) in specs:
+                flat += [x, seq[layer].weight, seq[layer].bias]
+            metas = tuple((self._derived, key + str(layer), ops.ACT_RELU, False) for key, _, _ in specs)
+            ys = AG.ConvGemmMultiFn.apply(metas, *flat)
+            specs = [(key, seq, y) for (key, seq, _), y in zip(specs, ys)]
+        return [y for _, _, y in specs]
+
     def _expand_and_predict(self, encodings, src_len, duration_target, log_d, max_len, mel_len_in, mel_mask,
                             pitch_target, energy_target, d_control, p_control, e_control, pitch_plus_speaker=True,
                             want_noise_sum=True, ids=None):
@@ -448,9 +460,16 @@ class StyleModeling(_HipModule):
             # main + DAT pass of the classifiers (train.py:135-136 and 149-153) as one batch of 2B items; the rows of the two
             # passes are cut apart on the [2B, 2] log-probabilities
             (d_all, p_all, e_all), se.stacked_encodings = se.stacked_encodings, None
-            post = [AG.SplitBatchFn.apply(c(t)) for c, t in ((self.augmentation_classifier_d, d_all),
-                                                             (self.augmentation_classifier_p, p_all),
-                                                             (self.augmentation_classifier_e, e_all))]
+            cls = (self.augmentation_classifier_d, self.augmentation_classifier_p, self.augmentation_classifier_e)
+            if rt.grouped_mlps:                      # the three first Linears (GRL: negated dX) as one grouped launch
+                flat = []
+                for c, t in zip(cls, (d_all, p_all, e_all)):
+                    flat += [t, c.classifier.d_fc1.weight, c.classifier.d_fc1.bias]
+                hs = AG.ConvGemmMultiFn.apply(tuple((c._derived, "fc1", ops.ACT_NONE, True) for c in cls), *flat)
+                post = [AG.SplitBatchFn.apply(AG.AugTailFn.apply(h, c.classifier.d_fc2.weight, c.classifier))
+                        for c, h in zip(cls, hs)]
+            else:
+                post = [AG.SplitBatchFn.apply(c(t)) for c, t in zip(cls, (d_all, p_all, e_all))]
             aug_posterior_d, aug_posterior_p, aug_posterior_e = (pp[0] for pp in post)
             self.dat_posteriors = tuple(pp[1] for pp in post)
         else:
@@ -467,14 +486,22 @@ class StyleModeling(_HipModule):
         if grad:
             pitch_in = AG.AddRowvecFn.apply(pitch_encoding, speaker_encoding_p, S)
             text_neck_up = self._gemm("tlu", text_encoding_neck, self.text_linear_up[0], act=ops.ACT_RELU)
-            duration_up = self._mlp2("dl", self.duration_linear, duration_encoding)
+            if rt.grouped_mlps:
+                # round 4: the four style MLPs advance layer by layer together (one grouped launch per layer and direction)
+                duration_up, pitch_up, energy_up, residual_up = self._mlp2_multi([
+                    ("dl", self.duration_linear, duration_encoding), ("pl", self.pitch_linear, pitch_in),
+                    ("el", self.energy_linear, energy_encoding), ("rl", self.residual_linear, noise_encoding)])
+                sl[1] = AG.Add2Fn.apply(pitch_up, text_neck_up)
+                sl[4] = residual_up
+            else:
+                duration_up = self._mlp2("dl", self.duration_linear, duration_encoding)
+                sl[1] = self._mlp2("pl", self.pitch_linear, pitch_in, res=text_neck_up)
+                energy_up = self._mlp2("el", self.energy_linear, energy_encoding)
+                sl[4] = self._mlp2("rl", self.residual_linear, noise_encoding)
             dp_in = AG.Add2Fn.apply(text_neck_up, duration_up)
             sl[0] = text_encoding
-            sl[1] = self._mlp2("pl", self.pitch_linear, pitch_in, res=text_neck_up)
             sl[2] = AG.AddRowvecFn.apply(None, speaker_encoding, S)
-            energy_up = self._mlp2("el", self.energy_linear, energy_encoding)
             sl[3] = AG.Add2Fn.apply(text_neck_up, energy_up)
-            sl[4] = self._mlp2("rl", self.residual_linear, noise_encoding)
             encodings = AG.CatFn.apply(*sl)
         else:
             pitch_in = ops.add_rowvec(pitch_encoding, speaker_encoding_p, S)

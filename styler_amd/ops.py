@@ -451,6 +451,50 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
     return out
 
 
+def conv_gemm_multi(calls):
+    """Several INDEPENDENT Linear-shaped GEMMs -> list of outputs.  `calls`: dicts with the keyword arguments of `conv_gemm`
+    (x, w, bias, n, act, prec, scale, res, out).  In throughput mode the members that take the 64 x 64 bf16 tile (k = 1, fp32
+    activations in and out) run as ONE launch (styler_conv_gemm_group, <= 8 members each); anything else -- other
+    precisions, large shapes, bf16 storage -- is launched one by one."""
+    from ._lib import GemmProblem
+    outs = [None] * len(calls)
+    group = []
+    for i, c in enumerate(calls):
+        x, w = c["x"], c["w"]
+        B, L, cin = x.shape
+        n = c.get("n") or w.shape[0]
+        ok = (c.get("prec") == PREC_BF16 and w.dtype == torch.bfloat16 and x.dtype == torch.float32 and cin % 8 == 0
+              and w.shape[-1] == cin and gemm_profiler is None
+              and (c.get("res") is None or c["res"].dtype == torch.float32)
+              and not (lib.styler_conv_gemm_variant(B, L, cin, n, 1, PREC_BF16) & 1))
+        if not ok:
+            outs[i] = conv_gemm(x, w, c.get("bias"), n=n, act=c.get("act", ACT_NONE), prec=c.get("prec", PREC_F32),
+                                scale=c.get("scale"), res=c.get("res"), out=c.get("out"))
+            continue
+        out = c.get("out")
+        if out is None:
+            out = torch.empty(B, L, n, device=x.device, dtype=torch.float32)
+        outs[i] = out
+        group.append((c, out, B, L, cin, n))
+    for j in range(0, len(group), 8):
+        part = group[j:j + 8]
+        if len(part) == 1:
+            c, out, B, L, cin, n = part[0]
+            conv_gemm(c["x"], c["w"], c.get("bias"), n=n, act=c.get("act", ACT_NONE), prec=PREC_BF16, scale=c.get("scale"),
+                      res=c.get("res"), out=out)
+            continue
+        arr = (GemmProblem * len(part))()
+        for k, (c, out, B, L, cin, n) in enumerate(part):
+            x, res = _f32(c["x"]), c.get("res")
+            m = arr[k]
+            m.x, m.w, m.scale, m.shift, m.res, m.y, m.len = (x.data_ptr(), c["w"].data_ptr(), _ptr(c.get("scale")),
+                                                             _ptr(c.get("bias")), _ptr(res), out.data_ptr(), None)
+            m.ldx, m.ldres, m.ldy = _ld(x), (_ld(res) if res is not None else 0), _ld(out)
+            m.B, m.L, m.cin, m.n, m.act = B, L, cin, n, c.get("act", ACT_NONE)
+        _chk(lib.styler_conv_gemm_group(arr, len(part), _stream()), "styler_conv_gemm_group")
+    return outs
+
+
 ACT_CRELU = 5                      # min(max(v, 0), 20): DeepSpeaker's clipped ReLU
 ACT_RES_FIRST = 0x100              # y = act(scale * (acc + res) + shift): last call of a conv summed over several calls
 

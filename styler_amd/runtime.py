@@ -93,6 +93,11 @@ class _Runtime:
     # (STYLER_PAIR_CLASSIFIERS=0: two passes)
     pair_classifiers = os.environ.get("STYLER_PAIR_CLASSIFIERS", "1") != "0"
 
+    # round 4: Linear layers of the S-domain that do not depend on one another -- the four style MLPs layer by layer, the three
+    # classifiers' first Linear -- as one tape node / ONE grouped launch each way (autograd.ConvGemmMultiFn; the BiLSTM input
+    # projections of a layer are always grouped).  STYLER_GROUPED_MLPS=0: one launch per Linear.
+    grouped_mlps = os.environ.get("STYLER_GROUPED_MLPS", "1") != "0"
+
     # each StylePredictor stage (conv -> ReLU -> LayerNorm -> dropout [-> Linear -> mask]) as one tape node whose backward
     # is one LayerNorm-backward kernel + weight gradient + dX GEMM (STYLER_FUSED_PREDICTOR=0: separate nodes)
     fused_predictor = os.environ.get("STYLER_FUSED_PREDICTOR", "1") != "0"
