@@ -489,6 +489,14 @@ int styler_l2_normalize_rows(const float* x, float* y, int rows, int C, void* st
  * post-activation y); rows t >= len[b] get zero (masked_fill backward). */
 int styler_act_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, float* dz,
                    int64_t lddz, int B, int L, int C, int act, const int64_t* len, void* stream);
+/* Up to 8 of those in one launch (ReLU / tanh, no length mask; dz contiguous [rows, C]): the activation backward of the
+ * members of a grouped Linear node. */
+typedef struct StylerActSeg {
+  const void* dy; const void* y; void* dz;
+  int64_t lddy, ldy, rows;
+  int32_t C, act;
+} StylerActSeg;
+int styler_act_bwd_multi(const StylerActSeg* segs, int count, void* stream);
 
 /* Weight (+ bias) gradient of Linear / Conv1d, all kw taps in one launch (autograd of
  * SubLayers.py:41-43,72-76 etc.):

@@ -79,6 +79,7 @@ _SIGS = {
     "styler_attention_bwd": [P, P, P, P, P, P, I, I, P, P, P],
     "styler_layernorm_bwd": [P, I64, P, I64, P, P, P, I64, P, P, P, P, P, P, I, I, I, P, F, ctypes.c_uint64, F, ctypes.c_uint64, P, I64, I, I, P],
     "styler_conv_gemm_group": [P, I, P],
+    "styler_act_bwd_multi": [P, I, P],
     "styler_gemm256_config": [I, I],
     "styler_gemm256_policy": [I, I],
     "styler_conv_gemm_engine2": [I, I, I, I, I, I, I, I64, I, I, I],
@@ -137,6 +138,11 @@ class GemmProblem(ctypes.Structure):
     _fields_ = [(k, ctypes.c_void_p) for k in ("x", "w", "scale", "shift", "res", "y", "len")] + \
                [(k, ctypes.c_int64) for k in ("ldx", "ldres", "ldy")] + \
                [(k, ctypes.c_int32) for k in ("B", "L", "cin", "n", "act", "_pad")]
+
+
+class ActSeg(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_void_p) for k in ("dy", "y", "dz")] + [(k, ctypes.c_int64) for k in ("lddy", "ldy", "rows")] + \
+               [(k, ctypes.c_int32) for k in ("C", "act")]
 
 
 class MaskedTerm(ctypes.Structure):

@@ -126,12 +126,13 @@ class ConvGemmMultiFn(Function):
         xs, ys = saved[:K], saved[K:]
         calls, slots = [], []
         grads = [None] * (3 * K)
+        live = [k for k in range(K) if dys[k] is not None and ctx.metas[k][2] != NONE]
+        dzs = dict(zip(live, ops.act_bwd_multi([(dys[k], ys[k], ctx.metas[k][2]) for k in live]))) if live else {}
         for k, ((cache, key, act, neg_dx), x, y, weight, bias, dy) in enumerate(zip(ctx.metas, xs, ys, ctx.ws, ctx.bs, dys)):
             if dy is None:
                 continue
             n, cin = weight.shape[0], x.shape[-1]
-            dy = ops._rows_view(dy)
-            dz = ops.act_bwd(dy, y, act) if act != NONE else dy
+            dz = dzs[k] if act != NONE else ops._rows_view(dy)
             dzg, dzp = _x3_split(dz, n)
             if weight.requires_grad:
                 ops.wgrad(dz, x, G(weight), n, cin, db=G(bias) if (bias is not None and bias.requires_grad) else None,

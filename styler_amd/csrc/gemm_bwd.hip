@@ -56,6 +56,55 @@ extern "C" int styler_act_bwd(const float* dy, int64_t lddy, const float* y, int
   return launch_status();
 }
 
+// Up to 8 act_bwd problems in one launch (blockIdx.y = problem; descriptors in the kernel arguments): the ReLU backward of
+// the members of a grouped Linear node (autograd.ConvGemmMultiFn).
+struct ActSegs {
+  const float* dy[8]; const float* y[8]; float* dz[8];
+  int64_t lddy[8], ldy[8], rows[8];
+  int32_t C[8], act[8];
+  int32_t n;
+};
+__global__ __launch_bounds__(256) void act_bwd_multi_kernel(const ActSegs g) {
+  const int k = blockIdx.y;
+  if (k >= g.n) return;
+  const float* __restrict__ dy = g.dy[k];
+  const float* __restrict__ y = g.y[k];
+  float* __restrict__ dz = g.dz[k];
+  const int C = g.C[k], act = g.act[k], nq = C / 4;
+  const int64_t total = g.rows[k] * nq, lddy = g.lddy[k], ldy = g.ldy[k];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / nq; const int q = (int)(i - row * nq);
+    float4 gq = *reinterpret_cast<const float4*>(dy + row * lddy + q * 4);
+    const float4 v = *reinterpret_cast<const float4*>(y + row * ldy + q * 4);
+    if (act == STYLER_ACT_RELU) {
+      gq.x = v.x > 0.f ? gq.x : 0.f; gq.y = v.y > 0.f ? gq.y : 0.f; gq.z = v.z > 0.f ? gq.z : 0.f; gq.w = v.w > 0.f ? gq.w : 0.f;
+    } else if (act == STYLER_ACT_TANH) {
+      gq.x *= 1.f - v.x * v.x; gq.y *= 1.f - v.y * v.y; gq.z *= 1.f - v.z * v.z; gq.w *= 1.f - v.w * v.w;
+    }
+    *reinterpret_cast<float4*>(dz + row * (int64_t)C + q * 4) = gq;
+  }
+}
+
+extern "C" int styler_act_bwd_multi(const StylerActSeg* segs, int count, void* stream) {
+  if (!segs || count <= 0 || count > 8) return STYLER_EINVAL;
+  ActSegs g;
+  int64_t most = 0;
+  for (int k = 0; k < count; ++k) {
+    const StylerActSeg& s = segs[k];
+    if (!s.dy || !s.y || !s.dz || s.rows <= 0 || s.C <= 0 || (s.C & 3) || (s.act != STYLER_ACT_RELU && s.act != STYLER_ACT_TANH)) return STYLER_EINVAL;
+    if ((s.lddy & 3) || (s.ldy & 3) || (((uintptr_t)s.dy | (uintptr_t)s.y | (uintptr_t)s.dz) & 15)) return STYLER_EALIGN;
+    g.dy[k] = reinterpret_cast<const float*>(s.dy); g.y[k] = reinterpret_cast<const float*>(s.y); g.dz[k] = reinterpret_cast<float*>(s.dz);
+    g.lddy[k] = s.lddy; g.ldy[k] = s.ldy; g.rows[k] = s.rows; g.C[k] = s.C; g.act[k] = s.act;
+    const int64_t t = s.rows * (s.C / 4);
+    most = t > most ? t : most;
+  }
+  g.n = count;
+  int64_t bx = (most + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(act_bwd_multi_kernel, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, (hipStream_t)stream, g);
+  return launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------
 // wgrad: all KW taps of a conv weight (or a Linear, KW = 1) in ONE launch.
 //   dw[nn*sn + c*sc + j*sj] += sum_{b,t} dz[b,t,nn] * x[b, t + j - pad_left, c]      (x = 0 outside the item)

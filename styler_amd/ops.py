@@ -900,6 +900,25 @@ def act_bwd(dy, y, act, lens=None):
     return dz
 
 
+def act_bwd_multi(items):
+    """[(dy, y, act), ...] -> [dz, ...]: the activation backward of several tensors in one launch (<= 8 per launch)."""
+    from ._lib import ActSeg
+    outs = []
+    for j in range(0, len(items), 8):
+        part = items[j:j + 8]
+        arr = (ActSeg * len(part))()
+        for k, (dy, y, act) in enumerate(part):
+            dy = _rows_view(dy)
+            C = dy.shape[-1]
+            dz = torch.empty(dy.shape, device=dy.device, dtype=torch.float32)
+            outs.append(dz)
+            m = arr[k]
+            m.dy, m.y, m.dz = _f32(dy).data_ptr(), _f32(y).data_ptr(), dz.data_ptr()
+            m.lddy, m.ldy, m.rows, m.C, m.act = _ld(dy), _ld(y), dy.numel() // C, C, act
+        _chk(lib.styler_act_bwd_multi(arr, len(part), _stream()), "styler_act_bwd_multi")
+    return outs
+
+
 LIN128_SPLITS = int(os.environ.get("STYLER_WGRAD_LIN128_SPLITS", "8"))
 
 
