@@ -49,6 +49,16 @@ extern "C" {
 #define STYLER_IO_Z_BF16 16   /* GroupNorm / BatchNorm forward and backward: the normalised tensor x (a convolution's output,
                                  kept for the backward) is stored as bf16 -- throughput mode; the statistics are those of the
                                  rounded values, forward and backward agree on them */
+/* styler_wgrad / styler_wgrad_packed / styler_wgrad_group_desc only (the bf16x3 arithmetic on fp32-typed operands): the
+ * kernel stages the LOW part of the operand, bf16(v - float(bf16(v))), instead of its rounding to bf16 (the high part);
+ * ignored for an operand stored as bf16.  dw += dz_hi^T x_lo and dw += dz_lo^T x_hi without materialising the low parts. */
+#define STYLER_IO_X_LO 32
+#define STYLER_IO_DZ_LO 64
+/* the same entry points, both operands [hi | hi | lo] bf16 split tensors (styler_split3_bf16: row strides >= 3 n / 3 cin,
+ * STYLER_IO_X_BF16 | STYLER_IO_Y_BF16 set): dw += dz_hi^T x_hi + dz_hi^T x_lo + dz_lo^T x_hi as ONE launch whose contraction axis
+ * runs over the three parts (one set of split-K partial tiles instead of three); db += colsum(dz_hi) + colsum(dz_lo).
+ * LDS-DMA kernels only: styler_wgrad_x3cat_ok(n, cin, kw, pad_left) says whether the shape has one. */
+#define STYLER_IO_X3CAT 128
 /* styler_add_layernorm io_flags (round 3: the decoder's residual stream is stored as bf16 in throughput mode) */
 #define STYLER_LN_RES_BF16 1  /* res is bf16 */
 #define STYLER_LN_Y_BF16 2    /* y is written as bf16 (ldy in elements) */
@@ -163,6 +173,12 @@ int styler_gemm_n96_config(int enabled, int min_rows);
 int64_t styler_conv_gemm_workspace_bytes(int B, int L, int cin, int n, int kw, int act, int prec, int io_flags,
                                          int64_t ldx, int packed, int has_mask);
 int styler_gemm_set_workspace(void* ptr, int64_t bytes);
+/* Split-K of the 64 x 64 tile (bf16 MFMA mode): a k >= 3 convolution over few rows and a long contraction axis -- at most
+ * 256 tiles, >= 48 (chunk, tap) steps, plain epilogue: the dX of the text encoder's FFN convolution, M = B * S rows,
+ * K = 9 * 1024 (transformer/SubLayers.py:72-76, Models.py:60-84) -- deals its 64-channel chunks to about four blocks per CU;
+ * the partial tiles (same workspace protocol as above) are folded in a fixed order by the combine pass.  enabled 0 / 1
+ * (-1 keeps; default STYLER_GEMM_SMALL_SPLITK or 1); returns the previous value. */
+int styler_gemm_small_split_config(int enabled);
 /* Measurement hook (tools/gemm_trace.py): while `buf` is non-null every styler_conv_gemm block writes 8 uint64 words at
  * buf[8 * blockIdx]: block, then 100 MHz timestamps at entry / first tile staged / main loop done / stores issued /
  * stores acknowledged, the hardware id register and the tile index.  Pass NULL to switch it off (the default). */
@@ -228,6 +244,13 @@ int styler_attention_fwd_bf16_io(const void* qkv, void* out, float* lse, int B, 
 int styler_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse,
                               void* dqkv, float* delta_ws, int B, int L, const int64_t* len,
                               const int32_t* cu, int io_flags, void* stream);
+/* The same two operations in the bf16x3 arithmetic (STYLER_PREC_BF16X3; Modules.py:14-25, SubLayers.py:41-56 and their
+ * autograd): fp32 tensors on both sides, every MFMA operand carried as hi + lo bf16 and every product as hi hi + hi lo +
+ * lo hi on the bf16 matrix cores, fp32 softmax / lse / delta.  Arguments as styler_attention_fwd / styler_attention_bwd. */
+int styler_attention_fwd_x3(const float* qkv, float* out, float* lse, int B, int L, const int64_t* len, const int32_t* cu,
+                            void* stream);
+int styler_attention_bwd_x3(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
+                            float* delta_ws, int B, int L, const int64_t* len, const int32_t* cu, void* stream);
 
 /* ---- normalisation / epilogues ------------------------------------------------------
  * y = LayerNorm_256(x + res) * gamma + beta, then rows t >= len[b] set to 0
@@ -527,6 +550,7 @@ int styler_wgrad_packed(const float* dz, int64_t lddz, const float* x, int64_t l
  * setting as mode | (stages128 << 2).  Env: STYLER_WGRAD_DMA=0|1|2.  The split count / workspace of a launch depend on its
  * operand formats: use the _io forms below with the io_flags the launch will be given. */
 int styler_wgrad_dma_config(int mode, int stages128);
+int styler_wgrad_x3cat_ok(int n, int cin, int kw, int pad_left);
 int styler_wgrad_splits_io(int B, int L, int n, int cin, int kw, int pad_left, int prec, int io_flags);
 int64_t styler_wgrad_workspace_bytes_io(int B, int L, int n, int cin, int kw, int pad_left, int prec, int io_flags);
 /* Split count styler_wgrad uses for a shape (workspace = splits * n * kw * cin floats). */

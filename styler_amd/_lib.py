@@ -27,6 +27,8 @@ _SIGS = {
     "styler_repack_conv_weight": [P, P, I, I, I, I, I, P],
     "styler_attention_fwd": [P, P, P, I, I, P, P, P],
     "styler_attention_fwd_bf16": [P, P, P, I, I, P, P, P],
+    "styler_attention_fwd_x3": [P, P, P, I, I, P, P, P],
+    "styler_attention_bwd_x3": [P, P, P, P, P, P, I, I, P, P, P],
     "styler_attention_fwd_bf16_io": [P, P, P, I, I, P, P, I, P],
     "styler_attention_bwd_bf16": [P, P, P, P, P, P, I, I, P, P, I, P],
     "styler_add_layernorm": [P, I64, P, I64, P, P, P, I64, P, P, P, I, I, I, P, F, ctypes.c_uint64, F, ctypes.c_uint64, P, I64, P, I64, I, P],
@@ -69,6 +71,7 @@ _SIGS = {
     "styler_wgrad": [P, I64, P, I64, P, P, P, I64, I64, I64, I, I, I, I, I, I, I, P, I, I, P],
     "styler_wgrad_splits": [I, I, I, I, I, I, I],
     "styler_wgrad_dma_config": [I, I],
+    "styler_wgrad_x3cat_ok": [I, I, I, I],
     "styler_wgrad_splits_io": [I, I, I, I, I, I, I, I],
     "styler_wgrad_workspace_bytes_io": [I, I, I, I, I, I, I, I],
     "styler_wgrad_reduce_multi": [P, I, I64, P],
@@ -84,6 +87,7 @@ _SIGS = {
     "styler_gemm256_policy": [I, I],
     "styler_conv_gemm_engine2": [I, I, I, I, I, I, I, I64, I, I, I],
     "styler_gemm_n96_config": [I, I],
+    "styler_gemm_small_split_config": [I],
     "styler_groupnorm_fused_rows": [I],
     "styler_conv_gemm_workspace_bytes": [I, I, I, I, I, I, I, I, I64, I, I],
     "styler_gemm_set_workspace": [P, I64],

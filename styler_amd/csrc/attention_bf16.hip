@@ -585,6 +585,357 @@ __global__ __launch_bounds__(256, STYLER_ATTN_DKV_WAVES) void attention_bwd_dkv_
   }
 }
 
+// ================================================================================================= bf16x3
+// The bf16x3 arithmetic (STYLER_PREC_BF16X3) for the three kernels above: every MFMA operand is carried as
+// hi + lo (hi = bf16(v), lo = bf16(v - hi): 16 mantissa bits) and every product a b runs as a_hi b_hi + a_hi b_lo + a_lo b_hi
+// on v_mfma_f32_32x32x16_bf16 into the same fp32 accumulator.  Storage is fp32 on both sides; a staged tile becomes two
+// bf16 LDS tiles (hi and lo), a register operand two fragments, P / dS are split while they are packed.  Softmax, lse and
+// delta stay fp32 as in every mode.  Same decomposition, masks and early exits as the bf16 kernels.
+__device__ __forceinline__ void split_pk(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = cvtpk(a, b);
+  lo = cvtpk(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+// 8 consecutive floats at p (scaled) -> hi / lo bf16x8
+__device__ __forceinline__ void load8_x3(const float* p, float scale, bf16x8& hi, bf16x8& lo) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  uint4 h, l;
+  split_pk(a.x * scale, a.y * scale, h.x, l.x);
+  split_pk(a.z * scale, a.w * scale, h.y, l.y);
+  split_pk(b.x * scale, b.y * scale, h.z, l.z);
+  split_pk(b.z * scale, b.w * scale, h.w, l.w);
+  hi = *reinterpret_cast<bf16x8*>(&h);
+  lo = *reinterpret_cast<bf16x8*>(&l);
+}
+__device__ __forceinline__ void pack_acc_x3(const f32x16& a, int s2, bf16x8& hi, bf16x8& lo) {
+  uint4 h, l;
+  split_pk(a[s2 * 8 + 0], a[s2 * 8 + 1], h.x, l.x);
+  split_pk(a[s2 * 8 + 2], a[s2 * 8 + 3], h.y, l.y);
+  split_pk(a[s2 * 8 + 4], a[s2 * 8 + 5], h.z, l.z);
+  split_pk(a[s2 * 8 + 6], a[s2 * 8 + 7], h.w, l.w);
+  hi = *reinterpret_cast<bf16x8*>(&h);
+  lo = *reinterpret_cast<bf16x8*>(&l);
+}
+// a staged fp32 tile (load_rows) -> the hi and the lo bf16 [64][ALD] tiles
+__device__ __forceinline__ void store_rows_x3(uint32_t* dh, uint32_t* dl, const float4 (&v)[4], int tid) {
+  const int o = (tid >> 4) * ALD + (tid & 15) * 2;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    uint2 h, l;
+    split_pk(v[p].x, v[p].y, h.x, l.x);
+    split_pk(v[p].z, v[p].w, h.y, l.y);
+    *reinterpret_cast<uint2*>(&dh[o + p * 16 * ALD]) = h;
+    *reinterpret_cast<uint2*>(&dl[o + p * 16 * ALD]) = l;
+  }
+}
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+// c += a b with both operands split (three products, the lo lo one dropped)
+#define MFMA_X3(ah, al, bh, bl, c) { c = MFMA_BF16(ah, bh, c); c = MFMA_BF16(ah, bl, c); c = MFMA_BF16(al, bh, c); }
+
+__global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                  float* __restrict__ lse, int B, int L,
+                                                                  const int64_t* __restrict__ len, const int* __restrict__ cu) {
+  __shared__ __attribute__((aligned(16))) uint32_t sKh[64 * ALD], sKl[64 * ALD], sVh[64 * ALD], sVl[64 * ALD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int tq = lane & 15, tc = (lane >> 4) & 1;
+  int bx, head, b;
+  if (!attn_block(L, B, bx, head, b)) return;
+  const int q0 = bx * 128 + wave * 32;
+  const int64_t rowbase = cu ? (int64_t)cu[b] : (int64_t)b * L;
+  int klen = len ? (int)len[b] : L;
+  if (klen > L) klen = L;
+  const int Lr = cu ? klen : L;
+  if (Lr <= 0) return;
+  const int q = q0 + li, qc = q < Lr ? q : Lr - 1;
+  if (bx * 128 >= klen) {
+    if (q < Lr) {
+      zero32(out, (rowbase + q) * 256 + head * AD + lh * 32, 0);
+      if (lse && lh == 0) lse[((int64_t)b * 4 + head) * L + q] = 0.f;
+    }
+    return;
+  }
+  bf16x8 qh[4], ql[4];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) load8_x3(qkv + (rowbase + qc) * 768 + head * AD + st * 16 + lh * 8, ATTN_SCALE_LOG2, qh[st], ql[st]);
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;
+  const __amdgpu_buffer_rsrc_t krs = rows_rsrc(qkv + rowbase * 768 + 256 + head * AD, 768, Lr);
+  const __amdgpu_buffer_rsrc_t vrs = rows_rsrc(qkv + rowbase * 768 + 512 + head * AD, 768, Lr);
+  const int ntiles = (klen + 63) / 64;
+  float4 rk[4], rv[4];
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int k0 = kt * 64;
+    load_rows(rk, krs, 768, k0, tid);
+    load_rows(rv, vrs, 768, k0, tid);
+    __syncthreads();
+    store_rows_x3(sKh, sKl, rk, tid);
+    store_rows_x3(sVh, sVl, rv, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (k0 + kb * 32 >= klen) break;
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const int o = (kb * 32 + li) * ALD + st * 8 + lh * 4;
+        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(&sKh[o]);
+        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(&sKl[o]);
+        MFMA_X3(kh, kl, qh[st], ql[st], s);
+      }
+      if (k0 + kb * 32 + 32 > klen) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (key >= klen) s[r] = -INFINITY;
+        }
+      }
+      float mb = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mb = fmaxf(mb, s[r]);
+      mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+      const float m_new = fmaxf(m_run, mb);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); rs += s[r]; }
+      rs += __shfl_xor(rs, 32, 64);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 ph, pl;
+        pack_acc_x3(s, s2, ph, pl);
+        { const bf16x8 vh = fragT(sVh, 0, tq, tc, kb, s2, lh), vl = fragT(sVl, 0, tq, tc, kb, s2, lh); MFMA_X3(vh, vl, ph, pl, o0); }
+        { const bf16x8 vh = fragT(sVh, 1, tq, tc, kb, s2, lh), vl = fragT(sVl, 1, tq, tc, kb, s2, lh); MFMA_X3(vh, vl, ph, pl, o1); }
+      }
+    }
+  }
+  if (q < Lr) {
+    store_accT(out + (rowbase + q) * 256 + head * AD, o0, o1, lh, 1.f / l_run);
+    if (lse && lh == 0) lse[((int64_t)b * 4 + head) * L + q] = (m_run + log2f(l_run)) * 0.693147180559945f;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attention_bwd_dq_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                                     const float* __restrict__ dout, const float* __restrict__ lse,
+                                                                     float* __restrict__ dqkv, float* __restrict__ delta,
+                                                                     int B, int L, const int64_t* __restrict__ len,
+                                                                     const int* __restrict__ cu) {
+  __shared__ __attribute__((aligned(16))) uint32_t sKh[64 * ALD], sKl[64 * ALD], sVh[64 * ALD], sVl[64 * ALD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int tq = lane & 15, tc = (lane >> 4) & 1;
+  int bx, head, b;
+  if (!attn_block(L, B, bx, head, b)) return;
+  const int q0 = bx * 128 + wave * 32;
+  const int64_t rowbase = cu ? (int64_t)cu[b] : (int64_t)b * L;
+  int klen = len ? (int)len[b] : L;
+  if (klen > L) klen = L;
+  const int Lr = cu ? klen : L;
+  if (Lr <= 0) return;
+  const int q = q0 + li, qc = q < Lr ? q : Lr - 1;
+  if (bx * 128 >= klen) {
+    if (q < Lr) {
+      zero32(dqkv, (rowbase + q) * 768 + head * AD + lh * 32, 0);
+      if (lh == 0) delta[((int64_t)b * 4 + head) * L + q] = 0.f;
+    }
+    return;
+  }
+  constexpr float LOG2E = 1.44269504088896f;
+  bf16x8 qh[4], ql[4], dh[4], dlo[4];
+  float dl = 0.f;
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const int off = head * AD + st * 16 + lh * 8;
+    load8_x3(qkv + (rowbase + qc) * 768 + off, 0.125f * LOG2E, qh[st], ql[st]);
+    const float* dp = dout + (rowbase + qc) * 256 + off;
+    const float* op = o + (rowbase + qc) * 256 + off;
+    load8_x3(dp, 1.0f, dh[st], dlo[st]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl += dp[e] * op[e];
+  }
+  dl += __shfl_xor(dl, 32, 64);
+  const float my_lse = lse[((int64_t)b * 4 + head) * L + qc] * LOG2E;
+  if (q < Lr && lh == 0) delta[((int64_t)b * 4 + head) * L + q] = dl;
+
+  f32x16 dq0, dq1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
+  const __amdgpu_buffer_rsrc_t krs = rows_rsrc(qkv + rowbase * 768 + 256 + head * AD, 768, Lr);
+  const __amdgpu_buffer_rsrc_t vrs = rows_rsrc(qkv + rowbase * 768 + 512 + head * AD, 768, Lr);
+  const int ntiles = (klen + 63) / 64;
+  float4 rk[4], rv[4];
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int k0 = kt * 64;
+    load_rows(rk, krs, 768, k0, tid);
+    load_rows(rv, vrs, 768, k0, tid);
+    __syncthreads();
+    store_rows_x3(sKh, sKl, rk, tid);
+    store_rows_x3(sVh, sVl, rv, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (k0 + kb * 32 >= klen) break;
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const int of = (kb * 32 + li) * ALD + st * 8 + lh * 4;
+        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(&sKh[of]), kl = *reinterpret_cast<const bf16x8*>(&sKl[of]);
+        const bf16x8 vh = *reinterpret_cast<const bf16x8*>(&sVh[of]), vl = *reinterpret_cast<const bf16x8*>(&sVl[of]);
+        MFMA_X3(kh, kl, qh[st], ql[st], s);
+        MFMA_X3(vh, vl, dh[st], dlo[st], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] - my_lse) * (dp[r] - dl);
+      if (k0 + kb * 32 + 32 > klen) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (key >= klen) s[r] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 sh, sl;
+        pack_acc_x3(s, s2, sh, sl);
+        { const bf16x8 kh = fragT(sKh, 0, tq, tc, kb, s2, lh), kl = fragT(sKl, 0, tq, tc, kb, s2, lh); MFMA_X3(kh, kl, sh, sl, dq0); }
+        { const bf16x8 kh = fragT(sKh, 1, tq, tc, kb, s2, lh), kl = fragT(sKl, 1, tq, tc, kb, s2, lh); MFMA_X3(kh, kl, sh, sl, dq1); }
+      }
+    }
+  }
+  if (q < Lr) store_accT(dqkv + (rowbase + q) * 768 + head * AD, dq0, dq1, lh, 0.125f);
+}
+
+__global__ __launch_bounds__(256, 2) void attention_bwd_dkv_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                      const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                      float* __restrict__ dqkv, int B, int L,
+                                                                      const int64_t* __restrict__ len, const int* __restrict__ cu) {
+  __shared__ __attribute__((aligned(16))) uint32_t sQh[64 * ALD], sQl[64 * ALD], sDh[64 * ALD], sDl2[64 * ALD];
+  __shared__ __attribute__((aligned(16))) float sLse[64], sDl[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int tq = lane & 15, tc = (lane >> 4) & 1;
+  int bx, head, b;
+  if (!attn_block(L, B, bx, head, b)) return;
+  const int key0 = bx * 128 + wave * 32;
+  const int64_t rowbase = cu ? (int64_t)cu[b] : (int64_t)b * L;
+  int klen = len ? (int)len[b] : L;
+  if (klen > L) klen = L;
+  const int Lr = cu ? klen : L;
+  if (Lr <= 0) return;
+  const int key = key0 + li, keyc = key < Lr ? key : Lr - 1;
+  const bool key_ok = key < klen;
+  constexpr float LOG2E = 1.44269504088896f;
+  bf16x8 kh[4], kl[4], vh[4], vl[4];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    load8_x3(qkv + (rowbase + keyc) * 768 + 256 + head * AD + st * 16 + lh * 8, 0.125f * LOG2E, kh[st], kl[st]);
+    load8_x3(qkv + (rowbase + keyc) * 768 + 512 + head * AD + st * 16 + lh * 8, 1.0f, vh[st], vl[st]);
+  }
+  f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
+  const __amdgpu_buffer_rsrc_t qrs = rows_rsrc(qkv + rowbase * 768 + head * AD, 768, Lr);
+  const __amdgpu_buffer_rsrc_t drs = rows_rsrc(dout + rowbase * 256 + head * AD, 256, Lr);
+  const float* lse_row = lse + ((int64_t)b * 4 + head) * L;
+  const float* dl_row = delta + ((int64_t)b * 4 + head) * L;
+  const int ntiles = bx * 128 < klen ? (klen + 63) / 64 : 0;
+  float4 rq[4], rdo[4];
+  float r_lse = 0.f, r_dl = 0.f;
+  for (int qt = 0; qt < ntiles; ++qt) {
+    const int qb = qt * 64;
+    if (tid < 64) {
+      const int qq = qb + tid, qi = qq < klen ? qq : klen - 1;
+      r_lse = lse_row[qi]; r_dl = dl_row[qi];
+    }
+    load_rows(rq, qrs, 768, qb, tid);
+    load_rows(rdo, drs, 256, qb, tid);
+    __syncthreads();
+    store_rows_x3(sQh, sQl, rq, tid);
+    store_rows_x3(sDh, sDl2, rdo, tid);
+    if (tid < 64) {
+      const bool okq = qb + tid < klen;
+      sLse[tid] = okq ? r_lse * LOG2E : 1e30f;
+      sDl[tid] = okq ? r_dl : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qk = 0; qk < 2; ++qk) {
+      if (qb + qk * 32 >= klen) break;
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const int of = (qk * 32 + li) * ALD + st * 8 + lh * 4;
+        const bf16x8 qvh = *reinterpret_cast<const bf16x8*>(&sQh[of]), qvl = *reinterpret_cast<const bf16x8*>(&sQl[of]);
+        const bf16x8 dvh = *reinterpret_cast<const bf16x8*>(&sDh[of]), dvl = *reinterpret_cast<const bf16x8*>(&sDl2[of]);
+        MFMA_X3(qvh, qvl, kh[st], kl[st], s);
+        MFMA_X3(dvh, dvl, vh[st], vl[st], dp);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ql_ = qk * 32 + 8 * g + 4 * lh;
+        const float4 l4 = *reinterpret_cast<const float4*>(&sLse[ql_]);
+        const float4 d4 = *reinterpret_cast<const float4*>(&sDl[ql_]);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = g * 4 + e;
+          const float p = __builtin_amdgcn_exp2f(s[r] - lv[e]);
+          s[r] = p;
+          dp[r] = p * (dp[r] - dvv[e]);
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 ph, pl, sh, sl;
+        pack_acc_x3(s, s2, ph, pl);
+        pack_acc_x3(dp, s2, sh, sl);
+        { const bf16x8 ah = fragT(sDh, 0, tq, tc, qk, s2, lh), al = fragT(sDl2, 0, tq, tc, qk, s2, lh); MFMA_X3(ah, al, ph, pl, dv0); }
+        { const bf16x8 ah = fragT(sDh, 1, tq, tc, qk, s2, lh), al = fragT(sDl2, 1, tq, tc, qk, s2, lh); MFMA_X3(ah, al, ph, pl, dv1); }
+        { const bf16x8 ah = fragT(sQh, 0, tq, tc, qk, s2, lh), al = fragT(sQl, 0, tq, tc, qk, s2, lh); MFMA_X3(ah, al, sh, sl, dk0); }
+        { const bf16x8 ah = fragT(sQh, 1, tq, tc, qk, s2, lh), al = fragT(sQl, 1, tq, tc, qk, s2, lh); MFMA_X3(ah, al, sh, sl, dk1); }
+      }
+    }
+  }
+  if (key < Lr) {
+    const int64_t off = (rowbase + key) * 768 + head * AD;
+    if (key_ok) {
+      store_accT(dqkv + off + 256, dk0, dk1, lh, 0.125f);
+      store_accT(dqkv + off + 512, dv0, dv1, lh, 1.0f);
+    } else {
+      zero32(dqkv, off + 256 + lh * 32, 0);
+      zero32(dqkv, off + 512 + lh * 32, 0);
+    }
+  }
+}
+
+// fp32 tensors on both sides; same arguments as styler_attention_fwd / styler_attention_bwd
+extern "C" int styler_attention_fwd_x3(const float* qkv, float* out, float* lse, int B, int L, const int64_t* len,
+                                       const int32_t* cu, void* stream) {
+  if (!qkv || !out || B <= 0 || L <= 0 || (cu && !len)) return STYLER_EINVAL;
+  if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return STYLER_EALIGN;
+  hipLaunchKernelGGL(attention_fwd_x3_kernel, attn_grid(L, B), dim3(256), 0, (hipStream_t)stream, qkv, out, lse, B, L, len, cu);
+  return launch_status();
+}
+extern "C" int styler_attention_bwd_x3(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
+                                       float* delta_ws, int B, int L, const int64_t* len, const int32_t* cu, void* stream) {
+  if (!qkv || !out || !dout || !lse || !dqkv || !delta_ws || B <= 0 || L <= 0) return STYLER_EINVAL;
+  if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 15)) return STYLER_EALIGN;
+  const dim3 grid = attn_grid(L, B);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(attention_bwd_dq_x3_kernel, grid, dim3(256), 0, st, qkv, out, dout, lse, dqkv, delta_ws, B, L, len, cu);
+  hipLaunchKernelGGL(attention_bwd_dkv_x3_kernel, grid, dim3(256), 0, st, qkv, dout, lse, delta_ws, dqkv, B, L, len, cu);
+  return launch_status();
+}
+
 // io_flags & STYLER_IO_X_BF16: qkv is stored as bf16 ([rows][768] elements; throughput mode writes it that way from the QKV
 // GEMM's epilogue -- its only readers are these three kernels, which round it to bf16 anyway).  io_flags & STYLER_IO_Y_BF16:
 // `out` is written as bf16.

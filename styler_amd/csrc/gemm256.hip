@@ -572,14 +572,31 @@ static int gemm256_ksplit(int B, int L, int cin, int n, int kw, int64_t ldx, int
 extern "C" int64_t styler_conv_gemm_workspace_bytes(int B, int L, int cin, int n, int kw, int act, int prec, int io_flags,
                                                     int64_t ldx, int packed, int has_mask) {
   if (prec != STYLER_PREC_BF16) return 0;
-  const int ks = gemm256_ksplit(B, L, cin, n, kw, ldx, io_flags & STYLER_IO_X_BF16, packed != 0, act, has_mask != 0);
+  int ks = gemm256_ksplit(B, L, cin, n, kw, ldx, io_flags & STYLER_IO_X_BF16, packed != 0, act, has_mask != 0);
+  if (ks <= 1) {
+    int mt, nt;                                    // (the 64 x 64 split-K only where the 256 x 256 engine does not take the launch)
+    if (gemm256_eligible(B, L, cin, n, kw, ldx, io_flags & STYLER_IO_X_BF16, packed != 0, &mt, &nt)) return 0;
+    ks = styler_gemm_small_ksplit(B, L, cin, n, kw, act, has_mask != 0);
+  }
   return ks > 1 ? (int64_t)ks * B * L * n * 4 : 0;
 }
 
-int styler_gemm256_try(const GemmArgs& a0, int x16, int y16, hipStream_t st) {
-  void* ws = t_ws;
-  const int64_t ws_bytes = t_ws_bytes;
-  t_ws = nullptr; t_ws_bytes = 0;                                    // consumed by this call, whatever engine takes it
+void styler_gemm_take_workspace(void** ws, int64_t* bytes) {
+  *ws = t_ws; *bytes = t_ws_bytes;
+  t_ws = nullptr; t_ws_bytes = 0;
+}
+
+int styler_gemm_combine(const GemmArgs& a0, int ks, int y16, hipStream_t st) {
+  const int64_t M = (int64_t)a0.B * a0.L;
+  const int64_t quads = M * (a0.n >> 2);
+  const unsigned cb = (unsigned)((quads + 255) / 256 > 4096 ? 4096 : (quads + 255) / 256);
+  const int64_t* nrows = (a0.rowinfo && a0.B == 1) ? a0.len : nullptr;
+  if (y16) hipLaunchKernelGGL(gemm256_combine_kernel<true>, dim3(cb), dim3(256), 0, st, a0.part, M, a0.n, ks, a0.scale, a0.shift, a0.res, a0.ldres, a0.y, a0.ldy, nrows, a0.res16);
+  else hipLaunchKernelGGL(gemm256_combine_kernel<false>, dim3(cb), dim3(256), 0, st, a0.part, M, a0.n, ks, a0.scale, a0.shift, a0.res, a0.ldres, a0.y, a0.ldy, nrows, a0.res16);
+  return launch_status();
+}
+
+int styler_gemm256_try(const GemmArgs& a0, int x16, int y16, hipStream_t st, void* ws, int64_t ws_bytes) {
   if (a0.trace) return 0;
   int mt, nt;
   const int64_t M = (int64_t)a0.B * a0.L;
@@ -591,12 +608,8 @@ int styler_gemm256_try(const GemmArgs& a0, int x16, int y16, hipStream_t st) {
     a.ksplit = ks; a.part = reinterpret_cast<float*>(ws);
     const dim3 grid((unsigned)(((a.mt + 7) / 8) * 8 * a.nt), (unsigned)ks);
     hipLaunchKernelGGL(conv_gemm256_kernel<false>, grid, dim3(512), 0, st, a);
-    const int64_t quads = M * (a0.n >> 2);
-    const unsigned cb = (unsigned)((quads + 255) / 256 > 4096 ? 4096 : (quads + 255) / 256);
-    const int64_t* nrows = (a0.rowinfo && a0.B == 1) ? a0.len : nullptr;
-    if (y16) hipLaunchKernelGGL(gemm256_combine_kernel<true>, dim3(cb), dim3(256), 0, st, a.part, M, a0.n, ks, a0.scale, a0.shift, a0.res, a0.ldres, a0.y, a0.ldy, nrows, a0.res16);
-    else hipLaunchKernelGGL(gemm256_combine_kernel<false>, dim3(cb), dim3(256), 0, st, a.part, M, a0.n, ks, a0.scale, a0.shift, a0.res, a0.ldres, a0.y, a0.ldy, nrows, a0.res16);
-    const int rc = launch_status();
+    int rc = launch_status();
+    if (!rc) rc = styler_gemm_combine(a, ks, y16, st);
     return rc ? (rc < 0 ? rc : -rc) : 1;
   }
   if (!gemm256_eligible(a0.B, a0.L, a0.cin, a0.n, a0.kw, a0.ldx, x16, a0.rowinfo != nullptr, &mt, &nt)) return 0;

@@ -26,4 +26,11 @@ struct GemmArgs {
 
 // gemm256.hip: returns 1 when the 256x256 LDS-DMA engine takes the launch (and has enqueued it), 0 when the shape is not
 // eligible, < 0 on a launch error.
-int styler_gemm256_try(const GemmArgs& a, int x16, int y16, hipStream_t st);
+// `ws` / `ws_bytes`: the workspace registered for this call (styler_gemm_take_workspace), needed by its split-K path.
+int styler_gemm256_try(const GemmArgs& a, int x16, int y16, hipStream_t st, void* ws, int64_t ws_bytes);
+// hands over (and clears) the workspace the host thread registered with styler_gemm_set_workspace
+void styler_gemm_take_workspace(void** ws, int64_t* bytes);
+// gemm_conv.hip: split-K factor of a small-M, long-K launch on the 64 x 64 tile (1: none)
+int styler_gemm_small_ksplit(int B, int L, int cin, int n, int kw, int act, bool has_mask);
+// gemm256.hip: the combine pass of a split-K launch (a.part holds ks partial tiles [B*L][n]; epilogue from a)
+int styler_gemm_combine(const GemmArgs& a, int ks, int y16, hipStream_t st);

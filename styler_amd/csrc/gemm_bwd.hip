@@ -274,15 +274,25 @@ __device__ __forceinline__ uint2 lds_tr_read(const uint16_t* p) {
   return *reinterpret_cast<const uint2*>(&v);
 }
 
+// the low parts of two fp32 values, packed: bf16(v - float(bf16(v))), same rounding as the high part's
+__device__ __forceinline__ uint32_t lo_pk(float a, float b) {
+  const uint32_t h = cvt_pk_bf16_b(a, b);
+  return cvt_pk_bf16_b(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u));
+}
+
 // DZ16 / X16: the operand lives in HBM as bf16 already (the FFN hidden activation / its gradient in throughput mode):
 // 8-byte loads, no conversion on the staging path.
+// `pad_parts` = (pad_left & 0xff) | parts << 8.  parts (the bf16x3 arithmetic on fp32-typed operands, ops.wgrad): bit 0 = stage the LOW
+// part of x, v - float(bf16(v)), instead of its rounding to bf16 (the high part); bit 1 = the same for dz.
 template <int KW, int TA, int TB, bool DZ16 = false, bool X16 = false>
 __device__ __forceinline__ void wgrad_tr_body(const int bid, const void* __restrict__ dz, int64_t lddz,
                                               const void* __restrict__ x, int64_t ldx, float* __restrict__ db,
-                                              float* __restrict__ db2, int B, int L, int n, int cin, int pad_left, int ct,
+                                              float* __restrict__ db2, int B, int L, int n, int cin, int pad_parts, int ct,
                                               int cpi, int chunks_per_split, int tiles, int splits,
                                               float* __restrict__ ws, const int4* __restrict__ chunktab,
                                               const int64_t* __restrict__ counts) {
+  const int pad_left = (int)(int8_t)(pad_parts & 0xff);   // (-1: the shifted Linear of the LSTM's reverse direction)
+  const bool x_lo = !X16 && (pad_parts & 0x100), dz_lo = !DZ16 && (pad_parts & 0x200);
   constexpr int FA = 64 * TA, FB = 64 * TB;          // features per block tile
   constexpr int XR = KW == 1 ? 64 : 72;              // x rows per chunk incl. halo (KW - 1 <= 8)
   constexpr int NR = (8 + KW - 1 + 3) / 4;           // transpose reads per x window
@@ -404,7 +414,8 @@ __device__ __forceinline__ void wgrad_tr_body(const int bid, const void* __restr
       } else {
         bs.x += ra[p].x; bs.y += ra[p].y; bs.z += ra[p].z; bs.w += ra[p].w;
         *reinterpret_cast<uint2*>(da + p * (RPA / 4) * SA * 64) =
-            make_uint2(cvt_pk_bf16_b(ra[p].x, ra[p].y), cvt_pk_bf16_b(ra[p].z, ra[p].w));
+            dz_lo ? make_uint2(lo_pk(ra[p].x, ra[p].y), lo_pk(ra[p].z, ra[p].w))
+                  : make_uint2(cvt_pk_bf16_b(ra[p].x, ra[p].y), cvt_pk_bf16_b(ra[p].z, ra[p].w));
       }
     }
 #pragma unroll
@@ -412,7 +423,8 @@ __device__ __forceinline__ void wgrad_tr_body(const int bid, const void* __restr
       if (br + p * RPB < XR)
         *reinterpret_cast<uint2*>(dbp + p * (RPB / 4) * SB * 64) =
             X16 ? make_uint2(__float_as_uint(rb[p].x), __float_as_uint(rb[p].y))
-                : make_uint2(cvt_pk_bf16_b(rb[p].x, rb[p].y), cvt_pk_bf16_b(rb[p].z, rb[p].w));
+                : (x_lo ? make_uint2(lo_pk(rb[p].x, rb[p].y), lo_pk(rb[p].z, rb[p].w))
+                        : make_uint2(cvt_pk_bf16_b(rb[p].x, rb[p].y), cvt_pk_bf16_b(rb[p].z, rb[p].w)));
   };
 
   // ---- fragment read coordinates: 16-lane group (ch = feature half, lh = k half), q = lane in the group ----
@@ -563,10 +575,16 @@ template <int N> __device__ __forceinline__ void wg_vm_wait() { asm volatile("s_
 template <int KW, int TA, int TB, int NST, int KG, int TAG = 0>
 __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __restrict__ dz, int64_t lddz,
                                                const void* __restrict__ x, int64_t ldx, float* __restrict__ db,
-                                               float* __restrict__ db2, int B, int L, int n, int cin, int pad_left, int ct,
+                                               float* __restrict__ db2, int B, int L, int n, int cin, int pad_cat, int ct,
                                                int cpi, int chunks_per_split, int tiles, int splits,
                                                float* __restrict__ ws, const int4* __restrict__ chunktab,
                                                const int64_t* __restrict__ counts) {
+  // pad_cat = (pad_left & 0xff) | (x3cat ? 0x400 : 0).  x3cat (STYLER_IO_X3CAT, the bf16x3 arithmetic): dz and x are
+  // [hi | hi | lo] split tensors (n resp. cin columns per part) and the launch computes dz_hi^T x_hi + dz_hi^T x_lo + dz_lo^T x_hi
+  // as ONE contraction over three times the chunks: chunk ch of part p = ch / (chunks per part) reads column block p of dz
+  // and column block (0, 2, 1)[p] of x.  One set of partial tiles instead of three; the bias row sums skip part 1 (dz_hi twice).
+  const int pad_left = (int)(int8_t)(pad_cat & 0xff);
+  const bool x3cat = pad_cat & 0x400;
   constexpr int FA = 64 * TA, FB = 64 * TB;
   constexpr int XR = KW == 1 ? 64 : 72;
   constexpr int NR = (8 + KW - 1 + 3) / 4;
@@ -604,14 +622,17 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
   }
   const int n0 = (tile / ct) * FA, c0 = (tile % ct) * FB;
   int64_t nchunks = (int64_t)B * cpi;
+  if (counts) nchunks = chunktab ? counts[1] : (counts[0] + WB_BK - 1) / WB_BK;
+  const int nch1 = (int)nchunks;                     // chunks per part
+  if (x3cat) nchunks *= 3;
   if (counts) {
-    nchunks = chunktab ? counts[1] : (counts[0] + WB_BK - 1) / WB_BK;
     chunks_per_split = (int)((nchunks + splits - 1) / splits);
     if (!chunktab) L = (int)counts[0];
   }
   const int64_t ch0 = (int64_t)split * chunks_per_split;
   int64_t ch1 = ch0 + chunks_per_split; if (ch1 > nchunks) ch1 = nchunks;
   if (ch0 >= ch1 && !counts) return;
+  auto part_of = [&](int ch) -> int { return x3cat ? (ch >= 2 * nch1 ? 2 : (ch >= nch1 ? 1 : 0)) : 0; };
 
   // ---- DMA source offsets (bytes, relative to the chunk's descriptor base), one per piece of this wave ----
   constexpr uint32_t OOB = 0x80000000u;
@@ -635,9 +656,10 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
   // chunk table entry of chunk `ch` (packed / item-aligned chunks), fetched one iteration before it is needed: the scalar
   // load's latency would otherwise sit between the barrier and the DMA issue of every iteration
   auto entry = [&](int ch) -> int4 {
-    return (chunktab && ch < (int)ch1) ? chunktab[ch] : make_int4(0, 0, 0, 0);
+    return (chunktab && ch < (int)ch1) ? chunktab[ch - part_of(ch) * nch1] : make_int4(0, 0, 0, 0);
   };
-  auto issue = [&](int ch, int stage, const int4 e) {
+  auto issue = [&](int chk, int stage, const int4 e) {
+    const int part = part_of(chk), ch = chk - part * nch1;
     int t0, Li;
     int64_t rowb;
     if (chunktab) {
@@ -652,8 +674,9 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
     int64_t b_rec = ((int64_t)(Li - txb - 1) * ldx + cin) * 2;
     a_rec = a_rec > REC_MAX ? REC_MAX : a_rec;
     b_rec = b_rec > REC_MAX ? REC_MAX : (b_rec < 0 ? 0 : b_rec);
-    const char* a_base = reinterpret_cast<const char*>(dz) + (rowb + t0) * lddz * 2;
-    const char* b_base = reinterpret_cast<const char*>(x) + (rowb + txb) * ldx * 2;
+    // (x3cat: column block `part` of dz, column block (0, 2, 1)[part] of x)
+    const char* a_base = reinterpret_cast<const char*>(dz) + ((rowb + t0) * lddz + (int64_t)part * n) * 2;
+    const char* b_base = reinterpret_cast<const char*>(x) + ((rowb + txb) * ldx + (int64_t)((part * 2) % 3) * cin) * 2;
     const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a_base), 0, (int)a_rec, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b_base), 0, (int)b_rec, 0x00020000);
     const uint32_t b_off = (uint32_t)((tx - txb) * (int)ldx * 2);        // <= 0: rows before the item wrap out of range
@@ -701,7 +724,7 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
   const uint4 ones4 = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
   const bf16x8 ones = *reinterpret_cast<const bf16x8*>(&ones4);
 
-  auto compute = [&](int stage, auto s_lo_tag, auto s_hi_tag) {
+  auto compute = [&](int stage, const bool bias_now, auto s_lo_tag, auto s_hi_tag) {
     constexpr int S_LO = decltype(s_lo_tag)::value, S_HI = decltype(s_hi_tag)::value;
     const uint16_t* pa = reinterpret_cast<const uint16_t*>(smem + stage * STAGE);
     const uint16_t* pb = reinterpret_cast<const uint16_t*>(smem + stage * STAGE + A_BYTES);
@@ -739,7 +762,7 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
           for (int i = 0; i < TA; ++i) acc[i][jt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb, acc[i][jt][j], 0, 0, 0);
         }
       }
-      if (do_bias) {
+      if (bias_now) {
 #pragma unroll
         for (int i = 0; i < TA; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, accb[i], 0, 0, 0);
       }
@@ -781,19 +804,20 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    const bool bias_now = do_bias && part_of(ich0 + KG * i) != 1;
     if (live) {
       if (i + D < nch) {                             // the stage read in iteration i - 1: every wave is past those reads
         issue(ich0 + KG * (i + D), st_i, e_next);
         e_next = entry(ich0 + KG * (i + D + 1));
       }
-      if (STAG) compute(st_c, integral_constant<int, 0>{}, integral_constant<int, NS / 2>{});
-      else compute(st_c, integral_constant<int, 0>{}, integral_constant<int, NS>{});
+      if (STAG) compute(st_c, bias_now, integral_constant<int, 0>{}, integral_constant<int, NS / 2>{});
+      else compute(st_c, bias_now, integral_constant<int, 0>{}, integral_constant<int, NS>{});
     }
     if (STAG) {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if (live) compute(st_c, integral_constant<int, NS / 2>{}, integral_constant<int, NS>{});
+      if (live) compute(st_c, bias_now, integral_constant<int, NS / 2>{}, integral_constant<int, NS>{});
     }
     st_c = st_c + 1 == NST ? 0 : st_c + 1;
     st_i = st_i + 1 == NST ? 0 : st_i + 1;
@@ -926,7 +950,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_group_lin128_kernel(const Style
   const int64_t* pcn = reinterpret_cast<const int64_t*>(d.counts);
   const int lb = bid - d.block_start;
   const int64_t lddz = d.lddz, ldx = d.ldx;
-  const int B = d.B, L = d.L, n = d.n, cin = d.cin, pad_left = d.pad_left, ct = d.ct, cpi = d.cpi, cps = d.cps, tiles = d.tiles,
+  const int B = d.B, L = d.L, n = d.n, cin = d.cin, pad_left = d.pad_left & 0x4ff, ct = d.ct, cpi = d.cpi, cps = d.cps, tiles = d.tiles,
             splits = d.splits;
   wgrad_dma_body<1, 2, 2, 2, 1, 1>(lb, pdz, lddz, px, ldx, pdb, pdb2, B, L, n, cin, pad_left, ct, cpi, cps, tiles, splits, pws,
                                      pct, pcn);
@@ -987,8 +1011,19 @@ static int wgrad_kgroups(int n, int cin, int kw, int prec, int io_flags) {
   return ((kw == 5 || kw == 9) && TA == 1 && TB == 1) ? 2 : 1;
 }
 
+// STYLER_IO_X3CAT launches exist on the LDS-DMA ring only: both parts bf16-resident, whole 16-byte pieces, a ring kernel
+// for the (taps, tile) combination.
+static bool wgrad_x3cat_ok(int n, int cin, int kw, int pad_left) {
+  if (!g_wgrad_dma || (n & 7) || (cin & 7)) return false;
+  int TA, TB;
+  wgrad_tile(n, cin, kw, STYLER_PREC_BF16, &TA, &TB);
+  if (kw == 1) return pad_left == 0 && TA == 2 && TB == 2;
+  return (kw == 5 || kw == 9) && pad_left == kw / 2 && TA == 1 && TB == 1;
+}
+extern "C" int styler_wgrad_x3cat_ok(int n, int cin, int kw, int pad_left) { return wgrad_x3cat_ok(n, cin, kw, pad_left) ? 1 : 0; }
+
 static void wgrad_plan(int B, int L, int n, int cin, int kw, int pad_left, int prec, int* Be, int* Le, int* cpi, int* cps,
-                       int* splits, int want_splits = 0, int kg = 1) {
+                       int* splits, int want_splits = 0, int kg = 1, int kcat = 1) {
   int TA, TB;
   wgrad_tile(n, cin, kw, prec, &TA, &TB);
   const int fa = 64 * TA, fb = 64 * TB;
@@ -998,7 +1033,7 @@ static void wgrad_plan(int B, int L, int n, int cin, int kw, int pad_left, int p
   if (prec == STYLER_PREC_BF16) {
     if (kw == 1 && pad_left == 0) { *Le = (int)((int64_t)B * L); *Be = 1; }   // no shifts: one flat item
     *cpi = (*Le + WB_BK - 1) / WB_BK;
-    nchunks = (int64_t)(*Be) * (*cpi);
+    nchunks = (int64_t)(*Be) * (*cpi) * kcat;        // (kcat = 3: STYLER_IO_X3CAT, three parts along the contraction axis)
   } else {
     *cpi = 0;
     nchunks = ((int64_t)B * L + WG_BK - 1) / WG_BK;
@@ -1022,7 +1057,8 @@ static void wgrad_plan(int B, int L, int n, int cin, int kw, int pad_left, int p
 extern "C" int64_t styler_wgrad_workspace_bytes_io(int B, int L, int n, int cin, int kw, int pad_left, int prec, int io_flags) {
   if (B <= 0 || L <= 0 || n <= 0 || cin <= 0 || kw <= 0) return 0;
   int Be, Le, cpi, cps, splits;
-  wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, 0, wgrad_kgroups(n, cin, kw, prec, io_flags));
+  wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, 0, wgrad_kgroups(n, cin, kw, prec, io_flags),
+             (io_flags & STYLER_IO_X3CAT) ? 3 : 1);
   return (int64_t)splits * n * kw * cin * 4;
 }
 extern "C" int64_t styler_wgrad_workspace_bytes(int B, int L, int n, int cin, int kw, int pad_left, int prec) {
@@ -1050,19 +1086,27 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
   hipStream_t st = (hipStream_t)stream;
   int Be, Le, cpi, cps, splits;
   const int kg = wgrad_kgroups(n, cin, kw, prec, io_flags);
-  wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, 0, kg);
+  const bool x3cat = io_flags & STYLER_IO_X3CAT;
+  if (x3cat && !(prec == STYLER_PREC_BF16 && dz16 && x16 && wgrad_x3cat_ok(n, cin, kw, pad_left) && !(lddz & 7) && !(ldx & 7) &&
+                 lddz >= 3 * (int64_t)n && ldx >= 3 * (int64_t)cin))
+    return STYLER_EINVAL;
+  wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, 0, kg, x3cat ? 3 : 1);
+  const int pad_cat = (pad_left & 0xff) | (x3cat ? 0x400 : 0);
   float* ws = reinterpret_cast<float*>(workspace);
   const dim3 grid(nt * ct, (unsigned)splits);
+  // low-part flags of the register-staged kernels (fp32-typed operands only; see wgrad_tr_body)
+  const int pad_k = (pad_left & 0xff) | ((io_flags & STYLER_IO_X_LO) && !x16 ? 0x100 : 0) | ((io_flags & STYLER_IO_DZ_LO) && !dz16 ? 0x200 : 0);
   if (prec == STYLER_PREC_BF16) {
     const int tiles = nt * ct;
     const dim3 grid1((unsigned)(splits >= 8 ? (tiles * splits + 7) / 8 * 8 : tiles * splits));
 #define WT_LAUNCH(K, A_, B_) hipLaunchKernelGGL((wgrad_tr_kernel<K, A_, B_>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, \
-                                                db2, Be, Le, n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, \
+                                                db2, Be, Le, n, cin, pad_k, ct, cpi, cps, tiles, splits, ws, \
                                                 kw > 1 ? reinterpret_cast<const int4*>(chunktab) : nullptr, counts)
     // both operands bf16-resident, rows and feature counts in whole 16-byte pieces: the LDS-DMA ring (wgrad_dma_kernel)
     const bool dma = g_wgrad_dma && dz16 && x16 && !(n & 7) && !(cin & 7) && !((uintptr_t)dz & 15) && !((uintptr_t)x & 15);
+    if (x3cat && !dma) return STYLER_EALIGN;
 #define WD_LAUNCH(K, A_, B_, S_, G_) hipLaunchKernelGGL((wgrad_dma_kernel<K, A_, B_, S_, G_>), grid1, dim3(256 * G_), 0, st, dz, lddz, \
-                                                        x, ldx, db, db2, Be, Le, n, cin, pad_left, ct, cpi, cps, tiles, splits, ws,  \
+                                                        x, ldx, db, db2, Be, Le, n, cin, pad_cat, ct, cpi, cps, tiles, splits, ws,   \
                                                         kw > 1 ? reinterpret_cast<const int4*>(chunktab) : nullptr, counts)
     if (dma && kw == 1 && TA == 2 && TB == 2) {
       if (kg == 2) WD_LAUNCH(1, 2, 2, 2, 2);
@@ -1078,20 +1122,20 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
         if (TA != 2 || TB != 2) return STYLER_EINVAL;
         if (x16 && dz16)                             // (both: the decoder's bf16 residual stream, round 3)
           hipLaunchKernelGGL((wgrad_tr_kernel<1, 2, 2, true, true>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, db2, Be, Le,
-                             n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, nullptr, counts);
+                             n, cin, pad_k, ct, cpi, cps, tiles, splits, ws, nullptr, counts);
         else if (x16)
           hipLaunchKernelGGL((wgrad_tr_kernel<1, 2, 2, false, true>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, db2, Be, Le,
-                             n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, nullptr, counts);
+                             n, cin, pad_k, ct, cpi, cps, tiles, splits, ws, nullptr, counts);
         else
           hipLaunchKernelGGL((wgrad_tr_kernel<1, 2, 2, true, false>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, db2, Be, Le,
-                             n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, nullptr, counts);
+                             n, cin, pad_k, ct, cpi, cps, tiles, splits, ws, nullptr, counts);
       } else if (TA == 2 && TB == 2) WT_LAUNCH(1, 2, 2); else if (TA == 2) WT_LAUNCH(1, 2, 1);
       else if (TB == 2) WT_LAUNCH(1, 1, 2); else WT_LAUNCH(1, 1, 1);
     } else if (kw == 3) {
       if (TA == 2) WT_LAUNCH(3, 2, 1); else WT_LAUNCH(3, 1, 1);
     } else if (kw == 5) {
 #define WT5(D_, X_) hipLaunchKernelGGL((wgrad_tr_kernel<5, 1, 1, D_, X_>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, db2, Be, \
-                                       Le, n, cin, pad_left, ct, cpi, cps, tiles, splits, ws,                                  \
+                                       Le, n, cin, pad_k, ct, cpi, cps, tiles, splits, ws,                                     \
                                        reinterpret_cast<const int4*>(chunktab), counts)
       if (dz16 || x16) {
         if (TA != 1 || TB != 1) return STYLER_EINVAL;
@@ -1101,10 +1145,10 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
     } else {
       if (dz16 && x16)
         hipLaunchKernelGGL((wgrad_tr_kernel<9, 1, 1, true, true>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, db2, Be, Le,
-                           n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, reinterpret_cast<const int4*>(chunktab), counts);
+                           n, cin, pad_k, ct, cpi, cps, tiles, splits, ws, reinterpret_cast<const int4*>(chunktab), counts);
       else if (dz16)
         hipLaunchKernelGGL((wgrad_tr_kernel<9, 1, 1, true, false>), grid1, dim3(256), 0, st, dz, lddz, x, ldx, db, db2, Be, Le,
-                           n, cin, pad_left, ct, cpi, cps, tiles, splits, ws, reinterpret_cast<const int4*>(chunktab), counts);
+                           n, cin, pad_k, ct, cpi, cps, tiles, splits, ws, reinterpret_cast<const int4*>(chunktab), counts);
       else
         WT_LAUNCH(9, 1, 1);
     }
@@ -1183,14 +1227,19 @@ extern "C" int styler_wgrad_group_desc(StylerWgradGroupDesc* out, const float* d
   const int variant = wgrad_variant(kw, TA, TB, dz16, x16);
   if (variant < 0) return 0;
   int Be, Le, cpi, cps, splits;
-  wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, want_splits);
+  const bool x3cat = io_flags & STYLER_IO_X3CAT;
+  if (x3cat && !(dz16 && x16 && wgrad_x3cat_ok(n, cin, kw, pad_left) && variant == 8 && lddz >= 3 * (int64_t)n && ldx >= 3 * (int64_t)cin))
+    return STYLER_EINVAL;
+  wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, want_splits, 1, x3cat ? 3 : 1);
   const int nt = (n + 64 * TA - 1) / (64 * TA), ct = (cin + 64 * TB - 1) / (64 * TB), tiles = nt * ct;
   out->dz = (uint64_t)(uintptr_t)dz; out->x = (uint64_t)(uintptr_t)x; out->db = (uint64_t)(uintptr_t)db;
   out->db2 = (uint64_t)(uintptr_t)db2; out->ws = (uint64_t)(uintptr_t)workspace;
   out->counts = (uint64_t)(uintptr_t)packed_counts;
   out->chunktab = (uint64_t)(uintptr_t)(kw > 1 ? packed_chunktab : nullptr);
   out->lddz = lddz; out->ldx = ldx;
-  out->B = Be; out->L = Le; out->n = n; out->cin = cin; out->pad_left = pad_left; out->ct = ct; out->cpi = cpi;
+  out->B = Be; out->L = Le; out->n = n; out->cin = cin; out->ct = ct; out->cpi = cpi;
+  out->pad_left = (pad_left & 0xff) | ((io_flags & STYLER_IO_X_LO) && !x16 ? 0x100 : 0) | ((io_flags & STYLER_IO_DZ_LO) && !dz16 ? 0x200 : 0) |
+                  (x3cat ? 0x400 : 0);
   out->cps = cps; out->tiles = tiles; out->splits = splits; out->block_start = 0;
   out->nblocks = splits >= 8 ? (tiles * splits + 7) / 8 * 8 : tiles * splits;
   out->variant = variant; out->kw = kw;
@@ -1225,7 +1274,8 @@ extern "C" int styler_wgrad_group(const StylerWgradGroupDesc* desc_dev, int coun
 extern "C" int styler_wgrad_splits_io(int B, int L, int n, int cin, int kw, int pad_left, int prec, int io_flags) {
   if (B <= 0 || L <= 0 || n <= 0 || cin <= 0 || kw <= 0) return 0;
   int Be, Le, cpi, cps, splits;
-  wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, 0, wgrad_kgroups(n, cin, kw, prec, io_flags));
+  wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, 0, wgrad_kgroups(n, cin, kw, prec, io_flags),
+             (io_flags & STYLER_IO_X3CAT) ? 3 : 1);
   return splits;
 }
 extern "C" int styler_wgrad_splits(int B, int L, int n, int cin, int kw, int pad_left, int prec) {

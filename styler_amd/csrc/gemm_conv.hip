@@ -112,8 +112,16 @@ __device__ __forceinline__ void conv_gemm_body(const GemmArgs& a, const int bid_
   const int kw = KW1 ? 1 : a.kw;
   const int pad = KW1 ? 0 : a.pad;
   const int ktot = kw * a.cin;
-  const int ncc = (a.cin + BK - 1) / BK;           // channel chunks
-  const int nsteps = ncc * kw;
+  // channel chunks; a split-K launch (a.ksplit > 1, conv_gemm_kernel below) gives blockIdx.y its share of them
+  const int ncc_all = (a.cin + BK - 1) / BK;
+  int cc0 = 0, cc1 = ncc_all;
+  if (a.ksplit > 1) {
+    const int per = (ncc_all + a.ksplit - 1) / a.ksplit;
+    cc0 = (int)blockIdx.y * per;
+    cc1 = cc0 + per < ncc_all ? cc0 + per : ncc_all;
+    cc0 = cc0 < cc1 ? cc0 : cc1;
+  }
+  const int nsteps = (cc1 - cc0) * kw;
 
   // ---- tiles made only of rows at or past their item's length produce zeros: write them and leave (in the packed
   // decoder layout B = 1 and len[0] = the number of packed rows: every tile behind the data is skipped) ----
@@ -243,9 +251,9 @@ __device__ __forceinline__ void conv_gemm_body(const GemmArgs& a, const int bid_
 
   if (tid < LD) sZ[tid] = 0u;
   const uint32_t* const zrow = sZ + lh * (BF16 ? 4 : 16);
-  load_a(0);
-  load_b(0, 0);
-  store_a(0);
+  load_a(cc0);
+  load_b(cc0, 0);
+  store_a(cc0 & 1);
   store_b(0);
   __syncthreads();
   if (a.trace) stamp[1] = wall_clock64();
@@ -256,7 +264,7 @@ __device__ __forceinline__ void conv_gemm_body(const GemmArgs& a, const int bid_
 #else
 #define PH_MARK(i, t0)
 #endif
-  int cc = 0, j = 0;
+  int cc = cc0, j = 0;
   for (int step = 0; step < nsteps; ++step) {
     // next step's coordinates; its global loads are issued now and land in LDS after this step's MFMAs
     int ccn = cc, jn = j + 1;
@@ -525,6 +533,13 @@ __device__ __forceinline__ void conv_gemm_body(const GemmArgs& a, const int bid_
 
 template <int TM, int TN, bool BF16, bool KW1, bool OCC3, bool A16 = false, bool Y16 = false, int WM = 2>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
+  // split-K (small-M, long-K launches, gemm_small_ksplit below): blockIdx.y owns a range of channel chunks and stores its raw
+  // fp32 accumulators as a plain [M][n] partial tile; styler_gemm_combine adds them in a fixed order and applies the epilogue
+  if (!Y16 && a.ksplit > 1) {
+    a.y = a.part + (int64_t)blockIdx.y * a.B * a.L * a.n;
+    a.ldy = a.n;
+    a.scale = nullptr; a.shift = nullptr; a.res = nullptr; a.mask = nullptr; a.act = STYLER_ACT_NONE;
+  }
   conv_gemm_body<TM, TN, BF16, KW1, OCC3, A16, Y16, WM, 0>(a, blockIdx.x);
 }
 
@@ -550,7 +565,7 @@ static int launch_gemm(GemmArgs a, hipStream_t st, int x16, int y16) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * (4 / WM);
   a.mt = (int)((M + BM - 1) / BM);
   a.nt = (a.n + BN - 1) / BN;
-  const dim3 grid((unsigned)(((a.mt + 7) / 8) * 8 * a.nt));
+  const dim3 grid((unsigned)(((a.mt + 7) / 8) * 8 * a.nt), (unsigned)(a.ksplit > 1 ? a.ksplit : 1));
   // occupancy-3 layout (one extra barrier per chunk): measured +12..15 % on the k = 9 / k = 5 convs; on k = 3 it lost 5 %
   // with the round-1 epilogue and is a small gain with the present one (train step 11.989 -> 11.972 ms same-box).
   // STYLER_GEMM_OCC3=0/1 overrides for experiments.
@@ -637,6 +652,31 @@ extern "C" int styler_gemm_n96_config(int enabled, int min_rows) {
   return prev;
 }
 
+// Split-K for the 64 x 64 tile: a conv GEMM over few rows and a long contraction axis (the text encoder's FFN k = 9 dX:
+// M = 2880, n = 256, K = 9 x 1024 -> 180 tiles x 144 steps) has fewer blocks than CUs and nothing to hide the load -> LDS ->
+// barrier latency of a step behind (0.73 us per step, 105 us per launch at 129 TFLOP/s).  Its channel chunks are dealt to
+// blockIdx.y so that about four blocks share a CU; the partial tiles are folded by the combine pass of gemm256.hip.
+// Plain epilogues only (bias / scale, residual), like the 256 x 256 engine's split-K.
+static int g_small_split = [] { const char* e = getenv("STYLER_GEMM_SMALL_SPLITK"); return e ? atoi(e) : 1; }();
+// enabled: 0 / 1, -1 keeps; returns the previous value (the A/B switch of the parity test)
+extern "C" int styler_gemm_small_split_config(int enabled) {
+  const int prev = g_small_split;
+  if (enabled >= 0) g_small_split = enabled ? 1 : 0;
+  return prev;
+}
+int styler_gemm_small_ksplit(int B, int L, int cin, int n, int kw, int act, bool has_mask) {
+  if (!g_small_split || kw < 3 || (cin & 63) || (n & 3) || (act & 0xff) != STYLER_ACT_NONE || (act & STYLER_ACT_RES_FIRST) || has_mask) return 1;
+  const int64_t M = (int64_t)B * L;
+  const int64_t tiles = ((M + 63) / 64) * ((n + 63) / 64);
+  const int ncc = cin / 64;
+  if (tiles > 256 || ncc * kw < 48) return 1;
+  const int want = (int)(1024 / tiles);                              // about four blocks per CU
+  if (want < 2) return 1;
+  const int per = ncc / want > 0 ? ncc / want : 1;
+  const int ks = (ncc + per - 1) / per;
+  return ks > 1 ? ks : 1;
+}
+
 // Internal entry with an explicit left padding (pad = kw/2 is the 'same' conv of the model; pad = 0 with an
 // even kw is the framing conv of the STFT, stft.hip).
 int styler_conv_gemm_impl2(const float* x, int64_t ldx, const void* w, const float* scale, const float* shift,
@@ -671,9 +711,19 @@ int styler_conv_gemm_impl2(const float* x, int64_t ldx, const void* w, const flo
              reinterpret_cast<const int2*>(rowinfo), mask, ldmask, m16 ? 1 : 0, g_gemm_trace};
   a.res16 = r16 ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
+  void* ws = nullptr;
+  int64_t ws_bytes = 0;
+  styler_gemm_take_workspace(&ws, &ws_bytes);      // consumed by this call, whatever engine takes it
   if (prec == STYLER_PREC_BF16) {                  // large launches on bf16 activations: the 256 x 256 LDS-DMA engine (gemm256.hip)
-    const int r = styler_gemm256_try(a, x16, y16, st);
+    const int r = styler_gemm256_try(a, x16, y16, st, ws, ws_bytes);
     if (r) return r < 0 ? r : 0;
+    const int ks = styler_gemm_small_ksplit(B, L, cin, n, kw, act, mask != nullptr);
+    if (ks > 1 && ws && ws_bytes >= (int64_t)ks * B * L * n * 4 && !((uintptr_t)ws & 15) && (!len || (rowinfo && B == 1))) {
+      a.ksplit = ks; a.part = reinterpret_cast<float*>(ws);
+      const int rc = launch_gemm<1, 1, true>(a, st, x16, 0);
+      if (rc) return rc;
+      return styler_gemm_combine(a, ks, y16, st);
+    }
   }
   const bool big = styler_conv_gemm_variant(B, L, cin, n, kw, prec) & 1;
   // narrow outputs (64 < n <= 96) over many rows: one 128 x 96 tile per row block (see the kernel's WM note)

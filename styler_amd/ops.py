@@ -367,14 +367,29 @@ def unpack_rows(xp, plan):
     return out
 
 
+# bf16x3 mode, inside a training step (training.forward_backward sets a dict): the split of a tensor is kept until the step
+# ends, so the activation a GEMM split in the forward is not split again for that layer's weight gradient in backward (a
+# third of the step's split passes).  An entry holds the source tensor too: its memory cannot be handed to another tensor
+# while the entry lives, so (address, shape, strides, version) identifies the VALUES that were split.
+x3_cache = None
+
+
 def split3(x, plan=None):
     """[.., C] fp32 -> [.., 3C] bf16 rows [hi | hi | lo] (styler_split3_bf16): the activation operand of a bf16x3 GEMM.  With
     `plan` (packed rows) only the valid prefix is written."""
+    cache = x3_cache
+    if cache is not None:
+        key = (x.data_ptr(), tuple(x.shape), x.stride(), plan is not None)
+        hit = cache.get(key)
+        if hit is not None and hit[1] == x._version:
+            return hit[2]
     C = x.shape[-1]
     rows = x.numel() // C
     y = torch.empty(*x.shape[:-1], 3 * C, device=x.device, dtype=torch.bfloat16)
     _chk(lib.styler_split3_bf16(_f32(x).data_ptr(), _ld(x), y.data_ptr(), rows, C,
                                 plan.counts.data_ptr() if plan is not None else None, _stream()), "styler_split3_bf16")
+    if cache is not None:
+        cache[key] = (x, x._version, y)
     return y
 
 
@@ -422,7 +437,7 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     ws = None
-    if prec == PREC_BF16 and (io & 1):               # split-K launches of the 256 x 256 engine want scratch for their partial tiles
+    if prec == PREC_BF16 and ((io & 1) or kw >= 3):  # split-K launches (256 x 256 engine / small-M 64 x 64 tile) want scratch for their partial tiles
         need = lib.styler_conv_gemm_workspace_bytes(B, L, cin, n, kw, act, prec, io, _ld(x), int(plan is not None),
                                                     int(mask is not None))
         if need and lens is None:
@@ -559,6 +574,12 @@ def gemm256_config(enabled=-1, min_tiles=-1, split=-1, take_all=-1):
     return prev & 1, prev >> 1, pol & 3, pol >> 2
 
 
+def gemm_small_split_config(enabled=-1):
+    """Test / tuning hook of the 64 x 64 tile's split-K (small-M, long-K conv GEMMs in bf16 mode): on / off (-1 keeps).
+    Returns the previous value."""
+    return lib.styler_gemm_small_split_config(int(enabled))
+
+
 def gemm_n96_config(enabled=-1, min_rows=-1):
     """Test / tuning hook of the narrow-output GEMM tile (128 x 96, bf16 mode, 64 < n <= 96): on / off and the smallest row
     count it takes (-1 keeps a value).  Returns the previous (enabled, min_rows)."""
@@ -574,6 +595,10 @@ def _prec(prec):
     return prec
 
 
+# bf16x3 mode: attention on three-product bf16 MFMAs (attention_*_x3_kernel); STYLER_ATTN_X3=0: the exact-fp32 MFMA kernels
+rt_attn_x3 = os.environ.get("STYLER_ATTN_X3", "1") != "0"
+
+
 def attention_fwd(qkv, lens, lse=None, prec=None, plan=None, out_bf16=False):
     """qkv [B, L, 768] (or, with `plan`, the packed [1, B*T, 768]); lse (optional) [B, 4, L] (packed: [B, 4, T]).
     out_bf16 (throughput mode): the output is stored as bf16."""
@@ -585,7 +610,9 @@ def attention_fwd(qkv, lens, lse=None, prec=None, plan=None, out_bf16=False):
         io = (1 if qkv.dtype == torch.bfloat16 else 0) | (2 if out_bf16 else 0)
         fn = lambda *a: lib.styler_attention_fwd_bf16_io(*a[:-1], io, a[-1])
     else:
-        fn = lib.styler_attention_fwd_bf16 if _prec(prec) == PREC_BF16 else lib.styler_attention_fwd
+        fn = {PREC_BF16: lib.styler_attention_fwd_bf16, PREC_BF16X3: lib.styler_attention_fwd_x3}.get(_prec(prec), lib.styler_attention_fwd)
+        if not rt_attn_x3 and _prec(prec) == PREC_BF16X3:
+            fn = lib.styler_attention_fwd
     if plan is not None:
         _chk(fn(qkv.data_ptr(), out.data_ptr(), _ptr(lse), plan.B, plan.T, plan.lens.data_ptr(), plan.cu.data_ptr(),
                 _stream()), "styler_attention_fwd")
@@ -927,8 +954,19 @@ def split3_parts(t3, C):
     return t3[..., 0:C], t3[..., 2 * C:3 * C]
 
 
+IO_X_LO, IO_DZ_LO, IO_X3CAT = 32, 64, 128      # STYLER_IO_X_LO / STYLER_IO_DZ_LO / STYLER_IO_X3CAT
+# bf16x3 weight gradients on bf16-resident splits as one launch over the three parts (STYLER_WGRAD_X3CAT=0: three launches)
+x3cat = os.environ.get("STYLER_WGRAD_X3CAT", "1") != "0"
+
+
+def _is_split3(hi, lo, C):
+    """(hi, lo) are the views split3_parts makes of ONE [.., 3C] split tensor."""
+    return (hi.dtype == torch.bfloat16 and lo.dtype == torch.bfloat16 and hi.shape == lo.shape and hi.stride() == lo.stride()
+            and hi.stride(-1) == 1 and hi.stride(-2) >= 3 * C and lo.data_ptr() - hi.data_ptr() == 4 * C)
+
+
 def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=None, db2=None, plan=None, dz_parts=None,
-          x_parts=None, x_exact=False):
+          x_parts=None, x_exact=False, parts=0):
     """dw (fp32, parameter layout [n, cin] or [n, cin, kw]) += dz^T x over all taps; db (and db2) += colsum(dz)."""
     B, L = dz.shape[0], dz.shape[1]
     if strides is None:
@@ -953,19 +991,24 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
                 # parts of dz: colsum(dz_hi) from the first call, colsum(dz_lo) from the third.
                 dzh, dzl = dz_parts if dz_parts is not None else split3_parts(split3(dz, plan), n)
                 xh, xl = x_parts if x_parts is not None else split3_parts(split3(x, plan), cin)
+                if (x3cat and db2 is None and lib.styler_wgrad_x3cat_ok(n, cin, kw, pad_left) and _is_split3(dzh, dzl, n)
+                        and _is_split3(xh, xl, cin)):
+                    # ONE launch over the three parts (STYLER_IO_X3CAT): a third of the partial tiles and of the launches
+                    wgrad(dzh, xh, dw, n, cin, db=db, parts=IO_X3CAT, **kwargs)
+                    return
                 wgrad(dzh, xh, dw, n, cin, db=db, db2=db2, **kwargs)
                 wgrad(dzh, xl, dw, n, cin, **kwargs)
                 wgrad(dzl, xh, dw, n, cin, db=db, db2=db2, **kwargs)
                 return
-            # any other shape: fp32-typed operands (the kernels round an fp32 operand to bf16 while staging = its high part;
-            # the low parts are materialised as fp32 holding bf16-representable values).  The bias sums come from the first
-            # call, which adds the fp32 values of dz before rounding them.
+            # any other shape: fp32-typed operands (the kernels round an fp32 operand to bf16 while staging = its high part,
+            # or, with STYLER_IO_X_LO / STYLER_IO_DZ_LO, stage its low part).  The bias sums come from the first call, which
+            # adds the fp32 values of dz before rounding them.
             if dz.dtype != torch.float32 or x.dtype != torch.float32:
                 raise StylerHipError("bf16x3 weight gradient: fp32 operands expected")
             wgrad(dz, x, dw, n, cin, db=db, db2=db2, **kwargs)
             if not x_exact:                           # (a one-hot x is exact in bf16: its low part is zero)
-                wgrad(dz, lo_part(x, plan), dw, n, cin, **kwargs)
-            wgrad(lo_part(dz, plan), x, dw, n, cin, **kwargs)
+                wgrad(dz, x, dw, n, cin, parts=IO_X_LO, **kwargs)
+            wgrad(dz, x, dw, n, cin, parts=IO_DZ_LO, **kwargs)
             return
     prof = gemm_profiler
     if prof is not None:
@@ -973,6 +1016,8 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
         e0.record()
     arena = wgrad_arena
     io = (2 if dz.dtype == torch.bfloat16 else 0) | (1 if x.dtype == torch.bfloat16 else 0)    # bf16-resident operands
+    if parts:
+        assert prec == PREC_BF16 and io == (3 if parts == IO_X3CAT else 0), "low-part flags: fp32-typed operands; x3cat: bf16 splits"
     if (arena is not None and arena.buf is not None and prec == PREC_BF16 and prof is None and (plan is None or db2 is None)
             and (arena.group_all or (kw == 1 and io in (0, 2, 3)))):
         # grouped path (default: the small Linear gradients, variant 0; STYLER_WGRAD_GROUP_ALL=1: every bf16 gradient):
@@ -982,14 +1027,14 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
         d = WgradGroupDesc()
         args = (dz.data_ptr(), _ld(dz), x.data_ptr(), _ld(x), _ptr(db), _ptr(db2), B, L, n, cin, kw, pad_left, prec)
         packed = (plan.counts.data_ptr(), plan.chunktab.data_ptr()) if plan is not None else (None, None)
-        nb = lib.styler_wgrad_group_desc(ctypes.byref(d), *args, None, *packed, io, 0)
+        nb = lib.styler_wgrad_group_desc(ctypes.byref(d), *args, None, *packed, io | parts, 0)
         if nb < 0:
             _chk(nb, "styler_wgrad_group_desc")
         small = ((n + 63) // 64) * ((cin + 63) // 64) < 48
         if nb > 0 and (arena.group_all or d.variant == 0 or (d.variant in (1, 7, 8) and small)):
             want = arena.want_splits(d.variant) if arena.group_all else (LIN128_SPLITS if d.variant in (1, 7, 8) else 0)
             if want:
-                nb = lib.styler_wgrad_group_desc(ctypes.byref(d), *args, None, *packed, io, want)
+                nb = lib.styler_wgrad_group_desc(ctypes.byref(d), *args, None, *packed, io | parts, want)
             ws = arena.take(d.splits * n * kw * cin, dz.device)
             if ws is not None:
                 d.ws = ws.data_ptr()
@@ -998,14 +1043,14 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
                 arena.group_keep.append((dz, x, plan))
                 return
             arena.total -= (d.splits * n * kw * cin + 3) & ~3      # did not fit: the stand-alone request below is counted
-    nfloats = int(lib.styler_wgrad_workspace_bytes_io(B, L, n, cin, kw, pad_left, prec, io)) // 4
+    nfloats = int(lib.styler_wgrad_workspace_bytes_io(B, L, n, cin, kw, pad_left, prec, io | parts)) // 4
     ws, defer = None, 0
     if arena is not None:
         ws = arena.take(nfloats, dz.device)
         if ws is not None:
             defer = 1
             arena.descs.append((ws.data_ptr(), dw.data_ptr(), strides[0], strides[1], strides[2], n, cin, kw,
-                                int(lib.styler_wgrad_splits_io(B, L, n, cin, kw, pad_left, prec, io))))
+                                int(lib.styler_wgrad_splits_io(B, L, n, cin, kw, pad_left, prec, io | parts))))
     if ws is None:
         ws = torch.empty(nfloats, device=dz.device, dtype=torch.float32)
     grouped = False
@@ -1016,9 +1061,9 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
         arena.side_keep.append((dz, x, plan))
     if side is not None:
         with torch.cuda.stream(side):
-            _wgrad_launch(dz, x, dw, db, db2, strides, B, L, n, cin, kw, pad_left, prec, ws, defer, io, plan)
+            _wgrad_launch(dz, x, dw, db, db2, strides, B, L, n, cin, kw, pad_left, prec, ws, defer, io | parts, plan)
     elif not grouped:
-        _wgrad_launch(dz, x, dw, db, db2, strides, B, L, n, cin, kw, pad_left, prec, ws, defer, io, plan)
+        _wgrad_launch(dz, x, dw, db, db2, strides, B, L, n, cin, kw, pad_left, prec, ws, defer, io | parts, plan)
     if prof is not None:
         e1.record()
         prof.records.append(("wgrad_bf16" if prec == PREC_BF16 else "wgrad", 2.0 * B * L * n * kw * cin, e0, e1,
@@ -1062,8 +1107,9 @@ def attention_bwd(qkv, out, dout, lse, lens, prec=None, plan=None, out_bf16=Fals
                                            (4 if out.dtype == torch.bfloat16 else 0) | (8 if dout.dtype == torch.bfloat16 else 0),
                                            _stream()), "styler_attention_bwd_bf16")
     else:
-        _chk(lib.styler_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
-                                      ws.data_ptr(), B, L, _ptr(lens), cu, _stream()), "styler_attention_bwd")
+        fn = lib.styler_attention_bwd_x3 if (_prec(prec) == PREC_BF16X3 and rt_attn_x3) else lib.styler_attention_bwd
+        _chk(fn(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                ws.data_ptr(), B, L, _ptr(lens), cu, _stream()), "styler_attention_bwd")
     return dqkv
 
 

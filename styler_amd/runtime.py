@@ -98,6 +98,10 @@ class _Runtime:
     # projections of a layer are always grouped).  STYLER_GROUPED_MLPS=0: one launch per Linear.
     grouped_mlps = os.environ.get("STYLER_GROUPED_MLPS", "1") != "0"
 
+    # round 4, bf16x3 arithmetic: the [hi | hi | lo] split of a GEMM's activation operand is kept from the forward to that
+    # layer's weight gradient (ops.x3_cache; STYLER_X3_CACHE=0: split again in backward)
+    x3_cache = os.environ.get("STYLER_X3_CACHE", "1") != "0"
+
     # each StylePredictor stage (conv -> ReLU -> LayerNorm -> dropout [-> Linear -> mask]) as one tape node whose backward
     # is one LayerNorm-backward kernel + weight gradient + dX GEMM (STYLER_FUSED_PREDICTOR=0: separate nodes)
     fused_predictor = os.environ.get("STYLER_FUSED_PREDICTOR", "1") != "0"

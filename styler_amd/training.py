@@ -258,6 +258,7 @@ def forward_backward(model, state, batch, loss_fn=None, dat_fn=None):
     state.drop_epoch.add_(1)
     state.zero_slab.begin(state.flat_g.device)         # the norm kernels' statistics workspaces: one clear per step
     ops.zero_slab = state.zero_slab
+    ops.x3_cache = {} if (rt.prec == ops.PREC_BF16X3 and rt.x3_cache) else None   # (bf16x3: splits live until the step ends)
     try:
         losses = train_losses(model, batch, loss_fn, dat_fn)
         # The decoder-side all-reduce may only start from the LAST micro-batch of an accumulation window: an earlier one
@@ -275,6 +276,7 @@ def forward_backward(model, state, batch, loss_fn=None, dat_fn=None):
         rt.grad_ready_hook = None
         ops.wgrad_arena = None
         ops.zero_slab = None
+        ops.x3_cache = None
     return losses
 
 

@@ -204,6 +204,52 @@ def test_gemm_narrow_output_tile_vs_math_and_vs_64_tile(dev, case):
     assert torch.equal(ys[1], ys[0]) and torch.equal(ys[2], ys[0]), f"{case}: repeated launches differ"
     assert torch.equal(ys[0], y64), f"{case}: 128x96 tile != 64x64 tile, max diff {float((ys[0].float() - y64.float()).abs().max()):.3e}"
 
+SMALL_SPLIT_CASES = {
+    # name: (B, L, cin, n, kw, x_bf16, y_bf16, with_res)
+    "text_encoder_ffn_dx_k9": (48, 60, 1024, 256, 9, True, False, True),
+    "one_chunk_per_split_k5_bf16_out": (3, 50, 640, 68, 5, True, True, False),
+    "uneven_chunks_k3_fp32_x": (2, 77, 1088, 128, 3, False, False, True),
+}
+
+
+@pytest.mark.parametrize("case", sorted(SMALL_SPLIT_CASES))
+def test_gemm_small_split_k_vs_math_and_vs_unsplit(dev, case):
+    """Split-K of the 64 x 64 tile (few rows, long contraction axis: the dX of the text encoder's FFN convolution,
+    SubLayers.py:72-76 at M = B * S rows): against fp64 math on the bf16-rounded operands and against the unsplit launch
+    (same products, different fp32 summation order: 1e-5 of the largest output); repeated launches bit-equal (fixed-order
+    combine)."""
+    from styler_amd import ops
+    from styler_amd._lib import lib
+    B, L, cin, n, kw, x_bf16, y16, with_res = SMALL_SPLIT_CASES[case]
+    g = torch.Generator().manual_seed(sum(map(ord, case)))
+    x16 = torch.randn(B, L, cin, generator=g).to(torch.bfloat16)
+    w16 = (torch.randn(n, cin, kw, generator=g) / np.sqrt(cin * kw)).to(torch.bfloat16)
+    b = torch.randn(n, generator=g)
+    res = torch.randn(B, L, n, generator=g) if with_res else None
+    ref = _conv_ref64(x16.float(), w16.float(), kw) + b.double()
+    if res is not None:
+        ref = ref + res.double()
+    wk = w16.permute(0, 2, 1).reshape(n, -1).contiguous().to(dev)
+    xd = (x16 if x_bf16 else x16.float()).to(dev)
+    args = dict(kw=kw, prec=ops.PREC_BF16, res=res.to(dev) if with_res else None, out_bf16=y16)
+    io = (1 if x_bf16 else 0) | (2 if y16 else 0)
+    prev = ops.gemm_small_split_config(1)
+    try:
+        need = lib.styler_conv_gemm_workspace_bytes(B, L, cin, n, kw, 0, ops.PREC_BF16, io, cin, 0, 0)
+        assert need > 0, f"{case}: the launch was expected to split"
+        ys = [ops.conv_gemm(xd, wk, b.to(dev), **args).clone() for _ in range(3)]
+        ops.gemm_small_split_config(0)
+        assert lib.styler_conv_gemm_workspace_bytes(B, L, cin, n, kw, 0, ops.PREC_BF16, io, cin, 0, 0) == 0
+        y1 = ops.conv_gemm(xd, wk, b.to(dev), **args)
+    finally:
+        ops.gemm_small_split_config(prev)
+    scale = float(ref.abs().max())
+    e = float((ys[0].double().cpu() - ref).abs().max()) / scale
+    assert e <= (1e-2 if y16 else 1e-4), f"{case}: max err / max|ref| = {e:.3e}"
+    assert torch.equal(ys[1], ys[0]) and torch.equal(ys[2], ys[0]), f"{case}: repeated launches differ"
+    d = float((ys[0].double() - y1.double()).abs().max()) / scale
+    assert d <= (8e-3 if y16 else 1e-5), f"{case}: split vs unsplit differ by {d:.3e} of the largest output"
+
 
 def test_gemm256_engine_packed_rows(dev):
     """The engine on the decoder's packed-rows layout (ops.PackPlan): taps stop at item boundaries (rowinfo), tiles behind
@@ -314,6 +360,10 @@ def test_attention(dev, B, L, lens):
     vq = (torch.arange(L)[None, :] < ln[:, None])
     check(out16 * vq[..., None].to(dev), ref.float() * vq[..., None], 3e-2, "attention bf16")
     check(lse * vq[:, None, :].to(dev), torch.logsumexp(s, -1).float() * vq[:, None, :], 3e-2, "lse bf16")
+    # bf16x3 arithmetic (three-product bf16 MFMAs on hi + lo operands): fp32-class, same don't-care rows as the bf16 kernel
+    out3 = ops.attention_fwd(qkv.to(dev), ln.to(dev), lse=lse, prec=ops.PREC_BF16X3)
+    check(out3 * vq[..., None].to(dev), ref.float() * vq[..., None], 1e-4, "attention bf16x3")
+    check(lse * vq[:, None, :].to(dev), torch.logsumexp(s, -1).float() * vq[:, None, :], 1e-4, "lse bf16x3")
 
 
 def test_add_layernorm(dev):

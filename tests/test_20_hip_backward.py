@@ -96,6 +96,31 @@ def test_wgrad_bf16(dev, B, L, cin, n, kw, pad):
                   strides=(cin_eff * kw, kw, 1), prec=prec)
         check(dw, ref, tol, f"dw prec={prec}")
         check(db, dz.sum((0, 1)), 1e-4, "db")
+    # bf16x3 arithmetic on fp32-typed operands: three calls of the bf16 engine, the low parts staged by the kernel itself
+    # (STYLER_IO_X_LO / STYLER_IO_DZ_LO) -- fp32-class, and bit-equal to the same calls on materialised low parts
+    dzd, xd = dz.float().to(dev), x.float().to(dev)
+    kw_args = dict(kw=kw, pad_left=pad, strides=(cin_eff * kw, kw, 1), prec=ops.PREC_BF16)
+    dw3 = torch.zeros(n, cin_eff, kw, device=dev)
+    db3 = torch.zeros(n, device=dev)
+    ops.wgrad(dzd, xd, dw3, n, cin_eff, kw=kw, db=db3, pad_left=pad, strides=(cin_eff * kw, kw, 1), prec=ops.PREC_BF16X3)
+    check(dw3, ref, 1e-4 * max(1.0, float(ref.abs().max())), "dw prec=bf16x3")
+    check(db3, dz.sum((0, 1)), 1e-4, "db bf16x3")
+    # (shapes with an LDS-DMA kernel run the three parts as ONE launch, STYLER_IO_X3CAT: against three launches)
+    prev_cat, ops.x3cat = ops.x3cat, False
+    try:
+        dw3b, db3b = torch.zeros(n, cin_eff, kw, device=dev), torch.zeros(n, device=dev)
+        ops.wgrad(dzd, xd, dw3b, n, cin_eff, kw=kw, db=db3b, pad_left=pad, strides=(cin_eff * kw, kw, 1), prec=ops.PREC_BF16X3)
+    finally:
+        ops.x3cat = prev_cat
+    check(dw3, dw3b, 2e-6 * max(1.0, float(ref.abs().max())), "dw bf16x3: one launch vs three")
+    check(db3, db3b, 1e-5 * max(1.0, float(dz.sum((0, 1)).abs().max())), "db bf16x3: one launch vs three")
+    if n % 4 == 0:
+        a, b_ = torch.zeros_like(dw3), torch.zeros_like(dw3)
+        ops.wgrad(dzd, xd, a, n, cin_eff, parts=ops.IO_X_LO, **kw_args)
+        ops.wgrad(dzd, xd, a, n, cin_eff, parts=ops.IO_DZ_LO, **kw_args)
+        ops.wgrad(dzd, ops.lo_part(xd), b_, n, cin_eff, **kw_args)
+        ops.wgrad(ops.lo_part(dzd), xd, b_, n, cin_eff, **kw_args)
+        assert torch.equal(a, b_), f"low-part flags differ from materialised low parts by {float((a - b_).abs().max()):.3e}"
 
 
 @pytest.mark.parametrize("B,L,lens", [(2, 24, [24, 17]), (2, 150, [150, 77]), (1, 200, [131])])
@@ -119,6 +144,13 @@ def test_attention_backward(dev, B, L, lens):
     od16 = ops.attention_fwd(qd, ln.to(dev), lse=lse, prec=ops.PREC_BF16)
     dq16 = ops.attention_bwd(qd, od16, gy.float().to(dev), lse, ln.to(dev), prec=ops.PREC_BF16)
     check(dq16, qkv.grad, 3e-2, "dqkv bf16")
+    # bf16x3 arithmetic: fp32-class (rows past an item's length are don't-care, as in the bf16 kernels)
+    od3 = ops.attention_fwd(qd, ln.to(dev), lse=lse, prec=ops.PREC_BF16X3)
+    dq3 = ops.attention_bwd(qd, od3, gy.float().to(dev), lse, ln.to(dev), prec=ops.PREC_BF16X3)
+    vrow = (torch.arange(L)[None, :, None] < ln[:, None, None])
+    check(dq3 * vrow.to(dev), qkv.grad * vrow, 2e-4, "dqkv bf16x3")
+    lse = torch.empty(B, 4, L, device=dev)
+    od16 = ops.attention_fwd(qd, ln.to(dev), lse=lse, prec=ops.PREC_BF16)
     # bf16 storage of dqkv: the fp32 result rounded (valid rows; rows past an item's length are don't-care in both)
     dq16s = ops.attention_bwd(qd, od16, gy.float().to(dev), lse, ln.to(dev), prec=ops.PREC_BF16, out_bf16=True)
     assert dq16s.dtype == torch.bfloat16
