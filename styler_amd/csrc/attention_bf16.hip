@@ -204,7 +204,14 @@ __device__ __forceinline__ bool attn_block(int L, int B, int& bx, int& head, int
 static inline dim3 attn_grid(int L, int B) { return dim3((unsigned)((((L + 127) / 128) * 4 * B + 7) / 8 * 8)); }
 
 // ------------------------------------------------------------------------------------------------- forward
-template <bool Q16>
+// LAZY (round 4).  PMC on the config-4 launch (profiles/r04_attn_c4_pmc.txt): 13.2 VALU instructions per MFMA, the VALU pipe busy
+// 64 % and the matrix pipe 33 % of the time, and the two add up to the kernel's duration -- at d_k = 64 a 64-key tile is 16
+// MFMAs (512 cycles) against 34 quarter-rate v_exp_f32 and ~160 other vector instructions that compete with the MFMAs for
+// the SIMD's issue slots.  LAZY trims the part of that which is not needed on every tile: the running maximum is only
+// moved when a tile's maximum exceeds it by more than 8 in the log2 domain (p <= 256: exact in fp32, harmless in bf16; o and
+// l carry the same stale maximum, o / l does not change), so the rescaling of the 32 output accumulators leaves the common
+// path behind a wave-uniform branch.
+template <bool Q16, bool LAZY = false>
 __global__ __launch_bounds__(256, STYLER_ATTN_FWD_WAVES) void attention_fwd_bf16_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                  float* __restrict__ lse, int B, int L,
                                                                  const int64_t* __restrict__ len,
@@ -287,6 +294,31 @@ __global__ __launch_bounds__(256, STYLER_ATTN_FWD_WAVES) void attention_fwd_bf16
 #pragma unroll
       for (int r = 0; r < 16; ++r) mb = fmaxf(mb, s[r]);
       mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+      if constexpr (LAZY) {
+        constexpr float TH = 8.f / SC;                 // 8 in the log2 domain, in units of the stored scores
+        const bool move = mb > m_run + TH;             // (the first tile: m_run = -1e30 -> every lane moves)
+        if (__builtin_amdgcn_ballot_w64(move) != 0) {
+          const float m_new = move ? mb : m_run;
+          const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * SC);
+          m_run = m_new;
+          l_run *= alpha;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
+        const float mneg = -m_run * SC;
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], SC, mneg)); rs += s[r]; }
+        rs += __shfl_xor(rs, 32, 64);
+        l_run += rs;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pb = pack_acc(s, s2);
+          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sV, 0, tq, tc, kb, s2, lh), pb, o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sV, 1, tq, tc, kb, s2, lh), pb, o1, 0, 0, 0);
+        }
+        continue;
+      }
       const float m_new = fmaxf(m_run, mb);
       const float alpha = __builtin_amdgcn_exp2f(Q16 ? (m_run - m_new) * SC : m_run - m_new);
       float rs = 0.f;
@@ -946,10 +978,12 @@ extern "C" int styler_attention_fwd_bf16_io(const void* qkv, void* out, float* l
   const float* q = reinterpret_cast<const float*>(qkv);
   float* o = reinterpret_cast<float*>(out);
   const int out16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
-  if (io_flags & STYLER_IO_X_BF16)
-    hipLaunchKernelGGL(attention_fwd_bf16_kernel<true>, attn_grid(L, B), dim3(256), 0, (hipStream_t)stream, q, o, lse, B, L, len, cu, out16);
-  else
-    hipLaunchKernelGGL(attention_fwd_bf16_kernel<false>, attn_grid(L, B), dim3(256), 0, (hipStream_t)stream, q, o, lse, B, L, len, cu, out16);
+  // STYLER_ATTN_LAZY=0: the eager-rescaling form of the forward (see the kernel's LAZY note)
+  static const int lazy = [] { const char* e = getenv("STYLER_ATTN_LAZY"); return e ? atoi(e) : 1; }();
+#define FWD_LAUNCH(Q_, L_) hipLaunchKernelGGL((attention_fwd_bf16_kernel<Q_, L_>), attn_grid(L, B), dim3(256), 0, (hipStream_t)stream, q, o, lse, B, L, len, cu, out16)
+  if (io_flags & STYLER_IO_X_BF16) { if (lazy) FWD_LAUNCH(true, true); else FWD_LAUNCH(true, false); }
+  else { if (lazy) FWD_LAUNCH(false, true); else FWD_LAUNCH(false, false); }
+#undef FWD_LAUNCH
   return launch_status();
 }
 
