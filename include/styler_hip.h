@@ -59,6 +59,15 @@ extern "C" {
  * runs over the three parts (one set of split-K partial tiles instead of three); db += colsum(dz_hi) + colsum(dz_lo).
  * LDS-DMA kernels only: styler_wgrad_x3cat_ok(n, cin, kw, pad_left) says whether the shape has one. */
 #define STYLER_IO_X3CAT 128
+/* the same entry points with a deferred reduce (defer_reduce = 1 / grouped members): `db` is not the bias gradient but a
+ * [splits][n] fp32 slot array (splits = styler_wgrad_splits_io of the call) into which split s STORES its column sums of dz;
+ * the caller folds the slots into the bias gradient(s) in split order with styler_wgrad_reduce_multi (a descriptor with
+ * cin = kw = 1).  No atomics: the bias gradients of nn.Linear / nn.Conv1d are bit-reproducible.  db2 must be NULL. */
+#define STYLER_IO_DB_SLOTS 256
+/* styler_groupnorm_relu_bwd / styler_aug_classifier_tail_bwd_io: the parameter-gradient pointers are SLOT arrays that the
+ * launch stores its per-block sums into (GroupNorm: [B][C] for gamma and for beta, single-pass kernel only); the caller folds
+ * them in slot order with styler_wgrad_reduce_multi.  No fp32 atomics: the gradients are bit-reproducible. */
+#define STYLER_IO_PARAM_SLOTS 512
 /* styler_add_layernorm io_flags (round 3: the decoder's residual stream is stored as bf16 in throughput mode) */
 #define STYLER_LN_RES_BF16 1  /* res is bf16 */
 #define STYLER_LN_Y_BF16 2    /* y is written as bf16 (ldy in elements) */
@@ -628,6 +637,7 @@ int styler_attention_bwd(const float* qkv, const float* out, const float* dout, 
 #define STYLER_LNB_DY_BF16 4    /* dy is bf16 */
 #define STYLER_LNB_DX_BF16 8    /* dx is written as bf16 */
 #define STYLER_LNB_DXD_BF16 16  /* dx_drop is written as bf16 */
+#define STYLER_LNB_DOTB_SLOTS 64 /* with replicas >= the launch's blocks: ddot_b is a [replicas] slot array (stored, not added) */
 int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy,
                          const float* gamma, const float* beta, float* dx, int64_t lddx,
                          float* dgamma, float* dbeta, const float* dot_w, const float* dout,
@@ -658,6 +668,10 @@ int styler_batchnorm_bwd(const float* x, const float* y, const void* dy, const f
 
 int styler_embed_bwd(const int64_t* text, const float* dy, int64_t lddy, float* demb, int B, int L,
                      int C, void* stream);
+/* The same without atomics: one block per table row (V rows, row 0 = padding_idx) adds the dy rows of its tokens in token
+ * order -- bit-reproducible (nn.Embedding backward, Models.py:52-53). */
+int styler_embed_bwd_det(const int64_t* text, const float* dy, int64_t lddy, float* demb, int B, int L, int C, int V,
+                         void* stream);
 /* Backward of styler_onehot_conv5: materialise the one-hot rows [rows, 260] (257 zero-padded)
  * so that the weight gradient becomes styler_wgrad(dy, onehot, dw [C,257,5], db, strides
  * (257*5, 5, 1), n = C, cin = 257, kw = 5) on the MFMA engine. */
@@ -686,10 +700,20 @@ int styler_aug_classifier_tail_bwd(const float* h, const float* ln_g, const floa
                                    const float* w2, const float* b2, const float* dout, float* dh,
                                    float* dln_g, float* dln_b, float* dw2, float* db2, int B, int S,
                                    void* stream);
+/* ... with the four parameter gradients as slot arrays (io_flags & STYLER_IO_PARAM_SLOTS): [slots][256], [slots][256],
+ * [slots][512], [slots][2], slots = styler_aug_classifier_tail_slots(B, S) (modules.py:38-45 autograd). */
+int styler_aug_classifier_tail_slots(int B, int S);
+int styler_aug_classifier_tail_bwd_io(const float* h, const float* ln_g, const float* ln_b, const float* w2, const float* b2,
+                                      const float* dout, float* dh, float* dln_g, float* dln_b, float* dw2, float* db2, int B,
+                                      int S, int io_flags, void* stream);
 int styler_length_regulate_bwd(const float* dy, int64_t lddy, const int32_t* csum, float* dx,
                                int64_t lddx, int B, int S, int T, int C, void* stream);
 int styler_bucket_embed_bwd(const float* dy, const int32_t* p_ids, const int32_t* e_ids,
                             float* dpitch_emb, float* denergy_emb, int B, int T, void* stream);
+/* ... into slot arrays [styler_bucket_embed_slices()][256 * 256] per table (stored; folded by styler_wgrad_reduce_multi). */
+int styler_bucket_embed_slices(void);
+int styler_bucket_embed_bwd_slots(const float* dy, const int32_t* p_ids, const int32_t* e_ids, float* dpitch_slots,
+                                  float* denergy_slots, int B, int T, void* stream);
 /* out[b,:] (+)= sum_t x[b,t,:] */
 int styler_rowsum(const float* x, int64_t ldx, float* out, int64_t ldo, int B, int L, int C,
                   int accumulate, void* stream);

@@ -95,13 +95,18 @@ _SIGS = {
     "styler_groupnorm_relu_bwd": [P, I64, P, I64, P, P, P, P, I64, P, P, P, I, I, I, I, I, P],
     "styler_batchnorm_bwd": [P, P, P, P, P, P, P, P, P, P, I, I64, I, I, P, F, ctypes.c_uint64, I, I, P],
     "styler_embed_bwd": [P, P, I64, P, I, I, I, P],
+    "styler_embed_bwd_det": [P, P, I64, P, I, I, I, I, P],
     "styler_onehot_expand": [P, P, I64, P],
     "styler_mel_calibrate_bwd": [P, I64, P, I64, P, P, I, I, I, I, P],
     "styler_mel_calibrate_bwd_io": [P, I64, P, I64, P, P, I, I, I, I, I, P],
     "styler_lstm_bidir_bwd": [P, P, P, P, P, I, I, I, P],
     "styler_aug_classifier_tail_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, P],
+    "styler_aug_classifier_tail_bwd_io": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "styler_aug_classifier_tail_slots": [I, I],
     "styler_length_regulate_bwd": [P, I64, P, P, I64, I, I, I, I, P],
     "styler_bucket_embed_bwd": [P, P, P, P, P, I, I, P],
+    "styler_bucket_embed_bwd_slots": [P, P, P, P, P, I, I, P],
+    "styler_bucket_embed_slices": [],
     "styler_rowsum": [P, I64, P, I64, I, I, I, I, P],
     "styler_masked_err_bwd": [P, I64, P, I64, P, P, P, I, I, I, I, P, P],
     "styler_nll": [P, P, P, P, P, I, P],

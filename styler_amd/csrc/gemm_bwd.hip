@@ -123,9 +123,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dz
                                                     const float* __restrict__ x, int64_t ldx, float* __restrict__ dw,
                                                     float* __restrict__ db, float* __restrict__ db2, int64_t sn,
                                                     int64_t sc, int64_t sj, int B,
-                                                    int L, int n, int cin, int pad_left, int ct, int chunks_per_split,
+                                                    int L, int n, int cin, int pad_bits, int ct, int chunks_per_split,
                                                     float* __restrict__ ws, const int2* __restrict__ rowinfo,
                                                     const int64_t* __restrict__ counts) {
+  // pad_bits = (pad_left & 0xff) | (0x800: db is a [splits][n] slot array -- STYLER_IO_DB_SLOTS -- that this launch STORES its
+  // per-split column sums into; the caller's multi-tensor reduce folds them in split order: no atomics, fixed order)
+  const int pad_left = (int)(int8_t)(pad_bits & 0xff);
+  const bool db_slots = pad_bits & 0x800;
   constexpr int XR = WG_BK + KW - 1;                 // x rows per chunk (with halo)
   __shared__ __attribute__((aligned(16))) float sA[2][WG_BK * WG_LD];
   __shared__ __attribute__((aligned(16))) float sB[2][XR * WG_LD];
@@ -242,8 +246,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dz
       }
   }
   if (do_bias && n0 + tid < n) {
-    atomicAdd(db + n0 + tid, bsum);
-    if (db2) atomicAdd(db2 + n0 + tid, bsum);
+    if (db_slots) db[(int64_t)blockIdx.y * n + n0 + tid] = bsum;
+    else {
+      atomicAdd(db + n0 + tid, bsum);
+      if (db2) atomicAdd(db2 + n0 + tid, bsum);
+    }
   }
 }
 
@@ -293,6 +300,7 @@ __device__ __forceinline__ void wgrad_tr_body(const int bid, const void* __restr
                                               const int64_t* __restrict__ counts) {
   const int pad_left = (int)(int8_t)(pad_parts & 0xff);   // (-1: the shifted Linear of the LSTM's reverse direction)
   const bool x_lo = !X16 && (pad_parts & 0x100), dz_lo = !DZ16 && (pad_parts & 0x200);
+  const bool db_slots = pad_parts & 0x800;           // STYLER_IO_DB_SLOTS: db = [splits][n] slots, stored (see wgrad_kernel)
   constexpr int FA = 64 * TA, FB = 64 * TB;          // features per block tile
   constexpr int XR = KW == 1 ? 64 : 72;              // x rows per chunk incl. halo (KW - 1 <= 8)
   constexpr int NR = (8 + KW - 1 + 3) / 4;           // transpose reads per x window
@@ -530,8 +538,11 @@ __device__ __forceinline__ void wgrad_tr_body(const int bid, const void* __restr
       float t = 0.f;
 #pragma unroll
       for (int r = 0; r < RPA; ++r) t += sBias[r * FA + tid];
-      atomicAdd(db + n0 + tid, t);
-      if (db2) atomicAdd(db2 + n0 + tid, t);
+      if (db_slots) db[(int64_t)split * n + n0 + tid] = t;
+      else {
+        atomicAdd(db + n0 + tid, t);
+        if (db2) atomicAdd(db2 + n0 + tid, t);
+      }
     }
   }
 }
@@ -585,6 +596,7 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
   // and column block (0, 2, 1)[p] of x.  One set of partial tiles instead of three; the bias row sums skip part 1 (dz_hi twice).
   const int pad_left = (int)(int8_t)(pad_cat & 0xff);
   const bool x3cat = pad_cat & 0x400;
+  const bool db_slots = pad_cat & 0x800;             // STYLER_IO_DB_SLOTS: db = [splits][n] slots, stored (see wgrad_kernel)
   constexpr int FA = 64 * TA, FB = 64 * TB;
   constexpr int XR = KW == 1 ? 64 : 72;
   constexpr int NR = (8 + KW - 1 + 3) / 4;
@@ -895,8 +907,11 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
       for (int r = 0; r < 16; ++r) {
         const int nn = n0 + (wm * TA + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (nn < n) {
-          atomicAdd(db + nn, accb[i][r]);
-          if (db2) atomicAdd(db2 + nn, accb[i][r]);
+          if (db_slots) db[(int64_t)split * n + nn] = accb[i][r];
+          else {
+            atomicAdd(db + nn, accb[i][r]);
+            if (db2) atomicAdd(db2 + nn, accb[i][r]);
+          }
         }
       }
   }
@@ -950,7 +965,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_group_lin128_kernel(const Style
   const int64_t* pcn = reinterpret_cast<const int64_t*>(d.counts);
   const int lb = bid - d.block_start;
   const int64_t lddz = d.lddz, ldx = d.ldx;
-  const int B = d.B, L = d.L, n = d.n, cin = d.cin, pad_left = d.pad_left & 0x4ff, ct = d.ct, cpi = d.cpi, cps = d.cps, tiles = d.tiles,
+  const int B = d.B, L = d.L, n = d.n, cin = d.cin, pad_left = d.pad_left & 0xcff, ct = d.ct, cpi = d.cpi, cps = d.cps, tiles = d.tiles,
             splits = d.splits;
   wgrad_dma_body<1, 2, 2, 2, 1, 1>(lb, pdz, lddz, px, ldx, pdb, pdb2, B, L, n, cin, pad_left, ct, cpi, cps, tiles, splits, pws,
                                      pct, pcn);
@@ -1091,11 +1106,14 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
                  lddz >= 3 * (int64_t)n && ldx >= 3 * (int64_t)cin))
     return STYLER_EINVAL;
   wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, 0, kg, x3cat ? 3 : 1);
-  const int pad_cat = (pad_left & 0xff) | (x3cat ? 0x400 : 0);
+  const int pad_cat = (pad_left & 0xff) | (x3cat ? 0x400 : 0) | ((io_flags & STYLER_IO_DB_SLOTS) ? 0x800 : 0);
   float* ws = reinterpret_cast<float*>(workspace);
   const dim3 grid(nt * ct, (unsigned)splits);
   // low-part flags of the register-staged kernels (fp32-typed operands only; see wgrad_tr_body)
-  const int pad_k = (pad_left & 0xff) | ((io_flags & STYLER_IO_X_LO) && !x16 ? 0x100 : 0) | ((io_flags & STYLER_IO_DZ_LO) && !dz16 ? 0x200 : 0);
+  const bool db_slots = io_flags & STYLER_IO_DB_SLOTS;
+  if (db_slots && (!db || db2 || !defer_reduce)) return STYLER_EINVAL;
+  const int pad_k = (pad_left & 0xff) | ((io_flags & STYLER_IO_X_LO) && !x16 ? 0x100 : 0) | ((io_flags & STYLER_IO_DZ_LO) && !dz16 ? 0x200 : 0) |
+                    (db_slots ? 0x800 : 0);
   if (prec == STYLER_PREC_BF16) {
     const int tiles = nt * ct;
     const dim3 grid1((unsigned)(splits >= 8 ? (tiles * splits + 7) / 8 * 8 : tiles * splits));
@@ -1155,7 +1173,7 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
 #undef WT_LAUNCH
   } else {
 #define WG_LAUNCH(K) hipLaunchKernelGGL(wgrad_kernel<K>, grid, dim3(256), 0, st, dz, lddz, x, ldx, dw, db, db2, stride_n, \
-                                        stride_c, stride_j, B, L, n, cin, pad_left, ct, cps, ws, \
+                                        stride_c, stride_j, B, L, n, cin, pad_k, ct, cps, ws, \
                                         reinterpret_cast<const int2*>(rowinfo), counts)
     if (kw == 1) WG_LAUNCH(1); else if (kw == 3) WG_LAUNCH(3); else if (kw == 5) WG_LAUNCH(5); else WG_LAUNCH(9);
 #undef WG_LAUNCH
@@ -1239,7 +1257,8 @@ extern "C" int styler_wgrad_group_desc(StylerWgradGroupDesc* out, const float* d
   out->lddz = lddz; out->ldx = ldx;
   out->B = Be; out->L = Le; out->n = n; out->cin = cin; out->ct = ct; out->cpi = cpi;
   out->pad_left = (pad_left & 0xff) | ((io_flags & STYLER_IO_X_LO) && !x16 ? 0x100 : 0) | ((io_flags & STYLER_IO_DZ_LO) && !dz16 ? 0x200 : 0) |
-                  (x3cat ? 0x400 : 0);
+                  (x3cat ? 0x400 : 0) | ((io_flags & STYLER_IO_DB_SLOTS) ? 0x800 : 0);
+  if ((io_flags & STYLER_IO_DB_SLOTS) && (!db || db2)) return STYLER_EINVAL;
   out->cps = cps; out->tiles = tiles; out->splits = splits; out->block_start = 0;
   out->nblocks = splits >= 8 ? (tiles * splits + 7) / 8 * 8 : tiles * splits;
   out->variant = variant; out->kw = kw;
@@ -1297,13 +1316,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const StylerWgr
     // channels, all taps): it sums the splits as kw coalesced runs of 128 floats, transposes the [kw][128] tile in LDS and
     // read-modify-writes ONE contiguous run of 128 * kw floats of dw.  (Walked in workspace order, consecutive lanes hit dw
     // with a stride of kw floats: a 5-9x amplified read-modify-write of the whole 118 MB gradient.)
-    __shared__ float tile[9][129];
-    const int ct = (d.cin + 127) / 128;
+    // (round 4: a block takes up to RW = 512 channels of its n -- for cin <= 512 the whole [kw][cin] slab of a partial, ONE
+    // contiguous run per split, instead of kw runs of 512 bytes at a stride of cin floats)
+    constexpr int RW = 512;
+    __shared__ float tile[9][RW + 1];
+    const int ct = (d.cin + RW - 1) / RW;
     const int64_t t = bid - d.block_start;
-    const int nn = (int)(t / ct), c0 = (int)(t % ct) * 128;
-    const int cn = d.cin - c0 < 128 ? d.cin - c0 : 128;             // multiple of 4
-    const int q = threadIdx.x & 31, jj = threadIdx.x >> 5;          // 32 float4 columns x 8 taps per pass
-    for (int j = jj; j < d.kw; j += 8) {
+    const int nn = (int)(t / ct), c0 = (int)(t % ct) * RW;
+    const int cn = d.cin - c0 < RW ? d.cin - c0 : RW;               // multiple of 4
+    const int q = threadIdx.x & 127, jj = threadIdx.x >> 7;         // 128 float4 columns x 2 taps per pass
+    for (int j = jj; j < d.kw; j += 2) {
       if (q * 4 < cn) {
         const float* p = ws + ((int64_t)nn * d.kw + j) * d.cin + c0 + q * 4;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1328,6 +1350,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const StylerWgr
     for (int i = threadIdx.x; i < cn * d.kw; i += 256) {
       const int c = i / d.kw, j = i - c * d.kw;
       out[i] += tile[j][c];
+    }
+    return;
+  }
+  if (per & 3) {
+    // a vector whose length is not a multiple of 4 (slot folds of tiny parameter gradients: the classifier's two output
+    // biases, the predictor tail's scalar bias -- round 4): one thread per element, splits in order
+    const int64_t i = (bid - d.block_start) * 1024 + threadIdx.x;
+    for (int64_t e = i; e < per && e < i + 1024; e += 256) {
+      float t = 0.f;
+      for (int sp = 0; sp < d.splits; ++sp) t += ws[(int64_t)sp * per + e];
+      const int c = (int)(e % d.cin); const int j = (int)((e / d.cin) % d.kw); const int64_t nn = e / ((int64_t)d.cin * d.kw);
+      dw[nn * d.stride_n + c * d.stride_c + j * d.stride_j] += t;
     }
     return;
   }
@@ -1401,7 +1435,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const StylerWgr
 // blocks a descriptor of styler_wgrad_reduce_multi owns (the host lays block_start out with this)
 extern "C" int64_t styler_wgrad_reduce_blocks(int n, int cin, int kw, int64_t stride_c, int64_t stride_j) {
   if (n <= 0 || cin <= 0 || kw <= 0) return 0;
-  if (kw > 1 && stride_j == 1 && stride_c == kw && !(cin & 3)) return (int64_t)n * ((cin + 127) / 128);
+  if (kw > 1 && stride_j == 1 && stride_c == kw && !(cin & 3)) return (int64_t)n * ((cin + 511) / 512);
   return ((int64_t)n * cin * kw + 1023) / 1024;
 }
 

@@ -20,6 +20,47 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
   }
 }
 
+// The same without atomics (round 4): block v OWNS row v of the table -- it scans the token ids (a few thousand, L2 / scalar
+// cache), compacts the positions that hold v in token order, and adds their dy rows in that order: bit-reproducible.
+__global__ __launch_bounds__(256) void embed_bwd_det_kernel(const int64_t* __restrict__ text, const float* __restrict__ dy,
+                                                            int64_t lddy, float* __restrict__ demb, int rows, int C) {
+  __shared__ int hits[256];
+  __shared__ int wcount[4], nhit;
+  const int v = blockIdx.x + 1;                      // (row 0 = padding_idx: no gradient)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};               // channels threadIdx.x + 256 k, C <= 1024
+  for (int base = 0; base < rows; base += 256) {
+    const int r = base + threadIdx.x;
+    const bool hit = r < rows && text[r] == v;
+    const uint64_t m = __ballot(hit);
+    if (lane == 0) wcount[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += wcount[w];
+    if (hit) hits[off + __popcll(m & ((1ull << lane) - 1ull))] = r;
+    if (threadIdx.x == 0) nhit = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    __syncthreads();
+    const int n = nhit;
+    for (int i = 0; i < n; ++i) {
+      const float* row = dy + (int64_t)hits[i] * lddy;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int c = threadIdx.x + 256 * k; if (c < C) acc[k] += row[c]; }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int c = threadIdx.x + 256 * k; if (c < C) demb[(int64_t)v * C + c] += acc[k]; }
+}
+
+extern "C" int styler_embed_bwd_det(const int64_t* text, const float* dy, int64_t lddy, float* demb, int B, int L, int C,
+                                    int V, void* stream) {
+  if (!text || !dy || !demb || B <= 0 || L <= 0 || C <= 0 || C > 1024 || V <= 1 || (int64_t)B * L >= ((int64_t)1 << 31))
+    return STYLER_EINVAL;
+  hipLaunchKernelGGL(embed_bwd_det_kernel, dim3((unsigned)(V - 1)), dim3(256), 0, (hipStream_t)stream, text, dy, lddy, demb,
+                     B * L, C);
+  return launch_status();
+}
+
 extern "C" int styler_embed_bwd(const int64_t* text, const float* dy, int64_t lddy, float* demb, int B, int L, int C,
                                 void* stream) {
   if (!text || !dy || !demb || B <= 0 || L <= 0 || C <= 0) return STYLER_EINVAL;
@@ -58,45 +99,52 @@ extern "C" int styler_onehot_expand(const float* v, float* onehot, int64_t rows,
 
 // ---- mel calibrator backward: grid (T, B) over INPUT frames -----------------------------------------------
 // (block = 256 / (C / 4) input frames of one item, thread = (frame, float4 column): see mel_calibrate_kernel)
+#define MCB_FR 8
 template <bool DX16>                                 // dx (the gradient of the concatenated streams) written as bf16
 __global__ __launch_bounds__(256) void mel_calibrate_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
                                                                 void* __restrict__ dx, int64_t lddx,
                                                                 const int64_t* __restrict__ mel_len,
                                                                 const int64_t* __restrict__ src_len, int T, int S, int C) {
+  // (round 4: a block walks MCB_FR consecutive groups of frames -- at C = 1024 a block was ONE frame, 42 k blocks of one
+  //  16-byte load and one store per thread: 54 us for 87 MB)
   const int nq = C >> 2, cpr = nq < 256 ? nq : 256, rpb = 256 / cpr;
   const int rl = threadIdx.x / cpr, ql = threadIdx.x - rl * cpr;
-  const int t = blockIdx.x * rpb + rl, b = blockIdx.y;
-  if (rl >= rpb || t >= T) return;
+  const int b = blockIdx.y;
+  if (rl >= rpb) return;
   const int ml = (int)mel_len[b], sl = (int)src_len[b];
-  const int64_t dxo = ((int64_t)b * T + t) * lddx;
   const float* dyb = dy + (int64_t)b * S * lddy;
-  // div > 0: frame t lies in exactly one segment (compression / copy): grad = dy[s0] / div
-  // div == 0: frame t was repeated `cnt` times (expansion): grad = sum of those output rows
-  int s0 = 0, cnt = 0, div = 0;
-  if (t < ml && sl > 0) {
-    if (ml >= sl) {
-      const int q = ml / sl, r = ml % sl;
-      s0 = (t < r * (q + 1)) ? t / (q + 1) : r + (t - r * (q + 1)) / q;
-      div = q + (s0 < r ? 1 : 0);
-    } else {
-      const int q = sl / ml, r = sl % ml;
-      cnt = q + (t < r ? 1 : 0);
-      s0 = t * q + (t < r ? t : r);
+  for (int f = 0; f < MCB_FR; ++f) {
+    const int t = (blockIdx.x * MCB_FR + f) * rpb + rl;
+    if (t >= T) return;
+    const int64_t dxo = ((int64_t)b * T + t) * lddx;
+    // div > 0: frame t lies in exactly one segment (compression / copy): grad = dy[s0] / div
+    // div == 0: frame t was repeated `cnt` times (expansion): grad = sum of those output rows
+    int s0 = 0, cnt = 0, div = 0;
+    if (t < ml && sl > 0) {
+      if (ml >= sl) {
+        const int q = ml / sl, r = ml % sl;
+        s0 = (t < r * (q + 1)) ? t / (q + 1) : r + (t - r * (q + 1)) / q;
+        div = q + (s0 < r ? 1 : 0);
+      } else {
+        const int q = sl / ml, r = sl % ml;
+        cnt = q + (t < r ? 1 : 0);
+        s0 = t * q + (t < r ? t : r);
+      }
     }
-  }
-  const int n = div > 0 ? 1 : cnt;                    // rows of dy that reach this frame
-  for (int q4 = ql; q4 < nq; q4 += cpr) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k0 = 0; k0 < n; k0 += 4) {
-      float4 g[4];
+    const int n = div > 0 ? 1 : cnt;                    // rows of dy that reach this frame
+    for (int q4 = ql; q4 < nq; q4 += cpr) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k0 = 0; k0 < n; k0 += 4) {
+        float4 g[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) g[u] = *reinterpret_cast<const float4*>(dyb + (int64_t)(s0 + (k0 + u < n ? k0 + u : n - 1)) * lddy + q4 * 4);
+        for (int u = 0; u < 4; ++u) g[u] = *reinterpret_cast<const float4*>(dyb + (int64_t)(s0 + (k0 + u < n ? k0 + u : n - 1)) * lddy + q4 * 4);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (k0 + u < n) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
+        for (int u = 0; u < 4; ++u)
+          if (k0 + u < n) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
+      }
+      if (div > 1) { const float d = (float)div; acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d; }
+      stg4(dx, dxo + q4 * 4, acc, DX16);
     }
-    if (div > 1) { const float d = (float)div; acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d; }
-    stg4(dx, dxo + q4 * 4, acc, DX16);
   }
 }
 
@@ -107,10 +155,10 @@ extern "C" int styler_mel_calibrate_bwd_io(const float* dy, int64_t lddy, void* 
   if ((lddy & 3) || (lddx & 3)) return STYLER_EALIGN;
   const int nq = C >> 2, rpb = 256 / (nq < 256 ? nq : 256);
   if (io_flags & STYLER_IO_Y_BF16)
-    hipLaunchKernelGGL(mel_calibrate_bwd_kernel<true>, dim3((T + rpb - 1) / rpb, B), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx,
+    hipLaunchKernelGGL(mel_calibrate_bwd_kernel<true>, dim3((T + rpb * MCB_FR - 1) / (rpb * MCB_FR), B), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx,
                        lddx, mel_len, src_len, T, S, C);
   else
-    hipLaunchKernelGGL(mel_calibrate_bwd_kernel<false>, dim3((T + rpb - 1) / rpb, B), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx,
+    hipLaunchKernelGGL(mel_calibrate_bwd_kernel<false>, dim3((T + rpb * MCB_FR - 1) / (rpb * MCB_FR), B), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx,
                        lddx, mel_len, src_len, T, S, C);
   return launch_status();
 }
@@ -127,7 +175,7 @@ __global__ __launch_bounds__(256) void aug_tail_bwd_kernel(const float* __restri
                                                            const float* __restrict__ b2, const float* __restrict__ dout,
                                                            float* __restrict__ dh, float* __restrict__ dg,
                                                            float* __restrict__ dbt, float* __restrict__ dw2,
-                                                           float* __restrict__ db2, int S, int seg_rows) {
+                                                           float* __restrict__ db2, int S, int seg_rows, int pslots) {
   // grid (B, segments of the S axis): 48 blocks walking 60 rows each were a 45 us latency chain (6 wave reductions per row)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x;
   const int s_lo = blockIdx.y * seg_rows, s_hi = min(S, s_lo + seg_rows);
@@ -180,6 +228,17 @@ __global__ __launch_bounds__(256) void aug_tail_bwd_kernel(const float* __restri
   __syncthreads();
   float* dsts[4] = {dg, dbt, dw2, dw2 + 256};
   const int c = threadIdx.x;
+  if (pslots) {
+    // STYLER_IO_PARAM_SLOTS: the four gradients are slot arrays [blocks][256 | 256 | 512 | 2]; this block STORES its sums into
+    // slot blockIdx.y * gridDim.x + b, the caller's multi-tensor reduce folds the slots in order (no atomics)
+    const int64_t blk = (int64_t)blockIdx.y * gridDim.x + b;
+    dsts[0] = dg + blk * 256; dsts[1] = dbt + blk * 256; dsts[2] = dw2 + blk * 512; dsts[3] = dw2 + blk * 512 + 256;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dsts[k][c] = (red[k][0][c] + red[k][1][c]) + (red[k][2][c] + red[k][3][c]);
+    if (threadIdx.x < 2)
+      db2[blk * 2 + threadIdx.x] = (redb[0][threadIdx.x] + redb[1][threadIdx.x]) + (redb[2][threadIdx.x] + redb[3][threadIdx.x]);
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k)
     atomicAdd(dsts[k] + c, (red[k][0][c] + red[k][1][c]) + (red[k][2][c] + red[k][3][c]));
@@ -193,7 +252,22 @@ extern "C" int styler_aug_classifier_tail_bwd(const float* h, const float* ln_g,
     return STYLER_EINVAL;
   const int seg_rows = 16;
   hipLaunchKernelGGL(aug_tail_bwd_kernel, dim3(B, (S + seg_rows - 1) / seg_rows), dim3(256), 0, (hipStream_t)stream, h, ln_g,
-                     ln_b, w2, b2, dout, dh, dln_g, dln_b, dw2, db2, S, seg_rows);
+                     ln_b, w2, b2, dout, dh, dln_g, dln_b, dw2, db2, S, seg_rows, 0);
+  return launch_status();
+}
+
+// The same with the four parameter gradients as SLOT arrays (io_flags & STYLER_IO_PARAM_SLOTS): [slots][256], [slots][256],
+// [slots][512], [slots][2] with slots = styler_aug_classifier_tail_slots(B, S); every slot is stored.
+extern "C" int styler_aug_classifier_tail_slots(int B, int S) { return B * ((S + 15) / 16); }
+extern "C" int styler_aug_classifier_tail_bwd_io(const float* h, const float* ln_g, const float* ln_b, const float* w2,
+                                                 const float* b2, const float* dout, float* dh, float* dln_g,
+                                                 float* dln_b, float* dw2, float* db2, int B, int S, int io_flags,
+                                                 void* stream) {
+  if (!h || !ln_g || !ln_b || !w2 || !b2 || !dout || !dh || !dln_g || !dln_b || !dw2 || !db2 || B <= 0 || S <= 0)
+    return STYLER_EINVAL;
+  const int seg_rows = 16;
+  hipLaunchKernelGGL(aug_tail_bwd_kernel, dim3(B, (S + seg_rows - 1) / seg_rows), dim3(256), 0, (hipStream_t)stream, h, ln_g,
+                     ln_b, w2, b2, dout, dh, dln_g, dln_b, dw2, db2, S, seg_rows, (io_flags & STYLER_IO_PARAM_SLOTS) ? 1 : 0);
   return launch_status();
 }
 
@@ -235,7 +309,8 @@ extern "C" int styler_length_regulate_bwd(const float* dy, int64_t lddy, const i
 #define BEB_SLICES 16
 __global__ __launch_bounds__(256) void bucket_embed_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ pid,
                                                                const int32_t* __restrict__ eid, float* __restrict__ dpe,
-                                                               float* __restrict__ dee, int64_t rows, int nbuckets) {
+                                                               float* __restrict__ dee, int64_t rows, int nbuckets,
+                                                               int pslots) {
   __shared__ float red[4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bucket = blockIdx.x % nbuckets, table = blockIdx.x / nbuckets, slice = blockIdx.y;
@@ -266,6 +341,13 @@ __global__ __launch_bounds__(256) void bucket_embed_bwd_kernel(const float* __re
   }
   red[wave][lane * 4 + 0] = acc.x; red[wave][lane * 4 + 1] = acc.y; red[wave][lane * 4 + 2] = acc.z; red[wave][lane * 4 + 3] = acc.w;
   const int hits = __syncthreads_or(any);
+  if (pslots) {
+    // STYLER_IO_PARAM_SLOTS: dpe / dee are [BEB_SLICES][nbuckets * 256] slot arrays; every (bucket, slice) block STORES its sum
+    // (zeros included), the caller's multi-tensor reduce folds the slices in order: no atomics
+    float* dst = (table ? dee : dpe) + ((int64_t)slice * nbuckets + bucket) * 256 + threadIdx.x;
+    *dst = hits ? (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]) : 0.f;
+    return;
+  }
   if (!hits) return;
   const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
   if (t != 0.f) atomicAdd((table ? dee : dpe) + (int64_t)bucket * 256 + threadIdx.x, t);
@@ -277,7 +359,19 @@ extern "C" int styler_bucket_embed_bwd(const float* dy, const int32_t* p_ids, co
   const int64_t rows = (int64_t)B * T;
   const int nbuckets = 256;                            // hparams.n_bins (modules.py:278-281)
   hipLaunchKernelGGL(bucket_embed_bwd_kernel, dim3(2 * nbuckets, BEB_SLICES), dim3(256), 0, (hipStream_t)stream, dy, p_ids,
-                     e_ids, dpitch_emb, denergy_emb, rows, nbuckets);
+                     e_ids, dpitch_emb, denergy_emb, rows, nbuckets, 0);
+  return launch_status();
+}
+
+// The same with the two gradients as slot arrays [styler_bucket_embed_slices()][256 * 256] (every slot is stored).
+extern "C" int styler_bucket_embed_slices(void) { return BEB_SLICES; }
+extern "C" int styler_bucket_embed_bwd_slots(const float* dy, const int32_t* p_ids, const int32_t* e_ids, float* dpitch_slots,
+                                             float* denergy_slots, int B, int T, void* stream) {
+  if (!dy || !p_ids || !e_ids || !dpitch_slots || !denergy_slots || B <= 0 || T <= 0) return STYLER_EINVAL;
+  const int64_t rows = (int64_t)B * T;
+  const int nbuckets = 256;
+  hipLaunchKernelGGL(bucket_embed_bwd_kernel, dim3(2 * nbuckets, BEB_SLICES), dim3(256), 0, (hipStream_t)stream, dy, p_ids,
+                     e_ids, dpitch_slots, denergy_slots, rows, nbuckets, 1);
   return launch_status();
 }
 

@@ -242,7 +242,9 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < LNB_WAVES; ++w) t += redb[w];
-    atomicAdd(ddot_b, t);
+    // STYLER_LNB_DOTB_SLOTS (with one replica per block): ddot_b is a [replicas] slot array, stored like the three vectors
+    if ((flags & STYLER_LNB_DOTB_SLOTS) && replicas >= (int)gridDim.x) ddot_b[blockIdx.x] = t;
+    else atomicAdd(ddot_b, t);
   }
 }
 
@@ -462,7 +464,11 @@ __global__ __launch_bounds__(1024) void gn_bwd_fused_kernel(const void* __restri
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ stats, void* __restrict__ dx,
                                                             int64_t lddx, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int L, int C, int dx16) {
+                                                            float* __restrict__ dbeta, int L, int C, int dx16_slots) {
+  // dx16_slots: bit 0 = dx is written as bf16; bit 1 (STYLER_IO_PARAM_SLOTS) = dgamma / dbeta are [B][C] slot arrays this launch
+  // STORES item b's sums into (folded in item order by the caller's multi-tensor reduce: no atomics, bit-reproducible)
+  const int dx16 = dx16_slots & 1;
+  const bool pslots = dx16_slots & 2;
   __shared__ float red[2][16][4];
   __shared__ float pg[2][16][64];
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
@@ -525,7 +531,8 @@ __global__ __launch_bounds__(1024) void gn_bwd_fused_kernel(const void* __restri
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) t += pg[which][w][c];
-    atomicAdd((which ? dbeta : dgamma) + c0 + c, t);
+    if (pslots) (which ? dbeta : dgamma)[(int64_t)b * C + c0 + c] = t;
+    else atomicAdd((which ? dbeta : dgamma) + c0 + c, t);
   }
   const float inv_n = 1.f / (16.f * (float)L);
   const float m1 = t1 * inv_n, m2 = t2 * inv_n;
@@ -557,9 +564,11 @@ extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void
   const int dy16 = (io_flags & STYLER_IO_X_BF16) ? 1 : 0;
   const int dx16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
   const bool x16 = (io_flags & STYLER_IO_Z_BF16) != 0;
+  const bool pslots = (io_flags & STYLER_IO_PARAM_SLOTS) != 0;
+  if (pslots && !gn_fused_iters(L, true)) return STYLER_EINVAL;        // slots: the single-pass kernel only
   if (gn_fused_iters(L, true)) {
 #define GNB_LAUNCH(D_, I_, X_) hipLaunchKernelGGL((gn_bwd_fused_kernel<D_, I_, X_>), dim3(C / 64, B), dim3(1024), 0, st, x, ldx, dy, \
-                                                  lddy, gamma, beta, stats, dx, lddx, dgamma, dbeta, L, C, dx16)
+                                                  lddy, gamma, beta, stats, dx, lddx, dgamma, dbeta, L, C, dx16 | (pslots ? 2 : 0))
     if (dy16 && x16) GNB_LAUNCH(true, GNB_IT, true);
     else if (dy16) GNB_LAUNCH(true, GNB_IT, false);
     else if (x16) GNB_LAUNCH(false, GNB_IT, true);

@@ -649,6 +649,7 @@ def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, 
     return dot_out if dot_w is not None else out
 
 
+IO_PARAM_SLOTS = 512  # STYLER_IO_PARAM_SLOTS: parameter gradients leave the kernel as per-block slots (see _param_slots)
 IO_Z_BF16 = 16       # STYLER_IO_Z_BF16: the tensor a norm kernel normalises (a convolution's output) is stored as bf16
 
 
@@ -954,7 +955,36 @@ def split3_parts(t3, C):
     return t3[..., 0:C], t3[..., 2 * C:3 * C]
 
 
-IO_X_LO, IO_DZ_LO, IO_X3CAT = 32, 64, 128      # STYLER_IO_X_LO / STYLER_IO_DZ_LO / STYLER_IO_X3CAT
+IO_X_LO, IO_DZ_LO, IO_X3CAT, IO_DB_SLOTS = 32, 64, 128, 256      # STYLER_IO_X_LO / _DZ_LO / _X3CAT / _DB_SLOTS
+# inside a training step the bias gradients leave the weight-gradient kernels as per-split slots that the step's multi-tensor
+# reduce folds in split order (bit-reproducible; STYLER_BIAS_SLOTS=0: fp32 atomics as before round 4)
+bias_slots = os.environ.get("STYLER_BIAS_SLOTS", "1") != "0"
+
+
+def _param_slots(nslots, length, target):
+    """Inside a training step: [nslots][length] floats from the step's arena, their in-order fold into `target` queued on the
+    step's multi-tensor reduce; None outside a step, with STYLER_BIAS_SLOTS=0, or while the arena is being sized (the caller
+    then takes its atomics path)."""
+    arena = wgrad_arena
+    if arena is None or not bias_slots:
+        return None
+    sl = arena.take(nslots * length, target.device)
+    if sl is None:
+        return None
+    arena.descs.append((sl.data_ptr(), target.data_ptr(), 1, 0, 0, length, 1, 1, nslots))
+    return sl
+
+
+def _bias_slots(arena, splits, n, db, db2, device):
+    """Takes [splits][n] floats from the arena and queues their fold into db (and db2); None when the arena has no room (the
+    measuring pass of the first step)."""
+    bs = arena.take(splits * n, device)
+    if bs is None:
+        return None
+    arena.descs.append((bs.data_ptr(), db.data_ptr(), 1, 0, 0, n, 1, 1, splits))
+    if db2 is not None:
+        arena.descs.append((bs.data_ptr(), db2.data_ptr(), 1, 0, 0, n, 1, 1, splits))
+    return bs
 # bf16x3 weight gradients on bf16-resident splits as one launch over the three parts (STYLER_WGRAD_X3CAT=0: three launches)
 x3cat = os.environ.get("STYLER_WGRAD_X3CAT", "1") != "0"
 
@@ -1039,6 +1069,10 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
             if ws is not None:
                 d.ws = ws.data_ptr()
                 arena.descs.append((ws.data_ptr(), dw.data_ptr(), strides[0], strides[1], strides[2], n, cin, kw, d.splits))
+                if db is not None and bias_slots:
+                    bs = _bias_slots(arena, d.splits, n, db, db2, dz.device)
+                    if bs is not None:               # the member stores its column sums into the slots (0x800: see gemm_bwd.hip)
+                        d.db, d.db2, d.pad_left = bs.data_ptr(), 0, d.pad_left | 0x800
                 arena.group.append(d)
                 arena.group_keep.append((dz, x, plan))
                 return
@@ -1051,6 +1085,13 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
             defer = 1
             arena.descs.append((ws.data_ptr(), dw.data_ptr(), strides[0], strides[1], strides[2], n, cin, kw,
                                 int(lib.styler_wgrad_splits_io(B, L, n, cin, kw, pad_left, prec, io | parts))))
+    if arena is not None and db is not None and bias_slots:
+        if defer:
+            bs = _bias_slots(arena, arena.descs[-1][8], n, db, db2, dz.device)
+            if bs is not None:
+                db, db2, parts = bs, None, parts | IO_DB_SLOTS
+        else:                                        # measuring pass: the slots count towards the next step's arena
+            arena.total += (int(lib.styler_wgrad_splits_io(B, L, n, cin, kw, pad_left, prec, io | parts)) * n + 3) & ~3
     if ws is None:
         ws = torch.empty(nfloats, device=dz.device, dtype=torch.float32)
     grouped = False
@@ -1135,6 +1176,8 @@ def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, do
     if slab is not None:
         nvec = 3 if ddot_w is not None else 2
         sc = slab.take(nvec * LN_REPLICAS * 128)     # doubles = nvec * 16 * 256 floats (asked for in every pass: sizing)
+        want_db = ddot_w is not None and ddot_b is not None and bias_slots
+        sdb = slab.take(LN_REPLICAS // 2) if want_db else None           # (likewise)
         if sc is not None and arena is not None and arena.buf is not None:
             sc = sc.view(torch.float32).view(nvec, LN_REPLICAS, 256)
             rep, pg, pb = LN_REPLICAS, sc[0], sc[1]
@@ -1143,6 +1186,10 @@ def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, do
             if ddot_w is not None:
                 pw = sc[2]
                 arena.descs.append((pw.data_ptr(), ddot_w.data_ptr(), 1, 0, 0, 256, 1, 1, rep))
+                if sdb is not None:                  # the tail's scalar bias: one slot per block as well
+                    sdb = sdb.view(torch.float32)
+                    arena.descs.append((sdb.data_ptr(), ddot_b.data_ptr(), 1, 0, 0, 1, 1, 1, rep))
+                    ddot_b, lnb_io = sdb, lnb_io | 64        # STYLER_LNB_DOTB_SLOTS
     fold = None
     if rep == 1:
         # stand-alone call (no training step around it): the blocks still store into per-block slots -- never fp32 atomics
@@ -1171,11 +1218,20 @@ def groupnorm_relu_bwd(x, dy, gamma, beta, stats, dgamma, dbeta, dx_bf16=False):
     dy = _rows_view(dy)
     dx = torch.empty(B, L, C, device=x.device, dtype=torch.bfloat16 if dx_bf16 else torch.float32)
     ws, z = _norm_ws(B * (C // 16) * 2, x.device)
+    # gamma / beta gradients: per-item slots folded in item order by the step's reduce (single-pass kernel; else atomics)
+    sg = sb = None
+    if L <= lib.styler_groupnorm_fused_rows(1):
+        sg = _param_slots(B, C, dgamma)
+        sb = _param_slots(B, C, dbeta) if sg is not None else None
+        if sg is not None and sb is None:
+            wgrad_arena.descs.pop()                  # (no room for the second array: back to atomics for both)
+            sg = None
+    pg, pb, slots = (sg, sb, IO_PARAM_SLOTS) if sb is not None else (dgamma, dbeta, 0)
     _chk(lib.styler_groupnorm_relu_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), gamma.data_ptr(), beta.data_ptr(),
-                                       stats.data_ptr(), dx.data_ptr(), C, dgamma.data_ptr(), dbeta.data_ptr(),
+                                       stats.data_ptr(), dx.data_ptr(), C, pg.data_ptr(), pb.data_ptr(),
                                        ws.data_ptr(), z, B, L, C,
                                        (2 if dx_bf16 else 0) | (1 if dy.dtype == torch.bfloat16 else 0) |
-                                       (IO_Z_BF16 if x.dtype == torch.bfloat16 else 0), _stream()),
+                                       (IO_Z_BF16 if x.dtype == torch.bfloat16 else 0) | slots, _stream()),
          "styler_groupnorm_relu_bwd")
     return dx
 
@@ -1198,8 +1254,13 @@ def batchnorm_bwd(x, y, dy, gamma, mean, rstd, dgamma, dbeta, act, beta=None, dr
 
 
 def embed_bwd(text, dy, demb):
+    """demb [V, C] += the dy rows of every token, per table row in token order (no atomics: bit-reproducible)."""
     dy = _rows_view(dy)
     B, L = text.shape
+    if demb.shape[1] <= 1024 and bias_slots:
+        _chk(lib.styler_embed_bwd_det(text.data_ptr(), dy.data_ptr(), _ld(dy), demb.data_ptr(), B, L, demb.shape[1],
+                                      demb.shape[0], _stream()), "styler_embed_bwd_det")
+        return
     _chk(lib.styler_embed_bwd(text.data_ptr(), dy.data_ptr(), _ld(dy), demb.data_ptr(), B, L, demb.shape[1], _stream()),
          "styler_embed_bwd")
 
@@ -1236,6 +1297,23 @@ def aug_classifier_tail_bwd(h, ln_g, ln_b, w2, b2, dout, dln_g, dln_b, dw2, db2)
     B, S, _ = h.shape
     dh = torch.empty_like(h)
     dout = dout.contiguous()
+    ns = lib.styler_aug_classifier_tail_slots(B, S)
+    tg = [(dln_g, 256), (dln_b, 256), (dw2, 512), (db2, 2)]
+    sl, arena = [], wgrad_arena
+    for t, n in tg:
+        a = _param_slots(ns, n, t) if (not sl or sl[-1] is not None) else None
+        sl.append(a)
+    if sl[-1] is None and arena is not None:          # not all four fit: drop the queued folds, atomics for all
+        for a in sl:
+            if a is not None:
+                arena.descs.pop()
+        sl = None
+    if sl is not None and sl[-1] is not None:
+        _chk(lib.styler_aug_classifier_tail_bwd_io(h.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                                   dout.data_ptr(), dh.data_ptr(), sl[0].data_ptr(), sl[1].data_ptr(),
+                                                   sl[2].data_ptr(), sl[3].data_ptr(), B, S, IO_PARAM_SLOTS, _stream()),
+             "styler_aug_classifier_tail_bwd_io")
+        return dh
     _chk(lib.styler_aug_classifier_tail_bwd(h.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), w2.data_ptr(), b2.data_ptr(),
                                             dout.data_ptr(), dh.data_ptr(), dln_g.data_ptr(), dln_b.data_ptr(),
                                             dw2.data_ptr(), db2.data_ptr(), B, S, _stream()),
@@ -1255,6 +1333,16 @@ def length_regulate_bwd(dy, csum, S):
 def bucket_embed_bwd(dy, p_ids, e_ids, dpitch_emb, denergy_emb):
     dy = dy.contiguous()
     B, T, _ = dy.shape
+    ns = lib.styler_bucket_embed_slices()
+    sp = _param_slots(ns, dpitch_emb.numel(), dpitch_emb) if dpitch_emb.numel() == 256 * 256 else None
+    se = _param_slots(ns, denergy_emb.numel(), denergy_emb) if sp is not None and denergy_emb.numel() == 256 * 256 else None
+    if sp is not None and se is None:
+        wgrad_arena.descs.pop()
+        sp = None
+    if se is not None:                               # per-slice slots, folded in slice order by the step's reduce
+        _chk(lib.styler_bucket_embed_bwd_slots(dy.data_ptr(), p_ids.data_ptr(), e_ids.data_ptr(), sp.data_ptr(), se.data_ptr(),
+                                               B, T, _stream()), "styler_bucket_embed_bwd_slots")
+        return
     _chk(lib.styler_bucket_embed_bwd(dy.data_ptr(), p_ids.data_ptr(), e_ids.data_ptr(), dpitch_emb.data_ptr(),
                                      denergy_emb.data_ptr(), B, T, _stream()), "styler_bucket_embed_bwd")
 

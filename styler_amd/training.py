@@ -373,9 +373,19 @@ class GraphedTrainStep:
         grads = state.flat_g.clone() if accum else None
         try:
             with torch.cuda.stream(side), torch.enable_grad():
-                for _ in range(warmup):
+                # at least `warmup` passes, and then until a pass neither re-sized the arena / the zero slab nor built a new
+                # descriptor table: the capture may not upload one (the first pass measures, the second runs with the
+                # buffers that measurement sized, grouped launches and slot arrays settle one or two passes later)
+                def scratch_state():
+                    a, z = state.arena, state.zero_slab
+                    return (a.buf.data_ptr() if a.buf is not None else 0, a.buf.numel() if a.buf is not None else 0,
+                            z.buf.data_ptr() if z.buf is not None else 0, len(a._cache), len(a._gcache))
+                done, prev = 0, None
+                while done < warmup or (scratch_state() != prev and done < warmup + 6):
+                    prev = scratch_state()
                     state._accum = 0
                     forward_backward(model, state, self.static, loss_fn, dat_fn)
+                    done += 1
         finally:
             state.split_hook = None
         torch.cuda.current_stream().wait_stream(side)
