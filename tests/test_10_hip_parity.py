@@ -144,7 +144,11 @@ def test_gemm256_engine_vs_math_and_vs_128_engine(dev, case):
         ys = [ops.conv_gemm(xd, wk, bd, **args).clone() for _ in range(4)]
         ops.gemm256_config(0)
         assert ops.lib.styler_conv_gemm_engine(B, L, cin, n, kw, ops.PREC_BF16, 1, cin, 0) != 4
-        y128 = ops.conv_gemm(xd, wk, bd, **args)
+        prev_small = ops.gemm_small_split_config(0)           # (the unsplit engine: the reference bits)
+        try:
+            y128 = ops.conv_gemm(xd, wk, bd, **args)
+        finally:
+            ops.gemm_small_split_config(prev_small)
     finally:
         ops.gemm256_config(*prev)
     tol = 1e-2 if y16 else 1e-4                       # bf16 output: 2^-9 relative rounding of values up to ~4
@@ -268,7 +272,11 @@ def test_gemm256_engine_packed_rows(dev):
     try:
         yp = [ops.conv_gemm(xp, wk, None, kw=kw, prec=ops.PREC_BF16, plan=plan).clone() for _ in range(3)]
         ops.gemm256_config(0)
-        y128 = ops.conv_gemm(xp, wk, None, kw=kw, prec=ops.PREC_BF16, plan=plan)
+        prev_small = ops.gemm_small_split_config(0)
+        try:
+            y128 = ops.conv_gemm(xp, wk, None, kw=kw, prec=ops.PREC_BF16, plan=plan)
+        finally:
+            ops.gemm_small_split_config(prev_small)
     finally:
         ops.gemm256_config(*prev)
     nvalid = int(lens.sum())
@@ -312,7 +320,11 @@ def test_gemm256_split_k(dev, packed):
         ops.gemm256_config(1, -1, split=1, take_all=1)
         y1 = run()
         ops.gemm256_config(0)
-        y128 = run()
+        prev_small = ops.gemm_small_split_config(0)           # (the unsplit 64 x 64 / 128 x 128 engine: the reference bits)
+        try:
+            y128 = run()
+        finally:
+            ops.gemm_small_split_config(prev_small)
     finally:
         ops.gemm256_config(*prev)
     nv = int(lens.sum()) if packed else B * T

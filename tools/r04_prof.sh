@@ -41,6 +41,7 @@ timeout 300 python tools/wgrad_bench.py 5 > $O/r04_wgrad_bench.txt 2>&1
 timeout 300 python tools/gemm256_bench.py 3 > $O/r04_gemm256_bench.txt 2>&1
 timeout 300 python tools/gemm_bench.py bf16 > $O/r04_gemm_bench.txt 2>&1
 timeout 300 python tools/find_torch_ops.py > $O/r04_torch_ops.txt 2>&1
+timeout 300 python tools/attn_bench.py > $O/r04_attn_bench.txt 2>&1
 cp $O/r04_pmc_traffic.jsonl $R/profiles/r04_pmc_traffic.jsonl    # the default line below embeds THIS pass as roofline.traffic
 cp $O/r04_train_bf16_graph_kernel_stats.txt $R/profiles/r04_train_bf16_graph_kernel_stats.txt   # ... and frac_rocprof from THIS trace
 timeout 900 python bench.py > $O/r04_bench_default.json 2> $O/r04_bench_default.err
