@@ -29,6 +29,14 @@
 
 #include "gemm_args.h"
 
+// Round 4: in the occupancy-3 layout (unpadded 128-byte weight rows) the weight tile of a K step goes L2 -> LDS by DMA
+// (buffer_load_dwordx4 ... lds) instead of through registers: no staging registers, no ds_write pass; the XOR swizzle of the
+// 16-byte slots is applied to the SOURCE address (the DMA writes lane-linear).  -DSTYLER_GEMM_B_DMA=0: register staging.
+#ifndef STYLER_GEMM_B_DMA
+#define STYLER_GEMM_B_DMA 1
+#endif
+typedef __attribute__((address_space(3))) void cg_lds_void;
+
 // Phase timestamps (constant 100 MHz counter, s_memrealtime) of every block of the launches that follow
 // styler_gemm_set_trace(buf): [block, entry, first tile staged, main loop done, stores issued, stores acknowledged,
 // hardware id, tile].  A measurement hook (tools/gemm_trace.py), off (null) by default.
@@ -172,6 +180,20 @@ __device__ __forceinline__ void conv_gemm_body(const GemmArgs& a, const int bid_
   for (int sx = 0; sx < 4; ++sx) fb_sw[sx] = (uint32_t)(((sx * 2 + lh) ^ ((li & 7) ^ ((li >> 3) & 3))) * 4);
   const uint32_t sa_off = a_r0 * LD + (BF16 ? a_col / 2 : a_col);     // dwords (a bf16 pair per dword)
   const uint32_t sb_off = OCC3 ? b_r0 * LDB + (((tid % B_V) ^ ((b_r0 & 7) ^ ((b_r0 >> 3) & 3))) * 4) : b_r0 * LD + (tid % B_V) * 4;
+  // weight tile by LDS-DMA (occupancy-3 layout): piece P = wave + 4 q covers tile rows 8 P .. 8 P + 7 (1 KB of LDS); lane l
+  // lands at row 8 P + (l >> 3), physical 16-byte slot l & 7, which holds the LOGICAL chunk (l & 7) ^ swz(row)
+  constexpr bool BDMA = OCC3 && BF16 && (STYLER_GEMM_B_DMA != 0);
+  static_assert(!BDMA || BN == 128, "B-tile DMA: 16 pieces of 8 rows");
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint32_t vbd[4];                                 // byte offset of (row, logical chunk) inside the (n0, tap 0, chunk 0) tile
+  int lc8[4];                                      // first channel of the lane's logical chunk inside the 64-channel chunk
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = 8 * (wave_u + 4 * q) + (lane >> 3);
+    const int lc = (lane & 7) ^ ((row & 7) ^ ((row >> 3) & 3));
+    lc8[q] = lc * 8;
+    vbd[q] = (uint32_t)((row * ktot + lc * 8) * 2);
+  }
 
   // per-lane tap validity for the wave's output rows: bit j set <=> row t + j - pad lies in [0, L)
   uint32_t tapmask[TM];
@@ -240,6 +262,17 @@ __device__ __forceinline__ void conv_gemm_body(const GemmArgs& a, const int bid_
 #pragma unroll
     for (int p = 0; p < B_P; ++p) *reinterpret_cast<uint4*>(&dst[p * B_RPP * LDB]) = rb[p];
   };
+  auto dma_b = [&](int cc, int j, int buf) {         // the whole [BN x 64] weight tile of step (cc, j) -> sB[buf]
+    const int c0 = cc * BK;
+    int64_t rec = ((int64_t)(a.n - n0 - 1) * ktot + (a.cin - c0)) * B_ES;
+    rec = rec > REC_MAX ? REC_MAX : rec;
+    const char* base = reinterpret_cast<const char*>(a.w) + ((int64_t)n0 * ktot + (int64_t)j * a.cin + c0) * B_ES;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)rec, 0x00020000);
+    char* dst = reinterpret_cast<char*>(sB + buf * BN * LDB) + wave_u * 1024;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (cg_lds_void*)(dst + q * 4096), 16, c0 + lc8[q] < a.cin ? vbd[q] : OOB, 0, 0, 0);
+  };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -252,9 +285,9 @@ __device__ __forceinline__ void conv_gemm_body(const GemmArgs& a, const int bid_
   if (tid < LD) sZ[tid] = 0u;
   const uint32_t* const zrow = sZ + lh * (BF16 ? 4 : 16);
   load_a(cc0);
-  load_b(cc0, 0);
+  if constexpr (BDMA) dma_b(cc0, 0, 0); else load_b(cc0, 0);
   store_a(cc0 & 1);
-  store_b(0);
+  if constexpr (BDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else store_b(0);
   __syncthreads();
   if (a.trace) stamp[1] = wall_clock64();
 
@@ -274,7 +307,8 @@ __device__ __forceinline__ void conv_gemm_body(const GemmArgs& a, const int bid_
     uint64_t tp = __builtin_readcyclecounter();
 #endif
     if (more) {
-      load_b(ccn, jn);
+      // (DMA: straight into the other weight buffer -- its last reader was step - 1, behind the barrier that ended it)
+      if constexpr (BDMA) dma_b(ccn, jn, (step + 1) & 1); else load_b(ccn, jn);
       if (jn == 0) load_a(ccn);
     }
     PH_MARK(0, tp)
@@ -330,11 +364,12 @@ __device__ __forceinline__ void conv_gemm_body(const GemmArgs& a, const int bid_
 #endif
     PH_MARK(1, tp)
     if (more) {
-      store_b((step + 1) & 1);
+      if constexpr (!BDMA) store_b((step + 1) & 1);
       if (jn == 0) {
         if (OCC3) __syncthreads();                     // every wave is done with the single activation buffer
         store_a(ccn & 1);
       }
+      if constexpr (BDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces have landed
     }
     PH_MARK(2, tp)
     __syncthreads();
