@@ -680,8 +680,10 @@ def bn_fold(gamma, beta, running_mean, running_var, conv_bias):
     return scale, shift
 
 
-LN_REPLICAS = int(os.environ.get("STYLER_LN_REPLICAS", "256"))          # scratch replicas of LayerNorm's parameter gradients inside a training step: one per block
-                           # (styler_layernorm_bwd launches <= 256 blocks), so the blocks store instead of adding atomically
+# scratch replicas of LayerNorm's parameter gradients: one per block of styler_layernorm_bwd (<= STYLER_LNBWD_BLOCKS = 256 blocks),
+# so the blocks STORE instead of adding atomically -- never fewer slots than that cap (with fewer the kernel would fall back to
+# fp32 atomics into slot block % replicas)
+LN_REPLICAS = max(int(os.environ.get("STYLER_LN_REPLICAS", "256")), int(os.environ.get("STYLER_LNBWD_BLOCKS", "256")))
 BN_WS_COPIES = 16        # STYLER_BN_COPIES (norms.hip): replicas of the 2C-double column accumulator
 
 
@@ -1198,8 +1200,12 @@ def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, do
         nvec = 3 if ddot_w is not None else 2
         fold = torch.zeros(nvec, LN_REPLICAS, 256, device=x.device, dtype=torch.float32)
         rep, pg, pb = LN_REPLICAS, fold[0], fold[1]
+        fold_db = None
         if ddot_w is not None:
             pw = fold[2]
+            if ddot_b is not None:                       # the tail's scalar bias: per-block slots too (round-3 advisor)
+                fold_db, fold_db_dst = torch.zeros(LN_REPLICAS, device=x.device, dtype=torch.float32), ddot_b
+                ddot_b, lnb_io = fold_db, lnb_io | 64    # STYLER_LNB_DOTB_SLOTS
     _chk(lib.styler_layernorm_bwd(x.data_ptr(), _ld(x), _ptr(dy), _ld(dy) if dy is not None else 0, gamma.data_ptr(),
                                   _ptr(beta), _ptr(dx), C, pg.data_ptr(), pb.data_ptr(), _ptr(dot_w),
                                   _ptr(dout), _ptr(pw), _ptr(ddot_b), B, L, C, _ptr(lens), float(drop_p),
@@ -1210,6 +1216,9 @@ def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, do
         _chk(lib.styler_fold_replicas(fold[0].data_ptr(), fold[1].data_ptr(), _ptr(fold[2]) if ddot_w is not None else None,
                                       dgamma.data_ptr(), dbeta.data_ptr(), _ptr(ddot_w), LN_REPLICAS, 256, _stream()),
              "styler_fold_replicas")
+        if fold_db is not None:
+            _chk(lib.styler_fold_replicas(fold_db.data_ptr(), None, None, fold_db_dst.data_ptr(), None, None, LN_REPLICAS, 1,
+                                          _stream()), "styler_fold_replicas")
     return (dx, dxd) if dxd is not None else dx
 
 

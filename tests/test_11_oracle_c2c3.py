@@ -123,6 +123,44 @@ def test_c2_forward_vs_oracle(dev, bench_batch, ref_state_dict, oracle_forward, 
         assert rep[k]["max_abs"] <= mel_abs, (k, rep[k])
 
 
+def test_c2_forward_bf16_storage_budget(dev, bench_batch, ref_state_dict, oracle_forward):
+    """What each bf16 STORAGE decision of the throughput mode costs against the oracle (round-3 advisor: the switches are not
+    bit-neutral and all default on): the C2 forward with one switch off at a time, and with all of them off (bf16 MFMA
+    operands only).  The measured errors go to the parity report; every variant has to stay inside the mode's bound, so a
+    change that makes ONE of them the tipping point shows up here and not only in the all-on figure."""
+    from styler_amd import STYLER, rt
+    b = {k: v.to(dev) for k, v in bench_batch.items()}
+    S, T = b["text"].shape[1], b["mel_target"].shape[1]
+    m = STYLER()
+    m.load_state_dict(ref_state_dict)
+    m = m.to(dev).eval()
+    m.clean_only = True
+    switches = ("bf16_acts", "bf16_stream", "bf16_z", "bf16_qkv", "bf16_att")
+    saved = {k: getattr(rt, k) for k in switches}
+    ref = oracle_forward
+    rep = {}
+    rt.set_precision("bf16")
+    try:
+        for off in ("none",) + switches + ("all",):
+            for k in switches:
+                setattr(rt, k, saved[k] and not (off == k or off == "all"))
+            with torch.no_grad():
+                out = m(b["text"], b["mel_target"], b["mel_aug"], b["f0_norm"], b["energy_input"], b["src_len"], b["mel_len"],
+                        b["D"], b["f0"], b["energy"], S, T, speaker_embed=b["speaker_embed"])
+            rep[f"off={off}"] = {name: float((got.detach().cpu().double() - exp.double()).abs().max())
+                                 for name, got, exp in (("mel", out[0][0], ref[0][0]), ("mel_postnet", out[1][0], ref[1][0]),
+                                                        ("log_d", out[2], ref[2]), ("p_pred", out[3], ref[3]),
+                                                        ("e_pred", out[4], ref[4]))}
+    finally:
+        for k in switches:
+            setattr(rt, k, saved[k])
+        rt.set_precision("fp32")
+    _report("c2_forward_bf16_storage_budget", rep)
+    bound = TOL["bf16"][0]
+    for variant, errs in rep.items():
+        assert max(errs.values()) <= bound, (variant, errs)
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16x3"])
 def test_c3_train_step_vs_oracle(dev, bench_batch, ref_state_dict, oracle_train, prec):
     """BASELINE config 3 per-rank step (dual decode + DAT pass + ten losses + backward), B = 48: the default workload
