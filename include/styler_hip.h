@@ -54,7 +54,7 @@ extern "C" {
  * ignored for an operand stored as bf16.  dw += dz_hi^T x_lo and dw += dz_lo^T x_hi without materialising the low parts. */
 #define STYLER_IO_X_LO 32
 #define STYLER_IO_DZ_LO 64
-/* the same entry points, both operands [hi | hi | lo] bf16 split tensors (styler_split3_bf16: row strides >= 3 n / 3 cin,
+/* the same entry points, both operands bf16 split tensors [hi | lo (| hi)] (styler_split3_bf16: row strides >= 2 n / 2 cin,
  * STYLER_IO_X_BF16 | STYLER_IO_Y_BF16 set): dw += dz_hi^T x_hi + dz_hi^T x_lo + dz_lo^T x_hi as ONE launch whose contraction axis
  * runs over the three parts (one set of split-K partial tiles instead of three); db += colsum(dz_hi) + colsum(dz_lo).
  * LDS-DMA kernels only: styler_wgrad_x3cat_ok(n, cin, kw, pad_left) says whether the shape has one. */
@@ -68,6 +68,10 @@ extern "C" {
  * launch stores its per-block sums into (GroupNorm: [B][C] for gamma and for beta, single-pass kernel only); the caller folds
  * them in slot order with styler_wgrad_reduce_multi.  No fp32 atomics: the gradients are bit-reproducible. */
 #define STYLER_IO_PARAM_SLOTS 512
+/* styler_conv_gemm / styler_conv_gemm_packed (bf16 MFMA mode, STYLER_IO_X_BF16 set, cin = 3 C with C % 64 == 0): x is the COMPACT
+ * bf16x3 split [hi | lo] of C channels each (styler_split3_bf16 with parts = 2, row stride >= 2 C); the channel chunks of
+ * the third product (cin / 3 * 2 .. cin) read the hi block a second time.  The weight row stays [w_hi | w_hi | w_lo]. */
+#define STYLER_IO_X3A 1024
 /* styler_add_layernorm io_flags (round 3: the decoder's residual stream is stored as bf16 in throughput mode) */
 #define STYLER_LN_RES_BF16 1  /* res is bf16 */
 #define STYLER_LN_Y_BF16 2    /* y is written as bf16 (ldy in elements) */
@@ -423,13 +427,15 @@ int styler_add_rowvec(const float* a, int64_t lda, const float* v, int64_t ldv, 
                       int64_t ldy, int B, int L, int C, void* stream);
 /* bf16x3 arithmetic (precision STYLER_PREC_BF16X3 of the host layer): fp32-class products on the bf16 matrix cores.  An
  * operand is carried as hi + lo (hi = bf16(v), lo = bf16(v - hi)); a x w = a_hi w_hi + a_hi w_lo + a_lo w_hi is ONE bf16
- * GEMM over a three times longer contraction axis: styler_split3_bf16 writes the activation row [hi | hi | lo] (bf16,
- * [rows, 3C]), the weight row is [w_hi | w_lo | w_hi] (StylerCopyDesc.flags bit 3 = low part), and styler_conv_gemm runs
- * it with prec = STYLER_PREC_BF16, cin = 3C.  Replaces the fp32 arithmetic of every nn.Linear / nn.Conv1d of the path
- * (transformer/SubLayers.py:41-61,72-89; modules.py; transformer/Layers.py:78-118) at ~3x the bf16 cost instead of 16x.
- * `count` (optional, device int64): only rows < count[0] are written (packed rows).  styler_lo_part: y = bf16(x - hi)
- * stored as fp32, the low operand of the three styler_wgrad calls that make a weight gradient in this arithmetic. */
-int styler_split3_bf16(const float* x, int64_t ldx, void* y, int64_t rows, int C, const int64_t* count, void* stream);
+ * GEMM over a three times longer contraction axis: the activation blocks (hi, lo, hi) against the weight row
+ * [w_hi | w_hi | w_lo] (StylerCopyDesc.flags bit 3 = low part); styler_conv_gemm runs it with prec = STYLER_PREC_BF16,
+ * cin = 3C.  styler_split3_bf16 writes the activation row: parts = 3 -> [hi | lo | hi] (bf16 [rows, 3C]); parts = 2 ->
+ * the compact [hi | lo] ([rows, 2C], C % 64 == 0: the GEMM takes it with STYLER_IO_X3A).  Replaces the fp32 arithmetic of
+ * every nn.Linear / nn.Conv1d of the path (transformer/SubLayers.py:41-61,72-89; modules.py; transformer/Layers.py:78-118)
+ * at ~2.4x the bf16 cost instead of 16x.  `count` (optional, device int64): only rows < count[0] are written (packed
+ * rows).  styler_lo_part: y = bf16(x - hi) stored as fp32 (tests; the weight-gradient kernels stage low parts themselves). */
+int styler_split3_bf16(const float* x, int64_t ldx, void* y, int64_t rows, int C, const int64_t* count, int parts,
+                       void* stream);
 int styler_lo_part(const float* x, int64_t ldx, float* y, int64_t rows, int C, const int64_t* count, void* stream);
 /* Up to 8 strided row copies in one launch (the descriptors travel in the kernel arguments): segment k copies `rows` rows of
  * `C` floats (C % 4 == 0) from src (row stride ld_src; NULL = zero fill) to dst (row stride ld_dst).  The torch.cat /

@@ -297,10 +297,10 @@ class AttnSublayerFn(Function):
                               out_bf16=bf16 and att.dtype == torch.bfloat16)
         dqkv = ops.attention_bwd(qkv, att, d_att, lse, lens, plan=plan, out_bf16=bf16 and rt.bf16_acts and rt.bf16_dqkv)
         srcs = [mha.w_qs.weight, mha.w_ks.weight, mha.w_vs.weight]
-        dqg, _ = _x3_split(dqkv, 768, plan)           # [hi(768) | hi(768) | lo(768)]: per projection, slices of both parts
+        dqg, _ = _x3_split(dqkv, 768, plan)           # [hi(768) | lo(768) (| hi)]: per projection, slices of both parts
         x3p = ops.split3_parts(ops.split3(x, plan), 256) if dqg is not dqkv else None
         for i, lin in enumerate((mha.w_qs, mha.w_ks, mha.w_vs)):
-            dzp = ((dqg[..., i * 256:(i + 1) * 256], dqg[..., 1536 + i * 256:1536 + (i + 1) * 256]) if dqg is not dqkv else None)
+            dzp = ((dqg[..., i * 256:(i + 1) * 256], dqg[..., 768 + i * 256:768 + (i + 1) * 256]) if dqg is not dqkv else None)
             ops.wgrad(dqkv[..., i * 256:(i + 1) * 256], x, G(lin.weight), 256, 256, db=G(lin.bias), plan=plan,
                       dz_parts=dzp, x_parts=x3p)
         if rt.prec == ops.PREC_BF16X3:

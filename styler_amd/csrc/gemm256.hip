@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
   // piece p: unit row i = 8 p + (l >> 3), physical 16-byte chunk l & 7 = logical chunk ^ ((i >> 1) & 7).
   // UA0 row i -> tile row (i < 64 ? i : 128 + i - 64), UA1: + 64.  UB0 row i -> weight row (i >> 5) * 64 + (i & 31), UB1: + 32.
   const __amdgpu_buffer_rsrc_t x_rs = [&] {
-    int64_t rec = ((M - 1) * a.ldx + a.cin) * 2;
+    int64_t rec = ((M - 1) * a.ldx + (a.x3n1 ? 2 * a.x3n1 * BK : a.cin)) * 2;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)(rec > 0x7fffffff ? 0x7fffffff : rec), 0x00020000);
   }();
   const __amdgpu_buffer_rsrc_t w_rs = [&] {
@@ -161,7 +161,8 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
 
   // one unit of K step (cc, j) into stage `st`: 2 DMA instructions per wave
   auto issue_a = [&](int u, int cc, int j, uint32_t st) {
-    const uint32_t sh = (uint32_t)(j * (int)a.ldx * 2 + cc * (BK * 2));
+    const int ccs = (a.x3n1 && cc >= 2 * a.x3n1) ? cc - 2 * a.x3n1 : cc;      // compact bf16x3 rows [hi | lo]: third product = hi again
+    const uint32_t sh = (uint32_t)(j * (int)a.ldx * 2 + ccs * (BK * 2));
     const uint32_t base = st + (u ? U_A1 : U_A0);
     dma16(x_rs, base + lds_piece0, ((tapmask[u][0] >> j) & 1u) ? va[u][0] + sh : OOB, smem);
     dma16(x_rs, base + lds_piece1, ((tapmask[u][1] >> j) & 1u) ? va[u][1] + sh : OOB, smem);

@@ -22,6 +22,8 @@ struct GemmArgs {
   int ksplit = 1;                                  // gemm256.hip: split-K factor of the launch (1 or 2)
   float* part = nullptr;                           // ... and its fp32 partial tiles [ksplit][B*L][n] (styler_gemm_set_workspace)
   int res16 = 0;                                   // the residual tensor is bf16 (STYLER_IO_RES_BF16; ldres in elements)
+  int x3n1 = 0;                                    // STYLER_IO_X3A: x rows hold [hi | lo] of cin / 3 channels each; x3n1 = (cin / 3) / 64 chunks per part,
+                                                   // channel chunk cc >= 2 * x3n1 (the third product) reads chunk cc - 2 * x3n1 (hi again)
 };
 
 // gemm256.hip: returns 1 when the 256x256 LDS-DMA engine takes the launch (and has enqueued it), 0 when the shape is not

@@ -591,9 +591,9 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
                                                float* __restrict__ ws, const int4* __restrict__ chunktab,
                                                const int64_t* __restrict__ counts) {
   // pad_cat = (pad_left & 0xff) | (x3cat ? 0x400 : 0).  x3cat (STYLER_IO_X3CAT, the bf16x3 arithmetic): dz and x are
-  // [hi | hi | lo] split tensors (n resp. cin columns per part) and the launch computes dz_hi^T x_hi + dz_hi^T x_lo + dz_lo^T x_hi
-  // as ONE contraction over three times the chunks: chunk ch of part p = ch / (chunks per part) reads column block p of dz
-  // and column block (0, 2, 1)[p] of x.  One set of partial tiles instead of three; the bias row sums skip part 1 (dz_hi twice).
+  // [hi | lo (| hi)] split tensors (n resp. cin columns per part) and the launch computes dz_hi^T x_hi + dz_hi^T x_lo + dz_lo^T x_hi
+  // as ONE contraction over three times the chunks: chunk ch of part p = ch / (chunks per part) reads column block
+  // (0, 0, 1)[p] of dz and column block (0, 1, 0)[p] of x.  One set of partial tiles instead of three; the bias row sums skip part 1 (dz_hi twice).
   const int pad_left = (int)(int8_t)(pad_cat & 0xff);
   const bool x3cat = pad_cat & 0x400;
   const bool db_slots = pad_cat & 0x800;             // STYLER_IO_DB_SLOTS: db = [splits][n] slots, stored (see wgrad_kernel)
@@ -686,9 +686,9 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
     int64_t b_rec = ((int64_t)(Li - txb - 1) * ldx + cin) * 2;
     a_rec = a_rec > REC_MAX ? REC_MAX : a_rec;
     b_rec = b_rec > REC_MAX ? REC_MAX : (b_rec < 0 ? 0 : b_rec);
-    // (x3cat: column block `part` of dz, column block (0, 2, 1)[part] of x)
-    const char* a_base = reinterpret_cast<const char*>(dz) + ((rowb + t0) * lddz + (int64_t)part * n) * 2;
-    const char* b_base = reinterpret_cast<const char*>(x) + ((rowb + txb) * ldx + (int64_t)((part * 2) % 3) * cin) * 2;
+    // (x3cat: splits are [hi | lo (| hi)] -- column block (0, 0, 1)[part] of dz, column block (0, 1, 0)[part] of x)
+    const char* a_base = reinterpret_cast<const char*>(dz) + ((rowb + t0) * lddz + (int64_t)(part >> 1) * n) * 2;
+    const char* b_base = reinterpret_cast<const char*>(x) + ((rowb + txb) * ldx + (int64_t)(part & 1) * cin) * 2;
     const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a_base), 0, (int)a_rec, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b_base), 0, (int)b_rec, 0x00020000);
     const uint32_t b_off = (uint32_t)((tx - txb) * (int)ldx * 2);        // <= 0: rows before the item wrap out of range
@@ -1103,7 +1103,7 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
   const int kg = wgrad_kgroups(n, cin, kw, prec, io_flags);
   const bool x3cat = io_flags & STYLER_IO_X3CAT;
   if (x3cat && !(prec == STYLER_PREC_BF16 && dz16 && x16 && wgrad_x3cat_ok(n, cin, kw, pad_left) && !(lddz & 7) && !(ldx & 7) &&
-                 lddz >= 3 * (int64_t)n && ldx >= 3 * (int64_t)cin))
+                 lddz >= 2 * (int64_t)n && ldx >= 2 * (int64_t)cin))
     return STYLER_EINVAL;
   wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, 0, kg, x3cat ? 3 : 1);
   const int pad_cat = (pad_left & 0xff) | (x3cat ? 0x400 : 0) | ((io_flags & STYLER_IO_DB_SLOTS) ? 0x800 : 0);
@@ -1246,7 +1246,7 @@ extern "C" int styler_wgrad_group_desc(StylerWgradGroupDesc* out, const float* d
   if (variant < 0) return 0;
   int Be, Le, cpi, cps, splits;
   const bool x3cat = io_flags & STYLER_IO_X3CAT;
-  if (x3cat && !(dz16 && x16 && wgrad_x3cat_ok(n, cin, kw, pad_left) && variant == 8 && lddz >= 3 * (int64_t)n && ldx >= 3 * (int64_t)cin))
+  if (x3cat && !(dz16 && x16 && wgrad_x3cat_ok(n, cin, kw, pad_left) && variant == 8 && lddz >= 2 * (int64_t)n && ldx >= 2 * (int64_t)cin))
     return STYLER_EINVAL;
   wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, want_splits, 1, x3cat ? 3 : 1);
   const int nt = (n + 64 * TA - 1) / (64 * TA), ct = (cin + 64 * TB - 1) / (64 * TB), tiles = nt * ct;

@@ -218,9 +218,12 @@ __device__ __forceinline__ void conv_gemm_body(const GemmArgs& a, const int bid_
 
   auto load_a = [&](int cc) {
     const int c0 = cc * BK;
-    int64_t rec = ((M - mbase - 1) * a.ldx + (a.cin - c0)) * A_ES;
+    // (compact bf16x3 activations, a.x3n1: the row holds [hi | lo]; the chunks of the third product read hi again)
+    const int cs = (a.x3n1 && cc >= 2 * a.x3n1) ? c0 - 2 * a.x3n1 * BK : c0;
+    const int ccols = a.x3n1 ? 2 * a.x3n1 * BK : a.cin;                // columns a row really has
+    int64_t rec = ((M - mbase - 1) * a.ldx + (ccols - cs)) * A_ES;
     rec = rec > REC_MAX ? REC_MAX : rec;
-    const char* abase = reinterpret_cast<const char*>(a.x) + (mbase * a.ldx + c0) * A_ES;
+    const char* abase = reinterpret_cast<const char*>(a.x) + (mbase * a.ldx + cs) * A_ES;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(abase), 0, (int)rec, 0x00020000);
     const uint32_t v = c0 + a_col < a.cin ? va0 : OOB;
 #pragma unroll
@@ -745,6 +748,10 @@ int styler_conv_gemm_impl2(const float* x, int64_t ldx, const void* w, const flo
   GemmArgs a{x, ldx, w, scale, shift, res, ldres, y, ldy, B, L, cin, n, kw, act, pad, len, 0, 0,
              reinterpret_cast<const int2*>(rowinfo), mask, ldmask, m16 ? 1 : 0, g_gemm_trace};
   a.res16 = r16 ? 1 : 0;
+  if (io_flags & STYLER_IO_X3A) {                  // compact bf16x3 activation rows [hi | lo]: whole 64-channel chunks per part
+    if (prec != STYLER_PREC_BF16 || !x16 || (cin % 192) || ldx < 2 * (int64_t)(cin / 3)) return STYLER_EINVAL;
+    a.x3n1 = cin / 192;
+  }
   hipStream_t st = (hipStream_t)stream;
   void* ws = nullptr;
   int64_t ws_bytes = 0;

@@ -402,12 +402,14 @@ extern "C" int styler_copy_rows_multi(const StylerCopySeg* segs, int count, void
 // The parity-grade arithmetic on the bf16 matrix cores: a value is carried as hi + lo (hi = bf16(v), lo = bf16(v - hi): 16
 // mantissa bits) and a product a * w as a_hi w_hi + a_hi w_lo + a_lo w_hi (fp32 accumulate; the dropped a_lo w_lo term is
 // 2^-18 relative).  The three products are ONE bf16 GEMM over a contraction axis three times as long: the activation
-// row [hi | hi | lo] (this kernel) against the weight row [w_hi | w_lo | w_hi] (runtime.gemm_weight), so every bf16 GEMM
-// engine of the library -- 128 x 128, 256 x 256 LDS-DMA -- computes it unchanged.
-//   y[row, 0:C] = y[row, C:2C] = bf16(x[row]);  y[row, 2C:3C] = bf16(x[row] - float(bf16(x[row])))
+// blocks (hi, lo, hi) against the weight blocks [w_hi | w_hi | w_lo] (runtime.x3), so every bf16 GEMM engine of the library --
+// 128 x 128, 256 x 256 LDS-DMA, the grouped kernel -- computes it unchanged.  Two storage forms of the activation:
+//   compact (C % 64 == 0; STYLER_IO_X3A at the GEMM, which reads the hi block a second time for the third product):
+//     y[row, 0:C] = bf16(x[row]);  y[row, C:2C] = bf16(x[row] - float(bf16(x[row])))                 (4 bytes per element)
+//   triple (any C % 4 == 0):  y[row, 0:C] = y[row, 2C:3C] = hi,  y[row, C:2C] = lo                      (6 bytes per element)
 // `count` (optional, device): rows at or past count[0] are skipped (packed rows: only the valid prefix is ever read).
 __global__ __launch_bounds__(256) void split3_bf16_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y,
-                                                          int64_t rows, int C, const int64_t* __restrict__ count) {
+                                                          int64_t rows, int C, const int64_t* __restrict__ count, int parts) {
   const int nq = C / 4;
   if (count && count[0] < rows) rows = count[0];
   const int64_t total = rows * nq;
@@ -417,20 +419,21 @@ __global__ __launch_bounds__(256) void split3_bf16_kernel(const float* __restric
     const uint32_t h01 = cvt_pk_bf16_rne(v.x, v.y), h23 = cvt_pk_bf16_rne(v.z, v.w);
     const float l0 = v.x - __uint_as_float(h01 << 16), l1 = v.y - __uint_as_float(h01 & 0xffff0000u);
     const float l2 = v.z - __uint_as_float(h23 << 16), l3 = v.w - __uint_as_float(h23 & 0xffff0000u);
-    uint16_t* yr = y + row * (int64_t)(3 * C) + q * 4;
+    uint16_t* yr = y + row * (int64_t)(parts * C) + q * 4;
     const uint2 hi = make_uint2(h01, h23);
     *reinterpret_cast<uint2*>(yr) = hi;
-    *reinterpret_cast<uint2*>(yr + C) = hi;
-    *reinterpret_cast<uint2*>(yr + 2 * C) = make_uint2(cvt_pk_bf16_rne(l0, l1), cvt_pk_bf16_rne(l2, l3));
+    *reinterpret_cast<uint2*>(yr + C) = make_uint2(cvt_pk_bf16_rne(l0, l1), cvt_pk_bf16_rne(l2, l3));
+    if (parts == 3) *reinterpret_cast<uint2*>(yr + 2 * C) = hi;
   }
 }
 
-extern "C" int styler_split3_bf16(const float* x, int64_t ldx, void* y, int64_t rows, int C, const int64_t* count,
+// parts: 3 = the triple form [hi | lo | hi], 2 = the compact form [hi | lo] (see above)
+extern "C" int styler_split3_bf16(const float* x, int64_t ldx, void* y, int64_t rows, int C, const int64_t* count, int parts,
                                   void* stream) {
-  if (!x || !y || rows <= 0 || C <= 0 || (C & 3)) return STYLER_EINVAL;
+  if (!x || !y || rows <= 0 || C <= 0 || (C & 3) || (parts != 2 && parts != 3)) return STYLER_EINVAL;
   if ((ldx & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return STYLER_EALIGN;
   hipLaunchKernelGGL(split3_bf16_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx,
-                     reinterpret_cast<uint16_t*>(y), rows, C, count);
+                     reinterpret_cast<uint16_t*>(y), rows, C, count, parts);
   return launch_status();
 }
 

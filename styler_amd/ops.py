@@ -372,11 +372,14 @@ def unpack_rows(xp, plan):
 # third of the step's split passes).  An entry holds the source tensor too: its memory cannot be handed to another tensor
 # while the entry lives, so (address, shape, strides, version) identifies the VALUES that were split.
 x3_cache = None
+# the compact [hi | lo] split where the channel count allows it (STYLER_X3_COMPACT=0: always the triple form)
+x3_compact = os.environ.get("STYLER_X3_COMPACT", "1") != "0"
 
 
 def split3(x, plan=None):
-    """[.., C] fp32 -> [.., 3C] bf16 rows [hi | hi | lo] (styler_split3_bf16): the activation operand of a bf16x3 GEMM.  With
-    `plan` (packed rows) only the valid prefix is written."""
+    """[.., C] fp32 -> the bf16x3 split of the rows (styler_split3_bf16), the activation operand of a bf16x3 GEMM: the compact
+    [.., 2C] = [hi | lo] when C % 64 == 0 (the GEMM reads hi a second time for the third product, STYLER_IO_X3A), else the
+    triple [.., 3C] = [hi | lo | hi].  With `plan` (packed rows) only the valid prefix is written."""
     cache = x3_cache
     if cache is not None:
         key = (x.data_ptr(), tuple(x.shape), x.stride(), plan is not None)
@@ -385,9 +388,10 @@ def split3(x, plan=None):
             return hit[2]
     C = x.shape[-1]
     rows = x.numel() // C
-    y = torch.empty(*x.shape[:-1], 3 * C, device=x.device, dtype=torch.bfloat16)
+    parts = 2 if (C % 64 == 0 and x3_compact) else 3
+    y = torch.empty(*x.shape[:-1], parts * C, device=x.device, dtype=torch.bfloat16)
     _chk(lib.styler_split3_bf16(_f32(x).data_ptr(), _ld(x), y.data_ptr(), rows, C,
-                                plan.counts.data_ptr() if plan is not None else None, _stream()), "styler_split3_bf16")
+                                plan.counts.data_ptr() if plan is not None else None, parts, _stream()), "styler_split3_bf16")
     if cache is not None:
         cache[key] = (x, x._version, y)
     return y
@@ -405,7 +409,7 @@ def lo_part(x, plan=None):
 
 
 def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, scale=None, res=None,
-              out=None, lens=None, plan=None, mask=None, out_bf16=False):
+              out=None, lens=None, plan=None, mask=None, out_bf16=False, _x3a=False):
     """y = act(scale * conv1d_same(x, w) + bias) (+ res); x [B, L, cin] -> y [B, L, n].
     `w` is the kernel-layout weight [n, kw*cin] (fp32, or bf16 when prec == PREC_BF16).
     Throughput mode only: x, the output (`out_bf16` / a bf16 `out`) and `mask` may be bf16 tensors (the FFN hidden
@@ -414,11 +418,14 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
         # fp32-class products on the bf16 engines: x -> [hi | hi | lo] (3 cin channels) against the weight's [w_hi | w_lo | w_hi]
         # rows (runtime.gemm_weight); everything behind the contraction -- bias, activation, residual, masks -- is unchanged
         x3 = x if x.dtype == torch.bfloat16 else split3(x, plan)      # (a bf16 x is a split3 tensor the caller shares)
-        if w.dtype != torch.bfloat16 or w.shape[-1] != kw * x3.shape[-1] or x3.shape[-1] % 3:
-            raise StylerHipError("bf16x3 GEMM needs the x3 weight layout [n, kw * 3 cin]")
+        cin3 = w.shape[-1] // kw                                       # 3 C
+        if w.dtype != torch.bfloat16 or w.shape[-1] != kw * cin3 or cin3 % 3 or x3.shape[-1] not in (cin3, cin3 // 3 * 2):
+            raise StylerHipError("bf16x3 GEMM needs the x3 weight layout [n, kw * 3 cin] and a split3 activation")
         return conv_gemm(x3, w, bias, kw=kw, n=n, act=act, prec=PREC_BF16, scale=scale, res=res, out=out,
-                         lens=lens, plan=plan, mask=mask, out_bf16=False)
+                         lens=lens, plan=plan, mask=mask, out_bf16=False, _x3a=x3.shape[-1] != cin3)
     B, L, cin = x.shape
+    if _x3a:                                           # compact [hi | lo] rows: the contraction still runs over 3 C channels
+        cin = cin // 2 * 3
     n = w.shape[0] if n is None else n
     if prec == PREC_BF16 and (w.dtype != torch.bfloat16 or cin % 8):
         raise StylerHipError("bf16 GEMM needs a bf16 weight shadow and cin % 8 == 0")
@@ -426,7 +433,7 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
         out = torch.empty(B, L, n, device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     io = (1 if x.dtype == torch.bfloat16 else 0) | (2 if out.dtype == torch.bfloat16 else 0) | \
          (4 if mask is not None and mask.dtype == torch.bfloat16 else 0) | \
-         (8 if res is not None and res.dtype == torch.bfloat16 else 0)
+         (8 if res is not None and res.dtype == torch.bfloat16 else 0) | (IO_X3A if _x3a else 0)
     if io:
         if prec != PREC_BF16:
             raise StylerHipError("bf16 activations only in throughput mode")
@@ -649,6 +656,7 @@ def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, 
     return dot_out if dot_w is not None else out
 
 
+IO_X3A = 1024         # STYLER_IO_X3A: the activation operand of a bf16x3 GEMM is the compact [hi | lo] split
 IO_PARAM_SLOTS = 512  # STYLER_IO_PARAM_SLOTS: parameter gradients leave the kernel as per-block slots (see _param_slots)
 IO_Z_BF16 = 16       # STYLER_IO_Z_BF16: the tensor a norm kernel normalises (a convolution's output) is stored as bf16
 
@@ -953,8 +961,8 @@ LIN128_SPLITS = int(os.environ.get("STYLER_WGRAD_LIN128_SPLITS", "8"))
 
 
 def split3_parts(t3, C):
-    """(hi, lo) bf16 views [.., C] (row stride 3C) of a split3 tensor [.., 3C] = [hi | hi | lo]."""
-    return t3[..., 0:C], t3[..., 2 * C:3 * C]
+    """(hi, lo) bf16 views [.., C] of a split3 tensor ([.., 2C] = [hi | lo] or [.., 3C] = [hi | lo | hi])."""
+    return t3[..., 0:C], t3[..., C:2 * C]
 
 
 IO_X_LO, IO_DZ_LO, IO_X3CAT, IO_DB_SLOTS = 32, 64, 128, 256      # STYLER_IO_X_LO / _DZ_LO / _X3CAT / _DB_SLOTS
@@ -992,9 +1000,9 @@ x3cat = os.environ.get("STYLER_WGRAD_X3CAT", "1") != "0"
 
 
 def _is_split3(hi, lo, C):
-    """(hi, lo) are the views split3_parts makes of ONE [.., 3C] split tensor."""
+    """(hi, lo) are the views split3_parts makes of ONE split tensor (lo right behind hi in every row)."""
     return (hi.dtype == torch.bfloat16 and lo.dtype == torch.bfloat16 and hi.shape == lo.shape and hi.stride() == lo.stride()
-            and hi.stride(-1) == 1 and hi.stride(-2) >= 3 * C and lo.data_ptr() - hi.data_ptr() == 4 * C)
+            and hi.stride(-1) == 1 and hi.stride(-2) >= 2 * C and lo.data_ptr() - hi.data_ptr() == 2 * C)
 
 
 def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=None, db2=None, plan=None, dz_parts=None,

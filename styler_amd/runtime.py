@@ -305,8 +305,8 @@ class _Spec:
 
 def x3(segs, g, W=None):
     """The bf16x3 layout of a derived weight matrix [R, W] whose contraction axis is the minor one, tripled at granularity
-    `g` (W = kw * g for conv taps, W = g otherwise): every block [w] of g elements becomes [w_hi | w_lo | w_hi] -- the partner
-    of the activation block [a_hi | a_hi | a_lo] written by styler_split3_bf16.  `segs` are the Segs of the plain layout; a
+    `g` (W = kw * g for conv taps, W = g otherwise): every block [w] of g elements becomes [w_hi | w_hi | w_lo] -- the partner
+    of the activation blocks (a_hi, a_lo, a_hi) of styler_split3_bf16 (triple form, or compact [hi | lo] + STYLER_IO_X3A).  `segs` are the Segs of the plain layout; a
     destination offset r * W + t * g + c maps to r * 3W + t * 3g + part * g + c, strides that step rows or blocks triple."""
     W = g if W is None else W
 
@@ -321,7 +321,7 @@ def x3(segs, g, W=None):
     out = []
     for sg in segs:
         assert all(st == 0 or st % g == 0 or abs(st) == 1 for st in sg.dstr), (sg.dstr, g)
-        for part, lo in ((0, False), (1, True), (2, False)):
+        for part, lo in ((0, False), (1, False), (2, True)):
             out.append(Seg(sg.src, sg.dims, sg.sstr, tuple(stride(st) for st in sg.dstr), src_off=sg.src_off,
                            dst_off=off(sg.dst_off) + part * g, src2=sg.src2, lo=lo))
     return out
@@ -332,7 +332,7 @@ def gemm_weight(cache, key, weight, cin):
     n = weight.shape[0]
     kdim = weight.numel() // n
     if rt.prec == ops.PREC_BF16X3 and cin % 8 == 0:
-        # [n, kw, 3 cin]: per tap [w_hi | w_lo | w_hi] (x3): rows of `cin` elements inside a destination row of kw * cin
+        # [n, kw, 3 cin]: per tap [w_hi | w_hi | w_lo] (x3): rows of `cin` elements inside a destination row of kw * cin
         wx = cache.get_spec(key + ":x3", (n, 3 * kdim), True, lambda: x3([seg_conv_fwd(weight)], cin, kdim))
         return wx, ops.PREC_BF16X3
     if rt.prec == ops.PREC_BF16 and cin % 8 == 0:
