@@ -153,11 +153,13 @@ int styler_conv_gemm_variant(int B, int L, int cin, int n, int kw, int prec);
 /* Up to 8 INDEPENDENT small GEMMs in one launch (bf16 MFMA, 64 x 64 tile, k = 1, fp32 activations in / out; bf16 weight
  * shadows [n, cin], cin % 8 == 0): y_p = act(scale_p * x_p w_p^T + shift_p) (+ res_p), as styler_conv_gemm computes each.
  * The nn.Linear launches of the S-domain that do not depend on one another (modules.py:179-182 -- the four BiLSTMs' input
- * projections; 250-271, 335-348 -- the style MLPs; 23-45 -- the classifiers' first Linear). */
+ * projections; 250-271, 335-348 -- the style MLPs; 23-45 -- the classifiers' first Linear).
+ * `flags` (the same for every member of a launch): bit 0 = x is bf16 (ldx in elements, ldx % 8 == 0); bit 1 = x is the
+ * compact bf16x3 split [hi | lo] (cin = 3 C, C % 64 == 0: STYLER_IO_X3A) -- the grouped launches of the bf16x3 arithmetic. */
 typedef struct StylerGemmProblem {
   const void* x; const void* w; const void* scale; const void* shift; const void* res; void* y; const void* len;
   int64_t ldx, ldres, ldy;
-  int32_t B, L, cin, n, act, _pad;
+  int32_t B, L, cin, n, act, flags;
 } StylerGemmProblem;
 int styler_conv_gemm_group(const StylerGemmProblem* probs, int count, void* stream);
 int styler_conv_gemm_engine(int B, int L, int cin, int n, int kw, int prec, int io_flags, int64_t ldx, int packed);

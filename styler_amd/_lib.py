@@ -146,7 +146,7 @@ class WgradGroupDesc(ctypes.Structure):
 class GemmProblem(ctypes.Structure):
     _fields_ = [(k, ctypes.c_void_p) for k in ("x", "w", "scale", "shift", "res", "y", "len")] + \
                [(k, ctypes.c_int64) for k in ("ldx", "ldres", "ldy")] + \
-               [(k, ctypes.c_int32) for k in ("B", "L", "cin", "n", "act", "_pad")]
+               [(k, ctypes.c_int32) for k in ("B", "L", "cin", "n", "act", "flags")]
 
 
 class ActSeg(ctypes.Structure):

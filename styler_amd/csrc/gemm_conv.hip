@@ -596,6 +596,14 @@ __global__ __launch_bounds__(256) void conv_gemm_group_kernel(const GemmGroup g)
   for (int i = 1; i < 8; ++i) p += (i < g.n && (int)blockIdx.x >= g.start[i]) ? 1 : 0;
   conv_gemm_body<1, 1, true, true, false, false, false, 2, 1>(g.a[p], (int)blockIdx.x - g.start[p]);
 }
+// ... with bf16 activations in (StylerGemmProblem.flags bit 0): the grouped launches of the bf16x3 arithmetic, whose members
+// read split activations (GemmArgs.x3n1 for the compact form)
+__global__ __launch_bounds__(256) void conv_gemm_group16_kernel(const GemmGroup g) {
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i) p += (i < g.n && (int)blockIdx.x >= g.start[i]) ? 1 : 0;
+  conv_gemm_body<1, 1, true, true, false, true, false, 2, 2>(g.a[p], (int)blockIdx.x - g.start[p]);
+}
 
 template <int TM, int TN, bool BF16, int WM = 2>
 static int launch_gemm(GemmArgs a, hipStream_t st, int x16, int y16) {
@@ -641,10 +649,12 @@ extern "C" int styler_conv_gemm_group(const StylerGemmProblem* probs, int count,
   if (!probs || count <= 0 || count > 8) return STYLER_EINVAL;
   GemmGroup g;
   int start = 0;
+  const int x16 = probs[0].flags & 1;
   for (int k = 0; k < count; ++k) {
     const StylerGemmProblem& p = probs[k];
     if (!p.x || !p.w || !p.y || p.B <= 0 || p.L <= 0 || p.cin <= 0 || p.n <= 0) return STYLER_EINVAL;
-    if ((p.cin & 7) || (p.ldx & 3) || ((uintptr_t)p.x & 15) || ((uintptr_t)p.w & 15)) return STYLER_EALIGN;
+    if ((p.flags & 1) != x16 || ((p.flags & 2) && (!x16 || (p.cin % 192) || p.ldx < 2 * (int64_t)(p.cin / 3)))) return STYLER_EINVAL;
+    if ((p.cin & 7) || (p.ldx & (x16 ? 7 : 3)) || ((uintptr_t)p.x & 15) || ((uintptr_t)p.w & 15)) return STYLER_EALIGN;
     if ((p.n & 3) || (p.ldy & 3) || ((uintptr_t)p.y & 15) || (p.res && ((p.ldres & 3) || ((uintptr_t)p.res & 15)))) return STYLER_EALIGN;
     if ((int64_t)p.B * p.L >= ((int64_t)1 << 31) || p.ldy >= (1 << 22) || p.ldres >= (1 << 22)) return STYLER_EINVAL;
     GemmArgs a{p.x, p.ldx, p.w, reinterpret_cast<const float*>(p.scale), reinterpret_cast<const float*>(p.shift),
@@ -653,6 +663,7 @@ extern "C" int styler_conv_gemm_group(const StylerGemmProblem* probs, int count,
     const int64_t M = (int64_t)p.B * p.L;
     a.mt = (int)((M + 63) / 64);
     a.nt = (p.n + 63) / 64;
+    if (p.flags & 2) a.x3n1 = p.cin / 192;
     g.a[k] = a;
     g.start[k] = start;
     start += ((a.mt + 7) / 8) * 8 * a.nt;
@@ -660,7 +671,8 @@ extern "C" int styler_conv_gemm_group(const StylerGemmProblem* probs, int count,
   for (int k = count; k < 9; ++k) g.start[k] = start;
   for (int k = count; k < 8; ++k) g.a[k] = g.a[0];
   g.n = count;
-  hipLaunchKernelGGL(conv_gemm_group_kernel, dim3((unsigned)start), dim3(256), 0, (hipStream_t)stream, g);
+  if (x16) hipLaunchKernelGGL(conv_gemm_group16_kernel, dim3((unsigned)start), dim3(256), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL(conv_gemm_group_kernel, dim3((unsigned)start), dim3(256), 0, (hipStream_t)stream, g);
   return launch_status();
 }
 

@@ -374,6 +374,8 @@ def unpack_rows(xp, plan):
 x3_cache = None
 # the compact [hi | lo] split where the channel count allows it (STYLER_X3_COMPACT=0: always the triple form)
 x3_compact = os.environ.get("STYLER_X3_COMPACT", "1") != "0"
+# bf16x3 mode: independent small Linears as grouped launches (STYLER_X3_GROUPED=0: one launch per Linear)
+x3_grouped = os.environ.get("STYLER_X3_GROUPED", "1") != "0"
 
 
 def split3(x, plan=None):
@@ -475,9 +477,10 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
 
 def conv_gemm_multi(calls):
     """Several INDEPENDENT Linear-shaped GEMMs -> list of outputs.  `calls`: dicts with the keyword arguments of `conv_gemm`
-    (x, w, bias, n, act, prec, scale, res, out).  In throughput mode the members that take the 64 x 64 bf16 tile (k = 1, fp32
-    activations in and out) run as ONE launch (styler_conv_gemm_group, <= 8 members each); anything else -- other
-    precisions, large shapes, bf16 storage -- is launched one by one."""
+    (x, w, bias, n, act, prec, scale, res, out).  The members that take the 64 x 64 bf16 tile (k = 1) run as ONE launch
+    (styler_conv_gemm_group, <= 8 members each): in throughput mode those with fp32 activations in and out, in the bf16x3
+    arithmetic every member (its activation is split first; the grouped kernel reads the split, STYLER_IO_X3A for the
+    compact form); anything else -- fp32 mode, large shapes, bf16 storage -- is launched one by one."""
     from ._lib import GemmProblem
     outs = [None] * len(calls)
     group = []
@@ -485,34 +488,46 @@ def conv_gemm_multi(calls):
         x, w = c["x"], c["w"]
         B, L, cin = x.shape
         n = c.get("n") or w.shape[0]
-        ok = (c.get("prec") == PREC_BF16 and w.dtype == torch.bfloat16 and x.dtype == torch.float32 and cin % 8 == 0
-              and w.shape[-1] == cin and gemm_profiler is None
-              and (c.get("res") is None or c["res"].dtype == torch.float32)
-              and not (lib.styler_conv_gemm_variant(B, L, cin, n, 1, PREC_BF16) & 1))
+        x3m = c.get("prec") == PREC_BF16X3 and w.dtype == torch.bfloat16 and x3_grouped and gemm_profiler is None
+        if x3m:
+            xs = x if x.dtype == torch.bfloat16 else split3(x)        # (a bf16 x is a split3 tensor the caller shares)
+            cin = w.shape[-1]                                          # 3 C: the contraction the kernel walks
+            flags = 1 | (2 if xs.shape[-1] != cin else 0)
+            ok = (cin % 3 == 0 and xs.shape[-1] in (cin, cin // 3 * 2) and cin % 8 == 0 and _ld(xs) % 8 == 0
+                  and (c.get("res") is None or c["res"].dtype == torch.float32)
+                  and not (lib.styler_conv_gemm_variant(B, L, cin, n, 1, PREC_BF16) & 1))
+            if ok:
+                x = xs
+        else:
+            flags = 0
+            ok = (c.get("prec") == PREC_BF16 and w.dtype == torch.bfloat16 and x.dtype == torch.float32 and cin % 8 == 0
+                  and w.shape[-1] == cin and gemm_profiler is None
+                  and (c.get("res") is None or c["res"].dtype == torch.float32)
+                  and not (lib.styler_conv_gemm_variant(B, L, cin, n, 1, PREC_BF16) & 1))
         if not ok:
-            outs[i] = conv_gemm(x, w, c.get("bias"), n=n, act=c.get("act", ACT_NONE), prec=c.get("prec", PREC_F32),
+            outs[i] = conv_gemm(c["x"], w, c.get("bias"), n=n, act=c.get("act", ACT_NONE), prec=c.get("prec", PREC_F32),
                                 scale=c.get("scale"), res=c.get("res"), out=c.get("out"))
             continue
         out = c.get("out")
         if out is None:
             out = torch.empty(B, L, n, device=x.device, dtype=torch.float32)
         outs[i] = out
-        group.append((c, out, B, L, cin, n))
+        group.append((c, out, B, L, cin, n, x, flags))
     for j in range(0, len(group), 8):
         part = group[j:j + 8]
         if len(part) == 1:
-            c, out, B, L, cin, n = part[0]
-            conv_gemm(c["x"], c["w"], c.get("bias"), n=n, act=c.get("act", ACT_NONE), prec=PREC_BF16, scale=c.get("scale"),
-                      res=c.get("res"), out=out)
+            c, out, B, L, cin, n, x, flags = part[0]
+            conv_gemm(c["x"], c["w"], c.get("bias"), n=n, act=c.get("act", ACT_NONE), prec=c.get("prec", PREC_BF16),
+                      scale=c.get("scale"), res=c.get("res"), out=out)
             continue
         arr = (GemmProblem * len(part))()
-        for k, (c, out, B, L, cin, n) in enumerate(part):
-            x, res = _f32(c["x"]), c.get("res")
+        for k, (c, out, B, L, cin, n, x, flags) in enumerate(part):
+            x, res = (x if flags else _f32(x)), c.get("res")
             m = arr[k]
             m.x, m.w, m.scale, m.shift, m.res, m.y, m.len = (x.data_ptr(), c["w"].data_ptr(), _ptr(c.get("scale")),
                                                              _ptr(c.get("bias")), _ptr(res), out.data_ptr(), None)
             m.ldx, m.ldres, m.ldy = _ld(x), (_ld(res) if res is not None else 0), _ld(out)
-            m.B, m.L, m.cin, m.n, m.act = B, L, cin, n, c.get("act", ACT_NONE)
+            m.B, m.L, m.cin, m.n, m.act, m.flags = B, L, cin, n, c.get("act", ACT_NONE), flags
         _chk(lib.styler_conv_gemm_group(arr, len(part), _stream()), "styler_conv_gemm_group")
     return outs
 
