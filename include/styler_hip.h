@@ -439,6 +439,10 @@ int styler_add_rowvec(const float* a, int64_t lda, const float* v, int64_t ldv, 
 int styler_split3_bf16(const float* x, int64_t ldx, void* y, int64_t rows, int C, const int64_t* count, int parts,
                        void* stream);
 int styler_lo_part(const float* x, int64_t ldx, float* y, int64_t rows, int C, const int64_t* count, void* stream);
+/* Up to 8 styler_split3_bf16 passes in one launch: seg.src = fp32 rows (ld_src), seg.dst = the bf16 split (contiguous rows of
+ * parts * C), seg.rows, seg.C, seg._pad = parts (2 or 3); ld_dst is ignored. */
+struct StylerCopySeg;
+int styler_split3_multi(const struct StylerCopySeg* segs, int count, void* stream);
 /* Up to 8 strided row copies in one launch (the descriptors travel in the kernel arguments): segment k copies `rows` rows of
  * `C` floats (C % 4 == 0) from src (row stride ld_src; NULL = zero fill) to dst (row stride ld_dst).  The torch.cat /
  * torch.split plumbing of modules.py:218-223,350,362 and the gathered slice gradients of their backward: one launch per

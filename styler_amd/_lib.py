@@ -63,6 +63,7 @@ _SIGS = {
     "styler_masked_err_mean_multi": [P, I, P],
     "styler_masked_err_bwd_multi": [P, I, P],
     "styler_split3_bf16": [P, I64, P, I64, I, P, I, P],
+    "styler_split3_multi": [P, I, P],
     "styler_lo_part": [P, I64, P, I64, I, P, P],
     "styler_add_rowvec": [P, I64, P, I64, P, I64, I, I, I, P],
     "styler_length_mask": [P, P, I, I, P],

@@ -437,6 +437,57 @@ extern "C" int styler_split3_bf16(const float* x, int64_t ldx, void* y, int64_t 
   return launch_status();
 }
 
+// Up to 8 of those splits in ONE launch (segments by value in the kernel arguments, as styler_copy_rows_multi): the S-domain
+// of the bf16x3 step splits dozens of [B S, 256..1280] tensors of a few microseconds each.  seg.src fp32 rows (ld_src),
+// seg.dst the bf16 split (contiguous rows of parts * C), seg._pad = parts (2 or 3).
+struct SplitSegs {
+  const float* src[8];
+  uint16_t* dst[8];
+  int64_t lds[8], rows[8];
+  int32_t C[8], parts[8];
+  int32_t n;
+};
+__global__ __launch_bounds__(256) void split3_multi_kernel(const SplitSegs g) {
+  const int k = blockIdx.y;
+  if (k >= g.n) return;
+  const float* __restrict__ x = g.src[k];
+  uint16_t* __restrict__ y = g.dst[k];
+  const int C = g.C[k], parts = g.parts[k], nq = C / 4;
+  const int64_t total = g.rows[k] * nq, ldx = g.lds[k];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / nq; const int q = (int)(i - row * nq);
+    const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + q * 4);
+    const uint32_t h01 = cvt_pk_bf16_rne(v.x, v.y), h23 = cvt_pk_bf16_rne(v.z, v.w);
+    const float l0 = v.x - __uint_as_float(h01 << 16), l1 = v.y - __uint_as_float(h01 & 0xffff0000u);
+    const float l2 = v.z - __uint_as_float(h23 << 16), l3 = v.w - __uint_as_float(h23 & 0xffff0000u);
+    uint16_t* yr = y + row * (int64_t)(parts * C) + q * 4;
+    const uint2 hi = make_uint2(h01, h23);
+    *reinterpret_cast<uint2*>(yr) = hi;
+    *reinterpret_cast<uint2*>(yr + C) = make_uint2(cvt_pk_bf16_rne(l0, l1), cvt_pk_bf16_rne(l2, l3));
+    if (parts == 3) *reinterpret_cast<uint2*>(yr + 2 * C) = hi;
+  }
+}
+
+extern "C" int styler_split3_multi(const StylerCopySeg* segs, int count, void* stream) {
+  if (!segs || count <= 0 || count > 8) return STYLER_EINVAL;
+  SplitSegs g;
+  int64_t most = 0;
+  for (int k = 0; k < count; ++k) {
+    const StylerCopySeg& s = segs[k];
+    if (!s.src || !s.dst || s.rows <= 0 || s.C <= 0 || (s.C & 3) || (s._pad != 2 && s._pad != 3)) return STYLER_EINVAL;
+    if ((s.ld_src & 3) || ((uintptr_t)s.src & 15) || ((uintptr_t)s.dst & 7)) return STYLER_EALIGN;
+    g.src[k] = reinterpret_cast<const float*>(s.src); g.dst[k] = reinterpret_cast<uint16_t*>(s.dst);
+    g.lds[k] = s.ld_src; g.rows[k] = s.rows; g.C[k] = s.C; g.parts[k] = s._pad;
+    const int64_t t = s.rows * (s.C / 4);
+    most = t > most ? t : most;
+  }
+  g.n = count;
+  int64_t bx = (most + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(split3_multi_kernel, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, (hipStream_t)stream, g);
+  return launch_status();
+}
+
 // y = x - float(bf16(x)), rounded to bf16 and stored as fp32 (exactly representable): the low part of an operand of the
 // weight-gradient GEMMs in the bf16x3 arithmetic, in the format every wgrad kernel variant accepts.
 __global__ __launch_bounds__(256) void lo_part_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,

@@ -399,6 +399,42 @@ def split3(x, plan=None):
     return y
 
 
+def split3_multi(xs):
+    """split3 of several tensors (no packed plan) with ONE launch per eight that are not in the step's split cache."""
+    from ._lib import CopySeg
+    outs, todo = [None] * len(xs), []
+    cache = x3_cache
+    for i, x in enumerate(xs):
+        key = (x.data_ptr(), tuple(x.shape), x.stride(), False)
+        hit = cache.get(key) if cache is not None else None
+        if hit is not None and hit[1] == x._version:
+            outs[i] = hit[2]
+            continue
+        C = x.shape[-1]
+        parts = 2 if (C % 64 == 0 and x3_compact) else 3
+        y = torch.empty(*x.shape[:-1], parts * C, device=x.device, dtype=torch.bfloat16)
+        outs[i] = y
+        todo.append((_f32(x), y, parts, key))
+    for j in range(0, len(todo), 8):
+        part = todo[j:j + 8]
+        if len(part) == 1:
+            x, y, parts, _ = part[0]
+            C = x.shape[-1]
+            _chk(lib.styler_split3_bf16(x.data_ptr(), _ld(x), y.data_ptr(), x.numel() // C, C, None, parts, _stream()),
+                 "styler_split3_bf16")
+            continue
+        arr = (CopySeg * len(part))()
+        for k, (x, y, parts, _) in enumerate(part):
+            C = x.shape[-1]
+            arr[k].src, arr[k].dst, arr[k].ld_src, arr[k].ld_dst = x.data_ptr(), y.data_ptr(), _ld(x), parts * C
+            arr[k].rows, arr[k].C, arr[k]._pad = x.numel() // C, C, parts
+        _chk(lib.styler_split3_multi(arr, len(part), _stream()), "styler_split3_multi")
+    if cache is not None:
+        for x, y, _, key in todo:
+            cache[key] = (x, x._version, y)
+    return outs
+
+
 def lo_part(x, plan=None):
     """bf16(x - float(bf16(x))) stored as fp32 (styler_lo_part): the low operand of a bf16x3 weight gradient."""
     C = x.shape[-1]
@@ -484,6 +520,10 @@ def conv_gemm_multi(calls):
     from ._lib import GemmProblem
     outs = [None] * len(calls)
     group = []
+    if x3_grouped and gemm_profiler is None and x3_cache is not None:   # bf16x3 members: their activation splits in one launch (kept in the step's cache)
+        need = [c["x"] for c in calls if c.get("prec") == PREC_BF16X3 and c["x"].dtype == torch.float32 and c["x"].dim() == 3]
+        if len(need) > 1:
+            split3_multi(need)
     for i, c in enumerate(calls):
         x, w = c["x"], c["w"]
         B, L, cin = x.shape
