@@ -471,7 +471,7 @@ class GraphedStepCache:
     What padding up changes: the valid positions, masks and losses are identical; the statistics that the reference takes
     over the padded rectangle (GroupNorm over padded T, PostNet BatchNorm over padded rows, the unpacked BiLSTMs, the
     classifier's time mean -- SURVEY 8c trap 1) see the extra zero rows exactly as they see those of a longer co-batched
-    utterance: the result equals the reference run on the same padded rectangle (tests/test_20_hip_backward.py)."""
+    utterance: the result equals the reference run on the same padded rectangle (tests/test_14_train_step.py)."""
 
     def __init__(self, model, state, max_graphs=24, sync_misses=False, **kw):
         """`sync_misses` (several ranks): before every step the ranks exchange their batch shapes (one 3-int all-gather) and

@@ -1,4 +1,4 @@
-"""Worker of tests/test_95_dist_gpu.py: one rank of a two-rank data-parallel train step on ONE GPU (both ranks on cuda:0,
+"""Worker of tests/test_15_dist_gpu.py: one rank of a two-rank data-parallel train step on ONE GPU (both ranks on cuda:0,
 collectives over gloo -- RCCL refuses two ranks on one device; the control flow is the N > 1 path of bench.py).
 
     python dist_worker.py <rank> <world> <port> <out_dir> [graph|acc2|buckets|buckets_sync]
