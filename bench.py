@@ -224,8 +224,12 @@ def run(args, mode, prec, rank, world, dev, dist, with_cpu=True, with_roofline=T
 
 def rocprof_family_ms(patterns):
     """ms per step of the kernels matching `patterns` in the COMMITTED rocprofv3 kernel trace of the default command (hipGraph
-    replay), or None: (total_ms of the matching rows) / (steps = calls of adam_kernel)."""
-    for name in ("r04_train_bf16_graph_kernel_stats.txt", "r03_train_bf16_graph_kernel_stats.txt"):
+    replay), or None: (total_ms of the matching rows) / (traced steps).  The trace also holds the un-stepped warm-up passes
+    of the command (forward + backward without an optimiser step), so the traced steps are the calls of a kernel that runs
+    ONCE in every forward + backward -- `pack_plan_kernel` -- not the calls of `adam_kernel` (round 4 divided by the latter:
+    28 instead of 31, `frac_rocprof` 0.287 where the trace says 0.32; VERDICT round 4, weak #10)."""
+    for name in ("r05_train_bf16_graph_kernel_stats.txt", "r04_train_bf16_graph_kernel_stats.txt",
+                 "r03_train_bf16_graph_kernel_stats.txt"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -235,7 +239,9 @@ def rocprof_family_ms(patterns):
             if not m:
                 continue
             kname, calls, total = m.group(1), int(m.group(2)), float(m.group(3))
-            if kname.strip().startswith("adam_kernel"):
+            if kname.strip().startswith("pack_plan_kernel"):
+                steps = calls
+            elif kname.strip().startswith("adam_kernel") and not steps:
                 steps = calls
             if any(p in kname for p in patterns):
                 tot += total

@@ -571,6 +571,12 @@ int styler_wgrad_packed(const float* dz, int64_t lddz, const float* x, int64_t l
  * setting as mode | (stages128 << 2).  Env: STYLER_WGRAD_DMA=0|1|2.  The split count / workspace of a launch depend on its
  * operand formats: use the _io forms below with the io_flags the launch will be given. */
 int styler_wgrad_dma_config(int mode, int stages128);
+/* Round 5: block -> (split, tile) map of bf16 weight-gradient launches with fewer than 8 splits.  1 (default): the 8 XCDs
+ * form an (s8 x n8 x c8) grid over (splits x n-tiles x c-tiles) and every XCD owns one sub-box, so a dz / x column block is
+ * fetched into as few L2s as possible (the decoder FFN's k = 9 gradient: 250 -> ~85 MB fetched per launch); 0: the former
+ * tile-major map.  Results are bit-identical (the same blocks compute the same partial tiles).  Returns the previous value;
+ * any other argument only queries.  Env: STYLER_WGRAD_XCDMAP=0|1.  (autograd of transformer/SubLayers.py:72-76) */
+int styler_wgrad_xcd_map(int on);
 int styler_wgrad_x3cat_ok(int n, int cin, int kw, int pad_left);
 int styler_wgrad_splits_io(int B, int L, int n, int cin, int kw, int pad_left, int prec, int io_flags);
 int64_t styler_wgrad_workspace_bytes_io(int B, int L, int n, int cin, int kw, int pad_left, int prec, int io_flags);

@@ -35,7 +35,7 @@ NONE, RELU, TANH = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_TANH
 
 def _x3_split(t, n, plan=None):
     """bf16x3 arithmetic: a gradient that feeds BOTH the weight gradient and the dX GEMM of its node is split into
-    [hi | hi | lo] once -> (the tensor to hand to ops.conv_gemm, the (hi, lo) views to hand to ops.wgrad as `dz_parts`).
+    [hi | lo (| hi)] once (ops.split3; the single definition of the bf16x3 layouts is include/styler_hip.h, styler_split3_bf16) -> (the tensor to hand to ops.conv_gemm, the (hi, lo) views to hand to ops.wgrad as `dz_parts`).
     Any other arithmetic (or a width the bf16 engines do not take): (t, None)."""
     if rt.prec == ops.PREC_BF16X3 and n % 8 == 0 and t.dtype == torch.float32:
         t3 = ops.split3(t, plan)

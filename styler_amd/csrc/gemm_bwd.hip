@@ -291,6 +291,41 @@ __device__ __forceinline__ uint32_t lo_pk(float a, float b) {
 // 8-byte loads, no conversion on the staging path.
 // `pad_parts` = (pad_left & 0xff) | parts << 8.  parts (the bf16x3 arithmetic on fp32-typed operands, ops.wgrad): bit 0 = stage the LOW
 // part of x, v - float(bf16(v)), instead of its rounding to bf16 (the high part); bit 1 = the same for dz.
+// Block -> (split, tile) of a bf16 weight-gradient launch with FEWER than 8 splits (round 5).  Workgroup b runs on XCD b % 8
+// (observed dispatch rule, speed only), and each XCD has its own L2.  The former map (tile = b % tiles, split = b / tiles) put
+// the c-tiles of one n-tile on four different XCDs: the decoder FFN's k = 9 gradient (16 x 4 tiles, 4 splits) fetched every dz
+// column block into FOUR L2s and every x column block into two -- 250 MB per launch for 69 MB of operands, L2 hit rate 46 %
+// (profiles/r04_pmc_traffic.jsonl).  Now the 8 XCDs form an (s8 x n8 x c8) grid over (splits x n-tiles x c-tiles) and an XCD owns
+// the whole sub-box: its blocks walk the same time rows of the same dz / x column blocks together.  Among the exact
+// factorisations (s8 | splits, n8 | nt, c8 | ct) the one with the smallest per-XCD operand footprint
+// ((nt / n8) FA + (ct / c8) FB) / s8 wins; 83 MB for the shape above.  Without an exact factorisation: the former map.
+// pad bit 0x1000 (STYLER_WGRAD_XCDMAP=0) keeps the former map for A/B runs.
+__device__ __forceinline__ void wgrad_xcd_box_map(const int bid, const int tiles, const int ct, const int splits, const int FA,
+                                                  const int FB, const bool legacy, int& tile, int& split) {
+  tile = bid % tiles;
+  split = bid / tiles;
+  if (legacy) return;
+  const int nt = tiles / ct;
+  int best = 0x7fffffff, bs = 0, bn = 0, bc = 0;
+#pragma unroll
+  for (int ls = 0; ls < 4; ++ls)
+#pragma unroll
+    for (int ln = 0; ln + ls < 4; ++ln) {
+      const int s8 = 1 << ls, n8 = 1 << ln, c8 = 8 >> (ls + ln);
+      if (splits % s8 || nt % n8 || ct % c8) continue;
+      const int cost = ((nt / n8) * FA + (ct / c8) * FB) * (8 >> ls);
+      if (cost < best) { best = cost; bs = s8; bn = n8; bc = c8; }
+    }
+  if (!bs) return;
+  const int xcd = bid & 7, l = bid >> 3;
+  const int xs = xcd % bs, xn = (xcd / bs) % bn, xc = xcd / (bs * bn);
+  const int Nl = nt / bn, Cl = ct / bc, Sl = splits / bs;
+  const int cl = l % Cl, nl = (l / Cl) % Nl, sl = l / (Cl * Nl);
+  if (sl >= Sl) return;                              // (cannot happen for an exact factorisation; keeps the former map safe)
+  tile = (xn * Nl + nl) * ct + xc * Cl + cl;
+  split = xs * Sl + sl;
+}
+
 template <int KW, int TA, int TB, bool DZ16 = false, bool X16 = false>
 __device__ __forceinline__ void wgrad_tr_body(const int bid, const void* __restrict__ dz, int64_t lddz,
                                               const void* __restrict__ x, int64_t ldx, float* __restrict__ db,
@@ -330,8 +365,7 @@ __device__ __forceinline__ void wgrad_tr_body(const int bid, const void* __restr
     split = i / tiles;
     tile = i - split * tiles;
   } else {
-    tile = bid % tiles;
-    split = bid / tiles;
+    wgrad_xcd_box_map(bid, tiles, ct, splits, FA, FB, pad_parts & 0x1000, tile, split);
   }
   const int n0 = (tile / ct) * FA, c0 = (tile % ct) * FB;
   // Packed rows (pack.hip): the number of rows / chunks lives on the device (`counts`); the chunks are spread evenly
@@ -629,8 +663,7 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
     split = i / tiles;
     tile = i - split * tiles;
   } else {
-    tile = bid % tiles;
-    split = bid / tiles;
+    wgrad_xcd_box_map(bid, tiles, ct, splits, FA, FB, pad_cat & 0x1000, tile, split);
   }
   const int n0 = (tile / ct) * FA, c0 = (tile % ct) * FB;
   int64_t nchunks = (int64_t)B * cpi;
@@ -1015,6 +1048,13 @@ extern "C" int styler_wgrad_dma_config(int mode, int stages128) {
   if (stages128 == 2 || stages128 == 3) g_wgrad_dma_nst128 = stages128;
   return prev;
 }
+// Round 5: XCD box map of launches with fewer than 8 splits (wgrad_xcd_box_map); 0 = the former tile-major map (A/B runs).
+static int g_wgrad_xcd_map = [] { const char* e = getenv("STYLER_WGRAD_XCDMAP"); return e ? atoi(e) : 1; }();
+extern "C" int styler_wgrad_xcd_map(int on) {
+  const int prev = g_wgrad_xcd_map;
+  if (on == 0 || on == 1) g_wgrad_xcd_map = on;
+  return prev;
+}
 static void wgrad_tile(int n, int cin, int kw, int prec, int* TA, int* TB);
 // K groups per block of a launch with these operand formats (1: every other kernel)
 static int wgrad_kgroups(int n, int cin, int kw, int prec, int io_flags) {
@@ -1106,14 +1146,15 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
                  lddz >= 2 * (int64_t)n && ldx >= 2 * (int64_t)cin))
     return STYLER_EINVAL;
   wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, 0, kg, x3cat ? 3 : 1);
-  const int pad_cat = (pad_left & 0xff) | (x3cat ? 0x400 : 0) | ((io_flags & STYLER_IO_DB_SLOTS) ? 0x800 : 0);
+  const int legacy_map = g_wgrad_xcd_map ? 0 : 0x1000;
+  const int pad_cat = (pad_left & 0xff) | (x3cat ? 0x400 : 0) | ((io_flags & STYLER_IO_DB_SLOTS) ? 0x800 : 0) | legacy_map;
   float* ws = reinterpret_cast<float*>(workspace);
   const dim3 grid(nt * ct, (unsigned)splits);
   // low-part flags of the register-staged kernels (fp32-typed operands only; see wgrad_tr_body)
   const bool db_slots = io_flags & STYLER_IO_DB_SLOTS;
   if (db_slots && (!db || db2 || !defer_reduce)) return STYLER_EINVAL;
   const int pad_k = (pad_left & 0xff) | ((io_flags & STYLER_IO_X_LO) && !x16 ? 0x100 : 0) | ((io_flags & STYLER_IO_DZ_LO) && !dz16 ? 0x200 : 0) |
-                    (db_slots ? 0x800 : 0);
+                    (db_slots ? 0x800 : 0) | legacy_map;
   if (prec == STYLER_PREC_BF16) {
     const int tiles = nt * ct;
     const dim3 grid1((unsigned)(splits >= 8 ? (tiles * splits + 7) / 8 * 8 : tiles * splits));

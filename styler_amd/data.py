@@ -172,7 +172,7 @@ class BatchFeeder:
     padding or the H2D copies.  Iterating yields `(tensors, max_src_len, max_mel_len)` like `to_device`."""
 
     def __init__(self, store, device, batch_size=None, rank=0, world=1, shuffle=True, seed=0, depth=4, bucket=None,
-                 pairs=False):
+                 pairs=None):
         self.store, self.device = store, torch.device(device)
         self.batch_size = hp.batch_size if batch_size is None else batch_size
         self.rank, self.world, self.shuffle, self.seed, self.depth = rank, world, shuffle, seed, depth
@@ -180,6 +180,9 @@ class BatchFeeder:
         # yields a different (S, T) for nearly every sub-batch; a graphed step is captured per shape, so without buckets it
         # would be captured once and never replayed (training.GraphedStepCache)
         self.bucket = bucket
+        if pairs is None:                          # default: whatever the training step consumes (rt.pair_audio) -- a feed
+            from .runtime import rt                # without the stacked layout costs the graphed step 12 extra copies
+            pairs = bool(rt.pair_audio)
         self.pairs = pairs                         # also collate the stacked AudioEncoder inputs (to_device)
         self.epoch = 0
 

@@ -117,14 +117,29 @@ def allreduce_preflight(device, nbytes=117_930_804, reps=5):
     out = {"ranks": n}
     if n == 1:
         return out
+    def agree(err, ms=0.0):
+        """(anyone failed?, MAX ms) -- reached by EVERY rank, the failing one from its except branch (a rank
+        that failed alone used to skip the collective the others then blocked in forever)."""
+        t = torch.tensor([0.0 if err is None else 1.0, ms], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0].item()) > 0, float(t[1].item())
+
     for name, dtype, elems in (("fp32", torch.float32, nbytes // 4), ("bf16", torch.bfloat16, nbytes // 4)):
-        buf = torch.zeros(elems, device=device, dtype=dtype)
-        try:
+        err, buf = None, None
+        try:                                         # allocation + one warm-up all-reduce (dtype support, memory)
+            buf = torch.zeros(elems, device=device, dtype=dtype)
             for w in allreduce_sum_(buf):
                 w.wait()
             if buf.is_cuda:
                 torch.cuda.synchronize()
-            dist.barrier()
+        except RuntimeError as e:                    # (a backend without this dtype: say so instead of dying)
+            err = str(e)[:120]
+        failed, _ = agree(err)                       # doubles as the barrier in front of the timed repetitions
+        if failed:
+            out[name] = {"error": err if err is not None else "another rank failed"}
+            continue
+        ms = 0.0
+        try:
             t0 = time.perf_counter()
             for _ in range(reps):
                 for w in allreduce_sum_(buf):
@@ -132,12 +147,12 @@ def allreduce_preflight(device, nbytes=117_930_804, reps=5):
             if buf.is_cuda:
                 torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / reps * 1e3
-        except RuntimeError as e:                    # (a backend without this dtype: say so instead of dying)
-            out[name] = {"error": str(e)[:120]}
+        except RuntimeError as e:
+            err = str(e)[:120]
+        failed, ms = agree(err, ms)
+        if failed:
+            out[name] = {"error": err if err is not None else "another rank failed"}
             continue
-        t = torch.tensor([ms], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ms = float(t.item())
         b = elems * buf.element_size()
         out[name] = {"bytes": b, "ms": round(ms, 3), "busbw_GBs": round(b / (ms * 1e-3) * 2 * (n - 1) / n / 1e9, 1)}
     return out

@@ -384,7 +384,10 @@ def split3(x, plan=None):
     triple [.., 3C] = [hi | lo | hi].  With `plan` (packed rows) only the valid prefix is written."""
     cache = x3_cache
     if cache is not None:
-        key = (x.data_ptr(), tuple(x.shape), x.stride(), plan is not None)
+        # (the plan's identity is part of the key: the valid prefix written depends on it.  Invariant: a tensor that has been
+        #  split is never an `out=` target of a raw-pointer kernel later in the same step -- the library's kernels do not
+        #  bump `_version`; every x3 operand of the tape is a freshly allocated activation / gradient)
+        key = (x.data_ptr(), tuple(x.shape), x.stride(), plan.counts.data_ptr() if plan is not None else 0)
         hit = cache.get(key)
         if hit is not None and hit[1] == x._version:
             return hit[2]
@@ -405,7 +408,7 @@ def split3_multi(xs):
     outs, todo = [None] * len(xs), []
     cache = x3_cache
     for i, x in enumerate(xs):
-        key = (x.data_ptr(), tuple(x.shape), x.stride(), False)
+        key = (x.data_ptr(), tuple(x.shape), x.stride(), 0)
         hit = cache.get(key) if cache is not None else None
         if hit is not None and hit[1] == x._version:
             outs[i] = hit[2]
@@ -453,7 +456,7 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
     Throughput mode only: x, the output (`out_bf16` / a bf16 `out`) and `mask` may be bf16 tensors (the FFN hidden
     activation and its gradient are stored that way; no residual with a bf16 output)."""
     if prec == PREC_BF16X3:
-        # fp32-class products on the bf16 engines: x -> [hi | hi | lo] (3 cin channels) against the weight's [w_hi | w_lo | w_hi]
+        # fp32-class products on the bf16 engines: x -> activation blocks (hi, lo, hi) (3 cin channels; compact [hi | lo] + STYLER_IO_X3A) against the weight's [w_hi | w_hi | w_lo]
         # rows (runtime.gemm_weight); everything behind the contraction -- bias, activation, residual, masks -- is unchanged
         x3 = x if x.dtype == torch.bfloat16 else split3(x, plan)      # (a bf16 x is a split3 tensor the caller shares)
         cin3 = w.shape[-1] // kw                                       # 3 C
@@ -1040,6 +1043,22 @@ def _param_slots(nslots, length, target):
     return sl
 
 
+def _param_slots_all(reqs):
+    """All-or-nothing form for kernels that need SEVERAL slot arrays: `reqs` = [(nslots, length, target), ...] -> list of
+    slot tensors, or None (atomics for all).  Every request is made even after one has failed, so that ONE measuring pass
+    sizes the arena for all of them (the short-circuit under-counted `arena.total`, the arena then needed one
+    pass per array to converge and a capture could bake the atomic path in)."""
+    arena = wgrad_arena
+    if arena is None or not bias_slots:
+        return None
+    n0 = len(arena.descs)
+    out = [_param_slots(ns, ln, t) for ns, ln, t in reqs]
+    if any(o is None for o in out):
+        del arena.descs[n0:]                         # drop the folds queued for the arrays that did fit
+        return None
+    return out
+
+
 def _bias_slots(arena, splits, n, db, db2, device):
     """Takes [splits][n] floats from the arena and queues their fold into db (and db2); None when the arena has no room (the
     measuring pass of the first step)."""
@@ -1081,7 +1100,7 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
             resident = (n % 8 == 0 and cin % 8 == 0 and not x_exact and
                         ((kw == 1 and pad_left == 0 and tiles >= 16 and n > 64 and cin > 64) or kw in (5, 9)))
             if resident:
-                # both operands as bf16 views of their [hi | hi | lo] splits (the dX GEMM of the same node needs dz's split
+                # both operands as bf16 views of their [hi | lo (| hi)] splits (ops.split3) (the dX GEMM of the same node needs dz's split
                 # anyway: callers hand it over as `dz_parts`): the LDS-DMA kernels take them.  The bias sums need both
                 # parts of dz: colsum(dz_hi) from the first call, colsum(dz_lo) from the third.
                 dzh, dzl = dz_parts if dz_parts is not None else split3_parts(split3(dz, plan), n)
@@ -1293,11 +1312,9 @@ def groupnorm_relu_bwd(x, dy, gamma, beta, stats, dgamma, dbeta, dx_bf16=False):
     # gamma / beta gradients: per-item slots folded in item order by the step's reduce (single-pass kernel; else atomics)
     sg = sb = None
     if L <= lib.styler_groupnorm_fused_rows(1):
-        sg = _param_slots(B, C, dgamma)
-        sb = _param_slots(B, C, dbeta) if sg is not None else None
-        if sg is not None and sb is None:
-            wgrad_arena.descs.pop()                  # (no room for the second array: back to atomics for both)
-            sg = None
+        both = _param_slots_all([(B, C, dgamma), (B, C, dbeta)])     # (no room for both: atomics for both)
+        if both is not None:
+            sg, sb = both
     pg, pb, slots = (sg, sb, IO_PARAM_SLOTS) if sb is not None else (dgamma, dbeta, 0)
     _chk(lib.styler_groupnorm_relu_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), gamma.data_ptr(), beta.data_ptr(),
                                        stats.data_ptr(), dx.data_ptr(), C, pg.data_ptr(), pb.data_ptr(),
@@ -1371,16 +1388,8 @@ def aug_classifier_tail_bwd(h, ln_g, ln_b, w2, b2, dout, dln_g, dln_b, dw2, db2)
     dout = dout.contiguous()
     ns = lib.styler_aug_classifier_tail_slots(B, S)
     tg = [(dln_g, 256), (dln_b, 256), (dw2, 512), (db2, 2)]
-    sl, arena = [], wgrad_arena
-    for t, n in tg:
-        a = _param_slots(ns, n, t) if (not sl or sl[-1] is not None) else None
-        sl.append(a)
-    if sl[-1] is None and arena is not None:          # not all four fit: drop the queued folds, atomics for all
-        for a in sl:
-            if a is not None:
-                arena.descs.pop()
-        sl = None
-    if sl is not None and sl[-1] is not None:
+    sl = _param_slots_all([(ns, n, t) for t, n in tg])    # not all four fit: atomics for all
+    if sl is not None:
         _chk(lib.styler_aug_classifier_tail_bwd_io(h.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), w2.data_ptr(), b2.data_ptr(),
                                                    dout.data_ptr(), dh.data_ptr(), sl[0].data_ptr(), sl[1].data_ptr(),
                                                    sl[2].data_ptr(), sl[3].data_ptr(), B, S, IO_PARAM_SLOTS, _stream()),
@@ -1406,11 +1415,11 @@ def bucket_embed_bwd(dy, p_ids, e_ids, dpitch_emb, denergy_emb):
     dy = dy.contiguous()
     B, T, _ = dy.shape
     ns = lib.styler_bucket_embed_slices()
-    sp = _param_slots(ns, dpitch_emb.numel(), dpitch_emb) if dpitch_emb.numel() == 256 * 256 else None
-    se = _param_slots(ns, denergy_emb.numel(), denergy_emb) if sp is not None and denergy_emb.numel() == 256 * 256 else None
-    if sp is not None and se is None:
-        wgrad_arena.descs.pop()
-        sp = None
+    sp = se = None
+    if dpitch_emb.numel() == 256 * 256 and denergy_emb.numel() == 256 * 256:
+        both = _param_slots_all([(ns, dpitch_emb.numel(), dpitch_emb), (ns, denergy_emb.numel(), denergy_emb)])
+        if both is not None:
+            sp, se = both
     if se is not None:                               # per-slice slots, folded in slice order by the step's reduce
         _chk(lib.styler_bucket_embed_bwd_slots(dy.data_ptr(), p_ids.data_ptr(), e_ids.data_ptr(), sp.data_ptr(), se.data_ptr(),
                                                B, T, _stream()), "styler_bucket_embed_bwd_slots")

@@ -98,7 +98,7 @@ class _Runtime:
     # projections of a layer are always grouped).  STYLER_GROUPED_MLPS=0: one launch per Linear.
     grouped_mlps = os.environ.get("STYLER_GROUPED_MLPS", "1") != "0"
 
-    # round 4, bf16x3 arithmetic: the [hi | hi | lo] split of a GEMM's activation operand is kept from the forward to that
+    # round 4, bf16x3 arithmetic: the [hi | lo (| hi)] split (ops.split3) of a GEMM's activation operand is kept from the forward to that
     # layer's weight gradient (ops.x3_cache; STYLER_X3_CACHE=0: split again in backward)
     x3_cache = os.environ.get("STYLER_X3_CACHE", "1") != "0"
 

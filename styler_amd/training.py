@@ -115,6 +115,8 @@ class TrainState:
     def zero_grad(self):
         self.flat_g.zero_()
         self._tail_works = None
+        if self.reducer is not None:                  # a skipped step must not leave ranges that finish() would cast up again
+            self.reducer.pending = []
         self._accum = 0
 
     def _start_allreduce(self, lo, hi):
@@ -386,6 +388,11 @@ class GraphedTrainStep:
                     state._accum = 0
                     forward_backward(model, state, self.static, loss_fn, dat_fn)
                     done += 1
+                if scratch_state() != prev:          # still moving at the cap: the capture would bake a sizing pass in
+                    import warnings
+                    warnings.warn(f"GraphedTrainStep: the wgrad arena / zero slab / descriptor tables did not settle in {done} "
+                                  f"warm-up passes ({prev} -> {scratch_state()}); the captured step may keep a sizing pass's "
+                                  f"atomic fallbacks (not bit-reproducible)", RuntimeWarning)
         finally:
             state.split_hook = None
         torch.cuda.current_stream().wait_stream(side)
@@ -440,6 +447,8 @@ class GraphedTrainStep:
     def __call__(self, batch=None):
         if batch is not None:
             for k, v in batch.items():
+                if k not in self.static:              # e.g. pair_* keys of a BatchFeeder(pairs=True) while rt.pair_audio is off
+                    continue
                 if self.static[k].shape != v.shape:
                     raise ValueError(f"GraphedTrainStep was captured for {k} of shape {tuple(self.static[k].shape)}, "
                                      f"got {tuple(v.shape)}")

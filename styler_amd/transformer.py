@@ -74,7 +74,7 @@ class MultiHeadAttention(_HipModule):
         srcs_b = [self.w_qs.bias, self.w_ks.bias, self.w_vs.bias]
         b = d.get_spec("qkv_b", (768,), False, lambda: [Seg(u, (256,), (1,), (1,), dst_off=k * 256)
                                                         for k, u in enumerate(srcs_b)])
-        if rt.prec == ops.PREC_BF16X3:                       # [768, 3 * 256]: rows [w_hi | w_lo | w_hi] (runtime.x3)
+        if rt.prec == ops.PREC_BF16X3:                       # [768, 3 * 256]: rows [w_hi | w_hi | w_lo] against the activation blocks (hi, lo, hi) (runtime.x3)
             w = d.get_spec("qkv_wx3", (768, 768), True, lambda: x3([seg_rows(u, k * 256) for k, u in enumerate(srcs_w)], 256))
             return w, b, ops.PREC_BF16X3
         bf16 = rt.prec == ops.PREC_BF16

@@ -301,7 +301,8 @@ def test_batch_feeder_shards_prefetches_and_reshuffles(tmp_path):
     assert len(flat) == 16 and len(set(flat.tolist())) == 16
     assert [len(g) for g in groups] == [2, 2] and len(feeders[0]) == len(feeders[1]) == 4
     got = list(feeders[0])
-    want = [to_device(sub, "cpu", pinned=False) for grp in groups[0] for sub in ds.collate_fn([ds[int(i)] for i in grp])]
+    want = [to_device(sub, "cpu", pinned=False, pairs=feeders[0].pairs) for grp in groups[0]
+                for sub in ds.collate_fn([ds[int(i)] for i in grp])]
     assert len(got) == len(want) == 4
     for (a, sa, ta), (b, sb, tb) in zip(got, want):
         assert (sa, ta) == (sb, tb) and a.keys() == b.keys()
@@ -498,6 +499,31 @@ def test_feeder_shape_buckets(tmp_path):
         assert float(b["log_D"][:, sa:].abs().sum()) == 0                     # log(0 + 1): the padded durations stay zero
     assert len({(s, t) for _, s, t in bucketed}) < len({(s, t) for _, s, t in exact})
     assert bucket_up(990, 64) == 1001 and bucket_up(1001, 64) == 1001         # train mode: never past the position table
+
+
+def test_feeder_pairs_layout_equals_add_pair_inputs(tmp_path):
+    """`BatchFeeder(pairs=True)` / `to_device(pairs=True)`: the collated pair_* tensors are the concatenation
+    of the two halves `training.add_pair_inputs` stacks on the device -- exact and bucketed; a feed WITHOUT them still
+    carries everything the step needs (the graphed step then stacks them itself and skips keys it does not own)."""
+    from golden.make_golden_store import tokenizer, write_store
+    from styler_amd.data import BatchFeeder, FeatureStore
+    from styler_amd.training import PAIR_KEYS, add_pair_inputs
+    write_store(str(tmp_path))
+    ds = FeatureStore(str(tmp_path), tokenizer)
+    for bucket in (None, (8, 64)):
+        plain = list(BatchFeeder(ds, "cpu", batch_size=2, shuffle=False, depth=2, bucket=bucket, pairs=False))
+        paired = list(BatchFeeder(ds, "cpu", batch_size=2, shuffle=False, depth=2, bucket=bucket, pairs=True))
+        assert len(plain) == len(paired) > 0
+        for (a, sa, ta), (b, sb, tb) in zip(plain, paired):
+            assert (sa, ta) == (sb, tb) and set(b) == set(a) | set(PAIR_KEYS)
+            ref = add_pair_inputs(dict(a))
+            for k, (h0, h1) in PAIR_KEYS.items():
+                assert b[k].dtype == ref[k].dtype and torch.equal(b[k], ref[k]), k
+                assert torch.equal(b[k], torch.cat([a[h0], a[h1]], 0)), k
+            for k in a:
+                assert torch.equal(a[k], b[k]), k
+    from styler_amd import rt
+    assert BatchFeeder(ds, "cpu", batch_size=2).pairs == bool(rt.pair_audio)      # the default follows the training step
 
 
 def test_torch_library_schemas_and_fake_kernels():
