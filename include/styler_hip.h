@@ -571,12 +571,17 @@ int styler_wgrad_packed(const float* dz, int64_t lddz, const float* x, int64_t l
  * setting as mode | (stages128 << 2).  Env: STYLER_WGRAD_DMA=0|1|2.  The split count / workspace of a launch depend on its
  * operand formats: use the _io forms below with the io_flags the launch will be given. */
 int styler_wgrad_dma_config(int mode, int stages128);
-/* Round 5: block -> (split, tile) map of bf16 weight-gradient launches with fewer than 8 splits.  1 (default): the 8 XCDs
- * form an (s8 x n8 x c8) grid over (splits x n-tiles x c-tiles) and every XCD owns one sub-box, so a dz / x column block is
- * fetched into as few L2s as possible (the decoder FFN's k = 9 gradient: 250 -> ~85 MB fetched per launch); 0: the former
- * tile-major map.  Results are bit-identical (the same blocks compute the same partial tiles).  Returns the previous value;
- * any other argument only queries.  Env: STYLER_WGRAD_XCDMAP=0|1.  (autograd of transformer/SubLayers.py:72-76) */
-int styler_wgrad_xcd_map(int on);
+/* Round 5 tuning knobs of the bf16 weight-gradient engine: styler_wgrad_tune(knob, value) sets knob to value (0 | 1; any
+ * other value only queries) and returns the previous value (STYLER_EINVAL for an unknown knob).
+ *   knob 0 (default 1, env STYLER_WGRAD_XCDMAP): block -> (split, tile) map of launches with fewer than 8 splits.  1: the 8 XCDs
+ *     form an (s8 x n8 x c8) grid over (splits x n-tiles x c-tiles) and every XCD owns one sub-box, so a dz / x column block is
+ *     fetched into as few L2s as possible (the decoder FFN's k = 9 gradient: 250 -> ~85 MB fetched per launch); 0: the former
+ *     tile-major map.  Results are bit-identical (the same blocks compute the same partial tiles).
+ *   knob 1 (default 0, env STYLER_WGRAD_K5_TALL): k = 5 gradients with both operands bf16-resident and n % 128 == 0 on a
+ *     128 (n) x 64 (c) x 5 taps block tile instead of 64 x 64 x 5 (fewer operand bytes per MFMA; the split plan changes with it,
+ *     so query the workspace / split count with the _io forms AFTER setting the knob).
+ * (autograd of transformer/SubLayers.py:72-76, transformer/Layers.py:78-118) */
+int styler_wgrad_tune(int knob, int value);
 int styler_wgrad_x3cat_ok(int n, int cin, int kw, int pad_left);
 int styler_wgrad_splits_io(int B, int L, int n, int cin, int kw, int pad_left, int prec, int io_flags);
 int64_t styler_wgrad_workspace_bytes_io(int B, int L, int n, int cin, int kw, int pad_left, int prec, int io_flags);

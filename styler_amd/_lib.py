@@ -72,7 +72,7 @@ _SIGS = {
     "styler_wgrad": [P, I64, P, I64, P, P, P, I64, I64, I64, I, I, I, I, I, I, I, P, I, I, P],
     "styler_wgrad_splits": [I, I, I, I, I, I, I],
     "styler_wgrad_dma_config": [I, I],
-    "styler_wgrad_xcd_map": [I],
+    "styler_wgrad_tune": [I, I],
     "styler_wgrad_x3cat_ok": [I, I, I, I],
     "styler_wgrad_splits_io": [I, I, I, I, I, I, I, I],
     "styler_wgrad_workspace_bytes_io": [I, I, I, I, I, I, I, I],

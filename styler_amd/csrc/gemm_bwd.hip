@@ -1050,11 +1050,18 @@ extern "C" int styler_wgrad_dma_config(int mode, int stages128) {
 }
 // Round 5: XCD box map of launches with fewer than 8 splits (wgrad_xcd_box_map); 0 = the former tile-major map (A/B runs).
 static int g_wgrad_xcd_map = [] { const char* e = getenv("STYLER_WGRAD_XCDMAP"); return e ? atoi(e) : 1; }();
-extern "C" int styler_wgrad_xcd_map(int on) {
-  const int prev = g_wgrad_xcd_map;
-  if (on == 0 || on == 1) g_wgrad_xcd_map = on;
+// Round 5: the k = 5 gradients on the LDS-DMA ring with a 128 (n) x 64 (c) x 5 taps block tile (TA = 2): 16 + 9 KB of operands
+// per 64-row chunk for twice the MFMAs of the 64 x 64 tile's 8 + 9 KB (154 -> 210 FLOP per operand byte; the k = 5 kernels ran
+// at the CU's L2 -> LDS rate, not at the MFMA rate).  n % 128 == 0, both operands bf16-resident, mode 2 only.
+static int g_wgrad_k5_tall = [] { const char* e = getenv("STYLER_WGRAD_K5_TALL"); return e ? atoi(e) : 0; }();
+extern "C" int styler_wgrad_tune(int knob, int value) {
+  int* const k = knob == 0 ? &g_wgrad_xcd_map : knob == 1 ? &g_wgrad_k5_tall : nullptr;
+  if (!k) return STYLER_EINVAL;
+  const int prev = *k;
+  if (value == 0 || value == 1) *k = value;
   return prev;
 }
+static bool wgrad_k5_tall(int n, int cin, int kw, int prec, int io_flags);
 static void wgrad_tile(int n, int cin, int kw, int prec, int* TA, int* TB);
 // K groups per block of a launch with these operand formats (1: every other kernel)
 static int wgrad_kgroups(int n, int cin, int kw, int prec, int io_flags) {
@@ -1064,6 +1071,10 @@ static int wgrad_kgroups(int n, int cin, int kw, int prec, int io_flags) {
   wgrad_tile(n, cin, kw, prec, &TA, &TB);
   if (kw == 1) return (TA == 2 && TB == 2) ? 2 : 1;
   return ((kw == 5 || kw == 9) && TA == 1 && TB == 1) ? 2 : 1;
+}
+static bool wgrad_k5_tall(int n, int cin, int kw, int prec, int io_flags) {
+  return g_wgrad_k5_tall && g_wgrad_dma == 2 && prec == STYLER_PREC_BF16 && kw == 5 && (io_flags & STYLER_IO_Y_BF16) &&
+         (io_flags & STYLER_IO_X_BF16) && !(n & 127) && !(cin & 7);
 }
 
 // STYLER_IO_X3CAT launches exist on the LDS-DMA ring only: both parts bf16-resident, whole 16-byte pieces, a ring kernel
@@ -1078,9 +1089,10 @@ static bool wgrad_x3cat_ok(int n, int cin, int kw, int pad_left) {
 extern "C" int styler_wgrad_x3cat_ok(int n, int cin, int kw, int pad_left) { return wgrad_x3cat_ok(n, cin, kw, pad_left) ? 1 : 0; }
 
 static void wgrad_plan(int B, int L, int n, int cin, int kw, int pad_left, int prec, int* Be, int* Le, int* cpi, int* cps,
-                       int* splits, int want_splits = 0, int kg = 1, int kcat = 1) {
+                       int* splits, int want_splits = 0, int kg = 1, int kcat = 1, bool tall = false) {
   int TA, TB;
   wgrad_tile(n, cin, kw, prec, &TA, &TB);
+  if (tall) TA = 2;
   const int fa = 64 * TA, fb = 64 * TB;
   const int nt = (n + fa - 1) / fa, ct = (cin + fb - 1) / fb;
   *Be = B; *Le = L;
@@ -1113,7 +1125,7 @@ extern "C" int64_t styler_wgrad_workspace_bytes_io(int B, int L, int n, int cin,
   if (B <= 0 || L <= 0 || n <= 0 || cin <= 0 || kw <= 0) return 0;
   int Be, Le, cpi, cps, splits;
   wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, 0, wgrad_kgroups(n, cin, kw, prec, io_flags),
-             (io_flags & STYLER_IO_X3CAT) ? 3 : 1);
+             (io_flags & STYLER_IO_X3CAT) ? 3 : 1, wgrad_k5_tall(n, cin, kw, prec, io_flags));
   return (int64_t)splits * n * kw * cin * 4;
 }
 extern "C" int64_t styler_wgrad_workspace_bytes(int B, int L, int n, int cin, int kw, int pad_left, int prec) {
@@ -1136,6 +1148,7 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
   if ((lddz & 3) || (ldx & 3) || (n & 3) || ldx < ((cin + 3) & ~3) || ((uintptr_t)dz & 15) || ((uintptr_t)x & 15)) return STYLER_EALIGN;
   int TA, TB;
   wgrad_tile(n, cin, kw, prec, &TA, &TB);
+  if (wgrad_k5_tall(n, cin, kw, prec, io_flags)) TA = 2;
   const int fa = 64 * TA, fb = 64 * TB;
   const int nt = (n + fa - 1) / fa, ct = (cin + fb - 1) / fb;
   hipStream_t st = (hipStream_t)stream;
@@ -1145,7 +1158,8 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
   if (x3cat && !(prec == STYLER_PREC_BF16 && dz16 && x16 && wgrad_x3cat_ok(n, cin, kw, pad_left) && !(lddz & 7) && !(ldx & 7) &&
                  lddz >= 2 * (int64_t)n && ldx >= 2 * (int64_t)cin))
     return STYLER_EINVAL;
-  wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, 0, kg, x3cat ? 3 : 1);
+  const bool tall = wgrad_k5_tall(n, cin, kw, prec, io_flags);
+  wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, 0, kg, x3cat ? 3 : 1, tall);
   const int legacy_map = g_wgrad_xcd_map ? 0 : 0x1000;
   const int pad_cat = (pad_left & 0xff) | (x3cat ? 0x400 : 0) | ((io_flags & STYLER_IO_DB_SLOTS) ? 0x800 : 0) | legacy_map;
   float* ws = reinterpret_cast<float*>(workspace);
@@ -1170,6 +1184,8 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
     if (dma && kw == 1 && TA == 2 && TB == 2) {
       if (kg == 2) WD_LAUNCH(1, 2, 2, 2, 2);
       else if (g_wgrad_dma_nst128 == 3) WD_LAUNCH(1, 2, 2, 3, 1); else WD_LAUNCH(1, 2, 2, 2, 1);
+    } else if (dma && kw == 5 && TA == 2 && TB == 1 && tall) {
+      WD_LAUNCH(5, 2, 1, 3, 2);
     } else if (dma && kw == 5 && TA == 1 && TB == 1) {
       if (kg == 2) WD_LAUNCH(5, 1, 1, 3, 2); else WD_LAUNCH(5, 1, 1, 3, 1);
     } else if (dma && kw == 9 && TA == 1 && TB == 1) {
@@ -1335,7 +1351,7 @@ extern "C" int styler_wgrad_splits_io(int B, int L, int n, int cin, int kw, int 
   if (B <= 0 || L <= 0 || n <= 0 || cin <= 0 || kw <= 0) return 0;
   int Be, Le, cpi, cps, splits;
   wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, 0, wgrad_kgroups(n, cin, kw, prec, io_flags),
-             (io_flags & STYLER_IO_X3CAT) ? 3 : 1);
+             (io_flags & STYLER_IO_X3CAT) ? 3 : 1, wgrad_k5_tall(n, cin, kw, prec, io_flags));
   return splits;
 }
 extern "C" int styler_wgrad_splits(int B, int L, int n, int cin, int kw, int pad_left, int prec) {
