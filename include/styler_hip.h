@@ -188,6 +188,14 @@ int styler_gemm_n96_config(int enabled, int min_rows);
 int64_t styler_conv_gemm_workspace_bytes(int B, int L, int cin, int n, int kw, int act, int prec, int io_flags,
                                          int64_t ldx, int packed, int has_mask);
 int styler_gemm_set_workspace(void* ptr, int64_t bytes);
+/* Round 5 (bf16x3 arithmetic): producers write the operand split themselves.  The next PRODUCER call of this host thread --
+ * styler_conv_gemm / styler_conv_gemm_packed (fp32 output in bf16 MFMA mode; whatever engine takes it, including its split-K
+ * combine pass), styler_add_layernorm, styler_groupnorm_relu / _bwd, styler_batchnorm_train / _bwd (fp32 outputs, contiguous
+ * rows) -- ALSO stores the [hi | lo (| hi)] bf16 split of its fp32 output rows into y3: rows of parts * C bf16, parts = 2 | 3,
+ * the layout and the values of styler_split3_bf16 bit for bit, so that the GEMM consuming the output as a bf16x3 operand
+ * needs no split pass (transformer/SubLayers.py:41-61,83-89, transformer/Layers.py:91-128, modules.py:103-172 and their
+ * autograd).  Consumed by that call; a producer that cannot honour it returns STYLER_EINVAL.  y3 = NULL clears it. */
+int styler_set_x3_out(void* y3, int parts);
 /* Split-K of the 64 x 64 tile (bf16 MFMA mode): a k >= 3 convolution over few rows and a long contraction axis -- at most
  * 256 tiles, >= 48 (chunk, tap) steps, plain epilogue: the dX of the text encoder's FFN convolution, M = B * S rows,
  * K = 9 * 1024 (transformer/SubLayers.py:72-76, Models.py:60-84) -- deals its 64-channel chunks to about four blocks per CU;
@@ -573,11 +581,12 @@ int styler_wgrad_packed(const float* dz, int64_t lddz, const float* x, int64_t l
 int styler_wgrad_dma_config(int mode, int stages128);
 /* Round 5 tuning knobs of the bf16 weight-gradient engine: styler_wgrad_tune(knob, value) sets knob to value (0 | 1; any
  * other value only queries) and returns the previous value (STYLER_EINVAL for an unknown knob).
- *   knob 0 (default 1, env STYLER_WGRAD_XCDMAP): block -> (split, tile) map of launches with fewer than 8 splits.  1: the 8 XCDs
+ *   knob 0 (default 0 -- measured: no gain, the operands are Infinity-Cache resident; env STYLER_WGRAD_XCDMAP): block -> (split, tile) map of launches with fewer than 8 splits.  1: the 8 XCDs
  *     form an (s8 x n8 x c8) grid over (splits x n-tiles x c-tiles) and every XCD owns one sub-box, so a dz / x column block is
  *     fetched into as few L2s as possible (the decoder FFN's k = 9 gradient: 250 -> ~85 MB fetched per launch); 0: the former
  *     tile-major map.  Results are bit-identical (the same blocks compute the same partial tiles).
- *   knob 1 (default 0, env STYLER_WGRAD_K5_TALL): k = 5 gradients with both operands bf16-resident and n % 128 == 0 on a
+ *   knob 1 (default 1, env STYLER_WGRAD_K5_TALL): k = 5 gradients with both operands bf16-resident, n % 128 == 0 and at least 64
+ *     tiles of 64 x 64 (the PostNet's 512 -> 512 convolutions: 128.6 -> 115.2 us per launch) on a
  *     128 (n) x 64 (c) x 5 taps block tile instead of 64 x 64 x 5 (fewer operand bytes per MFMA; the split plan changes with it,
  *     so query the workspace / split count with the _io forms AFTER setting the knob).
  * (autograd of transformer/SubLayers.py:72-76, transformer/Layers.py:78-118) */

@@ -93,6 +93,7 @@ _SIGS = {
     "styler_groupnorm_fused_rows": [I],
     "styler_conv_gemm_workspace_bytes": [I, I, I, I, I, I, I, I, I64, I, I],
     "styler_gemm_set_workspace": [P, I64],
+    "styler_set_x3_out": [P, I],
     "styler_fold_replicas": [P, P, P, P, P, P, I, I, P],
     "styler_groupnorm_relu_bwd": [P, I64, P, I64, P, P, P, P, I64, P, P, P, I, I, I, I, I, P],
     "styler_batchnorm_bwd": [P, P, P, P, P, P, P, P, P, P, I, I64, I, I, P, F, ctypes.c_uint64, I, I, P],

@@ -179,7 +179,7 @@ class LayerNormFn(Function):
         return dx, (dx if ctx.has_res else None), None, None, None, None
 
 
-def _ln_tail_fwd(o, x, ln, lens, drop_p, want16=False):
+def _ln_tail_fwd(o, x, ln, lens, drop_p, want16=False, plan=None):
     """dropout(o) + x -> LayerNorm -> pad mask in one kernel; returns (y, pre-norm sum, (p, seed)) -- and with `want16` a
     fourth value, the bf16 copy of y for the GEMM that consumes it."""
     drop_p = 0.0 if rt.disable_dropout else drop_p
@@ -187,7 +187,7 @@ def _ln_tail_fwd(o, x, ln, lens, drop_p, want16=False):
     s = torch.empty_like(x)                           # bf16 when the residual stream is (x bf16): y comes out as bf16 too
     y16 = torch.empty_like(x, dtype=torch.bfloat16) if (want16 and x.dtype != torch.bfloat16) else None
     y = ops.add_layernorm(o, ln.weight, ln.bias, res=x, lens=lens, in_drop_p=drop_p, in_drop_seed=seed, sum_out=s,
-                          out16=y16)
+                          out16=y16, x3=True, plan=plan)   # (bf16x3: y feeds the next sublayer's GEMM -- split written here)
     if rt.sim_bf16_stream and rt.prec == ops.PREC_BF16 and x.dtype != torch.bfloat16:
         y, s = _r16(y), _r16(s)
     return (y, s, (drop_p, seed), y16) if want16 else (y, s, (drop_p, seed))
@@ -229,10 +229,10 @@ class FfnSublayerFn(Function):
         # x16: the bf16 copy of x written by the LayerNorm that produced it (same values the GEMM would round x to)
         xa = x16 if (x16 is not None and p1 == ops.PREC_BF16) else x
         h = ops.conv_gemm(xa, w1, ffn.w_1.bias, kw=kw1, n=ffn.w_1.weight.shape[0], act=RELU, prec=p1, plan=plan,
-                          out_bf16=h16)
+                          out_bf16=h16, x3_out=True)             # (bf16x3: h is the second conv's operand -- split in the epilogue)
         w2, p2 = gemm_weight(ffn._derived, "w_2", ffn.w_2.weight, h.shape[-1])
         o = ops.conv_gemm(h, w2, ffn.w_2.bias, kw=kw2, n=ffn.w_2.weight.shape[0], prec=p2, plan=plan)
-        y, s, ctx.drop = _ln_tail_fwd(o, x, ffn.layer_norm, lens, drop_p)
+        y, s, ctx.drop = _ln_tail_fwd(o, x, ffn.layer_norm, lens, drop_p, plan=plan)
         ctx.save_for_backward(x, h, s, lens)
         ctx.ffn, ctx.plan = ffn, plan
         return y
@@ -249,7 +249,7 @@ class FfnSublayerFn(Function):
         ops.wgrad(d_o, h, G(w_2.weight), d_in, d_hid, kw=kw2, db=G(w_2.bias), plan=plan, dz_parts=d_op)
         wt2, prec2 = gemm_weight_bwd_auto(ffn._derived, "w_2", w_2.weight)
         dh = ops.conv_gemm(d_og if prec2 == ops.PREC_BF16X3 else d_o, wt2, None, kw=kw2, n=d_hid, prec=prec2, plan=plan,
-                           mask=h, out_bf16=h.dtype == torch.bfloat16)
+                           mask=h, out_bf16=h.dtype == torch.bfloat16, x3_out=True)
         dhg, dhp = _x3_split(dh, d_hid, plan)
         ops.wgrad(dh, x, G(w_1.weight), d_hid, d_in, kw=kw1, db=G(w_1.bias), plan=plan, dz_parts=dhp)
         wt1, prec1 = gemm_weight_bwd_auto(ffn._derived, "w_1", w_1.weight)
@@ -273,9 +273,9 @@ class AttnSublayerFn(Function):
         o = ops.conv_gemm(att, wfc, mha.fc.bias, n=256, prec=pfc, plan=plan)
         want16 = want16 and prec == ops.PREC_BF16
         if want16:                                    # (on a bf16 stream the second value is None: y itself is bf16)
-            y, s, ctx.drop, y16 = _ln_tail_fwd(o, x, mha.layer_norm, lens, drop_p, want16=True)
+            y, s, ctx.drop, y16 = _ln_tail_fwd(o, x, mha.layer_norm, lens, drop_p, want16=True, plan=plan)
         else:
-            y, s, ctx.drop = _ln_tail_fwd(o, x, mha.layer_norm, lens, drop_p)
+            y, s, ctx.drop = _ln_tail_fwd(o, x, mha.layer_norm, lens, drop_p, plan=plan)
         ctx.save_for_backward(x, qkv, att, lse, s, lens)
         ctx.mha, ctx.plan = mha, plan
         if want16:
@@ -401,7 +401,7 @@ class ConvNormFn(Function):
         out_bf16 = out_bf16 and b16
         if kind == "gn":
             aux = torch.empty(z.shape[0], z.shape[2] // 16, 2, device=z.device, dtype=torch.float32)
-            y = ops.groupnorm_relu(z, norm.weight, norm.bias, stats=aux,
+            y = ops.groupnorm_relu(z, norm.weight, norm.bias, stats=aux, x3=True,    # (bf16x3: y feeds the next conv's GEMM)
                                    out=torch.empty_like(z, dtype=torch.bfloat16 if out_bf16 else torch.float32))
             ctx.save_for_backward(x, z, aux)
             ctx.drop = (0.0, 0)
@@ -409,7 +409,7 @@ class ConvNormFn(Function):
             drop_p = 0.0 if rt.disable_dropout else drop_p
             seed = next_dropout_seed() if drop_p > 0 else 0
             y, mean, rstd = ops.batchnorm_train(z, norm.weight, norm.bias, norm.running_mean, norm.running_var, act,
-                                                drop_p=drop_p, drop_seed=seed, segs=segs, out_bf16=out_bf16)
+                                                drop_p=drop_p, drop_seed=seed, segs=segs, out_bf16=out_bf16, x3=True)
             ctx.save_for_backward(x, z, mean, rstd)
             ctx.drop = (drop_p, seed)
         ctx.weight, ctx.bias, ctx.cache, ctx.key, ctx.kw = weight, bias, cache, key, kw
@@ -421,12 +421,13 @@ class ConvNormFn(Function):
         norm, weight, bias, kw = ctx.norm, ctx.weight, ctx.bias, ctx.kw
         if ctx.kind == "gn":
             x, z, stats = ctx.saved_tensors
-            dz = ops.groupnorm_relu_bwd(z, dy, norm.weight, norm.bias, stats, G(norm.weight), G(norm.bias), dx_bf16=ctx.b16)
+            dz = ops.groupnorm_relu_bwd(z, dy, norm.weight, norm.bias, stats, G(norm.weight), G(norm.bias), dx_bf16=ctx.b16,
+                                        x3=True)     # (bf16x3: dz feeds the dX GEMM and the weight gradient)
         else:
             x, z, mean, rstd = ctx.saved_tensors
             dz = ops.batchnorm_bwd(z, None, dy, norm.weight, mean, rstd, G(norm.weight), G(norm.bias), ctx.act,
                                    beta=norm.bias, drop_p=ctx.drop[0], drop_seed=ctx.drop[1], segs=ctx.segs,
-                                   dx_bf16=ctx.b16)
+                                   dx_bf16=ctx.b16, x3=True)
         n, cin = weight.shape[0], x.shape[-1]
         dzg, dzp = _x3_split(dz, n)
         if weight.requires_grad:
@@ -479,7 +480,7 @@ class ConvNormCatFn(Function):
         for i, (weight, bias, key, norm, wd, b16) in enumerate(zip(ws, bs, keys, norms, widths, b16s)):
             x, z, stats = saved[3 * i:3 * i + 3]
             dz = ops.groupnorm_relu_bwd(z, dy[..., off:off + wd], norm.weight, norm.bias, stats, G(norm.weight), G(norm.bias),
-                                        dx_bf16=b16)
+                                        dx_bf16=b16, x3=True)
             off += wd
             n, cin = weight.shape[0], x.shape[-1]
             dzg, dzp = _x3_split(dz, n)

@@ -102,6 +102,29 @@ __device__ __forceinline__ void stg4(void* base, int64_t idx, const float4& v, b
   else *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx) = v;
 }
 
+// bf16x3 producer-side split (round 5): the (hi, lo) bf16 pairs of four consecutive fp32 values, bit for bit what
+// split3_bf16_kernel (misc.hip) writes for them -- hi = bf16_rne(v), lo = bf16_rne(v - float(hi)).  Producers (GEMM epilogues,
+// norms, attention) store the split next to their fp32 output, so no separate pass re-reads it (1.5 ms of the 21 ms step).
+__device__ __forceinline__ void x3_split4(const float4 v, uint2& hi, uint2& lo) {
+  const uint32_t h01 = cvt_pk_bf16_rne(v.x, v.y), h23 = cvt_pk_bf16_rne(v.z, v.w);
+  hi = make_uint2(h01, h23);
+  lo = make_uint2(cvt_pk_bf16_rne(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u)),
+                  cvt_pk_bf16_rne(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u)));
+}
+// ... and their store into row `row` of a split tensor [rows, parts * C] (parts = 2: [hi | lo]; 3: [hi | lo | hi]), channel c
+__device__ __forceinline__ void x3_store4(uint16_t* __restrict__ y3, int64_t row, int c, int C, int parts, const float4 v) {
+  uint2 hi, lo;
+  x3_split4(v, hi, lo);
+  uint16_t* yr = y3 + row * (int64_t)(parts * C) + c;
+  *reinterpret_cast<uint2*>(yr) = hi;
+  *reinterpret_cast<uint2*>(yr + C) = lo;
+  if (parts == 3) *reinterpret_cast<uint2*>(yr + 2 * C) = hi;
+}
+
+// hands over (and clears) the split output the host thread registered with styler_set_x3_out (misc.hip) for its NEXT producer
+// call: every entry point that can fill one takes it first thing, so a registration never leaks to a later call
+void styler_take_x3_out(uint16_t** y3, int* parts);
+
 // v - float(bf16(v)): the low part of the hi + lo split of the bf16x3 arithmetic (exact in fp32)
 __device__ __forceinline__ float bf16_lo_part(float v) { return v - __uint_as_float(f32_to_bf16_bits(v) << 16); }
 

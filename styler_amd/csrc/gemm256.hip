@@ -98,6 +98,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
     a.scale = a.shift = a.res = nullptr;
     a.mask = nullptr;
     a.act = STYLER_ACT_NONE;
+    a.y3 = nullptr;                                   // (the split of the OUTPUT is written by the combine pass)
   }
 
   // ---- tiles made only of rows at or past their item's length: zeros (packed rows: nothing behind the data is read) ----
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
         if (m0 + r < M && c < a.n) {
           if (Y16) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.y) + (m0 + r) * a.ldy + c) = make_uint2(0u, 0u);
           else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (m0 + r) * a.ldy + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (!Y16 && a.y3) x3_store4(a.y3, m0 + r, c, a.n, a.y3parts, make_float4(0.f, 0.f, 0.f, 0.f));
         }
       }
       return;
@@ -381,6 +383,17 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
   const uint32_t om0 = col_ok ? (uint32_t)((wrow0 * (int)a.ldmask + col) * m_es) : OOB;
   const uint32_t ystep = (uint32_t)(RPP * (int)a.ldy * Y_ES), rstep = (uint32_t)(RPP * (int)a.ldres * r_es),
                  mstep = (uint32_t)(RPP * (int)a.ldmask * m_es);
+  // round 5, bf16x3: the [hi | lo (| hi)] split of the fp32 output rows, stored next to them (GemmArgs.y3; rows of y3parts * n)
+  const bool want3 = !Y16 && a.y3 != nullptr;
+  const int ld3 = a.y3parts * a.n;
+  const __amdgpu_buffer_rsrc_t y3_rs = [&] {
+    int64_t rec = ((M - m0 - 1) * (int64_t)ld3 + ld3) * 2;
+    rec = rec > REC_MAX ? REC_MAX : rec;
+    const char* b = reinterpret_cast<const char*>(want3 ? a.y3 : reinterpret_cast<uint16_t*>(a.y)) + (want3 ? m0 * (int64_t)ld3 * 2 : 0);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b), 0, want3 ? (int)rec : 0, 0x00020000);
+  }();
+  const uint32_t o30 = (col_ok && want3) ? (uint32_t)((wrow0 * ld3 + col) * 2) : OOB;
+  const uint32_t step3 = (uint32_t)(RPP * ld3 * 2), lo3 = (uint32_t)(a.n * 2);
 
   auto tail = [&](auto act_tag) {
     constexpr int ACT = decltype(act_tag)::value;
@@ -452,6 +465,15 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
           __builtin_amdgcn_raw_buffer_store_b64(o, y_rs, oy0 + (i * 8 + u) * ystep, 0, 0);
         } else {
           __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const i32x4*>(&w), y_rs, oy0 + (i * 8 + u) * ystep, 0, 0);
+          if (want3) {
+            uint2 h3, l3;
+            x3_split4(w, h3, l3);
+            const i32x2 hv = {(int)h3.x, (int)h3.y}, lv = {(int)l3.x, (int)l3.y};
+            const uint32_t o3 = o30 + (i * 8 + u) * step3;
+            __builtin_amdgcn_raw_buffer_store_b64(hv, y3_rs, o3, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(lv, y3_rs, o3 + lo3, 0, 0);
+            if (a.y3parts == 3) __builtin_amdgcn_raw_buffer_store_b64(hv, y3_rs, o3 + 2 * lo3, 0, 0);
+          }
         }
       }
     }
@@ -472,7 +494,8 @@ template <bool Y16>
 __global__ __launch_bounds__(256) void gemm256_combine_kernel(const float* __restrict__ part, int64_t M, int n, int ksplit,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* __restrict__ res, int64_t ldres, void* __restrict__ y,
-                                                              int64_t ldy, const int64_t* __restrict__ nrows, int res16) {
+                                                              int64_t ldy, const int64_t* __restrict__ nrows, int res16,
+                                                              uint16_t* __restrict__ y3, int y3parts) {
   const int q = n >> 2;                                                      // float4 per row
   const int64_t lim = nrows ? (nrows[0] < M ? nrows[0] : M) : M;
   const int64_t total = lim * q;
@@ -489,6 +512,7 @@ __global__ __launch_bounds__(256) void gemm256_combine_kernel(const float* __res
     if (res) { const float4 t = ldg4(res, r * ldres + c, res16 != 0); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
     if (Y16) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(y) + r * ldy + c) = make_uint2(cvt_pk_bf16_rne(v.x, v.y), cvt_pk_bf16_rne(v.z, v.w));
     else *reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + r * ldy + c) = v;
+    if (!Y16 && y3) x3_store4(y3, r, c, n, y3parts, v);     // round 5: the bf16x3 split of the output rows (GemmArgs.y3)
   }
 }
 
@@ -592,8 +616,8 @@ int styler_gemm_combine(const GemmArgs& a0, int ks, int y16, hipStream_t st) {
   const int64_t quads = M * (a0.n >> 2);
   const unsigned cb = (unsigned)((quads + 255) / 256 > 4096 ? 4096 : (quads + 255) / 256);
   const int64_t* nrows = (a0.rowinfo && a0.B == 1) ? a0.len : nullptr;
-  if (y16) hipLaunchKernelGGL(gemm256_combine_kernel<true>, dim3(cb), dim3(256), 0, st, a0.part, M, a0.n, ks, a0.scale, a0.shift, a0.res, a0.ldres, a0.y, a0.ldy, nrows, a0.res16);
-  else hipLaunchKernelGGL(gemm256_combine_kernel<false>, dim3(cb), dim3(256), 0, st, a0.part, M, a0.n, ks, a0.scale, a0.shift, a0.res, a0.ldres, a0.y, a0.ldy, nrows, a0.res16);
+  if (y16) hipLaunchKernelGGL(gemm256_combine_kernel<true>, dim3(cb), dim3(256), 0, st, a0.part, M, a0.n, ks, a0.scale, a0.shift, a0.res, a0.ldres, a0.y, a0.ldy, nrows, a0.res16, nullptr, 0);
+  else hipLaunchKernelGGL(gemm256_combine_kernel<false>, dim3(cb), dim3(256), 0, st, a0.part, M, a0.n, ks, a0.scale, a0.shift, a0.res, a0.ldres, a0.y, a0.ldy, nrows, a0.res16, a0.y3, a0.y3parts);
   return launch_status();
 }
 

@@ -24,6 +24,8 @@ struct GemmArgs {
   int res16 = 0;                                   // the residual tensor is bf16 (STYLER_IO_RES_BF16; ldres in elements)
   int x3n1 = 0;                                    // STYLER_IO_X3A: x rows hold [hi | lo] of cin / 3 channels each; x3n1 = (cin / 3) / 64 chunks per part,
                                                    // channel chunk cc >= 2 * x3n1 (the third product) reads chunk cc - 2 * x3n1 (hi again)
+  uint16_t* y3 = nullptr;                          // round 5 (styler_set_x3_out): ALSO store the bf16x3 split of the fp32 output,
+  int y3parts = 0;                                 // rows of y3parts * n bf16: [hi | lo (| hi)] (fp32 outputs only)
 };
 
 // gemm256.hip: returns 1 when the 256x256 LDS-DMA engine takes the launch (and has enqueued it), 0 when the shape is not

@@ -1049,11 +1049,16 @@ extern "C" int styler_wgrad_dma_config(int mode, int stages128) {
   return prev;
 }
 // Round 5: XCD box map of launches with fewer than 8 splits (wgrad_xcd_box_map); 0 = the former tile-major map (A/B runs).
-static int g_wgrad_xcd_map = [] { const char* e = getenv("STYLER_WGRAD_XCDMAP"); return e ? atoi(e) : 1; }();
+// Measured (profiles/r05_wgrad_map_bench.txt, same-box A/B): the box map does NOT pay -- k = 9 123.5 -> 126.7 us, PostNet k = 5
+// 128.6 -> 134.1 us, the step unchanged within noise.  The operands of a launch (55 + 14 MB) live in the 256 MB Infinity Cache, so
+// the re-fetches of the tile-major map never reached HBM; what the kernel waits for is not the L2 miss rate.  Default: off.
+static int g_wgrad_xcd_map = [] { const char* e = getenv("STYLER_WGRAD_XCDMAP"); return e ? atoi(e) : 0; }();
 // Round 5: the k = 5 gradients on the LDS-DMA ring with a 128 (n) x 64 (c) x 5 taps block tile (TA = 2): 16 + 9 KB of operands
 // per 64-row chunk for twice the MFMAs of the 64 x 64 tile's 8 + 9 KB (154 -> 210 FLOP per operand byte; the k = 5 kernels ran
 // at the CU's L2 -> LDS rate, not at the MFMA rate).  n % 128 == 0, both operands bf16-resident, mode 2 only.
-static int g_wgrad_k5_tall = [] { const char* e = getenv("STYLER_WGRAD_K5_TALL"); return e ? atoi(e) : 0; }();
+// Measured (same file): PostNet 512 -> 512: 128.6 -> 115.2 us (+11.6 %); 256 -> 256 (16 tiles of 64 x 64: the tall tile doubles
+// its split count to 32): 43.6 -> 44.4 us.  Default: on, for gradients of at least 64 tiles of 64 x 64.
+static int g_wgrad_k5_tall = [] { const char* e = getenv("STYLER_WGRAD_K5_TALL"); return e ? atoi(e) : 1; }();
 extern "C" int styler_wgrad_tune(int knob, int value) {
   int* const k = knob == 0 ? &g_wgrad_xcd_map : knob == 1 ? &g_wgrad_k5_tall : nullptr;
   if (!k) return STYLER_EINVAL;
@@ -1074,7 +1079,7 @@ static int wgrad_kgroups(int n, int cin, int kw, int prec, int io_flags) {
 }
 static bool wgrad_k5_tall(int n, int cin, int kw, int prec, int io_flags) {
   return g_wgrad_k5_tall && g_wgrad_dma == 2 && prec == STYLER_PREC_BF16 && kw == 5 && (io_flags & STYLER_IO_Y_BF16) &&
-         (io_flags & STYLER_IO_X_BF16) && !(n & 127) && !(cin & 7);
+         (io_flags & STYLER_IO_X_BF16) && !(n & 127) && !(cin & 7) && (n / 64) * ((cin + 63) / 64) >= 64;
 }
 
 // STYLER_IO_X3CAT launches exist on the LDS-DMA ring only: both parts bf16-resident, whole 16-byte pieces, a ring kernel

@@ -147,6 +147,7 @@ __device__ __forceinline__ void conv_gemm_body(const GemmArgs& a, const int bid_
         if (m0 + r < M && c < a.n) {
           if (Y16) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.y) + (m0 + r) * a.ldy + c) = make_uint2(0u, 0u);
           else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (m0 + r) * a.ldy + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (!Y16 && a.y3) x3_store4(a.y3, m0 + r, c, a.n, a.y3parts, make_float4(0.f, 0.f, 0.f, 0.f));
         }
       }
       return;
@@ -458,6 +459,17 @@ __device__ __forceinline__ void conv_gemm_body(const GemmArgs& a, const int bid_
   const uint32_t om0 = col_ok ? (uint32_t)((wrow0 * (int)a.ldmask + col) * m_es) : OOB;
   const uint32_t ystep = (uint32_t)(RPP * (int)a.ldy * Y_ES), rstep = (uint32_t)(RPP * (int)a.ldres * r_es),
                  mstep = (uint32_t)(RPP * (int)a.ldmask * m_es);
+  // round 5, bf16x3: the [hi | lo (| hi)] split of the fp32 output rows, stored next to them (GemmArgs.y3; rows of y3parts * n)
+  const bool want3 = !Y16 && a.y3 != nullptr;
+  const int ld3 = a.y3parts * a.n;
+  const __amdgpu_buffer_rsrc_t y3_rs = [&] {
+    int64_t rec = ((M - m0 - 1) * (int64_t)ld3 + ld3) * 2;
+    rec = rec > REC_MAX ? REC_MAX : rec;
+    const char* b = reinterpret_cast<const char*>(want3 ? a.y3 : reinterpret_cast<uint16_t*>(a.y)) + (want3 ? m0 * (int64_t)ld3 * 2 : 0);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b), 0, want3 ? (int)rec : 0, 0x00020000);
+  }();
+  const uint32_t o30 = (col_ok && want3) ? (uint32_t)((wrow0 * ld3 + col) * 2) : OOB;
+  const uint32_t step3 = (uint32_t)(RPP * ld3 * 2), lo3 = (uint32_t)(a.n * 2);
 
   auto tail = [&](auto act_tag) {
     constexpr int ACT = decltype(act_tag)::value;
@@ -537,6 +549,15 @@ __device__ __forceinline__ void conv_gemm_body(const GemmArgs& a, const int bid_
             __builtin_amdgcn_raw_buffer_store_b64(o, y_rs, oy0 + (p0 + u) * ystep, 0, 0);
           } else {
             __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const i32x4*>(&w), y_rs, oy0 + (p0 + u) * ystep, 0, 0);
+            if (want3) {
+              uint2 h3, l3;
+              x3_split4(w, h3, l3);
+              const i32x2 hv = {(int)h3.x, (int)h3.y}, lv = {(int)l3.x, (int)l3.y};
+              const uint32_t o3 = o30 + (p0 + u) * step3;
+              __builtin_amdgcn_raw_buffer_store_b64(hv, y3_rs, o3, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b64(lv, y3_rs, o3 + lo3, 0, 0);
+              if (a.y3parts == 3) __builtin_amdgcn_raw_buffer_store_b64(hv, y3_rs, o3 + 2 * lo3, 0, 0);
+            }
           }
         }
       }
@@ -577,6 +598,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs a) {
     a.y = a.part + (int64_t)blockIdx.y * a.B * a.L * a.n;
     a.ldy = a.n;
     a.scale = nullptr; a.shift = nullptr; a.res = nullptr; a.mask = nullptr; a.act = STYLER_ACT_NONE;
+    a.y3 = nullptr;                                  // (the split of the OUTPUT is written by the combine pass)
   }
   conv_gemm_body<TM, TN, BF16, KW1, OCC3, A16, Y16, WM, 0>(a, blockIdx.x);
 }
@@ -768,6 +790,10 @@ int styler_conv_gemm_impl2(const float* x, int64_t ldx, const void* w, const flo
   void* ws = nullptr;
   int64_t ws_bytes = 0;
   styler_gemm_take_workspace(&ws, &ws_bytes);      // consumed by this call, whatever engine takes it
+  styler_take_x3_out(&a.y3, &a.y3parts);           // (likewise: the split of the fp32 output, styler_set_x3_out)
+  if (a.y3 && (y16 || prec != STYLER_PREC_BF16 || (a.y3parts != 2 && a.y3parts != 3) || ((uintptr_t)a.y3 & 7) ||
+               (int64_t)B * L * a.y3parts * n * 2 >= ((int64_t)1 << 31)))
+    return STYLER_EINVAL;
   if (prec == STYLER_PREC_BF16) {                  // large launches on bf16 activations: the 256 x 256 LDS-DMA engine (gemm256.hip)
     const int r = styler_gemm256_try(a, x16, y16, st, ws, ws_bytes);
     if (r) return r < 0 ? r : 0;

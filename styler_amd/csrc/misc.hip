@@ -427,6 +427,25 @@ __global__ __launch_bounds__(256) void split3_bf16_kernel(const float* __restric
   }
 }
 
+// Round 5: producers write the split themselves.  The next PRODUCER call of this host thread -- styler_conv_gemm[_packed] (fp32
+// output, bf16 MFMA mode; any engine, incl. the split-K combine pass), styler_add_layernorm, styler_groupnorm_relu[_bwd],
+// styler_batchnorm_train / _bwd (fp32 outputs, contiguous rows) -- ALSO stores the [hi | lo (| hi)] bf16 split of its fp32 output
+// rows into y3: rows of parts * C bf16 (parts = 2 | 3), the layout and the values of styler_split3_bf16 bit for bit, so that
+// the GEMM consuming the output as a bf16x3 operand needs no split pass (116 passes = 1.5 ms of the 21 ms bf16x3 step in round
+// 4).  The registration is consumed by that call (taken first thing, whatever path it then runs); a producer that cannot honour
+// it (bf16 output, strided rows) returns STYLER_EINVAL.  y3 = NULL clears a registration.
+static thread_local uint16_t* t_y3 = nullptr;
+static thread_local int t_y3_parts = 0;
+extern "C" int styler_set_x3_out(void* y3, int parts) {
+  if (y3 && ((parts != 2 && parts != 3) || ((uintptr_t)y3 & 7))) return STYLER_EINVAL;
+  t_y3 = reinterpret_cast<uint16_t*>(y3); t_y3_parts = y3 ? parts : 0;
+  return 0;
+}
+void styler_take_x3_out(uint16_t** y3, int* parts) {
+  *y3 = t_y3; *parts = t_y3_parts;
+  t_y3 = nullptr; t_y3_parts = 0;
+}
+
 // parts: 3 = the triple form [hi | lo | hi], 2 = the compact form [hi | lo] (see above)
 extern "C" int styler_split3_bf16(const float* x, int64_t ldx, void* y, int64_t rows, int C, const int64_t* count, int parts,
                                   void* stream) {

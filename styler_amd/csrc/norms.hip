@@ -11,7 +11,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
     const float* __restrict__ dot_w, const float* __restrict__ dot_b, float* __restrict__ dot_out, int64_t rows,
     int L, const int64_t* __restrict__ len, float drop_p, uint64_t drop_seed_host, const uint64_t* __restrict__ epoch,
     float in_drop_p, uint64_t in_drop_seed_host, float* __restrict__ sum_out, int64_t ldsum, uint16_t* __restrict__ y16,
-    int64_t ldy16, int io) {
+    int64_t ldy16, int io, uint16_t* __restrict__ y3, int y3parts) {
   const bool res16 = io & STYLER_LN_RES_BF16, yb16 = io & STYLER_LN_Y_BF16, sum16 = io & STYLER_LN_SUM_BF16;
   const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   const int lane = threadIdx.x & 63;
@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
   if (masked) {
     if (y) stg4(y, row * ldy + lane * 4, make_float4(0.f, 0.f, 0.f, 0.f), yb16);
     if (y16) *reinterpret_cast<uint2*>(y16 + row * ldy16 + lane * 4) = make_uint2(0u, 0u);
+    if (y3) x3_store4(y3, row, lane * 4, 256, y3parts, make_float4(0.f, 0.f, 0.f, 0.f));
     if (dot_out && lane == 0) dot_out[row] = 0.f;
     return;                                              // (sum_out is only read back on unmasked rows)
   }
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
   // y16: a second copy of the output as bf16 (round to nearest even) for the GEMMs that consume it -- they round their
   // activation operand to bf16 anyway, so results do not change; the 256 x 256 engine (gemm256.hip) DMAs it straight into LDS
   if (y16) *reinterpret_cast<uint2*>(y16 + row * ldy16 + lane * 4) = make_uint2(cvt_pk_bf16_rne(o.x, o.y), cvt_pk_bf16_rne(o.z, o.w));
+  if (y3) x3_store4(y3, row, lane * 4, 256, y3parts, o);     // round 5, bf16x3: the split of the fp32 output (styler_set_x3_out)
   if (dot_out) {
     const float4 w = *reinterpret_cast<const float4*>(dot_w + lane * 4);
     const float d = wave_sum(o.x * w.x + o.y * w.y + o.z * w.z + o.w * w.w);
@@ -85,6 +87,10 @@ extern "C" int styler_add_layernorm(const float* x, int64_t ldx, const float* re
                                     const int64_t* len, float drop_p, uint64_t drop_seed, float in_drop_p,
                                     uint64_t in_drop_seed, float* sum_out, int64_t ldsum, uint16_t* y16, int64_t ldy16,
                                     int io_flags, void* stream) {
+  uint16_t* y3 = nullptr;
+  int y3parts = 0;
+  styler_take_x3_out(&y3, &y3parts);               // (bf16x3: the split of the fp32 output rows, filed by the caller)
+  if (y3 && (!y || (io_flags & STYLER_LN_Y_BF16) || ldy != C)) return STYLER_EINVAL;
   if (!x || !gamma || !beta || (!y && !dot_out) || B <= 0 || L <= 0) return STYLER_EINVAL;
   if (y16 && ((ldy16 & 3) || ((uintptr_t)y16 & 7))) return STYLER_EALIGN;
   if (C != 256) return STYLER_EINVAL;
@@ -95,7 +101,7 @@ extern "C" int styler_add_layernorm(const float* x, int64_t ldx, const float* re
   if (rows >= ((int64_t)1 << 31)) return STYLER_EINVAL;
   hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
                      ldx, res, ldres, gamma, beta, y, ldy, dot_w, dot_b, dot_out, rows, L, len, drop_p, drop_seed,
-                     g_styler_drop_epoch, in_drop_p, in_drop_seed, sum_out, ldsum, y16, ldy16, io_flags);
+                     g_styler_drop_epoch, in_drop_p, in_drop_seed, sum_out, ldsum, y16, ldy16, io_flags, y3, y3parts);
   return launch_status();
 }
 
@@ -142,7 +148,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int64_t ldx,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const double* __restrict__ ws, void* __restrict__ y, int64_t ldy,
-                                                       float* __restrict__ stats, int L, int C, int seg_rows, int y16) {
+                                                       float* __restrict__ stats, int L, int C, int seg_rows, int y16,
+                                                       uint16_t* __restrict__ y3, int y3parts) {
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int t0 = blockIdx.z * seg_rows;
@@ -170,6 +177,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     o.w = fmaxf((v.w - mean) * rstd * g.w + bt.w, 0.f);
     if (y16) *reinterpret_cast<uint2*>(yp16 + (int64_t)t * ldy) = make_uint2(cvt_pk_bf16_rne(o.x, o.y), cvt_pk_bf16_rne(o.z, o.w));
     else *reinterpret_cast<float4*>(yp + (int64_t)t * ldy) = o;
+    if (y3) x3_store4(y3, (int64_t)b * L + t, c0 + cq * 4, C, y3parts, o);
   }
 }
 
@@ -190,7 +198,7 @@ template <int IT, bool X16 = false>
 __global__ __launch_bounds__(1024) void gn_fused_kernel(const void* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         void* __restrict__ y, int64_t ldy, float* __restrict__ stats, int L,
-                                                        int C, int y16) {
+                                                        int C, int y16, uint16_t* __restrict__ y3, int y3parts) {
   __shared__ float red[2][16][4];
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4, wave = threadIdx.x >> 6, grp = cq >> 2;
@@ -250,6 +258,7 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const void* __restrict__
     o.z = fmaxf(v[i].z * a.z + bt.z, 0.f); o.w = fmaxf(v[i].w * a.w + bt.w, 0.f);
     if (y16) *reinterpret_cast<uint2*>(yp16 + (int64_t)t * ldy) = make_uint2(cvt_pk_bf16_rne(o.x, o.y), cvt_pk_bf16_rne(o.z, o.w));
     else *reinterpret_cast<float4*>(yp + (int64_t)t * ldy) = o;
+    if (y3) x3_store4(y3, (int64_t)b * L + t, c0 + cq * 4, C, y3parts, o);    // round 5, bf16x3 (styler_set_x3_out)
   }
 }
 // 0: two-kernel form; otherwise the rows per thread of the single-pass variant that holds an item of L rows.  The backward
@@ -272,6 +281,10 @@ extern "C" int styler_groupnorm_fused_rows(int bwd) {
 extern "C" int styler_groupnorm_relu(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y,
                                      int64_t ldy, float* stats, double* workspace, int ws_zeroed, int B, int L, int C,
                                      int io_flags, void* stream) {
+  uint16_t* y3 = nullptr;
+  int y3parts = 0;
+  styler_take_x3_out(&y3, &y3parts);               // (bf16x3: the split of the fp32 output rows, filed by the caller)
+  if (y3 && ((io_flags & STYLER_IO_Y_BF16) || ldy != C)) return STYLER_EINVAL;
   if (!x || !y || !gamma || !beta || !workspace || B <= 0 || L <= 0 || C <= 0 || (C & 63)) return STYLER_EINVAL;
   if ((ldx & 3) || (ldy & 3)) return STYLER_EALIGN;
   hipStream_t st = (hipStream_t)stream;
@@ -279,7 +292,7 @@ extern "C" int styler_groupnorm_relu(const float* x, int64_t ldx, const float* g
   if (const int it = gn_fused_iters(L, false)) {
     const int y16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
 #define GNF_LAUNCH(IT_, X_) hipLaunchKernelGGL((gn_fused_kernel<IT_, X_>), dim3(C / 64, B), dim3(1024), 0, st, x, ldx, gamma, beta, y, \
-                                               ldy, stats, L, C, y16)
+                                               ldy, stats, L, C, y16, y3, y3parts)
     if (it == GNF_IT) { if (x16) GNF_LAUNCH(GNF_IT, true); else GNF_LAUNCH(GNF_IT, false); }
     else { if (x16) GNF_LAUNCH(2 * GNF_IT, true); else GNF_LAUNCH(2 * GNF_IT, false); }
 #undef GNF_LAUNCH
@@ -295,7 +308,7 @@ extern "C" int styler_groupnorm_relu(const float* x, int64_t ldx, const float* g
   const dim3 grid(C / 64, B, (L + seg_rows - 1) / seg_rows);
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, st, x, ldx, workspace, L, C, seg_rows);
   hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, st, x, ldx, gamma, beta, workspace, y, ldy, stats, L, C,
-                     seg_rows, (io_flags & STYLER_IO_Y_BF16) ? 1 : 0);
+                     seg_rows, (io_flags & STYLER_IO_Y_BF16) ? 1 : 0, y3, y3parts);
   return launch_status();
 }
 
@@ -499,7 +512,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ 
                                                        const float* __restrict__ rstd, void* __restrict__ yv,
                                                        int C, int act, float drop_p, uint64_t drop_seed_host,
                                                        const uint64_t* __restrict__ epoch, int rpb, int bps, int64_t rps,
-                                                       int y16) {
+                                                       int y16, uint16_t* __restrict__ y3, int y3parts) {
   float* const y = reinterpret_cast<float*>(yv);
   uint16_t* const yh = reinterpret_cast<uint16_t*>(yv);    // y16: bf16 output (see gn_apply_kernel)
   const int seg = blockIdx.x / bps, chunk = blockIdx.x - seg * bps;
@@ -548,6 +561,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ 
         }
         if (y16) *reinterpret_cast<uint2*>(yh + ru * C + q * 4) = make_uint2(cvt_pk_bf16_rne(o.x, o.y), cvt_pk_bf16_rne(o.z, o.w));
         else *reinterpret_cast<float4*>(y + ru * C + q * 4) = o;
+        if (y3) x3_store4(y3, ru, q * 4, C, y3parts, o);     // round 5, bf16x3: the split of the fp32 output (styler_set_x3_out)
       }
     }
   }
@@ -557,6 +571,10 @@ extern "C" int styler_batchnorm_train(const float* x, const float* gamma, const 
                                       float* save_mean, float* save_rstd, float* running_mean, float* running_var,
                                       double* workspace, int ws_zeroed, int64_t rows, int C, int act, float drop_p,
                                       uint64_t drop_seed, int segs, int io_flags, void* stream) {
+  uint16_t* y3 = nullptr;
+  int y3parts = 0;
+  styler_take_x3_out(&y3, &y3parts);               // (bf16x3: the split of the fp32 output rows, filed by the caller)
+  if (y3 && (io_flags & STYLER_IO_Y_BF16)) return STYLER_EINVAL;
   if (!x || !gamma || !beta || !y || !save_mean || !save_rstd || !workspace || rows <= 0 || C <= 0 || (C & 3) ||
       drop_p < 0.f || drop_p >= 1.f || segs < 1 || rows % segs)
     return STYLER_EINVAL;
@@ -571,9 +589,9 @@ extern "C" int styler_batchnorm_train(const float* x, const float* gamma, const 
   const int bps = (int)((rps + BN_RPB - 1) / BN_RPB);
   if (x16)
     hipLaunchKernelGGL(bn_apply_kernel<true>, dim3((unsigned)(bps * segs)), dim3(256), 0, st, x, gamma, beta, save_mean, save_rstd,
-                       y, C, act, drop_p, drop_seed, g_styler_drop_epoch, BN_RPB, bps, rps, (io_flags & STYLER_IO_Y_BF16) ? 1 : 0);
+                       y, C, act, drop_p, drop_seed, g_styler_drop_epoch, BN_RPB, bps, rps, (io_flags & STYLER_IO_Y_BF16) ? 1 : 0, y3, y3parts);
   else
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3((unsigned)(bps * segs)), dim3(256), 0, st, x, gamma, beta, save_mean, save_rstd,
-                       y, C, act, drop_p, drop_seed, g_styler_drop_epoch, BN_RPB, bps, rps, (io_flags & STYLER_IO_Y_BF16) ? 1 : 0);
+                       y, C, act, drop_p, drop_seed, g_styler_drop_epoch, BN_RPB, bps, rps, (io_flags & STYLER_IO_Y_BF16) ? 1 : 0, y3, y3parts);
   return launch_status();
 }

@@ -410,7 +410,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ stats,
                                                            const double* __restrict__ ws, void* __restrict__ dx,
-                                                           int64_t lddx, int L, int C, int seg_rows, int dx16) {
+                                                           int64_t lddx, int L, int C, int seg_rows, int dx16,
+                                                           uint16_t* __restrict__ y3, int y3parts) {
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int t0 = blockIdx.z * seg_rows;
@@ -449,6 +450,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
       if (t < t1) {                                      // (the store is predicated, the loads above are not)
         if (dx16) *reinterpret_cast<uint2*>(dxp16 + (int64_t)t * lddx) = make_uint2(cvt_pk_bf16_rne(o.x, o.y), cvt_pk_bf16_rne(o.z, o.w));
         else *reinterpret_cast<float4*>(dxp + (int64_t)t * lddx) = o;
+        if (y3) x3_store4(y3, (int64_t)b * L + t, c0 + cq * 4, C, y3parts, o);
       }
     }
   }
@@ -464,7 +466,8 @@ __global__ __launch_bounds__(1024) void gn_bwd_fused_kernel(const void* __restri
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ stats, void* __restrict__ dx,
                                                             int64_t lddx, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int L, int C, int dx16_slots) {
+                                                            float* __restrict__ dbeta, int L, int C, int dx16_slots,
+                                                            uint16_t* __restrict__ y3, int y3parts) {
   // dx16_slots: bit 0 = dx is written as bf16; bit 1 (STYLER_IO_PARAM_SLOTS) = dgamma / dbeta are [B][C] slot arrays this launch
   // STORES item b's sums into (folded in item order by the caller's multi-tensor reduce: no atomics, bit-reproducible)
   const int dx16 = dx16_slots & 1;
@@ -549,6 +552,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_fused_kernel(const void* __restri
                                  rstd * (g.z - m1 - v[i].z * m2), rstd * (g.w - m1 - v[i].w * m2));
     if (dx16) *reinterpret_cast<uint2*>(dxp16 + (int64_t)t * lddx) = make_uint2(cvt_pk_bf16_rne(o.x, o.y), cvt_pk_bf16_rne(o.z, o.w));
     else *reinterpret_cast<float4*>(dxp + (int64_t)t * lddx) = o;
+    if (y3) x3_store4(y3, (int64_t)b * L + t, c0 + cq * 4, C, y3parts, o);     // round 5, bf16x3 (styler_set_x3_out)
   }
 }
 
@@ -556,6 +560,10 @@ extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void
                                          const float* gamma, const float* beta, const float* stats, void* dx,
                                          int64_t lddx, float* dgamma, float* dbeta, double* workspace, int ws_zeroed, int B,
                                          int L, int C, int io_flags, void* stream) {
+  uint16_t* y3 = nullptr;
+  int y3parts = 0;
+  styler_take_x3_out(&y3, &y3parts);               // (bf16x3: the split of the fp32 gradient rows, filed by the caller)
+  if (y3 && ((io_flags & STYLER_IO_Y_BF16) || lddx != C)) return STYLER_EINVAL;
   if (!x || !dy || !gamma || !beta || !stats || !dx || !dgamma || !dbeta || !workspace || B <= 0 || L <= 0 || C <= 0 ||
       (C & 63))
     return STYLER_EINVAL;
@@ -568,7 +576,7 @@ extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void
   if (pslots && !gn_fused_iters(L, true)) return STYLER_EINVAL;        // slots: the single-pass kernel only
   if (gn_fused_iters(L, true)) {
 #define GNB_LAUNCH(D_, I_, X_) hipLaunchKernelGGL((gn_bwd_fused_kernel<D_, I_, X_>), dim3(C / 64, B), dim3(1024), 0, st, x, ldx, dy, \
-                                                  lddy, gamma, beta, stats, dx, lddx, dgamma, dbeta, L, C, dx16 | (pslots ? 2 : 0))
+                                                  lddy, gamma, beta, stats, dx, lddx, dgamma, dbeta, L, C, dx16 | (pslots ? 2 : 0), y3, y3parts)
     if (dy16 && x16) GNB_LAUNCH(true, GNB_IT, true);
     else if (dy16) GNB_LAUNCH(true, GNB_IT, false);
     else if (x16) GNB_LAUNCH(false, GNB_IT, true);
@@ -588,12 +596,12 @@ extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void
     hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, grid, dim3(256), 0, st, x, ldx, dy, lddy, gamma, beta, stats, workspace,
                        dgamma, dbeta, L, C, seg_rows);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, grid, dim3(256), 0, st, x, ldx, dy, lddy, gamma, beta, stats, workspace, dx,
-                       lddx, L, C, seg_rows, dx16);
+                       lddx, L, C, seg_rows, dx16, y3, y3parts);
   } else {
     hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, grid, dim3(256), 0, st, x, ldx, dy, lddy, gamma, beta, stats, workspace,
                        dgamma, dbeta, L, C, seg_rows);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, grid, dim3(256), 0, st, x, ldx, dy, lddy, gamma, beta, stats, workspace, dx,
-                       lddx, L, C, seg_rows, dx16);
+                       lddx, L, C, seg_rows, dx16, y3, y3parts);
   }
   return launch_status();
 }
@@ -618,7 +626,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
                                                            int C, int act, const float* __restrict__ beta,
                                                            float drop_p, uint64_t drop_seed_host,
                                                            const uint64_t* __restrict__ epoch, int segs, int rpb, int bps,
-                                                           int64_t rps, int dx16) {
+                                                           int64_t rps, int dx16, uint16_t* __restrict__ y3, int y3parts) {
   float* const dx = reinterpret_cast<float*>(dxv);
   uint16_t* const dxh = reinterpret_cast<uint16_t*>(dxv);  // dx16: bf16 output (see gn_bwd_apply_kernel)
   // parameter gradients: first C * segs threads of the grid
@@ -684,6 +692,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
         }
         if (dx16) *reinterpret_cast<uint2*>(dxh + ru * C + q * 4) = make_uint2(cvt_pk_bf16_rne(out[0], out[1]), cvt_pk_bf16_rne(out[2], out[3]));
         else *reinterpret_cast<float4*>(dx + ru * C + q * 4) = make_float4(out[0], out[1], out[2], out[3]);
+        if (y3) x3_store4(y3, ru, q * 4, C, y3parts, make_float4(out[0], out[1], out[2], out[3]));     // round 5, bf16x3
       }
     }
   }
@@ -693,6 +702,10 @@ extern "C" int styler_batchnorm_bwd(const float* x, const float* y, const void* 
                                     const float* save_mean, const float* save_rstd, void* dx, float* dgamma,
                                     float* dbeta, double* workspace, int ws_zeroed, int64_t rows, int C, int act,
                                     const float* beta, float drop_p, uint64_t drop_seed, int segs, int io_flags, void* stream) {
+  uint16_t* y3 = nullptr;
+  int y3parts = 0;
+  styler_take_x3_out(&y3, &y3parts);               // (bf16x3: the split of the fp32 gradient rows, filed by the caller)
+  if (y3 && (io_flags & STYLER_IO_Y_BF16)) return STYLER_EINVAL;
   if (!x || !dy || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || C <= 0 ||
       (C & 3) || (act == STYLER_ACT_TANH && !y && !beta) || drop_p < 0.f || drop_p >= 1.f || segs < 1 || rows % segs)
     return STYLER_EINVAL;
@@ -710,7 +723,7 @@ extern "C" int styler_batchnorm_bwd(const float* x, const float* y, const void* 
   const int dx16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
 #define BNB_LAUNCH(D_, X_)                                                                                                      \
   hipLaunchKernelGGL((bn_bwd_apply_kernel<D_, X_>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd, \
-                     workspace, dx, dgamma, dbeta, C, act, beta, drop_p, drop_seed, g_styler_drop_epoch, segs, RPB, bps, rps, dx16)
+                     workspace, dx, dgamma, dbeta, C, act, beta, drop_p, drop_seed, g_styler_drop_epoch, segs, RPB, bps, rps, dx16, y3, y3parts)
   if (dy16 && x16) BNB_LAUNCH(true, true);
   else if (dy16) BNB_LAUNCH(true, false);
   else if (x16) BNB_LAUNCH(false, true);

@@ -438,6 +438,44 @@ def split3_multi(xs):
     return outs
 
 
+# Round 5: producers write the split of their fp32 output themselves (GEMM epilogues and norms: styler_set_x3_out) and file it in the step's split cache, so the consumer's split3() is a lookup -- no pass re-reads the tensor.
+# STYLER_X3_PRODUCERS=0: every split is a separate pass again (A/B switch, the tests compare both).
+x3_producers = os.environ.get("STYLER_X3_PRODUCERS", "1") != "0"
+
+
+def x3_out_for(shape_prefix, C, device):
+    """(split tensor [.., parts * C] bf16, parts) a producer should fill for an fp32 output [.., C] -- or (None, 0) outside a
+    bf16x3 training step (no cache to file it in) or with STYLER_X3_PRODUCERS=0."""
+    if x3_cache is None or not x3_producers or C % 4:
+        return None, 0
+    parts = 2 if (C % 64 == 0 and x3_compact) else 3
+    return torch.empty(*shape_prefix, parts * C, device=device, dtype=torch.bfloat16), parts
+
+
+def x3_register(y, y3, plan=None):
+    """Files `y3`, the split a producer wrote for its fp32 output `y`, under the key split3(y, plan) looks up."""
+    if y3 is not None and x3_cache is not None:
+        key = (y.data_ptr(), tuple(y.shape), y.stride(), plan.counts.data_ptr() if plan is not None else 0)
+        x3_cache[key] = (y, y._version, y3)
+
+
+def _x3_begin(out, enable=True):
+    """Registers a split output for the NEXT producer call (styler_set_x3_out) when `out` (fp32, contiguous rows) is going to be
+    a bf16x3 GEMM operand in this training step; returns the split tensor to hand to `_x3_end`, or None."""
+    if not enable or out is None or out.dtype != torch.float32 or not out.is_contiguous():
+        return None
+    y3, parts = x3_out_for(out.shape[:-1], out.shape[-1], out.device)
+    if y3 is not None:
+        _chk(lib.styler_set_x3_out(y3.data_ptr(), parts), "styler_set_x3_out")
+    return y3
+
+
+def _x3_end(out, y3, plan=None):
+    if y3 is not None:
+        lib.styler_set_x3_out(None, 0)               # (consumed by the producer; cleared again in case it never got there)
+        x3_register(out, y3, plan)
+
+
 def lo_part(x, plan=None):
     """bf16(x - float(bf16(x))) stored as fp32 (styler_lo_part): the low operand of a bf16x3 weight gradient."""
     C = x.shape[-1]
@@ -450,7 +488,7 @@ def lo_part(x, plan=None):
 
 
 def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, scale=None, res=None,
-              out=None, lens=None, plan=None, mask=None, out_bf16=False, _x3a=False):
+              out=None, lens=None, plan=None, mask=None, out_bf16=False, _x3a=False, x3_out=False):
     """y = act(scale * conv1d_same(x, w) + bias) (+ res); x [B, L, cin] -> y [B, L, n].
     `w` is the kernel-layout weight [n, kw*cin] (fp32, or bf16 when prec == PREC_BF16).
     Throughput mode only: x, the output (`out_bf16` / a bf16 `out`) and `mask` may be bf16 tensors (the FFN hidden
@@ -463,7 +501,7 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
         if w.dtype != torch.bfloat16 or w.shape[-1] != kw * cin3 or cin3 % 3 or x3.shape[-1] not in (cin3, cin3 // 3 * 2):
             raise StylerHipError("bf16x3 GEMM needs the x3 weight layout [n, kw * 3 cin] and a split3 activation")
         return conv_gemm(x3, w, bias, kw=kw, n=n, act=act, prec=PREC_BF16, scale=scale, res=res, out=out,
-                         lens=lens, plan=plan, mask=mask, out_bf16=False, _x3a=x3.shape[-1] != cin3)
+                         lens=lens, plan=plan, mask=mask, out_bf16=False, _x3a=x3.shape[-1] != cin3, x3_out=x3_out)
     B, L, cin = x.shape
     if _x3a:                                           # compact [hi | lo] rows: the contraction still runs over 3 C channels
         cin = cin // 2 * 3
@@ -491,6 +529,12 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
         if need and lens is None:
             ws = torch.empty(need, device=x.device, dtype=torch.uint8)
             lib.styler_gemm_set_workspace(ws.data_ptr(), need)
+    y3 = None
+    if x3_out and prec == PREC_BF16 and out.dtype == torch.float32 and out.is_contiguous() and prof is None:
+        # (bf16x3: this output is the activation operand of a following GEMM -- its split leaves with the epilogue)
+        y3, parts3 = x3_out_for(out.shape[:-1], n, x.device)
+        if y3 is not None:
+            _chk(lib.styler_set_x3_out(y3.data_ptr(), parts3), "styler_set_x3_out")
     if plan is not None:                             # packed rows: taps stay inside their item, tiles behind the data skip
         assert B == 1 and L == plan.rows
         _chk(lib.styler_conv_gemm_packed(x.data_ptr(), _ld(x), w.data_ptr(), _ptr(scale), _ptr(bias), _ptr(res),
@@ -505,6 +549,9 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
                                   _stream()), "styler_conv_gemm")
     if ws is not None:
         lib.styler_gemm_set_workspace(None, 0)       # (consumed by the call above; cleared again in case it never got there)
+    if y3 is not None:
+        lib.styler_set_x3_out(None, 0)
+        x3_register(out, y3, plan)
     if prof is not None:
         e1.record()
         prof.records.append((lib.styler_conv_gemm_engine2(B, L, cin, n, kw, prec, io, _ld(x), int(plan is not None), act,
@@ -688,7 +735,7 @@ def attention_fwd(qkv, lens, lse=None, prec=None, plan=None, out_bf16=False):
 
 
 def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, dot_b=None, drop_p=0.0, drop_seed=0,
-                  in_drop_p=0.0, in_drop_seed=0, sum_out=None, out16=None, out_bf16=False):
+                  in_drop_p=0.0, in_drop_seed=0, sum_out=None, out16=None, out_bf16=False, x3=False, plan=None):
     """LayerNorm(dropout(x) + res) with pad-mask; with dot_w returns the [B, L] scalar head instead.  `sum_out`
     (optional) receives the pre-norm sum (what layernorm_bwd needs); `out16` (optional, a bf16 [B, L, C] tensor) a second
     copy of the output rounded to bf16, for the GEMMs that take it as their activation operand."""
@@ -704,6 +751,8 @@ def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, 
     ln_io = (1 if res is not None and res.dtype == torch.bfloat16 else 0) | \
             (2 if out is not None and out.dtype == torch.bfloat16 else 0) | \
             (4 if sum_out is not None and sum_out.dtype == torch.bfloat16 else 0)
+    # x3: the output is the activation operand of a bf16x3 GEMM (filed under the key split3(out, plan) looks up)
+    y3 = _x3_begin(out if dot_w is None else None, x3)
     _chk(lib.styler_add_layernorm(x.data_ptr(), _ld(x), _ptr(res), _ld(res) if res is not None else 0,
                                   gamma.data_ptr(), beta.data_ptr(), _ptr(out),
                                   _ld(out) if out is not None else 0, _ptr(dot_w), _ptr(dot_b),
@@ -711,6 +760,7 @@ def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, 
                                   int(in_drop_seed), _ptr(sum_out), _ld(sum_out) if sum_out is not None else 0,
                                   _ptr(out16), _ld(out16) if out16 is not None else 0, ln_io, _stream()),
          "styler_add_layernorm")
+    _x3_end(out, y3, plan)
     return dot_out if dot_w is not None else out
 
 
@@ -724,7 +774,7 @@ def groupnorm_z_bf16_ok(L):
     return 0 < L <= lib.styler_groupnorm_fused_rows(1)
 
 
-def groupnorm_relu(x, gamma, beta, out=None, stats=None):
+def groupnorm_relu(x, gamma, beta, out=None, stats=None, x3=False):
     """`stats` (optional, [B, C/16, 2] fp32) receives mean / rstd of every group for the backward.  x may be bf16
     (groupnorm_z_bf16_ok) -- then `out` must be given."""
     B, L, C = x.shape
@@ -732,8 +782,10 @@ def groupnorm_relu(x, gamma, beta, out=None, stats=None):
         out = x
     ws, z = _norm_ws(B * (C // 16) * 2, x.device)
     io = (2 if out.dtype == torch.bfloat16 else 0) | (IO_Z_BF16 if x.dtype == torch.bfloat16 else 0)
+    y3 = _x3_begin(out, x3)
     _chk(lib.styler_groupnorm_relu(x.data_ptr(), _ld(x), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
                                    _ld(out), _ptr(stats), ws.data_ptr(), z, B, L, C, io, _stream()), "styler_groupnorm_relu")
+    _x3_end(out, y3)
     return out
 
 
@@ -753,7 +805,8 @@ LN_REPLICAS = max(int(os.environ.get("STYLER_LN_REPLICAS", "256")), int(os.envir
 BN_WS_COPIES = 16        # STYLER_BN_COPIES (norms.hip): replicas of the 2C-double column accumulator
 
 
-def batchnorm_train(x, gamma, beta, running_mean, running_var, act, drop_p=0.0, drop_seed=0, segs=1, out_bf16=False):
+def batchnorm_train(x, gamma, beta, running_mean, running_var, act, drop_p=0.0, drop_seed=0, segs=1, out_bf16=False,
+                    x3=False):
     """x [B, L, C] contiguous (conv output incl. bias). Returns y (= dropout(act(BN(x))) with drop_p > 0), save_mean,
     save_rstd ([segs, C]: `segs` equal row ranges, each normalised with its own batch statistics)."""
     assert x.is_contiguous()
@@ -763,11 +816,13 @@ def batchnorm_train(x, gamma, beta, running_mean, running_var, act, drop_p=0.0, 
     mean = torch.empty(segs, C, device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
     ws, z = _norm_ws(2 * C * BN_WS_COPIES * segs, x.device)
+    y3 = _x3_begin(y, x3)
     _chk(lib.styler_batchnorm_train(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
                                     mean.data_ptr(), rstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
                                     ws.data_ptr(), z, rows, C, act, float(drop_p), int(drop_seed), int(segs),
                                     (2 if out_bf16 else 0) | (IO_Z_BF16 if x.dtype == torch.bfloat16 else 0), _stream()),
          "styler_batchnorm_train")
+    _x3_end(y, y3)
     return y, mean, rstd
 
 
@@ -1304,7 +1359,7 @@ def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, do
     return (dx, dxd) if dxd is not None else dx
 
 
-def groupnorm_relu_bwd(x, dy, gamma, beta, stats, dgamma, dbeta, dx_bf16=False):
+def groupnorm_relu_bwd(x, dy, gamma, beta, stats, dgamma, dbeta, dx_bf16=False, x3=False):
     B, L, C = x.shape
     dy = _rows_view(dy)
     dx = torch.empty(B, L, C, device=x.device, dtype=torch.bfloat16 if dx_bf16 else torch.float32)
@@ -1316,29 +1371,33 @@ def groupnorm_relu_bwd(x, dy, gamma, beta, stats, dgamma, dbeta, dx_bf16=False):
         if both is not None:
             sg, sb = both
     pg, pb, slots = (sg, sb, IO_PARAM_SLOTS) if sb is not None else (dgamma, dbeta, 0)
+    y3 = _x3_begin(dx, x3)
     _chk(lib.styler_groupnorm_relu_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), gamma.data_ptr(), beta.data_ptr(),
                                        stats.data_ptr(), dx.data_ptr(), C, pg.data_ptr(), pb.data_ptr(),
                                        ws.data_ptr(), z, B, L, C,
                                        (2 if dx_bf16 else 0) | (1 if dy.dtype == torch.bfloat16 else 0) |
                                        (IO_Z_BF16 if x.dtype == torch.bfloat16 else 0) | slots, _stream()),
          "styler_groupnorm_relu_bwd")
+    _x3_end(dx, y3)
     return dx
 
 
 def batchnorm_bwd(x, y, dy, gamma, mean, rstd, dgamma, dbeta, act, beta=None, drop_p=0.0, drop_seed=0, segs=1,
-                  dx_bf16=False):
+                  dx_bf16=False, x3=False):
     """`y` may be None when `beta` is given (the activation output is recomputed from x)."""
     C = x.shape[-1]
     rows = x.numel() // C
     dy = dy.contiguous()
     dx = torch.empty_like(x, dtype=torch.bfloat16 if dx_bf16 else torch.float32)
     ws, z = _norm_ws(2 * C * BN_WS_COPIES * segs, x.device)
+    y3 = _x3_begin(dx, x3)
     _chk(lib.styler_batchnorm_bwd(x.data_ptr(), _ptr(y), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                   rstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), z,
                                   rows, C, act, _ptr(beta), float(drop_p), int(drop_seed), int(segs),
                                   (2 if dx_bf16 else 0) | (1 if dy.dtype == torch.bfloat16 else 0) |
                                   (IO_Z_BF16 if x.dtype == torch.bfloat16 else 0), _stream()),
          "styler_batchnorm_bwd")
+    _x3_end(dx, y3)
     return dx
 
 
