@@ -198,16 +198,16 @@ def _r16(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
-def _ln_tail_bwd(s, dy, ln, lens, drop):
+def _ln_tail_bwd(s, dy, ln, lens, drop, plan=None):
     """-> (gradient of the residual input, gradient of the dropout branch)."""
     sim = rt.sim_bf16_stream and rt.prec == ops.PREC_BF16 and s.dtype != torch.bfloat16
     if sim:
         dy = _r16(dy)
     if drop[0] > 0:
         dx, dxd = ops.layernorm_bwd(s, dy, ln.weight, ln.bias, G(ln.weight), G(ln.bias), lens=lens, in_drop_p=drop[0],
-                                    in_drop_seed=drop[1])
+                                    in_drop_seed=drop[1], x3=True, plan=plan)
         return (_r16(dx), _r16(dxd)) if sim else (dx, dxd)
-    dx = ops.layernorm_bwd(s, dy, ln.weight, ln.bias, G(ln.weight), G(ln.bias), lens=lens)
+    dx = ops.layernorm_bwd(s, dy, ln.weight, ln.bias, G(ln.weight), G(ln.bias), lens=lens, x3=True, plan=plan)
     if sim:
         dx = _r16(dx)
     return dx, dx
@@ -244,7 +244,7 @@ class FfnSublayerFn(Function):
         w_1, w_2 = ffn.w_1, ffn.w_2
         kw1, kw2 = w_1.weight.shape[2], w_2.weight.shape[2]
         d_hid, d_in = w_1.weight.shape[0], w_2.weight.shape[0]
-        dx_res, d_o = _ln_tail_bwd(s, ops._rows_view(dy), ffn.layer_norm, lens, ctx.drop)
+        dx_res, d_o = _ln_tail_bwd(s, ops._rows_view(dy), ffn.layer_norm, lens, ctx.drop, plan=plan)
         d_og, d_op = _x3_split(d_o, d_in, plan)
         ops.wgrad(d_o, h, G(w_2.weight), d_in, d_hid, kw=kw2, db=G(w_2.bias), plan=plan, dz_parts=d_op)
         wt2, prec2 = gemm_weight_bwd_auto(ffn._derived, "w_2", w_2.weight)
@@ -287,7 +287,7 @@ class AttnSublayerFn(Function):
     def backward(ctx, dy, *_unused):
         x, qkv, att, lse, s, lens = ctx.saved_tensors
         mha, plan = ctx.mha, ctx.plan
-        dx_res, d_o = _ln_tail_bwd(s, ops._rows_view(dy), mha.layer_norm, lens, ctx.drop)
+        dx_res, d_o = _ln_tail_bwd(s, ops._rows_view(dy), mha.layer_norm, lens, ctx.drop, plan=plan)
         bf16 = rt.prec == ops.PREC_BF16
         prec = ops.PREC_BF16 if bf16 else ops.PREC_F32
         d_og, d_op = _x3_split(d_o, 256, plan)

@@ -29,7 +29,10 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ dot_w,
     const float* __restrict__ dout, float* __restrict__ ddot_w, float* __restrict__ ddot_b, int64_t rows, int L,
     const int64_t* __restrict__ len, float drop_p, uint64_t drop_seed_host, const uint64_t* __restrict__ epoch,
-    float in_drop_p, uint64_t in_drop_seed_host, float* __restrict__ dx_drop, int64_t lddxd, int replicas, int flags) {
+    float in_drop_p, uint64_t in_drop_seed_host, float* __restrict__ dx_drop, int64_t lddxd, int replicas, int flags,
+    uint16_t* __restrict__ y3) {
+  // y3 (round 5, bf16x3; styler_set_x3_out): the [hi | lo] split (rows of 512 bf16) of the gradient that feeds the sublayer's
+  // GEMMs -- dx_drop when the forward dropped its input, else dx
   constexpr bool GEN = M < 0;
   const bool x16 = GEN ? (flags & STYLER_LNB_X_BF16) != 0 : (M & LNM_ALL16) != 0;
   const bool dy16 = GEN ? (flags & STYLER_LNB_DY_BF16) != 0 : (M & LNM_ALL16) != 0;
@@ -106,6 +109,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
           if (!live[k]) continue;
           if (dx) stg4(dx, row[k] * lddx + l4, make_float4(0.f, 0.f, 0.f, 0.f), dx16);
           if (has_indrop) stg4(dx_drop, row[k] * lddxd + l4, make_float4(0.f, 0.f, 0.f, 0.f), dxd16);
+          if (y3) x3_store4(y3, row[k], (int)l4, 256, 2, make_float4(0.f, 0.f, 0.f, 0.f));
         }
         continue;
       }
@@ -144,6 +148,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
         live[k] = false;
         if (dx) stg4(dx, row[k] * lddx + l4, make_float4(0.f, 0.f, 0.f, 0.f), dx16);
         if (has_indrop) stg4(dx_drop, row[k] * lddxd + l4, make_float4(0.f, 0.f, 0.f, 0.f), dxd16);
+        if (y3) x3_store4(y3, row[k], (int)l4, 256, 2, make_float4(0.f, 0.f, 0.f, 0.f));
       }
       if (!live[k]) { v[k] = make_float4(0.f, 0.f, 0.f, 0.f); go[k] = 0.f; }
       kx[k][0] = kx[k][1] = kx[k][2] = kx[k][3] = 1.f;
@@ -209,11 +214,14 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
       if (dx) stg4(dx, row[k] * lddx + l4, gx, dx16);
       if (has_indrop) {                                  // gradient of the dropout(x) that fed the sum (same stream)
         const uint32_t elo = ((uint32_t)row[k] << 8) | l4, ehi = (uint32_t)((uint64_t)row[k] >> 24);
-        stg4(dx_drop, row[k] * lddxd + l4,
-             make_float4(dropout_hash32_keyed(key_in, elo, ehi) >= thr_in ? gx.x * sc_in : 0.f,
-                         dropout_hash32_keyed(key_in, elo + 1, ehi) >= thr_in ? gx.y * sc_in : 0.f,
-                         dropout_hash32_keyed(key_in, elo + 2, ehi) >= thr_in ? gx.z * sc_in : 0.f,
-                         dropout_hash32_keyed(key_in, elo + 3, ehi) >= thr_in ? gx.w * sc_in : 0.f), dxd16);
+        const float4 gd = make_float4(dropout_hash32_keyed(key_in, elo, ehi) >= thr_in ? gx.x * sc_in : 0.f,
+                                      dropout_hash32_keyed(key_in, elo + 1, ehi) >= thr_in ? gx.y * sc_in : 0.f,
+                                      dropout_hash32_keyed(key_in, elo + 2, ehi) >= thr_in ? gx.z * sc_in : 0.f,
+                                      dropout_hash32_keyed(key_in, elo + 3, ehi) >= thr_in ? gx.w * sc_in : 0.f);
+        stg4(dx_drop, row[k] * lddxd + l4, gd, dxd16);
+        if (y3) x3_store4(y3, row[k], (int)l4, 256, 2, gd);
+      } else if (y3) {
+        x3_store4(y3, row[k], (int)l4, 256, 2, gx);
       }
     }
   }
@@ -254,6 +262,11 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
                                     int C, const int64_t* len, float drop_p, uint64_t drop_seed, float in_drop_p,
                                     uint64_t in_drop_seed, float* dx_drop, int64_t lddxd, int replicas, int flags,
                                     void* stream) {
+  uint16_t* y3 = nullptr;
+  int y3parts = 0;
+  styler_take_x3_out(&y3, &y3parts);               // (bf16x3: the split of the gradient that feeds the sublayer's GEMMs)
+  if (y3 && (y3parts != 2 || (dx_drop ? (lddxd != C || (flags & STYLER_LNB_DXD_BF16)) : (!dx || lddx != C || (flags & STYLER_LNB_DX_BF16)))))
+    return STYLER_EINVAL;
   if (!x || !gamma || !dgamma || !dbeta || B <= 0 || L <= 0 || C != 256 || replicas < 1) return STYLER_EINVAL;
   if ((int64_t)B * L >= ((int64_t)1 << 31)) return STYLER_EINVAL;
   if (!dot_w && !dy) return STYLER_EINVAL;
@@ -278,7 +291,7 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
 #define LNB_LAUNCH(MODE)                                                                                                       \
   hipLaunchKernelGGL((layernorm_bwd_kernel<2, MODE>), dim3((unsigned)blocks), dim3(64 * LNB_WAVES), 0, (hipStream_t)stream, x,  \
                      ldx, dy, lddy, gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b, rows, L, len, drop_p,    \
-                     drop_seed, g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd, replicas, flags)
+                     drop_seed, g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd, replicas, flags, y3)
 #define LNB_CASE(MODE) case (MODE): LNB_LAUNCH(MODE); break
   switch (mode) {
     // attention / FFN sublayer tails (decoder: packed bf16 stream, encoder: fp32 with lengths), with and without dropout

@@ -1294,7 +1294,7 @@ def attention_bwd(qkv, out, dout, lse, lens, prec=None, plan=None, out_bf16=Fals
 
 
 def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, dot_w=None, dout=None, ddot_w=None,
-                  ddot_b=None, drop_p=0.0, drop_seed=0, in_drop_p=0.0, in_drop_seed=0, relu_input=False):
+                  ddot_b=None, drop_p=0.0, drop_seed=0, in_drop_p=0.0, in_drop_seed=0, relu_input=False, x3=False, plan=None):
     """Returns dx, or (dx, dx_drop) when in_drop_p > 0 (dx_drop = dx through the forward's input-dropout mask).
     relu_input: x is a ReLU output and dx comes back as the gradient w.r.t. the ReLU's input."""
     B, L, C = x.shape
@@ -1343,12 +1343,17 @@ def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, do
             if ddot_b is not None:                       # the tail's scalar bias: per-block slots too (round-3 advisor)
                 fold_db, fold_db_dst = torch.zeros(LN_REPLICAS, device=x.device, dtype=torch.float32), ddot_b
                 ddot_b, lnb_io = fold_db, lnb_io | 64    # STYLER_LNB_DOTB_SLOTS
+    # x3: the gradient that continues into the sublayer's GEMMs (dx_drop when the forward dropped its input, else dx) leaves
+    # with its bf16x3 split, filed under the key split3(., plan) looks up
+    d_o = dxd if dxd is not None else dx
+    y3 = _x3_begin(d_o, x3)
     _chk(lib.styler_layernorm_bwd(x.data_ptr(), _ld(x), _ptr(dy), _ld(dy) if dy is not None else 0, gamma.data_ptr(),
                                   _ptr(beta), _ptr(dx), C, pg.data_ptr(), pb.data_ptr(), _ptr(dot_w),
                                   _ptr(dout), _ptr(pw), _ptr(ddot_b), B, L, C, _ptr(lens), float(drop_p),
                                   int(drop_seed), float(in_drop_p), int(in_drop_seed), _ptr(dxd), C, rep, (1 if relu_input else 0) | lnb_io,
                                   _stream()),
          "styler_layernorm_bwd")
+    _x3_end(d_o, y3, plan)
     if fold is not None:
         _chk(lib.styler_fold_replicas(fold[0].data_ptr(), fold[1].data_ptr(), _ptr(fold[2]) if ddot_w is not None else None,
                                       dgamma.data_ptr(), dbeta.data_ptr(), _ptr(ddot_w), LN_REPLICAS, 256, _stream()),

@@ -110,6 +110,14 @@ def test_norm_producers_file_the_split(dev):
     with _Cache() as cache:
         y = ops.add_layernorm(o, ga, be, res=x, lens=lens, sum_out=torch.empty_like(x), x3=True)
         _same(_filed(cache, y), y, "add_layernorm")
+    # ... and its backward: the gradient that feeds the sublayer's GEMMs (dx_drop with input dropout, else dx)
+    dyl = torch.randn(B, L, 256, generator=g).to(dev)
+    for p_in in (0.0, 0.2):
+        with _Cache() as cache:
+            dg, db = torch.zeros(256, device=dev), torch.zeros(256, device=dev)
+            r = ops.layernorm_bwd(o + x, dyl, ga, be, dg, db, lens=lens, in_drop_p=p_in, in_drop_seed=5, x3=True)
+            d_o = r[1] if p_in > 0 else r
+            _same(_filed(cache, d_o), d_o, f"layernorm_bwd in_drop_p={p_in}")
     # GroupNorm + ReLU forward / backward: single-pass kernels (L <= 512) and the two-kernel forms (L = 700)
     for C, Lg in ((256, 441), (320, 441), (256, 700)):
         xg = (torch.randn(2, Lg, C, generator=g) * 2 + 0.3).to(dev)
