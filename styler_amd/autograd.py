@@ -268,7 +268,7 @@ class AttnSublayerFn(Function):
         qkv = ops.conv_gemm(x, w, b, n=768, prec=prec, plan=plan, out_bf16=prec == ops.PREC_BF16 and rt.bf16_qkv)
         B, L = (plan.B, plan.T) if plan is not None else x.shape[:2]
         lse = torch.empty(B, 4, L, device=x.device, dtype=torch.float32)
-        att = ops.attention_fwd(qkv, lens, lse=lse, plan=plan, out_bf16=prec == ops.PREC_BF16 and rt.bf16_att)
+        att = ops.attention_fwd(qkv, lens, lse=lse, plan=plan, out_bf16=prec == ops.PREC_BF16 and rt.bf16_att, x3=True)
         wfc, pfc = gemm_weight(mha._derived, "fc", mha.fc.weight, 256)
         o = ops.conv_gemm(att, wfc, mha.fc.bias, n=256, prec=pfc, plan=plan)
         want16 = want16 and prec == ops.PREC_BF16
@@ -295,7 +295,8 @@ class AttnSublayerFn(Function):
         wfc, pfc = gemm_weight_bwd_auto(mha._derived, "fc", mha.fc.weight)
         d_att = ops.conv_gemm(d_og if pfc == ops.PREC_BF16X3 else d_o, wfc, None, n=256, prec=pfc, plan=plan,
                               out_bf16=bf16 and att.dtype == torch.bfloat16)
-        dqkv = ops.attention_bwd(qkv, att, d_att, lse, lens, plan=plan, out_bf16=bf16 and rt.bf16_acts and rt.bf16_dqkv)
+        dqkv = ops.attention_bwd(qkv, att, d_att, lse, lens, plan=plan, out_bf16=bf16 and rt.bf16_acts and rt.bf16_dqkv,
+                                 x3=True)
         srcs = [mha.w_qs.weight, mha.w_ks.weight, mha.w_vs.weight]
         dqg, _ = _x3_split(dqkv, 768, plan)           # [hi(768) | lo(768) (| hi)]: per projection, slices of both parts
         x3p = ops.split3_parts(ops.split3(x, plan), 256) if dqg is not dqkv else None

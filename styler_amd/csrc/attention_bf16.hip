@@ -166,6 +166,28 @@ __device__ __forceinline__ void zero32(void* base, int64_t off, int out16) {
     for (int d = 0; d < 32; d += 4) *reinterpret_cast<float4*>(op + d) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
+// round 5, bf16x3: the [hi | lo] split of the same 64 features (the values store_accT writes, split as styler_split3_bf16 does);
+// op3 = the hi block's address of these features, the lo block sits lo_off elements behind it (styler_set_x3_out)
+__device__ __forceinline__ void store_accT_x3(uint16_t* op3, int lo_off, const f32x16& a0, const f32x16& a1, int lh, float scale) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int d = 8 * g + 4 * lh;
+    uint2 h, l;
+    x3_split4(make_float4(a0[g * 4 + 0] * scale, a0[g * 4 + 1] * scale, a0[g * 4 + 2] * scale, a0[g * 4 + 3] * scale), h, l);
+    *reinterpret_cast<uint2*>(op3 + d) = h;
+    *reinterpret_cast<uint2*>(op3 + lo_off + d) = l;
+    x3_split4(make_float4(a1[g * 4 + 0] * scale, a1[g * 4 + 1] * scale, a1[g * 4 + 2] * scale, a1[g * 4 + 3] * scale), h, l);
+    *reinterpret_cast<uint2*>(op3 + 32 + d) = h;
+    *reinterpret_cast<uint2*>(op3 + lo_off + 32 + d) = l;
+  }
+}
+__device__ __forceinline__ void zero32_x3(uint16_t* op3, int lo_off) {          // 32 zeros in both blocks
+#pragma unroll
+  for (int d = 0; d < 32; d += 8) {
+    *reinterpret_cast<uint4*>(op3 + d) = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(op3 + lo_off + d) = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
 __device__ __forceinline__ void store_accT(float* op, const f32x16& a0, const f32x16& a1, int lh, float scale) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -666,7 +688,9 @@ __device__ __forceinline__ void store_rows_x3(uint32_t* dh, uint32_t* dl, const 
 
 __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                   float* __restrict__ lse, int B, int L,
-                                                                  const int64_t* __restrict__ len, const int* __restrict__ cu) {
+                                                                  const int64_t* __restrict__ len, const int* __restrict__ cu,
+                                                                  uint16_t* __restrict__ y3) {
+  // y3 (round 5, styler_set_x3_out): the [hi(256) | lo(256)] split of the output rows, written next to them
   __shared__ __attribute__((aligned(16))) uint32_t sKh[64 * ALD], sKl[64 * ALD], sVh[64 * ALD], sVl[64 * ALD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int tq = lane & 15, tc = (lane >> 4) & 1;
@@ -682,6 +706,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const float* _
   if (bx * 128 >= klen) {
     if (q < Lr) {
       zero32(out, (rowbase + q) * 256 + head * AD + lh * 32, 0);
+      if (y3) zero32_x3(y3 + (rowbase + q) * 512 + head * AD + lh * 32, 256);
       if (lse && lh == 0) lse[((int64_t)b * 4 + head) * L + q] = 0.f;
     }
     return;
@@ -750,6 +775,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const float* _
   }
   if (q < Lr) {
     store_accT(out + (rowbase + q) * 256 + head * AD, o0, o1, lh, 1.f / l_run);
+    if (y3) store_accT_x3(y3 + (rowbase + q) * 512 + head * AD, 256, o0, o1, lh, 1.f / l_run);
     if (lse && lh == 0) lse[((int64_t)b * 4 + head) * L + q] = (m_run + log2f(l_run)) * 0.693147180559945f;
   }
 }
@@ -758,7 +784,8 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_dq_x3_kernel(const float
                                                                      const float* __restrict__ dout, const float* __restrict__ lse,
                                                                      float* __restrict__ dqkv, float* __restrict__ delta,
                                                                      int B, int L, const int64_t* __restrict__ len,
-                                                                     const int* __restrict__ cu) {
+                                                                     const int* __restrict__ cu, uint16_t* __restrict__ y3) {
+  // y3 (round 5, styler_set_x3_out): the [hi(768) | lo(768)] split of the dqkv rows (this kernel: the dq third)
   __shared__ __attribute__((aligned(16))) uint32_t sKh[64 * ALD], sKl[64 * ALD], sVh[64 * ALD], sVl[64 * ALD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int tq = lane & 15, tc = (lane >> 4) & 1;
@@ -774,6 +801,7 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_dq_x3_kernel(const float
   if (bx * 128 >= klen) {
     if (q < Lr) {
       zero32(dqkv, (rowbase + q) * 768 + head * AD + lh * 32, 0);
+      if (y3) zero32_x3(y3 + (rowbase + q) * 1536 + head * AD + lh * 32, 768);
       if (lh == 0) delta[((int64_t)b * 4 + head) * L + q] = 0.f;
     }
     return;
@@ -842,13 +870,17 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_dq_x3_kernel(const float
       }
     }
   }
-  if (q < Lr) store_accT(dqkv + (rowbase + q) * 768 + head * AD, dq0, dq1, lh, 0.125f);
+  if (q < Lr) {
+    store_accT(dqkv + (rowbase + q) * 768 + head * AD, dq0, dq1, lh, 0.125f);
+    if (y3) store_accT_x3(y3 + (rowbase + q) * 1536 + head * AD, 768, dq0, dq1, lh, 0.125f);
+  }
 }
 
 __global__ __launch_bounds__(256, 2) void attention_bwd_dkv_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                       const float* __restrict__ lse, const float* __restrict__ delta,
                                                                       float* __restrict__ dqkv, int B, int L,
-                                                                      const int64_t* __restrict__ len, const int* __restrict__ cu) {
+                                                                      const int64_t* __restrict__ len, const int* __restrict__ cu,
+                                                                      uint16_t* __restrict__ y3) {
   __shared__ __attribute__((aligned(16))) uint32_t sQh[64 * ALD], sQl[64 * ALD], sDh[64 * ALD], sDl2[64 * ALD];
   __shared__ __attribute__((aligned(16))) float sLse[64], sDl[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -946,25 +978,43 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_dkv_x3_kernel(const floa
       zero32(dqkv, off + 256 + lh * 32, 0);
       zero32(dqkv, off + 512 + lh * 32, 0);
     }
+    if (y3) {                                          // round 5: the split of the dk / dv thirds of the row
+      uint16_t* const o3 = y3 + (rowbase + key) * 1536 + head * AD;
+      if (key_ok) {
+        store_accT_x3(o3 + 256, 768, dk0, dk1, lh, 0.125f);
+        store_accT_x3(o3 + 512, 768, dv0, dv1, lh, 1.0f);
+      } else {
+        zero32_x3(o3 + 256 + lh * 32, 768);
+        zero32_x3(o3 + 512 + lh * 32, 768);
+      }
+    }
   }
 }
 
 // fp32 tensors on both sides; same arguments as styler_attention_fwd / styler_attention_bwd
 extern "C" int styler_attention_fwd_x3(const float* qkv, float* out, float* lse, int B, int L, const int64_t* len,
                                        const int32_t* cu, void* stream) {
+  uint16_t* y3 = nullptr;
+  int y3parts = 0;
+  styler_take_x3_out(&y3, &y3parts);               // (the [hi | lo] split of the output rows, for the out-projection GEMM)
+  if (y3 && (y3parts != 2 || ((uintptr_t)y3 & 15))) return STYLER_EINVAL;
   if (!qkv || !out || B <= 0 || L <= 0 || (cu && !len)) return STYLER_EINVAL;
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return STYLER_EALIGN;
-  hipLaunchKernelGGL(attention_fwd_x3_kernel, attn_grid(L, B), dim3(256), 0, (hipStream_t)stream, qkv, out, lse, B, L, len, cu);
+  hipLaunchKernelGGL(attention_fwd_x3_kernel, attn_grid(L, B), dim3(256), 0, (hipStream_t)stream, qkv, out, lse, B, L, len, cu, y3);
   return launch_status();
 }
 extern "C" int styler_attention_bwd_x3(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
                                        float* delta_ws, int B, int L, const int64_t* len, const int32_t* cu, void* stream) {
+  uint16_t* y3 = nullptr;
+  int y3parts = 0;
+  styler_take_x3_out(&y3, &y3parts);               // (the [hi | lo] split of the dqkv rows, for the QKV dX GEMM and weight gradients)
+  if (y3 && (y3parts != 2 || ((uintptr_t)y3 & 15))) return STYLER_EINVAL;
   if (!qkv || !out || !dout || !lse || !dqkv || !delta_ws || B <= 0 || L <= 0) return STYLER_EINVAL;
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 15)) return STYLER_EALIGN;
   const dim3 grid = attn_grid(L, B);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(attention_bwd_dq_x3_kernel, grid, dim3(256), 0, st, qkv, out, dout, lse, dqkv, delta_ws, B, L, len, cu);
-  hipLaunchKernelGGL(attention_bwd_dkv_x3_kernel, grid, dim3(256), 0, st, qkv, dout, lse, delta_ws, dqkv, B, L, len, cu);
+  hipLaunchKernelGGL(attention_bwd_dq_x3_kernel, grid, dim3(256), 0, st, qkv, out, dout, lse, dqkv, delta_ws, B, L, len, cu, y3);
+  hipLaunchKernelGGL(attention_bwd_dkv_x3_kernel, grid, dim3(256), 0, st, qkv, dout, lse, delta_ws, dqkv, B, L, len, cu, y3);
   return launch_status();
 }
 

@@ -711,7 +711,7 @@ def _prec(prec):
 rt_attn_x3 = os.environ.get("STYLER_ATTN_X3", "1") != "0"
 
 
-def attention_fwd(qkv, lens, lse=None, prec=None, plan=None, out_bf16=False):
+def attention_fwd(qkv, lens, lse=None, prec=None, plan=None, out_bf16=False, x3=False):
     """qkv [B, L, 768] (or, with `plan`, the packed [1, B*T, 768]); lse (optional) [B, 4, L] (packed: [B, 4, T]).
     out_bf16 (throughput mode): the output is stored as bf16."""
     assert qkv.is_contiguous() and qkv.shape[2] == 768
@@ -725,12 +725,15 @@ def attention_fwd(qkv, lens, lse=None, prec=None, plan=None, out_bf16=False):
         fn = {PREC_BF16: lib.styler_attention_fwd_bf16, PREC_BF16X3: lib.styler_attention_fwd_x3}.get(_prec(prec), lib.styler_attention_fwd)
         if not rt_attn_x3 and _prec(prec) == PREC_BF16X3:
             fn = lib.styler_attention_fwd
+    # x3 (bf16x3, the x3 kernels only): the output feeds the out-projection GEMM -- its split leaves with it
+    y3 = _x3_begin(out, x3 and fn is lib.styler_attention_fwd_x3)
     if plan is not None:
         _chk(fn(qkv.data_ptr(), out.data_ptr(), _ptr(lse), plan.B, plan.T, plan.lens.data_ptr(), plan.cu.data_ptr(),
                 _stream()), "styler_attention_fwd")
     else:
         B, L, _ = qkv.shape
         _chk(fn(qkv.data_ptr(), out.data_ptr(), _ptr(lse), B, L, _ptr(lens), None, _stream()), "styler_attention_fwd")
+    _x3_end(out, y3, plan)
     return out
 
 
@@ -1269,7 +1272,7 @@ def colsum(dz, out, out2=None):
     _chk(lib.styler_colsum(dz.data_ptr(), _ld(dz), out.data_ptr(), _ptr(out2), rows, C, _stream()), "styler_colsum")
 
 
-def attention_bwd(qkv, out, dout, lse, lens, prec=None, plan=None, out_bf16=False):
+def attention_bwd(qkv, out, dout, lse, lens, prec=None, plan=None, out_bf16=False, x3=False):
     """out_bf16 (throughput mode only): dqkv comes back as bf16 -- what the QKV dX GEMM and the weight gradients round it to."""
     B, L = (plan.B, plan.T) if plan is not None else (qkv.shape[0], qkv.shape[1])
     dout = dout.contiguous()
@@ -1288,8 +1291,10 @@ def attention_bwd(qkv, out, dout, lse, lens, prec=None, plan=None, out_bf16=Fals
                                            _stream()), "styler_attention_bwd_bf16")
     else:
         fn = lib.styler_attention_bwd_x3 if (_prec(prec) == PREC_BF16X3 and rt_attn_x3) else lib.styler_attention_bwd
+        y3 = _x3_begin(dqkv, x3 and fn is lib.styler_attention_bwd_x3)      # (dqkv feeds the QKV dX GEMM + weight gradients)
         _chk(fn(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
                 ws.data_ptr(), B, L, _ptr(lens), cu, _stream()), "styler_attention_bwd")
+        _x3_end(dqkv, y3, plan)
     return dqkv
 
 

@@ -145,6 +145,32 @@ def test_norm_producers_file_the_split(dev):
             _same(_filed(cache, dxb), dxb, f"batchnorm_bwd C={C}")
 
 
+@pytest.mark.parametrize("packed", [False, True])
+def test_attention_x3_kernels_file_the_splits(dev, packed):
+    """The x3 attention kernels: the output's split (for the out-projection GEMM) and dqkv's (QKV dX GEMM + weight gradients),
+    padded rectangle (padded query rows are computed, all-padding key blocks zeroed) and packed rows."""
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(23)
+    B, L = 3, 300
+    lens = torch.tensor([300, 140, 9])
+    valid = (torch.arange(L)[None, :, None] < lens[:, None, None])
+    qkv = (torch.randn(B, L, 768, generator=g) * valid).to(dev)
+    dout = (torch.randn(B, L, 256, generator=g) * valid).to(dev)
+    plan, rows = None, None
+    if packed:
+        plan = ops.PackPlan(lens.to(dev), B, L)
+        qkv, dout = ops.pack_rows(qkv, plan), ops.pack_rows(dout, plan)
+        rows = int(lens.sum())
+    lse = torch.empty(B, 4, L, device=dev)
+    with _Cache() as cache:
+        att = ops.attention_fwd(qkv, lens.to(dev), lse=lse, prec=ops.PREC_BF16X3, plan=plan, x3=True)
+        _same(_filed(cache, att, plan), att, "attention_fwd_x3", plan=plan, rows=rows)
+        dqkv = ops.attention_bwd(qkv, att, dout, lse, lens.to(dev), prec=ops.PREC_BF16X3, plan=plan, x3=True)
+        _same(_filed(cache, dqkv, plan), dqkv, "attention_bwd_x3", plan=plan, rows=rows)
+    plain = ops.attention_fwd(qkv, lens.to(dev), lse=torch.empty_like(lse), prec=ops.PREC_BF16X3, plan=plan)
+    assert torch.equal(plain if rows is None else plain[:, :rows], att if rows is None else att[:, :rows])
+
+
 def test_registration_is_consumed_and_rejected_where_it_cannot_be_honoured(dev):
     from styler_amd import ops
     lib = ops.lib
