@@ -323,8 +323,9 @@ int styler_bn_fold(const float* gamma, const float* beta, const float* running_m
 /* Train-mode BatchNorm1d over (B*L) rows incl. padded frames: computes batch mean / biased
  * var per channel of x (= conv output incl. bias), writes y = act((x-mean)*rstd*g + b),
  * saves mean / rstd [C] for backward and updates running stats with momentum 0.1
- * (unbiased var), as torch.nn.BatchNorm1d does.  workspace: 16 * 2*C doubles (16 replicas of the
- * column accumulator, spreading the fp64 atomics), zeroed here.
+ * (unbiased var), as torch.nn.BatchNorm1d does.  workspace: styler_bn_workspace_doubles(rows, C, segs) doubles -- one [2C]
+ * slot per (segment, 128-row chunk) that the statistics kernels STORE and a fixed-order fold adds up (round 5: no fp64 atomics,
+ * bit-reproducible, nothing to zero: ws_zeroed is ignored).
  * drop_p > 0: y = dropout(act(BN(x))) -- the F.dropout of Layers.py:126-128 in the same pass, with the stream
  * styler_dropout(seed drop_seed) would draw on the [rows, C] tensor. */
 int styler_batchnorm_train(const float* x, const float* gamma, const float* beta, void* y,
@@ -333,8 +334,9 @@ int styler_batchnorm_train(const float* x, const float* gamma, const float* beta
                            int act, float drop_p, uint64_t drop_seed, int segs, int io_flags, void* stream);
 /* `segs` >= 1 (rows % segs == 0): rows [s * rows/segs, (s+1) * rows/segs) are normalised with THEIR OWN batch statistics,
  * exactly as `segs` separate calls (the clean and the noisy decode of styler.py:52,55 run through the PostNet as one batch;
- * Layers.py:126 uses per-call statistics); save_mean / save_rstd are [segs, C], workspace segs * 16 * 2*C doubles, the
- * running statistics receive the segments' momentum updates in order. */
+ * Layers.py:126 uses per-call statistics); save_mean / save_rstd are [segs, C], the running statistics receive the segments'
+ * momentum updates in order. */
+int64_t styler_bn_workspace_doubles(int64_t rows, int C, int segs);
 
 /* ---- embeddings / positions ---------------------------------------------------------
  * out[b,t,:] = emb[text[b,t],:] + pe[t,:]            (Models.py:73-74; emb [152,256])
@@ -690,7 +692,7 @@ int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void* dy, int64
                               int64_t lddx, float* dgamma, float* dbeta, double* workspace, int ws_zeroed,
                               int B, int L, int C, int io_flags, void* stream);
 
-/* BatchNorm1d(train)+act(+dropout) backward; x, y, dy, dx contiguous [rows, C]; workspace 16 * 2*C doubles.
+/* BatchNorm1d(train)+act(+dropout) backward; x, y, dy, dx contiguous [rows, C]; workspace styler_bn_workspace_doubles(rows, C, segs) doubles.
  * y may be NULL when beta is given: the tanh output is then recomputed from x (one read less); drop_p / drop_seed
  * must repeat the forward's (the mask is regenerated, dy is the gradient of the dropped output). */
 int styler_batchnorm_bwd(const float* x, const float* y, const void* dy, const float* gamma,

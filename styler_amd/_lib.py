@@ -94,6 +94,7 @@ _SIGS = {
     "styler_conv_gemm_workspace_bytes": [I, I, I, I, I, I, I, I, I64, I, I],
     "styler_gemm_set_workspace": [P, I64],
     "styler_set_x3_out": [P, I],
+    "styler_bn_workspace_doubles": [I64, I, I],
     "styler_fold_replicas": [P, P, P, P, P, P, I, I, P],
     "styler_groupnorm_relu_bwd": [P, I64, P, I64, P, P, P, P, I64, P, P, P, I, I, I, I, I, P],
     "styler_batchnorm_bwd": [P, P, P, P, P, P, P, P, P, P, I, I64, I, I, P, F, ctypes.c_uint64, I, I, P],
@@ -187,7 +188,7 @@ def _load():
     for name, argtypes in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int64 if name.endswith(("_bytes", "_blocks", "_bytes_io")) else ctypes.c_int
+        fn.restype = ctypes.c_int64 if name.endswith(("_bytes", "_blocks", "_bytes_io", "_doubles")) else ctypes.c_int
     return lib
 
 

@@ -332,10 +332,13 @@ extern "C" int styler_bn_fold(const float* gamma, const float* beta, const float
 }
 
 // Train-mode BatchNorm: pass 1 column sums, pass 2 finalize + normalise.
-// Column sums: block = 32 rows x all channels, 256 threads as (row-lane, float4 column); per-thread fp64 partials are
-// folded across the row-lanes in LDS and leave as fp64 atomics into one of STYLER_BN_COPIES replicas of the 2C-double
-// accumulator (replica = block % COPIES: 16x fewer collisions per address); bn_fold_copies_kernel sums the replicas.
-#define STYLER_BN_COPIES 16
+// Column sums: block = (segment, chunk of 128 rows, tile of 128 channels), 256 threads as (row-lane, float4 column); per-thread
+// fp64 partials are folded across the row-lanes in LDS.  Round 5: they leave as plain STORES into the block's own slot
+// ws[segment][chunk][2C] (until round 4: fp64 atomics into one of 16 replicas -- 41 us with them, 14 us without at
+// [42 336, 512], and the last source of run-to-run order noise in a training step); bn_fold_slots_kernel / bn_finalize_kernel
+// add the chunks of a column in a FIXED order (16 lanes per column take every 16th chunk, then a fixed tree).
+// Workspace: styler_bn_workspace_doubles(rows, C, segs) = segs * ceil(rows / segs / 128) * 2C doubles, no zeroing needed.
+#define BN_FOLD_LANES 16
 #define BN_RPB 32                                  // rows per block of the apply kernels
 #define BN_STAT_RPB 128                            // rows per block of the column statistics
 #define BN_CT 32                                   // float4 columns per block of the column statistics
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const void* __restrict
   const int ct = (nq + nqt - 1) / nqt;               // column tiles
   const int ctile = blockIdx.x % ct, bc = blockIdx.x / ct;
   const int seg = bc / bps, chunk = bc - seg * bps;
-  ws += (int64_t)seg * STYLER_BN_COPIES * 2 * C;
+  ws += ((int64_t)seg * bps + chunk) * 2 * C;         // this block's slot: [2C] doubles (its column tile of them)
   if (BWD) { mean += (int64_t)seg * C; rstd += (int64_t)seg * C; }
   const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
   __shared__ double red[256][8];
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const void* __restrict
   const int64_t r0 = (int64_t)seg * rps + (int64_t)chunk * rpb;
   int64_t r1 = r0 + rpb; if (r1 > (seg + 1) * rps) r1 = (seg + 1) * rps;
   (void)rows;
-  double* wsc = ws + (int64_t)(chunk % STYLER_BN_COPIES) * 2 * C;
+  double* const wsc = ws;
   {
     const int q = ctile * nqt + ql;
     double s[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
@@ -435,29 +438,53 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const void* __restrict
     }
     if (rl == 0 && q < nq && !(dbg & 1)) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { atomicAdd(&wsc[q * 4 + k], s[k]); atomicAdd(&wsc[C + q * 4 + k], t[k]); }
+      for (int k = 0; k < 4; ++k) { wsc[q * 4 + k] = s[k]; wsc[C + q * 4 + k] = t[k]; }
     }
   }
 }
 
-__global__ void bn_fold_copies_kernel(double* __restrict__ ws, int C2, int segs) {
-  const int gi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gi >= C2 * segs) return;
-  const int seg = gi / C2, i = gi - seg * C2;
-  ws += (int64_t)seg * STYLER_BN_COPIES * C2;
+// Sum over the chunk slots of one column, fixed order: lane l of the column's BN_FOLD_LANES lanes adds chunks l, l + 16, ... (four
+// interleaved partial sums: independent loads in flight), then the lanes' sums are added in lane order.
+__device__ __forceinline__ double bn_fold_column(const double* __restrict__ w, int64_t slot_stride, int nslots, int lane,
+                                                 double* __restrict__ red /* [BN_FOLD_LANES] of this column */) {
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+  int k = lane;
+  for (; k + 3 * BN_FOLD_LANES < nslots; k += 4 * BN_FOLD_LANES) {
+    t0 += w[(int64_t)k * slot_stride]; t1 += w[(int64_t)(k + BN_FOLD_LANES) * slot_stride];
+    t2 += w[(int64_t)(k + 2 * BN_FOLD_LANES) * slot_stride]; t3 += w[(int64_t)(k + 3 * BN_FOLD_LANES) * slot_stride];
+  }
+  for (; k < nslots; k += BN_FOLD_LANES) t0 += w[(int64_t)k * slot_stride];
+  red[lane] = (t0 + t1) + (t2 + t3);
+  __syncthreads();
   double t = 0.0;
 #pragma unroll
-  for (int k = 0; k < STYLER_BN_COPIES; ++k) t += ws[(int64_t)k * C2 + i];
-  ws[i] = t;
+  for (int l = 0; l < BN_FOLD_LANES; ++l) t += red[l];
+  return t;
+}
+
+// backward: ws[seg][0][i] = sum over the chunk slots of column i (i < 2C: dbeta and dgamma partial sums), in place
+__global__ __launch_bounds__(256) void bn_fold_slots_kernel(double* __restrict__ ws, int C2, int nslots) {
+  __shared__ double red[16][BN_FOLD_LANES];
+  const int cl = threadIdx.x >> 4, lane = threadIdx.x & 15;
+  const int i = blockIdx.x * 16 + cl, seg = blockIdx.y;
+  double* w = ws + (int64_t)seg * nslots * C2;
+  const int ic = i < C2 ? i : C2 - 1;                 // (clamped: every thread meets the barrier)
+  const double t = bn_fold_column(w + ic, C2, nslots, lane, red[cl]);
+  if (lane == 0 && i < C2) w[i] = t;                 // slot 0 of this column: read above by lane 0 only, before the barrier
+}
+
+extern "C" int64_t styler_bn_workspace_doubles(int64_t rows, int C, int segs) {
+  if (rows <= 0 || C <= 0 || segs < 1) return 0;
+  static const int rpb_env = [] { const char* e = getenv("STYLER_BN_RPB"); return e ? atoi(e) : BN_STAT_RPB; }();
+  const int rpb = rpb_env > 0 ? rpb_env : BN_STAT_RPB;
+  const int64_t rps = rows / segs;
+  return (int64_t)segs * ((rps + rpb - 1) / rpb) * 2 * C;
 }
 
 int styler_bn_colstats(bool bwd, const void* x, const float* y, const void* dy, const float* mean, const float* rstd,
                        double* ws, int ws_zeroed, int64_t rows, int C, int act, const float* gamma, const float* beta,
                        float drop_p, uint64_t drop_seed, int segs, int dy16, int x16, hipStream_t st, bool fold) {
-  if (!ws_zeroed) {
-    hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * STYLER_BN_COPIES * segs, st);
-    if (e != hipSuccess) return (int)e;
-  }
+  (void)ws_zeroed;                                   // (slots are stored, not accumulated: nothing to clear)
   static const int rpb_env = [] { const char* e = getenv("STYLER_BN_RPB"); return e ? atoi(e) : BN_STAT_RPB; }();
   const int rpb = rpb_env > 0 ? rpb_env : BN_STAT_RPB;
   static const int dbg = [] { const char* e = getenv("STYLER_BN_DBG"); return e ? atoi(e) : 0; }();   // timing experiments
@@ -475,20 +502,24 @@ int styler_bn_colstats(bool bwd, const void* x, const float* y, const void* dy, 
   else BN_STATS_LAUNCH(false, false, false);
 #undef BN_STATS_LAUNCH
   // (the forward's finalize kernel sums the replicas itself: one launch less per BatchNorm layer)
-  if (fold) hipLaunchKernelGGL(bn_fold_copies_kernel, dim3((2 * C * segs + 255) / 256), dim3(256), 0, st, ws, 2 * C, segs);
+  if (fold) hipLaunchKernelGGL(bn_fold_slots_kernel, dim3((2 * C + 15) / 16, segs), dim3(256), 0, st, ws, 2 * C, bps);
   return 0;
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ ws, float* save_mean, float* save_rstd,
-                                   float* running_mean, float* running_var, int64_t rows, int C, int segs) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// block = 16 columns x BN_FOLD_LANES lanes: the lanes of a column fold its chunk slots (fixed order), lane 0 finishes
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ ws, float* save_mean, float* save_rstd,
+                                                          float* running_mean, float* running_var, int64_t rows, int C, int segs,
+                                                          int nslots) {
+  __shared__ double red[2][16][BN_FOLD_LANES];
+  const int cl = threadIdx.x >> 4, lane = threadIdx.x & 15;
+  const int c = blockIdx.x * 16 + cl, cc = c < C ? c : C - 1;
   const double n = (double)(rows / segs);
   for (int seg = 0; seg < segs; ++seg) {             // the running statistics see the segments as consecutive calls
-    const double* w = ws + (int64_t)seg * STYLER_BN_COPIES * 2 * C;
-    double s1 = 0.0, s2 = 0.0;                       // the replicas of the column sums, in replica order (bn_fold_copies' sum)
-#pragma unroll
-    for (int k = 0; k < STYLER_BN_COPIES; ++k) { s1 += w[(int64_t)k * 2 * C + c]; s2 += w[(int64_t)k * 2 * C + C + c]; }
+    const double* w = ws + (int64_t)seg * nslots * 2 * C;
+    if (seg) __syncthreads();                        // (the previous segment's reads of `red` are done)
+    const double s1 = bn_fold_column(w + cc, 2 * C, nslots, lane, red[0][cl]);
+    const double s2 = bn_fold_column(w + C + cc, 2 * C, nslots, lane, red[1][cl]);
+    if (lane != 0 || c >= C) continue;
     const double mean = s1 / n;
     double var = s2 / n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -583,8 +614,8 @@ extern "C" int styler_batchnorm_train(const float* x, const float* gamma, const 
   const int rc = styler_bn_colstats(false, x, nullptr, nullptr, nullptr, nullptr, workspace, ws_zeroed, rows, C, act, nullptr,
                                     nullptr, 0.f, 0, segs, 0, x16, st, /*fold=*/false);
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, save_mean, save_rstd,
-                     running_mean, running_var, rows, C, segs);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, save_mean, save_rstd,
+                     running_mean, running_var, rows, C, segs, (int)(styler_bn_workspace_doubles(rows, C, segs) / ((int64_t)segs * 2 * C)));
   const int64_t rps = rows / segs;
   const int bps = (int)((rps + BN_RPB - 1) / BN_RPB);
   if (x16)

@@ -625,7 +625,7 @@ extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void
 int styler_bn_colstats(bool bwd, const void* x, const float* y, const void* dy, const float* mean, const float* rstd,
                        double* ws, int ws_zeroed, int64_t rows, int C, int act, const float* gamma, const float* beta,
                        float drop_p, uint64_t drop_seed, int segs, int dy16, int x16, hipStream_t st, bool fold);   // norms.hip
-#define STYLER_BN_COPIES 16                          // norms.hip
+extern "C" int64_t styler_bn_workspace_doubles(int64_t rows, int C, int segs);   // norms.hip: segs * chunk slots * 2C
 
 // Same geometry as the forward's column statistics / apply kernels (norms.hip): block = (segment, chunk of rpb rows),
 // thread = (row-lane, float4 column); per-channel constants (incl. the two fp64 column sums) once per thread, rows in
@@ -639,15 +639,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
                                                            int C, int act, const float* __restrict__ beta,
                                                            float drop_p, uint64_t drop_seed_host,
                                                            const uint64_t* __restrict__ epoch, int segs, int rpb, int bps,
-                                                           int64_t rps, int dx16, uint16_t* __restrict__ y3, int y3parts) {
+                                                           int64_t rps, int dx16, uint16_t* __restrict__ y3, int y3parts,
+                                                           int nslots) {
   float* const dx = reinterpret_cast<float*>(dxv);
   uint16_t* const dxh = reinterpret_cast<uint16_t*>(dxv);  // dx16: bf16 output (see gn_bwd_apply_kernel)
-  // parameter gradients: first C * segs threads of the grid
+  // parameter gradients: first C threads of the grid, one per channel, the segments added in order (round 5: no atomics --
+  // two segments adding into one element in arrival order was the BatchNorm's share of the step's order noise)
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid < (int64_t)C * segs) {
-    const int sg = (int)(gid / C), c = (int)(gid - (int64_t)sg * C);
-    const double* wseg = ws + (int64_t)sg * STYLER_BN_COPIES * 2 * C;
-    atomicAdd(dbeta + c, (float)wseg[c]); atomicAdd(dgamma + c, (float)wseg[C + c]);
+  if (gid < (int64_t)C) {
+    const int c = (int)gid;
+    float gb = dbeta[c], gg = dgamma[c];
+    for (int sg = 0; sg < segs; ++sg) {
+      const double* wseg = ws + (int64_t)sg * nslots * 2 * C;
+      gb += (float)wseg[c]; gg += (float)wseg[C + c];
+    }
+    dbeta[c] = gb; dgamma[c] = gg;
   }
   const int seg = blockIdx.x / bps, chunk = blockIdx.x - seg * bps;
   if (seg >= segs) return;                           // (blocks added only to carry the parameter-gradient threads)
@@ -658,7 +664,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
   if (rl >= lanes) return;
   const double inv_n = 1.0 / (double)rps;
   const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
-  const double* wseg = ws + (int64_t)seg * STYLER_BN_COPIES * 2 * C;
+  const double* wseg = ws + (int64_t)seg * nslots * 2 * C;
   const bool has_y = y && act == STYLER_ACT_TANH;
   const int64_t r0 = (int64_t)seg * rps + (int64_t)chunk * rpb;
   int64_t r1 = r0 + rpb; if (r1 > (seg + 1) * rps) r1 = (seg + 1) * rps;
@@ -732,11 +738,12 @@ extern "C" int styler_batchnorm_bwd(const float* x, const float* y, const void* 
   const int64_t rps = rows / segs;
   const int bps = (int)((rps + RPB - 1) / RPB);
   int64_t blocks = (int64_t)bps * segs;
-  if (blocks * 256 < (int64_t)C * segs) blocks = ((int64_t)C * segs + 255) / 256;
+  if (blocks * 256 < (int64_t)C) blocks = ((int64_t)C + 255) / 256;
+  const int nslots = (int)(styler_bn_workspace_doubles(rows, C, segs) / ((int64_t)segs * 2 * C));
   const int dx16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
 #define BNB_LAUNCH(D_, X_)                                                                                                      \
   hipLaunchKernelGGL((bn_bwd_apply_kernel<D_, X_>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd, \
-                     workspace, dx, dgamma, dbeta, C, act, beta, drop_p, drop_seed, g_styler_drop_epoch, segs, RPB, bps, rps, dx16, y3, y3parts)
+                     workspace, dx, dgamma, dbeta, C, act, beta, drop_p, drop_seed, g_styler_drop_epoch, segs, RPB, bps, rps, dx16, y3, y3parts, nslots)
   if (dy16 && x16) BNB_LAUNCH(true, true);
   else if (dy16) BNB_LAUNCH(true, false);
   else if (x16) BNB_LAUNCH(false, true);

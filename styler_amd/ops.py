@@ -805,7 +805,10 @@ def bn_fold(gamma, beta, running_mean, running_var, conv_bias):
 # so the blocks STORE instead of adding atomically -- never fewer slots than that cap (with fewer the kernel would fall back to
 # fp32 atomics into slot block % replicas)
 LN_REPLICAS = max(int(os.environ.get("STYLER_LN_REPLICAS", "256")), int(os.environ.get("STYLER_LNBWD_BLOCKS", "256")))
-BN_WS_COPIES = 16        # STYLER_BN_COPIES (norms.hip): replicas of the 2C-double column accumulator
+def _bn_ws(rows, C, segs, device):
+    """BatchNorm's column-statistics workspace: one [2C]-double slot per (segment, 128-row chunk), STORED by the statistics
+    kernels and folded in a fixed order (round 5: no fp64 atomics, nothing to zero -- not taken from the zero slab)."""
+    return torch.empty(int(lib.styler_bn_workspace_doubles(rows, C, segs)), device=device, dtype=torch.float64), 0
 
 
 def batchnorm_train(x, gamma, beta, running_mean, running_var, act, drop_p=0.0, drop_seed=0, segs=1, out_bf16=False,
@@ -818,7 +821,7 @@ def batchnorm_train(x, gamma, beta, running_mean, running_var, act, drop_p=0.0, 
     y = torch.empty_like(x, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     mean = torch.empty(segs, C, device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
-    ws, z = _norm_ws(2 * C * BN_WS_COPIES * segs, x.device)
+    ws, z = _bn_ws(rows, C, segs, x.device)
     y3 = _x3_begin(y, x3)
     _chk(lib.styler_batchnorm_train(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
                                     mean.data_ptr(), rstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
@@ -1399,7 +1402,7 @@ def batchnorm_bwd(x, y, dy, gamma, mean, rstd, dgamma, dbeta, act, beta=None, dr
     rows = x.numel() // C
     dy = dy.contiguous()
     dx = torch.empty_like(x, dtype=torch.bfloat16 if dx_bf16 else torch.float32)
-    ws, z = _norm_ws(2 * C * BN_WS_COPIES * segs, x.device)
+    ws, z = _bn_ws(rows, C, segs, x.device)
     y3 = _x3_begin(dx, x3)
     _chk(lib.styler_batchnorm_bwd(x.data_ptr(), _ptr(y), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                   rstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), z,
