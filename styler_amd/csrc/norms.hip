@@ -336,9 +336,9 @@ extern "C" int styler_bn_fold(const float* gamma, const float* beta, const float
 // fp64 partials are folded across the row-lanes in LDS.  Round 5: they leave as plain STORES into the block's own slot
 // ws[segment][chunk][2C] (until round 4: fp64 atomics into one of 16 replicas -- 41 us with them, 14 us without at
 // [42 336, 512], and the last source of run-to-run order noise in a training step); bn_fold_slots_kernel / bn_finalize_kernel
-// add the chunks of a column in a FIXED order (16 lanes per column take every 16th chunk, then a fixed tree).
+// add the chunks of a column in a FIXED order (the 64 lanes of a wave take every 64th chunk, then a fixed shuffle tree).
 // Workspace: styler_bn_workspace_doubles(rows, C, segs) = segs * ceil(rows / segs / 128) * 2C doubles, no zeroing needed.
-#define BN_FOLD_LANES 16
+
 #define BN_RPB 32                                  // rows per block of the apply kernels
 #define BN_STAT_RPB 128                            // rows per block of the column statistics
 #define BN_CT 32                                   // float4 columns per block of the column statistics
@@ -443,34 +443,32 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const void* __restrict
   }
 }
 
-// Sum over the chunk slots of one column, fixed order: lane l of the column's BN_FOLD_LANES lanes adds chunks l, l + 16, ... (four
-// interleaved partial sums: independent loads in flight), then the lanes' sums are added in lane order.
-__device__ __forceinline__ double bn_fold_column(const double* __restrict__ w, int64_t slot_stride, int nslots, int lane,
-                                                 double* __restrict__ red /* [BN_FOLD_LANES] of this column */) {
-  double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+// Sums over the chunk slots of TWO columns (a, b) at once, fixed order: lane l of the pair's 64 lanes adds chunks l, l + 64, ...
+// (both columns' loads in flight together), a wave shuffle tree in a fixed pattern adds the 64 lane sums -- every lane returns
+// the totals.  (331 chunks at the PostNet shape: five or six dependent loads per lane; the 16-lane form of the first build took
+// 21 per lane and the forward's finalize pass went from 5 to ~12 us.)
+__device__ __forceinline__ void bn_fold_pair(const double* __restrict__ wa, const double* __restrict__ wb, int64_t slot_stride,
+                                             int nslots, int lane, double& sa, double& sb) {
+  double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
   int k = lane;
-  for (; k + 3 * BN_FOLD_LANES < nslots; k += 4 * BN_FOLD_LANES) {
-    t0 += w[(int64_t)k * slot_stride]; t1 += w[(int64_t)(k + BN_FOLD_LANES) * slot_stride];
-    t2 += w[(int64_t)(k + 2 * BN_FOLD_LANES) * slot_stride]; t3 += w[(int64_t)(k + 3 * BN_FOLD_LANES) * slot_stride];
+  for (; k + 64 < nslots; k += 128) {
+    a0 += wa[(int64_t)k * slot_stride]; b0 += wb[(int64_t)k * slot_stride];
+    a1 += wa[(int64_t)(k + 64) * slot_stride]; b1 += wb[(int64_t)(k + 64) * slot_stride];
   }
-  for (; k < nslots; k += BN_FOLD_LANES) t0 += w[(int64_t)k * slot_stride];
-  red[lane] = (t0 + t1) + (t2 + t3);
-  __syncthreads();
-  double t = 0.0;
-#pragma unroll
-  for (int l = 0; l < BN_FOLD_LANES; ++l) t += red[l];
-  return t;
+  if (k < nslots) { a0 += wa[(int64_t)k * slot_stride]; b0 += wb[(int64_t)k * slot_stride]; }
+  sa = wave_sum_d(a0 + a1);                          // xor butterfly: the same association on every lane and every launch
+  sb = wave_sum_d(b0 + b1);
 }
 
-// backward: ws[seg][0][i] = sum over the chunk slots of column i (i < 2C: dbeta and dgamma partial sums), in place
-__global__ __launch_bounds__(256) void bn_fold_slots_kernel(double* __restrict__ ws, int C2, int nslots) {
-  __shared__ double red[16][BN_FOLD_LANES];
-  const int cl = threadIdx.x >> 4, lane = threadIdx.x & 15;
-  const int i = blockIdx.x * 16 + cl, seg = blockIdx.y;
-  double* w = ws + (int64_t)seg * nslots * C2;
-  const int ic = i < C2 ? i : C2 - 1;                 // (clamped: every thread meets the barrier)
-  const double t = bn_fold_column(w + ic, C2, nslots, lane, red[cl]);
-  if (lane == 0 && i < C2) w[i] = t;                 // slot 0 of this column: read above by lane 0 only, before the barrier
+// backward: ws[seg][0][i] = sum over the chunk slots of column i (i < 2C: the dbeta / dgamma partial sums), in place.
+// One wave per pair of columns (i, i + C): 4 pairs per block.
+__global__ __launch_bounds__(256) void bn_fold_slots_kernel(double* __restrict__ ws, int C, int nslots) {
+  const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6), seg = blockIdx.y;
+  if (c >= C) return;
+  double* w = ws + (int64_t)seg * nslots * 2 * C;
+  double s1, s2;
+  bn_fold_pair(w + c, w + C + c, 2 * C, nslots, lane, s1, s2);
+  if (lane == 0) { w[c] = s1; w[C + c] = s2; }       // slot 0 of the two columns: read above by THIS lane only (k = lane = 0)
 }
 
 extern "C" int64_t styler_bn_workspace_doubles(int64_t rows, int C, int segs) {
@@ -502,24 +500,22 @@ int styler_bn_colstats(bool bwd, const void* x, const float* y, const void* dy, 
   else BN_STATS_LAUNCH(false, false, false);
 #undef BN_STATS_LAUNCH
   // (the forward's finalize kernel sums the replicas itself: one launch less per BatchNorm layer)
-  if (fold) hipLaunchKernelGGL(bn_fold_slots_kernel, dim3((2 * C + 15) / 16, segs), dim3(256), 0, st, ws, 2 * C, bps);
+  if (fold) hipLaunchKernelGGL(bn_fold_slots_kernel, dim3((C + 3) / 4, segs), dim3(256), 0, st, ws, C, bps);
   return 0;
 }
 
-// block = 16 columns x BN_FOLD_LANES lanes: the lanes of a column fold its chunk slots (fixed order), lane 0 finishes
+// one wave per channel (4 per block): its lanes fold the chunk slots of the channel's two column sums (fixed order), lane 0 finishes
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ ws, float* save_mean, float* save_rstd,
                                                           float* running_mean, float* running_var, int64_t rows, int C, int segs,
                                                           int nslots) {
-  __shared__ double red[2][16][BN_FOLD_LANES];
-  const int cl = threadIdx.x >> 4, lane = threadIdx.x & 15;
-  const int c = blockIdx.x * 16 + cl, cc = c < C ? c : C - 1;
+  const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
   const double n = (double)(rows / segs);
   for (int seg = 0; seg < segs; ++seg) {             // the running statistics see the segments as consecutive calls
     const double* w = ws + (int64_t)seg * nslots * 2 * C;
-    if (seg) __syncthreads();                        // (the previous segment's reads of `red` are done)
-    const double s1 = bn_fold_column(w + cc, 2 * C, nslots, lane, red[0][cl]);
-    const double s2 = bn_fold_column(w + C + cc, 2 * C, nslots, lane, red[1][cl]);
-    if (lane != 0 || c >= C) continue;
+    double s1, s2;
+    bn_fold_pair(w + c, w + C + c, 2 * C, nslots, lane, s1, s2);
+    if (lane != 0) continue;
     const double mean = s1 / n;
     double var = s2 / n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -614,7 +610,7 @@ extern "C" int styler_batchnorm_train(const float* x, const float* gamma, const 
   const int rc = styler_bn_colstats(false, x, nullptr, nullptr, nullptr, nullptr, workspace, ws_zeroed, rows, C, act, nullptr,
                                     nullptr, 0.f, 0, segs, 0, x16, st, /*fold=*/false);
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, save_mean, save_rstd,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, save_mean, save_rstd,
                      running_mean, running_var, rows, C, segs, (int)(styler_bn_workspace_doubles(rows, C, segs) / ((int64_t)segs * 2 * C)));
   const int64_t rps = rows / segs;
   const int bps = (int)((rps + BN_RPB - 1) / BN_RPB);
