@@ -194,7 +194,10 @@ __device__ __forceinline__ float gn_group_sum_wave(float s) {    // over the lan
   return s;
 }
 // X16: x (the convolution output, kept for the backward) is stored as bf16 (STYLER_IO_Z_BF16).
-template <int IT, bool X16 = false>
+// Y3 (round 5, bf16x3): the split of the fp32 output is stored too (styler_set_x3_out).  A template argument, not a runtime
+// test: the two extra kernel arguments cost the bf16 instantiations registers they do not have (gn_bwd_fused spilled, bn_apply
+// went from 98 to 146 VGPRs when y3 was a plain argument of every instantiation).
+template <int IT, bool X16 = false, bool Y3 = false>
 __global__ __launch_bounds__(1024) void gn_fused_kernel(const void* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         void* __restrict__ y, int64_t ldy, float* __restrict__ stats, int L,
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const void* __restrict__
     o.z = fmaxf(v[i].z * a.z + bt.z, 0.f); o.w = fmaxf(v[i].w * a.w + bt.w, 0.f);
     if (y16) *reinterpret_cast<uint2*>(yp16 + (int64_t)t * ldy) = make_uint2(cvt_pk_bf16_rne(o.x, o.y), cvt_pk_bf16_rne(o.z, o.w));
     else *reinterpret_cast<float4*>(yp + (int64_t)t * ldy) = o;
-    if (y3) x3_store4(y3, (int64_t)b * L + t, c0 + cq * 4, C, y3parts, o);    // round 5, bf16x3 (styler_set_x3_out)
+    if (Y3) x3_store4(y3, (int64_t)b * L + t, c0 + cq * 4, C, y3parts, o);    // round 5, bf16x3 (styler_set_x3_out)
   }
 }
 // 0: two-kernel form; otherwise the rows per thread of the single-pass variant that holds an item of L rows.  The backward
@@ -291,10 +294,11 @@ extern "C" int styler_groupnorm_relu(const float* x, int64_t ldx, const float* g
   const bool x16 = (io_flags & STYLER_IO_Z_BF16) != 0;
   if (const int it = gn_fused_iters(L, false)) {
     const int y16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
-#define GNF_LAUNCH(IT_, X_) hipLaunchKernelGGL((gn_fused_kernel<IT_, X_>), dim3(C / 64, B), dim3(1024), 0, st, x, ldx, gamma, beta, y, \
-                                               ldy, stats, L, C, y16, y3, y3parts)
-    if (it == GNF_IT) { if (x16) GNF_LAUNCH(GNF_IT, true); else GNF_LAUNCH(GNF_IT, false); }
-    else { if (x16) GNF_LAUNCH(2 * GNF_IT, true); else GNF_LAUNCH(2 * GNF_IT, false); }
+#define GNF_LAUNCH(IT_, X_, Y_) hipLaunchKernelGGL((gn_fused_kernel<IT_, X_, Y_>), dim3(C / 64, B), dim3(1024), 0, st, x, ldx, gamma, beta, y, \
+                                                   ldy, stats, L, C, y16, y3, y3parts)
+    if (y3 && x16) return STYLER_EINVAL;             // (the split goes with fp32 tensors: the bf16x3 arithmetic stores fp32)
+    if (it == GNF_IT) { if (x16) GNF_LAUNCH(GNF_IT, true, false); else if (y3) GNF_LAUNCH(GNF_IT, false, true); else GNF_LAUNCH(GNF_IT, false, false); }
+    else { if (x16) GNF_LAUNCH(2 * GNF_IT, true, false); else if (y3) GNF_LAUNCH(2 * GNF_IT, false, true); else GNF_LAUNCH(2 * GNF_IT, false, false); }
 #undef GNF_LAUNCH
     return launch_status();
   }
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
 // Normalise + activation + dropout.  Same geometry as the column statistics: block = (segment, chunk of rpb rows), thread =
 // (row-lane, float4 column): the per-channel constants are fetched once per thread, the rows in batches of four, and no
 // index is ever divided.
-template <bool X16>
+template <bool X16, bool Y3 = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
                                                        const float* __restrict__ mean,
@@ -588,7 +592,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ 
         }
         if (y16) *reinterpret_cast<uint2*>(yh + ru * C + q * 4) = make_uint2(cvt_pk_bf16_rne(o.x, o.y), cvt_pk_bf16_rne(o.z, o.w));
         else *reinterpret_cast<float4*>(y + ru * C + q * 4) = o;
-        if (y3) x3_store4(y3, ru, q * 4, C, y3parts, o);     // round 5, bf16x3: the split of the fp32 output (styler_set_x3_out)
+        if (Y3) x3_store4(y3, ru, q * 4, C, y3parts, o);     // round 5, bf16x3: the split of the fp32 output (styler_set_x3_out)
       }
     }
   }
@@ -601,7 +605,7 @@ extern "C" int styler_batchnorm_train(const float* x, const float* gamma, const 
   uint16_t* y3 = nullptr;
   int y3parts = 0;
   styler_take_x3_out(&y3, &y3parts);               // (bf16x3: the split of the fp32 output rows, filed by the caller)
-  if (y3 && (io_flags & STYLER_IO_Y_BF16)) return STYLER_EINVAL;
+  if (y3 && (io_flags & (STYLER_IO_Y_BF16 | STYLER_IO_Z_BF16))) return STYLER_EINVAL;
   if (!x || !gamma || !beta || !y || !save_mean || !save_rstd || !workspace || rows <= 0 || C <= 0 || (C & 3) ||
       drop_p < 0.f || drop_p >= 1.f || segs < 1 || rows % segs)
     return STYLER_EINVAL;
@@ -617,6 +621,9 @@ extern "C" int styler_batchnorm_train(const float* x, const float* gamma, const 
   if (x16)
     hipLaunchKernelGGL(bn_apply_kernel<true>, dim3((unsigned)(bps * segs)), dim3(256), 0, st, x, gamma, beta, save_mean, save_rstd,
                        y, C, act, drop_p, drop_seed, g_styler_drop_epoch, BN_RPB, bps, rps, (io_flags & STYLER_IO_Y_BF16) ? 1 : 0, y3, y3parts);
+  else if (y3)
+    hipLaunchKernelGGL((bn_apply_kernel<false, true>), dim3((unsigned)(bps * segs)), dim3(256), 0, st, x, gamma, beta, save_mean, save_rstd,
+                       y, C, act, drop_p, drop_seed, g_styler_drop_epoch, BN_RPB, bps, rps, 0, y3, y3parts);
   else
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3((unsigned)(bps * segs)), dim3(256), 0, st, x, gamma, beta, save_mean, save_rstd,
                        y, C, act, drop_p, drop_seed, g_styler_drop_epoch, BN_RPB, bps, rps, (io_flags & STYLER_IO_Y_BF16) ? 1 : 0, y3, y3parts);

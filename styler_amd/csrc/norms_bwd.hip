@@ -22,7 +22,7 @@
 // Same expressions in the same order as before: the results are bit-identical to the round-2 kernel.
 enum { LNM_ALL16 = 1, LNM_DOT = 2, LNM_DROP = 4, LNM_INDROP = 8, LNM_LEN = 16, LNM_RELU = 32 };
 
-template <int R, int M>
+template <int R, int M, bool Y3 = false>
 __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dx, int64_t lddx,
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
           if (!live[k]) continue;
           if (dx) stg4(dx, row[k] * lddx + l4, make_float4(0.f, 0.f, 0.f, 0.f), dx16);
           if (has_indrop) stg4(dx_drop, row[k] * lddxd + l4, make_float4(0.f, 0.f, 0.f, 0.f), dxd16);
-          if (y3) x3_store4(y3, row[k], (int)l4, 256, 2, make_float4(0.f, 0.f, 0.f, 0.f));
+          if (Y3) x3_store4(y3, row[k], (int)l4, 256, 2, make_float4(0.f, 0.f, 0.f, 0.f));
         }
         continue;
       }
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
         live[k] = false;
         if (dx) stg4(dx, row[k] * lddx + l4, make_float4(0.f, 0.f, 0.f, 0.f), dx16);
         if (has_indrop) stg4(dx_drop, row[k] * lddxd + l4, make_float4(0.f, 0.f, 0.f, 0.f), dxd16);
-        if (y3) x3_store4(y3, row[k], (int)l4, 256, 2, make_float4(0.f, 0.f, 0.f, 0.f));
+        if (Y3) x3_store4(y3, row[k], (int)l4, 256, 2, make_float4(0.f, 0.f, 0.f, 0.f));
       }
       if (!live[k]) { v[k] = make_float4(0.f, 0.f, 0.f, 0.f); go[k] = 0.f; }
       kx[k][0] = kx[k][1] = kx[k][2] = kx[k][3] = 1.f;
@@ -219,8 +219,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
                                       dropout_hash32_keyed(key_in, elo + 2, ehi) >= thr_in ? gx.z * sc_in : 0.f,
                                       dropout_hash32_keyed(key_in, elo + 3, ehi) >= thr_in ? gx.w * sc_in : 0.f);
         stg4(dx_drop, row[k] * lddxd + l4, gd, dxd16);
-        if (y3) x3_store4(y3, row[k], (int)l4, 256, 2, gd);
-      } else if (y3) {
+        if (Y3) x3_store4(y3, row[k], (int)l4, 256, 2, gd);
+      } else if (Y3) {
         x3_store4(y3, row[k], (int)l4, 256, 2, gx);
       }
     }
@@ -292,6 +292,26 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
   hipLaunchKernelGGL((layernorm_bwd_kernel<2, MODE>), dim3((unsigned)blocks), dim3(64 * LNB_WAVES), 0, (hipStream_t)stream, x,  \
                      ldx, dy, lddy, gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b, rows, L, len, drop_p,    \
                      drop_seed, g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd, replicas, flags, y3)
+  if (y3) {                                          // bf16x3: the fp32 sublayer-tail modes with the split output (Y3 = true)
+#define LNB3_CASE(MODE)                                                                                                         \
+    case (MODE):                                                                                                                \
+      hipLaunchKernelGGL((layernorm_bwd_kernel<2, MODE, true>), dim3((unsigned)blocks), dim3(64 * LNB_WAVES), 0,                  \
+                         (hipStream_t)stream, x, ldx, dy, lddy, gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b, \
+                         rows, L, len, drop_p, drop_seed, g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd, replicas,  \
+                         flags, y3);                                                                                            \
+      break
+    switch (mode) {
+      LNB3_CASE(0); LNB3_CASE(LNM_INDROP); LNB3_CASE(LNM_LEN); LNB3_CASE(LNM_LEN | LNM_INDROP);
+      default:
+        hipLaunchKernelGGL((layernorm_bwd_kernel<2, -1, true>), dim3((unsigned)blocks), dim3(64 * LNB_WAVES), 0,
+                           (hipStream_t)stream, x, ldx, dy, lddy, gamma, beta, dx, lddx, dgamma, dbeta, dot_w, dout, ddot_w, ddot_b,
+                           rows, L, len, drop_p, drop_seed, g_styler_drop_epoch, in_drop_p, in_drop_seed, dx_drop, lddxd, replicas,
+                           flags, y3);
+        break;
+    }
+#undef LNB3_CASE
+    return launch_status();
+  }
 #define LNB_CASE(MODE) case (MODE): LNB_LAUNCH(MODE); break
   switch (mode) {
     // attention / FFN sublayer tails (decoder: packed bf16 stream, encoder: fp32 with lengths), with and without dropout
@@ -473,7 +493,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 // loaded once and stay in registers between the group sums and dx -- 3 tensor passes over HBM instead of 5.
 #define GNB_IT 8
 int gn_fused_iters(int L, bool bwd);                // norms.hip
-template <bool DY16, int IT, bool X16 = false>
+template <bool DY16, int IT, bool X16 = false, bool Y3 = false>      // (Y3: see gn_fused_kernel, norms.hip)
 __global__ __launch_bounds__(1024) void gn_bwd_fused_kernel(const void* __restrict__ x, int64_t ldx,
                                                             const void* __restrict__ dy, int64_t lddy,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -565,7 +585,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_fused_kernel(const void* __restri
                                  rstd * (g.z - m1 - v[i].z * m2), rstd * (g.w - m1 - v[i].w * m2));
     if (dx16) *reinterpret_cast<uint2*>(dxp16 + (int64_t)t * lddx) = make_uint2(cvt_pk_bf16_rne(o.x, o.y), cvt_pk_bf16_rne(o.z, o.w));
     else *reinterpret_cast<float4*>(dxp + (int64_t)t * lddx) = o;
-    if (y3) x3_store4(y3, (int64_t)b * L + t, c0 + cq * 4, C, y3parts, o);     // round 5, bf16x3 (styler_set_x3_out)
+    if (Y3) x3_store4(y3, (int64_t)b * L + t, c0 + cq * 4, C, y3parts, o);     // round 5, bf16x3 (styler_set_x3_out)
   }
 }
 
@@ -576,7 +596,7 @@ extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void
   uint16_t* y3 = nullptr;
   int y3parts = 0;
   styler_take_x3_out(&y3, &y3parts);               // (bf16x3: the split of the fp32 gradient rows, filed by the caller)
-  if (y3 && ((io_flags & STYLER_IO_Y_BF16) || lddx != C)) return STYLER_EINVAL;
+  if (y3 && ((io_flags & (STYLER_IO_Y_BF16 | STYLER_IO_X_BF16 | STYLER_IO_Z_BF16)) || lddx != C)) return STYLER_EINVAL;
   if (!x || !dy || !gamma || !beta || !stats || !dx || !dgamma || !dbeta || !workspace || B <= 0 || L <= 0 || C <= 0 ||
       (C & 63))
     return STYLER_EINVAL;
@@ -588,12 +608,13 @@ extern "C" int styler_groupnorm_relu_bwd(const float* x, int64_t ldx, const void
   const bool pslots = (io_flags & STYLER_IO_PARAM_SLOTS) != 0;
   if (pslots && !gn_fused_iters(L, true)) return STYLER_EINVAL;        // slots: the single-pass kernel only
   if (gn_fused_iters(L, true)) {
-#define GNB_LAUNCH(D_, I_, X_) hipLaunchKernelGGL((gn_bwd_fused_kernel<D_, I_, X_>), dim3(C / 64, B), dim3(1024), 0, st, x, ldx, dy, \
-                                                  lddy, gamma, beta, stats, dx, lddx, dgamma, dbeta, L, C, dx16 | (pslots ? 2 : 0), y3, y3parts)
-    if (dy16 && x16) GNB_LAUNCH(true, GNB_IT, true);
-    else if (dy16) GNB_LAUNCH(true, GNB_IT, false);
-    else if (x16) GNB_LAUNCH(false, GNB_IT, true);
-    else GNB_LAUNCH(false, GNB_IT, false);
+#define GNB_LAUNCH(D_, I_, X_, Y_) hipLaunchKernelGGL((gn_bwd_fused_kernel<D_, I_, X_, Y_>), dim3(C / 64, B), dim3(1024), 0, st, x, ldx, dy, \
+                                                      lddy, gamma, beta, stats, dx, lddx, dgamma, dbeta, L, C, dx16 | (pslots ? 2 : 0), y3, y3parts)
+    if (dy16 && x16) GNB_LAUNCH(true, GNB_IT, true, false);
+    else if (dy16) GNB_LAUNCH(true, GNB_IT, false, false);
+    else if (x16) GNB_LAUNCH(false, GNB_IT, true, false);
+    else if (y3) GNB_LAUNCH(false, GNB_IT, false, true);
+    else GNB_LAUNCH(false, GNB_IT, false, false);
 #undef GNB_LAUNCH
     return launch_status();
   }
@@ -630,7 +651,7 @@ extern "C" int64_t styler_bn_workspace_doubles(int64_t rows, int C, int segs);  
 // Same geometry as the forward's column statistics / apply kernels (norms.hip): block = (segment, chunk of rpb rows),
 // thread = (row-lane, float4 column); per-channel constants (incl. the two fp64 column sums) once per thread, rows in
 // batches of four, no index divisions.
-template <bool DY16, bool X16 = false>
+template <bool DY16, bool X16 = false, bool Y3 = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restrict__ x, const float* __restrict__ y,
                                                            const void* __restrict__ dy, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -711,7 +732,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
         }
         if (dx16) *reinterpret_cast<uint2*>(dxh + ru * C + q * 4) = make_uint2(cvt_pk_bf16_rne(out[0], out[1]), cvt_pk_bf16_rne(out[2], out[3]));
         else *reinterpret_cast<float4*>(dx + ru * C + q * 4) = make_float4(out[0], out[1], out[2], out[3]);
-        if (y3) x3_store4(y3, ru, q * 4, C, y3parts, make_float4(out[0], out[1], out[2], out[3]));     // round 5, bf16x3
+        if (Y3) x3_store4(y3, ru, q * 4, C, y3parts, make_float4(out[0], out[1], out[2], out[3]));     // round 5, bf16x3
       }
     }
   }
@@ -724,7 +745,7 @@ extern "C" int styler_batchnorm_bwd(const float* x, const float* y, const void* 
   uint16_t* y3 = nullptr;
   int y3parts = 0;
   styler_take_x3_out(&y3, &y3parts);               // (bf16x3: the split of the fp32 gradient rows, filed by the caller)
-  if (y3 && (io_flags & STYLER_IO_Y_BF16)) return STYLER_EINVAL;
+  if (y3 && (io_flags & (STYLER_IO_Y_BF16 | STYLER_IO_X_BF16 | STYLER_IO_Z_BF16))) return STYLER_EINVAL;
   if (!x || !dy || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || C <= 0 ||
       (C & 3) || (act == STYLER_ACT_TANH && !y && !beta) || drop_p < 0.f || drop_p >= 1.f || segs < 1 || rows % segs)
     return STYLER_EINVAL;
@@ -741,13 +762,14 @@ extern "C" int styler_batchnorm_bwd(const float* x, const float* y, const void* 
   if (blocks * 256 < (int64_t)C) blocks = ((int64_t)C + 255) / 256;
   const int nslots = (int)(styler_bn_workspace_doubles(rows, C, segs) / ((int64_t)segs * 2 * C));
   const int dx16 = (io_flags & STYLER_IO_Y_BF16) ? 1 : 0;
-#define BNB_LAUNCH(D_, X_)                                                                                                      \
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<D_, X_>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd, \
+#define BNB_LAUNCH(D_, X_, Y_)                                                                                                  \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<D_, X_, Y_>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd, \
                      workspace, dx, dgamma, dbeta, C, act, beta, drop_p, drop_seed, g_styler_drop_epoch, segs, RPB, bps, rps, dx16, y3, y3parts, nslots)
-  if (dy16 && x16) BNB_LAUNCH(true, true);
-  else if (dy16) BNB_LAUNCH(true, false);
-  else if (x16) BNB_LAUNCH(false, true);
-  else BNB_LAUNCH(false, false);
+  if (dy16 && x16) BNB_LAUNCH(true, true, false);
+  else if (dy16) BNB_LAUNCH(true, false, false);
+  else if (x16) BNB_LAUNCH(false, true, false);
+  else if (y3) BNB_LAUNCH(false, false, true);
+  else BNB_LAUNCH(false, false, false);
 #undef BNB_LAUNCH
   return launch_status();
 }
