@@ -1058,9 +1058,11 @@ static int g_wgrad_xcd_map = [] { const char* e = getenv("STYLER_WGRAD_XCDMAP");
 // at the CU's L2 -> LDS rate, not at the MFMA rate).  n % 128 == 0, both operands bf16-resident, mode 2 only.
 // Measured (same file): PostNet 512 -> 512: 128.6 -> 115.2 us (+11.6 %); 256 -> 256 (16 tiles of 64 x 64: the tall tile doubles
 // its split count to 32): 43.6 -> 44.4 us.  Default: on, for gradients of at least 64 tiles of 64 x 64.
+// knob 2 (experiment): a ring of FOUR stages (prefetch distance 3 chunks) for the 64 x 64 k = 5 / k = 9 kernels of mode 2
+static int g_wgrad_ring4 = [] { const char* e = getenv("STYLER_WGRAD_RING4"); return e ? atoi(e) : 0; }();
 static int g_wgrad_k5_tall = [] { const char* e = getenv("STYLER_WGRAD_K5_TALL"); return e ? atoi(e) : 1; }();
 extern "C" int styler_wgrad_tune(int knob, int value) {
-  int* const k = knob == 0 ? &g_wgrad_xcd_map : knob == 1 ? &g_wgrad_k5_tall : nullptr;
+  int* const k = knob == 0 ? &g_wgrad_xcd_map : knob == 1 ? &g_wgrad_k5_tall : knob == 2 ? &g_wgrad_ring4 : nullptr;
   if (!k) return STYLER_EINVAL;
   const int prev = *k;
   if (value == 0 || value == 1) *k = value;
@@ -1192,9 +1194,11 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
     } else if (dma && kw == 5 && TA == 2 && TB == 1 && tall) {
       WD_LAUNCH(5, 2, 1, 3, 2);
     } else if (dma && kw == 5 && TA == 1 && TB == 1) {
-      if (kg == 2) WD_LAUNCH(5, 1, 1, 3, 2); else WD_LAUNCH(5, 1, 1, 3, 1);
+      if (kg == 2 && g_wgrad_ring4) WD_LAUNCH(5, 1, 1, 4, 2);
+      else if (kg == 2) WD_LAUNCH(5, 1, 1, 3, 2); else WD_LAUNCH(5, 1, 1, 3, 1);
     } else if (dma && kw == 9 && TA == 1 && TB == 1) {
-      if (kg == 2) WD_LAUNCH(9, 1, 1, 3, 2); else WD_LAUNCH(9, 1, 1, 3, 1);
+      if (kg == 2 && g_wgrad_ring4) WD_LAUNCH(9, 1, 1, 4, 2);
+      else if (kg == 2) WD_LAUNCH(9, 1, 1, 3, 2); else WD_LAUNCH(9, 1, 1, 3, 1);
     } else
 #undef WD_LAUNCH
     if (kw == 1) {

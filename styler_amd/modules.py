@@ -408,12 +408,24 @@ class StyleModeling(_HipModule):
         else:
             t_e, p_e, s_e, e_e, n_e = (lr[..., i * H:(i + 1) * H] for i in range(5))       # [B, T, 1280] slices
 
-        energy_prediction = self.energy_predictor(e_e, lens)
-        if pitch_plus_speaker:
-            p_in = AG.Add2Fn.apply(p_e, s_e) if grad else ops.add2(p_e, s_e)
+        self._pred_side = None
+        if grad and rt.pred_stream and energy_target is not None and pitch_target is not None:
+            # (teacher-forced: the predictions only feed the loss -- see rt.pred_stream; joined by STYLER.forward)
+            main = torch.cuda.current_stream()
+            side = self.__dict__.setdefault("_pred_stream", torch.cuda.Stream(device=lr.device))
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                energy_prediction = self.energy_predictor(e_e, lens)
+                p_in = AG.Add2Fn.apply(p_e, s_e) if pitch_plus_speaker else p_e
+                pitch_prediction = self.pitch_predictor(p_in, lens)
+            self._pred_side = side
         else:
-            p_in = p_e
-        pitch_prediction = self.pitch_predictor(p_in, lens)
+            energy_prediction = self.energy_predictor(e_e, lens)
+            if pitch_plus_speaker:
+                p_in = AG.Add2Fn.apply(p_e, s_e) if grad else ops.add2(p_e, s_e)
+            else:
+                p_in = p_e
+            pitch_prediction = self.pitch_predictor(p_in, lens)
         if energy_target is not None:
             e_src, e_scale = energy_target.contiguous(), 1.0
         else:

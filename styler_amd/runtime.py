@@ -35,6 +35,12 @@ class _Runtime:
     # forward and (through autograd's stream bookkeeping) backward: 15.11 -> 15.00, 15.20 -> 15.03 ms same-box A/B
     text_stream = os.environ.get("STYLER_TEXT_STREAM", "1") != "0"
 
+    # EXPERIMENT (round 5): the pitch and energy predictors on a side stream next to the decoder.  Teacher-forced training feeds
+    # the decoder from the TARGET pitch / energy (modules.py:365-381), so the two predictors (2 x [conv k3 -> ReLU -> LayerNorm] x 2
+    # on [B, T, 256]) only feed the loss: one fork behind the LengthRegulator, one join behind the decode, and autograd replays
+    # their backward on the same stream next to the decoder's backward (STYLER_PRED_STREAM=1)
+    pred_stream = os.environ.get("STYLER_PRED_STREAM", "0") == "1"
+
     # clean + noisy branch through the PostNet as one batch (per-branch BatchNorm statistics in the kernels): half the
     # GEMM / norm launches of the PostNet, weight gradients with twice the rows (STYLER_PAIR_POSTNET=0: two passes)
     pair_postnet = os.environ.get("STYLER_PAIR_POSTNET", "1") != "0"

@@ -88,5 +88,9 @@ class STYLER(_HipModule):
         else:
             mel_output, mel_output_postnet = self.decode(style_modeling_output, mel_mask, mel_len)
             mel_output_noisy, mel_output_postnet_noisy = self.decode(noisy_in, mel_mask, mel_len)
+        side = getattr(self.style_modeling, "_pred_side", None)
+        if side is not None:                          # rt.pred_stream: the predictors ran next to the decode
+            torch.cuda.current_stream().wait_stream(side)
+            self.style_modeling._pred_side = None
         return ((mel_output, mel_output_noisy), (mel_output_postnet, mel_output_postnet_noisy), d_prediction,
                 p_prediction, e_prediction, src_mask, mel_mask, mel_len, aug)

@@ -27,7 +27,7 @@ def run(dz, x, n, cin, kw, ws, db):
 
 
 def setup(cfg):
-    lib.styler_wgrad_tune(0, cfg[0]); lib.styler_wgrad_tune(1, cfg[1])
+    lib.styler_wgrad_tune(0, cfg[0]); lib.styler_wgrad_tune(1, cfg[1]); lib.styler_wgrad_tune(2, cfg[2] if len(cfg) > 2 else 0)
 
 
 def main():
@@ -35,7 +35,7 @@ def main():
     dev = torch.device("cuda")
     g = torch.Generator().manual_seed(4)
     lib.styler_wgrad_dma_config(2, 2)
-    cfgs = {"map0": (0, 0), "map1": (1, 0), "tall": (1, 1)}
+    cfgs = {"map0": (0, 0, 0), "map1": (0, 0, 1), "tall": (0, 1, 0)}     # round-5 second series: "map1" column = ring of 4 stages (knob 2)
     print(f"{'shape':16s} {'rows':>6s} | map0: splits us TF/s | map1: us TF/s x | tall: splits us TF/s x   (median of {rounds} x 10 launches)")
     for name, B, L, cin, n, kw in SHAPES:
         dz = torch.randn(B, L, n, generator=g).to(dev).to(torch.bfloat16)
@@ -85,7 +85,7 @@ def main():
         print(f"{name:16s} {B * L:6d} | {plans['map0'][1]:4d} {med['map0']:7.1f} {fl / med['map0'] / 1e6:5.0f} | {med['map1']:7.1f} "
               f"{fl / med['map1'] / 1e6:5.0f} {med['map0'] / med['map1']:.3f} | {plans['tall'][1]:4d} {med['tall']:7.1f} "
               f"{fl / med['tall'] / 1e6:5.0f} {med['map0'] / med['tall']:.3f}", flush=True)
-    lib.styler_wgrad_tune(0, 1); lib.styler_wgrad_tune(1, 0)
+    lib.styler_wgrad_tune(0, 0); lib.styler_wgrad_tune(1, 1); lib.styler_wgrad_tune(2, 0)
 
 
 if __name__ == "__main__":
