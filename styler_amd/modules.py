@@ -367,6 +367,21 @@ class StyleModeling(_HipModule):
         self.energy_embedding = nn.Embedding(hp.n_bins, hp.encoder_hidden)
 
     # -- helpers ------------------------------------------------------------------------------
+    def _loss_only_stream(self, on):
+        """Context for work whose results only feed the LOSS in a teacher-forced training step (the augmentation classifiers, the
+        duration / pitch / energy predictors): with rt.pred_stream it runs on ONE side stream next to the main chain (LengthRegulator,
+        decoder, PostNet) -- a single fork here, a single join in STYLER.forward -- and autograd replays the backward of these nodes
+        on that stream next to the decoder's backward.  The side stream first waits for everything enqueued so far on the current
+        stream (its inputs).  `on` False (eval, free-running, switch off): a null context."""
+        import contextlib
+        if not on:
+            return contextlib.nullcontext()
+        main = torch.cuda.current_stream()
+        side = self.__dict__.setdefault("_pred_stream", torch.cuda.Stream(device=main.device))
+        side.wait_stream(main)
+        self._pred_side = side
+        return torch.cuda.stream(side)
+
     def _mlp2(self, key, seq, x, res=None, out=None):
         h = self._gemm(key + "0", x, seq[0], act=ops.ACT_RELU)
         return self._gemm(key + "2", h, seq[2], act=ops.ACT_RELU, res=res, out=out)
@@ -408,18 +423,8 @@ class StyleModeling(_HipModule):
         else:
             t_e, p_e, s_e, e_e, n_e = (lr[..., i * H:(i + 1) * H] for i in range(5))       # [B, T, 1280] slices
 
-        self._pred_side = None
-        if grad and rt.pred_stream and energy_target is not None and pitch_target is not None:
-            # (teacher-forced: the predictions only feed the loss -- see rt.pred_stream; joined by STYLER.forward)
-            main = torch.cuda.current_stream()
-            side = self.__dict__.setdefault("_pred_stream", torch.cuda.Stream(device=lr.device))
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                energy_prediction = self.energy_predictor(e_e, lens)
-                p_in = AG.Add2Fn.apply(p_e, s_e) if pitch_plus_speaker else p_e
-                pitch_prediction = self.pitch_predictor(p_in, lens)
-            self._pred_side = side
-        else:
+        # (teacher-forced training: the two predictions only feed the loss -- rt.pred_stream; joined by STYLER.forward)
+        with self._loss_only_stream(grad and rt.pred_stream and energy_target is not None and pitch_target is not None):
             energy_prediction = self.energy_predictor(e_e, lens)
             if pitch_plus_speaker:
                 p_in = AG.Add2Fn.apply(p_e, s_e) if grad else ops.add2(p_e, s_e)
@@ -468,26 +473,29 @@ class StyleModeling(_HipModule):
 
         se = self.style_encoder
         self.dat_posteriors = None
-        if se.stacked_encodings is not None:
-            # main + DAT pass of the classifiers (train.py:135-136 and 149-153) as one batch of 2B items; the rows of the two
-            # passes are cut apart on the [2B, 2] log-probabilities
-            (d_all, p_all, e_all), se.stacked_encodings = se.stacked_encodings, None
-            cls = (self.augmentation_classifier_d, self.augmentation_classifier_p, self.augmentation_classifier_e)
-            if rt.grouped_mlps:                      # the three first Linears (GRL: negated dX) as one grouped launch
-                flat = []
-                for c, t in zip(cls, (d_all, p_all, e_all)):
-                    flat += [t, c.classifier.d_fc1.weight, c.classifier.d_fc1.bias]
-                hs = AG.ConvGemmMultiFn.apply(tuple((c._derived, "fc1", ops.ACT_NONE, True) for c in cls), *flat)
-                post = [AG.SplitBatchFn.apply(AG.AugTailFn.apply(h, c.classifier.d_fc2.weight, c.classifier))
-                        for c, h in zip(cls, hs)]
+        self._pred_side = None
+        side_ok = grad and rt.pred_stream and duration_target is not None
+        with self._loss_only_stream(side_ok and rt.pred_stream_cls):
+            if se.stacked_encodings is not None:
+                # main + DAT pass of the classifiers (train.py:135-136 and 149-153) as one batch of 2B items; the rows of the two
+                # passes are cut apart on the [2B, 2] log-probabilities
+                (d_all, p_all, e_all), se.stacked_encodings = se.stacked_encodings, None
+                cls = (self.augmentation_classifier_d, self.augmentation_classifier_p, self.augmentation_classifier_e)
+                if rt.grouped_mlps:                      # the three first Linears (GRL: negated dX) as one grouped launch
+                    flat = []
+                    for c, t in zip(cls, (d_all, p_all, e_all)):
+                        flat += [t, c.classifier.d_fc1.weight, c.classifier.d_fc1.bias]
+                    hs = AG.ConvGemmMultiFn.apply(tuple((c._derived, "fc1", ops.ACT_NONE, True) for c in cls), *flat)
+                    post = [AG.SplitBatchFn.apply(AG.AugTailFn.apply(h, c.classifier.d_fc2.weight, c.classifier))
+                            for c, h in zip(cls, hs)]
+                else:
+                    post = [AG.SplitBatchFn.apply(c(t)) for c, t in zip(cls, (d_all, p_all, e_all))]
+                aug_posterior_d, aug_posterior_p, aug_posterior_e = (pp[0] for pp in post)
+                self.dat_posteriors = tuple(pp[1] for pp in post)
             else:
-                post = [AG.SplitBatchFn.apply(c(t)) for c, t in zip(cls, (d_all, p_all, e_all))]
-            aug_posterior_d, aug_posterior_p, aug_posterior_e = (pp[0] for pp in post)
-            self.dat_posteriors = tuple(pp[1] for pp in post)
-        else:
-            aug_posterior_d = self.augmentation_classifier_d(duration_encoding)
-            aug_posterior_p = self.augmentation_classifier_p(pitch_encoding)
-            aug_posterior_e = self.augmentation_classifier_e(energy_encoding)
+                aug_posterior_d = self.augmentation_classifier_d(duration_encoding)
+                aug_posterior_p = self.augmentation_classifier_p(pitch_encoding)
+                aug_posterior_e = self.augmentation_classifier_e(energy_encoding)
 
         # for the inspection (modules.py:327-333)
         self.max_seq_len = max_seq_len
@@ -535,7 +543,8 @@ class StyleModeling(_HipModule):
         self.src_mask = src_mask
         self.max_len = max_len
 
-        log_duration_prediction = self.duration_predictor(dp_in, src_len)
+        with self._loss_only_stream(side_ok and duration_target is not None):
+            log_duration_prediction = self.duration_predictor(dp_in, src_len)
         out, out_noisy, n_e, pitch_prediction, energy_prediction, out_len, out_mask, _ = self._expand_and_predict(
             encodings, src_len, duration_target, log_duration_prediction, max_len, mel_len, mel_mask, pitch_target,
             energy_target, d_control, p_control, e_control)

@@ -40,6 +40,7 @@ class _Runtime:
     # on [B, T, 256]) only feed the loss: one fork behind the LengthRegulator, one join behind the decode, and autograd replays
     # their backward on the same stream next to the decoder's backward (STYLER_PRED_STREAM=1)
     pred_stream = os.environ.get("STYLER_PRED_STREAM", "0") == "1"
+    pred_stream_cls = os.environ.get("STYLER_PRED_STREAM_CLS", "1") == "1"     # ... the augmentation classifiers too
 
     # clean + noisy branch through the PostNet as one batch (per-branch BatchNorm statistics in the kernels): half the
     # GEMM / norm launches of the PostNet, weight gradients with twice the rows (STYLER_PAIR_POSTNET=0: two passes)
