@@ -380,6 +380,7 @@ class StyleModeling(_HipModule):
         side = self.__dict__.setdefault("_pred_stream", torch.cuda.Stream(device=main.device))
         side.wait_stream(main)
         self._pred_side = side
+        ops.loss_side_stream = side                   # (every WgradArena.flush joins it: partial tiles are written there too)
         return torch.cuda.stream(side)
 
     def _mlp2(self, key, seq, x, res=None, out=None):

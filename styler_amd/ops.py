@@ -47,6 +47,10 @@ def _f32(t):
     return t
 
 
+# the loss-only side stream of the current step (modules.StyleModeling._loss_only_stream, rt.pred_stream), or None
+loss_side_stream = None
+
+
 class WgradArena:
     """Workspace arena for one backward pass: every styler_wgrad call takes a slice and defers its split-K
     reduction; `flush()` folds all partials into the gradients with ONE launch.  The first pass only measures
@@ -138,6 +142,8 @@ class WgradArena:
     def flush(self, device):
         import ctypes
         import numpy as np
+        if loss_side_stream is not None:             # rt.pred_stream: weight-gradient partials written on the loss-only side
+            torch.cuda.current_stream().wait_stream(loss_side_stream)   # stream are folded below (a no-op edge once joined)
         if self.side_used:                           # join: the partial tiles written on the side stream are read below
             torch.cuda.current_stream().wait_stream(self.side)
             self.side_used, self.side_keep = False, []

@@ -279,6 +279,7 @@ def forward_backward(model, state, batch, loss_fn=None, dat_fn=None):
         ops.wgrad_arena = None
         ops.zero_slab = None
         ops.x3_cache = None
+        ops.loss_side_stream = None
     return losses
 
 
@@ -418,8 +419,10 @@ class GraphedTrainStep:
             if cut["done"]:
                 return
             state.arena.flush(state.flat_g.device)      # fold the decoder-side split-K partials: that range is final now
-            ga.capture_end()
+            ga.capture_end()                            # (the flush joined the loss-only side stream: no forked stream is left)
             gb.capture_begin(pool=ga.pool())
+            if ops.loss_side_stream is not None:        # ... and forks it again: the rest of its backward chain belongs to graph B
+                ops.loss_side_stream.wait_stream(torch.cuda.current_stream())
             cut["done"] = True
 
         gc.collect()
