@@ -35,12 +35,16 @@ class _Runtime:
     # forward and (through autograd's stream bookkeeping) backward: 15.11 -> 15.00, 15.20 -> 15.03 ms same-box A/B
     text_stream = os.environ.get("STYLER_TEXT_STREAM", "1") != "0"
 
-    # EXPERIMENT (round 5): the pitch and energy predictors on a side stream next to the decoder.  Teacher-forced training feeds
-    # the decoder from the TARGET pitch / energy (modules.py:365-381), so the two predictors (2 x [conv k3 -> ReLU -> LayerNorm] x 2
-    # on [B, T, 256]) only feed the loss: one fork behind the LengthRegulator, one join behind the decode, and autograd replays
-    # their backward on the same stream next to the decoder's backward (STYLER_PRED_STREAM=1)
-    pred_stream = os.environ.get("STYLER_PRED_STREAM", "0") == "1"
-    pred_stream_cls = os.environ.get("STYLER_PRED_STREAM_CLS", "1") == "1"     # ... the augmentation classifiers too
+    # Round 5: everything that only feeds the LOSS of a teacher-forced training step on ONE side stream next to the main chain.
+    # The decoder is fed from the TARGET durations / pitch / energy (modules.py:352-381), so the duration / pitch / energy predictors
+    # (2 x [conv k3 -> ReLU -> LayerNorm] each; pitch and energy on [B, T, 256]) and the three augmentation classifiers produce
+    # nothing the LengthRegulator -> decoder -> PostNet chain reads: one fork, one join behind the decode, and autograd replays
+    # their backward on the same stream next to the decoder's backward.  Same-box A/B (profiles/r05_concurrency_ab.txt): 9.61 ->
+    # 9.44, 9.62 -> 9.49 ms (predictors), 9.92 -> 9.70 ms (predictors + classifiers).  Unlike the side streams that lost in rounds
+    # 2-4 (weight gradients: 45 fork edges; the AudioEncoder's chip-filling convolutions) this branch is long, has ONE fork and ONE
+    # join, and its kernels fit into the tails the decoder's 1.66-round launches leave.  STYLER_PRED_STREAM=0 switches it off.
+    pred_stream = os.environ.get("STYLER_PRED_STREAM", "1") != "0"
+    pred_stream_cls = os.environ.get("STYLER_PRED_STREAM_CLS", "1") != "0"     # ... the augmentation classifiers too
 
     # clean + noisy branch through the PostNet as one batch (per-branch BatchNorm statistics in the kernels): half the
     # GEMM / norm launches of the PostNet, weight gradients with twice the rows (STYLER_PAIR_POSTNET=0: two passes)
