@@ -46,6 +46,10 @@ class _Runtime:
     pred_stream = os.environ.get("STYLER_PRED_STREAM", "1") != "0"
     pred_stream_cls = os.environ.get("STYLER_PRED_STREAM_CLS", "1") != "0"     # ... the augmentation classifiers too
 
+    # EXPERIMENT (round 5): on one rank, the decoder-side flush of the weight-gradient arena (grouped Linear gradients + the fold
+    # of the split-K partials so far) on a side stream next to the rest of backward (training.TrainState.early_flush_on_side)
+    early_flush = os.environ.get("STYLER_EARLY_FLUSH", "0") == "1"
+
     # clean + noisy branch through the PostNet as one batch (per-branch BatchNorm statistics in the kernels): half the
     # GEMM / norm launches of the PostNet, weight gradients with twice the rows (STYLER_PAIR_POSTNET=0: two passes)
     pair_postnet = os.environ.get("STYLER_PAIR_POSTNET", "1") != "0"

@@ -59,6 +59,7 @@ class TrainState:
         self.arena = ops.WgradArena()                  # split-K partials of every weight gradient of one backward
         self.zero_slab = ops.ZeroSlab()
         self.split_hook = None                         # set while GraphedTrainStep captures its two graphs
+        self._flush_stream, self._flush_side, self._flush_keep = None, None, None     # rt.early_flush
         self.overlap_allreduce = True                  # start the decoder-side all-reduce from inside backward
         # device step counter mixed into every dropout seed: host seeds are baked into a captured hipGraph, the
         # counter is what changes between replays (styler_set_dropout_counter)
@@ -124,6 +125,29 @@ class TrainState:
         if self.reducer is not None:
             return self.reducer.start(lo, hi)
         return allreduce_sum_(self.flat_g[lo:hi])
+
+    def early_flush_on_side(self):
+        """rt.early_flush (one rank, no all-reduce to start): called from BucketEmbedAddFn.backward like on_decoder_grads_ready.
+        The decoder-side weight-gradient work that waits for a flush -- the grouped launches of the decoder's deferred Linear
+        gradients and the HBM-bound fold of all split-K partials so far (54 % of the gradient bytes) -- runs on a side stream
+        next to the rest of backward (the AudioEncoder's MFMA-bound convolutions): one fork here, one join in front of the
+        final flush.  Nothing behind this point reads or writes those gradients before the optimiser."""
+        if self._flush_side is not None:
+            return
+        main = torch.cuda.current_stream()
+        if self._flush_stream is None:
+            self._flush_stream = torch.cuda.Stream(device=self.flat_g.device)
+        side = self._flush_stream
+        side.wait_stream(main)
+        keep = list(self.arena.group_keep)              # operands of the grouped launches: alive until the join
+        with torch.cuda.stream(side):
+            self.arena.flush(self.flat_g.device)
+        self._flush_side, self._flush_keep = side, keep
+
+    def join_early_flush(self):
+        if self._flush_side is not None:
+            torch.cuda.current_stream().wait_stream(self._flush_side)
+            self._flush_side, self._flush_keep = None, None
 
     def on_decoder_grads_ready(self):
         """Called from BucketEmbedAddFn.backward (both decode branches fully back-propagated): start the all-reduce
@@ -269,10 +293,13 @@ def forward_backward(model, state, batch, loss_fn=None, dat_fn=None):
         last_micro = state._accum % hp.acc_steps == 0
         rt.grad_ready_hook = state.split_hook or (state.on_decoder_grads_ready
                                                   if (state.overlap_allreduce and last_micro) else None)
+        if rt.grad_ready_hook is None and rt.early_flush:
+            rt.grad_ready_hook = state.early_flush_on_side
         state.arena.begin(state.flat_g.device)
         ops.wgrad_arena = state.arena
         # loss / acc_steps (train.py:175) as the seed gradient of backward: no division kernel, no ones_like
         losses[0].backward(gradient=_seed_grad(1.0 / hp.acc_steps, losses[0].device))
+        state.join_early_flush()
         state.arena.flush(state.flat_g.device)         # one launch folds all split-K partials into flat_g
     finally:
         rt.grad_ready_hook = None
@@ -280,6 +307,7 @@ def forward_backward(model, state, batch, loss_fn=None, dat_fn=None):
         ops.zero_slab = None
         ops.x3_cache = None
         ops.loss_side_stream = None
+        state.join_early_flush()                        # (error paths: never leave a forked stream behind)
     return losses
 
 
