@@ -721,7 +721,7 @@ def pmc_traffic(want, prec):
     read from that file; null when the file has no record for the kernel or was taken for another precision."""
     if prec != "bf16":
         return None, None
-    for name in ("r04_pmc_traffic.jsonl", "r03_pmc_traffic.jsonl", "r02_pmc_traffic.jsonl"):
+    for name in ("r05_pmc_traffic.jsonl", "r04_pmc_traffic.jsonl", "r03_pmc_traffic.jsonl", "r02_pmc_traffic.jsonl"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue

@@ -957,7 +957,8 @@ def test_batch_feeder_pinned_async_h2d(dev, tmp_path):
     write_store(str(tmp_path))
     ds = FeatureStore(str(tmp_path), tokenizer)
     feeder = BatchFeeder(ds, dev, batch_size=2, seed=1, depth=3)
-    want = [to_device(sub, "cpu", pinned=False) for grp in feeder.groups() for sub in ds.collate_fn([ds[int(i)] for i in grp])]
+    want = [to_device(sub, "cpu", pinned=False, pairs=feeder.pairs)          # (the feeder collates the stacked AudioEncoder inputs
+            for grp in feeder.groups() for sub in ds.collate_fn([ds[int(i)] for i in grp])]     # when the step consumes them)
     got = list(feeder)
     assert len(got) == len(want) == 10
     for (a, sa, ta), (b, sb, tb) in zip(got, want):
