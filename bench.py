@@ -719,6 +719,19 @@ def main():
             line["roofline"]["hbm"] = hbm
         if aux:
             line["aux"] = aux
+            x3 = aux.get("train_bf16x3")
+            if x3:
+                # the SAME step in the arithmetic that meets north_star's 1e-3 bound (bf16x3: fp32-class products as three bf16
+                # MFMA products), next to the throughput-mode headline (VERDICT round 4, next #4c).  Its roofline is
+                # the whole step's: algorithmic FLOPs (265 MFLOP per valid frame of a train step; every GEMM product
+                # costs three MFMA products in this mode, so the matrix cores execute ~3x that) over the bf16 dense peak.
+                alg = x3["value"] * 265e6 / 1e12
+                line["value_parity"], line["ms_per_step_parity"], line["dtype_parity"] = x3["value"], x3["ms_per_step"], "bf16x3"
+                line["roofline_parity"] = {"bound": "mfma", "kernel": "whole bf16x3 train step (all GEMM engines, 3 bf16 products per product)",
+                                           "achieved": round(alg, 1), "executed": round(3 * alg, 1), "peak": MFMA_PEAK_TFLOPS["bf16"],
+                                           "unit": "TFLOP/s", "frac": round(alg / MFMA_PEAK_TFLOPS["bf16"], 4),
+                                           "frac_executed": round(3 * alg / MFMA_PEAK_TFLOPS["bf16"], 4),
+                                           "flops_model": "265 MFLOP per valid mel frame (SURVEY 8d, train step) x frames/s"}
     # The JSON line must be the LAST line of the job's stdout.  RCCL writes a version banner to the C-level stdout of every
     # process that creates a communicator; behind a pipe it sits in the stdio buffer until exit, i.e. it used to land AFTER
     # the line.  So: tear the group down first, push whatever C code buffered out, and only then print (ranks other than 0

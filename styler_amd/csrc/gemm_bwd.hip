@@ -615,6 +615,21 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const void* __restrict__ 
 typedef __attribute__((address_space(3))) void wg_lds_void;
 template <int N> __device__ __forceinline__ void wg_vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
+// STYLER_WGRAD_TRACE builds only (tools/wgrad_trace.sh: a second library next to the product's): per-wave cycle sums of the
+// phases of the ring loop -- [DMA wait | barrier | issue | MFMA half 1 | barrier | MFMA half 2] -- for the first 16 blocks.
+#ifdef STYLER_WGRAD_TRACE
+__device__ uint64_t* g_wgrad_trace = nullptr;
+extern "C" int styler_wgrad_trace_ptr(void* p) {
+  uint64_t* v = reinterpret_cast<uint64_t*>(p);
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_trace), &v, sizeof(v));
+}
+#define WGT_DECL uint64_t wgt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t wgt_t = __builtin_amdgcn_s_memtime(); const uint64_t wgt_t0 = wgt_t;
+#define WGT(k) { __builtin_amdgcn_s_waitcnt(0xc07f); const uint64_t t_ = __builtin_amdgcn_s_memtime(); wgt[k] += t_ - wgt_t; wgt_t = t_; }
+#else
+#define WGT_DECL
+#define WGT(k)
+#endif
+
 // (TAG only makes the specialisations of the two kernels that share a shape distinct: hipcc's host pass fails the SECOND
 // kernel's call of one and the same body specialisation with "substitution failure")
 template <int KW, int TA, int TB, int NST, int KG, int TAG = 0>
@@ -837,8 +852,10 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
+  WGT_DECL
   for (int i = 0; i < trips; ++i) {
     const bool live = i < nch;
+    WGT(7)
     if (live) {
       const int rem = nch - 1 - i < D - 1 ? nch - 1 - i : D - 1;        // chunks requested after chunk i
       if (HALO && wave == 3) {
@@ -847,26 +864,41 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
         if (rem >= 2) wg_vm_wait<2 * PW>(); else if (rem == 1) wg_vm_wait<PW>(); else wg_vm_wait<0>();
       }
     }
+    WGT(0)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    WGT(1)
     const bool bias_now = do_bias && part_of(ich0 + KG * i) != 1;
     if (live) {
       if (i + D < nch) {                             // the stage read in iteration i - 1: every wave is past those reads
         issue(ich0 + KG * (i + D), st_i, e_next);
         e_next = entry(ich0 + KG * (i + D + 1));
       }
+      WGT(2)
       if (STAG) compute(st_c, bias_now, integral_constant<int, 0>{}, integral_constant<int, NS / 2>{});
       else compute(st_c, bias_now, integral_constant<int, 0>{}, integral_constant<int, NS>{});
     }
+    WGT(3)
     if (STAG) {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      WGT(4)
       if (live) compute(st_c, bias_now, integral_constant<int, NS / 2>{}, integral_constant<int, NS>{});
+      WGT(5)
     }
     st_c = st_c + 1 == NST ? 0 : st_c + 1;
     st_i = st_i + 1 == NST ? 0 : st_i + 1;
   }
+#ifdef STYLER_WGRAD_TRACE
+  if (g_wgrad_trace && bid < 16 && lane == 0) {
+    uint64_t* t = g_wgrad_trace + ((int64_t)bid * 8 + wave8) * 10;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = wgt[k];
+    t[8] = (uint64_t)trips;
+    t[9] = __builtin_amdgcn_s_memtime() - wgt_t0;
+  }
+#endif
   if (STAG && grp == 0) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
