@@ -713,12 +713,19 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
   if (HALO) vh = piece_off(4 * PB, SB, ldx, c0, cin);
   const uint32_t lds_w = (uint32_t)wave * 1024u;
 
-  // chunk table entry of chunk `ch` (packed / item-aligned chunks), fetched one iteration before it is needed: the scalar
-  // load's latency would otherwise sit between the barrier and the DMA issue of every iteration
+  // chunk table entry of chunk `ch` (packed / item-aligned chunks)
   auto entry = [&](int ch) -> int4 {
     return (chunktab && ch < (int)ch1) ? chunktab[ch - part_of(ch) * nch1] : make_int4(0, 0, 0, 0);
   };
-  auto issue = [&](int chk, int stage, const int4 e) {
+  // The two buffer descriptors of a chunk (bases, record counts, halo offset) depend on the chunk only -- not on the tile,
+  // the wave or the stage.  Until round 5 every wave rebuilt them in front of every DMA issue: 64-bit multiplies, clamps, an
+  // integer division in the padded-rectangle form.  tools/wgrad_trace.py (phase cycle sums, trace build) put that arithmetic at
+  // 12-18 % of a wave's life in the k = 9 / k = 5 kernels and 17-30 % in the Linear tile -- twice what the DMA instructions
+  // themselves cost.  Now the block computes the descriptors of ITS chunks once, one chunk per thread, into an LDS table
+  // (32 bytes per chunk); an issue reads one entry (fetched an iteration ahead) and moves it to scalar registers.
+  // pad bit 0x2000 (STYLER_WGRAD_DESCTAB=0) or more than WG_TCAP chunks in the block: the former on-the-fly path.
+  struct WgDesc { uint32_t a_lo, a_hi, b_lo, b_hi, a_rec, b_rec, b_off, pad; };
+  auto make_desc = [&](int chk, const int4 e) -> WgDesc {
     const int part = part_of(chk), ch = chk - part * nch1;
     int t0, Li;
     int64_t rowb;
@@ -735,13 +742,43 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
     a_rec = a_rec > REC_MAX ? REC_MAX : a_rec;
     b_rec = b_rec > REC_MAX ? REC_MAX : (b_rec < 0 ? 0 : b_rec);
     // (x3cat: splits are [hi | lo (| hi)] -- column block (0, 0, 1)[part] of dz, column block (0, 1, 0)[part] of x)
-    const char* a_base = reinterpret_cast<const char*>(dz) + ((rowb + t0) * lddz + (int64_t)(part >> 1) * n) * 2;
-    const char* b_base = reinterpret_cast<const char*>(x) + ((rowb + txb) * ldx + (int64_t)(part & 1) * cin) * 2;
-    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a_base), 0, (int)a_rec, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b_base), 0, (int)b_rec, 0x00020000);
-    const uint32_t b_off = (uint32_t)((tx - txb) * (int)ldx * 2);        // <= 0: rows before the item wrap out of range
+    const uint64_t a_base = (uint64_t)(reinterpret_cast<const char*>(dz) + ((rowb + t0) * lddz + (int64_t)(part >> 1) * n) * 2);
+    const uint64_t b_base = (uint64_t)(reinterpret_cast<const char*>(x) + ((rowb + txb) * ldx + (int64_t)(part & 1) * cin) * 2);
+    WgDesc d;
+    d.a_lo = (uint32_t)a_base; d.a_hi = (uint32_t)(a_base >> 32); d.b_lo = (uint32_t)b_base; d.b_hi = (uint32_t)(b_base >> 32);
+    d.a_rec = (uint32_t)a_rec; d.b_rec = (uint32_t)b_rec;
+    d.b_off = (uint32_t)((tx - txb) * (int)ldx * 2);   // <= 0: rows before the item wrap out of range
+    d.pad = 0u;
+    return d;
+  };
+  constexpr int WG_TCAP = 256;
+  __shared__ __attribute__((aligned(16))) uint4 s_desc[2 * WG_TCAP];
+  const int nall_blk = (int)(ch1 - ch0);
+  const bool use_tab = !(pad_cat & 0x2000) && nall_blk <= WG_TCAP;
+  if (use_tab) {
+    for (int k = tid; k < nall_blk; k += 256 * KG) {
+      const int chk = (int)ch0 + k;
+      const WgDesc d = make_desc(chk, entry(chk));
+      s_desc[2 * k] = make_uint4(d.a_lo, d.a_hi, d.b_lo, d.b_hi);
+      s_desc[2 * k + 1] = make_uint4(d.a_rec, d.b_rec, d.b_off, 0u);
+    }
+    __syncthreads();
+  }
+  // (raw 8 dwords of a chunk's table entry: read an iteration ahead, the LDS latency stays off the issue path)
+  auto tab_read = [&](int chk, uint4& r0, uint4& r1) {
+    const int k = chk - (int)ch0;
+    if (use_tab && k >= 0 && k < nall_blk) { r0 = s_desc[2 * k]; r1 = s_desc[2 * k + 1]; }
+  };
+  WGT_DECL
+  auto launch = [&](int stage, const WgDesc d) {
+    const char* a_base = reinterpret_cast<const char*>(((uint64_t)d.a_hi << 32) | d.a_lo);
+    const char* b_base = reinterpret_cast<const char*>(((uint64_t)d.b_hi << 32) | d.b_lo);
+    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a_base), 0, (int)d.a_rec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b_base), 0, (int)d.b_rec, 0x00020000);
+    const uint32_t b_off = d.b_off;
     unsigned char* sa = smem + stage * STAGE + lds_w;
     unsigned char* sb = smem + stage * STAGE + A_BYTES + lds_w;
+    WGT(6)                                           // (trace builds: descriptor arithmetic | the DMA instructions)
 #pragma unroll
     for (int q = 0; q < PA; ++q)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_rsrc, (wg_lds_void*)(sa + q * 4096), 16, va[q], 0, 0, 0);
@@ -751,6 +788,19 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
     if (HALO && wave == 3)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_rsrc, (wg_lds_void*)(smem + stage * STAGE + A_BYTES + 4 * PB * 1024), 16,
                                                vh + b_off, 0, 0, 0);
+  };
+  // issue the DMA of chunk `chk` into `stage`: from the table entry (r0, r1) read earlier, or (no table) built on the spot
+  auto issue = [&](int chk, int stage, const uint4 r0, const uint4 r1) {
+    if (use_tab) {
+      WgDesc d;
+      d.a_lo = __builtin_amdgcn_readfirstlane(r0.x); d.a_hi = __builtin_amdgcn_readfirstlane(r0.y);
+      d.b_lo = __builtin_amdgcn_readfirstlane(r0.z); d.b_hi = __builtin_amdgcn_readfirstlane(r0.w);
+      d.a_rec = __builtin_amdgcn_readfirstlane(r1.x); d.b_rec = __builtin_amdgcn_readfirstlane(r1.y);
+      d.b_off = __builtin_amdgcn_readfirstlane(r1.z); d.pad = 0u;
+      launch(stage, d);
+    } else {
+      launch(stage, make_desc(chk, entry(chk)));
+    }
   };
 
   // ---- fragment read coordinates (wgrad_tr_body's) ----
@@ -834,10 +884,14 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
   const int ich0 = (int)ch0 + grp, nall = (int)(ch1 - ch0);
   const int nch = nall > grp ? (nall - grp + KG - 1) / KG : 0, trips = (nall + KG - 1) / KG;
   constexpr int PW = PA + PB;                        // pieces per chunk of waves 0..2 (wave 3: + the halo piece)
+  uint4 nx0 = make_uint4(0u, 0u, 0u, 0u), nx1 = nx0;
 #pragma unroll
   for (int d = 0; d < D; ++d)
-    if (d < nch) issue(ich0 + KG * d, d, entry(ich0 + KG * d));
-  int4 e_next = entry(ich0 + KG * D);
+    if (d < nch) {
+      tab_read(ich0 + KG * d, nx0, nx1);
+      issue(ich0 + KG * d, d, nx0, nx1);
+    }
+  tab_read(ich0 + KG * D, nx0, nx1);
   int st_c = 0, st_i = D % NST;                      // stage computed / stage refilled in the current iteration
   // KG = 2: the two groups run ONE BARRIER APART (group 1 meets one extra barrier before the loop, group 0 one behind it),
   // and an iteration has two phases -- [wait, barrier, refill the ring, first half of the chunk's MFMAs] and [barrier, second
@@ -852,7 +906,6 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
-  WGT_DECL
   for (int i = 0; i < trips; ++i) {
     const bool live = i < nch;
     WGT(7)
@@ -871,8 +924,8 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
     const bool bias_now = do_bias && part_of(ich0 + KG * i) != 1;
     if (live) {
       if (i + D < nch) {                             // the stage read in iteration i - 1: every wave is past those reads
-        issue(ich0 + KG * (i + D), st_i, e_next);
-        e_next = entry(ich0 + KG * (i + D + 1));
+        issue(ich0 + KG * (i + D), st_i, nx0, nx1);
+        tab_read(ich0 + KG * (i + D + 1), nx0, nx1);
       }
       WGT(2)
       if (STAG) compute(st_c, bias_now, integral_constant<int, 0>{}, integral_constant<int, NS / 2>{});
@@ -1199,7 +1252,8 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
     return STYLER_EINVAL;
   const bool tall = wgrad_k5_tall(n, cin, kw, prec, io_flags);
   wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, 0, kg, x3cat ? 3 : 1, tall);
-  const int legacy_map = g_wgrad_xcd_map ? 0 : 0x1000;
+  static const int desctab_env = [] { const char* e = getenv("STYLER_WGRAD_DESCTAB"); return e ? atoi(e) : 1; }();
+  const int legacy_map = (g_wgrad_xcd_map ? 0 : 0x1000) | (desctab_env ? 0 : 0x2000);
   const int pad_cat = (pad_left & 0xff) | (x3cat ? 0x400 : 0) | ((io_flags & STYLER_IO_DB_SLOTS) ? 0x800 : 0) | legacy_map;
   float* ws = reinterpret_cast<float*>(workspace);
   const dim3 grid(nt * ct, (unsigned)splits);

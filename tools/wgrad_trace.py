@@ -12,7 +12,7 @@ from styler_amd import ops
 from styler_amd._lib import lib
 
 SHAPES = [("dec_ffn_w1_k9", 61, 441, 256, 1024, 9), ("postnet_512_k5", 96, 441, 512, 512, 5), ("dec_ffn_w2_k1", 1, 27060, 1024, 256, 1)]
-NAMES = ["dma wait", "barrier 1", "dma issue", "mfma half 1", "barrier 2", "mfma half 2", "(unused)", "loop top"]
+NAMES = ["dma wait", "barrier 1", "dma instrs", "mfma half 1", "barrier 2", "mfma half 2", "dma descr", "loop top"]
 
 
 def main():
@@ -42,13 +42,13 @@ def main():
         cl.styler_wgrad_trace_ptr(None)
         t = tr.view(16, 8, 10).cpu()
         print(f"== {name}: rows {B * L}, n {n}, cin {cin}, kw {kw}")
-        for b in (0, 1, 9):
+        for b in (0, 9):
             for w in range(8):
                 r = t[b, w]
                 tot = int(r[9])
                 if tot == 0:
                     continue
-                parts = "  ".join(f"{NAMES[k]} {100.0 * int(r[k]) / tot:5.1f}%" for k in (7, 0, 1, 2, 3, 4, 5))
+                parts = "  ".join(f"{NAMES[k]} {100.0 * int(r[k]) / tot:5.1f}%" for k in (7, 0, 1, 6, 2, 3, 4, 5))
                 print(f"block {b:2d} wave {w}: trips {int(r[8]):4d}  total {tot:8d} cyc ({tot / max(1, int(r[8])):7.0f} / trip)  {parts}")
 
 
