@@ -770,36 +770,56 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
     if (use_tab && k >= 0 && k < nall_blk) { r0 = s_desc[2 * k]; r1 = s_desc[2 * k + 1]; }
   };
   WGT_DECL
-  auto launch = [&](int stage, const WgDesc d) {
+  // The refill of a stage is PA + PB (+ 1 halo) DMA pieces per wave.  `ilv` (pad bit 0x4000, STYLER_WGRAD_ILV): they are not issued
+  // in one burst behind the barrier but between the K steps of the chunk being computed (`piece`, called from compute):
+  // an LDS-DMA instruction holds the wave's issue for 60-180 cycles, which a burst puts in front of the first MFMA.
+  constexpr int NPIECE = PA + PB + (HALO ? 1 : 0), NSTEP = WB_BK / 16, PPS = (NPIECE + NSTEP - 1) / NSTEP;
+  const bool ilv = pad_cat & 0x4000;
+  __amdgpu_buffer_rsrc_t pend_ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dz), 0, 0, 0x00020000), pend_rb = pend_ra;
+  uint32_t pend_boff = 0u;
+  int pend_stage = 0;
+  bool pend_on = false;
+  auto piece = [&](int q) {                          // DMA piece q of the pending refill
+    if (q < PA) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(pend_ra, (wg_lds_void*)(smem + pend_stage * STAGE + lds_w + q * 4096), 16, va[q], 0, 0, 0);
+    } else if (q < PA + PB) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(pend_rb, (wg_lds_void*)(smem + pend_stage * STAGE + A_BYTES + lds_w + (q - PA) * 4096), 16,
+                                               vb[q - PA] + pend_boff, 0, 0, 0);
+    } else if (HALO && wave == 3) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(pend_rb, (wg_lds_void*)(smem + pend_stage * STAGE + A_BYTES + 4 * PB * 1024), 16,
+                                               vh + pend_boff, 0, 0, 0);
+    }
+  };
+  auto after_step = [&](int s) {                     // called by compute behind K step s of the current chunk
+    if (!pend_on) return;
+#pragma unroll
+    for (int q = 0; q < PPS; ++q)
+      if (s * PPS + q < NPIECE) piece(s * PPS + q);
+    if (s == NSTEP - 1) pend_on = false;
+  };
+  auto launch = [&](int stage, const WgDesc d, const bool defer) {
     const char* a_base = reinterpret_cast<const char*>(((uint64_t)d.a_hi << 32) | d.a_lo);
     const char* b_base = reinterpret_cast<const char*>(((uint64_t)d.b_hi << 32) | d.b_lo);
-    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a_base), 0, (int)d.a_rec, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b_base), 0, (int)d.b_rec, 0x00020000);
-    const uint32_t b_off = d.b_off;
-    unsigned char* sa = smem + stage * STAGE + lds_w;
-    unsigned char* sb = smem + stage * STAGE + A_BYTES + lds_w;
+    pend_ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a_base), 0, (int)d.a_rec, 0x00020000);
+    pend_rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b_base), 0, (int)d.b_rec, 0x00020000);
+    pend_boff = d.b_off;
+    pend_stage = stage;
     WGT(6)                                           // (trace builds: descriptor arithmetic | the DMA instructions)
+    if (defer) { pend_on = true; return; }
 #pragma unroll
-    for (int q = 0; q < PA; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_rsrc, (wg_lds_void*)(sa + q * 4096), 16, va[q], 0, 0, 0);
-#pragma unroll
-    for (int q = 0; q < PB; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_rsrc, (wg_lds_void*)(sb + q * 4096), 16, vb[q] + b_off, 0, 0, 0);
-    if (HALO && wave == 3)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_rsrc, (wg_lds_void*)(smem + stage * STAGE + A_BYTES + 4 * PB * 1024), 16,
-                                               vh + b_off, 0, 0, 0);
+    for (int q = 0; q < NPIECE; ++q) piece(q);
   };
   // issue the DMA of chunk `chk` into `stage`: from the table entry (r0, r1) read earlier, or (no table) built on the spot
-  auto issue = [&](int chk, int stage, const uint4 r0, const uint4 r1) {
+  auto issue = [&](int chk, int stage, const uint4 r0, const uint4 r1, const bool defer = false) {
     if (use_tab) {
       WgDesc d;
       d.a_lo = __builtin_amdgcn_readfirstlane(r0.x); d.a_hi = __builtin_amdgcn_readfirstlane(r0.y);
       d.b_lo = __builtin_amdgcn_readfirstlane(r0.z); d.b_hi = __builtin_amdgcn_readfirstlane(r0.w);
       d.a_rec = __builtin_amdgcn_readfirstlane(r1.x); d.b_rec = __builtin_amdgcn_readfirstlane(r1.y);
       d.b_off = __builtin_amdgcn_readfirstlane(r1.z); d.pad = 0u;
-      launch(stage, d);
+      launch(stage, d, defer);
     } else {
-      launch(stage, make_desc(chk, entry(chk)));
+      launch(stage, make_desc(chk, entry(chk)), defer);
     }
   };
 
@@ -876,6 +896,7 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
 #pragma unroll
         for (int i = 0; i < TA; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, accb[i], 0, 0, 0);
       }
+      after_step(s);                                 // (ilv: this step's share of the pending refill's DMA pieces)
     }
   };
 
@@ -924,7 +945,7 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
     const bool bias_now = do_bias && part_of(ich0 + KG * i) != 1;
     if (live) {
       if (i + D < nch) {                             // the stage read in iteration i - 1: every wave is past those reads
-        issue(ich0 + KG * (i + D), st_i, nx0, nx1);
+        issue(ich0 + KG * (i + D), st_i, nx0, nx1, ilv);
         tab_read(ich0 + KG * (i + D + 1), nx0, nx1);
       }
       WGT(2)
@@ -1253,7 +1274,8 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
   const bool tall = wgrad_k5_tall(n, cin, kw, prec, io_flags);
   wgrad_plan(B, L, n, cin, kw, pad_left, prec, &Be, &Le, &cpi, &cps, &splits, 0, kg, x3cat ? 3 : 1, tall);
   static const int desctab_env = [] { const char* e = getenv("STYLER_WGRAD_DESCTAB"); return e ? atoi(e) : 1; }();
-  const int legacy_map = (g_wgrad_xcd_map ? 0 : 0x1000) | (desctab_env ? 0 : 0x2000);
+  static const int ilv_env = [] { const char* e = getenv("STYLER_WGRAD_ILV"); return e ? atoi(e) : 0; }();
+  const int legacy_map = (g_wgrad_xcd_map ? 0 : 0x1000) | (desctab_env ? 0 : 0x2000) | (ilv_env ? 0x4000 : 0);
   const int pad_cat = (pad_left & 0xff) | (x3cat ? 0x400 : 0) | ((io_flags & STYLER_IO_DB_SLOTS) ? 0x800 : 0) | legacy_map;
   float* ws = reinterpret_cast<float*>(workspace);
   const dim3 grid(nt * ct, (unsigned)splits);
