@@ -399,7 +399,13 @@ __device__ __forceinline__ void wgrad_tr_body(const int bid, const void* __restr
   const uint32_t vb0 = c0 + bq < cinp ? (uint32_t)((br * ldx + c0 + bq) * BES) : OOB;
   const uint32_t a_pstep = (uint32_t)(RPA * lddz * AES), b_pstep = (uint32_t)(RPB * ldx * BES);
   float4 ra0[PA], rb0[PB];                           // (bf16 operands use the first 8 bytes of each)
-  auto load = [&](float4 (&ra)[PA], float4 (&rb)[PB], int ch) {
+  // The two buffer descriptors of a chunk: chunk-only quantities (64-bit multiplies, clamps, a division in the padded form).
+  // Round 5: the block builds them once for ITS chunks into an LDS table, one chunk per thread, instead of every wave
+  // rebuilding them in front of every load (wgrad_dma_body has the measurements; pad bit 0x2000 = the former path).
+  const int ich0_t = (int)ch0, nall_t = (int)(ch1 - ch0);
+  constexpr int WT_TCAP = 256;
+  __shared__ __attribute__((aligned(16))) uint4 s_desc_t[2 * WT_TCAP];
+  auto make_desc = [&](int ch, uint4& r0, uint4& r1) {
     int t0, Li;
     int64_t rowb;                                    // first row of the chunk's item, the item's length
     if (chunktab) {
@@ -415,11 +421,27 @@ __device__ __forceinline__ void wgrad_tr_body(const int bid, const void* __restr
     int64_t b_rec = ((int64_t)(Li - txb - 1) * ldx + cinp) * BES;
     a_rec = a_rec > REC_MAX ? REC_MAX : a_rec;
     b_rec = b_rec > REC_MAX ? REC_MAX : (b_rec < 0 ? 0 : b_rec);
-    const char* a_base = reinterpret_cast<const char*>(dz) + (rowb + t0) * lddz * AES;
-    const char* b_base = reinterpret_cast<const char*>(x) + (rowb + txb) * ldx * BES;
-    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a_base), 0, (int)a_rec, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b_base), 0, (int)b_rec, 0x00020000);
-    const uint32_t b_off = (uint32_t)((tx - txb) * (int)ldx * BES);      // <= 0: rows before the item wrap out of range
+    const uint64_t a_base = (uint64_t)(reinterpret_cast<const char*>(dz) + (rowb + t0) * lddz * AES);
+    const uint64_t b_base = (uint64_t)(reinterpret_cast<const char*>(x) + (rowb + txb) * ldx * BES);
+    r0 = make_uint4((uint32_t)a_base, (uint32_t)(a_base >> 32), (uint32_t)b_base, (uint32_t)(b_base >> 32));
+    r1 = make_uint4((uint32_t)a_rec, (uint32_t)b_rec, (uint32_t)((tx - txb) * (int)ldx * BES), 0u);   // .z <= 0: rows before the item wrap out of range
+  };
+  const bool use_tab_t = !(pad_parts & 0x2000) && nall_t > 0 && nall_t <= WT_TCAP;
+  if (use_tab_t) {
+    for (int k = tid; k < nall_t; k += 256) make_desc(ich0_t + k, s_desc_t[2 * k], s_desc_t[2 * k + 1]);
+    __syncthreads();
+  }
+  auto load = [&](float4 (&ra)[PA], float4 (&rb)[PB], int ch) {
+    uint4 r0, r1;
+    if (use_tab_t) { r0 = s_desc_t[2 * (ch - ich0_t)]; r1 = s_desc_t[2 * (ch - ich0_t) + 1]; }
+    else make_desc(ch, r0, r1);
+    const uint32_t a_lo = __builtin_amdgcn_readfirstlane(r0.x), a_hi = __builtin_amdgcn_readfirstlane(r0.y);
+    const uint32_t b_lo = __builtin_amdgcn_readfirstlane(r0.z), b_hi = __builtin_amdgcn_readfirstlane(r0.w);
+    const char* a_base = reinterpret_cast<const char*>(((uint64_t)a_hi << 32) | a_lo);
+    const char* b_base = reinterpret_cast<const char*>(((uint64_t)b_hi << 32) | b_lo);
+    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a_base), 0, (int)__builtin_amdgcn_readfirstlane(r1.x), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b_base), 0, (int)__builtin_amdgcn_readfirstlane(r1.y), 0x00020000);
+    const uint32_t b_off = __builtin_amdgcn_readfirstlane(r1.z);
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
       if (DZ16) {
@@ -774,7 +796,7 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
   // in one burst behind the barrier but between the K steps of the chunk being computed (`piece`, called from compute):
   // an LDS-DMA instruction holds the wave's issue for 60-180 cycles, which a burst puts in front of the first MFMA.
   constexpr int NPIECE = PA + PB + (HALO ? 1 : 0), NSTEP = WB_BK / 16, PPS = (NPIECE + NSTEP - 1) / NSTEP;
-  const bool ilv = pad_cat & 0x4000;
+  const bool ilv = (pad_cat & 0x4000) || (KW == 5 && TA == 2);      // measured: +3.5 % on the tall k = 5 tile, neutral elsewhere
   __amdgpu_buffer_rsrc_t pend_ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dz), 0, 0, 0x00020000), pend_rb = pend_ra;
   uint32_t pend_boff = 0u;
   int pend_stage = 0;
