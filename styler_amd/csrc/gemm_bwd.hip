@@ -944,7 +944,10 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
   constexpr int NS = WB_BK / 16;
   // (only where a half chunk is still a long MFMA run -- k = 9: 18 MFMAs per wave and phase; measured: k = 9 123 -> 117 us,
   //  k = 5 (10 per phase) 122 -> 127 us, the Linear tile unchanged)
-  constexpr bool STAG = KG == 2 && KW == 9;
+#ifndef STYLER_WGRAD_STAG_TALL
+#define STYLER_WGRAD_STAG_TALL 1
+#endif
+  constexpr bool STAG = KG == 2 && (KW == 9 || (STYLER_WGRAD_STAG_TALL && KW == 5 && TA == 2));    // (tall k = 5: 20 MFMAs per wave and phase)
   if (STAG && grp == 1) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -1193,7 +1196,7 @@ extern "C" int styler_wgrad_tune(int knob, int value) {
   int* const k = knob == 0 ? &g_wgrad_xcd_map : knob == 1 ? &g_wgrad_k5_tall : knob == 2 ? &g_wgrad_ring4 : nullptr;
   if (!k) return STYLER_EINVAL;
   const int prev = *k;
-  if (value == 0 || value == 1) *k = value;
+  if (value == 0 || value == 1 || (value == 2 && knob == 1)) *k = value;
   return prev;
 }
 static bool wgrad_k5_tall(int n, int cin, int kw, int prec, int io_flags);
@@ -1209,7 +1212,7 @@ static int wgrad_kgroups(int n, int cin, int kw, int prec, int io_flags) {
 }
 static bool wgrad_k5_tall(int n, int cin, int kw, int prec, int io_flags) {
   return g_wgrad_k5_tall && g_wgrad_dma == 2 && prec == STYLER_PREC_BF16 && kw == 5 && (io_flags & STYLER_IO_Y_BF16) &&
-         (io_flags & STYLER_IO_X_BF16) && !(n & 127) && !(cin & 7) && (n / 64) * ((cin + 63) / 64) >= 64;
+         (io_flags & STYLER_IO_X_BF16) && !(n & 127) && !(cin & 7) && ((n / 64) * ((cin + 63) / 64) >= 64 || g_wgrad_k5_tall >= 2);
 }
 
 // STYLER_IO_X3CAT launches exist on the LDS-DMA ring only: both parts bf16-resident, whole 16-byte pieces, a ring kernel
