@@ -1190,6 +1190,9 @@ static int g_wgrad_xcd_map = [] { const char* e = getenv("STYLER_WGRAD_XCDMAP");
 // Measured (same file): PostNet 512 -> 512: 128.6 -> 115.2 us (+11.6 %); 256 -> 256 (16 tiles of 64 x 64: the tall tile doubles
 // its split count to 32): 43.6 -> 44.4 us.  Default: on, for gradients of at least 64 tiles of 64 x 64.
 // knob 2 (experiment): a ring of FOUR stages (prefetch distance 3 chunks) for the 64 x 64 k = 5 / k = 9 kernels of mode 2
+// experiment: the Linear (k = 1) gradients on the register-staged kernel although both operands are bf16-resident (its 128 x 128
+// tile issues 8 DMA pieces per 16 MFMAs on the ring: stand-alone the register-staged kernel is 8-27 % faster there)
+static int g_wgrad_lin_dma = [] { const char* e = getenv("STYLER_WGRAD_LIN_DMA"); return e ? atoi(e) : 1; }();
 static int g_wgrad_ring4 = [] { const char* e = getenv("STYLER_WGRAD_RING4"); return e ? atoi(e) : 0; }();
 static int g_wgrad_k5_tall = [] { const char* e = getenv("STYLER_WGRAD_K5_TALL"); return e ? atoi(e) : 1; }();
 extern "C" int styler_wgrad_tune(int knob, int value) {
@@ -1207,7 +1210,7 @@ static int wgrad_kgroups(int n, int cin, int kw, int prec, int io_flags) {
   if (!(io_flags & STYLER_IO_Y_BF16) || !(io_flags & STYLER_IO_X_BF16) || (n & 7) || (cin & 7)) return 1;
   int TA, TB;
   wgrad_tile(n, cin, kw, prec, &TA, &TB);
-  if (kw == 1) return (TA == 2 && TB == 2) ? 2 : 1;
+  if (kw == 1) return (TA == 2 && TB == 2 && g_wgrad_lin_dma) ? 2 : 1;
   return ((kw == 5 || kw == 9) && TA == 1 && TB == 1) ? 2 : 1;
 }
 static bool wgrad_k5_tall(int n, int cin, int kw, int prec, int io_flags) {
@@ -1321,7 +1324,7 @@ static int wgrad_impl(const float* dz, int64_t lddz, const float* x, int64_t ldx
 #define WD_LAUNCH(K, A_, B_, S_, G_) hipLaunchKernelGGL((wgrad_dma_kernel<K, A_, B_, S_, G_>), grid1, dim3(256 * G_), 0, st, dz, lddz, \
                                                         x, ldx, db, db2, Be, Le, n, cin, pad_cat, ct, cpi, cps, tiles, splits, ws,   \
                                                         kw > 1 ? reinterpret_cast<const int4*>(chunktab) : nullptr, counts)
-    if (dma && kw == 1 && TA == 2 && TB == 2) {
+    if (dma && kw == 1 && TA == 2 && TB == 2 && g_wgrad_lin_dma) {
       if (kg == 2) WD_LAUNCH(1, 2, 2, 2, 2);
       else if (g_wgrad_dma_nst128 == 3) WD_LAUNCH(1, 2, 2, 3, 1); else WD_LAUNCH(1, 2, 2, 2, 1);
     } else if (dma && kw == 5 && TA == 2 && TB == 1 && tall) {
@@ -1480,7 +1483,7 @@ extern "C" int styler_wgrad_group(const StylerWgradGroupDesc* desc_dev, int coun
     case 6: WGG(9, 1, 1, true, false); break;
     case 7: WGG(1, 2, 2, true, false); break;
     case 8:
-      if (g_wgrad_dma) hipLaunchKernelGGL(wgrad_dma_group_lin128_kernel, grid, block, 0, st, desc_dev, count);
+      if (g_wgrad_dma && g_wgrad_lin_dma) hipLaunchKernelGGL(wgrad_dma_group_lin128_kernel, grid, block, 0, st, desc_dev, count);
       else WGG(1, 2, 2, true, true);
       break;
     default: return STYLER_EINVAL;
