@@ -425,27 +425,13 @@ class StyleModeling(_HipModule):
             t_e, p_e, s_e, e_e, n_e = (lr[..., i * H:(i + 1) * H] for i in range(5))       # [B, T, 1280] slices
 
         # (teacher-forced training: the two predictions only feed the loss -- rt.pred_stream; joined by STYLER.forward)
-        side_pred = grad and rt.pred_stream and energy_target is not None and pitch_target is not None
-        self._late_pred = None
-        if side_pred and rt.pred_late:
-            # EXPERIMENT rt.pred_late: the two predictors are CALLED behind the decode (STYLER.forward -> run_late_predictors), so
-            # their tape nodes are younger than the decoder's and autograd replays their backward FIRST -- the side stream's
-            # backward chain is captured (and starts) at the head of backward instead of at the tail of the decoder's
-            def late(e_e=e_e, p_e=p_e, s_e=s_e, lens=lens):
-                with self._loss_only_stream(True):
-                    ep = self.energy_predictor(e_e, lens)
-                    pp = self.pitch_predictor(AG.Add2Fn.apply(p_e, s_e) if pitch_plus_speaker else p_e, lens)
-                return pp, ep
-            self._late_pred = late
-            energy_prediction = pitch_prediction = None
-        else:
-            with self._loss_only_stream(side_pred):
-                energy_prediction = self.energy_predictor(e_e, lens)
-                if pitch_plus_speaker:
-                    p_in = AG.Add2Fn.apply(p_e, s_e) if grad else ops.add2(p_e, s_e)
-                else:
-                    p_in = p_e
-                pitch_prediction = self.pitch_predictor(p_in, lens)
+        with self._loss_only_stream(grad and rt.pred_stream and energy_target is not None and pitch_target is not None):
+            energy_prediction = self.energy_predictor(e_e, lens)
+            if pitch_plus_speaker:
+                p_in = AG.Add2Fn.apply(p_e, s_e) if grad else ops.add2(p_e, s_e)
+            else:
+                p_in = p_e
+            pitch_prediction = self.pitch_predictor(p_in, lens)
         if energy_target is not None:
             e_src, e_scale = energy_target.contiguous(), 1.0
         else:

@@ -45,7 +45,6 @@ class _Runtime:
     # join, and its kernels fit into the tails the decoder's 1.66-round launches leave.  STYLER_PRED_STREAM=0 switches it off.
     pred_stream = os.environ.get("STYLER_PRED_STREAM", "1") != "0"
     pred_stream_cls = os.environ.get("STYLER_PRED_STREAM_CLS", "1") != "0"     # ... the augmentation classifiers too
-    pred_late = os.environ.get("STYLER_PRED_LATE", "0") == "1"                # EXPERIMENT: see modules._expand_and_predict
 
     # EXPERIMENT (round 5): on one rank, the decoder-side flush of the weight-gradient arena (grouped Linear gradients + the fold
     # of the split-K partials so far) on a side stream next to the rest of backward (training.TrainState.early_flush_on_side)

@@ -25,19 +25,6 @@ class STYLER(_HipModule):
             self.postnet = PostNet()
         self.clean_only = False
 
-    def _run_late_predictors(self, final=False):
-        """rt.pred_late: the pitch / energy predictors, deferred by StyleModeling._expand_and_predict, run now on the loss-only
-        side stream (between the decoder and the PostNet: next to the PostNet's forward, and -- being the youngest tape nodes
-        but the PostNet's -- at the head of backward).  `final`: hand over (pitch, energy) once."""
-        late = getattr(self.style_modeling, "_late_pred", None)
-        if late is not None:
-            self.style_modeling._late_pred = None
-            self._late_result = late()
-        if not final:
-            return None
-        res, self._late_result = getattr(self, "_late_result", None), None
-        return res
-
     def _lens_from_mask(self, mel_mask):
         return (~mel_mask).sum(dim=1).to(torch.int64)
 
@@ -58,7 +45,6 @@ class STYLER(_HipModule):
         lens = mel_len if mel_len is not None else self._lens_from_mask(mel_mask)
         B = out_clean.shape[0]
         mel2 = self._gemm("mel_linear", self.decoder.forward_pair(out_clean, out_noisy, lens), self.mel_linear)
-        self._run_late_predictors()
         tape = self.training and torch.is_grad_enabled() and mel2.requires_grad
         split = (lambda t: AG.SplitBatchFn.apply(t)) if tape else (lambda t: (t[:B], t[B:]))
         if self.use_postnet and rt.pair_postnet:
@@ -102,9 +88,6 @@ class STYLER(_HipModule):
         else:
             mel_output, mel_output_postnet = self.decode(style_modeling_output, mel_mask, mel_len)
             mel_output_noisy, mel_output_postnet_noisy = self.decode(noisy_in, mel_mask, mel_len)
-        late = self._run_late_predictors(final=True)   # (rt.pred_late; normally they already ran in front of the PostNet)
-        if late is not None:
-            p_prediction, e_prediction = late
         side = getattr(self.style_modeling, "_pred_side", None)
         if side is not None:                          # rt.pred_stream: the predictors ran next to the decode
             torch.cuda.current_stream().wait_stream(side)
