@@ -47,3 +47,13 @@ cp $O/r05_pmc_traffic.jsonl $R/profiles/r05_pmc_traffic.jsonl    # the default l
 cp $O/r05_train_bf16_graph_kernel_stats.txt $R/profiles/r05_train_bf16_graph_kernel_stats.txt   # ... and frac_rocprof from THIS trace
 timeout 900 python bench.py > $O/r05_bench_default.json 2> $O/r05_bench_default.err
 cat $O/r05_pmc_traffic.jsonl; head -12 $O/r05_timeline.txt; tail -c 400 $O/r05_bench_default.json
+# round 5 extras: the weight-gradient phase trace (trace build, built in the container by tools/wgrad_trace.sh) with the
+# descriptor table off / on, and the stand-alone kernel A/B of the table
+if [ -f $R/styler_amd/libstyler_hip_trace.so ]; then
+  { echo "# tools/wgrad_trace.py: per-wave cycle sums of the ring loop's phases (trace build), block 0 and 9"; echo "## descriptor table OFF (STYLER_WGRAD_DESCTAB=0: the round-4 path)";
+    STYLER_WGRAD_DESCTAB=0 STYLER_LIB=$R/styler_amd/libstyler_hip_trace.so timeout 300 python tools/wgrad_trace.py 2>&1 | grep -v amdgpu.ids
+    echo "## descriptor table ON (default)";
+    STYLER_LIB=$R/styler_amd/libstyler_hip_trace.so timeout 300 python tools/wgrad_trace.py 2>&1 | grep -v amdgpu.ids; } > $O/r05_wgrad_trace.txt
+fi
+{ echo "# tools/wgrad_bench.py 5, same box: STYLER_WGRAD_DESCTAB=0 (per-issue descriptor arithmetic, round 4) then =1 (per-block LDS table, default)"
+  for v in 0 1; do echo "## STYLER_WGRAD_DESCTAB=$v"; STYLER_WGRAD_DESCTAB=$v timeout 300 python tools/wgrad_bench.py 5 2>&1 | grep -v amdgpu.ids; done; } > $O/r05_wgrad_bench.txt
