@@ -789,7 +789,12 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
   // (raw 8 dwords of a chunk's table entry: read an iteration ahead, the LDS latency stays off the issue path)
   auto tab_read = [&](int chk, uint4& r0, uint4& r1) {
     const int k = chk - (int)ch0;
-    if (use_tab && k >= 0 && k < nall_blk) { r0 = s_desc[2 * k]; r1 = s_desc[2 * k + 1]; }
+    if (use_tab) {
+      if (k >= 0 && k < nall_blk) { r0 = s_desc[2 * k]; r1 = s_desc[2 * k + 1]; }
+    } else {                                         // (no table: the chunk-table entry itself travels an iteration ahead, as in round 4)
+      const int4 e = entry(chk);
+      r0 = make_uint4((uint32_t)e.x, (uint32_t)e.y, (uint32_t)e.z, (uint32_t)e.w);
+    }
   };
   WGT_DECL
   // The refill of a stage is PA + PB (+ 1 halo) DMA pieces per wave.  `ilv` (pad bit 0x4000, STYLER_WGRAD_ILV): they are not issued
@@ -841,7 +846,7 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
       d.b_off = __builtin_amdgcn_readfirstlane(r1.z); d.pad = 0u;
       launch(stage, d, defer);
     } else {
-      launch(stage, make_desc(chk, entry(chk)), defer);
+      launch(stage, make_desc(chk, make_int4((int)r0.x, (int)r0.y, (int)r0.z, (int)r0.w)), defer);
     }
   };
 

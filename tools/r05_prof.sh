@@ -19,6 +19,9 @@ trace() {   # trace <name> <bench args...>
   rm -rf $O/trace_$name
 }
 trace train_bf16_graph --mode train --steps 20 --warmup 5
+# the same step with every side stream off (text encoder, loss-only branch): per-kernel durations WITHOUT co-runners -- in the default
+# trace above a launch's duration includes the time it shared the chip with a side-stream kernel (15 % of the step)
+STYLER_PRED_STREAM=0 STYLER_TEXT_STREAM=0 trace train_bf16_graph_serial --mode train --steps 20 --warmup 5
 trace fwd_bf16_graph --mode fwd --steps 20 --warmup 5
 trace c4_fwd_dual --mode fwd --shape c4 --batch 128 --dual --steps 5 --warmup 2
 trace train_bf16x3_graph --mode train --prec bf16x3 --steps 10 --warmup 3
