@@ -846,7 +846,8 @@ __device__ __forceinline__ void wgrad_dma_body(const int bid, const void* __rest
       d.b_off = __builtin_amdgcn_readfirstlane(r1.z); d.pad = 0u;
       launch(stage, d, defer);
     } else {
-      launch(stage, make_desc(chk, make_int4((int)r0.x, (int)r0.y, (int)r0.z, (int)r0.w)), defer);
+      launch(stage, make_desc(chk, make_int4((int)__builtin_amdgcn_readfirstlane(r0.x), (int)__builtin_amdgcn_readfirstlane(r0.y),
+                                             (int)__builtin_amdgcn_readfirstlane(r0.z), (int)__builtin_amdgcn_readfirstlane(r0.w))), defer);
     }
   };
 
