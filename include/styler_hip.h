@@ -190,8 +190,8 @@ int64_t styler_conv_gemm_workspace_bytes(int B, int L, int cin, int n, int kw, i
 int styler_gemm_set_workspace(void* ptr, int64_t bytes);
 /* Round 5 (bf16x3 arithmetic): producers write the operand split themselves.  The next PRODUCER call of this host thread --
  * styler_conv_gemm / styler_conv_gemm_packed (fp32 output in bf16 MFMA mode; whatever engine takes it, including its split-K
- * combine pass), styler_add_layernorm, styler_groupnorm_relu / _bwd, styler_batchnorm_train / _bwd (fp32 outputs, contiguous
- * rows) -- ALSO stores the [hi | lo (| hi)] bf16 split of its fp32 output rows into y3: rows of parts * C bf16, parts = 2 | 3,
+ * combine pass), styler_add_layernorm, styler_layernorm_bwd (its dx), styler_groupnorm_relu / _bwd, styler_batchnorm_train /
+ * _bwd, styler_attention_fwd_x3 (its output) / styler_attention_bwd_x3 (dqkv) (fp32 outputs, contiguous rows) -- ALSO stores the [hi | lo (| hi)] bf16 split of its fp32 output rows into y3: rows of parts * C bf16, parts = 2 | 3,
  * the layout and the values of styler_split3_bf16 bit for bit, so that the GEMM consuming the output as a bf16x3 operand
  * needs no split pass (transformer/SubLayers.py:41-61,83-89, transformer/Layers.py:91-128, modules.py:103-172 and their
  * autograd).  Consumed by that call; a producer that cannot honour it returns STYLER_EINVAL.  y3 = NULL clears it. */

@@ -374,6 +374,206 @@ __global__ __launch_bounds__(256, STYLER_ATTN_FWD_WAVES) void attention_fwd_bf16
   }
 }
 
+// Round 5: the LAZY forward with the softmax bookkeeping taken off the LDS pipe and out of the per-32-key dependency chain
+// (VERDICT r04 item 8).  V is a bit set:
+//   1  s_setprio 1 around the two MFMA clusters (a wave in its matrix phase wins the issue slot over its SIMD partners' VALU);
+//   2  the two half-wave exchanges of a key block -- row maximum and row sum, each a ds_bpermute + s_waitcnt lgkmcnt(0) round
+//      trip in the middle of the chain S -> max -> exp2 -> P V -- become one v_permlane32_swap (VALU, no wait) for the maximum
+//      and NONE for the sum: both lane halves rescale by the same alpha, so each keeps the sum of its own 16 keys per block
+//      and the halves are added once, after the last tile;
+//   4  one softmax step per 64-key tile instead of per 32-key block: 8 independent S MFMAs in flight, one maximum / one
+//      move test per tile, then 32 exp2 and 8 P V MFMAs;
+//   8  the next tile's K / V rows are loaded into registers across the current tile's steps (16 more live registers).
+__device__ __forceinline__ float xhalf_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <bool Q16, int V>
+__global__ __launch_bounds__(256, STYLER_ATTN_FWD_WAVES) void attention_fwd_bf16_v_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                 float* __restrict__ lse, int B, int L,
+                                                                 const int64_t* __restrict__ len,
+                                                                 const int* __restrict__ cu, int out16) {
+  constexpr bool PRIO = V & 1, SWAP = V & 2, T64 = V & 4, PF = V & 8;
+  __shared__ __attribute__((aligned(16))) uint32_t sK[64 * ALD];
+  __shared__ __attribute__((aligned(16))) uint32_t sV[64 * ALD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int tq = lane & 15, tc = (lane >> 4) & 1;
+  int bx, head, b;
+  if (!attn_block(L, B, bx, head, b)) return;
+  const int q0 = bx * 128 + wave * 32;
+  const int64_t rowbase = cu ? (int64_t)cu[b] : (int64_t)b * L;
+  int klen = len ? (int)len[b] : L;
+  if (klen > L) klen = L;
+  const int Lr = cu ? klen : L;
+  if (Lr <= 0) return;
+  const int q = q0 + li, qc = q < Lr ? q : Lr - 1;
+  if (bx * 128 >= klen) {
+    if (q < Lr) {
+      zero32(out, (rowbase + q) * 256 + head * AD + lh * 32, out16);
+      if (lse && lh == 0) lse[((int64_t)b * 4 + head) * L + q] = 0.f;
+    }
+    return;
+  }
+  bf16x8 qf[4];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    if constexpr (Q16) qf[st] = load8_raw16(qkv, (rowbase + qc) * 768 + head * AD + st * 16 + lh * 8);
+    else qf[st] = load8_bf16(qkv + (rowbase + qc) * 768 + head * AD + st * 16 + lh * 8, ATTN_SCALE_LOG2);
+  }
+  constexpr float SC = Q16 ? ATTN_SCALE_LOG2 : 1.f;
+  constexpr float TH = 8.f / SC;
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;               // SWAP: l_run is this lane half's share of the row sum
+
+  const __amdgpu_buffer_rsrc_t krs = Q16 ? rows_rsrc16(qkv, rowbase * 768 + 256 + head * AD, 768, Lr)
+                                          : rows_rsrc(qkv + rowbase * 768 + 256 + head * AD, 768, Lr);
+  const __amdgpu_buffer_rsrc_t vrs = Q16 ? rows_rsrc16(qkv, rowbase * 768 + 512 + head * AD, 768, Lr)
+                                          : rows_rsrc(qkv + rowbase * 768 + 512 + head * AD, 768, Lr);
+  const int ntiles = (klen + 63) / 64;
+  TileRegs<Q16> rk, rv;
+  // the tile's K and V rows -> LDS.  Loads are issued ahead of the barrier; PF: one tile ahead, across the tile's MFMAs
+  auto stage = [&](int k0, int knext) {
+    if constexpr (!PF) { tile_load<Q16>(rk, krs, 768, k0, tid); tile_load<Q16>(rv, vrs, 768, k0, tid); }
+    __syncthreads();
+    tile_store<Q16>(sK, rk, tid);
+    tile_store<Q16>(sV, rv, tid);
+    if constexpr (PF) if (knext >= 0) { tile_load<Q16>(rk, krs, 768, knext, tid); tile_load<Q16>(rv, vrs, 768, knext, tid); }
+    __syncthreads();
+  };
+  if constexpr (PF) { tile_load<Q16>(rk, krs, 768, 0, tid); tile_load<Q16>(rv, vrs, 768, 0, tid); }
+  // one softmax step over the 32-key block kb of the tile
+  auto step32 = [&](int k0, int kb) {
+    bf16x8 kf[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) kf[st] = *reinterpret_cast<const bf16x8*>(&sK[(kb * 32 + li) * ALD + st * 8 + lh * 4]);
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s, 0, 0, 0);
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    if (k0 + kb * 32 + 32 > klen) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (key >= klen) s[r] = -INFINITY;
+      }
+    }
+    float mb = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mb = fmaxf(mb, s[r]);
+    mb = SWAP ? xhalf_max(mb) : fmaxf(mb, __shfl_xor(mb, 32, 64));
+    const bool move = mb > m_run + TH;
+    if (__builtin_amdgcn_ballot_w64(move) != 0) {
+      const float m_new = move ? mb : m_run;
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * SC);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    }
+    const float mneg = -m_run * SC;
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], SC, mneg)); rs += s[r]; }
+    if constexpr (!SWAP) rs += __shfl_xor(rs, 32, 64);
+    l_run += rs;
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 pb = pack_acc(s, s2);
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sV, 0, tq, tc, kb, s2, lh), pb, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sV, 1, tq, tc, kb, s2, lh), pb, o1, 0, 0, 0);
+    }
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+  };
+  auto step64 = [&](int k0) {
+    // both key blocks in one step (all keys of block 0 are valid here: only block 1 can cross the length)
+    bf16x8 kf[8];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      kf[st] = *reinterpret_cast<const bf16x8*>(&sK[li * ALD + st * 8 + lh * 4]);
+      kf[4 + st] = *reinterpret_cast<const bf16x8*>(&sK[(32 + li) * ALD + st * 8 + lh * 4]);
+    }
+    f32x16 sa, sb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], sa, 0, 0, 0);
+      sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[4 + st], qf[st], sb, 0, 0, 0);
+    }
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    if (k0 + 64 > klen) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (key >= klen) sb[r] = -INFINITY;
+      }
+    }
+    float mb = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mb = fmaxf(mb, sa[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mb = fmaxf(mb, sb[r]);
+    mb = SWAP ? xhalf_max(mb) : fmaxf(mb, __shfl_xor(mb, 32, 64));
+    const bool move = mb > m_run + TH;
+    if (__builtin_amdgcn_ballot_w64(move) != 0) {
+      const float m_new = move ? mb : m_run;
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * SC);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    }
+    const float mneg = -m_run * SC;
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sa[r] = __builtin_amdgcn_exp2f(fmaf(sa[r], SC, mneg)); rs += sa[r]; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sb[r] = __builtin_amdgcn_exp2f(fmaf(sb[r], SC, mneg)); rs += sb[r]; }
+    if constexpr (!SWAP) rs += __shfl_xor(rs, 32, 64);
+    l_run += rs;
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 pa = pack_acc(sa, s2);
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sV, 0, tq, tc, 0, s2, lh), pa, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sV, 1, tq, tc, 0, s2, lh), pa, o1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 pb = pack_acc(sb, s2);
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sV, 0, tq, tc, 1, s2, lh), pb, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fragT(sV, 1, tq, tc, 1, s2, lh), pb, o1, 0, 0, 0);
+    }
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+  };
+  // tiles whose second key block holds data (k0 + 32 < klen), then -- klen % 64 in 1..32 -- a last tile of one block
+  const int n2 = (klen + 31) >> 6;
+  for (int kt = 0; kt < n2; ++kt) {
+    stage(kt * 64, kt + 1 < ntiles ? kt * 64 + 64 : -1);
+    if constexpr (T64) step64(kt * 64);
+    else { step32(kt * 64, 0); step32(kt * 64, 1); }
+  }
+  if (n2 < ntiles) { stage(n2 * 64, -1); step32(n2 * 64, 0); }
+  if constexpr (SWAP) l_run = xhalf_sum(l_run);
+  if (q < Lr) {
+    if (out16) store_accT16(reinterpret_cast<uint16_t*>(out) + (rowbase + q) * 256 + head * AD, o0, o1, lh, 1.f / l_run);
+    else store_accT(out + (rowbase + q) * 256 + head * AD, o0, o1, lh, 1.f / l_run);
+    if (lse && lh == 0) lse[((int64_t)b * 4 + head) * L + q] = (m_run * SC + log2f(l_run)) * 0.693147180559945f;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------- dQ
 template <bool Q16>
 __global__ __launch_bounds__(256, STYLER_ATTN_DQ_WAVES) void attention_bwd_dq_bf16_kernel(const float* __restrict__ qkv,
@@ -1031,6 +1231,15 @@ extern "C" int styler_attention_fwd_bf16_io(const void* qkv, void* out, float* l
   // STYLER_ATTN_LAZY=0: the eager-rescaling form of the forward (see the kernel's LAZY note)
   static const int lazy = [] { const char* e = getenv("STYLER_ATTN_LAZY"); return e ? atoi(e) : 1; }();
 #define FWD_LAUNCH(Q_, L_) hipLaunchKernelGGL((attention_fwd_bf16_kernel<Q_, L_>), attn_grid(L, B), dim3(256), 0, (hipStream_t)stream, q, o, lse, B, L, len, cu, out16)
+  // STYLER_ATTN_FWD_V = 1..7: the round-5 variants of the lazy forward (attention_fwd_bf16_v_kernel)
+  static const int fv = [] { const char* e = getenv("STYLER_ATTN_FWD_V"); return e ? atoi(e) : 0; }();
+#define FWDV_LAUNCH(Q_, V_) hipLaunchKernelGGL((attention_fwd_bf16_v_kernel<Q_, V_>), attn_grid(L, B), dim3(256), 0, (hipStream_t)stream, q, o, lse, B, L, len, cu, out16)
+#define FWDV_CASE(V_) case V_: if (io_flags & STYLER_IO_X_BF16) FWDV_LAUNCH(true, V_); else FWDV_LAUNCH(false, V_); return launch_status();
+  if (lazy && fv > 0) {
+    switch (fv) { FWDV_CASE(1) FWDV_CASE(2) FWDV_CASE(3) FWDV_CASE(4) FWDV_CASE(6) FWDV_CASE(7) FWDV_CASE(14) FWDV_CASE(15) default: break; }
+  }
+#undef FWDV_CASE
+#undef FWDV_LAUNCH
   if (io_flags & STYLER_IO_X_BF16) { if (lazy) FWD_LAUNCH(true, true); else FWD_LAUNCH(true, false); }
   else { if (lazy) FWD_LAUNCH(false, true); else FWD_LAUNCH(false, false); }
 #undef FWD_LAUNCH

@@ -428,8 +428,9 @@ __global__ __launch_bounds__(256) void split3_bf16_kernel(const float* __restric
 }
 
 // Round 5: producers write the split themselves.  The next PRODUCER call of this host thread -- styler_conv_gemm[_packed] (fp32
-// output, bf16 MFMA mode; any engine, incl. the split-K combine pass), styler_add_layernorm, styler_groupnorm_relu[_bwd],
-// styler_batchnorm_train / _bwd (fp32 outputs, contiguous rows) -- ALSO stores the [hi | lo (| hi)] bf16 split of its fp32 output
+// output, bf16 MFMA mode; any engine, incl. the split-K combine pass), styler_add_layernorm, styler_layernorm_bwd (dx),
+// styler_groupnorm_relu[_bwd], styler_batchnorm_train / _bwd, styler_attention_fwd_x3 / _bwd_x3 (fp32 outputs, contiguous rows)
+// -- ALSO stores the [hi | lo (| hi)] bf16 split of its fp32 output
 // rows into y3: rows of parts * C bf16 (parts = 2 | 3), the layout and the values of styler_split3_bf16 bit for bit, so that
 // the GEMM consuming the output as a bf16x3 operand needs no split pass (116 passes = 1.5 ms of the 21 ms bf16x3 step in round
 // 4).  The registration is consumed by that call (taken first thing, whatever path it then runs); a producer that cannot honour
