@@ -1231,12 +1231,16 @@ extern "C" int styler_attention_fwd_bf16_io(const void* qkv, void* out, float* l
   // STYLER_ATTN_LAZY=0: the eager-rescaling form of the forward (see the kernel's LAZY note)
   static const int lazy = [] { const char* e = getenv("STYLER_ATTN_LAZY"); return e ? atoi(e) : 1; }();
 #define FWD_LAUNCH(Q_, L_) hipLaunchKernelGGL((attention_fwd_bf16_kernel<Q_, L_>), attn_grid(L, B), dim3(256), 0, (hipStream_t)stream, q, o, lse, B, L, len, cu, out16)
-  // STYLER_ATTN_FWD_V = 1..7: the round-5 variants of the lazy forward (attention_fwd_bf16_v_kernel)
-  static const int fv = [] { const char* e = getenv("STYLER_ATTN_FWD_V"); return e ? atoi(e) : 0; }();
+  // the round-5 form of the lazy forward (attention_fwd_bf16_v_kernel), variant 7 = setprio + permlane swap / deferred row sum
+  // + 64-key softmax step: 888-901 -> 854 us on the config-4 launch, 19.0 -> 17.6 us on the config-3 decoder's, same box
+  // (profiles/r05_attn_variants.txt, which also has the variants not compiled in any more: 1, 2, 4 alone ~1 %; 14 = 6 +
+  // register prefetch 869; a V tile at a row stride of 48 dwords -- conflict-free ds_read_b64_tr_b16 -- no change).
+  // STYLER_ATTN_FWD_V=0: the round-4 kernel; 3, 6, 15: 7 without the 64-key step / without setprio / with the prefetch.
+  static const int fv = [] { const char* e = getenv("STYLER_ATTN_FWD_V"); return e ? atoi(e) : 7; }();
 #define FWDV_LAUNCH(Q_, V_) hipLaunchKernelGGL((attention_fwd_bf16_v_kernel<Q_, V_>), attn_grid(L, B), dim3(256), 0, (hipStream_t)stream, q, o, lse, B, L, len, cu, out16)
 #define FWDV_CASE(V_) case V_: if (io_flags & STYLER_IO_X_BF16) FWDV_LAUNCH(true, V_); else FWDV_LAUNCH(false, V_); return launch_status();
   if (lazy && fv > 0) {
-    switch (fv) { FWDV_CASE(1) FWDV_CASE(2) FWDV_CASE(3) FWDV_CASE(4) FWDV_CASE(6) FWDV_CASE(7) FWDV_CASE(14) FWDV_CASE(15) default: break; }
+    switch (fv) { FWDV_CASE(3) FWDV_CASE(6) FWDV_CASE(7) FWDV_CASE(15) default: break; }
   }
 #undef FWDV_CASE
 #undef FWDV_LAUNCH

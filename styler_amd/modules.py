@@ -125,8 +125,6 @@ class AudioEncoder(_HipModule):
         W = self.widths
         offs = [0, W[0], W[0] + W[1], W[0] + W[1] + W[2]]
         grad = (self.training and torch.is_grad_enabled())
-        if grad and rt.lstm_pipeline and max_seq_len is not None:
-            return self._forward_pipelined(mel, p_norm, e_input, mel_aug, len_org, seq_len, int(max_seq_len))
         catbuf = None if grad else torch.empty(B, T, sum(W), device=dev, dtype=torch.float32)
         err = torch.zeros(1, device=dev, dtype=torch.int32) if rt.strict_inputs else None
         finals, last = [], []
@@ -197,41 +195,6 @@ class AudioEncoder(_HipModule):
         return tuple(xs)
 
 
-    def _forward_pipelined(self, mel, p_norm, e_input, mel_aug, len_org, seq_len, S):
-        """EXPERIMENT rt.lstm_pipeline (training): the four streams are independent of one another until the style MLPs, and a
-        stream's tail -- mel calibrator (T -> S) and its 2-layer BiLSTM: latency-bound launches of 2B blocks that leave the chip
-        mostly idle -- only needs THAT stream's convolutions.  So the tails are not batched behind all four conv stacks (one
-        concatenation, one calibrator, one recurrent launch per layer for the four LSTMs: 245 us of the forward with nothing
-        next to them) but run per stream on ONE side stream next to the NEXT stream's chip-filling convolutions; autograd replays
-        the backward the same way (a stream's BPTT next to another stream's conv-stack backward)."""
-        W = self.widths
-        err = torch.zeros(1, device=mel.device, dtype=torch.int32) if rt.strict_inputs else None
-        main = torch.cuda.current_stream()
-        side = self.__dict__.setdefault("_tail_stream", torch.cuda.Stream(device=mel.device))
-        outs = [None] * 4
-        for s in (1, 2, 0, 3):                           # (the two one-hot streams first: their first stage is not a GEMM)
-            convs = getattr(self, f"convolutions_{s + 1}")
-            x = None
-            for i in range(3):
-                conv, gn = convs[i][0].conv, convs[i][1]
-                if i == 0 and s in (1, 2):
-                    y = AG.OnehotConv5Fn.apply(p_norm if s == 1 else e_input, conv.weight, conv, self._derived, f"oh{s}", err)
-                    b16 = rt.bf16_acts and rt.prec == ops.PREC_BF16 and W[s] % 8 == 0
-                    x = AG.GroupNormReluFn.apply(y, gn.weight, gn, b16, False)
-                else:
-                    src = (mel if s == 0 else mel_aug) if i == 0 else x
-                    x = AG.ConvNormFn.apply(src, conv.weight, conv.bias, self._derived, f"c{s}_{i}", 5, gn, "gn",
-                                            ops.ACT_RELU, 0.0, 1, i < 2)
-            side.wait_stream(main)                        # the stream's last GroupNorm is enqueued: its tail may start behind it
-            with torch.cuda.stream(side):
-                h = AG.MelCalibrateFn.apply(x, len_org, seq_len, S)
-                outs[s] = self._lstm(s, h)
-        main.wait_stream(side)
-        if err is not None and int(err.item()) != 0:
-            raise AssertionError("quantize_1D_torch: input outside [0, 1] (utils.py:423)")
-        return tuple(outs)
-
-
 class StyleEncoder(_HipModule):
     """modules.py:204-235."""
 
@@ -257,11 +220,18 @@ class StyleEncoder(_HipModule):
             # the text encoder (two FFT blocks on [B, S] rows: ~40 launch-latency-bound kernels) on a side stream next to
             # the AudioEncoder's T-domain convolutions; autograd replays each node's backward on its forward stream, so
             # the two backward chains overlap the same way (rt.text_stream)
+            # The embedding stays on the MAIN stream: its tape node is the last one of the text encoder's backward chain, autograd
+            # runs it on the stream of its forward and orders that stream behind the node's input gradient -- so the side
+            # stream's whole backward chain (its parameter gradients are written by the kernels themselves, no AccumulateGrad
+            # node of that stream tells the engine to wait for it) is joined into the main stream before backward() returns.
+            # (Round 5: with the chain delayed on purpose, the B = 48 eager step folded the embedding's slots before they were
+            # written -- the join had been a matter of timing.)
             main = torch.cuda.current_stream()
             side = self.__dict__.setdefault("_text_stream", torch.cuda.Stream(device=text.device))
+            x0 = self.text_encoder.embed(text)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                text_encoding = self.text_encoder(text, src_len, out=text_out)
+                text_encoding = self.text_encoder(text, src_len, out=text_out, x0=x0)
                 text_encoding_neck = self._gemm("tld", text_encoding, self.text_linear_down[0], act=ops.ACT_RELU)
         else:
             text_encoding = self.text_encoder(text, src_len, out=text_out)

@@ -82,10 +82,6 @@ class WgradArena:
         # graph): descriptor tables are never evicted, and once `frozen` the buffer must not be re-sized
         self.owned_by_graph = False
         self.frozen = False
-        # round 5 (rt.wgrad_hot_mb): the stand-alone launches' partial tiles are folded while they are still in the 256 MB
-        # Infinity Cache -- every `hot_limit` bytes of partials written on the pass's main stream -- instead of all 1 GB of
-        # them from HBM at the end of backward
-        self.hot, self.hot_bytes, self.hot_limit, self.main = [], 0, 0, None
 
     def begin(self, device=None):
         """Start of a backward pass.  The buffer is (re)sized HERE, from what the previous pass asked for in total --
@@ -101,25 +97,6 @@ class WgradArena:
         self.group, self.group_keep = [], []
         self.flush_no = 0
         self.side_used, self.side_keep = False, []
-        from .runtime import rt as _rt
-        self.hot, self.hot_bytes = [], 0
-        self.hot_limit = int(_rt.wgrad_hot_mb * (1 << 20)) if (device is not None and self.buf is not None) else 0
-        self.main = torch.cuda.current_stream() if self.hot_limit else None
-
-    def hot_mark(self, first_desc, device):
-        """The descriptors queued since `first_desc` belong to a stand-alone launch that has just been enqueued: when it ran
-        on the pass's main stream they move to the hot list, and once that holds `hot_limit` bytes of partials it is folded
-        right here (same multi-tensor reduce kernel; a gradient is written by exactly one descriptor set per pass, so WHEN it
-        is folded does not change a bit of it)."""
-        if not self.hot_limit or torch.cuda.current_stream() != self.main:
-            return
-        moved = self.descs[first_desc:]
-        del self.descs[first_desc:]
-        self.hot += moved
-        self.hot_bytes += sum(d[5] * d[6] * d[7] * d[8] * 4 for d in moved)
-        if self.hot_bytes >= self.hot_limit:
-            descs, self.hot, self.hot_bytes = self.hot, [], 0
-            self._reduce(descs, device)
 
     def side_stream(self, device):
         """The weight-gradient stream, ordered behind everything enqueued so far on the current one."""
@@ -213,8 +190,6 @@ class WgradArena:
                      "styler_wgrad_group")
             self.group, self.group_keep = [], []
         self.flush_no += 1
-        if self.hot:
-            self.descs, self.hot, self.hot_bytes = self.hot + self.descs, [], 0
         if not self.descs:
             return
         descs, self.descs = self.descs, []
@@ -1259,7 +1234,6 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
             arena.total -= (d.splits * n * kw * cin + 3) & ~3      # did not fit: the stand-alone request below is counted
     nfloats = int(lib.styler_wgrad_workspace_bytes_io(B, L, n, cin, kw, pad_left, prec, io | parts)) // 4
     ws, defer = None, 0
-    first_desc = len(arena.descs) if arena is not None else 0
     if arena is not None:
         ws = arena.take(nfloats, dz.device)
         if ws is not None:
@@ -1286,8 +1260,6 @@ def wgrad(dz, x, dw, n, cin, kw=1, db=None, pad_left=None, strides=None, prec=No
             _wgrad_launch(dz, x, dw, db, db2, strides, B, L, n, cin, kw, pad_left, prec, ws, defer, io | parts, plan)
     elif not grouped:
         _wgrad_launch(dz, x, dw, db, db2, strides, B, L, n, cin, kw, pad_left, prec, ws, defer, io | parts, plan)
-        if defer:
-            arena.hot_mark(first_desc, dz.device)
     if prof is not None:
         e1.record()
         prof.records.append(("wgrad_bf16" if prec == PREC_BF16 else "wgrad", 2.0 * B * L * n * kw * cin, e0, e1,

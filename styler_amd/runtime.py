@@ -50,13 +50,6 @@ class _Runtime:
     # of the split-K partials so far) on a side stream next to the rest of backward (training.TrainState.early_flush_on_side)
     early_flush = os.environ.get("STYLER_EARLY_FLUSH", "0") == "1"
 
-    # weight-gradient partial tiles folded every `wgrad_hot_mb` MB (while still in the Infinity Cache); 0 = once, at the end
-    wgrad_hot_mb = float(os.environ.get("STYLER_WGRAD_HOT_MB", "0"))
-
-    # EXPERIMENT (round 5): the AudioEncoder's per-stream tails (mel calibrator + BiLSTM) on a side stream next to the next
-    # stream's convolutions instead of batched behind all four conv stacks (modules.AudioEncoder._forward_pipelined)
-    lstm_pipeline = os.environ.get("STYLER_LSTM_PIPELINE", "0") == "1"
-
     # clean + noisy branch through the PostNet as one batch (per-branch BatchNorm statistics in the kernels): half the
     # GEMM / norm launches of the PostNet, weight gradients with twice the rows (STYLER_PAIR_POSTNET=0: two passes)
     pair_postnet = os.environ.get("STYLER_PAIR_POSTNET", "1") != "0"

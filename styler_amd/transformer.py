@@ -187,12 +187,16 @@ class Encoder(nn.Module, _PositionMixin):
         self.layer_stack = nn.ModuleList(
             [FFTBlock(d_model, d_inner, n_head, d_k, d_v, dropout=dropout) for _ in range(n_layers)])
 
-    def forward(self, src_seq, lens, out=None):
+    def embed(self, src_seq):
+        """Token embedding + positional encoding (Models.py:72-73): the first node of forward()."""
         pe = self._pe(src_seq.shape[1], src_seq.device)
         if (self.training and torch.is_grad_enabled()) and self.src_word_emb.weight.requires_grad:
-            x = AG.EmbedPosFn.apply(src_seq, self.src_word_emb.weight, self.src_word_emb, pe)
-        else:
-            x = ops.embed_pos(src_seq, self.src_word_emb.weight, pe)
+            return AG.EmbedPosFn.apply(src_seq, self.src_word_emb.weight, self.src_word_emb, pe)
+        return ops.embed_pos(src_seq, self.src_word_emb.weight, pe)
+
+    def forward(self, src_seq, lens, out=None, x0=None):
+        """x0: embed(src_seq) computed by the caller (StyleEncoder: on the main stream, the FFT blocks on a side stream)."""
+        x = self.embed(src_seq) if x0 is None else x0
         for i, layer in enumerate(self.layer_stack):
             x = layer(x, lens, out=out if i == len(self.layer_stack) - 1 else None)
         return x

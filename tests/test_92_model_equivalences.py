@@ -215,13 +215,16 @@ def test_paired_decodes_match_separate(dev, ref_state_dict, prec):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("switch", ["pair_audio", "fused_split", "fused_cat", "pair_classifiers", "grouped_mlps"])
+@pytest.mark.parametrize("switch", ["pair_audio", "fused_split", "fused_cat", "pair_classifiers", "grouped_mlps",
+                                    "text_stream", "pred_stream"])
 def test_experimental_switches_match_default(dev, ref_state_dict, prec, switch):
     """rt.pair_audio (main forward + DAT pass of the AudioEncoder as one batch of 2B items), rt.fused_split (gathered
     gradient of the LengthRegulator output's channel slices), rt.fused_cat (the AudioEncoder's four last conv + GroupNorm
     stages as one tape node writing into the concatenated buffer) and rt.pair_classifiers (round 4: the augmentation
     classifiers of the main and the DAT pass as one batch of 2B items; the batch here has B = 5: its [2B, 2] log-probabilities
-    take the unaligned path of the split) and rt.grouped_mlps (round 4: independent S-domain Linears as grouped launches) vs the path without them: same ten losses and the same gradients (dropout off)."""
+    take the unaligned path of the split) and rt.grouped_mlps (round 4: independent S-domain Linears as grouped launches), and
+    the stream switches -- rt.text_stream (text encoder's FFT blocks on a side stream), rt.pred_stream (round 5: loss-only
+    predictors and classifiers on a side stream) -- vs the path without them: same ten losses and the same gradients (dropout off)."""
     from closed_form import make_batch
     from styler_amd import STYLER, rt
     from styler_amd.training import train_losses
