@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: STYLER_WGRAD_HOT_MB and STYLER_LSTM_PIPELINE were experiment switches of this lease; both lost (profiles/r05_rejected_ab.txt) and their code was removed.
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r05q11; mkdir -p $O
 STYLER_WGRAD_HOT_MB=96 STYLER_LSTM_PIPELINE=1 timeout 900 python -m pytest tests/test_11_oracle_c2c3.py tests/test_14_train_step.py tests/test_15_dist_gpu.py -x -q -m gpu > $O/t.txt 2>&1; tail -3 $O/t.txt
 timeout 200 python tools/lstm_bench.py > $O/lstm.txt 2>&1; grep -v amdgpu $O/lstm.txt | tail -12

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: variant 23 (V tile at a row stride of 48 dwords) showed no gain and is not compiled in any more.
 # round 5: embedding on the main stream (text-stream join), attention forward variant 23 (V tile stride 48) vs 7
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r05q14; mkdir -p $O
 for v in 7 23 7 23; do

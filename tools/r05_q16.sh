@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the per-tap-read build lost (profiles/r05_rejected_ab.txt); the code was reverted, libstyler_hip_alt.so is not built any more.
 # round 5, last lease: the ring kernels' x operand per tap as two transposed LDS reads (default build) vs the sliding register
 # window (libstyler_hip_alt.so = -DSTYLER_WGRAD_TAPREAD=0), same box: stand-alone kernels, tests, step A/B
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r05q16; mkdir -p $O
