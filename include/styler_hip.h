@@ -174,6 +174,13 @@ int styler_gemm256_policy(int split_mode, int take_all);
 /* Test / tuning hook of that engine: enabled (0 / 1) and the smallest tile count it takes; -1 keeps a value (defaults:
  * STYLER_GEMM256, STYLER_GEMM256_MIN_TILES or 1, 384).  Returns the previous state as enabled | min_tiles << 1. */
 int styler_gemm256_config(int enabled, int min_tiles);
+/* Round 6: the engine's tile HEIGHT.  ht = 4: 256-row tiles, ht = 3: 192-row tiles (same LDS image and phase schedule,
+ * three MFMA row tiles per wave row), ht = 0: the dispatch policy picks per launch (rounds of 256 CUs x tile height);
+ * min_tiles3 = the smallest count of 192 x 256 tiles the policy gives to the 192-row tile (0: never; -1 keeps; defaults
+ * STYLER_GEMM256_HT or 0, STYLER_GEMM256_MIN_TILES3 or 300).  Any other ht keeps the value.  Returns the previous state
+ * as ht | min_tiles3 << 3.  Same results bit for bit at either height (tests/test_10_hip_parity.py::test_gemm256_*).
+ * Replaces: nothing in the reference (a scheduling knob of nn.Conv1d / nn.Linear forward + dX, Layers.py:78-118). */
+int styler_gemm256_height(int ht, int min_tiles3);
 /* The narrow-output tile of styler_conv_gemm (bf16 MFMA mode, 64 < n <= 96 -- the 80 mel channels of PostNet's last
  * convolution, of the dX of its first one and of mel_linear, Layers.py:78-118, styler.py:22): one 128 x 96 block tile per
  * row block instead of two 64 x 64 tiles.  enabled (0 / 1) and the smallest row count B * L it takes; -1 keeps a value
@@ -730,6 +737,14 @@ typedef struct StylerLstmBwdDesc {
   int32_t _pad;
 } StylerLstmBwdDesc;
 int styler_lstm_bidir_bwd_multi(const StylerLstmBwdDesc* descs, int count, int B, int S, void* stream);
+/* Round 6: the same two recurrences on the matrix cores (csrc/lstm_mfma.hip) -- a block takes 16 items of one (layer,
+ * direction) and runs every step as v_mfma_f32_16x16x32_bf16 against W_hh fragments held in registers; h_t / the gate
+ * gradients cross the block as bf16 through LDS.  parts = 1: bf16 products, fp32 accumulation (the bf16 mode's GEMM
+ * arithmetic); parts = 3: bf16x3 products (operands split hi + lo, three products per product).  Same descriptors, same
+ * saved tensors (post-activation gates, cell, out) and outputs as the two entry points above, which stay the fp32 path.
+ * Replaces: nn.LSTM(bidirectional=True) forward + autograd, modules.py:100-101,117,132,147,162,179-182. */
+int styler_lstm_bidir_multi_mfma(const StylerLstmDesc* descs, int count, int B, int S, int parts, void* stream);
+int styler_lstm_bidir_bwd_multi_mfma(const StylerLstmBwdDesc* descs, int count, int B, int S, int parts, void* stream);
 int styler_aug_classifier_tail_bwd(const float* h, const float* ln_g, const float* ln_b,
                                    const float* w2, const float* b2, const float* dout, float* dh,
                                    float* dln_g, float* dln_b, float* dw2, float* db2, int B, int S,

@@ -54,6 +54,8 @@ _SIGS = {
     "styler_conv_gemm_packed": [P, I64, P, P, P, P, I64, P, I64, I, I, I, I, I, I, P, P, P, I64, I, P],
     "styler_wgrad_packed": [P, I64, P, I64, P, P, I64, I64, I64, I, I, I, I, I, P, I, P, P, P, I, P],
     "styler_lstm_bidir_bwd_multi": [P, I, I, I, P],
+    "styler_lstm_bidir_multi_mfma": [P, I, I, I, I, P],
+    "styler_lstm_bidir_bwd_multi_mfma": [P, I, I, I, I, P],
     "styler_aug_classifier_tail": [P, P, P, P, P, P, I, I, P],
     "styler_duration_scan": [P, I, P, F, P, P, P, I, I, P],
     "styler_length_regulate": [P, I64, P, P, I64, P, I, I, I, I, P],
@@ -87,6 +89,7 @@ _SIGS = {
     "styler_act_bwd_multi": [P, I, P],
     "styler_gemm256_config": [I, I],
     "styler_gemm256_policy": [I, I],
+    "styler_gemm256_height": [I, I],
     "styler_conv_gemm_engine2": [I, I, I, I, I, I, I, I64, I, I, I],
     "styler_gemm_n96_config": [I, I],
     "styler_gemm_small_split_config": [I],

@@ -639,9 +639,10 @@ class LstmMultiLayerFn(Function):
             calls.append(dict(x=x, w=w, bias=bias, n=8 * Hs[s], prec=prec))
             w_hhs.append(w_hh)
         gxs = ops.conv_gemm_multi(calls)             # the four input projections: one grouped launch
-        outs, cells, gates = ops.lstm_bidir_multi(gxs, w_hhs, Hs, save=True)
+        parts = rt.lstm_parts()
+        outs, cells, gates = ops.lstm_bidir_multi(gxs, w_hhs, Hs, save=True, parts=parts)
         ctx.save_for_backward(*xs, *outs, *cells, *gates, *w_hhs)
-        ctx.enc, ctx.layer = enc, layer
+        ctx.enc, ctx.layer, ctx.parts = enc, layer, parts
         return tuple(outs)
 
     @staticmethod
@@ -650,7 +651,7 @@ class LstmMultiLayerFn(Function):
         Hs = enc.necks
         t = ctx.saved_tensors
         xs, outs, cells, gates, w_hhs = t[0:4], t[4:8], t[8:12], t[12:16], t[16:20]
-        dgps = ops.lstm_bidir_bwd_multi(douts, gates, cells, w_hhs, Hs)
+        dgps = ops.lstm_bidir_bwd_multi(douts, gates, cells, w_hhs, Hs, parts=ctx.parts)
         dxs, dx_calls, dx_slots = [], [], []
         for s in range(4):
             lstm = getattr(enc, f"lstm_{s + 1}")

@@ -59,8 +59,16 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t lds_
 
 }  // namespace
 
-template <bool Y16>
+// HT (round 6): MFMA row tiles per wave row -- the block covers H = 64 HT rows (256 or 192).  The LDS image, the DMA
+// pieces and the phase / vmcnt schedule are those of the 256-row tile; with HT = 3 the rows 96..127 of each wave row do not
+// exist (their DMA pieces carry the out-of-range offset: zero fill, no memory traffic) and phases 2 / 3 issue 4 MFMAs per
+// wave instead of 8.  Why: tile quantisation -- M = 42 336 rows x 512 columns (PostNet) is 332 tiles of 256 x 256 = 1.30
+// rounds of 256 CUs (paid as 2), but 442 tiles of 192 x 256 = 1.73 rounds of 3/4 the height (paid as 1.5); the 256-column
+// AudioEncoder convolutions are 166 tiles (0.65 of a round) against 221 (0.86 of a 3/4-height round).
+template <bool Y16, int HT>
 __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
+  static_assert(HT == 3 || HT == 4, "wave rows of 96 or 128 rows");
+  constexpr int H = 64 * HT, HW = 32 * HT;                               // block rows, rows per wave row
   __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];       // the ONLY LDS object of the kernel
 
   const int tid = threadIdx.x;
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
     ntile = k % a.nt;
   }
   const int64_t M = (int64_t)a.B * a.L;
-  const int64_t m0 = (int64_t)mtile * BM;
+  const int64_t m0 = (int64_t)mtile * H;
   const int n0 = ntile * BN;
   const int kw = a.kw, pad = a.pad;
   const int ktot = kw * a.cin;
@@ -103,12 +111,12 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
 
   // ---- tiles made only of rows at or past their item's length: zeros (packed rows: nothing behind the data is read) ----
   if (a.len) {
-    const uint32_t span = (uint32_t)((m0 + BM < M ? m0 + BM : M) - 1 - m0);
+    const uint32_t span = (uint32_t)((m0 + H < M ? m0 + H : M) - 1 - m0);
     const uint32_t b0 = (uint32_t)m0 / (uint32_t)a.L, t0 = (uint32_t)m0 - b0 * (uint32_t)a.L;
     if (t0 + span < (uint32_t)a.L && (int64_t)t0 >= a.len[b0]) {
       if (a.rowinfo) return;
       constexpr int QPR = BN / 4;
-      for (int i = tid; i < BM * QPR; i += 512) {
+      for (int i = tid; i < H * QPR; i += 512) {
         const int r = i / QPR, c = n0 + (i - r * QPR) * 4;
         if (m0 + r < M && c < a.n) {
           if (Y16) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.y) + (m0 + r) * a.ldy + c) = make_uint2(0u, 0u);
@@ -122,7 +130,8 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
 
   // ---- DMA source addresses.  A unit = 16 pieces of 1 KB (8 rows x 128 B); wave w issues pieces w and w + 8.  Lane l of
   // piece p: unit row i = 8 p + (l >> 3), physical 16-byte chunk l & 7 = logical chunk ^ ((i >> 1) & 7).
-  // UA0 row i -> tile row (i < 64 ? i : 128 + i - 64), UA1: + 64.  UB0 row i -> weight row (i >> 5) * 64 + (i & 31), UB1: + 32.
+  // UA0 row i -> row (i & 63) of wave row i >> 6 = tile row (i >> 6) * HW + (i & 63), UA1: + 64 (rows at or past HW do not
+  // exist: HT = 3).  UB0 row i -> weight row (i >> 5) * 64 + (i & 31), UB1: + 32.
   const __amdgpu_buffer_rsrc_t x_rs = [&] {
     int64_t rec = ((M - 1) * a.ldx + (a.x3n1 ? 2 * a.x3n1 * BK : a.cin)) * 2;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)(rec > 0x7fffffff ? 0x7fffffff : rec), 0x00020000);
@@ -141,10 +150,10 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
     const int cl = (lane & 7) ^ ((i >> 1) & 7);       // logical 16-byte chunk this lane fetches
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int trow = (i < 64 ? i : 64 + i) + 64 * u;
-      const int64_t m = m0 + trow;
+      const int wrow = (i & 63) + 64 * u;             // row inside its wave row
+      const int64_t m = m0 + (i >> 6) * HW + wrow;
       uint32_t bits = 0;
-      if (m < M) {
+      if (wrow < HW && m < M) {
         int t, rem;
         if (a.rowinfo) { const int2 ri = a.rowinfo[m]; t = ri.x; rem = ri.y; }
         else { t = (int)((uint32_t)m % (uint32_t)a.L); rem = a.L - 1 - t; }
@@ -186,9 +195,9 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
     rb[s] = (uint32_t)((wc * 32 + li) * 128) + ch;
   }
 
-  f32x16 acc[4][2];
+  f32x16 acc[HT][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < HT; ++i)
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -270,9 +279,9 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
     __builtin_amdgcn_s_setprio(0);
     PHASE_SYNC();
 
-    // ---------------- phase 2: rows 64..127 x cols 32..63 ----------------
+    // ---------------- phase 2: rows 64..127 (HT = 3: 64..95) x cols 32..63 ----------------
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < HT - 2; ++i)
 #pragma unroll
       for (int s = 0; s < 4; ++s) fa[i][s] = LDS_FRAG(st + U_A1 + i * 4096 + ra[s]);
     if (more) {
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[2 + i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb1[s], acc[2 + i][1], 0, 0, 0);
+      for (int i = 0; i < HT - 2; ++i) acc[2 + i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb1[s], acc[2 + i][1], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     PHASE_SYNC();
 
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[2 + i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fbc[s], acc[2 + i][0], 0, 0, 0);
+      for (int i = 0; i < HT - 2; ++i) acc[2 + i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fbc[s], acc[2 + i][0], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     PHASE_SYNC();
     cc = ccn; j = jn;
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
   const int c4 = (lane % LPR) * 4;
   const int col = n0 + wc * 64 + c4;
   const bool col_ok = col < a.n;
-  const int wrow0 = wr * 128 + lrow;                    // tile-relative row of this lane's first row
+  const int wrow0 = wr * HW + lrow;                     // tile-relative row of this lane's first row
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
   if (col_ok) {
     if (a.scale) sc = *reinterpret_cast<const float4*>(a.scale + col);
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
     live = 0u;
     if (a.B == 1) {
       const int64_t lim64 = a.len[0] - m0;
-      const int lim = lim64 > BM ? BM : (lim64 < 0 ? 0 : (int)lim64);
+      const int lim = lim64 > H ? H : (lim64 < 0 ? 0 : (int)lim64);
 #pragma unroll
       for (int q = 0; q < 32; ++q) live |= (uint32_t)(wrow0 + (q >> 3) * 32 + (q & 7) * RPP < lim) << q;
     } else {
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
   auto tail = [&](auto act_tag) {
     constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < HT; ++i) {
       if (i) __syncthreads();
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
@@ -550,20 +559,47 @@ extern "C" int styler_gemm256_policy(int split_mode, int take_all) {
   return prev;
 }
 
-static bool gemm256_eligible(int B, int L, int cin, int n, int kw, int64_t ldx, int x16, bool packed, int* mt_out, int* nt_out) {
+// Round 6: the tile HEIGHT is a dispatch decision too (HT = 4: 256 rows, HT = 3: 192 rows, see the kernel).  The 192-row
+// tile takes launches the 256-row bound turns away when they (a) have at least `g_min_tiles3` tiles of 192 x 256 and (b) fill
+// the rounds they occupy to >= 80 % (442 tiles = 1.73 rounds: 0.86; 221 tiles: 0.86 of one round), and launches of the 256-row
+// tile when rounds x (height + fixed cost) comes out lower.  STYLER_GEMM256_HT = 3 / 4 forces a height (0: this policy),
+// STYLER_GEMM256_MIN_TILES3 = 0 switches the 192-row tile off.
+static int g_ht = [] { const char* e = getenv("STYLER_GEMM256_HT"); return e ? atoi(e) : 0; }();
+static int g_min_tiles3 = [] { const char* e = getenv("STYLER_GEMM256_MIN_TILES3"); return e ? atoi(e) : 300; }();
+extern "C" int styler_gemm256_height(int ht, int min_tiles3) {       // test / tuning hook; returns the previous ht | min_tiles3 << 3
+  const int prev = g_ht | (g_min_tiles3 << 3);
+  if (ht == 0 || ht == 3 || ht == 4) g_ht = ht;
+  if (min_tiles3 >= 0) g_min_tiles3 = min_tiles3;
+  return prev;
+}
+
+static bool gemm256_eligible(int B, int L, int cin, int n, int kw, int64_t ldx, int x16, bool packed, int* mt_out, int* nt_out,
+                             int* ht_out = nullptr) {
   const int enabled = g_enabled, min_tiles = g_take_all ? 1 : (g_min_tiles > 1 ? g_min_tiles : 1);
   if (!enabled || !x16) return false;
   if ((cin % BK) || (ldx & 7) || (n & 3) || kw > 9) return false;
   const int64_t M = (int64_t)B * L;
-  const int mt = (int)((M + BM - 1) / BM), nt = (n + BN - 1) / BN;
-  // packed decoder rows: M is the row CAPACITY (B * T); the valid prefix is known on the device only and is ~64 % of it at
-  // VCTK shapes -- tiles behind the data exit at once, so the bound is applied to 60 % of the m-tiles
-  const int64_t mt_eff = packed ? (mt * 3 + 4) / 5 : mt;
-  if (mt_eff * nt < min_tiles) return false;
+  const int nt = (n + BN - 1) / BN;
   if (!g_take_all && (cin / BK) * kw < 8) return false;             // short K: prologue + epilogue dominate a 1-block-per-CU tile
   if ((n % BN) > 0 && (n % BN) < 192) return false;                // a mostly empty last column tile wastes its MFMAs
   if (((M + 8) * ldx * 2) >= ((int64_t)1 << 31) || ((int64_t)n * kw * cin * 2) >= ((int64_t)1 << 31)) return false;
-  *mt_out = mt; *nt_out = nt;
+  // packed decoder rows: M is the row CAPACITY (B * T); the valid prefix is known on the device only and is ~64 % of it at
+  // VCTK shapes -- tiles behind the data exit at once, so the bound is applied to 60 % of the m-tiles
+  auto tiles_of = [&](int h, int* mt) {
+    *mt = (int)((M + h - 1) / h);
+    return (packed ? ((int64_t)*mt * 3 + 4) / 5 : (int64_t)*mt) * nt;
+  };
+  int mt4, mt3;
+  const int64_t t4 = tiles_of(256, &mt4), t3 = tiles_of(192, &mt3);
+  const bool ok4 = t4 >= min_tiles && g_ht != 3;
+  const int64_t r3 = (t3 + 255) / 256;
+  const bool ok3 = g_ht != 4 && (g_ht == 3 ? t3 >= min_tiles || g_take_all
+                                           : g_min_tiles3 > 0 && t3 >= g_min_tiles3 && t3 * 5 >= r3 * 256 * 4);
+  if (!ok4 && !ok3) return false;
+  int ht = ok4 ? 4 : 3;
+  if (ok4 && ok3 && !g_ht && r3 * 7 < ((t4 + 255) / 256) * 9) ht = 3;      // rounds x (height + 0.5)
+  *mt_out = ht == 4 ? mt4 : mt3; *nt_out = nt;
+  if (ht_out) *ht_out = ht;
   return true;
 }
 
@@ -632,17 +668,23 @@ int styler_gemm256_try(const GemmArgs& a0, int x16, int y16, hipStream_t st, voi
     a.mt = (int)((M + BM - 1) / BM); a.nt = a0.n / BN;
     a.ksplit = ks; a.part = reinterpret_cast<float*>(ws);
     const dim3 grid((unsigned)(((a.mt + 7) / 8) * 8 * a.nt), (unsigned)ks);
-    hipLaunchKernelGGL(conv_gemm256_kernel<false>, grid, dim3(512), 0, st, a);
+    hipLaunchKernelGGL((conv_gemm256_kernel<false, 4>), grid, dim3(512), 0, st, a);
     int rc = launch_status();
     if (!rc) rc = styler_gemm_combine(a, ks, y16, st);
     return rc ? (rc < 0 ? rc : -rc) : 1;
   }
-  if (!gemm256_eligible(a0.B, a0.L, a0.cin, a0.n, a0.kw, a0.ldx, x16, a0.rowinfo != nullptr, &mt, &nt)) return 0;
+  int ht = 4;
+  if (!gemm256_eligible(a0.B, a0.L, a0.cin, a0.n, a0.kw, a0.ldx, x16, a0.rowinfo != nullptr, &mt, &nt, &ht)) return 0;
   GemmArgs a = a0;
   a.mt = mt; a.nt = nt;
   const dim3 grid((unsigned)(((mt + 7) / 8) * 8 * nt));
-  if (y16) hipLaunchKernelGGL(conv_gemm256_kernel<true>, grid, dim3(512), 0, st, a);
-  else hipLaunchKernelGGL(conv_gemm256_kernel<false>, grid, dim3(512), 0, st, a);
+  if (ht == 3) {
+    if (y16) hipLaunchKernelGGL((conv_gemm256_kernel<true, 3>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv_gemm256_kernel<false, 3>), grid, dim3(512), 0, st, a);
+  } else {
+    if (y16) hipLaunchKernelGGL((conv_gemm256_kernel<true, 4>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv_gemm256_kernel<false, 4>), grid, dim3(512), 0, st, a);
+  }
   const int rc = launch_status();
   return rc ? (rc < 0 ? rc : -rc) : 1;
 }

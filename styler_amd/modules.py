@@ -191,7 +191,7 @@ class AudioEncoder(_HipModule):
                                                              xs[s].shape[-1])
                     gxs.append(ops.conv_gemm(xs[s], w, bias, n=8 * self.necks[s], prec=prec))
                     w_hhs.append(w_hh)
-                xs = ops.lstm_bidir_multi(gxs, w_hhs, self.necks)
+                xs = ops.lstm_bidir_multi(gxs, w_hhs, self.necks, parts=rt.lstm_parts())
         return tuple(xs)
 
 

@@ -247,6 +247,7 @@ class GemmProfiler:
 
     def __init__(self):
         self.records = []          # (variant, flops, start_event, end_event, packed)
+        self.shapes = []           # per record: (B, L, cin, n, kw, io, act) -- tools/step_gemms.py
 
     def summary(self, packed_fraction=1.0):
         """`packed_fraction` = valid rows / row capacity of the packed decoder tensors: launches on packed rows are
@@ -568,6 +569,7 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
                                                           int(mask is not None)) if ws is not None or not (io & 1)
                              else lib.styler_conv_gemm_engine(B, L, cin, n, kw, prec, io, _ld(x), int(plan is not None)),
                              2.0 * B * L * n * kw * cin, e0, e1, plan is not None))
+        prof.shapes.append((B, L, cin, n, kw, io, act))
     return out
 
 
@@ -694,6 +696,13 @@ def gemm256_config(enabled=-1, min_tiles=-1, split=-1, take_all=-1):
     lib.styler_gemm256_config(int(enabled), int(min_tiles))
     lib.styler_gemm256_policy(int(split), int(take_all))
     return prev & 1, prev >> 1, pol & 3, pol >> 2
+
+
+def gemm256_height(ht=-1, min_tiles3=-1):
+    """Tile height of the 256-column LDS-DMA engine: ht 4 = 256 rows, 3 = 192 rows, 0 = per-launch policy (-1 keeps);
+    `min_tiles3`: smallest 192 x 256 tile count the policy hands to the 192-row tile.  Returns the previous (ht, min_tiles3)."""
+    prev = lib.styler_gemm256_height(int(ht), int(min_tiles3))
+    return prev & 7, prev >> 3
 
 
 def gemm_small_split_config(enabled=-1):
@@ -902,8 +911,9 @@ def lstm_bidir(gx, w_hh, H, cell_out=None, gates_out=None):
     return out
 
 
-def lstm_bidir_multi(gxs, w_hhs, Hs, save=False):
-    """Up to 4 independent BiLSTM layers in one launch.  Returns outs (and, with save=True, cells and gates)."""
+def lstm_bidir_multi(gxs, w_hhs, Hs, save=False, parts=0):
+    """Up to 4 independent BiLSTM layers in one launch.  Returns outs (and, with save=True, cells and gates).
+    `parts`: 0 = the VALU recurrence (fp32 arithmetic), 1 / 3 = the MFMA recurrence with bf16 / bf16x3 products (round 6)."""
     from ._lib import LstmDesc
     n = len(gxs)
     B, S, _ = gxs[0].shape
@@ -916,11 +926,14 @@ def lstm_bidir_multi(gxs, w_hhs, Hs, save=False):
         assert gxs[i].is_contiguous() and w_hhs[i].is_contiguous() and gxs[i].shape[2] == 8 * Hs[i]
         descs[i] = LstmDesc(gxs[i].data_ptr(), w_hhs[i].data_ptr(), outs[i].data_ptr(), _ptr(cells[i]), _ptr(gates[i]),
                             Hs[i], 0)
-    _chk(lib.styler_lstm_bidir_multi(descs, n, B, S, _stream()), "styler_lstm_bidir_multi")
+    if parts:
+        _chk(lib.styler_lstm_bidir_multi_mfma(descs, n, B, S, parts, _stream()), "styler_lstm_bidir_multi_mfma")
+    else:
+        _chk(lib.styler_lstm_bidir_multi(descs, n, B, S, _stream()), "styler_lstm_bidir_multi")
     return (outs, cells, gates) if save else outs
 
 
-def lstm_bidir_bwd_multi(douts, gates, cells, w_hhs, Hs):
+def lstm_bidir_bwd_multi(douts, gates, cells, w_hhs, Hs, parts=0):
     from ._lib import LstmBwdDesc
     n = len(douts)
     douts = [d.contiguous() for d in douts]
@@ -930,7 +943,10 @@ def lstm_bidir_bwd_multi(douts, gates, cells, w_hhs, Hs):
     for i in range(n):
         descs[i] = LstmBwdDesc(douts[i].data_ptr(), gates[i].data_ptr(), cells[i].data_ptr(), w_hhs[i].data_ptr(),
                                dgps[i].data_ptr(), Hs[i], 0)
-    _chk(lib.styler_lstm_bidir_bwd_multi(descs, n, B, S, _stream()), "styler_lstm_bidir_bwd_multi")
+    if parts:
+        _chk(lib.styler_lstm_bidir_bwd_multi_mfma(descs, n, B, S, parts, _stream()), "styler_lstm_bidir_bwd_multi_mfma")
+    else:
+        _chk(lib.styler_lstm_bidir_bwd_multi(descs, n, B, S, _stream()), "styler_lstm_bidir_bwd_multi")
     return dgps
 
 

@@ -46,6 +46,12 @@ class _Runtime:
     pred_stream = os.environ.get("STYLER_PRED_STREAM", "1") != "0"
     pred_stream_cls = os.environ.get("STYLER_PRED_STREAM_CLS", "1") != "0"     # ... the augmentation classifiers too
 
+    # Round 6: the BiLSTM recurrences (forward and BPTT) on the matrix cores in the bf16 / bf16x3 modes (csrc/lstm_mfma.hip: a
+    # block = 16 items of one (layer, direction), a step = v_mfma_f32_16x16x32_bf16 against W_hh fragments kept in registers; bf16x3:
+    # three products per product).  fp32 mode keeps the VALU kernels of csrc/lstm.hip.  STYLER_LSTM_MFMA=0: the VALU kernels in
+    # every mode (the round-5 path).
+    lstm_mfma = os.environ.get("STYLER_LSTM_MFMA", "1") != "0"
+
     # EXPERIMENT (round 5): on one rank, the decoder-side flush of the weight-gradient arena (grouped Linear gradients + the fold
     # of the split-K partials so far) on a side stream next to the rest of backward (training.TrainState.early_flush_on_side)
     early_flush = os.environ.get("STYLER_EARLY_FLUSH", "0") == "1"
@@ -125,6 +131,13 @@ class _Runtime:
         """The precision code of the C entry points that take one (STFT, DeepSpeaker, vocoder): bf16x3 is a host-level
         arithmetic of the Linear / Conv1d GEMMs of the model; those pipelines run their fp32 form in it."""
         return ops.PREC_F32 if self.prec == ops.PREC_BF16X3 else self.prec
+
+    def lstm_parts(self):
+        """0: the VALU recurrence kernels (fp32 arithmetic); 1 / 3: the MFMA kernels with bf16 / bf16x3 products."""
+        from . import ops
+        if not self.lstm_mfma or self.prec == ops.PREC_F32:
+            return 0
+        return 3 if self.prec == ops.PREC_BF16X3 else 1
 
     def set_precision(self, name):
         """fp32: exact-fp32 MFMA (parity mode); bf16: throughput mode (bf16 operands, bf16 activation storage); bf16x3: fp32-class

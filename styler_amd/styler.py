@@ -25,6 +25,21 @@ class STYLER(_HipModule):
             self.postnet = PostNet()
         self.clean_only = False
 
+    @property
+    def module(self):
+        """`nn.DataParallel(STYLER()).module` of the reference's callers (train.py:33,38-43,149-153; synthesize.py:62-63,116-128,
+        202,313; evaluate.py:20,97-101).  Data parallelism here is one process per GPU (styler_amd.dist), so the model is its
+        own replica: `model.module` is the model.  (Wrapping in a real `nn.DataParallel` works as well -- with the one visible
+        device of a rank it forwards straight to the module.)"""
+        return self
+
+    def load_state_dict(self, state_dict, strict=True, **kwargs):
+        """Also accepts the keys of a reference checkpoint, which carry the DataParallel wrapper's `module.` prefix
+        (train.py:54,222; synthesize.py:63: `model.load_state_dict(checkpoint['model'])`)."""
+        if state_dict and all(k.startswith("module.") for k in state_dict):
+            state_dict = type(state_dict)((k[len("module."):], v) for k, v in state_dict.items())
+        return super().load_state_dict(state_dict, strict=strict, **kwargs)
+
     def _lens_from_mask(self, mel_mask):
         return (~mel_mask).sum(dim=1).to(torch.int64)
 

@@ -37,6 +37,39 @@ def test_state_dict_layout_matches_reference_table():
     assert n_train == 29482701
 
 
+def test_dataparallel_call_sites_resolve_through_module():
+    """every attribute path the reference's callers reach through `nn.DataParallel(STYLER()).module` (train.py:33,
+    38-43,149-153; synthesize.py:62-63,116-128,171,195-197,202,313; evaluate.py:20,97-101) resolves on the bare model (its
+    own `.module`) and on a real `nn.DataParallel` wrapper, and a `module.`-prefixed reference checkpoint loads into both."""
+    import functools
+    from styler_amd import STYLER
+    paths = ["decode", "decoder", "style_modeling", "style_modeling.style_encoder.text_encoder",
+             "style_modeling.style_encoder.audio_encoder", "style_modeling.style_encoder.encoder_input_cat",
+             "style_modeling.style_encoder.speaker_linear", "style_modeling.style_encoder.speaker_linear_p",
+             "style_modeling.duration_predictor", "style_modeling.pitch_predictor", "style_modeling.energy_predictor",
+             "style_modeling.augmentation_classifier_d", "style_modeling.augmentation_classifier_p",
+             "style_modeling.augmentation_classifier_e", "style_modeling.predict_inference", "style_modeling.pitch_linear",
+             "style_modeling.length_regulator", "mel_linear", "postnet"]
+    bare = STYLER()
+    assert bare.module is bare and "module" not in dict(bare.named_children())
+    wrapped = torch.nn.DataParallel(STYLER())
+    for model in (bare, wrapped):
+        for p in paths:
+            obj = functools.reduce(getattr, p.split("."), model.module)
+            assert callable(obj), p
+        n = sum(q.numel() for q in model.module.decoder.parameters())      # utils.get_param_num (train.py:43)
+        assert n > 0
+    ref_sd = {"module." + k: torch.full_like(v, 3) if v.is_floating_point() else v.clone() for k, v in bare.state_dict().items()}
+    assert len(ref_sd) == 328
+    for model in (bare, wrapped):
+        res = model.load_state_dict(ref_sd)                                 # synthesize.py:63 / train.py:54
+        assert not res.missing_keys and not res.unexpected_keys
+        assert float(model.module.mel_linear.weight.min()) == 3.0
+    assert list(wrapped.state_dict()) == list(ref_sd)                       # train.py:222 writes these keys
+    assert list(bare.state_dict(prefix="module.")) == list(ref_sd)
+    bare.load_state_dict(bare.state_dict())                                 # bare keys still load
+
+
 def test_product_never_imports_oracle():
     bad = []
     for dirpath, _, files in os.walk(os.path.join(ROOT, "styler_amd")):

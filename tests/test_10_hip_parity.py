@@ -106,13 +106,14 @@ def _conv_ref64(x, w, kw, lens=None):
     return F.conv1d(x.double().transpose(1, 2), w.double(), None, padding=kw // 2).transpose(1, 2)
 
 
+@pytest.mark.parametrize("ht", [4, 3])
 @pytest.mark.parametrize("case", sorted(GEMM256_CASES))
-def test_gemm256_engine_vs_math_and_vs_128_engine(dev, case):
+def test_gemm256_engine_vs_math_and_vs_128_engine(dev, case, ht):
     """The 256 x 256 eight-wave LDS-DMA engine (csrc/gemm256.hip): (a) against fp64 math on the bf16-rounded operands,
     (b) bit for bit against the 128 x 128 engine (both accumulate the same v_mfma_f32_32x32x16_bf16 sequence), (c) the same
     bits on repeated launches (its LDS hand-offs are ordered by counted vmcnt + barriers: a race would show up as a
     flicker).  Conv taps at item boundaries, ragged lengths, rows past M inside a tile, a partial column tile, a single
-    K step, every epilogue input."""
+    K step, every epilogue input.  `ht`: the 256-row and the 192-row tile (round 6) -- same bits."""
     from styler_amd import ops
     B, L, cin, n, kw, lens, act, y16, with_res, with_mask = GEMM256_CASES[case]
     g = torch.Generator().manual_seed(sum(map(ord, case)))
@@ -139,6 +140,7 @@ def test_gemm256_engine_vs_math_and_vs_128_engine(dev, case):
                 out_bf16=y16)
     xd, bd = x16.to(dev), b.to(dev)
     prev = ops.gemm256_config(1, -1, split=1, take_all=1)
+    prev_h = ops.gemm256_height(ht)
     try:
         assert ops.lib.styler_conv_gemm_engine(B, L, cin, n, kw, ops.PREC_BF16, 1, cin, 0) == 4
         ys = [ops.conv_gemm(xd, wk, bd, **args).clone() for _ in range(4)]
@@ -151,6 +153,7 @@ def test_gemm256_engine_vs_math_and_vs_128_engine(dev, case):
             ops.gemm_small_split_config(prev_small)
     finally:
         ops.gemm256_config(*prev)
+        ops.gemm256_height(*prev_h)
     tol = 1e-2 if y16 else 1e-4                       # bf16 output: 2^-9 relative rounding of values up to ~4
     e = float((ys[0].double().cpu() - ref).abs().max()) / float(ref.abs().max())
     assert e <= tol, f"{case}: max err / max|ref| = {e:.3e}"
@@ -255,7 +258,8 @@ def test_gemm_small_split_k_vs_math_and_vs_unsplit(dev, case):
     assert d <= (8e-3 if y16 else 1e-5), f"{case}: split vs unsplit differ by {d:.3e} of the largest output"
 
 
-def test_gemm256_engine_packed_rows(dev):
+@pytest.mark.parametrize("ht", [4, 3])
+def test_gemm256_engine_packed_rows(dev, ht):
     """The engine on the decoder's packed-rows layout (ops.PackPlan): taps stop at item boundaries (rowinfo), tiles behind
     the data are skipped, rows at or past the device row counter are written as zeros."""
     from styler_amd import ops
@@ -269,6 +273,7 @@ def test_gemm256_engine_packed_rows(dev):
     xp = ops.pack_rows(xs.to(dev), plan).to(torch.bfloat16)
     wk = w16.permute(0, 2, 1).reshape(n, -1).contiguous().to(dev)
     prev = ops.gemm256_config(1, -1, split=1, take_all=1)
+    prev_h = ops.gemm256_height(ht)
     try:
         yp = [ops.conv_gemm(xp, wk, None, kw=kw, prec=ops.PREC_BF16, plan=plan).clone() for _ in range(3)]
         ops.gemm256_config(0)
@@ -279,6 +284,7 @@ def test_gemm256_engine_packed_rows(dev):
             ops.gemm_small_split_config(prev_small)
     finally:
         ops.gemm256_config(*prev)
+        ops.gemm256_height(*prev_h)
     nvalid = int(lens.sum())
     assert torch.equal(yp[0][:, :nvalid], y128[:, :nvalid]) and torch.equal(yp[0][:, :nvalid], yp[1][:, :nvalid]) \
         and torch.equal(yp[0][:, :nvalid], yp[2][:, :nvalid])

@@ -14,6 +14,8 @@ SHAPES = [  # name, B, L, cin, n, kw, y_bf16
     ("p_ffn_w1_k9 (C3 decoder, 424 tiles)", 1, 27060, 256, 1024, 9, True),
     ("s_postnet_512_k5 (C3, 332 tiles)", 96, 441, 512, 512, 5, False),
     ("s_aenc_256_k5 (C3, 166 tiles)", 96, 441, 256, 256, 5, False),
+    ("s_postnet_512_k5 bf16 out", 96, 441, 512, 512, 5, True),
+    ("s_aenc_256_k5 bf16 out", 96, 441, 256, 256, 5, True),
     ("p_dx_w1_k9 (C3, 106 tiles, K=9216)", 1, 27060, 1024, 256, 9, False),
     ("p_ffn_w2_k1 (C3, 106 tiles, K=1024)", 1, 27060, 1024, 256, 1, False),
     ("q_ffn_2x (848 tiles)", 1, 54120, 256, 1024, 9, True),
@@ -36,12 +38,14 @@ def main():
         y = torch.empty(B, L, n, device=dev, dtype=torch.bfloat16 if y16 else torch.float32)
         fl = 2.0 * B * L * n * kw * cin
         act = ops.ACT_NONE if "dx" in name else ops.ACT_RELU     # dX launches have a plain epilogue (and may run split-K)
-        res = {0: [], 1: []}
+        res = {0: [], 1: [], 2: []}
         prev = ops.gemm256_config(-1, -1)
+        prev_h = ops.gemm256_height(-1)
         try:
             for r in range(rounds):
-                for eng in (0, 1):
-                    ops.gemm256_config(eng, -1, split=1, take_all=1)
+                for eng in (0, 1, 2):                   # 128 x 128 | 256 x 256 | 192 x 256 (round 6)
+                    ops.gemm256_config(min(eng, 1), -1, split=1, take_all=1)
+                    ops.gemm256_height(3 if eng == 2 else 4)
                     for _ in range(2):
                         ops.conv_gemm(x, w, b, kw=kw, act=act, prec=ops.PREC_BF16, out=y)
                     iters = max(3, min(20, int(4e-3 / (fl / 0.9e15))))
@@ -54,9 +58,11 @@ def main():
                     res[eng].append(e0.elapsed_time(e1) * 1e3 / iters)
         finally:
             ops.gemm256_config(*prev)
+            ops.gemm256_height(*prev_h)
         m = {k: sorted(v)[len(v) // 2] for k, v in res.items()}
         print(f"{name:42s} M={B * L:7d} N={n:5d} K={kw * cin:5d}  128^2: {m[0]:9.1f} us {fl / m[0] / 1e6:7.1f} TF/s   "
-              f"256^2: {m[1]:9.1f} us {fl / m[1] / 1e6:7.1f} TF/s   x{m[0] / m[1]:.3f}", flush=True)
+              f"256^2: {m[1]:9.1f} us {fl / m[1] / 1e6:7.1f} TF/s x{m[0] / m[1]:.3f}   192x256: {m[2]:9.1f} us "
+              f"{fl / m[2] / 1e6:7.1f} TF/s x{m[0] / m[2]:.3f}", flush=True)
         del x, w, y
         torch.cuda.empty_cache()
 

@@ -29,6 +29,9 @@ def main():
     whs = [(torch.randn(2, 4 * H, H, generator=g) / H ** 0.5).to(dev) for H in Hs]
     t_multi = timeit(lambda: ops.lstm_bidir_multi(gxs, whs, Hs, save=True))
     print(f"forward, four LSTMs in one launch: {t_multi:.1f} us")
+    for parts in (1, 3):                     # round 6: the matrix-core recurrence (csrc/lstm_mfma.hip)
+        t = timeit(lambda: ops.lstm_bidir_multi(gxs, whs, Hs, save=True, parts=parts))
+        print(f"forward, four in one launch, MFMA parts = {parts}: {t:.1f} us")
     tot = 0.0
     for i, H in enumerate(Hs):
         gates = torch.empty(B, S, 8 * H, device=dev); cell = torch.empty(B, S, 2 * H, device=dev)
@@ -40,6 +43,9 @@ def main():
     douts = [torch.randn_like(o) for o in outs]
     t_bm = timeit(lambda: ops.lstm_bidir_bwd_multi(douts, gates, cells, whs, Hs))
     print(f"backward, four in one launch: {t_bm:.1f} us")
+    for parts in (1, 3):
+        t = timeit(lambda: ops.lstm_bidir_bwd_multi(douts, gates, cells, whs, Hs, parts=parts))
+        print(f"backward, four in one launch, MFMA parts = {parts}: {t:.1f} us")
     tot = 0.0
     for i, H in enumerate(Hs):
         t = timeit(lambda: ops.lstm_bidir_bwd(douts[i], gates[i], cells[i], whs[i], H))
