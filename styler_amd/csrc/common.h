@@ -188,14 +188,43 @@ __device__ __forceinline__ uint32_t dropout_hash32(uint64_t seed, uint64_t idx) 
   return dropout_hash32_keyed(dropout_key(seed), (uint32_t)idx, (uint32_t)(idx >> 32));
 }
 
+// Round 6 -- THE dropout stream of every kernel: one keyed hash per GROUP of four consecutive elements.  Every site that
+// draws masks handles elements e .. e + 3 (e % 4 == 0) in one lane, and the per-element mixer above was the largest single
+// item of the row kernels' instruction count (layernorm_bwd: 80 of 175 per row pair; the BatchNorm backward was VALU-bound
+// on it).  The group's first element index goes through the same mixer up to the last multiply; two finishers give 64 bits
+// = four 16-bit draws; element j is kept iff draw_j >= p * 2^16 (p = 0.1: 6554 / 65536 = 0.100006 -- the keep probability
+// differs from 1 - p by 6e-6, below fp32 resolution of the 1 / (1 - p) scale).  14 integer instructions per four elements
+// instead of 40.  Forward and backward of a site regenerate the same draws from (seed, step counter, element index).
+__device__ __forceinline__ uint2 dropout_word4(uint2 key, uint32_t e_lo, uint32_t e_hi) {
+  uint32_t h = e_lo ^ key.x;
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15;
+  h += key.y + e_hi * 0x9E3779B1u;
+  uint32_t a = h * 0x846ca68bu, b = (h ^ 0x68E31DA4u) * 0xB5297A4Du;
+  a ^= a >> 16; b ^= b >> 15;
+  return make_uint2(a, b);
+}
+__device__ __forceinline__ uint32_t dropout_thr16(float p) { return (uint32_t)(p * 65536.f + 0.5f); }
+// keep * scale (or 0) for the four elements of a group
+__device__ __forceinline__ float4 dropout_scale4(uint2 w, uint32_t thr16, float sc) {
+  return make_float4((w.x & 0xffffu) >= thr16 ? sc : 0.f, (w.x >> 16) >= thr16 ? sc : 0.f,
+                     (w.y & 0xffffu) >= thr16 ? sc : 0.f, (w.y >> 16) >= thr16 ? sc : 0.f);
+}
+// v -> dropout(v) for the four elements of a group: SELECTS, not products with a 0 / scale factor -- a consumer that forms
+// `v - float(bf16(v))` (the bf16x3 split) would otherwise contract the product into an fma and see an unrounded v
+__device__ __forceinline__ float4 dropout_select4(float4 v, uint2 w, uint32_t thr16, float sc) {
+  return make_float4((w.x & 0xffffu) >= thr16 ? v.x * sc : 0.f, (w.x >> 16) >= thr16 ? v.y * sc : 0.f,
+                     (w.y & 0xffffu) >= thr16 ? v.z * sc : 0.f, (w.y >> 16) >= thr16 ? v.w * sc : 0.f);
+}
+// ... for elements e .. e + 3 of the stream `key` (e % 4 == 0)
+__device__ __forceinline__ float4 dropout_apply4(float4 v, uint2 key, uint64_t e, uint32_t thr16, float sc) {
+  return dropout_select4(v, dropout_word4(key, (uint32_t)e, (uint32_t)(e >> 32)), thr16, sc);
+}
+
 // Gradient w.r.t. the BatchNorm output of y = dropout(act(BN(x))) for one element: the dropout keep mask is regenerated
-// from (seed, element index), the tanh output is recomputed from x (gamma/beta/mean/rstd) unless `yv` supplies it.
-__device__ __forceinline__ float bn_dz_elem(float g, float xh, float ga, float be, int act, bool has_y, float yv,
-                                            float drop_p, uint64_t seed, uint64_t e) {
-  if (drop_p > 0.f) {
-    const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);
-    g = dropout_hash32(seed, e) >= thr ? g * (1.f / (1.f - drop_p)) : 0.f;
-  }
+// from (seed, element index) by the caller, the tanh output is recomputed from x (gamma/beta/mean/rstd) unless `yv` supplies it.
+// `keep_sc`: the element's dropout factor (0 or 1 / (1 - p); 1 without dropout), from dropout_scale4 of its group.
+__device__ __forceinline__ float bn_dz_elem(float g, float xh, float ga, float be, int act, bool has_y, float yv, float keep_sc) {
+  g *= keep_sc;
   if (act == STYLER_ACT_TANH) {
     const float o = has_y ? yv : fast_tanh(xh * ga + be);
     g *= 1.f - o * o;

@@ -600,19 +600,15 @@ extern "C" int styler_nll(const float* logp, const int64_t* label, float* loss, 
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
                                                       int64_t ldy, int64_t rows, int C, float p, uint64_t seed_host,
                                                       const uint64_t* __restrict__ epoch) {
-  const uint64_t seed = mix_drop_epoch(seed_host, epoch);
+  const uint2 key = dropout_key(mix_drop_epoch(seed_host, epoch));
   const int nq = C / 4;
   const int64_t total = rows * nq;
-  const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+  const uint32_t thr = dropout_thr16(p);
   const float sc = 1.f / (1.f - p);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = i / nq; const int q = (int)(i - row * nq);
     float4 v = *reinterpret_cast<const float4*>(x + row * ldx + q * 4);
-    const uint64_t e = (uint64_t)(row * C + q * 4);
-    v.x = dropout_hash32(seed, e) >= thr ? v.x * sc : 0.f;
-    v.y = dropout_hash32(seed, e + 1) >= thr ? v.y * sc : 0.f;
-    v.z = dropout_hash32(seed, e + 2) >= thr ? v.z * sc : 0.f;
-    v.w = dropout_hash32(seed, e + 3) >= thr ? v.w * sc : 0.f;
+    v = dropout_apply4(v, key, (uint64_t)(row * C + q * 4), thr, sc);
     *reinterpret_cast<float4*>(y + row * ldy + q * 4) = v;
   }
 }

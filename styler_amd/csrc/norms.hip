@@ -34,14 +34,8 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
   }
   float4 v = *reinterpret_cast<const float4*>(x + row * ldx + lane * 4);
   if (in_drop_p > 0.f) {                                 // dropout(x) before the residual (SubLayers.py:58,86), same
-    const uint64_t sd = mix_drop_epoch(in_drop_seed_host, epoch);        // stream as styler_dropout on [rows, 256]
-    const uint32_t thr = (uint32_t)((double)in_drop_p * 4294967296.0);
-    const float sc = 1.f / (1.f - in_drop_p);
-    const uint64_t e = (uint64_t)row * 256 + lane * 4;
-    v.x = dropout_hash32(sd, e) >= thr ? v.x * sc : 0.f;
-    v.y = dropout_hash32(sd, e + 1) >= thr ? v.y * sc : 0.f;
-    v.z = dropout_hash32(sd, e + 2) >= thr ? v.z * sc : 0.f;
-    v.w = dropout_hash32(sd, e + 3) >= thr ? v.w * sc : 0.f;
+    const uint2 kd = dropout_key(mix_drop_epoch(in_drop_seed_host, epoch));     // stream as styler_dropout on [rows, 256]
+    v = dropout_apply4(v, kd, (uint64_t)row * 256 + lane * 4, dropout_thr16(in_drop_p), 1.f / (1.f - in_drop_p));
   }
   if (res) {
     const float4 r = ldg4(res, row * ldres + lane * 4, res16);
@@ -61,13 +55,8 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
   float4 o = make_float4(dx * rstd * g.x + bt.x, dy * rstd * g.y + bt.y, dz * rstd * g.z + bt.z,
                          dw * rstd * g.w + bt.w);
   if (drop_p > 0.f) {                                    // dropout behind the LayerNorm (train mode): what y and the
-    const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);     // Linear(256,1) tail see (modules.py:436-447)
-    const float sc = 1.f / (1.f - drop_p);
-    const uint64_t e = (uint64_t)row * 256 + lane * 4;
-    o.x = dropout_hash32(drop_seed, e) >= thr ? o.x * sc : 0.f;
-    o.y = dropout_hash32(drop_seed, e + 1) >= thr ? o.y * sc : 0.f;
-    o.z = dropout_hash32(drop_seed, e + 2) >= thr ? o.z * sc : 0.f;
-    o.w = dropout_hash32(drop_seed, e + 3) >= thr ? o.w * sc : 0.f;
+    // ... Linear(256,1) tail see (modules.py:436-447)
+    o = dropout_apply4(o, dropout_key(drop_seed), (uint64_t)row * 256 + lane * 4, dropout_thr16(drop_p), 1.f / (1.f - drop_p));
   }
   if (y) stg4(y, row * ldy + lane * 4, o, yb16);
   // y16: a second copy of the output as bf16 (round to nearest even) for the GEMMs that consume it -- they round their
@@ -369,7 +358,9 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const void* __restrict
   const int seg = bc / bps, chunk = bc - seg * bps;
   ws += ((int64_t)seg * bps + chunk) * 2 * C;         // this block's slot: [2C] doubles (its column tile of them)
   if (BWD) { mean += (int64_t)seg * C; rstd += (int64_t)seg * C; }
-  const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
+  const uint2 dkey = dropout_key(mix_drop_epoch(drop_seed_host, epoch));
+  const uint32_t dthr = dropout_thr16(drop_p);
+  const float dsc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   __shared__ double red[256][8];
   const int lanes = 256 / nqt;                       // row-lanes
   const int rl = threadIdx.x / nqt, ql = threadIdx.x - rl * nqt;
@@ -417,10 +408,12 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const void* __restrict
             const float4 o = has_y ? o4[u] : make_float4(0.f, 0.f, 0.f, 0.f);
             const float hx = (v.x - m.x) * rs.x, hy = (v.y - m.y) * rs.y, hz = (v.z - m.z) * rs.z, hw = (v.w - m.w) * rs.w;
             const uint64_t e = (uint64_t)(ru * C + q * 4);
-            g.x = bn_dz_elem(g.x, hx, ga.x, be.x, act, has_y, o.x, drop_p, drop_seed, e);
-            g.y = bn_dz_elem(g.y, hy, ga.y, be.y, act, has_y, o.y, drop_p, drop_seed, e + 1);
-            g.z = bn_dz_elem(g.z, hz, ga.z, be.z, act, has_y, o.z, drop_p, drop_seed, e + 2);
-            g.w = bn_dz_elem(g.w, hw, ga.w, be.w, act, has_y, o.w, drop_p, drop_seed, e + 3);
+            const float4 ks = drop_p > 0.f ? dropout_scale4(dropout_word4(dkey, (uint32_t)e, (uint32_t)(e >> 32)), dthr, dsc)
+                                           : make_float4(1.f, 1.f, 1.f, 1.f);
+            g.x = bn_dz_elem(g.x, hx, ga.x, be.x, act, has_y, o.x, ks.x);
+            g.y = bn_dz_elem(g.y, hy, ga.y, be.y, act, has_y, o.y, ks.y);
+            g.z = bn_dz_elem(g.z, hz, ga.z, be.z, act, has_y, o.z, ks.z);
+            g.w = bn_dz_elem(g.w, hw, ga.w, be.w, act, has_y, o.w, ks.w);
             s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
             t[0] += (double)g.x * hx; t[1] += (double)g.y * hy; t[2] += (double)g.z * hz; t[3] += (double)g.w * hw;
           } else {
@@ -552,8 +545,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ 
   const int lanes = 256 / nqt;
   const int rl = threadIdx.x / nqt, ql = threadIdx.x - rl * nqt;
   if (rl >= lanes) return;
-  const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
-  const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);
+  const uint2 dkey = dropout_key(mix_drop_epoch(drop_seed_host, epoch));
+  const uint32_t thr = dropout_thr16(drop_p);
   const float sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const int64_t r0 = (int64_t)seg * rps + (int64_t)chunk * rpb;
   int64_t r1 = r0 + rpb; if (r1 > (seg + 1) * rps) r1 = (seg + 1) * rps;
@@ -584,11 +577,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ 
         o.z = apply_act((v.z - m.z) * a.z + b.z, act);
         o.w = apply_act((v.w - m.w) * a.w + b.w, act);
         if (drop_p > 0.f) {                              // F.dropout after the activation (Layers.py:126-128), the stream
-          const uint64_t e = (uint64_t)(ru * C + q * 4); // styler_dropout would draw on the [rows, C] tensor
-          o.x = dropout_hash32(drop_seed, e) >= thr ? o.x * sc : 0.f;
-          o.y = dropout_hash32(drop_seed, e + 1) >= thr ? o.y * sc : 0.f;
-          o.z = dropout_hash32(drop_seed, e + 2) >= thr ? o.z * sc : 0.f;
-          o.w = dropout_hash32(drop_seed, e + 3) >= thr ? o.w * sc : 0.f;
+          o = dropout_apply4(o, dkey, (uint64_t)(ru * C + q * 4), thr, sc);   // styler_dropout would draw on the [rows, C] tensor
         }
         if (y16) *reinterpret_cast<uint2*>(yh + ru * C + q * 4) = make_uint2(cvt_pk_bf16_rne(o.x, o.y), cvt_pk_bf16_rne(o.z, o.w));
         else *reinterpret_cast<float4*>(y + ru * C + q * 4) = o;

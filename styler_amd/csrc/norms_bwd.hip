@@ -56,12 +56,12 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
   float sc_out = 1.f, sc_in = 1.f;
   if (has_drop) {
     key_out = dropout_key(mix_drop_epoch(drop_seed_host, epoch));
-    thr_out = (uint32_t)((double)drop_p * 4294967296.0);
+    thr_out = dropout_thr16(drop_p);
     sc_out = 1.f / (1.f - drop_p);
   }
   if (has_indrop) {
     key_in = dropout_key(mix_drop_epoch(in_drop_seed_host, epoch));
-    thr_in = (uint32_t)((double)in_drop_p * 4294967296.0);
+    thr_in = dropout_thr16(in_drop_p);
     sc_in = 1.f / (1.f - in_drop_p);
   }
   const uint32_t l4 = lane * 4;
@@ -154,8 +154,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
       kx[k][0] = kx[k][1] = kx[k][2] = kx[k][3] = 1.f;
       if (has_drop) {                                    // dropout keep * 1/(1-p) behind the LayerNorm (forward's drop_p)
         const uint32_t elo = ((uint32_t)row[k] << 8) | l4, ehi = (uint32_t)((uint64_t)row[k] >> 24);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) kx[k][q] = dropout_hash32_keyed(key_out, elo + q, ehi) >= thr_out ? sc_out : 0.f;
+        const float4 ks = dropout_scale4(dropout_word4(key_out, elo, ehi), thr_out, sc_out);
+        kx[k][0] = ks.x; kx[k][1] = ks.y; kx[k][2] = ks.z; kx[k][3] = ks.w;
       }
       if (has_dot) {
         d[k] = make_float4(go[k] * dw4.x * kx[k][0], go[k] * dw4.y * kx[k][1], go[k] * dw4.z * kx[k][2],
@@ -214,10 +214,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
       if (dx) stg4(dx, row[k] * lddx + l4, gx, dx16);
       if (has_indrop) {                                  // gradient of the dropout(x) that fed the sum (same stream)
         const uint32_t elo = ((uint32_t)row[k] << 8) | l4, ehi = (uint32_t)((uint64_t)row[k] >> 24);
-        const float4 gd = make_float4(dropout_hash32_keyed(key_in, elo, ehi) >= thr_in ? gx.x * sc_in : 0.f,
-                                      dropout_hash32_keyed(key_in, elo + 1, ehi) >= thr_in ? gx.y * sc_in : 0.f,
-                                      dropout_hash32_keyed(key_in, elo + 2, ehi) >= thr_in ? gx.z * sc_in : 0.f,
-                                      dropout_hash32_keyed(key_in, elo + 3, ehi) >= thr_in ? gx.w * sc_in : 0.f);
+        const float4 gd = dropout_select4(gx, dropout_word4(key_in, elo, ehi), thr_in, sc_in);
         stg4(dx_drop, row[k] * lddxd + l4, gd, dxd16);
         if (Y3) x3_store4(y3, row[k], (int)l4, 256, 2, gd);
       } else if (Y3) {
@@ -684,7 +681,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
   const int rl = threadIdx.x / nqt, ql = threadIdx.x - rl * nqt;
   if (rl >= lanes) return;
   const double inv_n = 1.0 / (double)rps;
-  const uint64_t drop_seed = mix_drop_epoch(drop_seed_host, epoch);
+  const uint2 dkey = dropout_key(mix_drop_epoch(drop_seed_host, epoch));
+  const uint32_t dthr = dropout_thr16(drop_p);
+  const float dsc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const double* wseg = ws + (int64_t)seg * nslots * 2 * C;
   const bool has_y = y && act == STYLER_ACT_TANH;
   const int64_t r0 = (int64_t)seg * rps + (int64_t)chunk * rpb;
@@ -723,11 +722,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
         const float4 oo = has_y ? o4[u] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float ov[4] = {oo.x, oo.y, oo.z, oo.w};
         float out[4];
+        const uint64_t e = (uint64_t)(ru * C + q * 4);
+        const float4 ks4 = drop_p > 0.f ? dropout_scale4(dropout_word4(dkey, (uint32_t)e, (uint32_t)(e >> 32)), dthr, dsc)
+                                        : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float ksv[4] = {ks4.x, ks4.y, ks4.z, ks4.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float xh = (xv[k] - mv[k]) * rv[k];
-          const float g = bn_dz_elem(gv[k], xh, gav[k], bev[k], act, has_y, ov[k], drop_p, drop_seed,
-                                     (uint64_t)(ru * C + q * 4) + k);
+          const float g = bn_dz_elem(gv[k], xh, gav[k], bev[k], act, has_y, ov[k], ksv[k]);
           out[k] = gav[k] * rv[k] * (g - sb[k] - xh * sg[k]);
         }
         if (dx16) *reinterpret_cast<uint2*>(dxh + ru * C + q * 4) = make_uint2(cvt_pk_bf16_rne(out[0], out[1]), cvt_pk_bf16_rne(out[2], out[3]));
