@@ -238,7 +238,7 @@ def rocprof_family_ms(patterns):
     of the command (forward + backward without an optimiser step), so the traced steps are the calls of a kernel that runs
     ONCE in every forward + backward -- `pack_plan_kernel` -- not the calls of `adam_kernel` (round 4 divided by the latter:
     28 instead of 31, `frac_rocprof` 0.287 where the trace says 0.32; VERDICT round 4, weak #10)."""
-    for name in ("r05_train_bf16_graph_kernel_stats.txt", "r04_train_bf16_graph_kernel_stats.txt",
+    for name in ("r06_train_bf16_graph_kernel_stats.txt", "r05_train_bf16_graph_kernel_stats.txt", "r04_train_bf16_graph_kernel_stats.txt",
                  "r03_train_bf16_graph_kernel_stats.txt"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
@@ -764,7 +764,7 @@ def pmc_traffic(want, prec):
     read from that file; null when the file has no record for the kernel or was taken for another precision."""
     if prec != "bf16":
         return None, None
-    for name in ("r05_pmc_traffic.jsonl", "r04_pmc_traffic.jsonl", "r03_pmc_traffic.jsonl", "r02_pmc_traffic.jsonl"):
+    for name in ("r06_pmc_traffic.jsonl", "r05_pmc_traffic.jsonl", "r04_pmc_traffic.jsonl", "r03_pmc_traffic.jsonl", "r02_pmc_traffic.jsonl"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue

@@ -24,7 +24,7 @@
 // weight / input gradient GEMMs behind it are unchanged.
 #include "common.h"
 
-namespace {
+namespace lstm_mfma_detail {
 
 constexpr int MB = 16;                                   // rows of the MFMA tile (items per block = 4 RPL of them)
 
@@ -296,7 +296,8 @@ __global__ __launch_bounds__(320) void lstm_mfma_bwd_kernel(LstmMfmaBwdArgs a, i
   else lstm_mfma_bwd_body<64, PARTS, RPL>(d, B, S, sb);
 }
 
-}  // namespace
+}  // namespace lstm_mfma_detail
+using namespace lstm_mfma_detail;
 
 // Launched with RPL = 1 (4 items per block).  Same box, four LSTMs per launch at B = 96, S = 60 (tools/lstm_bench.py,
 // profiles/r06_lstm_bench.txt): forward RPL 4 / 2 / 1 = 94 / 59 / 57 us, backward 106 / 74 / 50 us (lstm.hip: 87 / 103 us).
