@@ -203,6 +203,13 @@ def run(args, mode, prec, rank, world, dev, dist, with_cpu=True, with_roofline=T
         ar = state.allreduce_info()
         if world > 1:                               # what a gradient all-reduce costs on this job's links (after the timed
             from styler_amd.dist import allreduce_preflight      # region: it must not perturb the measurement)
+            # ... and where the step's own all-reduce sits: five extra steps with events around the collective waits
+            state.ar_events = []
+            for _ in range(5):
+                go()
+            torch.cuda.synchronize()
+            ar["allreduce_step_timing"] = state.allreduce_timing()
+            state.ar_events = None
             ar["allreduce_preflight"] = allreduce_preflight(dev)
         state.close()
     if rank != 0:
@@ -689,6 +696,19 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if dist is not None and world > 1:
+        # Fail LOUDLY before anything is timed unless every rank of the job is there on the expected transport: a 1-element SUM
+        # all-reduce must count `world` ranks, on RCCL (backend "nccl") unless the shared-GPU test hook asked for gloo.  A job that
+        # silently ran on fewer ranks, or on a fallback backend, would print a scaling number that means nothing.
+        want = "gloo" if os.environ.get("STYLER_TEST_SHARED_GPU") else "nccl"
+        if dist.get_backend() != want:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: process group backend is {dist.get_backend()!r}, expected {want!r}")
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)
+        torch.cuda.synchronize()
+        if int(seen.item()) != world or world != args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: the rank-count all-reduce saw {int(seen.item())} ranks "
+                             f"(WORLD_SIZE={world}); refusing to time a partial job")
 
     main_res = run(args, args.mode, args.prec, rank, world, dev, dist)
     aux = {}
@@ -778,59 +798,87 @@ def pmc_traffic(want, prec):
     return None, None
 
 
-def cpu_baseline(model, batch, S, T, clean_only, sample_items=16, thread_counts=(16, 32, 64), train=False):
-    """The oracle (kind "port": plain PyTorch-CPU eager fp32 restatement of the reference) on a bounded sample of the same
-    workload: the first `sample_items` utterances of the batch, re-padded to their own max lengths.  Train mode times one
-    full pass = forward (both decodes) + DAT pass + ten losses + backward (no optimiser update).  Several intra-op thread
-    counts are tried (about 8 s each: torch's pool stops scaling on these small per-op shapes well before the host's core
-    count); the best one is reported as `value` / `cores`, all of them in `sample`."""
+def cpu_baseline(model, batch, S, T, clean_only, thread_counts=(8, 16, 32), train=False, passes=5, budget_s=75.0):
+    """The oracle (kind "port": plain PyTorch-CPU eager fp32 restatement of the reference) on the BENCH BATCH itself, timed on
+    this host's cores as BASELINE.md section 3 lays out: both figures -- the eval forward (teacher-forced; dual-branch unless the
+    config is clean-only) and the full train step = forward (both decodes) + DAT pass + ten losses + backward +
+    clip_grad_norm_(1.0) + Adam (train.py:135-186) -- each as the MEDIAN of `passes` timed passes behind one warm-up pass.
+    The intra-op thread count is probed first on a small sample (torch's pool stops scaling on these per-op shapes well
+    before the core count of a 256-core host); `cores` = the threads the measurement used.  `value` is the figure of the
+    headline workload (train step in train mode, else the forward).  A wall-clock budget bounds the leg: if a pass is slower
+    than expected the pass count drops (never below 3) and `sample` says so."""
     from oracle import styler_oracle as O
-    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    n_items = min(sample_items, batch["text"].shape[0])
-    sb = {k: v[:n_items] for k, v in batch.items()}
-    S2, T2 = int(sb["src_len"].max()), int(sb["mel_len"].max())
-    for k in ("text", "D", "log_D"):
-        sb[k] = sb[k][:, :S2]
-    for k in ("mel_target", "mel_aug", "f0", "f0_norm", "f0_norm_aug", "energy", "energy_input", "energy_input_aug"):
-        sb[k] = sb[k][:, :T2]
+    import statistics
+    t_leg = time.perf_counter()
+    sd0 = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    sb = {k: v.detach().cpu() for k, v in batch.items()}
     frames = int(sb["mel_len"].sum())
+    n_items = int(sb["text"].shape[0])
 
-    if train:
-        sd = {k: (v.requires_grad_(True) if v.is_floating_point() and "position_enc" not in k and "_bins" not in k
-                  and "running_" not in k else v) for k, v in sd.items()}
-
-    def run():
-        if train:
-            for v in sd.values():
-                v.grad = None
-            O.train_losses(sd, sb, training=True)[0].backward()
-            return
+    def fwd(b, S_, T_):
         with torch.no_grad():
-            O.styler_forward(sd, sb["text"], sb["mel_target"], sb["mel_aug"], sb["f0_norm"], sb["energy_input"],
-                             sb["src_len"], sb["mel_len"], sb["D"], sb["f0"], sb["energy"], S2, T2,
-                             speaker_embed=sb["speaker_embed"], noisy_branch=not clean_only)
+            O.styler_forward(sd0, b["text"], b["mel_target"], b["mel_aug"], b["f0_norm"], b["energy_input"], b["src_len"],
+                             b["mel_len"], b["D"], b["f0"], b["energy"], S_, T_, speaker_embed=b["speaker_embed"],
+                             noisy_branch=not clean_only)
 
-    results = []
+    # ---- thread-count probe: one forward of the first 8 utterances per candidate (after one untimed call)
     ncpu = os.cpu_count() or 1
+    k = min(8, n_items)
+    pb = {key: v[:k] for key, v in sb.items()}
+    S2, T2 = int(pb["src_len"].max()), int(pb["mel_len"].max())
+    for key in ("text", "D", "log_D"):
+        pb[key] = pb[key][:, :S2]
+    for key in ("mel_target", "mel_aug", "f0", "f0_norm", "f0_norm_aug", "energy", "energy_input", "energy_input_aug"):
+        pb[key] = pb[key][:, :T2]
+    probe = []
     for threads in sorted({min(t, ncpu) for t in thread_counts}):
         torch.set_num_threads(threads)
+        fwd(pb, S2, T2)
         t0 = time.perf_counter()
-        run()
-        warm = time.perf_counter() - t0
-        n, t0 = 0, time.perf_counter()
-        while n < 4 and (time.perf_counter() - t0) + warm < 8.0:
-            run()
-            n += 1
-        dt = (time.perf_counter() - t0) / n if n else warm
-        results.append((frames / dt, threads, dt, max(n, 1)))
-        if warm > 8.0:                          # the pool has collapsed: more threads will not help
-            break
-    best = max(results)
-    what = "pass(es) of forward + DAT pass + 10 losses + backward" if train else "forward(s)"
-    tried = "; ".join(f"{t} threads: {d:.2f} s/pass ({v:.0f} frames/s)" for v, t, d, _ in results)
-    return {"value": round(best[0], 1), "unit": "valid mel-frames/s", "cores": best[1], "kind": "port",
-            "sample": f"first {n_items} utterances of the batch ({frames} valid frames), {best[3]} timed {what} per thread "
-                      f"count, torch {torch.__version__} CPU fp32 on a {ncpu}-core host; {tried}"}
+        fwd(pb, S2, T2)
+        probe.append((time.perf_counter() - t0, threads))
+    threads = min(probe)[1]
+    torch.set_num_threads(threads)
+
+    def timed(fn, n, deadline):
+        fn()                                             # warm-up pass
+        ts = []
+        for i in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+            if i + 1 >= 3 and time.perf_counter() + ts[-1] > deadline:
+                break
+        return statistics.median(ts), len(ts)
+
+    res = {}
+    dt, n = timed(lambda: fwd(sb, S, T), passes, t_leg + (0.3 if train else 1.0) * budget_s)
+    res["fwd"] = {"value": round(frames / dt, 1), "s_per_pass": round(dt, 3), "timed_passes": n,
+                  "what": f"eval forward, teacher-forced, {'clean' if clean_only else 'dual'}-branch"}
+    if train:
+        sd = {key: (v.clone().requires_grad_(True) if v.is_floating_point() and "position_enc" not in key and "_bins" not in key
+                    and "running_" not in key else v) for key, v in sd0.items()}
+        params = [v for v in sd.values() if v.requires_grad]
+        import styler_amd.hparams as hp
+        opt = torch.optim.Adam(params, lr=1e-4, betas=hp.betas, eps=hp.eps, weight_decay=hp.weight_decay)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            O.train_losses(sd, sb, training=True)[0].backward()
+            torch.nn.utils.clip_grad_norm_(params, hp.grad_clip_thresh)
+            opt.step()
+
+        dt, n = timed(step, passes, t_leg + budget_s)
+        res["train"] = {"value": round(frames / dt, 1), "s_per_pass": round(dt, 3), "timed_passes": n,
+                        "what": "forward (both decodes) + DAT pass + 10 losses + backward + clip_grad_norm_ + Adam"}
+    head = res["train" if train else "fwd"]
+    tried = "; ".join(f"{t} threads {d * 1e3:.0f} ms" for d, t in sorted(probe, key=lambda x: x[1]))
+    out = {"value": head["value"], "unit": "valid mel-frames/s", "cores": threads, "kind": "port",
+           "sample": (f"the bench batch itself: {n_items} utterances, {frames} valid frames; 1 warm-up + {head['timed_passes']} timed "
+                      f"passes, median; torch {torch.__version__} CPU fp32, {threads} intra-op threads on a {ncpu}-core host "
+                      f"(probe, one forward of the first {k} utterances: {tried}); leg took {time.perf_counter() - t_leg:.0f} s")}
+    out.update(res)
+    return out
 
 
 if __name__ == "__main__":

@@ -598,6 +598,12 @@ int styler_wgrad_dma_config(int mode, int stages128);
  *     tiles of 64 x 64 (the PostNet's 512 -> 512 convolutions: 128.6 -> 115.2 us per launch) on a
  *     128 (n) x 64 (c) x 5 taps block tile instead of 64 x 64 x 5 (fewer operand bytes per MFMA; the split plan changes with it,
  *     so query the workspace / split count with the _io forms AFTER setting the knob).
+ *     Value 2 (test-only): the tall tile for EVERY eligible k = 5 gradient, whatever its tile count.
+ *   knob 2 (default 0 -- measured: k = 9 122 -> 128 us, no gain; env STYLER_WGRAD_RING4): EXPERIMENT, a ring of four
+ *     stages instead of three in the LDS-DMA kernels.  Same partial tiles.
+ * A caller that flips knob 1 between steps must re-plan: the split counts and workspace bytes of the affected launches
+ * change, so sizes cached from the _io queries (styler_amd.ops.wgrad_tune resets WgradArena's sizing and descriptor tables; a
+ * captured hipGraph must be re-captured).
  * (autograd of transformer/SubLayers.py:72-76, transformer/Layers.py:78-118) */
 int styler_wgrad_tune(int knob, int value);
 int styler_wgrad_x3cat_ok(int n, int cin, int kw, int pad_left);

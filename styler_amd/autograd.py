@@ -452,7 +452,7 @@ class ConvNormCatFn(Function):
     @staticmethod
     def forward(ctx, cache, keys, norms, *flat):
         xs, ws, bs = flat[0::3], flat[1::3], flat[2::3]
-        B, L = xs[0].shape[:2]
+        B, L = xs[0].shape[:2]                        # (a stream may cover only the first Bs < B items: AudioEncoder.noise_items)
         widths = [w.shape[0] for w in ws]
         # throughput mode (rt.bf16_cat): the concatenation itself is bf16 -- its only reader, the mel calibrator, averages it in
         # fp32, and the gradient that comes back for it is bf16 too (read by the four GroupNorm backwards)
@@ -464,8 +464,11 @@ class ConvNormCatFn(Function):
             b16 = prec == ops.PREC_BF16 and rt.bf16_acts and wd % 8 == 0
             z16 = b16 and rt.bf16_z and ops.groupnorm_z_bf16_ok(L)
             z = ops.conv_gemm(x, w, bias, kw=5, n=wd, prec=prec, out_bf16=z16)
-            aux = torch.empty(B, wd // 16, 2, device=z.device, dtype=torch.float32)
-            ops.groupnorm_relu(z, norm.weight, norm.bias, stats=aux, out=out[..., off:off + wd])
+            Bs = x.shape[0]
+            aux = torch.empty(Bs, wd // 16, 2, device=z.device, dtype=torch.float32)
+            ops.groupnorm_relu(z, norm.weight, norm.bias, stats=aux, out=out[:Bs, :, off:off + wd])
+            if Bs < B:                                # the items this stream skips: zeros (finite inputs for the calibrator / BiLSTM)
+                ops.fill_zero(out[Bs:, :, off:off + wd])
             saved += [x, z, aux]
             b16s.append(b16)
             off += wd
@@ -480,8 +483,8 @@ class ConvNormCatFn(Function):
         grads, off = [], 0
         for i, (weight, bias, key, norm, wd, b16) in enumerate(zip(ws, bs, keys, norms, widths, b16s)):
             x, z, stats = saved[3 * i:3 * i + 3]
-            dz = ops.groupnorm_relu_bwd(z, dy[..., off:off + wd], norm.weight, norm.bias, stats, G(norm.weight), G(norm.bias),
-                                        dx_bf16=b16, x3=True)
+            dz = ops.groupnorm_relu_bwd(z, dy[:x.shape[0], :, off:off + wd], norm.weight, norm.bias, stats, G(norm.weight),
+                                        G(norm.bias), dx_bf16=b16, x3=True)
             off += wd
             n, cin = weight.shape[0], x.shape[-1]
             dzg, dzp = _x3_split(dz, n)

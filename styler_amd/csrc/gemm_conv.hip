@@ -767,6 +767,14 @@ int styler_conv_gemm_impl2(const float* x, int64_t ldx, const void* w, const flo
                            const float* res, int64_t ldres, float* y, int64_t ldy, int B, int L, int cin, int n,
                            int kw, int pad, int act, int prec, const int64_t* len, const int32_t* rowinfo,
                            const float* mask, int64_t ldmask, int io_flags, void* stream) {
+  // the one-shot registrations of this host thread are consumed FIRST, whatever happens below: an argument error must not
+  // leave them for the next call (round-5 advisor)
+  void* ws = nullptr;
+  int64_t ws_bytes = 0;
+  styler_gemm_take_workspace(&ws, &ws_bytes);      // consumed by this call, whatever engine takes it
+  uint16_t* y3_reg = nullptr;
+  int y3_parts = 0;
+  styler_take_x3_out(&y3_reg, &y3_parts);          // (likewise: the split of the fp32 output, styler_set_x3_out)
   const int x16 = io_flags & STYLER_IO_X_BF16, y16 = io_flags & STYLER_IO_Y_BF16, m16 = io_flags & STYLER_IO_MASK_BF16;
   const int r16 = io_flags & STYLER_IO_RES_BF16;
   if ((x16 || y16 || r16) && (prec != STYLER_PREC_BF16 || (y16 && (ldy & 3)) || (x16 && (ldx & 7)) || (r16 && (!res || (ldres & 3)))))
@@ -787,10 +795,7 @@ int styler_conv_gemm_impl2(const float* x, int64_t ldx, const void* w, const flo
     a.x3n1 = cin / 192;
   }
   hipStream_t st = (hipStream_t)stream;
-  void* ws = nullptr;
-  int64_t ws_bytes = 0;
-  styler_gemm_take_workspace(&ws, &ws_bytes);      // consumed by this call, whatever engine takes it
-  styler_take_x3_out(&a.y3, &a.y3parts);           // (likewise: the split of the fp32 output, styler_set_x3_out)
+  a.y3 = y3_reg; a.y3parts = y3_parts;
   if (a.y3 && (y16 || prec != STYLER_PREC_BF16 || (a.y3parts != 2 && a.y3parts != 3) || ((uintptr_t)a.y3 & 7) ||
                (int64_t)B * L * a.y3parts * n * 2 >= ((int64_t)1 << 31)))
     return STYLER_EINVAL;

@@ -126,13 +126,22 @@ def allreduce_preflight(device, nbytes=117_930_804, reps=5):
 
     for name, dtype, elems in (("fp32", torch.float32, nbytes // 4), ("bf16", torch.bfloat16, nbytes // 4)):
         err, buf = None, None
-        try:                                         # allocation + one warm-up all-reduce (dtype support, memory)
+        try:                                         # the allocation alone: a rank that fails HERE has entered no collective yet
             buf = torch.zeros(elems, device=device, dtype=dtype)
+        except RuntimeError as e:
+            err = str(e)[:120]
+        # every rank agrees on the allocation BEFORE any data collective, so all ranks issue the same collective sequence (round-5
+        # advisor: a rank that died allocating used to answer the others' bucketed all-reduce with agree()'s 2-element one)
+        failed, _ = agree(err)
+        if failed:
+            out[name] = {"error": err if err is not None else "another rank failed"}
+            continue
+        try:                                         # one warm-up all-reduce (dtype support of the backend): entered by every rank
             for w in allreduce_sum_(buf):
                 w.wait()
             if buf.is_cuda:
                 torch.cuda.synchronize()
-        except RuntimeError as e:                    # (a backend without this dtype: say so instead of dying)
+        except RuntimeError as e:                    # (a backend without this dtype fails on every rank alike: say so instead of dying)
             err = str(e)[:120]
         failed, _ = agree(err)                       # doubles as the barrier in front of the timed repetitions
         if failed:

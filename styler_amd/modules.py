@@ -112,10 +112,14 @@ class AudioEncoder(_HipModule):
                 x = ops.lstm_bidir(ops.conv_gemm(x, w, bias, n=8 * H, prec=prec), w_hh, H)
         return x
 
-    def forward(self, cat, len_org, seq_len, mask=None, max_seq_len=None):
+    def forward(self, cat, len_org, seq_len, mask=None, max_seq_len=None, noise_items=None):
         """cat: EncoderInput (from StyleEncoder.encoder_input_cat); len_org = mel_len, seq_len = src_len.
         Returns (duration, f0, energy, noise) encodings [B, S, 2*neck].  S = max(seq_len) as in
-        utils.mel_calibrator's re-padding; pass `max_seq_len` to avoid the host sync that needs."""
+        utils.mel_calibrator's re-padding; pass `max_seq_len` to avoid the host sync that needs.
+        `noise_items` (round 6, training with the stacked main + DAT batch): only the first `noise_items` items need the
+        noise stream -- the DAT pass discards its fourth output (train.py:150 `..., _ = audio_encoder(...)`), so the three
+        convolution + GroupNorm stages of stream 4 run on those items only and the other items' columns of the concatenation
+        are zeros (their rows of the noise encoding are never read, their gradient is exactly zero)."""
         if not isinstance(cat, EncoderInput):
             raise TypeError("audio_encoder expects the EncoderInput returned by encoder_input_cat "
                             "(the dense one-hot [B, 674, T] tensor is never materialised)")
@@ -128,6 +132,9 @@ class AudioEncoder(_HipModule):
         catbuf = None if grad else torch.empty(B, T, sum(W), device=dev, dtype=torch.float32)
         err = torch.zeros(1, device=dev, dtype=torch.int32) if rt.strict_inputs else None
         finals, last = [], []
+        Bn = B
+        if noise_items is not None and grad and rt.fused_cat and rt.skip_dat_noise and 0 < noise_items < B:
+            Bn = int(noise_items)
         for s in range(4):
             convs = getattr(self, f"convolutions_{s + 1}")
             x = None
@@ -142,7 +149,7 @@ class AudioEncoder(_HipModule):
                         y = torch.empty(B, T, W[s], device=dev, dtype=torch.float32)
                         ops.onehot_conv5(v, wt, conv.bias, y, err_flag=err)
                 else:
-                    src = (mel if s == 0 else mel_aug) if i == 0 else x
+                    src = (mel if s == 0 else mel_aug[:Bn]) if i == 0 else x
                     if grad and i == 2 and rt.fused_cat:    # the four last stages: one node writing into the concatenation
                         last.append((src, conv, gn, f"c{s}_{i}"))
                         continue
@@ -227,7 +234,9 @@ class StyleEncoder(_HipModule):
             # (Round 5: with the chain delayed on purpose, the B = 48 eager step folded the embedding's slots before they were
             # written -- the join had been a matter of timing.)
             main = torch.cuda.current_stream()
-            side = self.__dict__.setdefault("_text_stream", torch.cuda.Stream(device=text.device))
+            if "_text_stream" not in self.__dict__:
+                self.__dict__["_text_stream"] = torch.cuda.Stream(device=text.device)
+            side = self.__dict__["_text_stream"]
             x0 = self.text_encoder.embed(text)
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -256,7 +265,7 @@ class StyleEncoder(_HipModule):
                 enc_cat = self.encoder_input_cat(torch.cat([mel_target, dat[0]]), torch.cat([p_norm, dat[1]]),
                                                  torch.cat([e_input, dat[2]]), torch.cat([mel_aug, dat[0]]))
                 len2, src2 = torch.cat([mel_len, mel_len]), torch.cat([src_len, src_len])
-            d, p, e, n = self.audio_encoder(enc_cat, len2, src2, mask=None, max_seq_len=text.shape[1])
+            d, p, e, n = self.audio_encoder(enc_cat, len2, src2, mask=None, max_seq_len=text.shape[1], noise_items=B)
             if rt.pair_classifiers:
                 # round 4: the augmentation classifiers run ONCE on the stacked [2B, S, C] encodings (StyleModeling.forward;
                 # every op of a classifier is per item) -- half the classifier launches, and the DAT halves never need to be
@@ -381,10 +390,15 @@ class StyleModeling(_HipModule):
         on that stream next to the decoder's backward.  The side stream first waits for everything enqueued so far on the current
         stream (its inputs).  `on` False (eval, free-running, switch off): a null context."""
         import contextlib
-        if not on:
+        # Only inside training.forward_backward (it owns the joins: the forward one in STYLER.forward, the backward one in every
+        # WgradArena.flush, and it resets ops.loss_side_stream).  A caller that runs StyleModeling / loss.backward() on its own
+        # gets everything on its current stream (round-5 advisor).
+        if not on or ops.zero_slab is None:
             return contextlib.nullcontext()
         main = torch.cuda.current_stream()
-        side = self.__dict__.setdefault("_pred_stream", torch.cuda.Stream(device=main.device))
+        if "_pred_stream" not in self.__dict__:       # (created once: setdefault() would build and drop a stream per forward)
+            self.__dict__["_pred_stream"] = torch.cuda.Stream(device=main.device)
+        side = self.__dict__["_pred_stream"]
         side.wait_stream(main)
         self._pred_side = side
         ops.loss_side_stream = side                   # (every WgradArena.flush joins it: partial tiles are written there too)

@@ -22,6 +22,10 @@ class StylerHipError(RuntimeError):
 
 def _chk(rc, name):
     if rc != 0:
+        # a failed entry point may have returned before consuming this thread's one-shot registrations (the bf16x3 split output,
+        # the split-K workspace): drop them, so the NEXT call cannot write into a buffer the unwinding frees (round-5 advisor)
+        lib.styler_set_x3_out(None, 0)
+        lib.styler_gemm_set_workspace(None, 0)
         raise StylerHipError(f"{name} failed with code {rc}")
 
 
@@ -82,6 +86,15 @@ class WgradArena:
         # graph): descriptor tables are never evicted, and once `frozen` the buffer must not be re-sized
         self.owned_by_graph = False
         self.frozen = False
+
+    def reset_plan(self):
+        """Forget everything sized / cached from the engine's split plan (ops.wgrad_tune flipped a knob): the next pass measures
+        again.  Refused for an arena a captured hipGraph addresses -- that step has to be captured anew."""
+        if self.frozen:
+            raise StylerHipError("WgradArena: a captured hipGraph addresses this arena; re-capture the step after wgrad_tune")
+        self.buf, self.used, self.total = None, 0, 0
+        self._cache.clear(); self._gcache.clear(); self.hist.clear()
+        self.descs, self.group, self.group_keep = [], [], []
 
     def begin(self, device=None):
         """Start of a backward pass.  The buffer is (re)sized HERE, from what the previous pass asked for in total --
@@ -470,14 +483,18 @@ def x3_register(y, y3, plan=None):
         x3_cache[key] = (y, y._version, y3)
 
 
-def _x3_begin(out, enable=True):
+def _x3_begin(out, enable=True, allowed_parts=(2, 3)):
     """Registers a split output for the NEXT producer call (styler_set_x3_out) when `out` (fp32, contiguous rows) is going to be
-    a bf16x3 GEMM operand in this training step; returns the split tensor to hand to `_x3_end`, or None."""
+    a bf16x3 GEMM operand in this training step; returns the split tensor to hand to `_x3_end`, or None.
+    `allowed_parts`: the storage forms THIS producer can write -- the x3 attention kernels and layernorm_bwd only know the
+    compact [hi | lo] form (parts = 2); with STYLER_X3_COMPACT=0 (triple form everywhere) they do not register, and the
+    consumer's split3() makes the pass instead (round-5 advisor: they used to return STYLER_EINVAL there)."""
     if not enable or out is None or out.dtype != torch.float32 or not out.is_contiguous():
         return None
     y3, parts = x3_out_for(out.shape[:-1], out.shape[-1], out.device)
-    if y3 is not None:
-        _chk(lib.styler_set_x3_out(y3.data_ptr(), parts), "styler_set_x3_out")
+    if y3 is None or parts not in allowed_parts:
+        return None
+    _chk(lib.styler_set_x3_out(y3.data_ptr(), parts), "styler_set_x3_out")
     return y3
 
 
@@ -485,6 +502,13 @@ def _x3_end(out, y3, plan=None):
     if y3 is not None:
         lib.styler_set_x3_out(None, 0)               # (consumed by the producer; cleared again in case it never got there)
         x3_register(out, y3, plan)
+
+
+def _x3_abort(y3):
+    """Error path of a producer call: drop the thread-local registration, so that the NEXT producer call of this thread cannot
+    write a split into a buffer that is about to be freed (round-5 advisor)."""
+    if y3 is not None:
+        lib.styler_set_x3_out(None, 0)
 
 
 def lo_part(x, plan=None):
@@ -698,6 +722,19 @@ def gemm256_config(enabled=-1, min_tiles=-1, split=-1, take_all=-1):
     return prev & 1, prev >> 1, pol & 3, pol >> 2
 
 
+def wgrad_tune(knob, value, arenas=()):
+    """styler_wgrad_tune with the host-side bookkeeping it needs: knob 1 (tall k = 5 tile) changes split counts and workspace
+    bytes, so every WgradArena in `arenas` (training.TrainState.arena, ...) forgets its sizing and descriptor tables when the
+    value actually changes (round-5 advisor).  Returns the previous value."""
+    prev = lib.styler_wgrad_tune(int(knob), int(value))
+    if prev < 0:
+        raise StylerHipError(f"styler_wgrad_tune: unknown knob {knob}")
+    if prev != value and value in (0, 1, 2):
+        for a in arenas:
+            a.reset_plan()
+    return prev
+
+
 def gemm256_height(ht=-1, min_tiles3=-1):
     """Tile height of the 256-column LDS-DMA engine: ht 4 = 256 rows, 3 = 192 rows, 0 = per-launch policy (-1 keeps);
     `min_tiles3`: smallest 192 x 256 tile count the policy hands to the 192-row tile.  Returns the previous (ht, min_tiles3)."""
@@ -745,13 +782,17 @@ def attention_fwd(qkv, lens, lse=None, prec=None, plan=None, out_bf16=False, x3=
         if not rt_attn_x3 and _prec(prec) == PREC_BF16X3:
             fn = lib.styler_attention_fwd
     # x3 (bf16x3, the x3 kernels only): the output feeds the out-projection GEMM -- its split leaves with it
-    y3 = _x3_begin(out, x3 and fn is lib.styler_attention_fwd_x3)
-    if plan is not None:
-        _chk(fn(qkv.data_ptr(), out.data_ptr(), _ptr(lse), plan.B, plan.T, plan.lens.data_ptr(), plan.cu.data_ptr(),
-                _stream()), "styler_attention_fwd")
-    else:
-        B, L, _ = qkv.shape
-        _chk(fn(qkv.data_ptr(), out.data_ptr(), _ptr(lse), B, L, _ptr(lens), None, _stream()), "styler_attention_fwd")
+    y3 = _x3_begin(out, x3 and fn is lib.styler_attention_fwd_x3, allowed_parts=(2,))
+    try:
+        if plan is not None:
+            _chk(fn(qkv.data_ptr(), out.data_ptr(), _ptr(lse), plan.B, plan.T, plan.lens.data_ptr(), plan.cu.data_ptr(),
+                    _stream()), "styler_attention_fwd")
+        else:
+            B, L, _ = qkv.shape
+            _chk(fn(qkv.data_ptr(), out.data_ptr(), _ptr(lse), B, L, _ptr(lens), None, _stream()), "styler_attention_fwd")
+    except Exception:
+        _x3_abort(y3)
+        raise
     _x3_end(out, y3, plan)
     return out
 
@@ -1008,6 +1049,14 @@ def add2(a, b, out=None):
     _chk(lib.styler_add2(a.data_ptr(), _ld(a), _ptr(b), _ld(b) if b is not None else 0, out.data_ptr(), _ld(out),
                          rows, C, _stream()), "styler_add2")
     return out
+
+
+def fill_zero(t):
+    """Zeros into a [.., C] view with contiguous channels (a channel / item slice of a wider buffer; fp32, or bf16 with an even
+    channel count, offset and row stride): styler_copy_rows_multi with a null source -- no torch fill on the step."""
+    if t.dtype == torch.bfloat16:
+        t = t.view(torch.float32)
+    copy_rows_multi([(None, t)])
 
 
 def copy_rows_multi(pairs):
@@ -1320,9 +1369,13 @@ def attention_bwd(qkv, out, dout, lse, lens, prec=None, plan=None, out_bf16=Fals
                                            _stream()), "styler_attention_bwd_bf16")
     else:
         fn = lib.styler_attention_bwd_x3 if (_prec(prec) == PREC_BF16X3 and rt_attn_x3) else lib.styler_attention_bwd
-        y3 = _x3_begin(dqkv, x3 and fn is lib.styler_attention_bwd_x3)      # (dqkv feeds the QKV dX GEMM + weight gradients)
-        _chk(fn(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
-                ws.data_ptr(), B, L, _ptr(lens), cu, _stream()), "styler_attention_bwd")
+        y3 = _x3_begin(dqkv, x3 and fn is lib.styler_attention_bwd_x3, allowed_parts=(2,))   # (dqkv feeds the QKV dX GEMM + weight gradients)
+        try:
+            _chk(fn(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                    ws.data_ptr(), B, L, _ptr(lens), cu, _stream()), "styler_attention_bwd")
+        except Exception:
+            _x3_abort(y3)
+            raise
         _x3_end(dqkv, y3, plan)
     return dqkv
 
@@ -1380,13 +1433,17 @@ def layernorm_bwd(x, dy, gamma, beta, dgamma, dbeta, lens=None, need_dx=True, do
     # x3: the gradient that continues into the sublayer's GEMMs (dx_drop when the forward dropped its input, else dx) leaves
     # with its bf16x3 split, filed under the key split3(., plan) looks up
     d_o = dxd if dxd is not None else dx
-    y3 = _x3_begin(d_o, x3)
-    _chk(lib.styler_layernorm_bwd(x.data_ptr(), _ld(x), _ptr(dy), _ld(dy) if dy is not None else 0, gamma.data_ptr(),
-                                  _ptr(beta), _ptr(dx), C, pg.data_ptr(), pb.data_ptr(), _ptr(dot_w),
-                                  _ptr(dout), _ptr(pw), _ptr(ddot_b), B, L, C, _ptr(lens), float(drop_p),
-                                  int(drop_seed), float(in_drop_p), int(in_drop_seed), _ptr(dxd), C, rep, (1 if relu_input else 0) | lnb_io,
-                                  _stream()),
-         "styler_layernorm_bwd")
+    y3 = _x3_begin(d_o, x3, allowed_parts=(2,))
+    try:
+        _chk(lib.styler_layernorm_bwd(x.data_ptr(), _ld(x), _ptr(dy), _ld(dy) if dy is not None else 0, gamma.data_ptr(),
+                                      _ptr(beta), _ptr(dx), C, pg.data_ptr(), pb.data_ptr(), _ptr(dot_w),
+                                      _ptr(dout), _ptr(pw), _ptr(ddot_b), B, L, C, _ptr(lens), float(drop_p),
+                                      int(drop_seed), float(in_drop_p), int(in_drop_seed), _ptr(dxd), C, rep, (1 if relu_input else 0) | lnb_io,
+                                      _stream()),
+             "styler_layernorm_bwd")
+    except Exception:
+        _x3_abort(y3)
+        raise
     _x3_end(d_o, y3, plan)
     if fold is not None:
         _chk(lib.styler_fold_replicas(fold[0].data_ptr(), fold[1].data_ptr(), _ptr(fold[2]) if ddot_w is not None else None,

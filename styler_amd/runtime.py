@@ -52,6 +52,11 @@ class _Runtime:
     # every mode (the round-5 path).
     lstm_mfma = os.environ.get("STYLER_LSTM_MFMA", "1") != "0"
 
+    # Round 6: in the stacked main + DAT AudioEncoder batch (pair_audio) the DAT half of the NOISE stream is dead work -- the DAT pass
+    # discards the fourth encoding (train.py:150), and its input (mel_aug) is the main half's anyway -- so the stream's three
+    # conv + GroupNorm stages (forward, dX, weight gradients) run on the first B items only.  STYLER_SKIP_DAT_NOISE=0: all 2B items.
+    skip_dat_noise = os.environ.get("STYLER_SKIP_DAT_NOISE", "1") != "0"
+
     # EXPERIMENT (round 5): on one rank, the decoder-side flush of the weight-gradient arena (grouped Linear gradients + the fold
     # of the split-K partials so far) on a side stream next to the rest of backward (training.TrainState.early_flush_on_side)
     early_flush = os.environ.get("STYLER_EARLY_FLUSH", "0") == "1"

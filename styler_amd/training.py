@@ -47,6 +47,8 @@ class TrainState:
         # all-reduce is launched from there and overlaps the rest of backward (style encoders, predictors, DAT pass)
         self.tail_start = self._tail_offset(model, params, align)
         self._tail_works = None
+        self.ar_events = None          # diagnostic: a list here makes step() / on_decoder_grads_ready time the collectives
+        self._ar_t0 = None
         # optional bf16 transport of the gradient all-reduce (dist.Bf16Reducer; off by default)
         self.reducer = (Bf16Reducer(self.flat_g) if __import__("os").environ.get("STYLER_ALLREDUCE_BF16", "0") == "1"
                         else None)
@@ -155,6 +157,9 @@ class TrainState:
         if self._tail_works is None:
             self.arena.flush(self.flat_g.device)      # fold the decoder-side split-K partials before they are reduced
             self._tail_works = self._start_allreduce(self.tail_start, self.n)
+            if self.ar_events is not None:            # diagnostic (bench.py, N > 1): when the overlapped range was launched
+                self._ar_t0 = torch.cuda.Event(enable_timing=True)
+                self._ar_t0.record()
 
     def lr(self):
         """optimizer.py:21-32: the counter is incremented BEFORE the rate is computed."""
@@ -163,12 +168,21 @@ class TrainState:
 
     def step(self):
         """nn.utils.clip_grad_norm_(params, 1.0) + ScheduledOptim.step_and_update_lr() (train.py:181-185)."""
-        if self._tail_works is not None:                     # tail range already in flight: reduce only the head
+        ev = None
+        if self.ar_events is not None:                       # diagnostic: main-stream time spent blocked in the collective
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        overlapped = self._tail_works is not None
+        if overlapped:                                       # tail range already in flight: reduce only the head
             works = self._tail_works + self._start_allreduce(0, self.tail_start)
         else:
             works = self._start_allreduce(0, self.n)
         for w in works:
             w.wait()
+        if ev is not None:
+            ev[1].record()
+            self.ar_events.append((self._ar_t0 if overlapped else None, ev[0], ev[1]))
+            self._ar_t0 = None
         if self.reducer is not None:
             self.reducer.finish()
         self._tail_works = None
@@ -189,6 +203,24 @@ class TrainState:
         self.sumsq.zero_()
         ops.sumsq(self.flat_g, self.sumsq)
         return float(self.sumsq.sqrt().item())
+
+    def allreduce_timing(self):
+        """Summary of the events `ar_events` collected (set it to [] before a few diagnostic steps): per step, `exposed_ms` = the
+        main stream's time inside step()'s collective waits (the head range's whole all-reduce + what was left of the overlapped
+        tail range), `overlap_window_ms` = from the tail range's launch (backward has left both decode branches) to step() --
+        the time the tail's all-reduce had to hide in.  Medians; the caller synchronises first."""
+        ev = self.ar_events or []
+        if not ev:
+            return None
+        med = lambda v: sorted(v)[len(v) // 2]
+        out = {"steps": len(ev), "exposed_ms": round(med([a.elapsed_time(b) for _, a, b in ev]), 3)}
+        win = [t0.elapsed_time(a) for t0, a, _ in ev if t0 is not None]
+        if win:
+            out["overlap_window_ms"] = round(med(win), 3)
+        es = 2 if self.reducer is not None else 4
+        out["exposed_bytes"] = self.tail_start * es
+        out["overlapped_bytes"] = (self.n - self.tail_start) * es
+        return out
 
     def allreduce_info(self):
         """What one step exchanges (bench.py prints it, so a silent fallback of the overlap is visible)."""

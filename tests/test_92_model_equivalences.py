@@ -216,7 +216,7 @@ def test_paired_decodes_match_separate(dev, ref_state_dict, prec):
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("switch", ["pair_audio", "fused_split", "fused_cat", "pair_classifiers", "grouped_mlps",
-                                    "text_stream", "pred_stream"])
+                                    "text_stream", "pred_stream", "skip_dat_noise"])
 def test_experimental_switches_match_default(dev, ref_state_dict, prec, switch):
     """rt.pair_audio (main forward + DAT pass of the AudioEncoder as one batch of 2B items), rt.fused_split (gathered
     gradient of the LengthRegulator output's channel slices), rt.fused_cat (the AudioEncoder's four last conv + GroupNorm
@@ -224,7 +224,9 @@ def test_experimental_switches_match_default(dev, ref_state_dict, prec, switch):
     classifiers of the main and the DAT pass as one batch of 2B items; the batch here has B = 5: its [2B, 2] log-probabilities
     take the unaligned path of the split) and rt.grouped_mlps (round 4: independent S-domain Linears as grouped launches), and
     the stream switches -- rt.text_stream (text encoder's FFT blocks on a side stream), rt.pred_stream (round 5: loss-only
-    predictors and classifiers on a side stream) -- vs the path without them: same ten losses and the same gradients (dropout off)."""
+    predictors and classifiers on a side stream) -- and rt.skip_dat_noise (round 6: the noise stream's conv stages skip the DAT
+    half of the stacked batch, whose fourth encoding train.py:150 discards) -- vs the path without them: same ten losses and
+    the same gradients (dropout off)."""
     from closed_form import make_batch
     from styler_amd import STYLER, rt
     from styler_amd.training import train_losses

@@ -216,3 +216,37 @@ def test_bf16x3_train_step_producers_equal_separate_passes(dev, ref_state_dict):
         rt.set_precision("fp32")
     assert torch.equal(outs[0][0], outs[1][0]), (outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1]), f"{int((outs[0][1] != outs[1][1]).sum())} gradient entries differ"
+
+
+def test_bf16x3_train_step_triple_form(dev, ref_state_dict):
+    """STYLER_X3_COMPACT=0 (every split stored as [hi | lo | hi]): the x3 attention kernels and layernorm_bwd can only write the
+    compact form, so they must NOT register as producers there (round-5 advisor: the step used to die with STYLER_EINVAL on
+    the first attention sublayer) -- the consumers make those splits as passes.  The two storage forms hold the same hi / lo
+    values, so the step's losses and gradients agree to accumulation-order noise."""
+    from closed_form import make_batch
+    from styler_amd import STYLER, ops, rt
+    from styler_amd.training import TrainState, forward_backward
+    b = {k: v.to(dev) for k, v in make_batch(6, 20, 40, 2, 9, seed=3).items()}
+    rt.set_precision("bf16x3")
+    prev_drop, rt.disable_dropout = rt.disable_dropout, True
+    prev_compact = ops.x3_compact
+    outs = []
+    try:
+        for compact in (True, False):
+            ops.x3_compact = compact
+            torch.manual_seed(0)
+            m = STYLER()
+            m.load_state_dict(ref_state_dict)
+            m = m.to(dev).train()
+            st = TrainState(m)
+            for _ in range(2):
+                st.zero_grad()
+                losses = forward_backward(m, st, b)
+            outs.append((torch.stack([l.detach().float().reshape(()) for l in losses]).cpu(), st.flat_g.clone()))
+    finally:
+        ops.x3_compact = prev_compact
+        rt.disable_dropout = prev_drop
+        rt.set_precision("fp32")
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6), (outs[0][0], outs[1][0])
+    d = float((outs[0][1] - outs[1][1]).abs().max()) / float(outs[0][1].abs().max())
+    assert d <= 1e-5, f"compact vs triple storage: gradients differ by {d:.3e} of the largest entry"
