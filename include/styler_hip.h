@@ -301,6 +301,25 @@ int styler_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t 
                          uint64_t in_drop_seed, float* sum_out, int64_t ldsum, uint16_t* y16, int64_t ldy16,
                          int io_flags, void* stream);
 
+/* Round 6: the Linear in front of that LayerNorm and the LayerNorm as ONE launch (throughput mode, bf16 operands):
+ *   s = dropout(a W^T + bias, drop_p) + res;   y = LayerNorm_256(s) * gamma + beta;   rows t >= len[b]: y = 0
+ * a: bf16 rows [B*L, K] (row stride lda elements, K % 64 == 0), w: bf16 [256, K] (nn.Linear layout / the k = 1 Conv1d
+ * weight), bias fp32 [256] or NULL.  Replaces `fc` + dropout + residual + layer_norm of MultiHeadAttention
+ * (transformer/SubLayers.py:55-61) and `w_2` + dropout + residual + layer_norm of PositionwiseFeedForward
+ * (SubLayers.py:86-89) together with the masked_fill of Layers.py:29,32: a 128 x 256 tile owns whole rows, the fp32
+ * projection never reaches HBM.  res / y / sum_out / y16 / len / drop_seed / io_flags (STYLER_LN_*) exactly as
+ * styler_add_layernorm (in_drop_p = drop_p there): the same dropout stream, the same statistics, so
+ * styler_layernorm_bwd consumes sum_out unchanged.  styler_linear_ln_ok says whether a shape is taken (1) or not (0). */
+int styler_linear_ln(const void* a, int64_t lda, int K, const void* w, const float* bias, const void* res,
+                     int64_t ldres, const float* gamma, const float* beta, void* y, int64_t ldy, void* sum_out,
+                     int64_t ldsum, uint16_t* y16, int64_t ldy16, int B, int L, const int64_t* len, float drop_p,
+                     uint64_t drop_seed, int io_flags, void* stream);
+int styler_linear_ln_ok(int64_t rows, int K, int n, int64_t lda);
+/* Measurement hook (tools/linear_ln_trace.py): the launches that follow write 8 x uint64 per block into buf -- block, then
+ * 100 MHz timestamps of entry, masks known, first K step landed, K loop done, tile staged, rows issued, stores acknowledged;
+ * NULL switches it off.  Replaces nothing in the reference. */
+int styler_linear_ln_set_trace(void* buf);
+
 /* y = relu(GroupNorm(x)) with groups of 16 channels and statistics over 16 ch x the whole
  * padded L (modules.py:103-113,171-175; eps 1e-5).  In place allowed (y == x).
  * workspace: 2*B*C/16 doubles (scratch; ws_zeroed != 0 = the caller hands it over already zeroed, e.g. a

@@ -32,6 +32,9 @@ _SIGS = {
     "styler_attention_fwd_bf16_io": [P, P, P, I, I, P, P, I, P],
     "styler_attention_bwd_bf16": [P, P, P, P, P, P, I, I, P, P, I, P],
     "styler_add_layernorm": [P, I64, P, I64, P, P, P, I64, P, P, P, I, I, I, P, F, ctypes.c_uint64, F, ctypes.c_uint64, P, I64, P, I64, I, P],
+    "styler_linear_ln": [P, I64, I, P, P, P, I64, P, P, P, I64, P, I64, P, I64, I, I, P, F, ctypes.c_uint64, I, P],
+    "styler_linear_ln_ok": [I64, I, I, I64],
+    "styler_linear_ln_set_trace": [P],
     "styler_groupnorm_relu": [P, I64, P, P, P, I64, P, P, I, I, I, I, I, P],
     "styler_bn_fold": [P, P, P, P, P, P, P, I, P],
     "styler_batchnorm_train": [P, P, P, P, P, P, P, P, P, I, I64, I, I, F, ctypes.c_uint64, I, I, P],

@@ -193,6 +193,23 @@ def _ln_tail_fwd(o, x, ln, lens, drop_p, want16=False, plan=None):
     return (y, s, (drop_p, seed), y16) if want16 else (y, s, (drop_p, seed))
 
 
+def _linear_ln_fwd(a, w, bias, x, ln, lens, drop_p, want16=False, plan=None):
+    """_ln_tail_fwd with the Linear in front of it in the same launch (ops.linear_ln, csrc/linear_ln.hip): the same seed
+    sequence, the same saved sum, so _ln_tail_bwd and the Linear's own backward GEMMs run unchanged."""
+    drop_p = 0.0 if rt.disable_dropout else drop_p
+    seed = next_dropout_seed() if drop_p > 0 else 0
+    s = torch.empty_like(x)
+    y16 = torch.empty_like(x, dtype=torch.bfloat16) if (want16 and x.dtype != torch.bfloat16) else None
+    y = ops.linear_ln(a, w, bias, x, ln.weight, ln.bias, lens=lens, drop_p=drop_p, drop_seed=seed, sum_out=s, out16=y16,
+                      packed=plan is not None)
+    return (y, s, (drop_p, seed), y16) if want16 else (y, s, (drop_p, seed))
+
+
+def _linear_ln_takes(a, prec):
+    """The fused Linear + LayerNorm launch: throughput mode, bf16 rows, no simulated stream."""
+    return rt.linear_ln and prec == ops.PREC_BF16 and not rt.sim_bf16_stream and ops.linear_ln_ok(a, 256)
+
+
 def _r16(t):
     """rt.sim_bf16_stream: the value a bf16-stored tensor would hold."""
     return t.to(torch.bfloat16).to(torch.float32)
@@ -231,8 +248,11 @@ class FfnSublayerFn(Function):
         h = ops.conv_gemm(xa, w1, ffn.w_1.bias, kw=kw1, n=ffn.w_1.weight.shape[0], act=RELU, prec=p1, plan=plan,
                           out_bf16=h16, x3_out=True)             # (bf16x3: h is the second conv's operand -- split in the epilogue)
         w2, p2 = gemm_weight(ffn._derived, "w_2", ffn.w_2.weight, h.shape[-1])
-        o = ops.conv_gemm(h, w2, ffn.w_2.bias, kw=kw2, n=ffn.w_2.weight.shape[0], prec=p2, plan=plan)
-        y, s, ctx.drop = _ln_tail_fwd(o, x, ffn.layer_norm, lens, drop_p, plan=plan)
+        if kw2 == 1 and ffn.w_2.weight.shape[0] == 256 and _linear_ln_takes(h, p2):
+            y, s, ctx.drop = _linear_ln_fwd(h, w2, ffn.w_2.bias, x, ffn.layer_norm, lens, drop_p, plan=plan)
+        else:
+            o = ops.conv_gemm(h, w2, ffn.w_2.bias, kw=kw2, n=ffn.w_2.weight.shape[0], prec=p2, plan=plan)
+            y, s, ctx.drop = _ln_tail_fwd(o, x, ffn.layer_norm, lens, drop_p, plan=plan)
         ctx.save_for_backward(x, h, s, lens)
         ctx.ffn, ctx.plan = ffn, plan
         return y
@@ -270,12 +290,16 @@ class AttnSublayerFn(Function):
         lse = torch.empty(B, 4, L, device=x.device, dtype=torch.float32)
         att = ops.attention_fwd(qkv, lens, lse=lse, plan=plan, out_bf16=prec == ops.PREC_BF16 and rt.bf16_att, x3=True)
         wfc, pfc = gemm_weight(mha._derived, "fc", mha.fc.weight, 256)
-        o = ops.conv_gemm(att, wfc, mha.fc.bias, n=256, prec=pfc, plan=plan)
         want16 = want16 and prec == ops.PREC_BF16
-        if want16:                                    # (on a bf16 stream the second value is None: y itself is bf16)
-            y, s, ctx.drop, y16 = _ln_tail_fwd(o, x, mha.layer_norm, lens, drop_p, want16=True, plan=plan)
+        if _linear_ln_takes(att, pfc):                # output projection + dropout + residual + LayerNorm: one launch
+            r = _linear_ln_fwd(att, wfc, mha.fc.bias, x, mha.layer_norm, lens, drop_p, want16=want16, plan=plan)
+            (y, s, ctx.drop, y16) = r if want16 else (r + (None,))
         else:
-            y, s, ctx.drop = _ln_tail_fwd(o, x, mha.layer_norm, lens, drop_p, plan=plan)
+            o = ops.conv_gemm(att, wfc, mha.fc.bias, n=256, prec=pfc, plan=plan)
+            if want16:                                # (on a bf16 stream the second value is None: y itself is bf16)
+                y, s, ctx.drop, y16 = _ln_tail_fwd(o, x, mha.layer_norm, lens, drop_p, want16=True, plan=plan)
+            else:
+                y, s, ctx.drop = _ln_tail_fwd(o, x, mha.layer_norm, lens, drop_p, plan=plan)
         ctx.save_for_backward(x, qkv, att, lse, s, lens)
         ctx.mha, ctx.plan = mha, plan
         if want16:

@@ -827,6 +827,40 @@ def add_layernorm(x, gamma, beta, *, res=None, lens=None, out=None, dot_w=None, 
     return dot_out if dot_w is not None else out
 
 
+def linear_ln_ok(a, n):
+    """Does csrc/linear_ln.hip take this Linear (bf16 rows `a` [B, L, K] -> n channels)?"""
+    return (a.dtype == torch.bfloat16 and a.dim() == 3 and a.stride(-1) == 1 and
+            bool(lib.styler_linear_ln_ok(a.shape[0] * a.shape[1], a.shape[2], int(n), _ld(a))))
+
+
+def linear_ln(a, w, bias, res, gamma, beta, *, lens=None, drop_p=0.0, drop_seed=0, sum_out=None, out16=None, out=None,
+              packed=False):
+    """LayerNorm(dropout(a W^T + bias) + res) with pad mask as one launch (styler_linear_ln): a bf16 [B, L, K], w bf16
+    [256, K]; the output follows the residual's storage format (as add_layernorm); `sum_out` receives the pre-norm sum."""
+    B, L, K = a.shape
+    if out is None:
+        out = torch.empty(B, L, 256, device=a.device,
+                          dtype=torch.bfloat16 if (res is not None and res.dtype == torch.bfloat16) else torch.float32)
+    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or tuple(w.shape) != (256, K):
+        raise StylerHipError("linear_ln needs bf16 rows and a bf16 [256, K] weight")
+    ln_io = (1 if res is not None and res.dtype == torch.bfloat16 else 0) | \
+            (2 if out.dtype == torch.bfloat16 else 0) | \
+            (4 if sum_out is not None and sum_out.dtype == torch.bfloat16 else 0)
+    prof = gemm_profiler
+    if prof is not None:                              # bench.py's live brackets: filed under its own key (not a conv_gemm engine)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _chk(lib.styler_linear_ln(a.data_ptr(), _ld(a), K, w.data_ptr(), _ptr(bias), _ptr(res),
+                              _ld(res) if res is not None else 0, gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), _ld(out),
+                              _ptr(sum_out), _ld(sum_out) if sum_out is not None else 0, _ptr(out16),
+                              _ld(out16) if out16 is not None else 0, B, L, _ptr(lens), float(drop_p), int(drop_seed), ln_io,
+                              _stream()), "styler_linear_ln")
+    if prof is not None:
+        e1.record()
+        prof.records.append(("linear_ln", 2.0 * B * L * 256 * K, e0, e1, packed))
+    return out
+
+
 IO_X3A = 1024         # STYLER_IO_X3A: the activation operand of a bf16x3 GEMM is the compact [hi | lo] split
 IO_PARAM_SLOTS = 512  # STYLER_IO_PARAM_SLOTS: parameter gradients leave the kernel as per-block slots (see _param_slots)
 IO_Z_BF16 = 16       # STYLER_IO_Z_BF16: the tensor a norm kernel normalises (a convolution's output) is stored as bf16

@@ -77,6 +77,10 @@ class _Runtime:
     # convolution takes that copy as its activation operand (it rounds the operand to bf16 anyway: same results) -- which
     # is what lets the 256 x 256 LDS-DMA engine (csrc/gemm256.hip) fetch it straight into LDS
     ln_bf16_copy = os.environ.get("STYLER_LN_BF16_COPY", "1") != "0"
+    # round 6, throughput mode: the Linear in front of a sublayer's LayerNorm (`fc` of the attention, `w_2` of the FFN) and
+    # dropout + residual + LayerNorm + pad mask as ONE launch on a 128 x 256 tile that owns whole rows (csrc/linear_ln.hip):
+    # the fp32 projection never reaches HBM.  STYLER_LINEAR_LN=0: styler_conv_gemm + styler_add_layernorm (two launches).
+    linear_ln = os.environ.get("STYLER_LINEAR_LN", "1") != "0"
     # throughput mode: the dX GEMM of the BiLSTM input projections (gate gradients x W_ih) on bf16 operands like every
     # other dX GEMM of the step (round 2 left these eight launches on the fp32 MFMA path: 0.2 ms per step)
     lstm_dx_bf16 = os.environ.get("STYLER_LSTM_DX_BF16", "1") != "0"

@@ -105,8 +105,15 @@ class MultiHeadAttention(_HipModule):
             y = self._ln(self._gemm("fc", ctx, self.fc, plan=plan), x, self.layer_norm, lens, out,
                          drop_p=self.dropout.p if self.training else 0.0)
             return (y, None) if asked else y
-        o = self._gemm("fc", ctx, self.fc, res=x, plan=plan)  # eval: residual rides in the GEMM epilogue
         s16 = x.dtype == torch.bfloat16                       # bf16 residual stream (the packed decoder): y is bf16
+        if AG._linear_ln_takes(ctx, prec) and out is None:    # projection + residual + LayerNorm + mask: one launch (csrc/linear_ln.hip)
+            wfc, _ = gemm_weight(self._derived, "fc", self.fc.weight, 256)
+            if want16 and not s16:
+                y16 = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+            y = ops.linear_ln(ctx, wfc, self.fc.bias, x, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out16=y16,
+                              packed=plan is not None)
+            return (y, y16) if asked else y
+        o = self._gemm("fc", ctx, self.fc, res=x, plan=plan)  # eval: residual rides in the GEMM epilogue
         if want16 and not s16:
             y16 = torch.empty_like(o, dtype=torch.bfloat16)
         y = ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out, out16=y16, out_bf16=s16)
@@ -137,6 +144,10 @@ class PositionwiseFeedForward(_HipModule):
         if (self.training and torch.is_grad_enabled()) or (self.training and self.dropout.p > 0):
             return self._ln(self._gemm("w_2", h, self.w_2, kw=k[1], plan=plan), x, self.layer_norm, lens, out,
                             drop_p=self.dropout.p if self.training else 0.0)
+        if k[1] == 1 and AG._linear_ln_takes(h, rt.prec) and out is None:
+            w2, _ = gemm_weight(self._derived, "w_2", self.w_2.weight, h.shape[-1])
+            return ops.linear_ln(h, w2, self.w_2.bias, x, self.layer_norm.weight, self.layer_norm.bias, lens=lens,
+                                 packed=plan is not None)
         o = self._gemm("w_2", h, self.w_2, kw=k[1], res=x, plan=plan)
         s16 = x.dtype == torch.bfloat16
         y = ops.add_layernorm(o, self.layer_norm.weight, self.layer_norm.bias, lens=lens, out=out, out_bf16=s16)
