@@ -823,6 +823,19 @@ int styler_nll3(const float* lp0, const float* lp1, const float* lp2, const int6
  * total loss of train.py:156-160 in one launch; styler_scale_weights is its backward, out[i] = g[0] * weights[i]. */
 int styler_weighted_sum(const float* const* terms, const float* weights, int n, float* out, void* stream);
 int styler_scale_weights(const float* g, const float* weights, int n, float* out, void* stream);
+/* Round 6: the tail of the train step's loss head as ONE launch each way (train.py:139-160: the classifier NLL of the main
+ * pass, that of the DAT pass, and the weighted total).  means: n <= 8 HOST-array pointers to scalar device tensors (the
+ * masked-error means, in the order of the total's sum); weights: n + 2 HOST floats (the last two weigh the two NLL3 terms);
+ * lp6: HOST array of the six [B, 2] log-probability tensors (main d, p, e, then DAT d, p, e); label0 / label1 int64 [B] or
+ * NULL (every label = label_const0 / 1).  out3 = {total, nll3(main), nll3(DAT)}.  Backward: gw[i] = g[0] * weights[i] for
+ * i < n, d6 [6, B, 2] = -(g[0] * weights[n + k / 3]) / B at the label entry, 0 elsewhere.  Bit-identical to
+ * styler_nll3 x 2 + styler_weighted_sum (forward) and styler_scale_weights + styler_nll3 x 2 (backward). */
+int styler_loss_tail(const float* const* means, const float* weights, int n, const float* const* lp6,
+                     const int64_t* label0, int label_const0, const int64_t* label1, int label_const1, int B,
+                     float* out3, void* stream);
+int styler_loss_tail_bwd(const float* g, const float* weights, int n, const float* const* lp6,
+                         const int64_t* label0, int label_const0, const int64_t* label1, int label_const1, int B,
+                         float* gw, float* d6, void* stream);
 /* Registers the device address of a uint64 step counter (or NULL to unregister).  Every dropout-drawing entry
  * point (styler_dropout, styler_add_layernorm / styler_layernorm_bwd with drop_p > 0) then uses
  * seed + counter * odd-constant as its stream key, read on the device at execution time: a training step

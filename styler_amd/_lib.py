@@ -124,6 +124,8 @@ _SIGS = {
     "styler_nll3": [P, P, P, P, I, P, P, P, I, P],
     "styler_weighted_sum": [P, P, I, P, P],
     "styler_scale_weights": [P, P, I, P, P],
+    "styler_loss_tail": [P, P, I, P, P, I, P, I, I, P, P],
+    "styler_loss_tail_bwd": [P, P, I, P, P, I, P, I, I, P, P, P],
     "styler_dropout": [P, I64, P, I64, I64, I, F, ctypes.c_uint64, P],
     "styler_sumsq": [P, I64, P, P],
     "styler_adam_step": [P, P, P, P, I64, P, F, F, F, F, F, I, F, P],

@@ -1036,6 +1036,34 @@ class WeightedSumFn(Function):
         return (None, *[gw[i] for i in range(len(ctx.weights))])
 
 
+class LossTailFn(Function):
+    """Round 6: the two classifier NLL3 terms (main pass, DAT pass) and the weighted total of train.py:156-160 as ONE tape node:
+    one launch forward (was nll3 x 2 + weighted_sum), one backward (was scale_weights + nll3 x 2).
+    apply(weights [n + 2], label0, label1, mean_0 .. mean_{n-1}, lp_0 .. lp_5) -> (total, cls, cls_dat).  Gradients flow from
+    `total` only (cls / cls_dat are returned for logging, as the reference logs them)."""
+
+    @staticmethod
+    def forward(ctx, weights, label0, label1, *t):
+        n = len(weights) - 2
+        means, lps = t[:n], [p.contiguous() for p in t[n:]]
+        tens = [l for l in (label0, label1) if not isinstance(l, int)]
+        ctx.save_for_backward(*lps, *tens)
+        ctx.weights, ctx.n = weights, n
+        ctx.labels = tuple(l if isinstance(l, int) else None for l in (label0, label1))
+        out = ops.loss_tail([m.reshape(1) for m in means], weights, lps, (label0, label1))
+        total, cls, dat = out[0:1].view(()), out[1:2].view(()), out[2:3].view(())
+        ctx.mark_non_differentiable(cls, dat)
+        return total, cls, dat
+
+    @staticmethod
+    def backward(ctx, g, g_cls, g_dat):
+        saved = list(ctx.saved_tensors)
+        lps, rest = saved[:6], saved[6:]
+        labels = tuple(l if l is not None else rest.pop(0) for l in ctx.labels)
+        gw, d6 = ops.loss_tail_bwd(g.reshape(1), ctx.weights, lps, labels)
+        return (None, None, None, *[gw[i] for i in range(ctx.n)], *[d6[k] for k in range(6)])
+
+
 class NllFn(Function):
     @staticmethod
     def forward(ctx, logp, label):

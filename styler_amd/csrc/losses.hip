@@ -5,9 +5,14 @@
 //                     (g * w_i for every term in one launch)
 // Each of these replaced 2-10 single-element aten kernels (div, cast, add, mul) that cost a launch slot apiece on the
 // serial chain of the step.
+#include <cstdlib>
 #include "common.h"
 
+// Blocks per masked-error term: every block ends in two fp64 atomics + a ticket on ONE address per term, which the L2
+// serialises -- past ~100 blocks per term the atomics, not the loads, set the kernel's time (STYLER_LOSS_BLOCKS: the cap).
 static inline unsigned loss_grid(int64_t work, int per_block, int cap) {
+  static const int env_cap = [] { const char* e = getenv("STYLER_LOSS_BLOCKS"); return e ? atoi(e) : 0; }();
+  if (env_cap > 0) cap = env_cap;
   int64_t b = (work + per_block - 1) / per_block;
   if (b > cap) b = cap;
   if (b < 1) b = 1;
@@ -215,6 +220,88 @@ extern "C" int styler_scale_weights(const float* g, const float* weights, int n,
   t.n = n;
   for (int i = 0; i < 16; ++i) { t.p[i] = nullptr; t.w[i] = i < n ? weights[i] : 0.f; }
   hipLaunchKernelGGL(scale_weights_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, g, out);
+  return launch_status();
+}
+
+// ---- the tail of the train step's loss head in ONE launch each way (round 6) -----------------------------------------------
+// forward : out[1] = NLL3 of the main pass' classifier triple, out[2] = NLL3 of the DAT pass' (loss.py:46-48, 60-68),
+//           out[0] = sum_{i<n} w[i] * mean_i + w[n] * out[1] + w[n+1] * out[2]   (train.py:156-160, left to right)
+// backward: gw[i] = g[0] * w[i] (i < n: the upstream gradients of the masked-error means) and the six d(logp) blocks
+//           d6[k][b][:] = -(g[0] * w[n + k/3]) / B at the label, 0 elsewhere.
+// Same per-thread summation order and the same float operations as nll3_kernel / weighted_sum_kernel / scale_weights_kernel:
+// the results are bit-identical to the five-launch form (tests/test_14_train_step.py).
+struct LossTail {
+  const float* mean[8]; float w[10];
+  const float* lp[6]; const int64_t* label[2];
+  int32_t label_const[2], n, B;
+};
+
+__global__ void loss_tail_kernel(const LossTail t, float* __restrict__ out) {
+  float cls[2];
+#pragma unroll
+  for (int grp = 0; grp < 2; ++grp) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < 3 * t.B; i += 64) {
+      const int k = i / t.B, b = i - k * t.B;
+      const int l = t.label[grp] ? (int)t.label[grp][b] : t.label_const[grp];
+      s -= t.lp[3 * grp + k][b * 2 + l];
+    }
+    cls[grp] = wave_sum(s) / (float)t.B;
+  }
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < t.n; ++i) s += t.w[i] * t.mean[i][0];
+    s += t.w[t.n] * cls[0];
+    s += t.w[t.n + 1] * cls[1];
+    out[0] = s; out[1] = cls[0]; out[2] = cls[1];
+  }
+}
+
+__global__ void loss_tail_bwd_kernel(const LossTail t, const float* __restrict__ g, float* __restrict__ gw, float* __restrict__ d6) {
+  if ((int)threadIdx.x < t.n) gw[threadIdx.x] = g[0] * t.w[threadIdx.x];
+#pragma unroll
+  for (int grp = 0; grp < 2; ++grp) {
+    const float gs = g[0] * t.w[t.n + grp];
+    const float gg = -gs / (float)t.B;
+    for (int i = threadIdx.x; i < 3 * t.B; i += 64) {
+      const int k = i / t.B, b = i - k * t.B;
+      const int l = t.label[grp] ? (int)t.label[grp][b] : t.label_const[grp];
+      float* d = d6 + ((int64_t)(3 * grp + k) * t.B + b) * 2;
+      d[l] = gg; d[1 - l] = 0.f;
+    }
+  }
+}
+
+static int loss_tail_fill(LossTail& t, const float* const* means, const float* weights, int n, const float* const* lp6,
+                          const int64_t* label0, int const0, const int64_t* label1, int const1, int B) {
+  if (!weights || !lp6 || n < 0 || n > 8 || B <= 0 || (n && !means)) return STYLER_EINVAL;
+  if ((!label0 && const0 != 0 && const0 != 1) || (!label1 && const1 != 0 && const1 != 1)) return STYLER_EINVAL;
+  for (int i = 0; i < 8; ++i) { t.mean[i] = i < n ? means[i] : nullptr; if (i < n && !t.mean[i]) return STYLER_EINVAL; }
+  for (int i = 0; i < 10; ++i) t.w[i] = i < n + 2 ? weights[i] : 0.f;
+  for (int i = 0; i < 6; ++i) { t.lp[i] = lp6[i]; if (!t.lp[i]) return STYLER_EINVAL; }
+  t.label[0] = label0; t.label[1] = label1; t.label_const[0] = const0; t.label_const[1] = const1;
+  t.n = n; t.B = B;
+  return 0;
+}
+
+extern "C" int styler_loss_tail(const float* const* means, const float* weights, int n, const float* const* lp6,
+                                const int64_t* label0, int label_const0, const int64_t* label1, int label_const1, int B,
+                                float* out3, void* stream) {
+  LossTail t;
+  if (!out3) return STYLER_EINVAL;
+  if (const int rc = loss_tail_fill(t, means, weights, n, lp6, label0, label_const0, label1, label_const1, B)) return rc;
+  hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, out3);
+  return launch_status();
+}
+
+extern "C" int styler_loss_tail_bwd(const float* g, const float* weights, int n, const float* const* lp6,
+                                    const int64_t* label0, int label_const0, const int64_t* label1, int label_const1, int B,
+                                    float* gw, float* d6, void* stream) {
+  LossTail t;
+  if (!g || !d6 || (n && !gw)) return STYLER_EINVAL;
+  const float* dummy[8] = {g, g, g, g, g, g, g, g};                   // (the means are not read by the backward)
+  if (const int rc = loss_tail_fill(t, dummy, weights, n, lp6, label0, label_const0, label1, label_const1, B)) return rc;
+  hipLaunchKernelGGL(loss_tail_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, g, gw, d6);
   return launch_status();
 }
 

@@ -1734,6 +1734,41 @@ def scale_weights(g, weights):
     return out
 
 
+def _loss_tail_args(weights, lps, labels):
+    import ctypes
+    n = len(weights) - 2
+    w = (ctypes.c_float * len(weights))(*[float(x) for x in weights])
+    lp = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in lps])
+    lab = [None if isinstance(l, int) else l for l in labels]
+    const = [l if isinstance(l, int) else 0 for l in labels]
+    return n, w, lp, lab, const
+
+
+def loss_tail(means, weights, lps, labels):
+    """The tail of the train step's loss head in one launch (styler_loss_tail): `means` = n <= 8 scalar fp32 device tensors,
+    `weights` = n + 2 floats, `lps` = six [B, 2] log-probability tensors (main pass d, p, e, then DAT pass d, p, e), `labels` =
+    two int64 [B] tensors or python ints -> out [3] = (total, nll3 of the main pass, nll3 of the DAT pass)."""
+    import ctypes
+    n, w, lp, lab, const = _loss_tail_args(weights, lps, labels)
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[_f32(t).data_ptr() for t in means])
+    B = lps[0].shape[0]
+    out = torch.empty(3, device=lps[0].device, dtype=torch.float32)
+    _chk(lib.styler_loss_tail(ptrs, w, n, lp, _ptr(lab[0]), const[0], _ptr(lab[1]), const[1], B, out.data_ptr(), _stream()),
+         "styler_loss_tail")
+    return out
+
+
+def loss_tail_bwd(g, weights, lps, labels):
+    """-> (gw [n] = g * weights[:n], d6 [6, B, 2]): the backward of loss_tail in one launch."""
+    n, w, lp, lab, const = _loss_tail_args(weights, lps, labels)
+    B = lps[0].shape[0]
+    gw = torch.empty(max(n, 1), device=g.device, dtype=torch.float32)
+    d6 = torch.empty(6, B, 2, device=g.device, dtype=torch.float32)
+    _chk(lib.styler_loss_tail_bwd(_f32(g).data_ptr(), w, n, lp, _ptr(lab[0]), const[0], _ptr(lab[1]), const[1], B,
+                                  gw.data_ptr(), d6.data_ptr(), _stream()), "styler_loss_tail_bwd")
+    return gw, d6
+
+
 def nll(logp, label, gscale=None, want_grad=False):
     B = logp.shape[0]
     loss = torch.empty(1, device=logp.device, dtype=torch.float32) if not want_grad else None

@@ -81,6 +81,9 @@ class _Runtime:
     # dropout + residual + LayerNorm + pad mask as ONE launch on a 128 x 256 tile that owns whole rows (csrc/linear_ln.hip):
     # the fp32 projection never reaches HBM.  STYLER_LINEAR_LN=0: styler_conv_gemm + styler_add_layernorm (two launches).
     linear_ln = os.environ.get("STYLER_LINEAR_LN", "1") != "0"
+    # round 6: the loss head of the train step (seven masked-error means, two classifier NLL3 terms, the weighted total) as two
+    # tape nodes = 2 launches forward + 2 backward instead of 5 + 5 (training.train_losses).  STYLER_FUSED_LOSS=0: the loss modules.
+    fused_loss = os.environ.get("STYLER_FUSED_LOSS", "1") != "0"
     # throughput mode: the dX GEMM of the BiLSTM input projections (gate gradients x W_ih) on bf16 operands like every
     # other dX GEMM of the step (round 2 left these eight launches on the fp32 MFMA path: 0.2 ms per step)
     lstm_dx_bf16 = os.environ.get("STYLER_LSTM_DX_BF16", "1") != "0"

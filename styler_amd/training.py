@@ -280,6 +280,24 @@ def train_losses(model, batch, loss_fn=None, dat_fn=None):
     # labels of train.py:139,152 (zeros for the clean pass, ones for the DAT pass): passed as python ints, the NLL kernel
     # needs no label tensor then; the masks are consumed as lengths (loss.py docstring), so no ~mask launches either
     zeros, ones = 0, 1
+    sm = model.style_modeling
+    if (rt.fused_loss and type(loss_fn) is STYLERLoss and type(dat_fn) is DomainAdversarialTrainingLoss
+            and torch.is_grad_enabled() and getattr(sm, "dat_posteriors", None) is not None and mel.requires_grad):
+        # Round 6: the whole loss head as two tape nodes -- the seven masked-error means of STYLERLoss.forward + cal_mel_loss
+        # (loss.py:16-50) in ONE launch each way, and the two classifier NLL3 terms + the weighted total of train.py:156-160 in
+        # ONE launch each way (autograd.LossTailFn): 4 launches on the serial chain between forward and backward instead of 10.
+        # Same kernels / same arithmetic per term as the loss modules (STYLER_FUSED_LOSS=0: the modules).
+        from . import loss as L
+        lens, slens = batch["mel_len"], batch["src_len"]
+        mel_l, post_l, d_l, p_l, e_l, mel_nl, post_nl = L._masked_means([
+            (mel, batch["mel_target"], 0, lens), (post, batch["mel_target"], 0, lens), (log_d, batch["log_D"], 1, slens),
+            (p_pred, batch["f0"], 1, lens), (e_pred, batch["energy"], 1, lens),
+            (mel_n, batch["mel_aug"], 0, lens), (post_n, batch["mel_aug"], 0, lens)])
+        dat_post, sm.dat_posteriors = sm.dat_posteriors, None
+        weights = (1.0,) * 7 + (float(hp.dat_weight),) * 2
+        total, cls, cls_dat = AG.LossTailFn.apply(weights, zeros, ones, mel_l, post_l, mel_nl, post_nl, d_l, p_l, e_l,
+                                                  *aug, *dat_post)
+        return total, mel_l, post_l, mel_nl, post_nl, d_l, p_l, e_l, cls, cls_dat
     mel_l, post_l, d_l, p_l, e_l, cls = loss_fn(log_d, batch["log_D"], p_pred, batch["f0"], e_pred, batch["energy"],
                                                 mel, post, batch["mel_target"], None, None,
                                                 batch["src_len"], batch["mel_len"], aug, zeros)

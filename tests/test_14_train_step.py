@@ -142,6 +142,61 @@ def test_train_step_vs_oracle_vctk_shape(dev, train_model, ref_state_dict):
     train_model.load_state_dict(ref_state_dict)
 
 
+def test_loss_tail_bit_identical_to_the_five_launch_form(dev):
+    """styler_loss_tail / _bwd (round 6) against styler_nll3 x 2 + styler_weighted_sum and styler_scale_weights + styler_nll3 x 2:
+    same summation order, same float operations -> equal bit for bit; tensor labels and python-int labels."""
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for B in (1, 5, 48, 96):
+        lps = [torch.log_softmax(torch.randn(B, 2, generator=g), dim=1).to(dev) for _ in range(6)]
+        means = [torch.rand(1, generator=g).to(dev) for _ in range(7)]
+        weights = (1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.037, 0.037)
+        lab_t = torch.randint(0, 2, (B,), generator=g).to(dev)
+        for labels in ((0, 1), (lab_t, 1), (lab_t, 1 - lab_t)):
+            out = ops.loss_tail(means, weights, lps, labels)
+            c0, c1 = ops.nll3(lps[:3], labels[0]), ops.nll3(lps[3:], labels[1])
+            tot = ops.weighted_sum(means + [c0, c1], weights)
+            assert torch.equal(out, torch.cat([tot, c0, c1]))
+            gsc = torch.rand(1, generator=g).to(dev)
+            gw, d6 = ops.loss_tail_bwd(gsc, weights, lps, labels)
+            gw_ref = ops.scale_weights(gsc, weights)
+            da = ops.nll3(lps[:3], labels[0], gscale=gw_ref[7:8], want_grad=True)
+            db = ops.nll3(lps[3:], labels[1], gscale=gw_ref[8:9], want_grad=True)
+            assert torch.equal(gw[:7], gw_ref[:7]) and torch.equal(d6, torch.cat([da, db]))
+
+
+def test_fused_loss_head_equals_the_loss_modules(dev, train_model, ref_state_dict):
+    """training.train_losses with rt.fused_loss (two tape nodes for the whole loss head) against the STYLERLoss /
+    DomainAdversarialTrainingLoss modules: the ten scalars and every parameter gradient.  The masked-error sums are fp64
+    atomics in both forms (arrival order differs from launch to launch): 1e-6 relative, not bit equality."""
+    from closed_form import make_batch
+    from styler_amd import rt
+    from styler_amd.training import train_losses
+    b = {k: v.to(dev) for k, v in make_batch(4, 20, 40, 2, 9, seed=32).items()}
+    got = {}
+    keep = rt.fused_loss
+    try:
+        for fused in (False, True):
+            rt.fused_loss = fused
+            train_model.load_state_dict(ref_state_dict)
+            train_model.zero_grad(set_to_none=True)
+            losses = train_losses(train_model, b)
+            losses[0].backward()
+            got[fused] = ([float(x) for x in losses], {k: p.grad.clone() for k, p in train_model.named_parameters() if p.grad is not None})
+    finally:
+        rt.fused_loss = keep
+        train_model.load_state_dict(ref_state_dict)
+    for a, e in zip(got[True][0], got[False][0]):
+        assert abs(a - e) <= 1e-6 * max(1.0, abs(e)), (a, e)
+    assert got[True][1].keys() == got[False][1].keys()
+    for k, ge in got[False][1].items():
+        # The two forms hand autograd the same gradients in a different ORDER (a tensor with three consumers, e.g. mel, sums them
+        # as (a + b) + c or (a + c) + b): fp32 reassociation noise, largest on tensors whose true gradient is zero (w_ks.bias,
+        # the conv biases in front of BatchNorm) -- hence the floor on the scale.
+        e = float((got[True][1][k] - ge).abs().max()) / max(float(ge.abs().max()), 1e-4)
+        assert e <= 1e-4, f"{k}: fused vs modules rel grad err {e:.3e}"
+
+
 def test_train_state_steps_and_bf16(dev, ref_state_dict):
     """Flat-buffer optimiser: two steps reduce nothing to NaN, parameters move, derived layouts refresh; bf16 mode
     gradients stay close to fp32 ones."""

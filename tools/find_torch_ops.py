@@ -48,6 +48,8 @@ class Tracer(TorchDispatchMode):
             if ("styler_amd" in fr.filename or fr.filename.endswith("bench.py")) and "find_torch_ops" not in fr.filename:
                 site = f"{os.path.relpath(fr.filename, ROOT)}:{fr.lineno} {fr.name}"
                 break
+        if os.environ.get("FIND_SHAPES"):          # which tensors: shapes / dtypes of the tensor arguments
+            site += "  " + " ".join(f"{tuple(a.shape)}:{str(a.dtype)[6:]}" for a in flat[:3])
         self.counts[(name, site)] += 1
         return out
 
