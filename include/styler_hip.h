@@ -195,6 +195,16 @@ int styler_gemm_n96_config(int enabled, int min_rows);
 int64_t styler_conv_gemm_workspace_bytes(int B, int L, int cin, int n, int kw, int act, int prec, int io_flags,
                                          int64_t ldx, int packed, int has_mask);
 int styler_gemm_set_workspace(void* ptr, int64_t bytes);
+/* Round 6: `count` int32 counters, ZERO on entry (2 per 256 x 256 tile of the call: 2 * ceil(B L / 256) * (n / 256)), registered
+ * for the next styler_conv_gemm / styler_conv_gemm_packed call of this host thread next to its workspace.  A split-K = 2 launch
+ * of the 256 x 256 engine is then finished INSIDE the kernel -- the half that arrives second adds the first one's accumulators
+ * (one raw image per tile in the workspace) and runs the epilogue: no partial rows in HBM, no combine launch.  fp32 addition is
+ * commutative, so the result does not depend on the arrival order: same bits launch after launch, and the same bits as the
+ * combine pass when there is no `scale`.  The kernel leaves the counters zero (a buffer can be re-used by later calls in stream
+ * order, never by two calls that may run concurrently).  Without counters (or with STYLER_GEMM256_FIXUP=0 /
+ * styler_gemm256_fixup(0)) the launch uses the combine pass. */
+int styler_gemm_set_counters(void* ptr, int64_t count);
+int styler_gemm256_fixup(int enabled);
 /* Round 5 (bf16x3 arithmetic): producers write the operand split themselves.  The next PRODUCER call of this host thread --
  * styler_conv_gemm / styler_conv_gemm_packed (fp32 output in bf16 MFMA mode; whatever engine takes it, including its split-K
  * combine pass), styler_add_layernorm, styler_layernorm_bwd (its dx), styler_groupnorm_relu / _bwd, styler_batchnorm_train /

@@ -99,6 +99,8 @@ _SIGS = {
     "styler_groupnorm_fused_rows": [I],
     "styler_conv_gemm_workspace_bytes": [I, I, I, I, I, I, I, I, I64, I, I],
     "styler_gemm_set_workspace": [P, I64],
+    "styler_gemm_set_counters": [P, I64],
+    "styler_gemm256_fixup": [I],
     "styler_set_x3_out": [P, I],
     "styler_bn_workspace_doubles": [I64, I, I],
     "styler_fold_replicas": [P, P, P, P, P, P, I, I, P],

@@ -48,7 +48,8 @@ constexpr int STAGE_BYTES = 4 * UNIT_BYTES;         // UA0, UA1, UB0, UB1
 constexpr int U_A0 = 0, U_A1 = UNIT_BYTES, U_B0 = 2 * UNIT_BYTES, U_B1 = 3 * UNIT_BYTES;
 constexpr int SMEM_BYTES = 2 * STAGE_BYTES;         // 128 KB
 constexpr int CLD = 68;                             // epilogue staging row stride (floats): 64 + 4
-constexpr uint32_t OOB = 0x80000000u;               // beyond every descriptor's num_records (< 2^31)
+constexpr uint32_t OOB = 0x80000000u;
+constexpr int FIX_AUX = 0x11;                       // buffer cache policy sc0 | sc1: system scope (the split-K hand-over)               // beyond every descriptor's num_records (< 2^31)
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -65,7 +66,9 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t lds_
 // wave instead of 8.  Why: tile quantisation -- M = 42 336 rows x 512 columns (PostNet) is 332 tiles of 256 x 256 = 1.30
 // rounds of 256 CUs (paid as 2), but 442 tiles of 192 x 256 = 1.73 rounds of 3/4 the height (paid as 1.5); the 256-column
 // AudioEncoder convolutions are 166 tiles (0.65 of a round) against 221 (0.86 of a 3/4-height round).
-template <bool Y16, int HT>
+// FIX (round 6): a split-K = 2 launch whose second-arriving half adds the first one's accumulators and runs the epilogue (a
+// template argument: the hand-over code must not cost the other instantiations a register -- they sit at 251 of 256).
+template <bool Y16, int HT, bool FIX = false>
 __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
   static_assert(HT == 3 || HT == 4, "wave rows of 96 or 128 rows");
   constexpr int H = 64 * HT, HW = 32 * HT;                               // block rows, rows per wave row
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
   const int split = a.ksplit > 1 ? (int)blockIdx.y : 0;
   const int step0 = split * (all_steps / a.ksplit);
   const int nsteps = (split + 1 == a.ksplit ? all_steps : (split + 1) * (all_steps / a.ksplit)) - step0;
-  if (a.ksplit > 1) {                                 // partial tiles: plain fp32 rows, the epilogue proper runs in the combine pass
+  if (a.ksplit > 1 && !FIX) {                       // partial tiles: plain fp32 rows, the epilogue proper runs in the combine pass
     a.y = a.part + (int64_t)split * M * a.n;
     a.ldy = a.n;
     a.scale = a.shift = a.res = nullptr;
@@ -330,6 +333,60 @@ __global__ __launch_bounds__(512) void conv_gemm256_kernel(GemmArgs a) {
 #undef LDS_FRAG
 #undef PHASE_SYNC
   __syncthreads();                                      // every wave is done with the operand stages: LDS becomes the epilogue's
+
+  // ---- split-K = 2 finished in the kernel (round 6; was: two partial tiles to HBM + gemm256_combine_kernel).  The two halves of
+  // a tile draw a ticket.  The first stores its accumulators as they sit in the registers (32 x 16 bytes per lane, 1 KB per
+  // wave-instruction; the reader is the same wave of the other block, so no layout change), releases a flag and leaves; the
+  // second waits for the flag (the first block drew its ticket, so it is resident: the wait is bounded by its stores), adds the
+  // image to its own accumulators -- a + b == b + a in fp32, so the result does not depend on which half came first -- and runs
+  // the epilogue.  Both ints of the tile are zero again afterwards.
+  if constexpr (FIX && HT == 4) {
+    const int tile = mtile * a.nt + ntile;
+    int* const c2 = a.cnt + 2 * tile;
+    int* const role_p = reinterpret_cast<int*>(smem);
+    if (tid == 0) *role_p = atomicAdd(c2, 1);
+    __syncthreads();
+    const int role = __builtin_amdgcn_readfirstlane(*role_p);
+    __syncthreads();                                  // (the epilogue re-uses smem)
+    const __amdgpu_buffer_rsrc_t p_rs = __builtin_amdgcn_make_buffer_rsrc(a.part + (int64_t)tile * (BM * BN), 0, BM * BN * 4, 0x00020000);
+    const uint32_t po = (uint32_t)((wave * 32 * 64 + lane) * 16);
+    if (role == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = make_float4(acc[i][jj][4 * q], acc[i][jj][4 * q + 1], acc[i][jj][4 * q + 2], acc[i][jj][4 * q + 3]);
+            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const i32x4*>(&v), p_rs, po + ((i * 2 + jj) * 4 + q) * 1024, 0, FIX_AUX);
+          }
+      // The image and the flag travel with the sc0 sc1 cache policy (written through to / read from the memory side, past
+      // the per-XCD L2s): no agent-scope release fence, which on this chip writes back the WHOLE L2 of the XCD (measured:
+      // +70 us per launch with __threadfence() here).  vmcnt(0) = the stores are acknowledged; then the flag.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(c2 + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(c2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                       // eight loads (32 registers) in flight at a time: the accumulators hold 128
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const i32x4 t = __builtin_amdgcn_raw_buffer_load_b128(p_rs, po + ((i * 2 + jj) * 4 + q) * 1024, 0, FIX_AUX);
+          const float4 o = *reinterpret_cast<const float4*>(&t);
+          acc[i][jj][4 * q] += o.x; acc[i][jj][4 * q + 1] += o.y; acc[i][jj][4 * q + 2] += o.z; acc[i][jj][4 * q + 3] += o.w;
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tid == 0) { c2[0] = 0; c2[1] = 0; }
+  }
 
   // ---- epilogue: per wave, one 32-row MFMA tile row (32 x 64) at a time through LDS -> coalesced 16-byte rows ----
   // C layout of v_mfma_f32_32x32x16: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
@@ -642,6 +699,21 @@ extern "C" int64_t styler_conv_gemm_workspace_bytes(int B, int L, int cin, int n
   return ks > 1 ? (int64_t)ks * B * L * n * 4 : 0;
 }
 
+// Round 6: with zeroed int counters registered next to the workspace (2 per 256 x 256 tile of the launch) a split-K launch of this
+// engine is finished inside the kernel (no combine pass); consumed together with the workspace.  The kernel leaves them zero.
+static thread_local int* t_cnt = nullptr;
+static thread_local int64_t t_cnt_n = 0;
+static int g_fixup = [] { const char* e = getenv("STYLER_GEMM256_FIXUP"); return e ? atoi(e) : 1; }();
+extern "C" int styler_gemm_set_counters(void* ptr, int64_t count) {
+  t_cnt = reinterpret_cast<int*>(ptr); t_cnt_n = ptr ? count : 0;
+  return 0;
+}
+extern "C" int styler_gemm256_fixup(int enabled) {                   // test / A-B hook; returns the previous value
+  const int prev = g_fixup;
+  if (enabled >= 0) g_fixup = enabled ? 1 : 0;
+  return prev;
+}
+
 void styler_gemm_take_workspace(void** ws, int64_t* bytes) {
   *ws = t_ws; *bytes = t_ws_bytes;
   t_ws = nullptr; t_ws_bytes = 0;
@@ -658,6 +730,8 @@ int styler_gemm_combine(const GemmArgs& a0, int ks, int y16, hipStream_t st) {
 }
 
 int styler_gemm256_try(const GemmArgs& a0, int x16, int y16, hipStream_t st, void* ws, int64_t ws_bytes) {
+  int* const cnt = t_cnt; const int64_t cnt_n = t_cnt_n;          // consumed by this call, whatever path it takes
+  t_cnt = nullptr; t_cnt_n = 0;
   if (a0.trace) return 0;
   int mt, nt;
   const int64_t M = (int64_t)a0.B * a0.L;
@@ -668,6 +742,14 @@ int styler_gemm256_try(const GemmArgs& a0, int x16, int y16, hipStream_t st, voi
     a.mt = (int)((M + BM - 1) / BM); a.nt = a0.n / BN;
     a.ksplit = ks; a.part = reinterpret_cast<float*>(ws);
     const dim3 grid((unsigned)(((a.mt + 7) / 8) * 8 * a.nt), (unsigned)ks);
+    if (g_fixup && ks == 2 && cnt && cnt_n >= 2 * (int64_t)a.mt * a.nt && !((uintptr_t)cnt & 3) &&
+        (int64_t)a.mt * a.nt * BM * BN * 4 <= ws_bytes) {          // finished in the kernel: one raw accumulator image per tile
+      a.cnt = cnt;
+      if (y16) hipLaunchKernelGGL((conv_gemm256_kernel<true, 4, true>), grid, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((conv_gemm256_kernel<false, 4, true>), grid, dim3(512), 0, st, a);
+      const int rc = launch_status();
+      return rc ? (rc < 0 ? rc : -rc) : 1;
+    }
     hipLaunchKernelGGL((conv_gemm256_kernel<false, 4>), grid, dim3(512), 0, st, a);
     int rc = launch_status();
     if (!rc) rc = styler_gemm_combine(a, ks, y16, st);

@@ -21,6 +21,8 @@ struct GemmArgs {
   uint64_t* trace;                                 // styler_gemm_set_trace: 8 words per block (phase timestamps), or null
   int ksplit = 1;                                  // gemm256.hip: split-K factor of the launch (1 or 2)
   float* part = nullptr;                           // ... and its fp32 partial tiles [ksplit][B*L][n] (styler_gemm_set_workspace)
+  int* cnt = nullptr;                              // round 6, split-K = 2 finished IN the kernel: 2 ints per tile (ticket, flag), zero on entry and
+                                                   // on exit; `part` then holds ONE raw accumulator image per tile (styler_gemm_set_counters)
   int res16 = 0;                                   // the residual tensor is bf16 (STYLER_IO_RES_BF16; ldres in elements)
   int x3n1 = 0;                                    // STYLER_IO_X3A: x rows hold [hi | lo] of cin / 3 channels each; x3n1 = (cin / 3) / 64 chunks per part,
                                                    // channel chunk cc >= 2 * x3n1 (the third product) reads chunk cc - 2 * x3n1 (hi again)

@@ -90,13 +90,16 @@ __device__ __forceinline__ void masked_err_mean_body(const float* __restrict__ a
   if (lane == 0) { red[wave][0] = s; red[wave][1] = n; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&acc[0], red[0][0] + red[1][0] + red[2][0] + red[3][0]);
-    atomicAdd(&acc[1], red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+    // The two sums are device-scope atomics (performed at the memory side, coherent across the XCDs); the ticket may only be
+    // drawn once they have been PERFORMED, i.e. once their return values are back -- a data dependency plus vmcnt(0), not
+    // __threadfence(): an agent-scope release fence writes back the whole L2 of the XCD, and every block of every term paid
+    // one (round 6: the kernel's time was those write-backs, 30 -> 12 us for the five terms of the clean pass).
+    const double r0 = atomicAdd(&acc[0], red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+    const double r1 = atomicAdd(&acc[1], red[0][1] + red[1][1] + red[2][1] + red[3][1]);
     if (mean_out) {
-      __threadfence();
+      asm volatile("s_waitcnt vmcnt(0)" :: "v"(r0), "v"(r1) : "memory");
       const unsigned long long t = atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2]), 1ull);
       if (t == (unsigned long long)nbx - 1) {
-        __threadfence();
         const double tot = atomicAdd(&acc[0], 0.0), cnt = atomicAdd(&acc[1], 0.0);   // read at the atomics' coherence point
         mean_out[0] = (float)(tot / cnt);
       }

@@ -26,6 +26,7 @@ def _chk(rc, name):
         # the split-K workspace): drop them, so the NEXT call cannot write into a buffer the unwinding frees (round-5 advisor)
         lib.styler_set_x3_out(None, 0)
         lib.styler_gemm_set_workspace(None, 0)
+        lib.styler_gemm_set_counters(None, 0)
         raise StylerHipError(f"{name} failed with code {rc}")
 
 
@@ -564,6 +565,12 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
         if need and lens is None:
             ws = torch.empty(need, device=x.device, dtype=torch.uint8)
             lib.styler_gemm_set_workspace(ws.data_ptr(), need)
+            if (io & 1) and n % 256 == 0:            # the 256 x 256 engine finishes its split-K = 2 launches in the kernel when it
+                ncnt = 2 * ((B * L + 255) // 256) * (n // 256)     # gets zeroed tile counters (it leaves them zero)
+                cnt = zero_slab.take((ncnt + 1) // 2) if zero_slab is not None else None
+                if cnt is None:
+                    cnt = torch.zeros(ncnt, device=x.device, dtype=torch.int32)
+                lib.styler_gemm_set_counters(cnt.data_ptr(), ncnt)
     y3 = None
     if x3_out and prec == PREC_BF16 and out.dtype == torch.float32 and out.is_contiguous() and prof is None:
         # (bf16x3: this output is the activation operand of a following GEMM -- its split leaves with the epilogue)
@@ -584,6 +591,7 @@ def conv_gemm(x, w, bias=None, *, kw=1, n=None, act=ACT_NONE, prec=PREC_F32, sca
                                   _stream()), "styler_conv_gemm")
     if ws is not None:
         lib.styler_gemm_set_workspace(None, 0)       # (consumed by the call above; cleared again in case it never got there)
+        lib.styler_gemm_set_counters(None, 0)
     if y3 is not None:
         lib.styler_set_x3_out(None, 0)
         x3_register(out, y3, plan)

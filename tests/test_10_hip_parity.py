@@ -323,6 +323,15 @@ def test_gemm256_split_k(dev, packed):
         assert ops.lib.styler_conv_gemm_workspace_bytes(shape[0], shape[1], cin, n, kw, 0, ops.PREC_BF16, 1, cin, int(packed), 0) \
             == 2 * shape[0] * shape[1] * n * 4
         ys = [run().clone() for _ in range(3)]
+        # round 6: the launches above were finished INSIDE the kernel (zeroed tile counters next to the workspace); the
+        # combine-pass form (styler_gemm256_fixup(0)) adds the same two halves: same bits (no `scale` here)
+        prev_fix = ops.lib.styler_gemm256_fixup(0)
+        try:
+            assert prev_fix == 1
+            yc = run().clone()
+        finally:
+            ops.lib.styler_gemm256_fixup(prev_fix)
+        assert torch.equal(yc.reshape(-1, n)[:int(lens.sum()) if packed else B * T], ys[0].reshape(-1, n)[:int(lens.sum()) if packed else B * T])
         ops.gemm256_config(1, -1, split=1, take_all=1)
         y1 = run()
         ops.gemm256_config(0)
