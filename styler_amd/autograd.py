@@ -580,6 +580,8 @@ class EmbedPosFn(Function):
     def backward(ctx, dy):
         (text,) = ctx.saved_tensors
         ops.embed_bwd(text, dy, G(ctx.emb.weight))
+        if rt.text_ready_hook is not None:      # the text encoder is back-propagated: the first range of the flat gradient is final
+            rt.text_ready_hook()
         return None, None, None, None
 
 

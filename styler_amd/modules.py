@@ -223,7 +223,7 @@ class StyleEncoder(_HipModule):
     def forward(self, text, speaker_embed, mel_target, p_norm, e_input, mel_aug, mel_len, src_len, src_mask,
                 text_out=None):
         side = None
-        if rt.text_stream and self.training and torch.is_grad_enabled():
+        if rt.text_stream and not rt.ar_text_point and self.training and torch.is_grad_enabled():
             # the text encoder (two FFT blocks on [B, S] rows: ~40 launch-latency-bound kernels) on a side stream next to
             # the AudioEncoder's T-domain convolutions; autograd replays each node's backward on its forward stream, so
             # the two backward chains overlap the same way (rt.text_stream)

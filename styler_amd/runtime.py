@@ -9,6 +9,7 @@ class _Runtime:
         self.prec = ops.PREC_F32        # PREC_F32: exact-fp32 MFMA (parity mode); PREC_BF16: throughput mode
         self.strict_inputs = True       # raise like the reference's assert on p_norm / e_input outside [0, 1]
         self.grad_ready_hook = None     # set by training.train_step: called when the decoder-side gradients are final
+        self.text_ready_hook = None     # ... and when the text encoder's are (rt.ar_text_point; autograd.EmbedPosFn.backward)
         self.weights_epoch = 0          # bumped by TrainState.step(): invalidates every derived weight layout
         self.base_seed = 0              # train.py:22 seeds torch with 0
         self.seed = 0                   # dropout stream seed of this process: base_seed * world + rank (TrainState)
@@ -34,6 +35,14 @@ class _Runtime:
     # the text encoder (S-domain, launch-latency-bound) on a side stream next to the AudioEncoder's T-domain convolutions,
     # forward and (through autograd's stream bookkeeping) backward: 15.11 -> 15.00, 15.20 -> 15.03 ms same-box A/B
     text_stream = os.environ.get("STYLER_TEXT_STREAM", "1") != "0"
+
+    # Round 6 (several ranks): a THIRD launch point of the gradient all-reduce.  The text encoder's parameters are the first 23.3 MB
+    # of the flat gradient and its backward ends (autograd.EmbedPosFn) while the AudioEncoder's -- the last 1.3 ms of a backward pass --
+    # has not begun: with the switch on their all-reduce starts there (eager: TrainState.on_text_grads_ready; graphed step: a second
+    # cut, three graphs), and step() only waits for the remaining 31 MB (AudioEncoder, style MLPs, predictors) instead of 54 MB.
+    # It keeps the text encoder on the main stream (no rt.text_stream: a graph cut needs every forked stream joined).  Off by
+    # default: no multi-GPU node has run this path yet (STYLER_AR_TEXT_POINT=1; tests/test_15_dist_gpu.py covers both settings).
+    ar_text_point = os.environ.get("STYLER_AR_TEXT_POINT", "0") == "1"
 
     # Round 5: everything that only feeds the LOSS of a teacher-forced training step on ONE side stream next to the main chain.
     # The decoder is fed from the TARGET durations / pitch / energy (modules.py:352-381), so the duration / pitch / energy predictors

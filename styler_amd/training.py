@@ -47,6 +47,10 @@ class TrainState:
         # all-reduce is launched from there and overlaps the rest of backward (style encoders, predictors, DAT pass)
         self.tail_start = self._tail_offset(model, params, align)
         self._tail_works = None
+        # rt.ar_text_point: the text encoder's parameters open the flat buffer ([0, text_end), 23.3 MB); 0 = no such prefix
+        self.text_end = self._prefix_end(model, params, align, "style_modeling.style_encoder.text_encoder.")
+        self._text_works = None
+        self.text_hook = None                          # set while GraphedTrainStep captures (the second cut)
         self.ar_events = None          # diagnostic: a list here makes step() / on_decoder_grads_ready time the collectives
         self._ar_t0 = None
         # optional bf16 transport of the gradient all-reduce (dist.Bf16Reducer; off by default)
@@ -115,9 +119,26 @@ class TrainState:
             off += align(p.numel())
         return off
 
+    @staticmethod
+    def _prefix_end(model, params, align, prefix):
+        """Flat offset behind the parameters whose names start with `prefix`, if exactly those open the buffer (else 0)."""
+        names = {id(p): n_ for n_, p in model.named_parameters()}
+        off, seen_other = 0, False
+        end = 0
+        for p in params:
+            if names.get(id(p), "").startswith(prefix):
+                if seen_other:
+                    return 0
+                end = off + align(p.numel())
+            else:
+                seen_other = True
+            off += align(p.numel())
+        return end
+
     def zero_grad(self):
         self.flat_g.zero_()
         self._tail_works = None
+        self._text_works = None
         if self.reducer is not None:                  # a skipped step must not leave ranges that finish() would cast up again
             self.reducer.pending = []
         self._accum = 0
@@ -161,6 +182,13 @@ class TrainState:
                 self._ar_t0 = torch.cuda.Event(enable_timing=True)
                 self._ar_t0.record()
 
+    def on_text_grads_ready(self):
+        """rt.ar_text_point -- called from EmbedPosFn.backward (the text encoder fully back-propagated; the AudioEncoder's backward
+        is still to come): start the all-reduce of the first range of the flat gradient, [0, text_end)."""
+        if self._text_works is None and self.text_end > 0:
+            self.arena.flush(self.flat_g.device)      # fold the split-K partials written so far (the text encoder's among them)
+            self._text_works = self._start_allreduce(0, self.text_end)
+
     def lr(self):
         """optimizer.py:21-32: the counter is incremented BEFORE the rate is computed."""
         self.n_current_steps += 1
@@ -173,10 +201,11 @@ class TrainState:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         overlapped = self._tail_works is not None
+        lo = self.text_end if self._text_works is not None else 0   # (the text encoder's range may be in flight as well)
         if overlapped:                                       # tail range already in flight: reduce only the head
-            works = self._tail_works + self._start_allreduce(0, self.tail_start)
+            works = self._tail_works + (self._text_works or []) + self._start_allreduce(lo, self.tail_start)
         else:
-            works = self._start_allreduce(0, self.n)
+            works = (self._text_works or []) + self._start_allreduce(lo, self.n)
         for w in works:
             w.wait()
         if ev is not None:
@@ -186,6 +215,7 @@ class TrainState:
         if self.reducer is not None:
             self.reducer.finish()
         self._tail_works = None
+        self._text_works = None
         self._accum = 0
         lr = self.lr()
         self.adam_steps += 1
@@ -218,18 +248,22 @@ class TrainState:
         if win:
             out["overlap_window_ms"] = round(med(win), 3)
         es = 2 if self.reducer is not None else 4
-        out["exposed_bytes"] = self.tail_start * es
-        out["overlapped_bytes"] = (self.n - self.tail_start) * es
+        text = self.text_end if rt.ar_text_point else 0
+        out["exposed_bytes"] = (self.tail_start - text) * es
+        out["overlapped_bytes"] = (self.n - self.tail_start + text) * es
         return out
 
     def allreduce_info(self):
         """What one step exchanges (bench.py prints it, so a silent fallback of the overlap is visible)."""
         tail = self.n - self.tail_start
+        text = self.text_end if rt.ar_text_point else 0
         es = 2 if self.reducer is not None else 4
         nb = lambda k: (k * es + BUCKET_BYTES - 1) // BUCKET_BYTES
         return {"allreduce_bytes": self.n * es, "allreduce_dtype": "bf16" if es == 2 else "fp32",
-                "allreduce_bucket_bytes": BUCKET_BYTES, "allreduce_buckets": nb(tail) + nb(self.tail_start),
-                "allreduce_overlapped_bytes": tail * es, "allreduce_world": world_size()}
+                "allreduce_bucket_bytes": BUCKET_BYTES,
+                "allreduce_buckets": nb(tail) + nb(self.tail_start - text) + (nb(text) if text else 0),
+                "allreduce_overlapped_bytes": (tail + text) * es, "allreduce_launch_points": 3 if text else 2,
+                "allreduce_world": world_size()}
 
 
 _seed_cache = {}
@@ -345,6 +379,8 @@ def forward_backward(model, state, batch, loss_fn=None, dat_fn=None):
                                                   if (state.overlap_allreduce and last_micro) else None)
         if rt.grad_ready_hook is None and rt.early_flush:
             rt.grad_ready_hook = state.early_flush_on_side
+        rt.text_ready_hook = state.text_hook or (state.on_text_grads_ready if (state.overlap_allreduce and last_micro and
+                                                                                 rt.ar_text_point and world_size() > 1) else None)
         state.arena.begin(state.flat_g.device)
         ops.wgrad_arena = state.arena
         # loss / acc_steps (train.py:175) as the seed gradient of backward: no division kernel, no ones_like
@@ -353,6 +389,7 @@ def forward_backward(model, state, batch, loss_fn=None, dat_fn=None):
         state.arena.flush(state.flat_g.device)         # one launch folds all split-K partials into flat_g
     finally:
         rt.grad_ready_hook = None
+        rt.text_ready_hook = None
         ops.wgrad_arena = None
         ops.zero_slab = None
         ops.x3_cache = None
@@ -449,6 +486,8 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream())
         if split:                                       # same flush pattern as the split capture: its descriptor tables
             state.split_hook = lambda: state.arena.flush(state.flat_g.device)   # must exist before (no H2D in a capture)
+            if rt.ar_text_point and state.text_end > 0:
+                state.text_hook = lambda: state.arena.flush(state.flat_g.device)
         keep = [(b, b.detach().clone()) for b in model.buffers()]
         epoch, calls, accum = state.drop_epoch.clone(), rt.dropout_calls, state._accum
         grads = state.flat_g.clone() if accum else None
@@ -474,6 +513,7 @@ class GraphedTrainStep:
                                   f"atomic fallbacks (not bit-reproducible)", RuntimeWarning)
         finally:
             state.split_hook = None
+            state.text_hook = None
         torch.cuda.current_stream().wait_stream(side)
         with torch.no_grad():
             for b, v in keep:
@@ -490,8 +530,10 @@ class GraphedTrainStep:
         """Two graphs sharing one memory pool, cut inside backward by the decoder-gradients-ready hook.  Backward must run
         on the capturing thread for that (a stream capture is ended by the thread that began it)."""
         import gc
+        three = bool(rt.ar_text_point and state.text_end > 0)    # a second cut where the text encoder's gradients are final
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        cut = {"done": False}
+        gc_ = torch.cuda.CUDAGraph() if three else None
+        cut = {"done": False, "text": False}
 
         def split_here():
             if cut["done"]:
@@ -503,6 +545,16 @@ class GraphedTrainStep:
                 ops.loss_side_stream.wait_stream(torch.cuda.current_stream())
             cut["done"] = True
 
+        def split_text():
+            if cut["text"] or not cut["done"]:
+                return
+            state.arena.flush(state.flat_g.device)      # (the text encoder's deferred weight gradients and partial tiles)
+            gb.capture_end()
+            gc_.capture_begin(pool=ga.pool())
+            if ops.loss_side_stream is not None:
+                ops.loss_side_stream.wait_stream(torch.cuda.current_stream())
+            cut["text"] = True
+
         gc.collect()
         torch.cuda.empty_cache()
         stream = torch.cuda.Stream()
@@ -510,20 +562,24 @@ class GraphedTrainStep:
         mt = torch.autograd.is_multithreading_enabled()
         torch.autograd.set_multithreading_enabled(False)
         state.split_hook = split_here
+        state.text_hook = split_text if three else None
         try:
             with torch.cuda.stream(stream), torch.enable_grad():
                 ga.capture_begin()
                 try:
                     self.losses = forward_backward(model, state, self.static, loss_fn, dat_fn)
                 finally:
-                    (gb if cut["done"] else ga).capture_end()
+                    (gc_ if cut["text"] else gb if cut["done"] else ga).capture_end()
         finally:
             state.split_hook = None
+            state.text_hook = None
             torch.autograd.set_multithreading_enabled(mt)
         torch.cuda.current_stream().wait_stream(stream)
         if not cut["done"]:
             raise RuntimeError("backward never reached the decoder-gradients-ready hook")
-        self.graphs = (ga, gb)
+        if three and not cut["text"]:
+            raise RuntimeError("backward never reached the text-encoder-gradients-ready hook")
+        self.graphs = (ga, gb, gc_) if three else (ga, gb)
 
     def __call__(self, batch=None):
         if batch is not None:
@@ -542,9 +598,12 @@ class GraphedTrainStep:
         st = self.state
         st._accum = 1                                   # the captured pass starts with its own zero_grad
         self.graphs[0].replay()
-        if len(self.graphs) == 2:
+        if len(self.graphs) >= 2:
             st._tail_works = st._start_allreduce(st.tail_start, st.n)     # overlaps the second graph
             self.graphs[1].replay()
+        if len(self.graphs) == 3:                                         # rt.ar_text_point: the text encoder's range overlaps the third
+            st._text_works = st._start_allreduce(0, st.text_end)
+            self.graphs[2].replay()
         lr = st.step()
         return self.losses, lr
 

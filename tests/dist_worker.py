@@ -79,9 +79,13 @@ def main():
         fired = []
         orig = state.on_decoder_grads_ready
         state.on_decoder_grads_ready = lambda: (fired.append(state._accum), orig())[1]
+        fired_text = []
+        orig_text = state.on_text_grads_ready
+        state.on_text_grads_ready = lambda: (fired_text.append(state._accum), orig_text())[1]
         for mb in micro_batches(gb, idx):
             losses, lr = train_step(model, state, {k: v.to(dev) for k, v in mb.items()})
         res["hook_fired_at"] = fired
+        res["text_hook_fired_at"] = fired_text
     elif mode in ("buckets", "buckets_sync"):
         # two consecutive optimisation steps through the graph cache, every rank with its own padded shapes per step;
         # "buckets_sync": the ranks exchange their shapes and capture every missing shape of the job in the same step

@@ -101,6 +101,32 @@ def test_two_rank_accumulation_with_overlapped_allreduce(tmp_path, ref_state_dic
     assert float((r0["flat_p"] - flat_p).abs().max()) <= 1e-6
 
 
+@pytest.mark.parametrize("mode", ["graph", "acc2"])
+def test_two_rank_third_launch_point(tmp_path, ref_state_dict, monkeypatch, mode):
+    """STYLER_AR_TEXT_POINT=1 (round 6): the text encoder's range of the flat gradient -- its first 23.3 MB -- is all-reduced from
+    the point where the text encoder is back-propagated (EmbedPosFn.backward), next to the AudioEncoder's backward: a THIRD graph
+    in the graphed step, a second hook in the eager one (which, like the first, may only fire on the last micro-batch of an
+    accumulation window).  Same summed gradient and parameters as one rank accumulating the shards."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_worker import global_batch, micro_batches, shard_batch
+    r0, r1 = _run_ranks(tmp_path, mode, {"STYLER_AR_TEXT_POINT": "1"})
+    assert r0["info"]["allreduce_launch_points"] == 3
+    assert r0["info"]["allreduce_overlapped_bytes"] > 0.7 * r0["info"]["allreduce_bytes"]
+    gb = global_batch()
+    if mode == "graph":
+        assert r0["graphs"] == r1["graphs"] == 3, "the three-graph capture fell back"
+        window = [shard_batch(gb, r["idx"]) for r in (r0, r1)]
+    else:
+        assert r0["hook_fired_at"] == r1["hook_fired_at"] == [2], r0["hook_fired_at"]
+        assert r0["text_hook_fired_at"] == r1["text_hook_fired_at"] == [2], r0["text_hook_fired_at"]
+        window = [mb for r in (r0, r1) for mb in micro_batches(gb, r["idx"])]
+    mean_g, flat_p, lr = _single_rank(ref_state_dict, monkeypatch, [window])
+    err_g = float((0.5 * r0["flat_g"] - mean_g).abs().max()) / float(mean_g.abs().max())
+    assert err_g <= 1e-5, err_g
+    assert lr == r0["lr"]
+    assert float((r0["flat_p"] - flat_p).abs().max()) <= 1e-6
+
+
 def test_two_rank_graph_cache_two_steps_different_shapes(tmp_path, ref_state_dict, monkeypatch):
     """Two consecutive optimisation steps through GraphedStepCache on two ranks, each rank with its own padded shapes in
     each step (two captures per rank, at different times relative to the peer's collectives): same trajectory as one
