@@ -7,7 +7,7 @@ and plain tensors; it holds no nn.Module state.
 
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import
 this module, and only as the checker / the timed CPU baseline.  Nothing under
-`styler_amd/` may import it (tests/test_no_oracle_in_product.py enforces that).
+`styler_amd/` may import it (tests/test_01_host_cpu.py::test_product_never_imports_oracle enforces that).
 
 Pinning: the reference ships no tests or golden vectors, so this
 oracle is pinned against outputs of the reference itself, generated in the build
