@@ -236,9 +236,9 @@ int styler_cast_from_bf16(const uint16_t* src, float* dst, int64_t count, void* 
  * (+ src2[same index] when src2 != 0); strides in elements, may be negative with src pre-offset.
  * flags: bit0 = bf16 destination; bit1 = tiled transpose: the caller asserts ds2 == 1, ss0 == d1, ss1 == +1 or -1 (src
  * pre-offset to the element (0, 0, 0) as always) and ss2 = the row stride of the source: the descriptor then owns
- * ceil(d2 / 32) * ceil(d0*d1 / 64) blocks, each moving a [32 a2] x [64 merged (a0, a1)] tile through LDS (the transposed
+ * ceil(d2 / 64) * ceil(d0*d1 / 64) blocks, each moving a [64 a2] x [64 merged (a0, a1)] tile through LDS (the transposed
  * dX weight layouts: coalesced on both sides); bit2 = tap interleave: ds2 == 1, ss1 == 1, ss2 == d1 <= 9 (the [n, kw, cin]
- * conv layout from [n, cin, kw]): d0 * ceil(d2 / 128) blocks, each moving 128 a2 values x d1 taps of one a0. */
+ * conv layout from [n, cin, kw]): ceil(d0 / 2) * ceil(d2 / 128) blocks, each moving 128 a2 values x d1 taps of two a0. */
 typedef struct {
   uint64_t src, src2, dst;
   int64_t ss0, ss1, ss2, ds0, ds1, ds2, block_start;

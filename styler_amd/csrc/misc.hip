@@ -602,39 +602,61 @@ __global__ __launch_bounds__(256) void strided_copy_multi_kernel(const StylerCop
     // destination element per thread, a wave touched 64 different cache lines for 256 useful bytes (32x the bytes through
     // L1 / L2: this launch took 300 us for 59 M elements).  Here a block moves a [32 a2] x [64 m] tile through LDS: reads
     // are 256-byte runs along m, writes 32-element runs along a2.
-    __shared__ float tile[32][65];
+    // Round 6: a block moves a [64 a2] x [64 m] tile (was 32 x 64): 16 independent 256-byte row reads per wave in flight
+    // (8 before: the launch ran at 3 TB/s, latency-bound), written as 64-element runs along a2, two bf16 per store.
+    __shared__ float tile[64][65];
     const uint32_t M = (uint32_t)d.d0 * (uint32_t)d.d1, N2 = (uint32_t)d.d2;
     const uint32_t mt = (M + 63u) / 64u;
     const uint32_t t = (uint32_t)(bid - d.block_start);
-    const uint32_t n0 = (t / mt) * 32u, m0 = (t % mt) * 64u;
+    const uint32_t n0 = (t / mt) * 64u, m0 = (t % mt) * 64u;
     const float* srcp = reinterpret_cast<const float*>(d.src) + (d.ss1 < 0 ? -(int64_t)(d.d1 - 1) : 0);
     const float* src2p = d.src2 ? reinterpret_cast<const float*>(d.src2) + (d.ss1 < 0 ? -(int64_t)(d.d1 - 1) : 0) : nullptr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float vv[16];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const uint32_t nn = n0 + wave * 8 + rr, m = m0 + lane;
+    for (int rr = 0; rr < 16; ++rr) {
+      const uint32_t nn = n0 + wave * 16 + rr, m = m0 + lane;
       float v = 0.f;
       if (nn < N2 && m < M) {
         const int64_t si = (int64_t)nn * d.ss2 + m;
         v = srcp[si];
         if (src2p) v += src2p[si];
       }
-      tile[wave * 8 + rr][lane] = v;
+      vv[rr] = v;
     }
-    __syncthreads();
-    const uint32_t nl = threadIdx.x & 31, ms = threadIdx.x >> 5;       // 32 a2 values x 8 m values per pass
-    const uint32_t ud1t = (uint32_t)d.d1;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const uint32_t ml = p * 8 + ms, m = m0 + ml, nn = n0 + nl;
-      if (m >= M || nn >= N2) continue;
-      const uint32_t a0 = m / ud1t, tt = m % ud1t;
-      const uint32_t a1 = d.ss1 < 0 ? ud1t - 1u - tt : tt;
-      const int64_t o = (int64_t)a0 * d.ds0 + (int64_t)a1 * d.ds1 + nn;
-      float v = tile[nl][ml];
-      if (d.flags & 8) v = bf16_lo_part(v);
-      if (d.flags & 1) reinterpret_cast<uint16_t*>(d.dst)[o] = (uint16_t)f32_to_bf16_bits(v);
-      else reinterpret_cast<float*>(d.dst)[o] = v;
+    for (int rr = 0; rr < 16; ++rr) tile[wave * 16 + rr][lane] = vv[rr];
+    __syncthreads();
+    const uint32_t ud1t = (uint32_t)d.d1;
+    const bool pair2 = !(N2 & 1u) && !(d.ds0 & 1) && !(d.ds1 & 1) && !((uintptr_t)d.dst & ((d.flags & 1) ? 3 : 7));
+    if (pair2) {
+      const uint32_t nl = (threadIdx.x & 31) * 2u, ms = threadIdx.x >> 5;     // 32 a2 pairs x 8 m values per pass
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const uint32_t ml = p * 8 + ms, m = m0 + ml, nn = n0 + nl;
+        if (m >= M || nn >= N2) continue;
+        const uint32_t a0 = m / ud1t, tt = m % ud1t;
+        const uint32_t a1 = d.ss1 < 0 ? ud1t - 1u - tt : tt;
+        const int64_t o = (int64_t)a0 * d.ds0 + (int64_t)a1 * d.ds1 + nn;
+        float v0 = tile[nl][ml], v1 = tile[nl + 1][ml];
+        if (d.flags & 8) { v0 = bf16_lo_part(v0); v1 = bf16_lo_part(v1); }
+        if (d.flags & 1) *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(d.dst) + o) = pack_bf16x2(v0, v1);
+        else *reinterpret_cast<float2*>(reinterpret_cast<float*>(d.dst) + o) = make_float2(v0, v1);
+      }
+    } else {
+      const uint32_t nl = threadIdx.x & 63, ms = threadIdx.x >> 6;            // 64 a2 values x 4 m values per pass
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const uint32_t ml = p * 4 + ms, m = m0 + ml, nn = n0 + nl;
+        if (m >= M || nn >= N2) continue;
+        const uint32_t a0 = m / ud1t, tt = m % ud1t;
+        const uint32_t a1 = d.ss1 < 0 ? ud1t - 1u - tt : tt;
+        const int64_t o = (int64_t)a0 * d.ds0 + (int64_t)a1 * d.ds1 + nn;
+        float v = tile[nl][ml];
+        if (d.flags & 8) v = bf16_lo_part(v);
+        if (d.flags & 1) reinterpret_cast<uint16_t*>(d.dst)[o] = (uint16_t)f32_to_bf16_bits(v);
+        else reinterpret_cast<float*>(d.dst)[o] = v;
+      }
     }
     return;
   }
@@ -642,23 +664,61 @@ __global__ __launch_bounds__(256) void strided_copy_multi_kernel(const StylerCop
     // Tap interleave (flags bit2): dst [a0][a1][a2] <- src[a0 * ss0 + a2 * d1 + a1]: the [n, kw, cin] conv layout from the
     // parameter's [n, cin, kw].  Inside one a0 the source is ONE contiguous run of d1 * d2 elements; a block moves 128
     // a2 values x all d1 taps of one a0 through LDS (read as a contiguous run, written as d1 runs of 128).
-    __shared__ float run[128 * 9 + 8];
+    // Round 6: a block takes TWO consecutive a0 (was one: 384-1152 elements per block, one or two loads in flight per thread);
+    // every load of the block is issued before the first LDS write.
+    __shared__ float run[2][128 * 9 + 8];
     const uint32_t ud1k = (uint32_t)d.d1, ud2k = (uint32_t)d.d2;
     const uint32_t ct = (ud2k + 127u) / 128u;
     const uint32_t t = (uint32_t)(bid - d.block_start);
-    const uint32_t a0 = t / ct, c0 = (t % ct) * 128u;
+    const uint32_t a0p = (t / ct) * 2u, c0 = (t % ct) * 128u;
     const uint32_t cn = ud2k - c0 < 128u ? ud2k - c0 : 128u;
-    const float* sp = reinterpret_cast<const float*>(d.src) + (int64_t)a0 * d.ss0 + (int64_t)c0 * ud1k;
-    const float* sp2 = d.src2 ? reinterpret_cast<const float*>(d.src2) + (int64_t)a0 * d.ss0 + (int64_t)c0 * ud1k : nullptr;
-    for (uint32_t i = threadIdx.x; i < cn * ud1k; i += 256u) run[i] = sp[i] + (sp2 ? sp2[i] : 0.f);
+    const uint32_t tot = cn * ud1k;                                      // <= 1152: five passes of 256 threads
+    float vv[2][5];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const uint32_t a0 = a0p + r;
+      const bool okr = a0 < (uint32_t)d.d0;
+      const float* sp = reinterpret_cast<const float*>(d.src) + (int64_t)(okr ? a0 : 0) * d.ss0 + (int64_t)c0 * ud1k;
+      const float* sp2 = d.src2 ? reinterpret_cast<const float*>(d.src2) + (int64_t)(okr ? a0 : 0) * d.ss0 + (int64_t)c0 * ud1k : nullptr;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const uint32_t i = threadIdx.x + (uint32_t)k * 256u;
+        vv[r][k] = (okr && i < tot) ? sp[i] + (sp2 ? sp2[i] : 0.f) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const uint32_t i = threadIdx.x + (uint32_t)k * 256u;
+        if (i < tot) run[r][i] = vv[r][k];
+      }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < cn * ud1k; i += 256u) {
-      const uint32_t a1 = i / cn, c = i - a1 * cn;
-      float v = run[c * ud1k + a1];
-      if (d.flags & 8) v = bf16_lo_part(v);
-      const int64_t o = (int64_t)a0 * d.ds0 + (int64_t)a1 * d.ds1 + c0 + c;
-      if (d.flags & 1) reinterpret_cast<uint16_t*>(d.dst)[o] = (uint16_t)f32_to_bf16_bits(v);
-      else reinterpret_cast<float*>(d.dst)[o] = v;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const uint32_t a0 = a0p + r;
+      if (a0 >= (uint32_t)d.d0) break;
+      const bool pr = !(cn & 1u) && !(c0 & 1u) && !(d.ds0 & 1) && !(d.ds1 & 1) && !((uintptr_t)d.dst & ((d.flags & 1) ? 3 : 7));
+      if (pr) {                                                            // two consecutive channels per store
+        const uint32_t hn = cn >> 1;
+        for (uint32_t i = threadIdx.x; i < hn * ud1k; i += 256u) {
+          const uint32_t a1 = i / hn, c = (i - a1 * hn) * 2u;
+          float v0 = run[r][c * ud1k + a1], v1 = run[r][(c + 1) * ud1k + a1];
+          if (d.flags & 8) { v0 = bf16_lo_part(v0); v1 = bf16_lo_part(v1); }
+          const int64_t o = (int64_t)a0 * d.ds0 + (int64_t)a1 * d.ds1 + c0 + c;
+          if (d.flags & 1) *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(d.dst) + o) = pack_bf16x2(v0, v1);
+          else *reinterpret_cast<float2*>(reinterpret_cast<float*>(d.dst) + o) = make_float2(v0, v1);
+        }
+      } else {
+        for (uint32_t i = threadIdx.x; i < tot; i += 256u) {
+          const uint32_t a1 = i / cn, c = i - a1 * cn;
+          float v = run[r][c * ud1k + a1];
+          if (d.flags & 8) v = bf16_lo_part(v);
+          const int64_t o = (int64_t)a0 * d.ds0 + (int64_t)a1 * d.ds1 + c0 + c;
+          if (d.flags & 1) reinterpret_cast<uint16_t*>(d.dst)[o] = (uint16_t)f32_to_bf16_bits(v);
+          else reinterpret_cast<float*>(d.dst)[o] = v;
+        }
+      }
     }
     return;
   }

@@ -331,10 +331,10 @@ class _Spec:
                     and not TILED_COPY_OFF)
             if tiled:
                 d.flags |= 2
-                start += ((dims[2] + 31) // 32) * ((dims[0] * dims[1] + 63) // 64)
+                start += ((dims[2] + 63) // 64) * ((dims[0] * dims[1] + 63) // 64)
             elif taps:
                 d.flags |= 4
-                start += dims[0] * ((dims[2] + 127) // 128)
+                start += ((dims[0] + 1) // 2) * ((dims[2] + 127) // 128)
             else:
                 start += (dims[0] * dims[1] * dims[2] + 1023) // 1024
             descs.append(d)

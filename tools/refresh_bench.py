@@ -33,9 +33,9 @@ for sp in specs:
 def nblocks(d):
     dims = (d.d0, d.d1, d.d2)
     if d.flags & 2:
-        return ((dims[2] + 31) // 32) * ((dims[0] * dims[1] + 63) // 64)
+        return ((dims[2] + 63) // 64) * ((dims[0] * dims[1] + 63) // 64)
     if d.flags & 4:
-        return dims[0] * ((dims[2] + 127) // 128)
+        return ((dims[0] + 1) // 2) * ((dims[2] + 127) // 128)
     return (dims[0] * dims[1] * dims[2] + 1023) // 1024
 
 
