@@ -253,6 +253,192 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
   }
 }
 
+// ---- Round 6: the LayerNorm backward of the decoder's bf16 stream with SIXTEEN lanes per row -----------------------------------
+// (modes LNM_ALL16 | LNM_LEN [| LNM_INDROP]: the eight launches of a training step; everything else keeps the kernel above.)
+// The wave-per-row kernel is bound by its instruction count: four 64-lane reductions and the whole scalar bookkeeping per row
+// for four channels per lane (175 wave-instructions per row).  Here a quarter wave owns a row -- lane l of the quarter holds
+// channels 16 l .. 16 l + 15 as two 16-byte loads per tensor -- so a wave works on FOUR rows at once, a reduction is four DPP
+// steps inside a 16-lane DPP row (quad permutes, row_half_mirror, row_mirror: no cross-row traffic at all), and the
+// per-row overhead is shared by four rows: ~75 wave-instructions per row.  Two row groups per iteration are in flight.
+// Same arithmetic per element as the kernel above (fp32, statistics recomputed from the saved sum); the order of the additions
+// inside a reduction differs, i.e. results agree to fp32 rounding, not bit for bit (tests/test_20_hip_backward.py).
+__device__ __forceinline__ float q16_sum(float v) {
+  v += dpp_f32<0xB1>(v);                               // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);                               // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);                              // row_half_mirror
+  v += dpp_f32<0x140>(v);                              // row_mirror
+  return v;
+}
+__device__ __forceinline__ void bf16x8_to_f32(const uint4& u, float* f) {
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 f32_to_bf16x8(const float* f) {
+  return make_uint4(cvt_pk_bf16_rne(f[0], f[1]), cvt_pk_bf16_rne(f[2], f[3]), cvt_pk_bf16_rne(f[4], f[5]), cvt_pk_bf16_rne(f[6], f[7]));
+}
+
+template <bool INDROP>
+__global__ __launch_bounds__(512) void layernorm_bwd_q16_kernel(
+    const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ dy, int64_t lddy, const float* __restrict__ gamma,
+    uint16_t* __restrict__ dx, int64_t lddx, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int L,
+    const int64_t* __restrict__ len, const uint64_t* __restrict__ epoch, float in_drop_p, uint64_t in_drop_seed_host,
+    uint16_t* __restrict__ dx_drop, int64_t lddxd, int replicas) {
+  constexpr int U = 2;                                 // row groups (4 rows each) per wave and iteration
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int qr = lane >> 4, c0 = (lane & 15) * 16;
+  float g[16], ag[16], ab[16];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float4 t = *reinterpret_cast<const float4*>(gamma + c0 + 4 * k);
+    g[4 * k] = t.x; g[4 * k + 1] = t.y; g[4 * k + 2] = t.z; g[4 * k + 3] = t.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { ag[k] = 0.f; ab[k] = 0.f; }
+  uint2 key_in = make_uint2(0u, 0u);
+  uint32_t thr_in = 0u;
+  float sc_in = 1.f;
+  if (INDROP) {
+    key_in = dropout_key(mix_drop_epoch(in_drop_seed_host, epoch));
+    thr_in = dropout_thr16(in_drop_p);
+    sc_in = 1.f / (1.f - in_drop_p);
+  }
+  const bool one_item = (int64_t)L >= rows;
+  const int lv_one = one_item ? reinterpret_cast<const int*>(len)[0] : 0;
+  const int64_t zero_end = ((int64_t)lv_one + 255) & ~(int64_t)255;      // (one_item) first row no consumer reads
+  const int64_t gstride = (int64_t)gridDim.x * (4 * LNB_WAVES);          // rows one sweep of the grid covers
+  // Software pipeline: the operands of the NEXT iteration's two row groups are requested before the current ones are worked on
+  // (a block runs two or three iterations: without it every iteration is a full memory round trip with nothing behind it).
+  struct Grp { int64_t row; bool inb, live; };
+  auto classify = [&](int64_t r) {
+    Grp gq;
+    gq.row = r; gq.inb = r < rows;
+    const int64_t rc = gq.inb ? r : rows - 1;
+    int t, lv;
+    if (one_item) { t = (int)rc; lv = lv_one; }
+    else {
+      const uint32_t b = (uint32_t)rc / (uint32_t)L;
+      t = (int)((uint32_t)rc - b * (uint32_t)L);
+      lv = reinterpret_cast<const int*>(len)[2 * b];
+    }
+    gq.live = gq.inb && t < lv;
+    return gq;
+  };
+  auto fetch = [&](const Grp& gq, bool wave_live, uint4 (&xo)[2], uint4 (&dO)[2]) {
+    if (!wave_live) return;                            // (wave-uniform: nobody in the wave needs these rows)
+    const int64_t rc = gq.inb ? gq.row : rows - 1;
+    const uint4* px = reinterpret_cast<const uint4*>(x + rc * ldx + c0);
+    const uint4* pd = reinterpret_cast<const uint4*>(dy + rc * lddy + c0);
+    xo[0] = px[0]; xo[1] = px[1];
+    dO[0] = pd[0]; dO[1] = pd[1];
+  };
+  int64_t base = ((int64_t)blockIdx.x * LNB_WAVES + wv) * 4;
+  Grp cur[U], nxt[U];
+  bool cur_wl[U], nxt_wl[U];
+  uint4 xr[U][2], dr[U][2], xn[U][2], dn[U][2];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    cur[u] = classify(base + u * gstride + qr);
+    cur_wl[u] = __any(cur[u].live);
+    xr[u][0] = xr[u][1] = dr[u][0] = dr[u][1] = make_uint4(0u, 0u, 0u, 0u);
+    fetch(cur[u], cur_wl[u], xr[u], dr[u]);
+  }
+  for (; base < rows; base += U * gstride) {
+    const bool more = base + U * gstride < rows;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      nxt[u] = classify(base + (U + u) * gstride + qr);
+      nxt_wl[u] = more && __any(nxt[u].live);
+      xn[u][0] = xn[u][1] = dn[u][0] = dn[u][1] = make_uint4(0u, 0u, 0u, 0u);
+      fetch(nxt[u], nxt_wl[u], xn[u], dn[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const Grp gq = cur[u];
+      if (!cur_wl[u]) {                                // every row of this group is padding (or past the end): zeros, nothing else
+        // packed rows: the tensors' consumers (GEMM tiles, weight-gradient chunks) never touch a 256-row tile that lies wholly
+        // behind the data -- the producing GEMMs leave those rows unwritten as well -- so only the last tile's padding is zeroed
+        if (gq.inb && !(one_item && gq.row >= zero_end)) {
+          const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+          uint4* o = reinterpret_cast<uint4*>(dx + gq.row * lddx + c0);
+          o[0] = z; o[1] = z;
+          if (INDROP) { uint4* od = reinterpret_cast<uint4*>(dx_drop + gq.row * lddxd + c0); od[0] = z; od[1] = z; }
+        }
+        continue;
+      }
+      float v[16], d[16];
+      bf16x8_to_f32(xr[u][0], v); bf16x8_to_f32(xr[u][1], v + 8);
+      bf16x8_to_f32(dr[u][0], d); bf16x8_to_f32(dr[u][1], d + 8);
+      if (!gq.live) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { v[k] = 0.f; d[k] = 0.f; }
+      }
+      float sm = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sm += v[k];
+      const float mean = q16_sum(sm) * (1.f / 256.f);
+      float h[16], ss = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { h[k] = v[k] - mean; ss += h[k] * h[k]; }
+      const float rstd = 1.0f / sqrtf(q16_sum(ss) * (1.f / 256.f) + 1e-5f);
+      float ex[16], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        h[k] *= rstd;
+        ex[k] = d[k] * g[k];
+        m1 += ex[k];
+        m2 += ex[k] * h[k];
+      }
+      if (gq.live) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { ag[k] += d[k] * h[k]; ab[k] += d[k]; }
+      }
+      m1 = q16_sum(m1) * (1.f / 256.f);
+      m2 = q16_sum(m2) * (1.f / 256.f);
+      float gx[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) gx[k] = gq.live ? rstd * (ex[k] - m1 - h[k] * m2) : 0.f;
+      if (gq.inb) {
+        uint4* o = reinterpret_cast<uint4*>(dx + gq.row * lddx + c0);
+        o[0] = f32_to_bf16x8(gx); o[1] = f32_to_bf16x8(gx + 8);
+        if (INDROP) {                                  // gradient of the dropout(x) that fed the sum: the forward's stream
+          float gd[16];
+          const uint32_t ehi = (uint32_t)((uint64_t)gq.row >> 24);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t elo = ((uint32_t)gq.row << 8) | (uint32_t)(c0 + 4 * j);
+            const float4 r4 = dropout_select4(make_float4(gx[4 * j], gx[4 * j + 1], gx[4 * j + 2], gx[4 * j + 3]),
+                                              dropout_word4(key_in, elo, ehi), thr_in, sc_in);
+            gd[4 * j] = r4.x; gd[4 * j + 1] = r4.y; gd[4 * j + 2] = r4.z; gd[4 * j + 3] = r4.w;
+          }
+          uint4* od = reinterpret_cast<uint4*>(dx_drop + gq.row * lddxd + c0);
+          od[0] = f32_to_bf16x8(gd); od[1] = f32_to_bf16x8(gd + 8);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      cur[u] = nxt[u]; cur_wl[u] = nxt_wl[u];
+      xr[u][0] = xn[u][0]; xr[u][1] = xn[u][1]; dr[u][0] = dn[u][0]; dr[u][1] = dn[u][1];
+    }
+  }
+  // parameter gradients: 32 partial vectors per block (8 waves x 4 quarters) -> LDS -> one slot per block (stores; atomics only when
+  // the caller handed fewer replicas than blocks)
+  __shared__ float red[2][LNB_WAVES * 4][256 + 4];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { red[0][wv * 4 + qr][c0 + k] = ag[k]; red[1][wv * 4 + qr][c0 + k] = ab[k]; }
+  __syncthreads();
+  const int c = threadIdx.x & 255, which = threadIdx.x >> 8;
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < LNB_WAVES * 4; ++w) t += red[which][w][c];
+  float* dst = which == 0 ? dgamma : dbeta;
+  if (replicas >= (int)gridDim.x) dst[(int64_t)blockIdx.x * 256 + c] = t;
+  else atomicAdd(dst + (blockIdx.x % replicas) * 256 + c, t);
+}
+
 extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* gamma,
                                     const float* beta, float* dx, int64_t lddx, float* dgamma, float* dbeta,
                                     const float* dot_w, const float* dout, float* ddot_w, float* ddot_b, int B, int L,
@@ -307,6 +493,22 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
         break;
     }
 #undef LNB3_CASE
+    return launch_status();
+  }
+  // round 6: sixteen lanes per row for the decoder's bf16 stream (STYLER_LNBWD_Q16=0: the wave-per-row kernel)
+  static const bool q16_on = [] { const char* e = getenv("STYLER_LNBWD_Q16"); return !e || atoi(e) != 0; }();
+  if (q16_on && LNB_WAVES == 8 && (mode == (LNM_ALL16 | LNM_LEN) || mode == (LNM_ALL16 | LNM_LEN | LNM_INDROP)) && dx && dy &&
+      !((ldx | lddy | lddx | (dx_drop ? lddxd : 0)) & 7) &&
+      !(((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)(dx_drop ? (const void*)dx_drop : (const void*)dx)) & 15)) {
+    int64_t qb = (rows + 4 * LNB_WAVES - 1) / (4 * LNB_WAVES);
+    if (qb > cap) qb = cap;
+#define LNQ_LAUNCH(ID)                                                                                                          \
+    hipLaunchKernelGGL((layernorm_bwd_q16_kernel<ID>), dim3((unsigned)qb), dim3(64 * LNB_WAVES), 0, (hipStream_t)stream,            \
+                       reinterpret_cast<const uint16_t*>(x), ldx, reinterpret_cast<const uint16_t*>(dy), lddy, gamma,               \
+                       reinterpret_cast<uint16_t*>(dx), lddx, dgamma, dbeta, rows, L, len, g_styler_drop_epoch, in_drop_p,            \
+                       in_drop_seed, reinterpret_cast<uint16_t*>(dx_drop), lddxd, replicas)
+    if (dx_drop) LNQ_LAUNCH(true); else LNQ_LAUNCH(false);
+#undef LNQ_LAUNCH
     return launch_status();
   }
 #define LNB_CASE(MODE) case (MODE): LNB_LAUNCH(MODE); break
