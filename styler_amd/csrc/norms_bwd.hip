@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(
 }
 
 // ---- Round 6: the LayerNorm backward of the decoder's bf16 stream with SIXTEEN lanes per row -----------------------------------
-// (modes LNM_ALL16 | LNM_LEN [| LNM_INDROP]: the eight launches of a training step; everything else keeps the kernel above.)
+// (modes LNM_ALL16 [| LNM_LEN] [| LNM_INDROP]: the eight launches of a training step; everything else keeps the kernel above.)
 // The wave-per-row kernel is bound by its instruction count: four 64-lane reductions and the whole scalar bookkeeping per row
 // for four channels per lane (175 wave-instructions per row).  Here a quarter wave owns a row -- lane l of the quarter holds
 // channels 16 l .. 16 l + 15 as two 16-byte loads per tensor -- so a wave works on FOUR rows at once, a reduction is four DPP
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(512) void layernorm_bwd_q16_kernel(
     thr_in = dropout_thr16(in_drop_p);
     sc_in = 1.f / (1.f - in_drop_p);
   }
-  const bool one_item = (int64_t)L >= rows;
+  const bool one_item = len != nullptr && (int64_t)L >= rows;
   const int lv_one = one_item ? reinterpret_cast<const int*>(len)[0] : 0;
   const int64_t zero_end = ((int64_t)lv_one + 255) & ~(int64_t)255;      // (one_item) first row no consumer reads
   const int64_t gstride = (int64_t)gridDim.x * (4 * LNB_WAVES);          // rows one sweep of the grid covers
@@ -316,9 +316,9 @@ __global__ __launch_bounds__(512) void layernorm_bwd_q16_kernel(
     Grp gq;
     gq.row = r; gq.inb = r < rows;
     const int64_t rc = gq.inb ? r : rows - 1;
-    int t, lv;
+    int t = 0, lv = 1;
     if (one_item) { t = (int)rc; lv = lv_one; }
-    else {
+    else if (len) {
       const uint32_t b = (uint32_t)rc / (uint32_t)L;
       t = (int)((uint32_t)rc - b * (uint32_t)L);
       lv = reinterpret_cast<const int*>(len)[2 * b];
@@ -497,7 +497,7 @@ extern "C" int styler_layernorm_bwd(const float* x, int64_t ldx, const float* dy
   }
   // round 6: sixteen lanes per row for the decoder's bf16 stream (STYLER_LNBWD_Q16=0: the wave-per-row kernel)
   static const bool q16_on = [] { const char* e = getenv("STYLER_LNBWD_Q16"); return !e || atoi(e) != 0; }();
-  if (q16_on && LNB_WAVES == 8 && (mode == (LNM_ALL16 | LNM_LEN) || mode == (LNM_ALL16 | LNM_LEN | LNM_INDROP)) && dx && dy &&
+  if (q16_on && LNB_WAVES == 8 && mode >= 0 && (mode & ~(LNM_LEN | LNM_INDROP)) == LNM_ALL16 && dx && dy &&
       !((ldx | lddy | lddx | (dx_drop ? lddxd : 0)) & 7) &&
       !(((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)(dx_drop ? (const void*)dx_drop : (const void*)dx)) & 15)) {
     int64_t qb = (rows + 4 * LNB_WAVES - 1) / (4 * LNB_WAVES);
