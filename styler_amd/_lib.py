@@ -194,6 +194,10 @@ def _load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C styler_amd/csrc`).  styler_amd has no CPU fallback.")
+    # torch first: its wheel carries its own HIP runtime (libamdhip64), and device pointers only mean something to the runtime
+    # that made them.  Loaded before torch, this library pulled in /opt/rocm's copy and every launch on a torch tensor failed with
+    # hipErrorNoDevice (seen with `python __graft_entry__.py smoke`: build() imports the package before smoke() imports torch).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
