@@ -575,3 +575,26 @@ def test_torch_library_schemas_and_fake_kernels():
         assert tuple(y.shape) == (2, 33, 64) and tuple(ml.shape) == (2,)
         mel, en, ei, fl = torch.ops.styler.stft_mel(torch.empty(3, 22050), None)
         assert tuple(mel.shape) == (3, 87, 80) and tuple(fl.shape) == (3,)
+        # round 6: one forward + one backward operator per fused kernel
+        assert len(T.OPS) == 28
+        dx, dw, db = torch.ops.styler.conv_gemm_bwd(torch.empty(2, 10, 512), torch.empty(2, 10, 256), torch.empty(512, 256, 5),
+                                                    torch.empty(2, 10, 512), 1, 0)
+        assert tuple(dx.shape) == (2, 10, 256) and tuple(dw.shape) == (512, 256, 5) and tuple(db.shape) == (512,)
+        assert tuple(torch.ops.styler.attention_bwd(torch.empty(2, 10, 768), torch.empty(2, 10, 256), torch.empty(2, 10, 256),
+                                                    torch.empty(2, 4, 10), torch.empty(2, dtype=torch.int64), 0).shape) == (2, 10, 768)
+        assert tuple(torch.ops.styler.length_regulate_bwd(torch.empty(2, 33, 64), torch.empty(2, 5, dtype=torch.int64), 5).shape) == (2, 5, 64)
+        y, st = torch.ops.styler.groupnorm_relu(torch.empty(2, 30, 320), torch.empty(320), torch.empty(320))
+        assert tuple(st.shape) == (2, 20, 2)
+        o = torch.ops.styler.batchnorm_act(torch.empty(4, 30, 512), torch.empty(512), torch.empty(512), torch.empty(512),
+                                           torch.empty(512), 2, 0.5, 3, 2)
+        assert [tuple(t.shape) for t in o] == [(4, 30, 512), (2, 512), (2, 512), (512,), (512,)]
+        o = torch.ops.styler.lstm_bidir(torch.empty(2, 10, 512), torch.empty(2, 256, 64), 64)
+        assert [tuple(t.shape) for t in o] == [(2, 10, 128), (2, 10, 512), (2, 10, 128)]
+        y, s_ = torch.ops.styler.linear_ln(torch.empty(2, 10, 1024), torch.empty(256, 1024), torch.empty(256), torch.empty(2, 10, 256),
+                                           torch.empty(256), torch.empty(256), None)
+        assert tuple(y.shape) == (2, 10, 256)
+        assert torch.ops.styler.nll3(torch.empty(4, 2), torch.empty(4, 2), torch.empty(4, 2), torch.empty(4, dtype=torch.int64)).shape == ()
+        assert tuple(torch.ops.styler.mel_calibrate(torch.empty(2, 40, 1152), torch.empty(2, dtype=torch.int64),
+                                                    torch.empty(2, dtype=torch.int64), 7).shape) == (2, 7, 1152)
+        assert tuple(torch.ops.styler.aug_classifier_tail(torch.empty(3, 6, 256), torch.empty(256), torch.empty(256), torch.empty(2, 256),
+                                                          torch.empty(2)).shape) == (3, 2)

@@ -1054,6 +1054,146 @@ def test_wave_sum_is_the_shuffle_butterfly(dev):
     assert torch.allclose(a.view(4096, 64)[:, 0].double(), x.view(4096, 64).double().sum(1), rtol=1e-4, atol=1e-3)
 
 
+def test_torch_library_ops_round6(dev):
+    """The operators registered in round 6 (every fused kernel of the path as a forward + a backward `torch.ops.styler.*`
+    operator): forward and gradients against fp64 torch math, and `torch.library.opcheck` (schema, fake kernel, autograd
+    registration) on one representative of each kind."""
+    import torch.nn.functional as F
+    import styler_amd.torch_ops as TO
+    g = torch.Generator().manual_seed(33)
+    r64 = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    d32 = lambda t: t.detach().float().to(dev)
+    # ---- groupnorm_relu ----
+    x, ga, be = r64(3, 37, 64).requires_grad_(True), (1 + 0.1 * r64(64)).requires_grad_(True), (0.1 * r64(64)).requires_grad_(True)
+    ref = torch.relu(F.group_norm(x.transpose(1, 2), 4, ga, be, eps=1e-5)).transpose(1, 2)
+    gy = r64(3, 37, 64)
+    ref.backward(gy)
+    xd, gd, bd = (d32(t).requires_grad_(True) for t in (x, ga, be))
+    y, _ = torch.ops.styler.groupnorm_relu(xd, gd, bd)
+    check(y, ref, 1e-5, "styler::groupnorm_relu")
+    y.backward(d32(gy))
+    check(xd.grad, x.grad, 5e-5, "groupnorm_relu dx"); check(gd.grad, ga.grad, 5e-5, "groupnorm_relu dgamma")
+    check(bd.grad, be.grad, 5e-5, "groupnorm_relu dbeta")
+    # ---- batchnorm_act (tanh, two segments, no dropout) ----
+    x, ga, be = r64(4, 25, 64).requires_grad_(True), (1 + 0.1 * r64(64)).requires_grad_(True), (0.1 * r64(64)).requires_grad_(True)
+    rm, rv = 0.1 * r64(64), 1 + 0.1 * r64(64).abs()
+    segs_ref, rm_ref, rv_ref = [], rm.clone(), rv.clone()
+    for sgm in x.reshape(2, 50, 64):
+        m_, v_ = sgm.mean(0), sgm.var(0, unbiased=False)
+        segs_ref.append(torch.tanh((sgm - m_) / torch.sqrt(v_ + 1e-5) * ga + be))
+        rm_ref = 0.9 * rm_ref + 0.1 * m_.detach()
+        rv_ref = 0.9 * rv_ref + 0.1 * (v_.detach() * 50 / 49)
+    ref = torch.stack(segs_ref).reshape(4, 25, 64)
+    gy = r64(4, 25, 64)
+    ref.backward(gy)
+    xd, gd, bd = (d32(t).requires_grad_(True) for t in (x, ga, be))
+    y, mean, rstd, rm2, rv2 = torch.ops.styler.batchnorm_act(xd, gd, bd, d32(rm), d32(rv), 2, 0.0, 0, 2)
+    check(y, ref, 2e-5, "styler::batchnorm_act"); check(rm2, rm_ref, 1e-5, "running_mean"); check(rv2, rv_ref, 1e-5, "running_var")
+    y.backward(d32(gy))
+    check(xd.grad, x.grad, 1e-4, "batchnorm_act dx"); check(gd.grad, ga.grad, 1e-4, "batchnorm_act dgamma")
+    check(bd.grad, be.grad, 1e-4, "batchnorm_act dbeta")
+    # ---- lstm_bidir: the recurrence on given gate pre-activations, both directions ----
+    B_, S_, H = 3, 7, 64
+    gx, whh = (0.5 * r64(B_, S_, 8 * H)).requires_grad_(True), 0.1 * r64(2, 4 * H, H)
+    outs = []
+    for d_ in range(2):
+        h, c, seq = torch.zeros(B_, H, dtype=torch.float64), torch.zeros(B_, H, dtype=torch.float64), []
+        for t in (range(S_) if d_ == 0 else reversed(range(S_))):
+            a = gx[:, t, d_ * 4 * H:(d_ + 1) * 4 * H] + h @ whh[d_].t()
+            i_, f_, g_, o_ = a.split(H, dim=1)
+            c = torch.sigmoid(f_) * c + torch.sigmoid(i_) * torch.tanh(g_)
+            h = torch.sigmoid(o_) * torch.tanh(c)
+            seq.append((t, h))
+        outs.append(torch.stack([h for _, h in sorted(seq, key=lambda p: p[0])], 1))
+    ref = torch.cat(outs, -1)
+    gy = r64(B_, S_, 2 * H)
+    ref.backward(gy)
+    out, gates, cell = torch.ops.styler.lstm_bidir(d32(gx), d32(whh), H)
+    check(out, ref, 2e-5, "styler::lstm_bidir")
+    dgx = torch.ops.styler.lstm_bidir_bwd(d32(gy), gates, cell, d32(whh), H)
+    check(dgx, gx.grad, 5e-5, "lstm_bidir_bwd dgx")
+    # ---- linear_ln (bf16 products: compared on the bf16-rounded operands) ----
+    a, w = r64(2, 19, 1024).bfloat16().double(), (r64(256, 1024) / 32).bfloat16().double()
+    b_, res = 0.1 * r64(256), r64(2, 19, 256).bfloat16().double()
+    ga, be = 1 + 0.1 * r64(256), 0.1 * r64(256)
+    lens = torch.tensor([19, 8])
+    keep = (torch.arange(19)[None] < lens[:, None])[..., None].double()
+    ref = F.layer_norm(a @ w.t() + b_ + res, (256,), ga, be) * keep
+    y, s_ = torch.ops.styler.linear_ln(d32(a), d32(w), d32(b_), d32(res).bfloat16(), d32(ga), d32(be), lens.to(dev))
+    check(y.float(), ref, 2 ** -8 * float(ref.abs().max()), "styler::linear_ln (bf16 output: half an ulp of the largest value)")
+    # ---- masked_err_mean / nll3 / dropout ----
+    for kind in (0, 1):
+        a, b2 = r64(2, 11, 80).requires_grad_(True), r64(2, 11, 80)
+        lens = torch.tensor([11, 4])
+        keep = (torch.arange(11)[None] < lens[:, None])[..., None].expand(2, 11, 80)
+        ref = ((a - b2)[keep] ** 2).mean() if kind == 0 else (a - b2)[keep].abs().mean()
+        ref.backward()
+        ad = d32(a).requires_grad_(True)
+        m, _ = torch.ops.styler.masked_err_mean(ad, d32(b2), kind, lens.to(dev))
+        assert abs(float(m) - float(ref)) <= 1e-5 * abs(float(ref))
+        m.backward()
+        check(ad.grad, a.grad, 1e-5, f"masked_err_mean kind {kind} da")
+    lps = [torch.log_softmax(r64(5, 2), 1).requires_grad_(True) for _ in range(3)]
+    label = torch.tensor([0, 1, 1, 0, 1])
+    ref = sum(F.nll_loss(lp, label) for lp in lps)
+    ref.backward()
+    lpd = [d32(lp).requires_grad_(True) for lp in lps]
+    out = torch.ops.styler.nll3(*lpd, label.to(dev))
+    assert abs(float(out) - float(ref)) <= 1e-5
+    out.backward()
+    for a_, b3 in zip(lpd, lps):
+        check(a_.grad, b3.grad, 1e-6, "nll3 dlogp")
+    xd = torch.randn(4, 9, 64, generator=g).to(dev).requires_grad_(True)
+    yd = torch.ops.styler.dropout(xd, 0.25, 11)
+    kept = yd != 0
+    assert 0.6 <= float(kept.float().mean()) <= 0.9 and torch.allclose(yd[kept], (xd / 0.75)[kept])
+    yd.backward(torch.ones_like(yd))
+    assert torch.equal(xd.grad != 0, kept)                                      # the backward regenerates the same mask
+    # ---- embed_pos / mel_calibrate / aug_classifier_tail against the ops they wrap (pinned to golden fixtures elsewhere) ----
+    from styler_amd import ops
+    text = torch.randint(0, 20, (2, 6), generator=g).to(dev)
+    emb = torch.randn(20, 256, generator=g).to(dev).requires_grad_(True)
+    pe = ops.sinusoid_table(8, 256, dev)
+    y = torch.ops.styler.embed_pos(text, emb, pe)
+    assert torch.equal(y, ops.embed_pos(text, emb.detach(), pe))
+    y.backward(torch.ones_like(y))
+    cnt = torch.zeros(20, device=dev).index_add_(0, text.reshape(-1), torch.ones(12, device=dev))
+    check(emb.grad, cnt[:, None].expand(20, 256), 1e-6, "embed_pos demb")
+    h = torch.randn(3, 6, 256, generator=g).to(dev).requires_grad_(True)
+    lg, lb = (1 + 0.1 * torch.randn(256, generator=g)).to(dev), (0.1 * torch.randn(256, generator=g)).to(dev)
+    w2, b2 = (torch.randn(2, 256, generator=g) / 16).to(dev), torch.randn(2, generator=g).to(dev)
+    lp = torch.ops.styler.aug_classifier_tail(h, lg, lb, w2, b2)
+    hr = h.detach().double().cpu().requires_grad_(True)
+    ref = torch.log_softmax(torch.relu(F.layer_norm(hr, (256,), lg.double().cpu(), lb.double().cpu())) @ w2.double().cpu().t()
+                            + b2.double().cpu(), dim=-1).mean(1)
+    check(lp, ref, 1e-5, "styler::aug_classifier_tail")
+    gy = torch.randn(3, 2, generator=g)
+    ref.backward(gy.double()); lp.backward(gy.to(dev))
+    check(h.grad, hr.grad, 5e-5, "aug_classifier_tail dh")
+    # ---- clip_adam_step against torch.optim.Adam ----
+    p0, gr = torch.randn(1003, generator=g), 3.0 * torch.randn(1003, generator=g)
+    pr = torch.nn.Parameter(p0.clone()); pr.grad = gr.clone()
+    opt = torch.optim.Adam([pr], lr=1e-3, betas=(0.9, 0.98), eps=1e-9)
+    norm_ref = torch.nn.utils.clip_grad_norm_([pr], 1.0)
+    opt.step()
+    pd, md, vd = p0.clone().to(dev), torch.zeros(1003, device=dev), torch.zeros(1003, device=dev)
+    norm = torch.ops.styler.clip_adam_step(pd, gr.to(dev), md, vd, 1.0, 1e-3, 0.9, 0.98, 1e-9, 1, 1.0)
+    assert abs(float(norm) - float(norm_ref)) <= 1e-4 * float(norm_ref)
+    check(pd, pr.detach(), 1e-5, "clip_adam_step p")
+    # ---- dispatcher-level checks ----
+    from torch.library import opcheck
+    tests = ("test_schema", "test_faketensor", "test_autograd_registration")
+    x = torch.randn(2, 21, 64, generator=g).to(dev).requires_grad_(True)
+    opcheck(torch.ops.styler.groupnorm_relu.default, (x, torch.ones(64, device=dev, requires_grad=True),
+                                                       torch.zeros(64, device=dev, requires_grad=True)), test_utils=tests)
+    opcheck(torch.ops.styler.add_layernorm_bwd.default, (torch.randn(2, 9, 256, device=dev), torch.randn(2, 9, 256, device=dev),
+                                                         torch.ones(256, device=dev), torch.zeros(256, device=dev), None),
+            test_utils=tests)
+    opcheck(torch.ops.styler.masked_err_mean.default, (torch.randn(2, 7, 80, device=dev, requires_grad=True),
+                                                       torch.randn(2, 7, 80, device=dev), 0, None), test_utils=tests)
+    assert all(hasattr(torch.ops.styler, n) for n in TO.OPS) and len(TO.OPS) == 28
+
+
 def test_torch_library_ops(dev):
     """The `torch.library` registrations (styler_amd/torch_ops.py): dispatcher-visible ops with autograd, against
     stock PyTorch math in fp64 on the CPU (forward and gradients)."""
