@@ -304,6 +304,7 @@ class AttnSublayerFn(Function):
         ctx.mha, ctx.plan = mha, plan
         if want16:
             ctx.mark_non_differentiable(y16)
+            ctx.set_materialize_grads(False)            # (no zero-filled bf16 tensor for the copy's unused gradient slot)
             return y, y16
         return y
 
@@ -839,6 +840,7 @@ class SplitBatchFn(Function):
     @staticmethod
     def forward(ctx, x):
         ctx.meta = (x.shape, x.device)
+        ctx.set_materialize_grads(False)               # an unused half arrives as None (handled below), not as a zero-filled tensor
         B = x.shape[0] // 2
         return x[:B], x[B:]
 
@@ -866,6 +868,41 @@ class SplitBatchFn(Function):
         if pairs:
             ops.copy_rows_multi(pairs)
         return out
+
+
+class StackedFanoutFn(Function):
+    """x [2B, ...] -> (x, x[:B]) for a stacked tensor with exactly these two consumers (the AudioEncoder's main + DAT encodings:
+    the classifiers take all 2B items, the style path the first B).  Backward = ONE launch: the first consumer's gradient with the
+    second one's added onto its first half, in place (that tensor is the classifier's fresh dX output and has no other reader) --
+    instead of autograd's zero-extended copy of the half + an aten add (round 6)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.meta = (x.shape, x.device)
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), x[: x.shape[0] // 2]
+
+    @staticmethod
+    def backward(ctx, g_all, g_main):
+        shape, dev = ctx.meta
+        B = shape[0] // 2
+        if g_all is None and g_main is None:
+            return None
+        if g_all is None:                               # only the half is used: zero-extended copy (as SplitBatchFn)
+            out = torch.empty(shape, device=dev, dtype=torch.float32)
+            flat = lambda t: t.reshape(-1, t.shape[-1])
+            ops.copy_rows_multi([(flat(g_main.contiguous().float()), flat(out[:B])), (None, flat(out[B:]))])
+            return out
+        if g_main is None:
+            return g_all
+        ok = (g_all.dtype == torch.float32 and g_all.is_contiguous() and g_main.dtype == torch.float32 and g_main.is_contiguous()
+              and g_all.shape[-1] % 4 == 0)
+        if not ok:
+            out = g_all.clone()
+            out[:B] += g_main
+            return out
+        ops.add2(g_all[:B], g_main, out=g_all[:B])
+        return g_all
 
 
 class PackPairFn(Function):
@@ -1055,6 +1092,7 @@ class LossTailFn(Function):
         out = ops.loss_tail([m.reshape(1) for m in means], weights, lps, (label0, label1))
         total, cls, dat = out[0:1].view(()), out[1:2].view(()), out[2:3].view(())
         ctx.mark_non_differentiable(cls, dat)
+        ctx.set_materialize_grads(False)               # (no zero fills for the two logging outputs' gradient slots)
         return total, cls, dat
 
     @staticmethod

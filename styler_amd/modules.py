@@ -271,8 +271,8 @@ class StyleEncoder(_HipModule):
                 # every op of a classifier is per item) -- half the classifier launches, and the DAT halves never need to be
                 # cut out: their only consumer is the classifier.  The main halves are views whose gradient comes back
                 # zero-extended (SplitBatchFn with an unused second output).
-                self.stacked_encodings = (d, p, e)
-                d, p, e = (AG.SplitBatchFn.apply(t)[0] for t in (d, p, e))
+                (da, d), (pa, p), (ea, e) = (AG.StackedFanoutFn.apply(t) for t in (d, p, e))
+                self.stacked_encodings = (da, pa, ea)
             else:
                 (d, d2), (p, p2), (e, e2) = (AG.SplitBatchFn.apply(t) for t in (d, p, e))
                 self.dat_encodings = (d2, p2, e2)
