@@ -39,6 +39,10 @@ def world_size():
 
 
 BUCKET_BYTES = 32 << 20
+# STYLER_FORCE_ALLREDUCE=1: issue the gradient all-reduce even on ONE rank (an identity, but every call of the N > 1 path -- RCCL
+# communicator, bucketed async collectives on the flat buffer, the launch point inside backward, the waits in step() -- runs on the
+# real backend): how a 1-GPU box exercises the "nccl" transport (tests/test_15_dist_gpu.py::test_one_rank_rccl_step)
+FORCE_COLLECTIVES = __import__("os").environ.get("STYLER_FORCE_ALLREDUCE", "0") == "1"
 
 
 def allreduce_sum_(flat_grads, bucket_bytes=BUCKET_BYTES):
@@ -46,7 +50,7 @@ def allreduce_sum_(flat_grads, bucket_bytes=BUCKET_BYTES):
     launched back to back on the collective stream.  Returns the async work handles so the caller can overlap the range
     with other work; call `.wait()` on each before the optimizer step.  The division by the world size is NOT a pass
     over the buffer: `TrainState.step` folds 1 / world into the clip + Adam kernel (`grad_scale`)."""
-    if world_size() == 1:
+    if world_size() == 1 and not (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized()):
         return []
     n = max(1, bucket_bytes // flat_grads.element_size())
     return [dist.all_reduce(flat_grads[start:start + n], op=dist.ReduceOp.SUM, async_op=True)

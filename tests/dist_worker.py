@@ -46,7 +46,10 @@ def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     mode = sys.argv[5] if len(sys.argv) > 5 else "graph"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if mode.startswith("rccl1"):         # ONE rank on the real transport (backend "nccl" = RCCL), as bench.py initialises it
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
     from conftest import _reference_state_dict
@@ -66,7 +69,24 @@ def main():
     gb = global_batch()
     idx = shard_indices(gb["text"].shape[0], rank, world, gb["mel_len"].tolist())
     res = {"idx": idx, "seed": rt.seed, "info": state.allreduce_info()}
-    if mode == "graph":
+    if mode.startswith("rccl1"):
+        # the graphed step with its cut(s) and the eager step with the hook-driven launch point, collectives FORCED on one rank
+        from styler_amd import dist as sdist
+        assert dist.get_backend() == "nccl" and sdist.FORCE_COLLECTIVES and world == 1
+        local = {k: v.to(dev) for k, v in shard_batch(gb, idx).items()}
+        calls = []
+        orig_ar = dist.all_reduce
+        dist.all_reduce = lambda *a, **k: (calls.append(int(a[0].numel())), orig_ar(*a, **k))[1]
+        if mode == "rccl1_graph":
+            step = GraphedTrainStep(model, state, local, split=True)
+            res["graphs"] = len(step.graphs)
+            calls.clear()
+            losses, lr = step(local)
+        else:
+            losses, lr = train_step(model, state, local)
+        res["collective_numels"] = list(calls)
+        dist.all_reduce = orig_ar
+    elif mode == "graph":
         local = {k: v.to(dev) for k, v in shard_batch(gb, idx).items()}
         step = GraphedTrainStep(model, state, local)              # N > 1: two graphs, tail all-reduce between the replays
         res["graphs"] = len(step.graphs)

@@ -127,6 +127,32 @@ def test_two_rank_third_launch_point(tmp_path, ref_state_dict, monkeypatch, mode
     assert float((r0["flat_p"] - flat_p).abs().max()) <= 1e-6
 
 
+@pytest.mark.parametrize("mode", ["rccl1_graph", "rccl1_eager"])
+def test_one_rank_rccl_step(tmp_path, ref_state_dict, monkeypatch, mode):
+    """The N > 1 code path on the REAL transport, as far as one GPU allows: ONE rank, backend "nccl" (= RCCL) initialised as
+    bench.py does (`device_id=`), STYLER_FORCE_ALLREDUCE=1 so that every gradient range is all-reduced although the sum over one
+    rank is the identity -- RCCL communicator creation, bucketed async all-reduces of views of the flat buffer, the launch point
+    inside backward (graph: the cut between two graphs; eager: the hook), the waits in step().  Result = the plain one-rank step
+    (same kernels, gradients bit-reproducible, SUM over one rank exact).  What this cannot show: a second rank, xGMI."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_worker import global_batch, shard_batch
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", STYLER_FORCE_ALLREDUCE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "0", "1", port, str(tmp_path), mode],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    r0 = torch.load(os.path.join(str(tmp_path), "rank0.pt"))
+    n = r0["flat_g"].numel()
+    assert sum(r0["collective_numels"]) == n and len(r0["collective_numels"]) >= 4, r0["collective_numels"]   # every element once
+    if mode == "rccl1_graph":
+        assert r0["graphs"] == 2
+    gb = global_batch()
+    g1, p1, lr = _single_rank(ref_state_dict, monkeypatch, [[shard_batch(gb, r0["idx"])]])
+    assert lr == r0["lr"]
+    assert float((r0["flat_g"] - g1).abs().max()) <= 1e-6 * float(g1.abs().max())
+    assert float((r0["flat_p"] - p1).abs().max()) <= 1e-6
+
+
 def test_two_rank_graph_cache_two_steps_different_shapes(tmp_path, ref_state_dict, monkeypatch):
     """Two consecutive optimisation steps through GraphedStepCache on two ranks, each rank with its own padded shapes in
     each step (two captures per rank, at different times relative to the peer's collectives): same trajectory as one
