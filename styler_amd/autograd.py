@@ -1097,6 +1097,8 @@ class LossTailFn(Function):
 
     @staticmethod
     def backward(ctx, g, g_cls, g_dat):
+        if g is None:                                   # (the total is not part of the differentiated graph)
+            return (None,) * (3 + ctx.n + 6)
         saved = list(ctx.saved_tensors)
         lps, rest = saved[:6], saved[6:]
         labels = tuple(l if l is not None else rest.pop(0) for l in ctx.labels)
