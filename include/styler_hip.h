@@ -245,6 +245,10 @@ typedef struct {
   int32_t d0, d1, d2, flags;
 } StylerCopyDesc;
 int styler_strided_copy_multi(const StylerCopyDesc* desc_dev, int count, int64_t total_blocks, void* stream);
+/* Round 6: the same launch with the owner of every block given (blockmap[b] = index of the descriptor block b belongs to, device
+ * int32 [total_blocks]) instead of searched for by every block. */
+int styler_strided_copy_multi_map(const StylerCopyDesc* desc_dev, int count, int64_t total_blocks, const int32_t* blockmap,
+                                  void* stream);
 
 /* Conv1d weight repack [n, cin, kw] <-> [n, kw, cin] (state-dict layout <-> kernel layout);
  * out_bf16 != 0 writes the bf16 shadow directly (dst is uint16). */
@@ -677,6 +681,9 @@ typedef struct StylerWgradDesc {
 } StylerWgradDesc;
 int styler_wgrad_reduce_multi(const StylerWgradDesc* desc_dev, int count, int64_t total_blocks,
                               void* stream);
+/* Round 6: the same fold with the descriptor of every block given (blockmap[b], device int32 [total_blocks]) instead of searched. */
+int styler_wgrad_reduce_multi_map(const StylerWgradDesc* desc_dev, int count, int64_t total_blocks, const int32_t* blockmap,
+                                  void* stream);
 /* Blocks descriptor i owns (block_start[i+1] - block_start[i]): ceil(n*kw*cin / 1024), or -- conv taps reduced into the
  * parameter layout (stride_j == 1, stride_c == kw) -- n * ceil(cin / 128): one block per (n, 128 channels, all taps). */
 int64_t styler_wgrad_reduce_blocks(int n, int cin, int kw, int64_t stride_c, int64_t stride_j);

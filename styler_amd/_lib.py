@@ -49,6 +49,7 @@ _SIGS = {
     "styler_lstm_bidir_multi": [P, I, I, I, P],
     "styler_set_dropout_counter": [P],
     "styler_strided_copy_multi": [P, I, I64, P],
+    "styler_strided_copy_multi_map": [P, I, I64, P, P],
     "styler_wgrad_group_desc": [P, P, I64, P, I64, P, P, I, I, I, I, I, I, I, P, P, P, I, I],
     "styler_wgrad_group": [P, I, I, I, P],
     "styler_pack_plan": [P, I, I, P, P, P, P, P],
@@ -82,6 +83,7 @@ _SIGS = {
     "styler_wgrad_splits_io": [I, I, I, I, I, I, I, I],
     "styler_wgrad_workspace_bytes_io": [I, I, I, I, I, I, I, I],
     "styler_wgrad_reduce_multi": [P, I, I64, P],
+    "styler_wgrad_reduce_multi_map": [P, I, I64, P, P],
     "styler_wgrad_reduce_blocks": [I, I, I, I64, I64],
     "styler_wgrad_workspace_bytes": [I, I, I, I, I, I, I],
     "styler_colsum": [P, I64, P, P, I64, I, P],

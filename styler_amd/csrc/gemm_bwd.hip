@@ -1511,10 +1511,12 @@ extern "C" int styler_wgrad_splits(int B, int L, int n, int cin, int kw, int pad
 
 // One launch reducing the split-K partials of MANY weight gradients (a whole backward pass): descriptor i covers
 // blocks [block_start[i], block_start[i+1]); every block handles 1024 consecutive outputs of its descriptor.
-__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const StylerWgradDesc* __restrict__ desc, int count) {
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const StylerWgradDesc* __restrict__ desc, int count,
+                                                                 const int32_t* __restrict__ blockmap) {
   int lo = 0, hi = count - 1;                        // last descriptor with block_start <= blockIdx.x
   const int64_t bid = blockIdx.x;
-  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].block_start <= bid) lo = mid; else hi = mid - 1; }
+  if (blockmap) lo = blockmap[bid];                  // round 6: the block's descriptor given by the host (styler_wgrad_reduce_multi_map)
+  else while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].block_start <= bid) lo = mid; else hi = mid - 1; }
   const StylerWgradDesc d = desc[lo];
   const int64_t per = (int64_t)d.n * d.kw * d.cin;   // multiple of 4 (n % 4 == 0); every slice is 16-byte aligned
   const float* ws = reinterpret_cast<const float*>(d.ws);
@@ -1650,7 +1652,14 @@ extern "C" int64_t styler_wgrad_reduce_blocks(int n, int cin, int kw, int64_t st
 extern "C" int styler_wgrad_reduce_multi(const StylerWgradDesc* desc_dev, int count, int64_t total_blocks, void* stream) {
   if (!desc_dev || count <= 0 || total_blocks <= 0) return STYLER_EINVAL;
   hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, desc_dev,
-                     count);
+                     count, (const int32_t*)nullptr);
+  return launch_status();
+}
+extern "C" int styler_wgrad_reduce_multi_map(const StylerWgradDesc* desc_dev, int count, int64_t total_blocks, const int32_t* blockmap,
+                                             void* stream) {
+  if (!desc_dev || count <= 0 || total_blocks <= 0) return STYLER_EINVAL;
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, desc_dev,
+                     count, blockmap);
   return launch_status();
 }
 

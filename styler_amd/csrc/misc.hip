@@ -590,10 +590,13 @@ extern "C" int styler_length_mask(const int64_t* len, uint8_t* mask, int B, int 
 // optimiser refreshes ALL derived layouts of the model with one launch after each update (runtime.Derived).
 // flags bit3 (round 4, the bf16x3 arithmetic): the element written is the LOW part of the source value, v - float(bf16(v)) --
 // together with the plain bf16 cast (the high part) it represents v to 16 mantissa bits (runtime.gemm_weight's x3 layouts).
-__global__ __launch_bounds__(256) void strided_copy_multi_kernel(const StylerCopyDesc* __restrict__ desc, int count) {
+__global__ __launch_bounds__(256) void strided_copy_multi_kernel(const StylerCopyDesc* __restrict__ desc, int count,
+                                                                 const int32_t* __restrict__ blockmap) {
   int lo = 0, hi = count - 1;                        // last descriptor with block_start <= blockIdx.x
   const int64_t bid = blockIdx.x;
-  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].block_start <= bid) lo = mid; else hi = mid - 1; }
+  if (blockmap) lo = blockmap[bid];                  // round 6: the owner of every block precomputed by the host -- the search is
+                                                     // eight dependent loads in front of 2-5 KB of work (103 -> 91 us for the model's table)
+  else while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].block_start <= bid) lo = mid; else hi = mid - 1; }
   const StylerCopyDesc d = desc[lo];
   if (d.flags & 2) {
     // Tiled transpose (flags bit1, set by the host when the pattern holds): dst is contiguous along a2, the source is
@@ -768,6 +771,13 @@ __global__ __launch_bounds__(256) void strided_copy_multi_kernel(const StylerCop
 extern "C" int styler_strided_copy_multi(const StylerCopyDesc* desc_dev, int count, int64_t total_blocks, void* stream) {
   if (!desc_dev || count <= 0 || total_blocks <= 0) return STYLER_EINVAL;
   hipLaunchKernelGGL(strided_copy_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, desc_dev,
-                     count);
+                     count, (const int32_t*)nullptr);
+  return launch_status();
+}
+extern "C" int styler_strided_copy_multi_map(const StylerCopyDesc* desc_dev, int count, int64_t total_blocks, const int32_t* blockmap,
+                                             void* stream) {
+  if (!desc_dev || count <= 0 || total_blocks <= 0) return STYLER_EINVAL;
+  hipLaunchKernelGGL(strided_copy_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, desc_dev,
+                     count, blockmap);
   return launch_status();
 }

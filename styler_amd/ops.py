@@ -241,18 +241,25 @@ class WgradArena:
                                ("splits", np.int32)])
                 arr = np.zeros(len(descs), dtype=dt)
                 start = 0
+                owners = []                          # which descriptor owns which block (the kernel would search for it)
                 for i, (ws, dw, sn, sc, sj, n, cin, kw, splits) in enumerate(descs):
                     arr[i] = (ws, dw, sn, sc, sj, start, n, cin, kw, splits)
-                    start += int(lib.styler_wgrad_reduce_blocks(n, cin, kw, sc, sj))
+                    nb = int(lib.styler_wgrad_reduce_blocks(n, cin, kw, sc, sj))
+                    owners.append(np.full(nb, i, dtype=np.int32))
+                    start += nb
                 if len(self._cache) > 8 and not self.owned_by_graph:
                     self._cache.clear()              # eager steps only: a graph's tables live as long as its arena
-                self._cache[key] = (torch.from_numpy(arr.view(np.uint8).copy()).to(device), start)
-            table, blocks = self._cache[key]
-            _chk(lib.styler_wgrad_reduce_multi(table.data_ptr(), len(descs), blocks, _stream()),
+                self._cache[key] = (torch.from_numpy(arr.view(np.uint8).copy()).to(device), start,
+                                    torch.from_numpy(np.concatenate(owners)).to(device))
+            table, blocks, bmap = self._cache[key]
+            _chk(lib.styler_wgrad_reduce_multi_map(table.data_ptr(), len(descs), blocks, bmap.data_ptr() if block_maps else None, _stream()),
                  "styler_wgrad_reduce_multi")
 
 
 wgrad_arena = None
+# round 6: the multi-descriptor launches (derived-layout refresh, fold of the split-K partials) get the owner of every block from the
+# host instead of searching the descriptor table per block (STYLER_BLOCKMAP=0: the search)
+block_maps = os.environ.get("STYLER_BLOCKMAP", "1") != "0"
 
 
 class GemmProfiler:

@@ -274,9 +274,14 @@ class Derived:
                 start = sp.fill(descs, start)
             arr = (_lib.CopyDesc * len(descs))(*descs)
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-            Derived._table = tab = (sig, host.to(specs[0].out.device), len(descs), start)
+            import numpy as np
+            bmap = np.empty(start, dtype=np.int32)     # which descriptor owns which block (the kernel would search for it)
+            for i, d in enumerate(descs):
+                bmap[d.block_start:(descs[i + 1].block_start if i + 1 < len(descs) else start)] = i
+            dev = specs[0].out.device
+            Derived._table = tab = (sig, host.to(dev), len(descs), start, torch.from_numpy(bmap).to(dev))
         # (specs of several devices in one process are not supported: one process per GPU)
-        ops._chk(ops.lib.styler_strided_copy_multi(tab[1].data_ptr(), tab[2], tab[3], ops._stream()),
+        ops._chk(ops.lib.styler_strided_copy_multi_map(tab[1].data_ptr(), tab[2], tab[3], tab[4].data_ptr() if ops.block_maps else None, ops._stream()),
                  "styler_strided_copy_multi")
         for sp in specs:
             sp.fresh = sp.stamp()
