@@ -820,6 +820,9 @@ int styler_nll(const float* logp, const int64_t* label, float* loss, const float
  * entry (sum, count, arrival ticket, pad); mean_out[0] = sum / count, written by the last block (may be NULL: sums only). */
 int styler_masked_err_mean(const float* a, int64_t lda, const float* b, int64_t ldb, double* acc, float* mean_out,
                            int kind, int B, int L, int C, const int64_t* len, void* stream);
+/* Round 6: size of a masked-error accumulator in doubles (zero on entry): totals, ticket and one slot pair per block -- the blocks
+ * STORE their sums and the last one adds them in a fixed order (no atomics on the values: the means are deterministic). */
+#define STYLER_MASKED_ACC_DOUBLES 2052
 /* Up to 8 masked-error terms per launch (forward: mean + accumulator per term; backward: da = gscale * d mean / d a):
  * loss.py:16-50 calls MSELoss / L1Loss on masked_select copies five times per STYLERLoss.forward and twice per
  * cal_mel_loss -- here one launch each way per call.  Fields as the arguments of styler_masked_err_mean / _bwd

@@ -12,15 +12,16 @@
 // serialises -- past ~100 blocks per term the atomics, not the loads, set the kernel's time (STYLER_LOSS_BLOCKS: the cap).
 static inline unsigned loss_grid(int64_t work, int per_block, int cap) {
   static const int env_cap = [] { const char* e = getenv("STYLER_LOSS_BLOCKS"); return e ? atoi(e) : 0; }();
-  if (env_cap > 0) cap = env_cap;
+  if (env_cap > 0) cap = env_cap < 1024 ? env_cap : 1024;   // (an accumulator has 1024 block slots)
   int64_t b = (work + per_block - 1) / per_block;
   if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (unsigned)b;
 }
 
-// acc: 4 doubles, zero on entry: [0] sum of errors, [1] count of valid elements, [2] arrival ticket (as uint64), [3] unused.
-// The block that draws the last ticket reads the two totals back through the same atomics path and writes the mean.
+// acc: STYLER_MASKED_ACC_DOUBLES (4 + 2 x 1024) doubles, zero on entry: [0] sum of errors, [1] count of valid elements (both written
+// by the block that draws the last ticket), [2] arrival ticket (as uint64), [3] unused, [4 + 2 b], [5 + 2 b] the sums of block b.
+// With mean_out == NULL (accumulate-only) just [0], [1] are touched, by atomics.
 __device__ __forceinline__ void masked_err_mean_body(const float* __restrict__ a, int64_t lda,
                                                      const float* __restrict__ b, int64_t ldb,
                                                      double* __restrict__ acc, float* __restrict__ mean_out,
@@ -89,21 +90,40 @@ __device__ __forceinline__ void masked_err_mean_body(const float* __restrict__ a
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) { red[wave][0] = s; red[wave][1] = n; }
   __syncthreads();
+  __shared__ int last_flag;
   if (threadIdx.x == 0) {
-    // The two sums are device-scope atomics (performed at the memory side, coherent across the XCDs); the ticket may only be
-    // drawn once they have been PERFORMED, i.e. once their return values are back -- a data dependency plus vmcnt(0), not
-    // __threadfence(): an agent-scope release fence writes back the whole L2 of the XCD, and every block of every term paid
-    // one (round 6: the kernel's time was those write-backs, 30 -> 12 us for the five terms of the clean pass).
-    const double r0 = atomicAdd(&acc[0], red[0][0] + red[1][0] + red[2][0] + red[3][0]);
-    const double r1 = atomicAdd(&acc[1], red[0][1] + red[1][1] + red[2][1] + red[3][1]);
-    if (mean_out) {
-      asm volatile("s_waitcnt vmcnt(0)" :: "v"(r0), "v"(r1) : "memory");
+    const double bs = red[0][0] + red[1][0] + red[2][0] + red[3][0], bn = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    last_flag = 0;
+    if (!mean_out) {                                     // accumulate-only form (styler_masked_err_sum): device-scope atomics
+      atomicAdd(&acc[0], bs);
+      atomicAdd(&acc[1], bn);
+    } else {
+      // Round 6: the block's two sums go to ITS slot (acc[4 + 2 bx], system-scope stores: visible past the per-XCD L2s without an
+      // agent-scope release fence, which writes back the whole L2), then one ticket; the block that draws the last ticket adds the
+      // slots in a fixed order.  One atomic per block instead of three, and the loss scalars no longer depend on the order the
+      // blocks arrive in (they were the last order-dependent values of a training step).
+      __hip_atomic_store(&acc[4 + 2 * bx], bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&acc[5 + 2 * bx], bn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned long long t = atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2]), 1ull);
-      if (t == (unsigned long long)nbx - 1) {
-        const double tot = atomicAdd(&acc[0], 0.0), cnt = atomicAdd(&acc[1], 0.0);   // read at the atomics' coherence point
-        mean_out[0] = (float)(tot / cnt);
-      }
+      last_flag = t == (unsigned long long)nbx - 1;
     }
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  double ts = 0.0, tn = 0.0;
+  for (unsigned i = threadIdx.x; i < nbx; i += 256) {    // (slot i to thread i % 256: a fixed assignment)
+    ts += __hip_atomic_load(&acc[4 + 2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    tn += __hip_atomic_load(&acc[5 + 2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  ts = wave_sum_d(ts); tn = wave_sum_d(tn);              // fixed butterfly, then the four waves in order
+  __syncthreads();
+  if (lane == 0) { red[wave][0] = ts; red[wave][1] = tn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tot = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0], cnt = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+    acc[0] = tot; acc[1] = cnt;                          // (the backward reads the count)
+    mean_out[0] = (float)(tot / cnt);
   }
 }
 

@@ -1642,6 +1642,9 @@ def rowsum(x, out=None, accumulate=False):
     return out
 
 
+MASKED_ACC_DOUBLES = 2052     # STYLER_MASKED_ACC_DOUBLES: totals, ticket and one slot pair per block (<= 1024 blocks per term)
+
+
 def masked_err_bwd(a, b, acc, gscale, kind, lens):
     if a.dim() == 2:
         B, L = a.shape
@@ -1666,9 +1669,9 @@ def masked_err_mean(a, b, kind, lens):
         lda, ldb = _ld(a), _ld(b)
     acc = None
     if zero_slab is not None:
-        acc = zero_slab.take(4)
+        acc = zero_slab.take(MASKED_ACC_DOUBLES)
     if acc is None:
-        acc = torch.zeros(4, dtype=torch.float64, device=a.device)
+        acc = torch.zeros(MASKED_ACC_DOUBLES, dtype=torch.float64, device=a.device)
     out = torch.empty(1, device=a.device, dtype=torch.float32)
     _chk(lib.styler_masked_err_mean(_f32(a).data_ptr(), lda, _f32(b).data_ptr(), ldb, acc.data_ptr(), out.data_ptr(), kind, B, L,
                                     C, _ptr(lens), _stream()), "styler_masked_err_mean")
@@ -1690,9 +1693,9 @@ def masked_err_mean_multi(terms):
     accs = []
     for k, (a, b, kind, lens) in enumerate(terms):
         B, L, C, lda, ldb = _masked_dims(a, b)
-        acc = zero_slab.take(4) if zero_slab is not None else None
+        acc = zero_slab.take(MASKED_ACC_DOUBLES) if zero_slab is not None else None
         if acc is None:
-            acc = torch.zeros(4, dtype=torch.float64, device=a.device)
+            acc = torch.zeros(MASKED_ACC_DOUBLES, dtype=torch.float64, device=a.device)
         accs.append(acc)
         m = arr[k]
         m.a, m.b, m.acc, m.mean, m.len = _f32(a).data_ptr(), _f32(b).data_ptr(), acc.data_ptr(), means[k:k + 1].data_ptr(), _ptr(lens)

@@ -392,7 +392,7 @@ def _mem_fwd(a, b, kind, lens):
 
 
 _pair("masked_err_mean", "(Tensor a, Tensor b, int kind, Tensor? lens) -> (Tensor, Tensor)", _mem_fwd,
-      lambda a, b, kind, lens: (a.new_empty(()), a.new_empty(4, dtype=torch.float64)))
+      lambda a, b, kind, lens: (a.new_empty(()), a.new_empty(ops.MASKED_ACC_DOUBLES, dtype=torch.float64)))
 _pair("masked_err_mean_bwd", "(Tensor a, Tensor b, Tensor acc, Tensor g, int kind, Tensor? lens) -> Tensor",
       lambda a, b, acc, g, kind, lens: ops.masked_err_bwd(a.contiguous(), b.contiguous(), acc, g.reshape(1).float().contiguous(), kind, lens),
       lambda a, b, acc, g, kind, lens: torch.empty_like(a))

@@ -32,15 +32,15 @@ def bwd(i):
     ops.masked_err_bwd_multi([(a, b, acc, gs, k, l) for (a, b, k, l), acc in zip(sets[i], accs)])
 for i in range(NS): fwd(i)
 print(f"masked_err_bwd_multi: {t(bwd):6.1f} us")
-z = [torch.zeros(4, dtype=torch.float64, device=dev) for _ in range(7)]
+z = [torch.zeros(ops.MASKED_ACC_DOUBLES, dtype=torch.float64, device=dev) for _ in range(7)]
 def zeros7(i):
-    for k in range(7): torch.zeros(4, dtype=torch.float64, device=dev)
+    for k in range(7): torch.zeros(ops.MASKED_ACC_DOUBLES, dtype=torch.float64, device=dev)
 print(f"(7 torch.zeros alone: {t(zeros7):6.1f} us)")
 # which terms cost what (forward kernel only, accumulators preallocated once and re-zeroed by ONE fill)
 import ctypes
 from styler_amd._lib import MaskedTerm
 def run_terms(idx, label):
-    accs = torch.zeros(len(idx), 4, dtype=torch.float64, device=dev)
+    accs = torch.zeros(len(idx), ops.MASKED_ACC_DOUBLES, dtype=torch.float64, device=dev)
     means = torch.empty(len(idx), device=dev)
     arrs = []
     for s_ in sets:
