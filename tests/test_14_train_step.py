@@ -165,6 +165,24 @@ def test_loss_tail_bit_identical_to_the_five_launch_form(dev):
             assert torch.equal(gw[:7], gw_ref[:7]) and torch.equal(d6, torch.cat([da, db]))
 
 
+def test_masked_error_means_are_deterministic(dev):
+    """Round 6: the masked MSE / L1 means no longer add their block sums with fp64 atomics (arrival order) but from per-block slots
+    in a fixed order: five launches on the same data give the same bits, and the value is the fp64 reference's."""
+    from styler_amd import ops
+    g = torch.Generator().manual_seed(77)
+    B, T = 48, 441
+    lens = torch.randint(150, T + 1, (B,), generator=g).to(dev)
+    a, b = torch.randn(B, T, 80, generator=g).to(dev), torch.randn(B, T, 80, generator=g).to(dev)
+    p, q = torch.randn(B, T, generator=g).to(dev), torch.randn(B, T, generator=g).to(dev)
+    terms = [(a, b, 0, lens), (p, q, 1, lens), (b, a, 1, lens)]
+    runs = [torch.cat(ops.masked_err_mean_multi(terms)[0]).clone() for _ in range(5)]
+    assert all(torch.equal(runs[0], r) for r in runs[1:])
+    keep = (torch.arange(T, device=dev)[None] < lens[:, None])
+    ref0 = ((a - b).double()[keep] ** 2).mean()
+    ref1 = (p - q).double()[keep].abs().mean()
+    assert abs(float(runs[0][0]) - float(ref0)) <= 1e-6 * float(ref0) and abs(float(runs[0][1]) - float(ref1)) <= 1e-6 * float(ref1)
+
+
 def test_fused_loss_head_equals_the_loss_modules(dev, train_model, ref_state_dict):
     """training.train_losses with rt.fused_loss (two tape nodes for the whole loss head) against the STYLERLoss /
     DomainAdversarialTrainingLoss modules: the ten scalars and every parameter gradient.  The masked-error sums are fp64
