@@ -18,25 +18,33 @@ static inline unsigned pack_grid(int64_t work) {
   return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
+// Round 6: 32 blocks instead of one (the kernel sits on the step's serial chain in front of the decoder: 22 us for 340 KB of index
+// tables -- one thread walking len[] with a global load per item, then one block writing every row).  Every block loads the
+// lengths into LDS with all its threads, scans them there (B <= 4096) and writes its slice of the rows; block 0 also writes cu / counts.
 __global__ __launch_bounds__(1024) void pack_plan_kernel(const int64_t* __restrict__ len, int B, int T,
                                                          int* __restrict__ cu, int2* __restrict__ rowinfo,
                                                          int4* __restrict__ chunktab, int64_t* __restrict__ counts) {
   __shared__ int s_cu[4097], s_cc[4097];
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    int l = (int)len[b];
+    s_cu[b] = l < 0 ? 0 : (l > T ? T : l);               // (the clamped length for now)
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     int r = 0, c = 0;
     for (int b = 0; b < B; ++b) {
-      int l = (int)len[b];
-      l = l < 0 ? 0 : (l > T ? T : l);
+      const int l = s_cu[b];
       s_cu[b] = r; s_cc[b] = c;
       r += l; c += (l + 63) / 64;
     }
     s_cu[B] = r; s_cc[B] = c;
-    counts[0] = r; counts[1] = c;
+    if (blockIdx.x == 0) { counts[0] = r; counts[1] = c; }
   }
   __syncthreads();
-  for (int b = threadIdx.x; b <= B; b += blockDim.x) cu[b] = s_cu[b];
+  if (blockIdx.x == 0)
+    for (int b = threadIdx.x; b <= B; b += blockDim.x) cu[b] = s_cu[b];
   const int total = B * T;
-  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int b = i / T, t = i - b * T;
     const int l = s_cu[b + 1] - s_cu[b];
     if (t < l) rowinfo[s_cu[b] + t] = make_int2(t, l - 1 - t);
@@ -48,7 +56,9 @@ __global__ __launch_bounds__(1024) void pack_plan_kernel(const int64_t* __restri
 extern "C" int styler_pack_plan(const int64_t* len, int B, int T, int32_t* cu, int32_t* rowinfo, int32_t* chunktab,
                                 int64_t* counts, void* stream) {
   if (!len || !cu || !rowinfo || !chunktab || !counts || B <= 0 || B > 4096 || T <= 0) return STYLER_EINVAL;
-  hipLaunchKernelGGL(pack_plan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, len, B, T, cu,
+  const int64_t total = (int64_t)B * T;
+  const unsigned blocks = (unsigned)(total >= 32 * 1024 ? 32 : (total + 1023) / 1024);
+  hipLaunchKernelGGL(pack_plan_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, len, B, T, cu,
                      reinterpret_cast<int2*>(rowinfo), reinterpret_cast<int4*>(chunktab), counts);
   return launch_status();
 }
