@@ -862,6 +862,10 @@ int styler_loss_tail_bwd(const float* g, const float* weights, int n, const floa
  * captured in a hipGraph draws fresh masks on every replay although its host seeds are baked in.  The caller
  * increments the counter once per step, before the forward. */
 int styler_set_dropout_counter(const uint64_t* counter_dev);
+/* Round 6: the head of a training step as ONE launch (was: two fills + a counter increment): zeros into [a, a + a_bytes) (the flat
+ * gradient, train.py:185 `zero_grad`) and [b, b + b_bytes) (the norm kernels' statistics slab), counter[0] += 1 (the dropout step
+ * counter registered with styler_set_dropout_counter).  Any of the three may be NULL / 0; sizes and addresses 16-byte multiples. */
+int styler_step_begin(void* a, int64_t a_bytes, void* b, int64_t b_bytes, uint64_t* counter, void* stream);
 
 /* y = x * keep / (1-p); keep is a counter-based hash of (seed, element index): the same call on
  * dy is the backward (no mask tensor). */

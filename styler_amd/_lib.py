@@ -49,6 +49,7 @@ _SIGS = {
     "styler_lstm_bidir_multi": [P, I, I, I, P],
     "styler_set_dropout_counter": [P],
     "styler_strided_copy_multi": [P, I, I64, P],
+    "styler_step_begin": [P, I64, P, I64, P, P],
     "styler_strided_copy_multi_map": [P, I, I64, P, P],
     "styler_wgrad_group_desc": [P, P, I64, P, I64, P, P, I, I, I, I, I, I, I, P, P, P, I, I],
     "styler_wgrad_group": [P, I, I, I, P],

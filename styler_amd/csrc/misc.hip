@@ -583,6 +583,29 @@ extern "C" int styler_length_mask(const int64_t* len, uint8_t* mask, int B, int 
   return launch_status();
 }
 
+// ---- start of a training step: clear the flat gradient and the norm kernels' statistics slab, advance the dropout step counter ----
+// (round 6: three launches -- two torch fills and an int64 add_ -- were three 5-16 us nodes at the head of every step; every node of
+// the step's graph costs >= 4.7 us whatever it does)
+__global__ __launch_bounds__(256) void step_begin_kernel(float4* __restrict__ a, int64_t na, float4* __restrict__ b, int64_t nb,
+                                                         uint64_t* __restrict__ counter) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += stride) a[i] = z;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) b[i] = z;
+  if (counter && blockIdx.x == 0 && threadIdx.x == 0) counter[0] += 1;
+}
+
+extern "C" int styler_step_begin(void* a, int64_t a_bytes, void* b, int64_t b_bytes, uint64_t* counter, void* stream) {
+  if (a_bytes < 0 || b_bytes < 0 || (a_bytes & 15) || (b_bytes & 15) || ((uintptr_t)a & 15) || ((uintptr_t)b & 15)) return STYLER_EALIGN;
+  if ((a_bytes && !a) || (b_bytes && !b)) return STYLER_EINVAL;
+  const int64_t na = a_bytes / 16, nb = b_bytes / 16, most = na > nb ? na : nb;
+  int64_t blocks = (most + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(step_begin_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4*>(a), na,
+                     reinterpret_cast<float4*>(b), nb, counter);
+  return launch_status();
+}
+
 // ---- derived weight layouts: many strided 3-D copies (+ fp32 -> bf16) in ONE launch -------------------------------
 // Every kernel-side view of a parameter (bf16 shadow, [n, kw, cin] conv layout, tap-flipped transposed dX layout, fused
 // QKV / BiLSTM matrices, summed LSTM biases) is an index permutation of parameter elements, optionally cast or

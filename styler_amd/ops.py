@@ -295,15 +295,17 @@ class ZeroSlab:
         self.total = 0
         self.frozen = False                          # set once a captured hipGraph addresses `buf`
 
-    def begin(self, device):
+    def begin(self, device, fill=True):
+        """`fill=False`: the caller clears `buf` itself (training.forward_backward: one launch with the gradient clear)."""
         if self.total > (self.buf.numel() if self.buf is not None else 0):
             if self.frozen:
                 raise StylerHipError("ZeroSlab: a captured hipGraph addresses this buffer; it cannot be re-sized")
             self.buf = torch.empty(self.total, device=device, dtype=torch.float64)
-        if self.buf is not None:
+        if self.buf is not None and fill:
             self.buf.zero_()
         self.used = 0
         self.total = 0
+        return self.buf
 
     def take(self, n):
         n = (n + 1) & ~1
@@ -1804,6 +1806,20 @@ def dropout(x, p, seed):
     _chk(lib.styler_dropout(x.data_ptr(), _ld(x), y.data_ptr(), C, rows, C, float(p), int(seed), _stream()),
          "styler_dropout")
     return y
+
+
+def step_begin(grad, slab, counter):
+    """One launch: zeros into `grad` and `slab` (either may be None), counter[0] += 1 (int64 [1] tensor or None)."""
+    nbytes = lambda t: 0 if t is None else t.numel() * t.element_size()
+    ok = all(t is None or (t.is_contiguous() and t.data_ptr() % 16 == 0 and nbytes(t) % 16 == 0) for t in (grad, slab))
+    if not ok:                                       # (not the step's case)
+        for t in (grad, slab):
+            if t is not None:
+                t.zero_()
+        if counter is not None:
+            counter.add_(1)
+        return
+    _chk(lib.styler_step_begin(_ptr(grad), nbytes(grad), _ptr(slab), nbytes(slab), _ptr(counter), _stream()), "styler_step_begin")
 
 
 def sumsq(flat, out):

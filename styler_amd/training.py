@@ -135,8 +135,10 @@ class TrainState:
             off += align(p.numel())
         return end
 
-    def zero_grad(self):
-        self.flat_g.zero_()
+    def zero_grad(self, fill=True):
+        """`fill=False`: bookkeeping only, the caller clears flat_g (forward_backward: one launch with the slab clear)."""
+        if fill:
+            self.flat_g.zero_()
         self._tail_works = None
         self._text_works = None
         if self.reducer is not None:                  # a skipped step must not leave ranges that finish() would cast up again
@@ -362,11 +364,13 @@ def forward_backward(model, state, batch, loss_fn=None, dat_fn=None):
     the flat gradient (train.py:135-176).  Capturable in a hipGraph.  The gradient buffer is cleared at the start of an
     accumulation window only (the reference zeroes after each optimiser update, train.py:185; with acc_steps > 1 the
     micro-batches in between add up)."""
-    if state._accum == 0:
-        state.zero_grad()
+    clear_g = state._accum == 0
+    if clear_g:
+        state.zero_grad(fill=False)
     state._accum += 1
-    state.drop_epoch.add_(1)
-    state.zero_slab.begin(state.flat_g.device)         # the norm kernels' statistics workspaces: one clear per step
+    slab = state.zero_slab.begin(state.flat_g.device, fill=False)   # the norm kernels' statistics workspaces: one clear per step
+    # gradient clear (accumulation windows: the first micro-batch only), slab clear and the dropout step counter: ONE launch
+    ops.step_begin(state.flat_g if clear_g else None, slab, state.drop_epoch)
     ops.zero_slab = state.zero_slab
     ops.x3_cache = {} if (rt.prec == ops.PREC_BF16X3 and rt.x3_cache) else None   # (bf16x3: splits live until the step ends)
     try:
