@@ -512,6 +512,9 @@ int styler_leaky_sum(const float* a, const float* b, const float* c, float* y, i
 /* get_mask_from_lengths (utils.py:223-232): mask[b,t] = (t >= len[b]), 1 byte per element
  * (torch.bool storage), True = padding. */
 int styler_length_mask(const int64_t* len, uint8_t* mask, int B, int L, void* stream);
+/* Round 6: the two masks of one forward (src_mask [B0, L0], mel_mask [B1, L1]; styler.py:42-43) in one launch. */
+int styler_length_mask2(const int64_t* len0, uint8_t* mask0, int B0, int L0, const int64_t* len1, uint8_t* mask1, int B1, int L1,
+                        void* stream);
 
 /* ---- losses (loss.py:16-50) -----------------------------------------------------------
  * acc[0] += sum over valid rows (t < len[b]) and C columns of (a-b)^2  (kind 0)

@@ -74,6 +74,7 @@ _SIGS = {
     "styler_lo_part": [P, I64, P, I64, I, P, P],
     "styler_add_rowvec": [P, I64, P, I64, P, I64, I, I, I, P],
     "styler_length_mask": [P, P, I, I, P],
+    "styler_length_mask2": [P, P, I, I, P, P, I, I, P],
     "styler_masked_err_sum": [P, I64, P, I64, P, I, I, I, I, P, P],
     "styler_act_bwd": [P, I64, P, I64, P, I64, I, I, I, I, P, P],
     "styler_wgrad": [P, I64, P, I64, P, P, P, I64, I64, I64, I, I, I, I, I, I, I, P, I, I, P],

@@ -583,6 +583,23 @@ extern "C" int styler_length_mask(const int64_t* len, uint8_t* mask, int B, int 
   return launch_status();
 }
 
+// both masks of a forward (styler.py:42-43: src_mask [B, S], mel_mask [B, T]) in one launch
+__global__ void length_mask2_kernel(const int64_t* __restrict__ len0, uint8_t* __restrict__ mask0, int64_t total0, int L0,
+                                    const int64_t* __restrict__ len1, uint8_t* __restrict__ mask1, int64_t total1, int L1) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total0 + total1; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < total0) { const int64_t b = i / L0; mask0[i] = (uint8_t)((i - b * L0) >= len0[b]); }
+    else { const int64_t j = i - total0, b = j / L1; mask1[j] = (uint8_t)((j - b * L1) >= len1[b]); }
+  }
+}
+extern "C" int styler_length_mask2(const int64_t* len0, uint8_t* mask0, int B0, int L0, const int64_t* len1, uint8_t* mask1, int B1,
+                                   int L1, void* stream) {
+  if (!len0 || !mask0 || !len1 || !mask1 || B0 <= 0 || L0 <= 0 || B1 <= 0 || L1 <= 0) return STYLER_EINVAL;
+  const int64_t t0 = (int64_t)B0 * L0, t1 = (int64_t)B1 * L1;
+  hipLaunchKernelGGL(length_mask2_kernel, dim3(grid_for(t0 + t1)), dim3(256), 0, (hipStream_t)stream, len0, mask0, t0, L0, len1,
+                     mask1, t1, L1);
+  return launch_status();
+}
+
 // ---- start of a training step: clear the flat gradient and the norm kernels' statistics slab, advance the dropout step counter ----
 // (round 6: three launches -- two torch fills and an int64 add_ -- were three 5-16 us nodes at the head of every step; every node of
 // the step's graph costs >= 4.7 us whatever it does)

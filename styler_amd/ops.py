@@ -1140,6 +1140,15 @@ def add_rowvec(a, v, L, out=None):
     return out
 
 
+def length_mask2(lens0, L0, lens1, L1):
+    """(mask [B0, L0], mask [B1, L1]) bool, True = padding: the two masks of a forward in one launch."""
+    m0 = torch.empty(lens0.shape[0], L0, device=lens0.device, dtype=torch.bool)
+    m1 = torch.empty(lens1.shape[0], L1, device=lens1.device, dtype=torch.bool)
+    _chk(lib.styler_length_mask2(lens0.data_ptr(), m0.data_ptr(), lens0.shape[0], L0, lens1.data_ptr(), m1.data_ptr(), lens1.shape[0], L1,
+                                 _stream()), "styler_length_mask2")
+    return m0, m1
+
+
 def length_mask(lens, L):
     B = lens.shape[0]
     mask = torch.empty(B, L, device=lens.device, dtype=torch.bool)

@@ -78,8 +78,13 @@ class STYLER(_HipModule):
             raise RuntimeError("styler_amd.STYLER runs on the MI355X HIP path only (no CPU fallback)")
         src_len = src_len.contiguous()
         mel_len = mel_len.contiguous()
-        src_mask = get_mask_from_lengths(src_len, max_src_len if max_src_len is not None else src_seq.shape[1])
-        mel_mask = get_mask_from_lengths(mel_len, max_mel_len if max_mel_len is not None else None)
+        if max_mel_len is not None:                    # both extents known on the host: the two masks in one launch
+            from . import ops
+            src_mask, mel_mask = ops.length_mask2(src_len, int(max_src_len) if max_src_len is not None else src_seq.shape[1],
+                                                  mel_len, int(max_mel_len))
+        else:
+            src_mask = get_mask_from_lengths(src_len, max_src_len if max_src_len is not None else src_seq.shape[1])
+            mel_mask = get_mask_from_lengths(mel_len, None)
         max_mel_len = None if max_mel_len is None else int(max_mel_len)
 
         (style_modeling_output, noise_encoding, d_prediction, p_prediction, e_prediction, new_len, new_mask,
