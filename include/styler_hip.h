@@ -470,6 +470,13 @@ int styler_bucket_embed_add(const float* text, int64_t ldt, const float* speaker
                             const float* noise, int64_t ldn, float* out2, int32_t* p_ids,
                             int32_t* e_ids, int B, int T, void* stream);
 
+/* Round 6: the decoder-input concatenation of StyleModeling.forward (modules.py:335-350) as one launch.  All operands fp32,
+ * contiguous [B, S, 256] (spk: [B, 256]); enc [B, S, 1280] = [text | pitch_up + neck_up | speaker | neck_up + energy_up | residual_up],
+ * dp [B, S, 256] = neck_up + duration_up (the duration predictor's input).  styler_add3: y = (a + b) + c over [rows, C] views. */
+int styler_style_cat(const float* te, const float* pu, const float* tnu, const float* spk, const float* eu, const float* ru,
+                     const float* du, float* enc, float* dp, int B, int S, void* stream);
+int styler_add3(const float* a, int64_t lda, const float* b, int64_t ldb, const float* c, int64_t ldc, float* y, int64_t ldy,
+                int64_t rows, int C, void* stream);
 /* elementwise helpers used to stitch channel slices: y = a (+ b) with row strides, and a
  * per-item row broadcast y[b,t,:] = (a[b,t,:] if a) + v[b,:] (speaker repeat,
  * modules.py:324-325,333). */

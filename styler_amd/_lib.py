@@ -74,6 +74,8 @@ _SIGS = {
     "styler_lo_part": [P, I64, P, I64, I, P, P],
     "styler_add_rowvec": [P, I64, P, I64, P, I64, I, I, I, P],
     "styler_length_mask": [P, P, I, I, P],
+    "styler_style_cat": [P, P, P, P, P, P, P, P, P, I, I, P],
+    "styler_add3": [P, I64, P, I64, P, I64, P, I64, I64, I, P],
     "styler_length_mask2": [P, P, I, I, P, P, I, I, P],
     "styler_masked_err_sum": [P, I64, P, I64, P, I, I, I, I, P, P],
     "styler_act_bwd": [P, I64, P, I64, P, I64, I, I, I, I, P, P],

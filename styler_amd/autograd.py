@@ -981,6 +981,33 @@ class CatFn(Function):
         return tuple(outs)
 
 
+class StyleCatFn(Function):
+    """Round 6: the decoder-input concatenation of StyleModeling.forward (modules.py:335-350) and the duration predictor's input as
+    ONE tape node / one launch: enc = [text | pitch_up + neck_up | speaker | neck_up + energy_up | residual_up], dp = neck_up +
+    duration_up (was three Add2Fn, two AddRowvecFn and the CatFn copy).  Backward: slice views of d_enc, the speaker's row sum, and
+    ONE launch for the neck's three contributions (autograd added them with two aten adds)."""
+
+    @staticmethod
+    def forward(ctx, te, pu, tnu, spk, eu, ru, du):
+        ctx.set_materialize_grads(False)
+        ctx.shape = te.shape
+        return ops.style_cat(*(t.contiguous() for t in (te, pu, tnu, spk, eu, ru, du)))
+
+    @staticmethod
+    def backward(ctx, d_enc, d_dp):
+        B, S, _ = ctx.shape
+        if d_enc is None and d_dp is None:
+            return (None,) * 7
+        if d_enc is None:
+            return None, None, d_dp, None, None, None, d_dp
+        part = lambda i: d_enc[..., 256 * i:256 * (i + 1)]
+        if d_dp is None:
+            d_tnu = ops.add2(ops._rows_view(part(1)), ops._rows_view(part(3)))
+        else:
+            d_tnu = ops.add3(part(1), part(3), d_dp)
+        return part(0), part(1), d_tnu, ops.rowsum(part(2)), part(3), part(4), d_dp
+
+
 class DropoutFn(Function):
     @staticmethod
     def forward(ctx, x, p, seed):

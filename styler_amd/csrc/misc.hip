@@ -342,6 +342,63 @@ extern "C" int styler_add2(const float* a, int64_t lda, const float* b, int64_t 
   return launch_status();
 }
 
+// ---- the decoder-input concatenation of StyleModeling.forward (modules.py:335-350) in ONE launch (round 6) ----------------------------
+//   enc[row] = [ text | pitch_up + neck_up | speaker[row / S] | neck_up + energy_up | residual_up ]   (5 x 256 channels)
+//   dp[row]  = neck_up + duration_up                                                              (the duration predictor's input)
+// Was: three add2, two add_rowvec and the concatenation's copy -- six nodes of >= 4.7 us each on the step's serial chain.
+struct StyleCatArgs {
+  const float* te; const float* pu; const float* tnu; const float* spk; const float* eu; const float* ru; const float* du;
+  float* enc; float* dp;
+  int64_t rows; int32_t S;
+};
+__global__ __launch_bounds__(256) void style_cat_kernel(const StyleCatArgs a) {
+  const int64_t total = a.rows * 384;                  // 320 float4 of enc + 64 of dp per row
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / 384;
+    const int q = (int)(i - row * 384), part = q >> 6, c = (q & 63) * 4;
+    const int64_t o = row * 256 + c;
+    float4 v;
+    if (part == 0) v = *reinterpret_cast<const float4*>(a.te + o);
+    else if (part == 2) v = *reinterpret_cast<const float4*>(a.spk + (row / a.S) * 256 + c);
+    else if (part == 4) v = *reinterpret_cast<const float4*>(a.ru + o);
+    else {
+      const float4 n = *reinterpret_cast<const float4*>(a.tnu + o);
+      const float4 w = *reinterpret_cast<const float4*>((part == 1 ? a.pu : part == 3 ? a.eu : a.du) + o);
+      v = part == 5 ? make_float4(n.x + w.x, n.y + w.y, n.z + w.z, n.w + w.w)          // dp_in = neck_up + duration_up
+                    : part == 1 ? make_float4(w.x + n.x, w.y + n.y, w.z + n.z, w.w + n.w)   // pitch_up + neck_up
+                                : make_float4(n.x + w.x, n.y + w.y, n.z + w.z, n.w + w.w);  // neck_up + energy_up
+    }
+    if (part == 5) *reinterpret_cast<float4*>(a.dp + o) = v;
+    else *reinterpret_cast<float4*>(a.enc + row * 1280 + part * 256 + c) = v;
+  }
+}
+extern "C" int styler_style_cat(const float* te, const float* pu, const float* tnu, const float* spk, const float* eu,
+                                const float* ru, const float* du, float* enc, float* dp, int B, int S, void* stream) {
+  if (!te || !pu || !tnu || !spk || !eu || !ru || !du || !enc || !dp || B <= 0 || S <= 0) return STYLER_EINVAL;
+  StyleCatArgs a{te, pu, tnu, spk, eu, ru, du, enc, dp, (int64_t)B * S, S};
+  hipLaunchKernelGGL(style_cat_kernel, dim3(grid_for(a.rows * 384)), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+// out = a + b + c over [rows, C] views (row strides in elements): the neck's gradient of the node above
+__global__ __launch_bounds__(256) void add3_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
+                                                   const float* __restrict__ c, int64_t ldc, float* __restrict__ y, int64_t ldy,
+                                                   int64_t rows, int C) {
+  const int nq = C / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * nq; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / nq; const int q = (int)(i - row * nq);
+    const float4 u = *reinterpret_cast<const float4*>(a + row * lda + q * 4), v = *reinterpret_cast<const float4*>(b + row * ldb + q * 4);
+    const float4 w = *reinterpret_cast<const float4*>(c + row * ldc + q * 4);
+    *reinterpret_cast<float4*>(y + row * ldy + q * 4) = make_float4((u.x + v.x) + w.x, (u.y + v.y) + w.y, (u.z + v.z) + w.z, (u.w + v.w) + w.w);
+  }
+}
+extern "C" int styler_add3(const float* a, int64_t lda, const float* b, int64_t ldb, const float* c, int64_t ldc, float* y, int64_t ldy,
+                           int64_t rows, int C, void* stream) {
+  if (!a || !b || !c || !y || rows <= 0 || C <= 0 || (C & 3)) return STYLER_EINVAL;
+  if ((lda & 3) || (ldb & 3) || (ldc & 3) || (ldy & 3)) return STYLER_EALIGN;
+  hipLaunchKernelGGL(add3_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, c, ldc, y, ldy, rows, C);
+  return launch_status();
+}
+
 extern "C" int styler_add_rowvec(const float* a, int64_t lda, const float* v, int64_t ldv, float* y, int64_t ldy,
                                  int B, int L, int C, void* stream) {
   if (!v || !y || B <= 0 || L <= 0 || C <= 0 || (C & 3)) return STYLER_EINVAL;

@@ -528,23 +528,30 @@ class StyleModeling(_HipModule):
         if grad:
             pitch_in = AG.AddRowvecFn.apply(pitch_encoding, speaker_encoding_p, S)
             text_neck_up = self._gemm("tlu", text_encoding_neck, self.text_linear_up[0], act=ops.ACT_RELU)
+            fused_cat = rt.grouped_mlps and rt.style_cat
             if rt.grouped_mlps:
                 # round 4: the four style MLPs advance layer by layer together (one grouped launch per layer and direction)
                 duration_up, pitch_up, energy_up, residual_up = self._mlp2_multi([
                     ("dl", self.duration_linear, duration_encoding), ("pl", self.pitch_linear, pitch_in),
                     ("el", self.energy_linear, energy_encoding), ("rl", self.residual_linear, noise_encoding)])
-                sl[1] = AG.Add2Fn.apply(pitch_up, text_neck_up)
-                sl[4] = residual_up
+                if not fused_cat:
+                    sl[1] = AG.Add2Fn.apply(pitch_up, text_neck_up)
+                    sl[4] = residual_up
             else:
                 duration_up = self._mlp2("dl", self.duration_linear, duration_encoding)
                 sl[1] = self._mlp2("pl", self.pitch_linear, pitch_in, res=text_neck_up)
                 energy_up = self._mlp2("el", self.energy_linear, energy_encoding)
                 sl[4] = self._mlp2("rl", self.residual_linear, noise_encoding)
-            dp_in = AG.Add2Fn.apply(text_neck_up, duration_up)
-            sl[0] = text_encoding
-            sl[2] = AG.AddRowvecFn.apply(None, speaker_encoding, S)
-            sl[3] = AG.Add2Fn.apply(text_neck_up, energy_up)
-            encodings = AG.CatFn.apply(*sl)
+            if fused_cat:                               # round 6: the five slices and the predictor's input in one launch
+                encodings, dp_in = AG.StyleCatFn.apply(text_encoding, pitch_up, text_neck_up, speaker_encoding, energy_up,
+                                                       residual_up, duration_up)
+                sl[0], sl[4] = text_encoding, residual_up
+            else:
+                dp_in = AG.Add2Fn.apply(text_neck_up, duration_up)
+                sl[0] = text_encoding
+                sl[2] = AG.AddRowvecFn.apply(None, speaker_encoding, S)
+                sl[3] = AG.Add2Fn.apply(text_neck_up, energy_up)
+                encodings = AG.CatFn.apply(*sl)
         else:
             pitch_in = ops.add_rowvec(pitch_encoding, speaker_encoding_p, S)
             text_neck_up = self._gemm("tlu", text_encoding_neck, self.text_linear_up[0], act=ops.ACT_RELU)

@@ -1102,6 +1102,26 @@ def add2(a, b, out=None):
     return out
 
 
+def style_cat(te, pu, tnu, spk, eu, ru, du):
+    """-> (enc [B, S, 1280], dp [B, S, 256]): styler_style_cat (all operands contiguous fp32)."""
+    B, S, _ = te.shape
+    enc = torch.empty(B, S, 1280, device=te.device, dtype=torch.float32)
+    dp = torch.empty(B, S, 256, device=te.device, dtype=torch.float32)
+    _chk(lib.styler_style_cat(te.data_ptr(), pu.data_ptr(), tnu.data_ptr(), spk.data_ptr(), eu.data_ptr(), ru.data_ptr(), du.data_ptr(),
+                              enc.data_ptr(), dp.data_ptr(), B, S, _stream()), "styler_style_cat")
+    return enc, dp
+
+
+def add3(a, b, c):
+    """(a + b) + c over [.., C] fp32 views with contiguous channels."""
+    a, b, c = _rows_view(a), _rows_view(b), _rows_view(c)
+    C = a.shape[-1]
+    out = torch.empty(a.shape, device=a.device, dtype=torch.float32)
+    _chk(lib.styler_add3(a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), c.data_ptr(), _ld(c), out.data_ptr(), C, a.numel() // C, C, _stream()),
+         "styler_add3")
+    return out
+
+
 def fill_zero(t):
     """Zeros into a [.., C] view with contiguous channels (a channel / item slice of a wider buffer; fp32, or bf16 with an even
     channel count, offset and row stride): styler_copy_rows_multi with a null source -- no torch fill on the step."""

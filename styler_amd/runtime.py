@@ -90,6 +90,9 @@ class _Runtime:
     # dropout + residual + LayerNorm + pad mask as ONE launch on a 128 x 256 tile that owns whole rows (csrc/linear_ln.hip):
     # the fp32 projection never reaches HBM.  STYLER_LINEAR_LN=0: styler_conv_gemm + styler_add_layernorm (two launches).
     linear_ln = os.environ.get("STYLER_LINEAR_LN", "1") != "0"
+    # round 6: the decoder-input concatenation of StyleModeling.forward + the duration predictor's input as one tape node / launch
+    # (autograd.StyleCatFn; needs grouped_mlps).  STYLER_STYLE_CAT=0: three Add2Fn, two AddRowvecFn and the CatFn copy.
+    style_cat = os.environ.get("STYLER_STYLE_CAT", "1") != "0"
     # round 6: the loss head of the train step (seven masked-error means, two classifier NLL3 terms, the weighted total) as two
     # tape nodes = 2 launches forward + 2 backward instead of 5 + 5 (training.train_losses).  STYLER_FUSED_LOSS=0: the loss modules.
     fused_loss = os.environ.get("STYLER_FUSED_LOSS", "1") != "0"

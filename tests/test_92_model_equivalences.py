@@ -216,7 +216,7 @@ def test_paired_decodes_match_separate(dev, ref_state_dict, prec):
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("switch", ["pair_audio", "fused_split", "fused_cat", "pair_classifiers", "grouped_mlps",
-                                    "text_stream", "pred_stream", "skip_dat_noise"])
+                                    "text_stream", "pred_stream", "skip_dat_noise", "style_cat", "fused_loss"])
 def test_experimental_switches_match_default(dev, ref_state_dict, prec, switch):
     """rt.pair_audio (main forward + DAT pass of the AudioEncoder as one batch of 2B items), rt.fused_split (gathered
     gradient of the LengthRegulator output's channel slices), rt.fused_cat (the AudioEncoder's four last conv + GroupNorm
